@@ -1,0 +1,403 @@
+// gs_backward.h -- backward kernels: per-tile back-to-front gradient pass and the per-Gaussian geometry backward.
+// gfx950 / wave64. DGR = submodules/diff-gaussian-rasterization.
+#pragma once
+#include "gs_forward.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------------------------------
+// B1: render backward (DGR/cuda_rasterizer/backward.cu:563-787), restructured for CDNA4:
+//  * one block per 16x16 tile, each lane owns PPL adjacent pixels (256/PPL threads, 4/PPL waves);
+//  * the tile's list is staged back-to-front through LDS in batches;
+//  * the per-(tile, Gaussian) sums over the tile's pixels are formed in registers: PPL pixels per lane, then a DPP
+//    wave reduction (6 v_add_f32 with DPP modifiers per value) -- no 256-thread shared-memory tree, no barriers per
+//    Gaussian (the reference spends 8 block barriers x 5 arrays per listed Gaussian, backward.cu:541-559,759-765);
+//  * instead of 10 float atomics per (tile, Gaussian) (backward.cu:774-783) each wave stores its 10 sums into the
+//    instance's private slot partials[(u * NW + wave) * 3 .. +2] (48 B); B2 sums an instance range per Gaussian in a fixed
+//    order. Results are therefore bit-reproducible, and no gradient buffer needs zero-filling.
+// Slot layout (3 x float4): {dmean2D.x, dmean2D.y, dconic.x, dconic.y} {dconic.w, dopacity, dcolor.r, dcolor.g}
+//                           {dcolor.b, ddepth, 0, 0}
+// ------------------------------------------------------------------------------------------------------------------
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                               const uint2* __restrict__ sorted, int W, int H,
+                                                               const float* __restrict__ bg, const float2* __restrict__ means2D,
+                                                               const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
+                                                               const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                               const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                               const float* __restrict__ dL_dpix_depth, float4* __restrict__ partials)
+{
+    constexpr int NT = 256 / PPL;
+    constexpr int NW = NT / 64;
+    constexpr int TPR = 16 / PPL;
+    __shared__ float4 s_a[NT];   // {mean.x, mean.y, conic.x, conic.y}
+    __shared__ float4 s_b[NT];   // {conic.z, opacity, depth, instance id bits}
+    __shared__ float4 s_c[NT];   // {r, g, b, -}
+
+    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const int py = ty * TILE_Y + t / TPR;
+    const int px0 = tx * TILE_X + (t % TPR) * PPL;
+    const float pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n == 0) return;
+
+    float pxf[PPL], T[PPL], Tfin[PPL], acc_r[PPL], acc_g[PPL], acc_b[PPL], acc_d[PPL];
+    float last_a[PPL], last_r[PPL], last_g[PPL], last_b[PPL], last_d[PPL];
+    float gr[PPL], gg[PPL], gb[PPL], gd[PPL], bgdot[PPL];
+    int last_contrib[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const bool inside = (px0 + p) < W && py < H;
+        const size_t pix = (size_t)py * W + (px0 + p);
+        pxf[p] = (float)(px0 + p);
+        Tfin[p] = inside ? final_T[pix] : 0.f;                            // backward.cu:617-623
+        T[p] = Tfin[p];
+        last_contrib[p] = inside ? (int)n_contrib[pix] : 0;
+        gr[p] = inside ? dL_dpix[pix] : 0.f;                              // :629-635
+        gg[p] = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
+        gb[p] = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
+        gd[p] = inside ? dL_dpix_depth[pix] : 0.f;
+        bgdot[p] = bg[0] * gr[p] + bg[1] * gg[p] + bg[2] * gb[p];         // :738-742 (loop invariant)
+        acc_r[p] = acc_g[p] = acc_b[p] = acc_d[p] = 0.f;
+        last_a[p] = last_r[p] = last_g[p] = last_b[p] = last_d[p] = 0.f;
+    }
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                 // :643-644
+
+    for (int base = 0; base < n; base += NT) {
+        __syncthreads();
+        if (base + t < n) {
+            const uint2 e = sorted[range.y - 1 - (uint32_t)(base + t)];   // back to front, :656
+            const float2 xy = means2D[e.x];
+            const float4 co = conic_opacity[e.x];
+            s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_b[t] = make_float4(co.z, co.w, depths[e.x], __uint_as_float(e.y));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+        }
+        __syncthreads();
+        const int m = min(NT, n - base);
+        for (int j = 0; j < m; j++) {
+            const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
+            const int pos = n - 1 - (base + j);   // 0-based list position == the reference's `contributor` after its decrement (:677)
+            const float dy = A4.y - pyf;
+            float s_m2x = 0.f, s_m2y = 0.f, s_cx = 0.f, s_cy = 0.f, s_cw = 0.f, s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b_ = 0.f, s_d = 0.f;
+            bool any_valid = false;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const float dx = A4.x - pxf[p];
+                const float power = -0.5f * (A4.z * dx * dx + B4.x * dy * dy) - A4.w * dx * dy;  // :684
+                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float alpha = fminf(0.99f, B4.y * G);                                       // :688 (no gradient mask for the clamp, Q23)
+                const bool valid = pos < last_contrib[p] && power <= 0.0f && alpha >= 1.0f / 255.0f;  // :678,:685,:689
+                any_valid = any_valid || valid;
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float Tn = valid ? T[p] * inv1ma : T[p];                                    // :700
+                T[p] = Tn;
+                const float dch = alpha * Tn;                                                      // :701
+                // :714-728 running "colour behind this Gaussian"
+                acc_r[p] = valid ? last_a[p] * last_r[p] + (1.f - last_a[p]) * acc_r[p] : acc_r[p];
+                acc_g[p] = valid ? last_a[p] * last_g[p] + (1.f - last_a[p]) * acc_g[p] : acc_g[p];
+                acc_b[p] = valid ? last_a[p] * last_b[p] + (1.f - last_a[p]) * acc_b[p] : acc_b[p];
+                acc_d[p] = valid ? last_a[p] * last_d[p] + (1.f - last_a[p]) * acc_d[p] : acc_d[p];
+                last_r[p] = valid ? C4.x : last_r[p];
+                last_g[p] = valid ? C4.y : last_g[p];
+                last_b[p] = valid ? C4.z : last_b[p];
+                last_d[p] = valid ? B4.z : last_d[p];
+                float dL_dalpha = (C4.x - acc_r[p]) * gr[p] + (C4.y - acc_g[p]) * gg[p] + (C4.z - acc_b[p]) * gb[p] +
+                                  (B4.z - acc_d[p]) * gd[p];
+                dL_dalpha *= Tn;                                                                   // :732
+                last_a[p] = valid ? alpha : last_a[p];
+                dL_dalpha += (-Tfin[p] * inv1ma) * bgdot[p];                                       // :743
+                const float dL_dG = valid ? B4.y * dL_dalpha : 0.f;                               // :746
+                const float Gv = valid ? G : 0.f;   // G may be +inf where power > 0; keep it out of the masked products
+                const float gdx = Gv * dx, gdy = Gv * dy;
+                const float dG_ddelx = -gdx * A4.z - gdy * A4.w;
+                const float dG_ddely = -gdy * B4.x - gdx * A4.w;
+                const float wv = valid ? dch : 0.f;
+                s_r += wv * gr[p]; s_g += wv * gg[p]; s_b_ += wv * gb[p]; s_d += wv * gd[p];      // :719,:729
+                s_m2x += dL_dG * dG_ddelx;                                                         // :752-757
+                s_m2y += dL_dG * dG_ddely;
+                s_cx += gdx * dx * dL_dG;
+                s_cy += gdx * dy * dL_dG;
+                s_cw += gdy * dy * dL_dG;
+                s_op += Gv * dL_dalpha;
+            }
+            float4* slot = partials + ((size_t)__float_as_uint(B4.w) * NW + wave) * 3;
+            if (__any(any_valid)) {
+                s_m2x = wave_sum_to_row3(s_m2x) * ddelx_dx;
+                s_m2y = wave_sum_to_row3(s_m2y) * ddely_dy;
+                s_cx = wave_sum_to_row3(s_cx) * -0.5f;
+                s_cy = wave_sum_to_row3(s_cy) * -0.5f;
+                s_cw = wave_sum_to_row3(s_cw) * -0.5f;
+                s_op = wave_sum_to_row3(s_op);
+                s_r = wave_sum_to_row3(s_r);
+                s_g = wave_sum_to_row3(s_g);
+                s_b_ = wave_sum_to_row3(s_b_);
+                s_d = wave_sum_to_row3(s_d);
+                if (lane == 63) {
+                    slot[0] = make_float4(s_m2x, s_m2y, s_cx, s_cy);
+                    slot[1] = make_float4(s_cw, s_op, s_r, s_g);
+                    slot[2] = make_float4(s_b_, s_d, 0.f, 0.f);
+                }
+            } else if (lane == 63) {   // nothing in this wave touched the Gaussian (the reference's skip_counter shortcut, :691-697)
+                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                slot[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// B2: per-Gaussian backward. Sums the Gaussian's instance slots (fixed order => deterministic), then runs the
+// reference's computeCov2DCUDA (backward.cu:150-346) and preprocessCUDA backward (:418-539) back to back in
+// registers, so dL_dconic / dL_dmean2D never round-trip through memory between two kernels.
+// Writes EVERY output element (zeros for culled Gaussians), so outputs need no pre-zeroing.
+// ------------------------------------------------------------------------------------------------------------------
+struct GeomBwdArgs {
+    int P, D, M, W, H, NW;
+    const float* means3D; const int* radii; const float* shs; const uint8_t* clamped; const float* scales; const float* rotations;
+    float scale_modifier; const float* cov3Ds; const float* viewmatrix; const float* projmatrix; const float* projmatrix_raw;
+    const float* campos; float focal_x, focal_y, tan_fovx, tan_fovy;
+    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials;
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
+    float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
+};
+
+__global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const size_t i = (size_t)idx;
+    const bool visible = a.radii[idx] > 0;   // backward.cu:163,443
+
+    float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
+    if (visible) {
+        const uint32_t cnt = a.tiles_touched[idx] * (uint32_t)a.NW;
+        const float4* sl = a.partials + (size_t)(a.point_offsets[idx] - a.tiles_touched[idx]) * a.NW * 3;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float4 v0 = sl[3 * k], v1 = sl[3 * k + 1], v2 = sl[3 * k + 2];
+            g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
+            g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
+            g_b += v2.x; g_d += v2.y;
+        }
+    }
+    a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
+    a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw;
+    a.dL_dopacity[i] = g_op;
+    a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b;
+    a.dL_ddepth[i] = g_d;
+
+    float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool has_sh = a.shs != nullptr && a.dL_dsh != nullptr;
+    if (!visible) {
+        if (has_sh) for (int k = 0; k < a.M * 3; k++) a.dL_dsh[i * a.M * 3 + k] = 0.f;
+    } else {
+        const float* vm = a.viewmatrix;
+        const f3 mean = mk3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
+        float cov6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov6[k] = a.cov3Ds[6 * i + k];
+
+        // ---- backward.cu:171-346: conic -> cov2D -> (cov3D, t) ----
+        const Cov2D cv = cov2d_eval(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov6, vm);
+        const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+        const float x_grad_mul = (cv.txtz < -limx || cv.txtz > limx) ? 0.f : 1.f;   // :182-183
+        const float y_grad_mul = (cv.tytz < -limy || cv.tytz > limy) ? 0.f : 1.f;
+        const float ca = cv.a, cb = cv.b, cc = cv.c;
+        const float denom = ca * cc - cb * cb;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);               // :210
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float (&A)[2][3] = cv.A;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * g_cx + 2 * cb * cc * g_cy + (denom - ca * cc) * g_cw);     // :217-219
+            dL_dc = denom2inv * (-ca * ca * g_cw + 2 * ca * cb * g_cy + (denom - ca * cc) * g_cx);
+            dL_db = denom2inv * 2 * (cb * cc * g_cx - (denom + 2 * cb * cb) * g_cy + ca * cb * g_cw);
+            dcov[0] = A[0][0] * A[0][0] * dL_da + A[0][0] * A[1][0] * dL_db + A[1][0] * A[1][0] * dL_dc;   // :224-234
+            dcov[3] = A[0][1] * A[0][1] * dL_da + A[0][1] * A[1][1] * dL_db + A[1][1] * A[1][1] * dL_dc;
+            dcov[5] = A[0][2] * A[0][2] * dL_da + A[0][2] * A[1][2] * dL_db + A[1][2] * A[1][2] * dL_dc;
+            dcov[1] = 2 * A[0][0] * A[0][1] * dL_da + (A[0][0] * A[1][1] + A[0][1] * A[1][0]) * dL_db + 2 * A[1][0] * A[1][1] * dL_dc;
+            dcov[2] = 2 * A[0][0] * A[0][2] * dL_da + (A[0][0] * A[1][2] + A[0][2] * A[1][0]) * dL_db + 2 * A[1][0] * A[1][2] * dL_dc;
+            dcov[4] = 2 * A[0][2] * A[0][1] * dL_da + (A[0][1] * A[1][2] + A[0][2] * A[1][1]) * dL_db + 2 * A[1][1] * A[1][2] * dL_dc;
+        }
+        const float V[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+        float dT0[3], dT1[3];   // dL/dA rows (:244-255)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float a0v = A[0][0] * V[k][0] + A[0][1] * V[k][1] + A[0][2] * V[k][2];
+            const float a1v = A[1][0] * V[k][0] + A[1][1] * V[k][1] + A[1][2] * V[k][2];
+            dT0[k] = 2 * a0v * dL_da + a1v * dL_db;
+            dT1[k] = 2 * a1v * dL_dc + a0v * dL_db;
+        }
+        const float dL_dJ00 = vm[0] * dT0[0] + vm[4] * dT0[1] + vm[8] * dT0[2];      // :259-262
+        const float dL_dJ02 = vm[2] * dT0[0] + vm[6] * dT0[1] + vm[10] * dT0[2];
+        const float dL_dJ11 = vm[1] * dT1[0] + vm[5] * dT1[1] + vm[9] * dT1[2];
+        const float dL_dJ12 = vm[2] * dT1[0] + vm[6] * dT1[1] + vm[10] * dT1[2];
+        const f3 t = cv.t;
+        const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float fx = a.focal_x, fy = a.focal_y;
+        const float dL_dtx = x_grad_mul * -fx * tz2 * dL_dJ02;                        // :269-271
+        const float dL_dty = y_grad_mul * -fy * tz2 * dL_dJ12;
+        const float dL_dtz = -fx * tz2 * dL_dJ00 - fy * tz2 * dL_dJ11 + (2 * fx * t.x) * tz3 * dL_dJ02 + (2 * fy * t.y) * tz3 * dL_dJ12;
+        // pose, :273-288: d p_C / d rho = I, d p_C / d theta = -[t]x with the CLAMPED t (Q17 iii)
+        dtau[0] += dL_dtx; dtau[1] += dL_dty; dtau[2] += dL_dtz;
+        dtau[3] += -dL_dty * t.z + dL_dtz * t.y;      // column 0 of -[t]x = (0, -t.z, t.y)
+        dtau[4] += dL_dtx * t.z - dL_dtz * t.x;       // column 1        = (t.z, 0, -t.x)
+        dtau[5] += -dL_dtx * t.y + dL_dty * t.x;      // column 2        = (-t.y, t.x, 0)
+        // :292-297 (assignment)
+        dmean[0] = vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz;
+        dmean[1] = vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz;
+        dmean[2] = vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz;
+        // rotation part through W = R_cw, :299-343
+        {
+            const float dW[3][3] = {   // dW[col c of dL_dW][component]: cols[c] = (dW0c, dW1c, dW2c)
+                {cv.J00 * dT0[0], cv.J11 * dT1[0], cv.J02 * dT0[0] + cv.J12 * dT1[0]},
+                {cv.J00 * dT0[1], cv.J11 * dT1[1], cv.J02 * dT0[1] + cv.J12 * dT1[1]},
+                {cv.J00 * dT0[2], cv.J11 * dT1[2], cv.J02 * dT0[2] + cv.J12 * dT1[2]}};
+            float th0 = 0.f, th1 = 0.f, th2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float cx_ = vm[4 * c], cy_ = vm[4 * c + 1], cz_ = vm[4 * c + 2];   // column c of R_cw
+                // columns of -[c]x: (0,-cz,cy), (cz,0,-cx), (-cy,cx,0)
+                th0 += -dW[c][1] * cz_ + dW[c][2] * cy_;
+                th1 += dW[c][0] * cz_ - dW[c][2] * cx_;
+                th2 += -dW[c][0] * cy_ + dW[c][1] * cx_;
+            }
+            dtau[3] += th0; dtau[4] += th1; dtau[5] += th2;
+        }
+
+        // ---- backward.cu:446-528: mean2D / depth -> mean3D and tau ----
+        const float* pr = a.projmatrix;
+        const float mhx = pr[0] * mean.x + pr[4] * mean.y + pr[8] * mean.z + pr[12];
+        const float mhy = pr[1] * mean.x + pr[5] * mean.y + pr[9] * mean.z + pr[13];
+        const float mhw = pr[3] * mean.x + pr[7] * mean.y + pr[11] * mean.z + pr[15];
+        const float m_w = 1.0f / (mhw + 0.0000001f);
+        const float mul1 = mhx * m_w * m_w, mul2 = mhy * m_w * m_w;
+        dmean[0] += (pr[0] * m_w - pr[3] * mul1) * g_m2x + (pr[1] * m_w - pr[3] * mul2) * g_m2y;   // :457-463
+        dmean[1] += (pr[4] * m_w - pr[7] * mul1) * g_m2x + (pr[5] * m_w - pr[7] * mul2) * g_m2y;
+        dmean[2] += (pr[8] * m_w - pr[11] * mul1) * g_m2x + (pr[9] * m_w - pr[11] * mul2) * g_m2y;
+        {   // approximate projection Jacobian w.r.t. the pose, :465-512 (only proj_raw[0], [5], [11]; Q17 i)
+            const float al = m_w, be = -mhx * m_w * m_w, ga = -mhy * m_w * m_w;
+            const float pa = a.projmatrix_raw[0], pb = a.projmatrix_raw[5], pe = a.projmatrix_raw[11];
+            const f3 pC = xform_point_4x3(mean, vm);   // unclamped (Q17 iii)
+            const f3 d1 = mk3(al * pa, 0.f, be * pe), d2 = mk3(0.f, al * pb, ga * pe);
+            // (-[pC]x)^T d = [pC]x d = pC x d
+            const f3 d1t = mk3(pC.y * d1.z - pC.z * d1.y, pC.z * d1.x - pC.x * d1.z, pC.x * d1.y - pC.y * d1.x);
+            const f3 d2t = mk3(pC.y * d2.z - pC.z * d2.y, pC.z * d2.x - pC.x * d2.z, pC.x * d2.y - pC.y * d2.x);
+            dtau[0] += g_m2x * d1.x + g_m2y * d2.x;
+            dtau[1] += g_m2x * d1.y + g_m2y * d2.y;
+            dtau[2] += g_m2x * d1.z + g_m2y * d2.z;
+            dtau[3] += g_m2x * d1t.x + g_m2y * d2t.x;
+            dtau[4] += g_m2x * d1t.y + g_m2y * d2t.y;
+            dtau[5] += g_m2x * d1t.z + g_m2y * d2t.z;
+            // depth, :518-528: z-row of I and of -[pC]x = (pC.y, -pC.x, 0)
+            dmean[0] += g_d * vm[2]; dmean[1] += g_d * vm[6]; dmean[2] += g_d * vm[10];
+            dtau[2] += g_d;
+            dtau[3] += g_d * pC.y;
+            dtau[4] += g_d * -pC.x;
+        }
+
+        // ---- backward.cu:21-145: colour -> SH coefficients and (through the view direction) the mean ----
+        if (has_sh) {
+            const float* sh = a.shs + i * a.M * 3;
+            float* dsh = a.dL_dsh + i * a.M * 3;
+            const uint32_t cb = a.clamped[idx];
+            const float dRGB[3] = {(cb & 1u) ? 0.f : g_r, (cb & 2u) ? 0.f : g_g, (cb & 4u) ? 0.f : g_b};   // :32-35
+            const f3 dir_orig = mk3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]);
+            const float inv = 1.0f / sqrtf(dot3(dir_orig, dir_orig));
+            const float x = dir_orig.x * inv, y = dir_orig.y * inv, z = dir_orig.z * inv;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/ddir
+            const int deg = a.D;
+            const int used = (deg + 1) * (deg + 1);
+            for (int k = used * 3; k < a.M * 3; k++) dsh[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float g = dRGB[k];
+                float rx = 0.f, ry = 0.f, rz = 0.f;   // dRGB/d{x,y,z} for this channel
+                dsh[k] = SH_C0 * g;
+                if (deg > 0) {
+                    dsh[3 + k] = -SH_C1 * y * g; dsh[6 + k] = SH_C1 * z * g; dsh[9 + k] = -SH_C1 * x * g;
+                    rx = -SH_C1 * sh[9 + k]; ry = -SH_C1 * sh[3 + k]; rz = SH_C1 * sh[6 + k];
+                    if (deg > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        dsh[12 + k] = SH_C2[0] * xy * g; dsh[15 + k] = SH_C2[1] * yz * g; dsh[18 + k] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                        dsh[21 + k] = SH_C2[3] * xz * g; dsh[24 + k] = SH_C2[4] * (xx - yy) * g;
+                        rx += SH_C2[0] * y * sh[12 + k] + SH_C2[2] * 2.f * -x * sh[18 + k] + SH_C2[3] * z * sh[21 + k] + SH_C2[4] * 2.f * x * sh[24 + k];
+                        ry += SH_C2[0] * x * sh[12 + k] + SH_C2[1] * z * sh[15 + k] + SH_C2[2] * 2.f * -y * sh[18 + k] + SH_C2[4] * 2.f * -y * sh[24 + k];
+                        rz += SH_C2[1] * y * sh[15 + k] + SH_C2[2] * 2.f * 2.f * z * sh[18 + k] + SH_C2[3] * x * sh[21 + k];
+                        if (deg > 2) {
+                            dsh[27 + k] = SH_C3[0] * y * (3.f * xx - yy) * g; dsh[30 + k] = SH_C3[1] * xy * z * g;
+                            dsh[33 + k] = SH_C3[2] * y * (4.f * zz - xx - yy) * g; dsh[36 + k] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                            dsh[39 + k] = SH_C3[4] * x * (4.f * zz - xx - yy) * g; dsh[42 + k] = SH_C3[5] * z * (xx - yy) * g;
+                            dsh[45 + k] = SH_C3[6] * x * (xx - 3.f * yy) * g;
+                            rx += SH_C3[0] * sh[27 + k] * 3.f * 2.f * xy + SH_C3[1] * sh[30 + k] * yz + SH_C3[2] * sh[33 + k] * -2.f * xy +
+                                  SH_C3[3] * sh[36 + k] * -3.f * 2.f * xz + SH_C3[4] * sh[39 + k] * (-3.f * xx + 4.f * zz - yy) +
+                                  SH_C3[5] * sh[42 + k] * 2.f * xz + SH_C3[6] * sh[45 + k] * 3.f * (xx - yy);
+                            ry += SH_C3[0] * sh[27 + k] * 3.f * (xx - yy) + SH_C3[1] * sh[30 + k] * xz + SH_C3[2] * sh[33 + k] * (-3.f * yy + 4.f * zz - xx) +
+                                  SH_C3[3] * sh[36 + k] * -3.f * 2.f * yz + SH_C3[4] * sh[39 + k] * -2.f * xy + SH_C3[5] * sh[42 + k] * -2.f * yz +
+                                  SH_C3[6] * sh[45 + k] * -3.f * 2.f * xy;
+                            rz += SH_C3[1] * sh[30 + k] * xy + SH_C3[2] * sh[33 + k] * 4.f * 2.f * yz + SH_C3[3] * sh[36 + k] * 3.f * (2.f * zz - xx - yy) +
+                                  SH_C3[4] * sh[39 + k] * 4.f * 2.f * xz + SH_C3[5] * sh[42 + k] * (xx - yy);
+                        }
+                    }
+                }
+                ddx += rx * g; ddy += ry * g; ddz += rz * g;   // :131
+            }
+            // dnormvdv, auxiliary.h:107-117
+            const f3 v = dir_orig;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float mx = ((+sum2 - v.x * v.x) * ddx - v.y * v.x * ddy - v.z * v.x * ddz) * invsum32;
+            const float my = (-v.x * v.y * ddx + (sum2 - v.y * v.y) * ddy - v.z * v.y * ddz) * invsum32;
+            const float mz = (-v.x * v.z * ddx - v.y * v.z * ddy + (sum2 - v.z * v.z) * ddz) * invsum32;
+            dmean[0] += mx; dmean[1] += my; dmean[2] += mz;       // :139
+            dtau[0] -= mx; dtau[1] -= my; dtau[2] -= mz;          // :141-143 (Q17 ii)
+        }
+
+        // ---- backward.cu:350-413: cov3D -> scale, quaternion (no normalisation backward, Q1) ----
+        if (a.scales != nullptr) {
+            const float* q4 = a.rotations + 4 * i;
+            const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+            const float Rq[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                                    {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                                    {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+            const float s[3] = {a.scale_modifier * a.scales[3 * i], a.scale_modifier * a.scales[3 * i + 1], a.scale_modifier * a.scales[3 * i + 2]};
+            const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float Dm[3][3];   // Dm[k][j] = (2 M dSigma)[k][j] * s_k with M[k][j] = s_k Rq[j][k]
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float dM = 2.0f * (s[k] * Rq[0][k] * dS[0][j] + s[k] * Rq[1][k] * dS[1][j] + s[k] * Rq[2][k] * dS[2][j]);
+                    Dm[k][j] = dM;
+                }
+                dscale[k] = Rq[0][k] * Dm[k][0] + Rq[1][k] * Dm[k][1] + Rq[2][k] * Dm[k][2];   // :394-397 (not multiplied by scale_modifier)
+#pragma unroll
+                for (int j = 0; j < 3; j++) Dm[k][j] *= s[k];                                     // :399-401
+            }
+            drot[0] = 2 * z * (Dm[0][1] - Dm[1][0]) + 2 * y * (Dm[2][0] - Dm[0][2]) + 2 * x * (Dm[1][2] - Dm[2][1]);   // :405-408
+            drot[1] = 2 * y * (Dm[1][0] + Dm[0][1]) + 2 * z * (Dm[2][0] + Dm[0][2]) + 2 * r * (Dm[1][2] - Dm[2][1]) - 4 * x * (Dm[2][2] + Dm[1][1]);
+            drot[2] = 2 * x * (Dm[1][0] + Dm[0][1]) + 2 * r * (Dm[2][0] - Dm[0][2]) + 2 * z * (Dm[1][2] + Dm[2][1]) - 4 * y * (Dm[2][2] + Dm[0][0]);
+            drot[3] = 2 * r * (Dm[0][1] - Dm[1][0]) + 2 * x * (Dm[2][0] + Dm[0][2]) + 2 * y * (Dm[1][2] + Dm[2][1]) - 4 * z * (Dm[1][1] + Dm[0][0]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * i + k] = dmean[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dcov[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dL_dtau[6 * i + k] = dtau[k];
+    if (a.dL_dscale) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
+    }
+    if (a.dL_drot) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+    }
+}
+
+}  // namespace gsr

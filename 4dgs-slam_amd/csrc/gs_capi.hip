@@ -1,0 +1,416 @@
+// gs_capi.hip -- host orchestration + the extern "C" boundary declared in include/gs_rasterizer.h.
+// Mirrors CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153,198-344,348-455) with an MI355X-first pipeline:
+//
+//   forward : memset(tile_count, header) -> F1 preprocess(+tile histogram, +block sums) -> F2 scans
+//             -> [one 12-byte D2H + stream sync: R, error flag, R_alloc] -> binning alloc
+//             -> F3 scatter -> F4 per-tile LDS bitonic depth sort -> F5 tile compositing
+//   backward: B1 per-tile gradient pass (register/DPP reductions, per-instance slots) -> B2 per-Gaussian gather + geometry
+//
+// No global 64-bit radix sort, no float atomics, no cooperative-groups block trees.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gs_rasterizer.h"
+#include "gs_backward.h"
+
+namespace gsr {
+
+static thread_local std::string g_last_error;
+static int g_fwd_ppl = 4;
+static int g_bwd_ppl = 4;
+
+#define GSR_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+            return GSR_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+// ---- scratch carving (same idea as rasterizer_impl.h:22-27 `obtain`, 256-byte aligned) -------------------------
+template <typename T>
+static inline void carve(char*& p, T*& ptr, size_t count)
+{
+    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
+    ptr = reinterpret_cast<T*>(a);
+    p = reinterpret_cast<char*>(ptr + count);
+}
+
+struct GeomState {
+    uint32_t* header;   // [0]=R, [1]=error flag, [2]=R_alloc, [3]=reserved
+    float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
+    int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
+    static GeomState from(char*& p, size_t P)
+    {
+        GeomState g;
+        const size_t nb = (P + 255) / 256 + 1;
+        carve(p, g.header, 4);
+        carve(p, g.depths, P); carve(p, g.means2D, P); carve(p, g.conic_opacity, P); carve(p, g.rgb, 3 * P);
+        carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
+        carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
+        return g;
+    }
+};
+struct ImageState {
+    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
+    static ImageState from(char*& p, size_t N, size_t T)
+    {
+        ImageState s;
+        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.tile_cursor, T);
+        return s;
+    }
+};
+struct BinningState {
+    uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted;
+    // Every base offset depends on R only, so backward re-carves without knowing R_alloc. `keys` (forward-only sort
+    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only gradient slots (R * nw * 48 B): 16R <= 48R.
+    static BinningState from(char*& p, size_t R, size_t R_alloc, int nw)
+    {
+        BinningState b;
+        carve(p, b.inst_gauss, R); carve(p, b.partials, R * 3 * (size_t)nw);
+        b.keys = reinterpret_cast<uint64_t*>(b.partials);
+        carve(p, b.sorted, R_alloc);
+        return b;
+    }
+};
+template <typename F>
+static size_t required(F&& f)
+{
+    char* p = nullptr;
+    f(p);
+    return reinterpret_cast<size_t>(p) + 256;
+}
+
+// ---- per-kernel timing with events on the launch stream ---------------------------------------------------------
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_GEOM_BWD, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "scatter_instances", "sort_tiles",
+                                                  "render_fwd", "render_bwd", "geometry_bwd"};
+struct Profiler {
+    bool enabled = false;
+    struct Rec { hipEvent_t a, b; int id; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[K_COUNT] = {0};
+    int calls[K_COUNT] = {0};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void drain()
+    {
+        for (auto& r : pending) {
+            (void)hipEventSynchronize(r.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { total_ms[r.id] += ms; calls[r.id]++; }
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+};
+static Profiler g_prof;
+struct ScopedKernelTimer {
+    int id; hipStream_t s; hipEvent_t a{}, b{}; bool on;
+    ScopedKernelTimer(int id_, hipStream_t s_) : id(id_), s(s_), on(g_prof.enabled)
+    {
+        if (on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, s); }
+    }
+    ~ScopedKernelTimer()
+    {
+        if (on) { (void)hipEventRecord(b, s); g_prof.pending.push_back({a, b, id}); if (g_prof.pending.size() > 4096) g_prof.drain(); }
+    }
+};
+
+static int debug_sync(int debug, hipStream_t s, const char* what)
+{
+    // CHECK_CUDA(..., debug) of the reference (auxiliary.h:166-173): synchronise after every stage when debugging.
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { g_last_error = std::string(what) + ": " + hipGetErrorString(e); return GSR_ERR_HIP; }
+    return 0;
+}
+#define GSR_STAGE(what) do { int _r = debug_sync(debug, stream, what); if (_r) return _r; } while (0)
+
+static thread_local uint32_t* t_pinned = nullptr;
+
+template <int PPL>
+static void launch_render_fwd(int T, int gx, const ImageState& img, const BinningState& bin, int W, int H, const GeomState& geom,
+                              const float* feat, const float* bg, float* out_color, float* out_depth, float* out_opacity,
+                              int* n_touched, hipStream_t s)
+{
+    hipLaunchKernelGGL(render_fwd_kernel<PPL>, dim3(T), dim3(256 / PPL), 0, s, T, gx, img.ranges, bin.sorted, W, H, geom.means2D, feat,
+                       geom.conic_opacity, geom.depths, bg, img.final_T, img.n_contrib, out_color, out_depth, out_opacity, n_touched);
+}
+template <int PPL>
+static void launch_render_bwd(int T, int gx, const ImageState& img, const BinningState& bin, int W, int H, const GeomState& geom,
+                              const float* feat, const float* bg, const float* dL_dpix, const float* dL_dpix_depth, hipStream_t s)
+{
+    hipLaunchKernelGGL(render_bwd_kernel<PPL>, dim3(T), dim3(256 / PPL), 0, s, T, gx, img.ranges, bin.sorted, W, H, bg, geom.means2D,
+                       geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth, bin.partials);
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" {
+
+const char* gsr_last_error(void) { return g_last_error.c_str(); }
+const char* gsr_version(void) { return "gs_rasterizer_hip 0.1 (gfx950)"; }
+
+size_t gsr_geometry_buffer_size(int P) { return required([&](char*& p) { GeomState::from(p, (size_t)P); }); }
+size_t gsr_image_buffer_size(int width, int height)
+{
+    const size_t T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
+    return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T); });
+}
+size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc, 4 / g_bwd_ppl); }); }
+
+int gsr_set_render_ppl(int forward_ppl, int backward_ppl)
+{
+    auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
+    if (ok(forward_ppl)) g_fwd_ppl = forward_ppl;
+    if (ok(backward_ppl)) g_bwd_ppl = backward_ppl;
+    return g_fwd_ppl * 10 + g_bwd_ppl;
+}
+
+int gsr_profile_enable(int enabled) { g_prof.enabled = enabled != 0; return 0; }
+void gsr_profile_reset(void)
+{
+    g_prof.drain();
+    for (int i = 0; i < K_COUNT; i++) { g_prof.total_ms[i] = 0; g_prof.calls[i] = 0; }
+}
+int gsr_profile_read(const char** names, float* total_ms, int* calls, int cap)
+{
+    g_prof.drain();
+    int n = 0;
+    for (int i = 0; i < K_COUNT && n < cap; i++, n++) {
+        if (names) names[n] = kKernelNames[i];
+        if (total_ms) total_ms[n] = (float)g_prof.total_ms[i];
+        if (calls) calls[n] = g_prof.calls[i];
+    }
+    return n;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present, void* stream_)
+{
+    (void)projmatrix;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { g_last_error = "gsr_mark_visible: null argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc) {
+        g_last_error = "gsr_forward: invalid size or missing allocator"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (!background || !out_color || !out_depth || !out_opacity || !n_touched) { g_last_error = "gsr_forward: null output/background"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P > 0) {
+        if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) { g_last_error = "gsr_forward: null input"; return GSR_ERR_INVALID_ARGUMENT; }
+        if (!cov3D_precomp && (!scales || !rotations)) { g_last_error = "gsr_forward: need scales+rotations or cov3D_precomp"; return GSR_ERR_INVALID_ARGUMENT; }
+        // rasterizer_impl.cu:245-248 analogue: colours must come from somewhere
+        if (!colors_precomp && (!shs || M <= 0)) { g_last_error = "gsr_forward: need shs (M>0) or colors_precomp"; return GSR_ERR_INVALID_ARGUMENT; }
+        if (!colors_precomp && (D < 0 || D > 3 || (D + 1) * (D + 1) > M)) { g_last_error = "gsr_forward: sh degree out of range for M"; return GSR_ERR_INVALID_ARGUMENT; }
+    }
+    const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
+    const size_t N = (size_t)width * height;
+
+    char* gchunk = geometry_alloc(geometry_user, gsr_geometry_buffer_size(P));
+    char* ichunk = image_alloc(image_user, gsr_image_buffer_size(width, height));
+    if (!gchunk || !ichunk) { g_last_error = "gsr_forward: allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+    GeomState geom = GeomState::from(gchunk, (size_t)P);
+    ImageState img = ImageState::from(ichunk, N, (size_t)T);
+    if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
+
+    GSR_HIP_CHECK(hipMemsetAsync(geom.header, 0, 4 * sizeof(uint32_t), stream));
+    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * sizeof(uint32_t), stream));
+
+    const int nblocks = (P + 255) / 256;
+    if (P > 0) {
+        PreprocessArgs a;
+        a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.gx = gx; a.gy = gy;
+        a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations; a.opacities = opacities;
+        a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+        a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos;
+        a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+        a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx);   // rasterizer_impl.cu:225-226
+        a.prefiltered = prefiltered; a.radii = radii; a.n_touched = n_touched;
+        a.depths = geom.depths; a.means2D = geom.means2D; a.conic_opacity = geom.conic_opacity; a.rgb = geom.rgb; a.cov3D = geom.cov3D;
+        a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums; a.tile_count = img.tile_count;
+        a.header = geom.header;
+        {
+            ScopedKernelTimer tm(K_PREPROCESS, stream);
+            hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+        }
+        GSR_STAGE("preprocess_fwd");
+    }
+    {
+        ScopedKernelTimer tm(K_SCAN, stream);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
+                           img.ranges, img.tile_cursor, geom.header);
+    }
+    GSR_STAGE("scan");
+
+    // The one host synchronisation of the forward pass (the reference's is rasterizer_impl.cu:283-284).
+    if (!t_pinned) GSR_HIP_CHECK(hipHostMalloc((void**)&t_pinned, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    GSR_HIP_CHECK(hipMemcpyAsync(t_pinned, geom.header, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_CHECK(hipStreamSynchronize(stream));
+    const uint32_t R = t_pinned[0], err = t_pinned[1], R_alloc = t_pinned[2];
+    if (err) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
+    if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
+
+    const int nw_bwd = 4 / g_bwd_ppl;   // gradient-slot count per instance; gsr_backward must run with the same setting
+    const size_t bsize = required([&](char*& p) { BinningState::from(p, (size_t)R, (size_t)R_alloc, nw_bwd); });
+    char* bchunk = binning_alloc(binning_user, bsize);
+    if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+    BinningState bin = BinningState::from(bchunk, (size_t)R, (size_t)R_alloc, nw_bwd);
+
+    if (R > 0) {
+        if (R_alloc != R) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, (size_t)R_alloc * sizeof(uint64_t), stream));   // sort padding
+        {
+            ScopedKernelTimer tm(K_SCATTER, stream);
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(256), 0, stream, P, gx, gy, radii, geom.means2D, geom.depths,
+                               geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, bin.keys, bin.inst_gauss);
+        }
+        GSR_STAGE("scatter_instances");
+        {
+            ScopedKernelTimer tm(K_SORT, stream);
+            hipLaunchKernelGGL(sort_tiles_kernel, dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys, bin.inst_gauss, bin.sorted);
+        }
+        GSR_STAGE("sort_tiles");
+    } else if (P > 0) {
+        // keep point_offsets defined for debug readers / backward even when nothing is visible
+        GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
+    }
+
+    // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
+    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
+    {
+        ScopedKernelTimer tm(K_RENDER_FWD, stream);
+        switch (g_fwd_ppl) {
+            case 1: launch_render_fwd<1>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
+            case 2: launch_render_fwd<2>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
+            default: launch_render_fwd<4>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
+        }
+    }
+    GSR_STAGE("render_fwd");
+    return (int)R;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                 char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, float* dL_dtau, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P == 0) return 0;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || !means3D || !viewmatrix ||
+        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
+        !dL_dmean3D || !dL_dcov3D || !dL_dtau) {
+        g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
+    char* gp = geom_buffer; char* bp = binning_buffer; char* ip = image_buffer;
+    GeomState geom = GeomState::from(gp, (size_t)P);
+    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R, 4 / g_bwd_ppl);   // offsets depend on R only
+    ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T);
+    if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
+    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
+    const int ppl = g_bwd_ppl;
+    if (R > 0) {
+        ScopedKernelTimer tm(K_RENDER_BWD, stream);
+        switch (ppl) {
+            case 1: launch_render_bwd<1>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
+            case 2: launch_render_bwd<2>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
+            default: launch_render_bwd<4>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
+        }
+    }
+    GSR_STAGE("render_bwd");
+    GeomBwdArgs a;
+    a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.NW = 4 / ppl;
+    a.means3D = means3D; a.radii = radii; a.shs = shs; a.clamped = geom.clamped; a.scales = scales; a.rotations = rotations;
+    a.scale_modifier = scale_modifier; a.cov3Ds = cov3D_precomp ? cov3D_precomp : geom.cov3D;   // rasterizer_impl.cu:429
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.projmatrix_raw = projmatrix_raw; a.campos = campos;
+    a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials;
+    a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
+    a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
+    {
+        ScopedKernelTimer tm(K_GEOM_BWD, stream);
+        hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+    }
+    GSR_STAGE("geometry_bwd");
+    return 0;
+}
+
+int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_buffer, const char* binning_buffer,
+                         const char* image_buffer, float* depths, float* means2D, float* conic_opacity, float* rgb, float* cov3D,
+                         unsigned char* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, float* final_T, uint32_t* n_contrib,
+                         uint32_t* ranges, uint32_t* point_list, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    GSR_HIP_CHECK(hipStreamSynchronize(stream));
+    const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
+    const size_t N = (size_t)width * height;
+    char* gp = const_cast<char*>(geom_buffer); char* bp = const_cast<char*>(binning_buffer); char* ip = const_cast<char*>(image_buffer);
+    GeomState geom = GeomState::from(gp, (size_t)P);
+    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R, 4 / g_bwd_ppl);
+    ImageState img = ImageState::from(ip, N, (size_t)T);
+#define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
+    D2H(depths, geom.depths, P * sizeof(float));
+    D2H(means2D, geom.means2D, P * 2 * sizeof(float));
+    D2H(conic_opacity, geom.conic_opacity, P * 4 * sizeof(float));
+    D2H(rgb, geom.rgb, P * 3 * sizeof(float));
+    D2H(cov3D, geom.cov3D, P * 6 * sizeof(float));
+    if (clamped && P) {
+        std::vector<uint8_t> bits(P);
+        GSR_HIP_CHECK(hipMemcpy(bits.data(), geom.clamped, P, hipMemcpyDeviceToHost));
+        for (int i = 0; i < P; i++) for (int k = 0; k < 3; k++) clamped[3 * i + k] = (bits[i] >> k) & 1;
+    }
+    D2H(tiles_touched, geom.tiles_touched, P * sizeof(uint32_t));
+    D2H(point_offsets, geom.point_offsets, P * sizeof(uint32_t));
+    D2H(final_T, img.final_T, N * sizeof(float));
+    D2H(n_contrib, img.n_contrib, N * sizeof(uint32_t));
+    std::vector<uint32_t> rg((size_t)T * 2);
+    GSR_HIP_CHECK(hipMemcpy(rg.data(), img.ranges, (size_t)T * 8, hipMemcpyDeviceToHost));
+    // Padded segments (huge tiles) are compacted so the caller sees the reference's packed layout.
+    std::vector<uint32_t> packed((size_t)T * 2);
+    uint32_t run = 0, maxend = 0;
+    for (int t = 0; t < T; t++) {
+        const uint32_t n = rg[2 * t + 1] - rg[2 * t];
+        packed[2 * t] = n ? run : 0; packed[2 * t + 1] = n ? run + n : 0;   // empty tiles stay (0,0) like the memset at rasterizer_impl.cu:313
+        run += n;
+        if (rg[2 * t + 1] > maxend) maxend = rg[2 * t + 1];
+    }
+    if (ranges) memcpy(ranges, packed.data(), (size_t)T * 8);
+    if (point_list && R > 0) {
+        std::vector<uint2> srt(maxend);
+        GSR_HIP_CHECK(hipMemcpy(srt.data(), bin.sorted, (size_t)maxend * sizeof(uint2), hipMemcpyDeviceToHost));
+        size_t o = 0;
+        for (int t = 0; t < T; t++)
+            for (uint32_t k = rg[2 * t]; k < rg[2 * t + 1]; k++) point_list[o++] = srt[k].x;
+    }
+#undef D2H
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// gs_device.h -- device-side helpers shared by the gfx950 rasterizer kernels.
+// wave64 only: every cross-lane helper hard-codes 64 lanes (CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int TILE_X = 16;   // DGR/cuda_rasterizer/config.h:15-17 (the binning granularity is part of the result)
+constexpr int TILE_Y = 16;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Spherical-harmonics constants, DGR/cuda_rasterizer/auxiliary.h:22-39
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                       -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ---- DPP cross-lane adds (one v_add_f32 with a DPP source modifier each) --------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (row 3), callers read lane 63.
+__device__ __forceinline__ float wave_sum_to_row3(float v)
+{
+    v += dpp_f<0xB1>(v);            // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_f<0x4E>(v);            // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_f<0x141>(v);           // row_half_mirror      (8-lane sums)
+    v += dpp_f<0x140>(v);           // row_mirror           (16-lane row sums in every lane)
+    v += dpp_f<0x142, 0xA>(v);      // row_bcast:15 -> rows 1,3
+    v += dpp_f<0x143, 0xC>(v);      // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Inclusive prefix sum across the wave (6 shuffle steps); used for instance expansion.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Expand per-lane item counts into a lane-parallel loop over all items of the wave, 64 items at a time:
+// f(src_lane, k, active) is called by ALL 64 lanes each round (so f may shuffle from src_lane -- a DS
+// permute only returns data of lanes that are active at the call); its side effects must be guarded by `active`.
+template <typename F>
+__device__ __forceinline__ void wave_expand(uint32_t cnt, F&& f)
+{
+    const int lane = lane_id();
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = __shfl(incl, 63, 64);
+    for (uint32_t base = 0; base < total; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        int lo = 0;  // smallest lane with incl > i
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t v = __shfl(incl, lo + step - 1, 64);
+            if (v <= i) lo += step;
+        }
+        lo = lo > 63 ? 63 : lo;
+        const uint32_t src_incl = __shfl(incl, lo, 64);
+        const uint32_t src_cnt = __shfl(cnt, lo, 64);
+        f(lo, i - (src_incl - src_cnt), i < total);
+    }
+}
+
+// ---- small geometry helpers (reference semantics cited at the call sites) --------------------------------------
+// DGR/cuda_rasterizer/auxiliary.h:41-44 evaluates in double because of its 1.0 / 0.5 literals; so do we.
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }
+
+// auxiliary.h:46-56: tile rectangle with int truncation, clamped to the grid.
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1, int& y1)
+{
+    x0 = min(gx, max(0, (int)((px - radius) / TILE_X)));
+    y0 = min(gy, max(0, (int)((py - radius) / TILE_Y)));
+    x1 = min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
+    y1 = min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
+}
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Matrices arrive as the reference passes them: row-major memory of the TRANSPOSED maths matrix,
+// i.e. m[0],m[4],m[8],m[12] is row 0 (auxiliary.h:58-77).
+__device__ __forceinline__ f3 xform_point_4x3(f3 p, const float* __restrict__ m)
+{
+    return mk3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+
+// XCD-aware tile order: block b runs on XCD b % 8 (observed, speed only); give each XCD a contiguous band of tiles
+// so neighbouring tiles (which share Gaussians) hit the same L2. Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile_of_block(int b, int ntiles)
+{
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = b & 7, k = b >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+}  // namespace gsr

@@ -1,0 +1,463 @@
+// gs_forward.h -- forward kernels: per-Gaussian preprocess, per-tile binning + depth sort, tile compositing.
+// gfx950 / wave64. Reference behaviour being reproduced is cited per function (DGR = submodules/diff-gaussian-rasterization).
+#pragma once
+#include "gs_device.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------------------------------
+// F1: per-Gaussian preprocess (DGR/cuda_rasterizer/forward.cu:157-258) fused with
+//     (a) the per-tile instance histogram (replaces the global 64-bit radix sort's first pass) and
+//     (b) the per-block partial sum of tiles_touched (first level of the scan, rasterizer_impl.cu:280).
+// One thread per Gaussian, 256 threads per block.
+// ------------------------------------------------------------------------------------------------------------------
+struct PreprocessArgs {
+    int P, D, M, W, H, gx, gy;
+    const float* means3D; const float* scales; float scale_modifier; const float* rotations; const float* opacities;
+    const float* shs; const float* cov3D_precomp; const float* colors_precomp;
+    const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int prefiltered;
+    int* radii; int* n_touched;
+    float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
+    uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* header;
+};
+
+// forward.cu:120-154 -- Sigma = Rq diag(s*mod)^2 Rq^T, quaternion deliberately NOT normalised (:129).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* s3, float mod, const float* q4, float* cov6)
+{
+    const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
+    const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+    const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+    const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+    const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+    // M[k][i] = s_k * R[i][k];  Sigma[i][j] = sum_k M[k][i] M[k][j]
+    const float m00 = sx * R00, m01 = sx * R10, m02 = sx * R20;
+    const float m10 = sy * R01, m11 = sy * R11, m12 = sy * R21;
+    const float m20 = sz * R02, m21 = sz * R12, m22 = sz * R22;
+    cov6[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    cov6[1] = m00 * m01 + m10 * m11 + m20 * m21;
+    cov6[2] = m00 * m02 + m10 * m12 + m20 * m22;
+    cov6[3] = m01 * m01 + m11 * m11 + m21 * m21;
+    cov6[4] = m01 * m02 + m11 * m12 + m21 * m22;
+    cov6[5] = m02 * m02 + m12 * m12 + m22 * m22;
+}
+
+// The 2x3 matrix A = J * R_cw and cov2D = A Sigma A^T + 0.3 I (forward.cu:76-115; re-used by backward.cu:171-206).
+struct Cov2D {
+    f3 t;                 // view-space mean with the fov clamp applied to x,y (forward.cu:84-89)
+    float txtz, tytz;     // unclamped ratios (backward.cu:177-183 needs them for the gradient masks)
+    float J00, J02, J11, J12;
+    float A[2][3];
+    float a, b, c;
+};
+__device__ __forceinline__ Cov2D cov2d_eval(f3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                            const float* cov6, const float* __restrict__ vm)
+{
+    Cov2D o;
+    f3 t = xform_point_4x3(mean, vm);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    o.txtz = t.x / t.z;
+    o.tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, o.txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, o.tytz)) * t.z;
+    o.t = t;
+    o.J00 = fx / t.z; o.J02 = -(fx * t.x) / (t.z * t.z);
+    o.J11 = fy / t.z; o.J12 = -(fy * t.y) / (t.z * t.z);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {  // R_cw[i][k] = vm[i + 4k]
+        o.A[0][k] = o.J00 * vm[0 + 4 * k] + o.J02 * vm[2 + 4 * k];
+        o.A[1][k] = o.J11 * vm[1 + 4 * k] + o.J12 * vm[2 + 4 * k];
+    }
+    const float V00 = cov6[0], V01 = cov6[1], V02 = cov6[2], V11 = cov6[3], V12 = cov6[4], V22 = cov6[5];
+    const float av00 = o.A[0][0] * V00 + o.A[0][1] * V01 + o.A[0][2] * V02;
+    const float av01 = o.A[0][0] * V01 + o.A[0][1] * V11 + o.A[0][2] * V12;
+    const float av02 = o.A[0][0] * V02 + o.A[0][1] * V12 + o.A[0][2] * V22;
+    const float av10 = o.A[1][0] * V00 + o.A[1][1] * V01 + o.A[1][2] * V02;
+    const float av11 = o.A[1][0] * V01 + o.A[1][1] * V11 + o.A[1][2] * V12;
+    const float av12 = o.A[1][0] * V02 + o.A[1][1] * V12 + o.A[1][2] * V22;
+    o.a = av00 * o.A[0][0] + av01 * o.A[0][1] + av02 * o.A[0][2] + 0.3f;  // low-pass, forward.cu:112-113
+    o.b = av00 * o.A[1][0] + av01 * o.A[1][1] + av02 * o.A[1][2];
+    o.c = av10 * o.A[1][0] + av11 * o.A[1][1] + av12 * o.A[1][2] + 0.3f;
+    return o;
+}
+
+// forward.cu:22-73. sh points at this Gaussian's [M,3] coefficients. Returns rgb (>=0) and the 3 clamp flags as bits.
+__device__ __forceinline__ f3 sh_to_rgb(int deg, const float* __restrict__ sh, f3 pos, f3 campos, uint32_t& clamp_bits)
+{
+    f3 dir = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+    const float inv = 1.0f / sqrtf(dot3(dir, dir));
+    const float x = dir.x * inv, y = dir.y * inv, z = dir.z * inv;
+    float res[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v = SH_C0 * sh[k];
+        if (deg > 0) {
+            v = v - SH_C1 * y * sh[3 + k] + SH_C1 * z * sh[6 + k] - SH_C1 * x * sh[9 + k];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                v = v + SH_C2[0] * xy * sh[12 + k] + SH_C2[1] * yz * sh[15 + k] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + k] +
+                    SH_C2[3] * xz * sh[21 + k] + SH_C2[4] * (xx - yy) * sh[24 + k];
+                if (deg > 2) {
+                    v = v + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + k] + SH_C3[1] * xy * z * sh[30 + k] +
+                        SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + k] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + k] +
+                        SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + k] + SH_C3[5] * z * (xx - yy) * sh[42 + k] +
+                        SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + k];
+                }
+            }
+        }
+        res[k] = v + 0.5f;
+    }
+    clamp_bits = (res[0] < 0 ? 1u : 0u) | (res[1] < 0 ? 2u : 0u) | (res[2] < 0 ? 4u : 0u);  // forward.cu:69-71
+    return mk3(fmaxf(res[0], 0.f), fmaxf(res[1], 0.f), fmaxf(res[2], 0.f));
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_wave_sum[4];
+
+    uint32_t touched = 0;
+    int rx0 = 0, ry0 = 0, rw = 0;
+    if (idx < a.P) {
+        int my_radius = 0;
+        if (a.n_touched) a.n_touched[idx] = 0;
+        const f3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const f3 p_view = xform_point_4x3(p, a.viewmatrix);
+        // near cull only (auxiliary.h:139-164); a culled point under `prefiltered` is an error (:156-160)
+        if (p_view.z <= 0.2f) {
+            if (a.prefiltered) atomicOr(&a.header[1], 1u);
+        } else {
+            const float* pm = a.projmatrix;
+            const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+            const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+            const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);  // forward.cu:201
+            float cov6[6];
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+            } else {
+                cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, cov6);
+#pragma unroll
+                for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = cov6[k];
+            }
+            const Cov2D cv = cov2d_eval(p, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov6, a.viewmatrix);
+            const float det = cv.a * cv.c - cv.b * cv.b;  // forward.cu:221-225
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (cv.a + cv.c);  // forward.cu:231-234
+                const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float rad_f = ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+                const float px = ndc2pix(hx * p_w, a.W), py = ndc2pix(hy * p_w, a.H);
+                int x0, y0, x1, y1;
+                tile_rect(px, py, (int)rad_f, a.gx, a.gy, x0, y0, x1, y1);
+                const int area = (x1 - x0) * (y1 - y0);
+                if (area != 0) {
+                    if (a.colors_precomp == nullptr) {
+                        uint32_t cb;
+                        const f3 c = sh_to_rgb(a.D, a.shs + (size_t)idx * a.M * 3, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
+                        a.rgb[3 * (size_t)idx] = c.x; a.rgb[3 * (size_t)idx + 1] = c.y; a.rgb[3 * (size_t)idx + 2] = c.z;
+                        a.clamped[idx] = (uint8_t)cb;
+                    }
+                    a.depths[idx] = p_view.z;
+                    a.means2D[idx] = make_float2(px, py);
+                    a.conic_opacity[idx] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, a.opacities[idx]);
+                    my_radius = (int)rad_f;
+                    touched = (uint32_t)area;
+                    rx0 = x0; ry0 = y0; rw = x1 - x0;
+                }
+            }
+        }
+        a.radii[idx] = my_radius;
+        a.tiles_touched[idx] = touched;
+    }
+    // (a) per-tile histogram: every (Gaussian, tile) instance adds one to its tile's counter.
+    wave_expand(touched, [&](int src, uint32_t k, bool active) {
+        const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
+        const int ty = sy0 + (int)(k / (uint32_t)sw), tx = sx0 + (int)(k % (uint32_t)sw);
+        if (active) atomicAdd(&a.tile_count[ty * a.gx + tx], 1u);
+    });
+    // (b) block partial sum
+    uint32_t s = touched;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) s_wave_sum[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_sums[blockIdx.x] = s_wave_sum[0] + s_wave_sum[1] + s_wave_sum[2] + s_wave_sum[3];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// F2: one block. (1) exclusive scan of the per-block sums -> block_base, R; (2) exclusive scan of the per-tile instance
+// counts -> tile ranges. A tile whose list exceeds the LDS sort capacity gets a power-of-two sized segment so that the
+// in-place global-memory bitonic sort can run on it (padding is pre-filled with ~0 keys); header[2] = allocated length.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SORT_LDS_CAP = 4096;  // keys per tile sorted in LDS (32 KiB)
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t v)
+{
+    return v <= 1 ? 1u : 1u << (32 - __clz((int)(v - 1)));
+}
+
+template <typename LOAD, typename STORE>
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, STORE store, uint32_t* s_tmp /*[17]*/)
+{
+    // sequential chunks of 1024 with a running carry; returns the grand total (valid in every thread).
+    uint32_t carry = 0;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? load(i) : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) s_tmp[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < 16; w++) { const uint32_t t = s_tmp[w]; s_tmp[w] = run; run += t; }
+            s_tmp[16] = run;
+        }
+        __syncthreads();
+        if (i < n) store(i, carry + s_tmp[wave] + incl - v, v);
+        carry += s_tmp[16];
+        __syncthreads();
+    }
+    return carry;
+}
+
+__global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
+                                                    int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
+                                                    uint32_t* header)
+{
+    __shared__ uint32_t s_tmp[17];
+    const uint32_t R = block_exclusive_scan_1024(
+        nblocks, [&](int i) { return block_sums[i]; }, [&](int i, uint32_t excl, uint32_t) { block_base[i] = excl; }, s_tmp);
+    const uint32_t R_alloc = block_exclusive_scan_1024(
+        ntiles,
+        [&](int i) { const uint32_t c = tile_count[i]; return c > (uint32_t)SORT_LDS_CAP ? next_pow2(c) : c; },
+        [&](int i, uint32_t excl, uint32_t) {
+            ranges[i] = make_uint2(excl, excl + tile_count[i]);
+            tile_cursor[i] = excl;
+        },
+        s_tmp);
+    if (threadIdx.x == 0) { header[0] = R; header[2] = R_alloc; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// F3: scatter every (Gaussian, tile) instance into its tile's segment (replaces duplicateWithKeys,
+// rasterizer_impl.cu:70-111). Instance id u = point_offsets_exclusive[g] + k is the reference's position in the
+// unsorted duplicate list; since u grows with g, sorting by (depth bits, u) reproduces the reference's stable
+// (tile | depth) sort order (rasterizer_impl.cu:98-108,306-311), ties included.
+// Also materialises the global inclusive scan point_offsets (rasterizer_impl.cu:280).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scatter_instances_kernel(int P, int gx, int gy, const int* radii, const float2* means2D,
+                                                                const float* depths, const uint32_t* tiles_touched,
+                                                                const uint32_t* block_base, uint32_t* point_offsets,
+                                                                uint32_t* tile_cursor, uint64_t* keys, uint32_t* inst_gauss)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_wave_sum[4];
+    const uint32_t cnt = idx < P ? tiles_touched[idx] : 0u;
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = block_base[blockIdx.x];
+    for (int w = 0; w < wave; w++) wbase += s_wave_sum[w];
+    const uint32_t off_incl = wbase + incl;
+    if (idx < P) point_offsets[idx] = off_incl;
+    int rx0 = 0, ry0 = 0, rw = 1;
+    uint32_t dbits = 0;
+    if (cnt) {
+        const float2 xy = means2D[idx];
+        int x1, y1;
+        tile_rect(xy.x, xy.y, radii[idx], gx, gy, rx0, ry0, x1, y1);
+        rw = x1 - rx0;
+        dbits = __float_as_uint(depths[idx]);
+    }
+    const uint32_t off_excl = off_incl - cnt;
+    wave_expand(cnt, [&](int src, uint32_t k, bool active) {
+        const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
+        const uint32_t sd = __shfl(dbits, src, 64), so = __shfl(off_excl, src, 64);
+        if (active) {
+            const int g = (blockIdx.x * 256 + (wave << 6)) + src;
+            const int ty = sy0 + (int)(k / (uint32_t)sw), tx = sx0 + (int)(k % (uint32_t)sw);
+            const uint32_t u = so + k;
+            const uint32_t pos = atomicAdd(&tile_cursor[ty * gx + tx], 1u);
+            keys[pos] = ((uint64_t)sd << 32) | (uint64_t)u;
+            inst_gauss[u] = (uint32_t)g;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// F4: per-tile depth sort. One 256-thread block per tile; bitonic network on 64-bit keys (depth bits << 32 | u), in
+// LDS when the (power-of-two padded) list fits SORT_LDS_CAP keys, otherwise in place in global memory on the tile's
+// power-of-two sized segment. Emits the sorted (gaussian id, instance id) pairs the render kernels walk.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename KEYS>
+__device__ __forceinline__ void bitonic_sort_block(KEYS keys, uint32_t npad)
+{
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                const bool asc = (i & k) == 0;
+                if ((a > b) == asc) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
+                                                         uint2* sorted)
+{
+    __shared__ uint64_t s_keys[SORT_LDS_CAP];
+    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    const uint2 r = ranges[tile];
+    const uint32_t n = r.y - r.x;
+    if (n == 0) return;
+    uint64_t* seg = keys + r.x;
+    if (n <= (uint32_t)SORT_LDS_CAP) {
+        const uint32_t npad = next_pow2(n);
+        for (uint32_t i = threadIdx.x; i < npad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
+        __syncthreads();
+        bitonic_sort_block(s_keys, npad);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t u = (uint32_t)s_keys[i];
+            sorted[r.x + i] = make_uint2(inst_gauss[u], u);
+        }
+    } else {
+        const uint32_t npad = next_pow2(n);  // segment was allocated with npad entries, tail pre-filled with ~0
+        bitonic_sort_block(seg, npad);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t u = (uint32_t)seg[i];
+            sorted[r.x + i] = make_uint2(inst_gauss[u], u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// F5: tile compositing (DGR/cuda_rasterizer/forward.cu:263-392). One block per 16x16 tile; each lane owns PPL
+// horizontally adjacent pixels, so a block has 256/PPL threads = 4/PPL wavefronts. The tile's sorted list is staged
+// through LDS in batches of NT entries (gathered by Gaussian id); every lane then walks the batch reading the
+// wave-uniform entry as LDS broadcasts. Early-out: a wave leaves a batch as soon as all its pixels are saturated,
+// the block leaves the list when every wave has (forward.cu:318-320 checks once per 256-entry round).
+// ------------------------------------------------------------------------------------------------------------------
+template <int PPL>
+__global__ void __launch_bounds__(256 / PPL) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                               const uint2* __restrict__ sorted, int W, int H,
+                                                               const float2* __restrict__ means2D, const float* __restrict__ feat,
+                                                               const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
+                                                               const float* __restrict__ bg, float* __restrict__ final_T,
+                                                               uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                                                               float* __restrict__ out_depth, float* __restrict__ out_opacity,
+                                                               int* __restrict__ n_touched)
+{
+    constexpr int NT = 256 / PPL;   // threads per block == entries per staged batch
+    constexpr int TPR = 16 / PPL;   // threads per pixel row
+    __shared__ float4 s_a[NT];      // {mean.x, mean.y, A, B}     with power = dx*(A*dx + B*dy) + C*dy*dy
+    __shared__ float4 s_b[NT];      // {C, opacity, depth, gaussian id bits}
+    __shared__ float4 s_c[NT];      // {r, g, b, -}
+
+    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int t = threadIdx.x, lane = lane_id();
+    const int py = ty * TILE_Y + t / TPR;
+    const int px0 = tx * TILE_X + (t % TPR) * PPL;
+    const float pyf = (float)py;
+    float pxf[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL], Dd[PPL];
+    uint32_t last[PPL];
+    bool done[PPL], inside[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        pxf[p] = (float)(px0 + p);
+        inside[p] = (px0 + p) < W && py < H;
+        done[p] = !inside[p];
+        T[p] = 1.0f; Cr[p] = Cg[p] = Cb[p] = Dd[p] = 0.f; last[p] = 0;
+    }
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    for (int base = 0; base < n; base += NT) {
+        bool all_done = true;
+#pragma unroll
+        for (int p = 0; p < PPL; p++) all_done = all_done && done[p];
+        if (__syncthreads_and(all_done)) break;
+        if (base + t < n) {
+            const uint2 e = sorted[range.x + base + t];
+            const float2 xy = means2D[e.x];
+            const float4 co = conic_opacity[e.x];
+            s_a[t] = make_float4(xy.x, xy.y, -0.5f * co.x, -co.y);
+            s_b[t] = make_float4(-0.5f * co.z, co.w, depths[e.x], __uint_as_float(e.x));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+        }
+        __syncthreads();
+        const int m = min(NT, n - base);
+        for (int j = 0; j < m; j++) {
+            const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
+            const uint32_t contributor = (uint32_t)(base + j + 1);
+            const float dy = A4.y - pyf;
+            const float cdy2 = B4.x * dy * dy, bdy = A4.w * dy;
+            int touched = 0;
+            bool wave_done = true;
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const float dx = A4.x - pxf[p];
+                const float power = dx * (A4.z * dx + bdy) + cdy2;           // forward.cu:345
+                const float alpha = fminf(0.99f, B4.y * __builtin_amdgcn_exp2f(power * LOG2E));  // :353
+                const bool valid = !done[p] && power <= 0.0f && alpha >= 1.0f / 255.0f;         // :346,:354
+                const float test_T = T[p] * (1.0f - alpha);
+                const bool stop = valid && test_T < 0.0001f;                   // :358-362
+                const bool blend = valid && !stop;
+                done[p] = done[p] || stop;
+                const float w = blend ? alpha * T[p] : 0.0f;
+                Cr[p] += C4.x * w; Cg[p] += C4.y * w; Cb[p] += C4.z * w; Dd[p] += B4.z * w;  // :364-367
+                touched += (blend && test_T > 0.5f) ? 1 : 0;                   // :369-371
+                T[p] = blend ? test_T : T[p];
+                last[p] = blend ? contributor : last[p];
+                wave_done = wave_done && done[p];
+            }
+            // one atomic per (wave, Gaussian) instead of one per pixel
+            const unsigned long long any_t = __ballot(touched != 0);
+            if (any_t) {
+                int cnt = touched;
+                if (PPL > 1) {
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+                } else {
+                    cnt = __popcll(any_t);
+                }
+                if (lane == 0) atomicAdd(&n_touched[__float_as_uint(B4.w)], cnt);
+            }
+            if (__all(wave_done)) break;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        if (inside[p]) {
+            const size_t pix = (size_t)py * W + (px0 + p);
+            final_T[pix] = T[p];
+            n_contrib[pix] = last[p];
+            out_color[pix] = Cr[p] + T[p] * bg[0];                             // forward.cu:384-390
+            out_color[(size_t)H * W + pix] = Cg[p] + T[p] * bg[1];
+            out_color[2 * (size_t)H * W + pix] = Cb[p] + T[p] * bg[2];
+            out_depth[pix] = Dd[p];
+            out_opacity[pix] = 1.0f - T[p];
+        }
+    }
+}
+
+// rasterizer_impl.cu:54-66
+__global__ void mark_visible_kernel(int P, const float* means3D, const float* viewmatrix, uint8_t* present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const f3 pv = xform_point_4x3(mk3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]), viewmatrix);
+    present[idx] = pv.z > 0.2f ? 1 : 0;
+}
+
+}  // namespace gsr

@@ -1,0 +1,260 @@
+"""ctypes binding of libgs_rasterizer_hip.so -- the counterpart of the reference's pybind module
+``diff_gaussian_rasterization._C`` (submodules/diff-gaussian-rasterization/ext.cpp:15-19,
+rasterize_points.{h,cu}).
+
+Same three entry points, same argument order, same return tuples:
+  rasterize_gaussians(...)          -> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, opacity, n_touched)
+  rasterize_gaussians_backward(...) -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau)
+  mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]
+
+PyTorch is plumbing here: it owns the device memory and the HIP stream; all arithmetic happens in
+hand-written HIP kernels behind the C ABI of include/gs_rasterizer.h. There is NO CPU fallback:
+tensors must live on a HIP device and the shared library must be present, otherwise this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_PKG_ROOT, "libgs_rasterizer_hip.so"))
+NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
+
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library (no GPU needed just to load it) and declare the C signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            f"(python __graft_entry__.py build, or 4dgs-slam_amd/csrc/build.sh). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, f, i = C.c_void_p, C.c_float, C.c_int
+    lib.gsr_forward.restype = i
+    lib.gsr_forward.argtypes = [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, i, i, i, vp, i, i,
+                                vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, i, vp, vp, vp, vp, vp, i, vp]
+    lib.gsr_backward.restype = i
+    lib.gsr_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, f, f, vp,
+                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+    lib.gsr_mark_visible.restype = i
+    lib.gsr_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_version.restype = C.c_char_p
+    lib.gsr_geometry_buffer_size.restype = C.c_size_t
+    lib.gsr_geometry_buffer_size.argtypes = [i]
+    lib.gsr_image_buffer_size.restype = C.c_size_t
+    lib.gsr_image_buffer_size.argtypes = [i, i]
+    lib.gsr_binning_buffer_size.restype = C.c_size_t
+    lib.gsr_binning_buffer_size.argtypes = [i]
+    lib.gsr_debug_read_state.restype = i
+    lib.gsr_debug_read_state.argtypes = [i, i, i, i] + [vp] * 16
+    lib.gsr_profile_enable.argtypes = [i]
+    lib.gsr_profile_read.restype = i
+    lib.gsr_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
+    lib.gsr_profile_reset.restype = None
+    lib.gsr_set_render_ppl.restype = i
+    lib.gsr_set_render_ppl.argtypes = [i, i]
+    _lib = lib
+    return lib
+
+
+def _err(lib, code, what):
+    msg = lib.gsr_last_error().decode(errors="replace")
+    raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def _require_device(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on '{t.device}': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); "
+            f"there is no CPU fallback in the product path."
+        )
+
+
+def _ptr(t):
+    """data pointer of a float32/int32 tensor made contiguous (rasterize_points.cu:98-118); empty -> NULL."""
+    if t is None or t.numel() == 0:
+        return None, None
+    tc = t.contiguous()
+    return tc.data_ptr(), tc
+
+
+class _Arena:
+    """The resizeFunctional of rasterize_points.cu:27-33: a growable uint8 device tensor handed to the C core."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width,
+                        sh, degree, campos, prefiltered, debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-122): same 20 arguments, same 9-tuple."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
+    _require_device(means3D, "means3D")
+    lib = load_library()
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    out_opacity = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    n_touched = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
+    if P == 0:  # rasterize_points.cu:85: nothing is launched, outputs stay zero
+        for t in (out_color, out_depth, out_opacity):
+            t.zero_()
+        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor, out_depth, out_opacity, n_touched
+    M = int(sh.shape[1]) if sh.numel() != 0 else 0  # rasterize_points.cu:87-91
+    keep = []
+
+    def p(t, name=None):
+        if t is not None and t.numel() != 0:
+            _require_device(t, name or "tensor")
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+        ptr, tc = _ptr(t)
+        keep.append(tc)
+        return ptr
+
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.gsr_forward(
+            geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M,
+            p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "shs"), p(colors, "colors_precomp"), p(opacity, "opacities"),
+            p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+            p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
+            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+            out_color.data_ptr(), out_depth.data_ptr(), out_opacity.data_ptr(), radii.data_ptr(), n_touched.data_ptr(),
+            int(bool(debug)), stream)
+    if rc < 0:
+        _err(lib, rc, "gsr_forward")
+    return rc, out_color, radii, geom.tensor, binning.tensor, img.tensor, out_depth, out_opacity, n_touched
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depths,
+                                 sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:124-211): same 23 arguments, same 9-tuple."""
+    _require_device(means3D, "means3D")
+    lib = load_library()
+    dev = means3D.device
+    P = int(means3D.shape[0])
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    M = int(sh.shape[1]) if sh.numel() != 0 else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    # the kernels write every element, so torch.empty replaces the 11 zero-fills of rasterize_points.cu:160-170
+    alloc = torch.zeros if P == 0 else torch.empty
+    dL_dmeans3D = alloc((P, 3), **f32)
+    dL_dmeans2D = alloc((P, 3), **f32)
+    dL_dcolors = alloc((P, NUM_CHANNELS), **f32)
+    dL_ddepths = alloc((P, 1), **f32)
+    dL_dconic = alloc((P, 2, 2), **f32)
+    dL_dopacity = alloc((P, 1), **f32)
+    dL_dcov3D = alloc((P, 6), **f32)
+    dL_dsh = alloc((P, M, 3), **f32)
+    dL_dscales = alloc((P, 3), **f32)
+    dL_drotations = alloc((P, 4), **f32)
+    dL_dtau = alloc((P, 6), **f32)
+    if P != 0:
+        keep = []
+
+        def p(t, name=None):
+            if t is not None and t.numel() != 0:
+                _require_device(t, name or "tensor")
+            ptr, tc = _ptr(t)
+            keep.append(tc)
+            return ptr
+
+        if M > 0 and colors.numel() != 0:
+            dL_dsh.zero_()  # colours were precomputed: the SH branch is not taken (backward.cu:533)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.gsr_backward(
+                P, int(degree), M, int(R), p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "shs"), p(colors, "colors_precomp"),
+                p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
+                p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(projmatrix_raw, "projmatrix_raw"), p(campos, "campos"),
+                float(tan_fovx), float(tan_fovy), p(radii, "radii"),
+                geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
+                p(dL_dout_color.to(torch.float32), "dL_dout_color"), p(dL_dout_depths.to(torch.float32), "dL_dout_depth"),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if (M > 0 and colors.numel() == 0) else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), dL_dtau.data_ptr(), int(bool(debug)), stream)
+        if rc < 0:
+            _err(lib, rc, "gsr_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:213-232)."""
+    _require_device(means3D, "means3D")
+    lib = load_library()
+    P = int(means3D.shape[0])
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        m, v, pr = means3D.contiguous(), viewmatrix.contiguous(), projmatrix.contiguous()
+        with torch.cuda.device(means3D.device):
+            rc = lib.gsr_mark_visible(P, m.data_ptr(), v.data_ptr(), pr.data_ptr(), present.data_ptr(),
+                                      torch.cuda.current_stream(means3D.device).cuda_stream)
+        if rc < 0:
+            _err(lib, rc, "gsr_mark_visible")
+    return present
+
+
+# ---- extras beyond the reference module (tests / bench) ---------------------------------------------------------
+def debug_read_state(P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
+    """Intermediate state as numpy arrays, in the reference's GeometryState/ImageState/BinningState terms."""
+    import numpy as np
+    lib = load_library()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out = dict(
+        depths=np.zeros(P, np.float32), means2D=np.zeros((P, 2), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
+        rgb=np.zeros((P, 3), np.float32), cov3D=np.zeros((P, 6), np.float32), clamped=np.zeros((P, 3), np.uint8),
+        tiles_touched=np.zeros(P, np.uint32), point_offsets=np.zeros(P, np.uint32), final_T=np.zeros((H, W), np.float32),
+        n_contrib=np.zeros((H, W), np.uint32), ranges=np.zeros((T, 2), np.uint32), point_list=np.zeros(max(R, 0), np.uint32),
+    )
+    order = ["depths", "means2D", "conic_opacity", "rgb", "cov3D", "clamped", "tiles_touched", "point_offsets",
+             "final_T", "n_contrib", "ranges", "point_list"]
+    stream = torch.cuda.current_stream(geomBuffer.device).cuda_stream
+    rc = lib.gsr_debug_read_state(P, R, W, H, geomBuffer.data_ptr(), binningBuffer.data_ptr() if binningBuffer.numel() else None,
+                                  imageBuffer.data_ptr(), *[out[k].ctypes.data_as(C.c_void_p) for k in order], stream)
+    if rc < 0:
+        _err(lib, rc, "gsr_debug_read_state")
+    return out
+
+
+def profile_enable(on: bool):
+    load_library().gsr_profile_enable(int(on))
+
+
+def profile_reset():
+    load_library().gsr_profile_reset()
+
+
+def profile_read():
+    lib = load_library()
+    cap = 16
+    names = (C.c_char_p * cap)()
+    ms = (C.c_float * cap)()
+    calls = (C.c_int * cap)()
+    n = lib.gsr_profile_read(names, ms, calls, cap)
+    return {names[i].decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
+
+
+def set_render_ppl(forward_ppl: int, backward_ppl: int) -> int:
+    return load_library().gsr_set_render_ppl(int(forward_ppl), int(backward_ppl))

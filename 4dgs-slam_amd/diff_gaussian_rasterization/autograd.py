@@ -1,0 +1,71 @@
+"""Autograd boundary of the MI355X rasterizer: the counterpart of ``_RasterizeGaussians``
+(submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py:48-171).
+
+``means2D``, ``theta`` and ``rho`` do not influence the forward value; they only receive gradients
+(reference :102-104,152-169). Only the colour and depth cotangents are consumed in backward; those of
+opacity / radii / n_touched are ignored exactly as the reference does (:108,116-138).
+"""
+import torch
+
+from . import _C
+
+
+def _snapshot(args):
+    """CPU copies of every tensor argument, taken before a debug-mode call (reference :17-19,90-97)."""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call(fn, args, debug, dump_path, message):
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_path)
+        print(message)
+        raise
+
+
+def _camera_block(rs):
+    """(scale_modifier, cov3D slot filled by caller, viewmatrix, projmatrix, projmatrix_raw, tanfovx, tanfovy)."""
+    return rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
+                raster_settings):
+        rs = raster_settings
+        # positional order of _C.rasterize_gaussians == rasterize_points.h:18-39
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                *_camera_block(rs), rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        (num_rendered, color, radii, geom_buf, binning_buf, img_buf, depth, opacity, n_touched) = _call(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_radii, grad_out_depth, grad_out_opacity, grad_n_touched):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
+        hw = (rs.image_height, rs.image_width)
+        if grad_out_color is None:
+            grad_out_color = means3D.new_zeros((3, *hw))
+        if grad_out_depth is None:
+            grad_out_depth = means3D.new_zeros((1, *hw))
+        # positional order of _C.rasterize_gaussians_backward == rasterize_points.h:41-65
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                *_camera_block(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos,
+                geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
+        (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau) = _call(
+            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump",
+            "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # per-Gaussian [rho | theta] rows -> one pose gradient, each returned as [1,3] (reference :152-154)
+        tau = g_tau.view(-1, 6).sum(dim=0)
+        g_rho, g_theta = tau[:3].view(1, -1), tau[3:].view(1, -1)
+        # one gradient per forward input, in input order (reference :157-169)
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rot, g_cov3D, g_theta, g_rho, None)

@@ -1,0 +1,123 @@
+/*
+ * gs_rasterizer.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer
+ * (libgs_rasterizer_hip.so, built from 4dgs-slam_amd/csrc/).
+ *
+ * This is the drop-in boundary for the reference's raw-pointer rasterizer core
+ *   CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+ *   (submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:24-88,
+ *    implemented in cuda_rasterizer/rasterizer_impl.cu:141-153,198-344,348-455)
+ * as called by the torch glue in rasterize_points.cu:35-232. Plain pointers and sizes only:
+ * every pointer is a DEVICE pointer into memory owned by the caller (PyTorch in practice),
+ * fp32 / int32, contiguous, laid out exactly as the reference lays them out. A NULL pointer
+ * selects the same branch a nullptr selects in the reference (shs / colors_precomp /
+ * scales+rotations / cov3D_precomp).
+ *
+ * Differences from the reference core, all on the safe side:
+ *   - the three std::function<char*(size_t)> resize callbacks (rasterizer.h:27-29,
+ *     rasterize_points.cu:27-33) become plain C callbacks gsr_alloc_fn + user pointer;
+ *   - an explicit hipStream_t (passed as void*) instead of the legacy default stream;
+ *   - errors are returned (negative codes + gsr_last_error()) instead of thrown / __trap'd;
+ *   - backward fully overwrites every gradient output, so the caller does not have to
+ *     zero-fill them first (rasterize_points.cu:160-170 does; doing so stays harmless).
+ * The byte layout inside the three scratch buffers is private to the library (as it is in the
+ * reference); they must be handed back unchanged to gsr_backward together with R.
+ */
+#ifndef GS_RASTERIZER_H_INCLUDED
+#define GS_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_BLOCK_X 16 /* cuda_rasterizer/config.h:15-17 */
+#define GSR_BLOCK_Y 16
+#define GSR_NUM_CHANNELS 3
+
+/* error codes (negative return values) */
+#define GSR_ERR_INVALID_ARGUMENT (-1)
+#define GSR_ERR_HIP (-2)          /* a HIP runtime call failed; text in gsr_last_error() */
+#define GSR_ERR_PREFILTERED (-3)  /* auxiliary.h:156-160: a point was culled although prefiltered was set */
+#define GSR_ERR_ALLOC (-4)        /* an allocation callback returned NULL */
+
+/* Replaces std::function<char*(size_t)> (rasterizer.h:27-29): must return a device pointer to at
+ * least `bytes` bytes (any alignment; the library aligns internally) that stays valid until the
+ * matching gsr_backward call has been enqueued. */
+typedef char* (*gsr_alloc_fn)(void* user, size_t bytes);
+
+/* Rasterizer::forward (rasterizer.h:24-52 / rasterizer_impl.cu:198-344).
+ * Returns num_rendered R >= 0 (the number of Gaussian x tile instances), or a negative error code.
+ * out_color[3,H,W], out_depth[1,H,W], out_opacity[1,H,W], radii[P], n_touched[P] are fully written
+ * (n_touched is zeroed by the library before accumulation). radii may be NULL (internal radii are used).
+ * Performs exactly one host synchronisation on `stream` (to learn R), like rasterizer_impl.cu:284. */
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user,
+                gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user,
+                int P, int D, int M,
+                const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, float* out_depth, float* out_opacity, int* radii, int* n_touched,
+                int debug, void* stream);
+
+/* Rasterizer::backward (rasterizer.h:54-88 / rasterizer_impl.cu:348-455). Returns 0 or a negative error code.
+ * Outputs (all fully written): dL_dmean2D[P,3] (z = 0), dL_dconic[P,2,2] (element [1][0] = 0), dL_dopacity[P],
+ * dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (may be NULL when M == 0 or shs == NULL),
+ * dL_dscale[P,3], dL_drot[P,4] (zero when scales == NULL), dL_dtau[P,6] = [rho(3), theta(3)] per Gaussian.
+ * Unlike the reference (float atomics, backward.cu:774-783) the result is bit-reproducible run to run. */
+int gsr_backward(int P, int D, int M, int R,
+                 const float* background, int width, int height,
+                 const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw, const float* campos,
+                 float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix, const float* dL_dpix_depth,
+                 float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtau,
+                 int debug, void* stream);
+
+/* Rasterizer::markVisible (rasterizer.h:20-22 / rasterizer_impl.cu:54-66,141-153): present[i] = (z_view > 0.2). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* stream);
+
+/* Scratch sizes, the counterpart of required<GeometryState|ImageState|BinningState>() (rasterizer_impl.h:68-73).
+ * gsr_forward passes exactly these sizes to the callbacks; exposed so a caller can pre-size arenas. */
+size_t gsr_geometry_buffer_size(int P);
+size_t gsr_image_buffer_size(int width, int height);
+size_t gsr_binning_buffer_size(int R_alloc);
+
+/* Reads back intermediate state for stage-by-stage parity checks (tests only; synchronises `stream`).
+ * Any destination may be NULL. depths[P], means2D[P,2], conic_opacity[P,4], rgb[P,3], cov3D[P,6], clamped[P,3] (0/1),
+ * tiles_touched[P], point_offsets[P] (inclusive scan), final_T[H*W], n_contrib[H*W], ranges[T,2],
+ * point_list (Gaussian id per sorted instance, packed tile after tile: exactly R entries). All HOST pointers. */
+int gsr_debug_read_state(int P, int R, int width, int height,
+                         const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                         float* depths, float* means2D, float* conic_opacity, float* rgb, float* cov3D, unsigned char* clamped,
+                         uint32_t* tiles_touched, uint32_t* point_offsets, float* final_T, uint32_t* n_contrib,
+                         uint32_t* ranges, uint32_t* point_list, void* stream);
+
+/* Thread-local text of the last error. */
+const char* gsr_last_error(void);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * gsr_profile_enable(1) starts collecting; gsr_profile_read copies up to `cap` entries
+ * (name pointers are static strings; ms = summed duration; calls = launches) and returns the count;
+ * it synchronises the recorded events. gsr_profile_reset() clears the accumulators. */
+int gsr_profile_enable(int enabled);
+int gsr_profile_read(const char** names, float* total_ms, int* calls, int cap);
+void gsr_profile_reset(void);
+
+/* Tuning knobs (process-wide): pixels per lane of the render kernels (1, 2 or 4). Returns the value in effect. */
+int gsr_set_render_ppl(int forward_ppl, int backward_ppl);
+
+const char* gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
