@@ -15,7 +15,9 @@
 #include <vector>
 
 #include "../../include/gs_rasterizer.h"
+#include "../../include/simple_knn.h"
 #include "gs_backward.h"
+#include "gs_knn.h"
 
 namespace gsr {
 
@@ -61,7 +63,8 @@ struct ImageState {
     static ImageState from(char*& p, size_t N, size_t T)
     {
         ImageState s;
-        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T); carve(p, s.tile_cursor, T);
+        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T * CTR_STRIDE);
+        carve(p, s.tile_cursor, T * CTR_STRIDE);
         return s;
     }
 };
@@ -87,11 +90,11 @@ static size_t required(F&& f)
 }
 
 // ---- per-kernel timing with events on the launch stream ---------------------------------------------------------
-enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_GEOM_BWD, K_COUNT };
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_GEOM_BWD, K_KNN, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "scatter_instances", "sort_tiles",
-                                                  "render_fwd", "render_bwd", "geometry_bwd"};
+                                                  "render_fwd", "render_bwd", "geometry_bwd", "knn_total"};
 struct Profiler {
-    bool enabled = false;
+    unsigned mask = 0;   // bit i set => kernel id i is timed
     struct Rec { hipEvent_t a, b; int id; };
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
@@ -116,7 +119,7 @@ struct Profiler {
 static Profiler g_prof;
 struct ScopedKernelTimer {
     int id; hipStream_t s; hipEvent_t a{}, b{}; bool on;
-    ScopedKernelTimer(int id_, hipStream_t s_) : id(id_), s(s_), on(g_prof.enabled)
+    ScopedKernelTimer(int id_, hipStream_t s_) : id(id_), s(s_), on((g_prof.mask >> id_) & 1u)
     {
         if (on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, s); }
     }
@@ -179,7 +182,7 @@ int gsr_set_render_ppl(int forward_ppl, int backward_ppl)
     return g_fwd_ppl * 10 + g_bwd_ppl;
 }
 
-int gsr_profile_enable(int enabled) { g_prof.enabled = enabled != 0; return 0; }
+int gsr_profile_enable(int kernel_mask) { g_prof.mask = (unsigned)kernel_mask; return K_COUNT; }
 void gsr_profile_reset(void)
 {
     g_prof.drain();
@@ -238,7 +241,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
     GSR_HIP_CHECK(hipMemsetAsync(geom.header, 0, 4 * sizeof(uint32_t), stream));
-    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * sizeof(uint32_t), stream));
+    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * CTR_STRIDE * sizeof(uint32_t), stream));
 
     const int nblocks = (P + 255) / 256;
     if (P > 0) {
@@ -410,6 +413,48 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
             for (uint32_t k = rg[2 * t]; k < rg[2 * t + 1]; k++) point_list[o++] = srt[k].x;
     }
 #undef D2H
+    return 0;
+}
+
+
+// ---- simple_knn.h ---------------------------------------------------------------------------------------------------
+struct KnnWorkspace {
+    KnnGrid* grid; uint32_t* cell_of; uint32_t* cell_count; uint32_t* cell_start; uint32_t* cursor; float4* sorted_pts;
+    static KnnWorkspace from(char*& p, size_t P, size_t C)
+    {
+        KnnWorkspace w;
+        carve(p, w.grid, 1); carve(p, w.cell_of, P); carve(p, w.cell_count, C); carve(p, w.cell_start, C + 1); carve(p, w.cursor, C);
+        carve(p, w.sorted_pts, P);
+        return w;
+    }
+};
+static inline size_t knn_max_cells(int P) { return (size_t)(P < 64 ? 64 : P); }
+
+size_t gsr_knn_workspace_size(int P)
+{
+    return required([&](char*& p) { KnnWorkspace::from(p, (size_t)(P > 0 ? P : 1), knn_max_cells(P)); });
+}
+
+int gsr_knn_mean_dist2(int P, const float* points, float* mean_dists, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || (P > 0 && (!points || !mean_dists || !workspace))) { g_last_error = "gsr_knn_mean_dist2: null argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P == 0) return 0;
+    const size_t C = knn_max_cells(P);
+    char* wp = workspace;
+    KnnWorkspace w = KnnWorkspace::from(wp, (size_t)P, C);
+    ScopedKernelTimer tm(K_KNN, stream);
+    GSR_HIP_CHECK(hipMemsetAsync(w.grid, 0xFF, 3 * sizeof(uint32_t), stream));                       // bbox min = ~0
+    GSR_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(w.grid) + 12, 0x00, 3 * sizeof(uint32_t), stream));   // bbox max = 0
+    GSR_HIP_CHECK(hipMemsetAsync(w.cell_count, 0, C * sizeof(uint32_t), stream));
+    const int nb = (P + 255) / 256;
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, stream, P, points, w.grid);
+    hipLaunchKernelGGL(knn_setup_kernel, dim3(1), dim3(1), 0, stream, P, (int)C, w.grid);
+    hipLaunchKernelGGL(knn_count_kernel, dim3(nb), dim3(256), 0, stream, P, points, w.grid, w.cell_of, w.cell_count);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, w.grid, w.cell_count, w.cell_start, w.cursor);
+    hipLaunchKernelGGL(knn_scatter_kernel, dim3(nb), dim3(256), 0, stream, P, points, w.cell_of, w.cursor, w.sorted_pts);
+    hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, stream, P, w.grid, w.cell_start, w.sorted_pts, mean_dists);
+    GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

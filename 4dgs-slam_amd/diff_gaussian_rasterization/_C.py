@@ -238,8 +238,21 @@ def debug_read_state(P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
     return out
 
 
-def profile_enable(on: bool):
-    load_library().gsr_profile_enable(int(on))
+KERNEL_IDS = {"preprocess_fwd": 0, "scan": 1, "scatter_instances": 2, "sort_tiles": 3, "render_fwd": 4, "render_bwd": 5,
+              "geometry_bwd": 6}
+
+
+def profile_enable(kernels=True):
+    """Time kernels with HIP events on the launch stream. True = all, False/None = off, or an iterable of names."""
+    if kernels is True:
+        mask = -1
+    elif not kernels:
+        mask = 0
+    else:
+        mask = 0
+        for k in kernels:
+            mask |= 1 << KERNEL_IDS[k]
+    load_library().gsr_profile_enable(int(mask))
 
 
 def profile_reset():

@@ -105,10 +105,11 @@ int gsr_debug_read_state(int P, int R, int width, int height,
 const char* gsr_last_error(void);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
- * gsr_profile_enable(1) starts collecting; gsr_profile_read copies up to `cap` entries
+ * gsr_profile_enable(mask) times the kernels whose bit is set in `mask` (bit i = i-th entry of gsr_profile_read;
+ * 0 disables, -1 enables all) and returns the number of kernels; gsr_profile_read copies up to `cap` entries
  * (name pointers are static strings; ms = summed duration; calls = launches) and returns the count;
  * it synchronises the recorded events. gsr_profile_reset() clears the accumulators. */
-int gsr_profile_enable(int enabled);
+int gsr_profile_enable(int kernel_mask);
 int gsr_profile_read(const char** names, float* total_ms, int* calls, int cap);
 void gsr_profile_reset(void);
 
