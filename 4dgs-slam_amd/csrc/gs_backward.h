@@ -2,153 +2,9 @@
 // gfx950 / wave64. DGR = submodules/diff-gaussian-rasterization.
 #pragma once
 #include "gs_forward.h"
+#include "gs_render.h"
 
 namespace gsr {
-
-// ------------------------------------------------------------------------------------------------------------------
-// B1: render backward (DGR/cuda_rasterizer/backward.cu:563-787), restructured for CDNA4:
-//  * one block per 16x16 tile, each lane owns PPL adjacent pixels (256/PPL threads, 4/PPL waves);
-//  * the tile's list is staged back-to-front through LDS in batches;
-//  * the per-(tile, Gaussian) sums over the tile's pixels are formed in registers: PPL pixels per lane, then a DPP
-//    wave reduction (6 v_add_f32 with DPP modifiers per value) -- no 256-thread shared-memory tree, no barriers per
-//    Gaussian (the reference spends 8 block barriers x 5 arrays per listed Gaussian, backward.cu:541-559,759-765);
-//  * instead of 10 float atomics per (tile, Gaussian) (backward.cu:774-783) each wave stores its 10 sums into the
-//    instance's private slot partials[(u * NW + wave) * 3 .. +2] (48 B); B2 sums an instance range per Gaussian in a fixed
-//    order. Results are therefore bit-reproducible, and no gradient buffer needs zero-filling.
-// Slot layout (3 x float4): {dmean2D.x, dmean2D.y, dconic.x, dconic.y} {dconic.w, dopacity, dcolor.r, dcolor.g}
-//                           {dcolor.b, ddepth, 0, 0}
-// ------------------------------------------------------------------------------------------------------------------
-template <int PPL>
-__global__ void __launch_bounds__(256 / PPL) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                               const uint2* __restrict__ sorted, int W, int H,
-                                                               const float* __restrict__ bg, const float2* __restrict__ means2D,
-                                                               const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
-                                                               const float* __restrict__ depths, const float* __restrict__ final_T,
-                                                               const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                               const float* __restrict__ dL_dpix_depth, float4* __restrict__ partials)
-{
-    constexpr int NT = 256 / PPL;
-    constexpr int NW = NT / 64;
-    constexpr int TPR = 16 / PPL;
-    __shared__ float4 s_a[NT];   // {mean.x, mean.y, conic.x, conic.y}
-    __shared__ float4 s_b[NT];   // {conic.z, opacity, depth, instance id bits}
-    __shared__ float4 s_c[NT];   // {r, g, b, -}
-
-    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
-    const int tx = tile % gx, ty = tile / gx;
-    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
-    const int py = ty * TILE_Y + t / TPR;
-    const int px0 = tx * TILE_X + (t % TPR) * PPL;
-    const float pyf = (float)py;
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    if (n == 0) return;
-
-    float pxf[PPL], T[PPL], Tfin[PPL], acc_r[PPL], acc_g[PPL], acc_b[PPL], acc_d[PPL];
-    float last_a[PPL], last_r[PPL], last_g[PPL], last_b[PPL], last_d[PPL];
-    float gr[PPL], gg[PPL], gb[PPL], gd[PPL], bgdot[PPL];
-    int last_contrib[PPL];
-#pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        const bool inside = (px0 + p) < W && py < H;
-        const size_t pix = (size_t)py * W + (px0 + p);
-        pxf[p] = (float)(px0 + p);
-        Tfin[p] = inside ? final_T[pix] : 0.f;                            // backward.cu:617-623
-        T[p] = Tfin[p];
-        last_contrib[p] = inside ? (int)n_contrib[pix] : 0;
-        gr[p] = inside ? dL_dpix[pix] : 0.f;                              // :629-635
-        gg[p] = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
-        gb[p] = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
-        gd[p] = inside ? dL_dpix_depth[pix] : 0.f;
-        bgdot[p] = bg[0] * gr[p] + bg[1] * gg[p] + bg[2] * gb[p];         // :738-742 (loop invariant)
-        acc_r[p] = acc_g[p] = acc_b[p] = acc_d[p] = 0.f;
-        last_a[p] = last_r[p] = last_g[p] = last_b[p] = last_d[p] = 0.f;
-    }
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                 // :643-644
-
-    for (int base = 0; base < n; base += NT) {
-        __syncthreads();
-        if (base + t < n) {
-            const uint2 e = sorted[range.y - 1 - (uint32_t)(base + t)];   // back to front, :656
-            const float2 xy = means2D[e.x];
-            const float4 co = conic_opacity[e.x];
-            s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_b[t] = make_float4(co.z, co.w, depths[e.x], __uint_as_float(e.y));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
-        }
-        __syncthreads();
-        const int m = min(NT, n - base);
-        for (int j = 0; j < m; j++) {
-            const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
-            const int pos = n - 1 - (base + j);   // 0-based list position == the reference's `contributor` after its decrement (:677)
-            const float dy = A4.y - pyf;
-            float s_m2x = 0.f, s_m2y = 0.f, s_cx = 0.f, s_cy = 0.f, s_cw = 0.f, s_op = 0.f, s_r = 0.f, s_g = 0.f, s_b_ = 0.f, s_d = 0.f;
-            bool any_valid = false;
-#pragma unroll
-            for (int p = 0; p < PPL; p++) {
-                const float dx = A4.x - pxf[p];
-                const float power = -0.5f * (A4.z * dx * dx + B4.x * dy * dy) - A4.w * dx * dy;  // :684
-                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
-                const float alpha = fminf(0.99f, B4.y * G);                                       // :688 (no gradient mask for the clamp, Q23)
-                const bool valid = pos < last_contrib[p] && power <= 0.0f && alpha >= 1.0f / 255.0f;  // :678,:685,:689
-                any_valid = any_valid || valid;
-                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = valid ? T[p] * inv1ma : T[p];                                    // :700
-                T[p] = Tn;
-                const float dch = alpha * Tn;                                                      // :701
-                // :714-728 running "colour behind this Gaussian"
-                acc_r[p] = valid ? last_a[p] * last_r[p] + (1.f - last_a[p]) * acc_r[p] : acc_r[p];
-                acc_g[p] = valid ? last_a[p] * last_g[p] + (1.f - last_a[p]) * acc_g[p] : acc_g[p];
-                acc_b[p] = valid ? last_a[p] * last_b[p] + (1.f - last_a[p]) * acc_b[p] : acc_b[p];
-                acc_d[p] = valid ? last_a[p] * last_d[p] + (1.f - last_a[p]) * acc_d[p] : acc_d[p];
-                last_r[p] = valid ? C4.x : last_r[p];
-                last_g[p] = valid ? C4.y : last_g[p];
-                last_b[p] = valid ? C4.z : last_b[p];
-                last_d[p] = valid ? B4.z : last_d[p];
-                float dL_dalpha = (C4.x - acc_r[p]) * gr[p] + (C4.y - acc_g[p]) * gg[p] + (C4.z - acc_b[p]) * gb[p] +
-                                  (B4.z - acc_d[p]) * gd[p];
-                dL_dalpha *= Tn;                                                                   // :732
-                last_a[p] = valid ? alpha : last_a[p];
-                dL_dalpha += (-Tfin[p] * inv1ma) * bgdot[p];                                       // :743
-                const float dL_dG = valid ? B4.y * dL_dalpha : 0.f;                               // :746
-                const float Gv = valid ? G : 0.f;   // G may be +inf where power > 0; keep it out of the masked products
-                const float gdx = Gv * dx, gdy = Gv * dy;
-                const float dG_ddelx = -gdx * A4.z - gdy * A4.w;
-                const float dG_ddely = -gdy * B4.x - gdx * A4.w;
-                const float wv = valid ? dch : 0.f;
-                s_r += wv * gr[p]; s_g += wv * gg[p]; s_b_ += wv * gb[p]; s_d += wv * gd[p];      // :719,:729
-                s_m2x += dL_dG * dG_ddelx;                                                         // :752-757
-                s_m2y += dL_dG * dG_ddely;
-                s_cx += gdx * dx * dL_dG;
-                s_cy += gdx * dy * dL_dG;
-                s_cw += gdy * dy * dL_dG;
-                s_op += Gv * dL_dalpha;
-            }
-            float4* slot = partials + ((size_t)__float_as_uint(B4.w) * NW + wave) * 3;
-            if (__any(any_valid)) {
-                s_m2x = wave_sum_to_row3(s_m2x) * ddelx_dx;
-                s_m2y = wave_sum_to_row3(s_m2y) * ddely_dy;
-                s_cx = wave_sum_to_row3(s_cx) * -0.5f;
-                s_cy = wave_sum_to_row3(s_cy) * -0.5f;
-                s_cw = wave_sum_to_row3(s_cw) * -0.5f;
-                s_op = wave_sum_to_row3(s_op);
-                s_r = wave_sum_to_row3(s_r);
-                s_g = wave_sum_to_row3(s_g);
-                s_b_ = wave_sum_to_row3(s_b_);
-                s_d = wave_sum_to_row3(s_d);
-                if (lane == 63) {
-                    slot[0] = make_float4(s_m2x, s_m2y, s_cx, s_cy);
-                    slot[1] = make_float4(s_cw, s_op, s_r, s_g);
-                    slot[2] = make_float4(s_b_, s_d, 0.f, 0.f);
-                }
-            } else if (lane == 63) {   // nothing in this wave touched the Gaussian (the reference's skip_counter shortcut, :691-697)
-                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                slot[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // B2: per-Gaussian backward. Sums the Gaussian's instance slots (fixed order => deterministic), then runs the
@@ -157,11 +13,11 @@ __global__ void __launch_bounds__(256 / PPL) render_bwd_kernel(int ntiles, int g
 // Writes EVERY output element (zeros for culled Gaussians), so outputs need no pre-zeroing.
 // ------------------------------------------------------------------------------------------------------------------
 struct GeomBwdArgs {
-    int P, D, M, W, H, NW;
+    int P, D, M, W, H;
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped; const float* scales; const float* rotations;
     float scale_modifier; const float* cov3Ds; const float* viewmatrix; const float* projmatrix; const float* projmatrix_raw;
     const float* campos; float focal_x, focal_y, tan_fovx, tan_fovy;
-    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials;
+    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials; const uint8_t* inst_mask;
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
 };
@@ -175,13 +31,21 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
     if (visible) {
-        const uint32_t cnt = a.tiles_touched[idx] * (uint32_t)a.NW;
-        const float4* sl = a.partials + (size_t)(a.point_offsets[idx] - a.tiles_touched[idx]) * a.NW * 3;
+        // instance ids of this Gaussian are contiguous: [point_offsets - tiles_touched, point_offsets)
+        const uint32_t cnt = a.tiles_touched[idx];
+        const uint32_t u0 = a.point_offsets[idx] - cnt;
         for (uint32_t k = 0; k < cnt; k++) {
-            const float4 v0 = sl[3 * k], v1 = sl[3 * k + 1], v2 = sl[3 * k + 2];
-            g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
-            g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
-            g_b += v2.x; g_d += v2.y;
+            const uint32_t bits = a.inst_mask[u0 + k];          // which quadrant slots the tile's block produced
+            const float4* sl = a.partials + (size_t)(u0 + k) * 12;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if ((bits >> q) & 1u) {
+                    const float4 v0 = sl[3 * q], v1 = sl[3 * q + 1], v2 = sl[3 * q + 2];
+                    g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
+                    g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
+                    g_b += v2.x; g_d += v2.y;
+                }
+            }
         }
     }
     a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14

@@ -69,13 +69,13 @@ struct ImageState {
     }
 };
 struct BinningState {
-    uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted;
+    uint32_t* inst_gauss; uint8_t* inst_mask; float4* partials; uint64_t* keys; uint2* sorted;
     // Every base offset depends on R only, so backward re-carves without knowing R_alloc. `keys` (forward-only sort
-    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only gradient slots (R * nw * 48 B): 16R <= 48R.
-    static BinningState from(char*& p, size_t R, size_t R_alloc, int nw)
+    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only gradient slots (R x 4 quadrants x 48 B).
+    static BinningState from(char*& p, size_t R, size_t R_alloc)
     {
         BinningState b;
-        carve(p, b.inst_gauss, R); carve(p, b.partials, R * 3 * (size_t)nw);
+        carve(p, b.inst_gauss, R); carve(p, b.inst_mask, R); carve(p, b.partials, R * 12);
         b.keys = reinterpret_cast<uint64_t*>(b.partials);
         carve(p, b.sorted, R_alloc);
         return b;
@@ -141,22 +141,6 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 
 static thread_local uint32_t* t_pinned = nullptr;
 
-template <int PPL>
-static void launch_render_fwd(int T, int gx, const ImageState& img, const BinningState& bin, int W, int H, const GeomState& geom,
-                              const float* feat, const float* bg, float* out_color, float* out_depth, float* out_opacity,
-                              int* n_touched, hipStream_t s)
-{
-    hipLaunchKernelGGL(render_fwd_kernel<PPL>, dim3(T), dim3(256 / PPL), 0, s, T, gx, img.ranges, bin.sorted, W, H, geom.means2D, feat,
-                       geom.conic_opacity, geom.depths, bg, img.final_T, img.n_contrib, out_color, out_depth, out_opacity, n_touched);
-}
-template <int PPL>
-static void launch_render_bwd(int T, int gx, const ImageState& img, const BinningState& bin, int W, int H, const GeomState& geom,
-                              const float* feat, const float* bg, const float* dL_dpix, const float* dL_dpix_depth, hipStream_t s)
-{
-    hipLaunchKernelGGL(render_bwd_kernel<PPL>, dim3(T), dim3(256 / PPL), 0, s, T, gx, img.ranges, bin.sorted, W, H, bg, geom.means2D,
-                       geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth, bin.partials);
-}
-
 }  // namespace gsr
 
 using namespace gsr;
@@ -172,7 +156,7 @@ size_t gsr_image_buffer_size(int width, int height)
     const size_t T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
     return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T); });
 }
-size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc, 4 / g_bwd_ppl); }); }
+size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc); }); }
 
 int gsr_set_render_ppl(int forward_ppl, int backward_ppl)
 {
@@ -277,11 +261,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     if (err) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
     if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
 
-    const int nw_bwd = 4 / g_bwd_ppl;   // gradient-slot count per instance; gsr_backward must run with the same setting
-    const size_t bsize = required([&](char*& p) { BinningState::from(p, (size_t)R, (size_t)R_alloc, nw_bwd); });
+    const size_t bsize = required([&](char*& p) { BinningState::from(p, (size_t)R, (size_t)R_alloc); });
     char* bchunk = binning_alloc(binning_user, bsize);
     if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
-    BinningState bin = BinningState::from(bchunk, (size_t)R, (size_t)R_alloc, nw_bwd);
+    BinningState bin = BinningState::from(bchunk, (size_t)R, (size_t)R_alloc);
 
     if (R > 0) {
         if (R_alloc != R) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, (size_t)R_alloc * sizeof(uint64_t), stream));   // sort padding
@@ -305,11 +288,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
     {
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
-        switch (g_fwd_ppl) {
-            case 1: launch_render_fwd<1>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
-            case 2: launch_render_fwd<2>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
-            default: launch_render_fwd<4>(T, gx, img, bin, width, height, geom, feat, background, out_color, out_depth, out_opacity, n_touched, stream); break;
-        }
+        hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D, feat,
+                           geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth, out_opacity,
+                           n_touched);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -334,27 +315,24 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
     char* gp = geom_buffer; char* bp = binning_buffer; char* ip = image_buffer;
     GeomState geom = GeomState::from(gp, (size_t)P);
-    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R, 4 / g_bwd_ppl);   // offsets depend on R only
+    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);   // offsets depend on R only
     ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T);
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
-    const int ppl = g_bwd_ppl;
     if (R > 0) {
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
-        switch (ppl) {
-            case 1: launch_render_bwd<1>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
-            case 2: launch_render_bwd<2>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
-            default: launch_render_bwd<4>(T, gx, img, bin, width, height, geom, feat, background, dL_dpix, dL_dpix_depth, stream); break;
-        }
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, background,
+                           geom.means2D, geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth,
+                           bin.partials, bin.inst_mask);
     }
     GSR_STAGE("render_bwd");
     GeomBwdArgs a;
-    a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.NW = 4 / ppl;
+    a.P = P; a.D = D; a.M = M; a.W = width; a.H = height;
     a.means3D = means3D; a.radii = radii; a.shs = shs; a.clamped = geom.clamped; a.scales = scales; a.rotations = rotations;
     a.scale_modifier = scale_modifier; a.cov3Ds = cov3D_precomp ? cov3D_precomp : geom.cov3D;   // rasterizer_impl.cu:429
     a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.projmatrix_raw = projmatrix_raw; a.campos = campos;
     a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials;
+    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials; a.inst_mask = bin.inst_mask;
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     {
@@ -376,7 +354,7 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     const size_t N = (size_t)width * height;
     char* gp = const_cast<char*>(geom_buffer); char* bp = const_cast<char*>(binning_buffer); char* ip = const_cast<char*>(image_buffer);
     GeomState geom = GeomState::from(gp, (size_t)P);
-    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R, 4 / g_bwd_ppl);
+    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);
     ImageState img = ImageState::from(ip, N, (size_t)T);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
     D2H(depths, geom.depths, P * sizeof(float));

@@ -21,23 +21,38 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// ---- DPP cross-lane adds (one v_add_f32 with a DPP source modifier each) --------------------------------------
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
-__device__ __forceinline__ float dpp_f(float v)
+// ---- wave reduction of ten values with DPP adds ------------------------------------------------------------------
+// One v_add_f32 with a DPP source modifier per value and butterfly stage (6 stages), written as inline asm: through
+// the update_dpp builtin hipcc emits v_mov_b32 (old = 0) + v_mov_b32_dpp + half a v_pk_add_f32 per step (its SLP
+// vectoriser packs the adds, and VOP3P cannot take a DPP operand), 2.5x the instructions.
+// The ten chains are interleaved stage by stage, so every DPP read is ten instructions behind the write of its
+// source (the gfx9 "VALU write -> DPP read" hazard needs two wait states; hipcc does not pad inside asm, and the
+// leading s_nop covers values produced right before the statement). Totals are valid in lanes 48..63 (row 3).
+#define GSR_DPP_STAGE(ctrl)                                   \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"                   \
+    "v_add_f32_dpp %9, %9, %9 " ctrl "\n\t"
+__device__ __forceinline__ void wave_sum10_to_row3(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
+                                                   float& v7, float& v8, float& v9)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+    asm volatile("s_nop 1\n\t"
+                 GSR_DPP_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_STAGE("row_mirror row_mask:0xf bank_mask:0xf")
+                 GSR_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 GSR_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
 }
-// Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (row 3), callers read lane 63.
-__device__ __forceinline__ float wave_sum_to_row3(float v)
-{
-    v += dpp_f<0xB1>(v);            // quad_perm [1,0,3,2]  (xor 1)
-    v += dpp_f<0x4E>(v);            // quad_perm [2,3,0,1]  (xor 2)
-    v += dpp_f<0x141>(v);           // row_half_mirror      (8-lane sums)
-    v += dpp_f<0x140>(v);           // row_mirror           (16-lane row sums in every lane)
-    v += dpp_f<0x142, 0xA>(v);      // row_bcast:15 -> rows 1,3
-    v += dpp_f<0x143, 0xC>(v);      // row_bcast:31 -> rows 2,3
-    return v;
-}
+#undef GSR_DPP_STAGE
 
 // Inclusive prefix sum across the wave (6 shuffle steps); used for instance expansion.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)

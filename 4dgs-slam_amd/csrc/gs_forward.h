@@ -344,117 +344,6 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// F5: tile compositing (DGR/cuda_rasterizer/forward.cu:263-392). One block per 16x16 tile; each lane owns PPL
-// horizontally adjacent pixels, so a block has 256/PPL threads = 4/PPL wavefronts. The tile's sorted list is staged
-// through LDS in batches of NT entries (gathered by Gaussian id); every lane then walks the batch reading the
-// wave-uniform entry as LDS broadcasts. Early-out: a wave leaves a batch as soon as all its pixels are saturated,
-// the block leaves the list when every wave has (forward.cu:318-320 checks once per 256-entry round).
-// ------------------------------------------------------------------------------------------------------------------
-template <int PPL>
-__global__ void __launch_bounds__(256 / PPL) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                               const uint2* __restrict__ sorted, int W, int H,
-                                                               const float2* __restrict__ means2D, const float* __restrict__ feat,
-                                                               const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
-                                                               const float* __restrict__ bg, float* __restrict__ final_T,
-                                                               uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                                                               float* __restrict__ out_depth, float* __restrict__ out_opacity,
-                                                               int* __restrict__ n_touched)
-{
-    constexpr int NT = 256 / PPL;   // threads per block == entries per staged batch
-    constexpr int TPR = 16 / PPL;   // threads per pixel row
-    __shared__ float4 s_a[NT];      // {mean.x, mean.y, A, B}     with power = dx*(A*dx + B*dy) + C*dy*dy
-    __shared__ float4 s_b[NT];      // {C, opacity, depth, gaussian id bits}
-    __shared__ float4 s_c[NT];      // {r, g, b, -}
-
-    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
-    const int tx = tile % gx, ty = tile / gx;
-    const int t = threadIdx.x, lane = lane_id();
-    const int py = ty * TILE_Y + t / TPR;
-    const int px0 = tx * TILE_X + (t % TPR) * PPL;
-    const float pyf = (float)py;
-    float pxf[PPL], T[PPL], Cr[PPL], Cg[PPL], Cb[PPL], Dd[PPL];
-    uint32_t last[PPL];
-    bool done[PPL], inside[PPL];
-#pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        pxf[p] = (float)(px0 + p);
-        inside[p] = (px0 + p) < W && py < H;
-        done[p] = !inside[p];
-        T[p] = 1.0f; Cr[p] = Cg[p] = Cb[p] = Dd[p] = 0.f; last[p] = 0;
-    }
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-
-    for (int base = 0; base < n; base += NT) {
-        bool all_done = true;
-#pragma unroll
-        for (int p = 0; p < PPL; p++) all_done = all_done && done[p];
-        if (__syncthreads_and(all_done)) break;
-        if (base + t < n) {
-            const uint2 e = sorted[range.x + base + t];
-            const float2 xy = means2D[e.x];
-            const float4 co = conic_opacity[e.x];
-            s_a[t] = make_float4(xy.x, xy.y, -0.5f * co.x, -co.y);
-            s_b[t] = make_float4(-0.5f * co.z, co.w, depths[e.x], __uint_as_float(e.x));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
-        }
-        __syncthreads();
-        const int m = min(NT, n - base);
-        for (int j = 0; j < m; j++) {
-            const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
-            const uint32_t contributor = (uint32_t)(base + j + 1);
-            const float dy = A4.y - pyf;
-            const float cdy2 = B4.x * dy * dy, bdy = A4.w * dy;
-            int touched = 0;
-            bool wave_done = true;
-#pragma unroll
-            for (int p = 0; p < PPL; p++) {
-                const float dx = A4.x - pxf[p];
-                const float power = dx * (A4.z * dx + bdy) + cdy2;           // forward.cu:345
-                const float alpha = fminf(0.99f, B4.y * __builtin_amdgcn_exp2f(power * LOG2E));  // :353
-                const bool valid = !done[p] && power <= 0.0f && alpha >= 1.0f / 255.0f;         // :346,:354
-                const float test_T = T[p] * (1.0f - alpha);
-                const bool stop = valid && test_T < 0.0001f;                   // :358-362
-                const bool blend = valid && !stop;
-                done[p] = done[p] || stop;
-                const float w = blend ? alpha * T[p] : 0.0f;
-                Cr[p] += C4.x * w; Cg[p] += C4.y * w; Cb[p] += C4.z * w; Dd[p] += B4.z * w;  // :364-367
-                touched += (blend && test_T > 0.5f) ? 1 : 0;                   // :369-371
-                T[p] = blend ? test_T : T[p];
-                last[p] = blend ? contributor : last[p];
-                wave_done = wave_done && done[p];
-            }
-            // one atomic per (wave, Gaussian) instead of one per pixel
-            const unsigned long long any_t = __ballot(touched != 0);
-            if (any_t) {
-                int cnt = touched;
-                if (PPL > 1) {
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-                } else {
-                    cnt = __popcll(any_t);
-                }
-                if (lane == 0) atomicAdd(&n_touched[__float_as_uint(B4.w)], cnt);
-            }
-            if (__all(wave_done)) break;
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < PPL; p++) {
-        if (inside[p]) {
-            const size_t pix = (size_t)py * W + (px0 + p);
-            final_T[pix] = T[p];
-            n_contrib[pix] = last[p];
-            out_color[pix] = Cr[p] + T[p] * bg[0];                             // forward.cu:384-390
-            out_color[(size_t)H * W + pix] = Cg[p] + T[p] * bg[1];
-            out_color[2 * (size_t)H * W + pix] = Cb[p] + T[p] * bg[2];
-            out_depth[pix] = Dd[p];
-            out_opacity[pix] = 1.0f - T[p];
-        }
-    }
-}
-
 // rasterizer_impl.cu:54-66
 __global__ void mark_visible_kernel(int P, const float* means3D, const float* viewmatrix, uint8_t* present)
 {

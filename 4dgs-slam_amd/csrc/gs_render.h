@@ -1,0 +1,273 @@
+// gs_render.h -- the two per-tile kernels: front-to-back compositing (forward) and the back-to-front gradient pass.
+// gfx950 / wave64. DGR = submodules/diff-gaussian-rasterization.
+//
+// Work decomposition (both kernels): one 256-thread block per 16x16 tile (the reference's binning granularity, which
+// is part of the result), four wavefronts, wave w owning the 8x8-pixel quadrant (w&1, w>>1), one pixel per lane.
+// The tile's depth-sorted list is staged through LDS in batches of 256 entries (gathered by Gaussian id). While
+// staging, each thread tests its entry against the four quadrants -- the region where alpha = o*exp(power) can reach
+// 1/255 is an ellipse whose bounding box is known in closed form -- and four 64-bit wave ballots per staging wave
+// give every quadrant a bit mask of the entries that can touch it at all. Each wave then walks ONLY the set bits of
+// its masks (scalar s_ff1 loop), so a (wave, Gaussian) pair that cannot contribute costs nothing: no exp, no
+// reduction. The cull is conservative (a superset of the pairs the reference blends), so results are unchanged.
+#pragma once
+#include "gs_forward.h"
+
+namespace gsr {
+
+constexpr int RB = 256;   // entries per staged batch == threads per block
+
+// Bounding box test of {p : o*exp(power(p)) >= 1/255} against the four 8x8 quadrants of tile (tx,ty).
+// power(d) = -1/2 d^T Q d with Q = [[a,b],[b,c]] (the conic); the level set power >= -tau is an ellipse with
+// half-extents sqrt(2 tau c/det), sqrt(2 tau a/det), det = ac - b^2. Returns a 4-bit mask (bit q = quadrant q).
+__device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, float b, float c, float o, int tx, int ty)
+{
+    const float tau = __logf(255.0f * o);           // alpha >= 1/255  <=>  power >= -tau
+    if (!(tau >= 0.f)) return 0u;                   // o < 1/255 (or NaN): can never be blended
+    const float det = a * c - b * b;
+    float ex, ey;
+    if (det > 0.f && a > 0.f && c > 0.f) {
+        const float k = 2.0f * (tau * 1.0002f + 1e-4f) / det;   // slack: the cull must stay a superset under fp rounding
+        ex = sqrtf(k * c) * 1.0001f + 0.01f;
+        ey = sqrtf(k * a) * 1.0001f + 0.01f;
+    } else {
+        ex = ey = 1e30f;                            // degenerate conic: never cull
+    }
+    const float X0 = (float)(tx * TILE_X), Y0 = (float)(ty * TILE_Y);
+    const bool xl = gx - ex <= X0 + 7.f && gx + ex >= X0;           // overlaps columns 0..7
+    const bool xr = gx - ex <= X0 + 15.f && gx + ex >= X0 + 8.f;    // columns 8..15
+    const bool yt = gy - ey <= Y0 + 7.f && gy + ey >= Y0;
+    const bool yb = gy - ey <= Y0 + 15.f && gy + ey >= Y0 + 8.f;
+    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+__device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned long long* p)
+{
+    const unsigned long long m = *p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)m), hi = __builtin_amdgcn_readfirstlane((uint32_t)(m >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint2* __restrict__ sorted, int W, int H,
+                                                        const float2* __restrict__ means2D, const float* __restrict__ feat,
+                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
+                                                        const float* __restrict__ bg, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_opacity,
+                                                        int* __restrict__ n_touched)
+{
+    __shared__ float4 s_a[RB];      // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
+    __shared__ float4 s_b[RB];      // {C, opacity, depth, gaussian id bits}
+    __shared__ float4 s_c[RB];      // {r, g, b, -}
+    __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
+
+    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const int px = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const bool inside = px < W && py < H;
+    bool done = !inside;
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
+    uint32_t last = 0;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    for (int base = 0; base < n; base += RB) {
+        if (__syncthreads_and(done)) break;                       // forward.cu:318-320
+        uint32_t qm = 0;
+        if (base + t < n) {
+            const uint2 e = sorted[range.x + base + t];
+            const float2 xy = means2D[e.x];
+            const float4 co = conic_opacity[e.x];
+            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
+            s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, depths[e.x], __uint_as_float(e.x));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long m = __ballot((qm >> q) & 1u);
+            if (lane == 0) s_mask[q][wave] = m;
+        }
+        __syncthreads();
+        bool wave_done = __all(done);
+        for (int sw = 0; sw < 4 && !wave_done; sw++) {
+            unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
+            while (m) {
+                const int j = sw * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
+                const float dx = A4.x - pxf, dy = A4.y - pyf;
+                const float power2 = dx * (A4.z * dx + A4.w * dy) + B4.x * dy * dy;               // forward.cu:345 (times log2 e)
+                const float alpha = fminf(0.99f, B4.y * __builtin_amdgcn_exp2f(power2));           // :353
+                const bool valid = !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;              // :346,:354
+                const float test_T = T * (1.0f - alpha);
+                const bool stop = valid && test_T < 0.0001f;                                        // :358-362
+                const bool blend = valid && !stop;
+                done = done || stop;
+                const float w = blend ? alpha * T : 0.0f;
+                Cr += C4.x * w; Cg += C4.y * w; Cb += C4.z * w; Dd += B4.z * w;                    // :364-367
+                T = blend ? test_T : T;
+                last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
+                const unsigned long long tm = __ballot(blend && test_T > 0.5f);                    // :369-371, one atomic per wave
+                if (tm && lane == 0) atomicAdd(&n_touched[__float_as_uint(B4.w)], (int)__popcll(tm));
+                if (__all(done)) { wave_done = true; break; }
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_color[pix] = Cr + T * bg[0];                                                            // forward.cu:384-390
+        out_color[(size_t)H * W + pix] = Cg + T * bg[1];
+        out_color[2 * (size_t)H * W + pix] = Cb + T * bg[2];
+        out_depth[pix] = Dd;
+        out_opacity[pix] = 1.0f - T;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// B1: render backward, DGR/cuda_rasterizer/backward.cu:563-787, restructured:
+//  * per-(quadrant, Gaussian) sums over the quadrant's 64 pixels are formed with a DPP wave reduction (6 v_add_f32
+//    with DPP modifiers per value); the reference runs a 256-thread shared-memory tree with 8 block barriers x 5
+//    arrays for every listed Gaussian (backward.cu:541-559,759-765);
+//  * instead of 10 float atomics per (tile, Gaussian) (backward.cu:774-783) each wave stores its sums into the private
+//    slot partials[(u*4 + wave)*3 .. +2] (u = instance id) and records in inst_mask[u] which of the four slots exist;
+//    B2 sums a Gaussian's slots in a fixed order: bit-reproducible gradients, nothing to zero-fill;
+//  * besides the quadrant cull, entries behind the deepest contributor of the quadrant (max n_contrib) are dropped
+//    at staging time, so saturated regions skip their occluded tail entirely.
+// Slot layout (3 x float4): {dmean2D.x, dmean2D.y, dconic.x, dconic.y} {dconic.w, dopacity, dcolor.r, dcolor.g}
+//                           {dcolor.b, ddepth, 0, 0}
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint2* __restrict__ sorted, int W, int H,
+                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
+                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
+                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                        const float* __restrict__ dL_dpix_depth, float4* __restrict__ partials,
+                                                        uint8_t* __restrict__ inst_mask)
+{
+    __shared__ float4 s_a[RB];   // {mean.x, mean.y, conic.x, conic.y}
+    __shared__ float4 s_b[RB];   // {conic.z, opacity, depth, instance id bits}
+    __shared__ float4 s_c[RB];   // {r, g, b, -}
+    __shared__ unsigned long long s_mask[4][4];
+    __shared__ int s_wmax[4];
+
+    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const int px = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n == 0) return;
+
+    const bool inside = px < W && py < H;
+    const size_t pix = (size_t)py * W + px;
+    const float Tfin = inside ? final_T[pix] : 0.f;                          // backward.cu:617-623
+    float T = Tfin;
+    const int last_contrib = inside ? (int)n_contrib[pix] : 0;
+    const float gr = inside ? dL_dpix[pix] : 0.f;                            // :629-635
+    const float gg = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
+    const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
+    const float gd = inside ? dL_dpix_depth[pix] : 0.f;
+    const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742 (loop invariant)
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
+    float last_a = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                    // :643-644
+
+    {   // deepest list position any pixel of this quadrant blended
+        int wm = last_contrib;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
+        if (lane == 0) s_wmax[wave] = wm;
+    }
+
+    for (int base = 0; base < n; base += RB) {
+        __syncthreads();
+        uint32_t qm = 0;
+        if (base + t < n) {
+            const int pos = n - 1 - (base + t);                               // 0-based list position, back to front (:656,:677)
+            const uint2 e = sorted[range.x + (uint32_t)pos];
+            const float2 xy = means2D[e.x];
+            const float4 co = conic_opacity[e.x];
+            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
+            inst_mask[e.y] = (uint8_t)qm;
+            s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_b[t] = make_float4(co.z, co.w, depths[e.x], __uint_as_float(e.y));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long m = __ballot((qm >> q) & 1u);
+            if (lane == 0) s_mask[q][wave] = m;
+        }
+        __syncthreads();
+        for (int sw = 0; sw < 4; sw++) {
+            unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
+            while (m) {
+                const int j = sw * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
+                const int pos = n - 1 - (base + j);
+                const float dx = A4.x - pxf, dy = A4.y - pyf;
+                const float power = -0.5f * (A4.z * dx * dx + B4.x * dy * dy) - A4.w * dx * dy;      // :684
+                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float alpha = fminf(0.99f, B4.y * G);                                           // :688 (clamp has no gradient mask, Q23)
+                const bool valid = pos < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;    // :678,:685,:689
+                float4* slot = partials + ((size_t)__float_as_uint(B4.w) * 4 + wave) * 3;
+                if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
+                    if (lane == 63) {
+                        slot[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        slot[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    continue;
+                }
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = valid ? T * inv1ma : T;                                                           // :700
+                const float wv = valid ? alpha * T : 0.f;                                             // :701 dchannel_dcolor
+                const float oma = 1.f - last_a;
+                acc_r = valid ? last_a * last_r + oma * acc_r : acc_r;                                // :714-728
+                acc_g = valid ? last_a * last_g + oma * acc_g : acc_g;
+                acc_b = valid ? last_a * last_b + oma * acc_b : acc_b;
+                acc_d = valid ? last_a * last_d + oma * acc_d : acc_d;
+                last_r = valid ? C4.x : last_r;
+                last_g = valid ? C4.y : last_g;
+                last_b = valid ? C4.z : last_b;
+                last_d = valid ? B4.z : last_d;
+                float dL_dalpha = (C4.x - acc_r) * gr + (C4.y - acc_g) * gg + (C4.z - acc_b) * gb + (B4.z - acc_d) * gd;
+                dL_dalpha *= T;                                                                        // :732
+                last_a = valid ? alpha : last_a;
+                dL_dalpha += (-Tfin * inv1ma) * bgdot;                                                 // :743
+                const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of masked products
+                const float dL_dG = valid ? B4.y * dL_dalpha : 0.f;                                   // :746
+                const float gdx = Gv * dx, gdy = Gv * dy;
+                const float tgx = gdx * dL_dG, tgy = gdy * dL_dG;
+                float s_m2x = dL_dG * (-gdx * A4.z - gdy * A4.w);                                     // :749-753
+                float s_m2y = dL_dG * (-gdy * B4.x - gdx * A4.w);
+                float s_cx = tgx * dx, s_cy = tgx * dy, s_cw = tgy * dy;                              // :754-756 (x -1/2 below)
+                float s_op = Gv * dL_dalpha;                                                           // :757
+                float s_r = wv * gr, s_g = wv * gg, s_b_ = wv * gb, s_d = wv * gd;                    // :719,:729
+                wave_sum10_to_row3(s_m2x, s_m2y, s_cx, s_cy, s_cw, s_op, s_r, s_g, s_b_, s_d);
+                if (lane == 63) {
+                    slot[0] = make_float4(s_m2x * ddelx_dx, s_m2y * ddely_dy, -0.5f * s_cx, -0.5f * s_cy);
+                    slot[1] = make_float4(-0.5f * s_cw, s_op, s_r, s_g);
+                    slot[2] = make_float4(s_b_, s_d, 0.f, 0.f);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace gsr
