@@ -1,0 +1,200 @@
+"""render() / render_flow() / get_dynamic_mask(): the Python wrapper between the SLAM code and the rasterizer -- a
+counterpart of the reference's ``gaussian_splatting/gaussian_renderer/__init__.py`` (render :41-226, render_flow
+:229-361, get_dynamic_mask :364-414) with the same signatures, the same dict keys and the same tensor semantics, so
+``utils/slam_frontend.py``, ``utils/slam_backend.py`` and ``utils/eval_utils.py`` can call it unchanged. It imports the
+MI355X rasterizer through the reference's own package name ``diff_gaussian_rasterization``.
+
+``pc`` is duck-typed (the reference's GaussianModel): get_xyz, get_opacity, get_scaling, get_rotation, get_features,
+active_sh_degree, max_sh_degree, dygs (bool[P] dynamic-Gaussian mask), and for the optional branches get_covariance(),
+_deformation(...), _scaling, _rotation, _opacity, scaling_activation, rotation_activation.
+``viewpoint_camera``: FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
+projection_matrix, camera_center, cam_rot_delta, cam_trans_delta, time.
+"""
+import math
+
+import torch
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+from .sh_eval import eval_sh
+
+
+# ---- quaternion helpers exported by the reference module (:24-38) ------------------------------------------------
+def standardize_quaternion(quaternions: torch.Tensor) -> torch.Tensor:
+    """Flip the sign so the real part is non-negative."""
+    return torch.where(quaternions[..., 0:1] < 0, -quaternions, quaternions)
+
+
+def quaternion_raw_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Hamilton product, real part first."""
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz,
+                        aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx,
+                        aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return standardize_quaternion(quaternion_raw_multiply(a, b))
+
+
+# ---- shared pieces ------------------------------------------------------------------------------------------------
+def _screenspace_points(pc):
+    """Zero [P,3] tensor whose .grad receives dL/d(NDC mean) -- read by add_densification_stats (reference :69-78)."""
+    pts = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
+    try:
+        pts.retain_grad()
+    except Exception:
+        pass
+    return pts
+
+
+def _settings(cam, bg, scaling_modifier, sh_degree):
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=bg, scale_modifier=scaling_modifier,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, projmatrix_raw=cam.projection_matrix,
+        sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+
+
+def _scatter_delta(like: torch.Tensor, index: torch.Tensor, delta) -> torch.Tensor:
+    """zeros_like(like) with `delta` written into the rows selected by the boolean mask `index` (reference :163-174)."""
+    full = torch.zeros_like(like)
+    full[index] = delta
+    return full
+
+
+def _python_colors(pc, cam):
+    """SH -> RGB on the Python side (pipe.convert_SHs_python, reference :134-143)."""
+    shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    dir_pp = pc.get_xyz - cam.camera_center.repeat(pc.get_features.shape[0], 1)
+    dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None,
+           dynamic=False, dx=None, ds=None, dr=None, do=None, dc=None, novel=0):
+    """Render the scene. Returns None for an empty model, else the dict
+    {render, viewspace_points, visibility_filter, radii, depth, opacity, n_touched} (reference :218-226)."""
+    if pc.get_xyz.shape[0] == 0:
+        return None
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree))
+
+    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+    time = torch.tensor(viewpoint_camera.time).to(means3D.device).repeat(means3D.shape[0], 1)
+
+    # covariance: Python-side precompute, or scales (+ isotropic expansion) / rotations for the kernel (:116-127)
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling.repeat(1, 3) if pc.get_scaling.shape[-1] == 1 else pc.get_scaling
+        rotations = pc.get_rotation
+
+    # colour: the reference never forwards override_color (its `colors_precomp is None` test is always true, :131-147)
+    shs = colors_precomp = None
+    if pipe.convert_SHs_python:
+        colors_precomp = _python_colors(pc, viewpoint_camera)
+    else:
+        shs = pc.get_features
+
+    if dynamic:  # 4DGaussians deformation field (:149-157)
+        raw_scaling = pc._scaling.repeat(1, 3) if pc.get_scaling.shape[-1] == 1 else pc._scaling
+        means3D, scales_final, rotations_final, _, _, _ = pc._deformation(means3D, raw_scaling, pc._rotation, pc._opacity, shs, time)
+        scales = pc.scaling_activation(scales_final)
+        rotations = pc.rotation_activation(rotations_final)
+
+    if dx is not None and ds is not None and dr is not None:  # control-node deltas on the dynamic subset (:159-174)
+        means3D = pc.get_xyz + _scatter_delta(means3D, pc.dygs, dx)
+        scales = scales + _scatter_delta(scales, pc.dygs, ds)
+        rotations = pc.get_rotation + _scatter_delta(rotations, pc.dygs, dr)   # not re-normalised
+
+    sel = (lambda t: t[mask]) if mask is not None else (lambda t: t)
+    opt = lambda t: None if t is None else sel(t)
+    kwargs = dict(
+        means3D=sel(means3D), means2D=sel(means2D),
+        shs=sel(shs) if mask is not None else shs,          # with a mask the reference indexes shs unconditionally (:183)
+        colors_precomp=opt(colors_precomp), opacities=sel(opacity),
+        scales=sel(scales) if mask is not None else scales,  # likewise scales / rotations (:186-187)
+        rotations=sel(rotations) if mask is not None else rotations,
+        cov3D_precomp=opt(cov3D_precomp),
+        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
+    rendered_image, radii, depth, opacity, n_touched = rasterizer(**kwargs)
+    return {
+        "render": rendered_image,
+        "viewspace_points": screenspace_points,
+        "visibility_filter": radii > 0,
+        "radii": radii,
+        "depth": depth,
+        "opacity": opacity,
+        "n_touched": n_touched,
+    }
+
+
+def render_flow(pc, viewpoint_camera1, viewpoint_camera2, d_xyz1, d_xyz2, d_rotation1, d_scaling1, scaling_modifier=1.0,
+                compute_cov3D_python=False, scale_const=None, d_rot_as_res=True, **kwargs):
+    """Rasterize (NDC flow u, NDC flow v, dynamic mask) as colours (reference :229-361). Flow is computed from DETACHED
+    canonical positions plus the attached deltas (:262); the rasterized means stay attached to pc.get_xyz (:261,305)."""
+    screenspace_points = _screenspace_points(pc)
+    canonical_xyz = pc.get_xyz.clone()
+    base = canonical_xyz.detach()
+    dxyz1 = _scatter_delta(base, pc.dygs, d_xyz1)
+    dxyz2 = _scatter_delta(base, pc.dygs, d_xyz2)
+    xyz_t1, xyz_t2 = base + dxyz1, base + dxyz2
+
+    def project(xyz, full_proj):
+        hom = torch.cat([xyz, torch.ones_like(xyz[..., :1])], dim=-1) @ full_proj
+        return hom[..., :3] / (hom[..., -1:] + 1e-7)
+
+    proj2 = viewpoint_camera2.full_proj_transform if viewpoint_camera2 is not None else viewpoint_camera1.full_proj_transform
+    flow_uvz = project(xyz_t2, proj2) - project(xyz_t1, viewpoint_camera1.full_proj_transform)
+    flow_uvz[..., -1:] = pc.dygs.unsqueeze(1)   # third channel renders the motion mask (:284)
+
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera1, torch.zeros_like(flow_uvz[0]), scaling_modifier, 0))
+    means3D = canonical_xyz + dxyz1
+    opacity = pc.get_opacity.clone().detach()
+
+    scales = rotations = cov3D_precomp = None
+    residual_rot = lambda: pc.get_rotation if type(d_rotation1) is float else quaternion_multiply(d_rotation1, pc.get_rotation)
+    if scale_const is not None:
+        scales = torch.ones_like(pc.get_scaling) * scale_const
+        rotations = pc.get_rotation + d_rotation1 if d_rot_as_res else residual_rot()
+    elif compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier, d_rotation=None if type(d_rotation1) is float else d_rotation1)
+    else:
+        scales = pc.get_scaling.clone().detach() + _scatter_delta(pc.get_scaling, pc.dygs, d_scaling1)
+        if d_rot_as_res:
+            rotations = pc.get_rotation.clone().detach() + _scatter_delta(pc.get_rotation, pc.dygs, d_rotation1)
+        else:
+            rotations = residual_rot()
+
+    rendered_image, radii, rendered_depth, rendered_alpha, n_touched = rasterizer(
+        means3D=means3D, means2D=screenspace_points, shs=None, colors_precomp=flow_uvz, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {
+        "render": rendered_image,
+        "depth": rendered_depth,
+        "alpha": rendered_alpha,
+        "viewspace_points": screenspace_points,
+        "visibility_filter": radii > 0,
+        "radii": radii,
+    }
+
+
+def get_dynamic_mask(viewpoint_camera, pc, pipe, override_color=None, dynamic=True):
+    """bool[P] static mask from the deformation field's displacement magnitudes (reference :364-414)."""
+    if pc.get_xyz.shape[0] == 0:
+        return None
+    means3D = pc.get_xyz.clone().detach()
+    time = torch.tensor(viewpoint_camera.time - 1).to(means3D.device).repeat(means3D.shape[0], 1)
+    shs = None if pipe.convert_SHs_python else pc.get_features
+    if not dynamic:
+        return None
+    if pc.get_scaling.shape[-1] == 1:
+        _, _, _, dx, ds, dr = pc._deformation(means3D, pc._scaling.repeat(1, 3).clone().detach(), pc._rotation.clone().detach(),
+                                              pc._opacity.clone().detach(), shs.clone().detach(), time)
+    else:
+        _, _, _, dx, ds, dr = pc._deformation(means3D, pc._scaling, pc._rotation, pc._opacity, shs, time)
+    return (torch.norm(dx, dim=1) < 1) & (torch.norm(ds, dim=1) < 2) & (torch.norm(dr, dim=1) < 1)

@@ -5,7 +5,7 @@
  *
  * Semantics (simple_knn.cu:131-183): for every point i, the mean of the squared Euclidean distances to its three
  * nearest OTHER points (self excluded by index, so exact duplicates count with distance 0); a slot for which no
- * neighbour exists keeps FLT_MAX, i.e. P < 4 yields +inf exactly as the reference does.
+ * neighbour exists keeps FLT_MAX, i.e. P < 4 yields ~FLT_MAX/3 (P = 3) or +inf (P <= 2) exactly as the reference does.
  *
  * The reference orders points along a Morton curve and prunes 1024-point boxes; this implementation bins the points
  * into a uniform spatial-hash grid (about 2 points per cell) and searches growing cube shells until the third-best

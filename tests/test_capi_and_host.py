@@ -1,0 +1,96 @@
+"""CPU-side checks of the product's boundary: the shared library loads without a GPU and exports every symbol the
+headers declare; the Python drop-in mirrors the reference API; and the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from util import REPO
+
+import diff_gaussian_rasterization as dgr
+from diff_gaussian_rasterization import _C
+
+
+def _declared_symbols():
+    syms = set()
+    for h in ("gs_rasterizer.h", "simple_knn.h"):
+        txt = open(os.path.join(REPO, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", txt))
+    syms.discard("gsr_alloc_fn")
+    return syms
+
+
+def test_library_loads_and_exports_all_declared_symbols():
+    lib = _C.load_library()
+    syms = _declared_symbols()
+    assert {"gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2"} <= syms
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
+    assert b"gfx950" in lib.gsr_version()
+    # sizes are pure host functions
+    assert lib.gsr_geometry_buffer_size(1000) > 1000 * 70
+    assert lib.gsr_image_buffer_size(640, 480) >= 640 * 480 * 8
+    assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 1 + 192 + 8)
+
+
+def test_public_names_and_settings_fields_match_reference():
+    assert set(dgr.__all__) == {"GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_RasterizeGaussians"}
+    assert dgr.GaussianRasterizationSettings._fields == (            # DGR/diff_gaussian_rasterization/__init__.py:173-186
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "projmatrix_raw",
+        "sh_degree", "campos", "prefiltered", "debug")
+    import inspect
+    sig = inspect.signature(dgr.GaussianRasterizer.forward)
+    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations",
+                                        "cov3D_precomp", "theta", "rho"]
+    from simple_knn._C import distCUDA2  # noqa: F401  (gaussian_model.py:18)
+
+
+def test_argument_validation_messages():
+    r = dgr.GaussianRasterizer(None)
+    z = torch.zeros(1, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(z, z, z)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(z, z, z, shs=z, colors_precomp=z)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(z, z, z, shs=z, scales=z)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(z, z, z, shs=z, scales=z, rotations=z, cov3D_precomp=z)
+
+
+def test_no_cpu_fallback():
+    """The product path must not silently compute on the CPU."""
+    rs = dgr.GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), torch.eye(4), 0,
+                                           torch.zeros(3), False, False)
+    r = dgr.GaussianRasterizer(rs)
+    P = 4
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(torch.zeros(P, 3), torch.zeros(P, 3), torch.ones(P, 1), shs=torch.zeros(P, 1, 3), scales=torch.ones(P, 3), rotations=torch.ones(P, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r.markVisible(torch.zeros(P, 3))
+    from simple_knn._C import distCUDA2
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        distCUDA2(torch.zeros(P, 3))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        _C.rasterize_gaussians(torch.zeros(3), torch.zeros(P, 4), *([torch.Tensor([])] * 4), 1.0, torch.Tensor([]), torch.eye(4), torch.eye(4),
+                               torch.eye(4), 1.0, 1.0, 16, 16, torch.Tensor([]), 0, torch.zeros(3), False, False)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "4dgs-slam_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), os.path.join(root, f)
+                assert "libgs_oracle" not in txt
+
+
+def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _C.load_library()

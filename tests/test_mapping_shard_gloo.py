@@ -1,0 +1,92 @@
+"""world_size-2 gloo test of the view-sharded mapping step: two ranks render different keyframes of the
+same Gaussians (oracle-backed stand-in on CPU), all-reduce the flat gradient bucket, and must end with the gradients a
+single process gets by summing both views."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import REPO, PKG, make_camera, make_gaussians, make_cotangents, keyframe_pose
+
+
+def _view_grads(g, k):
+    import oracle.torch_binding as ob
+    R, t = keyframe_pose(k)
+    cam = make_camera(64, 48, R=R, t=t)
+    gc, gd = make_cotangents(cam, seed=100 + k)
+    T = lambda a, rg=False: torch.tensor(a, requires_grad=rg)
+    rs = ob.GaussianRasterizationSettings(48, 64, cam.tanfovx, cam.tanfovy, torch.ones(3), 1.0, T(cam.viewmatrix), T(cam.projmatrix),
+                                          T(cam.projmatrix_raw), 0, T(cam.campos), False, False)
+    params = [T(g[k_], True) for k_ in ("means3D", "shs", "opacities", "scales", "rotations")]
+    P = params[0].shape[0]
+    c, r, d, o, n = ob.GaussianRasterizer(rs)(means3D=params[0], means2D=torch.zeros(P, 3, requires_grad=True), opacities=params[2],
+                                              shs=params[1], scales=params[3], rotations=params[4])
+    ((c * T(gc)).sum() + (d * T(gd)).sum()).backward()
+    return params
+
+
+def _worker(rank, world, port, keyframes, ret):
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapping_shard import shard_keyframes, GradBucket
+    cam0 = make_camera(64, 48)
+    g = make_gaussians(400, cam0, seed=4, scale_mean=0.03)
+    mine = shard_keyframes(keyframes, rank, world)
+    params = None
+    for k in mine:   # accumulate this rank's views
+        p = _view_grads(g, k)
+        if params is None:
+            params = p
+        else:
+            for a, b in zip(params, p):
+                a.grad += b.grad
+    bucket = GradBucket(params)
+    bucket.pack()
+    bucket.all_reduce()
+    bucket.unpack()
+    if rank == 0:
+        ret.put([p.grad.numpy().copy() for p in params])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_view_sharding_equals_single_process_sum():
+    from mapping_shard import shard_keyframes
+    keyframes = [0, 1, 2, 3]
+    assert shard_keyframes(keyframes, 0, 2) == [0, 2] and shard_keyframes(keyframes, 1, 2) == [1, 3]
+    assert sorted(shard_keyframes(list(range(64)), 3, 8)) == list(range(3, 64, 8))
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, keyframes, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cam0 = make_camera(64, 48)
+    g = make_gaussians(400, cam0, seed=4, scale_mean=0.03)
+    want = None
+    for k in keyframes:
+        p = _view_grads(g, k)
+        want = [x.grad.clone() for x in p] if want is None else [w + x.grad for w, x in zip(want, p)]
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a, b.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_grad_bucket_single_process_is_identity():
+    from mapping_shard import GradBucket, allreduce_gaussian_grads
+    ps = [torch.randn(5, 3, requires_grad=True), torch.randn(5, 1, requires_grad=True)]
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    b = allreduce_gaussian_grads(ps)
+    assert b.nbytes == 20 * 4
+    assert torch.equal(ps[0].grad, torch.full((5, 3), 2.0)) and torch.equal(ps[1].grad, torch.full((5, 1), 3.0))
