@@ -17,7 +17,7 @@ struct GeomBwdArgs {
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped; const float* scales; const float* rotations;
     float scale_modifier; const float* cov3Ds; const float* viewmatrix; const float* projmatrix; const float* projmatrix_raw;
     const float* campos; float focal_x, focal_y, tan_fovx, tan_fovy;
-    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials; const uint8_t* inst_mask;
+    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials;
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
 };
@@ -34,18 +34,12 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         // instance ids of this Gaussian are contiguous: [point_offsets - tiles_touched, point_offsets)
         const uint32_t cnt = a.tiles_touched[idx];
         const uint32_t u0 = a.point_offsets[idx] - cnt;
+        const float4* sl = a.partials + (size_t)u0 * 3;
         for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t bits = a.inst_mask[u0 + k];          // which quadrant slots the tile's block produced
-            const float4* sl = a.partials + (size_t)(u0 + k) * 12;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if ((bits >> q) & 1u) {
-                    const float4 v0 = sl[3 * q], v1 = sl[3 * q + 1], v2 = sl[3 * q + 2];
-                    g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
-                    g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
-                    g_b += v2.x; g_d += v2.y;
-                }
-            }
+            const float4 v0 = sl[3 * k], v1 = sl[3 * k + 1], v2 = sl[3 * k + 2];
+            g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
+            g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
+            g_b += v2.x; g_d += v2.y;
         }
     }
     a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14

@@ -69,13 +69,13 @@ struct ImageState {
     }
 };
 struct BinningState {
-    uint32_t* inst_gauss; uint8_t* inst_mask; float4* partials; uint64_t* keys; uint2* sorted;
+    uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted;
     // Every base offset depends on R only, so backward re-carves without knowing R_alloc. `keys` (forward-only sort
-    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only gradient slots (R x 4 quadrants x 48 B).
+    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only per-instance gradient slots (R x 48 B).
     static BinningState from(char*& p, size_t R, size_t R_alloc)
     {
         BinningState b;
-        carve(p, b.inst_gauss, R); carve(p, b.inst_mask, R); carve(p, b.partials, R * 12);
+        carve(p, b.inst_gauss, R); carve(p, b.partials, R * 3);
         b.keys = reinterpret_cast<uint64_t*>(b.partials);
         carve(p, b.sorted, R_alloc);
         return b;
@@ -323,7 +323,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
         hipLaunchKernelGGL(render_bwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, background,
                            geom.means2D, geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth,
-                           bin.partials, bin.inst_mask);
+                           reinterpret_cast<float*>(bin.partials));
     }
     GSR_STAGE("render_bwd");
     GeomBwdArgs a;
@@ -332,7 +332,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     a.scale_modifier = scale_modifier; a.cov3Ds = cov3D_precomp ? cov3D_precomp : geom.cov3D;   // rasterizer_impl.cu:429
     a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.projmatrix_raw = projmatrix_raw; a.campos = campos;
     a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials; a.inst_mask = bin.inst_mask;
+    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials;
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     {
@@ -432,6 +432,21 @@ int gsr_knn_mean_dist2(int P, const float* points, float* mean_dists, char* work
     hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, w.grid, w.cell_count, w.cell_start, w.cursor);
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(nb), dim3(256), 0, stream, P, points, w.cell_of, w.cursor, w.sorted_pts);
     hipLaunchKernelGGL(knn_query_kernel, dim3(nb), dim3(256), 0, stream, P, w.grid, w.cell_start, w.sorted_pts, mean_dists);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// Test hook: runs gsr::wave_sum10_transposed on one wave. in: device float[64][10]; out: device float[64] (what each lane holds).
+__global__ void debug_reduce10_kernel(const float* in, float* out)
+{
+    const int l = threadIdx.x;
+    const float* v = in + l * 10;
+    out[l] = wave_sum10_transposed(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+}
+int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
+{
+    hipLaunchKernelGGL(debug_reduce10_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, in, out);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -54,6 +54,82 @@ __device__ __forceinline__ void wave_sum10_to_row3(float& v0, float& v1, float& 
 }
 #undef GSR_DPP_STAGE
 
+// ---- transposed ("butterfly") wave reduction of ten values -------------------------------------------------------
+// Sums v0..v9 over the 64 lanes in 37 VALU instructions instead of 60: at every butterfly stage a lane keeps only
+// half of its values (adding the partner lane's copy of the same half) instead of carrying all ten through all six
+// stages. On return every lane l holds the wave-wide total of ONE value, selected by p = l & 15:
+//     p:      0   1   2   3   4   5   6   7   8,10,12,14   9,11,13,15
+//     value:  v0  v5  v3  v8  v1  v6  v4  v9      v2            v7
+// (wave_sum10_slot_of_lane() returns that index), so ten lanes can store the ten totals with a single instruction.
+// Stage partners: xor 1 / xor 2 by DPP quad_perm, xor 4 by row_shl:4 / row_shr:4 under bank masks, xor 8 by
+// row_ror:8, xor 16 / xor 32 by gfx950's v_permlane16_swap / v_permlane32_swap. Inline asm because hipcc neither
+// folds DPP into the adds (see above) nor knows the swap instructions; instructions are ordered so that every DPP /
+// permlane source was written at least two issue slots earlier (gfx9 VALU-write -> DPP-read hazard), with s_nop
+// where the stage is too short.
+__device__ __forceinline__ int wave_sum10_slot_of_lane(int lane) { return (int)((0x7272727294618350ull >> (4 * (lane & 15))) & 15ull); }
+
+__device__ __forceinline__ float wave_sum10_transposed(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                                       float v7, float v8, float v9)
+{
+    const unsigned long long m0 = 0xAAAAAAAAAAAAAAAAull, m1 = 0xCCCCCCCCCCCCCCCCull, m2 = 0xF0F0F0F0F0F0F0F0ull,
+                             m3 = 0xFF00FF00FF00FF00ull;   // lanes whose bit 0 / 1 / 2 / 3 is set
+    float k0, k1, k2, k3, k4, s0, s1, s2, s3, s4;
+    asm volatile(
+        // stage 1 (xor 1): pairs (v0,v5) (v1,v6) (v2,v7) (v3,v8) (v4,v9): keep = bit0 ? second : first, send the other
+        "v_cndmask_b32_e64 %[k0], %[v0], %[v5], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[s0], %[v5], %[v0], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[k1], %[v1], %[v6], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[s1], %[v6], %[v1], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[k2], %[v2], %[v7], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[s2], %[v7], %[v2], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[k3], %[v3], %[v8], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[s3], %[v8], %[v3], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[k4], %[v4], %[v9], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[s4], %[v9], %[v4], %[m0]\n\t"
+        "v_add_f32_dpp %[k0], %[s0], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[k1], %[s1], %[k1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[k2], %[s2], %[k2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[k3], %[s3], %[k3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[k4], %[s4], %[k4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        // stage 2 (xor 2): pairs (k0,k3) (k1,k4), k2 alone.  results: s0, s1, k2
+        "v_cndmask_b32_e64 %[s0], %[k0], %[k3], %[m1]\n\t"      // keep A
+        "v_cndmask_b32_e64 %[s2], %[k3], %[k0], %[m1]\n\t"      // send A
+        "v_cndmask_b32_e64 %[s1], %[k1], %[k4], %[m1]\n\t"      // keep B
+        "v_cndmask_b32_e64 %[s3], %[k4], %[k1], %[m1]\n\t"      // send B
+        "v_add_f32_dpp %[k2], %[k2], %[k2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s0], %[s2], %[s0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[s3], %[s1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        // stage 3 (xor 4): pair (s0,s1), k2 alone.  results: k0 (pair), k1 (single)
+        "v_cndmask_b32_e64 %[k3], %[s0], %[s1], %[m2]\n\t"      // keep
+        "v_cndmask_b32_e64 %[k4], %[s1], %[s0], %[m2]\n\t"      // send
+        "v_add_f32_dpp %[k1], %[k2], %[k2] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[k1], %[k2], %[k2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[k0], %[k4], %[k3] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[k0], %[k4], %[k3] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        // stage 4 (xor 8): pair (k0,k1).  result: s0
+        "v_cndmask_b32_e64 %[s0], %[k0], %[k1], %[m3]\n\t"      // keep
+        "v_cndmask_b32_e64 %[s1], %[k1], %[k0], %[m3]\n\t"      // send
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[s0], %[s1], %[s0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        // stages 5, 6 (xor 16, xor 32): every lane of a column ends with the column total
+        "v_mov_b32 %[s1], %[s0]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[s0], %[s1]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32 %[s0], %[s0], %[s1]\n\t"
+        "v_mov_b32 %[s1], %[s0]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[s0], %[s1]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32 %[s0], %[s0], %[s1]\n\t"
+        "s_nop 0"
+        : [k0] "=&v"(k0), [k1] "=&v"(k1), [k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [s0] "=&v"(s0), [s1] "=&v"(s1),
+          [s2] "=&v"(s2), [s3] "=&v"(s3), [s4] "=&v"(s4)
+        : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [v4] "v"(v4), [v5] "v"(v5), [v6] "v"(v6), [v7] "v"(v7),
+          [v8] "v"(v8), [v9] "v"(v9), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3));
+    return s0;
+}
+
 // Inclusive prefix sum across the wave (6 shuffle steps); used for instance expansion.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 {

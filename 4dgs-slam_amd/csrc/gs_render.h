@@ -134,30 +134,32 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 
 // ------------------------------------------------------------------------------------------------------------------
 // B1: render backward, DGR/cuda_rasterizer/backward.cu:563-787, restructured:
-//  * per-(quadrant, Gaussian) sums over the quadrant's 64 pixels are formed with a DPP wave reduction (6 v_add_f32
-//    with DPP modifiers per value); the reference runs a 256-thread shared-memory tree with 8 block barriers x 5
+//  * per-(quadrant, Gaussian) sums over the quadrant's 64 pixels use the transposed butterfly of gs_device.h (37 VALU
+//    instructions for all ten values); the reference runs a 256-thread shared-memory tree with 8 block barriers x 5
 //    arrays for every listed Gaussian (backward.cu:541-559,759-765);
-//  * instead of 10 float atomics per (tile, Gaussian) (backward.cu:774-783) each wave stores its sums into the private
-//    slot partials[(u*4 + wave)*3 .. +2] (u = instance id) and records in inst_mask[u] which of the four slots exist;
-//    B2 sums a Gaussian's slots in a fixed order: bit-reproducible gradients, nothing to zero-fill;
+//  * the four quadrant waves drop their totals into LDS (ten lanes, one ds_write each); after the batch the block adds
+//    the quadrants in a fixed order and writes one 48-byte slot per (tile, Gaussian) instance, coalesced. The reference
+//    issues 10 float atomics per instance instead (backward.cu:774-783). B2 then sums a Gaussian's consecutive
+//    instance slots in a fixed order: bit-reproducible gradients, nothing to zero-fill, no atomics;
 //  * besides the quadrant cull, entries behind the deepest contributor of the quadrant (max n_contrib) are dropped
 //    at staging time, so saturated regions skip their occluded tail entirely.
-// Slot layout (3 x float4): {dmean2D.x, dmean2D.y, dconic.x, dconic.y} {dconic.w, dopacity, dcolor.r, dcolor.g}
-//                           {dcolor.b, ddepth, 0, 0}
+// Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int BB = 128;   // entries per staged batch in the backward kernel (LDS: 6 KiB staging + 20 KiB quadrant totals)
+
 __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint2* __restrict__ sorted, int W, int H,
                                                         const float* __restrict__ bg, const float2* __restrict__ means2D,
                                                         const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
                                                         const float* __restrict__ depths, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                        const float* __restrict__ dL_dpix_depth, float4* __restrict__ partials,
-                                                        uint8_t* __restrict__ inst_mask)
+                                                        const float* __restrict__ dL_dpix_depth, float* __restrict__ partials)
 {
-    __shared__ float4 s_a[RB];   // {mean.x, mean.y, conic.x, conic.y}
-    __shared__ float4 s_b[RB];   // {conic.z, opacity, depth, instance id bits}
-    __shared__ float4 s_c[RB];   // {r, g, b, -}
-    __shared__ unsigned long long s_mask[4][4];
+    __shared__ float4 s_a[BB];   // {mean.x, mean.y, conic.x, conic.y}
+    __shared__ float4 s_b[BB];   // {conic.z, opacity, depth, instance id bits}
+    __shared__ float4 s_c[BB];   // {r, g, b, quadrant mask bits}
+    __shared__ float s_part[4][BB][10];
+    __shared__ unsigned long long s_mask[4][2];
     __shared__ int s_wmax[4];
 
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
@@ -180,9 +182,16 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
     const float gd = inside ? dL_dpix_depth[pix] : 0.f;
     const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742 (loop invariant)
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f;
-    float last_a = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_d = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;                    // :643-644
+    // The reference keeps accum_rec[3] + accum_rec_depth ("what lies behind") per channel and dots it with dL_dpixel
+    // every step (:714-728). Only that dot product is ever used, and the recurrence is linear, so the dot is taken first:
+    // acc = accum_rec . dL_dpixel,  last_cg = last_color . dL_dpixel  -- 9 VALU ops per pair instead of 24.
+    float acc = 0.f, last_a = 0.f, last_cg = 0.f;
+    // per-lane constants of the transposed reduction: which of the ten sums this lane ends up holding and its scale
+    // factor (:643-644 ddelx_dx, ddely_dy; the -1/2 of :754-756)
+    const int fi = wave_sum10_slot_of_lane(lane);
+    const float red_scale = fi == 0 ? 0.5f * W : fi == 1 ? 0.5f * H : fi <= 4 ? -0.5f : 1.0f;
+    float* const part_lane = &s_part[wave][0][fi];
+    const bool store_lane = lane < 10;
 
     {   // deepest list position any pixel of this quadrant blended
         int wm = last_contrib;
@@ -191,10 +200,10 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         if (lane == 0) s_wmax[wave] = wm;
     }
 
-    for (int base = 0; base < n; base += RB) {
+    for (int base = 0; base < n; base += BB) {
         __syncthreads();
         uint32_t qm = 0;
-        if (base + t < n) {
+        if (t < BB && base + t < n) {
             const int pos = n - 1 - (base + t);                               // 0-based list position, back to front (:656,:677)
             const uint2 e = sorted[range.x + (uint32_t)pos];
             const float2 xy = means2D[e.x];
@@ -202,18 +211,19 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #pragma unroll
             for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
-            inst_mask[e.y] = (uint8_t)qm;
             s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
             s_b[t] = make_float4(co.z, co.w, depths[e.x], __uint_as_float(e.y));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], __uint_as_float(qm));
         }
+        if (wave < 2) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long m = __ballot((qm >> q) & 1u);
-            if (lane == 0) s_mask[q][wave] = m;
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long m = __ballot((qm >> q) & 1u);
+                if (lane == 0) s_mask[q][wave] = m;
+            }
         }
         __syncthreads();
-        for (int sw = 0; sw < 4; sw++) {
+        for (int sw = 0; sw < 2; sw++) {
             unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
             while (m) {
                 const int j = sw * 64 + __builtin_ctzll(m);
@@ -225,28 +235,18 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 const float G = __builtin_amdgcn_exp2f(power * LOG2E);
                 const float alpha = fminf(0.99f, B4.y * G);                                           // :688 (clamp has no gradient mask, Q23)
                 const bool valid = pos < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;    // :678,:685,:689
-                float4* slot = partials + ((size_t)__float_as_uint(B4.w) * 4 + wave) * 3;
+                float* const dst = part_lane + j * 10;
                 if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
-                    if (lane == 63) {
-                        slot[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        slot[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    if (store_lane) *dst = 0.f;
                     continue;
                 }
                 const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = valid ? T * inv1ma : T;                                                           // :700
                 const float wv = valid ? alpha * T : 0.f;                                             // :701 dchannel_dcolor
-                const float oma = 1.f - last_a;
-                acc_r = valid ? last_a * last_r + oma * acc_r : acc_r;                                // :714-728
-                acc_g = valid ? last_a * last_g + oma * acc_g : acc_g;
-                acc_b = valid ? last_a * last_b + oma * acc_b : acc_b;
-                acc_d = valid ? last_a * last_d + oma * acc_d : acc_d;
-                last_r = valid ? C4.x : last_r;
-                last_g = valid ? C4.y : last_g;
-                last_b = valid ? C4.z : last_b;
-                last_d = valid ? B4.z : last_d;
-                float dL_dalpha = (C4.x - acc_r) * gr + (C4.y - acc_g) * gg + (C4.z - acc_b) * gb + (B4.z - acc_d) * gd;
+                const float cg = C4.x * gr + C4.y * gg + C4.z * gb + B4.z * gd;                      // colour.dL_dpixel + depth*dL_ddepth
+                acc = valid ? last_a * last_cg + (1.f - last_a) * acc : acc;                          // :714,:726
+                last_cg = valid ? cg : last_cg;                                                        // :715,:727
+                float dL_dalpha = cg - acc;                                                            // :718,:728
                 dL_dalpha *= T;                                                                        // :732
                 last_a = valid ? alpha : last_a;
                 dL_dalpha += (-Tfin * inv1ma) * bgdot;                                                 // :743
@@ -254,18 +254,26 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 const float dL_dG = valid ? B4.y * dL_dalpha : 0.f;                                   // :746
                 const float gdx = Gv * dx, gdy = Gv * dy;
                 const float tgx = gdx * dL_dG, tgy = gdy * dL_dG;
-                float s_m2x = dL_dG * (-gdx * A4.z - gdy * A4.w);                                     // :749-753
-                float s_m2y = dL_dG * (-gdy * B4.x - gdx * A4.w);
-                float s_cx = tgx * dx, s_cy = tgx * dy, s_cw = tgy * dy;                              // :754-756 (x -1/2 below)
-                float s_op = Gv * dL_dalpha;                                                           // :757
-                float s_r = wv * gr, s_g = wv * gg, s_b_ = wv * gb, s_d = wv * gd;                    // :719,:729
-                wave_sum10_to_row3(s_m2x, s_m2y, s_cx, s_cy, s_cw, s_op, s_r, s_g, s_b_, s_d);
-                if (lane == 63) {
-                    slot[0] = make_float4(s_m2x * ddelx_dx, s_m2y * ddely_dy, -0.5f * s_cx, -0.5f * s_cy);
-                    slot[1] = make_float4(-0.5f * s_cw, s_op, s_r, s_g);
-                    slot[2] = make_float4(s_b_, s_d, 0.f, 0.f);
-                }
+                const float s_m2x = dL_dG * (-gdx * A4.z - gdy * A4.w);                               // :749-753
+                const float s_m2y = dL_dG * (-gdy * B4.x - gdx * A4.w);
+                const float s_cx = tgx * dx, s_cy = tgx * dy, s_cw = tgy * dy;                        // :754-756 (x -1/2 via red_scale)
+                const float s_op = Gv * dL_dalpha;                                                     // :757
+                const float tot = wave_sum10_transposed(s_m2x, s_m2y, s_cx, s_cy, s_cw, s_op, wv * gr, wv * gg, wv * gb, wv * gd);
+                if (store_lane) *dst = tot * red_scale;
             }
+        }
+        __syncthreads();
+        // add the four quadrants in a fixed order and write each instance's slot (12 floats, 48 B) coalesced
+        const int m = min(BB, n - base);
+        for (int idx = t; idx < m * 12; idx += RB) {
+            const int j = idx / 12, c = idx - j * 12;
+            float v = 0.f;
+            if (c < 10) {
+                const uint32_t bits = __float_as_uint(s_c[j].w);
+#pragma unroll
+                for (int q = 0; q < 4; q++) v += ((bits >> q) & 1u) ? s_part[q][j][c] : 0.f;
+            }
+            partials[(size_t)__float_as_uint(s_b[j].w) * 12 + c] = v;
         }
     }
 }

@@ -33,7 +33,7 @@ def test_library_loads_and_exports_all_declared_symbols():
     # sizes are pure host functions
     assert lib.gsr_geometry_buffer_size(1000) > 1000 * 70
     assert lib.gsr_image_buffer_size(640, 480) >= 640 * 480 * 8
-    assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 1 + 192 + 8)
+    assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 48 + 8)
 
 
 def test_public_names_and_settings_fields_match_reference():

@@ -200,3 +200,22 @@ def test_full_size_config2_properties_and_subsampled_parity():
     gp = {k: (v[perm] if isinstance(v, np.ndarray) and v.shape[:1] == (P,) else v) for k, v in g.items()}
     op, _ = hip_run(gp, cam, bg)
     assert rel_l1(op["color"], oh["color"]) < 1e-5 and (op["radii"] == oh["radii"][perm]).all()
+
+
+def test_transposed_wave_reduction_unit():
+    """gs_device.h wave_sum10_transposed: every lane ends with the 64-lane total of the value its (lane & 15) selects."""
+    import ctypes
+    from diff_gaussian_rasterization import _C
+    lib = _C.load_library()
+    lib.gsr_debug_wave_reduce10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(64, 10)).astype(np.float32)
+    xin = torch.tensor(x, device="cuda")
+    out = torch.zeros(64, device="cuda")
+    assert lib.gsr_debug_wave_reduce10(xin.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    slot = [0, 5, 3, 8, 1, 6, 4, 9, 2, 7, 2, 7, 2, 7, 2, 7]
+    want = x.astype(np.float64).sum(0)
+    got = out.cpu().numpy()
+    for l in range(64):
+        assert abs(got[l] - want[slot[l & 15]]) < 1e-4, (l, got[l], want[slot[l & 15]])
