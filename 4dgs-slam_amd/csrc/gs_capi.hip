@@ -50,7 +50,7 @@ struct GeomState {
     static GeomState from(char*& p, size_t P)
     {
         GeomState g;
-        const size_t nb = (P + 255) / 256 + 1;
+        const size_t nb = (P + GB - 1) / GB + 1;
         carve(p, g.header, 4);
         carve(p, g.depths, P); carve(p, g.means2D, P); carve(p, g.conic_opacity, P); carve(p, g.rgb, 3 * P);
         carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
@@ -58,13 +58,16 @@ struct GeomState {
         return g;
     }
 };
+static inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
 struct ImageState {
     float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
-    static ImageState from(char*& p, size_t N, size_t T)
+    uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
+    static ImageState from(char*& p, size_t N, size_t T, size_t P)
     {
         ImageState s;
         carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T * CTR_STRIDE);
         carve(p, s.tile_cursor, T * CTR_STRIDE);
+        carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
         return s;
     }
 };
@@ -151,10 +154,10 @@ const char* gsr_last_error(void) { return g_last_error.c_str(); }
 const char* gsr_version(void) { return "gs_rasterizer_hip 0.1 (gfx950)"; }
 
 size_t gsr_geometry_buffer_size(int P) { return required([&](char*& p) { GeomState::from(p, (size_t)P); }); }
-size_t gsr_image_buffer_size(int width, int height)
+size_t gsr_image_buffer_size(int width, int height, int P)
 {
     const size_t T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
-    return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T); });
+    return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T, (size_t)P); });
 }
 size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc); }); }
 
@@ -218,16 +221,18 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     const size_t N = (size_t)width * height;
 
     char* gchunk = geometry_alloc(geometry_user, gsr_geometry_buffer_size(P));
-    char* ichunk = image_alloc(image_user, gsr_image_buffer_size(width, height));
+    char* ichunk = image_alloc(image_user, gsr_image_buffer_size(width, height, P));
     if (!gchunk || !ichunk) { g_last_error = "gsr_forward: allocation callback returned NULL"; return GSR_ERR_ALLOC; }
     GeomState geom = GeomState::from(gchunk, (size_t)P);
-    ImageState img = ImageState::from(ichunk, N, (size_t)T);
+    ImageState img = ImageState::from(ichunk, N, (size_t)T, (size_t)P);
+    const bool lds_hist = use_lds_hist((size_t)T);
+    const size_t hist_lds_bytes = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
     GSR_HIP_CHECK(hipMemsetAsync(geom.header, 0, 4 * sizeof(uint32_t), stream));
     GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * CTR_STRIDE * sizeof(uint32_t), stream));
 
-    const int nblocks = (P + 255) / 256;
+    const int nblocks = (P + GB - 1) / GB;
     if (P > 0) {
         PreprocessArgs a;
         a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.gx = gx; a.gy = gy;
@@ -239,10 +244,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         a.prefiltered = prefiltered; a.radii = radii; a.n_touched = n_touched;
         a.depths = geom.depths; a.means2D = geom.means2D; a.conic_opacity = geom.conic_opacity; a.rgb = geom.rgb; a.cov3D = geom.cov3D;
         a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums; a.tile_count = img.tile_count;
-        a.header = geom.header;
+        a.header = geom.header; a.block_tile_base = lds_hist ? img.block_tile_base : nullptr;
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
-            hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
     }
@@ -270,8 +275,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         if (R_alloc != R) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, (size_t)R_alloc * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
-            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(256), 0, stream, P, gx, gy, radii, geom.means2D, geom.depths,
-                               geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, bin.keys, bin.inst_gauss);
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.means2D,
+                               geom.depths, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
+                               lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss);
         }
         GSR_STAGE("scatter_instances");
         {
@@ -316,7 +322,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     char* gp = geom_buffer; char* bp = binning_buffer; char* ip = image_buffer;
     GeomState geom = GeomState::from(gp, (size_t)P);
     BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);   // offsets depend on R only
-    ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T);
+    ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T, 0);
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
     if (R > 0) {
@@ -355,7 +361,7 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     char* gp = const_cast<char*>(geom_buffer); char* bp = const_cast<char*>(binning_buffer); char* ip = const_cast<char*>(image_buffer);
     GeomState geom = GeomState::from(gp, (size_t)P);
     BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);
-    ImageState img = ImageState::from(ip, N, (size_t)T);
+    ImageState img = ImageState::from(ip, N, (size_t)T, 0);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
     D2H(depths, geom.depths, P * sizeof(float));
     D2H(means2D, geom.means2D, P * 2 * sizeof(float));

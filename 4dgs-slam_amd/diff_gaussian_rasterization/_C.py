@@ -51,7 +51,7 @@ def load_library():
     lib.gsr_geometry_buffer_size.restype = C.c_size_t
     lib.gsr_geometry_buffer_size.argtypes = [i]
     lib.gsr_image_buffer_size.restype = C.c_size_t
-    lib.gsr_image_buffer_size.argtypes = [i, i]
+    lib.gsr_image_buffer_size.argtypes = [i, i, i]
     lib.gsr_binning_buffer_size.restype = C.c_size_t
     lib.gsr_binning_buffer_size.argtypes = [i]
     lib.gsr_debug_read_state.restype = i

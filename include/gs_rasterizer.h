@@ -88,7 +88,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Scratch sizes, the counterpart of required<GeometryState|ImageState|BinningState>() (rasterizer_impl.h:68-73).
  * gsr_forward passes exactly these sizes to the callbacks; exposed so a caller can pre-size arenas. */
 size_t gsr_geometry_buffer_size(int P);
-size_t gsr_image_buffer_size(int width, int height);
+size_t gsr_image_buffer_size(int width, int height, int P);   /* P: the per-(Gaussian block, tile) binning scratch lives here */
 size_t gsr_binning_buffer_size(int R_alloc);
 
 /* Reads back intermediate state for stage-by-stage parity checks (tests only; synchronises `stream`).

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert b"gfx950" in lib.gsr_version()
     # sizes are pure host functions
     assert lib.gsr_geometry_buffer_size(1000) > 1000 * 70
-    assert lib.gsr_image_buffer_size(640, 480) >= 640 * 480 * 8
+    assert lib.gsr_image_buffer_size(640, 480, 200000) >= 640 * 480 * 8
     assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 48 + 8)
 
 

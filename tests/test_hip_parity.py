@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 IMG_TOL, GRAD_TOL = 1e-4, 1e-3
 
 
-def _check(m, flips=0):
+def _check(m, flips=0, nt_tol=2):
     for k in ("color", "depth", "opacity"):
         assert m[k] <= IMG_TOL, (k, m)
     for k, v in m.items():
@@ -22,7 +22,8 @@ def _check(m, flips=0):
             assert v <= GRAD_TOL, (k, m)
     assert m["radii_mismatch"] <= flips and m["visible_mismatch"] <= flips, m
     assert m["n_touched_gt0_mismatch"] <= flips, m
-    assert m["n_touched_mismatch"] <= max(flips, 2 + m.get("P", 0) // 50000), m
+    # n_touched counts pixels with T(1-alpha) > 0.5: a handful of exact-threshold pixels may flip between exp() implementations
+    assert m["n_touched_mismatch"] <= max(flips, nt_tol + m.get("P", 0) // 50000), m
 
 
 CASES = [
@@ -219,3 +220,15 @@ def test_transposed_wave_reduction_unit():
     got = out.cpu().numpy()
     for l in range(64):
         assert abs(got[l] - want[slot[l & 15]]) < 1e-4, (l, got[l], want[slot[l & 15]])
+
+
+def test_huge_tile_grid_uses_global_atomic_binning_fallback():
+    """More than HIST_LDS_TILES (12288) tiles: the per-block LDS histogram does not fit, binning falls back to one global
+    atomic per instance. 2048x1616 -> 128 x 101 = 12928 tiles."""
+    cam = make_camera(2048, 1616)
+    g = make_gaussians(4000, cam, seed=6, scale_mean=0.02)
+    gc, gd = make_cotangents(cam)
+    bg = np.zeros(3, np.float32)
+    oo, st, go = oracle_run(g, cam, bg, gc, gd)
+    oh, gh = hip_run(g, cam, bg, gc, gd)
+    _check(compare(oh, gh, oo, go), nt_tol=8)   # 3.3 M pixels
