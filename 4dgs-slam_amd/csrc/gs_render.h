@@ -11,6 +11,9 @@
 // reduction. The cull is conservative (a superset of the pairs the reference blends), so results are unchanged.
 #pragma once
 #include "gs_forward.h"
+#ifndef GSR_EXP
+#define GSR_EXP 0
+#endif
 
 namespace gsr {
 
@@ -21,6 +24,9 @@ constexpr int RB = 256;   // entries per staged batch == threads per block
 // half-extents sqrt(2 tau c/det), sqrt(2 tau a/det), det = ac - b^2. Returns a 4-bit mask (bit q = quadrant q).
 __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, float b, float c, float o, int tx, int ty)
 {
+#if GSR_EXP == 3
+    return 15u;
+#endif
     const float tau = __logf(255.0f * o);           // alpha >= 1/255  <=>  power >= -tau
     if (!(tau >= 0.f)) return 0u;                   // o < 1/255 (or NaN): can never be blended
     const float det = a * c - b * b;
@@ -63,6 +69,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     __shared__ float4 s_b[RB];      // {C, opacity, depth, gaussian id bits}
     __shared__ float4 s_c[RB];      // {r, g, b, -}
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
+    __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
 
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
@@ -72,13 +79,19 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = px < W && py < H;
     bool done = !inside;
+    s_nt[t] = 0;
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
     for (int base = 0; base < n; base += RB) {
-        if (__syncthreads_and(done)) break;                       // forward.cu:318-320
+        const int all_done = __syncthreads_and(done);             // forward.cu:318-320 (also orders the LDS reuse below)
+        {   // flush the previous batch's n_touched increments: one global atomic per (tile, Gaussian), off the hot loop
+            const int c = s_nt[t];
+            if (c) { atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c); s_nt[t] = 0; }
+        }
+        if (all_done) break;
         uint32_t qm = 0;
         if (base + t < n) {
             const uint2 e = sorted[range.x + base + t];
@@ -95,8 +108,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             if (lane == 0) s_mask[q][wave] = m;
         }
         __syncthreads();
-        bool wave_done = __all(done);
-        for (int sw = 0; sw < 4 && !wave_done; sw++) {
+        // The saturation test is per 64-entry group, not per entry: a per-entry wave vote + branch serialises the loop on the
+        // VALU->SALU round trip (measured: 111 -> 86 us), and pixels that are done blend nothing anyway.
+        for (int sw = 0; sw < 4; sw++) {
+            if (__all(done)) break;
             unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
             while (m) {
                 const int j = sw * 64 + __builtin_ctzll(m);
@@ -114,11 +129,15 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                 Cr += C4.x * w; Cg += C4.y * w; Cb += C4.z * w; Dd += B4.z * w;                    // :364-367
                 T = blend ? test_T : T;
                 last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
-                const unsigned long long tm = __ballot(blend && test_T > 0.5f);                    // :369-371, one atomic per wave
-                if (tm && lane == 0) atomicAdd(&n_touched[__float_as_uint(B4.w)], (int)__popcll(tm));
-                if (__all(done)) { wave_done = true; break; }
+                const unsigned long long tm = __ballot(blend && test_T > 0.5f);                    // :369-371
+                if (tm && lane == 0) atomicAdd(&s_nt[j], (int)__popcll(tm));                       // LDS; only the front-most layers take it
             }
         }
+    }
+    __syncthreads();
+    {
+        const int c = s_nt[t];
+        if (c) atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c);
     }
     if (inside) {
         const size_t pix = (size_t)py * W + px;
@@ -236,10 +255,12 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 const float alpha = fminf(0.99f, B4.y * G);                                           // :688 (clamp has no gradient mask, Q23)
                 const bool valid = pos < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;    // :678,:685,:689
                 float* const dst = part_lane + j * 10;
+#if GSR_EXP != 5
                 if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
                     if (store_lane) *dst = 0.f;
                     continue;
                 }
+#endif
                 const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                 T = valid ? T * inv1ma : T;                                                           // :700
                 const float wv = valid ? alpha * T : 0.f;                                             // :701 dchannel_dcolor
@@ -258,7 +279,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 const float s_m2y = dL_dG * (-gdy * B4.x - gdx * A4.w);
                 const float s_cx = tgx * dx, s_cy = tgx * dy, s_cw = tgy * dy;                        // :754-756 (x -1/2 via red_scale)
                 const float s_op = Gv * dL_dalpha;                                                     // :757
+#if GSR_EXP == 4
+                const float tot = s_m2x + s_m2y + s_cx + s_cy + s_cw + s_op + wv * gr + wv * gg + wv * gb + wv * gd;
+#else
                 const float tot = wave_sum10_transposed(s_m2x, s_m2y, s_cx, s_cy, s_cw, s_op, wv * gr, wv * gg, wv * gb, wv * gd);
+#endif
                 if (store_lane) *dst = tot * red_scale;
             }
         }
