@@ -1,0 +1,94 @@
+"""GPU tests at the sizes / shapes of BASELINE.json configs[2] and configs[4] (parity-test cases, not bench lines)."""
+import numpy as np
+import pytest
+import torch
+
+from util import oracle_run, make_camera, make_gaussians, make_cotangents, keyframe_pose, rel_l1
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, dev="cuda"):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    T = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+    return GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, T([1, 1, 1]), 1.0, T(cam.viewmatrix), T(cam.projmatrix),
+                                         T(cam.projmatrix_raw), 0, T(cam.campos), False, False)
+
+
+def test_config3_shape_500k_gaussians_delta_producer_and_pose_grad():
+    """configs[2]: 500k Gaussians, deformation deltas from a network, several keyframes, pose-grad on. The Delta producer
+    (utils/deformation.py) is outside the path; a small MLP stands in for it so that gradients must flow
+    rasterizer -> (dx, ds, dr) -> MLP parameters through autograd, per keyframe, with theta/rho gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    P = 500_000
+    cam0 = make_camera(640, 480)
+    g = make_gaussians(P, cam0, seed=0)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+    xyz, shs, opac, scal, rot = T(g["means3D"], True), T(g["shs"], True), T(g["opacities"], True), T(g["scales"], True), T(g["rotations"], True)
+    dygs = torch.tensor(np.random.default_rng(0).uniform(size=P) < 0.25, device="cuda")
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(4, 32), torch.nn.ReLU(), torch.nn.Linear(32, 10)).cuda()
+    total = 0.0
+    poses = []
+    for k in (0, 3):   # two of the eight keyframes keep the test short; each is an independent forward/backward of the path
+        R, t = keyframe_pose(k)
+        cam = make_camera(640, 480, R=R, t=t)
+        theta, rho = T(np.zeros(3), True), T(np.zeros(3), True)
+        poses.append((theta, rho))
+        time = torch.full((int(dygs.sum()), 1), float(k), device="cuda")
+        d = mlp(torch.cat([xyz[dygs].detach(), time], 1)) * 1e-3
+        dxyz = torch.zeros_like(xyz); dxyz[dygs] = d[:, :3]
+        dsc = torch.zeros_like(scal); dsc[dygs] = d[:, 3:6] * 0.1
+        drt = torch.zeros_like(rot); drt[dygs] = d[:, 6:10]
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+        color, radii, depth, opacity, n_touched = GaussianRasterizer(_settings(cam))(
+            means3D=xyz + dxyz, means2D=means2D, opacities=opac, shs=shs, scales=scal + dsc, rotations=rot + drt, theta=theta, rho=rho)
+        gc, gd = make_cotangents(cam, seed=10 + k)
+        total = total + (color * T(gc)).sum() + (depth * T(gd)).sum()
+    total.backward()
+    for p in list(mlp.parameters()) + [xyz, shs, opac, scal, rot] + [x for pr in poses for x in pr]:
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    # parity of the last view against the oracle with the same deformed inputs
+    with torch.no_grad():
+        gg = dict(g)
+        gg["means3D"] = (xyz + dxyz).cpu().numpy(); gg["scales"] = (scal + dsc).cpu().numpy(); gg["rotations"] = (rot + drt).cpu().numpy()
+    oo, st, go = oracle_run(gg, cam, np.ones(3, np.float32), gc, gd)
+    assert rel_l1(color.detach().cpu().numpy(), oo["color"]) <= 1e-4
+    assert rel_l1(depth.detach().cpu().numpy(), oo["depth"]) <= 1e-4
+    tau = go["dL_dtau"].sum(0)
+    assert rel_l1(poses[-1][1].grad.cpu().numpy().reshape(-1), tau[:3]) <= 1e-3      # rho
+    assert rel_l1(poses[-1][0].grad.cpu().numpy().reshape(-1), tau[3:]) <= 1e-3      # theta
+
+
+def test_config5_shape_2m_gaussians_one_shard():
+    """configs[4]: 2M Gaussians, views sharded across GPUs. One rank's share on one GPU: invariants that do not need the oracle
+    (which would take minutes at this size) + the flat gradient bucket that would be all-reduced."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from mapping_shard import GradBucket, shard_keyframes
+    P = 2_000_000
+    cam0 = make_camera(640, 480)
+    g = make_gaussians(P, cam0, seed=1)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+    params = [T(g[k], True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    outs = []
+    for k in shard_keyframes(list(range(64)), rank=5, world_size=8)[:2]:
+        R, t = keyframe_pose(k)
+        cam = make_camera(640, 480, R=R, t=t)
+        gc, gd = make_cotangents(cam, seed=k)
+        means2D = torch.zeros_like(params[0], requires_grad=True)
+        color, radii, depth, opacity, n_touched = GaussianRasterizer(_settings(cam))(
+            means3D=params[0], means2D=means2D, opacities=params[2], shs=params[1], scales=params[3], rotations=params[4])
+        ((color * T(gc)).sum() + (depth * T(gd)).sum()).backward()
+        assert float(opacity.min()) >= 0 and float(opacity.max()) <= 1 - 1e-4 + 1e-6
+        assert torch.isfinite(color).all() and torch.isfinite(depth).all()
+        assert int((radii > 0).sum()) > 0.7 * P
+        outs.append(color.detach().clone())
+    b = GradBucket(params)
+    b.pack()
+    assert b.nbytes == P * 14 * 4 and torch.isfinite(b.flat).all() and float(b.flat.abs().sum()) > 0
+    # determinism at scale: same view again -> identical image
+    R, t = keyframe_pose(5)
+    color2, *_ = GaussianRasterizer(_settings(make_camera(640, 480, R=R, t=t)))(
+        means3D=params[0].detach(), means2D=torch.zeros_like(params[0]), opacities=params[2].detach(), shs=params[1].detach(),
+        scales=params[3].detach(), rotations=params[4].detach())
+    assert torch.equal(color2, outs[0])
