@@ -20,39 +20,61 @@ struct GeomBwdArgs {
     const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials;
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
+    float* tau_partials;   // optional [nblocks][6]: per-block sums of dL_dtau, so the caller does not have to reduce [P,6]
 };
 
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    const size_t i = (size_t)idx;
-    const bool visible = a.radii[idx] > 0;   // backward.cu:163,443
+    const bool in_range = idx < a.P;
+    const size_t i = (size_t)(in_range ? idx : 0);
+    const bool visible = in_range && a.radii[idx] > 0;   // backward.cu:163,443
 
+    // ---- gather: sum this Gaussian's per-instance slots ----------------------------------------------------------
+    // Instance ids are a global running count over Gaussians, so the 256 Gaussians of a block own ONE contiguous range of
+    // slots [U0, U1). It is streamed through LDS in coalesced chunks (the whole block loads, every thread then picks its own
+    // instances out of LDS, in ascending instance order => fixed summation order). Per-thread scattered 16-byte loads from
+    // global memory made this kernel latency-bound before (3 waves per SIMD cannot hide them).
+    constexpr int CH = 256;                      // instances per chunk: 256 x 48 B = 12 KiB
+    __shared__ float4 s_slot[CH * 3];
+    __shared__ uint32_t s_range[2];
+    const uint32_t cnt = visible ? a.tiles_touched[idx] : 0u;
+    const uint32_t incl = in_range ? a.point_offsets[idx] : 0u;
+    const uint32_t u0 = incl - (in_range ? a.tiles_touched[idx] : 0u);
+    if (threadIdx.x == 0) s_range[0] = u0;
+    const int last = min(a.P - 1, blockIdx.x * 256 + 255);
+    if (idx == last) s_range[1] = incl;
+    __syncthreads();
+    const uint32_t U0 = s_range[0], U1 = s_range[1];
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-    if (visible) {
-        // instance ids of this Gaussian are contiguous: [point_offsets - tiles_touched, point_offsets)
-        const uint32_t cnt = a.tiles_touched[idx];
-        const uint32_t u0 = a.point_offsets[idx] - cnt;
-        const float4* sl = a.partials + (size_t)u0 * 3;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float4 v0 = sl[3 * k], v1 = sl[3 * k + 1], v2 = sl[3 * k + 2];
+    for (uint32_t c0 = U0; c0 < U1; c0 += CH) {
+        const uint32_t nch = min((uint32_t)CH, U1 - c0);
+        const float4* src = a.partials + (size_t)c0 * 3;
+        for (uint32_t k = threadIdx.x; k < nch * 3; k += 256) s_slot[k] = src[k];
+        __syncthreads();
+        const uint32_t lo = max(u0, c0), hi = min(u0 + cnt, c0 + nch);
+        for (uint32_t u = lo; u < hi; u++) {
+            const float4* sl = s_slot + (u - c0) * 3;
+            const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
             g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
             g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
             g_b += v2.x; g_d += v2.y;
         }
+        __syncthreads();
     }
-    a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
-    a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw;
-    a.dL_dopacity[i] = g_op;
-    a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b;
-    a.dL_ddepth[i] = g_d;
+    if (in_range) {
+        a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
+        a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw;
+        a.dL_dopacity[i] = g_op;
+        a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b;
+        a.dL_ddepth[i] = g_d;
+    }
 
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool has_sh = a.shs != nullptr && a.dL_dsh != nullptr;
     if (!visible) {
-        if (has_sh) for (int k = 0; k < a.M * 3; k++) a.dL_dsh[i * a.M * 3 + k] = 0.f;
+        if (has_sh && in_range) for (int k = 0; k < a.M * 3; k++) a.dL_dsh[i * a.M * 3 + k] = 0.f;
     } else {
         const float* vm = a.viewmatrix;
         const f3 mean = mk3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
@@ -242,20 +264,47 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
             drot[3] = 2 * r * (Dm[0][1] - Dm[1][0]) + 2 * x * (Dm[2][0] + Dm[0][2]) + 2 * y * (Dm[1][2] + Dm[2][1]) - 4 * z * (Dm[1][1] + Dm[0][0]);
         }
     }
+    if (in_range) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * i + k] = dmean[k];
+        for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * i + k] = dmean[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dcov[k];
+        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dL_dtau[6 * i + k] = dtau[k];
-    if (a.dL_dscale) {
+        for (int k = 0; k < 6; k++) a.dL_dtau[6 * i + k] = dtau[k];
+        if (a.dL_dscale) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
+            for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
+        }
+        if (a.dL_drot) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+        }
     }
-    if (a.dL_drot) {
+    // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with
+    // torch.sum on [P,6]); fold the first level into this kernel: fixed-order wave + block sums, one row per block.
+    if (a.tau_partials) {
+        __shared__ float s_tau[4][6];
 #pragma unroll
-        for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+        for (int k = 0; k < 6; k++) {
+            float v = in_range ? dtau[k] : 0.f;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane_id() == 0) s_tau[threadIdx.x >> 6][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) a.tau_partials[(size_t)blockIdx.x * 6 + threadIdx.x] = (s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + (s_tau[2][threadIdx.x] + s_tau[3][threadIdx.x]);
     }
+}
+
+// Second level of the pose-gradient sum: one block, 6 x 64 threads, fixed order.
+__global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
+{
+    const int k = threadIdx.x >> 6, lane = lane_id();
+    float v = 0.f;
+    for (int b = lane; b < nblocks; b += 64) v += partials[(size_t)b * 6 + k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane == 0) out6[k] = v;
 }
 
 }  // namespace gsr

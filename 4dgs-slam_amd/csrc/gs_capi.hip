@@ -10,6 +10,7 @@
 // No global 64-bit radix sort, no float atomics, no cooperative-groups block trees.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ struct GeomState {
     uint32_t* header;   // [0]=R, [1]=error flag, [2]=R_alloc, [3]=reserved
     float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
     int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
+    float* tau_partials;   // [ceil(P/256)][6] per-block sums of dL_dtau (backward)
     static GeomState from(char*& p, size_t P)
     {
         GeomState g;
@@ -55,6 +57,7 @@ struct GeomState {
         carve(p, g.depths, P); carve(p, g.means2D, P); carve(p, g.conic_opacity, P); carve(p, g.rgb, 3 * P);
         carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
         carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
+        carve(p, g.tau_partials, ((P + 255) / 256 + 1) * 6);
         return g;
     }
 };
@@ -142,7 +145,39 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 }
 #define GSR_STAGE(what) do { int _r = debug_sync(debug, stream, what); if (_r) return _r; } while (0)
 
-static thread_local uint32_t* t_pinned = nullptr;
+// Host mailbox: 8 words of pinned, host-coherent memory per host thread; word 4 carries the sequence number of the
+// forward call whose header (words 0-3) is valid. Plus the allocation size that was enough last time (speculative
+// binning allocation while the GPU is still busy with the preprocess).
+static thread_local uint32_t* t_mailbox = nullptr;       // host pointer
+static thread_local uint32_t* t_mailbox_dev = nullptr;   // device pointer to the same memory
+static thread_local uint32_t t_seq = 0;
+static thread_local size_t t_last_R_alloc = 0;
+static thread_local bool t_use_mailbox = true;
+
+static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
+{
+    if (t_use_mailbox) {
+        // spin on the mailbox; check the stream now and then so that a faulted / finished stream cannot hang us
+        for (unsigned long long spins = 0;; spins++) {
+            if (__atomic_load_n(&t_mailbox[4], __ATOMIC_ACQUIRE) == seq) {
+                for (int i = 0; i < 4; i++) out[i] = __atomic_load_n(&t_mailbox[i], __ATOMIC_RELAXED);
+                return 0;
+            }
+            if ((spins & 0xFFFFF) == 0xFFFFF) {
+                hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) {   // stream drained: the store must be visible by now, otherwise fall back for good
+                    if (__atomic_load_n(&t_mailbox[4], __ATOMIC_ACQUIRE) == seq) continue;
+                    t_use_mailbox = false;
+                    break;
+                }
+                if (q != hipErrorNotReady) { g_last_error = std::string("stream error while waiting for the header: ") + hipGetErrorString(q); return GSR_ERR_HIP; }
+            }
+        }
+    }
+    GSR_HIP_CHECK(hipMemcpyAsync(out, device_header, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP_CHECK(hipStreamSynchronize(stream));
+    return 0;
+}
 
 }  // namespace gsr
 
@@ -253,22 +288,41 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     }
     {
         ScopedKernelTimer tm(K_SCAN, stream);
+        if (!t_mailbox) {
+            if (const char* e = getenv("GSR_MAILBOX")) t_use_mailbox = e[0] != '0';
+            GSR_HIP_CHECK(hipHostMalloc((void**)&t_mailbox, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
+            memset(t_mailbox, 0, 8 * sizeof(uint32_t));
+            GSR_HIP_CHECK(hipHostGetDevicePointer((void**)&t_mailbox_dev, t_mailbox, 0));
+        }
+        if (++t_seq == 0) t_seq = 1;
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
-                           img.ranges, img.tile_cursor, geom.header);
+                           img.ranges, img.tile_cursor, geom.header, t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
     }
     GSR_STAGE("scan");
 
-    // The one host synchronisation of the forward pass (the reference's is rasterizer_impl.cu:283-284).
-    if (!t_pinned) GSR_HIP_CHECK(hipHostMalloc((void**)&t_pinned, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    GSR_HIP_CHECK(hipMemcpyAsync(t_pinned, geom.header, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP_CHECK(hipStreamSynchronize(stream));
-    const uint32_t R = t_pinned[0], err = t_pinned[1], R_alloc = t_pinned[2];
+    // Speculative binning allocation while the GPU is still preprocessing: the size that sufficed last time plus slack
+    // (a SLAM loop renders nearly the same scene again and again); re-done below only if it turns out too small.
+    char* bchunk = nullptr;
+    size_t bchunk_bytes = 0;
+    if (t_last_R_alloc) {
+        const size_t guess = t_last_R_alloc + t_last_R_alloc / 8 + 4096;
+        bchunk_bytes = required([&](char*& p) { BinningState::from(p, guess, guess); });
+        bchunk = binning_alloc(binning_user, bchunk_bytes);
+        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+    }
+    // The one host wait of the forward pass (the reference's is the blocking cudaMemcpy at rasterizer_impl.cu:283-284).
+    uint32_t hdr[4];
+    { const int rc = wait_for_header(stream, geom.header, t_seq, hdr); if (rc) return rc; }
+    const uint32_t R = hdr[0], err = hdr[1], R_alloc = hdr[2], max_tile_list = hdr[3];
     if (err) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
     if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
+    t_last_R_alloc = R_alloc;
 
     const size_t bsize = required([&](char*& p) { BinningState::from(p, (size_t)R, (size_t)R_alloc); });
-    char* bchunk = binning_alloc(binning_user, bsize);
-    if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+    if (!bchunk || bsize > bchunk_bytes) {
+        bchunk = binning_alloc(binning_user, bsize);
+        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+    }
     BinningState bin = BinningState::from(bchunk, (size_t)R, (size_t)R_alloc);
 
     if (R > 0) {
@@ -282,7 +336,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         GSR_STAGE("scatter_instances");
         {
             ScopedKernelTimer tm(K_SORT, stream);
-            hipLaunchKernelGGL(sort_tiles_kernel, dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys, bin.inst_gauss, bin.sorted);
+            hipLaunchKernelGGL((sort_tiles_kernel<SORT_SMALL_CAP, 0>), dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys,
+                               bin.inst_gauss, bin.sorted);
+            if (max_tile_list > (uint32_t)SORT_SMALL_CAP)
+                hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
+                                   bin.keys, bin.inst_gauss, bin.sorted);
         }
         GSR_STAGE("sort_tiles");
     } else if (P > 0) {
@@ -302,17 +360,17 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     return (int)R;
 }
 
-int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+int gsr_backward_fused(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
                  char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscale, float* dL_drot, float* dL_dtau, int debug, void* stream_)
+                 float* dL_dscale, float* dL_drot, float* dL_dtau, float* dL_dtau_sum, int debug, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
-    if (P == 0) return 0;
+    if (P == 0) { if (dL_dtau_sum) GSR_HIP_CHECK(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), stream)); return 0; }
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || !means3D || !viewmatrix ||
         !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
         !dL_dmean3D || !dL_dcov3D || !dL_dtau) {
@@ -341,12 +399,29 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials;
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
+    a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
         hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+        if (dL_dtau_sum)
+            hipLaunchKernelGGL(tau_sum_kernel, dim3(1), dim3(384), 0, stream, (P + 255) / 256, geom.tau_partials, dL_dtau_sum);
     }
     GSR_STAGE("geometry_bwd");
     return 0;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                 char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, float* dL_dtau, int debug, void* stream)
+{
+    return gsr_backward_fused(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                              cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+                              binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,
+                              dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dtau, nullptr, debug, stream);
 }
 
 int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_buffer, const char* binning_buffer,

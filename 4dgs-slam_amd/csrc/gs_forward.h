@@ -262,7 +262,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, 
 
 __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
                                                     int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
-                                                    uint32_t* header)
+                                                    uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
 {
     __shared__ uint32_t s_tmp[17];
     const uint32_t R = block_exclusive_scan_1024(
@@ -275,7 +275,29 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
             tile_cursor[(size_t)i * CTR_STRIDE] = excl;
         },
         s_tmp);
-    if (threadIdx.x == 0) { header[0] = R; header[2] = R_alloc; }
+    // largest tile list: lets the host pick the sort kernel variant (LDS footprint decides how many tiles sort concurrently)
+    uint32_t mx = 0;
+    for (int i = threadIdx.x; i < ntiles; i += 1024) mx = max(mx, tile_count[(size_t)i * CTR_STRIDE]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    __shared__ uint32_t s_mx[16];
+    if (lane_id() == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) mx = max(mx, s_mx[w]);
+        header[0] = R; header[2] = R_alloc; header[3] = mx;
+        // Host mailbox (pinned, host-coherent): the host spins on word 4 instead of paying a hipMemcpyAsync + a blocking
+        // hipStreamSynchronize (whose wake-up alone left the GPU idle for ~60 us per forward pass).
+        if (host_mailbox) {
+            const uint32_t err = __hip_atomic_load(&header[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&host_mailbox[0], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mailbox[1], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mailbox[2], R_alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mailbox[3], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&host_mailbox[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -368,23 +390,44 @@ __device__ __forceinline__ void bitonic_sort_block(KEYS keys, uint32_t npad)
     if (WAVE_LOCAL) __syncthreads();
 }
 
+// Two instantiations: CAP = SORT_SMALL_CAP (8 KiB of LDS: every tile of a 1200-tile frame sorts concurrently) handles the
+// lists of up to 1024 keys; CAP = SORT_LDS_CAP (32 KiB, only 4 blocks per CU) is launched only when some list is longer and
+// handles those (in LDS up to 4096 keys, in global memory beyond). With the 32 KiB variant alone the 1200 blocks of a
+// 640x480 frame did not fit in one residency round and the kernel took two (40 us -> 20 us).
+constexpr int SORT_SMALL_CAP = 1024;
+template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
                                                          uint2* sorted)
 {
-    __shared__ uint64_t s_keys[SORT_LDS_CAP];
+    __shared__ uint64_t s_keys[CAP];
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const uint2 r = ranges[tile];
     const uint32_t n = r.y - r.x;
-    if (n == 0) return;
+    if (n <= (uint32_t)LOWER) return;                       // empty, or the other instantiation's tile
+    if (CAP < SORT_LDS_CAP && n > (uint32_t)CAP) return;
     uint64_t* seg = keys + r.x;
-    if (n <= (uint32_t)SORT_LDS_CAP) {
-        const uint32_t npad = next_pow2(n);
-        for (uint32_t i = threadIdx.x; i < npad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
+    if (n <= (uint32_t)CAP) {
+        // A bitonic network wants a power of two; padding 520 keys to 1024 would more than double the work. Instead the list
+        // is split into A = the largest power of two <= n and the rest (padded to its own power of two), both halves are
+        // sorted, and every key finds its final rank with one binary search in the other half (keys are unique).
+        const uint32_t A = n <= 1 ? n : (1u << (31 - __clz((int)n)));
+        const uint32_t B = n - A, Bpad = B ? next_pow2(B) : 0;
+        for (uint32_t i = threadIdx.x; i < A + Bpad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
         __syncthreads();
-        bitonic_sort_block<true>(s_keys, npad);
+        bitonic_sort_block<true>(s_keys, A);
+        if (B) bitonic_sort_block<true>(s_keys + A, Bpad);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint32_t u = (uint32_t)s_keys[i];
-            sorted[r.x + i] = make_uint2(inst_gauss[u], u);
+            const uint64_t key = s_keys[i];
+            const bool in_a = i < A;
+            const uint64_t* other = in_a ? s_keys + A : s_keys;
+            uint32_t lo = 0, hi = in_a ? B : A;              // number of keys of the other half that are smaller
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (other[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t rank = (in_a ? i : i - A) + lo;
+            const uint32_t u = (uint32_t)key;
+            sorted[r.x + rank] = make_uint2(inst_gauss[u], u);
         }
     } else {
         const uint32_t npad = next_pow2(n);  // segment was allocated with npad entries, tail pre-filled with ~0

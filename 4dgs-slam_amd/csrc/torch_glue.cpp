@@ -1,0 +1,183 @@
+// torch_glue.cpp -- optional native host glue between PyTorch tensors and the C ABI of include/gs_rasterizer.h.
+//
+// It is the counterpart of the reference's torch/pybind layer (submodules/diff-gaussian-rasterization/ext.cpp:15-19 and
+// rasterize_points.cu:35-232; submodules/simple-knn/ext.cpp, spatial.cu:15-26): same entry points, same argument order,
+// same return tuples. All arithmetic stays behind the C ABI (libgs_rasterizer_hip.so); this file only allocates tensors,
+// extracts raw pointers and forwards the caller's HIP stream. The ctypes binding in diff_gaussian_rasterization/_C.py does
+// the same job in Python and remains the fallback; this one exists because at ~0.4 ms of GPU work per forward+backward the
+// Python marshalling (~0.4 ms of host time) was the bottleneck.
+//
+// Pure C++ (no device code, no HIP headers): the stream is passed in as an integer by the Python caller.
+#include <torch/extension.h>
+
+#include <string>
+#include <tuple>
+
+#include "../../include/gs_rasterizer.h"
+#include "../../include/simple_knn.h"
+
+namespace {
+
+constexpr int kChannels = GSR_NUM_CHANNELS;
+
+const float* fptr(const torch::Tensor& t, const char* name)
+{
+    if (!t.defined() || t.numel() == 0) return nullptr;   // empty tensor == nullptr at the boundary
+    TORCH_CHECK(t.is_cuda(), name, " is on '", t.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous (internal error: caller makes it so)");
+    return t.data_ptr<float>();
+}
+
+torch::Tensor contig(const torch::Tensor& t) { return (t.defined() && t.numel() != 0 && !t.is_contiguous()) ? t.contiguous() : t; }
+
+char* resize_cb(void* user, size_t n)   // the resizeFunctional of rasterize_points.cu:27-33
+{
+    auto* t = static_cast<torch::Tensor*>(user);
+    t->resize_({(int64_t)n});
+    return reinterpret_cast<char*>(t->data_ptr());
+}
+
+[[noreturn]] void fail(const char* what, int code)
+{
+    throw std::runtime_error(std::string(what) + " failed (code " + std::to_string(code) + "): " + gsr_last_error());
+}
+
+}  // namespace
+
+// RasterizeGaussiansCUDA, rasterize_points.cu:35-122 (+ the stream)
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& colors_, const torch::Tensor& opacity_,
+                    const torch::Tensor& scales_, const torch::Tensor& rotations_, double scale_modifier, const torch::Tensor& cov3D_,
+                    const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, const torch::Tensor& projmatrix_raw,
+                    double tan_fovx, double tan_fovy, int64_t image_height, int64_t image_width, const torch::Tensor& sh_, int64_t degree,
+                    const torch::Tensor& campos_, bool prefiltered, bool debug, int64_t stream)
+{
+    (void)projmatrix_raw;
+    TORCH_CHECK(means3D_.dim() == 2 && means3D_.size(1) == 3, "means3D must have dimensions (num_points, 3)");   // rasterize_points.cu:58-60
+    TORCH_CHECK(means3D_.is_cuda(), "means3D is on '", means3D_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int P = (int)means3D_.size(0), H = (int)image_height, W = (int)image_width;
+    auto fopt = means3D_.options().dtype(torch::kFloat32);
+    auto iopt = means3D_.options().dtype(torch::kInt32);
+    auto bopt = means3D_.options().dtype(torch::kUInt8);
+    torch::Tensor img = torch::empty({kChannels + 2, H, W}, fopt);
+    torch::Tensor ints = torch::empty({2, P}, iopt);
+    torch::Tensor out_color = img.narrow(0, 0, kChannels), out_depth = img.narrow(0, kChannels, 1), out_opacity = img.narrow(0, kChannels + 1, 1);
+    torch::Tensor radii = ints.select(0, 0), n_touched = ints.select(0, 1);
+    torch::Tensor geomBuffer = torch::empty({0}, bopt), binningBuffer = torch::empty({0}, bopt), imgBuffer = torch::empty({0}, bopt);
+    int rendered = 0;
+    if (P != 0) {
+        const int M = sh_.numel() != 0 ? (int)sh_.size(1) : 0;   // rasterize_points.cu:87-91
+        const torch::Tensor bg = contig(background), means3D = contig(means3D_), colors = contig(colors_), opacity = contig(opacity_),
+                            scales = contig(scales_), rotations = contig(rotations_), cov3D = contig(cov3D_), view = contig(viewmatrix_),
+                            proj = contig(projmatrix_), sh = contig(sh_), campos = contig(campos_);
+        rendered = gsr_forward(resize_cb, &geomBuffer, resize_cb, &binningBuffer, resize_cb, &imgBuffer, P, (int)degree, M,
+                               fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "shs"), fptr(colors, "colors_precomp"),
+                               fptr(opacity, "opacities"), fptr(scales, "scales"), (float)scale_modifier, fptr(rotations, "rotations"),
+                               fptr(cov3D, "cov3D_precomp"), fptr(view, "viewmatrix"), fptr(proj, "projmatrix"), fptr(campos, "campos"),
+                               (float)tan_fovx, (float)tan_fovy, prefiltered ? 1 : 0, out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
+                               out_opacity.data_ptr<float>(), radii.data_ptr<int>(), n_touched.data_ptr<int>(), debug ? 1 : 0,
+                               reinterpret_cast<void*>(stream));
+        if (rendered < 0) fail("gsr_forward", rendered);
+    } else {
+        img.zero_();   // rasterize_points.cu:85: nothing is launched, outputs stay zero
+    }
+    return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth, out_opacity, n_touched);
+}
+
+// RasterizeGaussiansBackwardCUDA, rasterize_points.cu:124-211, plus a 10th result: dL_dtau summed over Gaussians, float32[6]
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch::Tensor& means3D_, const torch::Tensor& radii_,
+                                   const torch::Tensor& colors_, const torch::Tensor& scales_, const torch::Tensor& rotations_,
+                                   double scale_modifier, const torch::Tensor& cov3D_, const torch::Tensor& viewmatrix_,
+                                   const torch::Tensor& projmatrix_, const torch::Tensor& projmatrix_raw_, double tan_fovx, double tan_fovy,
+                                   const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, const torch::Tensor& sh_,
+                                   int64_t degree, const torch::Tensor& campos_, const torch::Tensor& geomBuffer, int64_t R,
+                                   const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, int64_t stream)
+{
+    TORCH_CHECK(means3D_.is_cuda(), "means3D is on '", means3D_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int64_t P = means3D_.size(0);
+    const int H = (int)dL_dout_color_.size(1), W = (int)dL_dout_color_.size(2);
+    const int64_t M = sh_.numel() != 0 ? sh_.size(1) : 0;
+    auto fopt = means3D_.options().dtype(torch::kFloat32);
+    // the kernels write every element: one uninitialised allocation carved into the eleven gradient tensors
+    // (rasterize_points.cu:160-170 allocates and zero-fills eleven)
+    const int64_t widths[11] = {3, 3, kChannels, 1, 4, 1, 6, 3 * M, 3, 4, 6};
+    int64_t total = 6;
+    for (int64_t w : widths) total += P * w;
+    torch::Tensor flat = P == 0 ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);
+    torch::Tensor v[11];
+    int64_t o = 0;
+    for (int i = 0; i < 11; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
+    torch::Tensor dL_dmeans3D = v[0].view({P, 3}), dL_dmeans2D = v[1].view({P, 3}), dL_dcolors = v[2].view({P, kChannels}),
+                  dL_ddepths = v[3].view({P, 1}), dL_dconic = v[4].view({P, 2, 2}), dL_dopacity = v[5].view({P, 1}),
+                  dL_dcov3D = v[6].view({P, 6}), dL_dsh = v[7].view({P, M, 3}), dL_dscales = v[8].view({P, 3}),
+                  dL_drotations = v[9].view({P, 4}), dL_dtau = v[10].view({P, 6});
+    torch::Tensor tau_sum = flat.narrow(0, o, 6);
+    if (P != 0) {
+        const bool sh_path = M > 0 && colors_.numel() == 0;
+        if (M > 0 && !sh_path) dL_dsh.zero_();   // colours were precomputed: the SH branch is not taken (backward.cu:533)
+        const torch::Tensor bg = contig(background), means3D = contig(means3D_), colors = contig(colors_), scales = contig(scales_),
+                            rotations = contig(rotations_), cov3D = contig(cov3D_), view = contig(viewmatrix_), proj = contig(projmatrix_),
+                            proj_raw = contig(projmatrix_raw_), sh = contig(sh_), campos = contig(campos_), radii = contig(radii_),
+                            gc = contig(dL_dout_color_.scalar_type() == torch::kFloat32 ? dL_dout_color_ : dL_dout_color_.to(torch::kFloat32)),
+                            gd = contig(dL_dout_depths_.scalar_type() == torch::kFloat32 ? dL_dout_depths_ : dL_dout_depths_.to(torch::kFloat32));
+        TORCH_CHECK(radii.is_cuda() && radii.scalar_type() == torch::kInt32, "radii must be an int32 device tensor");
+        const int rc = gsr_backward_fused(
+            (int)P, (int)degree, (int)M, (int)R, fptr(bg, "bg"), W, H, fptr(means3D, "means3D"), fptr(sh, "shs"), fptr(colors, "colors_precomp"),
+            fptr(scales, "scales"), (float)scale_modifier, fptr(rotations, "rotations"), fptr(cov3D, "cov3D_precomp"), fptr(view, "viewmatrix"),
+            fptr(proj, "projmatrix"), fptr(proj_raw, "projmatrix_raw"), fptr(campos, "campos"), (float)tan_fovx, (float)tan_fovy,
+            radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()), reinterpret_cast<char*>(binningBuffer.data_ptr()),
+            reinterpret_cast<char*>(imageBuffer.data_ptr()), fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), dL_dmeans2D.data_ptr<float>(),
+            dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(), dL_ddepths.data_ptr<float>(),
+            dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), sh_path ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
+            dL_drotations.data_ptr<float>(), dL_dtau.data_ptr<float>(), tau_sum.data_ptr<float>(), debug ? 1 : 0, reinterpret_cast<void*>(stream));
+        if (rc < 0) fail("gsr_backward", rc);
+    }
+    return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum);
+}
+
+// markVisible, rasterize_points.cu:213-232
+torch::Tensor mark_visible(const torch::Tensor& means3D_, const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, int64_t stream)
+{
+    TORCH_CHECK(means3D_.is_cuda(), "means3D is on '", means3D_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int P = (int)means3D_.size(0);
+    torch::Tensor present = torch::zeros({P}, means3D_.options().dtype(torch::kBool));
+    if (P != 0) {
+        const torch::Tensor m = contig(means3D_), v = contig(viewmatrix_), pr = contig(projmatrix_);
+        const int rc = gsr_mark_visible(P, fptr(m, "means3D"), fptr(v, "viewmatrix"), fptr(pr, "projmatrix"),
+                                        reinterpret_cast<unsigned char*>(present.data_ptr()), reinterpret_cast<void*>(stream));
+        if (rc < 0) fail("gsr_mark_visible", rc);
+    }
+    return present;
+}
+
+// distCUDA2, simple-knn/spatial.cu:15-26
+torch::Tensor dist_cuda2(const torch::Tensor& points_, int64_t stream)
+{
+    TORCH_CHECK(points_.is_cuda(), "points is on '", points_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int P = (int)points_.size(0);
+    torch::Tensor means = torch::zeros({P}, points_.options().dtype(torch::kFloat32));
+    if (P != 0) {
+        const torch::Tensor pts = contig(points_);
+        torch::Tensor ws = torch::empty({(int64_t)gsr_knn_workspace_size(P)}, points_.options().dtype(torch::kUInt8));
+        const int rc = gsr_knn_mean_dist2(P, fptr(pts, "points"), means.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()),
+                                          reinterpret_cast<void*>(stream));
+        if (rc < 0) fail("gsr_knn_mean_dist2", rc);
+    }
+    return means;
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.def("rasterize_gaussians", &rasterize_gaussians);
+    m.def("rasterize_gaussians_backward_fused", &rasterize_gaussians_backward_fused);
+    m.def("mark_visible", &mark_visible);
+    m.def("dist_cuda2", &dist_cuda2);
+}

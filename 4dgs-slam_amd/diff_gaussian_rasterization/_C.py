@@ -25,6 +25,28 @@ NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 _lib = None
 
+# Two interchangeable host bindings of the same C ABI:
+#   "native": csrc/torch_glue.cpp compiled into _glue*.so (tensor allocation + pointer extraction in C++, ~10x less host time)
+#   "ctypes": the pure-Python marshalling below (always available once the HIP library is built)
+# GSR_GLUE=ctypes|native forces one; by default the native glue is used when it has been built.
+_glue = None
+_glue_error = None
+if os.environ.get("GSR_GLUE", "native") != "ctypes":
+    try:
+        from . import _glue  # type: ignore
+    except Exception as _e:  # not built (or built for another torch): fall back to ctypes, loudly only if it was requested
+        _glue, _glue_error = None, _e
+        if os.environ.get("GSR_GLUE") == "native":
+            raise ImportError(f"GSR_GLUE=native but the native glue cannot be imported: {_e}") from _e
+
+
+def binding() -> str:
+    return "native" if _glue is not None else "ctypes"
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
 
 def load_library():
     """dlopen the HIP library (no GPU needed just to load it) and declare the C signatures."""
@@ -44,6 +66,8 @@ def load_library():
     lib.gsr_backward.restype = i
     lib.gsr_backward.argtypes = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, f, f, vp,
                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+    lib.gsr_backward_fused.restype = i
+    lib.gsr_backward_fused.argtypes = lib.gsr_backward.argtypes[:-2] + [vp, i, vp]
     lib.gsr_mark_visible.restype = i
     lib.gsr_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
     lib.gsr_last_error.restype = C.c_char_p
@@ -107,19 +131,23 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:58-60
     _require_device(means3D, "means3D")
+    if _glue is not None:
+        with torch.cuda.device(means3D.device):
+            return _glue.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
+                                             viewmatrix, projmatrix, projmatrix_raw, float(tan_fovx), float(tan_fovy), int(image_height),
+                                             int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug), _stream(means3D.device))
     lib = load_library()
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(image_height), int(image_width)
-    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-    out_opacity = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    n_touched = torch.empty((P,), dtype=torch.int32, device=dev)
-    geom, binning, img = _Arena(dev), _Arena(dev), _Arena(dev)
+    # one float and one int allocation instead of five (allocator round trips are host time the GPU spends idle)
+    img = torch.empty((NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+    out_color, out_depth, out_opacity = img[:NUM_CHANNELS], img[NUM_CHANNELS:NUM_CHANNELS + 1], img[NUM_CHANNELS + 1:]
+    ints = torch.empty((2, P), dtype=torch.int32, device=dev)
+    radii, n_touched = ints[0], ints[1]
+    geom, binning, imgbuf = _Arena(dev), _Arena(dev), _Arena(dev)
     if P == 0:  # rasterize_points.cu:85: nothing is launched, outputs stay zero
-        for t in (out_color, out_depth, out_opacity):
-            t.zero_()
-        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor, out_depth, out_opacity, n_touched
+        img.zero_()
+        return 0, out_color, radii, geom.tensor, binning.tensor, imgbuf.tensor, out_depth, out_opacity, n_touched
     M = int(sh.shape[1]) if sh.numel() != 0 else 0  # rasterize_points.cu:87-91
     keep = []
 
@@ -135,7 +163,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.gsr_forward(
-            geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M,
+            geom.cb, None, binning.cb, None, imgbuf.cb, None, P, int(degree), M,
             p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "shs"), p(colors, "colors_precomp"), p(opacity, "opacities"),
             p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
             p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(campos, "campos"),
@@ -144,33 +172,48 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             int(bool(debug)), stream)
     if rc < 0:
         _err(lib, rc, "gsr_forward")
-    return rc, out_color, radii, geom.tensor, binning.tensor, img.tensor, out_depth, out_opacity, n_touched
+    return rc, out_color, radii, geom.tensor, binning.tensor, imgbuf.tensor, out_depth, out_opacity, n_touched
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depths,
                                  sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
     """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:124-211): same 23 arguments, same 9-tuple."""
+    return rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                              viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
+                                              dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug)[:9]
+
+
+def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                       viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depths,
+                                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """Same as rasterize_gaussians_backward plus a 10th result: dL_dtau summed over the Gaussians, float32[6] = [rho, theta]
+    (the reduction the reference's autograd Function does with torch.sum, __init__.py:152-154, fused into the kernels)."""
     _require_device(means3D, "means3D")
+    if _glue is not None:
+        with torch.cuda.device(means3D.device):
+            return _glue.rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, float(scale_modifier),
+                                                            cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, float(tan_fovx),
+                                                            float(tan_fovy), dL_dout_color, dL_dout_depths, sh, int(degree), campos,
+                                                            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug), _stream(means3D.device))
     lib = load_library()
     dev = means3D.device
     P = int(means3D.shape[0])
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
     M = int(sh.shape[1]) if sh.numel() != 0 else 0
-    f32 = dict(dtype=torch.float32, device=dev)
-    # the kernels write every element, so torch.empty replaces the 11 zero-fills of rasterize_points.cu:160-170
-    alloc = torch.zeros if P == 0 else torch.empty
-    dL_dmeans3D = alloc((P, 3), **f32)
-    dL_dmeans2D = alloc((P, 3), **f32)
-    dL_dcolors = alloc((P, NUM_CHANNELS), **f32)
-    dL_ddepths = alloc((P, 1), **f32)
-    dL_dconic = alloc((P, 2, 2), **f32)
-    dL_dopacity = alloc((P, 1), **f32)
-    dL_dcov3D = alloc((P, 6), **f32)
-    dL_dsh = alloc((P, M, 3), **f32)
-    dL_dscales = alloc((P, 3), **f32)
-    dL_drotations = alloc((P, 4), **f32)
-    dL_dtau = alloc((P, 6), **f32)
+    # The kernels write every element, so one torch.empty carved into views replaces the eleven torch.zeros of
+    # rasterize_points.cu:160-170 (eleven allocator calls + eleven memsets of host/GPU time per backward).
+    widths = [3, 3, NUM_CHANNELS, 1, 4, 1, 6, 3 * M, 3, 4, 6]   # means3D, means2D, colors, depths, conic, opacity, cov3D, sh, scales, rot, tau
+    flat = (torch.zeros if P == 0 else torch.empty)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
+    views, o = [], 0
+    for w_ in widths:
+        views.append(flat[o:o + P * w_])
+        o += P * w_
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = views[0].view(P, 3), views[1].view(P, 3), views[2].view(P, NUM_CHANNELS)
+    dL_ddepths, dL_dconic, dL_dopacity = views[3].view(P, 1), views[4].view(P, 2, 2), views[5].view(P, 1)
+    dL_dcov3D, dL_dsh, dL_dscales = views[6].view(P, 6), views[7].view(P, M, 3), views[8].view(P, 3)
+    dL_drotations, dL_dtau = views[9].view(P, 4), views[10].view(P, 6)
+    tau_sum = flat[o:o + 6]
     if P != 0:
         keep = []
 
@@ -181,28 +224,34 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             keep.append(tc)
             return ptr
 
-        if M > 0 and colors.numel() != 0:
+        sh_path = M > 0 and colors.numel() == 0
+        if M > 0 and not sh_path:
             dL_dsh.zero_()  # colours were precomputed: the SH branch is not taken (backward.cu:533)
+        gc = dL_dout_color if dL_dout_color.dtype == torch.float32 else dL_dout_color.to(torch.float32)
+        gd = dL_dout_depths if dL_dout_depths.dtype == torch.float32 else dL_dout_depths.to(torch.float32)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = lib.gsr_backward(
+            rc = lib.gsr_backward_fused(
                 P, int(degree), M, int(R), p(background, "bg"), W, H, p(means3D, "means3D"), p(sh, "shs"), p(colors, "colors_precomp"),
                 p(scales, "scales"), float(scale_modifier), p(rotations, "rotations"), p(cov3D_precomp, "cov3D_precomp"),
                 p(viewmatrix, "viewmatrix"), p(projmatrix, "projmatrix"), p(projmatrix_raw, "projmatrix_raw"), p(campos, "campos"),
                 float(tan_fovx), float(tan_fovy), p(radii, "radii"),
                 geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
-                p(dL_dout_color.to(torch.float32), "dL_dout_color"), p(dL_dout_depths.to(torch.float32), "dL_dout_depth"),
+                p(gc, "dL_dout_color"), p(gd, "dL_dout_depth"),
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
-                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if (M > 0 and colors.numel() == 0) else None,
-                dL_dscales.data_ptr(), dL_drotations.data_ptr(), dL_dtau.data_ptr(), int(bool(debug)), stream)
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if sh_path else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), dL_dtau.data_ptr(), tau_sum.data_ptr(), int(bool(debug)), stream)
         if rc < 0:
             _err(lib, rc, "gsr_backward")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible (rasterize_points.cu:213-232)."""
     _require_device(means3D, "means3D")
+    if _glue is not None:
+        with torch.cuda.device(means3D.device):
+            return _glue.mark_visible(means3D, viewmatrix, projmatrix, _stream(means3D.device))
     lib = load_library()
     P = int(means3D.shape[0])
     present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)

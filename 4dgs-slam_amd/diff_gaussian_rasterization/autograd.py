@@ -45,6 +45,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.set_materialize_grads(False)   # unused cotangents (opacity, radii, n_touched) arrive as None, not as zero-filled tensors
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
         return color, radii, depth, opacity, n_touched
 
@@ -61,11 +62,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 *_camera_block(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos,
                 geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
-        (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau) = _call(
-            _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump",
+        (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau, tau) = _call(
+            _C.rasterize_gaussians_backward_fused, args, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-        # per-Gaussian [rho | theta] rows -> one pose gradient, each returned as [1,3] (reference :152-154)
-        tau = g_tau.view(-1, 6).sum(dim=0)
+        # per-Gaussian [rho | theta] rows -> one pose gradient, each returned as [1,3] (reference :152-154: torch.sum over [P,6]);
+        # the sum is produced by the backward kernels themselves (tau = float32[6])
         g_rho, g_theta = tau[:3].view(1, -1), tau[3:].view(1, -1)
         # one gradient per forward input, in input order (reference :157-169)
         return (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rot, g_cov3D, g_theta, g_rho, None)

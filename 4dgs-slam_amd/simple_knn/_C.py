@@ -6,6 +6,7 @@ import ctypes as C
 
 import torch
 
+from diff_gaussian_rasterization import _C as _rast
 from diff_gaussian_rasterization._C import load_library, _err, _require_device
 
 _declared = False
@@ -26,6 +27,11 @@ def _lib():
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     """float[P]: mean squared distance of every point to its 3 nearest other points (spatial.cu:15-26)."""
     _require_device(points, "points")
+    if points.dtype != torch.float32:
+        raise RuntimeError(f"points must be float32, got {points.dtype}")
+    if _rast._glue is not None:
+        with torch.cuda.device(points.device):
+            return _rast._glue.dist_cuda2(points, torch.cuda.current_stream(points.device).cuda_stream)
     lib = _lib()
     P = int(points.shape[0])
     means = torch.zeros((P,), dtype=torch.float32, device=points.device)  # spatial.cu:21 (torch::full 0)

@@ -81,6 +81,20 @@ int gsr_backward(int P, int D, int M, int R,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtau,
                  int debug, void* stream);
 
+/* gsr_backward plus one fused extra: dL_dtau_sum[6] = sum over Gaussians of dL_dtau (what the reference's Python layer computes
+ * with torch.sum, DGR/diff_gaussian_rasterization/__init__.py:152-154). Pass NULL to skip. */
+int gsr_backward_fused(int P, int D, int M, int R,
+                       const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw, const float* campos,
+                       float tan_fovx, float tan_fovy, const int* radii,
+                       char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* dL_dpix, const float* dL_dpix_depth,
+                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtau,
+                       float* dL_dtau_sum, int debug, void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-22 / rasterizer_impl.cu:54-66,141-153): present[i] = (z_view > 0.2). */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      unsigned char* present, void* stream);
