@@ -201,14 +201,15 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
     const float gd = inside ? dL_dpix_depth[pix] : 0.f;
     const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742 (loop invariant)
-    // The reference keeps accum_rec[3] + accum_rec_depth ("what lies behind") per channel and dots it with dL_dpixel
-    // every step (:714-728). Only that dot product is ever used, and the recurrence is linear, so the dot is taken first:
-    // acc = accum_rec . dL_dpixel,  last_cg = last_color . dL_dpixel  -- 9 VALU ops per pair instead of 24.
-    float acc = 0.f, last_a = 0.f, last_cg = 0.f;
-    // per-lane constants of the transposed reduction: which of the ten sums this lane ends up holding and its scale
-    // factor (:643-644 ddelx_dx, ddely_dy; the -1/2 of :754-756)
+    // State per pixel: T (transmittance in front of the current entry) and
+    //   Sb = T_final * (bg . dL_dpixel) + sum over the entries already visited (those behind) of alpha_k T_k (c_k . dL_dpixel).
+    // The reference carries the normalised "colour behind" accum_rec[3] + accum_rec_depth and last_alpha/last_color (:714-728)
+    // and adds the background term separately (:738-743); with acc_i = S_i / (T_i (1 - alpha_i)) its
+    //   dL_dalpha_i = (c_i - acc_i).g T_i - T_final/(1 - alpha_i) bg.g   becomes   (c_i . g) T_i - Sb_i / (1 - alpha_i),
+    // which needs no per-channel state and -- because an invalid pair simply has alpha = 0 -- no selects on the state.
+    float Sb = Tfin * bgdot;
+    // which of the ten sums this lane ends up holding after the transposed reduction
     const int fi = wave_sum10_slot_of_lane(lane);
-    const float red_scale = fi == 0 ? 0.5f * W : fi == 1 ? 0.5f * H : fi <= 4 ? -0.5f : 1.0f;
     float* const part_lane = &s_part[wave][0][fi];
     const bool store_lane = lane < 10;
 
@@ -261,44 +262,49 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                     continue;
                 }
 #endif
-                const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = valid ? T * inv1ma : T;                                                           // :700
-                const float wv = valid ? alpha * T : 0.f;                                             // :701 dchannel_dcolor
+                const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
+                const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
+                const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
+                T *= inv1ma;                                                                           // :700
+                const float wv = av * T;                                                               // :701 dchannel_dcolor
                 const float cg = C4.x * gr + C4.y * gg + C4.z * gb + B4.z * gd;                      // colour.dL_dpixel + depth*dL_ddepth
-                acc = valid ? last_a * last_cg + (1.f - last_a) * acc : acc;                          // :714,:726
-                last_cg = valid ? cg : last_cg;                                                        // :715,:727
-                float dL_dalpha = cg - acc;                                                            // :718,:728
-                dL_dalpha *= T;                                                                        // :732
-                last_a = valid ? alpha : last_a;
-                dL_dalpha += (-Tfin * inv1ma) * bgdot;                                                 // :743
-                const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of masked products
-                const float dL_dG = valid ? B4.y * dL_dalpha : 0.f;                                   // :746
-                const float gdx = Gv * dx, gdy = Gv * dy;
-                const float tgx = gdx * dL_dG, tgy = gdy * dL_dG;
-                const float s_m2x = dL_dG * (-gdx * A4.z - gdy * A4.w);                               // :749-753
-                const float s_m2y = dL_dG * (-gdy * B4.x - gdx * A4.w);
-                const float s_cx = tgx * dx, s_cy = tgx * dy, s_cw = tgy * dy;                        // :754-756 (x -1/2 via red_scale)
-                const float s_op = Gv * dL_dalpha;                                                     // :757
-#if GSR_EXP == 4
-                const float tot = s_m2x + s_m2y + s_cx + s_cy + s_cw + s_op + wv * gr + wv * gg + wv * gb + wv * gd;
-#else
-                const float tot = wave_sum10_transposed(s_m2x, s_m2y, s_cx, s_cy, s_cw, s_op, wv * gr, wv * gg, wv * gb, wv * gd);
-#endif
-                if (store_lane) *dst = tot * red_scale;
+                const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
+                Sb += wv * cg;
+                // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
+                //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
+                //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
+                const float s_op = Gv * dL_dalpha;
+                const float q = B4.y * s_op;
+                const float qx = q * dx, qy = q * dy;
+                const float tot = wave_sum10_transposed(s_op, qx, qy, qx * dx, qx * dy, qy * dy, wv * gr, wv * gg, wv * gb, wv * gd);
+                if (store_lane) *dst = tot;
             }
         }
         __syncthreads();
-        // add the four quadrants in a fixed order and write each instance's slot (12 floats, 48 B) coalesced
+        // Add the four quadrants in a fixed order, turn the moments into the reference's gradients and write each instance's
+        // slot (12 floats, 48 B) coalesced.  s_part[q][j][] = {sum G dL_dalpha, M1x, M1y, M2xx, M2xy, M2yy, r, g, b, depth}
         const int m = min(BB, n - base);
-        for (int idx = t; idx < m * 12; idx += RB) {
-            const int j = idx / 12, c = idx - j * 12;
-            float v = 0.f;
-            if (c < 10) {
-                const uint32_t bits = __float_as_uint(s_c[j].w);
+        if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
+            const int j = t;
+            const uint32_t bits = __float_as_uint(s_c[j].w);
+            float sum[10];
 #pragma unroll
-                for (int q = 0; q < 4; q++) v += ((bits >> q) & 1u) ? s_part[q][j][c] : 0.f;
+            for (int k = 0; k < 10; k++) sum[k] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if ((bits >> q) & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
+                }
             }
-            partials[(size_t)__float_as_uint(s_b[j].w) * 12 + c] = v;
+            const float4 A4 = s_a[j];                       // {mean.x, mean.y, conic.x, conic.y}
+            const float4 B4 = s_b[j];                       // {conic.z, opacity, depth, instance id}
+            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.w) * 3;
+            slot[0] = make_float4(-(A4.z * sum[1] + A4.w * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
+                                  -(B4.x * sum[2] + A4.w * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
+                                  -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
+            slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
+            slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
         }
     }
 }
