@@ -63,13 +63,13 @@ struct GeomState {
 };
 static inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
 struct ImageState {
-    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
+    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor; uint32_t* work_counters;
     uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
     static ImageState from(char*& p, size_t N, size_t T, size_t P)
     {
         ImageState s;
         carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T * CTR_STRIDE);
-        carve(p, s.tile_cursor, T * CTR_STRIDE);
+        carve(p, s.tile_cursor, T * CTR_STRIDE); carve(p, s.work_counters, 64);
         carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
         return s;
     }
@@ -385,9 +385,17 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
     if (R > 0) {
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, background,
+        static const int persist = getenv("GSR_PERSIST_BLOCKS") ? atoi(getenv("GSR_PERSIST_BLOCKS")) : 0;
+        uint32_t* counter = nullptr;
+        int grid = T;
+        if (persist > 0 && persist < T) {
+            counter = img.work_counters + 32;
+            grid = persist;
+            GSR_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
+        }
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, background,
                            geom.means2D, geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth,
-                           reinterpret_cast<float*>(bin.partials));
+                           reinterpret_cast<float*>(bin.partials), counter);
     }
     GSR_STAGE("render_bwd");
     GeomBwdArgs a;

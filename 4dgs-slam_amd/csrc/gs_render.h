@@ -10,6 +10,7 @@
 // its masks (scalar s_ff1 loop), so a (wave, Gaussian) pair that cannot contribute costs nothing: no exp, no
 // reduction. The cull is conservative (a superset of the pairs the reference blends), so results are unchanged.
 #pragma once
+#include <type_traits>
 #include "gs_forward.h"
 #ifndef GSR_EXP
 #define GSR_EXP 0
@@ -44,6 +45,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, f
     const bool yt = gy - ey <= Y0 + 7.f && gy + ey >= Y0;
     const bool yb = gy - ey <= Y0 + 15.f && gy + ey >= Y0 + 8.f;
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+// j = index of the lowest set bit of m; clears it.  Two SALU instructions (the C idiom m &= m - 1 costs three plus the ff1).
+__device__ __forceinline__ int pop_lowest_bit(unsigned long long& m)
+{
+    int j;
+    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
+    return j;
 }
 
 __device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned long long* p)
@@ -110,12 +119,13 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         __syncthreads();
         // The saturation test is per 64-entry group, not per entry: a per-entry wave vote + branch serialises the loop on the
         // VALU->SALU round trip (measured: 111 -> 86 us), and pixels that are done blend nothing anyway.
-        for (int sw = 0; sw < 4; sw++) {
-            if (__all(done)) break;
-            unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
+        // Per 64-entry group the wave re-votes two things: whether any of its pixels is still unsaturated (else it skips the
+        // group), and whether any pixel still has T > 0.5 -- only then can an entry bump n_touched (forward.cu:369-371), and
+        // the loop variant without that bookkeeping is ~8 instructions per pair shorter. Every instruction (VALU, SALU, LDS,
+        // branch alike) costs this kernel one 4-cycle issue slot per SIMD, so they are counted alike.
+        auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int jbase) {
             while (m) {
-                const int j = sw * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+                const int j = jbase + pop_lowest_bit(m);
                 const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
                 const float dx = A4.x - pxf, dy = A4.y - pyf;
                 const float power2 = dx * (A4.z * dx + A4.w * dy) + B4.x * dy * dy;               // forward.cu:345 (times log2 e)
@@ -129,9 +139,19 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                 Cr += C4.x * w; Cg += C4.y * w; Cb += C4.z * w; Dd += B4.z * w;                    // :364-367
                 T = blend ? test_T : T;
                 last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
-                const unsigned long long tm = __ballot(blend && test_T > 0.5f);                    // :369-371
-                if (tm && lane == 0) atomicAdd(&s_nt[j], (int)__popcll(tm));                       // LDS; only the front-most layers take it
+                if (COUNT_TOUCHED.value) {
+                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(blend && test_T > 0.5f);   // :369-371
+                    if (tm) {
+                        if (lane == 0) atomicAdd(&s_nt[j], (int)__popcll(tm));                     // LDS; flushed once per batch
+                    }
+                }
             }
+        };
+        for (int sw = 0; sw < 4; sw++) {
+            if (__all(done)) break;
+            const unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
+            if (__any(!done && T > 0.5f)) composite(std::true_type{}, m, sw * 64);
+            else composite(std::false_type{}, m, sw * 64);
         }
     }
     __syncthreads();
@@ -166,13 +186,13 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int BB = 128;   // entries per staged batch in the backward kernel (LDS: 6 KiB staging + 20 KiB quadrant totals)
 
-__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                        const uint2* __restrict__ sorted, int W, int H,
-                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
-                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
-                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
-                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                        const float* __restrict__ dL_dpix_depth, float* __restrict__ partials)
+__device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const uint2* __restrict__ ranges,
+                                                const uint2* __restrict__ sorted, int W, int H,
+                                                const float* __restrict__ bg, const float2* __restrict__ means2D,
+                                                const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
+                                                const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                const float* __restrict__ dL_dpix_depth, float* __restrict__ partials)
 {
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, conic.x, conic.y}
     __shared__ float4 s_b[BB];   // {conic.z, opacity, depth, instance id bits}
@@ -181,7 +201,6 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     __shared__ unsigned long long s_mask[4][2];
     __shared__ int s_wmax[4];
 
-    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
     const int px = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
@@ -246,8 +265,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         for (int sw = 0; sw < 2; sw++) {
             unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
             while (m) {
-                const int j = sw * 64 + __builtin_ctzll(m);
-                m &= m - 1;
+                const int j = sw * 64 + pop_lowest_bit(m);
                 const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
                 const int pos = n - 1 - (base + j);
                 const float dx = A4.x - pxf, dy = A4.y - pyf;
@@ -306,6 +324,35 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
             slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
         }
+    }
+}
+
+// Launch wrapper. tile_counter == nullptr: one block per tile (XCD-banded order). Otherwise `gridDim.x` persistent blocks pull
+// tile indices from a global counter until the frame is done: per-tile work varies by +-40 % (early saturation, culling), and
+// with every tile resident at once a launch lasts as long as its unluckiest SIMD; pulling tiles dynamically evens that out.
+__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint2* __restrict__ sorted, int W, int H,
+                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
+                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
+                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                        const float* __restrict__ dL_dpix_depth, float* __restrict__ partials,
+                                                        uint32_t* tile_counter)
+{
+    if (tile_counter == nullptr) {
+        render_bwd_tile(xcd_tile_of_block(blockIdx.x, ntiles), gx, ranges, sorted, W, H, bg, means2D, conic_opacity, feat, depths, final_T,
+                        n_contrib, dL_dpix, dL_dpix_depth, partials);
+        return;
+    }
+    __shared__ int s_next;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (int)atomicAdd(tile_counter, 1u);
+        __syncthreads();
+        const int k = s_next;
+        if (k >= ntiles) break;
+        render_bwd_tile(k, gx, ranges, sorted, W, H, bg, means2D, conic_opacity, feat, depths, final_T, n_contrib, dL_dpix, dL_dpix_depth,
+                        partials);
     }
 }
 
