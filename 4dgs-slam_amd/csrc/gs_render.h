@@ -19,6 +19,7 @@
 namespace gsr {
 
 constexpr int RB = 256;   // entries per staged batch == threads per block
+typedef float f2 __attribute__((ext_vector_type(2)));   // arithmetic on f2 lowers to v_pk_{add,mul,fma}_f32: two fp32 ops per issue slot
 
 // Bounding box test of {p : o*exp(power(p)) >= 1/255} against the four 8x8 quadrants of tile (tx,ty).
 // power(d) = -1/2 d^T Q d with Q = [[a,b],[b,c]] (the conic); the level set power >= -tau is an ellipse with
@@ -75,8 +76,8 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         int* __restrict__ n_touched)
 {
     __shared__ float4 s_a[RB];      // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
-    __shared__ float4 s_b[RB];      // {C, opacity, depth, gaussian id bits}
-    __shared__ float4 s_c[RB];      // {r, g, b, -}
+    __shared__ float4 s_b[RB];      // {C, opacity, -, gaussian id bits}
+    __shared__ float4 s_c[RB];      // {r, g, b, depth}: two packed FMAs per blended entry
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
     __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
 
@@ -89,7 +90,9 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     const bool inside = px < W && py < H;
     bool done = !inside;
     s_nt[t] = 0;
-    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dd = 0.f;
+    float T = 1.0f;
+    f2 acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};   // (C.r, C.g) and (C.b, D): accumulated with v_pk_fma_f32
+    const f2 pxy = {pxf, pyf};
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -108,8 +111,8 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             const float4 co = conic_opacity[e.x];
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
             s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
-            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, depths[e.x], __uint_as_float(e.x));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], 0.f);
+            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, 0.f, __uint_as_float(e.x));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -126,17 +129,20 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int jbase) {
             while (m) {
                 const int j = jbase + pop_lowest_bit(m);
-                const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
-                const float dx = A4.x - pxf, dy = A4.y - pyf;
-                const float power2 = dx * (A4.z * dx + A4.w * dy) + B4.x * dy * dy;               // forward.cu:345 (times log2 e)
-                const float alpha = fminf(0.99f, B4.y * __builtin_amdgcn_exp2f(power2));           // :353
+                const float4 A4 = s_a[j];
+                const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
+                const float4 C4 = s_c[j];
+                const f2 d = f2{A4.x, A4.y} - pxy;
+                const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;           // forward.cu:345 (times log2 e)
+                const float alpha = fminf(0.99f, B2.y * __builtin_amdgcn_exp2f(power2));           // :353
                 const bool valid = !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;              // :346,:354
                 const float test_T = T * (1.0f - alpha);
                 const bool stop = valid && test_T < 0.0001f;                                        // :358-362
                 const bool blend = valid && !stop;
                 done = done || stop;
                 const float w = blend ? alpha * T : 0.0f;
-                Cr += C4.x * w; Cg += C4.y * w; Cb += C4.z * w; Dd += B4.z * w;                    // :364-367
+                acc_rg += f2{C4.x, C4.y} * w;                                                       // :364-367
+                acc_bd += f2{C4.z, C4.w} * w;
                 T = blend ? test_T : T;
                 last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
                 if (COUNT_TOUCHED.value) {
@@ -163,10 +169,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = T;
         n_contrib[pix] = last;
-        out_color[pix] = Cr + T * bg[0];                                                            // forward.cu:384-390
-        out_color[(size_t)H * W + pix] = Cg + T * bg[1];
-        out_color[2 * (size_t)H * W + pix] = Cb + T * bg[2];
-        out_depth[pix] = Dd;
+        out_color[pix] = acc_rg.x + T * bg[0];                                                      // forward.cu:384-390
+        out_color[(size_t)H * W + pix] = acc_rg.y + T * bg[1];
+        out_color[2 * (size_t)H * W + pix] = acc_bd.x + T * bg[2];
+        out_depth[pix] = acc_bd.y;
         out_opacity[pix] = 1.0f - T;
     }
 }
@@ -194,9 +200,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                                                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                 const float* __restrict__ dL_dpix_depth, float* __restrict__ partials)
 {
-    __shared__ float4 s_a[BB];   // {mean.x, mean.y, conic.x, conic.y}
-    __shared__ float4 s_b[BB];   // {conic.z, opacity, depth, instance id bits}
-    __shared__ float4 s_c[BB];   // {r, g, b, quadrant mask bits}
+    __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
+    __shared__ float4 s_b[BB];   // {C, opacity, instance id bits, quadrant mask bits}               (C = -c/2 log2e)
+    __shared__ float4 s_c[BB];   // {r, g, b, depth}
+    __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, -}: only the per-entry epilogue needs the unscaled conic
     __shared__ float s_part[4][BB][10];
     __shared__ unsigned long long s_mask[4][2];
     __shared__ int s_wmax[4];
@@ -227,6 +234,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
     //   dL_dalpha_i = (c_i - acc_i).g T_i - T_final/(1 - alpha_i) bg.g   becomes   (c_i . g) T_i - Sb_i / (1 - alpha_i),
     // which needs no per-channel state and -- because an invalid pair simply has alpha = 0 -- no selects on the state.
     float Sb = Tfin * bgdot;
+    const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
     // which of the ten sums this lane ends up holding after the transposed reduction
     const int fi = wave_sum10_slot_of_lane(lane);
     float* const part_lane = &s_part[wave][0][fi];
@@ -250,10 +258,13 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #pragma unroll
             for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
-            s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_b[t] = make_float4(co.z, co.w, depths[e.x], __uint_as_float(e.y));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], __uint_as_float(qm));
+            s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, __uint_as_float(e.y), __uint_as_float(qm));
+            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
+            s_d[t] = make_float4(co.x, co.y, co.z, 0.f);
         }
+        // pos < last_contrib (:678)  <=>  j >= n - base - last_contrib, with j the index inside this batch
+        const int j_thr = n - base - last_contrib;
         if (wave < 2) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -266,13 +277,13 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
             unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
             while (m) {
                 const int j = sw * 64 + pop_lowest_bit(m);
-                const float4 A4 = s_a[j], B4 = s_b[j], C4 = s_c[j];
-                const int pos = n - 1 - (base + j);
-                const float dx = A4.x - pxf, dy = A4.y - pyf;
-                const float power = -0.5f * (A4.z * dx * dx + B4.x * dy * dy) - A4.w * dx * dy;      // :684
-                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
-                const float alpha = fminf(0.99f, B4.y * G);                                           // :688 (clamp has no gradient mask, Q23)
-                const bool valid = pos < last_contrib && power <= 0.0f && alpha >= 1.0f / 255.0f;    // :678,:685,:689
+                const float4 A4 = s_a[j];
+                const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
+                const f2 d = f2{A4.x, A4.y} - pxy;
+                const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;             // :684 (times log2 e)
+                const float G = __builtin_amdgcn_exp2f(power2);
+                const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
+                const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
                 float* const dst = part_lane + j * 10;
 #if GSR_EXP != 5
                 if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
@@ -280,21 +291,25 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                     continue;
                 }
 #endif
+                const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
                 const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
                 const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
                 const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
                 T *= inv1ma;                                                                           // :700
                 const float wv = av * T;                                                               // :701 dchannel_dcolor
-                const float cg = C4.x * gr + C4.y * gg + C4.z * gb + B4.z * gd;                      // colour.dL_dpixel + depth*dL_ddepth
+                const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
+                const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
                 const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
                 Sb += wv * cg;
                 // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
                 //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
                 //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
                 const float s_op = Gv * dL_dalpha;
-                const float q = B4.y * s_op;
-                const float qx = q * dx, qy = q * dy;
-                const float tot = wave_sum10_transposed(s_op, qx, qy, qx * dx, qx * dy, qy * dy, wv * gr, wv * gg, wv * gb, wv * gd);
+                const float q = B2.y * s_op;
+                const f2 q1 = d * q;                  // (q dx, q dy)
+                const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
+                const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
+                const float tot = wave_sum10_transposed(s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
                 if (store_lane) *dst = tot;
             }
         }
@@ -304,7 +319,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
         const int m = min(BB, n - base);
         if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
             const int j = t;
-            const uint32_t bits = __float_as_uint(s_c[j].w);
+            const float4 B4 = s_b[j];                       // {C, opacity, instance id, quadrant mask}
+            const uint32_t bits = __float_as_uint(B4.w);
             float sum[10];
 #pragma unroll
             for (int k = 0; k < 10; k++) sum[k] = 0.f;
@@ -315,11 +331,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                     for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
                 }
             }
-            const float4 A4 = s_a[j];                       // {mean.x, mean.y, conic.x, conic.y}
-            const float4 B4 = s_b[j];                       // {conic.z, opacity, depth, instance id}
-            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.w) * 3;
-            slot[0] = make_float4(-(A4.z * sum[1] + A4.w * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
-                                  -(B4.x * sum[2] + A4.w * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
+            const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z}
+            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.z) * 3;
+            slot[0] = make_float4(-(K4.x * sum[1] + K4.y * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
+                                  -(K4.z * sum[2] + K4.y * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
                                   -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
             slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
             slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
