@@ -23,8 +23,6 @@
 namespace gsr {
 
 static thread_local std::string g_last_error;
-static int g_fwd_ppl = 4;
-static int g_bwd_ppl = 4;
 
 #define GSR_HIP_CHECK(expr)                                                                              \
     do {                                                                                                 \
@@ -195,14 +193,6 @@ size_t gsr_image_buffer_size(int width, int height, int P)
     return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T, (size_t)P); });
 }
 size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc); }); }
-
-int gsr_set_render_ppl(int forward_ppl, int backward_ppl)
-{
-    auto ok = [](int v) { return v == 1 || v == 2 || v == 4; };
-    if (ok(forward_ppl)) g_fwd_ppl = forward_ppl;
-    if (ok(backward_ppl)) g_bwd_ppl = backward_ppl;
-    return g_fwd_ppl * 10 + g_bwd_ppl;
-}
 
 int gsr_profile_enable(int kernel_mask) { g_prof.mask = (unsigned)kernel_mask; return K_COUNT; }
 void gsr_profile_reset(void)

@@ -12,9 +12,6 @@
 #pragma once
 #include <type_traits>
 #include "gs_forward.h"
-#ifndef GSR_EXP
-#define GSR_EXP 0
-#endif
 
 namespace gsr {
 
@@ -26,9 +23,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));   // arithmetic on f2 lowe
 // half-extents sqrt(2 tau c/det), sqrt(2 tau a/det), det = ac - b^2. Returns a 4-bit mask (bit q = quadrant q).
 __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, float b, float c, float o, int tx, int ty)
 {
-#if GSR_EXP == 3
-    return 15u;
-#endif
     const float tau = __logf(255.0f * o);           // alpha >= 1/255  <=>  power >= -tau
     if (!(tau >= 0.f)) return 0u;                   // o < 1/255 (or NaN): can never be blended
     const float det = a * c - b * b;
@@ -285,12 +279,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                 const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
                 const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
                 float* const dst = part_lane + j * 10;
-#if GSR_EXP != 5
                 if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
                     if (store_lane) *dst = 0.f;
                     continue;
                 }
-#endif
                 const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
                 const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
                 const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products

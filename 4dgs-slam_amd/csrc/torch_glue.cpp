@@ -106,17 +106,20 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     auto fopt = means3D_.options().dtype(torch::kFloat32);
     // the kernels write every element: one uninitialised allocation carved into the eleven gradient tensors
     // (rasterize_points.cu:160-170 allocates and zero-fills eleven)
-    const int64_t widths[11] = {3, 3, kChannels, 1, 4, 1, 6, 3 * M, 3, 4, 6};
+    // Layout: the five tensors that become the Gaussian parameters' .grad come first and back to back
+    // (means3D, sh, opacity, scales, rotations), so a data-parallel caller can all-reduce them in place as ONE flat range
+    // (mapping_shard.GradBucket detects this); the remaining six follow.
+    const int64_t widths[11] = {3, 3 * M, 1, 3, 4, 3, kChannels, 1, 4, 6, 6};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
     torch::Tensor flat = P == 0 ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);
     torch::Tensor v[11];
     int64_t o = 0;
     for (int i = 0; i < 11; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
-    torch::Tensor dL_dmeans3D = v[0].view({P, 3}), dL_dmeans2D = v[1].view({P, 3}), dL_dcolors = v[2].view({P, kChannels}),
-                  dL_ddepths = v[3].view({P, 1}), dL_dconic = v[4].view({P, 2, 2}), dL_dopacity = v[5].view({P, 1}),
-                  dL_dcov3D = v[6].view({P, 6}), dL_dsh = v[7].view({P, M, 3}), dL_dscales = v[8].view({P, 3}),
-                  dL_drotations = v[9].view({P, 4}), dL_dtau = v[10].view({P, 6});
+    torch::Tensor dL_dmeans3D = v[0].view({P, 3}), dL_dsh = v[1].view({P, M, 3}), dL_dopacity = v[2].view({P, 1}),
+                  dL_dscales = v[3].view({P, 3}), dL_drotations = v[4].view({P, 4}), dL_dmeans2D = v[5].view({P, 3}),
+                  dL_dcolors = v[6].view({P, kChannels}), dL_ddepths = v[7].view({P, 1}), dL_dconic = v[8].view({P, 2, 2}),
+                  dL_dcov3D = v[9].view({P, 6}), dL_dtau = v[10].view({P, 6});
     torch::Tensor tau_sum = flat.narrow(0, o, 6);
     if (P != 0) {
         const bool sh_path = M > 0 && colors_.numel() == 0;

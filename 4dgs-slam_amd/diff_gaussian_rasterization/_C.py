@@ -84,8 +84,6 @@ def load_library():
     lib.gsr_profile_read.restype = i
     lib.gsr_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
     lib.gsr_profile_reset.restype = None
-    lib.gsr_set_render_ppl.restype = i
-    lib.gsr_set_render_ppl.argtypes = [i, i]
     _lib = lib
     return lib
 
@@ -203,16 +201,18 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
     M = int(sh.shape[1]) if sh.numel() != 0 else 0
     # The kernels write every element, so one torch.empty carved into views replaces the eleven torch.zeros of
     # rasterize_points.cu:160-170 (eleven allocator calls + eleven memsets of host/GPU time per backward).
-    widths = [3, 3, NUM_CHANNELS, 1, 4, 1, 6, 3 * M, 3, 4, 6]   # means3D, means2D, colors, depths, conic, opacity, cov3D, sh, scales, rot, tau
+    # Layout: the five tensors that become the Gaussian parameters' .grad come first, back to back (means3D, sh, opacity,
+    # scales, rotations), so mapping_shard.GradBucket can all-reduce them in place as one flat range.
+    widths = [3, 3 * M, 1, 3, 4, 3, NUM_CHANNELS, 1, 4, 6, 6]
     flat = (torch.zeros if P == 0 else torch.empty)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
     views, o = [], 0
     for w_ in widths:
         views.append(flat[o:o + P * w_])
         o += P * w_
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = views[0].view(P, 3), views[1].view(P, 3), views[2].view(P, NUM_CHANNELS)
-    dL_ddepths, dL_dconic, dL_dopacity = views[3].view(P, 1), views[4].view(P, 2, 2), views[5].view(P, 1)
-    dL_dcov3D, dL_dsh, dL_dscales = views[6].view(P, 6), views[7].view(P, M, 3), views[8].view(P, 3)
-    dL_drotations, dL_dtau = views[9].view(P, 4), views[10].view(P, 6)
+    dL_dmeans3D, dL_dsh, dL_dopacity = views[0].view(P, 3), views[1].view(P, M, 3), views[2].view(P, 1)
+    dL_dscales, dL_drotations, dL_dmeans2D = views[3].view(P, 3), views[4].view(P, 4), views[5].view(P, 3)
+    dL_dcolors, dL_ddepths, dL_dconic = views[6].view(P, NUM_CHANNELS), views[7].view(P, 1), views[8].view(P, 2, 2)
+    dL_dcov3D, dL_dtau = views[9].view(P, 6), views[10].view(P, 6)
     tau_sum = flat[o:o + 6]
     if P != 0:
         keep = []
@@ -317,6 +317,3 @@ def profile_read():
     n = lib.gsr_profile_read(names, ms, calls, cap)
     return {names[i].decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
 
-
-def set_render_ppl(forward_ppl: int, backward_ppl: int) -> int:
-    return load_library().gsr_set_render_ppl(int(forward_ppl), int(backward_ppl))

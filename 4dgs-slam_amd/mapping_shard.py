@@ -62,11 +62,37 @@ class GradBucket:
             return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
+    def grads_as_one_range(self):
+        """If the parameters' .grad tensors already sit back to back in one allocation, in parameter order (the rasterizer's
+        backward returns means3D / sh / opacity / scales / rotations gradients that way), return a flat view over them, else None."""
+        gs = [p.grad for p in self.params]
+        if not gs or any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in gs):
+            return None
+        st = gs[0].untyped_storage().data_ptr()
+        off = gs[0].storage_offset()
+        for g in gs:
+            if g.untyped_storage().data_ptr() != st or g.storage_offset() != off:
+                return None
+            off += g.numel()
+        return gs[0].as_strided((off - gs[0].storage_offset(),), (1,), gs[0].storage_offset())
+
+    def all_reduce_grads(self, group=None):
+        """Sum the parameters' gradients over ranks: in place on the gradients' own storage when they form one range
+        (no pack / unpack copies), through the persistent flat buffer otherwise."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return "single"
+        flat = self.grads_as_one_range()
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            return "in-place"
+        self.pack()
+        self.all_reduce(group)
+        self.unpack()
+        return "packed"
+
 
 def allreduce_gaussian_grads(params: Iterable[torch.Tensor], group=None, bucket: GradBucket | None = None) -> GradBucket:
     """pack -> one all-reduce(sum) -> unpack. Re-use the returned bucket across iterations."""
     bucket = bucket or GradBucket(params)
-    bucket.pack()
-    bucket.all_reduce(group)
-    bucket.unpack()
+    bucket.all_reduce_grads(group)
     return bucket

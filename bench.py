@@ -49,7 +49,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=P_GAUSS)
     ap.add_argument("--sh-degree", type=int, default=0)
-    ap.add_argument("--ppl", type=str, default="", help="forward,backward pixels per lane (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -70,10 +69,6 @@ def main():
     from mapping_shard import GradBucket
     from synthetic_scene import make_camera, make_gaussians, make_cotangents, keyframe_pose
 
-    if args.ppl:
-        f, b = (int(x) for x in args.ppl.split(","))
-        _C.set_render_ppl(f, b)
-
     P = args.gaussians
     R_w, t_w = keyframe_pose(rank)  # rank r renders keyframe r of the same scene
     cam = make_camera(WIDTH, HEIGHT, R=R_w, t=t_w)
@@ -89,7 +84,7 @@ def main():
     scales, rots = T(g["scales"], True), T(g["rotations"], True)
     theta, rho = T(np.zeros(3), True), T(np.zeros(3), True)
     gcol, gdep = T(gc), T(gd)
-    params = [means3D, shs, opac, scales, rots]
+    params = [means3D, shs, opac, scales, rots]   # same order as the rasterizer's gradient block
     bucket = GradBucket(params) if world > 1 else None
     stats = {}
 
@@ -101,9 +96,7 @@ def main():
                                                        scales=scales, rotations=rots, theta=theta, rho=rho)
         torch.autograd.backward([color, depth], [gcol, gdep])
         if bucket is not None:
-            bucket.pack()
-            bucket.all_reduce()
-            bucket.unpack()
+            stats["allreduce"] = bucket.all_reduce_grads()   # in place on the backward's own output range when possible
         stats["radii"] = radii
 
     def barrier():
@@ -166,8 +159,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{P} static Gaussians, 1 cam @{WIDTH}x{HEIGHT} per GPU, SH degree {args.sh_degree}, fwd+bwd"
                                    + (f", {world} views sharded + RCCL all-reduce of {bucket.nbytes} B grads" if world > 1 else ""),
-                       "visible": V, "instances": nr, "pixels": N,
-                       "ppl": _C.set_render_ppl(0, 0)},
+                       "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding()},
             "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,

@@ -131,9 +131,6 @@ int gsr_profile_enable(int kernel_mask);
 int gsr_profile_read(const char** names, float* total_ms, int* calls, int cap);
 void gsr_profile_reset(void);
 
-/* Tuning knobs (process-wide): pixels per lane of the render kernels (1, 2 or 4). Returns the value in effect. */
-int gsr_set_render_ppl(int forward_ppl, int backward_ppl);
-
 const char* gsr_version(void);
 
 #ifdef __cplusplus

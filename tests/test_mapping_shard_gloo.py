@@ -83,6 +83,19 @@ def test_two_rank_view_sharding_equals_single_process_sum():
         np.testing.assert_allclose(a, b.numpy(), rtol=1e-5, atol=1e-9)
 
 
+def test_grads_in_one_allocation_are_detected():
+    from mapping_shard import GradBucket
+    flat = torch.arange(30, dtype=torch.float32)
+    ps = [torch.zeros(2, 3, requires_grad=True), torch.zeros(2, 1, 3, requires_grad=True), torch.zeros(2, 1, requires_grad=True)]
+    ps[0].grad, ps[1].grad, ps[2].grad = flat[4:10].view(2, 3), flat[10:16].view(2, 1, 3), flat[16:18].view(2, 1)
+    r = GradBucket(ps).grads_as_one_range()
+    assert r is not None and r.shape == (14,) and r.data_ptr() == flat[4:].data_ptr()
+    r += 1                                                   # in place on the gradients' own storage
+    assert float(ps[2].grad[1, 0]) == 18.0
+    ps[1].grad = torch.zeros(2, 1, 3)                        # not part of the same allocation any more
+    assert GradBucket(ps).grads_as_one_range() is None
+
+
 def test_grad_bucket_single_process_is_identity():
     from mapping_shard import GradBucket, allreduce_gaussian_grads
     ps = [torch.randn(5, 3, requires_grad=True), torch.randn(5, 1, requires_grad=True)]

@@ -5,7 +5,6 @@ import numpy as np, torch
 from diff_gaussian_rasterization import _C
 print(torch.cuda.get_device_name(0), flush=True)
 def run(P, W, H, deg=0, fppl=4, bppl=4, seed=0, scale_mean=0.005, precomp=False, tag=""):
-    _C.set_render_ppl(fppl, bppl)
     cam = make_camera(W, H)
     g = make_gaussians(P, cam, seed=seed, sh_degree=deg, scale_mean=scale_mean)
     gc, gd = make_cotangents(cam)
