@@ -17,7 +17,8 @@ struct GeomBwdArgs {
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped; const float* scales; const float* rotations;
     float scale_modifier; const float* cov3Ds; const float* viewmatrix; const float* projmatrix; const float* projmatrix_raw;
     const float* campos; float focal_x, focal_y, tan_fovx, tan_fovy;
-    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float4* partials;
+    const uint32_t* tiles_touched; const uint32_t* point_offsets;
+    const char* bin_base; const uint32_t* header;   // binning buffer + geometry header: the per-instance slots are located on the device
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
     float* tau_partials;   // optional [nblocks][6]: per-block sums of dL_dtau, so the caller does not have to reduce [P,6]
@@ -46,10 +47,11 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     if (idx == last) s_range[1] = incl;
     __syncthreads();
     const uint32_t U0 = s_range[0], U1 = s_range[1];
+    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], 0).partials;
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
     for (uint32_t c0 = U0; c0 < U1; c0 += CH) {
         const uint32_t nch = min((uint32_t)CH, U1 - c0);
-        const float4* src = a.partials + (size_t)c0 * 3;
+        const float4* src = partials + (size_t)c0 * 3;
         for (uint32_t k = threadIdx.x; k < nch * 3; k += 256) s_slot[k] = src[k];
         __syncthreads();
         const uint32_t lo = max(u0, c0), hi = min(u0 + cnt, c0 + nch);
@@ -296,7 +298,8 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     }
 }
 
-// Second level of the pose-gradient sum: one block, 6 x 64 threads, fixed order.
+// Second level of the pose-gradient sum: one block, 6 x 64 threads, fixed order. (Folding it into the block of geometry_bwd
+// that finishes last needs an agent-scope release per block -- an L2 write-back on this multi-XCD part -- which cost 100 us.)
 __global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
 {
     const int k = threadIdx.x >> 6, lane = lane_id();

@@ -43,7 +43,7 @@ static inline void carve(char*& p, T*& ptr, size_t count)
 }
 
 struct GeomState {
-    uint32_t* header;   // [0]=R, [1]=error flag, [2]=R_alloc, [3]=reserved
+    uint32_t* header;   // HDR_* words of gs_device.h
     float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
     int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
     float* tau_partials;   // [ceil(P/256)][6] per-block sums of dL_dtau (backward)
@@ -51,7 +51,7 @@ struct GeomState {
     {
         GeomState g;
         const size_t nb = (P + GB - 1) / GB + 1;
-        carve(p, g.header, 4);
+        carve(p, g.header, HDR_WORDS);
         carve(p, g.depths, P); carve(p, g.means2D, P); carve(p, g.conic_opacity, P); carve(p, g.rgb, 3 * P);
         carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
         carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
@@ -66,25 +66,19 @@ struct ImageState {
     static ImageState from(char*& p, size_t N, size_t T, size_t P)
     {
         ImageState s;
-        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.tile_count, T * CTR_STRIDE);
-        carve(p, s.tile_cursor, T * CTR_STRIDE); carve(p, s.work_counters, 64);
+        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T);
+        // one memset per forward pass clears [tile_count, work_counters + 64): per-tile counters, the flag word behind them
+        // (index T*CTR_STRIDE) and the work counters (word 0: geometry_bwd's finished-block count)
+        carve(p, s.tile_count, T * CTR_STRIDE + 64); carve(p, s.work_counters, 64);
+        carve(p, s.tile_cursor, T * CTR_STRIDE);
         carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
         return s;
     }
 };
-struct BinningState {
-    uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted;
-    // Every base offset depends on R only, so backward re-carves without knowing R_alloc. `keys` (forward-only sort
-    // scratch, R_alloc < 2R entries of 8 B) aliases the backward-only per-instance gradient slots (R x 48 B).
-    static BinningState from(char*& p, size_t R, size_t R_alloc)
-    {
-        BinningState b;
-        carve(p, b.inst_gauss, R); carve(p, b.partials, R * 3);
-        b.keys = reinterpret_cast<uint64_t*>(b.partials);
-        carve(p, b.sorted, R_alloc);
-        return b;
-    }
-};
+static size_t binning_bytes(size_t carve_R, size_t cap_sorted)
+{
+    return (size_t)(carve_binning(nullptr, carve_R, cap_sorted).end - (char*)nullptr) + 256;
+}
 template <typename F>
 static size_t required(F&& f)
 {
@@ -150,7 +144,9 @@ static thread_local uint32_t* t_mailbox = nullptr;       // host pointer
 static thread_local uint32_t* t_mailbox_dev = nullptr;   // device pointer to the same memory
 static thread_local uint32_t t_seq = 0;
 static thread_local size_t t_last_R_alloc = 0;
+static thread_local uint32_t t_last_max_tile = 0;
 static thread_local bool t_use_mailbox = true;
+static thread_local bool t_speculate = true;
 
 static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
 {
@@ -192,7 +188,7 @@ size_t gsr_image_buffer_size(int width, int height, int P)
     const size_t T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
     return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T, (size_t)P); });
 }
-size_t gsr_binning_buffer_size(int R_alloc) { return required([&](char*& p) { BinningState::from(p, (size_t)R_alloc, (size_t)R_alloc); }); }
+size_t gsr_binning_buffer_size(int R_alloc) { return binning_bytes((size_t)R_alloc, (size_t)R_alloc); }
 
 int gsr_profile_enable(int kernel_mask) { g_prof.mask = (unsigned)kernel_mask; return K_COUNT; }
 void gsr_profile_reset(void)
@@ -254,8 +250,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     const size_t hist_lds_bytes = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
-    GSR_HIP_CHECK(hipMemsetAsync(geom.header, 0, 4 * sizeof(uint32_t), stream));
-    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * CTR_STRIDE * sizeof(uint32_t), stream));
+    // One memset per forward pass: per-tile counters + the flag word + the work counters (ImageState::from keeps them adjacent).
+    uint32_t* const flags = img.tile_count + (size_t)T * CTR_STRIDE;
+    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)(img.work_counters + 64) - (char*)img.tile_count), stream));
 
     const int nblocks = (P + GB - 1) / GB;
     if (P > 0) {
@@ -269,82 +266,104 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         a.prefiltered = prefiltered; a.radii = radii; a.n_touched = n_touched;
         a.depths = geom.depths; a.means2D = geom.means2D; a.conic_opacity = geom.conic_opacity; a.rgb = geom.rgb; a.cov3D = geom.cov3D;
         a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums; a.tile_count = img.tile_count;
-        a.header = geom.header; a.block_tile_base = lds_hist ? img.block_tile_base : nullptr;
+        a.flags = flags; a.block_tile_base = lds_hist ? img.block_tile_base : nullptr;
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
             hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
     }
+
+    // Speculation: a SLAM loop renders nearly the same scene again and again, so the binning buffer is allocated for what
+    // sufficed last time plus slack and scatter / sort / render are enqueued right behind the scan, WITHOUT waiting for R;
+    // the host reads R from the mailbox afterwards, while the GPU is already busy with them. The scan kernel compares the
+    // frame's real needs with the speculative capacity and raises FLAG_OVERFLOW if they do not fit: the speculative kernels
+    // then exit at once and the host redoes them on an exact-size buffer (also the path of the first call and of debug mode).
+    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
+    const bool speculate = t_speculate && t_last_R_alloc && t_last_max_tile <= (uint32_t)SORT_LDS_CAP && !debug && P > 0;
+    const size_t cap = speculate ? t_last_R_alloc + t_last_R_alloc / 8 + 4096 : 0;
+    const uint32_t cap_tile = t_last_max_tile * 5 / 4 > (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_LDS_CAP : (uint32_t)SORT_SMALL_CAP;
     {
         ScopedKernelTimer tm(K_SCAN, stream);
         if (!t_mailbox) {
             if (const char* e = getenv("GSR_MAILBOX")) t_use_mailbox = e[0] != '0';
+            if (const char* e = getenv("GSR_SPECULATE")) t_speculate = e[0] != '0';
             GSR_HIP_CHECK(hipHostMalloc((void**)&t_mailbox, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
             memset(t_mailbox, 0, 8 * sizeof(uint32_t));
             GSR_HIP_CHECK(hipHostGetDevicePointer((void**)&t_mailbox_dev, t_mailbox, 0));
         }
         if (++t_seq == 0) t_seq = 1;
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
-                           img.ranges, img.tile_cursor, geom.header, t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
+                           img.ranges, img.tile_cursor, flags, (uint32_t)cap, cap_tile, geom.header,
+                           t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
     }
     GSR_STAGE("scan");
 
-    // Speculative binning allocation while the GPU is still preprocessing: the size that sufficed last time plus slack
-    // (a SLAM loop renders nearly the same scene again and again); re-done below only if it turns out too small.
-    char* bchunk = nullptr;
-    size_t bchunk_bytes = 0;
-    if (t_last_R_alloc) {
-        const size_t guess = t_last_R_alloc + t_last_R_alloc / 8 + 4096;
-        bchunk_bytes = required([&](char*& p) { BinningState::from(p, guess, guess); });
-        bchunk = binning_alloc(binning_user, bchunk_bytes);
-        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
-    }
-    // The one host wait of the forward pass (the reference's is the blocking cudaMemcpy at rasterizer_impl.cu:283-284).
-    uint32_t hdr[4];
-    { const int rc = wait_for_header(stream, geom.header, t_seq, hdr); if (rc) return rc; }
-    const uint32_t R = hdr[0], err = hdr[1], R_alloc = hdr[2], max_tile_list = hdr[3];
-    if (err) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
-    if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
-    t_last_R_alloc = R_alloc;
-
-    const size_t bsize = required([&](char*& p) { BinningState::from(p, (size_t)R, (size_t)R_alloc); });
-    if (!bchunk || bsize > bchunk_bytes) {
-        bchunk = binning_alloc(binning_user, bsize);
-        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
-    }
-    BinningState bin = BinningState::from(bchunk, (size_t)R, (size_t)R_alloc);
-
-    if (R > 0) {
-        if (R_alloc != R) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, (size_t)R_alloc * sizeof(uint64_t), stream));   // sort padding
+    // scatter -> sort -> render on a binning buffer laid out for carve_R instances / cap_sorted sorted entries
+    auto enqueue_binning_and_render = [&](char* chunk, size_t carve_R, size_t cap_sorted, bool spec, bool any_padding,
+                                          bool long_lists) -> int {
+        const BinningPtrs bin = carve_binning(chunk, carve_R, cap_sorted);
+        uint32_t* const chk = spec ? geom.header : nullptr;
+        if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
             hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.means2D,
                                geom.depths, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
-                               lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss);
+                               lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
+                               (uint32_t)carve_R);
         }
         GSR_STAGE("scatter_instances");
         {
             ScopedKernelTimer tm(K_SORT, stream);
             hipLaunchKernelGGL((sort_tiles_kernel<SORT_SMALL_CAP, 0>), dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys,
-                               bin.inst_gauss, bin.sorted);
-            if (max_tile_list > (uint32_t)SORT_SMALL_CAP)
+                               bin.inst_gauss, bin.sorted, chk);
+            if (long_lists)
                 hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
-                                   bin.keys, bin.inst_gauss, bin.sorted);
+                                   bin.keys, bin.inst_gauss, bin.sorted, chk);
         }
         GSR_STAGE("sort_tiles");
-    } else if (P > 0) {
-        // keep point_offsets defined for debug readers / backward even when nothing is visible
-        GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
-    }
+        {   // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
+            ScopedKernelTimer tm(K_RENDER_FWD, stream);
+            hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D,
+                               feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
+                               out_opacity, n_touched, chk);
+        }
+        GSR_STAGE("render_fwd");
+        return 0;
+    };
 
-    // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
-    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
-    {
+    char* bchunk = nullptr;
+    if (speculate) {
+        bchunk = binning_alloc(binning_user, binning_bytes(cap, cap));
+        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+        // a list longer than SORT_LDS_CAP needs padded segments (R_alloc != R) and pre-filled keys: cap_tile never allows that here
+        const int rc = enqueue_binning_and_render(bchunk, cap, cap, true, false, cap_tile > (uint32_t)SORT_SMALL_CAP);
+        if (rc) return rc;
+    }
+    // The one host wait of the forward pass (the reference's is the blocking cudaMemcpy at rasterizer_impl.cu:283-284).
+    uint32_t hdr[4];
+    { const int rc = wait_for_header(stream, geom.header, t_seq, hdr); if (rc) return rc; }
+    const uint32_t R = hdr[HDR_R], flg = hdr[HDR_FLAGS], R_alloc = hdr[HDR_R_ALLOC], max_tile_list = hdr[HDR_MAX_TILE];
+    if (flg & FLAG_PREFILTERED) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
+    if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
+    t_last_R_alloc = R_alloc > R ? R_alloc : R;
+    t_last_max_tile = max_tile_list;
+    if (speculate && !(flg & FLAG_OVERFLOW)) return (int)R;
+
+    if (R > 0) {
+        bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, (size_t)R_alloc));
+        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+        const int rc = enqueue_binning_and_render(bchunk, (size_t)R, (size_t)R_alloc, false, R_alloc != R, max_tile_list > (uint32_t)SORT_SMALL_CAP);
+        if (rc) return rc;
+    } else {
+        if (!bchunk) bchunk = binning_alloc(binning_user, binning_bytes(0, 0));
+        if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+        // keep point_offsets defined for debug readers / backward even when nothing is visible
+        if (P > 0) GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
-        hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D, feat,
-                           geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth, out_opacity,
-                           n_touched);
+        hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
+                           geom.means2D, feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color,
+                           out_depth, out_opacity, n_touched, (const uint32_t*)nullptr);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -367,9 +386,8 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
         g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
-    char* gp = geom_buffer; char* bp = binning_buffer; char* ip = image_buffer;
+    char* gp = geom_buffer; char* ip = image_buffer;
     GeomState geom = GeomState::from(gp, (size_t)P);
-    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);   // offsets depend on R only
     ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T, 0);
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
@@ -383,9 +401,9 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
             grid = persist;
             GSR_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
         }
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, background,
-                           geom.means2D, geom.conic_opacity, feat, geom.depths, img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth,
-                           reinterpret_cast<float*>(bin.partials), counter);
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, (const char*)binning_buffer,
+                           (const uint32_t*)geom.header, width, height, background, geom.means2D, geom.conic_opacity, feat, geom.depths,
+                           img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth, counter);
     }
     GSR_STAGE("render_bwd");
     GeomBwdArgs a;
@@ -394,7 +412,7 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     a.scale_modifier = scale_modifier; a.cov3Ds = cov3D_precomp ? cov3D_precomp : geom.cov3D;   // rasterizer_impl.cu:429
     a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.projmatrix_raw = projmatrix_raw; a.campos = campos;
     a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
-    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.partials = bin.partials;
+    a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.bin_base = binning_buffer; a.header = geom.header;
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
@@ -433,8 +451,10 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     const size_t N = (size_t)width * height;
     char* gp = const_cast<char*>(geom_buffer); char* bp = const_cast<char*>(binning_buffer); char* ip = const_cast<char*>(image_buffer);
     GeomState geom = GeomState::from(gp, (size_t)P);
-    BinningState bin = BinningState::from(bp, (size_t)R, (size_t)R);
     ImageState img = ImageState::from(ip, N, (size_t)T, 0);
+    uint32_t hdr[HDR_WORDS] = {0};
+    if (P > 0) GSR_HIP_CHECK(hipMemcpy(hdr, geom.header, sizeof(hdr), hipMemcpyDeviceToHost));
+    const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], 0);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
     D2H(depths, geom.depths, P * sizeof(float));
     D2H(means2D, geom.means2D, P * 2 * sizeof(float));
@@ -521,7 +541,7 @@ __global__ void debug_reduce10_kernel(const float* in, float* out)
 {
     const int l = threadIdx.x;
     const float* v = in + l * 10;
-    out[l] = wave_sum10_transposed(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+    out[l] = wave_sum10_transposed(wave_select_masks(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
 }
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
 {

@@ -68,11 +68,21 @@ __device__ __forceinline__ void wave_sum10_to_row3(float& v0, float& v1, float& 
 // where the stage is too short.
 __device__ __forceinline__ int wave_sum10_slot_of_lane(int lane) { return (int)((0x7272727294618350ull >> (4 * (lane & 15))) & 15ull); }
 
-__device__ __forceinline__ float wave_sum10_transposed(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                                       float v7, float v8, float v9)
+// The four lane-select masks (lanes whose bit 0 / 1 / 2 / 3 is set). Fetch them ONCE outside the loop that reduces: the
+// empty asm makes them opaque, so they live in four SGPR pairs; as visible constants hipcc notices that both halves of
+// each are equal, keeps one half and re-materialises the pair with an s_mov in front of every reduction.
+struct WaveSelectMasks { unsigned long long m0, m1, m2, m3; };
+__device__ __forceinline__ WaveSelectMasks wave_select_masks()
 {
-    const unsigned long long m0 = 0xAAAAAAAAAAAAAAAAull, m1 = 0xCCCCCCCCCCCCCCCCull, m2 = 0xF0F0F0F0F0F0F0F0ull,
-                             m3 = 0xFF00FF00FF00FF00ull;   // lanes whose bit 0 / 1 / 2 / 3 is set
+    WaveSelectMasks w{0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull, 0xFF00FF00FF00FF00ull};
+    asm volatile("" : "+s"(w.m0), "+s"(w.m1), "+s"(w.m2), "+s"(w.m3));
+    return w;
+}
+
+__device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float v0, float v1, float v2, float v3, float v4,
+                                                       float v5, float v6, float v7, float v8, float v9)
+{
+    const unsigned long long m0 = w.m0, m1 = w.m1, m2 = w.m2, m3 = w.m3;
     float k0, k1, k2, k3, k4, s0, s1, s2, s3, s4;
     asm volatile(
         // stage 1 (xor 1): pairs (v0,v5) (v1,v6) (v2,v7) (v3,v8) (v4,v9): keep = bit0 ? second : first, send the other
@@ -178,6 +188,29 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
     x1 = min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
     y1 = min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
 }
+
+// ---- the binning scratch buffer (the reference's BinningState, rasterizer_impl.h:55-66) --------------------------------
+// inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap], each 256-byte aligned.
+// carve_R is the instance count the buffer was LAID OUT for: the exact R when the host waited for it before allocating, or
+// the speculative capacity when the forward pass was enqueued without waiting. It lives in the geometry header (word 4),
+// so the backward kernels derive their pointers on the device and the host never has to know which of the two it was.
+struct BinningPtrs { uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; char* end; };
+__host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted)
+{
+    BinningPtrs b;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255);
+    b.inst_gauss = reinterpret_cast<uint32_t*>(p);
+    p = (p + carve_R * sizeof(uint32_t) + 255) & ~uintptr_t(255);
+    b.partials = reinterpret_cast<float4*>(p);
+    b.keys = reinterpret_cast<uint64_t*>(p);
+    p = (p + carve_R * 3 * sizeof(float4) + 255) & ~uintptr_t(255);
+    b.sorted = reinterpret_cast<uint2*>(p);
+    b.end = reinterpret_cast<char*>(p + cap_sorted * sizeof(uint2));
+    return b;
+}
+// geometry header words (uint32): R, flags, R_alloc, longest tile list, carve_R
+enum { HDR_R = 0, HDR_FLAGS = 1, HDR_R_ALLOC = 2, HDR_MAX_TILE = 3, HDR_CARVE_R = 4, HDR_WORDS = 8 };
+enum { FLAG_PREFILTERED = 1u, FLAG_OVERFLOW = 2u };   // FLAG_OVERFLOW: the speculative binning capacity did not suffice
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }

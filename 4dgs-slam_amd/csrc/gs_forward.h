@@ -32,7 +32,7 @@ struct PreprocessArgs {
     int prefiltered;
     int* radii; int* n_touched;
     float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
-    uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* header;
+    uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* flags;   // flags: zero-filled together with tile_count
     uint32_t* block_tile_base;   // [nblocks][T] when the LDS histogram path is taken, else nullptr
 };
 
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
         const f3 p_view = xform_point_4x3(p, a.viewmatrix);
         // near cull only (auxiliary.h:139-164); a culled point under `prefiltered` is an error (:156-160)
         if (p_view.z <= 0.2f) {
-            if (a.prefiltered) atomicOr(&a.header[1], 1u);
+            if (a.prefiltered) atomicOr(a.flags, (uint32_t)FLAG_PREFILTERED);
         } else {
             const float* pm = a.projmatrix;
             const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
@@ -262,6 +262,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, 
 
 __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
                                                     int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
+                                                    const uint32_t* flags, uint32_t cap_R, uint32_t cap_tile_list,
                                                     uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
 {
     __shared__ uint32_t s_tmp[17];
@@ -285,11 +286,14 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; w++) mx = max(mx, s_mx[w]);
-        header[0] = R; header[2] = R_alloc; header[3] = mx;
+        // cap_R != 0: the binning kernels were enqueued behind this one on a buffer sized for cap_R instances and tile lists of
+        // at most cap_tile_list entries; if this frame needs more they must not run (they test FLAG_OVERFLOW) and the host redoes them.
+        uint32_t err = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cap_R && (R > cap_R || R_alloc > cap_R || mx > cap_tile_list)) err |= (uint32_t)FLAG_OVERFLOW;
+        header[HDR_R] = R; header[HDR_FLAGS] = err; header[HDR_R_ALLOC] = R_alloc; header[HDR_MAX_TILE] = mx; header[HDR_CARVE_R] = cap_R;
         // Host mailbox (pinned, host-coherent): the host spins on word 4 instead of paying a hipMemcpyAsync + a blocking
         // hipStreamSynchronize (whose wake-up alone left the GPU idle for ~60 us per forward pass).
         if (host_mailbox) {
-            const uint32_t err = __hip_atomic_load(&header[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&host_mailbox[0], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mailbox[1], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mailbox[2], R_alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -311,8 +315,14 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const float* depths, const uint32_t* tiles_touched,
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
-                                                               uint64_t* keys, uint32_t* inst_gauss)
+                                                               uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
+                                                               uint32_t carve_R)
 {
+    if (speculative) {
+        if (header[HDR_FLAGS] & FLAG_OVERFLOW) return;          // uniform: the buffer behind keys/inst_gauss is too small for this frame
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        header[HDR_CARVE_R] = carve_R;                          // the host waited for R and laid the buffer out for exactly R
+    }
     const int idx = blockIdx.x * GB + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     __shared__ uint32_t s_wave_sum[GB / 64];
@@ -397,9 +407,10 @@ __device__ __forceinline__ void bitonic_sort_block(KEYS keys, uint32_t npad)
 constexpr int SORT_SMALL_CAP = 1024;
 template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
-                                                         uint2* sorted)
+                                                         uint2* sorted, const uint32_t* spec_header)
 {
     __shared__ uint64_t s_keys[CAP];
+    if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const uint2 r = ranges[tile];
     const uint32_t n = r.y - r.x;

@@ -18,28 +18,37 @@ namespace gsr {
 constexpr int RB = 256;   // entries per staged batch == threads per block
 typedef float f2 __attribute__((ext_vector_type(2)));   // arithmetic on f2 lowers to v_pk_{add,mul,fma}_f32: two fp32 ops per issue slot
 
-// Bounding box test of {p : o*exp(power(p)) >= 1/255} against the four 8x8 quadrants of tile (tx,ty).
-// power(d) = -1/2 d^T Q d with Q = [[a,b],[b,c]] (the conic); the level set power >= -tau is an ellipse with
-// half-extents sqrt(2 tau c/det), sqrt(2 tau a/det), det = ac - b^2. Returns a 4-bit mask (bit q = quadrant q).
+// Which of the four 8x8 quadrants of tile (tx,ty) can a Gaussian contribute to at all?
+// alpha = o*exp(power) reaches 1/255 only where d^T Q d <= 2 tau, tau = ln(255 o), Q = [[a,b],[b,c]] (the conic): an ellipse
+// around the mean. The test is the exact minimum of that quadratic form over the quadrant's pixel-centre rectangle: a convex
+// function on a convex set, so the minimum is 0 if the mean lies inside and otherwise sits on an edge FACING the mean (every
+// segment from the mean into the rectangle enters through one), where it is a clamped 1-D parabola. Two candidates cover
+// all cases: the point on the line x = clamp(mean.x) with the best y, and the point on y = clamp(mean.y) with the best x.
+// Slack (absolute, relative to tau, and relative to the magnitude of the cancelling terms) makes fp rounding only ever ADD
+// quadrants: the per-pixel test of the reference stays in the kernels, so results are unchanged.
+// Returns a 4-bit mask (bit q = quadrant q: 0 = top-left, 1 = top-right, 2 = bottom-left, 3 = bottom-right).
 __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, float b, float c, float o, int tx, int ty)
 {
     const float tau = __logf(255.0f * o);           // alpha >= 1/255  <=>  power >= -tau
     if (!(tau >= 0.f)) return 0u;                   // o < 1/255 (or NaN): can never be blended
-    const float det = a * c - b * b;
-    float ex, ey;
-    if (det > 0.f && a > 0.f && c > 0.f) {
-        const float k = 2.0f * (tau * 1.0002f + 1e-4f) / det;   // slack: the cull must stay a superset under fp rounding
-        ex = sqrtf(k * c) * 1.0001f + 0.01f;
-        ey = sqrtf(k * a) * 1.0001f + 0.01f;
-    } else {
-        ex = ey = 1e30f;                            // degenerate conic: never cull
+    if (!(a * c - b * b > 0.f && a > 0.f && c > 0.f)) return 15u;          // degenerate conic: never cull
+    const float thr = 2.0f * tau * 1.0005f + 2e-3f;
+    const float nboa = -b * __builtin_amdgcn_rcpf(a), nboc = -b * __builtin_amdgcn_rcpf(c), b2 = 2.0f * b;
+    const float X0 = (float)(tx * TILE_X) - gx, Y0 = (float)(ty * TILE_Y) - gy;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float dx0 = X0 + (q & 1) * 8.f, dx1 = dx0 + 7.f, dy0 = Y0 + (q >> 1) * 8.f, dy1 = dy0 + 7.f;
+        const float dxc = __builtin_amdgcn_fmed3f(0.f, dx0, dx1), dyc = __builtin_amdgcn_fmed3f(0.f, dy0, dy1);
+        const float dyv = __builtin_amdgcn_fmed3f(nboc * dxc, dy0, dy1);   // best y on the line x = clamp(mean.x)
+        const float dxh = __builtin_amdgcn_fmed3f(nboa * dyc, dx0, dx1);   // best x on the line y = clamp(mean.y)
+        const float v1 = a * dxc * dxc, v2 = b2 * dxc * dyv, v3 = c * dyv * dyv;
+        const float h1 = a * dxh * dxh, h2 = b2 * dxh * dyc, h3 = c * dyc * dyc;
+        const float qv = (v1 + v2 + v3) - 1e-5f * (v1 + fabsf(v2) + v3);
+        const float qh = (h1 + h2 + h3) - 1e-5f * (h1 + fabsf(h2) + h3);
+        if (fminf(qv, qh) <= thr) mask |= 1u << q;
     }
-    const float X0 = (float)(tx * TILE_X), Y0 = (float)(ty * TILE_Y);
-    const bool xl = gx - ex <= X0 + 7.f && gx + ex >= X0;           // overlaps columns 0..7
-    const bool xr = gx - ex <= X0 + 15.f && gx + ex >= X0 + 8.f;    // columns 8..15
-    const bool yt = gy - ey <= Y0 + 7.f && gy + ey >= Y0;
-    const bool yb = gy - ey <= Y0 + 15.f && gy + ey >= Y0 + 8.f;
-    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+    return mask;
 }
 
 // j = index of the lowest set bit of m; clears it.  Two SALU instructions (the C idiom m &= m - 1 costs three plus the ff1).
@@ -67,8 +76,9 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         const float* __restrict__ bg, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_opacity,
-                                                        int* __restrict__ n_touched)
+                                                        int* __restrict__ n_touched, const uint32_t* __restrict__ spec_header)
 {
+    if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     __shared__ float4 s_a[RB];      // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
     __shared__ float4 s_b[RB];      // {C, opacity, -, gaussian id bits}
     __shared__ float4 s_c[RB];      // {r, g, b, depth}: two packed FMAs per blended entry
@@ -82,7 +92,11 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     const int py = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
     const bool inside = px < W && py < H;
-    bool done = !inside;
+    // A pixel that is done (saturated, forward.cu:358-362, or outside the image, :292) is encoded in its alpha threshold:
+    // 1/255 while it still blends, +inf afterwards. One VGPR compare then replaces the lane-mask bookkeeping a `bool done`
+    // costs in the loop (six SALU instructions per pair).
+    const float INF = __builtin_inff();
+    float thr = inside ? 1.0f / 255.0f : INF;
     s_nt[t] = 0;
     float T = 1.0f;
     f2 acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};   // (C.r, C.g) and (C.b, D): accumulated with v_pk_fma_f32
@@ -92,7 +106,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     const int n = (int)(range.y - range.x);
 
     for (int base = 0; base < n; base += RB) {
-        const int all_done = __syncthreads_and(done);             // forward.cu:318-320 (also orders the LDS reuse below)
+        const int all_done = __syncthreads_and(thr > 1.0f);       // forward.cu:318-320 (also orders the LDS reuse below)
         {   // flush the previous batch's n_touched increments: one global atomic per (tile, Gaussian), off the hot loop
             const int c = s_nt[t];
             if (c) { atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c); s_nt[t] = 0; }
@@ -118,39 +132,44 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         // VALU->SALU round trip (measured: 111 -> 86 us), and pixels that are done blend nothing anyway.
         // Per 64-entry group the wave re-votes two things: whether any of its pixels is still unsaturated (else it skips the
         // group), and whether any pixel still has T > 0.5 -- only then can an entry bump n_touched (forward.cu:369-371), and
-        // the loop variant without that bookkeeping is ~8 instructions per pair shorter. Every instruction (VALU, SALU, LDS,
-        // branch alike) costs this kernel one 4-cycle issue slot per SIMD, so they are counted alike.
+        // the loop variant without that bookkeeping is shorter. Every instruction (VALU, SALU, LDS, branch alike) costs this
+        // kernel one 4-cycle issue slot per SIMD, so they are counted alike.
+        // n_touched bookkeeping: the wave visits each entry of the group once, so the count of entry jj is WRITTEN into lane jj
+        // of a VGPR (s_bcnt1 + v_writelane) and the 64 counts go to LDS with one ds_add per group.
         auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int jbase) {
+            int counts = 0;
             while (m) {
-                const int j = jbase + pop_lowest_bit(m);
+                const int jj = pop_lowest_bit(m);
+                const int j = jbase + jj;
                 const float4 A4 = s_a[j];
                 const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
                 const float4 C4 = s_c[j];
                 const f2 d = f2{A4.x, A4.y} - pxy;
                 const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;           // forward.cu:345 (times log2 e)
                 const float alpha = fminf(0.99f, B2.y * __builtin_amdgcn_exp2f(power2));           // :353
-                const bool valid = !done && power2 <= 0.0f && alpha >= 1.0f / 255.0f;              // :346,:354
+                const bool valid = power2 <= 0.0f && alpha >= thr;                                  // :346,:354 and "not done"
                 const float test_T = T * (1.0f - alpha);
                 const bool stop = valid && test_T < 0.0001f;                                        // :358-362
                 const bool blend = valid && !stop;
-                done = done || stop;
+                thr = stop ? INF : thr;
                 const float w = blend ? alpha * T : 0.0f;
                 acc_rg += f2{C4.x, C4.y} * w;                                                       // :364-367
                 acc_bd += f2{C4.z, C4.w} * w;
                 T = blend ? test_T : T;
                 last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
                 if (COUNT_TOUCHED.value) {
-                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(blend && test_T > 0.5f);   // :369-371
-                    if (tm) {
-                        if (lane == 0) atomicAdd(&s_nt[j], (int)__popcll(tm));                     // LDS; flushed once per batch
-                    }
+                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(test_T > (blend ? 0.5f : INF));   // blend && test_T > 0.5, :369-371
+                    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(counts) : "s"((int)__popcll(tm)), "s"(jj) : "m0");   // two SGPR operands would exceed the constant bus
                 }
+            }
+            if (COUNT_TOUCHED.value) {
+                if (counts) __hip_atomic_fetch_add(&s_nt[jbase + lane], counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
         for (int sw = 0; sw < 4; sw++) {
-            if (__all(done)) break;
+            if (__all(thr > 1.0f)) break;
             const unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
-            if (__any(!done && T > 0.5f)) composite(std::true_type{}, m, sw * 64);
+            if (__any(thr < 1.0f && T > 0.5f)) composite(std::true_type{}, m, sw * 64);
             else composite(std::false_type{}, m, sw * 64);
         }
     }
@@ -187,19 +206,23 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 constexpr int BB = 128;   // entries per staged batch in the backward kernel (LDS: 6 KiB staging + 20 KiB quadrant totals)
 
 __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const uint2* __restrict__ ranges,
-                                                const uint2* __restrict__ sorted, int W, int H,
+                                                const char* bin_base, const uint32_t* __restrict__ header, int W, int H,
                                                 const float* __restrict__ bg, const float2* __restrict__ means2D,
                                                 const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
                                                 const float* __restrict__ depths, const float* __restrict__ final_T,
                                                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                const float* __restrict__ dL_dpix_depth, float* __restrict__ partials)
+                                                const float* __restrict__ dL_dpix_depth)
 {
+    const BinningPtrs bin = carve_binning(const_cast<char*>(bin_base), header[HDR_CARVE_R], 0);   // uniform: a handful of SALU instructions
+    const uint2* __restrict__ sorted = bin.sorted;
+    float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
     __shared__ float4 s_b[BB];   // {C, opacity, instance id bits, quadrant mask bits}               (C = -c/2 log2e)
     __shared__ float4 s_c[BB];   // {r, g, b, depth}
     __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, -}: only the per-entry epilogue needs the unscaled conic
     __shared__ float s_part[4][BB][10];
     __shared__ unsigned long long s_mask[4][2];
+    __shared__ unsigned long long s_proc[4][2];   // [quadrant][64-entry group]: entries whose totals the quadrant wave actually wrote
     __shared__ int s_wmax[4];
 
     const int tx = tile % gx, ty = tile / gx;
@@ -231,8 +254,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
     const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
     // which of the ten sums this lane ends up holding after the transposed reduction
     const int fi = wave_sum10_slot_of_lane(lane);
-    float* const part_lane = &s_part[wave][0][fi];
-    const bool store_lane = lane < 10;
+    const uint32_t part_lane = (uint32_t)(wave * (BB * 10) + fi) * 4u;   // this lane's byte offset into s_part for entry 0
+    const WaveSelectMasks wsm = wave_select_masks();
 
     {   // deepest list position any pixel of this quadrant blended
         int wm = last_contrib;
@@ -269,8 +292,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
         __syncthreads();
         for (int sw = 0; sw < 2; sw++) {
             unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
+            unsigned long long proc = 0;
             while (m) {
-                const int j = sw * 64 + pop_lowest_bit(m);
+                const int jj = pop_lowest_bit(m);
+                const int j = sw * 64 + jj;
                 const float4 A4 = s_a[j];
                 const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
                 const f2 d = f2{A4.x, A4.y} - pxy;
@@ -278,11 +303,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                 const float G = __builtin_amdgcn_exp2f(power2);
                 const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
                 const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
-                float* const dst = part_lane + j * 10;
-                if (!__any(valid)) {                                                                  // the reference's skip_counter shortcut (:691-697)
-                    if (store_lane) *dst = 0.f;
-                    continue;
-                }
+                if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
+                asm("s_bitset1_b64 %0, %1" : "+s"(proc) : "s"(jj));
                 const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
                 const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
                 const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
@@ -301,9 +323,13 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
                 const f2 q1 = d * q;                  // (q dx, q dy)
                 const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
                 const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
-                const float tot = wave_sum10_transposed(s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
-                if (store_lane) *dst = tot;
+                // every lane stores: lanes that share a slot hold the same total
+                const float tot = wave_sum10_transposed(wsm, s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
+                uint32_t joff;                        // SALU multiply: hipcc would pick v_mad_u64_u32 (quarter rate) for j*40 + lane offset
+                asm("s_mul_i32 %0, %1, 40" : "=s"(joff) : "s"(j));
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + (part_lane + joff)) = tot;
             }
+            if (lane == 0) s_proc[wave][sw] = proc;
         }
         __syncthreads();
         // Add the four quadrants in a fixed order, turn the moments into the reference's gradients and write each instance's
@@ -312,13 +338,12 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
         if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
             const int j = t;
             const float4 B4 = s_b[j];                       // {C, opacity, instance id, quadrant mask}
-            const uint32_t bits = __float_as_uint(B4.w);
             float sum[10];
 #pragma unroll
             for (int k = 0; k < 10; k++) sum[k] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if ((bits >> q) & 1u) {
+                if ((s_proc[q][j >> 6] >> (j & 63)) & 1ull) {
 #pragma unroll
                     for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
                 }
@@ -338,17 +363,16 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
 // tile indices from a global counter until the frame is done: per-tile work varies by +-40 % (early saturation, culling), and
 // with every tile resident at once a launch lasts as long as its unluckiest SIMD; pulling tiles dynamically evens that out.
 __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                        const uint2* __restrict__ sorted, int W, int H,
+                                                        const char* bin_base, const uint32_t* __restrict__ header, int W, int H,
                                                         const float* __restrict__ bg, const float2* __restrict__ means2D,
                                                         const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
                                                         const float* __restrict__ depths, const float* __restrict__ final_T,
                                                         const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                        const float* __restrict__ dL_dpix_depth, float* __restrict__ partials,
-                                                        uint32_t* tile_counter)
+                                                        const float* __restrict__ dL_dpix_depth, uint32_t* tile_counter)
 {
     if (tile_counter == nullptr) {
-        render_bwd_tile(xcd_tile_of_block(blockIdx.x, ntiles), gx, ranges, sorted, W, H, bg, means2D, conic_opacity, feat, depths, final_T,
-                        n_contrib, dL_dpix, dL_dpix_depth, partials);
+        render_bwd_tile(xcd_tile_of_block(blockIdx.x, ntiles), gx, ranges, bin_base, header, W, H, bg, means2D, conic_opacity, feat, depths,
+                        final_T, n_contrib, dL_dpix, dL_dpix_depth);
         return;
     }
     __shared__ int s_next;
@@ -358,8 +382,8 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         __syncthreads();
         const int k = s_next;
         if (k >= ntiles) break;
-        render_bwd_tile(k, gx, ranges, sorted, W, H, bg, means2D, conic_opacity, feat, depths, final_T, n_contrib, dL_dpix, dL_dpix_depth,
-                        partials);
+        render_bwd_tile(k, gx, ranges, bin_base, header, W, H, bg, means2D, conic_opacity, feat, depths, final_T, n_contrib, dL_dpix,
+                        dL_dpix_depth);
     }
 }
 

@@ -5,6 +5,8 @@
 (reference :102-104,152-169). Only the colour and depth cotangents are consumed in backward; those of
 opacity / radii / n_touched are ignored exactly as the reference does (:108,116-138).
 """
+import math
+
 import torch
 
 from . import _C
@@ -27,6 +29,13 @@ def _call(fn, args, debug, dump_path, message):
         raise
 
 
+def _pose_grad(vec3, shape):
+    """A pose gradient (3 values) shaped like the 3-element input it belongs to, else [1,3] as the reference returns it."""
+    if shape is not None and len(shape) >= 1 and math.prod(shape) == 3:
+        return vec3.view(shape)
+    return vec3.view(1, 3)
+
+
 def _camera_block(rs):
     """(scale_modifier, cov3D slot filled by caller, viewmatrix, projmatrix, projmatrix_raw, tanfovx, tanfovy)."""
     return rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy
@@ -45,6 +54,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.pose_shapes = (tuple(theta.shape) if isinstance(theta, torch.Tensor) else None,
+                           tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
         ctx.set_materialize_grads(False)   # unused cotangents (opacity, radii, n_touched) arrive as None, not as zero-filled tensors
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
         return color, radii, depth, opacity, n_touched
@@ -67,6 +78,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # per-Gaussian [rho | theta] rows -> one pose gradient, each returned as [1,3] (reference :152-154: torch.sum over [P,6]);
         # the sum is produced by the backward kernels themselves (tau = float32[6])
-        g_rho, g_theta = tau[:3].view(1, -1), tau[3:].view(1, -1)
+        # The reference returns them as [1,3] and lets autograd sum_to_size them onto the (3,) camera parameters, which costs
+        # one reduction kernel each; a 3-element input gets its gradient in its own shape instead (same values).
+        th_shape, rho_shape = ctx.pose_shapes
+        g_rho, g_theta = _pose_grad(tau[:3], rho_shape), _pose_grad(tau[3:], th_shape)
         # one gradient per forward input, in input order (reference :157-169)
         return (g_means3D, g_means2D, g_sh, g_colors, g_opacity, g_scales, g_rot, g_cov3D, g_theta, g_rho, None)

@@ -88,10 +88,13 @@ def main():
     bucket = GradBucket(params) if world > 1 else None
     stats = {}
 
+    # screen-space gradient holder of the reference's render() (gaussian_renderer/__init__.py:71): an input of the rasterizer,
+    # created once here -- filling it is the caller's work, not part of the rasterizer's forward + backward
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+
     def step():
-        for p_ in params + [theta, rho]:
+        for p_ in params + [theta, rho, means2D]:
             p_.grad = None
-        means2D = torch.zeros_like(means3D, requires_grad=True)
         color, radii, depth, opacity, n_touched = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
                                                        scales=scales, rotations=rots, theta=theta, rho=rho)
         torch.autograd.backward([color, depth], [gcol, gdep])

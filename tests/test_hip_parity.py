@@ -232,3 +232,55 @@ def test_huge_tile_grid_uses_global_atomic_binning_fallback():
     oo, st, go = oracle_run(g, cam, bg, gc, gd)
     oh, gh = hip_run(g, cam, bg, gc, gd)
     _check(compare(oh, gh, oo, go), nt_tol=8)   # 3.3 M pixels
+
+
+@pytest.mark.gpu
+def test_speculative_binning_and_its_overflow_redo():
+    """The second forward pass of a host thread is enqueued without waiting for R (buffer sized from the previous frame).
+    Same scene again: bitwise the same result as the waited-for first pass. A much larger scene next: the speculative capacity
+    overflows, the kernels skip, the host redoes them on an exact buffer -- parity with the oracle must hold, as for the small
+    scene rendered after it (capacity now far too large) and for a frame with nothing visible in between."""
+    bg = np.array([0.2, 0.4, 0.6], np.float32)
+    cam = make_camera(160, 128)
+    small = make_gaussians(1500, cam, seed=21, sh_degree=1)
+    big = make_gaussians(30000, cam, seed=22, sh_degree=1)
+    behind = dict(small)
+    behind["means3D"] = small["means3D"] * np.array([1, 1, -1], np.float32)      # everything behind the camera: R = 0
+    gc, gd = make_cotangents(cam, seed=23)
+    first = hip_run(small, cam, bg, gc, gd)
+    for scene, tag in ((small, "same scene, speculative"), (big, "overflow -> redo"), (small, "oversized capacity"),
+                       (behind, "nothing visible"), (small, "after an empty frame")):
+        out_h, gr_h = hip_run(scene, cam, bg, gc, gd)
+        out_o, _, gr_o = oracle_run(scene, cam, bg, gc, gd)
+        m = compare(out_h, gr_h, out_o, gr_o, tag)
+        worst = max(v for k, v in m.items() if isinstance(v, float))
+        assert worst < 1e-3 and m["radii_mismatch"] == 0, m
+        if scene is small:
+            assert np.array_equal(out_h["color"], first[0]["color"]), tag
+            for k, v in gr_h.items():
+                assert v is None or np.array_equal(v, first[1][k]), (tag, k)
+
+
+@pytest.mark.gpu
+def test_pose_gradient_shapes_follow_the_inputs():
+    """theta / rho of shape (3,) (the reference's camera parameters) and of shape (1,3) both receive .grad of their own shape."""
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    cam = make_camera(64, 48)
+    g = make_gaussians(300, cam, seed=5)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+    rs = GaussianRasterizationSettings(
+        image_height=cam.H, image_width=cam.W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=T([0, 0, 0]), scale_modifier=1.0,
+        viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), projmatrix_raw=T(cam.projmatrix_raw), sh_degree=0,
+        campos=T(cam.campos), prefiltered=False, debug=False)
+    got = []
+    for shape in ((3,), (1, 3)):
+        theta, rho = T(np.zeros(shape), True), T(np.zeros(shape), True)
+        color, *_ = GaussianRasterizer(rs)(means3D=T(g["means3D"]), means2D=T(np.zeros((300, 3))), opacities=T(g["opacities"]),
+                                           shs=T(g["shs"]), scales=T(g["scales"]), rotations=T(g["rotations"]), theta=theta, rho=rho)
+        color.sum().backward()
+        assert tuple(theta.grad.shape) == shape and tuple(rho.grad.shape) == shape
+        got.append((theta.grad.reshape(-1).cpu().numpy(), rho.grad.reshape(-1).cpu().numpy()))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert np.abs(got[0][0]).sum() > 0
