@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     if (idx == last) s_range[1] = incl;
     __syncthreads();
     const uint32_t U0 = s_range[0], U1 = s_range[1];
-    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], 0).partials;
+    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], 0).partials;   // partials do not depend on the sorted capacity
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
     for (uint32_t c0 = U0; c0 < U1; c0 += CH) {
         const uint32_t nch = min((uint32_t)CH, U1 - c0);

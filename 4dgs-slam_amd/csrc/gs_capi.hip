@@ -62,11 +62,13 @@ struct GeomState {
 static inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
 struct ImageState {
     float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor; uint32_t* work_counters;
+    float4* final_C;        // per pixel: colour / depth sums without the background term (render_bwd's chunk start-up needs them)
+    uint32_t* chunk_base;   // [T + 1] exclusive scan of ceil(tile list length / CHUNK)
     uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
     static ImageState from(char*& p, size_t N, size_t T, size_t P)
     {
         ImageState s;
-        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T);
+        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
         // one memset per forward pass clears [tile_count, work_counters + 64): per-tile counters, the flag word behind them
         // (index T*CTR_STRIDE) and the work counters (word 0: geometry_bwd's finished-block count)
         carve(p, s.tile_count, T * CTR_STRIDE + 64); carve(p, s.work_counters, 64);
@@ -294,7 +296,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         }
         if (++t_seq == 0) t_seq = 1;
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
-                           img.ranges, img.tile_cursor, flags, (uint32_t)cap, cap_tile, geom.header,
+                           img.ranges, img.tile_cursor, flags, (uint32_t)cap, cap_tile, img.chunk_base, geom.header,
                            t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
     }
     GSR_STAGE("scan");
@@ -310,7 +312,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
             hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.means2D,
                                geom.depths, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
-                               (uint32_t)carve_R);
+                               (uint32_t)carve_R, (uint32_t)cap_sorted);
         }
         GSR_STAGE("scatter_instances");
         {
@@ -326,7 +328,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
             ScopedKernelTimer tm(K_RENDER_FWD, stream);
             hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D,
                                feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
-                               out_opacity, n_touched, chk);
+                               out_opacity, n_touched, img.final_C, bin.ckpt, chk);
         }
         GSR_STAGE("render_fwd");
         return 0;
@@ -363,7 +365,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
                            geom.means2D, feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color,
-                           out_depth, out_opacity, n_touched, (const uint32_t*)nullptr);
+                           out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -392,18 +394,12 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
     if (R > 0) {
+        // one block per CHUNK entries of a tile list; sum over tiles of ceil(n / CHUNK) <= R / CHUNK + T, surplus blocks exit
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
-        static const int persist = getenv("GSR_PERSIST_BLOCKS") ? atoi(getenv("GSR_PERSIST_BLOCKS")) : 0;
-        uint32_t* counter = nullptr;
-        int grid = T;
-        if (persist > 0 && persist < T) {
-            counter = img.work_counters + 32;
-            grid = persist;
-            GSR_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(uint32_t), stream));
-        }
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, (const char*)binning_buffer,
+        const int grid = R / CHUNK + T;
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, img.chunk_base, (const char*)binning_buffer,
                            (const uint32_t*)geom.header, width, height, background, geom.means2D, geom.conic_opacity, feat, geom.depths,
-                           img.final_T, img.n_contrib, dL_dpix, dL_dpix_depth, counter);
+                           img.final_T, img.final_C, img.n_contrib, dL_dpix, dL_dpix_depth);
     }
     GSR_STAGE("render_bwd");
     GeomBwdArgs a;
@@ -454,7 +450,7 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     ImageState img = ImageState::from(ip, N, (size_t)T, 0);
     uint32_t hdr[HDR_WORDS] = {0};
     if (P > 0) GSR_HIP_CHECK(hipMemcpy(hdr, geom.header, sizeof(hdr), hipMemcpyDeviceToHost));
-    const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], 0);
+    const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], hdr[HDR_CAP_SORTED]);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
     D2H(depths, geom.depths, P * sizeof(float));
     D2H(means2D, geom.means2D, P * 2 * sizeof(float));

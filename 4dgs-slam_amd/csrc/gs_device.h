@@ -190,11 +190,15 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 }
 
 // ---- the binning scratch buffer (the reference's BinningState, rasterizer_impl.h:55-66) --------------------------------
-// inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap], each 256-byte aligned.
+// inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap] | ckpt, each 256-byte
+// aligned. ckpt = per-pixel compositing state (T, r, g, b, depth) at every CHUNK-th entry of every tile list, written by the
+// forward tile kernel: with it the backward pass can start anywhere in a list (see render_bwd_kernel).
 // carve_R is the instance count the buffer was LAID OUT for: the exact R when the host waited for it before allocating, or
 // the speculative capacity when the forward pass was enqueued without waiting. It lives in the geometry header (word 4),
 // so the backward kernels derive their pointers on the device and the host never has to know which of the two it was.
-struct BinningPtrs { uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; char* end; };
+constexpr int CHUNK = 128;              // entries of a tile list per backward work item
+constexpr int CKPT_FLOATS = 5 * TILE_X * TILE_Y;   // one checkpoint: 5 planes of 256 pixels
+struct BinningPtrs { uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
 __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted)
 {
     BinningPtrs b;
@@ -205,11 +209,13 @@ __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R,
     b.keys = reinterpret_cast<uint64_t*>(p);
     p = (p + carve_R * 3 * sizeof(float4) + 255) & ~uintptr_t(255);
     b.sorted = reinterpret_cast<uint2*>(p);
-    b.end = reinterpret_cast<char*>(p + cap_sorted * sizeof(uint2));
+    p = (p + cap_sorted * sizeof(uint2) + 255) & ~uintptr_t(255);
+    b.ckpt = reinterpret_cast<float*>(p);            // checkpoint id = sorted position / CHUNK, ids 1 .. cap/CHUNK + 1
+    b.end = reinterpret_cast<char*>(p + (cap_sorted / CHUNK + 2) * (size_t)CKPT_FLOATS * sizeof(float));
     return b;
 }
-// geometry header words (uint32): R, flags, R_alloc, longest tile list, carve_R
-enum { HDR_R = 0, HDR_FLAGS = 1, HDR_R_ALLOC = 2, HDR_MAX_TILE = 3, HDR_CARVE_R = 4, HDR_WORDS = 8 };
+// geometry header words (uint32): R, flags, R_alloc, longest tile list, carve_R, capacity of sorted[], number of list chunks
+enum { HDR_R = 0, HDR_FLAGS = 1, HDR_R_ALLOC = 2, HDR_MAX_TILE = 3, HDR_CARVE_R = 4, HDR_CAP_SORTED = 5, HDR_CHUNKS = 6, HDR_WORDS = 8 };
 enum { FLAG_PREFILTERED = 1u, FLAG_OVERFLOW = 2u };   // FLAG_OVERFLOW: the speculative binning capacity did not suffice
 
 struct f3 { float x, y, z; };

@@ -263,7 +263,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, 
 __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
                                                     int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
                                                     const uint32_t* flags, uint32_t cap_R, uint32_t cap_tile_list,
-                                                    uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
+                                                    uint32_t* chunk_base, uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
 {
     __shared__ uint32_t s_tmp[17];
     const uint32_t R = block_exclusive_scan_1024(
@@ -276,6 +276,11 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
             tile_cursor[(size_t)i * CTR_STRIDE] = excl;
         },
         s_tmp);
+    // (3) the backward pass works on CHUNK-entry pieces of the tile lists: chunk_base[t] = number of pieces in front of tile t
+    const uint32_t nchunks = block_exclusive_scan_1024(
+        ntiles, [&](int i) { return (tile_count[(size_t)i * CTR_STRIDE] + (uint32_t)CHUNK - 1) / (uint32_t)CHUNK; },
+        [&](int i, uint32_t excl, uint32_t) { chunk_base[i] = excl; }, s_tmp);
+    if (threadIdx.x == 0) chunk_base[ntiles] = nchunks;
     // largest tile list: lets the host pick the sort kernel variant (LDS footprint decides how many tiles sort concurrently)
     uint32_t mx = 0;
     for (int i = threadIdx.x; i < ntiles; i += 1024) mx = max(mx, tile_count[(size_t)i * CTR_STRIDE]);
@@ -291,6 +296,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
         uint32_t err = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cap_R && (R > cap_R || R_alloc > cap_R || mx > cap_tile_list)) err |= (uint32_t)FLAG_OVERFLOW;
         header[HDR_R] = R; header[HDR_FLAGS] = err; header[HDR_R_ALLOC] = R_alloc; header[HDR_MAX_TILE] = mx; header[HDR_CARVE_R] = cap_R;
+        header[HDR_CAP_SORTED] = cap_R; header[HDR_CHUNKS] = nchunks;
         // Host mailbox (pinned, host-coherent): the host spins on word 4 instead of paying a hipMemcpyAsync + a blocking
         // hipStreamSynchronize (whose wake-up alone left the GPU idle for ~60 us per forward pass).
         if (host_mailbox) {
@@ -316,12 +322,13 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R)
+                                                               uint32_t carve_R, uint32_t cap_sorted)
 {
     if (speculative) {
         if (header[HDR_FLAGS] & FLAG_OVERFLOW) return;          // uniform: the buffer behind keys/inst_gauss is too small for this frame
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         header[HDR_CARVE_R] = carve_R;                          // the host waited for R and laid the buffer out for exactly R
+        header[HDR_CAP_SORTED] = cap_sorted;
     }
     const int idx = blockIdx.x * GB + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;

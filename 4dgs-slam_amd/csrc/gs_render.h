@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         const float* __restrict__ bg, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_opacity,
-                                                        int* __restrict__ n_touched, const uint32_t* __restrict__ spec_header)
+                                                        int* __restrict__ n_touched, float4* __restrict__ final_C,
+                                                        float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     __shared__ float4 s_a[RB];      // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
@@ -104,6 +105,15 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    // Checkpoint of the per-pixel compositing state in front of list entry `boundary` (a multiple of CHUNK): lets the backward
+    // pass start at any chunk of the list instead of walking the whole list from its end (render_bwd_kernel). Five coalesced
+    // 256-byte stores per wave and CHUNK entries. A wave whose pixels are all saturated stops writing them: the backward
+    // pass uses the final values for a pixel that blended nothing behind the boundary.
+    auto write_checkpoint = [&](int boundary) {
+        float* c = ckpt + (size_t)((range.x >> 7) + (uint32_t)(boundary >> 7)) * CKPT_FLOATS + t;
+        c[0] = T; c[256] = acc_rg.x; c[512] = acc_rg.y; c[768] = acc_bd.x; c[1024] = acc_bd.y;
+    };
+    static_assert(CHUNK == 128 && RB == 2 * CHUNK, "checkpoint cadence: one at the top of a batch, one in its middle");
 
     for (int base = 0; base < n; base += RB) {
         const int all_done = __syncthreads_and(thr > 1.0f);       // forward.cu:318-320 (also orders the LDS reuse below)
@@ -112,6 +122,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             if (c) { atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c); s_nt[t] = 0; }
         }
         if (all_done) break;
+        if (base > 0) write_checkpoint(base);
         uint32_t qm = 0;
         if (base + t < n) {
             const uint2 e = sorted[range.x + base + t];
@@ -168,6 +179,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         };
         for (int sw = 0; sw < 4; sw++) {
             if (__all(thr > 1.0f)) break;
+            if (sw == 2 && base + CHUNK < n) write_checkpoint(base + CHUNK);
             const unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
             if (__any(thr < 1.0f && T > 0.5f)) composite(std::true_type{}, m, sw * 64);
             else composite(std::false_type{}, m, sw * 64);
@@ -182,6 +194,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = T;
         n_contrib[pix] = last;
+        final_C[pix] = make_float4(acc_rg.x, acc_rg.y, acc_bd.x, acc_bd.y);   // colour / depth without the background term
         out_color[pix] = acc_rg.x + T * bg[0];                                                      // forward.cu:384-390
         out_color[(size_t)H * W + pix] = acc_rg.y + T * bg[1];
         out_color[2 * (size_t)H * W + pix] = acc_bd.x + T * bg[2];
@@ -200,20 +213,35 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 //    issues 10 float atomics per instance instead (backward.cu:774-783). B2 then sums a Gaussian's consecutive
 //    instance slots in a fixed order: bit-reproducible gradients, nothing to zero-fill, no atomics;
 //  * besides the quadrant cull, entries behind the deepest contributor of the quadrant (max n_contrib) are dropped
-//    at staging time, so saturated regions skip their occluded tail entirely.
+//    at staging time, so saturated regions skip their occluded tail entirely;
+//  * one block per CHUNK entries of a tile list, not per tile: the forward pass checkpoints the per-pixel compositing state
+//    every CHUNK entries, so every chunk can be differentiated on its own (details at the state set-up below).
 // Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int BB = 128;   // entries per staged batch in the backward kernel (LDS: 6 KiB staging + 20 KiB quadrant totals)
+constexpr int BB = CHUNK;   // entries per block of the backward kernel (LDS: 8 KiB staging + 20 KiB quadrant totals)
 
-__device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const uint2* __restrict__ ranges,
-                                                const char* bin_base, const uint32_t* __restrict__ header, int W, int H,
-                                                const float* __restrict__ bg, const float2* __restrict__ means2D,
-                                                const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
-                                                const float* __restrict__ depths, const float* __restrict__ final_T,
-                                                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                const float* __restrict__ dL_dpix_depth)
+__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ chunk_base, const char* bin_base,
+                                                        const uint32_t* __restrict__ header, int W, int H,
+                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
+                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
+                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                        const float4* __restrict__ final_C, const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth)
 {
-    const BinningPtrs bin = carve_binning(const_cast<char*>(bin_base), header[HDR_CARVE_R], 0);   // uniform: a handful of SALU instructions
+    // ---- which (tile, chunk) is this block? The grid is an upper bound (R / CHUNK + tiles); surplus blocks leave.
+    const uint32_t cid = (uint32_t)xcd_tile_of_block(blockIdx.x, gridDim.x);   // neighbouring chunks (same or adjacent tiles) share an XCD's L2
+    if (cid >= header[HDR_CHUNKS]) return;
+    int tile;
+    {   // largest t with chunk_base[t] <= cid (uniform binary search, scalar loads)
+        int lo = 0, hi = ntiles;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (chunk_base[mid] <= cid) lo = mid; else hi = mid;
+        }
+        tile = lo;
+    }
+    const BinningPtrs bin = carve_binning(const_cast<char*>(bin_base), header[HDR_CARVE_R], header[HDR_CAP_SORTED]);   // uniform: SALU
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
@@ -232,158 +260,149 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, int gx, const ui
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n == 0) return;
+    const int chunk = (int)(cid - chunk_base[tile]);
+    const int cstart = chunk * CHUNK, cend = min(n, cstart + CHUNK);   // list positions [cstart, cend) of this tile, front to back
+    const int m = cend - cstart;
 
     const bool inside = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
-    const float Tfin = inside ? final_T[pix] : 0.f;                          // backward.cu:617-623
-    float T = Tfin;
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
+    {   // deepest list position any pixel of this quadrant blended; a chunk behind all four has nothing to do (its instances'
+        // slots must still be written: zero)
+        int wm = last_contrib;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
+        if (lane == 0) s_wmax[wave] = wm;
+    }
+    __syncthreads();
+    if (max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) <= cstart) {
+        if (t < m) {
+            const uint2 e = sorted[range.x + (uint32_t)(cend - 1 - t)];
+            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e.y * 3;
+            slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+
+    // ---- per-pixel state at the BACK end of the chunk (the pass walks the chunk back to front, backward.cu:656,677) --------
+    //   T  = transmittance in front of entry `cend`:  the forward pass's checkpoint there, or the final value for a pixel that
+    //        blended nothing at or behind cend (in particular for the last chunk of the list);
+    //   Sb = T_final (bg . g) + sum over the blended entries at or behind cend of alpha_k T_k (c_k . g)
+    //      = (C_final - C_checkpoint) . g + T_final (bg . g),   C = the forward pass's running colour / depth sums.
+    // The reference carries the normalised "colour behind" accum_rec[3] + accum_rec_depth and last_alpha/last_color (:714-728)
+    // from the END of the list and adds the background term separately (:738-743); with acc_i = S_i / (T_i (1 - alpha_i)) its
+    //   dL_dalpha_i = (c_i - acc_i).g T_i - T_final/(1 - alpha_i) bg.g   becomes   (c_i . g) T_i - Sb_i / (1 - alpha_i),
+    // which needs no per-channel state and -- because an invalid pair simply has alpha = 0 -- no selects on the state; and
+    // since both T and Sb are available at every chunk boundary, every chunk of a list is an independent block: ~5000 short
+    // blocks instead of 1200 long ones, which the hardware dispatcher balances over the CUs (with one block per tile the
+    // kernel lasted as long as its slowest tile, 1.5x the mean).
+    const float Tfin = inside ? final_T[pix] : 0.f;                          // backward.cu:617-623
     const float gr = inside ? dL_dpix[pix] : 0.f;                            // :629-635
     const float gg = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
     const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
     const float gd = inside ? dL_dpix_depth[pix] : 0.f;
-    const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742 (loop invariant)
-    // State per pixel: T (transmittance in front of the current entry) and
-    //   Sb = T_final * (bg . dL_dpixel) + sum over the entries already visited (those behind) of alpha_k T_k (c_k . dL_dpixel).
-    // The reference carries the normalised "colour behind" accum_rec[3] + accum_rec_depth and last_alpha/last_color (:714-728)
-    // and adds the background term separately (:738-743); with acc_i = S_i / (T_i (1 - alpha_i)) its
-    //   dL_dalpha_i = (c_i - acc_i).g T_i - T_final/(1 - alpha_i) bg.g   becomes   (c_i . g) T_i - Sb_i / (1 - alpha_i),
-    // which needs no per-channel state and -- because an invalid pair simply has alpha = 0 -- no selects on the state.
-    float Sb = Tfin * bgdot;
+    const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742
+    float T = Tfin, Sb = Tfin * bgdot;
+    if (inside && cend < n && last_contrib > cend) {
+        const float* c = bin.ckpt + (size_t)((range.x >> 7) + (uint32_t)(cend >> 7)) * CKPT_FLOATS + t;
+        const float4 Cf = final_C[pix];
+        T = c[0];
+        Sb += (Cf.x - c[256]) * gr + (Cf.y - c[512]) * gg + (Cf.z - c[768]) * gb + (Cf.w - c[1024]) * gd;
+    }
     const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
     // which of the ten sums this lane ends up holding after the transposed reduction
     const int fi = wave_sum10_slot_of_lane(lane);
     const uint32_t part_lane = (uint32_t)(wave * (BB * 10) + fi) * 4u;   // this lane's byte offset into s_part for entry 0
     const WaveSelectMasks wsm = wave_select_masks();
 
-    {   // deepest list position any pixel of this quadrant blended
-        int wm = last_contrib;
+    uint32_t qm = 0;
+    if (t < m) {
+        const int pos = cend - 1 - t;                                     // 0-based list position, back to front (:656,:677)
+        const uint2 e = sorted[range.x + (uint32_t)pos];
+        const float2 xy = means2D[e.x];
+        const float4 co = conic_opacity[e.x];
+        qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
-        if (lane == 0) s_wmax[wave] = wm;
+        for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
+        s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+        s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, __uint_as_float(e.y), __uint_as_float(qm));
+        s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
+        s_d[t] = make_float4(co.x, co.y, co.z, 0.f);
     }
-
-    for (int base = 0; base < n; base += BB) {
-        __syncthreads();
-        uint32_t qm = 0;
-        if (t < BB && base + t < n) {
-            const int pos = n - 1 - (base + t);                               // 0-based list position, back to front (:656,:677)
-            const uint2 e = sorted[range.x + (uint32_t)pos];
-            const float2 xy = means2D[e.x];
-            const float4 co = conic_opacity[e.x];
-            qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
+    // pos < last_contrib (:678)  <=>  j >= cend - last_contrib, with j the index inside this chunk
+    const int j_thr = cend - last_contrib;
+    if (wave < 2) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
-            s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
-            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, __uint_as_float(e.y), __uint_as_float(qm));
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
-            s_d[t] = make_float4(co.x, co.y, co.z, 0.f);
-        }
-        // pos < last_contrib (:678)  <=>  j >= n - base - last_contrib, with j the index inside this batch
-        const int j_thr = n - base - last_contrib;
-        if (wave < 2) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned long long m = __ballot((qm >> q) & 1u);
-                if (lane == 0) s_mask[q][wave] = m;
-            }
-        }
-        __syncthreads();
-        for (int sw = 0; sw < 2; sw++) {
-            unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
-            unsigned long long proc = 0;
-            while (m) {
-                const int jj = pop_lowest_bit(m);
-                const int j = sw * 64 + jj;
-                const float4 A4 = s_a[j];
-                const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
-                const f2 d = f2{A4.x, A4.y} - pxy;
-                const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;             // :684 (times log2 e)
-                const float G = __builtin_amdgcn_exp2f(power2);
-                const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
-                const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
-                if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-                asm("s_bitset1_b64 %0, %1" : "+s"(proc) : "s"(jj));
-                const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
-                const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
-                const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
-                const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
-                T *= inv1ma;                                                                           // :700
-                const float wv = av * T;                                                               // :701 dchannel_dcolor
-                const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
-                const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
-                const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
-                Sb += wv * cg;
-                // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
-                //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
-                //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
-                const float s_op = Gv * dL_dalpha;
-                const float q = B2.y * s_op;
-                const f2 q1 = d * q;                  // (q dx, q dy)
-                const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
-                const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
-                // every lane stores: lanes that share a slot hold the same total
-                const float tot = wave_sum10_transposed(wsm, s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
-                uint32_t joff;                        // SALU multiply: hipcc would pick v_mad_u64_u32 (quarter rate) for j*40 + lane offset
-                asm("s_mul_i32 %0, %1, 40" : "=s"(joff) : "s"(j));
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + (part_lane + joff)) = tot;
-            }
-            if (lane == 0) s_proc[wave][sw] = proc;
-        }
-        __syncthreads();
-        // Add the four quadrants in a fixed order, turn the moments into the reference's gradients and write each instance's
-        // slot (12 floats, 48 B) coalesced.  s_part[q][j][] = {sum G dL_dalpha, M1x, M1y, M2xx, M2xy, M2yy, r, g, b, depth}
-        const int m = min(BB, n - base);
-        if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
-            const int j = t;
-            const float4 B4 = s_b[j];                       // {C, opacity, instance id, quadrant mask}
-            float sum[10];
-#pragma unroll
-            for (int k = 0; k < 10; k++) sum[k] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if ((s_proc[q][j >> 6] >> (j & 63)) & 1ull) {
-#pragma unroll
-                    for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
-                }
-            }
-            const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z}
-            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.z) * 3;
-            slot[0] = make_float4(-(K4.x * sum[1] + K4.y * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
-                                  -(K4.z * sum[2] + K4.y * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
-                                  -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
-            slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
-            slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long mk = __ballot((qm >> q) & 1u);
+            if (lane == 0) s_mask[q][wave] = mk;
         }
     }
-}
-
-// Launch wrapper. tile_counter == nullptr: one block per tile (XCD-banded order). Otherwise `gridDim.x` persistent blocks pull
-// tile indices from a global counter until the frame is done: per-tile work varies by +-40 % (early saturation, culling), and
-// with every tile resident at once a launch lasts as long as its unluckiest SIMD; pulling tiles dynamically evens that out.
-__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                        const char* bin_base, const uint32_t* __restrict__ header, int W, int H,
-                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
-                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
-                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
-                                                        const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                        const float* __restrict__ dL_dpix_depth, uint32_t* tile_counter)
-{
-    if (tile_counter == nullptr) {
-        render_bwd_tile(xcd_tile_of_block(blockIdx.x, ntiles), gx, ranges, bin_base, header, W, H, bg, means2D, conic_opacity, feat, depths,
-                        final_T, n_contrib, dL_dpix, dL_dpix_depth);
-        return;
+    __syncthreads();
+    for (int sw = 0; sw < 2; sw++) {
+        unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
+        unsigned long long proc = 0;
+        while (mk) {
+            const int jj = pop_lowest_bit(mk);
+            const int j = sw * 64 + jj;
+            const float4 A4 = s_a[j];
+            const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
+            const f2 d = f2{A4.x, A4.y} - pxy;
+            const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;             // :684 (times log2 e)
+            const float G = __builtin_amdgcn_exp2f(power2);
+            const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
+            const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
+            if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
+            asm("s_bitset1_b64 %0, %1" : "+s"(proc) : "s"(jj));
+            const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
+            const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
+            const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
+            const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
+            T *= inv1ma;                                                                           // :700
+            const float wv = av * T;                                                               // :701 dchannel_dcolor
+            const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
+            const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
+            const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
+            Sb += wv * cg;
+            // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
+            //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
+            //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
+            const float s_op = Gv * dL_dalpha;
+            const float q = B2.y * s_op;
+            const f2 q1 = d * q;                  // (q dx, q dy)
+            const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
+            const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
+            // every lane stores: lanes that share a slot hold the same total
+            const float tot = wave_sum10_transposed(wsm, s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
+            uint32_t joff;                        // SALU multiply: hipcc would pick v_mad_u64_u32 (quarter rate) for j*40 + lane offset
+            asm("s_mul_i32 %0, %1, 40" : "=s"(joff) : "s"(j));
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + (part_lane + joff)) = tot;
+        }
+        if (lane == 0) s_proc[wave][sw] = proc;
     }
-    __shared__ int s_next;
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_next = (int)atomicAdd(tile_counter, 1u);
-        __syncthreads();
-        const int k = s_next;
-        if (k >= ntiles) break;
-        render_bwd_tile(k, gx, ranges, bin_base, header, W, H, bg, means2D, conic_opacity, feat, depths, final_T, n_contrib, dL_dpix,
-                        dL_dpix_depth);
+    __syncthreads();
+    // Add the four quadrants in a fixed order, turn the moments into the reference's gradients and write each instance's
+    // slot (12 floats, 48 B) coalesced.  s_part[q][j][] = {sum G dL_dalpha, M1x, M1y, M2xx, M2xy, M2yy, r, g, b, depth}
+    if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
+        const int j = t;
+        const float4 B4 = s_b[j];                       // {C, opacity, instance id, quadrant mask}
+        float sum[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) sum[k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((s_proc[q][j >> 6] >> (j & 63)) & 1ull) {
+#pragma unroll
+                for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
+            }
+        }
+        const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z}
+        float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.z) * 3;
+        slot[0] = make_float4(-(K4.x * sum[1] + K4.y * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
+                              -(K4.z * sum[2] + K4.y * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
+                              -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
+        slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
+        slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
     }
 }
 
