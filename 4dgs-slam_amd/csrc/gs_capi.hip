@@ -537,7 +537,7 @@ __global__ void debug_reduce10_kernel(const float* in, float* out)
 {
     const int l = threadIdx.x;
     const float* v = in + l * 10;
-    out[l] = wave_sum10_transposed(wave_select_masks(), v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9]);
+    out[l] = wave_sum10_transposed(wave_select_masks(), v[0], f2v{v[1], v[2]}, f2v{v[3], v[4]}, v[5], f2v{v[6], v[7]}, f2v{v[8], v[9]});
 }
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
 {

@@ -21,123 +21,101 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// ---- wave reduction of ten values with DPP adds ------------------------------------------------------------------
-// One v_add_f32 with a DPP source modifier per value and butterfly stage (6 stages), written as inline asm: through
-// the update_dpp builtin hipcc emits v_mov_b32 (old = 0) + v_mov_b32_dpp + half a v_pk_add_f32 per step (its SLP
-// vectoriser packs the adds, and VOP3P cannot take a DPP operand), 2.5x the instructions.
-// The ten chains are interleaved stage by stage, so every DPP read is ten instructions behind the write of its
-// source (the gfx9 "VALU write -> DPP read" hazard needs two wait states; hipcc does not pad inside asm, and the
-// leading s_nop covers values produced right before the statement). Totals are valid in lanes 48..63 (row 3).
-#define GSR_DPP_STAGE(ctrl)                                   \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n\t"                   \
-    "v_add_f32_dpp %9, %9, %9 " ctrl "\n\t"
-__device__ __forceinline__ void wave_sum10_to_row3(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6,
-                                                   float& v7, float& v8, float& v9)
-{
-    asm volatile("s_nop 1\n\t"
-                 GSR_DPP_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 GSR_DPP_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 GSR_DPP_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 GSR_DPP_STAGE("row_mirror row_mask:0xf bank_mask:0xf")
-                 GSR_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 GSR_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 "s_nop 1"
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9));
-}
-#undef GSR_DPP_STAGE
-
 // ---- transposed ("butterfly") wave reduction of ten values -------------------------------------------------------
-// Sums v0..v9 over the 64 lanes in 37 VALU instructions instead of 60: at every butterfly stage a lane keeps only
-// half of its values (adding the partner lane's copy of the same half) instead of carrying all ten through all six
-// stages. On return every lane l holds the wave-wide total of ONE value, selected by p = l & 15:
-//     p:      0   1   2   3   4   5   6   7   8,10,12,14   9,11,13,15
-//     value:  v0  v5  v3  v8  v1  v6  v4  v9      v2            v7
-// (wave_sum10_slot_of_lane() returns that index), so ten lanes can store the ten totals with a single instruction.
-// Stage partners: xor 1 / xor 2 by DPP quad_perm, xor 4 by row_shl:4 / row_shr:4 under bank masks, xor 8 by
-// row_ror:8, xor 16 / xor 32 by gfx950's v_permlane16_swap / v_permlane32_swap. Inline asm because hipcc neither
-// folds DPP into the adds (see above) nor knows the swap instructions; instructions are ordered so that every DPP /
-// permlane source was written at least two issue slots earlier (gfx9 VALU-write -> DPP-read hazard), with s_nop
-// where the stage is too short.
-__device__ __forceinline__ int wave_sum10_slot_of_lane(int lane) { return (int)((0x7272727294618350ull >> (4 * (lane & 15))) & 15ull); }
+// Sums ten per-lane values over the 64 lanes in 23 VALU instructions (a plain butterfly: 60). At every stage a lane keeps
+// only HALF of its values, adding the partner lane's copy of that half, instead of carrying all ten through all six stages;
+// on return every lane holds the wave-wide total of ONE of the ten (wave_sum10_slot_of_lane() tells which), so the totals
+// leave the wave with a single store instruction.
+//   xor 32, xor 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange half of register A with the other half of
+//     register B; A + B then holds A's pair sums in one half of the lanes and B's in the other: 2 instructions per pair
+//     of values, 1.5 with v_pk_add_f32 when both registers of two pairs sit in aligned register pairs -- which is how the
+//     tile kernel produces them ((M1x,M1y), (M2xx,M2xy), (r,g), (b,depth) are f2 values). Ten values -> five -> three.
+//   xor 1, xor 2: DPP quad_perm adds; keep/send selection with v_cndmask (3 instructions per pair). Three values -> one.
+//   xor 8, xor 4: nothing left to select, plain DPP adds (row_ror:8, then row_ror:4 of the now 8-periodic value).
+// The swaps use the compiler builtins (hipcc places the VALU-write -> permlane-read wait states itself); the DPP part is
+// inline asm because hipcc does not fold DPP into the adds (it emits v_mov_dpp + v_add), with s_nop where a DPP source was
+// written less than two issue slots earlier.
+// Which total a lane ends with: bit 1 set -> bit 5 ? M2yy : s_op; else bit 0 ? (second components) : (first components),
+// bit 4 ? colours : moments, bit 5 ? (q2 / c_bd) : (q1 / c_rg).
+//   slots: 0 s_op, 1 q1.x, 2 q1.y, 3 q2.x, 4 q2.y, 5 m2yy, 6 c_rg.x, 7 c_rg.y, 8 c_bd.x, 9 c_bd.y
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wave_sum10_slot_of_lane(int lane)
+{
+    const int b0 = lane & 1, b1 = (lane >> 1) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+    if (b1) return b5 ? 5 : 0;
+    return (b4 ? 6 : 1) + b0 + 2 * b5;
+}
 
-// The four lane-select masks (lanes whose bit 0 / 1 / 2 / 3 is set). Fetch them ONCE outside the loop that reduces: the
-// empty asm makes them opaque, so they live in four SGPR pairs; as visible constants hipcc notices that both halves of
-// each are equal, keeps one half and re-materialises the pair with an s_mov in front of every reduction.
-struct WaveSelectMasks { unsigned long long m0, m1, m2, m3; };
+// The two lane-select masks (lanes whose bit 0 / bit 1 is set). Fetch them ONCE outside the loop that reduces: the empty asm
+// makes them opaque, so they live in SGPR pairs; as visible constants hipcc notices that both halves of each are equal,
+// keeps one half and re-materialises the pair with an s_mov in front of every reduction.
+struct WaveSelectMasks { unsigned long long m0, m1; };
 __device__ __forceinline__ WaveSelectMasks wave_select_masks()
 {
-    WaveSelectMasks w{0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull, 0xFF00FF00FF00FF00ull};
-    asm volatile("" : "+s"(w.m0), "+s"(w.m1), "+s"(w.m2), "+s"(w.m3));
+    WaveSelectMasks w{0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull};
+    asm volatile("" : "+s"(w.m0), "+s"(w.m1));
     return w;
 }
 
-__device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float v0, float v1, float v2, float v3, float v4,
-                                                       float v5, float v6, float v7, float v8, float v9)
+__device__ __forceinline__ void lane_swap32(float& a, float& b)   // lanes 32-63 of a <-> lanes 0-31 of b
 {
-    const unsigned long long m0 = w.m0, m1 = w.m1, m2 = w.m2, m3 = w.m3;
-    float k0, k1, k2, k3, k4, s0, s1, s2, s3, s4;
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b)   // odd 16-lane rows of a <-> even rows of b
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void lane_swap32(f2v& a, f2v& b)
+{
+    float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    lane_swap32(ax, bx); lane_swap32(ay, by);
+    a = f2v{ax, ay}; b = f2v{bx, by};
+}
+__device__ __forceinline__ void lane_swap16(f2v& a, f2v& b)
+{
+    float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    lane_swap16(ax, bx); lane_swap16(ay, by);
+    a = f2v{ax, ay}; b = f2v{bx, by};
+}
+
+__device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float s_op, f2v q1, f2v q2, float m2yy, f2v c_rg, f2v c_bd)
+{
+    // xor 32
+    lane_swap32(q1, q2);
+    f2v P = q1 + q2;
+    lane_swap32(c_rg, c_bd);
+    f2v C = c_rg + c_bd;
+    lane_swap32(s_op, m2yy);
+    float S = s_op + m2yy;
+    // xor 16
+    lane_swap16(P, C);
+    const f2v PC = P + C;
+    float S2 = S;
+    lane_swap16(S, S2);
+    S = S + S2;
+    // xor 1, xor 2 (selecting), xor 8, xor 4 (plain)
+    float keep, send, u, s1, t;
     asm volatile(
-        // stage 1 (xor 1): pairs (v0,v5) (v1,v6) (v2,v7) (v3,v8) (v4,v9): keep = bit0 ? second : first, send the other
-        "v_cndmask_b32_e64 %[k0], %[v0], %[v5], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[s0], %[v5], %[v0], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[k1], %[v1], %[v6], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[s1], %[v6], %[v1], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[k2], %[v2], %[v7], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[s2], %[v7], %[v2], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[k3], %[v3], %[v8], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[s3], %[v8], %[v3], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[k4], %[v4], %[v9], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[s4], %[v9], %[v4], %[m0]\n\t"
-        "v_add_f32_dpp %[k0], %[s0], %[k0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[k1], %[s1], %[k1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[k2], %[s2], %[k2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[k3], %[s3], %[k3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[k4], %[s4], %[k4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        // stage 2 (xor 2): pairs (k0,k3) (k1,k4), k2 alone.  results: s0, s1, k2
-        "v_cndmask_b32_e64 %[s0], %[k0], %[k3], %[m1]\n\t"      // keep A
-        "v_cndmask_b32_e64 %[s2], %[k3], %[k0], %[m1]\n\t"      // send A
-        "v_cndmask_b32_e64 %[s1], %[k1], %[k4], %[m1]\n\t"      // keep B
-        "v_cndmask_b32_e64 %[s3], %[k4], %[k1], %[m1]\n\t"      // send B
-        "v_add_f32_dpp %[k2], %[k2], %[k2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[s0], %[s2], %[s0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %[s1], %[s3], %[s1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        // stage 3 (xor 4): pair (s0,s1), k2 alone.  results: k0 (pair), k1 (single)
-        "v_cndmask_b32_e64 %[k3], %[s0], %[s1], %[m2]\n\t"      // keep
-        "v_cndmask_b32_e64 %[k4], %[s1], %[s0], %[m2]\n\t"      // send
-        "v_add_f32_dpp %[k1], %[k2], %[k2] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %[k1], %[k2], %[k2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %[k0], %[k4], %[k3] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %[k0], %[k4], %[k3] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        // stage 4 (xor 8): pair (k0,k1).  result: s0
-        "v_cndmask_b32_e64 %[s0], %[k0], %[k1], %[m3]\n\t"      // keep
-        "v_cndmask_b32_e64 %[s1], %[k1], %[k0], %[m3]\n\t"      // send
         "s_nop 1\n\t"
-        "v_add_f32_dpp %[s0], %[s1], %[s0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        // stages 5, 6 (xor 16, xor 32): every lane of a column ends with the column total
-        "v_mov_b32 %[s1], %[s0]\n\t"
+        "v_cndmask_b32_e64 %[send], %[y], %[x], %[m0]\n\t"      // bit 0 ? x : y
+        "v_cndmask_b32_e64 %[keep], %[x], %[y], %[m0]\n\t"      // bit 0 ? y : x
+        "v_add_f32_dpp %[s1], %[s], %[s] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[u], %[send], %[keep] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_e64 %[send], %[s1], %[u], %[m1]\n\t"     // bit 1 ? u : s1
+        "v_cndmask_b32_e64 %[keep], %[u], %[s1], %[m1]\n\t"     // bit 1 ? s1 : u
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %[t], %[send], %[keep] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %[s0], %[s1]\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
-        "v_add_f32 %[s0], %[s0], %[s1]\n\t"
-        "v_mov_b32 %[s1], %[s0]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %[s0], %[s1]\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32 %[s0], %[s0], %[s1]\n\t"
+        "v_add_f32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 0"
-        : [k0] "=&v"(k0), [k1] "=&v"(k1), [k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [s0] "=&v"(s0), [s1] "=&v"(s1),
-          [s2] "=&v"(s2), [s3] "=&v"(s3), [s4] "=&v"(s4)
-        : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [v4] "v"(v4), [v5] "v"(v5), [v6] "v"(v6), [v7] "v"(v7),
-          [v8] "v"(v8), [v9] "v"(v9), [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3));
-    return s0;
+        : [keep] "=&v"(keep), [send] "=&v"(send), [u] "=&v"(u), [s1] "=&v"(s1), [t] "=&v"(t)
+        : [x] "v"(PC.x), [y] "v"(PC.y), [s] "v"(S), [m0] "s"(w.m0), [m1] "s"(w.m1));
+    return t;
 }
 
 // Inclusive prefix sum across the wave (6 shuffle steps); used for instance expansion.

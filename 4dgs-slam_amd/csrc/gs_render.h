@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             const f2 q1 = d * q;                  // (q dx, q dy)
             const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
             const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
-            // every lane stores: lanes that share a slot hold the same total
-            const float tot = wave_sum10_transposed(wsm, s_op, q1.x, q1.y, q2.x, q2.y, q1.y * d.y, c_rg.x, c_rg.y, c_bd.x, c_bd.y);
+            // every lane ends with one of the ten totals and stores it: lanes that share a slot hold the same value
+            const float tot = wave_sum10_transposed(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd);
             uint32_t joff;                        // SALU multiply: hipcc would pick v_mad_u64_u32 (quarter rate) for j*40 + lane offset
             asm("s_mul_i32 %0, %1, 40" : "=s"(joff) : "s"(j));
             *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + (part_lane + joff)) = tot;

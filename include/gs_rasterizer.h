@@ -116,7 +116,8 @@ int gsr_debug_read_state(int P, int R, int width, int height,
                          uint32_t* ranges, uint32_t* point_list, void* stream);
 
 /* Test hook for the transposed wave reduction used by the backward tile kernel: in = device float[64][10] (lane-major),
- * out = device float[64]; lane l receives the 64-lane total of value k(l & 15), k = {0,5,3,8,1,6,4,9,2,7,2,7,2,7,2,7}. */
+ * out = device float[64]; lane l receives the 64-lane total of value k(l): bit 1 of l set -> (bit 5 ? 5 : 0), else
+ * (bit 4 ? 6 : 1) + bit 0 + 2 * bit 5. */
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
 
 /* Thread-local text of the last error. */

@@ -204,7 +204,7 @@ def test_full_size_config2_properties_and_subsampled_parity():
 
 
 def test_transposed_wave_reduction_unit():
-    """gs_device.h wave_sum10_transposed: every lane ends with the 64-lane total of the value its (lane & 15) selects."""
+    """gs_device.h wave_sum10_transposed: every lane ends with the 64-lane total of the value its lane bits 0, 1, 4, 5 select."""
     import ctypes
     from diff_gaussian_rasterization import _C
     lib = _C.load_library()
@@ -215,11 +215,14 @@ def test_transposed_wave_reduction_unit():
     out = torch.zeros(64, device="cuda")
     assert lib.gsr_debug_wave_reduce10(xin.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
-    slot = [0, 5, 3, 8, 1, 6, 4, 9, 2, 7, 2, 7, 2, 7, 2, 7]
+    def slot(l):   # gs_device.h wave_sum10_slot_of_lane
+        b0, b1, b4, b5 = l & 1, (l >> 1) & 1, (l >> 4) & 1, (l >> 5) & 1
+        return (5 if b5 else 0) if b1 else (6 if b4 else 1) + b0 + 2 * b5
     want = x.astype(np.float64).sum(0)
     got = out.cpu().numpy()
+    assert sorted(set(slot(l) for l in range(64))) == list(range(10))
     for l in range(64):
-        assert abs(got[l] - want[slot[l & 15]]) < 1e-4, (l, got[l], want[slot[l & 15]])
+        assert abs(got[l] - want[slot(l)]) < 1e-4, (l, got[l], want[slot(l)])
 
 
 def test_huge_tile_grid_uses_global_atomic_binning_fallback():
