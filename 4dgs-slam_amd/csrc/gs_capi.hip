@@ -70,7 +70,7 @@ struct ImageState {
         ImageState s;
         carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
         // one memset per forward pass clears [tile_count, work_counters + 64): per-tile counters, the flag word behind them
-        // (index T*CTR_STRIDE) and the work counters (word 0: geometry_bwd's finished-block count)
+        // (index T*CTR_STRIDE) and the work counters
         carve(p, s.tile_count, T * CTR_STRIDE + 64); carve(p, s.work_counters, 64);
         carve(p, s.tile_cursor, T * CTR_STRIDE);
         carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
@@ -537,7 +537,8 @@ __global__ void debug_reduce10_kernel(const float* in, float* out)
 {
     const int l = threadIdx.x;
     const float* v = in + l * 10;
-    out[l] = wave_sum10_transposed(wave_select_masks(), v[0], f2v{v[1], v[2]}, f2v{v[3], v[4]}, v[5], f2v{v[6], v[7]}, f2v{v[8], v[9]});
+    unsigned long long proc = 0; uint32_t addr;
+    out[l] = wave_sum10_transposed(wave_select_masks(), v[0], f2v{v[1], v[2]}, f2v{v[3], v[4]}, v[5], f2v{v[6], v[7]}, f2v{v[8], v[9]}, proc, 0, 0u, 0, addr);
 }
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
 {

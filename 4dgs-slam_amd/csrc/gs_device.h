@@ -81,7 +81,10 @@ __device__ __forceinline__ void lane_swap16(f2v& a, f2v& b)
     a = f2v{ax, ay}; b = f2v{bx, by};
 }
 
-__device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float s_op, f2v q1, f2v q2, float m2yy, f2v c_rg, f2v c_bd)
+// `proc`/`jj`, `lds_lane`/`j`: the caller's bookkeeping for this entry (mark bit jj in the processed mask, LDS byte address
+// lds_lane + 40 j of the total's slot) rides in issue slots the DPP hazards would otherwise fill with s_nop.
+__device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float s_op, f2v q1, f2v q2, float m2yy, f2v c_rg, f2v c_bd,
+                                                       unsigned long long& proc, int jj, uint32_t lds_lane, int j, uint32_t& lds_addr)
 {
     // xor 32
     lane_swap32(q1, q2);
@@ -96,25 +99,27 @@ __device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w,
     float S2 = S;
     lane_swap16(S, S2);
     S = S + S2;
-    // xor 1, xor 2 (selecting), xor 8, xor 4 (plain)
+    // xor 1, xor 2 (selecting), xor 8, xor 4 (plain). %[s] is read by a DPP two instructions into the block, so whatever wrote
+    // it is at least two issue slots away.
     float keep, send, u, s1, t;
+    uint32_t joff;
     asm volatile(
-        "s_nop 1\n\t"
         "v_cndmask_b32_e64 %[send], %[y], %[x], %[m0]\n\t"      // bit 0 ? x : y
         "v_cndmask_b32_e64 %[keep], %[x], %[y], %[m0]\n\t"      // bit 0 ? y : x
         "v_add_f32_dpp %[s1], %[s], %[s] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %[u], %[send], %[keep] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_cndmask_b32_e64 %[send], %[s1], %[u], %[m1]\n\t"     // bit 1 ? u : s1
         "v_cndmask_b32_e64 %[keep], %[u], %[s1], %[m1]\n\t"     // bit 1 ? s1 : u
-        "s_nop 0\n\t"
+        "s_mul_i32 %[joff], %[j], 40\n\t"
         "v_add_f32_dpp %[t], %[send], %[keep] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
+        "s_bitset1_b64 %[proc], %[jj]\n\t"
+        "v_add_u32 %[addr], %[joff], %[lane]\n\t"
         "v_add_f32_dpp %[t], %[t], %[t] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
-        "v_add_f32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0"
-        : [keep] "=&v"(keep), [send] "=&v"(send), [u] "=&v"(u), [s1] "=&v"(s1), [t] "=&v"(t)
-        : [x] "v"(PC.x), [y] "v"(PC.y), [s] "v"(S), [m0] "s"(w.m0), [m1] "s"(w.m1));
+        "v_add_f32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf"
+        : [keep] "=&v"(keep), [send] "=&v"(send), [u] "=&v"(u), [s1] "=&v"(s1), [t] "=&v"(t), [joff] "=&s"(joff), [addr] "=&v"(lds_addr),
+          [proc] "+s"(proc)
+        : [x] "v"(PC.x), [y] "v"(PC.y), [s] "v"(S), [m0] "s"(w.m0), [m1] "s"(w.m1), [j] "s"(j), [jj] "s"(jj), [lane] "v"(lds_lane));
     return t;
 }
 

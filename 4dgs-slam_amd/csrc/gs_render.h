@@ -347,14 +347,13 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             const int j = sw * 64 + jj;
             const float4 A4 = s_a[j];
             const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
+            const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
             const f2 d = f2{A4.x, A4.y} - pxy;
             const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;             // :684 (times log2 e)
             const float G = __builtin_amdgcn_exp2f(power2);
             const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
             const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
             if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-            asm("s_bitset1_b64 %0, %1" : "+s"(proc) : "s"(jj));
-            const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
             const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
             const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
             const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
@@ -373,10 +372,9 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
             const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
             // every lane ends with one of the ten totals and stores it: lanes that share a slot hold the same value
-            const float tot = wave_sum10_transposed(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd);
-            uint32_t joff;                        // SALU multiply: hipcc would pick v_mad_u64_u32 (quarter rate) for j*40 + lane offset
-            asm("s_mul_i32 %0, %1, 40" : "=s"(joff) : "s"(j));
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + (part_lane + joff)) = tot;
+            uint32_t lds_addr;
+            const float tot = wave_sum10_transposed(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd, proc, jj, part_lane, j, lds_addr);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + lds_addr) = tot;
         }
         if (lane == 0) s_proc[wave][sw] = proc;
     }
