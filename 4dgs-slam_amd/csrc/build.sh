@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -fno-slp-vectorize gs_capi.hip -o ../libgs_rasterizer_hip.so "$@"
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value -Wno-inline-asm -fno-slp-vectorize gs_capi.hip -o ../libgs_rasterizer_hip.so "$@"
 echo "built $(cd .. && pwd)/libgs_rasterizer_hip.so"

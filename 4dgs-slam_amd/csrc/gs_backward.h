@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     }
     if (in_range) {
         a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
-        a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw;
+        if (a.dL_dconic) { a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw; }
         a.dL_dopacity[i] = g_op;
-        a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b;
-        a.dL_ddepth[i] = g_d;
+        if (a.dL_dcolor) { a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b; }
+        if (a.dL_ddepth) a.dL_ddepth[i] = g_d;
     }
 
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -270,9 +270,9 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 #pragma unroll
         for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * i + k] = dmean[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * i + k] = dcov[k];
+        for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
-        for (int k = 0; k < 6; k++) a.dL_dtau[6 * i + k] = dtau[k];
+        for (int k = 0; k < 6; k++) if (a.dL_dtau) a.dL_dtau[6 * i + k] = dtau[k];
         if (a.dL_dscale) {
 #pragma unroll
             for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];

@@ -382,9 +382,10 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
     if (P == 0) { if (dL_dtau_sum) GSR_HIP_CHECK(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), stream)); return 0; }
+    // Intermediate gradients the caller does not want may be NULL (dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D; dL_dtau when
+    // dL_dtau_sum is given): the kernel then keeps them in registers only. gsr_backward itself requires all of them.
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || !means3D || !viewmatrix ||
-        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
-        !dL_dmean3D || !dL_dcov3D || !dL_dtau) {
+        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || (!dL_dtau && !dL_dtau_sum)) {
         g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
@@ -430,6 +431,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscale, float* dL_drot, float* dL_dtau, int debug, void* stream)
 {
+    if (P > 0 && (!dL_dconic || !dL_dcolor || !dL_ddepth || !dL_dcov3D || !dL_dtau)) { g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT; }
     return gsr_backward_fused(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
                               cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, campos, tan_fovx, tan_fovy, radii, geom_buffer,
                               binning_buffer, image_buffer, dL_dpix, dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth,

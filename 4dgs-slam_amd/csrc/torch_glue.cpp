@@ -96,7 +96,8 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
                                    const torch::Tensor& projmatrix_, const torch::Tensor& projmatrix_raw_, double tan_fovx, double tan_fovy,
                                    const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, const torch::Tensor& sh_,
                                    int64_t degree, const torch::Tensor& campos_, const torch::Tensor& geomBuffer, int64_t R,
-                                   const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, int64_t stream)
+                                   const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, bool lean,
+                                   int64_t stream)
 {
     TORCH_CHECK(means3D_.is_cuda(), "means3D is on '", means3D_.device().str(),
                 "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
@@ -109,17 +110,24 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     // Layout: the five tensors that become the Gaussian parameters' .grad come first and back to back
     // (means3D, sh, opacity, scales, rotations), so a data-parallel caller can all-reduce them in place as ONE flat range
     // (mapping_shard.GradBucket detects this); the remaining six follow.
-    const int64_t widths[11] = {3, 3 * M, 1, 3, 4, 3, kChannels, 1, 4, 6, 6};
+    // lean: gradients that only feed other gradients inside the kernel (conic, depth, per-Gaussian tau; colours when they
+    // come from SH; cov3D when it comes from scales/rotations) are neither allocated nor written -- 80 of the 148 bytes the
+    // geometry kernel stores per Gaussian. The autograd Function asks for this; the reference-shaped entry point does not.
+    const bool sh_in = M > 0 && colors_.numel() == 0, cov_in = cov3D_.numel() != 0;
+    const int64_t widths[11] = {3, 3 * M, 1, 3, 4, 3, (lean && sh_in) ? 0 : kChannels, lean ? 0 : 1, lean ? 0 : 4,
+                                (lean && !cov_in) ? 0 : 6, lean ? 0 : 6};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
     torch::Tensor flat = P == 0 ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);
     torch::Tensor v[11];
     int64_t o = 0;
     for (int i = 0; i < 11; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
+    auto shaped = [&](int i, std::vector<int64_t> shape) { return widths[i] ? v[i].view(shape) : v[i]; };   // skipped ones stay empty
     torch::Tensor dL_dmeans3D = v[0].view({P, 3}), dL_dsh = v[1].view({P, M, 3}), dL_dopacity = v[2].view({P, 1}),
                   dL_dscales = v[3].view({P, 3}), dL_drotations = v[4].view({P, 4}), dL_dmeans2D = v[5].view({P, 3}),
-                  dL_dcolors = v[6].view({P, kChannels}), dL_ddepths = v[7].view({P, 1}), dL_dconic = v[8].view({P, 2, 2}),
-                  dL_dcov3D = v[9].view({P, 6}), dL_dtau = v[10].view({P, 6});
+                  dL_dcolors = shaped(6, {P, kChannels}), dL_ddepths = shaped(7, {P, 1}), dL_dconic = shaped(8, {P, 2, 2}),
+                  dL_dcov3D = shaped(9, {P, 6}), dL_dtau = shaped(10, {P, 6});
+    auto optr = [](const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
     torch::Tensor tau_sum = flat.narrow(0, o, 6);
     if (P != 0) {
         const bool sh_path = M > 0 && colors_.numel() == 0;
@@ -136,9 +144,9 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
             fptr(proj, "projmatrix"), fptr(proj_raw, "projmatrix_raw"), fptr(campos, "campos"), (float)tan_fovx, (float)tan_fovy,
             radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()), reinterpret_cast<char*>(binningBuffer.data_ptr()),
             reinterpret_cast<char*>(imageBuffer.data_ptr()), fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), dL_dmeans2D.data_ptr<float>(),
-            dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(), dL_ddepths.data_ptr<float>(),
-            dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), sh_path ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
-            dL_drotations.data_ptr<float>(), dL_dtau.data_ptr<float>(), tau_sum.data_ptr<float>(), debug ? 1 : 0, reinterpret_cast<void*>(stream));
+            optr(dL_dconic), dL_dopacity.data_ptr<float>(), optr(dL_dcolors), optr(dL_ddepths),
+            dL_dmeans3D.data_ptr<float>(), optr(dL_dcov3D), sh_path ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
+            dL_drotations.data_ptr<float>(), optr(dL_dtau), tau_sum.data_ptr<float>(), debug ? 1 : 0, reinterpret_cast<void*>(stream));
         if (rc < 0) fail("gsr_backward", rc);
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum);

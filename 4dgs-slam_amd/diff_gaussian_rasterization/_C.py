@@ -184,16 +184,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                        viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depths,
-                                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, lean=False):
     """Same as rasterize_gaussians_backward plus a 10th result: dL_dtau summed over the Gaussians, float32[6] = [rho, theta]
-    (the reduction the reference's autograd Function does with torch.sum, __init__.py:152-154, fused into the kernels)."""
+    (the reduction the reference's autograd Function does with torch.sum, __init__.py:152-154, fused into the kernels).
+    lean=True: gradients that only feed other gradients inside the kernel are neither allocated nor written and come back
+    as empty tensors -- dL_dtau [P,6] always, dL_dcolors when colours come from SH, dL_dcov3D when it comes from scales and
+    rotations (plus the never-returned dL_dconic / dL_ddepth): 80 of the 148 bytes the kernel stores per Gaussian."""
     _require_device(means3D, "means3D")
     if _glue is not None:
         with torch.cuda.device(means3D.device):
             return _glue.rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, float(scale_modifier),
                                                             cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, float(tan_fovx),
                                                             float(tan_fovy), dL_dout_color, dL_dout_depths, sh, int(degree), campos,
-                                                            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug), _stream(means3D.device))
+                                                            geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug), bool(lean),
+                                                            _stream(means3D.device))
     lib = load_library()
     dev = means3D.device
     P = int(means3D.shape[0])
@@ -203,7 +207,9 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
     # rasterize_points.cu:160-170 (eleven allocator calls + eleven memsets of host/GPU time per backward).
     # Layout: the five tensors that become the Gaussian parameters' .grad come first, back to back (means3D, sh, opacity,
     # scales, rotations), so mapping_shard.GradBucket can all-reduce them in place as one flat range.
-    widths = [3, 3 * M, 1, 3, 4, 3, NUM_CHANNELS, 1, 4, 6, 6]
+    sh_in, cov_in = M > 0 and colors.numel() == 0, cov3D_precomp.numel() != 0
+    widths = [3, 3 * M, 1, 3, 4, 3, 0 if (lean and sh_in) else NUM_CHANNELS, 0 if lean else 1, 0 if lean else 4,
+              0 if (lean and not cov_in) else 6, 0 if lean else 6]
     flat = (torch.zeros if P == 0 else torch.empty)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
     views, o = [], 0
     for w_ in widths:
@@ -211,8 +217,10 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
         o += P * w_
     dL_dmeans3D, dL_dsh, dL_dopacity = views[0].view(P, 3), views[1].view(P, M, 3), views[2].view(P, 1)
     dL_dscales, dL_drotations, dL_dmeans2D = views[3].view(P, 3), views[4].view(P, 4), views[5].view(P, 3)
-    dL_dcolors, dL_ddepths, dL_dconic = views[6].view(P, NUM_CHANNELS), views[7].view(P, 1), views[8].view(P, 2, 2)
-    dL_dcov3D, dL_dtau = views[9].view(P, 6), views[10].view(P, 6)
+    shaped = lambda i, *shape: views[i].view(*shape) if widths[i] else views[i]     # skipped ones stay empty
+    dL_dcolors, dL_ddepths, dL_dconic = shaped(6, P, NUM_CHANNELS), shaped(7, P, 1), shaped(8, P, 2, 2)
+    dL_dcov3D, dL_dtau = shaped(9, P, 6), shaped(10, P, 6)
+    optr = lambda t: t.data_ptr() if t.numel() else None
     tau_sum = flat[o:o + 6]
     if P != 0:
         keep = []
@@ -238,9 +246,9 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
                 float(tan_fovx), float(tan_fovy), p(radii, "radii"),
                 geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
                 p(gc, "dL_dout_color"), p(gd, "dL_dout_depth"),
-                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_ddepths.data_ptr(),
-                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dsh.data_ptr() if sh_path else None,
-                dL_dscales.data_ptr(), dL_drotations.data_ptr(), dL_dtau.data_ptr(), tau_sum.data_ptr(), int(bool(debug)), stream)
+                dL_dmeans2D.data_ptr(), optr(dL_dconic), dL_dopacity.data_ptr(), optr(dL_dcolors), optr(dL_ddepths),
+                dL_dmeans3D.data_ptr(), optr(dL_dcov3D), dL_dsh.data_ptr() if sh_path else None,
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), optr(dL_dtau), tau_sum.data_ptr(), int(bool(debug)), stream)
         if rc < 0:
             _err(lib, rc, "gsr_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum

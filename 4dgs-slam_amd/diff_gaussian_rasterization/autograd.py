@@ -29,6 +29,11 @@ def _call(fn, args, debug, dump_path, message):
         raise
 
 
+def _lean_backward(*args):
+    """Backward without the intermediate per-Gaussian gradients nobody reads here (see _C.rasterize_gaussians_backward_fused)."""
+    return _C.rasterize_gaussians_backward_fused(*args, lean=True)
+
+
 def _pose_grad(vec3, shape):
     """A pose gradient (3 values) shaped like the 3-element input it belongs to, else [1,3] as the reference returns it."""
     if shape is not None and len(shape) >= 1 and math.prod(shape) == 3:
@@ -74,8 +79,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 *_camera_block(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos,
                 geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
         (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau, tau) = _call(
-            _C.rasterize_gaussians_backward_fused, args, rs.debug, "snapshot_bw.dump",
+            _lean_backward, args, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # gradients of inputs that were not given (empty tensors in, empty tensors out) are None for autograd
+        g_colors = g_colors if g_colors.numel() else None
+        g_cov3D = g_cov3D if g_cov3D.numel() else None
         # per-Gaussian [rho | theta] rows -> one pose gradient, each returned as [1,3] (reference :152-154: torch.sum over [P,6]);
         # the sum is produced by the backward kernels themselves (tau = float32[6])
         # The reference returns them as [1,3] and lets autograd sum_to_size them onto the (3,) camera parameters, which costs

@@ -82,7 +82,11 @@ int gsr_backward(int P, int D, int M, int R,
                  int debug, void* stream);
 
 /* gsr_backward plus one fused extra: dL_dtau_sum[6] = sum over Gaussians of dL_dtau (what the reference's Python layer computes
- * with torch.sum, DGR/diff_gaussian_rasterization/__init__.py:152-154). Pass NULL to skip. */
+ * with torch.sum, DGR/diff_gaussian_rasterization/__init__.py:152-154). Pass NULL to skip.
+ * Here -- not in gsr_backward -- gradients that only feed other gradients inside the kernel may be NULL and are then not
+ * written: dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D, and dL_dtau when dL_dtau_sum is given (80 of the 148 bytes stored
+ * per Gaussian). The reference allocates and fills all of them (rasterize_points.cu:160-170) although its autograd Function
+ * drops three (DGR/diff_gaussian_rasterization/__init__.py:139-151). */
 int gsr_backward_fused(int P, int D, int M, int R,
                        const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp,
