@@ -23,7 +23,7 @@ os.makedirs(dst, exist_ok=True)
 def agg(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in dd.items()} for k, dd in d.items()}
 
 
@@ -34,7 +34,7 @@ for name in ("bench.json", "bench_under_rocprof.json"):
 fe = agg(os.path.join(src, "pmc_fetch", f"{tag}_counter_collection.csv"))
 wr = agg(os.path.join(src, "pmc_write", f"{tag}_counter_collection.csv"))
 sq = agg(os.path.join(src, "pmc_sq", f"{tag}_counter_collection.csv"))
-stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
+stats = {r["Name"].split("(")[0].replace("void ", "").split("<")[0]: r for r in csv.DictReader(open(os.path.join(src, "stats", f"{tag}_kernel_stats.csv")))}
 out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 20 --warmup 5`; "
                  "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md)",
        "kernels": {}}
