@@ -22,6 +22,10 @@ struct GeomBwdArgs {
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
     float* tau_partials;   // optional [nblocks][6]: per-block sums of dL_dtau, so the caller does not have to reduce [P,6]
+    // Raw mode (raw.xyz != nullptr, see gs_device.h): the inputs are the model's raw parameters and the outputs their gradients:
+    // dL_dmean3D -> d/d_xyz, dL_dscale -> d/d_scaling [P,scale_dim], dL_drot -> d/d_rotation, dL_dopacity -> d/d_opacity (logit),
+    // rawg.f_dc / f_rest -> d/d_features_*, rawg.ddx / dds / ddr [K,*] -> gradients of the control-node deltas.
+    RawInputs raw; RawGrads rawg;
 };
 
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
@@ -67,19 +71,21 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     if (in_range) {
         a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
         if (a.dL_dconic) { a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw; }
-        a.dL_dopacity[i] = g_op;
+        a.dL_dopacity[i] = a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op;   // raw: through the sigmoid
         if (a.dL_dcolor) { a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b; }
         if (a.dL_ddepth) a.dL_ddepth[i] = g_d;
     }
 
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool has_sh = a.shs != nullptr && a.dL_dsh != nullptr;
+    const bool has_sh = a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr);
+    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * i, a.rawg.f_rest ? a.rawg.f_rest + i * (size_t)(a.M - 1) * 3 : nullptr}
+                                : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr};
     if (!visible) {
-        if (has_sh && in_range) for (int k = 0; k < a.M * 3; k++) a.dL_dsh[i * a.M * 3 + k] = 0.f;
+        if (has_sh && in_range) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
     } else {
         const float* vm = a.viewmatrix;
-        const f3 mean = mk3(a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]);
+        const f3 mean = load_mean(a.means3D, a.raw, i);
         float cov6[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) cov6[k] = a.cov3Ds[6 * i + k];
@@ -184,8 +190,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 
         // ---- backward.cu:21-145: colour -> SH coefficients and (through the view direction) the mean ----
         if (has_sh) {
-            const float* sh = a.shs + i * a.M * 3;
-            float* dsh = a.dL_dsh + i * a.M * 3;
+            const ShView sh = sh_view(a.shs, a.raw, i, a.M);
             const uint32_t cb = a.clamped[idx];
             const float dRGB[3] = {(cb & 1u) ? 0.f : g_r, (cb & 2u) ? 0.f : g_g, (cb & 4u) ? 0.f : g_b};   // :32-35
             const f3 dir_orig = mk3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]);
@@ -240,13 +245,15 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         }
 
         // ---- backward.cu:350-413: cov3D -> scale, quaternion (no normalisation backward, Q1) ----
-        if (a.scales != nullptr) {
-            const float* q4 = a.rotations + 4 * i;
+        if (a.scales != nullptr || a.raw.xyz) {
+            float q4[4], s3[3];
+            load_rot(a.rotations, a.raw, i, q4);
+            load_scale(a.scales, a.raw, i, s3);
             const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
             const float Rq[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                                     {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                                     {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-            const float s[3] = {a.scale_modifier * a.scales[3 * i], a.scale_modifier * a.scales[3 * i + 1], a.scale_modifier * a.scales[3 * i + 2]};
+            const float s[3] = {a.scale_modifier * s3[0], a.scale_modifier * s3[1], a.scale_modifier * s3[2]};
             const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
             float Dm[3][3];   // Dm[k][j] = (2 M dSigma)[k][j] * s_k with M[k][j] = s_k Rq[j][k]
 #pragma unroll
@@ -273,13 +280,36 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) if (a.dL_dtau) a.dL_dtau[6 * i + k] = dtau[k];
-        if (a.dL_dscale) {
+        if (!a.raw.xyz) {
+            if (a.dL_dscale) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
-        }
-        if (a.dL_drot) {
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
+            }
+            if (a.dL_drot) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+                for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+            }
+        } else {
+            // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
+            // effective parameters' gradients of their Gaussian (one Gaussian per slot: plain stores)
+            const int sl = raw_slot(a.raw, i);
+            if (sl >= 0) {
+                if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0]; a.rawg.ddx[3 * sl + 1] = dmean[1]; a.rawg.ddx[3 * sl + 2] = dmean[2]; }
+                if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
+                if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
+            }
+            if (a.raw.scale_dim == 1) {
+                a.dL_dscale[i] = (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k] * expf(a.raw.log_scales[3 * i + k]);
+            }
+            const float ra = a.raw.raw_rot[4 * i], rb = a.raw.raw_rot[4 * i + 1], rc = a.raw.raw_rot[4 * i + 2], rd = a.raw.raw_rot[4 * i + 3];
+            const float inv = 1.0f / fmaxf(sqrtf(ra * ra + rb * rb + rc * rc + rd * rd), 1e-12f);
+            const float qa = ra * inv, qb = rb * inv, qc = rc * inv, qd = rd * inv;
+            const float dotg = qa * drot[0] + qb * drot[1] + qc * drot[2] + qd * drot[3];
+            a.dL_drot[4 * i] = (drot[0] - qa * dotg) * inv; a.dL_drot[4 * i + 1] = (drot[1] - qb * dotg) * inv;
+            a.dL_drot[4 * i + 2] = (drot[2] - qc * dotg) * inv; a.dL_drot[4 * i + 3] = (drot[3] - qd * dotg) * inv;
         }
     }
     // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with

@@ -221,19 +221,40 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return 0;
 }
 
-int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
+}  // extern "C"
+
+static RawInputs to_device_view(const gsr_raw_inputs* in)
+{
+    RawInputs r{};
+    if (in) {
+        r.xyz = in->xyz; r.log_scales = in->log_scales; r.scale_dim = in->scale_dim; r.raw_rot = in->raw_rotations;
+        r.logit_opacity = in->logit_opacity; r.f_dc = in->features_dc; r.f_rest = in->features_rest;
+        r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr;
+    }
+    return r;
+}
+static bool raw_inputs_ok(const gsr_raw_inputs* in, int M)
+{
+    return in->xyz && in->log_scales && (in->scale_dim == 1 || in->scale_dim == 3) && in->raw_rotations && in->logit_opacity &&
+           in->features_dc && (M == 1 || in->features_rest) && ((!in->dx && !in->ds && !in->dr) || in->dyn_slot);
+}
+
+static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
                 gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream_)
+                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream_, const gsr_raw_inputs* raw)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc) {
         g_last_error = "gsr_forward: invalid size or missing allocator"; return GSR_ERR_INVALID_ARGUMENT;
     }
     if (!background || !out_color || !out_depth || !out_opacity || !n_touched) { g_last_error = "gsr_forward: null output/background"; return GSR_ERR_INVALID_ARGUMENT; }
-    if (P > 0) {
+    if (P > 0 && raw) {
+        if (!viewmatrix || !projmatrix || !cam_pos || M <= 0 || !raw_inputs_ok(raw, M)) { g_last_error = "gsr_forward_raw: null / inconsistent input"; return GSR_ERR_INVALID_ARGUMENT; }
+        if (D < 0 || D > 3 || (D + 1) * (D + 1) > M) { g_last_error = "gsr_forward_raw: sh degree out of range for M"; return GSR_ERR_INVALID_ARGUMENT; }
+    } else if (P > 0) {
         if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos) { g_last_error = "gsr_forward: null input"; return GSR_ERR_INVALID_ARGUMENT; }
         if (!cov3D_precomp && (!scales || !rotations)) { g_last_error = "gsr_forward: need scales+rotations or cov3D_precomp"; return GSR_ERR_INVALID_ARGUMENT; }
         // rasterizer_impl.cu:245-248 analogue: colours must come from somewhere
@@ -269,6 +290,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
         a.depths = geom.depths; a.means2D = geom.means2D; a.conic_opacity = geom.conic_opacity; a.rgb = geom.rgb; a.cov3D = geom.cov3D;
         a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums; a.tile_count = img.tile_count;
         a.flags = flags; a.block_tile_base = lds_hist ? img.block_tile_base : nullptr;
+        a.raw = to_device_view(raw);
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
             hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
@@ -371,21 +393,51 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn b
     return (int)R;
 }
 
-int gsr_backward_fused(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+extern "C" {
+
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream)
+{
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                        cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_opacity, radii, n_touched, debug, stream, nullptr);
+}
+
+int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                    gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+                    const gsr_raw_inputs* in, float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                    float tan_fovx, float tan_fovy, float* out_color, float* out_depth, float* out_opacity, int* radii, int* n_touched,
+                    int debug, void* stream)
+{
+    if (!in) { g_last_error = "gsr_forward_raw: null input descriptor"; return GSR_ERR_INVALID_ARGUMENT; }
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, 0, out_color, out_depth, out_opacity, radii, n_touched, debug, stream, in);
+}
+
+}  // extern "C"
+
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
                  const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
                  char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscale, float* dL_drot, float* dL_dtau, float* dL_dtau_sum, int debug, void* stream_)
+                 float* dL_dscale, float* dL_drot, float* dL_dtau, float* dL_dtau_sum, int debug, void* stream_,
+                 const gsr_raw_inputs* raw, const gsr_raw_grads* rawg)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
     if (P == 0) { if (dL_dtau_sum) GSR_HIP_CHECK(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), stream)); return 0; }
     // Intermediate gradients the caller does not want may be NULL (dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D; dL_dtau when
     // dL_dtau_sum is given): the kernel then keeps them in registers only. gsr_backward itself requires all of them.
-    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || !means3D || !viewmatrix ||
-        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || (!dL_dtau && !dL_dtau_sum)) {
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || (!means3D && !raw) || !viewmatrix ||
+        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || (!dL_dtau && !dL_dtau_sum) ||
+        (raw && (!raw_inputs_ok(raw, M) || !rawg || !dL_dscale || !dL_drot || !rawg->features_dc || (M > 1 && !rawg->features_rest)))) {
         g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
@@ -413,6 +465,9 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
+    a.raw = to_device_view(raw);
+    a.rawg = RawGrads{};
+    if (raw) { a.rawg.f_dc = rawg->features_dc; a.rawg.f_rest = rawg->features_rest; a.rawg.ddx = rawg->dx; a.rawg.dds = rawg->ds; a.rawg.ddr = rawg->dr; a.rawg.scale_dim = raw->scale_dim; }
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
         hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
@@ -421,6 +476,35 @@ int gsr_backward_fused(int P, int D, int M, int R, const float* background, int 
     }
     GSR_STAGE("geometry_bwd");
     return 0;
+}
+
+extern "C" {
+
+int gsr_backward_fused(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
+                 const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                 char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscale, float* dL_drot, float* dL_dtau, float* dL_dtau_sum, int debug, void* stream)
+{
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, projmatrix_raw, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer,
+                         dL_dpix, dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                         dL_dscale, dL_drot, dL_dtau, dL_dtau_sum, debug, stream, nullptr, nullptr);
+}
+
+int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const gsr_raw_inputs* in,
+                     float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw,
+                     const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,
+                     char* image_buffer, const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, const gsr_raw_grads* out,
+                     float* dL_dtau_sum, int debug, void* stream)
+{
+    if (!in || !out) { g_last_error = "gsr_backward_raw: null descriptor"; return GSR_ERR_INVALID_ARGUMENT; }
+    return backward_impl(P, D, M, R, background, width, height, nullptr, nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, viewmatrix,
+                         projmatrix, projmatrix_raw, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix,
+                         dL_dpix_depth, dL_dmean2D, nullptr, out->logit_opacity, nullptr, nullptr, out->xyz, nullptr, nullptr,
+                         out->log_scales, out->raw_rotations, nullptr, dL_dtau_sum, debug, stream, in, out);
 }
 
 int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,

@@ -201,9 +201,66 @@ __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R,
 enum { HDR_R = 0, HDR_FLAGS = 1, HDR_R_ALLOC = 2, HDR_MAX_TILE = 3, HDR_CARVE_R = 4, HDR_CAP_SORTED = 5, HDR_CHUNKS = 6, HDR_WORDS = 8 };
 enum { FLAG_PREFILTERED = 1u, FLAG_OVERFLOW = 2u };   // FLAG_OVERFLOW: the speculative binning capacity did not suffice
 
+// ---- how the kernels read a Gaussian: the reference's activated tensors, or the model's raw parameters ------------------
+// Raw mode (xyz != nullptr) folds the prologue of the reference's render() into the kernels' loads
+// (gaussian_splatting/gaussian_renderer/__init__.py:108-127,159-174; scene/gaussian_model.py:60-68,100-128):
+//   means3D = _xyz (+ dx[slot]);  scales = exp(_scaling) (+ ds[slot], isotropic models repeat the one value);
+//   rotations = _rotation / max(|_rotation|, 1e-12) (+ dr[slot]);  opacity = sigmoid(_opacity);  shs = cat(_features_dc, _features_rest)
+// where slot = dyn_slot[i] >= 0 marks the dynamic subset (pc.dygs) the control-node deltas apply to. The backward kernel
+// applies the matching chain rules on its stores (geometry_bwd_kernel).
+struct RawInputs {
+    const float* xyz; const float* log_scales; int scale_dim; const float* raw_rot; const float* logit_opacity;
+    const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;
+};
+struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; };
+struct ShView {    // SH coefficients of one Gaussian: [k] with k = 3 * coefficient + channel
+    const float* dc; const float* rest;
+    __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
+};
+struct ShOut {
+    float* dc; float* rest;
+    __device__ __forceinline__ float& operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
+};
+
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+__device__ __forceinline__ int raw_slot(const RawInputs& r, size_t i) { return r.dyn_slot ? r.dyn_slot[i] : -1; }
+__device__ __forceinline__ f3 load_mean(const float* means3D, const RawInputs& r, size_t i)
+{
+    if (!r.xyz) return mk3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    f3 m = mk3(r.xyz[3 * i], r.xyz[3 * i + 1], r.xyz[3 * i + 2]);
+    const int sl = raw_slot(r, i);
+    if (sl >= 0 && r.dx) { m.x += r.dx[3 * sl]; m.y += r.dx[3 * sl + 1]; m.z += r.dx[3 * sl + 2]; }
+    return m;
+}
+__device__ __forceinline__ void load_scale(const float* scales, const RawInputs& r, size_t i, float s[3])
+{
+    if (!r.xyz) { s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2]; return; }
+    if (r.scale_dim == 1) { s[0] = s[1] = s[2] = expf(r.log_scales[i]); }
+    else { s[0] = expf(r.log_scales[3 * i]); s[1] = expf(r.log_scales[3 * i + 1]); s[2] = expf(r.log_scales[3 * i + 2]); }
+    const int sl = raw_slot(r, i);
+    if (sl >= 0 && r.ds) { s[0] += r.ds[3 * sl]; s[1] += r.ds[3 * sl + 1]; s[2] += r.ds[3 * sl + 2]; }
+}
+__device__ __forceinline__ void load_rot(const float* rotations, const RawInputs& r, size_t i, float q[4])
+{
+    if (!r.xyz) { q[0] = rotations[4 * i]; q[1] = rotations[4 * i + 1]; q[2] = rotations[4 * i + 2]; q[3] = rotations[4 * i + 3]; return; }
+    const float a = r.raw_rot[4 * i], b = r.raw_rot[4 * i + 1], c = r.raw_rot[4 * i + 2], d = r.raw_rot[4 * i + 3];
+    const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c + d * d), 1e-12f);     // torch.nn.functional.normalize
+    q[0] = a * inv; q[1] = b * inv; q[2] = c * inv; q[3] = d * inv;
+    const int sl = raw_slot(r, i);
+    if (sl >= 0 && r.dr) { q[0] += r.dr[4 * sl]; q[1] += r.dr[4 * sl + 1]; q[2] += r.dr[4 * sl + 2]; q[3] += r.dr[4 * sl + 3]; }
+}
+__device__ __forceinline__ float load_opacity(const float* opacities, const RawInputs& r, size_t i)
+{
+    return r.xyz ? 1.0f / (1.0f + expf(-r.logit_opacity[i])) : opacities[i];           // torch.sigmoid
+}
+__device__ __forceinline__ ShView sh_view(const float* shs, const RawInputs& r, size_t i, int M)
+{
+    if (!r.xyz) { const float* p = shs + i * M * 3; return ShView{p, p + 3}; }
+    return ShView{r.f_dc + 3 * i, r.f_rest ? r.f_rest + i * (size_t)(M - 1) * 3 : nullptr};
+}
 
 // Matrices arrive as the reference passes them: row-major memory of the TRANSPOSED maths matrix,
 // i.e. m[0],m[4],m[8],m[12] is row 0 (auxiliary.h:58-77).

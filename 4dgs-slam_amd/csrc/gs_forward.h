@@ -34,6 +34,7 @@ struct PreprocessArgs {
     float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* flags;   // flags: zero-filled together with tile_count
     uint32_t* block_tile_base;   // [nblocks][T] when the LDS histogram path is taken, else nullptr
+    RawInputs raw;               // raw.xyz != nullptr: read the model's raw parameters instead (fused prologue, gs_device.h)
 };
 
 // forward.cu:120-154 -- Sigma = Rq diag(s*mod)^2 Rq^T, quaternion deliberately NOT normalised (:129).
@@ -96,7 +97,7 @@ __device__ __forceinline__ Cov2D cov2d_eval(f3 mean, float fx, float fy, float t
 }
 
 // forward.cu:22-73. sh points at this Gaussian's [M,3] coefficients. Returns rgb (>=0) and the 3 clamp flags as bits.
-__device__ __forceinline__ f3 sh_to_rgb(int deg, const float* __restrict__ sh, f3 pos, f3 campos, uint32_t& clamp_bits)
+__device__ __forceinline__ f3 sh_to_rgb(int deg, const ShView sh, f3 pos, f3 campos, uint32_t& clamp_bits)
 {
     f3 dir = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
     const float inv = 1.0f / sqrtf(dot3(dir, dir));
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
     if (idx < a.P) {
         int my_radius = 0;
         if (a.n_touched) a.n_touched[idx] = 0;
-        const f3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const f3 p = load_mean(a.means3D, a.raw, (size_t)idx);
         const f3 p_view = xform_point_4x3(p, a.viewmatrix);
         // near cull only (auxiliary.h:139-164); a culled point under `prefiltered` is an error (:156-160)
         if (p_view.z <= 0.2f) {
@@ -159,7 +160,10 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 #pragma unroll
                 for (int k = 0; k < 6; k++) cov6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                cov3d_from_scale_rot(a.scales + 3 * (size_t)idx, a.scale_modifier, a.rotations + 4 * (size_t)idx, cov6);
+                float s3[3], q4[4];
+                load_scale(a.scales, a.raw, (size_t)idx, s3);
+                load_rot(a.rotations, a.raw, (size_t)idx, q4);
+                cov3d_from_scale_rot(s3, a.scale_modifier, q4, cov6);
 #pragma unroll
                 for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = cov6[k];
             }
@@ -177,13 +181,13 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
                 if (area != 0) {
                     if (a.colors_precomp == nullptr) {
                         uint32_t cb;
-                        const f3 c = sh_to_rgb(a.D, a.shs + (size_t)idx * a.M * 3, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
+                        const f3 c = sh_to_rgb(a.D, sh_view(a.shs, a.raw, (size_t)idx, a.M), p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
                         a.rgb[3 * (size_t)idx] = c.x; a.rgb[3 * (size_t)idx + 1] = c.y; a.rgb[3 * (size_t)idx + 2] = c.z;
                         a.clamped[idx] = (uint8_t)cb;
                     }
                     a.depths[idx] = p_view.z;
                     a.means2D[idx] = make_float2(px, py);
-                    a.conic_opacity[idx] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, a.opacities[idx]);
+                    a.conic_opacity[idx] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, load_opacity(a.opacities, a.raw, (size_t)idx));
                     my_radius = (int)rad_f;
                     touched = (uint32_t)area;
                     rx0 = x0; ry0 = y0; rw = x1 - x0;

@@ -152,6 +152,118 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum);
 }
 
+// ---- fused prologue: gsr_forward_raw / gsr_backward_raw, see diff_gaussian_rasterization/raw.py ----
+namespace {
+const torch::Tensor& nz(const c10::optional<torch::Tensor>& t, const torch::Tensor& empty) { return t.has_value() ? *t : empty; }
+
+gsr_raw_inputs describe(const torch::Tensor& xyz, const torch::Tensor& log_scales, const torch::Tensor& raw_rot, const torch::Tensor& logit,
+                        const torch::Tensor& f_dc, const torch::Tensor& f_rest, const torch::Tensor& dyn_slot, const torch::Tensor& dx,
+                        const torch::Tensor& ds, const torch::Tensor& dr)
+{
+    gsr_raw_inputs d{};
+    d.xyz = fptr(xyz, "_xyz"); d.log_scales = fptr(log_scales, "_scaling"); d.scale_dim = (int)log_scales.size(-1);
+    d.raw_rotations = fptr(raw_rot, "_rotation"); d.logit_opacity = fptr(logit, "_opacity");
+    d.features_dc = fptr(f_dc, "_features_dc"); d.features_rest = fptr(f_rest, "_features_rest");
+    if (dyn_slot.defined() && dyn_slot.numel() != 0) {
+        TORCH_CHECK(dyn_slot.is_cuda() && dyn_slot.scalar_type() == torch::kInt32 && dyn_slot.is_contiguous(), "dyn_slot must be a contiguous int32 device tensor");
+        d.dyn_slot = dyn_slot.data_ptr<int>();
+    }
+    d.dx = fptr(dx, "dx"); d.ds = fptr(ds, "ds"); d.dr = fptr(dr, "dr");
+    return d;
+}
+}  // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterize_gaussians_raw(const torch::Tensor& background, const torch::Tensor& xyz_, const torch::Tensor& log_scales_, const torch::Tensor& raw_rot_,
+                        const torch::Tensor& logit_, const torch::Tensor& f_dc_, const c10::optional<torch::Tensor>& f_rest_,
+                        const c10::optional<torch::Tensor>& dyn_slot_, const c10::optional<torch::Tensor>& dx_,
+                        const c10::optional<torch::Tensor>& ds_, const c10::optional<torch::Tensor>& dr_, double scale_modifier,
+                        const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, double tan_fovx, double tan_fovy,
+                        int64_t image_height, int64_t image_width, int64_t degree, const torch::Tensor& campos_, bool debug, int64_t stream)
+{
+    TORCH_CHECK(xyz_.dim() == 2 && xyz_.size(1) == 3 && xyz_.size(0) > 0, "_xyz must have dimensions (num_points > 0, 3)");
+    TORCH_CHECK(xyz_.is_cuda(), "_xyz is on '", xyz_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const torch::Tensor none;
+    const int P = (int)xyz_.size(0), H = (int)image_height, W = (int)image_width;
+    auto fopt = xyz_.options().dtype(torch::kFloat32);
+    auto iopt = xyz_.options().dtype(torch::kInt32);
+    auto bopt = xyz_.options().dtype(torch::kUInt8);
+    torch::Tensor img = torch::empty({kChannels + 2, H, W}, fopt);
+    torch::Tensor ints = torch::empty({2, P}, iopt);
+    torch::Tensor out_color = img.narrow(0, 0, kChannels), out_depth = img.narrow(0, kChannels, 1), out_opacity = img.narrow(0, kChannels + 1, 1);
+    torch::Tensor radii = ints.select(0, 0), n_touched = ints.select(0, 1);
+    torch::Tensor geomBuffer = torch::empty({0}, bopt), binningBuffer = torch::empty({0}, bopt), imgBuffer = torch::empty({0}, bopt);
+    const torch::Tensor bg = contig(background), xyz = contig(xyz_), ls = contig(log_scales_), rr = contig(raw_rot_), lo = contig(logit_),
+                        fdc = contig(f_dc_), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none)), dx = contig(nz(dx_, none)),
+                        ds = contig(nz(ds_, none)), dr = contig(nz(dr_, none)), view = contig(viewmatrix_), proj = contig(projmatrix_),
+                        campos = contig(campos_);
+    const int M = 1 + (frest.defined() && frest.numel() != 0 ? (int)frest.size(1) : 0);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr);
+    const int rendered = gsr_forward_raw(resize_cb, &geomBuffer, resize_cb, &binningBuffer, resize_cb, &imgBuffer, P, (int)degree, M, fptr(bg, "bg"),
+                                         W, H, &in, (float)scale_modifier, fptr(view, "viewmatrix"), fptr(proj, "projmatrix"), fptr(campos, "campos"),
+                                         (float)tan_fovx, (float)tan_fovy, out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
+                                         out_opacity.data_ptr<float>(), radii.data_ptr<int>(), n_touched.data_ptr<int>(), debug ? 1 : 0,
+                                         reinterpret_cast<void*>(stream));
+    if (rendered < 0) fail("gsr_forward_raw", rendered);
+    return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth, out_opacity, n_touched);
+}
+
+// returns (g_xyz, g_f_dc, g_f_rest, g_logit, g_log_scales, g_raw_rot, g_means2D, g_dx, g_ds, g_dr, tau_sum): the first six are
+// views of one allocation in the optimizer's parameter order
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor, torch::Tensor>
+rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::Tensor& xyz_, const torch::Tensor& log_scales_,
+                                 const torch::Tensor& raw_rot_, const torch::Tensor& logit_, const torch::Tensor& f_dc_,
+                                 const c10::optional<torch::Tensor>& f_rest_, const c10::optional<torch::Tensor>& dyn_slot_,
+                                 const c10::optional<torch::Tensor>& dx_, const c10::optional<torch::Tensor>& ds_,
+                                 const c10::optional<torch::Tensor>& dr_, double scale_modifier, const torch::Tensor& viewmatrix_,
+                                 const torch::Tensor& projmatrix_, const torch::Tensor& projmatrix_raw_, double tan_fovx, double tan_fovy,
+                                 const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, int64_t degree,
+                                 const torch::Tensor& campos_, const torch::Tensor& radii_, const torch::Tensor& geomBuffer, int64_t R,
+                                 const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, int64_t stream)
+{
+    const torch::Tensor none;
+    const int64_t P = xyz_.size(0), S = log_scales_.size(-1);
+    const int H = (int)dL_dout_color_.size(1), W = (int)dL_dout_color_.size(2);
+    const torch::Tensor bg = contig(background), xyz = contig(xyz_), ls = contig(log_scales_), rr = contig(raw_rot_), lo = contig(logit_),
+                        fdc = contig(f_dc_), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none)), dx = contig(nz(dx_, none)),
+                        ds = contig(nz(ds_, none)), dr = contig(nz(dr_, none)), view = contig(viewmatrix_), proj = contig(projmatrix_),
+                        proj_raw = contig(projmatrix_raw_), campos = contig(campos_), radii = contig(radii_),
+                        gc = contig(dL_dout_color_.scalar_type() == torch::kFloat32 ? dL_dout_color_ : dL_dout_color_.to(torch::kFloat32)),
+                        gd = contig(dL_dout_depths_.scalar_type() == torch::kFloat32 ? dL_dout_depths_ : dL_dout_depths_.to(torch::kFloat32));
+    const int64_t M = 1 + (frest.defined() && frest.numel() != 0 ? frest.size(1) : 0);
+    auto fopt = xyz.options().dtype(torch::kFloat32);
+    const int64_t widths[7] = {3, 3, 3 * (M - 1), 1, S, 4, 3};
+    int64_t total = 6;
+    for (int64_t w : widths) total += P * w;
+    torch::Tensor flat = torch::empty({total}, fopt);
+    torch::Tensor v[7];
+    int64_t o = 0;
+    for (int i = 0; i < 7; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
+    torch::Tensor g_xyz = v[0].view({P, 3}), g_fdc = v[1].view({P, 1, 3}), g_frest = v[2].view({P, M - 1, 3}), g_logit = v[3].view(lo.sizes()),
+                  g_ls = v[4].view({P, S}), g_rot = v[5].view({P, 4}), g_m2d = v[6].view({P, 3});
+    torch::Tensor tau_sum = flat.narrow(0, o, 6);
+    auto zeros_like_opt = [&](const torch::Tensor& t) { return (t.defined() && t.numel() != 0) ? torch::zeros_like(t, fopt) : torch::Tensor(); };
+    torch::Tensor g_dx = zeros_like_opt(dx), g_ds = zeros_like_opt(ds), g_dr = zeros_like_opt(dr);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr);
+    gsr_raw_grads out{};
+    out.xyz = g_xyz.data_ptr<float>(); out.log_scales = g_ls.data_ptr<float>(); out.raw_rotations = g_rot.data_ptr<float>();
+    out.logit_opacity = g_logit.data_ptr<float>(); out.features_dc = g_fdc.data_ptr<float>();
+    out.features_rest = M > 1 ? g_frest.data_ptr<float>() : nullptr;
+    out.dx = g_dx.defined() ? g_dx.data_ptr<float>() : nullptr; out.ds = g_ds.defined() ? g_ds.data_ptr<float>() : nullptr;
+    out.dr = g_dr.defined() ? g_dr.data_ptr<float>() : nullptr;
+    TORCH_CHECK(radii.is_cuda() && radii.scalar_type() == torch::kInt32, "radii must be an int32 device tensor");
+    const int rc = gsr_backward_raw((int)P, (int)degree, (int)M, (int)R, fptr(bg, "bg"), W, H, &in, (float)scale_modifier, fptr(view, "viewmatrix"),
+                                    fptr(proj, "projmatrix"), fptr(proj_raw, "projmatrix_raw"), fptr(campos, "campos"), (float)tan_fovx,
+                                    (float)tan_fovy, radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()),
+                                    reinterpret_cast<char*>(binningBuffer.data_ptr()), reinterpret_cast<char*>(imageBuffer.data_ptr()),
+                                    fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), g_m2d.data_ptr<float>(), &out, tau_sum.data_ptr<float>(),
+                                    debug ? 1 : 0, reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_backward_raw", rc);
+    return std::make_tuple(g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau_sum);
+}
+
 // markVisible, rasterize_points.cu:213-232
 torch::Tensor mark_visible(const torch::Tensor& means3D_, const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, int64_t stream)
 {
@@ -189,6 +301,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("rasterize_gaussians", &rasterize_gaussians);
     m.def("rasterize_gaussians_backward_fused", &rasterize_gaussians_backward_fused);
+    m.def("rasterize_gaussians_raw", &rasterize_gaussians_raw);
+    m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
     m.def("mark_visible", &mark_visible);
     m.def("dist_cuda2", &dist_cuda2);
 }

@@ -1,0 +1,202 @@
+"""Fused prologue: rasterize straight from the GaussianModel's raw parameters.
+
+The reference's ``render()`` (gaussian_splatting/gaussian_renderer/__init__.py:108-127,159-174) builds the rasterizer inputs
+with a chain of small torch kernels per view --
+
+    means3D   = pc._xyz + scatter(dx -> pc.dygs)
+    scales    = exp(pc._scaling) [.repeat(1, 3) if isotropic] + scatter(ds -> pc.dygs)
+    rotations = normalize(pc._rotation) + scatter(dr -> pc.dygs)
+    opacities = sigmoid(pc._opacity)
+    shs       = cat(pc._features_dc, pc._features_rest, dim=1)
+
+(scene/gaussian_model.py:60-68,100-128) and autograd replays as many on the way back. ``rasterize_gaussians_raw`` hands the
+raw tensors to ``gsr_forward_raw`` / ``gsr_backward_raw`` (include/gs_rasterizer.h), which apply these maps and their chain
+rules inside the preprocess / geometry-backward kernels: same image, same gradients, ~25 kernel launches per view fewer.
+``gaussian_renderer.render`` takes this route by itself when the model allows it (see ``_fused_prologue_ok`` there).
+
+The six parameter gradients come back as views of ONE allocation, in the optimizer's parameter order
+(xyz, f_dc, f_rest, opacity, scaling, rotation; gaussian_model.py:404-434), so ``mapping_shard.GradBucket`` can all-reduce
+them in place.
+"""
+import ctypes as C
+
+import torch
+
+from . import _C
+from .autograd import _pose_grad
+
+_f, _i, _vp = C.c_float, C.c_int, C.c_void_p
+
+
+class _RawInputs(C.Structure):     # gsr_raw_inputs
+    _fields_ = [("xyz", _vp), ("log_scales", _vp), ("scale_dim", _i), ("raw_rotations", _vp), ("logit_opacity", _vp),
+                ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp)]
+
+
+class _RawGrads(C.Structure):      # gsr_raw_grads
+    _fields_ = [("xyz", _vp), ("log_scales", _vp), ("raw_rotations", _vp), ("logit_opacity", _vp), ("features_dc", _vp),
+                ("features_rest", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp)]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = _C.load_library()
+    if not _declared:
+        lib.gsr_forward_raw.restype = _i
+        lib.gsr_forward_raw.argtypes = [_C._ALLOC_FN, _vp, _C._ALLOC_FN, _vp, _C._ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i,
+                                        C.POINTER(_RawInputs), _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]
+        lib.gsr_backward_raw.restype = _i
+        lib.gsr_backward_raw.argtypes = [_i, _i, _i, _i, _vp, _i, _i, C.POINTER(_RawInputs), _f, _vp, _vp, _vp, _vp, _f, _f, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_RawGrads), _vp, _i, _vp]
+        _declared = True
+    return lib
+
+
+def _f32(t, name, keep):
+    """Device pointer of a contiguous float32 (or int32 for dyn_slot) tensor; None / empty -> NULL."""
+    if t is None or t.numel() == 0:
+        return None
+    _C._require_device(t, name)
+    tc = t.contiguous()
+    keep.append(tc)
+    return tc.data_ptr()
+
+
+def _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep):
+    for t, name in ((xyz, "_xyz"), (log_scales, "_scaling"), (raw_rot, "_rotation"), (logit_opacity, "_opacity"), (f_dc, "_features_dc")):
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    if dyn_slot is not None and dyn_slot.dtype != torch.int32:
+        raise RuntimeError("dyn_slot must be int32")
+    d = _RawInputs()
+    d.xyz, d.log_scales, d.scale_dim = _f32(xyz, "_xyz", keep), _f32(log_scales, "_scaling", keep), int(log_scales.shape[-1])
+    d.raw_rotations, d.logit_opacity = _f32(raw_rot, "_rotation", keep), _f32(logit_opacity, "_opacity", keep)
+    d.features_dc, d.features_rest = _f32(f_dc, "_features_dc", keep), _f32(f_rest, "_features_rest", keep)
+    d.dyn_slot, d.dx, d.ds, d.dr = _f32(dyn_slot, "dyn_slot", keep), _f32(dx, "dx", keep), _f32(ds, "ds", keep), _f32(dr, "dr", keep)
+    return d
+
+
+def dyn_slot_from_mask(dygs: torch.Tensor) -> torch.Tensor:
+    """int32[P]: position of every dynamic Gaussian inside ``x[dygs]`` (the row of dx / ds / dr it receives), -1 elsewhere."""
+    m = dygs.to(torch.bool)
+    return torch.where(m, torch.cumsum(m.to(torch.int32), 0, dtype=torch.int32) - 1, torch.full_like(m, -1, dtype=torch.int32))
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs):
+        _C._require_device(xyz, "_xyz")
+        dev = xyz.device
+        ctx.rs = rs
+        ctx.pose_shapes = (tuple(theta.shape) if isinstance(theta, torch.Tensor) else None,
+                           tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
+        ctx.set_materialize_grads(False)
+        if _C._glue is not None:      # native host glue (csrc/torch_glue.cpp): same calls, marshalled in C++
+            with torch.cuda.device(dev):
+                (rc, color, radii, geom_t, bin_t, img_t, depth, opacity, n_touched) = _C._glue.rasterize_gaussians_raw(
+                    rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
+                    rs.viewmatrix, rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height), int(rs.image_width),
+                    int(rs.sh_degree), rs.campos, bool(rs.debug), _C._stream(dev))
+            ctx.num_rendered = rc
+            ctx.M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
+            ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii, geom_t, bin_t, img_t)
+            ctx.mark_non_differentiable(radii, n_touched)
+            return color, radii, depth, opacity, n_touched
+        lib = _lib()
+        P, H, W = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width)
+        M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
+        img = torch.empty((_C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        color, depth, opacity = img[:_C.NUM_CHANNELS], img[_C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[_C.NUM_CHANNELS + 1:]
+        ints = torch.empty((2, P), dtype=torch.int32, device=dev)
+        radii, n_touched = ints[0], ints[1]
+        geom, binning, imgbuf = _C._Arena(dev), _C._Arena(dev), _C._Arena(dev)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_forward_raw(
+                geom.cb, None, binning.cb, None, imgbuf.cb, None, P, int(rs.sh_degree), M, _f32(rs.bg, "bg", keep), W, H,
+                C.byref(desc), float(rs.scale_modifier), _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep),
+                _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy),
+                color.data_ptr(), depth.data_ptr(), opacity.data_ptr(), radii.data_ptr(), n_touched.data_ptr(),
+                int(bool(rs.debug)), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_forward_raw")
+        ctx.num_rendered, ctx.M = rc, M
+        ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii,
+                              geom.tensor, binning.tensor, imgbuf.tensor)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_depth, _g_opacity, _g_touched):
+        rs, M = ctx.rs, ctx.M
+        (xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii, geom, binning, imgbuf) = ctx.saved_tensors
+        dev = xyz.device
+        P, H, W, S = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width), int(log_scales.shape[-1])
+        if g_color is None:
+            g_color = xyz.new_zeros((3, H, W))
+        if g_depth is None:
+            g_depth = xyz.new_zeros((1, H, W))
+        th_shape, rho_shape = ctx.pose_shapes
+        if _C._glue is not None:
+            with torch.cuda.device(dev):
+                (g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau) = _C._glue.rasterize_gaussians_raw_backward(
+                    rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
+                    rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth,
+                    int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), _C._stream(dev))
+            opt = lambda t, src: t if src is not None and src.numel() else None
+            return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, opt(g_dx, dx), opt(g_ds, ds), opt(g_dr, dr),
+                    _pose_grad(tau[3:], th_shape) if th_shape is not None else None,
+                    _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None, None)
+        lib = _lib()
+        g_color = g_color if g_color.dtype == torch.float32 else g_color.to(torch.float32)
+        g_depth = g_depth if g_depth.dtype == torch.float32 else g_depth.to(torch.float32)
+        # one allocation; parameter order of the optimizer (gaussian_model.py:404-434), then the screen-space gradient
+        widths = [3, 3, 3 * (M - 1), 1, S, 4, 3]
+        flat = torch.empty((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for w_ in widths:
+            views.append(flat[o:o + P * w_])
+            o += P * w_
+        g_xyz, g_fdc, g_frest = views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, M - 1, 3)
+        g_logit, g_ls, g_rot, g_m2d = views[3].view(logit_opacity.shape), views[4].view(P, S), views[5].view(P, 4), views[6].view(P, 3)
+        tau = flat[o:o + 6]
+        K = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
+        g_dx, g_ds, g_dr = K(dx), K(ds), K(dr)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep)
+        out = _RawGrads()
+        out.xyz, out.log_scales, out.raw_rotations, out.logit_opacity = g_xyz.data_ptr(), g_ls.data_ptr(), g_rot.data_ptr(), g_logit.data_ptr()
+        out.features_dc, out.features_rest = g_fdc.data_ptr(), (g_frest.data_ptr() if M > 1 else None)
+        out.dx, out.ds, out.dr = (g_dx.data_ptr() if g_dx is not None else None, g_ds.data_ptr() if g_ds is not None else None,
+                                  g_dr.data_ptr() if g_dr is not None else None)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward_raw(
+                P, int(rs.sh_degree), M, int(ctx.num_rendered), _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
+                _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.projmatrix_raw, "projmatrix_raw", keep),
+                _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
+                geom.data_ptr(), binning.data_ptr(), imgbuf.data_ptr(), _f32(g_color, "dL_dcolor", keep), _f32(g_depth, "dL_ddepth", keep),
+                g_m2d.data_ptr(), C.byref(out), tau.data_ptr(), int(bool(rs.debug)), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_backward_raw")
+        g_rho = _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None
+        g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
+        # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
+        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None)
+
+
+def rasterize_gaussians_raw(raster_settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest=None,
+                            dyn_slot=None, dx=None, ds=None, dr=None, theta=None, rho=None):
+    """(color[3,H,W], radii[P], depth[1,H,W], opacity[1,H,W], n_touched[P]) of GaussianRasterizer.forward, from raw model parameters.
+
+    ``dyn_slot`` (int32[P], see dyn_slot_from_mask) is required with dx / ds / dr. Empty models must be handled by the caller
+    (the reference's render() returns None for them)."""
+    if xyz.shape[0] == 0:
+        raise RuntimeError("rasterize_gaussians_raw: empty model")
+    if (dx is not None or ds is not None or dr is not None) and dyn_slot is None:
+        raise RuntimeError("rasterize_gaussians_raw: dx / ds / dr need dyn_slot")
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, dyn_slot,
+                                        dx, ds, dr, theta, rho, raster_settings)

@@ -11,9 +11,20 @@ _deformation(...), _scaling, _rotation, _opacity, scaling_activation, rotation_a
 projection_matrix, camera_center, cam_rot_delta, cam_trans_delta, time.
 """
 import math
+import os
 
 import torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+try:   # the MI355X package has the fused prologue; the CPU oracle stand-in used by the tests does not
+    from diff_gaussian_rasterization import raw as _raw
+except Exception:  # pragma: no cover
+    _raw = None
+
+# render() hands the model's RAW parameters to the rasterizer when it can (diff_gaussian_rasterization/raw.py): the
+# activations, the delta scatter and their autograd replay then run inside the kernels. GSR_FUSED_PROLOGUE=0 (or setting this
+# flag to False) keeps the reference's chain of torch kernels.
+FUSED_PROLOGUE = os.environ.get("GSR_FUSED_PROLOGUE", "1") != "0"
 
 from .sh_eval import eval_sh
 
@@ -73,6 +84,34 @@ def _python_colors(pc, cam):
     return torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
 
 
+def _fused_prologue_ok(pc, pipe, mask, dynamic) -> bool:
+    """The fused route reproduces exactly the branch of render() taken with the shipped configs: SH colours and covariance
+    from scale/rotation in the rasterizer (pipe.convert_SHs_python = compute_cov3D_python = False, base_config.yaml), no
+    boolean mask, no 4DGaussians deformation network, and a GaussianModel whose activations are the reference's
+    (scene/gaussian_model.py:60-68: exp, sigmoid, F.normalize)."""
+    if not FUSED_PROLOGUE or _raw is None or mask is not None or dynamic:
+        return False
+    if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
+        return False
+    try:
+        raws = (pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest)
+        acts = (pc.scaling_activation is torch.exp and pc.opacity_activation is torch.sigmoid
+                and pc.rotation_activation is torch.nn.functional.normalize)
+    except AttributeError:
+        return False
+    return acts and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in raws)
+
+
+def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr):
+    deltas = dx is not None and ds is not None and dr is not None        # the reference applies them only together (:159)
+    slot = _raw.dyn_slot_from_mask(pc.dygs) if deltas else None
+    f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
+    return _raw.rasterize_gaussians_raw(
+        _settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree), pc._xyz, screenspace_points, pc._scaling,
+        pc._rotation, pc._opacity, pc._features_dc, f_rest, slot, dx if deltas else None, ds if deltas else None,
+        dr if deltas else None, viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None,
            dynamic=False, dx=None, ds=None, dr=None, do=None, dc=None, novel=0):
     """Render the scene. Returns None for an empty model, else the dict
@@ -80,6 +119,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if pc.get_xyz.shape[0] == 0:
         return None
     screenspace_points = _screenspace_points(pc)
+    if _fused_prologue_ok(pc, pipe, mask, dynamic):
+        rendered_image, radii, depth, opacity, n_touched = _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
+                                                                         screenspace_points, dx, ds, dr)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+                "depth": depth, "opacity": opacity, "n_touched": n_touched}
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree))
 
     means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity

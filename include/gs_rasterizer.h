@@ -99,6 +99,61 @@ int gsr_backward_fused(int P, int D, int M, int R,
                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, float* dL_dtau,
                        float* dL_dtau_sum, int debug, void* stream);
 
+/* ---- fused prologue: the model's raw parameters in, their gradients out --------------------------
+ * The reference's render() turns GaussianModel parameters into rasterizer inputs with ~10 elementwise torch kernels per view
+ * (gaussian_splatting/gaussian_renderer/__init__.py:108-127,159-174; scene/gaussian_model.py:60-68,100-128) and autograd
+ * runs as many again on the way back:
+ *     means3D = _xyz + scatter(dx -> dygs);        scales = exp(_scaling) [.repeat(1,3) if isotropic] + scatter(ds -> dygs);
+ *     rotations = normalize(_rotation) + scatter(dr -> dygs);   opacities = sigmoid(_opacity);   shs = cat(_features_dc, _features_rest)
+ * gsr_forward_raw / gsr_backward_raw read the raw tensors directly and apply these maps (and their chain rules) inside the
+ * preprocess / geometry-backward kernels. Everything else is gsr_forward / gsr_backward_fused. */
+typedef struct gsr_raw_inputs {
+    const float* xyz;            /* [P,3]   GaussianModel._xyz */
+    const float* log_scales;     /* [P,scale_dim]  _scaling (log space) */
+    int scale_dim;               /* 3, or 1 for an isotropic model (gaussian_renderer/__init__.py:122-125) */
+    const float* raw_rotations;  /* [P,4]   _rotation; normalised like torch.nn.functional.normalize (eps 1e-12) */
+    const float* logit_opacity;  /* [P]     _opacity */
+    const float* features_dc;    /* [P,1,3] _features_dc */
+    const float* features_rest;  /* [P,M-1,3] _features_rest; may be NULL when M == 1 */
+    const int* dyn_slot;         /* [P] or NULL: >= 0 selects the row of dx / ds / dr added to this Gaussian (position of the
+                                    Gaussian inside pc.dygs), < 0 = static */
+    const float* dx;             /* [K,3] or NULL */
+    const float* ds;             /* [K,3] or NULL */
+    const float* dr;             /* [K,4] or NULL */
+} gsr_raw_inputs;
+
+typedef struct gsr_raw_grads {   /* all fully written; dx / ds / dr may be NULL (required when the corresponding input was given
+                                    and its gradient is wanted) */
+    float* xyz;                  /* [P,3] */
+    float* log_scales;           /* [P,scale_dim] */
+    float* raw_rotations;        /* [P,4] */
+    float* logit_opacity;        /* [P] */
+    float* features_dc;          /* [P,1,3] */
+    float* features_rest;        /* [P,M-1,3] (NULL allowed when M == 1) */
+    float* dx; float* ds; float* dr;   /* [K,3], [K,3], [K,4]: rows of slots that no Gaussian refers to are left untouched */
+} gsr_raw_grads;
+
+/* gsr_forward with the inputs described by `in` (no colors_precomp / cov3D_precomp / prefiltered in this variant). */
+int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_user,
+                    gsr_alloc_fn binning_alloc, void* binning_user,
+                    gsr_alloc_fn image_alloc, void* image_user,
+                    int P, int D, int M, const float* background, int width, int height,
+                    const gsr_raw_inputs* in, float scale_modifier,
+                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                    float* out_color, float* out_depth, float* out_opacity, int* radii, int* n_touched,
+                    int debug, void* stream);
+
+/* Backward of gsr_forward_raw: dL_dmean2D[P,3] as in gsr_backward, the parameter gradients of `out`, dL_dtau_sum[6] (may be NULL). */
+int gsr_backward_raw(int P, int D, int M, int R,
+                     const float* background, int width, int height,
+                     const gsr_raw_inputs* in, float scale_modifier,
+                     const float* viewmatrix, const float* projmatrix, const float* projmatrix_raw, const float* campos,
+                     float tan_fovx, float tan_fovy, const int* radii,
+                     char* geom_buffer, char* binning_buffer, char* image_buffer,
+                     const float* dL_dpix, const float* dL_dpix_depth,
+                     float* dL_dmean2D, const gsr_raw_grads* out, float* dL_dtau_sum,
+                     int debug, void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-22 / rasterizer_impl.cu:54-66,141-153): present[i] = (z_view > 0.2). */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      unsigned char* present, void* stream);

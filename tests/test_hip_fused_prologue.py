@@ -1,0 +1,94 @@
+"""SURVEY.md 8f rank 1 -- the fused prologue: render() over a reference-shaped GaussianModel (raw parameters + activations) must
+give the same image and the same parameter / delta / pose / screen-space gradients whether the activations, the delta scatter
+and their chain rules run as torch kernels (the reference's way) or inside the HIP kernels (gsr_forward_raw / gsr_backward_raw)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import make_camera, make_gaussians, make_cotangents, rel_l1
+
+pytestmark = pytest.mark.gpu
+
+
+class _GaussianModel:
+    """The attribute surface of scene/gaussian_model.py that render() touches (raw leaves + activations, :60-68,100-128)."""
+
+    def __init__(self, g, isotropic, dyn_frac, seed):
+        dev = "cuda"
+        L = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=True)
+        rng = np.random.default_rng(seed)
+        P = g["means3D"].shape[0]
+        self._xyz = L(g["means3D"])
+        sc = np.log(g["scales"])
+        self._scaling = L(sc[:, :1] if isotropic else sc)
+        self._rotation = L(g["rotations"] * rng.uniform(0.5, 2.0, size=(P, 1)))          # not unit length: normalize matters
+        op = np.clip(g["opacities"].reshape(P, 1), 1e-4, 1 - 1e-4)
+        self._opacity = L(np.log(op / (1 - op)))
+        self._features_dc = L(g["shs"][:, :1])
+        self._features_rest = L(g["shs"][:, 1:])
+        self.active_sh_degree = g.get("sh_degree", 0)
+        self.max_sh_degree = 3
+        self.dygs = torch.tensor(rng.uniform(size=P) < dyn_frac, device=dev)
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s.scaling_activation(s._scaling))
+    get_rotation = property(lambda s: s.rotation_activation(s._rotation))
+    get_opacity = property(lambda s: s.opacity_activation(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+    leaves = property(lambda s: dict(xyz=s._xyz, scaling=s._scaling, rotation=s._rotation, opacity=s._opacity,
+                                     f_dc=s._features_dc, f_rest=s._features_rest))
+
+
+def _camera(cam):
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+    return types.SimpleNamespace(
+        FoVx=2 * np.arctan(cam.tanfovx), FoVy=2 * np.arctan(cam.tanfovy), image_height=cam.H, image_width=cam.W,
+        world_view_transform=T(cam.viewmatrix), full_proj_transform=T(cam.projmatrix), projection_matrix=T(cam.projmatrix_raw),
+        camera_center=T(cam.campos), cam_rot_delta=T(np.zeros(3), True), cam_trans_delta=T(np.zeros(3), True), time=0.0)
+
+
+@pytest.mark.parametrize("isotropic,deg,with_deltas", [(False, 0, False), (False, 2, True), (True, 1, True), (False, 3, False)])
+def test_fused_prologue_matches_the_torch_prologue(isotropic, deg, with_deltas):
+    import gaussian_renderer as gr
+
+    cam = make_camera(200, 152)
+    g = make_gaussians(4000, cam, seed=31, sh_degree=deg)
+    gc, gd = make_cotangents(cam, seed=32)
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([0.1, 0.3, 0.5], device="cuda")
+    results = {}
+    for fused in (False, True):
+        m = _GaussianModel(g, isotropic, 0.3, seed=33)
+        view = _camera(cam)
+        K = int(m.dygs.sum())
+        rng = np.random.default_rng(34)
+        deltas = {}
+        if with_deltas:
+            deltas = {k: torch.tensor(rng.normal(scale=s, size=(K, n)).astype(np.float32), device="cuda", requires_grad=True)
+                      for k, n, s in (("dx", 3, 0.02), ("ds", 3, 0.001), ("dr", 4, 0.05))}
+        gr.FUSED_PROLOGUE = fused
+        try:
+            assert gr._fused_prologue_ok(m, pipe, None, False) == fused
+            res = gr.render(view, m, pipe, bg, **deltas)
+        finally:
+            gr.FUSED_PROLOGUE = True
+        loss = (res["render"] * torch.tensor(gc, device="cuda")).sum() + (res["depth"] * torch.tensor(gd, device="cuda")).sum()
+        loss.backward()
+        grads = {k: v.grad for k, v in m.leaves.items()}
+        grads.update({k: v.grad for k, v in deltas.items()})
+        grads.update(theta=view.cam_rot_delta.grad, rho=view.cam_trans_delta.grad, viewspace=res["viewspace_points"].grad)
+        results[fused] = (res, grads)
+    (r0, g0), (r1, g1) = results[False], results[True]
+    for k in ("render", "depth", "opacity"):
+        assert rel_l1(r1[k].detach().cpu().numpy(), r0[k].detach().cpu().numpy()) < 1e-5, k
+    assert torch.equal(r1["radii"], r0["radii"]) and (r1["n_touched"] != r0["n_touched"]).sum() <= 2
+    for k in g0:
+        if g0[k] is None or g0[k].numel() == 0:
+            assert g1[k] is None or g1[k].numel() == 0 or float(g1[k].abs().sum()) == 0.0, k
+            continue
+        assert g1[k] is not None and g1[k].shape == g0[k].shape, k
+        assert rel_l1(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-4, (k, rel_l1(g1[k].cpu().numpy(), g0[k].cpu().numpy()))
