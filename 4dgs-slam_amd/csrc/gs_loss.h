@@ -1,0 +1,88 @@
+// gs_loss.h -- fused photometric + depth L1 loss of the SLAM mapping / tracking steps:
+//   L = alpha * mean_{3,H,W}( w_rgb * |exp(a) * I + b - I_gt| ) + (1 - alpha) * mean_{H,W}( w_d * |D - D_gt| )
+// which is what utils/slam_utils.py:252-364 (get_loss_mapping*) evaluates with ~20 elementwise / reduction torch kernels per
+// view plus their autograd replay: every pixel mask there (rgb boundary threshold, valid depth, motion masks, the x2 weighting
+// of dynamic regions) is a constant of the keyframe and folds into the two weight images w_rgb, w_d in {0, 1, 2}.
+// One pass computes the loss, one pass (in backward, scaled by the upstream gradient read from device memory) writes
+// dL/dI, dL/dD -- exactly the cotangents the rasterizer's backward consumes -- and the exposure gradients.
+// Sums are two-level with a fixed order (per-block partials, then one block), so the value is reproducible.
+#pragma once
+#include "gs_device.h"
+
+namespace gsr {
+
+constexpr int LOSS_BLOCKS = 256, LOSS_THREADS = 256;
+
+struct LossArgs {
+    int N;                                   // pixels
+    const float* image; const float* depth;  // rendered [3,N], [N]
+    const float* gt_image; const float* gt_depth;
+    const float* w_rgb; const float* w_depth;   // [N] each or nullptr (= 1)
+    const float* exposure_a; const float* exposure_b;   // device scalars or nullptr (a = 0, b = 0)
+    float c_rgb, c_depth;                    // alpha / (3N), (1 - alpha) / N
+};
+
+__device__ __forceinline__ float block_sum_fixed(float v, float* s_tmp /*[LOSS_THREADS / 64]*/)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < LOSS_THREADS / 64; w++) t += s_tmp[w];
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // d|v|/dv as torch defines it
+
+__global__ void __launch_bounds__(LOSS_THREADS) l1_loss_fwd_kernel(LossArgs a, float* __restrict__ partials)
+{
+    __shared__ float s_tmp[LOSS_THREADS / 64];
+    const float ea = a.exposure_a ? expf(a.exposure_a[0]) : 1.f, eb = a.exposure_b ? a.exposure_b[0] : 0.f;
+    float acc = 0.f;
+    for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
+        const float wr = a.w_rgb ? a.w_rgb[p] : 1.f, wd = a.w_depth ? a.w_depth[p] : 1.f;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) s += fabsf(ea * a.image[(size_t)c * a.N + p] + eb - a.gt_image[(size_t)c * a.N + p]);
+        acc += a.c_rgb * wr * s + a.c_depth * wd * fabsf(a.depth[p] - a.gt_depth[p]);
+    }
+    const float t = block_sum_fixed(acc, s_tmp);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// out[k] = sum over blocks of partials[b * stride + k], k < stride, fixed order
+__global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restrict__ partials, int stride, float* __restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= stride) return;
+    float t = 0.f;
+    for (int b = 0; b < LOSS_BLOCKS; b++) t += partials[b * stride + k];
+    out[k] = t;
+}
+
+__global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, const float* __restrict__ upstream, float* __restrict__ dL_dimage,
+                                                                   float* __restrict__ dL_ddepth, float* __restrict__ partials /*[blocks][2]*/)
+{
+    __shared__ float s_tmp[LOSS_THREADS / 64];
+    const float g = upstream ? upstream[0] : 1.f;
+    const float ea = a.exposure_a ? expf(a.exposure_a[0]) : 1.f, eb = a.exposure_b ? a.exposure_b[0] : 0.f;
+    float da = 0.f, db = 0.f;
+    for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
+        const float wr = (a.w_rgb ? a.w_rgb[p] : 1.f) * a.c_rgb * g, wd = (a.w_depth ? a.w_depth[p] : 1.f) * a.c_depth * g;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float I = a.image[(size_t)c * a.N + p];
+            const float s = wr * sgn(ea * I + eb - a.gt_image[(size_t)c * a.N + p]);   // dL / d(exp(a) I + b)
+            dL_dimage[(size_t)c * a.N + p] = s * ea;
+            da += s * ea * I;
+            db += s;
+        }
+        dL_ddepth[p] = wd * sgn(a.depth[p] - a.gt_depth[p]);
+    }
+    const float ta = block_sum_fixed(da, s_tmp), tb = block_sum_fixed(db, s_tmp);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ta; partials[2 * blockIdx.x + 1] = tb; }
+}
+
+}  // namespace gsr

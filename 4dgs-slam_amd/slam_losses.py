@@ -1,0 +1,153 @@
+"""Fused mapping loss: the counterpart of ``utils/slam_utils.py:252-364`` (get_loss_mapping,
+get_loss_mapping_rgbd) with the same signature. Every pixel mask of the reference is a constant of the keyframe and folds into
+two weight images; the weighted L1 itself -- value, the cotangents dL/dI and dL/dD that feed the rasterizer's backward, and
+the exposure gradients -- is two HIP kernels (include/slam_losses.h) instead of ~20 torch kernels plus their autograd replay.
+
+There is no CPU implementation here: CPU tensors raise, as everywhere in the product path."""
+import ctypes as C
+
+import torch
+
+from diff_gaussian_rasterization import _C
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = _C.load_library()
+    if not _declared:
+        vp, f, i = C.c_void_p, C.c_float, C.c_int
+        lib.gsr_l1_loss_workspace_size.restype = C.c_size_t
+        lib.gsr_l1_loss_forward.restype = i
+        lib.gsr_l1_loss_forward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, vp, vp]
+        lib.gsr_l1_loss_backward.restype = i
+        lib.gsr_l1_loss_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
+        _declared = True
+    return lib
+
+
+def _p(t, keep):
+    if t is None:
+        return None
+    _C._require_device(t, "loss operand")
+    tc = t.detach()
+    tc = tc if tc.dtype == torch.float32 else tc.to(torch.float32)
+    tc = tc.contiguous()
+    keep.append(tc)
+    return tc.data_ptr()
+
+
+class _WeightedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha):
+        lib = _lib()
+        _C._require_device(image, "image")
+        H, W = int(image.shape[-2]), int(image.shape[-1])
+        dev = image.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty((int(lib.gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=dev)
+        keep = []
+        with torch.cuda.device(dev):
+            rc = lib.gsr_l1_loss_forward(W, H, _p(image, keep), _p(depth, keep), _p(gt_image, keep), _p(gt_depth, keep), _p(w_rgb, keep),
+                                         _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), float(alpha), loss.data_ptr(),
+                                         ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_l1_loss_forward")
+        ctx.alpha = float(alpha)
+        ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws = ctx.saved_tensors
+        H, W = int(image.shape[-2]), int(image.shape[-1])
+        dev = image.device
+        g_image, g_depth = torch.empty_like(image, dtype=torch.float32), torch.empty_like(depth, dtype=torch.float32)
+        g_exp = torch.empty((2,), dtype=torch.float32, device=dev) if exposure_a is not None else None
+        keep = []
+        with torch.cuda.device(dev):
+            rc = lib.gsr_l1_loss_backward(W, H, _p(image, keep), _p(depth, keep), _p(gt_image, keep), _p(gt_depth, keep), _p(w_rgb, keep),
+                                          _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), ctx.alpha, _p(g, keep),
+                                          g_image.data_ptr(), g_depth.data_ptr(), g_exp.data_ptr() if g_exp is not None else None,
+                                          ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_l1_loss_backward")
+        ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
+        gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
+        return g_image, g_depth, None, None, None, None, ga, gb, None
+
+
+def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None, exposure_a=None, exposure_b=None, alpha=0.95):
+    """alpha * mean(w_rgb |exp(a) image + b - gt_image|) + (1 - alpha) * mean(w_depth |depth - gt_depth|), differentiable in
+    image, depth, exposure_a, exposure_b. image [3,H,W], depth [1,H,W] (or [H,W]), weights [H,W] / [1,H,W] or None."""
+    if (exposure_a is None) != (exposure_b is None):
+        raise RuntimeError("weighted_l1_loss: give both exposure parameters or neither")
+    return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha)
+
+
+def _keyframe_constants(config, viewpoint, device):
+    """Ground-truth depth on the device and the two ground-truth-only masks (slam_utils.py:276-284), cached on the viewpoint:
+    the reference re-uploads the depth map from host memory and rebuilds the masks on every call of every iteration."""
+    key = (id(viewpoint.depth), id(viewpoint.original_image), str(device), float(config["Training"]["rgb_boundary_threshold"]))
+    cache = getattr(viewpoint, "_gsr_loss_cache", None)
+    if cache is None or cache[0] != key:
+        gt_image = viewpoint.original_image.to(device)
+        gt_depth = torch.as_tensor(viewpoint.depth, dtype=torch.float32, device=device)[None]
+        rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*gt_depth.shape).to(torch.float32)
+        dep = ((gt_depth > 0.01) & (gt_depth < 10000.0)).to(torch.float32)
+        cache = (key, gt_image, gt_depth, rgb, dep)
+        try:
+            viewpoint._gsr_loss_cache = cache
+        except Exception:  # pragma: no cover  (immutable stand-in)
+            pass
+    return cache[1:]
+
+
+def mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, dynamic=False, base=None):
+    """(w_rgb, w_depth) float32 [1,H,W]: the masks and region weights of get_loss_mapping_rgbd (slam_utils.py:276-290,350-360).
+    They depend on the keyframe only (ground truth, motion mask, the caller's mask), never on the rendering.
+    `base` = precomputed ground-truth-only masks (rgb, depth) as float tensors."""
+    shape = gt_depth.shape
+    if base is None:
+        rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*shape)
+        dep = (gt_depth > 0.01).view(*shape) & (gt_depth < 10000.0).view(*shape)
+        w_rgb, w_dep = rgb.to(torch.float32), dep.to(torch.float32)
+    else:
+        w_rgb, w_dep = base
+    motion = getattr(viewpoint, "motion_mask", None)
+    if motion is not None and rm_dynamic:
+        w_rgb, w_dep = motion.view(*shape) * w_rgb, motion.view(*shape) * w_dep
+    if mask is not None and rm_dynamic:
+        w_rgb, w_dep = mask.view(*shape) * w_rgb, mask.view(*shape) * w_dep
+    if dynamic:
+        boost = (mask.view(*shape).bool() | ~motion.view(*shape)) if mask is not None else ~motion.view(*shape)
+        scale = torch.where(boost, 2.0, 1.0)
+        w_rgb, w_dep = w_rgb * scale, w_dep * scale
+    return w_rgb.to(torch.float32), w_dep.to(torch.float32)
+
+
+def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=False, alpha=None, rm_dynamic=False, mask=None,
+                     dynamic=False, split=False):
+    """utils/slam_utils.py:252-259, same arguments and value. RGB-D, non-split calls (every call of utils/slam_backend.py with
+    the shipped configs) run fused; `monocular` and `split=True` are evaluated with the reference's tensor expression."""
+    _C._require_device(image, "image")
+    gt_image, gt_depth, base_rgb, base_dep = _keyframe_constants(config, viewpoint, image.device)
+    exposure = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
+    if config["Training"]["monocular"]:
+        image_ab = image if initialization else torch.exp(exposure[0]) * image + exposure[1]
+        m = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(1, *gt_image.shape[1:])
+        return torch.abs(image_ab * m - gt_image * m).mean()                     # get_loss_mapping_rgb, :262-272
+    if alpha is None:
+        alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
+    if split:                                                                     # :292-303
+        image_ab = image if initialization else torch.exp(exposure[0]) * image + exposure[1]
+        w_rgb, w_dep = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, False)
+        mm = viewpoint.motion_mask.view(*depth.shape)
+        part = lambda sel: (alpha * torch.abs(sel * w_rgb * image_ab - sel * w_rgb * gt_image).mean()
+                            + (1 - alpha) * torch.abs(sel * w_dep * depth - sel * w_dep * gt_depth).mean())
+        l_static, l_dynamic = part(mm), part(~mm)
+        return (l_static, 2 * l_dynamic) if dynamic else (l_static, l_dynamic)
+    w_rgb, w_dep = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep))
+    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha)

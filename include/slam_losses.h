@@ -1,0 +1,38 @@
+/*
+ * slam_losses.h -- C ABI of the fused photometric + depth L1 loss (libgs_rasterizer_hip.so), SURVEY.md 8(f) rank 2.
+ *
+ * Replaces the tensor expression of the reference's mapping / tracking losses
+ *   utils/slam_utils.py:252-364 (get_loss_mapping, get_loss_mapping_rgbd) and the same structure at :57-173, 200-250:
+ *     L = alpha * mean_{3,H,W}( w_rgb * |exp(a) * I + b - I_gt| ) + (1 - alpha) * mean_{H,W}( w_d * |D - D_gt| )
+ * where every mask of the reference (rgb boundary threshold, valid-depth range, motion masks, the x2 / x3 weighting of
+ * dynamic regions) is folded by the caller into the per-pixel weights w_rgb, w_d (constants of the keyframe).
+ * The backward call writes dL/dI [3,H,W] and dL/dD [1,H,W] -- the cotangents gsr_backward consumes -- already multiplied
+ * by the upstream gradient, plus dL/d(a, b). All pointers are DEVICE pointers, fp32, contiguous.
+ */
+#ifndef SLAM_LOSSES_H_INCLUDED
+#define SLAM_LOSSES_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bytes of scratch both calls need (per-block partial sums) */
+size_t gsr_l1_loss_workspace_size(void);
+
+/* loss[0] = L. w_rgb / w_depth [H*W] may be NULL (= 1); exposure_a / exposure_b (1 float each) may be NULL (a = b = 0,
+ * the `initialization` branch, slam_utils.py:253-254). Returns 0 or a negative GSR_ERR_* code (gs_rasterizer.h). */
+int gsr_l1_loss_forward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
+                        const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
+                        float* loss, char* workspace, void* stream);
+
+/* upstream: device pointer to dLoss_total/dL (NULL = 1). dL_dexposure[2] = (dL/da, dL/db), may be NULL. */
+int gsr_l1_loss_backward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
+                         const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
+                         const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,93 @@
+"""SURVEY.md 8f rank 2 -- fused mapping loss. Golden vectors come from the reference's own utils/slam_utils.py:get_loss_mapping
+(tests/golden/make_golden_loss.py). CPU: this repo's mask/weight logic + the plain-torch loss expression (oracle/loss_oracle.py)
+reproduce them. GPU: slam_losses.get_loss_mapping (two HIP kernels through the C ABI) reproduces value and gradients."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import util  # noqa: F401  (puts the repo and the package on sys.path)
+
+FX = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_loss.npz"), allow_pickle=False)
+CASES = [str(c) for c in FX["cases"]]
+CONFIG = {"Training": {"monocular": False, "rgb_boundary_threshold": float(FX["cfg_thr"]), "alpha": float(FX["cfg_alpha"])}}
+
+
+def _viewpoint(dev):
+    return types.SimpleNamespace(
+        original_image=torch.tensor(FX["gt_image"], device=dev), depth=FX["gt_depth"],
+        exposure_a=torch.nn.Parameter(torch.tensor([0.07], device=dev)), exposure_b=torch.nn.Parameter(torch.tensor([-0.03], device=dev)),
+        motion_mask=torch.tensor(FX["motion_mask"], device=dev), uid=3)
+
+
+def _kwargs(name, dev):
+    init, rm_dyn, dyn, use_mask, has_alpha = [bool(v) for v in FX[f"{name}/flags"]]
+    kw = dict(initialization=init, rm_dynamic=rm_dyn, dynamic=dyn, mask=torch.tensor(FX["mask"], device=dev) if use_mask else None)
+    if has_alpha:
+        kw["alpha"] = float(FX[f"{name}/alpha"])
+    return kw
+
+
+def _check(name, loss, image, depth, vp, tol):
+    loss.backward()
+    assert abs(float(loss) - float(FX[f"{name}/loss"])) < tol * max(1.0, abs(float(FX[f"{name}/loss"])))
+    assert util.rel_l1(image.grad.cpu().numpy(), FX[f"{name}/g_image"]) < tol
+    assert util.rel_l1(depth.grad.cpu().numpy(), FX[f"{name}/g_depth"]) < tol
+    if FX[f"{name}/g_a"].size:
+        assert abs(float(vp.exposure_a.grad) - float(FX[f"{name}/g_a"][0])) < 10 * tol * max(1e-3, abs(float(FX[f"{name}/g_a"][0])))
+        assert abs(float(vp.exposure_b.grad) - float(FX[f"{name}/g_b"][0])) < 10 * tol * max(1e-3, abs(float(FX[f"{name}/g_b"][0])))
+    else:
+        assert vp.exposure_a.grad is None and vp.exposure_b.grad is None
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_weight_logic_and_loss_expression_reproduce_the_reference_on_cpu(name):
+    from slam_losses import mapping_loss_weights
+    from oracle.loss_oracle import weighted_l1_loss_reference
+
+    vp = _viewpoint("cpu")
+    kw = _kwargs(name, "cpu")
+    image = torch.tensor(FX[f"{name}/image"], requires_grad=True)
+    depth = torch.tensor(FX[f"{name}/depth"], requires_grad=True)
+    gt_depth = torch.tensor(FX["gt_depth"])[None]
+    w_rgb, w_dep = mapping_loss_weights(CONFIG, vp, vp.original_image, gt_depth, kw["rm_dynamic"], kw["mask"], kw["dynamic"])
+    a, b = (None, None) if kw["initialization"] else (vp.exposure_a, vp.exposure_b)
+    loss = weighted_l1_loss_reference(image, depth, vp.original_image, gt_depth, w_rgb, w_dep, a, b, kw.get("alpha", CONFIG["Training"]["alpha"]))
+    _check(name, loss, image, depth, vp, 1e-5)
+
+
+def test_product_loss_refuses_cpu_tensors():
+    from slam_losses import get_loss_mapping
+
+    vp = _viewpoint("cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        get_loss_mapping(CONFIG, torch.tensor(FX["plain/image"]), torch.tensor(FX["plain/depth"]), vp, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_fused_mapping_loss_matches_the_reference(name):
+    from slam_losses import get_loss_mapping
+
+    vp = _viewpoint("cuda")
+    image = torch.tensor(FX[f"{name}/image"], device="cuda", requires_grad=True)
+    depth = torch.tensor(FX[f"{name}/depth"], device="cuda", requires_grad=True)
+    loss = get_loss_mapping(CONFIG, image, depth, vp, None, **_kwargs(name, "cuda"))
+    _check(name, loss, image, depth, vp, 2e-5)
+
+
+@pytest.mark.gpu
+def test_fused_loss_scales_with_the_upstream_gradient_and_is_reproducible():
+    from slam_losses import get_loss_mapping
+
+    grads = []
+    for scale in (1.0, 1.0, 3.0):
+        vp = _viewpoint("cuda")
+        image = torch.tensor(FX["plain/image"], device="cuda", requires_grad=True)
+        depth = torch.tensor(FX["plain/depth"], device="cuda", requires_grad=True)
+        (get_loss_mapping(CONFIG, image, depth, vp, None) * scale).backward()
+        grads.append((image.grad.clone(), depth.grad.clone(), vp.exposure_a.grad.clone()))
+    assert all(torch.equal(x, y) for x, y in zip(grads[0], grads[1]))                 # bit-reproducible
+    assert all(torch.allclose(3.0 * x, y, rtol=1e-6, atol=0) for x, y in zip(grads[0], grads[2]))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""render()-level timing of the fused prologue: gaussian_renderer.render + backward on a reference-shaped
-GaussianModel (200k Gaussians, 640x480, 25 % dynamic with control-node deltas), prologue as torch kernels vs inside the HIP
-kernels. Prints one JSON line; `python tools/bench_render_wrapper.py > profiles/r01_render_wrapper.json` on the GPU box."""
+"""Mapping-iteration-level timing of the two widenings of SURVEY.md 8f: gaussian_renderer.render + mapping loss + backward on a
+reference-shaped GaussianModel (200k Gaussians, 640x480, 25 % dynamic with control-node deltas),
+  "torch_*": prologue and loss as chains of torch kernels (what the reference does, restated), vs
+  "fused_*": prologue inside the rasterizer kernels (rank 1) and the loss as two HIP kernels (rank 2).
+Prints one JSON line; `python tools/bench_render_wrapper.py > profiles/r01_render_wrapper.json` on the GPU box."""
 import json
 import os
 import sys
@@ -17,6 +19,8 @@ for p in (REPO, os.path.join(REPO, "4dgs-slam_amd"), os.path.join(REPO, "tests")
 import gaussian_renderer as gr                                   # noqa: E402
 from synthetic_scene import make_camera, make_gaussians, make_cotangents   # noqa: E402
 from test_hip_fused_prologue import _GaussianModel, _camera      # noqa: E402  (the reference-shaped model stand-in)
+from slam_losses import get_loss_mapping, mapping_loss_weights   # noqa: E402
+from oracle.loss_oracle import weighted_l1_loss_reference       # noqa: E402  (timing comparison only)
 
 P, W, H = 200_000, 640, 480
 cam = make_camera(W, H)
@@ -26,21 +30,41 @@ gc, gd = torch.tensor(gc, device="cuda"), torch.tensor(gd, device="cuda")
 pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
 bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
 out = {"workload": f"render() fwd+bwd, {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr, SH degree 0"}
-for fused in (False, True):
+config = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.9}}
+rng0 = np.random.default_rng(9)
+gt_image = torch.tensor(rng0.uniform(0, 1, size=(3, H, W)).astype(np.float32), device="cuda")
+gt_depth_np = rng0.uniform(0.3, 5.0, size=(H, W)).astype(np.float32)
+
+
+def torch_mapping_loss(image, depth, vp):       # the reference's tensor expression (utils/slam_utils.py:252-364), masks recomputed per call
+    gt_depth = torch.from_numpy(vp.depth).to(dtype=torch.float32, device=image.device)[None]
+    w_rgb, w_dep = mapping_loss_weights(config, vp, vp.original_image, gt_depth)
+    return weighted_l1_loss_reference(image, depth, vp.original_image, gt_depth, w_rgb, w_dep, vp.exposure_a, vp.exposure_b, 0.9)
+
+
+for fused, with_loss in ((False, False), (True, False), (False, True), (True, True)):
     m = _GaussianModel(g, False, 0.25, seed=2)
     view = _camera(cam)
+    view.original_image, view.depth, view.motion_mask = gt_image, gt_depth_np, None
+    view.exposure_a = torch.nn.Parameter(torch.tensor([0.01], device="cuda"))
+    view.exposure_b = torch.nn.Parameter(torch.tensor([0.0], device="cuda"))
     K = int(m.dygs.sum())
     rng = np.random.default_rng(3)
     deltas = {k: torch.tensor(rng.normal(scale=s, size=(K, n)).astype(np.float32), device="cuda", requires_grad=True)
               for k, n, s in (("dx", 3, 0.002), ("ds", 3, 0.0001), ("dr", 4, 0.01))}
-    leaves = list(m.leaves.values()) + list(deltas.values()) + [view.cam_rot_delta, view.cam_trans_delta]
+    leaves = list(m.leaves.values()) + list(deltas.values()) + [view.cam_rot_delta, view.cam_trans_delta, view.exposure_a, view.exposure_b]
     gr.FUSED_PROLOGUE = fused
 
     def step():
         for t in leaves:
             t.grad = None
         res = gr.render(view, m, pipe, bg, **deltas)
-        torch.autograd.backward([res["render"], res["depth"]], [gc, gd])
+        if not with_loss:
+            torch.autograd.backward([res["render"], res["depth"]], [gc, gd])
+        elif fused:
+            get_loss_mapping(config, res["render"], res["depth"], view, res["opacity"]).backward()
+        else:
+            torch_mapping_loss(res["render"], res["depth"], view).backward()
 
     for _ in range(10):
         step()
@@ -51,7 +75,9 @@ for fused in (False, True):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    out["fused_prologue" if fused else "torch_prologue"] = {"ms_per_render_fwd_bwd": dt * 1e3, "gaussians_per_s": P / dt}
+    key = ("fused" if fused else "torch") + ("_prologue_and_loss" if with_loss else "_prologue")
+    out[key] = {"ms_per_iteration": dt * 1e3, "gaussians_per_s": P / dt}
 gr.FUSED_PROLOGUE = True
-out["speedup"] = out["torch_prologue"]["ms_per_render_fwd_bwd"] / out["fused_prologue"]["ms_per_render_fwd_bwd"]
+out["speedup_render"] = out["torch_prologue"]["ms_per_iteration"] / out["fused_prologue"]["ms_per_iteration"]
+out["speedup_render_and_loss"] = out["torch_prologue_and_loss"]["ms_per_iteration"] / out["fused_prologue_and_loss"]["ms_per_iteration"]
 print(json.dumps(out))
