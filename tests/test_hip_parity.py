@@ -287,3 +287,58 @@ def test_pose_gradient_shapes_follow_the_inputs():
         got.append((theta.grad.reshape(-1).cpu().numpy(), rho.grad.reshape(-1).cpu().numpy()))
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     assert np.abs(got[0][0]).sum() > 0
+
+
+ADVERSARIAL = ["needles", "giants", "opaque_wall", "tiny_image", "big_modifier", "far_needles"]
+
+
+@pytest.mark.parametrize("kind", ADVERSARIAL)
+def test_adversarial_scenes_for_the_quadrant_cull_and_the_chunked_backward(kind):
+    """Shapes that stress what is NOT in the reference: the exact ellipse-vs-quadrant cull (needles seen end-on and from far
+    away, Gaussians larger than the image), early termination + checkpoints (an opaque wall in front of everything, long
+    lists), and sizes below one tile."""
+    rng = np.random.default_rng(41)
+    W, H, P = (200, 136, 3000)
+    if kind == "tiny_image":
+        W, H, P = 17, 5, 400
+    cam = make_camera(W, H)
+    g = make_gaussians(P, cam, seed=42, sh_degree=1, scale_mean=0.01)
+    smod = 1.0
+    if kind in ("needles", "far_needles"):
+        s = g["scales"].copy()
+        s[:, 0] *= 40.0 if kind == "needles" else 400.0       # 1:40 / 1:400 anisotropy, random orientations
+        s[:, 1:] *= 0.3
+        g["scales"] = s
+        if kind == "far_needles":
+            g["opacities"] = np.clip(g["opacities"] * 0 + rng.uniform(0.5, 0.99, g["opacities"].shape), 0, 0.99).astype(np.float32)
+    elif kind == "giants":
+        g["scales"] = (g["scales"] * rng.choice([1.0, 60.0], size=(P, 1), p=[0.97, 0.03])).astype(np.float32)
+    elif kind == "opaque_wall":
+        n = P // 3                                              # a dense, nearly opaque layer at the front
+        g["means3D"][:n, 2] = 0.6
+        g["means3D"][:n, 0] = rng.uniform(-1, 1, n) * 0.6 * cam.tanfovx
+        g["means3D"][:n, 1] = rng.uniform(-1, 1, n) * 0.6 * cam.tanfovy
+        g["opacities"][:n] = 0.99
+        g["scales"][:n] = 0.03
+    elif kind == "big_modifier":
+        smod = 3.0
+    gc, gd = make_cotangents(cam, seed=43)
+    bg = np.array([0.3, 0.6, 0.9], np.float32)
+    oo, st, go = oracle_run(g, cam, bg, gc, gd, scale_modifier=smod)
+    oh, gh = hip_run(g, cam, bg, gc, gd, scale_modifier=smod)
+    m = compare(oh, gh, oo, go)
+    m["P"] = P
+    if kind not in ("needles", "far_needles"):
+        _check(m, nt_tol=6)
+        return
+    # Needles are ill-conditioned in fp32 (the reference's own arithmetic): the fp32 oracle itself is up to 1e-2 .. 1e-1 away
+    # from the fp64 oracle on these scenes. The bar here: the HIP path is no further from the fp64 result than the fp32
+    # restatement of the reference is (x1.5), and the discrete outputs agree.
+    o64, _, g64 = oracle_run(g, cam, bg, gc, gd, scale_modifier=smod, dtype=np.float64)
+    m_h64, m_o64 = compare(oh, gh, o64, g64), compare(oo, {k: go[ko] for k, ko in
+                                                           (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmeans2D"), ("opacities", "dL_dopacity"),
+                                                            ("shs", "dL_dsh"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"))}, o64, g64)
+    assert m["radii_mismatch"] == 0 and m["visible_mismatch"] == 0, m
+    for k, v in m_h64.items():
+        if isinstance(v, float) and k in m_o64:
+            assert v <= max(1.5 * m_o64[k], IMG_TOL if not k.startswith("g_") else GRAD_TOL), (k, v, m_o64[k])
