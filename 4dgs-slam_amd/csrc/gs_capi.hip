@@ -276,9 +276,13 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     const size_t hist_lds_bytes = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
-    // One memset per forward pass: per-tile counters + the flag word + the work counters (ImageState::from keeps them adjacent).
+    // One memset per forward pass: the flag word + the work counters, and the per-tile counters when they are accumulated with
+    // atomics (the fallback for frames with more tiles than the LDS histogram holds; otherwise tile_offsets_kernel writes them).
     uint32_t* const flags = img.tile_count + (size_t)T * CTR_STRIDE;
-    GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)((char*)(img.work_counters + 64) - (char*)img.tile_count), stream));
+    {
+        uint32_t* const from = lds_hist ? flags : img.tile_count;
+        GSR_HIP_CHECK(hipMemsetAsync(from, 0, (size_t)((char*)(img.work_counters + 64) - (char*)from), stream));
+    }
 
     const int nblocks = (P + GB - 1) / GB;
     if (P > 0) {
@@ -299,6 +303,14 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
+        if (lds_hist) {
+            ScopedKernelTimer tm(K_SCAN, stream);
+            hipLaunchKernelGGL(tile_offsets_kernel, dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS), 0, stream, nblocks, T,
+                               img.block_tile_base, img.tile_count);
+        }
+        GSR_STAGE("tile_offsets");
+    } else if (lds_hist) {
+        GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * CTR_STRIDE * sizeof(uint32_t), stream));   // no Gaussians: no columns to scan
     }
 
     // Speculation: a SLAM loop renders nearly the same scene again and again, so the binning buffer is allocated for what

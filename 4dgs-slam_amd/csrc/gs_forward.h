@@ -217,13 +217,42 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
         for (int w = 0; w < GB / 64; w++) tot += s_wave_sum[w];
         a.block_sums[blockIdx.x] = tot;
     }
-    // (c) reserve this block's sub-range inside every tile it touched: one returning atomic per (block, tile)
+    // (c) publish this block's histogram row; tile_offsets_kernel turns every column into an exclusive prefix over the
+    //     blocks (= the block's sub-range inside the tile's segment) and a column total. Plain coalesced stores: an earlier
+    //     version reserved the sub-ranges with one returning atomic per (block, tile), and those ~215 k agent-scope atomics
+    //     (executed at the memory side on this multi-XCD part) cost more than the rest of the kernel.
     if (lds_hist) {
         uint32_t* row = a.block_tile_base + (size_t)blockIdx.x * T;
-        for (int t = threadIdx.x; t < T; t += GB) {
-            const uint32_t h = s_hist[t];
-            if (h) row[t] = atomicAdd(&a.tile_count[(size_t)t * CTR_STRIDE], h);
+        for (int t = threadIdx.x; t < T; t += GB) row[t] = s_hist[t];
+    }
+}
+
+// F1b: column scan of the [nblocks][T] histogram: hist[b][t] <- sum_{b' < b} hist[b'][t], tile_count[t] <- column total.
+// 16 columns x 16 row segments per 256-thread block; a wave reads 4 x 64 contiguous bytes per row.
+constexpr int TO_COLS = 16, TO_SEGS = 16;
+__global__ void __launch_bounds__(TO_COLS * TO_SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
+                                                                         uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t s_seg[TO_SEGS][TO_COLS];
+    const int c = threadIdx.x & (TO_COLS - 1), seg = threadIdx.x / TO_COLS;
+    const int col = blockIdx.x * TO_COLS + c;
+    const int rows_per_seg = (nblocks + TO_SEGS - 1) / TO_SEGS;
+    const int r0 = seg * rows_per_seg, r1 = min(nblocks, r0 + rows_per_seg);
+    uint32_t sum = 0;
+    if (col < T)
+        for (int r = r0; r < r1; r++) sum += hist[(size_t)r * T + col];
+    s_seg[seg][c] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+    for (int k = 0; k < TO_SEGS; k++) { const uint32_t v = s_seg[k][c]; if (k < seg) run += v; total += v; }
+    if (col < T) {
+        for (int r = r0; r < r1; r++) {
+            uint32_t* p = &hist[(size_t)r * T + col];
+            const uint32_t v = *p;
+            *p = run;
+            run += v;
         }
+        if (seg == 0) tile_count[(size_t)col * CTR_STRIDE] = total;
     }
 }
 
@@ -242,7 +271,7 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t v)
 template <typename LOAD, typename STORE>
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, STORE store, uint32_t* s_tmp /*[17]*/)
 {
-    // sequential chunks of 1024 with a running carry; returns the grand total (valid in every thread).
+    // sequential chunks of 1024 with a running carry; returns the grand total (valid in every thread). Used by the k-NN grid.
     uint32_t carry = 0;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int base = 0; base < n; base += 1024) {
@@ -264,30 +293,67 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, 
     return carry;
 }
 
+__device__ __forceinline__ unsigned long long wave_inclusive_scan64(unsigned long long v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)v, d, 64), hi = __shfl_up((uint32_t)(v >> 32), d, 64);
+        if (lane >= d) v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// One pass over max(nblocks, ntiles) elements, 1024 at a time, carries three exclusive scans at once: the per-block instance
+// sums (32 bit) and, packed into one 64-bit value, the (padded) tile counts (low word) and the tile chunk counts (high word).
+// Three separate block scans cost 15 block barriers and three rounds of dependent loads on the critical path of every frame.
 __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
                                                     int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
                                                     const uint32_t* flags, uint32_t cap_R, uint32_t cap_tile_list,
                                                     uint32_t* chunk_base, uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
 {
-    __shared__ uint32_t s_tmp[17];
-    const uint32_t R = block_exclusive_scan_1024(
-        nblocks, [&](int i) { return block_sums[i]; }, [&](int i, uint32_t excl, uint32_t) { block_base[i] = excl; }, s_tmp);
-    const uint32_t R_alloc = block_exclusive_scan_1024(
-        ntiles,
-        [&](int i) { const uint32_t c = tile_count[(size_t)i * CTR_STRIDE]; return c > (uint32_t)SORT_LDS_CAP ? next_pow2(c) : c; },
-        [&](int i, uint32_t excl, uint32_t) {
-            ranges[i] = make_uint2(excl, excl + tile_count[(size_t)i * CTR_STRIDE]);
-            tile_cursor[(size_t)i * CTR_STRIDE] = excl;
-        },
-        s_tmp);
-    // (3) the backward pass works on CHUNK-entry pieces of the tile lists: chunk_base[t] = number of pieces in front of tile t
-    const uint32_t nchunks = block_exclusive_scan_1024(
-        ntiles, [&](int i) { return (tile_count[(size_t)i * CTR_STRIDE] + (uint32_t)CHUNK - 1) / (uint32_t)CHUNK; },
-        [&](int i, uint32_t excl, uint32_t) { chunk_base[i] = excl; }, s_tmp);
+    __shared__ uint32_t s_a[17];
+    __shared__ unsigned long long s_b[17];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t carry_a = 0, mx = 0;
+    unsigned long long carry_b = 0;
+    const int n = max(nblocks, ntiles);
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t va = i < nblocks ? block_sums[i] : 0u;
+        const uint32_t cnt = i < ntiles ? tile_count[(size_t)i * CTR_STRIDE] : 0u;
+        const uint32_t padded = cnt > (uint32_t)SORT_LDS_CAP ? next_pow2(cnt) : cnt;   // a list beyond the LDS sort gets a power-of-two segment
+        const unsigned long long vb = ((unsigned long long)((cnt + (uint32_t)CHUNK - 1) / (uint32_t)CHUNK) << 32) | padded;
+        mx = max(mx, cnt);
+        const uint32_t incl_a = wave_inclusive_scan(va);
+        const unsigned long long incl_b = wave_inclusive_scan64(vb);
+        if (lane == 63) { s_a[wave] = incl_a; s_b[wave] = incl_b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int w = 0; w < 16; w++) { const uint32_t t = s_a[w]; s_a[w] = run; run += t; }
+            s_a[16] = run;
+        } else if (threadIdx.x == 64) {
+            unsigned long long run = 0;
+            for (int w = 0; w < 16; w++) { const unsigned long long t = s_b[w]; s_b[w] = run; run += t; }
+            s_b[16] = run;
+        }
+        __syncthreads();
+        if (i < nblocks) block_base[i] = carry_a + s_a[wave] + incl_a - va;
+        if (i < ntiles) {
+            const unsigned long long ex = carry_b + s_b[wave] + incl_b - vb;
+            const uint32_t first = (uint32_t)ex;
+            ranges[i] = make_uint2(first, first + cnt);
+            tile_cursor[(size_t)i * CTR_STRIDE] = first;
+            chunk_base[i] = (uint32_t)(ex >> 32);          // number of CHUNK-entry pieces in front of tile i (render_bwd's work items)
+        }
+        carry_a += s_a[16];
+        carry_b += s_b[16];
+        __syncthreads();
+    }
+    const uint32_t R = carry_a, R_alloc = (uint32_t)carry_b, nchunks = (uint32_t)(carry_b >> 32);
     if (threadIdx.x == 0) chunk_base[ntiles] = nchunks;
     // largest tile list: lets the host pick the sort kernel variant (LDS footprint decides how many tiles sort concurrently)
-    uint32_t mx = 0;
-    for (int i = threadIdx.x; i < ntiles; i += 1024) mx = max(mx, tile_count[(size_t)i * CTR_STRIDE]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     __shared__ uint32_t s_mx[16];
@@ -344,7 +410,6 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
     const uint32_t incl = wave_inclusive_scan(cnt);
     if (lane == 63) s_wave_sum[wave] = incl;
     if (lds_path) {
-        // rows of block_tile_base are only defined where this block counted >= 1 instance; the rest is never read
         const uint32_t* row = block_tile_base + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += GB) s_pos[t] = ranges[t].x + row[t];
     }
