@@ -15,6 +15,7 @@
 
 #include "../../include/gs_rasterizer.h"
 #include "../../include/simple_knn.h"
+#include "../../include/slam_losses.h"
 
 namespace {
 
@@ -264,6 +265,60 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     return std::make_tuple(g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau_sum);
 }
 
+// ---- fused weighted L1 loss (include/slam_losses.h; slam_losses.py) ----------------------------------------------------------
+namespace {
+const float* optf(const c10::optional<torch::Tensor>& t, std::vector<torch::Tensor>& keep, const char* name)
+{
+    if (!t.has_value() || !t->defined() || t->numel() == 0) return nullptr;
+    torch::Tensor c = t->scalar_type() == torch::kFloat32 ? *t : t->to(torch::kFloat32);
+    c = c.contiguous();
+    keep.push_back(c);
+    return fptr(c, name);
+}
+}  // namespace
+
+// returns (loss [] , workspace)
+std::tuple<torch::Tensor, torch::Tensor> l1_loss_forward(const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image,
+                                                         const torch::Tensor& gt_depth, const c10::optional<torch::Tensor>& w_rgb,
+                                                         const c10::optional<torch::Tensor>& w_depth, const c10::optional<torch::Tensor>& exposure_a,
+                                                         const c10::optional<torch::Tensor>& exposure_b, double alpha, int64_t stream)
+{
+    TORCH_CHECK(image.is_cuda(), "image is on '", image.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int H = (int)image.size(-2), W = (int)image.size(-1);
+    std::vector<torch::Tensor> keep;
+    torch::Tensor loss = torch::empty({}, image.options().dtype(torch::kFloat32));
+    torch::Tensor ws = torch::empty({(int64_t)gsr_l1_loss_workspace_size()}, image.options().dtype(torch::kUInt8));
+    const int rc = gsr_l1_loss_forward(W, H, optf(image, keep, "image"), optf(depth, keep, "depth"), optf(gt_image, keep, "gt_image"),
+                                       optf(gt_depth, keep, "gt_depth"), optf(w_rgb, keep, "w_rgb"), optf(w_depth, keep, "w_depth"),
+                                       optf(exposure_a, keep, "exposure_a"), optf(exposure_b, keep, "exposure_b"), (float)alpha,
+                                       loss.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_l1_loss_forward", rc);
+    return std::make_tuple(loss, ws);
+}
+
+// returns (dL_dimage, dL_ddepth, dL_dexposure[2] or empty)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
+    const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image, const torch::Tensor& gt_depth,
+    const c10::optional<torch::Tensor>& w_rgb, const c10::optional<torch::Tensor>& w_depth, const c10::optional<torch::Tensor>& exposure_a,
+    const c10::optional<torch::Tensor>& exposure_b, double alpha, const torch::Tensor& upstream, const torch::Tensor& ws, int64_t stream)
+{
+    const int H = (int)image.size(-2), W = (int)image.size(-1);
+    std::vector<torch::Tensor> keep;
+    auto fopt = image.options().dtype(torch::kFloat32);
+    torch::Tensor g_image = torch::empty(image.sizes(), fopt), g_depth = torch::empty(depth.sizes(), fopt);
+    const bool has_exp = exposure_a.has_value() && exposure_a->defined() && exposure_a->numel() != 0;
+    torch::Tensor g_exp = has_exp ? torch::empty({2}, fopt) : torch::Tensor();
+    const int rc = gsr_l1_loss_backward(W, H, optf(image, keep, "image"), optf(depth, keep, "depth"), optf(gt_image, keep, "gt_image"),
+                                        optf(gt_depth, keep, "gt_depth"), optf(w_rgb, keep, "w_rgb"), optf(w_depth, keep, "w_depth"),
+                                        optf(exposure_a, keep, "exposure_a"), optf(exposure_b, keep, "exposure_b"), (float)alpha,
+                                        optf(upstream, keep, "upstream"), g_image.data_ptr<float>(), g_depth.data_ptr<float>(),
+                                        has_exp ? g_exp.data_ptr<float>() : nullptr, reinterpret_cast<char*>(ws.data_ptr()),
+                                        reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_l1_loss_backward", rc);
+    return std::make_tuple(g_image, g_depth, g_exp);
+}
+
 // markVisible, rasterize_points.cu:213-232
 torch::Tensor mark_visible(const torch::Tensor& means3D_, const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, int64_t stream)
 {
@@ -303,6 +358,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_backward_fused", &rasterize_gaussians_backward_fused);
     m.def("rasterize_gaussians_raw", &rasterize_gaussians_raw);
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
+    m.def("l1_loss_forward", &l1_loss_forward);
+    m.def("l1_loss_backward", &l1_loss_backward);
     m.def("mark_visible", &mark_visible);
     m.def("dist_cuda2", &dist_cuda2);
 }

@@ -41,8 +41,16 @@ def _p(t, keep):
 class _WeightedL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha):
-        lib = _lib()
         _C._require_device(image, "image")
+        if _C._glue is not None:     # native host glue (csrc/torch_glue.cpp)
+            with torch.cuda.device(image.device):
+                loss, ws = _C._glue.l1_loss_forward(image.detach(), depth.detach(), gt_image, gt_depth, w_rgb, w_depth,
+                                                    None if exposure_a is None else exposure_a.detach(),
+                                                    None if exposure_b is None else exposure_b.detach(), float(alpha), _C._stream(image.device))
+            ctx.alpha = float(alpha)
+            ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws)
+            return loss
+        lib = _lib()
         H, W = int(image.shape[-2]), int(image.shape[-1])
         dev = image.device
         loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -60,8 +68,16 @@ class _WeightedL1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib()
         image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws = ctx.saved_tensors
+        if _C._glue is not None:
+            with torch.cuda.device(image.device):
+                g_image, g_depth, g_exp = _C._glue.l1_loss_backward(
+                    image.detach(), depth.detach(), gt_image, gt_depth, w_rgb, w_depth, None if exposure_a is None else exposure_a.detach(),
+                    None if exposure_b is None else exposure_b.detach(), ctx.alpha, g, ws, _C._stream(image.device))
+            ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
+            gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
+            return g_image, g_depth, None, None, None, None, ga, gb, None
+        lib = _lib()
         H, W = int(image.shape[-2]), int(image.shape[-1])
         dev = image.device
         g_image, g_depth = torch.empty_like(image, dtype=torch.float32), torch.empty_like(depth, dtype=torch.float32)
