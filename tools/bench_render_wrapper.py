@@ -20,7 +20,6 @@ import gaussian_renderer as gr                                   # noqa: E402
 from synthetic_scene import make_camera, make_gaussians, make_cotangents   # noqa: E402
 from test_hip_fused_prologue import _GaussianModel, _camera      # noqa: E402  (the reference-shaped model stand-in)
 from slam_losses import get_loss_mapping, mapping_loss_weights   # noqa: E402
-from oracle.loss_oracle import weighted_l1_loss_reference       # noqa: E402  (timing comparison only)
 
 P, W, H = 200_000, 640, 480
 cam = make_camera(W, H)
@@ -39,7 +38,8 @@ gt_depth_np = rng0.uniform(0.3, 5.0, size=(H, W)).astype(np.float32)
 def torch_mapping_loss(image, depth, vp):       # the reference's tensor expression (utils/slam_utils.py:252-364), masks recomputed per call
     gt_depth = torch.from_numpy(vp.depth).to(dtype=torch.float32, device=image.device)[None]
     w_rgb, w_dep = mapping_loss_weights(config, vp, vp.original_image, gt_depth)
-    return weighted_l1_loss_reference(image, depth, vp.original_image, gt_depth, w_rgb, w_dep, vp.exposure_a, vp.exposure_b, 0.9)
+    image_ab = torch.exp(vp.exposure_a) * image + vp.exposure_b
+    return 0.9 * torch.abs(image_ab * w_rgb - vp.original_image * w_rgb).mean() + 0.1 * torch.abs(depth * w_dep - gt_depth * w_dep).mean()
 
 
 for fused, with_loss in ((False, False), (True, False), (False, True), (True, True)):
