@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -690,6 +691,34 @@ int gsr_l1_loss_backward(int width, int height, const float* image, const float*
     float* partials = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(LOSS_BLOCKS), dim3(LOSS_THREADS), 0, stream, a, upstream, dL_dimage, dL_ddepth, partials);
     if (dL_dexposure) hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partials, 2, dL_dexposure);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// ---- fused Adam (include/slam_losses.h) ---------------------------------------------------------------------------
+int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nseg < 0 || nseg > ADAM_MAX_SEGMENTS || (nseg > 0 && !segs)) { g_last_error = "gsr_adam_step: 0..8 segments"; return GSR_ERR_INVALID_ARGUMENT; }
+    AdamArgs a;
+    a.nseg = nseg; a.total = 0;
+    for (int k = 0; k < nseg; k++) {
+        const gsr_adam_segment& h = segs[k];
+        if (h.n && (!h.param || !h.grad || !h.exp_avg || !h.exp_avg_sq)) { g_last_error = "gsr_adam_step: null pointer"; return GSR_ERR_INVALID_ARGUMENT; }
+        if (h.step < 1) { g_last_error = "gsr_adam_step: step counts from 1"; return GSR_ERR_INVALID_ARGUMENT; }
+        a.start[k] = a.total;
+        AdamSegment& d = a.seg[k];
+        d.param = h.param; d.grad = h.grad; d.exp_avg = h.exp_avg; d.exp_avg_sq = h.exp_avg_sq; d.n = h.n;
+        const double bc1 = 1.0 - pow(h.beta1_d, (double)h.step), bc2 = 1.0 - pow(h.beta2_d, (double)h.step);
+        d.step_size = (float)((double)h.lr / bc1); d.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); d.eps = h.eps; d.beta2 = h.beta2;
+        d.one_minus_beta1 = (float)(1.0 - h.beta1_d); d.one_minus_beta2 = (float)(1.0 - h.beta2_d);
+        a.total += h.n;
+    }
+    a.start[nseg] = a.total;
+    if (a.total == 0) return 0;
+    const unsigned long long blocks = (a.total + 255) / 256;
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -86,3 +86,31 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, c
 }
 
 }  // namespace gsr
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused Adam step over several parameter tensors in ONE launch (second half): the reference steps six
+// groups (xyz, f_dc, f_rest, opacity, scaling, rotation; scene/gaussian_model.py:404-447, torch.optim.Adam(lr=0, eps=1e-15))
+// after every mapping iteration; torch's multi-tensor path needs ~10 launches for them. Same arithmetic as
+// torch.optim.Adam's single-tensor path (no amsgrad, no weight decay):
+//   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g^2;  p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int ADAM_MAX_SEGMENTS = 8;
+struct AdamSegment { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; unsigned long long n; float step_size, inv_bc2_sqrt, eps, beta2, one_minus_beta1, one_minus_beta2; };   // 1 - beta evaluated in double on the host, as torch does
+struct AdamArgs { int nseg; unsigned long long total; unsigned long long start[ADAM_MAX_SEGMENTS + 1]; AdamSegment seg[ADAM_MAX_SEGMENTS]; };
+
+__global__ void __launch_bounds__(256) adam_step_kernel(AdamArgs a)
+{
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < a.total; e += (unsigned long long)gridDim.x * 256) {
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < ADAM_MAX_SEGMENTS; k++) if (k < a.nseg && e >= a.start[k]) s = k;
+        const AdamSegment& g = a.seg[s];
+        const unsigned long long i = e - a.start[s];
+        const float gr = g.grad[i];
+        float m = g.exp_avg[i], v = g.exp_avg_sq[i];
+        m = m + (gr - m) * g.one_minus_beta1;
+        v = v * g.beta2 + g.one_minus_beta2 * gr * gr;
+        g.exp_avg[i] = m; g.exp_avg_sq[i] = v;
+        g.param[i] = g.param[i] - g.step_size * (m / (sqrtf(v) * g.inv_bc2_sqrt + g.eps));
+    }
+}

@@ -1,0 +1,81 @@
+"""Fused Adam for the Gaussian model (second half): a ``torch.optim.Adam`` whose ``step()`` updates every
+parameter tensor in ONE HIP launch (include/slam_losses.h, gsr_adam_step). It subclasses torch.optim.Adam and keeps its state
+layout (``state[p] = {"step", "exp_avg", "exp_avg_sq"}``, ``param_groups`` with per-group ``lr`` / ``name``), so the reference's
+densification code -- ``replace_tensor_to_optimizer``, ``cat_tensors_to_optimizer``, ``_prune_optimizer``
+(scene/gaussian_model.py:734-865), which edit ``optimizer.state`` and ``param_groups`` directly -- and its learning-rate schedule
+(:492-505) work unchanged:
+
+    self.optimizer = FusedAdam(l, lr=0.0, eps=1e-15)        # instead of torch.optim.Adam(l, lr=0.0, eps=1e-15), :447
+
+Only what the reference uses is fused (no amsgrad, weight decay, maximize, capturable); anything else, more than 8 tensors with
+gradients, or non-float32 / non-contiguous tensors goes through torch.optim.Adam's own step()."""
+import ctypes as C
+
+import torch
+
+from diff_gaussian_rasterization import _C
+
+_MAX_SEGMENTS = 8
+
+
+class _Segment(C.Structure):        # gsr_adam_segment
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_ulonglong), ("lr", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("beta1_d", C.c_double),
+                ("beta2_d", C.c_double), ("step", C.c_int)]
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = _C.load_library()
+    if not _declared:
+        lib.gsr_adam_step.restype = C.c_int
+        lib.gsr_adam_step.argtypes = [C.c_int, C.POINTER(_Segment), C.c_void_p]
+        _declared = True
+    return lib
+
+
+class FusedAdam(torch.optim.Adam):
+    def _fusable(self, todo):
+        if not todo or len(todo) > _MAX_SEGMENTS:
+            return False
+        for group, p in todo:
+            if group["amsgrad"] or group["weight_decay"] != 0 or group["maximize"] or group.get("capturable") or group.get("differentiable"):
+                return False
+            g = p.grad
+            if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse
+                    or not p.is_contiguous() or not g.is_contiguous()):
+                return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        todo = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if not self._fusable(todo):
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        segs = (_Segment * len(todo))()
+        dev = todo[0][1].device
+        for k, (group, p) in enumerate(todo):
+            st = self.state[p]
+            if len(st) == 0:          # lazy state initialisation, as torch.optim.Adam does it
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            s = segs[k]
+            s.param, s.grad, s.exp_avg, s.exp_avg_sq = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            s.n, s.lr, s.beta2, s.eps, s.step = p.numel(), float(group["lr"]), float(b2), float(group["eps"]), int(st["step"])
+            s.beta1_d, s.beta2_d = float(b1), float(b2)
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_adam_step(len(todo), segs, _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_adam_step")
+        return loss

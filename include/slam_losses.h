@@ -32,6 +32,19 @@ int gsr_l1_loss_backward(int width, int height, const float* image, const float*
                          const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
                          const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
 
+/* ---- fused Adam step: all parameter tensors of the Gaussian model in one launch -----------------
+ * Replaces optimizer.step() of scene/gaussian_model.py:447 (torch.optim.Adam(lr=0.0, eps=1e-15) over the six groups of :404-434)
+ * with the arithmetic of torch.optim.Adam's single-tensor path (no amsgrad, no weight decay, no maximize). At most 8 segments. */
+typedef struct gsr_adam_segment {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;   /* device, n floats each */
+    unsigned long long n;
+    float lr, beta2, eps;                                                  /* beta2 as the fp32 multiplier of v */
+    double beta1_d, beta2_d;                                               /* betas in double: 1 - beta and the bias corrections are
+                                                                              evaluated in double, as torch.optim.Adam does */
+    int step;                                                              /* step count AFTER this step (>= 1): bias corrections */
+} gsr_adam_segment;
+int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
