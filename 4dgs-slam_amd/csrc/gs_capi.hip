@@ -73,8 +73,7 @@ struct ImageState {
     {
         ImageState s;
         carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
-        // one memset per forward pass clears [tile_count, work_counters + 64): per-tile counters, the flag word behind them
-        // (index T*CTR_STRIDE) and the work counters
+        // the flag word sits behind the per-tile counters (index T*CTR_STRIDE)
         carve(p, s.tile_count, T * CTR_STRIDE + 64); carve(p, s.work_counters, 64);
         carve(p, s.tile_cursor, T * CTR_STRIDE);
         carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
@@ -277,13 +276,14 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     const size_t hist_lds_bytes = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
-    // One memset per forward pass: the flag word + the work counters, and the per-tile counters when they are accumulated with
-    // atomics (the fallback for frames with more tiles than the LDS histogram holds; otherwise tile_offsets_kernel writes them).
+    // Zero-filled scratch: the flag word only when someone can raise it (prefiltered; the reference's callers never set it), the
+    // per-tile counters only when they are accumulated with atomics (the fallback for frames with more tiles than the LDS
+    // histogram holds; otherwise tile_offsets_kernel writes them). The common case needs no memset at all.
     uint32_t* const flags = img.tile_count + (size_t)T * CTR_STRIDE;
-    {
-        uint32_t* const from = lds_hist ? flags : img.tile_count;
-        GSR_HIP_CHECK(hipMemsetAsync(from, 0, (size_t)((char*)(img.work_counters + 64) - (char*)from), stream));
-    }
+    if (!lds_hist)
+        GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, ((size_t)T * CTR_STRIDE + 1) * sizeof(uint32_t), stream));
+    else if (prefiltered)
+        GSR_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t), stream));
 
     const int nblocks = (P + GB - 1) / GB;
     if (P > 0) {
@@ -334,7 +334,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         }
         if (++t_seq == 0) t_seq = 1;
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
-                           img.ranges, img.tile_cursor, flags, (uint32_t)cap, cap_tile, img.chunk_base, geom.header,
+                           img.ranges, img.tile_cursor, prefiltered ? flags : (const uint32_t*)nullptr, (uint32_t)cap, cap_tile, img.chunk_base,
+                           geom.header,
                            t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
     }
     GSR_STAGE("scan");

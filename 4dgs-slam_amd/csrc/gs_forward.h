@@ -238,19 +238,38 @@ __global__ void __launch_bounds__(TO_COLS * TO_SEGS) tile_offsets_kernel(int nbl
     const int col = blockIdx.x * TO_COLS + c;
     const int rows_per_seg = (nblocks + TO_SEGS - 1) / TO_SEGS;
     const int r0 = seg * rows_per_seg, r1 = min(nblocks, r0 + rows_per_seg);
+    constexpr int RMAX = 16;                 // rows a thread keeps in registers: up to 256 Gaussian blocks (262 144 Gaussians) in one pass
+    const bool in_regs = rows_per_seg <= RMAX;
+    uint32_t v[RMAX];
     uint32_t sum = 0;
-    if (col < T)
-        for (int r = r0; r < r1; r++) sum += hist[(size_t)r * T + col];
+    if (col < T) {
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) v[k] = r0 + k < r1 ? hist[(size_t)(r0 + k) * T + col] : 0u;   // independent loads, all in flight
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) sum += v[k];
+        } else {
+            for (int r = r0; r < r1; r++) sum += hist[(size_t)r * T + col];
+        }
+    }
     s_seg[seg][c] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
-    for (int k = 0; k < TO_SEGS; k++) { const uint32_t v = s_seg[k][c]; if (k < seg) run += v; total += v; }
+    for (int k = 0; k < TO_SEGS; k++) { const uint32_t x = s_seg[k][c]; if (k < seg) run += x; total += x; }
     if (col < T) {
-        for (int r = r0; r < r1; r++) {
-            uint32_t* p = &hist[(size_t)r * T + col];
-            const uint32_t v = *p;
-            *p = run;
-            run += v;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) {
+                if (r0 + k < r1) hist[(size_t)(r0 + k) * T + col] = run;
+                run += v[k];
+            }
+        } else {
+            for (int r = r0; r < r1; r++) {
+                uint32_t* p = &hist[(size_t)r * T + col];
+                const uint32_t x = *p;
+                *p = run;
+                run += x;
+            }
         }
         if (seg == 0) tile_count[(size_t)col * CTR_STRIDE] = total;
     }
@@ -363,7 +382,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
         for (int w = 1; w < 16; w++) mx = max(mx, s_mx[w]);
         // cap_R != 0: the binning kernels were enqueued behind this one on a buffer sized for cap_R instances and tile lists of
         // at most cap_tile_list entries; if this frame needs more they must not run (they test FLAG_OVERFLOW) and the host redoes them.
-        uint32_t err = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t err = flags ? __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // flags == nullptr: nothing can have raised one
         if (cap_R && (R > cap_R || R_alloc > cap_R || mx > cap_tile_list)) err |= (uint32_t)FLAG_OVERFLOW;
         header[HDR_R] = R; header[HDR_FLAGS] = err; header[HDR_R_ALLOC] = R_alloc; header[HDR_MAX_TILE] = mx; header[HDR_CARVE_R] = cap_R;
         header[HDR_CAP_SORTED] = cap_R; header[HDR_CHUNKS] = nchunks;

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo/tests")
 from util import *
 import numpy as np, torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-cam = make_camera(640, 480); P = 200000
+cam = make_camera(640, 480); P = int(os.environ.get('P', 200000))
 g = make_gaussians(P, cam, seed=0); gc, gd = make_cotangents(cam)
 T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
 rs = GaussianRasterizationSettings(480, 640, cam.tanfovx, cam.tanfovy, T([1,1,1]), 1.0, T(cam.viewmatrix), T(cam.projmatrix), T(cam.projmatrix_raw), 0, T(cam.campos), False, False)
