@@ -152,6 +152,7 @@ static thread_local size_t t_last_R_alloc = 0;
 static thread_local uint32_t t_last_max_tile = 0;
 static thread_local bool t_use_mailbox = true;
 static thread_local bool t_speculate = true;
+static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] != '0' : true;   // sort short tile lists inside render_fwd
 
 static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
 {
@@ -354,10 +355,11 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                                (uint32_t)carve_R, (uint32_t)cap_sorted);
         }
         GSR_STAGE("scatter_instances");
-        {
+        if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here
             ScopedKernelTimer tm(K_SORT, stream);
-            hipLaunchKernelGGL((sort_tiles_kernel<SORT_SMALL_CAP, 0>), dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys,
-                               bin.inst_gauss, bin.sorted, chk);
+            if (!t_fuse_sort)
+                hipLaunchKernelGGL((sort_tiles_kernel<SORT_SMALL_CAP, 0>), dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys,
+                                   bin.inst_gauss, bin.sorted, chk);
             if (long_lists)
                 hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
                                    bin.keys, bin.inst_gauss, bin.sorted, chk);
@@ -367,7 +369,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             ScopedKernelTimer tm(K_RENDER_FWD, stream);
             hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D,
                                feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
-                               out_opacity, n_touched, img.final_C, bin.ckpt, chk);
+                               out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
+                               (const uint32_t*)bin.inst_gauss, bin.sorted);
         }
         GSR_STAGE("render_fwd");
         return 0;
@@ -404,7 +407,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
                            geom.means2D, feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color,
-                           out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr);
+                           out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
+                           (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr);
     }
     GSR_STAGE("render_fwd");
     return (int)R;

@@ -546,6 +546,36 @@ __device__ __forceinline__ void bitonic_sort_lds_pow2(uint64_t* keys, uint32_t n
 // handles those (in LDS up to 4096 keys, in global memory beyond). With the 32 KiB variant alone the 1200 blocks of a
 // 640x480 frame did not fit in one residency round and the kernel took two (40 us -> 20 us).
 constexpr int SORT_SMALL_CAP = 1024;
+// Sort of one tile list of n <= CAP keys in LDS (256 threads, s_keys holds CAP keys). A bitonic network wants a power of two;
+// padding 520 keys to 1024 would more than double the work. Instead the list is split into A = the largest power of two <= n
+// and the rest (padded to its own power of two), both halves are sorted, and every key finds its final rank with one binary
+// search in the other half (keys are unique). Ends with the sorted (gaussian, instance) pairs in global memory.
+__device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
+                                                 uint2* __restrict__ sorted, uint64_t* s_keys)
+{
+    const uint32_t n = r.y - r.x;
+    const uint64_t* seg = keys + r.x;
+    const uint32_t A = n <= 1 ? n : (1u << (31 - __clz((int)n)));
+    const uint32_t B = n - A, Bpad = B ? next_pow2(B) : 0;
+    for (uint32_t i = threadIdx.x; i < A + Bpad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds_pow2(s_keys, A);
+    if (B) bitonic_sort_lds_pow2(s_keys + A, Bpad);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint64_t key = s_keys[i];
+        const bool in_a = i < A;
+        const uint64_t* other = in_a ? s_keys + A : s_keys;
+        uint32_t lo = 0, hi = in_a ? B : A;              // number of keys of the other half that are smaller
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (other[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t rank = (in_a ? i : i - A) + lo;
+        const uint32_t u = (uint32_t)key;
+        sorted[r.x + rank] = make_uint2(inst_gauss[u], u);
+    }
+}
+
 template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
                                                          uint2* sorted, const uint32_t* spec_header)
@@ -557,31 +587,10 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2
     const uint32_t n = r.y - r.x;
     if (n <= (uint32_t)LOWER) return;                       // empty, or the other instantiation's tile
     if (CAP < SORT_LDS_CAP && n > (uint32_t)CAP) return;
-    uint64_t* seg = keys + r.x;
     if (n <= (uint32_t)CAP) {
-        // A bitonic network wants a power of two; padding 520 keys to 1024 would more than double the work. Instead the list
-        // is split into A = the largest power of two <= n and the rest (padded to its own power of two), both halves are
-        // sorted, and every key finds its final rank with one binary search in the other half (keys are unique).
-        const uint32_t A = n <= 1 ? n : (1u << (31 - __clz((int)n)));
-        const uint32_t B = n - A, Bpad = B ? next_pow2(B) : 0;
-        for (uint32_t i = threadIdx.x; i < A + Bpad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
-        __syncthreads();
-        bitonic_sort_lds_pow2(s_keys, A);
-        if (B) bitonic_sort_lds_pow2(s_keys + A, Bpad);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint64_t key = s_keys[i];
-            const bool in_a = i < A;
-            const uint64_t* other = in_a ? s_keys + A : s_keys;
-            uint32_t lo = 0, hi = in_a ? B : A;              // number of keys of the other half that are smaller
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (other[mid] < key) lo = mid + 1; else hi = mid;
-            }
-            const uint32_t rank = (in_a ? i : i - A) + lo;
-            const uint32_t u = (uint32_t)key;
-            sorted[r.x + rank] = make_uint2(inst_gauss[u], u);
-        }
+        sort_tile_in_lds(r, keys, inst_gauss, sorted, s_keys);
     } else {
+        uint64_t* seg = keys + r.x;
         const uint32_t npad = next_pow2(n);  // segment was allocated with npad entries, tail pre-filled with ~0
         bitonic_sort_block<false>(seg, npad);
         for (uint32_t i = threadIdx.x; i < n; i += 256) {

@@ -70,19 +70,22 @@ __device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned lo
 // F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                        const uint2* __restrict__ sorted, int W, int H,
+                                                        const uint2* sorted /* may alias sorted_out */, int W, int H,
                                                         const float2* __restrict__ means2D, const float* __restrict__ feat,
                                                         const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
                                                         const float* __restrict__ bg, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_opacity,
                                                         int* __restrict__ n_touched, float4* __restrict__ final_C,
-                                                        float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header)
+                                                        float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
+                                                        uint2* sorted_out)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
-    __shared__ float4 s_a[RB];      // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
-    __shared__ float4 s_b[RB];      // {C, opacity, -, gaussian id bits}
-    __shared__ float4 s_c[RB];      // {r, g, b, depth}: two packed FMAs per blended entry
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[3 * RB * sizeof(float4)];
+    float4* const s_a = reinterpret_cast<float4*>(s_raw);   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
+    float4* const s_b = s_a + RB;                            // {C, opacity, -, gaussian id bits}
+    float4* const s_c = s_b + RB;                            // {r, g, b, depth}: two packed FMAs per blended entry
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
     __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
 
@@ -105,6 +108,14 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    // keys != nullptr: this block first sorts its own tile list (the staging arrays double as the key buffer) -- one kernel and
+    // one GPU drain/fill less per frame than a separate sort launch; lists beyond the LDS capacity were sorted by
+    // sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP> before.
+    static_assert(3 * RB * sizeof(float4) >= SORT_SMALL_CAP * sizeof(uint64_t), "key buffer aliases the staging arrays");
+    if (keys != nullptr && n > 0 && n <= SORT_SMALL_CAP) {
+        sort_tile_in_lds(range, keys, inst_gauss, sorted_out, reinterpret_cast<uint64_t*>(s_raw));
+        __syncthreads();                                   // the sorted list (global) and the LDS buffer are reused below
+    }
     // Checkpoint of the per-pixel compositing state in front of list entry `boundary` (a multiple of CHUNK): lets the backward
     // pass start at any chunk of the list instead of walking the whole list from its end (render_bwd_kernel). Five coalesced
     // 256-byte stores per wave and CHUNK entries. A wave whose pixels are all saturated stops writing them: the backward
