@@ -65,7 +65,7 @@ struct GeomState {
 };
 static inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
 struct ImageState {
-    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor; uint32_t* work_counters;
+    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
     float4* final_C;        // per pixel: colour / depth sums without the background term (render_bwd's chunk start-up needs them)
     uint32_t* chunk_base;   // [T + 1] exclusive scan of ceil(tile list length / CHUNK)
     uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
@@ -74,7 +74,7 @@ struct ImageState {
         ImageState s;
         carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
         // the flag word sits behind the per-tile counters (index T*CTR_STRIDE)
-        carve(p, s.tile_count, T * CTR_STRIDE + 64); carve(p, s.work_counters, 64);
+        carve(p, s.tile_count, T * CTR_STRIDE + 64);
         carve(p, s.tile_cursor, T * CTR_STRIDE);
         carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
         return s;

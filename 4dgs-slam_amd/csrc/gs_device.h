@@ -274,9 +274,6 @@ __device__ __forceinline__ f3 xform_point_4x3(f3 p, const float* __restrict__ m)
 // so neighbouring tiles (which share Gaussians) hit the same L2. Bijective for any tile count.
 __device__ __forceinline__ int xcd_tile_of_block(int b, int ntiles)
 {
-#if defined(GSR_NO_BANDING) && GSR_NO_BANDING
-    return b;
-#endif
     const int q = ntiles >> 3, r = ntiles & 7;
     const int xcd = b & 7, k = b >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
