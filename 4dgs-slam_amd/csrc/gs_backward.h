@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     const bool in_range = idx < a.P;
     const size_t i = (size_t)(in_range ? idx : 0);
     const bool visible = in_range && a.radii[idx] > 0;   // backward.cu:163,443
+    const size_t o = in_range && a.raw.xyz ? raw_row(a.raw, i) : i;   // row of the parameter-gradient outputs (raw mode with a mask: the selected row)
 
     // ---- gather: sum this Gaussian's per-instance slots ----------------------------------------------------------
     // Instance ids are a global running count over Gaussians, so the 256 Gaussians of a block own ONE contiguous range of
@@ -69,9 +70,9 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         __syncthreads();
     }
     if (in_range) {
-        a.dL_dmean2D[3 * i] = g_m2x; a.dL_dmean2D[3 * i + 1] = g_m2y; a.dL_dmean2D[3 * i + 2] = 0.f;   // z never written, Q14
+        a.dL_dmean2D[3 * o] = g_m2x; a.dL_dmean2D[3 * o + 1] = g_m2y; a.dL_dmean2D[3 * o + 2] = 0.f;   // z never written, Q14
         if (a.dL_dconic) { a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw; }
-        a.dL_dopacity[i] = a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op;   // raw: through the sigmoid
+        a.dL_dopacity[o] = a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op;   // raw: through the sigmoid
         if (a.dL_dcolor) { a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b; }
         if (a.dL_ddepth) a.dL_ddepth[i] = g_d;
     }
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool has_sh = a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr);
-    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * i, a.rawg.f_rest ? a.rawg.f_rest + i * (size_t)(a.M - 1) * 3 : nullptr}
+    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr}
                                 : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr};
     if (!visible) {
         if (has_sh && in_range) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     }
     if (in_range) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * i + k] = dmean[k];
+        for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * o + k] = dmean[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
@@ -292,24 +293,24 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         } else {
             // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
             // effective parameters' gradients of their Gaussian (one Gaussian per slot: plain stores)
-            const int sl = raw_slot(a.raw, i);
+            const int sl = raw_slot(a.raw, o);
             if (sl >= 0) {
                 if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0]; a.rawg.ddx[3 * sl + 1] = dmean[1]; a.rawg.ddx[3 * sl + 2] = dmean[2]; }
                 if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
                 if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
             }
             if (a.raw.scale_dim == 1) {
-                a.dL_dscale[i] = (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[i]);
+                a.dL_dscale[o] = (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[o]);
             } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k] * expf(a.raw.log_scales[3 * i + k]);
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = dscale[k] * expf(a.raw.log_scales[3 * o + k]);
             }
-            const float ra = a.raw.raw_rot[4 * i], rb = a.raw.raw_rot[4 * i + 1], rc = a.raw.raw_rot[4 * i + 2], rd = a.raw.raw_rot[4 * i + 3];
+            const float ra = a.raw.raw_rot[4 * o], rb = a.raw.raw_rot[4 * o + 1], rc = a.raw.raw_rot[4 * o + 2], rd = a.raw.raw_rot[4 * o + 3];
             const float inv = 1.0f / fmaxf(sqrtf(ra * ra + rb * rb + rc * rc + rd * rd), 1e-12f);
             const float qa = ra * inv, qb = rb * inv, qc = rc * inv, qd = rd * inv;
             const float dotg = qa * drot[0] + qb * drot[1] + qc * drot[2] + qd * drot[3];
-            a.dL_drot[4 * i] = (drot[0] - qa * dotg) * inv; a.dL_drot[4 * i + 1] = (drot[1] - qb * dotg) * inv;
-            a.dL_drot[4 * i + 2] = (drot[2] - qc * dotg) * inv; a.dL_drot[4 * i + 3] = (drot[3] - qd * dotg) * inv;
+            a.dL_drot[4 * o] = (drot[0] - qa * dotg) * inv; a.dL_drot[4 * o + 1] = (drot[1] - qb * dotg) * inv;
+            a.dL_drot[4 * o + 2] = (drot[2] - qc * dotg) * inv; a.dL_drot[4 * o + 3] = (drot[3] - qd * dotg) * inv;
         }
     }
     // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with

@@ -233,7 +233,7 @@ static RawInputs to_device_view(const gsr_raw_inputs* in)
     if (in) {
         r.xyz = in->xyz; r.log_scales = in->log_scales; r.scale_dim = in->scale_dim; r.raw_rot = in->raw_rotations;
         r.logit_opacity = in->logit_opacity; r.f_dc = in->features_dc; r.f_rest = in->features_rest;
-        r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr;
+        r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr; r.gather = in->gather;
     }
     return r;
 }

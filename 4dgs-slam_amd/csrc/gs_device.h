@@ -211,6 +211,7 @@ enum { FLAG_PREFILTERED = 1u, FLAG_OVERFLOW = 2u };   // FLAG_OVERFLOW: the spec
 struct RawInputs {
     const float* xyz; const float* log_scales; int scale_dim; const float* raw_rot; const float* logit_opacity;
     const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;
+    const int* gather;   // optional: rasterized Gaussian i reads row gather[i] of the raw tensors (render()'s boolean mask, :179-191)
 };
 struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; };
 struct ShView {    // SH coefficients of one Gaussian: [k] with k = 3 * coefficient + channel
@@ -226,10 +227,12 @@ struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-__device__ __forceinline__ int raw_slot(const RawInputs& r, size_t i) { return r.dyn_slot ? r.dyn_slot[i] : -1; }
+__device__ __forceinline__ size_t raw_row(const RawInputs& r, size_t i) { return r.gather ? (size_t)r.gather[i] : i; }   // row of the raw tensors
+__device__ __forceinline__ int raw_slot(const RawInputs& r, size_t row) { return r.dyn_slot ? r.dyn_slot[row] : -1; }
 __device__ __forceinline__ f3 load_mean(const float* means3D, const RawInputs& r, size_t i)
 {
     if (!r.xyz) return mk3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    i = raw_row(r, i);
     f3 m = mk3(r.xyz[3 * i], r.xyz[3 * i + 1], r.xyz[3 * i + 2]);
     const int sl = raw_slot(r, i);
     if (sl >= 0 && r.dx) { m.x += r.dx[3 * sl]; m.y += r.dx[3 * sl + 1]; m.z += r.dx[3 * sl + 2]; }
@@ -238,6 +241,7 @@ __device__ __forceinline__ f3 load_mean(const float* means3D, const RawInputs& r
 __device__ __forceinline__ void load_scale(const float* scales, const RawInputs& r, size_t i, float s[3])
 {
     if (!r.xyz) { s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2]; return; }
+    i = raw_row(r, i);
     if (r.scale_dim == 1) { s[0] = s[1] = s[2] = expf(r.log_scales[i]); }
     else { s[0] = expf(r.log_scales[3 * i]); s[1] = expf(r.log_scales[3 * i + 1]); s[2] = expf(r.log_scales[3 * i + 2]); }
     const int sl = raw_slot(r, i);
@@ -246,6 +250,7 @@ __device__ __forceinline__ void load_scale(const float* scales, const RawInputs&
 __device__ __forceinline__ void load_rot(const float* rotations, const RawInputs& r, size_t i, float q[4])
 {
     if (!r.xyz) { q[0] = rotations[4 * i]; q[1] = rotations[4 * i + 1]; q[2] = rotations[4 * i + 2]; q[3] = rotations[4 * i + 3]; return; }
+    i = raw_row(r, i);
     const float a = r.raw_rot[4 * i], b = r.raw_rot[4 * i + 1], c = r.raw_rot[4 * i + 2], d = r.raw_rot[4 * i + 3];
     const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c + d * d), 1e-12f);     // torch.nn.functional.normalize
     q[0] = a * inv; q[1] = b * inv; q[2] = c * inv; q[3] = d * inv;
@@ -254,11 +259,12 @@ __device__ __forceinline__ void load_rot(const float* rotations, const RawInputs
 }
 __device__ __forceinline__ float load_opacity(const float* opacities, const RawInputs& r, size_t i)
 {
-    return r.xyz ? 1.0f / (1.0f + expf(-r.logit_opacity[i])) : opacities[i];           // torch.sigmoid
+    return r.xyz ? 1.0f / (1.0f + expf(-r.logit_opacity[raw_row(r, i)])) : opacities[i];           // torch.sigmoid
 }
 __device__ __forceinline__ ShView sh_view(const float* shs, const RawInputs& r, size_t i, int M)
 {
     if (!r.xyz) { const float* p = shs + i * M * 3; return ShView{p, p + 3}; }
+    i = raw_row(r, i);
     return ShView{r.f_dc + 3 * i, r.f_rest ? r.f_rest + i * (size_t)(M - 1) * 3 : nullptr};
 }
 

@@ -159,9 +159,13 @@ const torch::Tensor& nz(const c10::optional<torch::Tensor>& t, const torch::Tens
 
 gsr_raw_inputs describe(const torch::Tensor& xyz, const torch::Tensor& log_scales, const torch::Tensor& raw_rot, const torch::Tensor& logit,
                         const torch::Tensor& f_dc, const torch::Tensor& f_rest, const torch::Tensor& dyn_slot, const torch::Tensor& dx,
-                        const torch::Tensor& ds, const torch::Tensor& dr)
+                        const torch::Tensor& ds, const torch::Tensor& dr, const torch::Tensor& gather)
 {
     gsr_raw_inputs d{};
+    if (gather.defined() && gather.numel() != 0) {
+        TORCH_CHECK(gather.is_cuda() && gather.scalar_type() == torch::kInt32 && gather.is_contiguous(), "gather must be a contiguous int32 device tensor");
+        d.gather = gather.data_ptr<int>();
+    }
     d.xyz = fptr(xyz, "_xyz"); d.log_scales = fptr(log_scales, "_scaling"); d.scale_dim = (int)log_scales.size(-1);
     d.raw_rotations = fptr(raw_rot, "_rotation"); d.logit_opacity = fptr(logit, "_opacity");
     d.features_dc = fptr(f_dc, "_features_dc"); d.features_rest = fptr(f_rest, "_features_rest");
@@ -180,13 +184,16 @@ rasterize_gaussians_raw(const torch::Tensor& background, const torch::Tensor& xy
                         const c10::optional<torch::Tensor>& dyn_slot_, const c10::optional<torch::Tensor>& dx_,
                         const c10::optional<torch::Tensor>& ds_, const c10::optional<torch::Tensor>& dr_, double scale_modifier,
                         const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, double tan_fovx, double tan_fovy,
-                        int64_t image_height, int64_t image_width, int64_t degree, const torch::Tensor& campos_, bool debug, int64_t stream)
+                        int64_t image_height, int64_t image_width, int64_t degree, const torch::Tensor& campos_, bool debug,
+                        const c10::optional<torch::Tensor>& gather_, int64_t stream)
 {
     TORCH_CHECK(xyz_.dim() == 2 && xyz_.size(1) == 3 && xyz_.size(0) > 0, "_xyz must have dimensions (num_points > 0, 3)");
     TORCH_CHECK(xyz_.is_cuda(), "_xyz is on '", xyz_.device().str(),
                 "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
     const torch::Tensor none;
-    const int P = (int)xyz_.size(0), H = (int)image_height, W = (int)image_width;
+    const torch::Tensor gather = contig(nz(gather_, none));
+    const bool masked = gather.defined() && gather.numel() != 0;
+    const int P = (int)(masked ? gather.size(0) : xyz_.size(0)), H = (int)image_height, W = (int)image_width;   // rasterized Gaussians
     auto fopt = xyz_.options().dtype(torch::kFloat32);
     auto iopt = xyz_.options().dtype(torch::kInt32);
     auto bopt = xyz_.options().dtype(torch::kUInt8);
@@ -200,7 +207,7 @@ rasterize_gaussians_raw(const torch::Tensor& background, const torch::Tensor& xy
                         ds = contig(nz(ds_, none)), dr = contig(nz(dr_, none)), view = contig(viewmatrix_), proj = contig(projmatrix_),
                         campos = contig(campos_);
     const int M = 1 + (frest.defined() && frest.numel() != 0 ? (int)frest.size(1) : 0);
-    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr, gather);
     const int rendered = gsr_forward_raw(resize_cb, &geomBuffer, resize_cb, &binningBuffer, resize_cb, &imgBuffer, P, (int)degree, M, fptr(bg, "bg"),
                                          W, H, &in, (float)scale_modifier, fptr(view, "viewmatrix"), fptr(proj, "projmatrix"), fptr(campos, "campos"),
                                          (float)tan_fovx, (float)tan_fovy, out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
@@ -222,10 +229,13 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                                  const torch::Tensor& projmatrix_, const torch::Tensor& projmatrix_raw_, double tan_fovx, double tan_fovy,
                                  const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, int64_t degree,
                                  const torch::Tensor& campos_, const torch::Tensor& radii_, const torch::Tensor& geomBuffer, int64_t R,
-                                 const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, int64_t stream)
+                                 const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug,
+                                 const c10::optional<torch::Tensor>& gather_, int64_t stream)
 {
     const torch::Tensor none;
-    const int64_t P = xyz_.size(0), S = log_scales_.size(-1);
+    const torch::Tensor gather = contig(nz(gather_, none));
+    const bool masked = gather.defined() && gather.numel() != 0;
+    const int64_t P = xyz_.size(0), S = log_scales_.size(-1);   // P: rows of the raw tensors (= of every gradient)
     const int H = (int)dL_dout_color_.size(1), W = (int)dL_dout_color_.size(2);
     const torch::Tensor bg = contig(background), xyz = contig(xyz_), ls = contig(log_scales_), rr = contig(raw_rot_), lo = contig(logit_),
                         fdc = contig(f_dc_), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none)), dx = contig(nz(dx_, none)),
@@ -238,7 +248,7 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     const int64_t widths[7] = {3, 3, 3 * (M - 1), 1, S, 4, 3};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
-    torch::Tensor flat = torch::empty({total}, fopt);
+    torch::Tensor flat = masked ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);   // with a mask only the selected rows are written
     torch::Tensor v[7];
     int64_t o = 0;
     for (int i = 0; i < 7; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
@@ -247,7 +257,7 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     torch::Tensor tau_sum = flat.narrow(0, o, 6);
     auto zeros_like_opt = [&](const torch::Tensor& t) { return (t.defined() && t.numel() != 0) ? torch::zeros_like(t, fopt) : torch::Tensor(); };
     torch::Tensor g_dx = zeros_like_opt(dx), g_ds = zeros_like_opt(ds), g_dr = zeros_like_opt(dr);
-    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr, gather);
     gsr_raw_grads out{};
     out.xyz = g_xyz.data_ptr<float>(); out.log_scales = g_ls.data_ptr<float>(); out.raw_rotations = g_rot.data_ptr<float>();
     out.logit_opacity = g_logit.data_ptr<float>(); out.features_dc = g_fdc.data_ptr<float>();
@@ -255,7 +265,7 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     out.dx = g_dx.defined() ? g_dx.data_ptr<float>() : nullptr; out.ds = g_ds.defined() ? g_ds.data_ptr<float>() : nullptr;
     out.dr = g_dr.defined() ? g_dr.data_ptr<float>() : nullptr;
     TORCH_CHECK(radii.is_cuda() && radii.scalar_type() == torch::kInt32, "radii must be an int32 device tensor");
-    const int rc = gsr_backward_raw((int)P, (int)degree, (int)M, (int)R, fptr(bg, "bg"), W, H, &in, (float)scale_modifier, fptr(view, "viewmatrix"),
+    const int rc = gsr_backward_raw((int)(masked ? gather.size(0) : P), (int)degree, (int)M, (int)R, fptr(bg, "bg"), W, H, &in, (float)scale_modifier, fptr(view, "viewmatrix"),
                                     fptr(proj, "projmatrix"), fptr(proj_raw, "projmatrix_raw"), fptr(campos, "campos"), (float)tan_fovx,
                                     (float)tan_fovy, radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()),
                                     reinterpret_cast<char*>(binningBuffer.data_ptr()), reinterpret_cast<char*>(imageBuffer.data_ptr()),

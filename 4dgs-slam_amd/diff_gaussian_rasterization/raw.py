@@ -30,7 +30,7 @@ _f, _i, _vp = C.c_float, C.c_int, C.c_void_p
 
 class _RawInputs(C.Structure):     # gsr_raw_inputs
     _fields_ = [("xyz", _vp), ("log_scales", _vp), ("scale_dim", _i), ("raw_rotations", _vp), ("logit_opacity", _vp),
-                ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp)]
+                ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp), ("gather", _vp)]
 
 
 class _RawGrads(C.Structure):      # gsr_raw_grads
@@ -65,7 +65,7 @@ def _f32(t, name, keep):
     return tc.data_ptr()
 
 
-def _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep):
+def _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep, gather=None):
     for t, name in ((xyz, "_xyz"), (log_scales, "_scaling"), (raw_rot, "_rotation"), (logit_opacity, "_opacity"), (f_dc, "_features_dc")):
         if t.dtype != torch.float32:
             raise RuntimeError(f"{name} must be float32, got {t.dtype}")
@@ -76,6 +76,9 @@ def _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, d
     d.raw_rotations, d.logit_opacity = _f32(raw_rot, "_rotation", keep), _f32(logit_opacity, "_opacity", keep)
     d.features_dc, d.features_rest = _f32(f_dc, "_features_dc", keep), _f32(f_rest, "_features_rest", keep)
     d.dyn_slot, d.dx, d.ds, d.dr = _f32(dyn_slot, "dyn_slot", keep), _f32(dx, "dx", keep), _f32(ds, "ds", keep), _f32(dr, "dr", keep)
+    if gather is not None and gather.dtype != torch.int32:
+        raise RuntimeError("gather must be int32")
+    d.gather = _f32(gather, "gather", keep)
     return d
 
 
@@ -87,26 +90,27 @@ def dyn_slot_from_mask(dygs: torch.Tensor) -> torch.Tensor:
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs):
+    def forward(ctx, xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs, gather=None):
         _C._require_device(xyz, "_xyz")
         dev = xyz.device
         ctx.rs = rs
         ctx.pose_shapes = (tuple(theta.shape) if isinstance(theta, torch.Tensor) else None,
                            tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
         ctx.set_materialize_grads(False)
+        ctx.gather = gather
         if _C._glue is not None:      # native host glue (csrc/torch_glue.cpp): same calls, marshalled in C++
             with torch.cuda.device(dev):
                 (rc, color, radii, geom_t, bin_t, img_t, depth, opacity, n_touched) = _C._glue.rasterize_gaussians_raw(
                     rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
                     rs.viewmatrix, rs.projmatrix, float(rs.tanfovx), float(rs.tanfovy), int(rs.image_height), int(rs.image_width),
-                    int(rs.sh_degree), rs.campos, bool(rs.debug), _C._stream(dev))
+                    int(rs.sh_degree), rs.campos, bool(rs.debug), gather, _C._stream(dev))
             ctx.num_rendered = rc
             ctx.M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
             ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii, geom_t, bin_t, img_t)
             ctx.mark_non_differentiable(radii, n_touched)
             return color, radii, depth, opacity, n_touched
         lib = _lib()
-        P, H, W = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width)
+        P, H, W = int(xyz.shape[0] if gather is None else gather.shape[0]), int(rs.image_height), int(rs.image_width)
         M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
         img = torch.empty((_C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
         color, depth, opacity = img[:_C.NUM_CHANNELS], img[_C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[_C.NUM_CHANNELS + 1:]
@@ -114,7 +118,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         radii, n_touched = ints[0], ints[1]
         geom, binning, imgbuf = _C._Arena(dev), _C._Arena(dev), _C._Arena(dev)
         keep = []
-        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep)
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep, gather)
         with torch.cuda.device(dev):
             rc = lib.gsr_forward_raw(
                 geom.cb, None, binning.cb, None, imgbuf.cb, None, P, int(rs.sh_degree), M, _f32(rs.bg, "bg", keep), W, H,
@@ -141,22 +145,24 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if g_depth is None:
             g_depth = xyz.new_zeros((1, H, W))
         th_shape, rho_shape = ctx.pose_shapes
+        gather = ctx.gather
         if _C._glue is not None:
             with torch.cuda.device(dev):
                 (g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau) = _C._glue.rasterize_gaussians_raw_backward(
                     rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
                     rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth,
-                    int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), _C._stream(dev))
+                    int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), gather, _C._stream(dev))
             opt = lambda t, src: t if src is not None and src.numel() else None
             return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, opt(g_dx, dx), opt(g_ds, ds), opt(g_dr, dr),
                     _pose_grad(tau[3:], th_shape) if th_shape is not None else None,
-                    _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None, None)
+                    _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None, None, None)
         lib = _lib()
         g_color = g_color if g_color.dtype == torch.float32 else g_color.to(torch.float32)
         g_depth = g_depth if g_depth.dtype == torch.float32 else g_depth.to(torch.float32)
         # one allocation; parameter order of the optimizer (gaussian_model.py:404-434), then the screen-space gradient
         widths = [3, 3, 3 * (M - 1), 1, S, 4, 3]
-        flat = torch.empty((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
+        # with a mask only the selected rows are written: the rest of the gradients is zero
+        flat = (torch.empty if gather is None else torch.zeros)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
         views, o = [], 0
         for w_ in widths:
             views.append(flat[o:o + P * w_])
@@ -167,7 +173,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         K = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
         g_dx, g_ds, g_dr = K(dx), K(ds), K(dr)
         keep = []
-        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep)
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep, gather)
         out = _RawGrads()
         out.xyz, out.log_scales, out.raw_rotations, out.logit_opacity = g_xyz.data_ptr(), g_ls.data_ptr(), g_rot.data_ptr(), g_logit.data_ptr()
         out.features_dc, out.features_rest = g_fdc.data_ptr(), (g_frest.data_ptr() if M > 1 else None)
@@ -175,7 +181,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                   g_dr.data_ptr() if g_dr is not None else None)
         with torch.cuda.device(dev):
             rc = lib.gsr_backward_raw(
-                P, int(rs.sh_degree), M, int(ctx.num_rendered), _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
+                P if gather is None else int(gather.shape[0]), int(rs.sh_degree), M, int(ctx.num_rendered), _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
                 _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.projmatrix_raw, "projmatrix_raw", keep),
                 _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
                 geom.data_ptr(), binning.data_ptr(), imgbuf.data_ptr(), _f32(g_color, "dL_dcolor", keep), _f32(g_depth, "dL_ddepth", keep),
@@ -185,18 +191,25 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         g_rho = _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None
         g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
         # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
-        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None)
+        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
+
+
+def gather_from_mask(mask: torch.Tensor) -> torch.Tensor:
+    """int32[Pm]: rows selected by render()'s boolean `mask` (x[mask] order). Synchronises, exactly like x[mask] does."""
+    return mask.to(torch.bool).nonzero(as_tuple=False).squeeze(1).to(torch.int32)
 
 
 def rasterize_gaussians_raw(raster_settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest=None,
-                            dyn_slot=None, dx=None, ds=None, dr=None, theta=None, rho=None):
+                            dyn_slot=None, dx=None, ds=None, dr=None, theta=None, rho=None, gather=None):
     """(color[3,H,W], radii[P], depth[1,H,W], opacity[1,H,W], n_touched[P]) of GaussianRasterizer.forward, from raw model parameters.
 
-    ``dyn_slot`` (int32[P], see dyn_slot_from_mask) is required with dx / ds / dr. Empty models must be handled by the caller
+    ``dyn_slot`` (int32[P], see dyn_slot_from_mask) is required with dx / ds / dr. ``gather`` (int32[Pm], see gather_from_mask)
+    rasterizes only those rows, like render()'s ``mask``: radii / n_touched then have Pm entries and every gradient keeps its
+    full shape with zeros in the unselected rows. Empty models must be handled by the caller
     (the reference's render() returns None for them)."""
     if xyz.shape[0] == 0:
         raise RuntimeError("rasterize_gaussians_raw: empty model")
     if (dx is not None or ds is not None or dr is not None) and dyn_slot is None:
         raise RuntimeError("rasterize_gaussians_raw: dx / ds / dr need dyn_slot")
     return _RasterizeGaussiansRaw.apply(xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, dyn_slot,
-                                        dx, ds, dr, theta, rho, raster_settings)
+                                        dx, ds, dr, theta, rho, raster_settings, gather)

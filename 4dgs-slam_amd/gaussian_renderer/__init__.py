@@ -89,7 +89,7 @@ def _fused_prologue_ok(pc, pipe, mask, dynamic) -> bool:
     from scale/rotation in the rasterizer (pipe.convert_SHs_python = compute_cov3D_python = False, base_config.yaml), no
     boolean mask, no 4DGaussians deformation network, and a GaussianModel whose activations are the reference's
     (scene/gaussian_model.py:60-68: exp, sigmoid, F.normalize)."""
-    if not FUSED_PROLOGUE or _raw is None or mask is not None or dynamic:
+    if not FUSED_PROLOGUE or _raw is None or dynamic:
         return False
     if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
         return False
@@ -102,14 +102,15 @@ def _fused_prologue_ok(pc, pipe, mask, dynamic) -> bool:
     return acts and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in raws)
 
 
-def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr):
+def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr, mask=None):
     deltas = dx is not None and ds is not None and dr is not None        # the reference applies them only together (:159)
     slot = _raw.dyn_slot_from_mask(pc.dygs) if deltas else None
     f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
     return _raw.rasterize_gaussians_raw(
         _settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree), pc._xyz, screenspace_points, pc._scaling,
         pc._rotation, pc._opacity, pc._features_dc, f_rest, slot, dx if deltas else None, ds if deltas else None,
-        dr if deltas else None, viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta)
+        dr if deltas else None, viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta,
+        gather=None if mask is None else _raw.gather_from_mask(mask))
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None,
@@ -121,7 +122,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     screenspace_points = _screenspace_points(pc)
     if _fused_prologue_ok(pc, pipe, mask, dynamic):
         rendered_image, radii, depth, opacity, n_touched = _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
-                                                                         screenspace_points, dx, ds, dr)
+                                                                         screenspace_points, dx, ds, dr, mask)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
                 "depth": depth, "opacity": opacity, "n_touched": n_touched}
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree))

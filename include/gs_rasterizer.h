@@ -120,10 +120,12 @@ typedef struct gsr_raw_inputs {
     const float* dx;             /* [K,3] or NULL */
     const float* ds;             /* [K,3] or NULL */
     const float* dr;             /* [K,4] or NULL */
+    const int* gather;           /* [P] or NULL: rasterized Gaussian i is row gather[i] of the tensors above -- the boolean `mask`
+                                    selection of render() (gaussian_renderer/__init__.py:179-191), P = number of selected rows */
 } gsr_raw_inputs;
 
-typedef struct gsr_raw_grads {   /* all fully written; dx / ds / dr may be NULL (required when the corresponding input was given
-                                    and its gradient is wanted) */
+typedef struct gsr_raw_grads {   /* all fully written (with `gather`: only the selected rows -- zero-fill them first); dx / ds / dr may be
+                                    NULL (required when the corresponding input was given and its gradient is wanted) */
     float* xyz;                  /* [P,3] */
     float* log_scales;           /* [P,scale_dim] */
     float* raw_rotations;        /* [P,4] */
@@ -143,7 +145,7 @@ int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_user,
                     float* out_color, float* out_depth, float* out_opacity, int* radii, int* n_touched,
                     int debug, void* stream);
 
-/* Backward of gsr_forward_raw: dL_dmean2D[P,3] as in gsr_backward, the parameter gradients of `out`, dL_dtau_sum[6] (may be NULL). */
+/* Backward of gsr_forward_raw: dL_dmean2D[P,3] as in gsr_backward (with `gather`: one row per ROW of the raw tensors, like `out`), the parameter gradients of `out`, dL_dtau_sum[6] (may be NULL). */
 int gsr_backward_raw(int P, int D, int M, int R,
                      const float* background, int width, int height,
                      const gsr_raw_inputs* in, float scale_modifier,

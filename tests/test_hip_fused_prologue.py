@@ -51,8 +51,9 @@ def _camera(cam):
         camera_center=T(cam.campos), cam_rot_delta=T(np.zeros(3), True), cam_trans_delta=T(np.zeros(3), True), time=0.0)
 
 
-@pytest.mark.parametrize("isotropic,deg,with_deltas", [(False, 0, False), (False, 2, True), (True, 1, True), (False, 3, False)])
-def test_fused_prologue_matches_the_torch_prologue(isotropic, deg, with_deltas):
+@pytest.mark.parametrize("isotropic,deg,with_deltas,with_mask", [(False, 0, False, False), (False, 2, True, False), (True, 1, True, False),
+                                                                 (False, 3, False, False), (False, 1, False, True), (True, 0, True, True)])
+def test_fused_prologue_matches_the_torch_prologue(isotropic, deg, with_deltas, with_mask):
     import gaussian_renderer as gr
 
     cam = make_camera(200, 152)
@@ -72,8 +73,9 @@ def test_fused_prologue_matches_the_torch_prologue(isotropic, deg, with_deltas):
                       for k, n, s in (("dx", 3, 0.02), ("ds", 3, 0.001), ("dr", 4, 0.05))}
         gr.FUSED_PROLOGUE = fused
         try:
-            assert gr._fused_prologue_ok(m, pipe, None, False) == fused
-            res = gr.render(view, m, pipe, bg, **deltas)
+            mask = (m.dygs == False) if with_mask else None   # noqa: E712  (the tracking call, slam_frontend.py:412-414)
+            assert gr._fused_prologue_ok(m, pipe, mask, False) == fused
+            res = gr.render(view, m, pipe, bg, mask=mask, **deltas)
         finally:
             gr.FUSED_PROLOGUE = True
         loss = (res["render"] * torch.tensor(gc, device="cuda")).sum() + (res["depth"] * torch.tensor(gd, device="cuda")).sum()
@@ -91,4 +93,7 @@ def test_fused_prologue_matches_the_torch_prologue(isotropic, deg, with_deltas):
             assert g1[k] is None or g1[k].numel() == 0 or float(g1[k].abs().sum()) == 0.0, k
             continue
         assert g1[k] is not None and g1[k].shape == g0[k].shape, k
+        if float(g0[k].abs().max()) < 1e-9:          # analytically zero (rotation of an isotropic Gaussian): rounding noise on both sides
+            assert float(g1[k].abs().max()) < 1e-9, k
+            continue
         assert rel_l1(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-4, (k, rel_l1(g1[k].cpu().numpy(), g0[k].cpu().numpy()))
