@@ -659,9 +659,11 @@ int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
 size_t gsr_l1_loss_workspace_size(void) { return (size_t)LOSS_BLOCKS * 2 * sizeof(float); }
 
 static LossArgs make_loss_args(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
-                               const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha)
+                               const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
+                               const float* opacity, float opacity_thr)
 {
     LossArgs a;
+    a.opacity = opacity; a.opacity_thr = opacity_thr;
     a.N = width * height; a.image = image; a.depth = depth; a.gt_image = gt_image; a.gt_depth = gt_depth; a.w_rgb = w_rgb; a.w_depth = w_depth;
     a.exposure_a = exposure_a; a.exposure_b = exposure_b;
     a.c_rgb = alpha / (3.0f * (float)a.N); a.c_depth = (1.0f - alpha) / (float)a.N;
@@ -670,13 +672,14 @@ static LossArgs make_loss_args(int width, int height, const float* image, const 
 
 int gsr_l1_loss_forward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
                         const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
-                        float* loss, char* workspace, void* stream_)
+                        const float* opacity, float opacity_depth_threshold, float* loss, char* workspace, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (width <= 0 || height <= 0 || !image || !depth || !gt_image || !gt_depth || !loss || !workspace) {
         g_last_error = "gsr_l1_loss_forward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    const LossArgs a = make_loss_args(width, height, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha);
+    const LossArgs a = make_loss_args(width, height, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity,
+                                      opacity_depth_threshold);
     float* partials = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(l1_loss_fwd_kernel, dim3(LOSS_BLOCKS), dim3(LOSS_THREADS), 0, stream, a, partials);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partials, 1, loss);
@@ -686,13 +689,14 @@ int gsr_l1_loss_forward(int width, int height, const float* image, const float* 
 
 int gsr_l1_loss_backward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
                          const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
-                         const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream_)
+                         const float* opacity, float opacity_depth_threshold, const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (width <= 0 || height <= 0 || !image || !depth || !gt_image || !gt_depth || !dL_dimage || !dL_ddepth || !workspace) {
         g_last_error = "gsr_l1_loss_backward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    const LossArgs a = make_loss_args(width, height, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha);
+    const LossArgs a = make_loss_args(width, height, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity,
+                                      opacity_depth_threshold);
     float* partials = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(LOSS_BLOCKS), dim3(LOSS_THREADS), 0, stream, a, upstream, dL_dimage, dL_ddepth, partials);
     if (dL_dexposure) hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partials, 2, dL_dexposure);

@@ -1,7 +1,7 @@
 // gs_loss.h -- fused photometric + depth L1 loss of the SLAM mapping / tracking steps:
 //   L = alpha * mean_{3,H,W}( w_rgb * |exp(a) * I + b - I_gt| ) + (1 - alpha) * mean_{H,W}( w_d * |D - D_gt| )
-// which is what utils/slam_utils.py:252-364 (get_loss_mapping*) evaluates with ~20 elementwise / reduction torch kernels per
-// view plus their autograd replay: every pixel mask there (rgb boundary threshold, valid depth, motion masks, the x2 weighting
+// which is what utils/slam_utils.py:252-364 (get_loss_mapping*) and, with w_rgb *= rendered opacity and w_d *= (opacity > 0.95),
+// :57-173 (get_loss_tracking*) evaluate with ~20 elementwise / reduction torch kernels per view plus their autograd replay: every pixel mask there (rgb boundary threshold, valid depth, motion masks, the x2 weighting
 // of dynamic regions) is a constant of the keyframe and folds into the two weight images w_rgb, w_d in {0, 1, 2}.
 // One pass computes the loss, one pass (in backward, scaled by the upstream gradient read from device memory) writes
 // dL/dI, dL/dD -- exactly the cotangents the rasterizer's backward consumes -- and the exposure gradients.
@@ -19,6 +19,7 @@ struct LossArgs {
     const float* gt_image; const float* gt_depth;
     const float* w_rgb; const float* w_depth;   // [N] each or nullptr (= 1)
     const float* exposure_a; const float* exposure_b;   // device scalars or nullptr (a = 0, b = 0)
+    const float* opacity; float opacity_thr;            // rendered opacity [N] or nullptr: w_rgb *= opacity, w_depth *= (opacity > thr)
     float c_rgb, c_depth;                    // alpha / (3N), (1 - alpha) / N
 };
 
@@ -42,7 +43,8 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_fwd_kernel(LossArgs a, f
     const float ea = a.exposure_a ? expf(a.exposure_a[0]) : 1.f, eb = a.exposure_b ? a.exposure_b[0] : 0.f;
     float acc = 0.f;
     for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
-        const float wr = a.w_rgb ? a.w_rgb[p] : 1.f, wd = a.w_depth ? a.w_depth[p] : 1.f;
+        float wr = a.w_rgb ? a.w_rgb[p] : 1.f, wd = a.w_depth ? a.w_depth[p] : 1.f;
+        if (a.opacity) { const float op = a.opacity[p]; wr *= op; wd = op > a.opacity_thr ? wd : 0.f; }
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) s += fabsf(ea * a.image[(size_t)c * a.N + p] + eb - a.gt_image[(size_t)c * a.N + p]);
@@ -70,7 +72,9 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, c
     const float ea = a.exposure_a ? expf(a.exposure_a[0]) : 1.f, eb = a.exposure_b ? a.exposure_b[0] : 0.f;
     float da = 0.f, db = 0.f;
     for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
-        const float wr = (a.w_rgb ? a.w_rgb[p] : 1.f) * a.c_rgb * g, wd = (a.w_depth ? a.w_depth[p] : 1.f) * a.c_depth * g;
+        float wr = (a.w_rgb ? a.w_rgb[p] : 1.f) * a.c_rgb * g, wd = (a.w_depth ? a.w_depth[p] : 1.f) * a.c_depth * g;
+        if (a.opacity) { const float op = a.opacity[p]; wr *= op; wd = op > a.opacity_thr ? wd : 0.f; }   // opacity is a weight: the rasterizer
+                                                                                                    // drops its cotangent anyway
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float I = a.image[(size_t)c * a.N + p];

@@ -291,7 +291,8 @@ const float* optf(const c10::optional<torch::Tensor>& t, std::vector<torch::Tens
 std::tuple<torch::Tensor, torch::Tensor> l1_loss_forward(const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image,
                                                          const torch::Tensor& gt_depth, const c10::optional<torch::Tensor>& w_rgb,
                                                          const c10::optional<torch::Tensor>& w_depth, const c10::optional<torch::Tensor>& exposure_a,
-                                                         const c10::optional<torch::Tensor>& exposure_b, double alpha, int64_t stream)
+                                                         const c10::optional<torch::Tensor>& exposure_b, double alpha,
+                                                         const c10::optional<torch::Tensor>& opacity, double opacity_thr, int64_t stream)
 {
     TORCH_CHECK(image.is_cuda(), "image is on '", image.device().str(),
                 "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
@@ -302,7 +303,7 @@ std::tuple<torch::Tensor, torch::Tensor> l1_loss_forward(const torch::Tensor& im
     const int rc = gsr_l1_loss_forward(W, H, optf(image, keep, "image"), optf(depth, keep, "depth"), optf(gt_image, keep, "gt_image"),
                                        optf(gt_depth, keep, "gt_depth"), optf(w_rgb, keep, "w_rgb"), optf(w_depth, keep, "w_depth"),
                                        optf(exposure_a, keep, "exposure_a"), optf(exposure_b, keep, "exposure_b"), (float)alpha,
-                                       loss.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+                                       optf(opacity, keep, "opacity"), (float)opacity_thr, loss.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
     if (rc < 0) fail("gsr_l1_loss_forward", rc);
     return std::make_tuple(loss, ws);
 }
@@ -311,7 +312,8 @@ std::tuple<torch::Tensor, torch::Tensor> l1_loss_forward(const torch::Tensor& im
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
     const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image, const torch::Tensor& gt_depth,
     const c10::optional<torch::Tensor>& w_rgb, const c10::optional<torch::Tensor>& w_depth, const c10::optional<torch::Tensor>& exposure_a,
-    const c10::optional<torch::Tensor>& exposure_b, double alpha, const torch::Tensor& upstream, const torch::Tensor& ws, int64_t stream)
+    const c10::optional<torch::Tensor>& exposure_b, double alpha, const c10::optional<torch::Tensor>& opacity, double opacity_thr,
+    const torch::Tensor& upstream, const torch::Tensor& ws, int64_t stream)
 {
     const int H = (int)image.size(-2), W = (int)image.size(-1);
     std::vector<torch::Tensor> keep;
@@ -322,7 +324,7 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
     const int rc = gsr_l1_loss_backward(W, H, optf(image, keep, "image"), optf(depth, keep, "depth"), optf(gt_image, keep, "gt_image"),
                                         optf(gt_depth, keep, "gt_depth"), optf(w_rgb, keep, "w_rgb"), optf(w_depth, keep, "w_depth"),
                                         optf(exposure_a, keep, "exposure_a"), optf(exposure_b, keep, "exposure_b"), (float)alpha,
-                                        optf(upstream, keep, "upstream"), g_image.data_ptr<float>(), g_depth.data_ptr<float>(),
+                                        optf(opacity, keep, "opacity"), (float)opacity_thr, optf(upstream, keep, "upstream"), g_image.data_ptr<float>(), g_depth.data_ptr<float>(),
                                         has_exp ? g_exp.data_ptr<float>() : nullptr, reinterpret_cast<char*>(ws.data_ptr()),
                                         reinterpret_cast<void*>(stream));
     if (rc < 0) fail("gsr_l1_loss_backward", rc);

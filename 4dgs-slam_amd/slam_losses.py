@@ -20,9 +20,9 @@ def _lib():
         vp, f, i = C.c_void_p, C.c_float, C.c_int
         lib.gsr_l1_loss_workspace_size.restype = C.c_size_t
         lib.gsr_l1_loss_forward.restype = i
-        lib.gsr_l1_loss_forward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, vp, vp]
+        lib.gsr_l1_loss_forward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp]
         lib.gsr_l1_loss_backward.restype = i
-        lib.gsr_l1_loss_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
+        lib.gsr_l1_loss_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp, vp, vp, vp]
         _declared = True
     return lib
 
@@ -40,15 +40,17 @@ def _p(t, keep):
 
 class _WeightedL1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha):
+    def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity=None, opacity_thr=0.95):
         _C._require_device(image, "image")
+        ctx.alpha, ctx.opacity_thr = float(alpha), float(opacity_thr)
+        opacity = None if opacity is None else opacity.detach()
         if _C._glue is not None:     # native host glue (csrc/torch_glue.cpp)
             with torch.cuda.device(image.device):
                 loss, ws = _C._glue.l1_loss_forward(image.detach(), depth.detach(), gt_image, gt_depth, w_rgb, w_depth,
                                                     None if exposure_a is None else exposure_a.detach(),
-                                                    None if exposure_b is None else exposure_b.detach(), float(alpha), _C._stream(image.device))
-            ctx.alpha = float(alpha)
-            ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws)
+                                                    None if exposure_b is None else exposure_b.detach(), float(alpha), opacity,
+                                                    float(opacity_thr), _C._stream(image.device))
+            ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity)
             return loss
         lib = _lib()
         H, W = int(image.shape[-2]), int(image.shape[-1])
@@ -58,25 +60,24 @@ class _WeightedL1(torch.autograd.Function):
         keep = []
         with torch.cuda.device(dev):
             rc = lib.gsr_l1_loss_forward(W, H, _p(image, keep), _p(depth, keep), _p(gt_image, keep), _p(gt_depth, keep), _p(w_rgb, keep),
-                                         _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), float(alpha), loss.data_ptr(),
-                                         ws.data_ptr(), _C._stream(dev))
+                                         _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), float(alpha), _p(opacity, keep),
+                                         float(opacity_thr), loss.data_ptr(), ws.data_ptr(), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_l1_loss_forward")
-        ctx.alpha = float(alpha)
-        ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws)
+        ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws = ctx.saved_tensors
+        image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity = ctx.saved_tensors
         if _C._glue is not None:
             with torch.cuda.device(image.device):
                 g_image, g_depth, g_exp = _C._glue.l1_loss_backward(
                     image.detach(), depth.detach(), gt_image, gt_depth, w_rgb, w_depth, None if exposure_a is None else exposure_a.detach(),
-                    None if exposure_b is None else exposure_b.detach(), ctx.alpha, g, ws, _C._stream(image.device))
+                    None if exposure_b is None else exposure_b.detach(), ctx.alpha, opacity, ctx.opacity_thr, g, ws, _C._stream(image.device))
             ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
             gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
-            return g_image, g_depth, None, None, None, None, ga, gb, None
+            return g_image, g_depth, None, None, None, None, ga, gb, None, None, None
         lib = _lib()
         H, W = int(image.shape[-2]), int(image.shape[-1])
         dev = image.device
@@ -85,22 +86,26 @@ class _WeightedL1(torch.autograd.Function):
         keep = []
         with torch.cuda.device(dev):
             rc = lib.gsr_l1_loss_backward(W, H, _p(image, keep), _p(depth, keep), _p(gt_image, keep), _p(gt_depth, keep), _p(w_rgb, keep),
-                                          _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), ctx.alpha, _p(g, keep),
+                                          _p(w_depth, keep), _p(exposure_a, keep), _p(exposure_b, keep), ctx.alpha, _p(opacity, keep),
+                                          ctx.opacity_thr, _p(g, keep),
                                           g_image.data_ptr(), g_depth.data_ptr(), g_exp.data_ptr() if g_exp is not None else None,
                                           ws.data_ptr(), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_l1_loss_backward")
         ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
         gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
-        return g_image, g_depth, None, None, None, None, ga, gb, None
+        return g_image, g_depth, None, None, None, None, ga, gb, None, None, None
 
 
-def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None, exposure_a=None, exposure_b=None, alpha=0.95):
+def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None, exposure_a=None, exposure_b=None, alpha=0.95,
+                     opacity=None, opacity_depth_threshold=0.95):
     """alpha * mean(w_rgb |exp(a) image + b - gt_image|) + (1 - alpha) * mean(w_depth |depth - gt_depth|), differentiable in
-    image, depth, exposure_a, exposure_b. image [3,H,W], depth [1,H,W] (or [H,W]), weights [H,W] / [1,H,W] or None."""
+    image, depth, exposure_a, exposure_b. image [3,H,W], depth [1,H,W] (or [H,W]), weights [H,W] / [1,H,W] or None.
+    opacity (the rendered opacity, tracking loss): w_rgb *= opacity, w_depth *= (opacity > opacity_depth_threshold); it is a
+    constant weight here -- the rasterizer's backward discards the opacity cotangent in any case."""
     if (exposure_a is None) != (exposure_b is None):
         raise RuntimeError("weighted_l1_loss: give both exposure parameters or neither")
-    return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha)
+    return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold)
 
 
 def _keyframe_constants(config, viewpoint, device):
@@ -167,3 +172,32 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
         return (l_static, 2 * l_dynamic) if dynamic else (l_static, l_dynamic)
     w_rgb, w_dep = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep))
     return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha)
+
+
+def tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None):
+    """(w_rgb, w_depth) float32 [1,H,W] of get_loss_tracking_rgbd WITHOUT the rendered-opacity factors (slam_utils.py:65-77,118-135):
+    rgb: boundary threshold x grad_mask [x motion mask if rm_dynamic and uid > 0] [x mask]; depth: 0.01 < d < 1000 [x motion] [x mask]."""
+    shape = gt_depth.shape
+    w_rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*shape) * viewpoint.grad_mask.view(*shape)
+    w_dep = (gt_depth > 0.01).view(*shape) & (gt_depth < 1000.0).view(*shape)
+    motion = getattr(viewpoint, "motion_mask", None)
+    if motion is not None and rm_dynamic and viewpoint.uid > 0:
+        w_rgb, w_dep = motion.view(*shape) * w_rgb, motion.view(*shape) * w_dep
+    if mask is not None:
+        w_rgb, w_dep = mask.view(*shape) * w_rgb, mask.view(*shape) * w_dep
+    return w_rgb.to(torch.float32), w_dep.to(torch.float32)
+
+
+def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=False, rm_dynamic=False, mask=None, save_img=False):
+    """utils/slam_utils.py:57-61, same arguments and value (RGB-D: fused; monocular: the reference's tensor expression; save_img
+    is a debugging aid of the reference and is ignored). The exposure is always applied (:58)."""
+    _C._require_device(image, "image")
+    gt_image = viewpoint.original_image.to(image.device)
+    gt_depth = torch.as_tensor(viewpoint.depth, dtype=torch.float32, device=image.device)[None]
+    w_rgb, w_dep = tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask)
+    if config["Training"]["monocular"]:
+        image_ab = torch.exp(viewpoint.exposure_a) * image + viewpoint.exposure_b
+        return (opacity * torch.abs(image_ab * w_rgb - gt_image * w_rgb)).mean()                   # get_loss_tracking_rgb, :64-105
+    alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
+    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, viewpoint.exposure_a, viewpoint.exposure_b, alpha,
+                            opacity=opacity, opacity_depth_threshold=0.95)

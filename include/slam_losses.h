@@ -22,15 +22,18 @@ extern "C" {
 size_t gsr_l1_loss_workspace_size(void);
 
 /* loss[0] = L. w_rgb / w_depth [H*W] may be NULL (= 1); exposure_a / exposure_b (1 float each) may be NULL (a = b = 0,
- * the `initialization` branch, slam_utils.py:253-254). Returns 0 or a negative GSR_ERR_* code (gs_rasterizer.h). */
+ * the `initialization` branch, slam_utils.py:253-254). opacity [H*W] (may be NULL) is the RENDERED opacity of the tracking loss
+ * (slam_utils.py:104,125-137): w_rgb is multiplied by it and w_depth is kept only where it exceeds opacity_depth_threshold; it is
+ * treated as a constant weight (the rasterizer's backward ignores the opacity cotangent, DGR/diff_gaussian_rasterization/__init__.py:108).
+ * Returns 0 or a negative GSR_ERR_* code (gs_rasterizer.h). */
 int gsr_l1_loss_forward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
                         const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
-                        float* loss, char* workspace, void* stream);
+                        const float* opacity, float opacity_depth_threshold, float* loss, char* workspace, void* stream);
 
 /* upstream: device pointer to dLoss_total/dL (NULL = 1). dL_dexposure[2] = (dL/da, dL/db), may be NULL. */
 int gsr_l1_loss_backward(int width, int height, const float* image, const float* depth, const float* gt_image, const float* gt_depth,
                          const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
-                         const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
+                         const float* opacity, float opacity_depth_threshold, const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
 
 /* ---- fused Adam step: all parameter tensors of the Gaussian model in one launch -----------------
  * Replaces optimizer.step() of scene/gaussian_model.py:447 (torch.optim.Adam(lr=0.0, eps=1e-15) over the six groups of :404-434)

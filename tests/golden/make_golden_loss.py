@@ -53,5 +53,30 @@ for name, kw in cases.items():
     out[f"{name}/flags"] = np.array([kw.get("initialization", False), kw.get("rm_dynamic", False), kw.get("dynamic", False), use_mask,
                                      "alpha" in kw])
     out[f"{name}/alpha"] = kw.get("alpha", -1.0)
+# ---- tracking loss (utils/slam_utils.py:57-173); it creates config["Results"]["save_dir"]/tracking as a side effect
+import tempfile                                            # noqa: E402
+tcfg = {"Training": dict(config["Training"]), "Results": {"save_dir": tempfile.mkdtemp()}}
+grad_mask = rng.uniform(size=(1, H, W)) > 0.4
+out["grad_mask"] = grad_mask
+tcases = {"track_plain": dict(), "track_rm_dynamic": dict(rm_dynamic=True), "track_mask": dict(use_mask=True),
+          "track_rm_dynamic_mask": dict(rm_dynamic=True, use_mask=True)}
+out["tracking_cases"] = np.array(list(tcases))
+for name, kw in tcases.items():
+    kw = dict(kw)
+    image = torch.tensor(rng.uniform(0, 1, size=(3, H, W)).astype(np.float32), requires_grad=True)
+    depth = torch.tensor(rng.uniform(0.2, 5.0, size=(1, H, W)).astype(np.float32), requires_grad=True)
+    opacity = torch.tensor(rng.uniform(0.6, 1.0, size=(1, H, W)).astype(np.float32))
+    a = torch.nn.Parameter(torch.tensor([0.07]))
+    b = torch.nn.Parameter(torch.tensor([-0.03]))
+    vp = types.SimpleNamespace(original_image=torch.tensor(gt_image), depth=gt_depth, exposure_a=a, exposure_b=b,
+                               motion_mask=torch.tensor(motion), grad_mask=torch.tensor(grad_mask), uid=3)
+    use_mask = kw.pop("use_mask", False)
+    loss = ref.get_loss_tracking(tcfg, image, depth, opacity, vp, mask=torch.tensor(mask) if use_mask else None, **kw)
+    loss.backward()
+    out[f"{name}/image"], out[f"{name}/depth"], out[f"{name}/opacity"] = image.detach().numpy(), depth.detach().numpy(), opacity.numpy()
+    out[f"{name}/loss"] = loss.item()
+    out[f"{name}/g_image"], out[f"{name}/g_depth"] = image.grad.numpy(), depth.grad.numpy()
+    out[f"{name}/g_a"], out[f"{name}/g_b"] = a.grad.numpy(), b.grad.numpy()
+    out[f"{name}/flags"] = np.array([kw.get("rm_dynamic", False), use_mask])
 np.savez_compressed(os.path.join(HERE, "golden_loss.npz"), **out)
 print("wrote golden_loss.npz", {k: out[f"{k}/loss"] for k in cases})

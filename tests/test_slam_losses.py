@@ -91,3 +91,42 @@ def test_fused_loss_scales_with_the_upstream_gradient_and_is_reproducible():
         grads.append((image.grad.clone(), depth.grad.clone(), vp.exposure_a.grad.clone()))
     assert all(torch.equal(x, y) for x, y in zip(grads[0], grads[1]))                 # bit-reproducible
     assert all(torch.allclose(3.0 * x, y, rtol=1e-6, atol=0) for x, y in zip(grads[0], grads[2]))
+
+
+TCASES = [str(c) for c in FX["tracking_cases"]]
+
+
+def _tracking_viewpoint(dev):
+    vp = _viewpoint(dev)
+    vp.grad_mask = torch.tensor(FX["grad_mask"], device=dev)
+    return vp
+
+
+@pytest.mark.parametrize("name", TCASES)
+def test_tracking_weights_and_expression_reproduce_the_reference_on_cpu(name):
+    from slam_losses import tracking_loss_weights
+    from oracle.loss_oracle import weighted_l1_loss_reference
+
+    vp = _tracking_viewpoint("cpu")
+    rm_dyn, use_mask = [bool(v) for v in FX[f"{name}/flags"]]
+    image = torch.tensor(FX[f"{name}/image"], requires_grad=True)
+    depth = torch.tensor(FX[f"{name}/depth"], requires_grad=True)
+    gt_depth = torch.tensor(FX["gt_depth"])[None]
+    w_rgb, w_dep = tracking_loss_weights(CONFIG, vp, vp.original_image, gt_depth, rm_dyn, torch.tensor(FX["mask"]) if use_mask else None)
+    loss = weighted_l1_loss_reference(image, depth, vp.original_image, gt_depth, w_rgb, w_dep, vp.exposure_a, vp.exposure_b,
+                                      CONFIG["Training"]["alpha"], opacity=torch.tensor(FX[f"{name}/opacity"]))
+    _check(name, loss, image, depth, vp, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TCASES)
+def test_fused_tracking_loss_matches_the_reference(name):
+    from slam_losses import get_loss_tracking
+
+    vp = _tracking_viewpoint("cuda")
+    rm_dyn, use_mask = [bool(v) for v in FX[f"{name}/flags"]]
+    image = torch.tensor(FX[f"{name}/image"], device="cuda", requires_grad=True)
+    depth = torch.tensor(FX[f"{name}/depth"], device="cuda", requires_grad=True)
+    opacity = torch.tensor(FX[f"{name}/opacity"], device="cuda")
+    loss = get_loss_tracking(CONFIG, image, depth, opacity, vp, rm_dynamic=rm_dyn, mask=torch.tensor(FX["mask"], device="cuda") if use_mask else None)
+    _check(name, loss, image, depth, vp, 2e-5)
