@@ -118,7 +118,10 @@ def _keyframe_constants(config, viewpoint, device):
         gt_depth = torch.as_tensor(viewpoint.depth, dtype=torch.float32, device=device)[None]
         rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*gt_depth.shape).to(torch.float32)
         dep = ((gt_depth > 0.01) & (gt_depth < 10000.0)).to(torch.float32)
-        cache = (key, gt_image, gt_depth, rgb, dep)
+        grad_mask = getattr(viewpoint, "grad_mask", None)                  # tracking only (slam_utils.py:70,118-119)
+        t_rgb = rgb * grad_mask.view(*gt_depth.shape) if grad_mask is not None else None
+        t_dep = ((gt_depth > 0.01) & (gt_depth < 1000.0)).to(torch.float32)
+        cache = (key, gt_image, gt_depth, rgb, dep, t_rgb, t_dep)
         try:
             viewpoint._gsr_loss_cache = cache
         except Exception:  # pragma: no cover  (immutable stand-in)
@@ -154,7 +157,7 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
     """utils/slam_utils.py:252-259, same arguments and value. RGB-D, non-split calls (every call of utils/slam_backend.py with
     the shipped configs) run fused; `monocular` and `split=True` are evaluated with the reference's tensor expression."""
     _C._require_device(image, "image")
-    gt_image, gt_depth, base_rgb, base_dep = _keyframe_constants(config, viewpoint, image.device)
+    gt_image, gt_depth, base_rgb, base_dep, _, _ = _keyframe_constants(config, viewpoint, image.device)
     exposure = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
     if config["Training"]["monocular"]:
         image_ab = image if initialization else torch.exp(exposure[0]) * image + exposure[1]
@@ -174,12 +177,16 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
     return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha)
 
 
-def tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None):
+def tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, base=None):
     """(w_rgb, w_depth) float32 [1,H,W] of get_loss_tracking_rgbd WITHOUT the rendered-opacity factors (slam_utils.py:65-77,118-135):
-    rgb: boundary threshold x grad_mask [x motion mask if rm_dynamic and uid > 0] [x mask]; depth: 0.01 < d < 1000 [x motion] [x mask]."""
+    rgb: boundary threshold x grad_mask [x motion mask if rm_dynamic and uid > 0] [x mask]; depth: 0.01 < d < 1000 [x motion] [x mask].
+    `base` = the two ground-truth-only products, precomputed."""
     shape = gt_depth.shape
-    w_rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*shape) * viewpoint.grad_mask.view(*shape)
-    w_dep = (gt_depth > 0.01).view(*shape) & (gt_depth < 1000.0).view(*shape)
+    if base is None:
+        w_rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*shape) * viewpoint.grad_mask.view(*shape)
+        w_dep = (gt_depth > 0.01).view(*shape) & (gt_depth < 1000.0).view(*shape)
+    else:
+        w_rgb, w_dep = base
     motion = getattr(viewpoint, "motion_mask", None)
     if motion is not None and rm_dynamic and viewpoint.uid > 0:
         w_rgb, w_dep = motion.view(*shape) * w_rgb, motion.view(*shape) * w_dep
@@ -192,9 +199,8 @@ def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=F
     """utils/slam_utils.py:57-61, same arguments and value (RGB-D: fused; monocular: the reference's tensor expression; save_img
     is a debugging aid of the reference and is ignored). The exposure is always applied (:58)."""
     _C._require_device(image, "image")
-    gt_image = viewpoint.original_image.to(image.device)
-    gt_depth = torch.as_tensor(viewpoint.depth, dtype=torch.float32, device=image.device)[None]
-    w_rgb, w_dep = tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask)
+    gt_image, gt_depth, _, _, t_rgb, t_dep = _keyframe_constants(config, viewpoint, image.device)
+    w_rgb, w_dep = tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, base=(t_rgb, t_dep))
     if config["Training"]["monocular"]:
         image_ab = torch.exp(viewpoint.exposure_a) * image + viewpoint.exposure_b
         return (opacity * torch.abs(image_ab * w_rgb - gt_image * w_rgb)).mean()                   # get_loss_tracking_rgb, :64-105

@@ -19,7 +19,7 @@ for p in (REPO, os.path.join(REPO, "4dgs-slam_amd"), os.path.join(REPO, "tests")
 import gaussian_renderer as gr                                   # noqa: E402
 from synthetic_scene import make_camera, make_gaussians, make_cotangents   # noqa: E402
 from test_hip_fused_prologue import _GaussianModel, _camera      # noqa: E402  (the reference-shaped model stand-in)
-from slam_losses import get_loss_mapping, mapping_loss_weights   # noqa: E402
+from slam_losses import get_loss_mapping, get_loss_tracking, mapping_loss_weights, tracking_loss_weights   # noqa: E402
 
 P, W, H = 200_000, 640, 480
 cam = make_camera(W, H)
@@ -77,7 +77,45 @@ for fused, with_loss in ((False, False), (True, False), (False, True), (True, Tr
     dt = (time.perf_counter() - t0) / n
     key = ("fused" if fused else "torch") + ("_prologue_and_loss" if with_loss else "_prologue")
     out[key] = {"ms_per_iteration": dt * 1e3, "gaussians_per_s": P / dt}
+
+# ---- tracking iteration (utils/slam_frontend.py:405-440): render the static Gaussians (boolean mask), tracking loss, backward
+def torch_tracking_loss(image, depth, opacity, vp):
+    gt_depth = torch.from_numpy(vp.depth).to(dtype=torch.float32, device=image.device)[None]
+    w_rgb, w_dep = tracking_loss_weights(config, vp, vp.original_image, gt_depth)
+    image_ab = torch.exp(vp.exposure_a) * image + vp.exposure_b
+    w_dep = w_dep * (opacity > 0.95)
+    return 0.9 * (opacity * torch.abs(image_ab * w_rgb - vp.original_image * w_rgb)).mean() + 0.1 * torch.abs(depth * w_dep - gt_depth * w_dep).mean()
+
+
+for fused in (False, True):
+    m = _GaussianModel(g, False, 0.25, seed=2)
+    view = _camera(cam)
+    view.original_image, view.depth, view.motion_mask, view.uid = gt_image, gt_depth_np, None, 3
+    view.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device="cuda")
+    view.exposure_a = torch.nn.Parameter(torch.tensor([0.01], device="cuda"))
+    view.exposure_b = torch.nn.Parameter(torch.tensor([0.0], device="cuda"))
+    leaves = list(m.leaves.values()) + [view.cam_rot_delta, view.cam_trans_delta, view.exposure_a, view.exposure_b]
+    static = m.dygs == False   # noqa: E712
+    gr.FUSED_PROLOGUE = fused
+
+    def track_step():
+        for t in leaves:
+            t.grad = None
+        res = gr.render(view, m, pipe, bg, mask=static)
+        loss = (get_loss_tracking if fused else lambda c, i, d, o, v: torch_tracking_loss(i, d, o, v))(config, res["render"], res["depth"], res["opacity"], view)
+        loss.backward()
+
+    for _ in range(10):
+        track_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        track_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 50
+    out[("fused" if fused else "torch") + "_tracking_iteration"] = {"ms_per_iteration": dt * 1e3}
 gr.FUSED_PROLOGUE = True
+out["speedup_tracking_iteration"] = out["torch_tracking_iteration"]["ms_per_iteration"] / out["fused_tracking_iteration"]["ms_per_iteration"]
 out["speedup_render"] = out["torch_prologue"]["ms_per_iteration"] / out["fused_prologue"]["ms_per_iteration"]
 out["speedup_render_and_loss"] = out["torch_prologue_and_loss"]["ms_per_iteration"] / out["fused_prologue_and_loss"]["ms_per_iteration"]
 print(json.dumps(out))
