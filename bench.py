@@ -59,11 +59,18 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (tests/test_hip_configs.py runs the N > 1 code path on a 1-GPU box): GSR_BENCH_DEVICE pins every rank to one
+    # device, GSR_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on the same GPU
+    local_dev = int(os.environ.get("GSR_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("GSR_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     from mapping_shard import GradBucket
@@ -162,7 +169,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{P} static Gaussians, 1 cam @{WIDTH}x{HEIGHT} per GPU, SH degree {args.sh_degree}, fwd+bwd"
                                    + (f", {world} views sharded + RCCL all-reduce of {bucket.nbytes} B grads" if world > 1 else ""),
-                       "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding()},
+                       "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding(),
+                       **({"allreduce": stats.get("allreduce")} if world > 1 else {})},
             "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,

@@ -1,4 +1,6 @@
 """GPU tests at the sizes / shapes of BASELINE.json configs[2] and configs[4] (parity-test cases, not bench lines)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -92,3 +94,25 @@ def test_config5_shape_2m_gaussians_one_shard():
         means3D=params[0].detach(), means2D=torch.zeros_like(params[0]), opacities=params[2].detach(), shs=params[1].detach(),
         scales=params[3].detach(), rotations=params[4].detach())
     assert torch.equal(color2, outs[0])
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks pinned to
+    cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one GPU): exercises rank-dependent keyframes, the in-place
+    all-reduce of the rasterizer's gradient block, the max-over-ranks timing and the single JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSR_BENCH_DEVICE="0", GSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "20000",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "all-reduce" in d["config"]["workload"]
