@@ -2,10 +2,13 @@
 // Mirrors CudaRasterizer::Rasterizer::{forward,backward,markVisible}
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153,198-344,348-455) with an MI355X-first pipeline:
 //
-//   forward : memset(tile_count, header) -> F1 preprocess(+tile histogram, +block sums) -> F2 scans
-//             -> [one 12-byte D2H + stream sync: R, error flag, R_alloc] -> binning alloc
-//             -> F3 scatter -> F4 per-tile LDS bitonic depth sort -> F5 tile compositing
-//   backward: B1 per-tile gradient pass (register/DPP reductions, per-instance slots) -> B2 per-Gaussian gather + geometry
+//   forward : F1 preprocess (+ per-block tile histogram rows, + block sums) -> F1b column scan -> F2 single-pass scans (+ host mailbox)
+//             -> F3 scatter -> [F4 sort of lists > 1024] -> F5 tile kernel (sorts its own list, composites, checkpoints),
+//             all enqueued speculatively on a binning buffer sized from the previous frame; the host then reads R from the
+//             mailbox and only redoes F3..F5 if the scan kernel flagged the capacity as too small
+//   backward: B1 gradient pass, one block per 128-entry chunk of a tile list (swap/DPP reductions, per-instance slots)
+//             -> B2 per-Gaussian gather + geometry -> pose-gradient sum
+//   extras  : raw-parameter entry points (fused prologue), fused L1 losses, fused Adam, exact 3-NN (simple_knn)
 //
 // No global 64-bit radix sort, no float atomics, no cooperative-groups block trees.
 #include <hip/hip_runtime.h>
@@ -22,7 +25,6 @@
 #include "gs_knn.h"
 #include "gs_loss.h"
 #include "../../include/slam_losses.h"
-#include "gs_loss.h"
 
 namespace gsr {
 

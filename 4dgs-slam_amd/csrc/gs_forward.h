@@ -6,22 +6,22 @@
 namespace gsr {
 
 // Gaussians are processed in blocks of GB = 1024 threads. When the tile grid fits in LDS (T <= HIST_LDS_TILES) each block
-// bins its instances into a private LDS histogram and then reserves, with ONE returning global atomic per non-empty
-// (block, tile) pair, a contiguous sub-range inside every tile's segment; the scatter pass re-derives the same instances
-// and ranks them with LDS atomics only. Compared with one global atomic per instance in both passes (the fallback for
-// huge tile grids) this removes ~80 % of the global atomics and all of their serialised round trips.
+// bins its instances into a private LDS histogram and publishes it as one row of a [blocks][tiles] matrix; a column scan
+// (tile_offsets_kernel) turns the rows into each block's contiguous sub-range inside every tile's segment; the scatter pass
+// re-derives the same instances and ranks them with LDS atomics only. No global atomics at all on this path; the fallback
+// for huge tile grids uses one global atomic per instance in both passes.
 constexpr int GB = 1024;
 constexpr int HIST_LDS_TILES = 12288;   // 48 KiB of dynamic LDS
 
-// Per-tile counters live one per 128-byte L2 line: ~500 atomics hit each counter, and atomics to one line serialise in
-// the L2 atomic unit -- packed (32 counters per line) the histogram cost 85 us at 200k Gaussians, padded it is noise.
+// Per-tile counters live one per 128-byte L2 line: on the atomic fallback path ~500 atomics hit each counter, and atomics to
+// one line serialise in the L2 atomic unit -- packed (32 counters per line) the histogram cost 85 us at 200k Gaussians.
 constexpr int CTR_STRIDE = 32;
 
 // ------------------------------------------------------------------------------------------------------------------
 // F1: per-Gaussian preprocess (DGR/cuda_rasterizer/forward.cu:157-258) fused with
 //     (a) the per-tile instance histogram (replaces the global 64-bit radix sort's first pass) and
 //     (b) the per-block partial sum of tiles_touched (first level of the scan, rasterizer_impl.cu:280).
-// One thread per Gaussian, 256 threads per block.
+// One thread per Gaussian, GB threads per block.
 // ------------------------------------------------------------------------------------------------------------------
 struct PreprocessArgs {
     int P, D, M, W, H, gx, gy;

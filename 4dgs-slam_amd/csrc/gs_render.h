@@ -1,14 +1,15 @@
 // gs_render.h -- the two per-tile kernels: front-to-back compositing (forward) and the back-to-front gradient pass.
 // gfx950 / wave64. DGR = submodules/diff-gaussian-rasterization.
 //
-// Work decomposition (both kernels): one 256-thread block per 16x16 tile (the reference's binning granularity, which
-// is part of the result), four wavefronts, wave w owning the 8x8-pixel quadrant (w&1, w>>1), one pixel per lane.
-// The tile's depth-sorted list is staged through LDS in batches of 256 entries (gathered by Gaussian id). While
-// staging, each thread tests its entry against the four quadrants -- the region where alpha = o*exp(power) can reach
-// 1/255 is an ellipse whose bounding box is known in closed form -- and four 64-bit wave ballots per staging wave
-// give every quadrant a bit mask of the entries that can touch it at all. Each wave then walks ONLY the set bits of
-// its masks (scalar s_ff1 loop), so a (wave, Gaussian) pair that cannot contribute costs nothing: no exp, no
-// reduction. The cull is conservative (a superset of the pairs the reference blends), so results are unchanged.
+// Work decomposition (both kernels): 256-thread blocks on a 16x16 tile (the reference's binning granularity, which is part
+// of the result), four wavefronts, wave w owning the 8x8-pixel quadrant (w&1, w>>1), one pixel per lane. The forward kernel
+// runs one block per tile (and sorts the tile's list first), the backward kernel one block per 128-entry chunk of a tile list.
+// List entries are staged through LDS (gathered by Gaussian id). While staging, each thread tests its entry against the four
+// quadrants -- the region where alpha = o*exp(power) can reach 1/255 is an ellipse, and the minimum of its quadratic form over
+// a quadrant's pixel rectangle has a closed form -- and four 64-bit wave ballots per staging wave give every quadrant a bit
+// mask of the entries that can touch it at all. Each wave then walks ONLY the set bits of its masks (scalar s_ff1 loop), so a
+// (wave, Gaussian) pair that cannot contribute costs nothing: no exp, no reduction. The cull is conservative (a superset of
+// the pairs the reference blends; verified bit-identical against a build without it), so results are unchanged.
 #pragma once
 #include <type_traits>
 #include "gs_forward.h"
