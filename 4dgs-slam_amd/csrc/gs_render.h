@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[3 * RB * sizeof(float4)];
     float4* const s_a = reinterpret_cast<float4*>(s_raw);   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
-    float4* const s_b = s_a + RB;                            // {C, opacity, -, gaussian id bits}
+    float4* const s_b = s_a + RB;                            // {C, log2 opacity, -, gaussian id bits}
     float4* const s_c = s_b + RB;                            // {r, g, b, depth}: two packed FMAs per blended entry
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
     __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             const float4 co = conic_opacity[e.x];
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
             s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
-            s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, 0.f, __uint_as_float(e.x));
+            s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), 0.f, __uint_as_float(e.x));   // log2(opacity): folded into the exponent
             s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
         }
 #pragma unroll
@@ -168,9 +168,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                 const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
                 const float4 C4 = s_c[j];
                 const f2 d = f2{A4.x, A4.y} - pxy;
-                const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;           // forward.cu:345 (times log2 e)
-                const float alpha = fminf(0.99f, B2.y * __builtin_amdgcn_exp2f(power2));           // :353
-                const bool valid = power2 <= 0.0f && alpha >= thr;                                  // :346,:354 and "not done"
+                // alpha = o exp(power) = exp2(power log2e + log2 o): the opacity rides in the exponent (one multiply less per pair)
+                const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);      // forward.cu:345 (times log2 e) + log2 o
+                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(pw));                      // :353
+                const bool valid = pw <= B2.y && alpha >= thr;                                      // :346 (power <= 0), :354 and "not done"
                 const float test_T = T * (1.0f - alpha);
                 const bool stop = valid && test_T < 0.0001f;                                        // :358-362
                 const bool blend = valid && !stop;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
-    __shared__ float4 s_b[BB];   // {C, opacity, instance id bits, quadrant mask bits}               (C = -c/2 log2e)
+    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, opacity}                      (C = -c/2 log2e)
     __shared__ float4 s_c[BB];   // {r, g, b, depth}
     __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, -}: only the per-entry epilogue needs the unscaled conic
     __shared__ float s_part[4][BB][10];
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
 #pragma unroll
         for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
         s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
-        s_b[t] = make_float4(-0.5f * LOG2E * co.z, co.w, __uint_as_float(e.y), __uint_as_float(qm));
+        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), co.w);   // log2(opacity) for the loop, opacity for the epilogue
         s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
         s_d[t] = make_float4(co.x, co.y, co.z, 0.f);
     }
@@ -361,10 +362,12 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
             const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
             const f2 d = f2{A4.x, A4.y} - pxy;
-            const float power2 = d.x * (A4.z * d.x + A4.w * d.y) + B2.x * d.y * d.y;             // :684 (times log2 e)
-            const float G = __builtin_amdgcn_exp2f(power2);
-            const float alpha = fminf(0.99f, B2.y * G);                                           // :688 (clamp has no gradient mask, Q23)
-            const bool valid = j >= j_thr && power2 <= 0.0f && alpha >= 1.0f / 255.0f;          // :678,:685,:689
+            // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
+            // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
+            const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
+            const float G = __builtin_amdgcn_exp2f(pw);
+            const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
+            const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
             if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
             const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
             const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
@@ -378,8 +381,8 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
             //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
             //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
-            const float s_op = Gv * dL_dalpha;
-            const float q = B2.y * s_op;
+            const float q = Gv * dL_dalpha;       // = o G dL_dalpha
+            const float s_op = q;
             const f2 q1 = d * q;                  // (q dx, q dy)
             const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
             const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     // slot (12 floats, 48 B) coalesced.  s_part[q][j][] = {sum G dL_dalpha, M1x, M1y, M2xx, M2xy, M2yy, r, g, b, depth}
     if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
         const int j = t;
-        const float4 B4 = s_b[j];                       // {C, opacity, instance id, quadrant mask}
+        const float4 B4 = s_b[j];                       // {C, log2 opacity, instance id, opacity}
         float sum[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) sum[k] = 0.f;
@@ -411,7 +414,8 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         slot[0] = make_float4(-(K4.x * sum[1] + K4.y * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
                               -(K4.z * sum[2] + K4.y * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
                               -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
-        slot[1] = make_float4(-0.5f * sum[5], sum[0], sum[6], sum[7]);            // dL_dconic.w (:756), dL_dopacity (:757), colour r, g (:719)
+        const float dL_dopacity = B4.w > 0.f ? sum[0] / B4.w : 0.f;               // sum q / o = sum G dL_dalpha (:757); o = 0 blends nowhere
+        slot[1] = make_float4(-0.5f * sum[5], dL_dopacity, sum[6], sum[7]);       // dL_dconic.w (:756), dL_dopacity, colour r, g (:719)
         slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
     }
 }
