@@ -15,7 +15,7 @@ from diff_gaussian_rasterization import _C
 
 def _declared_symbols():
     syms = set()
-    for h in ("gs_rasterizer.h", "simple_knn.h"):
+    for h in ("gs_rasterizer.h", "simple_knn.h", "slam_losses.h"):
         txt = open(os.path.join(REPO, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         syms |= set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", txt))
@@ -26,7 +26,8 @@ def _declared_symbols():
 def test_library_loads_and_exports_all_declared_symbols():
     lib = _C.load_library()
     syms = _declared_symbols()
-    assert {"gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2"} <= syms
+    assert {"gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_knn_mean_dist2", "gsr_forward_raw", "gsr_backward_raw",
+            "gsr_l1_loss_forward", "gsr_l1_loss_backward", "gsr_adam_step"} <= syms
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert b"gfx950" in lib.gsr_version()
@@ -34,6 +35,26 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert lib.gsr_geometry_buffer_size(1000) > 1000 * 70
     assert lib.gsr_image_buffer_size(640, 480, 200000) >= 640 * 480 * 8
     assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 48 + 8)
+
+
+def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
+    """Argument validation is host code: negative GSR_ERR_INVALID_ARGUMENT (-1) and a message, no device needed."""
+    lib = _C.load_library()
+    lib.gsr_last_error.restype = ctypes.c_char_p
+    vp, i, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.gsr_forward_raw.restype = i
+    lib.gsr_forward_raw.argtypes = [vp] * 6 + [i, i, i, vp, i, i, vp, f, vp, vp, vp, f, f, vp, vp, vp, vp, vp, i, vp]
+    assert lib.gsr_forward_raw(None, None, None, None, None, None, 10, 0, 1, None, 64, 64, None, 1.0, None, None, None, 1.0, 1.0,
+                               None, None, None, None, None, 0, None) == -1
+    assert b"gsr_forward" in lib.gsr_last_error()
+    lib.gsr_l1_loss_forward.restype = i
+    lib.gsr_l1_loss_forward.argtypes = [i, i] + [vp] * 8 + [f, vp, f, vp, vp, vp]
+    assert lib.gsr_l1_loss_forward(64, 64, None, None, None, None, None, None, None, None, 0.9, None, 0.95, None, None, None) == -1
+    assert b"gsr_l1_loss_forward" in lib.gsr_last_error()
+    lib.gsr_adam_step.restype = i
+    lib.gsr_adam_step.argtypes = [i, vp, vp]
+    assert lib.gsr_adam_step(9, None, None) == -1 and lib.gsr_adam_step(0, None, None) == 0
+    assert lib.gsr_l1_loss_workspace_size() > 0
 
 
 def test_public_names_and_settings_fields_match_reference():
