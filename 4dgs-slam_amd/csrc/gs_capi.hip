@@ -734,4 +734,58 @@ int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream_)
     return 0;
 }
 
+
+// ---- fused SSIM (include/slam_losses.h) ---------------------------------------------------------------------------
+static SsimWindow ssim_window()
+{
+    SsimWindow w;                                          // loss_utils.py:46-53: exp(-(x - 5)^2 / (2 * 1.5^2)), normalised
+    double sum = 0.0, g[SSIM_WIN];
+    for (int k = 0; k < SSIM_WIN; k++) { g[k] = exp(-(double)((k - SSIM_R) * (k - SSIM_R)) / (2.0 * 1.5 * 1.5)); sum += g[k]; }
+    for (int k = 0; k < SSIM_WIN; k++) w.w[k] = (float)((float)g[k] / (float)sum);
+    return w;
+}
+static inline dim3 ssim_grid(int width, int height, int channels)
+{
+    return dim3((width + SSIM_T - 1) / SSIM_T, (height + SSIM_T - 1) / SSIM_T, channels);
+}
+size_t gsr_ssim_workspace_size(int width, int height, int channels)
+{
+    const dim3 g = ssim_grid(width, height, channels);
+    return (size_t)g.x * g.y * g.z * sizeof(float) + 256 + (size_t)3 * channels * width * height * sizeof(float);
+}
+
+int gsr_ssim_forward(int width, int height, int channels, const float* img1, const float* img2, const unsigned char* mask, float* ssim_mean,
+                     char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (width <= 0 || height <= 0 || channels <= 0 || !img1 || !img2 || !ssim_mean || !workspace) {
+        g_last_error = "gsr_ssim_forward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const dim3 g = ssim_grid(width, height, channels);
+    const int nblocks = (int)(g.x * g.y * g.z);
+    float* partials = reinterpret_cast<float*>(workspace);
+    float* dmaps = reinterpret_cast<float*>(workspace + (((size_t)nblocks * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(ssim_fwd_kernel, g, dim3(SSIM_T * SSIM_T), 0, stream, width, height, img1, img2, mask, ssim_window(), dmaps, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, nblocks, (const float*)partials,
+                       1.0f / ((float)channels * (float)width * (float)height), ssim_mean);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_ssim_backward(int width, int height, int channels, const float* img1, const float* img2, const unsigned char* mask,
+                      const float* upstream, float* dL_dimg1, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (width <= 0 || height <= 0 || channels <= 0 || !img1 || !img2 || !dL_dimg1 || !workspace) {
+        g_last_error = "gsr_ssim_backward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const dim3 g = ssim_grid(width, height, channels);
+    const int nblocks = (int)(g.x * g.y * g.z);
+    const float* dmaps = reinterpret_cast<const float*>(workspace + (((size_t)nblocks * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(ssim_bwd_kernel, g, dim3(SSIM_T * SSIM_T), 0, stream, width, height, img1, img2, mask, ssim_window(), dmaps, upstream,
+                       1.0f / ((float)channels * (float)width * (float)height), dL_dimg1);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

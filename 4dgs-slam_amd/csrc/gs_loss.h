@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, c
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ta; partials[2 * blockIdx.x + 1] = tb; }
 }
 
-}  // namespace gsr
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused Adam step over several parameter tensors in ONE launch (second half): the reference steps six
@@ -118,3 +118,130 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamArgs a)
         g.param[i] = g.param[i] - g.step_size * (m / (sqrtf(v) * g.inv_bc2_sqrt + g.eps));
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused SSIM ("optional SSIM"): gaussian_splatting/utils/loss_utils.py:46-111 as used by the colour
+// refinement / mapping losses (utils/slam_backend.py:636,824-832): 11x11 Gaussian window (sigma 1.5), zero padding, per channel,
+//   ssim_map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)),   loss term = mean(ssim_map).
+// torch evaluates it with five grouped conv2d + ~15 elementwise kernels and as many again in backward. Here: one kernel per
+// direction, one 16x16 pixel tile per block and channel, separable window through LDS.
+//   forward : the five windowed means (x, y, x^2, y^2, xy) -> ssim value (block-summed, fixed order) and, for the backward pass,
+//             the three partial derivatives of the map w.r.t. mu1, E[x^2], E[xy] (img2 is the ground truth: no gradient);
+//   backward: dL/dx(p) = sum_q w(q - p) [ dm/dmu1(q) + 2 x(p) dm/dE11(q) + y(p) dm/dE12(q) ] * upstream / (C H W): three more
+//             separable convolutions of those maps.
+// An optional pixel mask zeroes both images first (loss_utils.py:66-68), i.e. masks the gradient.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SSIM_WIN = 11, SSIM_R = 5, SSIM_T = 16, SSIM_P = SSIM_T + 2 * SSIM_R;   // window, radius, tile, padded tile (26)
+
+struct SsimWindow { float w[SSIM_WIN]; };
+
+__device__ __forceinline__ float ssim_load(const float* __restrict__ img, const unsigned char* __restrict__ mask, int W, int H, int x, int y)
+{
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;                          // conv2d zero padding
+    if (mask && !mask[(size_t)y * W + x]) return 0.f;                             // torch.where(mask, img, 0)
+    return img[(size_t)y * W + x];
+}
+
+__global__ void __launch_bounds__(SSIM_T * SSIM_T) ssim_fwd_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                                   const unsigned char* __restrict__ mask, SsimWindow win,
+                                                                   float* __restrict__ dmaps /*[C][3][H*W]*/, float* __restrict__ partials)
+{
+    __shared__ float s_x[SSIM_P][SSIM_P + 1], s_y[SSIM_P][SSIM_P + 1];
+    __shared__ float s_h[5][SSIM_P][SSIM_T + 1];          // horizontally filtered x, y, xx, yy, xy
+    __shared__ float s_tmp[SSIM_T * SSIM_T / 64];
+    const int c = blockIdx.z, tx = threadIdx.x % SSIM_T, ty = threadIdx.x / SSIM_T;
+    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    const size_t N = (size_t)W * H;
+    const float* a = img1 + c * N; const float* b = img2 + c * N;
+    for (int i = threadIdx.x; i < SSIM_P * SSIM_P; i += SSIM_T * SSIM_T) {
+        const int r = i / SSIM_P, q = i % SSIM_P;
+        s_x[r][q] = ssim_load(a, mask, W, H, x0 + q, y0 + r);
+        s_y[r][q] = ssim_load(b, mask, W, H, x0 + q, y0 + r);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SSIM_P * SSIM_T; i += SSIM_T * SSIM_T) {      // horizontal pass: 26 rows x 16 columns
+        const int r = i / SSIM_T, q = i % SSIM_T;
+        float hx = 0.f, hy = 0.f, hxx = 0.f, hyy = 0.f, hxy = 0.f;
+#pragma unroll
+        for (int k = 0; k < SSIM_WIN; k++) {
+            const float u = s_x[r][q + k], v = s_y[r][q + k], w = win.w[k];
+            hx += w * u; hy += w * v; hxx += w * u * u; hyy += w * v * v; hxy += w * u * v;
+        }
+        s_h[0][r][q] = hx; s_h[1][r][q] = hy; s_h[2][r][q] = hxx; s_h[3][r][q] = hyy; s_h[4][r][q] = hxy;
+    }
+    __syncthreads();
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;                // vertical pass: this thread's pixel
+#pragma unroll
+    for (int k = 0; k < SSIM_WIN; k++) {
+        const float w = win.w[k];
+        mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx]; e11 += w * s_h[2][ty + k][tx];
+        e22 += w * s_h[3][ty + k][tx]; e12 += w * s_h[4][ty + k][tx];
+    }
+    const int px = blockIdx.x * SSIM_T + tx, py = blockIdx.y * SSIM_T + ty;
+    const bool inside = px < W && py < H;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+    const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+    const float inv = 1.0f / (Cc * D);
+    const float m = A * B * inv;
+    if (inside && dmaps) {
+        float* dm = dmaps + (size_t)c * 3 * N + (size_t)py * W + px;
+        // d ssim / d mu1 (mu1 also enters s1 and s12), d / d E[x^2], d / d E[xy]
+        dm[0] = (2.f * mu2 * (B - A)) * inv - m * (2.f * mu1 * (D - Cc)) * inv;
+        dm[N] = -m / D;
+        dm[2 * N] = 2.f * A * inv;
+    }
+    const float t = block_sum_fixed(inside ? m : 0.f, s_tmp);
+    if (threadIdx.x == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+}
+
+// out[0] = scale * sum of n partials, fixed order (one block)
+__global__ void __launch_bounds__(256) sum_partials_kernel(int n, const float* __restrict__ partials, float scale, float* __restrict__ out)
+{
+    __shared__ float s_tmp[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    const float t = block_sum_fixed(v, s_tmp);
+    if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+__global__ void __launch_bounds__(SSIM_T * SSIM_T) ssim_bwd_kernel(int W, int H, const float* __restrict__ img1, const float* __restrict__ img2,
+                                                                   const unsigned char* __restrict__ mask, SsimWindow win,
+                                                                   const float* __restrict__ dmaps, const float* __restrict__ upstream,
+                                                                   float scale, float* __restrict__ dL_dimg1)
+{
+    __shared__ float s_m[3][SSIM_P][SSIM_P + 1];
+    __shared__ float s_h[3][SSIM_P][SSIM_T + 1];
+    const int c = blockIdx.z, tx = threadIdx.x % SSIM_T, ty = threadIdx.x / SSIM_T;
+    const int x0 = blockIdx.x * SSIM_T - SSIM_R, y0 = blockIdx.y * SSIM_T - SSIM_R;
+    const size_t N = (size_t)W * H;
+    for (int i = threadIdx.x; i < SSIM_P * SSIM_P; i += SSIM_T * SSIM_T) {
+        const int r = i / SSIM_P, q = i % SSIM_P, x = x0 + q, y = y0 + r;
+        const bool in = x >= 0 && y >= 0 && x < W && y < H;
+        const float* dm = dmaps + (size_t)c * 3 * N + (size_t)y * W + x;
+        s_m[0][r][q] = in ? dm[0] : 0.f; s_m[1][r][q] = in ? dm[N] : 0.f; s_m[2][r][q] = in ? dm[2 * N] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SSIM_P * SSIM_T; i += SSIM_T * SSIM_T) {
+        const int r = i / SSIM_T, q = i % SSIM_T;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SSIM_WIN; k++) { const float w = win.w[k]; h0 += w * s_m[0][r][q + k]; h1 += w * s_m[1][r][q + k]; h2 += w * s_m[2][r][q + k]; }
+        s_h[0][r][q] = h0; s_h[1][r][q] = h1; s_h[2][r][q] = h2;
+    }
+    __syncthreads();
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SSIM_WIN; k++) { const float w = win.w[k]; g0 += w * s_h[0][ty + k][tx]; g1 += w * s_h[1][ty + k][tx]; g2 += w * s_h[2][ty + k][tx]; }
+    const int px = blockIdx.x * SSIM_T + tx, py = blockIdx.y * SSIM_T + ty;
+    if (px < W && py < H) {
+        const size_t p = (size_t)py * W + px;
+        const bool on = !mask || mask[p];
+        const float x = on ? img1[c * N + p] : 0.f, y = on ? img2[c * N + p] : 0.f;
+        const float g = (upstream ? upstream[0] : 1.f) * scale;
+        dL_dimg1[c * N + p] = on ? g * (g0 + 2.f * x * g1 + y * g2) : 0.f;
+    }
+}
+
+}  // namespace gsr

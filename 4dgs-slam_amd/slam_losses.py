@@ -23,6 +23,12 @@ def _lib():
         lib.gsr_l1_loss_forward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp]
         lib.gsr_l1_loss_backward.restype = i
         lib.gsr_l1_loss_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp, vp, vp, vp]
+        lib.gsr_ssim_workspace_size.restype = C.c_size_t
+        lib.gsr_ssim_workspace_size.argtypes = [i, i, i]
+        lib.gsr_ssim_forward.restype = i
+        lib.gsr_ssim_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
+        lib.gsr_ssim_backward.restype = i
+        lib.gsr_ssim_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
         _declared = True
     return lib
 
@@ -207,3 +213,54 @@ def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=F
     alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
     return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, viewpoint.exposure_a, viewpoint.exposure_b, alpha,
                             opacity=opacity, opacity_depth_threshold=0.95)
+
+
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2, mask):
+        lib = _lib()
+        _C._require_device(img1, "img1")
+        Cn, H, W = int(img1.shape[-3]), int(img1.shape[-2]), int(img1.shape[-1])
+        dev = img1.device
+        keep = []
+        a, b = _p(img1, keep), _p(img2, keep)
+        m8 = None
+        if mask is not None:
+            m8 = mask.to(torch.uint8).contiguous().view(-1)
+            if m8.numel() != H * W:
+                raise RuntimeError("ssim: mask must have H*W elements")
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty((int(lib.gsr_ssim_workspace_size(W, H, Cn)),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_ssim_forward(W, H, Cn, a, b, m8.data_ptr() if m8 is not None else None, out.data_ptr(), ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_ssim_forward")
+        ctx.save_for_backward(keep[0], keep[1], m8, ws)
+        ctx.shape = img1.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        img1, img2, m8, ws = ctx.saved_tensors
+        Cn, H, W = int(ctx.shape[-3]), int(ctx.shape[-2]), int(ctx.shape[-1])
+        dev = img1.device
+        grad = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+        keep = []
+        with torch.cuda.device(dev):
+            rc = lib.gsr_ssim_backward(W, H, Cn, img1.data_ptr(), img2.data_ptr(), m8.data_ptr() if m8 is not None else None, _p(g, keep),
+                                       grad.data_ptr(), ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_ssim_backward")
+        return grad, None, None
+
+
+def ssim(img1, img2, window_size=11, size_average=True, mask=None):
+    """gaussian_splatting/utils/loss_utils.py:63-76, same arguments and value; differentiable in img1 (the rendering; the reference's
+    callers pass the ground truth as img2, utils/slam_backend.py:636,824-832). Fused for the only form the reference uses
+    (window 11, size_average=True); anything else raises."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("ssim: only window_size=11, size_average=True (the form utils/slam_backend.py uses) is implemented")
+    if img2.requires_grad:
+        raise RuntimeError("ssim: img2 is treated as the ground truth (no gradient)")
+    return _Ssim.apply(img1, img2, mask)

@@ -35,6 +35,18 @@ int gsr_l1_loss_backward(int width, int height, const float* image, const float*
                          const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
                          const float* opacity, float opacity_depth_threshold, const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
 
+/* ---- fused SSIM ("optional SSIM") ---------------------------------------------------------------
+ * gaussian_splatting/utils/loss_utils.py:46-111 (ssim, size_average=True, window 11, sigma 1.5, zero padding, per channel) as the
+ * mapping / colour-refinement losses use it (utils/slam_backend.py:636,824-832): ssim_mean[0] = mean of the SSIM map of img1
+ * (the rendering, [C,H,W]) against img2 (ground truth). mask [H*W] bytes (may be NULL): both images are zeroed where it is 0
+ * (loss_utils.py:66-68). The workspace (gsr_ssim_workspace_size bytes) carries the derivative maps from forward to backward. */
+size_t gsr_ssim_workspace_size(int width, int height, int channels);
+int gsr_ssim_forward(int width, int height, int channels, const float* img1, const float* img2, const unsigned char* mask,
+                     float* ssim_mean, char* workspace, void* stream);
+/* dL_dimg1 [C,H,W] = upstream[0] (NULL = 1) * d ssim_mean / d img1. img2 receives no gradient. */
+int gsr_ssim_backward(int width, int height, int channels, const float* img1, const float* img2, const unsigned char* mask,
+                      const float* upstream, float* dL_dimg1, char* workspace, void* stream);
+
 /* ---- fused Adam step: all parameter tensors of the Gaussian model in one launch -----------------
  * Replaces optimizer.step() of scene/gaussian_model.py:447 (torch.optim.Adam(lr=0.0, eps=1e-15) over the six groups of :404-434)
  * with the arithmetic of torch.optim.Adam's single-tensor path (no amsgrad, no weight decay, no maximize). At most 8 segments. */

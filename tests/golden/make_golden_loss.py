@@ -78,5 +78,22 @@ for name, kw in tcases.items():
     out[f"{name}/g_image"], out[f"{name}/g_depth"] = image.grad.numpy(), depth.grad.numpy()
     out[f"{name}/g_a"], out[f"{name}/g_b"] = a.grad.numpy(), b.grad.numpy()
     out[f"{name}/flags"] = np.array([kw.get("rm_dynamic", False), use_mask])
+# ---- SSIM (gaussian_splatting/utils/loss_utils.py:63-111); the module imports cv2 at the top (absent here, unused by ssim)
+if "cv2" not in sys.modules:
+    try:
+        import cv2  # noqa: F401
+    except Exception:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+import gaussian_splatting.utils.loss_utils as lu            # noqa: E402
+for name, use_mask, hw in (("ssim_plain", False, (H, W)), ("ssim_mask", True, (H, W)), ("ssim_ragged", False, (37, 53))):
+    hh, ww = hw
+    img1 = torch.tensor(rng.uniform(0, 1, size=(3, hh, ww)).astype(np.float32), requires_grad=True)
+    img2 = torch.tensor(np.clip(img1.detach().numpy() + rng.normal(scale=0.1, size=(3, hh, ww)), 0, 1).astype(np.float32))
+    mk = torch.tensor(rng.uniform(size=(hh, ww)) > 0.3) if use_mask else None
+    val = lu.ssim(img1, img2, mask=mk)
+    val.backward()
+    out[f"{name}/img1"], out[f"{name}/img2"], out[f"{name}/value"], out[f"{name}/g_img1"] = img1.detach().numpy(), img2.numpy(), val.item(), img1.grad.numpy()
+    out[f"{name}/mask"] = mk.numpy() if mk is not None else np.zeros(0, bool)
+out["ssim_cases"] = np.array(["ssim_plain", "ssim_mask", "ssim_ragged"])
 np.savez_compressed(os.path.join(HERE, "golden_loss.npz"), **out)
 print("wrote golden_loss.npz", {k: out[f"{k}/loss"] for k in cases})

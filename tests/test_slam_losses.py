@@ -130,3 +130,36 @@ def test_fused_tracking_loss_matches_the_reference(name):
     opacity = torch.tensor(FX[f"{name}/opacity"], device="cuda")
     loss = get_loss_tracking(CONFIG, image, depth, opacity, vp, rm_dynamic=rm_dyn, mask=torch.tensor(FX["mask"], device="cuda") if use_mask else None)
     _check(name, loss, image, depth, vp, 2e-5)
+
+
+SCASES = [str(c) for c in FX["ssim_cases"]]
+
+
+def _ssim_case(name, dev):
+    img1 = torch.tensor(FX[f"{name}/img1"], device=dev, requires_grad=True)
+    img2 = torch.tensor(FX[f"{name}/img2"], device=dev)
+    mk = torch.tensor(FX[f"{name}/mask"], device=dev) if FX[f"{name}/mask"].size else None
+    return img1, img2, mk
+
+
+@pytest.mark.parametrize("name", SCASES)
+def test_ssim_restatement_reproduces_the_reference_on_cpu(name):
+    from oracle.loss_oracle import ssim_reference
+
+    img1, img2, mk = _ssim_case(name, "cpu")
+    v = ssim_reference(img1, img2, mk)
+    v.backward()
+    assert abs(float(v) - float(FX[f"{name}/value"])) < 1e-6
+    assert util.rel_l1(img1.grad.numpy(), FX[f"{name}/g_img1"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCASES)
+def test_fused_ssim_matches_the_reference(name):
+    from slam_losses import ssim
+
+    img1, img2, mk = _ssim_case(name, "cuda")
+    v = ssim(img1, img2, mask=mk)
+    (0.2 * (1.0 - v)).backward()                       # the way the losses use it: lambda_dssim * (1 - ssim)
+    assert abs(float(v) - float(FX[f"{name}/value"])) < 2e-6
+    assert util.rel_l1(img1.grad.cpu().numpy(), -0.2 * FX[f"{name}/g_img1"]) < 2e-5
