@@ -788,4 +788,19 @@ int gsr_ssim_backward(int width, int height, int channels, const float* img1, co
     return 0;
 }
 
+
+int gsr_densification_stats(int P, const int* radii, const float* grad_mean2D, float* max_radii2D, float* xyz_gradient_accum, float* denom,
+                            void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || (P > 0 && (!radii || !grad_mean2D || !max_radii2D || !xyz_gradient_accum || !denom))) {
+        g_last_error = "gsr_densification_stats: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii, grad_mean2D, max_radii2D,
+                       xyz_gradient_accum, denom);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

@@ -244,4 +244,24 @@ __global__ void __launch_bounds__(SSIM_T * SSIM_T) ssim_bwd_kernel(int W, int H,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Densification statistics of one rendered view in one launch (utils/slam_backend.py:712-720 + scene/gaussian_model.py:973-977):
+//   visible = radii > 0;  max_radii2D[visible] = max(max_radii2D, radii);  xyz_gradient_accum[visible] += |grad_mean2D[:, :2]|;
+//   denom[visible] += 1
+// The reference does this with boolean-mask indexing: ~10 torch kernels and three host synchronisations per view.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) densification_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ grad_mean2D,
+                                                                  float* __restrict__ max_radii2D, float* __restrict__ grad_accum,
+                                                                  float* __restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = grad_mean2D[3 * (size_t)i], gy = grad_mean2D[3 * (size_t)i + 1];
+    grad_accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+
 }  // namespace gsr

@@ -29,6 +29,8 @@ def _lib():
         lib.gsr_ssim_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
         lib.gsr_ssim_backward.restype = i
         lib.gsr_ssim_backward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+        lib.gsr_densification_stats.restype = i
+        lib.gsr_densification_stats.argtypes = [i, vp, vp, vp, vp, vp, vp]
         _declared = True
     return lib
 
@@ -264,3 +266,25 @@ def ssim(img1, img2, window_size=11, size_average=True, mask=None):
     if img2.requires_grad:
         raise RuntimeError("ssim: img2 is treated as the ground truth (no gradient)")
     return _Ssim.apply(img1, img2, mask)
+
+
+@torch.no_grad()
+def add_densification_stats(gaussians, viewspace_point_tensor, radii):
+    """One launch for what utils/slam_backend.py:712-720 and GaussianModel.add_densification_stats (gaussian_model.py:973-977) do per
+    rendered view with boolean-mask indexing (three host synchronisations): for radii > 0 update gaussians.max_radii2D,
+    gaussians.xyz_gradient_accum and gaussians.denom in place. `radii` and `viewspace_point_tensor` come from render()."""
+    lib = _lib()
+    g = viewspace_point_tensor.grad
+    _C._require_device(g, "viewspace_point_tensor.grad")
+    P = int(radii.shape[0])
+    for name in ("max_radii2D", "xyz_gradient_accum", "denom"):
+        t = getattr(gaussians, name)
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P:
+            raise RuntimeError(f"add_densification_stats: gaussians.{name} must be a contiguous float32 tensor with one value per Gaussian")
+    g = g if g.is_contiguous() else g.contiguous()
+    r = radii if (radii.dtype == torch.int32 and radii.is_contiguous()) else radii.to(torch.int32).contiguous()
+    with torch.cuda.device(g.device):
+        rc = lib.gsr_densification_stats(P, r.data_ptr(), g.data_ptr(), gaussians.max_radii2D.data_ptr(),
+                                         gaussians.xyz_gradient_accum.data_ptr(), gaussians.denom.data_ptr(), _C._stream(g.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_densification_stats")

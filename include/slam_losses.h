@@ -60,6 +60,14 @@ typedef struct gsr_adam_segment {
 } gsr_adam_segment;
 int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream);
 
+/* ---- densification statistics of one rendered view in one launch ----------------------------------------------------------
+ * utils/slam_backend.py:712-720 + scene/gaussian_model.py:973-977 (add_densification_stats): for every Gaussian with radii > 0
+ *   max_radii2D = max(max_radii2D, radii);  xyz_gradient_accum += |grad_mean2D[:, :2]|;  denom += 1.
+ * radii int32[P] and grad_mean2D float[P,3] (viewspace_points.grad) are the rasterizer's outputs; the three state arrays are
+ * float[P] (the reference keeps them as [P] and [P,1] float tensors). No host synchronisation. */
+int gsr_densification_stats(int P, const int* radii, const float* grad_mean2D, float* max_radii2D, float* xyz_gradient_accum, float* denom,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,3 +163,25 @@ def test_fused_ssim_matches_the_reference(name):
     (0.2 * (1.0 - v)).backward()                       # the way the losses use it: lambda_dssim * (1 - ssim)
     assert abs(float(v) - float(FX[f"{name}/value"])) < 2e-6
     assert util.rel_l1(img1.grad.cpu().numpy(), -0.2 * FX[f"{name}/g_img1"]) < 2e-5
+
+
+@pytest.mark.gpu
+def test_fused_densification_stats_match_the_reference_expressions():
+    import types
+    from slam_losses import add_densification_stats
+
+    gen = torch.Generator().manual_seed(5)
+    P = 5000
+    radii = torch.where(torch.rand(P, generator=gen) < 0.3, 0, torch.randint(1, 40, (P,), generator=gen)).to(torch.int32).cuda()
+    vs = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    vs.grad = torch.randn(P, 3, generator=gen).cuda()
+    mk = lambda *s: torch.rand(*s, generator=gen).cuda() * 10
+    g = types.SimpleNamespace(max_radii2D=mk(P), xyz_gradient_accum=mk(P, 1), denom=mk(P, 1).round())
+    want = types.SimpleNamespace(max_radii2D=g.max_radii2D.clone(), xyz_gradient_accum=g.xyz_gradient_accum.clone(), denom=g.denom.clone())
+    vis = radii > 0                                                                  # utils/slam_backend.py:712-720, gaussian_model.py:973-977
+    want.max_radii2D[vis] = torch.max(want.max_radii2D[vis], radii[vis])
+    want.xyz_gradient_accum[vis] += torch.norm(vs.grad[vis, :2], dim=-1, keepdim=True)
+    want.denom[vis] += 1
+    add_densification_stats(g, vs, radii)
+    assert torch.equal(g.max_radii2D, want.max_radii2D) and torch.equal(g.denom, want.denom)
+    assert torch.allclose(g.xyz_gradient_accum, want.xyz_gradient_accum, rtol=1e-6, atol=1e-7)
