@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""One mapping iteration of the SLAM back-end (utils/slam_backend.py:336-771, single GPU) on synthetic data: K keyframes of the same
+200k-Gaussian model are rendered (25 % dynamic Gaussians with control-node deltas), the mapping loss of every view is summed, one
+backward, densification statistics per view, one Adam step.
+  "reference_chain": what the reference executes around the rasterizer -- torch prologue, torch loss, boolean-mask statistics,
+                     torch.optim.Adam -- over this repo's rasterizer;
+  "fused":           prologue inside the kernels, fused loss, fused statistics, FusedAdam.
+Prints one JSON line (profiles/r01_mapping_iteration.json)."""
+import json, os, sys, time, types
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "4dgs-slam_amd"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import gaussian_renderer as gr
+from synthetic_scene import make_camera, make_gaussians, keyframe_pose
+from test_hip_fused_prologue import _GaussianModel, _camera
+from slam_losses import get_loss_mapping, mapping_loss_weights, add_densification_stats
+from fused_adam import FusedAdam
+
+P, W, H, K = 200_000, 640, 480, 8
+config = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.9}}
+pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
+g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
+rng = np.random.default_rng(11)
+out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr, mapping loss, densification stats, Adam"}
+for fused in (False, True):
+    m = _GaussianModel(g, False, 0.25, seed=2)
+    m.max_radii2D = torch.zeros(P, device="cuda"); m.xyz_gradient_accum = torch.zeros(P, 1, device="cuda"); m.denom = torch.zeros(P, 1, device="cuda")
+    views = []
+    for k in range(K):
+        R_w, t_w = keyframe_pose(k)
+        v = _camera(make_camera(W, H, R=R_w, t=t_w))
+        v.original_image = torch.tensor(rng.uniform(0, 1, size=(3, H, W)).astype(np.float32), device="cuda")
+        v.depth, v.motion_mask, v.uid = rng.uniform(0.3, 5.0, size=(H, W)).astype(np.float32), None, k
+        v.exposure_a = torch.nn.Parameter(torch.tensor([0.0], device="cuda")); v.exposure_b = torch.nn.Parameter(torch.tensor([0.0], device="cuda"))
+        views.append(v)
+    Kd = int(m.dygs.sum())
+    deltas = [{k: torch.tensor(rng.normal(scale=s, size=(Kd, n)).astype(np.float32), device="cuda", requires_grad=True)
+               for k, n, s in (("dx", 3, 0.002), ("ds", 3, 0.0001), ("dr", 4, 0.01))} for _ in range(K)]
+    groups = [{"params": [p_], "lr": lr, "name": n} for n, p_, lr in (("xyz", m._xyz, 1.6e-4), ("f_dc", m._features_dc, 2.5e-3),
+              ("opacity", m._opacity, 0.05), ("scaling", m._scaling, 1e-3), ("rotation", m._rotation, 1e-3))]
+    opt = (FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    gr.FUSED_PROLOGUE = fused
+
+    def torch_loss(image, depth, vp):
+        gt_depth = torch.from_numpy(vp.depth).to(dtype=torch.float32, device=image.device)[None]
+        w_rgb, w_dep = mapping_loss_weights(config, vp, vp.original_image, gt_depth)
+        image_ab = torch.exp(vp.exposure_a) * image + vp.exposure_b
+        return 0.9 * torch.abs(image_ab * w_rgb - vp.original_image * w_rgb).mean() + 0.1 * torch.abs(depth * w_dep - gt_depth * w_dep).mean()
+
+    def iteration():
+        opt.zero_grad(set_to_none=True)
+        loss, pkgs = 0.0, []
+        for v, d in zip(views, deltas):
+            res = gr.render(v, m, pipe, bg, **d)
+            loss = loss + (get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"]) if fused else torch_loss(res["render"], res["depth"], v))
+            pkgs.append(res)
+        loss.backward()
+        with torch.no_grad():
+            for res in pkgs:
+                if fused:
+                    add_densification_stats(m, res["viewspace_points"], res["radii"])
+                else:                                                              # utils/slam_backend.py:712-720, gaussian_model.py:973-977
+                    vis = res["visibility_filter"]
+                    m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], res["radii"][vis])
+                    m.xyz_gradient_accum[vis] += torch.norm(res["viewspace_points"].grad[vis, :2], dim=-1, keepdim=True)
+                    m.denom[vis] += 1
+        opt.step()
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out["fused" if fused else "reference_chain"] = {"ms_per_iteration": dt * 1e3, "gaussian_views_per_s": P * K / dt}
+gr.FUSED_PROLOGUE = True
+out["speedup"] = out["reference_chain"]["ms_per_iteration"] / out["fused"]["ms_per_iteration"]
+print(json.dumps(out))
