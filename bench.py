@@ -45,8 +45,8 @@ def algorithmic_bytes(P, V, R, N, M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=P_GAUSS)
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
