@@ -331,6 +331,45 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
     return std::make_tuple(g_image, g_depth, g_exp);
 }
 
+// ---- fused SSIM (include/slam_losses.h) ----
+std::tuple<torch::Tensor, torch::Tensor> ssim_forward(const torch::Tensor& img1_, const torch::Tensor& img2_, const c10::optional<torch::Tensor>& mask_,
+                                                       int64_t stream)
+{
+    TORCH_CHECK(img1_.is_cuda(), "img1 is on '", img1_.device().str(),
+                "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    const int C = (int)img1_.size(-3), H = (int)img1_.size(-2), W = (int)img1_.size(-1);
+    std::vector<torch::Tensor> keep;
+    const float* a = optf(img1_, keep, "img1");
+    const float* b = optf(img2_, keep, "img2");
+    torch::Tensor m8;
+    if (mask_.has_value() && mask_->defined() && mask_->numel() != 0) {
+        m8 = mask_->to(torch::kUInt8).contiguous();
+        TORCH_CHECK(m8.numel() == (int64_t)H * W, "ssim: mask must have H*W elements");
+    }
+    torch::Tensor out = torch::empty({}, img1_.options().dtype(torch::kFloat32));
+    torch::Tensor ws = torch::empty({(int64_t)gsr_ssim_workspace_size(W, H, C)}, img1_.options().dtype(torch::kUInt8));
+    const int rc = gsr_ssim_forward(W, H, C, a, b, m8.defined() ? m8.data_ptr<unsigned char>() : nullptr, out.data_ptr<float>(),
+                                    reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_ssim_forward", rc);
+    return std::make_tuple(out, ws);
+}
+
+torch::Tensor ssim_backward(const torch::Tensor& img1_, const torch::Tensor& img2_, const c10::optional<torch::Tensor>& mask_,
+                            const torch::Tensor& upstream, const torch::Tensor& ws, int64_t stream)
+{
+    const int C = (int)img1_.size(-3), H = (int)img1_.size(-2), W = (int)img1_.size(-1);
+    std::vector<torch::Tensor> keep;
+    const float* a = optf(img1_, keep, "img1");
+    const float* b = optf(img2_, keep, "img2");
+    torch::Tensor m8;
+    if (mask_.has_value() && mask_->defined() && mask_->numel() != 0) m8 = mask_->to(torch::kUInt8).contiguous();
+    torch::Tensor grad = torch::empty(img1_.sizes(), img1_.options().dtype(torch::kFloat32));
+    const int rc = gsr_ssim_backward(W, H, C, a, b, m8.defined() ? m8.data_ptr<unsigned char>() : nullptr, optf(upstream, keep, "upstream"),
+                                     grad.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_ssim_backward", rc);
+    return grad;
+}
+
 // markVisible, rasterize_points.cu:213-232
 torch::Tensor mark_visible(const torch::Tensor& means3D_, const torch::Tensor& viewmatrix_, const torch::Tensor& projmatrix_, int64_t stream)
 {
@@ -372,6 +411,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
     m.def("l1_loss_forward", &l1_loss_forward);
     m.def("l1_loss_backward", &l1_loss_backward);
+    m.def("ssim_forward", &ssim_forward);
+    m.def("ssim_backward", &ssim_backward);
     m.def("mark_visible", &mark_visible);
     m.def("dist_cuda2", &dist_cuda2);
 }

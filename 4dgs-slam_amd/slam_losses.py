@@ -220,8 +220,16 @@ def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=F
 class _Ssim(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img1, img2, mask):
-        lib = _lib()
         _C._require_device(img1, "img1")
+        ctx.shape = img1.shape
+        if _C._glue is not None:
+            with torch.cuda.device(img1.device):
+                out, ws = _C._glue.ssim_forward(img1.detach(), img2, mask, _C._stream(img1.device))
+            ctx.save_for_backward(img1, img2, mask, ws)
+            ctx.native = True
+            return out
+        ctx.native = False
+        lib = _lib()
         Cn, H, W = int(img1.shape[-3]), int(img1.shape[-2]), int(img1.shape[-1])
         dev = img1.device
         keep = []
@@ -243,8 +251,11 @@ class _Ssim(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib()
         img1, img2, m8, ws = ctx.saved_tensors
+        if ctx.native:
+            with torch.cuda.device(img1.device):
+                return _C._glue.ssim_backward(img1.detach(), img2, m8, g, ws, _C._stream(img1.device)), None, None
+        lib = _lib()
         Cn, H, W = int(ctx.shape[-3]), int(ctx.shape[-2]), int(ctx.shape[-1])
         dev = img1.device
         grad = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
