@@ -342,3 +342,24 @@ def test_adversarial_scenes_for_the_quadrant_cull_and_the_chunked_backward(kind)
     for k, v in m_h64.items():
         if isinstance(v, float) and k in m_o64:
             assert v <= max(1.5 * m_o64[k], IMG_TOL if not k.startswith("g_") else GRAD_TOL), (k, v, m_o64[k])
+
+
+def test_randomised_scene_shapes_back_to_back():
+    """Random image sizes, Gaussian counts, scales (tile lists from a handful to several thousand entries, across the 1024 / 4096 sort
+    thresholds) and SH degrees, rendered back to back in one process so that the speculative binning capacity inherited from the
+    previous scene is alternately far too small and far too large."""
+    rng = np.random.default_rng(2)
+    for it in range(14):
+        W, H = int(rng.integers(17, 330)), int(rng.integers(17, 250))
+        P = int(rng.choice([1, 7, 300, 3000, 12000, 30000]))
+        sm = float(rng.choice([0.002, 0.01, 0.05, 0.2]))
+        deg = int(rng.integers(0, 4))
+        cam = make_camera(W, H)
+        g = make_gaussians(P, cam, seed=int(rng.integers(1 << 30)), sh_degree=deg, scale_mean=sm)
+        gc, gd = make_cotangents(cam, seed=it)
+        bg = rng.uniform(0, 1, 3).astype(np.float32)
+        oo, st, go = oracle_run(g, cam, bg, gc, gd)
+        oh, gh = hip_run(g, cam, bg, gc, gd)
+        m = compare(oh, gh, oo, go)
+        m.update(P=P, case=(W, H, P, sm, deg))
+        _check(m, nt_tol=4)
