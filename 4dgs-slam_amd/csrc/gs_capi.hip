@@ -24,6 +24,7 @@
 #include "gs_backward.h"
 #include "gs_knn.h"
 #include "gs_loss.h"
+#include "gs_hexplane.h"
 #include "../../include/slam_losses.h"
 
 namespace gsr {
@@ -501,6 +502,53 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     return 0;
 }
 
+// ---- HexPlane feature field (include/deformation_field.h) -------------------------------------------------------------------
+static int hexplane_check(const gsr_hexplane_field* f, int64_t n, const float* xyz, const float* time, const char* who)
+{
+    static thread_local std::string msg;
+    auto fail = [&](const char* what) { msg = std::string(who) + ": " + what; g_last_error = msg.c_str(); return GSR_ERR_INVALID_ARGUMENT; };
+    if (!f) return fail("null field descriptor");
+    if (n < 0) return fail("negative point count");
+    if (f->num_levels < 1 || f->num_levels > GSR_HEXPLANE_MAX_LEVELS) return fail("num_levels outside 1..8");
+    if (f->feat_dim != 8 && f->feat_dim != 16 && f->feat_dim != 32 && f->feat_dim != 64) return fail("feat_dim must be 8, 16, 32 or 64");
+    for (int l = 0; l < f->num_levels; l++) {
+        for (int k = 0; k < 4; k++) if (f->levels[l].res[k] < 1) return fail("resolution < 1");
+        for (int p = 0; p < 6; p++) if (!f->levels[l].planes[p]) return fail("null plane");
+    }
+    if (n > 0 && (!xyz || !time)) return fail("null xyz / time");
+    return 0;
+}
+
+template <bool BWD, typename... Args>
+static void hexplane_launch(const gsr_hexplane_field& f, int64_t n, hipStream_t stream, Args... args)
+{
+    const int lpp = f.feat_dim / 4;
+    if constexpr (BWD) {   // channels-last planes: one channel per lane, a whole texel per atomic instruction (gs_hexplane.h)
+        if (f.channels_last) {
+            const int ppb = HEX_BLOCK / f.feat_dim;
+            const dim3 g((unsigned)((n + ppb - 1) / ppb)), b(HEX_BLOCK);
+            switch (f.feat_dim) {
+            case 8: hipLaunchKernelGGL((hexplane_bwd_lane_kernel<8>), g, b, 0, stream, f, n, args...); break;
+            case 16: hipLaunchKernelGGL((hexplane_bwd_lane_kernel<16>), g, b, 0, stream, f, n, args...); break;
+            case 32: hipLaunchKernelGGL((hexplane_bwd_lane_kernel<32>), g, b, 0, stream, f, n, args...); break;
+            case 64: hipLaunchKernelGGL((hexplane_bwd_lane_kernel<64>), g, b, 0, stream, f, n, args...); break;
+            }
+            return;
+        }
+    }
+    const dim3 grid((unsigned)((n + HEX_BLOCK / lpp - 1) / (HEX_BLOCK / lpp))), block(HEX_BLOCK);
+#define GSR_HEX_CASE(LPP)                                                                                                       \
+    case LPP:                                                                                                                   \
+        if constexpr (BWD) { if (f.channels_last) hipLaunchKernelGGL((hexplane_bwd_kernel<LPP, HEX_VEC>), grid, block, 0, stream, f, n, args...);   \
+                   else hipLaunchKernelGGL((hexplane_bwd_kernel<LPP, HEX_PLANAR>), grid, block, 0, stream, f, n, args...); }        \
+        else     { if (f.channels_last) hipLaunchKernelGGL((hexplane_fwd_kernel<LPP, HEX_VEC>), grid, block, 0, stream, f, n, args...);   \
+                   else hipLaunchKernelGGL((hexplane_fwd_kernel<LPP, HEX_PLANAR>), grid, block, 0, stream, f, n, args...); }        \
+        break;
+    switch (lpp) { GSR_HEX_CASE(2) GSR_HEX_CASE(4) GSR_HEX_CASE(8) GSR_HEX_CASE(16) }
+#undef GSR_HEX_CASE
+}
+
+
 extern "C" {
 
 int gsr_backward_fused(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
@@ -799,6 +847,29 @@ int gsr_densification_stats(int P, const int* radii, const float* grad_mean2D, f
     if (P == 0) return 0;
     hipLaunchKernelGGL(densification_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, radii, grad_mean2D, max_radii2D,
                        xyz_gradient_accum, denom);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+int gsr_hexplane_forward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
+                         int64_t time_stride, float* features, void* stream_)
+{
+    if (int rc = hexplane_check(field, n, xyz, time, "gsr_hexplane_forward")) return rc;
+    if (n == 0) return 0;
+    if (!features) { g_last_error = "gsr_hexplane_forward: null features"; return GSR_ERR_INVALID_ARGUMENT; }
+    hexplane_launch<false>(*field, n, (hipStream_t)stream_, xyz, xyz_stride, time, time_stride, features);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
+                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, void* stream_)
+{
+    if (int rc = hexplane_check(field, n, xyz, time, "gsr_hexplane_backward")) return rc;
+    if (n == 0) return 0;
+    if (!dL_dfeatures) { g_last_error = "gsr_hexplane_backward: null dL_dfeatures"; return GSR_ERR_INVALID_ARGUMENT; }
+    hexplane_launch<true>(*field, n, (hipStream_t)stream_, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

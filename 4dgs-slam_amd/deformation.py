@@ -1,0 +1,171 @@
+"""The 4D-Gaussians deformation network on the MI355X library -- the counterpart of the reference's utils/deformation.py with
+the same public names (deform_network, Deformation, poc_fre, initialize_weights), constructor arguments, parameter / buffer
+names (a reference state dict loads unchanged) and return values:  (means3D, scales, rotations, dx, ds, dr).
+
+What differs is where the work happens: the HexPlane field -- 24 grid_sample calls, 20 products and a concat per call in the
+reference (gaussian_splatting/utils/hexplane.py:81-112) -- is one fused HIP launch per direction (hexplane.py ->
+include/deformation_field.h); the small dense layers stay nn.Linear, i.e. library GEMMs.  The sin/cos positional embeddings the
+reference computes and then discards (deform_network.forward_dynamic builds [n, 63] / [n, 15] / [n, 20] embeddings of which only
+the leading raw columns are read, utils/deformation.py:198-213,78,113,122,132) are not computed."""
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from hexplane import HexPlaneField
+
+
+def poc_fre(input_data, poc_buf):
+    """utils/deformation.py:227-233."""
+    poc_buf = poc_buf.to(device=input_data.device)
+    emb = (input_data.unsqueeze(-1) * poc_buf).flatten(-2)
+    return torch.cat([input_data, emb.sin(), emb.cos()], -1)
+
+
+def initialize_weights(m):
+    """utils/deformation.py:220-226: Xavier-uniform weights; biases keep nn.Linear's default."""
+    if isinstance(m, nn.Linear):
+        init.xavier_uniform_(m.weight, gain=1)
+
+
+def _head(width, out_dim):
+    return nn.Sequential(nn.ReLU(), nn.Linear(width, width), nn.ReLU(), nn.Linear(width, out_dim))
+
+
+class Deformation(nn.Module):
+    """utils/deformation.py:17-165."""
+
+    def __init__(self, D=8, W=256, input_ch=27, input_ch_time=9, grid_pe=0, skips=[], args=None, device="cuda"):
+        super().__init__()
+        self.D, self.W, self.input_ch, self.input_ch_time, self.skips, self.grid_pe = D, W, input_ch, input_ch_time, skips, grid_pe
+        self.no_grid = args.no_grid
+        self.grid = HexPlaneField(args.bounds, args.kplanes_config, args.multires)
+        self.args = args
+        if args.empty_voxel:
+            raise NotImplementedError("empty_voxel (a DenseGrid occupancy mask; marked 'useless' and off in the reference's "
+                                      "arguments/__init__.py:101) is not part of the MI355X deformation field")
+        if args.static_mlp:
+            self.static_mlp = _head(W, 1)
+        self.ratio = 0
+        self.device = device
+        self.create_net()
+
+    @property
+    def get_aabb(self):
+        return self.grid.get_aabb
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.grid.set_aabb(xyz_max, xyz_min)
+
+    def create_net(self):
+        grid_out_dim = self.grid.feat_dim * 3 if self.grid_pe != 0 else self.grid.feat_dim
+        layers = [nn.Linear(4 if self.no_grid else grid_out_dim, self.W)]
+        for _ in range(self.D - 1):
+            layers += [nn.ReLU(), nn.Linear(self.W, self.W)]
+        self.feature_out = nn.Sequential(*layers).to(self.device)
+        self.pos_deform = _head(self.W, 3).to(self.device)
+        self.scales_deform = _head(self.W, 3).to(self.device)
+        self.rotations_deform = _head(self.W, 4).to(self.device)
+        self.opacity_deform = _head(self.W, 1).to(self.device)
+        self.shs_deform = _head(self.W, 16 * 3).to(self.device)
+
+    def query_time(self, rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb):
+        time_emb = time_emb.to(device=rays_pts_emb.device)
+        if self.no_grid:
+            h = torch.cat([rays_pts_emb[:, :3], time_emb[:, :1]], -1)
+        else:
+            h = self.grid(rays_pts_emb[:, :3], time_emb[:, :1])
+            if self.grid_pe > 1:
+                h = poc_fre(h, self.grid_pe)
+        return self.feature_out(h)
+
+    @property
+    def get_empty_ratio(self):
+        return self.ratio
+
+    def forward(self, rays_pts_emb, scales_emb=None, rotations_emb=None, opacity=None, shs_emb=None, time_feature=None, time_emb=None):
+        if time_emb is None:
+            return self.forward_static(rays_pts_emb[:, :3])
+        return self.forward_dynamic(rays_pts_emb, scales_emb, rotations_emb, opacity, shs_emb, time_feature, time_emb)
+
+    def forward_static(self, rays_pts_emb):
+        return rays_pts_emb[:, :3] + self.static_mlp(self.grid(rays_pts_emb[:, :3]))
+
+    def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
+        hidden = self.query_time(rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb)
+        a = self.args
+        mask = self.static_mlp(hidden) if a.static_mlp else None       # None = the reference's all-ones mask (:107)
+        keep = (lambda x: x) if mask is None else (lambda x: x * mask)
+        dx = ds = dr = None                                             # the reference leaves these unbound when disabled
+        if a.no_dx:
+            pts = rays_pts_emb[:, :3]
+        else:
+            dx = self.pos_deform(hidden)
+            pts = keep(rays_pts_emb[:, :3]) + dx
+        if a.no_ds:
+            scales = scales_emb[:, :3]
+        else:
+            ds = self.scales_deform(hidden)
+            scales = keep(scales_emb[:, :3]) + ds
+        if a.no_dr:
+            rotations = rotations_emb[:, :4]
+        else:
+            dr = self.rotations_deform(hidden)
+            if a.apply_rotation:
+                rotations = batch_quaternion_multiply(rotations_emb, dr)
+            else:
+                rotations = rotations_emb[:, :4] + dr
+        # no_do / no_dshs: the opacity and SH heads' results never leave the reference's forward (:134-149); not evaluated
+        return pts, scales, rotations, dx, ds, dr
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" not in n]
+
+    def get_grid_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" in n]
+
+
+def batch_quaternion_multiply(q1, q2):
+    """gaussian_splatting/utils/graphics_utils.py:134-157: row-wise Hamilton product of (w, x, y, z) quaternions, normalised."""
+    a, b = q1[:, :1], q1[:, 1:4]
+    c, d = q2[:, :1], q2[:, 1:4]
+    q = torch.cat((a * c - (b * d).sum(dim=1, keepdim=True), a * d + c * b + torch.cross(b, d, dim=1)), dim=1)
+    return q / torch.norm(q, dim=1, keepdim=True)
+
+
+class deform_network(nn.Module):
+    """utils/deformation.py:166-219."""
+
+    def __init__(self, args, device):
+        super().__init__()
+        times_ch = 2 * args.timebase_pe + 1
+        self.timenet = nn.Sequential(nn.Linear(times_ch, args.timenet_width), nn.ReLU(), nn.Linear(args.timenet_width, args.timenet_output))
+        self.deformation_net = Deformation(W=args.net_width, D=args.defor_depth, input_ch=3 + 3 * args.posebase_pe * 2, grid_pe=args.grid_pe,
+                                           input_ch_time=args.timenet_output, args=args, device=device)
+        self.register_buffer("time_poc", torch.FloatTensor([2 ** i for i in range(args.timebase_pe)]))
+        self.register_buffer("pos_poc", torch.FloatTensor([2 ** i for i in range(args.posebase_pe)]))
+        self.register_buffer("rotation_scaling_poc", torch.FloatTensor([2 ** i for i in range(args.scale_rotation_pe)]))
+        self.register_buffer("opacity_poc", torch.FloatTensor([2 ** i for i in range(args.opacity_pe)]))
+        self.apply(initialize_weights)
+
+    def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
+        return self.forward_dynamic(point, scales, rotations, opacity, shs, times_sel)
+
+    @property
+    def get_aabb(self):
+        return self.deformation_net.get_aabb
+
+    @property
+    def get_empty_ratio(self):
+        return self.deformation_net.get_empty_ratio
+
+    def forward_static(self, points):
+        return self.deformation_net(points)
+
+    def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
+        return self.deformation_net(point, scales, rotations, opacity, shs, None, times_sel)
+
+    def get_mlp_parameters(self):
+        return self.deformation_net.get_mlp_parameters() + list(self.timenet.parameters())
+
+    def get_grid_parameters(self):
+        return self.deformation_net.get_grid_parameters()

@@ -1,0 +1,69 @@
+/*
+ * deformation_field.h -- C ABI of the HexPlane feature field of the 4D-Gaussians deformation network
+ * (libgs_rasterizer_hip.so), SURVEY.md 8(f) rank 3.
+ *
+ * Replaces, with ONE forward and ONE backward launch, the tensor program of
+ *   gaussian_splatting/utils/hexplane.py:19-22   normalize_aabb          p -> clamp((p - aabb[0]) * 2 / (aabb[1] - aabb[0]) - 1, -1, 1)
+ *   gaussian_splatting/utils/hexplane.py:23-50   grid_sample_wrapper     F.grid_sample(bilinear, border, align_corners=True)
+ *   gaussian_splatting/utils/hexplane.py:81-112  interpolate_ms_features product over the 6 coordinate planes, concat over levels
+ *   gaussian_splatting/utils/hexplane.py:162-188 HexPlaneField.get_density / forward
+ * (24 grid_sample launches + 20 products + 1 concat forward, and their autograd twins, per call of
+ *  utils/deformation.py:71-87 Deformation.query_time).
+ *
+ * Geometry.  The field has `num_levels` resolution levels; level l has six planes in itertools.combinations(range(4), 2) order
+ *   0: (x,y)  1: (x,z)  2: (x,t)  3: (y,z)  4: (y,t)  5: (z,t)
+ * plane (c0,c1) is the reference parameter of logical shape [1, C, res[l][c1], res[l][c0]] (hexplane.py:66-68): the FIRST
+ * coordinate indexes the width.  C = feat_dim channels (a multiple of 4, at most 64).  Two memory layouts are accepted:
+ *   channels_last = 1   [H][W][C]  (what torch calls channels_last for the logical [1,C,H,W]; one 16*C/4-byte run per texel --
+ *                                   the layout this library is designed for)
+ *   channels_last = 0   [C][H][W]  (the reference's contiguous layout; works, every corner fetch is C scattered 4-byte loads)
+ * Output features are [n, num_levels * C] with level l at columns [l*C, (l+1)*C).
+ *
+ * All pointers are DEVICE pointers to fp32 unless stated; the descriptor itself lives in host memory and is copied by value
+ * into the kernel arguments.  Returns 0 or a negative GSR_ERR_* code (gs_rasterizer.h).
+ */
+#ifndef DEFORMATION_FIELD_H_INCLUDED
+#define DEFORMATION_FIELD_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_HEXPLANE_MAX_LEVELS 8
+
+typedef struct gsr_hexplane_level {
+    const float* planes[6];      /* parameters, layout above */
+    float* grad_planes[6];       /* backward only: dL/dplane, same layout, ACCUMULATED into (caller zeroes or keeps .grad); an
+                                    entry may be NULL to skip that plane */
+    int32_t res[4];              /* resolution along x, y, z, t at this level (hexplane.py:139-145: spatial ones times multires) */
+} gsr_hexplane_level;
+
+typedef struct gsr_hexplane_field {
+    int32_t num_levels;          /* 1 .. GSR_HEXPLANE_MAX_LEVELS */
+    int32_t feat_dim;            /* C */
+    int32_t channels_last;       /* memory layout of every plane and gradient plane */
+    int32_t reserved;
+    const float* aabb;           /* 6 floats: aabb[0] (xyz) then aabb[1] (xyz), the reference's HexPlaneField.aabb parameter; NULL = xyz
+                                    is already normalised (interpolate_ms_features called directly: no scaling, no clamp) */
+    gsr_hexplane_level levels[GSR_HEXPLANE_MAX_LEVELS];
+} gsr_hexplane_field;
+
+/* features[n, L*C] = HexPlaneField.forward(xyz, time).  xyz row i = xyz + i * xyz_stride (floats; 3 used -- the reference passes
+ * the first three columns of a [n, 63] positional embedding, utils/deformation.py:78), time likewise (1 used). */
+int gsr_hexplane_forward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
+                         int64_t time_stride, float* features, void* stream);
+
+/* Backward of the above for the cotangent dL_dfeatures [n, L*C]: accumulates into field->levels[l].grad_planes[p] and, when
+ * dL_dxyz is not NULL, WRITES dL_dxyz [n, 3] (contiguous) -- including the zero the reference produces for a coordinate clamped
+ * by normalize_aabb or sitting on the sampler's border (GridSampler.h clip_coordinates_set_grad).  Time receives no gradient
+ * (the reference builds it with torch.tensor(...).repeat, gaussian_renderer/__init__.py:112). */
+int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
+                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+"""Host logic of the deformation network (4dgs-slam_amd/deformation.py, hexplane.py) on CPU: names, shapes, layouts and the MLP
+wiring against the golden vectors of the reference's deform_network -- with the HexPlane field, which has no CPU implementation in
+the product, temporarily served by the oracle.  Also: the product refuses CPU tensors."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import deformation
+import hexplane
+from oracle import deformation_oracle as O
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_deformation.npz"))
+
+
+def hidden_params(**over):
+    """The shipped ModelHiddenParams fields the network reads (arguments/__init__.py:76-104)."""
+    a = types.SimpleNamespace(net_width=64, timebase_pe=4, defor_depth=1, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2,
+                              timenet_width=64, timenet_output=32, bounds=1.6,
+                              kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
+                                              "resolution": [64, 64, 64, 25]},
+                              multires=[1, 2, 4, 8], no_dx=False, no_grid=False, no_ds=False, no_dr=False, no_do=True, no_dshs=True,
+                              empty_voxel=False, grid_pe=0, static_mlp=False, apply_rotation=False)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-30))
+
+
+def test_default_network_has_the_reference_state_dict():
+    net = deformation.deform_network(hidden_params(), "cpu")
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(G["default/state_keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(G["default/state_shapes"])
+    assert sum(p.numel() for p in net.parameters()) == int(G["default/parameter_count"]) == 35762977
+    for name, p in net.named_parameters():
+        if "grids" in name:
+            assert hexplane._plane_layout(p) == 1, name            # stored channels_last
+    # 24 planes + the aabb parameter, whose name also contains "grid" (utils/deformation.py:160-164)
+    assert len(net.get_grid_parameters()) == 25 and net.deformation_net.grid.feat_dim == 128
+    # init (hexplane.py:69-73): planes with a time axis are ones, spatial ones uniform in [0.1, 0.5]
+    for l, level in enumerate(net.deformation_net.grid.grids):
+        for p, plane in enumerate(level):
+            if p in (2, 4, 5):
+                assert torch.all(plane == 1)
+            else:
+                assert 0.1 <= float(plane.min()) and float(plane.max()) <= 0.5 and float(plane.std()) > 0.05
+
+
+def test_product_refuses_cpu_tensors():
+    net = deformation.deform_network(hidden_params(multires=[1], kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4,
+                                                                                 "output_coordinate_dim": 32, "resolution": [4, 4, 4, 3]}), "cpu")
+    with pytest.raises(Exception, match="HIP device|no CPU"):
+        net(torch.zeros(5, 3), torch.zeros(5, 3), torch.zeros(5, 4), torch.zeros(5, 1), torch.zeros(5, 16, 3), torch.zeros(5, 1))
+
+
+@pytest.mark.parametrize("tag", ["net1", "net2"])
+def test_network_wiring_matches_reference_golden(tag, monkeypatch):
+    """load the reference state dict into the build's module; HexPlane features come from the oracle (CPU)."""
+    depth = int(G[f"{tag}/defor_depth"])
+    res = [int(r) for r in G[f"{tag}/resolution"]]
+    net = deformation.deform_network(hidden_params(defor_depth=depth, multires=[int(m) for m in G[f"{tag}/multires"]],
+                                                   kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4,
+                                                                   "output_coordinate_dim": 32, "resolution": res}), "cpu")
+    state = {k: torch.tensor(G[f"{tag}/state/{k}"]) for k in G[f"{tag}/state_keys"]}
+    net.load_state_dict(state, strict=True)
+    for name, p in net.named_parameters():
+        if "grids" in name:
+            assert hexplane._plane_layout(p) == 1                  # copy_ keeps the channels_last storage
+    monkeypatch.setattr(hexplane, "hexplane_features", lambda pts, t, aabb, grids: O.hexplane_field(pts, t, aabb, [list(g) for g in grids]))
+    assert len(net.get_mlp_parameters()) == int(G[f"{tag}/mlp_parameter_count"])
+    assert len(net.get_grid_parameters()) == int(G[f"{tag}/grid_parameter_count"])
+    ins = {k: torch.tensor(G[f"{tag}/in_{k}"]) for k in ("point", "scales", "rotations", "opacity", "shs", "time")}
+    for k in ("point", "scales", "rotations"):
+        ins[k].requires_grad_(True)
+    outs = net(ins["point"], ins["scales"], ins["rotations"], ins["opacity"], ins["shs"], ins["time"])
+    loss = 0
+    for name, o in zip(["means3D", "scales", "rotations", "dx", "ds", "dr"], outs):
+        assert rel(o.detach(), G[f"{tag}/out_{name}"]) < 1e-5, name
+        loss = loss + (o * torch.tensor(G[f"{tag}/cot_{name}"])).sum()
+    loss.backward()
+    for k in ("point", "scales", "rotations"):
+        assert rel(ins[k].grad, G[f"{tag}/g_in_{k}"]) < 1e-4, k
+    for name, p in net.named_parameters():
+        g = G[f"{tag}/grad/{name}"]
+        if g.size == 0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+        else:
+            assert rel(p.grad, g) < 1e-4, name
+
+
+def test_quaternion_product_matches_formula():
+    q1, q2 = torch.randn(7, 4, dtype=torch.float64), torch.randn(7, 4, dtype=torch.float64)
+    w = q1[:, 0] * q2[:, 0] - (q1[:, 1:] * q2[:, 1:]).sum(1)
+    out = deformation.batch_quaternion_multiply(q1, q2)
+    assert torch.allclose(out.norm(dim=1), torch.ones(7, dtype=torch.float64))
+    raw = out * (q1.norm(dim=1) * q2.norm(dim=1))[:, None]         # |q1 q2| = |q1| |q2|
+    assert torch.allclose(raw[:, 0], w)
+    # i * j = k
+    e = lambda k: torch.eye(4, dtype=torch.float64)[k][None]
+    assert torch.allclose(deformation.batch_quaternion_multiply(e(1), e(2)), e(3))

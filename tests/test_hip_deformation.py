@@ -1,0 +1,250 @@
+"""GPU parity of the fused HexPlane field / deformation network (include/deformation_field.h) against
+  * the golden vectors of the reference's own HexPlaneField and deform_network (tests/golden/make_golden_deformation.py),
+  * the pinned CPU oracle (oracle/deformation_oracle.py) in fp64 on seeded inputs at the shipped geometry,
+  * torch's own F.grid_sample composition on the GPU (an independent fp32 statement of the same op).
+Tolerances: values rel-L1 <= 1e-5 (north_star asks 1e-4), gradients rel-L1 <= 1e-4 (north_star asks 1e-3)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import deformation
+import hexplane
+from oracle import deformation_oracle as O
+from test_deformation_host import hidden_params
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_deformation.npz"))
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-30))
+
+
+def torch_field(pts, tim, aabb, levels):
+    """F.grid_sample statement of HexPlaneField.forward (what the reference executes), on whatever device."""
+    p = torch.clamp((pts - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1.0, -1.0, 1.0)
+    p4 = torch.cat((p, tim), dim=-1)
+    feats = []
+    for planes in levels:
+        prod = 1.0
+        for (c0, c1), plane in zip(itertools.combinations(range(4), 2), planes):
+            grid = p4[:, [c0, c1]].view(1, 1, -1, 2)
+            s = F.grid_sample(plane, grid, align_corners=True, mode="bilinear", padding_mode="border")   # [1, C, 1, n]
+            prod = prod * s.view(plane.shape[1], -1).t()
+        feats.append(prod)
+    return torch.cat(feats, dim=-1)
+
+
+def golden_field(layout):
+    levels = []
+    for l in range(2):
+        lv = []
+        for p in range(6):
+            t = torch.tensor(G[f"field/plane_{l}_{p}"], device=DEV)
+            t = t.contiguous(memory_format=torch.channels_last) if layout == "channels_last" else t.contiguous()
+            lv.append(t.requires_grad_(True))
+        levels.append(lv)
+    return levels
+
+
+@pytest.mark.parametrize("layout", ["channels_last", "contiguous"])
+def test_field_matches_reference_golden(layout):
+    levels = golden_field(layout)
+    pts = torch.tensor(G["field/pts"], device=DEV, requires_grad=True)
+    feat = hexplane.hexplane_features(pts, torch.tensor(G["field/time"], device=DEV), torch.tensor(G["field/aabb"], device=DEV), levels)
+    assert feat.shape == (256, 64)
+    assert rel(feat, G["field/features"]) < 1e-6
+    (feat * torch.tensor(G["field/cotangent"], device=DEV)).sum().backward()
+    assert rel(pts.grad, G["field/g_pts"]) < 1e-5
+    for l in range(2):
+        for p in range(6):
+            g = levels[l][p].grad
+            assert g.shape == levels[l][p].shape and g.stride() == levels[l][p].stride()
+            assert rel(g, G[f"field/g_plane_{l}_{p}"]) < 1e-5, (l, p)
+    # exact zeros where the reference has exact zeros (clamped / border coordinates)
+    assert torch.all((pts.grad.cpu() == 0) == torch.tensor(G["field/g_pts"] == 0))
+
+
+@pytest.mark.parametrize("tag", ["net1", "net2"])
+def test_network_matches_reference_golden(tag):
+    res = [int(r) for r in G[f"{tag}/resolution"]]
+    net = deformation.deform_network(hidden_params(defor_depth=int(G[f"{tag}/defor_depth"]), multires=[int(m) for m in G[f"{tag}/multires"]],
+                                                   kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4,
+                                                                   "output_coordinate_dim": 32, "resolution": res}), DEV).to(DEV)
+    net.load_state_dict({k: torch.tensor(G[f"{tag}/state/{k}"]) for k in G[f"{tag}/state_keys"]}, strict=True)
+    ins = {k: torch.tensor(G[f"{tag}/in_{k}"], device=DEV) for k in ("point", "scales", "rotations", "opacity", "shs", "time")}
+    for k in ("point", "scales", "rotations"):
+        ins[k].requires_grad_(True)
+    outs = net(ins["point"], ins["scales"], ins["rotations"], ins["opacity"], ins["shs"], ins["time"])
+    loss = 0
+    for name, o in zip(["means3D", "scales", "rotations", "dx", "ds", "dr"], outs):
+        assert rel(o, G[f"{tag}/out_{name}"]) < 1e-5, name
+        loss = loss + (o * torch.tensor(G[f"{tag}/cot_{name}"], device=DEV)).sum()
+    loss.backward()
+    for k in ("point", "scales", "rotations"):
+        assert rel(ins[k].grad, G[f"{tag}/g_in_{k}"]) < 1e-4, k
+    for name, p in net.named_parameters():
+        g = G[f"{tag}/grad/{name}"]
+        if g.size:
+            assert rel(p.grad, g) < 1e-4, name
+
+
+def default_field(seed=0, scale=1.0):
+    torch.manual_seed(seed)
+    field = hexplane.HexPlaneField(1.6, {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
+                                         "resolution": [64, 64, 64, 25]}, [1, 2, 4, 8]).to(DEV)
+    with torch.no_grad():
+        for lv in field.grids:
+            for p in lv:
+                p.uniform_(0.2, 1.3)                                 # informative time planes (they start as ones)
+    return field
+
+
+def test_shipped_geometry_against_oracle_fp64_and_torch_grid_sample():
+    field = default_field()
+    rng = np.random.default_rng(3)
+    n = 20000
+    pts = torch.tensor(rng.uniform(-1.9, 1.9, size=(n, 3)).astype(np.float32), device=DEV, requires_grad=True)
+    tim = torch.tensor(rng.uniform(-1.1, 1.1, size=(n, 1)).astype(np.float32), device=DEV)
+    cot = torch.tensor(rng.normal(size=(n, 128)).astype(np.float32), device=DEV)
+    feat = field(pts, tim)
+    (feat * cot).sum().backward()
+    g_pts = pts.grad.clone()
+    g_planes = [[p.grad.clone() for p in lv] for lv in field.grids]
+    # (a) torch's grid_sample on the GPU, fp32, all points
+    pts2 = pts.detach().clone().requires_grad_(True)
+    lv2 = [[p.detach().clone().contiguous().requires_grad_(True) for p in lv] for lv in field.grids]
+    feat2 = torch_field(pts2, tim, field.aabb, lv2)
+    (feat2 * cot).sum().backward()
+    assert rel(feat, feat2) < 1e-6
+    assert rel(g_pts, pts2.grad) < 1e-5
+    for l in range(4):
+        for p in range(6):
+            assert rel(g_planes[l][p], lv2[l][p].grad) < 1e-5, (l, p)
+    # (b) the pinned oracle in fp64 on a subset (values; the plane gradients of a subset need their own backward)
+    m = 1500
+    sub = pts.detach()[:m].double().cpu().requires_grad_(True)
+    lv64 = [[p.detach().double().cpu().contiguous().requires_grad_(True) for p in lv] for lv in field.grids]
+    f64 = O.hexplane_field(sub, tim[:m].double().cpu(), field.aabb.detach().double().cpu(), lv64)
+    assert rel(feat[:m], f64) < 2e-5        # fp32 product of six fp32 samples against the exact answer
+    (f64 * cot[:m].double().cpu()).sum().backward()
+    pts3 = pts.detach()[:m].clone().requires_grad_(True)
+    for lv in field.grids:
+        for p in lv:
+            p.grad = None
+    (field(pts3, tim[:m]) * cot[:m]).sum().backward()
+    assert rel(pts3.grad, sub.grad) < 1e-4
+    for l in range(4):
+        for p in range(6):
+            assert rel(field.grids[l][p].grad, lv64[l][p].grad) < 1e-4, (l, p)   # fp32 kernel vs the exact answer
+
+
+@pytest.mark.parametrize("C", [8, 16, 64])
+def test_other_feature_widths(C):
+    rng = np.random.default_rng(C)
+    res = [5, 4, 6, 3]
+    levels = []
+    for m in (1, 3):
+        r = [res[0] * m, res[1] * m, res[2] * m, res[3]]
+        lv = [torch.tensor(rng.uniform(0.2, 1.2, size=(1, C, r[c1], r[c0])).astype(np.float32), device=DEV)
+              .contiguous(memory_format=torch.channels_last).requires_grad_(True) for c0, c1 in itertools.combinations(range(4), 2)]
+        levels.append(lv)
+    n = 777
+    pts = torch.tensor(rng.uniform(-1.2, 1.2, size=(n, 3)).astype(np.float32), device=DEV, requires_grad=True)
+    tim = torch.tensor(rng.uniform(-1.0, 1.0, size=(n, 1)).astype(np.float32), device=DEV)
+    aabb = torch.tensor([[1.0, 1.1, 0.9], [-1.0, -0.8, -1.2]], device=DEV)
+    feat = hexplane.hexplane_features(pts, tim, aabb, levels)
+    cot = torch.tensor(rng.normal(size=(n, 2 * C)).astype(np.float32), device=DEV)
+    (feat * cot).sum().backward()
+    p64 = pts.detach().double().cpu().requires_grad_(True)
+    l64 = [[p.detach().double().cpu().contiguous().requires_grad_(True) for p in lv] for lv in levels]
+    f64 = O.hexplane_field(p64, tim.double().cpu(), aabb.double().cpu(), l64)
+    (f64 * cot.double().cpu()).sum().backward()
+    assert rel(feat, f64) < 2e-5 and rel(pts.grad, p64.grad) < 1e-4
+    for l in range(2):
+        for p in range(6):
+            assert rel(levels[l][p].grad, l64[l][p].grad) < 1e-4
+
+
+def test_edge_cases_empty_ragged_strided_and_expanded():
+    field = default_field(1)
+    # empty: the reference returns zeros [0, 1] (hexplane.py:174-175)
+    out = field(torch.zeros((0, 3), device=DEV), torch.zeros((0, 1), device=DEV))
+    assert out.shape == (0, 1)
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 33, 257):
+        emb = torch.tensor(rng.uniform(-1.5, 1.5, size=(n, 63)).astype(np.float32), device=DEV, requires_grad=True)
+        t0 = torch.tensor([[0.25]], device=DEV)
+        a = field(emb[:, :3], t0.expand(n, 1))                       # strided rows (the reference's rays_pts_emb[:, :3]) + stride-0 time
+        b = field(emb[:, :3].detach().contiguous(), t0.repeat(n, 1))
+        assert torch.equal(a, b)
+        a.sum().backward()
+        assert emb.grad.shape == (n, 63) and float(emb.grad[:, 3:].abs().max()) == 0.0
+    # NaN / inf coordinates must not fault (ATen clips them onto the border)
+    bad = torch.tensor([[float("nan"), 0.0, 0.0], [float("inf"), -float("inf"), 0.0]], device=DEV)
+    out = field(bad, torch.zeros((2, 1), device=DEV))
+    torch.cuda.synchronize()
+    assert out.shape == (2, 128)
+
+
+def test_interpolate_ms_features_entry_point():
+    levels = golden_field("channels_last")
+    aabb = torch.tensor(G["field/aabb"], device=DEV)
+    pts = torch.tensor(G["field/pts"], device=DEV)
+    tim = torch.tensor(G["field/time"], device=DEV)
+    p4 = torch.cat((hexplane.normalize_aabb(pts, aabb), tim), dim=-1)
+    f = hexplane.interpolate_ms_features(p4, levels, grid_dimensions=2, concat_features=True, num_levels=None)
+    assert rel(f, G["field/features"]) < 1e-6
+    s = hexplane.interpolate_ms_features(p4, levels, grid_dimensions=2, concat_features=False, num_levels=None)
+    assert rel(s, G["field/features"][:, :32] + G["field/features"][:, 32:]) < 1e-6
+    one = hexplane.interpolate_ms_features(p4, levels, 2, True, num_levels=1)
+    assert rel(one, G["field/features"][:, :32]) < 1e-6
+
+
+def test_bad_arguments_raise():
+    levels = golden_field("channels_last")
+    pts = torch.zeros((4, 3), device=DEV)
+    tim = torch.zeros((4, 1), device=DEV)
+    with pytest.raises(ValueError, match="inconsistent resolution"):
+        bad = [list(levels[0]), list(levels[1])]
+        bad[0][1] = levels[1][1]
+        hexplane.hexplane_features(pts, tim, None, bad)
+    with pytest.raises(ValueError, match="six planes"):
+        hexplane.hexplane_features(pts, tim, None, [levels[0][:5]])
+    with pytest.raises(ValueError, match="share one memory layout"):
+        mixed = [list(levels[0])]
+        mixed[0][3] = levels[0][3].detach().contiguous()
+        hexplane.hexplane_features(pts, tim, None, mixed)
+    with pytest.raises(ValueError, match="timestamps"):
+        hexplane.hexplane_features(pts, torch.zeros((3, 1), device=DEV), None, levels)
+    with pytest.raises(Exception, match="HIP device|no CPU"):
+        hexplane.hexplane_features(pts.cpu(), tim.cpu(), None, levels)
+
+
+def test_render_dynamic_through_the_deformation_network():
+    """render(dynamic=True) (gaussian_renderer/__init__.py:149-157) with the build's deform_network as pc._deformation: gradients
+    reach the planes, the MLP and the Gaussian parameters."""
+    import types
+    import gaussian_renderer
+    from util import make_camera, make_gaussians
+    from test_hip_fused_prologue import _GaussianModel, _camera
+    cam = make_camera(160, 120)
+    pc = _GaussianModel(make_gaussians(3000, cam, seed=2), isotropic=False, dyn_frac=0.0, seed=3)
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=DEV)
+    view = _camera(cam)
+    view.time = 0.4
+    pc._deformation = deformation.deform_network(hidden_params(multires=[1, 2], bounds=8.0), DEV).to(DEV)
+    out = gaussian_renderer.render(view, pc, pipe, bg, dynamic=True)
+    loss = out["render"].mean() + 0.1 * out["depth"].mean()
+    loss.backward()
+    grid_g = [p.grad for p in pc._deformation.get_grid_parameters() if p.requires_grad]
+    assert all(g is not None for g in grid_g) and sum(float(g.abs().sum()) for g in grid_g) > 0
+    assert pc._xyz.grad is not None and torch.isfinite(pc._xyz.grad).all()
+    assert float(pc._deformation.deformation_net.pos_deform[3].weight.grad.abs().sum()) > 0
