@@ -1,0 +1,195 @@
+"""SC-GS control-node warp on the MI355X library (include/control_nodes.h) -- the per-Gaussian half of the reference's
+utils/time_utils.py ControlNodeWarp: `knn_points` (the pytorch3d.ops routine the reference imports, which has no ROCm build),
+`cal_nn_weight` (:981-1011) and `node_blend`, the body of ControlNodeWarp.forward (:1192-1258) after the node MLP.
+
+The per-NODE work of the reference (the node MLP, quaternion_to_matrix of 512 local rotations, exp / sigmoid of the node radius and
+weight) stays in torch: it is O(nodes), differentiable there, and feeds this module's inputs; everything O(Gaussians) is one HIP
+launch per direction.  There is no CPU path."""
+import ctypes
+from collections import namedtuple
+
+import torch
+
+from diff_gaussian_rasterization import _C
+
+MAX_K, MAX_DIM, BLEND_MAX_K = 32, 32, 8
+_KNN = namedtuple("KNN", "dists idx knn")
+
+
+class _Blend(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("m", ctypes.c_int32), ("K", ctypes.c_int32), ("local_frame", ctypes.c_int32),
+                ("rot_as_residual", ctypes.c_int32), ("node_stride", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("x", ctypes.c_void_p), ("motion_mask", ctypes.c_void_p), ("nodes", ctypes.c_void_p), ("node_radius", ctypes.c_void_p),
+                ("node_weight", ctypes.c_void_p), ("node_trans", ctypes.c_void_p), ("node_rot", ctypes.c_void_p),
+                ("node_scale", ctypes.c_void_p), ("node_frame", ctypes.c_void_p)]
+
+
+_lib_cache = None
+
+
+def _lib():
+    global _lib_cache
+    if _lib_cache is None:
+        lib = _C.load_library()
+        i64, vp, i = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        lib.gsr_knn_points.restype = i
+        lib.gsr_knn_points.argtypes = [i64, i64, i, i, vp, vp, vp, vp, vp]
+        lib.gsr_node_blend_forward.restype = i
+        lib.gsr_node_blend_forward.argtypes = [ctypes.POINTER(_Blend), vp, vp, vp, vp, vp, vp, vp]
+        lib.gsr_node_blend_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_node_blend_workspace_size.argtypes = [i64, ctypes.c_int32]
+        lib.gsr_node_blend_backward.restype = i
+        lib.gsr_node_blend_backward.argtypes = [ctypes.POINTER(_Blend)] + [vp] * 15
+        _lib_cache = lib
+    return _lib_cache
+
+
+def _f32(t, name):
+    _C._require_device(t, name)
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be fp32, got {t.dtype}")
+    return t.detach().contiguous()
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = -1, return_nn: bool = False, return_sorted: bool = True):
+    """pytorch3d.ops.knn_points for equal-length batches: p1 [B, N, D], p2 [B, M, D] -> (dists [B, N, K] squared, idx [B, N, K]
+    int64, knn [B, N, K, D] or None).  No gradient flows through dists (the reference only uses detached inputs here)."""
+    if lengths1 is not None or lengths2 is not None:
+        raise NotImplementedError("knn_points: ragged batches (lengths1 / lengths2) are not used by the reference and not implemented")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != p2.shape[2]:
+        raise ValueError(f"knn_points expects p1 [B, N, D] and p2 [B, M, D], got {tuple(p1.shape)} and {tuple(p2.shape)}")
+    B, N, D = p1.shape
+    if not (1 <= K <= MAX_K) or not (1 <= D <= MAX_DIM):
+        raise ValueError(f"knn_points: K = {K}, D = {D} outside 1..32")
+    a, b = _f32(p1, "p1"), _f32(p2, "p2")
+    dists = torch.empty((B, N, K), dtype=torch.float32, device=a.device)
+    idx = torch.empty((B, N, K), dtype=torch.int64, device=a.device)
+    lib = _lib()
+    with torch.cuda.device(a.device):
+        for bi in range(B):
+            rc = lib.gsr_knn_points(N, b.shape[1], D, K, a[bi].data_ptr(), b[bi].data_ptr(), dists[bi].data_ptr(), idx[bi].data_ptr(),
+                                    _C._stream(a.device))
+            if rc < 0:
+                _C._err(lib, rc, "gsr_knn_points")
+    knn = None
+    if return_nn:
+        knn = torch.gather(p2[:, None].expand(-1, N, -1, -1), 2, idx[..., None].expand(-1, -1, -1, D))
+    return _KNN(dists, idx, knn)
+
+
+def quaternion_to_matrix(q):
+    """utils/time_utils.py:115-133: real part first; the 2 / |q|^2 factor normalises."""
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+class _NodeBlend(torch.autograd.Function):
+    """(nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling) from per-node tensors; gradients to node_radius, node_weight,
+    node_trans, node_rot, node_scale, node_frame.  x and nodes are constants of the op (detached in the reference)."""
+
+    @staticmethod
+    def forward(ctx, x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, node_frame, K, local_frame,
+                rot_as_residual):
+        x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius")
+        n, m = x.shape[0], nodes.shape[0]
+        if x.dim() != 2 or x.shape[1] != 3 or nodes.dim() != 2 or nodes.shape[1] < 3:
+            raise ValueError(f"node blend expects x [N, 3] and nodes [M, >=3], got {tuple(x.shape)} and {tuple(nodes.shape)}")
+        if not 1 <= K <= BLEND_MAX_K:
+            raise ValueError(f"node blend: K = {K} outside 1..{BLEND_MAX_K}")
+        blend = node_trans is not None
+        opt = lambda t, name, shape: None if t is None else _checked(_f32(t, name), name, shape)
+        motion_mask = opt(motion_mask, "motion_mask", None)
+        if motion_mask is not None and motion_mask.numel() != n:
+            raise ValueError(f"motion_mask must have one value per Gaussian ({n}), got {tuple(motion_mask.shape)}")
+        node_weight = None if node_weight is None else _f32(node_weight, "node_weight").reshape(-1)
+        if node_radius.numel() != m or (node_weight is not None and node_weight.numel() != m):
+            raise ValueError("node_radius / node_weight must have one value per node")
+        node_trans, node_rot = opt(node_trans, "node_trans", (m, 3)), opt(node_rot, "node_rot", (m, 4))
+        node_scale = opt(node_scale, "node_scale", (m, 3))
+        node_frame = opt(node_frame, "node_frame", (m, 3, 3)) if local_frame and blend else None
+        a = _Blend(n=n, m=m, K=K, local_frame=int(bool(local_frame)), rot_as_residual=int(bool(rot_as_residual)), node_stride=nodes.shape[1])
+        keep = dict(x=x, motion_mask=motion_mask, nodes=nodes, node_radius=node_radius, node_weight=node_weight, node_trans=node_trans,
+                    node_rot=node_rot, node_scale=node_scale, node_frame=node_frame)
+        for k, t in keep.items():
+            setattr(a, k, t.data_ptr() if t is not None else None)
+        dev = x.device
+        w = torch.empty((n, K), dtype=torch.float32, device=dev)
+        dist = torch.empty((n, K), dtype=torch.float32, device=dev)
+        idx = torch.empty((n, K), dtype=torch.int64, device=dev)
+        outs = [torch.empty((n, c), dtype=torch.float32, device=dev) if blend else None for c in (3, 4, 3)]
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_forward(ctypes.byref(a), w.data_ptr(), dist.data_ptr(), idx.data_ptr(),
+                                            *(o.data_ptr() if o is not None else None for o in outs), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_forward")
+        ctx.keep, ctx.args = keep, (n, m, K, bool(local_frame), bool(rot_as_residual), nodes.shape[1])
+        ctx.saved = (w, dist, idx)
+        ctx.mark_non_differentiable(dist, idx)
+        empty = torch.empty(0, device=dev)
+        return (w, dist, idx, *(o if o is not None else empty for o in outs))
+
+    @staticmethod
+    def backward(ctx, g_w, _g_dist, _g_idx, g_xyz, g_rot, g_scale):
+        n, m, K, local_frame, rot_as_residual, stride = ctx.args
+        keep = ctx.keep
+        w, dist, idx = ctx.saved
+        dev = w.device
+        blend = keep["node_trans"] is not None
+        a = _Blend(n=n, m=m, K=K, local_frame=int(local_frame), rot_as_residual=int(rot_as_residual), node_stride=stride)
+        for k, t in keep.items():
+            setattr(a, k, t.data_ptr() if t is not None else None)
+        cot = lambda g: g.contiguous() if g is not None and g.numel() else None
+        g_w, g_xyz, g_rot, g_scale = cot(g_w), cot(g_xyz) if blend else None, cot(g_rot) if blend else None, cot(g_scale) if blend else None
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_radius = new(m)
+        g_weight = new(m) if keep["node_weight"] is not None else None
+        g_trans, g_nrot, g_nscale = (new(m, 3), new(m, 4), new(m, 3)) if blend else (None, None, None)
+        g_frame = new(m, 3, 3) if blend and local_frame else None
+        lib = _lib()
+        ws = torch.empty((lib.gsr_node_blend_workspace_size(n, m),), dtype=torch.uint8, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_backward(ctypes.byref(a), w.data_ptr(), dist.data_ptr(), idx.data_ptr(), p(g_xyz), p(g_rot), p(g_scale),
+                                             p(g_w), p(g_trans), p(g_nrot), p(g_nscale), p(g_frame), p(g_radius), p(g_weight), ws.data_ptr(),
+                                             _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_backward")
+        # inputs: x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, node_frame, K, local_frame, residual
+        return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_frame, None, None, None
+
+
+def _checked(t, name, shape):
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def cal_nn_weight(x, nodes, node_radius, node_weight=None, K: int = 3):
+    """ControlNodeWarp.cal_nn_weight (:981-1011, gs_kernel=True): node_radius = exp(_node_radius) [M], node_weight =
+    sigmoid(_node_weight) [M] or [M, 1] (None: with_node_weight False).  Returns (nn_weight [N, K], nn_dist [N, K], nn_idx [N, K])
+    with gradients to node_radius / node_weight."""
+    w, dist, idx, *_ = _NodeBlend.apply(x, None, nodes, node_radius, _flat(node_weight, node_radius), None, None, None, None, K, False, True)
+    return w, dist, idx
+
+
+def _flat(node_weight, like):
+    return None if node_weight is None else node_weight.reshape(like.shape)
+
+
+def node_blend(x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation=None, K: int = 3,
+               d_rot_as_res: bool = True):
+    """The body of ControlNodeWarp.forward (:1199-1258) after node_deform: blends the K nearest nodes' predictions.
+    local_rotation [M, 4] (node_attrs['local_rotation'], :1207) selects the local-frame translation; None = the global one.
+    Returns {'d_xyz', 'd_rotation', 'd_scaling', 'nn_weight', 'nn_dist', 'nn_idx'}."""
+    frame = None
+    if local_rotation is not None:
+        bias = torch.tensor([1.0, 0.0, 0.0, 0.0], device=local_rotation.device)
+        frame = quaternion_to_matrix(local_rotation + bias)                   # :1207-1208, O(nodes): torch
+    w, dist, idx, d_xyz, d_rot, d_scale = _NodeBlend.apply(x, motion_mask, nodes, node_radius, _flat(node_weight, node_radius), node_trans,
+                                                           node_rot, node_scale, frame, K, frame is not None, d_rot_as_res)
+    return {"d_xyz": d_xyz, "d_rotation": d_rot, "d_scaling": d_scale, "nn_weight": w, "nn_dist": dist, "nn_idx": idx}

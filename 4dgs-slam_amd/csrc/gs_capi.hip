@@ -18,6 +18,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/gs_rasterizer.h"
 #include "../../include/simple_knn.h"
@@ -25,6 +26,8 @@
 #include "gs_knn.h"
 #include "gs_loss.h"
 #include "gs_hexplane.h"
+#include "gs_linear.h"
+#include "gs_nodes.h"
 #include "../../include/slam_losses.h"
 
 namespace gsr {
@@ -870,6 +873,137 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
     if (n == 0) return 0;
     if (!dL_dfeatures) { g_last_error = "gsr_hexplane_backward: null dL_dfeatures"; return GSR_ERR_INVALID_ARGUMENT; }
     hexplane_launch<true>(*field, n, (hipStream_t)stream_, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// ---- dense-layer weight gradient (include/deformation_field.h) -----------------------------------------------------------------
+static void wgrad_plan(int64_t n, int64_t* chunk, int* nblocks)
+{
+    int64_t c = (n + 511) / 512;                                  // ~512 blocks along the reduction (2 per CU)
+    c = ((c + 4 * WGRAD_UNROLL - 1) / (4 * WGRAD_UNROLL)) * (4 * WGRAD_UNROLL);
+    if (c < 64) c = 64;
+    *chunk = c;
+    *nblocks = (int)((n + c - 1) / c);
+}
+
+size_t gsr_linear_wgrad_workspace_size(int64_t n, int in_dim, int out_dim)
+{
+    if (n <= 0 || in_dim <= 0 || out_dim <= 0) return 256;
+    int64_t chunk; int nb;
+    wgrad_plan(n, &chunk, &nb);
+    return (size_t)nb * out_dim * (in_dim + 1) * sizeof(float) + 256;
+}
+
+int gsr_linear_wgrad(int64_t n, int in_dim, int out_dim, const float* x, int64_t x_stride, const float* dy, int64_t dy_stride,
+                     float* dW, float* db, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || in_dim <= 0 || in_dim > 128 || out_dim <= 0 || (n > 0 && (!x || !dy || !workspace)) || (!dW && !db)) {
+        g_last_error = "gsr_linear_wgrad: null / invalid argument (in_dim must be 1..128)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) {
+        if (dW) GSR_HIP_CHECK(hipMemsetAsync(dW, 0, (size_t)out_dim * in_dim * sizeof(float), stream));
+        if (db) GSR_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)out_dim * sizeof(float), stream));
+        return 0;
+    }
+    int64_t chunk; int nb;
+    wgrad_plan(n, &chunk, &nb);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const dim3 grid((unsigned)nb, (unsigned)((out_dim + 63) / 64)), block(WGRAD_BLOCK);
+    const int nt = (in_dim + 15) / 16;
+    switch (nt) {
+#define GSR_WGRAD_CASE(NT) case NT: hipLaunchKernelGGL((linear_wgrad_kernel<NT>), grid, block, 0, stream, n, in_dim, out_dim, x, x_stride, dy, dy_stride, partial, chunk); break;
+        GSR_WGRAD_CASE(1) GSR_WGRAD_CASE(2) GSR_WGRAD_CASE(3) GSR_WGRAD_CASE(4) GSR_WGRAD_CASE(5) GSR_WGRAD_CASE(6) GSR_WGRAD_CASE(7) GSR_WGRAD_CASE(8)
+#undef GSR_WGRAD_CASE
+    }
+    const int per = out_dim * (in_dim + 1);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((per + WRED_OUT - 1) / WRED_OUT), dim3(WRED_OUT * WRED_SLICES), 0, stream, nb, in_dim, out_dim,
+                       (const float*)partial, dW, db);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// ---- SC-GS control nodes (include/control_nodes.h) ------------------------------------------------------------------------------
+int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || m < 0 || D < 1 || D > GSR_KNN_MAX_DIM || K < 1 || K > GSR_KNN_MAX_K || (n > 0 && (!p1 || !dist2 || !idx)) || (m > 0 && !p2)) {
+        g_last_error = "gsr_knn_points: null / invalid argument (1 <= D <= 32, 1 <= K <= 32)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return 0;
+    const int64_t rows = std::min<int64_t>((int64_t)(NODE_CHUNK * 3 / D), std::max<int64_t>(m, 1));
+    const size_t lds = (size_t)rows * D * sizeof(float);
+    const dim3 grid((unsigned)((n + NODE_BLOCK - 1) / NODE_BLOCK)), block(NODE_BLOCK);
+#define GSR_KNN_LAUNCH(DMAX, KMAX) hipLaunchKernelGGL((knn_points_kernel<DMAX, KMAX>), grid, block, lds, stream, n, m, D, K, p1, p2, dist2, idx)
+#define GSR_KNN_K(DMAX) do { if (K <= 4) GSR_KNN_LAUNCH(DMAX, 4); else if (K <= 8) GSR_KNN_LAUNCH(DMAX, 8); else if (K <= 16) GSR_KNN_LAUNCH(DMAX, 16); else GSR_KNN_LAUNCH(DMAX, 32); } while (0)
+    if (D <= 4) GSR_KNN_K(4); else if (D <= 8) GSR_KNN_K(8); else GSR_KNN_K(32);
+#undef GSR_KNN_K
+#undef GSR_KNN_LAUNCH
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int node_blend_check(const gsr_node_blend* a, const char* who)
+{
+    static thread_local std::string msg;
+    auto fail = [&](const char* what) { msg = std::string(who) + ": " + what; g_last_error = msg.c_str(); return GSR_ERR_INVALID_ARGUMENT; };
+    if (!a) return fail("null descriptor");
+    if (a->n < 0 || a->m < 1) return fail("n < 0 or no control nodes");
+    if (a->K < 1 || a->K > GSR_BLEND_MAX_K) return fail("K outside 1..8");
+    if (a->node_stride < 3) return fail("node_stride < 3");
+    if (a->n > 0 && !a->x) return fail("null x");
+    if (!a->nodes || !a->node_radius) return fail("null nodes / node_radius");
+    if (a->node_trans && (!a->node_rot || !a->node_scale)) return fail("node_trans without node_rot / node_scale");
+    if (a->node_trans && a->local_frame && !a->node_frame) return fail("local_frame without node_frame");
+    return 0;
+}
+
+int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_dist, int64_t* nn_idx, float* d_xyz, float* d_rotation,
+                           float* d_scaling, void* stream_)
+{
+    if (int rc = node_blend_check(a, "gsr_node_blend_forward")) return rc;
+    if (a->n == 0) return 0;
+    if (!nn_weight || !nn_dist || !nn_idx || (a->node_trans && (!d_xyz || !d_rotation || !d_scaling))) {
+        g_last_error = "gsr_node_blend_forward: null output"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(node_blend_fwd_kernel, dim3((unsigned)((a->n + NODE_BLOCK - 1) / NODE_BLOCK)), dim3(NODE_BLOCK), 0, (hipStream_t)stream_, *a,
+                       nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int node_bwd_blocks(int64_t n) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, (n + NODE_BLOCK - 1) / NODE_BLOCK)); }
+
+size_t gsr_node_blend_workspace_size(int64_t n, int32_t m)
+{
+    if (m < 1) return 256;
+    const size_t rows = m <= NODE_LDS_MAX ? (size_t)node_bwd_blocks(n) : 1;
+    return rows * (size_t)m * NODE_GRAD * sizeof(float) + 256;
+}
+
+int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
+                            const float* g_xyz, const float* g_rotation, const float* g_scaling, const float* g_nn_weight,
+                            float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
+                            float* g_node_weight, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = node_blend_check(a, "gsr_node_blend_backward")) return rc;
+    if (!workspace || (a->n > 0 && (!nn_weight || !nn_dist || !nn_idx))) { g_last_error = "gsr_node_blend_backward: null workspace / saved tensors"; return GSR_ERR_INVALID_ARGUMENT; }
+    float* partial = reinterpret_cast<float*>(workspace);
+    const int total = a->m * NODE_GRAD;
+    const bool use_lds = a->m <= NODE_LDS_MAX;
+    const int G = use_lds ? node_bwd_blocks(a->n) : 1;
+    if (!use_lds || a->n == 0) GSR_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)total * sizeof(float), stream));
+    if (a->n > 0) {
+        const int blocks = node_bwd_blocks(a->n);
+        hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
+                           nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0);
+    }
+    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, G, a->m, (const float*)partial, g_node_trans,
+                       g_node_rot, g_node_scale, g_node_frame, g_node_radius, g_node_weight);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

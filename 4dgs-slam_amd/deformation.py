@@ -4,14 +4,78 @@ names (a reference state dict loads unchanged) and return values:  (means3D, sca
 
 What differs is where the work happens: the HexPlane field -- 24 grid_sample calls, 20 products and a concat per call in the
 reference (gaussian_splatting/utils/hexplane.py:81-112) -- is one fused HIP launch per direction (hexplane.py ->
-include/deformation_field.h); the small dense layers stay nn.Linear, i.e. library GEMMs.  The sin/cos positional embeddings the
+include/deformation_field.h); the dense layers keep library GEMMs for the forward and input-gradient products and use the
+library's split-K MFMA kernel for the weight gradients (PointwiseLinear below).  The sin/cos positional embeddings the
 reference computes and then discards (deform_network.forward_dynamic builds [n, 63] / [n, 15] / [n, 20] embeddings of which only
 the leading raw columns are read, utils/deformation.py:198-213,78,113,122,132) are not computed."""
+import ctypes
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 import torch.nn.init as init
 
+from diff_gaussian_rasterization import _C
 from hexplane import HexPlaneField
+
+_lib_cache = None
+
+
+def _lib():
+    global _lib_cache
+    if _lib_cache is None:
+        lib = _C.load_library()
+        i64, vp, i = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        lib.gsr_linear_wgrad_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_linear_wgrad_workspace_size.argtypes = [i64, i, i]
+        lib.gsr_linear_wgrad.restype = i
+        lib.gsr_linear_wgrad.argtypes = [i64, i, i, vp, i64, vp, i64, vp, vp, vp, vp]
+        _lib_cache = lib
+    return _lib_cache
+
+
+class _PointwiseLinear(torch.autograd.Function):
+    """y = x Wᵀ + b over a long batch of points.  Forward and the input gradient are library GEMMs; the WEIGHT gradient --
+    a 64x128-or-smaller output reduced over every point, the shape the vendor GEMM handles worst (3.4 of the 4.5 ms the MLP took
+    forward+backward at 200k points) -- is the split-K MFMA kernel of include/deformation_field.h (gsr_linear_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            if gy.stride(1) != 1 or gy.stride(0) < gy.shape[1]:      # e.g. an expanded cotangent of sum()
+                gy = gy.contiguous()
+            n, in_dim, out_dim = x.shape[0], x.shape[1], gy.shape[1]
+            lib = _lib()
+            gw = torch.empty((out_dim, in_dim), dtype=torch.float32, device=x.device)
+            gb = torch.empty((out_dim,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws = torch.empty((lib.gsr_linear_wgrad_workspace_size(n, in_dim, out_dim),), dtype=torch.uint8, device=x.device)
+            with torch.cuda.device(x.device):
+                rc = lib.gsr_linear_wgrad(n, in_dim, out_dim, x.data_ptr(), x.stride(0), gy.data_ptr(), gy.stride(0), gw.data_ptr(),
+                                          gb.data_ptr() if gb is not None else None, ws.data_ptr(), _C._stream(x.device))
+            if rc < 0:
+                _C._err(lib, rc, "gsr_linear_wgrad")
+        return gx, gw, gb
+
+
+class PointwiseLinear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys, same value) whose weight gradient runs on the MI355X library when the
+    input is a 2-D fp32 batch of points on a HIP device with at most 128 features; anything else takes nn.Linear's own path."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] <= 128 and x.shape[0] > 0 and torch.is_grad_enabled():
+            return _PointwiseLinear.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
 
 
 def poc_fre(input_data, poc_buf):
@@ -28,7 +92,7 @@ def initialize_weights(m):
 
 
 def _head(width, out_dim):
-    return nn.Sequential(nn.ReLU(), nn.Linear(width, width), nn.ReLU(), nn.Linear(width, out_dim))
+    return nn.Sequential(nn.ReLU(), PointwiseLinear(width, width), nn.ReLU(), PointwiseLinear(width, out_dim))
 
 
 class Deformation(nn.Module):
@@ -58,9 +122,9 @@ class Deformation(nn.Module):
 
     def create_net(self):
         grid_out_dim = self.grid.feat_dim * 3 if self.grid_pe != 0 else self.grid.feat_dim
-        layers = [nn.Linear(4 if self.no_grid else grid_out_dim, self.W)]
+        layers = [PointwiseLinear(4 if self.no_grid else grid_out_dim, self.W)]
         for _ in range(self.D - 1):
-            layers += [nn.ReLU(), nn.Linear(self.W, self.W)]
+            layers += [nn.ReLU(), PointwiseLinear(self.W, self.W)]
         self.feature_out = nn.Sequential(*layers).to(self.device)
         self.pos_deform = _head(self.W, 3).to(self.device)
         self.scales_deform = _head(self.W, 3).to(self.device)

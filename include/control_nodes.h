@@ -1,0 +1,72 @@
+/*
+ * control_nodes.h -- C ABI of the SC-GS control-node warp (libgs_rasterizer_hip.so), SURVEY.md 8(f) rank 3, second half.
+ *
+ * The SLAM back-end moves its dynamic Gaussians with a sparse set of control nodes (utils/slam_backend.py:361-371 ->
+ * gaussian_splatting/scene/deform_model.py:33 -> utils/time_utils.py ControlNodeWarp.forward :1192-1296): every Gaussian finds
+ * its K nearest nodes (pytorch3d.ops.knn_points, :998), weights them with a Gaussian RBF of the node radius times a per-node
+ * weight, normalised over the K (:1000-1006), and blends the nodes' translation / rotation / scale predictions (:1206-1258).
+ * pytorch3d is an un-vendored CUDA dependency of the reference that does not exist on ROCm; this header replaces it on this
+ * path and fuses the ~20 gather / elementwise launches around it (and their autograd twins) into one launch per direction.
+ *
+ * All pointers are DEVICE pointers, fp32 unless stated, contiguous.  Returns 0 or a negative GSR_ERR_* code (gs_rasterizer.h).
+ */
+#ifndef CONTROL_NODES_H_INCLUDED
+#define CONTROL_NODES_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_KNN_MAX_K 32
+#define GSR_KNN_MAX_DIM 32
+#define GSR_BLEND_MAX_K 8
+
+/* pytorch3d.ops.knn_points(p1[None], p2[None], K=K) for one batch element (the only form the reference calls,
+ * utils/time_utils.py:998,1028,1099,1109,1183; utils/deform_utils.py:49,74,87): for each of the n rows of p1 [n, D] the K rows of
+ * p2 [m, D] with the smallest SQUARED Euclidean distance sum_d (p1 - p2)^2, ascending; among equal distances the lower index
+ * first.  dist2 [n, K] fp32, idx [n, K] int64.  If m < K the missing entries are dist2 = 0, idx = 0 (pytorch3d's padding).
+ * 1 <= K <= 32, 1 <= D <= 32. */
+int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream);
+
+typedef struct gsr_node_blend {
+    int64_t n;                    /* Gaussians */
+    int32_t m;                    /* control nodes */
+    int32_t K;                    /* neighbours per Gaussian, 1 .. GSR_BLEND_MAX_K (self.K, arguments/__init__.py: 3) */
+    int32_t local_frame;          /* :1206-1212: rotate the offset to the node by the node's local frame before translating */
+    int32_t rot_as_residual;      /* d_rot_as_res (:1254-1256); 0 = the absolute form with the (1,0,0,0) bias (:1218-1231) */
+    int32_t node_stride;          /* floats per row of `nodes` (3 + hyper_dim); the first 3 are the position */
+    int32_t reserved;
+    const float* x;               /* [n, 3]   Gaussian positions (detached in the reference, :1196) */
+    const float* motion_mask;     /* [n]      or NULL (= 1) */
+    const float* nodes;           /* [m, node_stride] */
+    const float* node_radius;     /* [m]      exp(_node_radius) (:893-894) */
+    const float* node_weight;     /* [m]      sigmoid(_node_weight) (:897-898), or NULL (with_node_weight False) */
+    const float* node_trans;      /* [m, 3]   node_attrs['d_xyz']; NULL = weights only (cal_nn_weight on its own) */
+    const float* node_rot;        /* [m, 4]   node_attrs['d_rotation'] */
+    const float* node_scale;      /* [m, 3]   node_attrs['d_scaling'] */
+    const float* node_frame;      /* [m, 9]   quaternion_to_matrix(node_attrs['local_rotation'] + (1,0,0,0)), row-major; local_frame only */
+} gsr_node_blend;
+
+/* Forward.  nn_weight / nn_dist [n, K] fp32 and nn_idx [n, K] int64 are the three results of cal_nn_weight (:981-1011) and are
+ * also what the backward call reads; d_xyz [n,3], d_rotation [n,4], d_scaling [n,3] may be NULL when node_trans is NULL. */
+int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_dist, int64_t* nn_idx, float* d_xyz, float* d_rotation,
+                           float* d_scaling, void* stream);
+
+/* Backward for the cotangents g_xyz [n,3], g_rotation [n,4], g_scaling [n,3] (each may be NULL = 0) and, optionally, a direct
+ * cotangent of nn_weight (g_nn_weight [n,K] or NULL).  WRITES the node gradients (any may be NULL to skip):
+ *   g_node_trans [m,3], g_node_rot [m,4], g_node_scale [m,3], g_node_frame [m,9], g_node_radius [m], g_node_weight [m].
+ * x and the node positions receive no gradient (both are detached on this path, :993,1196).  Deterministic: block partials in
+ * `workspace` (gsr_node_blend_workspace_size bytes) summed in a fixed order. */
+size_t gsr_node_blend_workspace_size(int64_t n, int32_t m);
+int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
+                            const float* g_xyz, const float* g_rotation, const float* g_scaling, const float* g_nn_weight,
+                            float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
+                            float* g_node_weight, char* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

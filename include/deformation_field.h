@@ -63,6 +63,17 @@ int gsr_hexplane_forward(const gsr_hexplane_field* field, int64_t n, const float
 int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
                           int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, void* stream);
 
+/* ---- weight gradient of the deformation MLP's dense layers ----------------------------------------------------------------
+ * utils/deformation.py:58-70 builds the network from nn.Linear layers (width 64, inputs <= 128) applied to every point; their
+ * weight gradients are GEMMs with a tiny output and a reduction over all n points, the shape vendor GEMMs handle worst.
+ *   dW[out_dim][in_dim] = dYᵀ X        (WRITTEN, row-major like nn.Linear.weight.grad)
+ *   db[out_dim]         = column sums of dY   (WRITTEN; may be NULL)
+ * X is [n, in_dim] with row stride x_stride floats, dY is [n, out_dim] with row stride dy_stride.  in_dim <= 128 per call.
+ * The result is deterministic (block partials in `workspace`, summed in a fixed order). */
+size_t gsr_linear_wgrad_workspace_size(int64_t n, int in_dim, int out_dim);
+int gsr_linear_wgrad(int64_t n, int in_dim, int out_dim, const float* x, int64_t x_stride, const float* dy, int64_t dy_stride,
+                     float* dW, float* db, char* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ from diff_gaussian_rasterization import _C
 
 def _declared_symbols():
     syms = set()
-    for h in ("gs_rasterizer.h", "simple_knn.h", "slam_losses.h"):
+    for h in sorted(f for f in os.listdir(os.path.join(REPO, "include")) if f.endswith(".h")):
         txt = open(os.path.join(REPO, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         syms |= set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", txt))
@@ -55,6 +55,24 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     lib.gsr_adam_step.argtypes = [i, vp, vp]
     assert lib.gsr_adam_step(9, None, None) == -1 and lib.gsr_adam_step(0, None, None) == 0
     assert lib.gsr_l1_loss_workspace_size() > 0
+    # deformation_field.h
+    import hexplane
+    i64 = ctypes.c_int64
+    hl = hexplane._lib()
+    field = hexplane._Field()
+    assert hl.gsr_hexplane_forward(None, 4, None, 3, None, 1, None, None) == -1 and b"null field" in lib.gsr_last_error()
+    field.num_levels, field.feat_dim = 0, 32
+    assert hl.gsr_hexplane_forward(ctypes.byref(field), 4, None, 3, None, 1, None, None) == -1 and b"num_levels" in lib.gsr_last_error()
+    field.num_levels, field.feat_dim = 1, 12
+    assert hl.gsr_hexplane_backward(ctypes.byref(field), 4, None, 3, None, 1, None, None, None) == -1 and b"feat_dim" in lib.gsr_last_error()
+    field.feat_dim = 32
+    assert hl.gsr_hexplane_forward(ctypes.byref(field), 4, None, 3, None, 1, None, None) == -1 and b"resolution" in lib.gsr_last_error()
+    lib.gsr_linear_wgrad.restype = i
+    lib.gsr_linear_wgrad.argtypes = [i64, i, i, vp, i64, vp, i64, vp, vp, vp, vp]
+    assert lib.gsr_linear_wgrad(10, 129, 4, None, 129, None, 4, None, None, None, None) == -1 and b"gsr_linear_wgrad" in lib.gsr_last_error()
+    lib.gsr_linear_wgrad_workspace_size.restype = ctypes.c_size_t
+    lib.gsr_linear_wgrad_workspace_size.argtypes = [i64, i, i]
+    assert lib.gsr_linear_wgrad_workspace_size(200000, 128, 64) >= 64 * 129 * 4
 
 
 def test_public_names_and_settings_fields_match_reference():

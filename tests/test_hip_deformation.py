@@ -248,3 +248,30 @@ def test_render_dynamic_through_the_deformation_network():
     assert all(g is not None for g in grid_g) and sum(float(g.abs().sum()) for g in grid_g) > 0
     assert pc._xyz.grad is not None and torch.isfinite(pc._xyz.grad).all()
     assert float(pc._deformation.deformation_net.pos_deform[3].weight.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("n,in_dim,out_dim", [(1, 64, 3), (5, 4, 64), (63, 128, 64), (64, 64, 4), (1000, 100, 48), (4097, 128, 70),
+                                              (200003, 128, 64), (200003, 64, 3)])
+def test_linear_weight_gradient_kernel(n, in_dim, out_dim):
+    """gsr_linear_wgrad (split-K fp32 MFMA) against the same products in fp64; strided rows; deterministic."""
+    torch.manual_seed(n + in_dim)
+    wide = torch.randn(n, in_dim + 7, device=DEV)
+    x = wide[:, 3:3 + in_dim]                                           # row stride in_dim + 7
+    lin = deformation.PointwiseLinear(in_dim, out_dim).to(DEV)
+    y = lin(x.requires_grad_(False))
+    gy = torch.randn(n, out_dim, device=DEV)
+    y.backward(gy)
+    gw64 = gy.double().t() @ x.double()
+    gb64 = gy.double().sum(0)
+    scale = (gy.double().abs().t() @ x.double().abs()).clamp_min(1e-30)   # sum |a b|: the natural unit of the rounding error
+    assert float(((lin.weight.grad.double() - gw64).abs() / scale).max()) < 2e-6
+    assert float(((lin.bias.grad.double() - gb64).abs() / gy.double().abs().sum(0).clamp_min(1e-30)).max()) < 2e-6
+    g1 = lin.weight.grad.clone()
+    lin.weight.grad = None
+    lin.bias.grad = None
+    lin(x).backward(gy)
+    assert torch.equal(g1, lin.weight.grad)                            # fixed summation order
+    # value and input gradient are the library GEMM
+    x2 = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(x2, lin.weight, lin.bias)
+    assert torch.allclose(lin(x2), ref)

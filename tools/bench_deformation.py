@@ -51,6 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200000)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only-network", action="store_true", help="time only the whole network fwd+bwd (for profiling)")
     ap.add_argument("--sorted", action="store_true", help="points in Morton-like (cell) order instead of random order")
     a = ap.parse_args()
     dev = "cuda"
@@ -86,6 +87,14 @@ def main():
         pts.grad = None
 
     res = {"n": a.n, "sorted": a.sorted, "unit": "us"}
+    if a.only_network:
+        def net_fb0():
+            zero()
+            o = net(pts, scales, rots, opac, shs, tim)
+            (o[0].sum() + o[1].sum() + o[2].sum()).backward()
+        res["network_fwdbwd_fused_field"] = round(timeit(net_fb0, a.iters), 1)
+        print(json.dumps(res))
+        return
     with torch.no_grad():
         res["field_fwd_fused"] = timeit(lambda: field(pts, tim), a.iters)
         res["field_fwd_torch"] = timeit(lambda: torch_field(pts, tim, field.aabb, ref_levels), a.iters)
