@@ -2,9 +2,9 @@
 utils/time_utils.py ControlNodeWarp: `knn_points` (the pytorch3d.ops routine the reference imports, which has no ROCm build),
 `cal_nn_weight` (:981-1011) and `node_blend`, the body of ControlNodeWarp.forward (:1192-1258) after the node MLP.
 
-The per-NODE work of the reference (the node MLP, quaternion_to_matrix of 512 local rotations, exp / sigmoid of the node radius and
-weight) stays in torch: it is O(nodes), differentiable there, and feeds this module's inputs; everything O(Gaussians) is one HIP
-launch per direction.  There is no CPU path."""
+The node MLP stays in torch (O(nodes) library GEMMs).  Everything else -- the K nearest nodes, exp / sigmoid of the raw node
+radius / weight (:893-898), quaternion_to_matrix of the local rotations (:115-133,1207-1208), the RBF weights, the blend, and all
+of their chain rules -- is one HIP launch forward and three backward.  There is no CPU path."""
 import ctypes
 from collections import namedtuple
 
@@ -18,10 +18,10 @@ _KNN = namedtuple("KNN", "dists idx knn")
 
 class _Blend(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int64), ("m", ctypes.c_int32), ("K", ctypes.c_int32), ("local_frame", ctypes.c_int32),
-                ("rot_as_residual", ctypes.c_int32), ("node_stride", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("rot_as_residual", ctypes.c_int32), ("node_stride", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("x", ctypes.c_void_p), ("motion_mask", ctypes.c_void_p), ("nodes", ctypes.c_void_p), ("node_radius", ctypes.c_void_p),
                 ("node_weight", ctypes.c_void_p), ("node_trans", ctypes.c_void_p), ("node_rot", ctypes.c_void_p),
-                ("node_scale", ctypes.c_void_p), ("node_frame", ctypes.c_void_p)]
+                ("node_scale", ctypes.c_void_p), ("node_frame", ctypes.c_void_p), ("node_local_rotation", ctypes.c_void_p)]
 
 
 _lib_cache = None
@@ -87,19 +87,36 @@ def quaternion_to_matrix(q):
     return o.reshape(q.shape[:-1] + (3, 3))
 
 
+RADIUS_IS_LOG, WEIGHT_IS_LOGIT = 1, 2
+
+
 class _NodeBlend(torch.autograd.Function):
     """(nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling) from per-node tensors; gradients to node_radius, node_weight,
-    node_trans, node_rot, node_scale, node_frame.  x and nodes are constants of the op (detached in the reference)."""
+    node_trans, node_rot, node_scale, local_rotation.  x and nodes are constants of the op (detached in the reference)."""
 
     @staticmethod
-    def forward(ctx, x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, node_frame, K, local_frame,
-                rot_as_residual):
-        x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius")
-        n, m = x.shape[0], nodes.shape[0]
-        if x.dim() != 2 or x.shape[1] != 3 or nodes.dim() != 2 or nodes.shape[1] < 3:
-            raise ValueError(f"node blend expects x [N, 3] and nodes [M, >=3], got {tuple(x.shape)} and {tuple(nodes.shape)}")
+    def forward(ctx, x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation, K,
+                rot_as_residual, raw):
         if not 1 <= K <= BLEND_MAX_K:
             raise ValueError(f"node blend: K = {K} outside 1..{BLEND_MAX_K}")
+        glue = _C._glue
+        if glue is not None and hasattr(glue, "node_blend_forward"):      # native host glue (csrc/torch_glue.cpp): ~10x less host time
+            _C._require_device(x, "x")
+            det = lambda t: None if t is None else t.detach()
+            args = (x.detach(), det(motion_mask), nodes.detach(), node_radius.detach(), det(node_weight), det(node_trans), det(node_rot),
+                    det(node_scale), det(local_rotation) if node_trans is not None else None, int(K), bool(rot_as_residual),
+                    (RADIUS_IS_LOG | WEIGHT_IS_LOGIT) if raw else 0)
+            try:
+                w, dist, idx, d_xyz, d_rot, d_scale = glue.node_blend_forward(*args, _C._stream(x.device))
+            except RuntimeError as e:
+                raise ValueError(str(e)) from e
+            ctx.glue_args, ctx.saved = args, (w, dist, idx)
+            ctx.mark_non_differentiable(dist, idx)
+            return w, dist, idx, d_xyz, d_rot, d_scale
+        x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius").reshape(-1)
+        if x.dim() != 2 or x.shape[1] != 3 or nodes.dim() != 2 or nodes.shape[1] < 3:
+            raise ValueError(f"node blend expects x [N, 3] and nodes [M, >=3], got {tuple(x.shape)} and {tuple(nodes.shape)}")
+        n, m = x.shape[0], nodes.shape[0]
         blend = node_trans is not None
         opt = lambda t, name, shape: None if t is None else _checked(_f32(t, name), name, shape)
         motion_mask = opt(motion_mask, "motion_mask", None)
@@ -110,10 +127,12 @@ class _NodeBlend(torch.autograd.Function):
             raise ValueError("node_radius / node_weight must have one value per node")
         node_trans, node_rot = opt(node_trans, "node_trans", (m, 3)), opt(node_rot, "node_rot", (m, 4))
         node_scale = opt(node_scale, "node_scale", (m, 3))
-        node_frame = opt(node_frame, "node_frame", (m, 3, 3)) if local_frame and blend else None
-        a = _Blend(n=n, m=m, K=K, local_frame=int(bool(local_frame)), rot_as_residual=int(bool(rot_as_residual)), node_stride=nodes.shape[1])
+        local_rotation = opt(local_rotation, "local_rotation", (m, 4)) if blend else None
         keep = dict(x=x, motion_mask=motion_mask, nodes=nodes, node_radius=node_radius, node_weight=node_weight, node_trans=node_trans,
-                    node_rot=node_rot, node_scale=node_scale, node_frame=node_frame)
+                    node_rot=node_rot, node_scale=node_scale, node_local_rotation=local_rotation)
+        scalars = dict(n=n, m=m, K=K, local_frame=int(local_rotation is not None), rot_as_residual=int(bool(rot_as_residual)),
+                       node_stride=nodes.shape[1], flags=(RADIUS_IS_LOG | WEIGHT_IS_LOGIT) if raw else 0)
+        a = _Blend(**scalars)
         for k, t in keep.items():
             setattr(a, k, t.data_ptr() if t is not None else None)
         dev = x.device
@@ -127,20 +146,25 @@ class _NodeBlend(torch.autograd.Function):
                                             *(o.data_ptr() if o is not None else None for o in outs), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_node_blend_forward")
-        ctx.keep, ctx.args = keep, (n, m, K, bool(local_frame), bool(rot_as_residual), nodes.shape[1])
-        ctx.saved = (w, dist, idx)
+        ctx.keep, ctx.scalars, ctx.saved, ctx.glue_args = keep, scalars, (w, dist, idx), None
         ctx.mark_non_differentiable(dist, idx)
         empty = torch.empty(0, device=dev)
         return (w, dist, idx, *(o if o is not None else empty for o in outs))
 
     @staticmethod
     def backward(ctx, g_w, _g_dist, _g_idx, g_xyz, g_rot, g_scale):
-        n, m, K, local_frame, rot_as_residual, stride = ctx.args
-        keep = ctx.keep
+        if ctx.glue_args is not None:
+            w, dist, idx = ctx.saved
+            some = lambda g: g if g is not None and g.numel() else None
+            g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local = _C._glue.node_blend_backward(
+                *ctx.glue_args, w, dist, idx, some(g_w), some(g_xyz), some(g_rot), some(g_scale), _C._stream(w.device))
+            return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local, None, None, None
+        keep, sc = ctx.keep, ctx.scalars
+        n, m = sc["n"], sc["m"]
         w, dist, idx = ctx.saved
         dev = w.device
         blend = keep["node_trans"] is not None
-        a = _Blend(n=n, m=m, K=K, local_frame=int(local_frame), rot_as_residual=int(rot_as_residual), node_stride=stride)
+        a = _Blend(**sc)
         for k, t in keep.items():
             setattr(a, k, t.data_ptr() if t is not None else None)
         cot = lambda g: g.contiguous() if g is not None and g.numel() else None
@@ -149,18 +173,18 @@ class _NodeBlend(torch.autograd.Function):
         g_radius = new(m)
         g_weight = new(m) if keep["node_weight"] is not None else None
         g_trans, g_nrot, g_nscale = (new(m, 3), new(m, 4), new(m, 3)) if blend else (None, None, None)
-        g_frame = new(m, 3, 3) if blend and local_frame else None
+        g_local = new(m, 4) if keep["node_local_rotation"] is not None else None
         lib = _lib()
         ws = torch.empty((lib.gsr_node_blend_workspace_size(n, m),), dtype=torch.uint8, device=dev)
         p = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(dev):
             rc = lib.gsr_node_blend_backward(ctypes.byref(a), w.data_ptr(), dist.data_ptr(), idx.data_ptr(), p(g_xyz), p(g_rot), p(g_scale),
-                                             p(g_w), p(g_trans), p(g_nrot), p(g_nscale), p(g_frame), p(g_radius), p(g_weight), ws.data_ptr(),
+                                             p(g_w), p(g_trans), p(g_nrot), p(g_nscale), p(g_local), p(g_radius), p(g_weight), ws.data_ptr(),
                                              _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_node_blend_backward")
-        # inputs: x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, node_frame, K, local_frame, residual
-        return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_frame, None, None, None
+        # inputs: x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation, K, residual, raw
+        return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local, None, None, None
 
 
 def _checked(t, name, shape):
@@ -169,27 +193,25 @@ def _checked(t, name, shape):
     return t
 
 
-def cal_nn_weight(x, nodes, node_radius, node_weight=None, K: int = 3):
-    """ControlNodeWarp.cal_nn_weight (:981-1011, gs_kernel=True): node_radius = exp(_node_radius) [M], node_weight =
-    sigmoid(_node_weight) [M] or [M, 1] (None: with_node_weight False).  Returns (nn_weight [N, K], nn_dist [N, K], nn_idx [N, K])
+def cal_nn_weight(x, nodes, node_radius, node_weight=None, K: int = 3, raw: bool = True):
+    """ControlNodeWarp.cal_nn_weight (:981-1011, gs_kernel=True).  raw=True (default): node_radius / node_weight are the module's RAW
+    parameters _node_radius [M] / _node_weight [M, 1] and exp / sigmoid (:893-898) happen in the kernel; raw=False: they are the
+    activated properties.  node_weight None: with_node_weight False.  Returns (nn_weight [N, K], nn_dist [N, K], nn_idx [N, K] int64)
     with gradients to node_radius / node_weight."""
-    w, dist, idx, *_ = _NodeBlend.apply(x, None, nodes, node_radius, _flat(node_weight, node_radius), None, None, None, None, K, False, True)
+    w, dist, idx, *_ = _NodeBlend.apply(x, None, nodes, node_radius.reshape(-1), _flat(node_weight), None, None, None, None, K, True, raw)
     return w, dist, idx
 
 
-def _flat(node_weight, like):
-    return None if node_weight is None else node_weight.reshape(like.shape)
+def _flat(node_weight):
+    return None if node_weight is None else node_weight.reshape(-1)
 
 
 def node_blend(x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation=None, K: int = 3,
-               d_rot_as_res: bool = True):
-    """The body of ControlNodeWarp.forward (:1199-1258) after node_deform: blends the K nearest nodes' predictions.
+               d_rot_as_res: bool = True, raw: bool = True):
+    """The body of ControlNodeWarp.forward (:1199-1258) after node_deform: blends the K nearest nodes' predictions
+    node_trans = node_attrs['d_xyz'], node_rot = node_attrs['d_rotation'], node_scale = node_attrs['d_scaling'].
     local_rotation [M, 4] (node_attrs['local_rotation'], :1207) selects the local-frame translation; None = the global one.
-    Returns {'d_xyz', 'd_rotation', 'd_scaling', 'nn_weight', 'nn_dist', 'nn_idx'}."""
-    frame = None
-    if local_rotation is not None:
-        bias = torch.tensor([1.0, 0.0, 0.0, 0.0], device=local_rotation.device)
-        frame = quaternion_to_matrix(local_rotation + bias)                   # :1207-1208, O(nodes): torch
-    w, dist, idx, d_xyz, d_rot, d_scale = _NodeBlend.apply(x, motion_mask, nodes, node_radius, _flat(node_weight, node_radius), node_trans,
-                                                           node_rot, node_scale, frame, K, frame is not None, d_rot_as_res)
+    raw: see cal_nn_weight.  Returns {'d_xyz', 'd_rotation', 'd_scaling', 'nn_weight', 'nn_dist', 'nn_idx'}."""
+    w, dist, idx, d_xyz, d_rot, d_scale = _NodeBlend.apply(x, motion_mask, nodes, node_radius.reshape(-1), _flat(node_weight), node_trans,
+                                                           node_rot, node_scale, local_rotation, K, d_rot_as_res, raw)
     return {"d_xyz": d_xyz, "d_rotation": d_rot, "d_scaling": d_scale, "nn_weight": w, "nn_dist": dist, "nn_idx": idx}

@@ -939,7 +939,17 @@ int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const fl
     const dim3 grid((unsigned)((n + NODE_BLOCK - 1) / NODE_BLOCK)), block(NODE_BLOCK);
 #define GSR_KNN_LAUNCH(DMAX, KMAX) hipLaunchKernelGGL((knn_points_kernel<DMAX, KMAX>), grid, block, lds, stream, n, m, D, K, p1, p2, dist2, idx)
 #define GSR_KNN_K(DMAX) do { if (K <= 4) GSR_KNN_LAUNCH(DMAX, 4); else if (K <= 8) GSR_KNN_LAUNCH(DMAX, 8); else if (K <= 16) GSR_KNN_LAUNCH(DMAX, 16); else GSR_KNN_LAUNCH(DMAX, 32); } while (0)
-    if (D <= 4) GSR_KNN_K(4); else if (D <= 8) GSR_KNN_K(8); else GSR_KNN_K(32);
+    if (D <= 4) {
+#define GSR_KNN3(KMAX, EXACT) hipLaunchKernelGGL((knn_points3_kernel<KMAX, EXACT>), grid, block, 0, stream, n, m, D, K, p1, p2, dist2, idx)
+        switch (K) {
+        case 1: GSR_KNN3(1, true); break;
+        case 2: GSR_KNN3(2, true); break;
+        case 3: GSR_KNN3(3, true); break;
+        case 4: GSR_KNN3(4, true); break;
+        default: if (K <= 8) GSR_KNN3(8, false); else if (K <= 16) GSR_KNN3(16, false); else GSR_KNN3(32, false);
+        }
+#undef GSR_KNN3
+    } else if (D <= 8) GSR_KNN_K(8); else GSR_KNN_K(32);
 #undef GSR_KNN_K
 #undef GSR_KNN_LAUNCH
     GSR_HIP_CHECK(hipGetLastError());
@@ -957,7 +967,7 @@ static int node_blend_check(const gsr_node_blend* a, const char* who)
     if (a->n > 0 && !a->x) return fail("null x");
     if (!a->nodes || !a->node_radius) return fail("null nodes / node_radius");
     if (a->node_trans && (!a->node_rot || !a->node_scale)) return fail("node_trans without node_rot / node_scale");
-    if (a->node_trans && a->local_frame && !a->node_frame) return fail("local_frame without node_frame");
+    if (a->node_trans && a->local_frame && !a->node_frame && !a->node_local_rotation) return fail("local_frame without node_frame / node_local_rotation");
     return 0;
 }
 
@@ -969,8 +979,16 @@ int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_
     if (!nn_weight || !nn_dist || !nn_idx || (a->node_trans && (!d_xyz || !d_rotation || !d_scaling))) {
         g_last_error = "gsr_node_blend_forward: null output"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(node_blend_fwd_kernel, dim3((unsigned)((a->n + NODE_BLOCK - 1) / NODE_BLOCK)), dim3(NODE_BLOCK), 0, (hipStream_t)stream_, *a,
-                       nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling);
+    const dim3 grid((unsigned)((a->n + NODE_BLOCK - 1) / NODE_BLOCK)), block(NODE_BLOCK);
+#define GSR_BLEND_FWD(KMAX, EXACT) hipLaunchKernelGGL((node_blend_fwd_kernel<KMAX, EXACT>), grid, block, 0, (hipStream_t)stream_, *a, nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling)
+    switch (a->K) {
+    case 1: GSR_BLEND_FWD(1, true); break;
+    case 2: GSR_BLEND_FWD(2, true); break;
+    case 3: GSR_BLEND_FWD(3, true); break;
+    case 4: GSR_BLEND_FWD(4, true); break;
+    default: GSR_BLEND_FWD(GSR_BLEND_MAX_K, false);
+    }
+#undef GSR_BLEND_FWD
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -981,7 +999,7 @@ size_t gsr_node_blend_workspace_size(int64_t n, int32_t m)
 {
     if (m < 1) return 256;
     const size_t rows = m <= NODE_LDS_MAX ? (size_t)node_bwd_blocks(n) : 1;
-    return rows * (size_t)m * NODE_GRAD * sizeof(float) + 256;
+    return (rows + 1) * (size_t)m * NODE_GRAD * sizeof(float) + 256;   // block partials + the summed row
 }
 
 int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
@@ -1002,8 +1020,10 @@ int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, con
         hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
                            nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0);
     }
-    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, G, a->m, (const float*)partial, g_node_trans,
-                       g_node_rot, g_node_scale, g_node_frame, g_node_radius, g_node_weight);
+    float* summed = partial + (size_t)G * total;
+    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, G, total, (const float*)partial, summed);
+    hipLaunchKernelGGL(node_grad_finalize_kernel, dim3((a->m + 255) / 256), dim3(256), 0, stream, *a, (const float*)summed, g_node_trans, g_node_rot,
+                       g_node_scale, g_node_frame, g_node_radius, g_node_weight);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -17,7 +17,9 @@
 namespace gsr {
 
 constexpr int NODE_BLOCK = 256;
-constexpr int NODE_CHUNK = 4096;          // node positions staged per pass: 48 KB of LDS
+constexpr int NODE_CHUNK = 4096;          // generic kNN: floats*3 staged per pass (48 KB of LDS)
+constexpr int NODE_CHUNK4 = 2048;         // 3-D scans: nodes staged per pass as float4 (32 KB of LDS)
+constexpr int NODE_BATCH = 8;             // LDS reads in flight per lane in the 3-D scan
 constexpr int NODE_GRAD = 21;             // per node: trans 3, rot 4, scale 3, frame 9, radius 1, weight 1
 constexpr int NODE_LDS_MAX = 720;         // backward keeps m * 21 floats in LDS up to this many nodes (< 64 KB)
 
@@ -48,7 +50,100 @@ __device__ __forceinline__ float topk_worst(const float (&bd)[KMAX], const int K
     return w;
 }
 
+// the same with the list length known at compile time: K compare-swaps, no predicates, no branch
+template <int K>
+__device__ __forceinline__ void topk_insert_exact(float (&bd)[K], int (&bi)[K], float d, int j)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool sw = d < bd[k];
+        const float td = sw ? bd[k] : d;
+        const int ti = sw ? bi[k] : j;
+        bd[k] = sw ? d : bd[k];
+        bi[k] = sw ? j : bi[k];
+        d = td;
+        j = ti;
+    }
+}
+
+// Stage `cnt` 3-D points (row stride `stride` floats, at most NODE_CHUNK4) as float4 and pad the tail of the last batch with +inf,
+// which no list accepts.  Every lane of a wave then reads the same address: an LDS broadcast, NODE_BATCH reads in flight.
+__device__ __forceinline__ void stage_points3(float4* s_pos4, const float* __restrict__ pts, int64_t base, int cnt, int stride, int D)
+{
+    const int padded = (cnt + NODE_BATCH - 1) / NODE_BATCH * NODE_BATCH;
+    for (int e = threadIdx.x; e < padded; e += NODE_BLOCK) {
+        float4 p = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        if (e < cnt) {
+            const float* r = pts + (size_t)(base + e) * stride;
+            p = make_float4(r[0], D > 1 ? r[1] : 0.f, D > 2 ? r[2] : 0.f, D > 3 ? r[3] : 0.f);
+        }
+        s_pos4[e] = p;
+    }
+}
+
+// EXACT: the list length is KMAX (compile time) and every candidate goes through the branch-free insertion -- with a short list
+// that is cheaper than a divergent `if (d < worst)` some lane of the wave takes on most iterations anyway.  Otherwise K <= KMAX
+// is a run-time value and the insertion is guarded.
+template <int KMAX, bool EXACT, bool FOURTH>
+__device__ __forceinline__ void scan_points3(const float4* s_pos4, int cnt, int base, const float (&x)[4], float (&bd)[KMAX], int (&bi)[KMAX],
+                                             int K, float& worst)
+{
+    for (int j0 = 0; j0 < cnt; j0 += NODE_BATCH) {
+        float4 p[NODE_BATCH];
+#pragma unroll
+        for (int u = 0; u < NODE_BATCH; u++) p[u] = s_pos4[j0 + u];
+#pragma unroll
+        for (int u = 0; u < NODE_BATCH; u++) {
+            const float tx = x[0] - p[u].x, ty = x[1] - p[u].y, tz = x[2] - p[u].z;
+            float d2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+            if (FOURTH) { const float tw = x[3] - p[u].w; d2 = fmaf(tw, tw, d2); }
+            if (EXACT) {
+                topk_insert_exact<KMAX>(bd, bi, d2, base + j0 + u);
+            } else if (d2 < worst) {
+                topk_insert<KMAX>(bd, bi, K, d2, base + j0 + u);
+                worst = topk_worst<KMAX>(bd, K);
+            }
+        }
+    }
+}
+
 // ---- pytorch3d.ops.knn_points for one batch element -------------------------------------------------------------------------
+// D <= 4 (the control-node case is D = 3): float4 staging, batched LDS reads, exact short lists
+template <int KMAX, bool EXACT>
+__global__ void __launch_bounds__(NODE_BLOCK)
+knn_points3_kernel(const int64_t n, const int64_t m, const int D, const int K, const float* __restrict__ p1, const float* __restrict__ p2,
+                   float* __restrict__ dist2, int64_t* __restrict__ idx)
+{
+    __shared__ float4 s_pos4[NODE_CHUNK4];
+    const int64_t i = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) x[d] = d < D ? p1[i * D + d] : 0.f;
+    }
+    float bd[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) { bd[k] = INFINITY; bi[k] = -1; }
+    float worst = INFINITY;
+    for (int64_t base = 0; base < m; base += NODE_CHUNK4) {
+        const int cnt = (int)min((int64_t)NODE_CHUNK4, m - base);
+        __syncthreads();
+        stage_points3(s_pos4, p2, base, cnt, D, D);
+        __syncthreads();
+        if (i < n) scan_points3<KMAX, EXACT, true>(s_pos4, cnt, (int)base, x, bd, bi, K, worst);
+    }
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        if (k < K) {
+            const bool ok = bi[k] >= 0;
+            dist2[i * K + k] = ok ? bd[k] : 0.f;
+            idx[i * K + k] = ok ? bi[k] : 0;
+        }
+    }
+}
+
 template <int DMAX, int KMAX>
 __global__ void __launch_bounds__(NODE_BLOCK)
 knn_points_kernel(const int64_t n, const int64_t m, const int D, const int K, const float* __restrict__ p1, const float* __restrict__ p2,
@@ -95,37 +190,61 @@ knn_points_kernel(const int64_t n, const int64_t m, const int D, const int K, co
     }
 }
 
+struct NodeFrame { float R[9]; };
+
+// quaternion_to_matrix(local_rotation + (1,0,0,0)), utils/time_utils.py:115-133,1207-1208
+__device__ __forceinline__ NodeFrame node_frame_of(const gsr_node_blend& a, int j)
+{
+    NodeFrame f;
+    if (!a.node_local_rotation) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) f.R[c] = a.node_frame[9 * (size_t)j + c];
+        return f;
+    }
+    const float* q = a.node_local_rotation + 4 * (size_t)j;
+    const float r = q[0] + 1.f, x = q[1], y = q[2], z = q[3];
+    const float s = 2.0f / (r * r + x * x + y * y + z * z);
+    f.R[0] = 1.f - s * (y * y + z * z); f.R[1] = s * (x * y - z * r); f.R[2] = s * (x * z + y * r);
+    f.R[3] = s * (x * y + z * r); f.R[4] = 1.f - s * (x * x + z * z); f.R[5] = s * (y * z - x * r);
+    f.R[6] = s * (x * z - y * r); f.R[7] = s * (y * z + x * r); f.R[8] = 1.f - s * (x * x + y * y);
+    return f;
+}
+
+__device__ __forceinline__ float node_radius_of(const gsr_node_blend& a, int j)
+{
+    const float v = a.node_radius[j];
+    return (a.flags & GSR_NODE_RADIUS_IS_LOG) ? expf(v) : v;
+}
+
+__device__ __forceinline__ float node_weight_of(const gsr_node_blend& a, int j)
+{
+    if (!a.node_weight) return 1.f;
+    const float v = a.node_weight[j];
+    return (a.flags & GSR_NODE_WEIGHT_IS_LOGIT) ? 1.f / (1.f + expf(-v)) : v;
+}
+
 // ---- cal_nn_weight + blend ------------------------------------------------------------------------------------------------------
+template <int KMAX, bool EXACT>
 __global__ void __launch_bounds__(NODE_BLOCK)
 node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, float* __restrict__ nn_dist, int64_t* __restrict__ nn_idx,
                       float* __restrict__ d_xyz, float* __restrict__ d_rotation, float* __restrict__ d_scaling)
 {
-    constexpr int KMAX = GSR_BLEND_MAX_K;
-    __shared__ float s_pos[NODE_CHUNK * 3];
+    __shared__ float4 s_pos4[NODE_CHUNK4];
     const int64_t i = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
     const int K = a.K;
-    float x[3] = {0.f, 0.f, 0.f};
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < a.n) { x[0] = a.x[3 * i]; x[1] = a.x[3 * i + 1]; x[2] = a.x[3 * i + 2]; }
     float bd[KMAX];
     int bi[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; k++) { bd[k] = INFINITY; bi[k] = -1; }
     float worst = INFINITY;
-    for (int base = 0; base < a.m; base += NODE_CHUNK) {
-        const int cnt = min(NODE_CHUNK, a.m - base);
+    for (int base = 0; base < a.m; base += NODE_CHUNK4) {
+        const int cnt = min(NODE_CHUNK4, a.m - base);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * 3; e += NODE_BLOCK) s_pos[e] = a.nodes[(size_t)(base + e / 3) * a.node_stride + e % 3];
+        stage_points3(s_pos4, a.nodes, base, cnt, a.node_stride, 3);
         __syncthreads();
-        if (i < a.n) {
-            for (int j = 0; j < cnt; j++) {                       // every lane reads the same node: an LDS broadcast
-                const float tx = x[0] - s_pos[3 * j], ty = x[1] - s_pos[3 * j + 1], tz = x[2] - s_pos[3 * j + 2];
-                const float d2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-                if (d2 < worst) {
-                    topk_insert<KMAX>(bd, bi, K, d2, base + j);
-                    worst = topk_worst<KMAX>(bd, K);
-                }
-            }
-        }
+        if (i < a.n) scan_points3<KMAX, EXACT, false>(s_pos4, cnt, base, x, bd, bi, K, worst);
     }
     if (i >= a.n) return;
     // weights: exp(-d / (2 r^2)) [* node weight] + 1e-7, normalised over the K (:1000-1006)
@@ -137,9 +256,8 @@ node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, flo
             const int j = max(bi[k], 0);
             if (bi[k] < 0) bd[k] = 0.f;                           // fewer nodes than K: pytorch3d pads with index 0, distance 0
             bi[k] = j;
-            const float r = a.node_radius[j];
-            float u = expf(-bd[k] / (2.f * r * r));
-            if (a.node_weight) u *= a.node_weight[j];
+            const float r = node_radius_of(a, j);
+            const float u = expf(-bd[k] / (2.f * r * r)) * node_weight_of(a, j);
             w[k] = u + 1e-7f;
             S += w[k];
         }
@@ -163,7 +281,8 @@ node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, flo
             const int j = bi[k];
             const float* tr = a.node_trans + 3 * (size_t)j;
             if (a.local_frame) {                                  // R (x - node) + node + trans (:1209)
-                const float* R = a.node_frame + 9 * (size_t)j;
+                const NodeFrame F = node_frame_of(a, j);
+                const float* R = F.R;
                 const float* nd = a.nodes + (size_t)j * a.node_stride;
                 const float ox = x[0] - nd[0], oy = x[1] - nd[1], oz = x[2] - nd[2];
 #pragma unroll
@@ -239,7 +358,8 @@ node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weigh
                     const float* qr = a.node_rot + 4 * (size_t)j;
                     const float* sc = a.node_scale + 3 * (size_t)j;
                     if (a.local_frame) {
-                        const float* R = a.node_frame + 9 * (size_t)j;
+                        const NodeFrame F = node_frame_of(a, j);
+                        const float* R = F.R;
                         const float* nd = a.nodes + (size_t)j * a.node_stride;
                         const float o[3] = {x[0] - nd[0], x[1] - nd[1], x[2] - nd[2]};
 #pragma unroll
@@ -270,9 +390,9 @@ node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weigh
         for (int k = 0; k < KMAX; k++) {
             e[k] = nw[k] = 0.f;
             if (k < K) {
-                const float r = a.node_radius[idx[k]];
+                const float r = node_radius_of(a, idx[k]);
                 e[k] = expf(-nn_dist[i * K + k] / (2.f * r * r));
-                nw[k] = a.node_weight ? a.node_weight[idx[k]] : 1.f;
+                nw[k] = node_weight_of(a, idx[k]);
                 S += e[k] * nw[k] + 1e-7f;
             }
         }
@@ -281,7 +401,7 @@ node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weigh
         for (int k = 0; k < KMAX; k++) {
             if (k < K) {
                 const float du = (G[k] - Gw) * invS;
-                const float r = a.node_radius[idx[k]];
+                const float r = node_radius_of(a, idx[k]);
                 add(idx[k] * NODE_GRAD + 19, du * nw[k] * e[k] * nn_dist[i * K + k] / (r * r * r));      // d e / d r = e d / r^3
                 if (a.node_weight) add(idx[k] * NODE_GRAD + 20, du * e[k]);
             }
@@ -294,26 +414,66 @@ node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weigh
     }
 }
 
-// out component c of node j = sum over the G partial rows, fixed order
+// summed[e] = sum over the G partial rows of element e (node j, component c = e % 21), fixed order
 __global__ void __launch_bounds__(256)
-node_grad_reduce_kernel(const int G, const int m, const float* __restrict__ partial, float* __restrict__ g_trans, float* __restrict__ g_rot,
-                        float* __restrict__ g_scale, float* __restrict__ g_frame, float* __restrict__ g_radius, float* __restrict__ g_weight)
+node_grad_reduce_kernel(const int G, const int total, const float* __restrict__ partial, float* __restrict__ summed)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    const int total = m * NODE_GRAD;
     if (e >= total) return;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = 0;
-    for (; b + 1 < G; b += 2) { s0 += partial[(size_t)b * total + e]; s1 += partial[(size_t)(b + 1) * total + e]; }
-    if (b < G) s0 += partial[(size_t)b * total + e];
-    const float s = s0 + s1;
-    const int j = e / NODE_GRAD, c = e % NODE_GRAD;
-    if (c < 3) { if (g_trans) g_trans[3 * j + c] = s; }
-    else if (c < 7) { if (g_rot) g_rot[4 * j + c - 3] = s; }
-    else if (c < 10) { if (g_scale) g_scale[3 * j + c - 7] = s; }
-    else if (c < 19) { if (g_frame) g_frame[9 * j + c - 10] = s; }
-    else if (c == 19) { if (g_radius) g_radius[j] = s; }
-    else if (g_weight) g_weight[j] = s;
+    for (; b + 3 < G; b += 4) {
+        s0 += partial[(size_t)b * total + e];
+        s1 += partial[(size_t)(b + 1) * total + e];
+        s2 += partial[(size_t)(b + 2) * total + e];
+        s3 += partial[(size_t)(b + 3) * total + e];
+    }
+    for (; b < G; b++) s0 += partial[(size_t)b * total + e];
+    summed[e] = (s0 + s1) + (s2 + s3);
+}
+
+// one thread per node: hand the 21 sums out, through the chain rules of the per-node activations where the inputs were raw
+__global__ void __launch_bounds__(256)
+node_grad_finalize_kernel(const gsr_node_blend a, const float* __restrict__ summed, float* __restrict__ g_trans, float* __restrict__ g_rot,
+                          float* __restrict__ g_scale, float* __restrict__ g_frame, float* __restrict__ g_radius, float* __restrict__ g_weight)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.m) return;
+    const float* s = summed + (size_t)j * NODE_GRAD;
+    if (g_trans) { g_trans[3 * j] = s[0]; g_trans[3 * j + 1] = s[1]; g_trans[3 * j + 2] = s[2]; }
+    if (g_rot) { g_rot[4 * j] = s[3]; g_rot[4 * j + 1] = s[4]; g_rot[4 * j + 2] = s[5]; g_rot[4 * j + 3] = s[6]; }
+    if (g_scale) { g_scale[3 * j] = s[7]; g_scale[3 * j + 1] = s[8]; g_scale[3 * j + 2] = s[9]; }
+    if (g_radius) g_radius[j] = (a.flags & GSR_NODE_RADIUS_IS_LOG) ? s[19] * expf(a.node_radius[j]) : s[19];       // d exp(v) = exp(v) dv
+    if (g_weight && a.node_weight) {
+        float g = s[20];
+        if (a.flags & GSR_NODE_WEIGHT_IS_LOGIT) { const float w = 1.f / (1.f + expf(-a.node_weight[j])); g *= w * (1.f - w); }
+        g_weight[j] = g;
+    }
+    if (!g_frame) return;
+    const float* Gm = s + 10;                                         // dL/dR, row-major
+    if (!a.node_local_rotation) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) g_frame[9 * j + c] = Gm[c];
+        return;
+    }
+    // R = I + s A(q), s = 2 / |q|^2, A homogeneous quadratic (time_utils.py:115-133); q = local_rotation + (1,0,0,0)
+    const float* q = a.node_local_rotation + 4 * (size_t)j;
+    const float r = q[0] + 1.f, x = q[1], y = q[2], z = q[3];
+    const float n2 = r * r + x * x + y * y + z * z, sc = 2.0f / n2;
+    const float A[9] = {-(y * y + z * z), x * y - z * r, x * z + y * r, x * y + z * r, -(x * x + z * z), y * z - x * r,
+                        x * z - y * r, y * z + x * r, -(x * x + y * y)};
+    float GA = 0.f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) GA += Gm[c] * A[c];
+    const float dr = -z * Gm[1] + y * Gm[2] + z * Gm[3] - x * Gm[5] - y * Gm[6] + x * Gm[7];
+    const float dx = y * Gm[1] + z * Gm[2] + y * Gm[3] - 2.f * x * Gm[4] - r * Gm[5] + z * Gm[6] + r * Gm[7] - 2.f * x * Gm[8];
+    const float dy = -2.f * y * Gm[0] + x * Gm[1] + r * Gm[2] + x * Gm[3] + z * Gm[5] - r * Gm[6] + z * Gm[7] - 2.f * y * Gm[8];
+    const float dz = -2.f * z * Gm[0] - r * Gm[1] + x * Gm[2] + r * Gm[3] - 2.f * z * Gm[4] + y * Gm[5] + x * Gm[6] + y * Gm[7];
+    const float k = -sc * sc * GA;                                    // d s / d q = -s^2 q
+    g_frame[4 * j] = sc * dr + k * r;
+    g_frame[4 * j + 1] = sc * dx + k * x;
+    g_frame[4 * j + 2] = sc * dy + k * y;
+    g_frame[4 * j + 3] = sc * dz + k * z;
 }
 
 }  // namespace gsr

@@ -12,10 +12,12 @@
 
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/gs_rasterizer.h"
 #include "../../include/simple_knn.h"
 #include "../../include/slam_losses.h"
+#include "../../include/control_nodes.h"
 
 namespace {
 
@@ -403,6 +405,97 @@ torch::Tensor dist_cuda2(const torch::Tensor& points_, int64_t stream)
     return means;
 }
 
+// ---- SC-GS control nodes (include/control_nodes.h) ----
+namespace {
+const float* optp(const c10::optional<torch::Tensor>& t, std::vector<torch::Tensor>& keep, const char* name)
+{
+    if (!t.has_value() || !t->defined() || t->numel() == 0) return nullptr;
+    keep.push_back(t->contiguous());
+    return fptr(keep.back(), name);
+}
+
+void fill_blend(gsr_node_blend& a, std::vector<torch::Tensor>& keep, const torch::Tensor& x, const c10::optional<torch::Tensor>& mask,
+                const torch::Tensor& nodes, const torch::Tensor& radius, const c10::optional<torch::Tensor>& weight,
+                const c10::optional<torch::Tensor>& trans, const c10::optional<torch::Tensor>& rot, const c10::optional<torch::Tensor>& scale,
+                const c10::optional<torch::Tensor>& local_rot, int64_t K, bool rot_as_residual, int64_t flags)
+{
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == 3 && nodes.dim() == 2 && nodes.size(1) >= 3, "node blend expects x [N, 3] and nodes [M, >=3]");
+    TORCH_CHECK(x.is_cuda(), "x is on '", x.device().str(),
+                "': the MI355X library needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    a = gsr_node_blend{};
+    a.n = x.size(0); a.m = (int32_t)nodes.size(0); a.K = (int32_t)K; a.rot_as_residual = rot_as_residual; a.node_stride = (int32_t)nodes.size(1);
+    a.flags = (int32_t)flags;
+    keep.push_back(x.contiguous()); a.x = keep.back().numel() ? fptr(keep.back(), "x") : nullptr;
+    keep.push_back(nodes.contiguous()); a.nodes = fptr(keep.back(), "nodes");
+    keep.push_back(radius.contiguous()); a.node_radius = fptr(keep.back(), "node_radius");
+    TORCH_CHECK(radius.numel() == a.m, "node_radius must have one value per node");
+    a.motion_mask = optp(mask, keep, "motion_mask");
+    TORCH_CHECK(!a.motion_mask || keep.back().numel() == a.n, "motion_mask must have one value per Gaussian");
+    a.node_weight = optp(weight, keep, "node_weight");
+    TORCH_CHECK(!a.node_weight || keep.back().numel() == a.m, "node_weight must have one value per node");
+    auto shaped = [&](const c10::optional<torch::Tensor>& t, int64_t c, const char* name) {
+        const float* p = optp(t, keep, name);
+        TORCH_CHECK(!p || (keep.back().dim() == 2 && keep.back().size(0) == a.m && keep.back().size(1) == c), name, " must have shape (", a.m, ", ", c, ")");
+        return p;
+    };
+    a.node_trans = shaped(trans, 3, "node_trans");
+    a.node_rot = shaped(rot, 4, "node_rot");
+    a.node_scale = shaped(scale, 3, "node_scale");
+    a.node_local_rotation = a.node_trans ? shaped(local_rot, 4, "local_rotation") : nullptr;
+    a.local_frame = a.node_local_rotation != nullptr;
+}
+}  // namespace
+
+std::vector<torch::Tensor> node_blend_forward(const torch::Tensor& x, const c10::optional<torch::Tensor>& mask, const torch::Tensor& nodes,
+                                              const torch::Tensor& radius, const c10::optional<torch::Tensor>& weight,
+                                              const c10::optional<torch::Tensor>& trans, const c10::optional<torch::Tensor>& rot,
+                                              const c10::optional<torch::Tensor>& scale, const c10::optional<torch::Tensor>& local_rot, int64_t K,
+                                              bool rot_as_residual, int64_t flags, int64_t stream)
+{
+    gsr_node_blend a;
+    std::vector<torch::Tensor> keep;
+    fill_blend(a, keep, x, mask, nodes, radius, weight, trans, rot, scale, local_rot, K, rot_as_residual, flags);
+    auto fopt = x.options().dtype(torch::kFloat32);
+    torch::Tensor w = torch::empty({a.n, K}, fopt), dist = torch::empty({a.n, K}, fopt), idx = torch::empty({a.n, K}, x.options().dtype(torch::kInt64));
+    const bool blend = a.node_trans != nullptr;
+    torch::Tensor d_xyz = torch::empty({blend ? a.n : 0, 3}, fopt), d_rot = torch::empty({blend ? a.n : 0, 4}, fopt), d_scale = torch::empty({blend ? a.n : 0, 3}, fopt);
+    const int rc = gsr_node_blend_forward(&a, w.data_ptr<float>(), dist.data_ptr<float>(), idx.data_ptr<int64_t>(), blend ? d_xyz.data_ptr<float>() : nullptr,
+                                          blend ? d_rot.data_ptr<float>() : nullptr, blend ? d_scale.data_ptr<float>() : nullptr, reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_node_blend_forward", rc);
+    return {w, dist, idx, d_xyz, d_rot, d_scale};
+}
+
+// returns (g_radius, g_weight, g_trans, g_rot, g_scale, g_local_rotation); undefined tensors where the input was absent
+std::vector<torch::Tensor> node_blend_backward(const torch::Tensor& x, const c10::optional<torch::Tensor>& mask, const torch::Tensor& nodes,
+                                               const torch::Tensor& radius, const c10::optional<torch::Tensor>& weight,
+                                               const c10::optional<torch::Tensor>& trans, const c10::optional<torch::Tensor>& rot,
+                                               const c10::optional<torch::Tensor>& scale, const c10::optional<torch::Tensor>& local_rot, int64_t K,
+                                               bool rot_as_residual, int64_t flags, const torch::Tensor& w, const torch::Tensor& dist,
+                                               const torch::Tensor& idx, const c10::optional<torch::Tensor>& g_w, const c10::optional<torch::Tensor>& g_xyz,
+                                               const c10::optional<torch::Tensor>& g_rot, const c10::optional<torch::Tensor>& g_scale, int64_t stream)
+{
+    gsr_node_blend a;
+    std::vector<torch::Tensor> keep;
+    fill_blend(a, keep, x, mask, nodes, radius, weight, trans, rot, scale, local_rot, K, rot_as_residual, flags);
+    auto fopt = x.options().dtype(torch::kFloat32);
+    const bool blend = a.node_trans != nullptr;
+    torch::Tensor g_radius = torch::empty({a.m}, fopt), g_weight, g_trans, g_nrot, g_nscale, g_local;
+    if (a.node_weight) g_weight = torch::empty({a.m}, fopt);
+    if (blend) { g_trans = torch::empty({a.m, 3}, fopt); g_nrot = torch::empty({a.m, 4}, fopt); g_nscale = torch::empty({a.m, 3}, fopt); }
+    if (a.node_local_rotation) g_local = torch::empty({a.m, 4}, fopt);
+    torch::Tensor ws = torch::empty({(int64_t)gsr_node_blend_workspace_size(a.n, a.m)}, x.options().dtype(torch::kUInt8));
+    auto p = [](torch::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; };
+    const float* cw = optp(g_w, keep, "g_nn_weight");
+    const float* cx = blend ? optp(g_xyz, keep, "g_xyz") : nullptr;
+    const float* cr = blend ? optp(g_rot, keep, "g_rotation") : nullptr;
+    const float* cs = blend ? optp(g_scale, keep, "g_scaling") : nullptr;
+    const int rc = gsr_node_blend_backward(&a, a.n ? w.data_ptr<float>() : nullptr, a.n ? dist.data_ptr<float>() : nullptr,
+                                           a.n ? idx.data_ptr<int64_t>() : nullptr, cx, cr, cs, cw, p(g_trans), p(g_nrot), p(g_nscale), p(g_local),
+                                           p(g_radius), p(g_weight), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_node_blend_backward", rc);
+    return {g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local};
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("rasterize_gaussians", &rasterize_gaussians);
@@ -415,4 +508,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ssim_backward", &ssim_backward);
     m.def("mark_visible", &mark_visible);
     m.def("dist_cuda2", &dist_cuda2);
+    m.def("node_blend_forward", &node_blend_forward);
+    m.def("node_blend_backward", &node_blend_backward);
 }

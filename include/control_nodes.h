@@ -23,6 +23,8 @@ extern "C" {
 #define GSR_KNN_MAX_K 32
 #define GSR_KNN_MAX_DIM 32
 #define GSR_BLEND_MAX_K 8
+#define GSR_NODE_RADIUS_IS_LOG 1     /* node_radius holds the raw parameter _node_radius; radius = exp(raw)   (:893-894) */
+#define GSR_NODE_WEIGHT_IS_LOGIT 2   /* node_weight holds the raw parameter _node_weight; weight = sigmoid(raw) (:897-898) */
 
 /* pytorch3d.ops.knn_points(p1[None], p2[None], K=K) for one batch element (the only form the reference calls,
  * utils/time_utils.py:998,1028,1099,1109,1183; utils/deform_utils.py:49,74,87): for each of the n rows of p1 [n, D] the K rows of
@@ -38,16 +40,18 @@ typedef struct gsr_node_blend {
     int32_t local_frame;          /* :1206-1212: rotate the offset to the node by the node's local frame before translating */
     int32_t rot_as_residual;      /* d_rot_as_res (:1254-1256); 0 = the absolute form with the (1,0,0,0) bias (:1218-1231) */
     int32_t node_stride;          /* floats per row of `nodes` (3 + hyper_dim); the first 3 are the position */
-    int32_t reserved;
+    int32_t flags;                /* GSR_NODE_RADIUS_IS_LOG | GSR_NODE_WEIGHT_IS_LOGIT: apply the activation (and its chain rule) in the kernels */
     const float* x;               /* [n, 3]   Gaussian positions (detached in the reference, :1196) */
     const float* motion_mask;     /* [n]      or NULL (= 1) */
     const float* nodes;           /* [m, node_stride] */
-    const float* node_radius;     /* [m]      exp(_node_radius) (:893-894) */
-    const float* node_weight;     /* [m]      sigmoid(_node_weight) (:897-898), or NULL (with_node_weight False) */
+    const float* node_radius;     /* [m]      exp(_node_radius) (:893-894), or the raw parameter with GSR_NODE_RADIUS_IS_LOG */
+    const float* node_weight;     /* [m]      sigmoid(_node_weight) (:897-898) or the raw parameter with GSR_NODE_WEIGHT_IS_LOGIT; NULL = with_node_weight False */
     const float* node_trans;      /* [m, 3]   node_attrs['d_xyz']; NULL = weights only (cal_nn_weight on its own) */
     const float* node_rot;        /* [m, 4]   node_attrs['d_rotation'] */
     const float* node_scale;      /* [m, 3]   node_attrs['d_scaling'] */
     const float* node_frame;      /* [m, 9]   quaternion_to_matrix(node_attrs['local_rotation'] + (1,0,0,0)), row-major; local_frame only */
+    const float* node_local_rotation; /* [m, 4] node_attrs['local_rotation'] itself (:1207): when not NULL it replaces node_frame -- the bias and
+                                     quaternion_to_matrix (:115-133) are applied in the kernels, and backward returns the quaternion's gradient */
 } gsr_node_blend;
 
 /* Forward.  nn_weight / nn_dist [n, K] fp32 and nn_idx [n, K] int64 are the three results of cal_nn_weight (:981-1011) and are
@@ -57,7 +61,8 @@ int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_
 
 /* Backward for the cotangents g_xyz [n,3], g_rotation [n,4], g_scaling [n,3] (each may be NULL = 0) and, optionally, a direct
  * cotangent of nn_weight (g_nn_weight [n,K] or NULL).  WRITES the node gradients (any may be NULL to skip):
- *   g_node_trans [m,3], g_node_rot [m,4], g_node_scale [m,3], g_node_frame [m,9], g_node_radius [m], g_node_weight [m].
+ *   g_node_trans [m,3], g_node_rot [m,4], g_node_scale [m,3], g_node_frame [m,9] (or [m,4], the gradient of node_local_rotation,
+ *   when that was given), g_node_radius [m], g_node_weight [m] (of the raw parameters when the flags say the inputs are raw).
  * x and the node positions receive no gradient (both are detached on this path, :993,1196).  Deterministic: block partials in
  * `workspace` (gsr_node_blend_workspace_size bytes) summed in a fixed order. */
 size_t gsr_node_blend_workspace_size(int64_t n, int32_t m);

@@ -73,6 +73,16 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     lib.gsr_linear_wgrad_workspace_size.restype = ctypes.c_size_t
     lib.gsr_linear_wgrad_workspace_size.argtypes = [i64, i, i]
     assert lib.gsr_linear_wgrad_workspace_size(200000, 128, 64) >= 64 * 129 * 4
+    # control_nodes.h
+    import control_nodes
+    cl = control_nodes._lib()
+    assert cl.gsr_knn_points(10, 10, 3, 33, None, None, None, None, None) == -1 and b"gsr_knn_points" in lib.gsr_last_error()
+    assert cl.gsr_knn_points(0, 10, 3, 3, None, None, None, None, None) == -1          # p2 null with m > 0
+    blend = control_nodes._Blend(n=4, m=0, K=3, node_stride=3)
+    assert cl.gsr_node_blend_forward(ctypes.byref(blend), None, None, None, None, None, None, None) == -1 and b"no control nodes" in lib.gsr_last_error()
+    blend = control_nodes._Blend(n=4, m=8, K=9, node_stride=3)
+    assert cl.gsr_node_blend_backward(ctypes.byref(blend), *([None] * 15)) == -1 and b"K outside" in lib.gsr_last_error()
+    assert cl.gsr_node_blend_workspace_size(100000, 512) >= 512 * 21 * 4 * 2
 
 
 def test_public_names_and_settings_fields_match_reference():

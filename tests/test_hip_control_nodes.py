@@ -15,18 +15,21 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def run_product(d):
-    radius = torch.exp(d["node_radius_raw"])                         # :893-898: the per-node activations stay in torch
-    weight = torch.sigmoid(d["node_weight_raw"])
+def run_product(d, raw=True):
+    if raw:                                                          # raw parameters: exp / sigmoid and their chain rules in the kernels
+        radius, weight = d["node_radius_raw"], d["node_weight_raw"]
+    else:                                                            # activated properties computed by torch (:893-898)
+        radius, weight = torch.exp(d["node_radius_raw"]), torch.sigmoid(d["node_weight_raw"])
     res = cn.node_blend(d["x"], d["motion_mask"], d["nodes"], radius, weight, d["node_trans"], d["node_rot"], d["node_scale"],
-                        d["local_rotation"] if d["local_frame"] else None, K=d["K"], d_rot_as_res=d["d_rot_as_res"])
+                        d["local_rotation"] if d["local_frame"] else None, K=d["K"], d_rot_as_res=d["d_rot_as_res"], raw=raw)
     return res
 
 
+@pytest.mark.parametrize("raw", [True, False])
 @pytest.mark.parametrize("name", list(G["cases"]))
-def test_node_blend_matches_reference_golden(name):
+def test_node_blend_matches_reference_golden(name, raw):
     d = load(name, device=DEV)
-    res = run_product(d)
+    res = run_product(d, raw)
     check_against_golden(name, (res["d_xyz"], res["d_rotation"], res["d_scaling"]), d, (res["nn_weight"], res["nn_dist"], res["nn_idx"]))
 
 
@@ -76,7 +79,7 @@ def test_node_blend_against_oracle_fp64(m, K, local_frame, rot_res, with_weight)
     leaves = dict(rr=T(np.log(rng.uniform(0.1, 0.5, size=m)), True), wr=T(rng.normal(size=(m, 1)), True),
                   tr=T(rng.normal(scale=0.1, size=(m, 3)), True), ro=T(rng.normal(scale=0.2, size=(m, 4)), True),
                   sc=T(rng.normal(scale=0.1, size=(m, 3)), True), lr=T(rng.normal(scale=0.3, size=(m, 4)), True))
-    res = cn.node_blend(x, mask, nodes, torch.exp(leaves["rr"]), torch.sigmoid(leaves["wr"]) if with_weight else None, leaves["tr"],
+    res = cn.node_blend(x, mask, nodes, leaves["rr"], leaves["wr"] if with_weight else None, leaves["tr"],
                         leaves["ro"], leaves["sc"], leaves["lr"] if local_frame else None, K=K, d_rot_as_res=rot_res)
     cots = [T(rng.normal(size=(n, c))) for c in (3, 4, 3)]
     (sum((res[k] * c).sum() for k, c in zip(("d_xyz", "d_rotation", "d_scaling"), cots))).backward()
@@ -96,7 +99,7 @@ def test_node_blend_against_oracle_fp64(m, K, local_frame, rot_res, with_weight)
 
 def test_cal_nn_weight_alone_with_gradients():
     d = load("shipped", device=DEV)
-    w, dist, idx = cn.cal_nn_weight(d["x"], d["nodes"], torch.exp(d["node_radius_raw"]), torch.sigmoid(d["node_weight_raw"]), K=3)
+    w, dist, idx = cn.cal_nn_weight(d["x"], d["nodes"], d["node_radius_raw"], d["node_weight_raw"], K=3)
     cot = torch.randn_like(w)
     (w * cot).sum().backward()
     x64 = d["x"].double().cpu()
@@ -109,7 +112,7 @@ def test_cal_nn_weight_alone_with_gradients():
 
 def test_edge_cases_and_errors():
     d = load("k1", device=DEV)
-    empty = cn.node_blend(torch.zeros((0, 3), device=DEV), None, d["nodes"], torch.exp(d["node_radius_raw"]), None, d["node_trans"],
+    empty = cn.node_blend(torch.zeros((0, 3), device=DEV), None, d["nodes"], d["node_radius_raw"], None, d["node_trans"],
                           d["node_rot"], d["node_scale"], None, K=1)
     assert empty["d_xyz"].shape == (0, 3) and empty["nn_idx"].shape == (0, 1)
     (empty["d_xyz"].sum() + empty["d_rotation"].sum()).backward()    # zero gradients, no fault
@@ -128,9 +131,9 @@ def test_edge_cases_and_errors():
     for a, b in zip(*grads):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError, match="K = 9"):
-        cn.node_blend(d["x"], None, d["nodes"], torch.exp(d["node_radius_raw"]), None, d["node_trans"], d["node_rot"], d["node_scale"], None, K=9)
+        cn.node_blend(d["x"], None, d["nodes"], d["node_radius_raw"], None, d["node_trans"], d["node_rot"], d["node_scale"], None, K=9)
     with pytest.raises(ValueError, match="node_rot must have shape"):
-        cn.node_blend(d["x"], None, d["nodes"], torch.exp(d["node_radius_raw"]), None, d["node_trans"], d["node_rot"][:, :3], d["node_scale"], None, K=3)
+        cn.node_blend(d["x"], None, d["nodes"], d["node_radius_raw"], None, d["node_trans"], d["node_rot"][:, :3], d["node_scale"], None, K=3)
     with pytest.raises(NotImplementedError):
         cn.knn_points(d["x"][None], d["nodes"][None], torch.tensor([5]), None, K=3)
     with pytest.raises(Exception, match="HIP device|no CPU"):
