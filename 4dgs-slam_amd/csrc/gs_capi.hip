@@ -26,6 +26,7 @@
 #include "gs_knn.h"
 #include "gs_loss.h"
 #include "gs_hexplane.h"
+#include "gs_hexplane_binned.h"
 #include "gs_linear.h"
 #include "gs_nodes.h"
 #include "../../include/slam_losses.h"
@@ -866,17 +867,103 @@ int gsr_hexplane_forward(const gsr_hexplane_field* field, int64_t n, const float
     return 0;
 }
 
-int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
-                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, void* stream_)
+static void hexsort_plan(const gsr_hexplane_field& f, HexSortPlan* P)
 {
+    for (int k = 0; k < 4; k++) {
+        int r = 1;
+        for (int l = 0; l < f.num_levels; l++) r = std::max(r, (int)f.levels[l].res[k]);
+        P->fine[k] = r;
+        int b = 0;
+        while ((1 << b) < r) b++;
+        P->bits[k] = b;
+    }
+    static const int C0[6] = {0, 0, 0, 1, 1, 2}, C1[6] = {1, 2, 3, 2, 3, 3};   // itertools.combinations(range(4), 2)
+    int off = 0;
+    for (int pl = 0; pl < 6; pl++) {
+        // every call of the reference passes ONE time for all points (gaussian_renderer/__init__.py:112): the time families then use a
+        // single row of cells, n / 512 points per cell -- give them 16 sub-counters per cell (the spatial families: 2), up to 2^20 counters
+        const int cell_bits = P->bits[C0[pl]] + P->bits[C1[pl]];
+        P->sub_bits[pl] = std::max(0, std::min(C1[pl] == 3 ? 4 : 1, 20 - cell_bits));
+        P->key_off[pl] = off;
+        off += 1 << (cell_bits + P->sub_bits[pl]);
+    }
+    P->key_off[6] = off;
+}
+
+static size_t hexsort_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, char* base, HexSortWs* ws)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    const size_t nb = (size_t)P.key_off[6];
+    HexSortWs w;
+    w.count = reinterpret_cast<uint32_t*>(take(nb * sizeof(uint32_t)));
+    w.block_sums = reinterpret_cast<uint32_t*>(take((nb / (1024 * HEXSORT_SCAN_ITEMS) + 1) * sizeof(uint32_t)));
+    w.coords = reinterpret_cast<float4*>(take((size_t)n * sizeof(float4)));
+    w.key = reinterpret_cast<uint32_t*>(take((size_t)6 * n * sizeof(uint32_t)));
+    w.rank = reinterpret_cast<int*>(take((size_t)6 * n * sizeof(int)));
+    w.scoords = reinterpret_cast<float4*>(take((size_t)6 * n * sizeof(float4)));
+    w.gs = reinterpret_cast<float*>(take((size_t)6 * n * f.num_levels * f.feat_dim * sizeof(float)));
+    if (ws) *ws = w;
+    return off + 256;
+}
+
+static bool hexsort_supported(const gsr_hexplane_field& f, int64_t n)
+{
+    if (!f.channels_last || n * 6 >= ((int64_t)1 << 31)) return false;
+    for (int l = 0; l < f.num_levels; l++)
+        for (int k = 0; k < 4; k++) if (f.levels[l].res[k] > 1024) return false;   // 2 x 10 key bits per family
+    return true;
+}
+
+size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int64_t n)
+{
+    if (!field || n <= 0 || field->num_levels < 1 || field->num_levels > GSR_HEXPLANE_MAX_LEVELS || !hexsort_supported(*field, n)) return 256;
+    HexSortPlan P;
+    hexsort_plan(*field, &P);
+    return hexsort_carve(*field, P, n, nullptr, nullptr);
+}
+
+int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
+                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
     if (int rc = hexplane_check(field, n, xyz, time, "gsr_hexplane_backward")) return rc;
     if (n == 0) return 0;
     if (!dL_dfeatures) { g_last_error = "gsr_hexplane_backward: null dL_dfeatures"; return GSR_ERR_INVALID_ARGUMENT; }
-    hexplane_launch<true>(*field, n, (hipStream_t)stream_, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
+    const gsr_hexplane_field& f = *field;
+    if (!workspace || !hexsort_supported(f, n)) {
+        hexplane_launch<true>(f, n, stream, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
+        GSR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    HexSortPlan P;
+    hexsort_plan(f, &P);
+    HexSortWs ws;
+    hexsort_carve(f, P, n, workspace, &ws);
+    const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
+    GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
+    const dim3 per_point((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(hexsort_count_kernel, per_point, dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, time, time_stride);
+    hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
+    hipLaunchKernelGGL(hexsort_scan_top_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, scan_blocks);
+    hipLaunchKernelGGL(hexsort_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, ws.count, nb, (const uint32_t*)ws.block_sums);
+    hipLaunchKernelGGL(hexsort_scatter_kernel, per_point, dim3(256), 0, stream, ws, n);
+    const int C = f.feat_dim, ppb = HEX_BLOCK / C;
+    const dim3 g1((unsigned)((n + ppb - 1) / ppb));
+    const int64_t groups = 6 * ((n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK);
+    const dim3 g2((unsigned)((groups + 256 / C - 1) / (256 / C)));
+#define GSR_HEXSORT_CASE(CC)                                                                                                              \
+    case CC:                                                                                                                               \
+        hipLaunchKernelGGL((hexsort_phase1_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, n, xyz, xyz_stride, time, time_stride,       \
+                           dL_dfeatures, dL_dxyz);                                                                                          \
+        if (f.num_levels <= 4) hipLaunchKernelGGL((hexsort_phase2_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, n);                     \
+        else hipLaunchKernelGGL((hexsort_phase2_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, n);                 \
+        break;
+    switch (C) { GSR_HEXSORT_CASE(8) GSR_HEXSORT_CASE(16) GSR_HEXSORT_CASE(32) GSR_HEXSORT_CASE(64) }
+#undef GSR_HEXSORT_CASE
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }
-
 
 // ---- dense-layer weight gradient (include/deformation_field.h) -----------------------------------------------------------------
 static void wgrad_plan(int64_t n, int64_t* chunk, int* nblocks)

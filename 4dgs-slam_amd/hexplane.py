@@ -10,6 +10,7 @@ logical shape (load_state_dict, the TV regularisers of scene/gaussian_model.py:9
 There is no CPU path: the product fails loudly when the tensors are not on a HIP device or the library is missing."""
 import ctypes
 import itertools
+import os
 from typing import Iterable, Optional, Sequence
 
 import torch
@@ -18,6 +19,7 @@ import torch.nn as nn
 from diff_gaussian_rasterization import _C
 
 MAX_LEVELS = 8
+BINNED_MIN_POINTS = 49152        # below this the direct-atomic backward is as fast (both are launch-bound) and needs no workspace
 
 
 class _Level(ctypes.Structure):
@@ -40,7 +42,9 @@ def _lib():
         lib.gsr_hexplane_forward.restype = ctypes.c_int
         lib.gsr_hexplane_forward.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, vp, i64, vp, vp]
         lib.gsr_hexplane_backward.restype = ctypes.c_int
-        lib.gsr_hexplane_backward.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, vp, i64, vp, vp, vp]
+        lib.gsr_hexplane_backward.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, vp, i64, vp, vp, vp, vp]
+        lib.gsr_hexplane_backward_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_hexplane_backward_workspace_size.argtypes = [ctypes.POINTER(_Field), i64]
         _lib_cache = lib
     return _lib_cache
 
@@ -56,8 +60,29 @@ def _plane_layout(p: torch.Tensor) -> int:
     raise ValueError(f"HexPlane plane of shape {tuple(p.shape)} has strides {s}: neither channels_last nor contiguous")
 
 
+_descriptor_cache = {}
+
+
 def _describe(levels, aabb, grads=None):
-    """levels: list of lists of six [1, C, H, W] tensors -> the C descriptor (+ the resolutions it implies)."""
+    """levels: list of lists of six [1, C, H, W] tensors -> the C descriptor.  The validated geometry of a plane set is cached by
+    the planes' (address, shape, strides): a field is described once, later calls only refresh the aabb and gradient pointers."""
+    key = tuple((p.data_ptr(), p.shape, p.stride()) for planes in levels for p in planes)
+    cached = _descriptor_cache.get(key)
+    if cached is None:
+        if len(_descriptor_cache) > 64:
+            _descriptor_cache.clear()
+        cached = _descriptor_cache[key] = _describe_uncached(levels)
+    f = _Field.from_buffer_copy(cached)
+    f.aabb = aabb.data_ptr() if aabb is not None else None
+    if grads is not None:
+        for l, row in enumerate(grads):
+            for p, g in enumerate(row):
+                f.levels[l].grad_planes[p] = g.data_ptr() if g is not None else None
+    return f
+
+
+def _describe_uncached(levels):
+    aabb, grads = None, None
     if not 1 <= len(levels) <= MAX_LEVELS:
         raise ValueError(f"HexPlane field with {len(levels)} levels (1..{MAX_LEVELS} supported)")
     f = _Field()
@@ -87,7 +112,7 @@ def _describe(levels, aabb, grads=None):
             f.levels[l].grad_planes[p] = grads[l][p].data_ptr() if grads is not None and grads[l][p] is not None else None
         for k in range(4):
             f.levels[l].res[k] = res[k]
-    return f
+    return bytes(f)
 
 
 class _HexPlaneFeatures(torch.autograd.Function):
@@ -134,18 +159,23 @@ class _HexPlaneFeatures(torch.autograd.Function):
             if not need:
                 views.append(None)
                 continue
-            _, C, H, W = p.shape
-            seg = flat[o:o + sz]
-            views.append(seg.view(1, H, W, C).permute(0, 3, 1, 2) if layout else seg.view(1, C, H, W))
+            views.append(torch.as_strided(flat, p.shape, p.stride(), o))      # the plane's own strides (either layout), offset o
             o += sz
         grads = [views[6 * l:6 * l + 6] for l in range(n_levels)]
         g = g.contiguous()
         gxyz = torch.empty((xyz.shape[0], 3), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
         field = _describe(levels, aabb, grads)
         lib = _lib()
+        # large batches on channels-last planes: the binned algorithm (counting sort per plane family, LDS accumulation per plane
+        # region, one flush) -- needs a workspace; small ones: one atomic per (point, corner)
+        ws = None
+        mode = os.environ.get("GSR_HEX_BINNED", "auto")
+        if layout == 1 and any(need_plane) and mode != "0" and (mode == "1" or xyz.shape[0] >= BINNED_MIN_POINTS):
+            ws = torch.empty(lib.gsr_hexplane_backward_workspace_size(ctypes.byref(field), xyz.shape[0]), dtype=torch.uint8, device=g.device)
         with torch.cuda.device(g.device):
             rc = lib.gsr_hexplane_backward(ctypes.byref(field), xyz.shape[0], xyz.data_ptr(), xyz.stride(0), time.data_ptr(), time.stride(0),
-                                           g.data_ptr(), gxyz.data_ptr() if gxyz is not None else None, _C._stream(g.device))
+                                           g.data_ptr(), gxyz.data_ptr() if gxyz is not None else None,
+                                           ws.data_ptr() if ws is not None else None, _C._stream(g.device))
         if rc < 0:
             _C._err(lib, rc, "gsr_hexplane_backward")
         if gxyz is not None and xyz.shape[1] > 3:                  # rows were a slice of a wider tensor
@@ -157,9 +187,23 @@ class _HexPlaneFeatures(torch.autograd.Function):
 
 def hexplane_features(pts, timestamps, aabb, ms_grids) -> torch.Tensor:
     """Fused normalize_aabb + interpolate_ms_features(concat_features=True).  aabb None: pts are already normalised."""
+    if isinstance(ms_grids, _PlaneList):                              # prepared by HexPlaneField: no nn.ParameterList walk per call
+        return _HexPlaneFeatures.apply(pts, timestamps, aabb, ms_grids.n_levels, *ms_grids.flat)
     levels = [list(g) for g in ms_grids]
     flat = [p for lv in levels for p in lv]
     return _HexPlaneFeatures.apply(pts, timestamps, aabb, len(levels), *flat)
+
+
+class _PlaneList:
+    """The planes of a HexPlaneField's nn.ModuleList of nn.ParameterList as a flat Python list."""
+
+    def __init__(self, grids):
+        # straight from the registries: iterating nn.ModuleList / nn.ParameterList goes through __getitem__ (~4 us per entry)
+        self.flat = [p for lv in grids._modules.values() for p in lv._parameters.values()]
+        self.n_levels = len(grids._modules)
+
+    def __iter__(self):                                               # still usable as ms_grids: a sequence of levels
+        return (self.flat[6 * l:6 * l + 6] for l in range(self.n_levels))
 
 
 # ---- the reference module's public names ------------------------------------------------------------------------------------
@@ -233,7 +277,7 @@ class HexPlaneField(nn.Module):
         pts = pts.reshape(-1, pts.shape[-1])
         if pts.shape[0] == 0:
             return torch.zeros((0, 1), device=pts.device)              # :174-175
-        return hexplane_features(pts, timestamps.reshape(-1, timestamps.shape[-1]), self.aabb, self.grids)
+        return hexplane_features(pts, timestamps.reshape(-1, timestamps.shape[-1]), self.aabb, _PlaneList(self.grids))
 
     def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
         return self.get_density(pts, timestamps)

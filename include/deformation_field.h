@@ -61,7 +61,13 @@ int gsr_hexplane_forward(const gsr_hexplane_field* field, int64_t n, const float
  * by normalize_aabb or sitting on the sampler's border (GridSampler.h clip_coordinates_set_grad).  Time receives no gradient
  * (the reference builds it with torch.tensor(...).repeat, gaussian_renderer/__init__.py:112). */
 int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, const float* time,
-                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, void* stream);
+                          int64_t time_stride, const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream);
+/* `workspace` (gsr_hexplane_backward_workspace_size bytes, contents undefined on entry) selects the sorted algorithm: the points
+ * are counting-sorted per plane family by the Morton code of their finest-level cell, dL/dsample is staged in the workspace in
+ * sorted order, and runs of points that share a cell are summed in registers before ONE set of four atomics per run
+ * (channels-last planes, resolutions <= 1024) -- the fast path for large n, and the one whose cost falls rather than rises when
+ * many points share texels.  workspace NULL = one float atomic per (point, corner), no extra memory. */
+size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int64_t n);
 
 /* ---- weight gradient of the deformation MLP's dense layers ----------------------------------------------------------------
  * utils/deformation.py:58-70 builds the network from nn.Linear layers (width 64, inputs <= 128) applied to every point; their

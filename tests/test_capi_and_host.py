@@ -64,7 +64,7 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     field.num_levels, field.feat_dim = 0, 32
     assert hl.gsr_hexplane_forward(ctypes.byref(field), 4, None, 3, None, 1, None, None) == -1 and b"num_levels" in lib.gsr_last_error()
     field.num_levels, field.feat_dim = 1, 12
-    assert hl.gsr_hexplane_backward(ctypes.byref(field), 4, None, 3, None, 1, None, None, None) == -1 and b"feat_dim" in lib.gsr_last_error()
+    assert hl.gsr_hexplane_backward(ctypes.byref(field), 4, None, 3, None, 1, None, None, None, None) == -1 and b"feat_dim" in lib.gsr_last_error()
     field.feat_dim = 32
     assert hl.gsr_hexplane_forward(ctypes.byref(field), 4, None, 3, None, 1, None, None) == -1 and b"resolution" in lib.gsr_last_error()
     lib.gsr_linear_wgrad.restype = i

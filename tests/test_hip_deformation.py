@@ -53,8 +53,10 @@ def golden_field(layout):
     return levels
 
 
-@pytest.mark.parametrize("layout", ["channels_last", "contiguous"])
-def test_field_matches_reference_golden(layout):
+@pytest.mark.parametrize("layout", ["channels_last", "contiguous", "channels_last_binned"])
+def test_field_matches_reference_golden(layout, monkeypatch):
+    monkeypatch.setenv("GSR_HEX_BINNED", "1" if layout.endswith("binned") else "0")
+    layout = layout.replace("_binned", "")
     levels = golden_field(layout)
     pts = torch.tensor(G["field/pts"], device=DEV, requires_grad=True)
     feat = hexplane.hexplane_features(pts, torch.tensor(G["field/time"], device=DEV), torch.tensor(G["field/aabb"], device=DEV), levels)
@@ -106,7 +108,10 @@ def default_field(seed=0, scale=1.0):
     return field
 
 
-def test_shipped_geometry_against_oracle_fp64_and_torch_grid_sample():
+@pytest.mark.parametrize("binned", ["0", "1"])
+def test_shipped_geometry_against_oracle_fp64_and_torch_grid_sample(binned, monkeypatch):
+    """binned = "1": the counting-sort + LDS-accumulation backward (gs_hexplane_binned.h); "0": one atomic per (point, corner)."""
+    monkeypatch.setenv("GSR_HEX_BINNED", binned)
     field = default_field()
     rng = np.random.default_rng(3)
     n = 20000
@@ -145,8 +150,10 @@ def test_shipped_geometry_against_oracle_fp64_and_torch_grid_sample():
             assert rel(field.grids[l][p].grad, lv64[l][p].grad) < 1e-4, (l, p)   # fp32 kernel vs the exact answer
 
 
+@pytest.mark.parametrize("binned", ["0", "1"])
 @pytest.mark.parametrize("C", [8, 16, 64])
-def test_other_feature_widths(C):
+def test_other_feature_widths(C, binned, monkeypatch):
+    monkeypatch.setenv("GSR_HEX_BINNED", binned)
     rng = np.random.default_rng(C)
     res = [5, 4, 6, 3]
     levels = []
@@ -275,3 +282,45 @@ def test_linear_weight_gradient_kernel(n, in_dim, out_dim):
     x2 = x.detach().clone().requires_grad_(True)
     ref = torch.nn.functional.linear(x2, lin.weight, lin.bias)
     assert torch.allclose(lin(x2), ref)
+
+
+@pytest.mark.parametrize("case", ["clustered", "one_texel", "uniform_t_large", "border"])
+def test_binned_backward_on_hostile_distributions(case, monkeypatch):
+    """The binned backward against the direct one: every point in one bin (split over several blocks), every point in ONE texel,
+    a large uniform-time batch (the render(dynamic=True) call shape), points on / outside the aabb faces."""
+    field = default_field(4)
+    rng = np.random.default_rng(9)
+    n = 60000
+    if case == "clustered":
+        pts = rng.normal(scale=0.01, size=(n, 3)) + np.array([0.3, -0.4, 0.2])
+        tim = np.full((n, 1), 0.1)
+    elif case == "one_texel":
+        pts = np.tile(np.array([[0.123, 0.456, -0.789]]), (n, 1)) + rng.uniform(-1e-5, 1e-5, size=(n, 3))
+        tim = np.full((n, 1), -0.5)
+    elif case == "uniform_t_large":
+        n = 150000
+        pts = rng.uniform(-1.6, 1.6, size=(n, 3))
+        tim = np.full((n, 1), 0.73)
+    else:
+        pts = rng.choice(np.array([-1.7, -1.6, 1.6, 1.7, 0.0]), size=(n, 3))
+        tim = rng.choice(np.array([-1.2, -1.0, 1.0, 1.3]), size=(n, 1))
+    pts_t = torch.tensor(pts.astype(np.float32), device=DEV)
+    tim_t = torch.tensor(tim.astype(np.float32), device=DEV)
+    cot = torch.tensor(rng.normal(size=(n, 128)).astype(np.float32), device=DEV)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GSR_HEX_BINNED", mode)
+        for lv in field.grids:
+            for p in lv:
+                p.grad = None
+        x = pts_t.clone().requires_grad_(True)
+        (field(x, tim_t) * cot).sum().backward()
+        results[mode] = (x.grad.clone(), [[p.grad.clone() for p in lv] for lv in field.grids])
+    assert torch.equal(results["0"][0], results["1"][0])                      # dL/dxyz does not go through the atomics
+    for l in range(4):
+        for p in range(6):
+            a, b = results["0"][1][l][p], results["1"][1][l][p]
+            # both sum the same terms in different orders: compare against the size of the terms
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) / scale < 2e-4, (case, l, p, float((a - b).abs().max()) / scale)
+            assert rel(a, b) < 1e-4, (case, l, p)
