@@ -87,9 +87,11 @@ def _python_colors(pc, cam):
 def _fused_prologue_ok(pc, pipe, mask, dynamic) -> bool:
     """The fused route reproduces exactly the branch of render() taken with the shipped configs: SH colours and covariance
     from scale/rotation in the rasterizer (pipe.convert_SHs_python = compute_cov3D_python = False, base_config.yaml), no
-    boolean mask, no 4DGaussians deformation network, and a GaussianModel whose activations are the reference's
-    (scene/gaussian_model.py:60-68: exp, sigmoid, F.normalize)."""
-    if not FUSED_PROLOGUE or _raw is None or dynamic:
+    and a GaussianModel whose activations are the reference's (scene/gaussian_model.py:60-68: exp, sigmoid, F.normalize).  With
+    `dynamic` the 4DGaussians deformation network runs first and ITS outputs (deformed means, log-scales, raw rotations) take the
+    place of the raw parameters; the combination dynamic + control-node deltas keeps the reference's torch chain (:159-174 then
+    overwrite part of the network's result)."""
+    if not FUSED_PROLOGUE or _raw is None:
         return False
     if getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
         return False
@@ -102,13 +104,28 @@ def _fused_prologue_ok(pc, pipe, mask, dynamic) -> bool:
     return acts and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in raws)
 
 
-def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr, mask=None):
+def _deform(pc, viewpoint_camera, means3D, shs):
+    """The 4DGaussians deformation field (:149-157): (deformed means, log-scales, raw rotations)."""
+    time = torch.tensor(viewpoint_camera.time).to(means3D.device).repeat(means3D.shape[0], 1)
+    raw_scaling = pc._scaling.repeat(1, 3) if pc._scaling.shape[-1] == 1 else pc._scaling
+    means3D, scales_final, rotations_final, _, _, _ = pc._deformation(means3D, raw_scaling, pc._rotation, pc._opacity, shs, time)
+    return means3D, scales_final, rotations_final
+
+
+def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr, mask=None, dynamic=False):
     deltas = dx is not None and ds is not None and dr is not None        # the reference applies them only together (:159)
     slot = _raw.dyn_slot_from_mask(pc.dygs) if deltas else None
     f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
+    xyz, log_scales, raw_rot = pc._xyz, pc._scaling, pc._rotation
+    if dynamic:
+        # the network's outputs are "raw parameters" too: exp / normalize (:155-156) and their chain rules happen in the kernels.
+        # shs is handed over only if the network can use it (no_dshs False); the reference concatenates it for every call (:145)
+        net_args = getattr(getattr(pc._deformation, "deformation_net", None), "args", None)
+        shs = None if getattr(net_args, "no_dshs", False) else pc.get_features
+        xyz, log_scales, raw_rot = _deform(pc, viewpoint_camera, pc.get_xyz, shs)
     return _raw.rasterize_gaussians_raw(
-        _settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree), pc._xyz, screenspace_points, pc._scaling,
-        pc._rotation, pc._opacity, pc._features_dc, f_rest, slot, dx if deltas else None, ds if deltas else None,
+        _settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree), xyz, screenspace_points, log_scales,
+        raw_rot, pc._opacity, pc._features_dc, f_rest, slot, dx if deltas else None, ds if deltas else None,
         dr if deltas else None, viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta,
         gather=None if mask is None else _raw.gather_from_mask(mask))
 
@@ -120,15 +137,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if pc.get_xyz.shape[0] == 0:
         return None
     screenspace_points = _screenspace_points(pc)
-    if _fused_prologue_ok(pc, pipe, mask, dynamic):
+    deltas = dx is not None and ds is not None and dr is not None
+    if _fused_prologue_ok(pc, pipe, mask, dynamic) and not (dynamic and deltas):
         rendered_image, radii, depth, opacity, n_touched = _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
-                                                                         screenspace_points, dx, ds, dr, mask)
+                                                                         screenspace_points, dx, ds, dr, mask, dynamic)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
                 "depth": depth, "opacity": opacity, "n_touched": n_touched}
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree))
 
     means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
-    time = torch.tensor(viewpoint_camera.time).to(means3D.device).repeat(means3D.shape[0], 1)
 
     # covariance: Python-side precompute, or scales (+ isotropic expansion) / rotations for the kernel (:116-127)
     scales = rotations = cov3D_precomp = None
@@ -146,8 +163,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         shs = pc.get_features
 
     if dynamic:  # 4DGaussians deformation field (:149-157)
-        raw_scaling = pc._scaling.repeat(1, 3) if pc.get_scaling.shape[-1] == 1 else pc._scaling
-        means3D, scales_final, rotations_final, _, _, _ = pc._deformation(means3D, raw_scaling, pc._rotation, pc._opacity, shs, time)
+        means3D, scales_final, rotations_final = _deform(pc, viewpoint_camera, means3D, shs)
         scales = pc.scaling_activation(scales_final)
         rotations = pc.rotation_activation(rotations_final)
 

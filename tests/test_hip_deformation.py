@@ -236,25 +236,47 @@ def test_bad_arguments_raise():
 
 def test_render_dynamic_through_the_deformation_network():
     """render(dynamic=True) (gaussian_renderer/__init__.py:149-157) with the build's deform_network as pc._deformation: gradients
-    reach the planes, the MLP and the Gaussian parameters."""
+    reach the planes, the MLP and the Gaussian parameters -- and the route that hands the network's outputs to the kernels as raw
+    parameters (exp / normalize in-kernel) gives the same image and gradients as the reference's torch chain."""
     import types
     import gaussian_renderer
     from util import make_camera, make_gaussians
     from test_hip_fused_prologue import _GaussianModel, _camera
     cam = make_camera(160, 120)
-    pc = _GaussianModel(make_gaussians(3000, cam, seed=2), isotropic=False, dyn_frac=0.0, seed=3)
     pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
     bg = torch.tensor([1.0, 1.0, 1.0], device=DEV)
-    view = _camera(cam)
-    view.time = 0.4
-    pc._deformation = deformation.deform_network(hidden_params(multires=[1, 2], bounds=8.0), DEV).to(DEV)
-    out = gaussian_renderer.render(view, pc, pipe, bg, dynamic=True)
-    loss = out["render"].mean() + 0.1 * out["depth"].mean()
-    loss.backward()
-    grid_g = [p.grad for p in pc._deformation.get_grid_parameters() if p.requires_grad]
-    assert all(g is not None for g in grid_g) and sum(float(g.abs().sum()) for g in grid_g) > 0
-    assert pc._xyz.grad is not None and torch.isfinite(pc._xyz.grad).all()
-    assert float(pc._deformation.deformation_net.pos_deform[3].weight.grad.abs().sum()) > 0
+    torch.manual_seed(0)
+    net = deformation.deform_network(hidden_params(multires=[1, 2], bounds=8.0), DEV).to(DEV)
+    results = {}
+    for fused in (False, True):
+        pc = _GaussianModel(make_gaussians(3000, cam, seed=2), isotropic=False, dyn_frac=0.0, seed=3)
+        view = _camera(cam)
+        view.time = 0.4
+        pc._deformation = net
+        for p in net.parameters():
+            p.grad = None
+        gaussian_renderer.FUSED_PROLOGUE = fused
+        try:
+            assert gaussian_renderer._fused_prologue_ok(pc, pipe, None, True) == fused
+            out = gaussian_renderer.render(view, pc, pipe, bg, dynamic=True)
+        finally:
+            gaussian_renderer.FUSED_PROLOGUE = True
+        (out["render"].mean() + 0.1 * out["depth"].mean()).backward()
+        grads = {"xyz": pc._xyz.grad, "scaling": pc._scaling.grad, "rotation": pc._rotation.grad, "opacity": pc._opacity.grad,
+                 "theta": view.cam_rot_delta.grad, "rho": view.cam_trans_delta.grad}
+        grads.update({"net." + k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+        results[fused] = (out, grads)
+    (o0, g0), (o1, g1) = results[False], results[True]
+    assert rel(o1["render"], o0["render"]) < 1e-5 and rel(o1["depth"], o0["depth"]) < 1e-5 and torch.equal(o1["radii"], o0["radii"])
+    assert set(g0) == set(g1)
+    for k in g0:
+        if float(g0[k].abs().max()) < 1e-12:
+            assert float(g1[k].abs().max()) < 1e-9, k
+        else:
+            assert rel(g1[k], g0[k]) < 5e-4, (k, rel(g1[k], g0[k]))
+    grid_g = [v for k, v in g1.items() if "grids" in k]
+    assert len(grid_g) == 12 and sum(float(g.abs().sum()) for g in grid_g) > 0
+    assert float(g1["net.deformation_net.pos_deform.3.weight"].abs().sum()) > 0 and torch.isfinite(g1["xyz"]).all()
 
 
 @pytest.mark.parametrize("n,in_dim,out_dim", [(1, 64, 3), (5, 4, 64), (63, 128, 64), (64, 64, 4), (1000, 100, 48), (4097, 128, 70),
