@@ -28,6 +28,7 @@
 #include "gs_hexplane.h"
 #include "gs_hexplane_binned.h"
 #include "gs_linear.h"
+#include "gs_mlp.h"
 #include "gs_nodes.h"
 #include "../../include/slam_losses.h"
 
@@ -1012,6 +1013,80 @@ int gsr_linear_wgrad(int64_t n, int in_dim, int out_dim, const float* x, int64_t
     return 0;
 }
 
+// ---- fused deformation MLP (include/deformation_field.h) ------------------------------------------------------------------------------
+static int mlp_fill(const gsr_deform_mlp* m, MlpWeights* w, const char* who)
+{
+    static thread_local std::string msg;
+    auto fail = [&](const char* what) { msg = std::string(who) + ": " + what; g_last_error = msg.c_str(); return GSR_ERR_INVALID_ARGUMENT; };
+    if (!m) return fail("null descriptor");
+    if (m->in_dim < 16 || m->in_dim > 128 || m->in_dim % 16) return fail("in_dim must be a multiple of 16 in 16..128");
+    if (!m->W0 || !m->b0) return fail("null W0 / b0");
+    static const int od[3] = {3, 3, 4}, oo[3] = {0, 3, 6};
+    w->W0 = m->W0; w->b0 = m->b0; w->in_dim = m->in_dim;
+    for (int j = 0; j < 3; j++) {
+        if (!m->W1[j] || !m->b1[j] || !m->W2[j] || !m->b2[j]) return fail("null head weights");
+        w->W1[j] = m->W1[j]; w->b1[j] = m->b1[j]; w->W2[j] = m->W2[j]; w->b2[j] = m->b2[j];
+        w->out_dim[j] = od[j]; w->out_off[j] = oo[j];
+    }
+    return 0;
+}
+
+static dim3 mlp_grid(int64_t n)
+{
+    const int64_t tiles = (n + MLP_TILE - 1) / MLP_TILE;
+    return dim3((unsigned)std::min<int64_t>(tiles, 256 * 16));   // persistent beyond 16 blocks per CU
+}
+
+constexpr int MLP_BWD_BLOCKS = 256;      // persistent: one block per CU (103 KB of LDS each)
+
+int gsr_deform_mlp_forward(const gsr_deform_mlp* mlp, int64_t n, const float* features, float* out, void* stream_)
+{
+    MlpWeights w;
+    if (int rc = mlp_fill(mlp, &w, "gsr_deform_mlp_forward")) return rc;
+    if (n < 0 || (n > 0 && (!features || !out))) { g_last_error = "gsr_deform_mlp_forward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return 0;
+    switch (w.in_dim / 16) {
+#define GSR_MLPF_CASE(NT) case NT: hipLaunchKernelGGL((deform_mlp_fwd_kernel<NT>), mlp_grid(n), dim3(MLP_BLOCK), 0, (hipStream_t)stream_, n, features, w, out); break;
+        GSR_MLPF_CASE(1) GSR_MLPF_CASE(2) GSR_MLPF_CASE(3) GSR_MLPF_CASE(4) GSR_MLPF_CASE(5) GSR_MLPF_CASE(6) GSR_MLPF_CASE(7) GSR_MLPF_CASE(8)
+#undef GSR_MLPF_CASE
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+size_t gsr_deform_mlp_grad_count(int in_dim)
+{
+    static const int od[3] = {3, 3, 4};
+    return (size_t)mlp_grad_layout(in_dim, od).total;
+}
+
+size_t gsr_deform_mlp_workspace_size(int in_dim)
+{
+    return (size_t)MLP_BWD_BLOCKS * gsr_deform_mlp_grad_count(in_dim) * sizeof(float) + 256;
+}
+
+int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
+                            float* grads, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    MlpWeights w;
+    if (int rc = mlp_fill(mlp, &w, "gsr_deform_mlp_backward")) return rc;
+    if (n < 0 || !grads || !workspace || (n > 0 && (!features || !dout || !dfeatures))) {
+        g_last_error = "gsr_deform_mlp_backward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const int total = (int)gsr_deform_mlp_grad_count(w.in_dim);
+    if (n == 0) { GSR_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)total * sizeof(float), stream)); return 0; }
+    const int blocks = (int)std::min<int64_t>(MLP_BWD_BLOCKS, (n + MLPB_TILE - 1) / MLPB_TILE);
+    float* partial = reinterpret_cast<float*>(workspace);
+    switch (w.in_dim / 16) {
+#define GSR_MLPB_CASE(NT) case NT: hipLaunchKernelGGL((deform_mlp_bwd_kernel<NT>), dim3(blocks), dim3(MLPB_BLOCK), 0, stream, n, features, dout, w, dfeatures, partial); break;
+        GSR_MLPB_CASE(1) GSR_MLPB_CASE(2) GSR_MLPB_CASE(3) GSR_MLPB_CASE(4) GSR_MLPB_CASE(5) GSR_MLPB_CASE(6) GSR_MLPB_CASE(7) GSR_MLPB_CASE(8)
+#undef GSR_MLPB_CASE
+    }
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, blocks, total, (const float*)partial, grads);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 // ---- SC-GS control nodes (include/control_nodes.h) ------------------------------------------------------------------------------
 int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream_)

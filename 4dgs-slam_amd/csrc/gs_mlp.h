@@ -1,0 +1,402 @@
+// gs_mlp.h -- the deformation MLP of the 4D-Gaussians network as two fused kernels (forward; backward w.r.t. activations).
+//
+// Reference: utils/deformation.py:58-70 (create_net) and :101-149 (forward_dynamic) with the shipped flags (defor_depth 1, width 64,
+// no_dx / no_ds / no_dr False, no_do / no_dshs True):
+//     h0 = F W0^T + b0                       F  [n, in]   HexPlane features (in = 128)
+//     a  = relu(h0)                          shared first ReLU of the three heads
+//     u_j = a W1j^T + b1j,  v_j = relu(u_j)  j = position, scale, rotation           [n, 64] each
+//     o_j = v_j W2j^T + b2j                  [n, 3], [n, 3], [n, 4]
+// The reference runs this as 7 GEMMs + 6 ReLUs + 7 bias adds per call (and twice that on the way back), each a round trip of
+// [n, 64] activations through HBM; the vendor GEMM handles the 3- and 4-column layers badly.
+//
+// Here one wave owns 16 points and carries them through all layers: v_mfma_f32_16x16x4_f32 (exact fp32: a k-ordered fmaf chain, so
+// results match an fp32 GEMM to rounding order), weights straight from L2 in MFMA fragment order (the whole network is 85 KB), the
+// activations of a layer handed to the next through an LDS tile (the MFMA result layout is rows = points in registers, the A
+// operand wants rows = points in lanes).  The forward kernel writes only the 10 outputs per point; the backward kernel recomputes the
+// activations from the features and produces dF and ALL parameter gradients (persistent register accumulators, see below).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gs_linear.h"
+
+namespace gsr {
+
+constexpr int MLP_W = 64;                 // network width (arguments/__init__.py: net_width = 64)
+constexpr int MLP_HEADS = 3;
+constexpr int MLP_OUT = 10;               // 3 + 3 + 4
+constexpr int MLP_BLOCK = 128;            // 2 waves x 16 points, 8.7 KB of LDS per block: 16 waves per CU hide the L2 latency of the weights
+constexpr int MLP_TILE = MLP_BLOCK / 64 * 16;
+constexpr int MLP_LDA = MLP_W + 4;        // LDS row stride of a [16][64] tile (floats): 16-byte aligned, conflict-free float4 reads
+
+struct MlpWeights {
+    const float* W0; const float* b0;                      // [64, in], [64]
+    const float* W1[MLP_HEADS]; const float* b1[MLP_HEADS]; // [64, 64], [64]
+    const float* W2[MLP_HEADS]; const float* b2[MLP_HEADS]; // [o_j, 64], [o_j]
+    int in_dim;                                             // multiple of 16, <= 128
+    int out_dim[MLP_HEADS];                                 // <= 4 each
+    int out_off[MLP_HEADS];                                 // column of head j in the [n, 10] output
+};
+
+__device__ __forceinline__ f32x4 mfma4(const float4 a, const float4 b, f32x4 c)   // four k-steps of one accumulator
+{
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+
+// four k-steps of four independent accumulators, interleaved so that consecutive MFMAs never depend on each other (a dependent
+// 16x16x4 issues after 40 cycles instead of 32)
+__device__ __forceinline__ void mfma4x4(const float4 a, const float4 (&b)[4], f32x4 (&c)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t].x, c[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t].y, c[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t].z, c[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; t++) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t].w, c[t], 0, 0, 0);
+}
+
+// Lane l = (i = l & 15, q = l >> 4).  A / B fragments are loaded as float4: K indices 16 S + 4 q + e, e = 0..3 (any assignment of K
+// indices to k-steps is fine as long as A and B agree).  C layout: column = i, rows = 4 q + r.
+template <int NT_IN>
+__global__ void __launch_bounds__(MLP_BLOCK)
+deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const MlpWeights w, float* __restrict__ out)
+{
+    constexpr int IN = 16 * NT_IN;
+    __shared__ __attribute__((aligned(16))) float s_a[MLP_BLOCK / 64][16][MLP_LDA];
+    __shared__ __attribute__((aligned(16))) float s_v[MLP_BLOCK / 64][16][MLP_LDA];   // one head at a time: 8.7 KB of LDS per block
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int64_t tiles = (n + MLP_TILE - 1) / MLP_TILE;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * MLP_TILE + wave * 16;
+        const int64_t prow = p0 + i;                              // the point this lane supplies as A row
+        // ---- h0 = F W0^T + b0 ----
+        f32x4 acc1[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const float b = w.b0[16 * t + i]; acc1[t] = f32x4{b, b, b, b}; }
+#pragma unroll
+        for (int S = 0; S < NT_IN; S++) {
+            const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b4[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W0 + (size_t)(16 * t + i) * IN + 16 * S + 4 * q);
+            mfma4x4(a4, b4, acc1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                s_a[wave][4 * q + r][16 * t + i] = fmaxf(acc1[t][r], 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- per head: u_j = a W1j^T + b1j, v_j = relu(u_j), o_j = v_j W2j^T + b2j (one 16-column tile, columns >= out_dim zero) ----
+#pragma unroll
+        for (int j = 0; j < MLP_HEADS; j++) {
+            f32x4 acc2[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const float b = w.b1[j][16 * t + i]; acc2[t] = f32x4{b, b, b, b}; }
+#pragma unroll
+            for (int S = 0; S < MLP_W / 16; S++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_a[wave][i][16 * S + 4 * q]);
+                float4 b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)(16 * t + i) * MLP_W + 16 * S + 4 * q);
+                mfma4x4(a4, b4, acc2);
+            }
+            if (j > 0) __syncthreads();                           // the previous head's v tile has been read
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    s_v[wave][4 * q + r][16 * t + i] = fmaxf(acc2[t][r], 0.f);
+                }
+            }
+            __syncthreads();
+            const bool col_ok = i < w.out_dim[j];
+            const float b = col_ok ? w.b2[j][i] : 0.f;
+            f32x4 acc3 = f32x4{b, b, b, b};
+#pragma unroll
+            for (int S = 0; S < MLP_W / 16; S++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_v[wave][i][16 * S + 4 * q]);
+                const float4 b4 = col_ok ? *reinterpret_cast<const float4*>(w.W2[j] + (size_t)i * MLP_W + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc3 = mfma4(a4, b4, acc3);
+            }
+            if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t p = p0 + 4 * q + r;
+                    if (p < n) out[p * MLP_OUT + w.out_off[j] + i] = acc3[r];
+                }
+            }
+        }
+        __syncthreads();                                          // the tiles are rewritten by the next iteration
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------------------------
+// One block = 4 waves = 64 points per iteration, persistent over the batch.  Nothing of the forward pass is read back: the block
+// recomputes h0, a, u_j, v_j from the features (cheaper than the 1 KB per point of pre-activations the forward pass would have to
+// store and three later kernels re-read), forms du_j, dh0, dF, and accumulates EVERY weight gradient in registers across its
+// iterations -- each wave owns a quarter of the output tiles of dW0 / dW1j / dW2j and reduces over the block's 64 points, with the
+// activation tiles of all four waves shared through LDS.  At the end the block writes one row of partial sums; a second kernel adds
+// the rows in a fixed order.  HBM traffic: features + dout in, dF out.
+//
+// flat gradient layout (also of a partial row): W0 [64][in] | b0 [64] | per head j: W1j [64][64] | b1j [64] | W2j [o_j][64] | b2j [o_j]
+struct MlpGradLayout {
+    int W0, b0, W1[MLP_HEADS], b1[MLP_HEADS], W2[MLP_HEADS], b2[MLP_HEADS], total;
+};
+
+__host__ __device__ inline MlpGradLayout mlp_grad_layout(int in_dim, const int* out_dim)
+{
+    MlpGradLayout g;
+    int off = 0;
+    g.W0 = off; off += MLP_W * in_dim;
+    g.b0 = off; off += MLP_W;
+    for (int j = 0; j < MLP_HEADS; j++) {
+        g.W1[j] = off; off += MLP_W * MLP_W;
+        g.b1[j] = off; off += MLP_W;
+        g.W2[j] = off; off += out_dim[j] * MLP_W;
+        g.b2[j] = off; off += out_dim[j];
+    }
+    g.total = off;
+    return g;
+}
+
+constexpr int MLPB_BLOCK = 256;           // 4 waves
+constexpr int MLPB_TILE = 64;             // points per block iteration
+constexpr int MLPB_LDF = 128 + 4;         // feature tile row stride (in_dim <= 128)
+
+template <int NT_IN>                      // in_dim / 16
+__global__ void __launch_bounds__(MLPB_BLOCK)
+deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const float* __restrict__ dout, const MlpWeights w,
+                      float* __restrict__ dfeat, float* __restrict__ partial)
+{
+    constexpr int IN = 16 * NT_IN;
+    __shared__ __attribute__((aligned(16))) float s_f[MLPB_TILE][MLPB_LDF];     // features of the block's 64 points
+    __shared__ __attribute__((aligned(16))) float s_a[MLPB_TILE][MLP_LDA];      // a = relu(h0)
+    __shared__ __attribute__((aligned(16))) float s_v[MLPB_TILE][MLP_LDA];      // v_j = relu(u_j), one head at a time
+    __shared__ __attribute__((aligned(16))) float s_d[MLPB_TILE][MLP_LDA];      // du_j, one head at a time; then dh0
+    __shared__ float s_o[MLPB_TILE][12];                                          // dout of the block's points (10 used)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int bc = threadIdx.x & 63, bg = threadIdx.x >> 6;                       // bias sums: column bc over rows 16 bg .. 16 bg + 15
+
+    // persistent weight-gradient accumulators (this wave's share) ...
+    f32x4 gW0[NT_IN];                     // rows 16 wave .. +15 of dW0, all in-tiles
+    f32x4 gW1[MLP_HEADS][4];              // rows 16 wave .. +15 of dW1j
+    f32x4 gW2[MLP_HEADS];                 // rows 0 .. 15 (o_j valid) x columns 16 wave .. +15 of dW2j
+#pragma unroll
+    for (int t = 0; t < NT_IN; t++) gW0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) {
+        gW2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; t++) gW1[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float gb0 = 0.f, gb1[MLP_HEADS] = {0.f, 0.f, 0.f}, gb2 = 0.f;                 // ... and bias sums (this thread's column / row group)
+
+    const int64_t tiles = (n + MLPB_TILE - 1) / MLPB_TILE;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t pblk = tile * MLPB_TILE;
+        const int r0 = wave * 16;                                 // this wave's rows of the block tile
+        const int64_t prow = pblk + r0 + i;
+        // stage dout (zero beyond n: those rows then contribute nothing anywhere)
+        for (int e = threadIdx.x; e < MLPB_TILE * MLP_OUT; e += MLPB_BLOCK) {
+            const int r = e / MLP_OUT, c = e - r * MLP_OUT;
+            s_o[r][c] = pblk + r < n ? dout[(pblk + r) * MLP_OUT + c] : 0.f;
+        }
+        // ---- recompute h0 = F W0^T + b0 for the wave's 16 points; keep the features and a = relu(h0) in LDS ----
+        f32x4 acc1[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const float b = w.b0[16 * t + i]; acc1[t] = f32x4{b, b, b, b}; }
+#pragma unroll
+        for (int S = 0; S < NT_IN; S++) {
+            const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&s_f[r0 + i][16 * S + 4 * q]) = a4;
+            float4 b4[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W0 + (size_t)(16 * t + i) * IN + 16 * S + 4 * q);
+            mfma4x4(a4, b4, acc1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_a[r0 + 4 * q + r][16 * t + i] = fmaxf(acc1[t][r], 0.f);
+        }
+        __syncthreads();
+        if (bc < MLP_OUT) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) gb2 += s_o[16 * bg + r][bc];
+        }
+        f32x4 da[4];                                              // dL/da of the wave's points
+#pragma unroll
+        for (int t = 0; t < 4; t++) da[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MLP_HEADS; j++) {
+            // u_j = a W1j^T + b1j (wave's points)
+            f32x4 acc2[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const float b = w.b1[j][16 * t + i]; acc2[t] = f32x4{b, b, b, b}; }
+#pragma unroll
+            for (int S = 0; S < MLP_W / 16; S++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_a[r0 + i][16 * S + 4 * q]);
+                float4 b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)(16 * t + i) * MLP_W + 16 * S + 4 * q);
+                mfma4x4(a4, b4, acc2);
+            }
+            // dv_j = dout_j W2j (one k-step), du_j = dv_j * [u_j > 0]; v_j = relu(u_j)
+            const bool k_ok = q < w.out_dim[j];
+            const float ao = k_ok ? s_o[r0 + i][w.out_off[j] + q] : 0.f;
+            if (j > 0) __syncthreads();                           // every wave is done with the previous head's s_v / s_d
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float b = k_ok ? w.W2[j][(size_t)q * MLP_W + 16 * t + i] : 0.f;
+                const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    s_v[r0 + 4 * q + r][16 * t + i] = fmaxf(acc2[t][r], 0.f);
+                    s_d[r0 + 4 * q + r][16 * t + i] = acc2[t][r] > 0.f ? dv[r] : 0.f;
+                }
+            }
+            __syncthreads();
+            // bias gradient b1j: column sums of du_j
+#pragma unroll
+            for (int r = 0; r < 16; r++) gb1[j] += s_d[16 * bg + r][bc];
+            // dW2j += dout_j^T v_j over the block's 64 points: rows = outputs (o_j valid), this wave's 16 columns
+            // dW1j += du_j^T a: this wave's 16 rows, all 64 columns.   A[i][k = point], B[k = point][column]: dword LDS reads
+#pragma unroll
+            for (int S = 0; S < MLPB_TILE / 4; S++) {
+                const int pt = 4 * S + q;
+                const float ao2 = i < w.out_dim[j] ? s_o[pt][w.out_off[j] + i] : 0.f;
+                gW2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao2, s_v[pt][16 * wave + i], gW2[j], 0, 0, 0);
+                const float ad = s_d[pt][16 * wave + i];
+#pragma unroll
+                for (int t = 0; t < 4; t++) gW1[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s_a[pt][16 * t + i], gW1[j][t], 0, 0, 0);
+            }
+            // dL/da += du_j W1j (wave's points):  B[k][col] = W1j[k][col]
+#pragma unroll
+            for (int S = 0; S < MLP_W / 16; S++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_d[r0 + i][16 * S + 4 * q]);
+                const float* wrow = w.W1[j] + (size_t)(16 * S + 4 * q) * MLP_W + i;
+                float4 b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) b4[t] = make_float4(wrow[16 * t], wrow[MLP_W + 16 * t], wrow[2 * MLP_W + 16 * t], wrow[3 * MLP_W + 16 * t]);
+                mfma4x4(a4, b4, da);
+            }
+        }
+        __syncthreads();                                          // the last head's s_d has been read by every wave
+        // ---- dh0 = dL/da * [a > 0] -> s_d ----
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_d[r0 + 4 * q + r][16 * t + i] = s_a[r0 + 4 * q + r][16 * t + i] > 0.f ? da[t][r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) gb0 += s_d[16 * bg + r][bc];
+        // ---- dW0 += dh0^T F over the block's points: this wave's 16 rows, all in-tiles ----
+#pragma unroll
+        for (int S = 0; S < MLPB_TILE / 4; S++) {
+            const int pt = 4 * S + q;
+            const float ad = s_d[pt][16 * wave + i];
+#pragma unroll
+            for (int t = 0; t < NT_IN; t++) gW0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s_f[pt][16 * t + i], gW0[t], 0, 0, 0);
+        }
+        // ---- dF = dh0 W0 (wave's points), four column tiles at a time ----
+#pragma unroll
+        for (int t0 = 0; t0 < NT_IN; t0 += 4) {
+            f32x4 accf[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) accf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < MLP_W / 16; S++) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_d[r0 + i][16 * S + 4 * q]);
+                const float* wrow = w.W0 + (size_t)(16 * S + 4 * q) * IN + 16 * t0 + i;
+                float4 b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int c = t0 + t < NT_IN ? 16 * t : 0;    // in_dim not a multiple of 64: the surplus tiles redo tile t0 and are dropped
+                    b4[t] = make_float4(wrow[c], wrow[IN + c], wrow[2 * IN + c], wrow[3 * IN + c]);
+                }
+                mfma4x4(a4, b4, accf);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (t0 + t < NT_IN) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int64_t p = pblk + r0 + 4 * q + r;
+                        if (p < n) dfeat[p * IN + 16 * (t0 + t) + i] = accf[t][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // tiles are rewritten by the next iteration
+    }
+
+    // ---- the block's partial row ----
+    const MlpGradLayout g = mlp_grad_layout(IN, w.out_dim);
+    float* row = partial + (size_t)blockIdx.x * g.total;
+#pragma unroll
+    for (int t = 0; t < NT_IN; t++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) row[g.W0 + (size_t)(16 * wave + 4 * q + r) * IN + 16 * t + i] = gW0[t][r];
+    }
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) row[g.W1[j] + (16 * wave + 4 * q + r) * MLP_W + 16 * t + i] = gW1[j][t][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (4 * q + r < w.out_dim[j]) row[g.W2[j] + (4 * q + r) * MLP_W + 16 * wave + i] = gW2[j][r];
+        }
+    }
+    // bias sums: add the four row groups through LDS (s_a is free now)
+    __syncthreads();
+    float* s_b = &s_a[0][0];                                      // [4][64 * 5]: b0, b1 x3, b2
+    s_b[bg * 320 + bc] = gb0;
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) s_b[bg * 320 + 64 * (1 + j) + bc] = gb1[j];
+    s_b[bg * 320 + 256 + bc] = gb2;
+    __syncthreads();
+    if (bg == 0) {
+        auto tot = [&](int k) { return (s_b[k] + s_b[320 + k]) + (s_b[640 + k] + s_b[960 + k]); };
+        row[g.b0 + bc] = tot(bc);
+#pragma unroll
+        for (int j = 0; j < MLP_HEADS; j++) row[g.b1[j] + bc] = tot(64 * (1 + j) + bc);
+        if (bc < MLP_OUT) {
+            int j = 0;
+            while (j + 1 < MLP_HEADS && bc >= w.out_off[j + 1]) j++;
+            row[g.b2[j] + bc - w.out_off[j]] = tot(256 + bc);
+        }
+    }
+}
+
+// grads[e] = sum over the G partial rows, fixed order
+__global__ void __launch_bounds__(256)
+mlp_grad_reduce_kernel(const int G, const int total, const float* __restrict__ partial, float* __restrict__ grads)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < G; b += 4) {
+        s0 += partial[(size_t)b * total + e];
+        s1 += partial[(size_t)(b + 1) * total + e];
+        s2 += partial[(size_t)(b + 2) * total + e];
+        s3 += partial[(size_t)(b + 3) * total + e];
+    }
+    for (; b < G; b++) s0 += partial[(size_t)b * total + e];
+    grads[e] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace gsr

@@ -9,6 +9,7 @@ library's split-K MFMA kernel for the weight gradients (PointwiseLinear below). 
 reference computes and then discards (deform_network.forward_dynamic builds [n, 63] / [n, 15] / [n, 20] embeddings of which only
 the leading raw columns are read, utils/deformation.py:198-213,78,113,122,132) are not computed."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -17,6 +18,14 @@ import torch.nn.init as init
 
 from diff_gaussian_rasterization import _C
 from hexplane import HexPlaneField
+
+FUSED_MLP = os.environ.get("GSR_FUSED_MLP", "1") != "0"   # fused forward / backward kernels for the shipped MLP structure
+
+
+class _Mlp(ctypes.Structure):
+    _fields_ = [("W0", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("W1", ctypes.c_void_p * 3), ("b1", ctypes.c_void_p * 3),
+                ("W2", ctypes.c_void_p * 3), ("b2", ctypes.c_void_p * 3), ("in_dim", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
 
 _lib_cache = None
 
@@ -30,6 +39,14 @@ def _lib():
         lib.gsr_linear_wgrad_workspace_size.argtypes = [i64, i, i]
         lib.gsr_linear_wgrad.restype = i
         lib.gsr_linear_wgrad.argtypes = [i64, i, i, vp, i64, vp, i64, vp, vp, vp, vp]
+        lib.gsr_deform_mlp_forward.restype = i
+        lib.gsr_deform_mlp_forward.argtypes = [ctypes.POINTER(_Mlp), i64, vp, vp, vp]
+        lib.gsr_deform_mlp_backward.restype = i
+        lib.gsr_deform_mlp_backward.argtypes = [ctypes.POINTER(_Mlp), i64, vp, vp, vp, vp, vp, vp]
+        lib.gsr_deform_mlp_grad_count.restype = ctypes.c_size_t
+        lib.gsr_deform_mlp_grad_count.argtypes = [i]
+        lib.gsr_deform_mlp_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_deform_mlp_workspace_size.argtypes = [i]
         _lib_cache = lib
     return _lib_cache
 
@@ -66,6 +83,59 @@ class _PointwiseLinear(torch.autograd.Function):
             if rc < 0:
                 _C._err(lib, rc, "gsr_linear_wgrad")
         return gx, gw, gb
+
+
+class _FusedDeformMLP(torch.autograd.Function):
+    """out [n, 10] = (dx, ds, dr) of the shipped deformation MLP from the HexPlane features, one fused kernel per direction
+    (csrc/gs_mlp.h) plus seven weight-gradient launches.  params: W0, b0, then (W1, b1, W2, b2) for the position, scale and
+    rotation heads -- the nn.Linear tensors themselves."""
+
+    @staticmethod
+    def _describe(in_dim, params):
+        m = _Mlp()
+        m.W0, m.b0, m.in_dim = params[0].data_ptr(), params[1].data_ptr(), in_dim
+        for j in range(3):
+            W1, b1, W2, b2 = params[2 + 4 * j:6 + 4 * j]
+            m.W1[j], m.b1[j], m.W2[j], m.b2[j] = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+        return m
+
+    @staticmethod
+    def forward(ctx, feat, *params):
+        feat = feat.contiguous()
+        params = tuple(p.detach().contiguous() for p in params)
+        n, in_dim = feat.shape
+        dev = feat.device
+        out = torch.empty((n, 10), dtype=torch.float32, device=dev)
+        lib = _lib()
+        m = _FusedDeformMLP._describe(in_dim, params)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_deform_mlp_forward(ctypes.byref(m), n, feat.data_ptr(), out.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_deform_mlp_forward")
+        ctx.save_for_backward(feat, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, *params = ctx.saved_tensors
+        n, in_dim = feat.shape
+        dev = feat.device
+        dout = dout.contiguous()
+        lib = _lib()
+        dfeat = torch.empty((n, in_dim), dtype=torch.float32, device=dev)
+        flat = torch.empty((lib.gsr_deform_mlp_grad_count(in_dim),), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.gsr_deform_mlp_workspace_size(in_dim),), dtype=torch.uint8, device=dev)
+        m = _FusedDeformMLP._describe(in_dim, params)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_deform_mlp_backward(ctypes.byref(m), n, feat.data_ptr(), dout.data_ptr(), dfeat.data_ptr(), flat.data_ptr(), ws.data_ptr(),
+                                             _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_deform_mlp_backward")
+        grads, off = [], 0                                       # the flat layout of include/deformation_field.h is the parameter order
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (dfeat if ctx.needs_input_grad[0] else None, *grads)
 
 
 class PointwiseLinear(nn.Linear):
@@ -154,7 +224,24 @@ class Deformation(nn.Module):
     def forward_static(self, rays_pts_emb):
         return rays_pts_emb[:, :3] + self.static_mlp(self.grid(rays_pts_emb[:, :3]))
 
+    def _fused_mlp_ok(self, x):
+        """the shipped structure: one trunk layer of width 64, the three delta heads, nothing else in the way"""
+        a = self.args
+        return (FUSED_MLP and x.is_cuda and x.dtype == torch.float32 and self.D == 1 and self.W == 64
+                and not (self.no_grid or a.static_mlp or a.no_dx or a.no_ds or a.no_dr or a.apply_rotation) and self.grid_pe == 0
+                and self.grid.feat_dim % 16 == 0 and self.grid.feat_dim <= 128)
+
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
+        if self._fused_mlp_ok(rays_pts_emb):
+            feat = self.grid(rays_pts_emb[:, :3], time_emb.to(device=rays_pts_emb.device)[:, :1])
+            if feat.shape[0] > 0:
+                heads = (self.pos_deform, self.scales_deform, self.rotations_deform)
+                params = [self.feature_out[0].weight, self.feature_out[0].bias]
+                for h in heads:
+                    params += [h[1].weight, h[1].bias, h[3].weight, h[3].bias]
+                out = _FusedDeformMLP.apply(feat, *params)
+                dx, ds, dr = out[:, 0:3], out[:, 3:6], out[:, 6:10]
+                return rays_pts_emb[:, :3] + dx, scales_emb[:, :3] + ds, rotations_emb[:, :4] + dr, dx, ds, dr
         hidden = self.query_time(rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb)
         a = self.args
         mask = self.static_mlp(hidden) if a.static_mlp else None       # None = the reference's all-ones mask (:107)

@@ -80,6 +80,28 @@ size_t gsr_linear_wgrad_workspace_size(int64_t n, int in_dim, int out_dim);
 int gsr_linear_wgrad(int64_t n, int in_dim, int out_dim, const float* x, int64_t x_stride, const float* dy, int64_t dy_stride,
                      float* dW, float* db, char* workspace, void* stream);
 
+/* ---- the deformation MLP, fused ---------------------------------------------------------------------------------------------
+ * utils/deformation.py:58-70,101-149 with the shipped flags (defor_depth 1, width 64, position / scale / rotation heads):
+ *   h0 = F W0^T + b0;  u_j = relu(h0) W1j^T + b1j;  o_j = relu(u_j) W2j^T + b2j,  j = 0 (3 outputs), 1 (3), 2 (4)
+ * Weights are nn.Linear tensors as they are ([out, in] row-major).  in_dim must be a multiple of 16, at most 128; width is 64. */
+typedef struct gsr_deform_mlp {
+    const float* W0; const float* b0;              /* [64, in_dim], [64]                    feature_out.0 */
+    const float* W1[3]; const float* b1[3];        /* [64, 64], [64]                        {pos,scales,rotations}_deform.1 */
+    const float* W2[3]; const float* b2[3];        /* [3|3|4, 64], [3|3|4]                  {pos,scales,rotations}_deform.3 */
+    int32_t in_dim;
+    int32_t reserved;
+} gsr_deform_mlp;
+
+/* features [n, in_dim] -> out [n, 10] = (dx 3, ds 3, dr 4).  Nothing else is kept: the backward call recomputes the activations. */
+int gsr_deform_mlp_forward(const gsr_deform_mlp* mlp, int64_t n, const float* features, float* out, void* stream);
+/* dout [n, 10] -> dfeatures [n, in_dim] and ALL parameter gradients, written into one flat array `grads` of
+ * gsr_deform_mlp_grad_count(in_dim) floats laid out as
+ *     W0 [64][in_dim] | b0 [64] | for j = 0, 1, 2:  W1j [64][64] | b1j [64] | W2j [o_j][64] | b2j [o_j]      (o = 3, 3, 4)
+ * (row-major like nn.Linear.weight.grad).  Deterministic: block partials in `workspace`, summed in a fixed order. */
+size_t gsr_deform_mlp_grad_count(int in_dim);
+size_t gsr_deform_mlp_workspace_size(int in_dim);
+int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
+                            float* grads, char* workspace, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,13 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     lib.gsr_linear_wgrad_workspace_size.restype = ctypes.c_size_t
     lib.gsr_linear_wgrad_workspace_size.argtypes = [i64, i, i]
     assert lib.gsr_linear_wgrad_workspace_size(200000, 128, 64) >= 64 * 129 * 4
+    import deformation
+    dl = deformation._lib()
+    assert dl.gsr_deform_mlp_forward(None, 4, None, None, None) == -1 and b"gsr_deform_mlp_forward" in lib.gsr_last_error()
+    mlp = deformation._Mlp(in_dim=100)
+    assert dl.gsr_deform_mlp_backward(ctypes.byref(mlp), 4, None, None, None, None, None, None) == -1 and b"multiple of 16" in lib.gsr_last_error()
+    assert dl.gsr_deform_mlp_grad_count(128) == 64 * 128 + 64 + 3 * (64 * 64 + 64) + 10 * 64 + 10
+    assert dl.gsr_deform_mlp_workspace_size(128) >= 256 * dl.gsr_deform_mlp_grad_count(128) * 4
     # control_nodes.h
     import control_nodes
     cl = control_nodes._lib()

@@ -73,8 +73,11 @@ def test_field_matches_reference_golden(layout, monkeypatch):
     assert torch.all((pts.grad.cpu() == 0) == torch.tensor(G["field/g_pts"] == 0))
 
 
+@pytest.mark.parametrize("fused_mlp", [True, False])
 @pytest.mark.parametrize("tag", ["net1", "net2"])
-def test_network_matches_reference_golden(tag):
+def test_network_matches_reference_golden(tag, fused_mlp, monkeypatch):
+    """net1 (defor_depth 1) takes the fused MLP kernels (csrc/gs_mlp.h) when fused_mlp, net2 always the layer-by-layer path."""
+    monkeypatch.setattr(deformation, "FUSED_MLP", fused_mlp)
     res = [int(r) for r in G[f"{tag}/resolution"]]
     net = deformation.deform_network(hidden_params(defor_depth=int(G[f"{tag}/defor_depth"]), multires=[int(m) for m in G[f"{tag}/multires"]],
                                                    kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4,
@@ -346,3 +349,41 @@ def test_binned_backward_on_hostile_distributions(case, monkeypatch):
             scale = float(b.abs().max()) + 1e-30
             assert float((a - b).abs().max()) / scale < 2e-4, (case, l, p, float((a - b).abs().max()) / scale)
             assert rel(a, b) < 1e-4, (case, l, p)
+
+
+@pytest.mark.parametrize("n,feat_levels", [(1, 4), (17, 2), (1000, 4), (4099, 1)])
+def test_fused_mlp_against_layerwise_path(n, feat_levels, monkeypatch):
+    """the fused MLP kernels (fp32 MFMA) against the same network evaluated layer by layer with library GEMMs: values, input
+    gradient and every weight / bias gradient; n not a multiple of the 16-point tile, in_dim 32 / 64 / 128."""
+    torch.manual_seed(n)
+    net = deformation.deform_network(hidden_params(multires=[1, 2, 4, 8][:feat_levels],
+                                                   kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
+                                                                   "resolution": [8, 8, 8, 5]}), DEV).to(DEV)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.requires_grad and p.dim() == 1:
+                p.normal_(0, 0.2)                                    # non-trivial biases
+    rng = np.random.default_rng(n)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=DEV, requires_grad=rg)
+    ins = [T(rng.uniform(-1.5, 1.5, size=(n, 3)), True), T(rng.normal(size=(n, 3)), True), T(rng.normal(size=(n, 4)), True),
+           T(rng.normal(size=(n, 1))), T(rng.normal(size=(n, 16, 3))), T(np.full((n, 1), 0.2))]
+    cots = [T(rng.normal(size=(n, c))) for c in (3, 3, 4, 3, 3, 4)]
+    results = {}
+    for fused in (False, True):
+        monkeypatch.setattr(deformation, "FUSED_MLP", fused)
+        for p in net.parameters():
+            p.grad = None
+        for t in ins[:3]:
+            t.grad = None
+        outs = net(*ins)
+        sum((o * c).sum() for o, c in zip(outs, cots)).backward()
+        results[fused] = ([o.detach().clone() for o in outs], [t.grad.clone() for t in ins[:3]],
+                          {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    (o0, gi0, gp0), (o1, gi1, gp1) = results[False], results[True]
+    for a, b in zip(o1, o0):
+        assert rel(a, b) < 1e-5
+    for a, b in zip(gi1, gi0):
+        assert rel(a, b) < 1e-4
+    assert set(gp0) == set(gp1)
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) < 1e-4, (k, rel(gp1[k], gp0[k]))
