@@ -1034,7 +1034,7 @@ static int mlp_fill(const gsr_deform_mlp* m, MlpWeights* w, const char* who)
 static dim3 mlp_grid(int64_t n)
 {
     const int64_t tiles = (n + MLP_TILE - 1) / MLP_TILE;
-    return dim3((unsigned)std::min<int64_t>(tiles, 256 * 16));   // persistent beyond 16 blocks per CU
+    return dim3((unsigned)std::min<int64_t>(tiles, 256));        // persistent: one block per CU (the weights live in its LDS)
 }
 
 constexpr int MLP_BWD_BLOCKS = 256;      // persistent: one block per CU (103 KB of LDS each)

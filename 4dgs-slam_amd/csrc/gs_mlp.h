@@ -25,7 +25,7 @@ namespace gsr {
 constexpr int MLP_W = 64;                 // network width (arguments/__init__.py: net_width = 64)
 constexpr int MLP_HEADS = 3;
 constexpr int MLP_OUT = 10;               // 3 + 3 + 4
-constexpr int MLP_BLOCK = 128;            // 2 waves x 16 points, 8.7 KB of LDS per block: 16 waves per CU hide the L2 latency of the weights
+constexpr int MLP_BLOCK = 256;            // forward: 4 waves x 16 points per iteration, one persistent block per CU (weights in LDS)
 constexpr int MLP_TILE = MLP_BLOCK / 64 * 16;
 constexpr int MLP_LDA = MLP_W + 4;        // LDS row stride of a [16][64] tile (floats): 16-byte aligned, conflict-free float4 reads
 
@@ -67,24 +67,62 @@ template <int NT_IN>
 __global__ void __launch_bounds__(MLP_BLOCK)
 deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const MlpWeights w, float* __restrict__ out)
 {
-    constexpr int IN = 16 * NT_IN;
+    constexpr int IN = 16 * NT_IN, LDW0 = IN + 4;
     __shared__ __attribute__((aligned(16))) float s_a[MLP_BLOCK / 64][16][MLP_LDA];
-    __shared__ __attribute__((aligned(16))) float s_v[MLP_BLOCK / 64][16][MLP_LDA];   // one head at a time: 8.7 KB of LDS per block
+    __shared__ __attribute__((aligned(16))) float s_v[MLP_BLOCK / 64][16][MLP_LDA];   // one head at a time
+    // the whole network in LDS (89 KB at in_dim 128), rows padded by 4 floats so that the 16 rows a quarter-wave reads as float4
+    // fall into 16 different bank groups; read from L2 per tile the kernel ran at a third of the MFMA rate
+    __shared__ __attribute__((aligned(16))) float s_W0[MLP_W][LDW0];
+    __shared__ __attribute__((aligned(16))) float s_W1[MLP_HEADS][MLP_W][MLP_LDA];
+    __shared__ __attribute__((aligned(16))) float s_W2[MLP_HEADS][4][MLP_LDA];
+    for (int e = threadIdx.x; e < MLP_W * IN / 4; e += MLP_BLOCK) {
+        const int r = e / (IN / 4), c = e - r * (IN / 4);
+        *reinterpret_cast<float4*>(&s_W0[r][4 * c]) = *reinterpret_cast<const float4*>(w.W0 + (size_t)r * IN + 4 * c);
+    }
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) {
+        for (int e = threadIdx.x; e < MLP_W * MLP_W / 4; e += MLP_BLOCK) {
+            const int r = e / (MLP_W / 4), c = e - r * (MLP_W / 4);
+            *reinterpret_cast<float4*>(&s_W1[j][r][4 * c]) = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)r * MLP_W + 4 * c);
+        }
+        for (int e = threadIdx.x; e < 4 * MLP_W; e += MLP_BLOCK) {
+            const int r = e / MLP_W, c = e - r * MLP_W;
+            s_W2[j][r][c] = r < w.out_dim[j] ? w.W2[j][(size_t)r * MLP_W + c] : 0.f;
+        }
+    }
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
     const int64_t tiles = (n + MLP_TILE - 1) / MLP_TILE;
+    auto load_features = [&](int64_t tile, float4 (&dst)[NT_IN]) {   // this lane's A fragments of a tile: point i, 4 features per k-step group
+        const int64_t prow = tile * MLP_TILE + wave * 16 + i;
+#pragma unroll
+        for (int S = 0; S < NT_IN; S++)
+            dst[S] = (tile < tiles && prow < n) ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float bias0[4], bias1[MLP_HEADS][4], bias2[MLP_HEADS];        // this lane's columns, read once
+#pragma unroll
+    for (int t = 0; t < 4; t++) bias0[t] = w.b0[16 * t + i];
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) bias1[j][t] = w.b1[j][16 * t + i];
+        bias2[j] = i < w.out_dim[j] ? w.b2[j][i] : 0.f;
+    }
+    float4 cur[NT_IN], nxt[NT_IN];
+    load_features(blockIdx.x, cur);
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t p0 = tile * MLP_TILE + wave * 16;
-        const int64_t prow = p0 + i;                              // the point this lane supplies as A row
+        load_features(tile + gridDim.x, nxt);                     // in flight while this tile runs through the layers
         // ---- h0 = F W0^T + b0 ----
         f32x4 acc1[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) { const float b = w.b0[16 * t + i]; acc1[t] = f32x4{b, b, b, b}; }
+        for (int t = 0; t < 4; t++) acc1[t] = f32x4{bias0[t], bias0[t], bias0[t], bias0[t]};
 #pragma unroll
         for (int S = 0; S < NT_IN; S++) {
-            const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a4 = cur[S];
             float4 b4[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W0 + (size_t)(16 * t + i) * IN + 16 * S + 4 * q);
+            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(&s_W0[16 * t + i][16 * S + 4 * q]);
             mfma4x4(a4, b4, acc1);
         }
 #pragma unroll
@@ -100,13 +138,13 @@ deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const Mlp
         for (int j = 0; j < MLP_HEADS; j++) {
             f32x4 acc2[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) { const float b = w.b1[j][16 * t + i]; acc2[t] = f32x4{b, b, b, b}; }
+            for (int t = 0; t < 4; t++) acc2[t] = f32x4{bias1[j][t], bias1[j][t], bias1[j][t], bias1[j][t]};
 #pragma unroll
             for (int S = 0; S < MLP_W / 16; S++) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s_a[wave][i][16 * S + 4 * q]);
                 float4 b4[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)(16 * t + i) * MLP_W + 16 * S + 4 * q);
+                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(&s_W1[j][16 * t + i][16 * S + 4 * q]);
                 mfma4x4(a4, b4, acc2);
             }
             if (j > 0) __syncthreads();                           // the previous head's v tile has been read
@@ -119,12 +157,11 @@ deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const Mlp
             }
             __syncthreads();
             const bool col_ok = i < w.out_dim[j];
-            const float b = col_ok ? w.b2[j][i] : 0.f;
-            f32x4 acc3 = f32x4{b, b, b, b};
+            f32x4 acc3 = f32x4{bias2[j], bias2[j], bias2[j], bias2[j]};
 #pragma unroll
             for (int S = 0; S < MLP_W / 16; S++) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s_v[wave][i][16 * S + 4 * q]);
-                const float4 b4 = col_ok ? *reinterpret_cast<const float4*>(w.W2[j] + (size_t)i * MLP_W + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b4 = *reinterpret_cast<const float4*>(&s_W2[j][i & 3][16 * S + 4 * q]) * (col_ok ? 1.f : 0.f);
                 acc3 = mfma4(a4, b4, acc3);
             }
             if (col_ok) {
@@ -136,6 +173,8 @@ deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const Mlp
             }
         }
         __syncthreads();                                          // the tiles are rewritten by the next iteration
+#pragma unroll
+        for (int S = 0; S < NT_IN; S++) cur[S] = nxt[S];
     }
 }
 
@@ -183,6 +222,15 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
     __shared__ __attribute__((aligned(16))) float s_v[MLPB_TILE][MLP_LDA];      // v_j = relu(u_j), one head at a time
     __shared__ __attribute__((aligned(16))) float s_d[MLPB_TILE][MLP_LDA];      // du_j, one head at a time; then dh0
     __shared__ float s_o[MLPB_TILE][12];                                          // dout of the block's points (10 used)
+    __shared__ __attribute__((aligned(16))) float s_W1[MLP_HEADS][MLP_W][MLP_LDA];  // the most-read weights (u_j recompute and dL/da), 52 KB
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++) {
+        for (int e = threadIdx.x; e < MLP_W * MLP_W / 4; e += MLPB_BLOCK) {
+            const int r = e / (MLP_W / 4), c = e - r * (MLP_W / 4);
+            *reinterpret_cast<float4*>(&s_W1[j][r][4 * c]) = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)r * MLP_W + 4 * c);
+        }
+    }
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
     const int bc = threadIdx.x & 63, bg = threadIdx.x >> 6;                       // bias sums: column bc over rows 16 bg .. 16 bg + 15
 
@@ -199,6 +247,13 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         for (int t = 0; t < 4; t++) gW1[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float gb0 = 0.f, gb1[MLP_HEADS] = {0.f, 0.f, 0.f}, gb2 = 0.f;                 // ... and bias sums (this thread's column / row group)
+    float bias0[4], bias1[MLP_HEADS][4];                                          // this lane's columns of b0 / b1j, read once
+#pragma unroll
+    for (int t = 0; t < 4; t++) bias0[t] = w.b0[16 * t + i];
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) bias1[j][t] = w.b1[j][16 * t + i];
 
     const int64_t tiles = (n + MLPB_TILE - 1) / MLPB_TILE;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -213,7 +268,7 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         // ---- recompute h0 = F W0^T + b0 for the wave's 16 points; keep the features and a = relu(h0) in LDS ----
         f32x4 acc1[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) { const float b = w.b0[16 * t + i]; acc1[t] = f32x4{b, b, b, b}; }
+        for (int t = 0; t < 4; t++) acc1[t] = f32x4{bias0[t], bias0[t], bias0[t], bias0[t]};
 #pragma unroll
         for (int S = 0; S < NT_IN; S++) {
             const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,13 +296,13 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
             // u_j = a W1j^T + b1j (wave's points)
             f32x4 acc2[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) { const float b = w.b1[j][16 * t + i]; acc2[t] = f32x4{b, b, b, b}; }
+            for (int t = 0; t < 4; t++) acc2[t] = f32x4{bias1[j][t], bias1[j][t], bias1[j][t], bias1[j][t]};
 #pragma unroll
             for (int S = 0; S < MLP_W / 16; S++) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s_a[r0 + i][16 * S + 4 * q]);
                 float4 b4[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W1[j] + (size_t)(16 * t + i) * MLP_W + 16 * S + 4 * q);
+                for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(&s_W1[j][16 * t + i][16 * S + 4 * q]);
                 mfma4x4(a4, b4, acc2);
             }
             // dv_j = dout_j W2j (one k-step), du_j = dv_j * [u_j > 0]; v_j = relu(u_j)
@@ -283,10 +338,10 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
 #pragma unroll
             for (int S = 0; S < MLP_W / 16; S++) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s_d[r0 + i][16 * S + 4 * q]);
-                const float* wrow = w.W1[j] + (size_t)(16 * S + 4 * q) * MLP_W + i;
+                const float* wrow = &s_W1[j][16 * S + 4 * q][i];     // B[k][col] = W1j[k][col]: four rows of the LDS copy per float4 of A
                 float4 b4[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++) b4[t] = make_float4(wrow[16 * t], wrow[MLP_W + 16 * t], wrow[2 * MLP_W + 16 * t], wrow[3 * MLP_W + 16 * t]);
+                for (int t = 0; t < 4; t++) b4[t] = make_float4(wrow[16 * t], wrow[MLP_LDA + 16 * t], wrow[2 * MLP_LDA + 16 * t], wrow[3 * MLP_LDA + 16 * t]);
                 mfma4x4(a4, b4, da);
             }
         }
