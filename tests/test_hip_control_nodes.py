@@ -85,7 +85,12 @@ def test_node_blend_against_oracle_fp64(m, K, local_frame, rot_res, with_weight)
     (sum((res[k] * c).sum() for k, c in zip(("d_xyz", "d_rotation", "d_scaling"), cots))).backward()
     l64 = {k: v.detach().double().cpu().requires_grad_(True) for k, v in leaves.items()}
     if m < K:
-        pytest.skip("the oracle's topk needs K <= m; padding is checked through knn_points")
+        # fewer nodes than K: pytorch3d pads the neighbour list with (index 0, distance 0); restate that by appending copies of
+        # node 0 placed ON each query point is not possible for all points at once, so check the padding and finiteness directly
+        assert torch.all(res["nn_idx"][:, m:] == 0) and torch.all(res["nn_dist"][:, m:] == 0)
+        assert torch.allclose(res["nn_weight"].sum(1), torch.ones(n, device=DEV), atol=1e-5)
+        assert all(torch.isfinite(v.grad).all() for v in leaves.values() if v.grad is not None)
+        return
     o = O.node_blend(x.double().cpu(), mask.double().cpu(), nodes.double().cpu(), l64["rr"], l64["wr"] if with_weight else None, l64["tr"],
                      l64["ro"], l64["sc"], l64["lr"], K, local_frame, rot_res)
     (sum((a * c.double().cpu()).sum() for a, c in zip(o, cots))).backward()
