@@ -38,6 +38,7 @@ struct HexSortWs {                              // device pointers carved from t
     uint32_t* key;                              // [6][n]    counter index of the point in each family
     uint32_t* count;                            // [NB]      histogram, then (after the scan) the running cursor
     uint32_t* block_sums;                       // [ceil(NB / 8192)]
+    uint32_t* header;                           // [0] = 6 x (number of points with a non-zero cotangent row)
     int* rank;                                  // [6][n]    sorted slot of the point in each family (0 .. 6n)
     float4* scoords;                            // [6n]      coordinates in sorted order
     float* gs;                                  // [6n][L][C]  dL/dsample in sorted order
@@ -63,10 +64,23 @@ __device__ __forceinline__ uint32_t hexsort_key(const HexSortPlan& P, int c0, in
 // ---- phase 0a: normalised coordinates, cell keys, histogram ----------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexSortWs ws, const int64_t n, const float* __restrict__ xyz,
-                     const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride)
+                     const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // A point whose cotangent row is exactly zero (a Gaussian the view does not see) adds nothing to any plane: it is left out of the
+    // sort altogether, so everything after this kernel costs in proportion to the points that carry a gradient.
+    const float4* row = reinterpret_cast<const float4*>(dL_dfeatures + i * ((int64_t)f.num_levels * f.feat_dim));
+    bool active = false;
+    for (int e = 0; e < f.num_levels * f.feat_dim / 4; e++) {
+        const float4 v = row[e];
+        active |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    }
+    if (!active) {
+#pragma unroll
+        for (int pl = 0; pl < 6; pl++) ws.key[(size_t)pl * n + i] = 0xFFFFFFFFu;
+        return;
+    }
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time + i * time_stride);
     ws.coords[i] = make_float4(p.c[0], p.c[1], p.c[2], p.c[3]);
     int i0[4];
@@ -103,10 +117,12 @@ hexsort_scan_sums_kernel(const uint32_t* __restrict__ count, const int nb, uint3
 }
 
 __global__ void __launch_bounds__(1024)
-hexsort_scan_top_kernel(uint32_t* __restrict__ block_sums, const int nblocks)
+hexsort_scan_top_kernel(uint32_t* __restrict__ block_sums, const int nblocks, uint32_t* __restrict__ header)
 {
     __shared__ uint32_t s_tmp[17];
-    block_exclusive_scan_1024(nblocks, [&](int b) { return block_sums[b]; }, [&](int b, uint32_t ex, uint32_t) { block_sums[b] = ex; }, s_tmp);
+    const uint32_t total = block_exclusive_scan_1024(nblocks, [&](int b) { return block_sums[b]; },
+                                                     [&](int b, uint32_t ex, uint32_t) { block_sums[b] = ex; }, s_tmp);
+    if (threadIdx.x == 0) header[0] = total;                      // 6 x active points
 }
 
 __global__ void __launch_bounds__(1024)
@@ -139,6 +155,10 @@ hexsort_scatter_kernel(const HexSortWs ws, const int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (ws.key[i] == 0xFFFFFFFFu) {                               // no gradient reaches this point
+        ws.rank[i] = -1;
+        return;
+    }
     const float4 c = ws.coords[i];
 #pragma unroll
     for (int pl = 0; pl < 6; pl++) {
@@ -158,6 +178,10 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
     const int ch = threadIdx.x % C;
     const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / C) + threadIdx.x / C;
     if (i >= n) return;
+    if (ws.rank[i] < 0) {                                         // zero cotangent: nothing to gather, nothing to hand over
+        if (dL_dxyz && ch < 3) dL_dxyz[3 * i + ch] = 0.f;
+        return;
+    }
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time + i * time_stride);
     const float (&c)[4] = p.c;
     const int L = f.num_levels;
@@ -236,16 +260,17 @@ hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
 {
     constexpr int GROUPS = 256 / C;
     const int ch = threadIdx.x % C;
-    const int64_t chunks_per_family = (n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    const int64_t na = ws.header[0] / 6;                          // points that were sorted (non-zero cotangent); the grid covers n
+    const int64_t chunks_per_family = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / C;
     if (gid >= 6 * chunks_per_family) return;
     const int pl = (int)(gid / chunks_per_family);
     const int64_t first = (gid - pl * chunks_per_family) * HEXSORT_CHUNK;
-    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, n - first);
+    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
     const int c0 = hex_c0(pl), c1 = hex_c1(pl);
     const int L = f.num_levels;
-    const float4* sc = ws.scoords + (size_t)pl * n + first;
-    const float* gsrow = ws.gs + ((size_t)pl * n + first) * L * C + ch;
+    const float4* sc = ws.scoords + (size_t)pl * na + first;
+    const float* gsrow = ws.gs + ((size_t)pl * na + first) * L * C + ch;
 
     float acc[LMAX][4];
     int cx[LMAX], cy[LMAX];

@@ -261,9 +261,19 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         const int r0 = wave * 16;                                 // this wave's rows of the block tile
         const int64_t prow = pblk + r0 + i;
         // stage dout (zero beyond n: those rows then contribute nothing anywhere)
+        int nonzero = 0;
         for (int e = threadIdx.x; e < MLPB_TILE * MLP_OUT; e += MLPB_BLOCK) {
             const int r = e / MLP_OUT, c = e - r * MLP_OUT;
-            s_o[r][c] = pblk + r < n ? dout[(pblk + r) * MLP_OUT + c] : 0.f;
+            const float v = pblk + r < n ? dout[(pblk + r) * MLP_OUT + c] : 0.f;
+            s_o[r][c] = v;
+            nonzero |= v != 0.f;
+        }
+        if (!__syncthreads_or(nonzero)) {                         // 64 points no gradient reaches (Gaussians the view does not see): dF = 0
+            for (int e = threadIdx.x; e < MLPB_TILE * IN / 4; e += MLPB_BLOCK) {
+                const int r = e / (IN / 4), c = e - r * (IN / 4);
+                if (pblk + r < n) *reinterpret_cast<float4*>(dfeat + (pblk + r) * IN + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
         }
         // ---- recompute h0 = F W0^T + b0 for the wave's 16 points; keep the features and a = relu(h0) in LDS ----
         f32x4 acc1[4];

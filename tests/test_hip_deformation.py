@@ -387,3 +387,39 @@ def test_fused_mlp_against_layerwise_path(n, feat_levels, monkeypatch):
     assert set(gp0) == set(gp1)
     for k in gp0:
         assert rel(gp1[k], gp0[k]) < 1e-4, (k, rel(gp1[k], gp0[k]))
+
+
+def test_points_without_gradient_are_skipped_correctly(monkeypatch):
+    """Gaussians a view does not see arrive with an exactly-zero cotangent: the sorted field backward leaves them out of the sort and
+    the fused MLP backward skips whole 64-point tiles of them.  Same gradients as the direct / layer-by-layer paths, zero dL/dxyz."""
+    torch.manual_seed(1)
+    net = deformation.deform_network(hidden_params(), DEV).to(DEV)
+    with torch.no_grad():
+        for p in net.get_grid_parameters():
+            if p.requires_grad:
+                p.uniform_(0.2, 1.2)
+    rng = np.random.default_rng(4)
+    n = 60000
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=DEV, requires_grad=rg)
+    ins = [T(rng.uniform(-1.5, 1.5, size=(n, 3)), True), T(rng.normal(size=(n, 3)), True), T(rng.normal(size=(n, 4)), True),
+           T(rng.normal(size=(n, 1))), None, T(np.full((n, 1), -0.3))]
+    seen = rng.uniform(size=n) < 0.3                                  # scattered visible points ...
+    seen[20000:45000] = False                                         # ... and a long run of invisible ones (whole MLP tiles)
+    seen_t = torch.tensor(seen, device=DEV)[:, None]
+    cots = [T(rng.normal(size=(n, c))) * seen_t for c in (3, 3, 4)]
+    results = {}
+    for mode in ("reference_paths", "fast_paths"):
+        monkeypatch.setenv("GSR_HEX_BINNED", "0" if mode == "reference_paths" else "1")
+        monkeypatch.setattr(deformation, "FUSED_MLP", mode == "fast_paths")
+        for p in net.parameters():
+            p.grad = None
+        for t in ins[:3]:
+            t.grad = None
+        outs = net(*ins)
+        sum((o * c).sum() for o, c in zip(outs[3:], cots)).backward()      # only dx, ds, dr carry a cotangent: invisible rows stay exactly zero
+        results[mode] = (ins[0].grad.clone(), {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+    (gx0, gp0), (gx1, gp1) = results["reference_paths"], results["fast_paths"]
+    assert torch.all(gx1[~seen_t[:, 0]] == 0) and rel(gx1, gx0) < 1e-4
+    assert set(gp0) == set(gp1)
+    for k in gp0:
+        assert rel(gp1[k], gp0[k]) < 2e-4, (k, rel(gp1[k], gp0[k]))
