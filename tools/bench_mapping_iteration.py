@@ -5,7 +5,11 @@ backward, densification statistics per view, one Adam step.
   "reference_chain": what the reference executes around the rasterizer -- torch prologue, torch loss, boolean-mask statistics,
                      torch.optim.Adam -- over this repo's rasterizer;
   "fused":           prologue inside the kernels, fused loss, fused statistics, FusedAdam.
-Prints one JSON line (profiles/r01_mapping_iteration.json)."""
+With --nodes the deltas of the dynamic Gaussians come from the SC-GS control-node warp (utils/time_utils.py:1192-1258: K = 3 nearest
+of 512 nodes, RBF weights, local-frame blend) applied per view to leaf tensors standing for the node MLP's outputs -- the
+reference's tensor program (brute-force cdist + topk for pytorch3d's knn_points) in "reference_chain", control_nodes.node_blend in
+"fused" -- and their gradients flow back to the node attributes, radii and weights.
+Prints one JSON line (profiles/r01_mapping_iteration.json, r01_mapping_iteration_nodes.json)."""
 import json, os, sys, time, types
 import numpy as np
 import torch
@@ -17,6 +21,10 @@ from synthetic_scene import make_camera, make_gaussians, keyframe_pose
 from test_hip_fused_prologue import _GaussianModel, _camera
 from slam_losses import get_loss_mapping, mapping_loss_weights, add_densification_stats
 from fused_adam import FusedAdam
+import control_nodes as cn
+from tools.bench_control_nodes import torch_program
+
+NODES = "--nodes" in sys.argv
 
 P, W, H, K = 200_000, 640, 480, 8
 config = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.9}}
@@ -24,7 +32,7 @@ pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=Fals
 bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
 g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
 rng = np.random.default_rng(11)
-out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr, mapping loss, densification stats, Adam"}
+out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr" + (" from the control-node warp (512 nodes, K=3)" if NODES else "") + ", mapping loss, densification stats, Adam"}
 for fused in (False, True):
     m = _GaussianModel(g, False, 0.25, seed=2)
     m.max_radii2D = torch.zeros(P, device="cuda"); m.xyz_gradient_accum = torch.zeros(P, 1, device="cuda"); m.denom = torch.zeros(P, 1, device="cuda")
@@ -39,6 +47,23 @@ for fused in (False, True):
     Kd = int(m.dygs.sum())
     deltas = [{k: torch.tensor(rng.normal(scale=s, size=(Kd, n)).astype(np.float32), device="cuda", requires_grad=True)
                for k, n, s in (("dx", 3, 0.002), ("ds", 3, 0.0001), ("dr", 4, 0.01))} for _ in range(K)]
+    if NODES:
+        M = 512
+        T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+        nodes = T(g["means3D"][rng.choice(P, M, replace=False)])
+        node_leaves = dict(rr=T(np.log(rng.uniform(0.2, 0.6, size=M)), True), wr=T(rng.normal(size=(M, 1)), True))
+        per_view = [dict(tr=T(rng.normal(scale=0.002, size=(M, 3)), True), ro=T(rng.normal(scale=0.01, size=(M, 4)), True),
+                         sc=T(rng.normal(scale=0.0001, size=(M, 3)), True), lr=T(rng.normal(scale=0.05, size=(M, 4)), True)) for _ in range(K)]
+        motion = torch.ones(Kd, 1, device="cuda")
+
+        def view_deltas(k):
+            x = m._xyz.detach()[m.dygs]                            # gaussians.get_dygs_xyz.detach() (slam_backend.py:364)
+            a = per_view[k]
+            if fused:
+                r = cn.node_blend(x, motion, nodes, node_leaves["rr"], node_leaves["wr"], a["tr"], a["ro"], a["sc"], a["lr"], K=3)
+                return {"dx": r["d_xyz"], "ds": r["d_scaling"], "dr": r["d_rotation"]}
+            dx, dr, ds = torch_program(x, motion, nodes, node_leaves["rr"], node_leaves["wr"], a["tr"], a["ro"], a["sc"], a["lr"], 3)
+            return {"dx": dx, "ds": ds, "dr": dr}
     groups = [{"params": [p_], "lr": lr, "name": n} for n, p_, lr in (("xyz", m._xyz, 1.6e-4), ("f_dc", m._features_dc, 2.5e-3),
               ("opacity", m._opacity, 0.05), ("scaling", m._scaling, 1e-3), ("rotation", m._rotation, 1e-3))]
     opt = (FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
@@ -53,7 +78,9 @@ for fused in (False, True):
     def iteration():
         opt.zero_grad(set_to_none=True)
         loss, pkgs = 0.0, []
-        for v, d in zip(views, deltas):
+        for k, (v, d) in enumerate(zip(views, deltas)):
+            if NODES:
+                d = view_deltas(k)
             res = gr.render(v, m, pipe, bg, **d)
             loss = loss + (get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"]) if fused else torch_loss(res["render"], res["depth"], v))
             pkgs.append(res)
