@@ -12,6 +12,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
+import types
+
 import numpy as np
 
 # TUM fr3 intrinsics, configs/rgbd/tum/fr3_sitting_static.yaml:7-18
@@ -111,3 +113,45 @@ def make_cotangents(cam: CameraArrays, seed: int = 1):
     gc = rng.normal(0, 1, (3, cam.H, cam.W)) / (3 * N)
     gd = rng.normal(0, 1, (1, cam.H, cam.W)) / N
     return np.ascontiguousarray(gc, np.float32), np.ascontiguousarray(gd, np.float32)
+
+
+class GaussianModelStub:
+    """The attribute surface of scene/gaussian_model.py that render() touches (raw leaves + activations, :60-68,100-128), filled from a
+    make_gaussians() scene: what the benches and tests hand to gaussian_renderer.render() in place of a GaussianModel."""
+
+    def __init__(self, g, isotropic, dyn_frac, seed):
+        import torch
+        dev = "cuda"
+        L = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=True)
+        rng = np.random.default_rng(seed)
+        P = g["means3D"].shape[0]
+        self._xyz = L(g["means3D"])
+        sc = np.log(g["scales"])
+        self._scaling = L(sc[:, :1] if isotropic else sc)
+        self._rotation = L(g["rotations"] * rng.uniform(0.5, 2.0, size=(P, 1)))          # not unit length: normalize matters
+        op = np.clip(g["opacities"].reshape(P, 1), 1e-4, 1 - 1e-4)
+        self._opacity = L(np.log(op / (1 - op)))
+        self._features_dc = L(g["shs"][:, :1])
+        self._features_rest = L(g["shs"][:, 1:])
+        self.active_sh_degree = g.get("sh_degree", 0)
+        self.max_sh_degree = 3
+        self.dygs = torch.tensor(rng.uniform(size=P) < dyn_frac, device=dev)
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s.scaling_activation(s._scaling))
+    get_rotation = property(lambda s: s.rotation_activation(s._rotation))
+    get_opacity = property(lambda s: s.opacity_activation(s._opacity))
+    get_features = property(lambda s: __import__("torch").cat((s._features_dc, s._features_rest), dim=1))
+    leaves = property(lambda s: dict(xyz=s._xyz, scaling=s._scaling, rotation=s._rotation, opacity=s._opacity,
+                                     f_dc=s._features_dc, f_rest=s._features_rest))
+
+
+def camera_namespace(cam):
+    import torch
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+    return types.SimpleNamespace(
+        FoVx=2 * np.arctan(cam.tanfovx), FoVy=2 * np.arctan(cam.tanfovy), image_height=cam.H, image_width=cam.W,
+        world_view_transform=T(cam.viewmatrix), full_proj_transform=T(cam.projmatrix), projection_matrix=T(cam.projmatrix_raw),
+        camera_center=T(cam.campos), cam_rot_delta=T(np.zeros(3), True), cam_trans_delta=T(np.zeros(3), True), time=0.0)

@@ -17,15 +17,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_deformatio
 
 def hidden_params(**over):
     """The shipped ModelHiddenParams fields the network reads (arguments/__init__.py:76-104)."""
-    a = types.SimpleNamespace(net_width=64, timebase_pe=4, defor_depth=1, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2,
-                              timenet_width=64, timenet_output=32, bounds=1.6,
-                              kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
-                                              "resolution": [64, 64, 64, 25]},
-                              multires=[1, 2, 4, 8], no_dx=False, no_grid=False, no_ds=False, no_dr=False, no_do=True, no_dshs=True,
-                              empty_voxel=False, grid_pe=0, static_mlp=False, apply_rotation=False)
-    for k, v in over.items():
-        setattr(a, k, v)
-    return a
+    return deformation.default_hidden_params(**over)
 
 
 def rel(a, b):

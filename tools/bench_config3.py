@@ -17,8 +17,8 @@ import gaussian_renderer as gr
 import deformation
 import hexplane
 from synthetic_scene import make_camera, make_gaussians, keyframe_pose
-from test_hip_fused_prologue import _GaussianModel, _camera
-from test_deformation_host import hidden_params
+from synthetic_scene import GaussianModelStub as _GaussianModel, camera_namespace as _camera
+hidden_params = deformation.default_hidden_params
 from slam_losses import get_loss_mapping, mapping_loss_weights
 from fused_adam import FusedAdam
 from tools.bench_deformation import torch_field

@@ -56,12 +56,7 @@ def main():
     ap.add_argument("--sorted", action="store_true", help="points in Morton-like (cell) order instead of random order")
     a = ap.parse_args()
     dev = "cuda"
-    args = types.SimpleNamespace(net_width=64, timebase_pe=4, defor_depth=1, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2,
-                                 timenet_width=64, timenet_output=32, bounds=1.6,
-                                 kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
-                                                 "resolution": [64, 64, 64, 25]},
-                                 multires=[1, 2, 4, 8], no_dx=False, no_grid=False, no_ds=False, no_dr=False, no_do=True, no_dshs=True,
-                                 empty_voxel=False, grid_pe=0, static_mlp=False, apply_rotation=False)
+    args = deformation.default_hidden_params()
     torch.manual_seed(0)
     net = deformation.deform_network(args, dev).to(dev)
     field = net.deformation_net.grid

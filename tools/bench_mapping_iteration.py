@@ -18,7 +18,7 @@ for p in (REPO, os.path.join(REPO, "4dgs-slam_amd"), os.path.join(REPO, "tests")
     sys.path.insert(0, p)
 import gaussian_renderer as gr
 from synthetic_scene import make_camera, make_gaussians, keyframe_pose
-from test_hip_fused_prologue import _GaussianModel, _camera
+from synthetic_scene import GaussianModelStub as _GaussianModel, camera_namespace as _camera
 from slam_losses import get_loss_mapping, mapping_loss_weights, add_densification_stats
 from fused_adam import FusedAdam
 import control_nodes as cn

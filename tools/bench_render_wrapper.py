@@ -18,7 +18,7 @@ for p in (REPO, os.path.join(REPO, "4dgs-slam_amd"), os.path.join(REPO, "tests")
     sys.path.insert(0, p)
 import gaussian_renderer as gr                                   # noqa: E402
 from synthetic_scene import make_camera, make_gaussians, make_cotangents   # noqa: E402
-from test_hip_fused_prologue import _GaussianModel, _camera      # noqa: E402  (the reference-shaped model stand-in)
+from synthetic_scene import GaussianModelStub as _GaussianModel, camera_namespace as _camera      # noqa: E402  (the reference-shaped model stand-in)
 from slam_losses import get_loss_mapping, get_loss_tracking, mapping_loss_weights, tracking_loss_weights   # noqa: E402
 
 P, W, H = 200_000, 640, 480
