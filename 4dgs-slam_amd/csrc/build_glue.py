@@ -17,7 +17,8 @@ def main():
     out = os.path.join(PKG, "diff_gaussian_rasterization", "_glue" + sysconfig.get_config_var("EXT_SUFFIX"))
     src = os.path.join(HERE, "torch_glue.cpp")
     deps = [src, os.path.join(PKG, "..", "include", "gs_rasterizer.h"), os.path.join(PKG, "..", "include", "simple_knn.h"),
-            os.path.join(PKG, "..", "include", "slam_losses.h"), os.path.join(PKG, "..", "include", "control_nodes.h")]
+            os.path.join(PKG, "..", "include", "slam_losses.h"), os.path.join(PKG, "..", "include", "control_nodes.h"),
+            os.path.join(PKG, "..", "include", "deformation_field.h")]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps) and "--force" not in sys.argv:
         print("up to date:", out)
         return

@@ -18,6 +18,7 @@
 #include "../../include/simple_knn.h"
 #include "../../include/slam_losses.h"
 #include "../../include/control_nodes.h"
+#include "../../include/deformation_field.h"
 
 namespace {
 
@@ -496,6 +497,147 @@ std::vector<torch::Tensor> node_blend_backward(const torch::Tensor& x, const c10
     return {g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local};
 }
 
+// ---- HexPlane field + deformation MLP (include/deformation_field.h) ----
+namespace {
+// 1 = channels_last ([H][W][C] memory), 0 = contiguous ([C][H][W]); anything else is rejected
+int plane_layout(const torch::Tensor& p)
+{
+    const int64_t C = p.size(1), H = p.size(2), W = p.size(3);
+    const auto st = p.strides();
+    if ((C == 1 || st[1] == 1) && (W == 1 || st[3] == C) && (H == 1 || st[2] == W * C)) return 1;
+    if ((W == 1 || st[3] == 1) && (H == 1 || st[2] == W) && (C == 1 || st[1] == H * W)) return 0;
+    TORCH_CHECK_VALUE(false, "HexPlane plane has strides that are neither channels_last nor contiguous");
+    return -1;
+}
+
+void describe_field(gsr_hexplane_field& f, const std::vector<torch::Tensor>& planes, int64_t n_levels, const c10::optional<torch::Tensor>& aabb)
+{
+    static const int C0[6] = {0, 0, 0, 1, 1, 2}, C1[6] = {1, 2, 3, 2, 3, 3};   // itertools.combinations(range(4), 2)
+    TORCH_CHECK_VALUE(n_levels >= 1 && n_levels <= GSR_HEXPLANE_MAX_LEVELS, "HexPlane field with ", n_levels, " levels (1..8 supported)");
+    TORCH_CHECK_VALUE((int64_t)planes.size() == 6 * n_levels, "a HexPlane level has six planes (grid_dimensions=2 over 4 input coordinates)");
+    f = gsr_hexplane_field{};
+    f.num_levels = (int32_t)n_levels;
+    const int64_t C = planes[0].size(1);
+    f.feat_dim = (int32_t)C;
+    f.channels_last = plane_layout(planes[0]);
+    f.aabb = (aabb.has_value() && aabb->defined()) ? aabb->data_ptr<float>() : nullptr;
+    for (int64_t l = 0; l < n_levels; l++) {
+        int res[4] = {0, 0, 0, 0};
+        for (int p = 0; p < 6; p++) {
+            const torch::Tensor& t = planes[6 * l + p];
+            TORCH_CHECK(t.is_cuda(), "HexPlane plane is on '", t.device().str(),
+                        "': the MI355X library needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+            TORCH_CHECK_VALUE(t.scalar_type() == torch::kFloat32 && t.dim() == 4 && t.size(0) == 1 && t.size(1) == C, "HexPlane plane must be fp32 [1, ", C, ", H, W]");
+            TORCH_CHECK_VALUE(plane_layout(t) == f.channels_last, "all HexPlane planes must share one memory layout");
+            const int sz[2] = {(int)t.size(3), (int)t.size(2)}, cc[2] = {C0[p], C1[p]};   // the first coordinate indexes the width
+            for (int k = 0; k < 2; k++) {
+                TORCH_CHECK_VALUE(res[cc[k]] == 0 || res[cc[k]] == sz[k], "level ", l, ": inconsistent resolution along coordinate ", cc[k], ": ", res[cc[k]], " vs ", sz[k]);
+                res[cc[k]] = sz[k];
+            }
+            f.levels[l].planes[p] = t.data_ptr<float>();
+        }
+        for (int k = 0; k < 4; k++) f.levels[l].res[k] = res[k];
+    }
+}
+
+void check_points(const torch::Tensor& xyz, const torch::Tensor& time)
+{
+    TORCH_CHECK(xyz.is_cuda(), "pts is on '", xyz.device().str(),
+                "': the MI355X library needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+    TORCH_CHECK_VALUE(xyz.scalar_type() == torch::kFloat32 && time.scalar_type() == torch::kFloat32, "HexPlane inputs must be fp32");
+    TORCH_CHECK_VALUE(xyz.dim() == 2 && xyz.size(1) >= 3 && time.dim() == 2 && time.size(0) == xyz.size(0) && xyz.stride(1) == 1,
+                      "HexPlane expects pts [n, 3] and timestamps [n, 1]");
+}
+}  // namespace
+
+torch::Tensor hexplane_forward(const std::vector<torch::Tensor>& planes, int64_t n_levels, const torch::Tensor& xyz, const torch::Tensor& time,
+                               const c10::optional<torch::Tensor>& aabb, int64_t stream)
+{
+    check_points(xyz, time);
+    gsr_hexplane_field f;
+    describe_field(f, planes, n_levels, aabb);
+    torch::Tensor out = torch::empty({xyz.size(0), n_levels * (int64_t)f.feat_dim}, xyz.options().dtype(torch::kFloat32));
+    const int rc = gsr_hexplane_forward(&f, xyz.size(0), xyz.data_ptr<float>(), xyz.stride(0), time.data_ptr<float>(), time.stride(0),
+                                        out.data_ptr<float>(), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_hexplane_forward", rc);
+    return out;
+}
+
+// returns [dL_dxyz (or undefined), gradient of plane 0, plane 1, ... (undefined where not needed)]; the plane gradients are views of ONE
+// zeroed buffer with the planes' own strides
+std::vector<torch::Tensor> hexplane_backward(const std::vector<torch::Tensor>& planes, int64_t n_levels, const torch::Tensor& xyz,
+                                             const torch::Tensor& time, const c10::optional<torch::Tensor>& aabb, const torch::Tensor& g_,
+                                             const std::vector<bool>& need_plane, bool need_xyz, bool sorted, int64_t stream)
+{
+    check_points(xyz, time);
+    gsr_hexplane_field f;
+    describe_field(f, planes, n_levels, aabb);
+    const torch::Tensor g = g_.contiguous();
+    int64_t total = 0;
+    for (size_t k = 0; k < planes.size(); k++) if (need_plane[k]) total += planes[k].numel();
+    torch::Tensor flat = torch::zeros({total}, xyz.options().dtype(torch::kFloat32));
+    std::vector<torch::Tensor> out(1 + planes.size());
+    int64_t off = 0;
+    for (size_t k = 0; k < planes.size(); k++) {
+        if (!need_plane[k]) continue;
+        out[1 + k] = flat.as_strided(planes[k].sizes(), planes[k].strides(), off);
+        f.levels[k / 6].grad_planes[k % 6] = flat.data_ptr<float>() + off;
+        off += planes[k].numel();
+    }
+    if (need_xyz) out[0] = torch::empty({xyz.size(0), 3}, xyz.options().dtype(torch::kFloat32));
+    torch::Tensor ws;
+    if (sorted && total > 0) ws = torch::empty({(int64_t)gsr_hexplane_backward_workspace_size(&f, xyz.size(0))}, xyz.options().dtype(torch::kUInt8));
+    const int rc = gsr_hexplane_backward(&f, xyz.size(0), xyz.data_ptr<float>(), xyz.stride(0), time.data_ptr<float>(), time.stride(0),
+                                         g.data_ptr<float>(), need_xyz ? out[0].data_ptr<float>() : nullptr,
+                                         ws.defined() ? reinterpret_cast<char*>(ws.data_ptr()) : nullptr, reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_hexplane_backward", rc);
+    return out;
+}
+
+namespace {
+void describe_mlp(gsr_deform_mlp& m, const std::vector<torch::Tensor>& params, int64_t in_dim)
+{
+    TORCH_CHECK_VALUE(params.size() == 14, "the fused deformation MLP takes W0, b0 and (W1, b1, W2, b2) for three heads");
+    for (const auto& p : params) TORCH_CHECK(p.is_cuda() && p.scalar_type() == torch::kFloat32 && p.is_contiguous(), "MLP parameters must be contiguous fp32 HIP tensors");
+    m = gsr_deform_mlp{};
+    m.W0 = params[0].data_ptr<float>(); m.b0 = params[1].data_ptr<float>(); m.in_dim = (int32_t)in_dim;
+    for (int j = 0; j < 3; j++) {
+        m.W1[j] = params[2 + 4 * j].data_ptr<float>(); m.b1[j] = params[3 + 4 * j].data_ptr<float>();
+        m.W2[j] = params[4 + 4 * j].data_ptr<float>(); m.b2[j] = params[5 + 4 * j].data_ptr<float>();
+    }
+}
+}  // namespace
+
+torch::Tensor deform_mlp_forward(const torch::Tensor& feat_, const std::vector<torch::Tensor>& params, int64_t stream)
+{
+    const torch::Tensor feat = feat_.contiguous();
+    gsr_deform_mlp m;
+    describe_mlp(m, params, feat.size(1));
+    torch::Tensor out = torch::empty({feat.size(0), 10}, feat.options());
+    const int rc = gsr_deform_mlp_forward(&m, feat.size(0), feat.data_ptr<float>(), out.data_ptr<float>(), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_deform_mlp_forward", rc);
+    return out;
+}
+
+// returns [dfeat, dW0, db0, (dW1, db1, dW2, db2) x 3]: the parameter gradients are views of one flat buffer in parameter order
+std::vector<torch::Tensor> deform_mlp_backward(const torch::Tensor& feat, const std::vector<torch::Tensor>& params, const torch::Tensor& dout_, int64_t stream)
+{
+    const torch::Tensor dout = dout_.contiguous();
+    gsr_deform_mlp m;
+    describe_mlp(m, params, feat.size(1));
+    const int in_dim = (int)feat.size(1);
+    torch::Tensor dfeat = torch::empty_like(feat);
+    torch::Tensor flat = torch::empty({(int64_t)gsr_deform_mlp_grad_count(in_dim)}, feat.options());
+    torch::Tensor ws = torch::empty({(int64_t)gsr_deform_mlp_workspace_size(in_dim)}, feat.options().dtype(torch::kUInt8));
+    const int rc = gsr_deform_mlp_backward(&m, feat.size(0), feat.data_ptr<float>(), dout.data_ptr<float>(), dfeat.data_ptr<float>(),
+                                           flat.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()), reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_deform_mlp_backward", rc);
+    std::vector<torch::Tensor> out{dfeat};
+    int64_t off = 0;
+    for (const auto& p : params) { out.push_back(flat.narrow(0, off, p.numel()).view(p.sizes())); off += p.numel(); }
+    return out;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("rasterize_gaussians", &rasterize_gaussians);
@@ -510,4 +652,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("dist_cuda2", &dist_cuda2);
     m.def("node_blend_forward", &node_blend_forward);
     m.def("node_blend_backward", &node_blend_backward);
+    m.def("hexplane_forward", &hexplane_forward);
+    m.def("hexplane_backward", &hexplane_backward);
+    m.def("deform_mlp_forward", &deform_mlp_forward);
+    m.def("deform_mlp_backward", &deform_mlp_backward);
 }

@@ -103,6 +103,11 @@ class _FusedDeformMLP(torch.autograd.Function):
     def forward(ctx, feat, *params):
         feat = feat.contiguous()
         params = tuple(p.detach().contiguous() for p in params)
+        glue = _C._glue
+        if glue is not None and hasattr(glue, "deform_mlp_forward"):      # native host glue (csrc/torch_glue.cpp)
+            out = glue.deform_mlp_forward(feat.detach(), list(params), _C._stream(feat.device))
+            ctx.save_for_backward(feat, *params)
+            return out
         n, in_dim = feat.shape
         dev = feat.device
         out = torch.empty((n, 10), dtype=torch.float32, device=dev)
@@ -118,6 +123,10 @@ class _FusedDeformMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         feat, *params = ctx.saved_tensors
+        glue = _C._glue
+        if glue is not None and hasattr(glue, "deform_mlp_backward"):
+            res = glue.deform_mlp_backward(feat, list(params), dout, _C._stream(feat.device))
+            return (res[0] if ctx.needs_input_grad[0] else None, *res[1:])
         n, in_dim = feat.shape
         dev = feat.device
         dout = dout.contiguous()

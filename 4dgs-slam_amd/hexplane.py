@@ -120,6 +120,22 @@ class _HexPlaneFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, time, aabb, n_levels, *planes):
+        glue = _C._glue
+        if glue is not None and hasattr(glue, "hexplane_forward"):        # native host glue (csrc/torch_glue.cpp)
+            _C._require_device(xyz, "pts")
+            if xyz.dim() == 2 and xyz.stride(1) != 1:
+                xyz = xyz.contiguous()
+            det = [p.detach() for p in planes]
+            try:
+                out = glue.hexplane_forward(det, n_levels, xyz.detach(), time.detach(), None if aabb is None else aabb.detach(), _C._stream(xyz.device))
+            except (ValueError, RuntimeError) as e:
+                if isinstance(e, ValueError) or "HIP device" in str(e):
+                    raise
+                raise ValueError(str(e)) from e
+            ctx.save_for_backward(xyz, time, aabb if aabb is not None else torch.empty(0), *planes)
+            ctx.n_levels, ctx.has_aabb, ctx.use_glue = n_levels, aabb is not None, True
+            return out
+        ctx.use_glue = False
         _C._require_device(xyz, "pts")
         _C._require_device(time, "timestamps")
         if xyz.dtype != torch.float32 or time.dtype != torch.float32:
@@ -148,6 +164,18 @@ class _HexPlaneFeatures(torch.autograd.Function):
         xyz, time, aabb, *planes = ctx.saved_tensors
         n_levels = ctx.n_levels
         aabb = aabb if ctx.has_aabb else None
+        if ctx.use_glue:
+            need_plane = list(ctx.needs_input_grad[4:])
+            mode = os.environ.get("GSR_HEX_BINNED", "auto")
+            sorted_bwd = any(need_plane) and mode != "0" and (mode == "1" or xyz.shape[0] >= BINNED_MIN_POINTS)
+            res = _C._glue.hexplane_backward([p.detach() for p in planes], n_levels, xyz, time, aabb, g, need_plane,
+                                             bool(ctx.needs_input_grad[0]), sorted_bwd, _C._stream(g.device))
+            gxyz = res[0]
+            if gxyz is not None and xyz.shape[1] > 3:
+                full = torch.zeros_like(xyz)
+                full[:, :3] = gxyz
+                gxyz = full
+            return (gxyz, None, None, None, *res[1:])
         levels = [[p.detach() for p in planes[6 * l:6 * l + 6]] for l in range(n_levels)]
         need_plane = list(ctx.needs_input_grad[4:])
         layout = _plane_layout(levels[0][0])
