@@ -103,3 +103,57 @@ def test_grad_bucket_single_process_is_identity():
     b = allreduce_gaussian_grads(ps)
     assert b.nbytes == 20 * 4
     assert torch.equal(ps[0].grad, torch.full((5, 3), 2.0)) and torch.equal(ps[1].grad, torch.full((5, 1), 3.0))
+
+
+def _net_worker(rank, world, port, ret):
+    """The deformation network's gradients ride the same collective ("plus deformation-net grads")."""
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import deformation
+    from mapping_shard import GradBucket
+    torch.manual_seed(0)                                          # the same replica on every rank
+    net = deformation.deform_network(deformation.default_hidden_params(
+        multires=[1, 2], kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [6, 5, 4, 3]}), "cpu")
+    params = [p for p in net.parameters() if p.requires_grad]
+    gen = torch.Generator().manual_seed(100 + rank)               # different views -> different gradients per rank
+    for i, p in enumerate(params):
+        if i % 5 != 4:                                            # some parameters see no gradient on a rank (unused heads)
+            p.grad = torch.randn(p.shape, generator=gen).contiguous(memory_format=torch.channels_last if p.dim() == 4 else torch.contiguous_format)
+    bucket = GradBucket(params)
+    mode = bucket.all_reduce_grads()
+    if rank == 0:
+        ret.put((mode, [None if p.grad is None else p.grad.clone().contiguous().numpy() for p in params], [tuple(p.grad.stride()) if p.grad is not None else None for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_of_deformation_network_gradients():
+    import deformation
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29000 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_net_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mode, got, strides = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert mode == "packed"                                       # channels-last plane gradients are not one contiguous range
+    torch.manual_seed(0)
+    net = deformation.deform_network(deformation.default_hidden_params(
+        multires=[1, 2], kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [6, 5, 4, 3]}), "cpu")
+    params = [p for p in net.parameters() if p.requires_grad]
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
+    for i, p in enumerate(params):
+        if i % 5 == 4:
+            assert got[i] is not None and float(np.abs(got[i]).max()) == 0.0      # no rank had a gradient: the bucket hands back zeros
+            continue
+        want = sum(torch.randn(p.shape, generator=g) for g in gens)
+        assert np.allclose(got[i], want.numpy(), rtol=1e-6, atol=1e-6), i
+        if p.dim() == 4:
+            assert strides[i] == tuple(torch.empty(p.shape).contiguous(memory_format=torch.channels_last).stride())   # layout kept
