@@ -945,7 +945,8 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
     const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
     GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
     const dim3 per_point((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL(hexsort_count_kernel, per_point, dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, time, time_stride, dL_dfeatures);
+    hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, time, time_stride,
+                       dL_dfeatures);
     hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
     hipLaunchKernelGGL(hexsort_scan_top_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, scan_blocks, ws.header);
     hipLaunchKernelGGL(hexsort_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, ws.count, nb, (const uint32_t*)ws.block_sums);

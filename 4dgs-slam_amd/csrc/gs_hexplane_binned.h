@@ -66,16 +66,22 @@ __global__ void __launch_bounds__(256)
 hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexSortWs ws, const int64_t n, const float* __restrict__ xyz,
                      const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // eight lanes per point: they read the point's cotangent row together (coalesced float4 loads), lane 0 of the group then bins it
+    const int sub = threadIdx.x & 7;
+    const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (i >= n) return;
     // A point whose cotangent row is exactly zero (a Gaussian the view does not see) adds nothing to any plane: it is left out of the
     // sort altogether, so everything after this kernel costs in proportion to the points that carry a gradient.
     const float4* row = reinterpret_cast<const float4*>(dL_dfeatures + i * ((int64_t)f.num_levels * f.feat_dim));
-    bool active = false;
-    for (int e = 0; e < f.num_levels * f.feat_dim / 4; e++) {
+    int active = 0;
+    for (int e = sub; e < f.num_levels * f.feat_dim / 4; e += 8) {
         const float4 v = row[e];
         active |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
     }
+    active |= __shfl_xor(active, 1, 64);
+    active |= __shfl_xor(active, 2, 64);
+    active |= __shfl_xor(active, 4, 64);
+    if (sub != 0) return;
     if (!active) {
 #pragma unroll
         for (int pl = 0; pl < 6; pl++) ws.key[(size_t)pl * n + i] = 0xFFFFFFFFu;
