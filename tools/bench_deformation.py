@@ -63,8 +63,11 @@ def main():
     rng = np.random.default_rng(0)
     pts_np = rng.uniform(-1.5, 1.5, size=(a.n, 3)).astype(np.float32)
     if a.sorted:
-        cell = np.floor((pts_np + 1.6) / 3.2 * 64).astype(np.int64)
-        pts_np = pts_np[np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))]
+        cell = np.floor((pts_np + 1.6) / 3.2 * 512).astype(np.int64)            # Morton order of the finest xy cells
+        def spread(v):
+            v = (v | (v << 8)) & 0x00FF00FF; v = (v | (v << 4)) & 0x0F0F0F0F; v = (v | (v << 2)) & 0x33333333; v = (v | (v << 1)) & 0x55555555
+            return v
+        pts_np = pts_np[np.argsort(spread(cell[:, 0]) | (spread(cell[:, 1]) << 1), kind="stable")]
     pts = torch.tensor(pts_np, device=dev, requires_grad=True)
     tim = torch.full((a.n, 1), 0.3, device=dev)
     scales = torch.randn(a.n, 3, device=dev, requires_grad=True)
