@@ -183,8 +183,9 @@ deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const Mlp
 // recomputes h0, a, u_j, v_j from the features (cheaper than the 1 KB per point of pre-activations the forward pass would have to
 // store and three later kernels re-read), forms du_j, dh0, dF, and accumulates EVERY weight gradient in registers across its
 // iterations -- each wave owns a quarter of the output tiles of dW0 / dW1j / dW2j and reduces over the block's 64 points, with the
-// activation tiles of all four waves shared through LDS.  At the end the block writes one row of partial sums; a second kernel adds
-// the rows in a fixed order.  HBM traffic: features + dout in, dF out.
+// activation tiles of all four waves shared through LDS.  W0 and the W1j live in LDS too (86 KB of the block's 141 KB); the features
+// -- B operand of dW0 -- are re-read from L2, the block having read them a moment before.  At the end the block writes one row of
+// partial sums; a second kernel adds the rows in a fixed order.  HBM traffic: features + dout in, dF out.
 //
 // flat gradient layout (also of a partial row): W0 [64][in] | b0 [64] | per head j: W1j [64][64] | b1j [64] | W2j [o_j][64] | b2j [o_j]
 struct MlpGradLayout {
@@ -209,7 +210,6 @@ __host__ __device__ inline MlpGradLayout mlp_grad_layout(int in_dim, const int* 
 
 constexpr int MLPB_BLOCK = 256;           // 4 waves
 constexpr int MLPB_TILE = 64;             // points per block iteration
-constexpr int MLPB_LDF = 128 + 4;         // feature tile row stride (in_dim <= 128)
 
 template <int NT_IN>                      // in_dim / 16
 __global__ void __launch_bounds__(MLPB_BLOCK)
@@ -217,12 +217,16 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
                       float* __restrict__ dfeat, float* __restrict__ partial)
 {
     constexpr int IN = 16 * NT_IN;
-    __shared__ __attribute__((aligned(16))) float s_f[MLPB_TILE][MLPB_LDF];     // features of the block's 64 points
+    __shared__ __attribute__((aligned(16))) float s_W0[MLP_W][IN + 4];          // W0 (h0 recompute and dF); the features for dW0 are re-read from L2
     __shared__ __attribute__((aligned(16))) float s_a[MLPB_TILE][MLP_LDA];      // a = relu(h0)
     __shared__ __attribute__((aligned(16))) float s_v[MLPB_TILE][MLP_LDA];      // v_j = relu(u_j), one head at a time
     __shared__ __attribute__((aligned(16))) float s_d[MLPB_TILE][MLP_LDA];      // du_j, one head at a time; then dh0
     __shared__ float s_o[MLPB_TILE][12];                                          // dout of the block's points (10 used)
-    __shared__ __attribute__((aligned(16))) float s_W1[MLP_HEADS][MLP_W][MLP_LDA];  // the most-read weights (u_j recompute and dL/da), 52 KB
+    __shared__ __attribute__((aligned(16))) float s_W1[MLP_HEADS][MLP_W][MLP_LDA];  // u_j recompute and dL/da, 52 KB
+    for (int e = threadIdx.x; e < MLP_W * IN / 4; e += MLPB_BLOCK) {
+        const int r = e / (IN / 4), c = e - r * (IN / 4);
+        *reinterpret_cast<float4*>(&s_W0[r][4 * c]) = *reinterpret_cast<const float4*>(w.W0 + (size_t)r * IN + 4 * c);
+    }
 #pragma unroll
     for (int j = 0; j < MLP_HEADS; j++) {
         for (int e = threadIdx.x; e < MLP_W * MLP_W / 4; e += MLPB_BLOCK) {
@@ -282,10 +286,9 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
 #pragma unroll
         for (int S = 0; S < NT_IN; S++) {
             const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&s_f[r0 + i][16 * S + 4 * q]) = a4;
             float4 b4[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(w.W0 + (size_t)(16 * t + i) * IN + 16 * S + 4 * q);
+            for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(&s_W0[16 * t + i][16 * S + 4 * q]);
             mfma4x4(a4, b4, acc1);
         }
 #pragma unroll
@@ -370,8 +373,12 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         for (int S = 0; S < MLPB_TILE / 4; S++) {
             const int pt = 4 * S + q;
             const float ad = s_d[pt][16 * wave + i];
+            const int64_t pg = min(pblk + pt, n - 1);                 // rows beyond n have dh0 = 0: any valid row will do
+            float fb[NT_IN];                                          // the block read these rows a moment ago: L2
 #pragma unroll
-            for (int t = 0; t < NT_IN; t++) gW0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s_f[pt][16 * t + i], gW0[t], 0, 0, 0);
+            for (int t = 0; t < NT_IN; t++) fb[t] = feat[pg * IN + 16 * t + i];
+#pragma unroll
+            for (int t = 0; t < NT_IN; t++) gW0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, fb[t], gW0[t], 0, 0, 0);
         }
         // ---- dF = dh0 W0 (wave's points), four column tiles at a time ----
 #pragma unroll
@@ -382,12 +389,13 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
 #pragma unroll
             for (int S = 0; S < MLP_W / 16; S++) {
                 const float4 a4 = *reinterpret_cast<const float4*>(&s_d[r0 + i][16 * S + 4 * q]);
-                const float* wrow = w.W0 + (size_t)(16 * S + 4 * q) * IN + 16 * t0 + i;
+                const float* wrow = &s_W0[16 * S + 4 * q][16 * t0 + i];   // B[k][col] = W0[k][col]: four rows of the LDS copy
+                constexpr int LDW = IN + 4;
                 float4 b4[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int c = t0 + t < NT_IN ? 16 * t : 0;    // in_dim not a multiple of 64: the surplus tiles redo tile t0 and are dropped
-                    b4[t] = make_float4(wrow[c], wrow[IN + c], wrow[2 * IN + c], wrow[3 * IN + c]);
+                    b4[t] = make_float4(wrow[c], wrow[LDW + c], wrow[2 * LDW + c], wrow[3 * LDW + c]);
                 }
                 mfma4x4(a4, b4, accf);
             }
