@@ -237,7 +237,7 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
             const HexAxis& Y = ax[c1];
             const float gs = prefix * suffix[pl];
             prefix *= s[pl];
-            ws.gs[slot[pl] + (size_t)l * C] = gs;
+            __builtin_nontemporal_store(gs, &ws.gs[slot[pl] + (size_t)l * C]);   // streamed once: keep the planes in L2 (331 -> 299 us)
             if (dL_dxyz) {
                 const float nw = corner[pl][0] * gs, ne = X.has1 ? corner[pl][1] * gs : 0.f, sw = Y.has1 ? corner[pl][2] * gs : 0.f;
                 const float se = X.has1 && Y.has1 ? corner[pl][3] * gs : 0.f;
