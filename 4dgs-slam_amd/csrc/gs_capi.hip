@@ -31,6 +31,8 @@
 #include "gs_mlp.h"
 #include "gs_nodes.h"
 #include "../../include/slam_losses.h"
+#include "../../include/slam_map.h"
+#include "gs_map.h"
 
 namespace gsr {
 
@@ -1188,6 +1190,105 @@ int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, con
     hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, G, total, (const float*)partial, summed);
     hipLaunchKernelGGL(node_grad_finalize_kernel, dim3((a->m + 255) / 256), dim3(256), 0, stream, *a, (const float*)summed, g_node_trans, g_node_rot,
                        g_node_scale, g_node_frame, g_node_radius, g_node_weight);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- map maintenance + camera step (include/slam_map.h) -----------------------------------------------------------------------
+extern "C" {
+
+size_t gsr_seed_workspace_size(int n)
+{
+    const size_t N = (size_t)(n > 0 ? n : 1);
+    return gsr_knn_workspace_size(n) + N * sizeof(float) + 512;      // k-NN scratch + the mean squared distances
+}
+
+int gsr_seed_from_rgbd(int n, const int* pix, int width, int height, const float* depth, const float* image, const float* exposure_a,
+                       const float* exposure_b, float fx, float fy, float cx, float cy, const float* R, const float* T, float point_size,
+                       int scale_dim, float* xyz, float* features_dc, float* log_scales, float* rotations, float* logit_opacity,
+                       char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || width <= 0 || height <= 0 || (scale_dim != 1 && scale_dim != 3) || !(fx != 0.f) || !(fy != 0.f)) {
+        g_last_error = "gsr_seed_from_rgbd: invalid size / intrinsics / scale_dim"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return 0;
+    if (!pix || !depth || !image || !R || !T || !xyz || !features_dc || !log_scales || !rotations || !logit_opacity || !workspace) {
+        g_last_error = "gsr_seed_from_rgbd: null argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    hipLaunchKernelGGL(seed_backproject_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, pix, width, height, depth, image, exposure_a,
+                       exposure_b, fx, fy, cx, cy, R, T, xyz, features_dc, rotations, logit_opacity);
+    uintptr_t a = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255);
+    float* dist2 = reinterpret_cast<float*>(a);
+    char* knn_ws = reinterpret_cast<char*>((a + (size_t)n * sizeof(float) + 255) & ~uintptr_t(255));
+    if (int rc = gsr_knn_mean_dist2(n, xyz, dist2, knn_ws, stream_)) return rc;
+    hipLaunchKernelGGL(seed_scales_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, (const float*)dist2, point_size, scale_dim, log_scales);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_densify_select(int P, const float* xyz_gradient_accum, const float* denom, const float* log_scales, int scale_dim,
+                       const float* logit_opacity, float grad_threshold, float dense_scale, float min_opacity, float big_scale, int* flags,
+                       void* stream_)
+{
+    if (P < 0 || (scale_dim != 1 && scale_dim != 3)) { g_last_error = "gsr_densify_select: invalid size / scale_dim"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P == 0) return 0;
+    if (!xyz_gradient_accum || !denom || !log_scales || !logit_opacity || !flags) { g_last_error = "gsr_densify_select: null argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    hipLaunchKernelGGL(densify_select_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, P, xyz_gradient_accum, denom, log_scales,
+                       scale_dim, logit_opacity, grad_threshold, dense_scale, min_opacity, big_scale, flags);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_densify_apply(int P, const int* flags, const int* offsets, int n_keep, int n_clone, int n_split, int n_child, int ntensors,
+                      const gsr_densify_tensor* tensors, const float* xyz, const float* log_scales, int scale_dim, const float* raw_rotations,
+                      const float* noise, void* stream_)
+{
+    if (P < 0 || n_keep < 0 || n_clone < 0 || n_split < 0 || n_child < 0 || ntensors < 0 || ntensors > DENSIFY_MAX_TENSORS || (ntensors > 0 && !tensors)) {
+        g_last_error = "gsr_densify_apply: invalid counts (at most 32 tensors)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0 || ntensors == 0) return 0;
+    if (!flags || !offsets) { g_last_error = "gsr_densify_apply: null flags / offsets"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (n_child > 0 && (!xyz || !log_scales || !raw_rotations || !noise || (scale_dim != 1 && scale_dim != 3))) {
+        g_last_error = "gsr_densify_apply: children need xyz, log_scales, raw_rotations and noise"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    DensifyArgs a;
+    a.P = P; a.n_keep = n_keep; a.n_clone = n_clone; a.n_split = n_split; a.n_child = n_child; a.ntensors = ntensors; a.scale_dim = scale_dim;
+    a.flags = flags; a.offsets = offsets; a.xyz = xyz; a.log_scales = log_scales; a.raw_rot = raw_rotations; a.noise = noise;
+    const long long n_out = (long long)n_keep + n_clone + 2LL * n_child;
+    for (int k = 0; k < ntensors; k++) {
+        const gsr_densify_tensor& t = tensors[k];
+        if (t.width <= 0 || !t.src || (n_out > 0 && !t.dst) || t.kind < GSR_DENSIFY_COPY || t.kind > GSR_DENSIFY_SCALE ||
+            (t.kind == GSR_DENSIFY_XYZ && t.width != 3)) {
+            g_last_error = "gsr_densify_apply: bad tensor descriptor"; return GSR_ERR_INVALID_ARGUMENT;
+        }
+        a.t[k] = DensifyTensor{t.src, t.dst, t.width, t.kind};
+    }
+    hipLaunchKernelGGL(densify_apply_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
+{
+    if (!s || !s->R || !s->T || !s->viewmatrix || (s->full_proj && !s->projmatrix)) { g_last_error = "gsr_camera_step_launch: null pose / output"; return GSR_ERR_INVALID_ARGUMENT; }
+    const bool any_grad = s->g_rot_delta || s->g_trans_delta || s->g_exposure_a || s->g_exposure_b;
+    if (any_grad && (!s->exp_avg || !s->exp_avg_sq || !s->step)) { g_last_error = "gsr_camera_step_launch: Adam state missing"; return GSR_ERR_INVALID_ARGUMENT; }
+    if ((s->g_rot_delta && !s->rot_delta) || (s->g_trans_delta && !s->trans_delta) || (s->g_exposure_a && !s->exposure_a) || (s->g_exposure_b && !s->exposure_b) ||
+        (s->do_pose && (!s->rot_delta || !s->trans_delta))) {
+        g_last_error = "gsr_camera_step_launch: gradient / pose step without its parameter"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    CameraStepArgs a;
+    a.p[0] = s->rot_delta; a.g[0] = s->g_rot_delta; a.n[0] = 3; a.lr[0] = s->lr_rot;
+    a.p[1] = s->trans_delta; a.g[1] = s->g_trans_delta; a.n[1] = 3; a.lr[1] = s->lr_trans;
+    a.p[2] = s->exposure_a; a.g[2] = s->g_exposure_a; a.n[2] = 1; a.lr[2] = s->lr_exposure;
+    a.p[3] = s->exposure_b; a.g[3] = s->g_exposure_b; a.n[3] = 1; a.lr[3] = s->lr_exposure;
+    a.exp_avg = s->exp_avg; a.exp_avg_sq = s->exp_avg_sq; a.step = s->step; a.beta1 = s->beta1; a.beta2 = s->beta2; a.eps = s->eps;
+    a.R = s->R; a.T = s->T; a.proj = s->projmatrix; a.view = s->viewmatrix; a.full = s->full_proj; a.campos = s->campos;
+    a.converged = s->converged; a.thr = s->converged_threshold; a.do_pose = s->do_pose;
+    hipLaunchKernelGGL(camera_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

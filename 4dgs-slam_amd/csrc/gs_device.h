@@ -82,7 +82,8 @@ __device__ __forceinline__ void lane_swap16(f2v& a, f2v& b)
 }
 
 // `proc`/`jj`, `lds_lane`/`j`: the caller's bookkeeping for this entry (mark bit jj in the processed mask, LDS byte address
-// lds_lane + 40 j of the total's slot) rides in issue slots the DPP hazards would otherwise fill with s_nop.
+// lds_lane + ROW_BYTES j of the total's slot) rides in issue slots the DPP hazards would otherwise fill with s_nop.
+template <int ROW_BYTES = 40>
 __device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w, float s_op, f2v q1, f2v q2, float m2yy, f2v c_rg, f2v c_bd,
                                                        unsigned long long& proc, int jj, uint32_t lds_lane, int j, uint32_t& lds_addr)
 {
@@ -110,7 +111,7 @@ __device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w,
         "v_add_f32_dpp %[u], %[send], %[keep] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_cndmask_b32_e64 %[send], %[s1], %[u], %[m1]\n\t"     // bit 1 ? u : s1
         "v_cndmask_b32_e64 %[keep], %[u], %[s1], %[m1]\n\t"     // bit 1 ? s1 : u
-        "s_mul_i32 %[joff], %[j], 40\n\t"
+        "s_mul_i32 %[joff], %[j], %[rowb]\n\t"
         "v_add_f32_dpp %[t], %[send], %[keep] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_bitset1_b64 %[proc], %[jj]\n\t"
         "v_add_u32 %[addr], %[joff], %[lane]\n\t"
@@ -119,7 +120,7 @@ __device__ __forceinline__ float wave_sum10_transposed(const WaveSelectMasks& w,
         "v_add_f32_dpp %[t], %[t], %[t] row_ror:4 row_mask:0xf bank_mask:0xf"
         : [keep] "=&v"(keep), [send] "=&v"(send), [u] "=&v"(u), [s1] "=&v"(s1), [t] "=&v"(t), [joff] "=&s"(joff), [addr] "=&v"(lds_addr),
           [proc] "+s"(proc)
-        : [x] "v"(PC.x), [y] "v"(PC.y), [s] "v"(S), [m0] "s"(w.m0), [m1] "s"(w.m1), [j] "s"(j), [jj] "s"(jj), [lane] "v"(lds_lane));
+        : [x] "v"(PC.x), [y] "v"(PC.y), [s] "v"(S), [m0] "s"(w.m0), [m1] "s"(w.m1), [j] "s"(j), [jj] "s"(jj), [lane] "v"(lds_lane), [rowb] "n"(ROW_BYTES));
     return t;
 }
 

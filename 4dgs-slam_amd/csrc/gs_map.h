@@ -1,0 +1,238 @@
+// gs_map.h -- per-Gaussian / per-camera kernels of the SLAM loop around the rasterizer (include/slam_map.h):
+// RGB-D seeding, densify / clone / split / prune, camera step. gfx950 / wave64. GM = gaussian_splatting/scene/gaussian_model.py.
+#pragma once
+#include "gs_device.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Seeding, GM:185-255. One thread per selected pixel: back-projection through the keyframe's pose (Open3D's
+// PointCloud::CreateFromRGBDImage with extrinsic = W2C: p_world = W2C^-1 p_cam; rigid, so R^T (p - T)) and the colour of the byte
+// image the reference builds first (:186-188).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) seed_backproject_kernel(int n, const int* __restrict__ pix, int W, int H, const float* __restrict__ depth,
+                                                               const float* __restrict__ image, const float* exposure_a, const float* exposure_b,
+                                                               float fx, float fy, float cx, float cy, const float* __restrict__ R,
+                                                               const float* __restrict__ T, float* __restrict__ xyz, float* __restrict__ f_dc,
+                                                               float* __restrict__ rot, float* __restrict__ logit_opacity)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = pix[i];
+    const int u = p % W, v = p / W;
+    const float z = depth[p];
+    const float xc = ((float)u - cx) * z / fx, yc = ((float)v - cy) * z / fy;
+    const float dx = xc - T[0], dy = yc - T[1], dz = z - T[2];
+    xyz[3 * (size_t)i] = R[0] * dx + R[3] * dy + R[6] * dz;          // R^T (p_cam - T)
+    xyz[3 * (size_t)i + 1] = R[1] * dx + R[4] * dy + R[7] * dz;
+    xyz[3 * (size_t)i + 2] = R[2] * dx + R[5] * dy + R[8] * dz;
+    const float ea = exposure_a ? expf(exposure_a[0]) : 1.0f, eb = exposure_b ? exposure_b[0] : 0.0f;
+    const size_t N = (size_t)W * H;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float ab = fminf(fmaxf(ea * image[c * N + p] + eb, 0.0f), 1.0f);          // :186-187
+        const float byte = floorf(ab * 255.0f);                                         // .byte() truncates, :188
+        f_dc[3 * (size_t)i + c] = (byte / 255.0f - 0.5f) / SH_C0;                       // Open3D colour in [0,1] -> RGB2SH
+    }
+    rot[4 * (size_t)i] = 1.f; rot[4 * (size_t)i + 1] = 0.f; rot[4 * (size_t)i + 2] = 0.f; rot[4 * (size_t)i + 3] = 0.f;   // :244-245
+    logit_opacity[i] = 0.0f;                                                             // inverse_sigmoid(0.5), :246-253
+}
+
+// GM:235-242: scales = log(sqrt(clamp_min(distCUDA2, 1e-7) * point_size)), one value (isotropic) or the value three times.
+__global__ void __launch_bounds__(256) seed_scales_kernel(int n, const float* __restrict__ mean_dist2, float point_size, int scale_dim,
+                                                          float* __restrict__ log_scales)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s = logf(sqrtf(fmaxf(mean_dist2[i], 0.0000001f) * point_size));
+    for (int k = 0; k < scale_dim; k++) log_scales[(size_t)i * scale_dim + k] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Densification decisions, GM:866-971 (see include/slam_map.h for the exact predicate). flags[4][P].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) densify_select_kernel(int P, const float* __restrict__ accum, const float* __restrict__ denom,
+                                                             const float* __restrict__ log_scales, int scale_dim,
+                                                             const float* __restrict__ logit_opacity, float grad_threshold, float dense_scale,
+                                                             float min_opacity, float big_scale, int* __restrict__ flags)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float g = accum[i] / denom[i];                                    // :954
+    if (g != g) g = 0.0f;                                             // grads[grads.isnan()] = 0, :955
+    float s = expf(log_scales[(size_t)i * scale_dim]);
+    for (int k = 1; k < scale_dim; k++) s = fmaxf(s, expf(log_scales[(size_t)i * scale_dim + k]));
+    const float o = 1.0f / (1.0f + expf(-logit_opacity[i]));
+    const bool hot = g >= grad_threshold;
+    const bool clone = hot && s <= dense_scale;                       // :922-929
+    const bool split = hot && s > dense_scale;                        // :871-877
+    const bool faint = o < min_opacity;                               // :960
+    const bool pruned = faint || (big_scale > 0.0f && s > big_scale);                         // :963-969 (the screen-size term is dead: :857)
+    // the children's scale is exp(log(scale / 1.6)): evaluate the test on what get_scaling will return for them
+    const bool pruned_child = faint || (big_scale > 0.0f && expf(logf(s / 1.6f)) > big_scale);
+    flags[i] = (!split && !pruned) ? 1 : 0;
+    flags[(size_t)P + i] = (clone && !pruned) ? 1 : 0;
+    flags[2 * (size_t)P + i] = split ? 1 : 0;
+    flags[3 * (size_t)P + i] = (split && !pruned_child) ? 1 : 0;
+}
+
+constexpr int DENSIFY_MAX_TENSORS = 32;
+struct DensifyTensor { const float* src; float* dst; int width; int kind; };
+struct DensifyArgs {
+    int P, n_keep, n_clone, n_split, n_child, ntensors, scale_dim;
+    const int* flags; const int* offsets;
+    const float* xyz; const float* log_scales; const float* raw_rot; const float* noise;
+    DensifyTensor t[DENSIFY_MAX_TENSORS];
+};
+
+// One thread per SOURCE Gaussian: writes its surviving copy, its clone and its two children (whichever exist) into every
+// destination tensor. Source-parallel, so no index map is needed: the exclusive prefix sums of the flag rows are the destinations.
+__global__ void __launch_bounds__(256) densify_apply_kernel(DensifyArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const size_t P = (size_t)a.P;
+    const bool keep = a.flags[i] != 0, clone = a.flags[P + i] != 0, split = a.flags[2 * P + i] != 0, child = a.flags[3 * P + i] != 0;
+    if (!keep && !clone && !child) return;
+    const long long r_keep = keep ? a.offsets[i] : -1;
+    const long long r_clone = clone ? (long long)a.n_keep + a.offsets[P + i] : -1;
+    const long long r_c0 = child ? (long long)a.n_keep + a.n_clone + a.offsets[3 * P + i] : -1;
+    const long long r_c1 = child ? r_c0 + a.n_child : -1;
+    float cx[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // children's positions
+    if (child && split) {
+        // GM:877-883: samples ~ N(0, diag(scale^2)) rotated by the (normalised) quaternion, added to the parent's position
+        float st[3];
+        for (int k = 0; k < 3; k++) st[k] = expf(a.log_scales[(size_t)i * a.scale_dim + (a.scale_dim == 1 ? 0 : k)]);
+        const float qr = a.raw_rot[4 * (size_t)i], qx = a.raw_rot[4 * (size_t)i + 1], qy = a.raw_rot[4 * (size_t)i + 2], qz = a.raw_rot[4 * (size_t)i + 3];
+        const float nrm = sqrtf(qr * qr + qx * qx + qy * qy + qz * qz);           // build_rotation, general_utils.py:118-141
+        const float r = qr / nrm, x = qx / nrm, y = qy / nrm, z = qz / nrm;
+        const float Rm[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                                {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                                {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+        const size_t s0 = (size_t)a.offsets[2 * P + i];
+        for (int c = 0; c < 2; c++) {
+            const float* nz = a.noise + 3 * (s0 + (size_t)c * a.n_split);
+            const float v0 = nz[0] * st[0], v1 = nz[1] * st[1], v2 = nz[2] * st[2];
+            for (int k = 0; k < 3; k++) cx[c][k] = Rm[k][0] * v0 + Rm[k][1] * v1 + Rm[k][2] * v2 + a.xyz[3 * (size_t)i + k];
+        }
+    }
+    for (int ti = 0; ti < a.ntensors; ti++) {
+        const DensifyTensor& t = a.t[ti];
+        const float* src = t.src + (size_t)i * t.width;
+        for (int k = 0; k < t.width; k++) {
+            const float v = src[k];
+            if (r_keep >= 0) t.dst[(size_t)r_keep * t.width + k] = v;
+            if (t.kind == GSR_DENSIFY_STATE) {                     // fresh rows start with zero moments, GM:812-830
+                if (r_clone >= 0) t.dst[(size_t)r_clone * t.width + k] = 0.0f;
+                if (r_c0 >= 0) { t.dst[(size_t)r_c0 * t.width + k] = 0.0f; t.dst[(size_t)r_c1 * t.width + k] = 0.0f; }
+            } else {
+                if (r_clone >= 0) t.dst[(size_t)r_clone * t.width + k] = v;
+                if (r_c0 >= 0) {
+                    float c0 = v, c1 = v;
+                    if (t.kind == GSR_DENSIFY_XYZ) { c0 = cx[0][k]; c1 = cx[1][k]; }
+                    else if (t.kind == GSR_DENSIFY_SCALE) { c0 = c1 = logf(expf(v) / (0.8f * 2.0f)); }      // GM:885-887
+                    t.dst[(size_t)r_c0 * t.width + k] = c0; t.dst[(size_t)r_c1 * t.width + k] = c1;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Camera step (include/slam_map.h): Adam on the camera's four small tensors, update_pose (utils/pose_utils.py:80-97),
+// and the matrices of utils/camera_utils.py:124-148. One wave; lane 0 does the 3x3 algebra.
+// ------------------------------------------------------------------------------------------------------------------
+struct CameraStepArgs {
+    float* p[4]; const float* g[4]; int n[4]; float lr[4];
+    float* exp_avg; float* exp_avg_sq; float* step; float beta1, beta2, eps;
+    float* R; float* T; const float* proj; float* view; float* full; float* campos; int* converged; float thr; int do_pose;
+};
+
+__device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C)
+{
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+__global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a)
+{
+    const int lane = threadIdx.x;
+    // (1) Adam, torch.optim.Adam single-tensor arithmetic (bias corrections in double like torch's _single_tensor_adam)
+    bool any_grad = false;
+    for (int s = 0; s < 4; s++) any_grad |= a.g[s] != nullptr;
+    if (any_grad) {
+        const float stepf = a.step[0] + 1.0f;
+        const double bc1 = 1.0 - pow((double)a.beta1, (double)stepf), bc2 = 1.0 - pow((double)a.beta2, (double)stepf);
+        int base = 0;
+        for (int s = 0; s < 4; s++) {
+            if (a.g[s] && lane < a.n[s]) {
+                const float gr = a.g[s][lane];
+                float m = a.exp_avg[base + lane], v = a.exp_avg_sq[base + lane];
+                m = m + (gr - m) * (float)(1.0 - (double)a.beta1);
+                v = v * a.beta2 + (float)(1.0 - (double)a.beta2) * gr * gr;
+                a.exp_avg[base + lane] = m; a.exp_avg_sq[base + lane] = v;
+                const float step_size = (float)((double)a.lr[s] / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+                a.p[s][lane] = a.p[s][lane] - step_size * (m / (sqrtf(v) * inv_bc2_sqrt + a.eps));
+            }
+            base += a.n[s];
+        }
+        __syncthreads();
+        if (lane == 0) a.step[0] = stepf;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane != 0) return;
+    float Rm[9], Tv[3];
+    for (int k = 0; k < 9; k++) Rm[k] = a.R[k];
+    for (int k = 0; k < 3; k++) Tv[k] = a.T[k];
+    if (a.do_pose) {
+        // (2) SE3_exp(tau) @ [R | T], pose_utils.py:27-97
+        const float rho[3] = {a.p[1][0], a.p[1][1], a.p[1][2]}, th[3] = {a.p[0][0], a.p[0][1], a.p[0][2]};
+        const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};          // skew_sym_mat
+        float W2[9];
+        mat3_mul(Wm, Wm, W2);
+        const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+        float ca, cb, va, vb;   // R = I + ca W + cb W2;  V = I + va W + vb W2
+        if (angle < 1e-5f) { ca = 1.0f; cb = 0.5f; va = 0.5f; vb = 1.0f / 6.0f; }
+        else {
+            ca = sinf(angle) / angle; cb = (1.0f - cosf(angle)) / (angle * angle);
+            va = (1.0f - cosf(angle)) / (angle * angle); vb = (angle - sinf(angle)) / (angle * angle * angle);
+        }
+        float dR[9], Vm[9];
+        for (int k = 0; k < 9; k++) {
+            const float I = (k == 0 || k == 4 || k == 8) ? 1.0f : 0.0f;
+            dR[k] = I + ca * Wm[k] + cb * W2[k];
+            Vm[k] = I + Wm[k] * va + W2[k] * vb;
+        }
+        float dt[3];
+        for (int i = 0; i < 3; i++) dt[i] = Vm[3 * i] * rho[0] + Vm[3 * i + 1] * rho[1] + Vm[3 * i + 2] * rho[2];
+        float Rn[9], Tn[3];
+        mat3_mul(dR, Rm, Rn);
+        for (int i = 0; i < 3; i++) Tn[i] = dR[3 * i] * Tv[0] + dR[3 * i + 1] * Tv[1] + dR[3 * i + 2] * Tv[2] + dt[i];
+        const float tn = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+        if (a.converged) a.converged[0] = tn < a.thr ? 1 : 0;
+        for (int k = 0; k < 9; k++) { Rm[k] = Rn[k]; a.R[k] = Rn[k]; }
+        for (int k = 0; k < 3; k++) { Tv[k] = Tn[k]; a.T[k] = Tn[k]; a.p[0][k] = 0.f; a.p[1][k] = 0.f; }
+    }
+    // (3) viewmatrix = W2C^T (row-major memory of the transposed matrix): view[4*c + r] = W2C[r][c]
+    float view[16];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) view[4 * c + r] = Rm[3 * r + c];
+        view[12 + r] = Tv[r];
+        view[4 * r + 3] = 0.f;
+    }
+    view[15] = 1.f;
+    for (int k = 0; k < 16; k++) a.view[k] = view[k];
+    if (a.full) {
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                float s = 0.f;
+                for (int k = 0; k < 4; k++) s += view[4 * i + k] * a.proj[4 * k + j];
+                a.full[4 * i + j] = s;
+            }
+    }
+    if (a.campos) {   // camera centre = -R^T T  (= inverse(view)[3, :3])
+        for (int c = 0; c < 3; c++) a.campos[c] = -(Rm[c] * Tv[0] + Rm[3 + c] * Tv[1] + Rm[6 + c] * Tv[2]);
+    }
+}
+
+}  // namespace gsr

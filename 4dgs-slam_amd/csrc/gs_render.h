@@ -231,7 +231,12 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 //    every CHUNK entries, so every chunk can be differentiated on its own (details at the state set-up below).
 // Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int BB = CHUNK;   // entries per block of the backward kernel (LDS: 8 KiB staging + 20 KiB quadrant totals)
+constexpr int BB = CHUNK;   // entries per block of the backward kernel
+constexpr int GRP = 64;     // entries per group: the quadrant totals in LDS cover one group at a time
+constexpr int PART_STRIDE = 12;   // floats per (quadrant, entry) in s_part: {M1x, M1y, M2xx, M2xy | M2yy, sum q, r, g | b, depth, -, -}
+// position of sum k (wave_sum10 slot numbering: 0 s_op, 1 M1x, 2 M1y, 3 M2xx, 4 M2xy, 5 M2yy, 6 r, 7 g, 8 b, 9 depth) inside an s_part row:
+// the order in which the three float4 pieces of the gradient slot consume them
+__device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <= 5 ? k - 1 : k); }
 
 __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ chunk_base, const char* bin_base,
@@ -243,8 +248,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                                                         const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth)
 {
     // ---- which (tile, chunk) is this block? The grid is an upper bound (R / CHUNK + tiles); surplus blocks leave.
-    const uint32_t cid = (uint32_t)xcd_tile_of_block(blockIdx.x, gridDim.x);   // neighbouring chunks (same or adjacent tiles) share an XCD's L2
-    if (cid >= header[HDR_CHUNKS]) return;
+    // The XCD banding is computed over the REAL number of chunks: banding over the grid (an upper bound) put every surplus id
+    // into the last XCD's band, which then ran out of work while the other seven still had a quarter of theirs.
+    const uint32_t nchunks = header[HDR_CHUNKS];
+    if (blockIdx.x >= nchunks) return;
+    const uint32_t cid = (uint32_t)xcd_tile_of_block(blockIdx.x, (int)nchunks);   // neighbouring chunks (same or adjacent tiles) share an XCD's L2
     int tile;
     {   // largest t with chunk_base[t] <= cid (uniform binary search, scalar loads)
         int lo = 0, hi = ntiles;
@@ -258,10 +266,15 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
-    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, opacity}                      (C = -c/2 log2e)
+    __shared__ float2 s_b[BB];   // {C, log2 opacity}                                                 (C = -c/2 log2e)
     __shared__ float4 s_c[BB];   // {r, g, b, depth}
-    __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, -}: only the per-entry epilogue needs the unscaled conic
-    __shared__ float s_part[4][BB][10];
+    __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, opacity}: only the per-entry epilogue needs the unscaled conic
+    __shared__ uint32_t s_inst[BB];   // instance id of the entry (its gradient slot)
+    // Quadrant totals of ONE 64-entry group (12 floats per (quadrant, entry): three float4 = the three 16-byte pieces of a slot).
+    // Sized for a group, not for the whole chunk, the block needs 19.6 KiB of LDS instead of 28.8 and eight blocks share a CU
+    // instead of five: a single wave issues one instruction per ~8 cycles on this part (profiles/r02_ubench_issue.json), the SIMD
+    // needs four READY waves to keep its VALU busy, and 42 % of this kernel's wave-cycles are parked on memory or barriers.
+    __shared__ __attribute__((aligned(16))) float s_part[4][GRP][PART_STRIDE];
     __shared__ unsigned long long s_mask[4][2];
     __shared__ unsigned long long s_proc[4][2];   // [quadrant][64-entry group]: entries whose totals the quadrant wave actually wrote
     __shared__ int s_wmax[4];
@@ -325,7 +338,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
     // which of the ten sums this lane ends up holding after the transposed reduction
     const int fi = wave_sum10_slot_of_lane(lane);
-    const uint32_t part_lane = (uint32_t)(wave * (BB * 10) + fi) * 4u;   // this lane's byte offset into s_part for entry 0
+    const uint32_t part_lane = (uint32_t)(wave * (GRP * PART_STRIDE) + part_pos_of_sum(fi)) * 4u;   // this lane's byte offset into s_part for entry 0 of a group
     const WaveSelectMasks wsm = wave_select_masks();
 
     uint32_t qm = 0;
@@ -338,9 +351,10 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
 #pragma unroll
         for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
         s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
-        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), co.w);   // log2(opacity) for the loop, opacity for the epilogue
+        s_b[t] = make_float2(-0.5f * LOG2E * co.z, __log2f(co.w));   // log2(opacity): folded into the exponent
         s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
-        s_d[t] = make_float4(co.x, co.y, co.z, 0.f);
+        s_d[t] = co;
+        s_inst[t] = e.y;
     }
     // pos < last_contrib (:678)  <=>  j >= cend - last_contrib, with j the index inside this chunk
     const int j_thr = cend - last_contrib;
@@ -352,71 +366,76 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         }
     }
     __syncthreads();
+    unsigned long long proc = 0;
+    int group_base = 0;
+    // One (quadrant, entry) pair: entry jj of the current group. (Issuing the LDS reads one iteration ahead was measured: +3 % -- the
+    // extra scalar bookkeeping costs more issue slots than the hidden latency returns; the other resident waves already cover it.)
+    auto bwd_pair = [&](int jj) {
+        const int j = group_base + jj;
+        const float4 A4 = s_a[j];
+        const float2 B2 = s_b[j];
+        const f2 d = f2{A4.x, A4.y} - pxy;
+        // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
+        // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
+        const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
+        const float G = __builtin_amdgcn_exp2f(pw);
+        const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
+        const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
+        if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
+        const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
+        const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
+        const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
+        const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
+        T *= inv1ma;                                                                           // :700
+        const float wv = av * T;                                                               // :701 dchannel_dcolor
+        const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
+        const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
+        const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
+        Sb += wv * cg;
+        // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
+        //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
+        //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
+        const float q = Gv * dL_dalpha;       // = o G dL_dalpha
+        const float s_op = q;
+        const f2 q1 = d * q;                  // (q dx, q dy)
+        const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
+        const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
+        // every lane ends with one of the ten totals and stores it: lanes that share a slot hold the same value
+        uint32_t lds_addr;
+        const float tot = wave_sum10_transposed<PART_STRIDE * 4>(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd, proc, jj, part_lane, jj, lds_addr);
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + lds_addr) = tot;
+    };
     for (int sw = 0; sw < 2; sw++) {
         unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
-        unsigned long long proc = 0;
-        while (mk) {
-            const int jj = pop_lowest_bit(mk);
-            const int j = sw * 64 + jj;
-            const float4 A4 = s_a[j];
-            const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
-            const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
-            const f2 d = f2{A4.x, A4.y} - pxy;
-            // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
-            // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
-            const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
-            const float G = __builtin_amdgcn_exp2f(pw);
-            const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
-            const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
-            if (!__any(valid)) continue;          // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-            const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
-            const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
-            const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
-            T *= inv1ma;                                                                           // :700
-            const float wv = av * T;                                                               // :701 dchannel_dcolor
-            const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
-            const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
-            const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
-            Sb += wv * cg;
-            // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
-            //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
-            //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
-            const float q = Gv * dL_dalpha;       // = o G dL_dalpha
-            const float s_op = q;
-            const f2 q1 = d * q;                  // (q dx, q dy)
-            const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
-            const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
-            // every lane ends with one of the ten totals and stores it: lanes that share a slot hold the same value
-            uint32_t lds_addr;
-            const float tot = wave_sum10_transposed(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd, proc, jj, part_lane, j, lds_addr);
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + lds_addr) = tot;
-        }
+        proc = 0;
+        group_base = sw * 64;
+        while (mk) bwd_pair(pop_lowest_bit(mk));
         if (lane == 0) s_proc[wave][sw] = proc;
-    }
-    __syncthreads();
-    // Add the four quadrants in a fixed order, turn the moments into the reference's gradients and write each instance's
-    // slot (12 floats, 48 B) coalesced.  s_part[q][j][] = {sum G dL_dalpha, M1x, M1y, M2xx, M2xy, M2yy, r, g, b, depth}
-    if (t < m) {   // one thread per entry: no divergence, three 16-byte stores per slot
-        const int j = t;
-        const float4 B4 = s_b[j];                       // {C, log2 opacity, instance id, opacity}
-        float sum[10];
+        __syncthreads();
+        // Group epilogue: add the four quadrants in a fixed order, turn the moments into the reference's gradients and write the
+        // group's instance slots (12 floats, 48 B each). Wave w produces the w-th 16-byte piece of the 64 slots (one ds_read_b128
+        // per quadrant, one 16-byte store); wave 3 has nothing to do.
+        const int j = sw * GRP + lane;
+        if (wave < 3 && j < m) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 10; k++) sum[k] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if ((s_proc[q][j >> 6] >> (j & 63)) & 1ull) {
-#pragma unroll
-                for (int k = 0; k < 10; k++) sum[k] += s_part[q][j][k];
+            for (int q = 0; q < 4; q++) {
+                if ((s_proc[q][sw] >> lane) & 1ull) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_part[q][lane][4 * wave]);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
             }
+            const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z, opacity}
+            float4 o4;
+            if (wave == 0)          // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
+                o4 = make_float4(-(K4.x * sum.x + K4.y * sum.y) * (0.5f * W), -(K4.z * sum.y + K4.y * sum.x) * (0.5f * H), -0.5f * sum.z, -0.5f * sum.w);
+            else if (wave == 1)     // {M2yy, sum q, r, g} -> dL_dconic.w (:756), dL_dopacity = sum q / o = sum G dL_dalpha (:757; o = 0 blends nowhere), colour r, g (:719)
+                o4 = make_float4(-0.5f * sum.x, K4.w > 0.f ? sum.y / K4.w : 0.f, sum.z, sum.w);
+            else                    // {b, depth} (:719,:729)
+                o4 = make_float4(sum.x, sum.y, 0.f, 0.f);
+            reinterpret_cast<float4*>(partials)[(size_t)s_inst[j] * 3 + wave] = o4;
         }
-        const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z}
-        float4* slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(B4.z) * 3;
-        slot[0] = make_float4(-(K4.x * sum[1] + K4.y * sum[2]) * (0.5f * W),     // dL_dmean2D.x, :749,:752 with ddelx_dx (:643)
-                              -(K4.z * sum[2] + K4.y * sum[1]) * (0.5f * H),     // dL_dmean2D.y, :750,:753
-                              -0.5f * sum[3], -0.5f * sum[4]);                    // dL_dconic.x, .y, :754-755
-        const float dL_dopacity = B4.w > 0.f ? sum[0] / B4.w : 0.f;               // sum q / o = sum G dL_dalpha (:757); o = 0 blends nowhere
-        slot[1] = make_float4(-0.5f * sum[5], dL_dopacity, sum[6], sum[7]);       // dL_dconic.w (:756), dL_dopacity, colour r, g (:719)
-        slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                          // colour b, depth (:729)
+        if (sw == 0) __syncthreads();   // s_part is reused by the second group
     }
 }
 

@@ -1,0 +1,97 @@
+/*
+ * slam_map.h -- C ABI of the per-Gaussian / per-camera work of the SLAM loop around the rasterizer (libgs_rasterizer_hip.so),
+ * seeding Gaussians from an RGB-D keyframe, densify / clone / split / prune with optimizer-state surgery,
+ * and the camera-pose update of the tracking / mapping loops. Host control flow (keyframe selection, windows, queues) stays in
+ * Python (4dgs-slam_amd/slam/), as in the reference. All pointers are DEVICE pointers unless stated; fp32 / int32; contiguous.
+ * Functions return 0 or a negative GSR_ERR_* code (gs_rasterizer.h); gsr_last_error() has the text.
+ */
+#ifndef SLAM_MAP_H_INCLUDED
+#define SLAM_MAP_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- seeding: GaussianModel.create_pcd_from_image_and_depth, gaussian_splatting/scene/gaussian_model.py:185-255 -----------------
+ * (Open3D's create_from_rgbd_image + the attribute initialisation), for n already selected pixels pix[i] = v * width + u whose
+ * depth is valid (the random down-sampling of :215 stays with the caller):
+ *   z = depth[pix];  p_cam = ((u - cx) z / fx, (v - cy) z / fy, z);  xyz = R^T (p_cam - T)           (extrinsic = W2C = [R | T])
+ *   rgb = floor(clamp(exp(a) * image + b, 0, 1) * 255) / 255          (:186-188: the byte image Open3D turns back into floats)
+ *   features_dc = (rgb - 0.5) / 0.28209479177387814                   (RGB2SH, gaussian_splatting/utils/sh_utils.py:121-122)
+ *   log_scales  = log(sqrt(max(distCUDA2(xyz), 1e-7) * point_size))   (:235-242; scale_dim 1 = isotropic model, 3 = repeated)
+ *   rotations = (1, 0, 0, 0);  logit_opacity = inverse_sigmoid(0.5) = 0                                            (:244-253)
+ * R [3,3] row-major and T [3] are the camera's device tensors; exposure_a / exposure_b (1 float each) may be NULL (a = b = 0).
+ * The 3-nearest-neighbour distances come from the same spatial-hash kernels as gsr_knn_mean_dist2 (simple_knn.h). */
+size_t gsr_seed_workspace_size(int n);
+int gsr_seed_from_rgbd(int n, const int* pix, int width, int height, const float* depth, const float* image, const float* exposure_a,
+                       const float* exposure_b, float fx, float fy, float cx, float cy, const float* R, const float* T, float point_size,
+                       int scale_dim, float* xyz, float* features_dc, float* log_scales, float* rotations, float* logit_opacity,
+                       char* workspace, void* stream);
+
+/* ---- densification: GaussianModel.densify_and_prune, gaussian_model.py:866-971 -------------------------------------------------
+ * Step 1, gsr_densify_select: the per-Gaussian decisions of densify_and_clone (:920-951), densify_and_split (:866-918) and the
+ * prune mask (:953-971), evaluated for the P Gaussians the call starts with:
+ *   g = xyz_gradient_accum / denom (NaN -> 0);  s = max_k exp(log_scales[k]);  o = sigmoid(logit_opacity)
+ *   clone  = g >= grad_threshold && s <= dense_scale            split = g >= grad_threshold && s > dense_scale
+ *   pruned(original / clone) = o < min_opacity || (big_scale > 0 && s > big_scale)
+ *   pruned(children)         = o < min_opacity || (big_scale > 0 && s / 1.6 > big_scale)      (children: scale / (0.8 * 2), :885-887)
+ * dense_scale = percent_dense * extent, big_scale = 0.1 * extent when the caller passes a max_screen_size, else <= 0 (:961-969; the
+ * screen-size test itself never fires in the reference because densification_postfix zeroes max_radii2D first, :857).
+ * flags int32[4][P] (0 / 1): [0] original survives (not split, not pruned), [1] a clone survives, [2] selected for splitting
+ * (consumes two rows of the caller's normal samples), [3] its two children survive.
+ * Step 2 (caller): exclusive prefix sums of the four flag rows -> offsets int32[4][P], totals n_keep, n_clone, n_split, n_child.
+ * Step 3, gsr_densify_apply: writes every output tensor in ONE launch. Output rows, in the reference's order:
+ *   [0, n_keep) surviving originals | [n_keep, +n_clone) clones | then the first samples of the surviving split parents
+ *   [.., +n_child) | then their second samples [.., +n_child).
+ * Each gsr_densify_tensor describes one [P, width] fp32 (or any 4-byte) tensor and its [n_out, width] destination:
+ *   GSR_DENSIFY_COPY   rows are copied (parameters, per-Gaussian bookkeeping)
+ *   GSR_DENSIFY_STATE  optimizer moments: copied for surviving originals, ZERO for clones and children (cat_tensors_to_optimizer, :812-830)
+ *   GSR_DENSIFY_XYZ    like COPY, children get  xyz + Rq(normalize(raw_rot)) (noise * exp(log_scales))           (:877-883)
+ *   GSR_DENSIFY_SCALE  like COPY, children get  log(exp(log_scale) / 1.6)                                          (:885-887)
+ * noise float[2 * n_split, 3]: standard normal samples in the reference's order (row off_split[i] for the first child of parent i,
+ * n_split + off_split[i] for the second) -- torch.normal(mean=0, std=stds) draws exactly those (:875-876). */
+enum { GSR_DENSIFY_COPY = 0, GSR_DENSIFY_STATE = 1, GSR_DENSIFY_XYZ = 2, GSR_DENSIFY_SCALE = 3 };
+typedef struct gsr_densify_tensor { const float* src; float* dst; int width; int kind; } gsr_densify_tensor;
+#define GSR_DENSIFY_MAX_TENSORS 32
+int gsr_densify_select(int P, const float* xyz_gradient_accum, const float* denom, const float* log_scales, int scale_dim,
+                       const float* logit_opacity, float grad_threshold, float dense_scale, float min_opacity, float big_scale,
+                       int* flags, void* stream);
+int gsr_densify_apply(int P, const int* flags, const int* offsets, int n_keep, int n_clone, int n_split, int n_child, int ntensors,
+                      const gsr_densify_tensor* tensors /* host array */, const float* xyz, const float* log_scales, int scale_dim,
+                      const float* raw_rotations, const float* noise, void* stream);
+
+/* ---- pruning by a mask: GaussianModel.prune_points, gaussian_model.py:786-810 -- the same apply step with flags[0] = !mask and no
+ * clones / children; kept for symmetry: gsr_densify_apply(P, flags, offsets, n_keep, 0, 0, 0, ...). */
+
+/* ---- camera step of the tracking / mapping loops -------------------------------------------------------------------------------
+ * One launch, no host synchronisation, capturable in a hipGraph (every operand lives in device memory, including the Adam step):
+ *  (1) Adam (torch.optim.Adam single-tensor arithmetic, no weight decay) on up to 4 small tensors of the camera -- cam_rot_delta[3],
+ *      cam_trans_delta[3], exposure_a[1], exposure_b[1] (utils/slam_frontend.py:346-376, utils/slam_backend.py:948-992) -- whose
+ *      gradients the rasterizer / loss kernels left in device memory; `step` (1 float, device) is incremented;
+ *  (2) update_pose (utils/pose_utils.py:80-97): tau = [trans_delta | rot_delta], [R | T] <- SE3_exp(tau) [R | T], deltas <- 0,
+ *      converged[0] = |tau| < threshold;
+ *  (3) the matrices the rasterizer reads (utils/camera_utils.py:124-148): viewmatrix = W2C^T, full_proj = viewmatrix @ projmatrix
+ *      (projmatrix = P^T as the callers keep it), campos = -R^T T.
+ * A NULL gradient pointer skips that tensor's Adam update; do_pose = 0 skips (2) (then (3) just refreshes the matrices). */
+typedef struct gsr_camera_step {
+    float* rot_delta; const float* g_rot_delta; float* trans_delta; const float* g_trans_delta;
+    float* exposure_a; const float* g_exposure_a; float* exposure_b; const float* g_exposure_b;
+    float* exp_avg;       /* [8] first moments: rot 3, trans 3, a, b */
+    float* exp_avg_sq;    /* [8] */
+    float* step;          /* [1] */
+    float lr_rot, lr_trans, lr_exposure, beta1, beta2, eps;
+    float* R; float* T;   /* [3,3] row-major, [3] */
+    const float* projmatrix;   /* [4,4] = P^T */
+    float* viewmatrix; float* full_proj; float* campos;   /* outputs [4,4], [4,4], [3] */
+    int* converged;       /* [1] */
+    float converged_threshold;
+    int do_pose;
+} gsr_camera_step;
+int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
