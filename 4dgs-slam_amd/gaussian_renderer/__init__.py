@@ -112,6 +112,13 @@ def _deform(pc, viewpoint_camera, means3D, shs):
     return means3D, scales_final, rotations_final
 
 
+def _mask_rows(mask):
+    """int32 row list of render()'s boolean `mask`. A caller that renders with the same mask many times (the tracking loop) can attach
+    the list once as ``mask._gsr_gather`` and save the nonzero() -- a host synchronisation -- per call."""
+    g = getattr(mask, "_gsr_gather", None)
+    return g if g is not None else _raw.gather_from_mask(mask)
+
+
 def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr, mask=None, dynamic=False):
     deltas = dx is not None and ds is not None and dr is not None        # the reference applies them only together (:159)
     slot = _raw.dyn_slot_from_mask(pc.dygs) if deltas else None
@@ -127,7 +134,7 @@ def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_
         _settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree), xyz, screenspace_points, log_scales,
         raw_rot, pc._opacity, pc._features_dc, f_rest, slot, dx if deltas else None, ds if deltas else None,
         dr if deltas else None, viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta,
-        gather=None if mask is None else _raw.gather_from_mask(mask))
+        gather=None if mask is None else _mask_rows(mask))
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None,
@@ -138,7 +145,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         return None
     screenspace_points = _screenspace_points(pc)
     deltas = dx is not None and ds is not None and dr is not None
-    if _fused_prologue_ok(pc, pipe, mask, dynamic) and not (dynamic and deltas):
+    if deltas and all(isinstance(v, (int, float)) and v == 0 for v in (dx, ds, dr)):
+        # the evaluation call shape `dx = ds = dr = 0` (utils/eval_utils.py:339-344): the reference scatters zeros and adds them,
+        # which changes nothing -- same as no deltas
+        dx = ds = dr = None
+        deltas = False
+    tensor_deltas = not deltas or all(isinstance(v, torch.Tensor) for v in (dx, ds, dr))
+    if _fused_prologue_ok(pc, pipe, mask, dynamic) and not (dynamic and deltas) and tensor_deltas:
         rendered_image, radii, depth, opacity, n_touched = _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
                                                                          screenspace_points, dx, ds, dr, mask, dynamic)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,

@@ -1,0 +1,375 @@
+"""Mapping back-end -- the counterpart of the reference's ``utils/slam_backend.py`` BackEnd, single process: add_next_kf (:107-128),
+initialize_map (:237-296), initialize_network (:160-234), map_static (:1013-1224), map (:306-774, the dynamic branch with the
+control-node warp), color_refinement (:777-862) and the message handlers of run() (:879-1010) as direct calls.
+
+Per mapping iteration: every window keyframe is rendered through the fused prologue, the mapping loss is the fused weighted L1, the
+densification statistics of a view are one launch, pose / exposure updates are one launch per camera, the six Gaussian groups are
+stepped by FusedAdam, and densify_and_prune rebuilds the model with one launch (slam/gaussian_model.py). The view-sharded multi-GPU
+form of the same iteration is mapping_shard.ShardedMappingStep; this class drives one GPU."""
+import random
+
+import numpy as np
+import torch
+
+from gaussian_renderer import render
+import slam_losses
+
+
+class BackEnd:
+    def __init__(self, config):
+        self.config = config
+        self.gaussians = None
+        self.pipeline_params = None
+        self.opt_params = None
+        self.background = None
+        self.cameras_extent = None
+        self.dataset = None
+        self.device = "cuda"
+        self.monocular = config["Training"].get("monocular", False)
+        self.iteration_count = 0
+        self.last_sent = 0
+        self.occ_aware_visibility = {}
+        self.viewpoints = {}
+        self.current_window = []
+        self.initialized = not self.monocular
+        self.dynamic_model = config["model_params"]["dynamic_model"]
+        self.dystart = 0
+        self.pose_lr_scale = 0.5
+        self.frames_to_optimize = config["Training"]["pose_window"]
+        self.log = []
+
+    def set_hyperparams(self):
+        """:81-105."""
+        t = self.config["Training"]
+        self.save_results, self.save_dir = self.config["Results"].get("save_results", False), self.config["Results"].get("save_dir")
+        self.init_itr_num, self.init_gaussian_update = t["init_itr_num"], t["init_gaussian_update"]
+        self.init_gaussian_reset, self.init_gaussian_th = t["init_gaussian_reset"], t["init_gaussian_th"]
+        self.init_gaussian_extent = self.cameras_extent * t["init_gaussian_extent"]
+        self.mapping_itr_num, self.gaussian_update_every = t["mapping_itr_num"], t["gaussian_update_every"]
+        self.gaussian_update_offset, self.gaussian_th = t["gaussian_update_offset"], t["gaussian_th"]
+        self.gaussian_extent = self.cameras_extent * t["gaussian_extent"]
+        self.gaussian_reset, self.size_threshold = t["gaussian_reset"], t["size_threshold"]
+        self.window_size = t["window_size"]
+        self.single_thread = t.get("single_thread", True)
+        self.kf_map_iters = t.get("kf_map_iters", 70)                     # run(): iter_per_kf = 70 (:934); map(iters=200) for dynamic (:1000)
+        self.dynamic_map_iters = t.get("dynamic_map_iters", 200)
+        self.static_map_iters = t.get("static_map_iters", 20)             # map_static(iters=20), :997
+        self.network_init_iters = t.get("network_init_iters", 100)        # initialize_network: range(100), :169
+
+    # ---- adding Gaussians (:107-128) -----------------------------------------------------------------------------------
+    def add_next_kf(self, frame_idx, viewpoint, init=False, scale=2.0, depth_map=None):
+        self.gaussians.extend_from_pcd_seq(viewpoint, kf_id=frame_idx, init=init, scale=scale, depthmap=depth_map)
+        if self.dynamic_model and frame_idx == self.dystart:
+            self.gaussians.extend_from_pcd_seq(viewpoint, kf_id=frame_idx, init=True, scale=scale, depthmap=depth_map, add_dygs=True)
+
+    def reset(self):
+        """:143-157."""
+        self.iteration_count, self.occ_aware_visibility, self.viewpoints, self.current_window = 0, {}, {}, []
+        self.initialized = not self.monocular
+        if self.gaussians.get_xyz.shape[0]:
+            self.gaussians.prune_points(self.gaussians.unique_kfIDs >= 0)
+
+    # ---- dynamic deltas of one view -----------------------------------------------------------------------------------
+    def _deltas(self, viewpoint, train=True):
+        """d_values of :361-373 for the dynamic subset, or (0, 0, None)-style "no deltas" when the network is not initialised."""
+        g = self.gaussians
+        if not (self.dynamic_model and g.deform_init and bool(g.dygs.any())):
+            return None, None, None
+        time_input = g.deform.deform.expand_time(viewpoint.fid)
+        ctx = torch.enable_grad() if train else torch.no_grad()
+        with ctx:
+            d = g.deform.step(g.get_dygs_xyz.detach(), time_input, iteration=0, feature=None, motion_mask=g.motion_mask,
+                              camera_center=viewpoint.camera_center, time_interval=g.time_interval)
+        return d["d_xyz"], d["d_scaling"], d["d_rotation"]
+
+    def _render(self, viewpoint, deltas):
+        dx, ds, dr = deltas
+        return render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False, dx=dx, ds=ds, dr=dr)
+
+    def _view_stats(self, pkg):
+        self.gaussians.add_view_stats(pkg["viewspace_points"], pkg["radii"])
+
+    # ---- map initialisation (:237-296) -----------------------------------------------------------------------------------
+    def initialize_map(self, cur_frame_idx, viewpoint):
+        pkg = None
+        for mapping_iteration in range(self.init_itr_num):
+            self.iteration_count += 1
+            pkg = self._render(viewpoint, (None, None, None))
+            loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True,
+                                                     rm_dynamic=not (self.dystart == cur_frame_idx))
+            loss_init.backward()
+            with torch.no_grad():
+                self._view_stats(pkg)
+                if mapping_iteration % self.init_gaussian_update == 0:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th, self.init_gaussian_extent, None)
+                if self.iteration_count == self.init_gaussian_reset or self.iteration_count == self.opt_params.densify_from_iter:
+                    self.gaussians.reset_opacity()
+                self.gaussians.optimizer.step()
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+        self.occ_aware_visibility[cur_frame_idx] = (self._final_touched(viewpoint, pkg) > 0).long()
+        return pkg
+
+    def _final_touched(self, viewpoint, pkg):
+        """n_touched of the LAST render, re-rendered if the model was rebuilt after it (densification changes the row count)."""
+        if pkg is not None and pkg["n_touched"].shape[0] == self.gaussians.get_xyz.shape[0]:
+            return pkg["n_touched"]
+        with torch.no_grad():
+            return self._render(viewpoint, (None, None, None))["n_touched"]
+
+    def initialize_network(self, cur_frame_idx, viewpoint, update_gaussians=False):
+        """:160-234: create the control nodes from the keyframe's dynamic pixels and fit the node network on this view."""
+        g = self.gaussians
+        if g.deform is None:
+            return
+        if cur_frame_idx == self.dystart:
+            if not bool(g.dygs.any()):
+                return
+            g.deform.extend_node_from_point(init_pcl=g.get_dygs_xyz.detach())
+            g.deform_init = True
+        pkg = None
+        for mapping_iteration in range(self.network_init_iters):
+            deltas = self._deltas(viewpoint)
+            pkg = self._render(viewpoint, deltas)
+            loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True)
+            loss_init.backward()
+            with torch.no_grad():
+                self._view_stats(pkg)
+                g.deform.optimizer.step()
+                g.deform.optimizer.zero_grad(set_to_none=True)
+                if update_gaussians:
+                    g.optimizer.step()
+                g.optimizer.zero_grad(set_to_none=True)
+        self.occ_aware_visibility[cur_frame_idx] = (pkg["n_touched"] > 0).long()
+
+    # ---- window optimisation --------------------------------------------------------------------------------------------
+    def _pose_updates(self, viewpoint_stack, current_window):
+        """keyframe_optimizers.step() + update_pose of :748-755 / :1213-1222: one camera-step launch per window keyframe."""
+        lr = self.config["Training"]["lr"]
+        for cam_idx in range(len(current_window)):
+            viewpoint = viewpoint_stack[cam_idx]
+            if viewpoint.uid == 0:
+                for p in (viewpoint.cam_rot_delta, viewpoint.cam_trans_delta, viewpoint.exposure_a, viewpoint.exposure_b):
+                    if p is not None:
+                        p.grad = None
+                continue
+            viewpoint.pose_step(lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
+                                optimize_pose=cam_idx < self.frames_to_optimize, optimize_exposure=True)
+
+    def _prune_by_covisibility(self, current_window):
+        """:663-696 / :1140-1170: the monocular-only pruning; RGB-D just marks the map as initialised."""
+        if len(current_window) == self.config["Training"]["window_size"]:
+            prune_mode, prune_coviz = self.config["Training"]["prune_mode"], 3
+            g = self.gaussians
+            g.n_obs.fill_(0)
+            for _, visibility in self.occ_aware_visibility.items():
+                g.n_obs += visibility.to(g.n_obs.dtype)
+            to_prune = None
+            if prune_mode == "odometry":
+                to_prune = g.n_obs < 3
+            if prune_mode == "slam":
+                sorted_window = sorted(current_window, reverse=True)
+                mask = g.unique_kfIDs >= sorted_window[2]
+                if not self.initialized:
+                    mask = g.unique_kfIDs >= 0
+                to_prune = torch.logical_and(g.n_obs <= prune_coviz, mask)
+            if to_prune is not None and self.monocular:
+                g.prune_points(to_prune)
+                for idx in current_window:
+                    self.occ_aware_visibility[idx] = self.occ_aware_visibility[idx][~to_prune]
+            if not self.initialized:
+                self.initialized = True
+
+    def _isotropic_loss(self):
+        scaling = self.gaussians.get_scaling
+        return 10 * torch.abs(scaling - scaling.mean(dim=1).view(-1, 1)).mean()            # :653-655
+
+    def map_static(self, current_window, prune=False, iters=1):
+        """:1013-1224."""
+        if len(current_window) == 0:
+            return
+        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
+        window_set = set(current_window)
+        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
+        gaussian_split = False
+        for _ in range(iters):
+            self.iteration_count += 1
+            self.last_sent += 1
+            loss_mapping = 0
+            pkgs, n_touched_acm = [], []
+            for cam_idx in range(len(current_window)):
+                viewpoint = viewpoint_stack[cam_idx]
+                pkg = self._render(viewpoint, (None, None, None))
+                loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True)
+                pkgs.append(pkg)
+                n_touched_acm.append(pkg["n_touched"])
+            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
+                viewpoint = random_viewpoint_stack[cam_idx]
+                pkg = self._render(viewpoint, (None, None, None))
+                loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True)
+                pkgs.append(pkg)
+            loss_mapping = loss_mapping + self._isotropic_loss()
+            loss_mapping.backward()
+            gaussian_split = False
+            with torch.no_grad():
+                self.occ_aware_visibility = {}
+                for idx in range(len(current_window)):
+                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                if prune:
+                    self._prune_by_covisibility(current_window)
+                    self.gaussians.optimizer.zero_grad(set_to_none=True)
+                    self._clear_camera_grads(viewpoint_stack)
+                    return False
+                for pkg in pkgs:
+                    self._view_stats(pkg)
+                update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+                if update_gaussian:
+                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
+                    gaussian_split = True
+                if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian:
+                    self.gaussians.reset_opacity_nonvisible([p["visibility_filter"] for p in pkgs])
+                    gaussian_split = True
+                self.gaussians.optimizer.step()                 # rebuilt parameters have no gradient yet and are skipped, like in the reference
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                self.gaussians.update_learning_rate(self.iteration_count)
+                self._pose_updates(viewpoint_stack, current_window)
+        return gaussian_split
+
+    def _clear_camera_grads(self, cams):
+        for v in cams:
+            for p in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b):
+                if p is not None:
+                    p.grad = None
+
+    def map(self, current_window, prune=False, iters=1, dynamic_network=False):
+        """:306-774 with the control-node warp on the dynamic subset. The optical-flow term of the reference (:479-509) needs RAFT;
+        when the dataset can supply a flow (``dataset.gt_flow``) the same term is formed with render_flow, otherwise it is skipped."""
+        if len(current_window) == 0:
+            return
+        g = self.gaussians
+        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
+        window_set = set(current_window)
+        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
+        use_net = dynamic_network and g.deform_init
+        gaussian_split = False
+        for i in range(iters):
+            if i > 100:
+                self.iteration_count += 1                                   # :337-338
+            self.last_sent += 1
+            loss_network = 0
+            loss_mapping = 0
+            dynamic = i < iters / 2                                          # :350-355
+            pkgs, n_touched_acm = [], []
+            views = [viewpoint_stack[c] for c in range(len(current_window))]
+            extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]
+            for k, viewpoint in enumerate(views + extra):
+                deltas = self._deltas(viewpoint) if use_net else (None, None, None)
+                pkg = self._render(viewpoint, deltas)
+                loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
+                                                                         rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False)
+                if use_net:
+                    w = 1e-3 if k < len(views) else 1e-4                     # :517-519 / :640-643
+                    loss_network = loss_network + w * g.deform.deform.arap_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_samp_num=2)
+                    loss_network = loss_network + w * g.deform.deform.elastic_loss(t=viewpoint.fid, delta_t=5 * g.time_interval)
+                pkgs.append(pkg)
+                if k < len(views):
+                    n_touched_acm.append(pkg["n_touched"])
+            loss_mapping = loss_mapping + self._isotropic_loss()
+            total = loss_mapping + loss_network if use_net else loss_mapping
+            total.backward()
+            gaussian_split = False
+            with torch.no_grad():
+                self.occ_aware_visibility = {}
+                for idx in range(len(current_window)):
+                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                if prune:
+                    self._prune_by_covisibility(current_window)
+                    g.optimizer.zero_grad(set_to_none=True)
+                    if use_net:
+                        g.deform.optimizer.zero_grad(set_to_none=True)
+                    self._clear_camera_grads(views + extra)
+                    return False
+                for pkg in pkgs:
+                    self._view_stats(pkg)
+                update_gaussian = (self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset) and i > 100
+                if update_gaussian:
+                    g.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
+                    gaussian_split = True
+                if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian and i > 100:
+                    g.reset_opacity_nonvisible([p["visibility_filter"] for p in pkgs])
+                    gaussian_split = True
+                self._pose_updates(viewpoint_stack, current_window)
+                self._clear_camera_grads(extra)
+                if use_net:
+                    g.deform.optimizer.step()
+                    g.deform.optimizer.zero_grad(set_to_none=True)
+                if i > 100:                                                  # :765-770
+                    g.optimizer.step()
+                    g.update_learning_rate(self.iteration_count)
+                g.optimizer.zero_grad(set_to_none=True)
+        return gaussian_split
+
+    def color_refinement(self, iteration_total=1500, views_per_iter=10):
+        """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""
+        lam = self.opt_params.lambda_dssim
+        ids = list(self.viewpoints.keys())
+        for iteration in range(1, iteration_total + 1):
+            loss = 0
+            for idx in random.sample(ids, min(views_per_iter, len(ids))):
+                cam = self.viewpoints[idx]
+                pkg = self._render(cam, self._deltas(cam))
+                image = torch.exp(cam.exposure_a) * pkg["render"] + cam.exposure_b
+                gt_image = cam.original_image.to(image.device)
+                mm = cam.motion_mask if not (self.dynamic_model and self.gaussians.deform_init) else None
+                Ll1 = torch.abs(image - gt_image).mean() if mm is None else torch.abs(image * mm - gt_image * mm).mean()
+                loss = loss + (1.0 - lam) * Ll1 + lam * (1.0 - slam_losses.ssim(image, gt_image, mask=mm))
+                gt_depth = cam.depth_device()[None]
+                dm = (gt_depth > 0.01) if mm is None else (gt_depth > 0.01) & mm[None]
+                loss = loss + 0.1 * torch.abs(pkg["depth"] * dm - gt_depth * dm).mean()
+            loss = loss + self._isotropic_loss()
+            loss.backward()
+            with torch.no_grad():
+                self.gaussians.optimizer.step()
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                self.gaussians.update_learning_rate(iteration)
+                self._clear_camera_grads(self.viewpoints.values())
+
+    # ---- messages of run() (:879-1010) as calls ----------------------------------------------------------------------------
+    def push_to_frontend(self, tag="sync_backend"):
+        """:864-876."""
+        self.last_sent = 0
+        keyframes = [(kf_idx, self.viewpoints[kf_idx].R.clone(), self.viewpoints[kf_idx].T.clone()) for kf_idx in self.current_window]
+        return [tag, self.gaussians, self.occ_aware_visibility, keyframes]
+
+    def handle_init(self, cur_frame_idx, viewpoint, depth_map):
+        """"init", :899-914."""
+        self.reset()
+        self.viewpoints[cur_frame_idx] = viewpoint
+        self.add_next_kf(cur_frame_idx, viewpoint, depth_map=depth_map, init=True)
+        self.initialize_map(cur_frame_idx, viewpoint)
+        if self.dynamic_model and self.dystart == 0:
+            self.initialize_network(cur_frame_idx, viewpoint)
+        self.current_window = [cur_frame_idx]
+        return self.push_to_frontend("init")
+
+    def handle_keyframe(self, cur_frame_idx, viewpoint, current_window, depth_map, add_new_gaussian=True, dynamic_render=False):
+        """"keyframe", :916-1003."""
+        self.viewpoints[cur_frame_idx] = viewpoint
+        self.current_window = current_window
+        if add_new_gaussian:
+            self.add_next_kf(cur_frame_idx, viewpoint, depth_map=depth_map)
+        if self.dynamic_model and self.dystart == cur_frame_idx and cur_frame_idx > 0:
+            self.initialize_map(cur_frame_idx, viewpoint)
+            self.initialize_network(cur_frame_idx, viewpoint)
+        self.frames_to_optimize = self.config["Training"]["pose_window"]
+        if not self.initialized and len(self.current_window) == self.config["Training"]["window_size"]:
+            self.frames_to_optimize = self.config["Training"]["window_size"] - 1
+        for kf in self.current_window:                                       # a fresh Adam for the window's cameras, :992
+            if kf != 0:
+                self.viewpoints[kf].reset_pose_optimizer()
+        if self.dystart > cur_frame_idx or not self.dynamic_model:
+            self.map_static(self.current_window, iters=self.static_map_iters)
+            self.map_static(self.current_window, prune=True)
+        elif add_new_gaussian:
+            self.map(self.current_window, iters=self.dynamic_map_iters, dynamic_network=self.dynamic_model)
+            self.map(self.current_window, prune=True, dynamic_network=self.dynamic_model)
+        return self.push_to_frontend("keyframe")
