@@ -30,6 +30,7 @@ struct GeomBwdArgs {
 
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 {
+    if (a.header[HDR_FLAGS] & FLAG_OVERFLOW) return;   // lazy forward pass that outgrew its buffer: there are no instance slots to sum
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool in_range = idx < a.P;
     const size_t i = (size_t)(in_range ? idx : 0);

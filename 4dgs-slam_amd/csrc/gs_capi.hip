@@ -162,7 +162,23 @@ static thread_local size_t t_last_R_alloc = 0;
 static thread_local uint32_t t_last_max_tile = 0;
 static thread_local bool t_use_mailbox = true;
 static thread_local bool t_speculate = true;
+// Lazy mode (gsr_set_option("lazy", 1)): a speculative forward pass returns WITHOUT waiting for the scan kernel's header -- no host
+// synchronisation at all, which is also what makes the call capturable in a hipGraph. The value returned in place of num_rendered is
+// then the capacity the binning buffer was laid out for (an upper bound of R; gsr_backward only sizes its grid from it, the kernels
+// read the true counts from the device header). If a frame outgrows the capacity, the speculative kernels and both backward kernels
+// of that frame exit at once (outputs / gradients of THAT call are undefined) and the sticky overflow counter in the mailbox is
+// bumped: a caller that uses lazy mode polls gsr_forward_status() at a convenient point and repeats the affected work eagerly.
+static thread_local bool t_lazy = false;
+static thread_local bool t_options_read = false;
 static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] != '0' : true;   // sort short tile lists inside render_fwd
+static void read_option_env()
+{
+    if (t_options_read) return;
+    t_options_read = true;
+    if (const char* e = getenv("GSR_MAILBOX")) t_use_mailbox = e[0] != '0';
+    if (const char* e = getenv("GSR_SPECULATE")) t_speculate = e[0] != '0';
+    if (const char* e = getenv("GSR_LAZY")) t_lazy = e[0] != '0';
+}
 
 static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
 {
@@ -205,6 +221,25 @@ size_t gsr_image_buffer_size(int width, int height, int P)
     return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T, (size_t)P); });
 }
 size_t gsr_binning_buffer_size(int R_alloc) { return binning_bytes((size_t)R_alloc, (size_t)R_alloc); }
+
+int gsr_set_option(const char* name, int value)
+{
+    read_option_env();
+    if (!name) { g_last_error = "gsr_set_option: null name"; return GSR_ERR_INVALID_ARGUMENT; }
+    const std::string n(name);
+    bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox)"; return GSR_ERR_INVALID_ARGUMENT; }
+    const int old = *opt ? 1 : 0;
+    if (value >= 0) *opt = value != 0;
+    return old;
+}
+
+int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered)
+{
+    if (overflow_count) *overflow_count = t_mailbox ? __atomic_load_n(&t_mailbox[5], __ATOMIC_ACQUIRE) : 0u;
+    if (last_num_rendered) *last_num_rendered = t_mailbox ? __atomic_load_n(&t_mailbox[0], __ATOMIC_ACQUIRE) : 0u;
+    return 0;
+}
 
 int gsr_profile_enable(int kernel_mask) { g_prof.mask = (unsigned)kernel_mask; return K_COUNT; }
 void gsr_profile_reset(void)
@@ -331,14 +366,27 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     // frame's real needs with the speculative capacity and raises FLAG_OVERFLOW if they do not fit: the speculative kernels
     // then exit at once and the host redoes them on an exact-size buffer (also the path of the first call and of debug mode).
     const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
+    read_option_env();
+    if (t_lazy && t_mailbox) {
+        // lazy mode never waits, so the capacity estimate is refreshed from whatever header the GPU published last (a few calls old)
+        const uint32_t s0 = __atomic_load_n(&t_mailbox[4], __ATOMIC_ACQUIRE);
+        if (s0 != 0) {
+            const uint32_t r = __atomic_load_n(&t_mailbox[0], __ATOMIC_RELAXED), ra = __atomic_load_n(&t_mailbox[2], __ATOMIC_RELAXED);
+            const uint32_t mx = __atomic_load_n(&t_mailbox[3], __ATOMIC_RELAXED);
+            if (__atomic_load_n(&t_mailbox[4], __ATOMIC_ACQUIRE) == s0 && r <= 0x7fffffffu && ra <= 0x7fffffffu) {
+                const size_t need = ra > r ? ra : r;
+                // grow at once, shrink slowly: a view that briefly needs less must not take the slack away from the next one
+                t_last_R_alloc = need > t_last_R_alloc ? need : t_last_R_alloc - (t_last_R_alloc - need) / 16;
+                t_last_max_tile = mx > t_last_max_tile ? mx : t_last_max_tile;
+            }
+        }
+    }
     const bool speculate = t_speculate && t_last_R_alloc && t_last_max_tile <= (uint32_t)SORT_LDS_CAP && !debug && P > 0;
     const size_t cap = speculate ? t_last_R_alloc + t_last_R_alloc / 8 + 4096 : 0;
     const uint32_t cap_tile = t_last_max_tile * 5 / 4 > (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_LDS_CAP : (uint32_t)SORT_SMALL_CAP;
     {
         ScopedKernelTimer tm(K_SCAN, stream);
         if (!t_mailbox) {
-            if (const char* e = getenv("GSR_MAILBOX")) t_use_mailbox = e[0] != '0';
-            if (const char* e = getenv("GSR_SPECULATE")) t_speculate = e[0] != '0';
             GSR_HIP_CHECK(hipHostMalloc((void**)&t_mailbox, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
             memset(t_mailbox, 0, 8 * sizeof(uint32_t));
             GSR_HIP_CHECK(hipHostGetDevicePointer((void**)&t_mailbox_dev, t_mailbox, 0));
@@ -394,6 +442,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         const int rc = enqueue_binning_and_render(bchunk, cap, cap, true, false, cap_tile > (uint32_t)SORT_SMALL_CAP);
         if (rc) return rc;
     }
+    if (speculate && t_lazy) return (int)(cap > 0x7fffffffull ? 0x7fffffffull : cap);   // no wait: see t_lazy
     // The one host wait of the forward pass (the reference's is the blocking cudaMemcpy at rasterizer_impl.cu:283-284).
     uint32_t hdr[4];
     { const int rc = wait_for_header(stream, geom.header, t_seq, hdr); if (rc) return rc; }

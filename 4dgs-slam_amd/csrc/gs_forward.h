@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
             __hip_atomic_store(&host_mailbox[1], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mailbox[2], R_alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mailbox[3], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (err & (uint32_t)FLAG_OVERFLOW)   // sticky count of frames that outgrew their speculative buffer (lazy mode polls it)
+                __hip_atomic_fetch_add(&host_mailbox[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(&host_mailbox[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     // The XCD banding is computed over the REAL number of chunks: banding over the grid (an upper bound) put every surplus id
     // into the last XCD's band, which then ran out of work while the other seven still had a quarter of theirs.
     const uint32_t nchunks = header[HDR_CHUNKS];
-    if (blockIdx.x >= nchunks) return;
+    if (blockIdx.x >= nchunks || (header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // overflow: a lazy forward pass whose lists were never built
     const uint32_t cid = (uint32_t)xcd_tile_of_block(blockIdx.x, (int)nchunks);   // neighbouring chunks (same or adjacent tiles) share an XCD's L2
     int tile;
     {   // largest t with chunk_base[t] <= cid (uniform binary search, scalar loads)

@@ -84,8 +84,29 @@ def load_library():
     lib.gsr_profile_read.restype = i
     lib.gsr_profile_read.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int), i]
     lib.gsr_profile_reset.restype = None
+    lib.gsr_set_option.restype = i
+    lib.gsr_set_option.argtypes = [C.c_char_p, i]
+    lib.gsr_forward_status.restype = i
+    lib.gsr_forward_status.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int = -1) -> int:
+    """gsr_set_option (include/gs_rasterizer.h): "speculate" | "lazy" | "mailbox"; returns the previous value (value < 0: query)."""
+    lib = load_library()
+    rc = lib.gsr_set_option(name.encode(), int(value))
+    if rc < 0:
+        _err(lib, rc, "gsr_set_option")
+    return rc
+
+
+def forward_status():
+    """(overflow_count, last_num_rendered) of this thread's forward passes; never blocks (gsr_forward_status)."""
+    lib = load_library()
+    a, b = C.c_uint(0), C.c_uint(0)
+    lib.gsr_forward_status(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def _err(lib, code, what):

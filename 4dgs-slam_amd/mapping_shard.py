@@ -9,6 +9,13 @@ the rank that owns the view (utils/slam_backend.py:955-992).
 
 Backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the CPU tests. One flat bucket, one collective per step:
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a single large all-reduce beats many small ones.
+
+Why there is ONE exposed all-reduce and nothing overlapped with it: the sum over views is linear, every parameter's gradient is
+complete only when the LAST view's geometry kernel has run (the fused K8+K9 kernel writes all five tensors at once), and the optimizer
+needs the reduced sum before the next forward pass. Splitting the exchange (reduce the first n-1 views early, the last one at the
+end) moves no bytes off the critical path: a full-size exchange still follows the last backward. SURVEY.md 8e's "start the
+all-reduce of SH / opacity while K8/K9 run" would overlap with ~0.3 ms of a ~1.3 ms exchange at config #5 (2 M Gaussians); it is not
+built. `GradBucket.attach()` removes the other cost -- pack / unpack copies -- for every parameter layout, channels-last included.
 """
 from __future__ import annotations
 
@@ -41,6 +48,32 @@ class GradBucket:
     @property
     def nbytes(self) -> int:
         return self.flat.numel() * 4
+
+    # ---- persistent gradient storage: the parameters' .grad tensors ARE views of the flat buffer ---------------------------------
+    def attach(self):
+        """Make every parameter's ``.grad`` a view of the flat buffer with the PARAMETER's own strides (so channels-last HexPlane planes,
+        whose dense gradient is not one contiguous row-major range, qualify too). autograd accumulates into an existing ``.grad`` in
+        place, so after any number of backward passes the flat buffer holds all gradients back to back and ``all_reduce()`` needs no
+        pack / unpack copy. Call ``zero_grads()`` instead of ``optimizer.zero_grad(set_to_none=True)`` between iterations."""
+        self.views = []
+        o = 0
+        for p, n in zip(self.params, self.sizes):
+            dense = p.numel() == 0 or _is_dense(p)
+            if not dense:
+                raise ValueError("GradBucket.attach: parameter with overlapping / gapped memory")
+            v = torch.as_strided(self.flat, p.shape, p.stride(), o) if p.numel() else self.flat[o:o].view(p.shape)
+            self.views.append(v)
+            p.grad = v
+            o += n
+        self.attached = True
+        return self
+
+    def zero_grads(self):
+        self.flat.zero_()
+        if getattr(self, "attached", False):
+            for p, v in zip(self.params, self.views):
+                if p.grad is not v:            # something (an optimizer's zero_grad(set_to_none=True)) dropped the view: put it back
+                    p.grad = v
 
     def pack(self):
         for p, v in zip(self.params, self.views):
@@ -81,6 +114,9 @@ class GradBucket:
         (no pack / unpack copies), through the persistent flat buffer otherwise."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return "single"
+        if getattr(self, "attached", False) and all(p.grad is v for p, v in zip(self.params, self.views)):
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            return "attached"
         flat = self.grads_as_one_range()
         if flat is not None:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -96,3 +132,59 @@ def allreduce_gaussian_grads(params: Iterable[torch.Tensor], group=None, bucket:
     bucket = bucket or GradBucket(params)
     bucket.all_reduce_grads(group)
     return bucket
+
+
+def _is_dense(t: torch.Tensor) -> bool:
+    """True if t's elements occupy exactly numel() consecutive storage slots in some dimension order (contiguous, channels-last, ...)."""
+    dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1), key=lambda x: x[0])
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def allreduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor, group=None):
+    """The cross-rank reduction of the densification statistics: every rank accumulated them over ITS views
+    (gaussian_model.py:973-977, utils/slam_backend.py:714-721), so before densify_and_prune
+        xyz_gradient_accum, denom -> sum over ranks (one collective over both, packed),   max_radii2D -> max over ranks.
+    In place; call it only on the iterations that densify (every ``gaussian_update_every``), not every step."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    P = xyz_gradient_accum.numel()
+    packed = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    xyz_gradient_accum.copy_(packed[:P].view_as(xyz_gradient_accum))
+    denom.copy_(packed[P:].view_as(denom))
+    dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
+class ShardedMappingStep:
+    """One mapping iteration over a set of keyframes, view-sharded (BASELINE config #5):
+
+        step():  zero the gradient bucket
+                 for k in this rank's keyframes:  view_fn(k)      # render + loss + backward; gradients accumulate in the bucket
+                 ONE all-reduce(sum) of the bucket                # 14 floats per Gaussian at SH degree 0: 112 MB at 2 M Gaussians
+                 optimizer.step()                                 # every rank applies the same update to its replica
+
+    ``params`` in the optimizer's order; ``view_fn(k)`` must leave pose / exposure gradients alone (they belong to the owner)."""
+
+    def __init__(self, params, keyframe_ids, view_fn, optimizer=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.keyframes = shard_keyframes(list(keyframe_ids), self.rank, self.world)
+        self.view_fn = view_fn
+        self.optimizer = optimizer
+        self.bucket = GradBucket(params).attach()
+        self.mode = None
+
+    def step(self):
+        self.bucket.zero_grads()
+        for k in self.keyframes:
+            self.view_fn(k)
+        self.mode = self.bucket.all_reduce_grads(self.group)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return self.mode

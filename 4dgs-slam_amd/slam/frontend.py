@@ -64,6 +64,9 @@ class FrontEnd:
         self.dystart = 0
         self.median_depth = 1.0
         self.converge_check_every = int(config["Training"].get("converge_check_every", 5))
+        self.use_tracking_graph = bool(config["Training"].get("tracking_graph", False))     # slam/tracking_graph.py
+        self._tgraph = None
+        self.graph_stats = {"captures": 0, "replayed_frames": 0, "eager_frames": 0, "overflow_redos": 0}
         self.log = []
 
     def set_hyperparams(self):
@@ -98,9 +101,32 @@ class FrontEnd:
         self.reset = False
 
     # ---- tracking (:335-470) -------------------------------------------------------------------------------------------
+    def _track_with_graph(self, viewpoint):
+        """The tracking loop as hipGraph replays (slam/tracking_graph.py). Returns False if the frame has to be redone eagerly."""
+        from .tracking_graph import TrackingGraph
+        if self._tgraph is None or self._tgraph.version != TrackingGraph.model_version(self.gaussians):
+            self._tgraph = TrackingGraph(self.gaussians, self.pipeline_params, self.background, self.config, viewpoint)
+            self._tgraph.load(viewpoint)
+            self._tgraph.capture()
+            self.graph_stats["captures"] += 1
+        self._tgraph.load(viewpoint)
+        _, ok = self._tgraph.run(self.tracking_itr_num, self.converge_check_every)
+        if ok:
+            self._tgraph.store(viewpoint)
+            self.graph_stats["replayed_frames"] += 1
+        else:
+            self.graph_stats["overflow_redos"] += 1
+        return ok
+
     def tracking(self, cur_frame_idx, viewpoint, last_keyframe_idx):
         prev = self.cameras[cur_frame_idx - self.use_every_n_frames]
         viewpoint.update_RT(prev.R, prev.T)
+        if self.use_tracking_graph and self._track_with_graph(viewpoint):
+            with torch.no_grad():
+                render_pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False)
+            self.median_depth = get_median_depth(render_pkg["depth"], render_pkg["opacity"])
+            return render_pkg
+        self.graph_stats["eager_frames"] += 1
         lr = self.config["Training"]["lr"]
         viewpoint.reset_pose_optimizer()
         static = None

@@ -1,0 +1,126 @@
+"""A tracking iteration as ONE hipGraph launch (utils/slam_frontend.py:405-448 is the loop being replaced):
+
+    render(static Gaussians) -> fused tracking loss -> backward -> camera step (Adam on pose + exposure, update_pose, matrices)
+
+Eager, that is ~12 kernel launches plus PyTorch's autograd bookkeeping: ~0.2 ms of host time per iteration, which is what bounds
+scenes below ~50k Gaussians (100 iterations per frame). Captured, the host does one ``graph.replay()`` per iteration and reads one
+flag every few iterations. Three things make the iteration capturable:
+  * the rasterizer's lazy mode (gsr_set_option("lazy", 1)): the forward pass does not wait for num_rendered;
+  * the camera lives in persistent device buffers and its optimizer step / pose update / matrix refresh is one kernel whose Adam
+    step counter is in device memory (Camera.pose_step, include/slam_map.h);
+  * the frame's data (image, depth, loss weights, pose) is COPIED into a static slot per frame, so one captured graph serves every
+    frame tracked against the same map; it is re-captured when the map's tensors change (after every keyframe).
+If a frame outgrows the speculative binning capacity during replay (gsr_forward_status), the caller repeats the frame eagerly."""
+import torch
+
+from diff_gaussian_rasterization import _C
+from diff_gaussian_rasterization import raw as _raw
+from gaussian_renderer import render
+import slam_losses
+
+from .camera import Camera
+
+
+class TrackingGraph:
+    def __init__(self, gaussians, pipeline_params, background, config, proto: Camera):
+        self.gaussians, self.pipe, self.background, self.config = gaussians, pipeline_params, background, config
+        dev = proto.device
+        H, W = int(proto.image_height), int(proto.image_width)
+        self.cam = Camera(1, None, None, torch.eye(4), proto.projection_matrix, proto.fx, proto.fy, proto.cx, proto.cy, proto.FoVx, proto.FoVy,
+                          H, W, 0.0, None, device=dev)
+        self.gt_image = torch.zeros((3, H, W), device=dev)
+        self.gt_depth = torch.zeros((1, H, W), device=dev)
+        self.w_rgb = torch.zeros((1, H, W), device=dev)
+        self.w_dep = torch.zeros((1, H, W), device=dev)
+        self.alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
+        lr = config["Training"]["lr"]
+        self.lrs = (lr["cam_rot_delta"], lr["cam_trans_delta"], 0.01)
+        self.static = None
+        if bool(gaussians.dygs.any()):
+            self.static = gaussians.dygs == False  # noqa: E712
+            self.static._gsr_gather = _raw.gather_from_mask(self.static)
+        self.graph = None
+        self.version = self.model_version(gaussians)
+
+    @staticmethod
+    def model_version(g):
+        """Changes whenever the tensors a captured graph points at are replaced."""
+        return tuple(int(t.data_ptr()) for t in (g._xyz, g._scaling, g._rotation, g._opacity, g._features_dc)) + (int(g._xyz.shape[0]),)
+
+    # ---- per frame -----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def load(self, viewpoint):
+        """Copy the frame into the static slot: start pose, exposure, ground truth and the loss weights of get_loss_tracking
+        (utils/slam_utils.py:65-77,118-135; they depend on the frame only)."""
+        c = self.cam
+        c.update_RT(viewpoint.R, viewpoint.T)
+        c.reset_pose_optimizer()
+        c.exposure_a.copy_(viewpoint.exposure_a)
+        c.exposure_b.copy_(viewpoint.exposure_b)
+        c.cam_rot_delta.zero_()
+        c.cam_trans_delta.zero_()
+        gt_image, gt_depth, _, _, t_rgb, t_dep = slam_losses._keyframe_constants(self.config, viewpoint, c.device)
+        w_rgb, w_dep = slam_losses.tracking_loss_weights(self.config, viewpoint, gt_image, gt_depth, rm_dynamic=True, mask=None, base=(t_rgb, t_dep))
+        self.gt_image.copy_(gt_image)
+        self.gt_depth.copy_(gt_depth.view_as(self.gt_depth))
+        self.w_rgb.copy_(w_rgb.view_as(self.w_rgb))
+        self.w_dep.copy_(w_dep.view_as(self.w_dep))
+
+    @torch.no_grad()
+    def store(self, viewpoint):
+        viewpoint.update_RT(self.cam.R, self.cam.T)
+        viewpoint.exposure_a.copy_(self.cam.exposure_a)
+        viewpoint.exposure_b.copy_(self.cam.exposure_b)
+
+    # ---- the iteration ---------------------------------------------------------------------------------------------------
+    def iteration(self):
+        c = self.cam
+        pkg = render(c, self.gaussians, self.pipe, self.background, dynamic=False, mask=self.static)
+        loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], self.gt_image, self.gt_depth, self.w_rgb, self.w_dep, c.exposure_a,
+                                            c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95)
+        loss.backward()
+        c.pose_step(*self.lrs)
+        if self.gaussians.optimizer is not None:
+            self.gaussians.optimizer.zero_grad(set_to_none=True)
+        return pkg
+
+    def capture(self, warmup=3):
+        """Warm up eagerly (allocator, lazy-mode capacity), then capture one iteration. The slot's state is restored afterwards, so
+        capture() does not move the camera."""
+        c = self.cam
+        keep = [t.detach().clone() for t in (c._R, c._T, c._adam, c.exposure_a, c.exposure_b)]
+        self._lazy_before = _C.set_option("lazy", 1)
+        s = torch.cuda.Stream(device=c.device)
+        s.wait_stream(torch.cuda.current_stream(c.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.iteration()
+        torch.cuda.current_stream(c.device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.iteration()
+        _C.set_option("lazy", self._lazy_before)      # the flag only matters while host code runs: replays never consult it
+        with torch.no_grad():
+            for dst, src in zip((c._R, c._T, c._adam, c.exposure_a, c.exposure_b), keep):
+                dst.copy_(src)
+            c.cam_rot_delta.zero_()
+            c.cam_trans_delta.zero_()
+            c.refresh_matrices()
+        return self
+
+    def run(self, iters, check_every=5):
+        """Replay up to `iters` iterations; stops at the first convergence poll that succeeds. Returns (iterations run, ok) where
+        ok = False means a replayed forward pass outgrew its binning buffer and the frame must be redone eagerly."""
+        done = 0
+        torch.cuda.current_stream(self.cam.device).synchronize()     # eager work queued before (mapping, evaluation renders) may still bump the counter
+        self.overflow0 = _C.forward_status()[0]
+        for it in range(iters):
+            self.graph.replay()
+            done += 1
+            if (it + 1) % check_every == 0 and self.cam.converged():
+                break
+        torch.cuda.current_stream(self.cam.device).synchronize()
+        return done, _C.forward_status()[0] == self.overflow0
+
+    def release(self):
+        self.graph = None

@@ -181,6 +181,20 @@ int gsr_debug_read_state(int P, int R, int width, int height,
  * (bit 4 ? 6 : 1) + bit 0 + 2 * bit 5. */
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
 
+/* Per-host-thread options of the forward pass; returns the previous value (value < 0: query only) or a negative error code.
+ *   "speculate" (default 1): scatter / sort / render are enqueued on a binning buffer sized from the previous frame before the host
+ *                knows num_rendered; 0 = wait for it first, like the reference's blocking copy (rasterizer_impl.cu:283-284).
+ *   "lazy"      (default 0): a speculative gsr_forward returns without ANY host wait; its return value is then an upper bound of
+ *                num_rendered (the buffer capacity) -- valid as the R argument of gsr_backward, whose kernels read the true counts
+ *                on the device. Needed to capture forward + backward in a hipGraph. A frame that outgrows the capacity leaves its
+ *                outputs undefined and bumps the overflow counter of gsr_forward_status(): poll it and redo that work with lazy = 0.
+ *   "mailbox"   (default 1): read the header through pinned host memory instead of a blocking copy.
+ * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX set the initial values. */
+int gsr_set_option(const char* name, int value);
+/* overflow_count: number of forward passes of this thread whose speculative capacity was too small (sticky);
+ * last_num_rendered: num_rendered of the most recent forward pass the GPU has finished binning. Never blocks. */
+int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered);
+
 /* Thread-local text of the last error. */
 const char* gsr_last_error(void);
 

@@ -36,12 +36,26 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+_variant = "serial"
+
+
+def set_variant(which: str = "serial", threads: int | None = None):
+    """"serial" (the checker, default) or "omp": libgs_oracle_omp.so, the same fp32 restatement with its tile and per-Gaussian
+    loops under OpenMP and atomic accumulation -- ONLY for bench.py's all-core cpu_baseline timing (summation order not fixed)."""
+    global _lib, _variant
+    assert which in ("serial", "omp")
+    if which != _variant:
+        _lib, _variant = None, which
+    if which == "omp" and threads:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        for sfx in ("f32", "f64"):
+        _lib = C.CDLL(_LIB_PATH if _variant == "serial" else os.path.join(_HERE, "libgs_oracle_omp.so"))
+        for sfx in (("f32", "f64") if _variant == "serial" else ("f32",)):
             getattr(_lib, f"gso_forward_{sfx}").restype = C.c_void_p
             getattr(_lib, f"gso_num_rendered_{sfx}").restype = C.c_int
             getattr(_lib, f"gso_num_rendered_{sfx}").argtypes = [C.c_void_p]

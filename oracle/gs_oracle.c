@@ -46,6 +46,19 @@
 typedef REAL real;
 
 /* DGR/cuda_rasterizer/auxiliary.h:22-39 */
+/* GSO_OMP (oracle/Makefile target libgs_oracle_omp.so, bench.py's all-core cpu_baseline only): the tile loops and the per-Gaussian
+ * loops run under OpenMP, per-Gaussian accumulations become atomic adds. The summation order is then not fixed, so the CHECKER is
+ * always the serial build. */
+#ifdef GSO_OMP
+#define GSO_FOR_TILES _Pragma("omp parallel for collapse(2) schedule(dynamic, 2)")
+#define GSO_FOR_POINTS _Pragma("omp parallel for schedule(static)")
+#define GSO_ATOMIC _Pragma("omp atomic")
+#else
+#define GSO_FOR_TILES
+#define GSO_FOR_POINTS
+#define GSO_ATOMIC
+#endif
+
 static const real SH_C0 = (real)0.28209479177387814;
 static const real SH_C1 = (real)0.4886025119029199;
 static const real SH_C2[5] = {(real)1.0925484305920792, (real)-1.0925484305920792, (real)0.31539156525252005,
@@ -253,7 +266,7 @@ FN(gso_ctx)* FN(gso_forward)(int P, int D, int M, const real* background, int W,
     c->final_T = (real*)calloc(N, sizeof(real)); c->n_contrib = (uint32_t*)calloc(N, 4);
     c->ranges = (uint32_t*)calloc((size_t)gx * gy * 2, 4);
 
-    /* ---- K1: preprocessCUDA, forward.cu:184-257 ---- */
+    /* ---- K1: preprocessCUDA, forward.cu:184-257 ---- (serial in every build: it can return early) */
     for (int idx = 0; idx < P; idx++) {
         c->radii[idx] = 0; c->tiles_touched[idx] = 0;
         v3 p_orig = V3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -333,6 +346,7 @@ FN(gso_ctx)* FN(gso_forward)(int P, int D, int M, const real* background, int W,
 
     /* ---- K6: renderCUDA, forward.cu:263-392 (per pixel; the block-level early-out :318-320 does not change results) ---- */
     const real* features = colors_precomp ? colors_precomp : c->rgb; /* rasterizer_impl.cu:324 */
+    GSO_FOR_TILES
     for (int ty = 0; ty < gy; ty++) for (int tx = 0; tx < gx; tx++) {
         uint32_t r0 = c->ranges[2 * (ty * gx + tx)], r1 = c->ranges[2 * (ty * gx + tx) + 1];
         for (int ly = 0; ly < BLOCK_Y; ly++) for (int lx = 0; lx < BLOCK_X; lx++) {
@@ -354,7 +368,7 @@ FN(gso_ctx)* FN(gso_forward)(int P, int D, int M, const real* background, int W,
                 if (test_T < (real)0.0001) break; /* done = true */
                 for (int ch = 0; ch < 3; ch++) C[ch] += features[g * 3 + ch] * alpha * T;
                 Dd += c->depths[g] * alpha * T;
-                if (test_T > (real)0.5) n_touched[g] += 1;
+                if (test_T > (real)0.5) { GSO_ATOMIC n_touched[g] += 1; }
                 T = test_T;
                 last_contributor = contributor;
             }
@@ -495,6 +509,7 @@ void FN(gso_backward)(const FN(gso_ctx)* c, const real* background, const real* 
 
     /* ---- K7: renderCUDA backward, backward.cu:617-786 ---- */
     const real ddelx_dx = (real)0.5 * W, ddely_dy = (real)0.5 * H; /* :643-644 */
+    GSO_FOR_TILES
     for (int ty = 0; ty < gy; ty++) for (int tx = 0; tx < gx; tx++) {
         uint32_t r0 = c->ranges[2 * (ty * gx + tx)], r1 = c->ranges[2 * (ty * gx + tx) + 1];
         if (r1 <= r0) continue;
@@ -560,16 +575,20 @@ void FN(gso_backward)(const FN(gso_ctx)* c, const real* background, const real* 
                 s_op += G * dL_dalpha;
             }
             /* block reduction + atomicAdd (:759-784) */
-            dL_dmean2D[3 * g + 0] += (real)s_m2x; dL_dmean2D[3 * g + 1] += (real)s_m2y;
-            dL_dconic[4 * g + 0] += (real)s_cx; dL_dconic[4 * g + 1] += (real)s_cy; dL_dconic[4 * g + 3] += (real)s_cw;
-            dL_dopacity[g] += (real)s_op;
-            for (int ch = 0; ch < 3; ch++) dL_dcolor[3 * g + ch] += (real)s_col[ch];
-            dL_ddepth[g] += (real)s_dep;
+            GSO_ATOMIC dL_dmean2D[3 * g + 0] += (real)s_m2x;
+            GSO_ATOMIC dL_dmean2D[3 * g + 1] += (real)s_m2y;
+            GSO_ATOMIC dL_dconic[4 * g + 0] += (real)s_cx;
+            GSO_ATOMIC dL_dconic[4 * g + 1] += (real)s_cy;
+            GSO_ATOMIC dL_dconic[4 * g + 3] += (real)s_cw;
+            GSO_ATOMIC dL_dopacity[g] += (real)s_op;
+            for (int ch = 0; ch < 3; ch++) { GSO_ATOMIC dL_dcolor[3 * g + ch] += (real)s_col[ch]; }
+            GSO_ATOMIC dL_ddepth[g] += (real)s_dep;
         }
     }
 
     /* ---- K8: computeCov2DCUDA, backward.cu:150-346 ---- */
     const real* cov3Ds = cov3D_precomp ? cov3D_precomp : c->cov3D; /* rasterizer_impl.cu:429 */
+    GSO_FOR_POINTS
     for (int idx = 0; idx < P; idx++) {
         if (!(c->radii[idx] > 0)) continue;
         const real* cov3D = cov3Ds + 6 * (size_t)idx;
@@ -637,6 +656,7 @@ void FN(gso_backward)(const FN(gso_ctx)* c, const real* background, const real* 
     }
 
     /* ---- K9: preprocessCUDA backward, backward.cu:442-538 ---- */
+    GSO_FOR_POINTS
     for (int idx = 0; idx < P; idx++) {
         if (!(c->radii[idx] > 0)) continue;
         v3 m = V3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);

@@ -69,11 +69,13 @@ def _cov3d(scales, mod, rot):
 
 def rasterize(means3D, means2D, opacities, *, shs=None, colors_precomp=None, scales=None, rotations=None,
               cov3D_precomp=None, bg, viewmatrix, projmatrix, campos, tanfovx, tanfovy, image_height, image_width,
-              sh_degree=0, scale_modifier=1.0):
+              sh_degree=0, scale_modifier=1.0, tile_window=None):
     """Differentiable forward. Returns (color[3,H,W], radii[P] i32, depth[1,H,W], opacity[1,H,W], n_touched[P] i32).
 
     ``means2D`` is the reference's dummy [P,3] zeros tensor whose gradient is d L / d(NDC mean).
     All tensors live on one device/dtype (cpu, fp32 or fp64). viewmatrix/projmatrix may require grad.
+    ``tile_window`` = (tx0, ty0, tx1, ty1): composite only that rectangle of 16x16 tiles (everything else stays background) --
+    bench.py's bounded CPU-baseline sample; the per-Gaussian preprocess always covers all P.
     """
     dev, dt = means3D.device, means3D.dtype
     P = means3D.shape[0]
@@ -154,8 +156,11 @@ def rasterize(means3D, means2D, opacities, *, shs=None, colors_precomp=None, sca
     for tyi in range(gy):
         row_c, row_d, row_o = [], [], []
         for txi in range(gx):
-            m = vis & (rminx <= txi) & (txi < rmaxx) & (rminy <= tyi) & (tyi < rmaxy)
-            ids = order[m[order]]
+            if tile_window is not None and not (tile_window[0] <= txi < tile_window[2] and tile_window[1] <= tyi < tile_window[3]):
+                ids = order[:0]
+            else:
+                m = vis & (rminx <= txi) & (txi < rmaxx) & (rminy <= tyi) & (tyi < rmaxy)
+                ids = order[m[order]]
             pxs = (txi * BLOCK + lx).to(dt)
             pys = (tyi * BLOCK + lx).to(dt)
             PX, PY = torch.meshgrid(pxs, pys, indexing="xy")      # [16(y),16(x)]

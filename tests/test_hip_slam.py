@@ -269,3 +269,69 @@ def test_slam_dynamic_sequence_end_to_end():
     assert res["frames"] == 30 and g.deform_init and int(g.dygs.sum()) > 50
     assert res["ate_rmse"] < 0.015, res
     assert res["before_opt"]["mean_psnr"] > 20.0, res
+
+
+def _tracking_fixture(P_scale=1.0):
+    """A small mapped scene + one frame to track: returns (gaussians, pipe, background, config, frame camera, dataset)."""
+    import types
+    from slam.camera import Camera
+    from slam.dataset import SyntheticRGBDDataset
+    from slam.system import SLAM
+    torch.manual_seed(0)
+    ds = SyntheticRGBDDataset(num_frames=8, width=320, height=240, seed=0)
+    cfg = _quick_config(init_itr_num=120, tracking_itr_num=12)
+    slam = SLAM(cfg, ds)
+    slam.frontend.run(max_frames=1)                      # initialise the map from frame 0
+    cam = Camera.init_from_dataset(ds, 1, ds.projection_matrix)
+    cam.compute_grad_mask(cfg)
+    cam.update_RT(slam.frontend.cameras[0].R, slam.frontend.cameras[0].T)
+    return slam, cam
+
+
+def test_tracking_iteration_as_hip_graph_is_bit_identical_to_eager():
+    """render(mask) -> fused tracking loss -> backward -> pose Adam + update_pose, replayed as one graph, must give
+    bit-identical poses to the eager loop; the forward pass runs in lazy mode (no host wait)."""
+    import copy
+    from diff_gaussian_rasterization import _C
+    from slam.tracking_graph import TrackingGraph
+    slam, cam = _tracking_fixture()
+    fe = slam.frontend
+    R0, T0 = cam.R.clone(), cam.T.clone()
+    # eager reference: 10 iterations of the front-end's loop body on the slot camera of a TrackingGraph (same code path, no capture)
+    tg = TrackingGraph(fe.gaussians, fe.pipeline_params, fe.background, fe.config, cam)
+    tg.load(cam)
+    for _ in range(10):
+        tg.iteration()
+    R_eager, T_eager, ea, eb = tg.cam.R.clone(), tg.cam.T.clone(), tg.cam.exposure_a.detach().clone(), tg.cam.exposure_b.detach().clone()
+    assert float((R_eager - R0).abs().max()) > 0 and float((T_eager - T0).abs().max()) > 1e-4       # the pose moved
+    # graph: capture once, replay 10 times from the same start
+    tg2 = TrackingGraph(fe.gaussians, fe.pipeline_params, fe.background, fe.config, cam)
+    tg2.load(cam)
+    tg2.capture()
+    assert _C.set_option("lazy") == 0                                  # restored after capture
+    tg2.load(cam)
+    done, ok = tg2.run(10, check_every=100)
+    assert done == 10 and ok
+    assert torch.equal(tg2.cam.R, R_eager) and torch.equal(tg2.cam.T, T_eager)
+    assert torch.equal(tg2.cam.exposure_a.detach(), ea) and torch.equal(tg2.cam.exposure_b.detach(), eb)
+    # a second frame through the SAME graph (new data copied into the slot), again equal to eager
+    cam2 = copy.copy(cam)
+    tg.load(cam); tg.cam.update_RT(R_eager, T_eager)
+    tg2.load(cam); tg2.cam.update_RT(R_eager, T_eager)
+    for _ in range(4):
+        tg.iteration()
+    tg2.run(4, check_every=100)
+    assert torch.equal(tg2.cam.R, tg.cam.R) and torch.equal(tg2.cam.T, tg.cam.T)
+
+
+def test_slam_with_tracking_graph_matches_eager_quality():
+    from slam.dataset import SyntheticRGBDDataset
+    from slam.system import SLAM
+    torch.manual_seed(0)
+    ds = SyntheticRGBDDataset(num_frames=16, width=320, height=240, seed=0)
+    slam = SLAM(_quick_config(tracking_graph=True), ds)
+    res = slam.run()
+    st = slam.frontend.graph_stats
+    print(res, st)
+    assert st["replayed_frames"] >= 10 and st["captures"] >= 2
+    assert res["ate_rmse"] < 0.02 and res["before_opt"]["mean_psnr"] > 22.0, res

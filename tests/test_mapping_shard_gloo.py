@@ -157,3 +157,63 @@ def test_two_rank_allreduce_of_deformation_network_gradients():
         assert np.allclose(got[i], want.numpy(), rtol=1e-6, atol=1e-6), i
         if p.dim() == 4:
             assert strides[i] == tuple(torch.empty(p.shape).contiguous(memory_format=torch.channels_last).stride())   # layout kept
+
+
+# ---- config #5's step: ShardedMappingStep (attached bucket, no pack / unpack) and the densification-statistics reduction ----------
+def _sharded_step_worker(rank, world, port, ret):
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapping_shard import ShardedMappingStep, allreduce_densification_stats
+    g = torch.Generator().manual_seed(0)                       # identical replicas on every rank
+    a = torch.nn.Parameter(torch.randn(50, 3, generator=g))
+    planes = torch.nn.Parameter(torch.randn(1, 8, 6, 5, generator=g).contiguous(memory_format=torch.channels_last))   # HexPlane-style layout
+    w = torch.nn.Parameter(torch.randn(7, generator=g))
+    opt = torch.optim.SGD([a, planes, w], lr=0.1)
+
+    def view_fn(k):        # a "view": a loss that depends on the keyframe id
+        ((a * (k + 1)).sum() + (planes * planes).sum() * (k + 2) + (w * k).sum()).backward()
+
+    step = ShardedMappingStep([a, planes, w], list(range(6)), view_fn, optimizer=opt)
+    before = [p.detach().clone() for p in (a, planes, w)]
+    modes = [step.step() for _ in range(2)]
+    # statistics of this rank's views: sum / sum / max over ranks
+    acc = torch.full((10, 1), float(rank + 1))
+    den = torch.full((10, 1), float(2 * rank + 1))
+    rad = torch.arange(10, dtype=torch.float32) * (1 if rank == 0 else -1) + 3 * rank
+    allreduce_densification_stats(acc, den, rad)
+    if rank == 0:
+        ret.put((modes, [p.detach().numpy().copy() for p in (a, planes, w)], [b.numpy() for b in before], planes.grad.stride() == planes.stride(),
+                 acc.numpy(), den.numpy(), rad.numpy(), step.keyframes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mapping_step_and_stats_reduction_two_ranks():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29500 + ((os.getpid() + 137) % 500)
+    procs = [ctx.Process(target=_sharded_step_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    modes, after, before, stride_ok, acc, den, rad, kfs = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert modes == ["attached", "attached"] and stride_ok and kfs == [0, 2, 4]
+    # single-process reference: all six views, two SGD steps
+    a, planes, w = (torch.nn.Parameter(torch.tensor(b)) for b in before)
+    opt = torch.optim.SGD([a, planes, w], lr=0.1)
+    for _ in range(2):
+        opt.zero_grad()
+        for k in range(6):
+            ((a * (k + 1)).sum() + (planes * planes).sum() * (k + 2) + (w * k).sum()).backward()
+        opt.step()
+    for got, want in zip(after, (a, planes, w)):
+        np.testing.assert_allclose(got, want.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(acc, np.full((10, 1), 3.0))                 # 1 + 2
+    np.testing.assert_allclose(den, np.full((10, 1), 4.0))                 # 1 + 3
+    np.testing.assert_allclose(rad, np.maximum(np.arange(10.0), -np.arange(10.0) + 3))

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Tracking-iteration time (render static Gaussians -> fused tracking loss -> backward -> camera step), eager vs captured in a hipGraph
+(slam/tracking_graph.py), for several map sizes: shows the host floor of the eager loop and what the graph leaves of it.
+    gpurun -- 'python tools/bench_tracking.py > gpurun_out/tracking_graph.json'"""
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "4dgs-slam_amd")):
+    sys.path.insert(0, p)
+
+from slam.camera import Camera, fov_from_focal, getProjectionMatrix2  # noqa: E402
+from slam.system import default_config  # noqa: E402
+from slam.tracking_graph import TrackingGraph  # noqa: E402
+from synthetic_scene import GaussianModelStub, make_camera, make_gaussians  # noqa: E402
+
+
+def main():
+    W, H = 640, 480
+    fx, fy, cx, cy = 535.4, 539.2, 320.1, 247.6
+    proj = getProjectionMatrix2(0.01, 100.0, cx, cy, fx, fy, W, H).transpose(0, 1)
+    cfg = default_config()
+    rng = np.random.default_rng(0)
+    rows = []
+    for P in (10_000, 50_000, 200_000):
+        g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
+        pc = GaussianModelStub(g, isotropic=False, dyn_frac=0.0, seed=0)
+        pc.optimizer = None
+        img = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device="cuda")
+        depth = rng.uniform(0.5, 5, (H, W)).astype(np.float32)
+        cam = Camera(1, img, depth, torch.eye(4), proj, fx, fy, cx, cy, fov_from_focal(fx, W), fov_from_focal(fy, H), H, W, 0.0)
+        cam.compute_grad_mask(cfg)
+        bg = torch.ones(3, device="cuda")
+        pipe = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+        tg = TrackingGraph(pc, pipe, bg, cfg, cam)
+        tg.load(cam)
+        for _ in range(100):          # clocks + allocator + speculation warm
+            tg.iteration()
+        torch.cuda.synchronize()
+        n = 200
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tg.iteration()
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / n
+        tg.load(cam)
+        tg.capture()
+        tg.load(cam)
+        tg.run(20, check_every=1000)
+        t0 = time.perf_counter()
+        done, ok = tg.run(n, check_every=1000)
+        graph = (time.perf_counter() - t0) / n
+        rows.append({"gaussians": P, "eager_us_per_iteration": eager * 1e6, "graph_us_per_iteration": graph * 1e6, "speedup": eager / graph, "overflow_free": ok})
+    print(json.dumps({"what": "tracking iteration @640x480: render + fused tracking loss + backward + camera step; eager launches vs one hipGraph replay",
+                      "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
