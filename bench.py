@@ -1,22 +1,29 @@
 #!/usr/bin/env python
-"""bench.py -- rasterized Gaussians/s, forward+backward, 200k Gaussians @640x480 (BASELINE.json metric, configs[1]).
+"""bench.py -- rasterized Gaussians/s, forward+backward (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|cfg2|cfg5|long]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one pass of the hot path over one batch of synthetic input: GaussianRasterizer forward + autograd backward
-(colour + depth cotangents) of P=200 000 Gaussians on one 640x480 view, inputs resident in HBM before the timed
-region. With N>1 every rank renders its own keyframe of the same Gaussian set (weak scaling, view sharding of
-SURVEY.md 8e) and the flattened Gaussian gradient block is summed with ONE RCCL all-reduce per step -- the step of the
-mapping back-end that north_star shards. value = N * P * K / max-over-ranks(time).
+Workloads (``--workload auto``: cfg2 at N = 1, cfg5 at N > 1):
+  cfg2  BASELINE configs[1], the configuration the metric is quoted on: P = 200 000 static Gaussians, one 640x480 view. A step = one
+        GaussianRasterizer forward + autograd backward (colour + depth cotangents), inputs resident in HBM. With N > 1 every rank
+        renders its own keyframe of the same Gaussians and the gradients are summed with one RCCL all-reduce (weak scaling).
+  cfg5  BASELINE configs[4], the mapping back-end's iteration that north_star shards: P = 2 000 000 Gaussians, 64 synthetic keyframes
+        (SURVEY.md 8d poses) sharded round-robin over the N ranks -> 64 / N views per rank, gradients accumulated locally in a flat
+        bucket, ONE all-reduce of 14 P floats (112 MB), then the fused Adam step on every replica. A step = that whole iteration;
+        value = P * 64 * K / time (Gaussian-views per second, whole job); strong scaling (the 64 views are fixed).
+  long  a SLAM-shaped variant of cfg2 (scale_mean 0.03 -> tile lists of several thousand entries, SH degree 3): profiles/ only.
 
-One JSON line on rank 0, with `roofline` (dominant kernel = render_bwd, timed with HIP events on its launch stream
-inside the timed region) and `cpu_baseline` (the C oracle = a sequential port of the reference algorithm, timed on
-this box's host CPU, 1 core). The oracle is imported ONLY for that leg.
+One JSON line on rank 0 with `roofline` (dominant kernel = render_bwd, HIP events on its launch stream inside the timed region) and
+`cpu_baseline` (BASELINE.md's baseline A: the tile-binned pure-PyTorch CPU rasterizer oracle/torch_raster.py on all host cores; the
+single-core figure, and the C port single-threaded and under OpenMP, ride along). The oracle package is imported ONLY for that leg,
+outside the timed region. At N = 1 the line also carries a short cfg5 measurement (`config5`), at N > 1 a short weak-scaling
+cfg2 measurement (`weak_200k`) and rank 0's single-GPU time for the same cfg5 iteration (`n1_reference`).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,8 +37,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-P_GAUSS, WIDTH, HEIGHT = 200_000, 640, 480
+WIDTH, HEIGHT = 640, 480
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CFG2_P, CFG5_P, CFG5_KEYFRAMES = 200_000, 2_000_000, 64
 
 
 def algorithmic_bytes(P, V, R, N, M):
@@ -42,15 +50,219 @@ def algorithmic_bytes(P, V, R, N, M):
     return total, render_bwd
 
 
+class Scene:
+    """Device-resident synthetic scene + per-keyframe rasterizer settings."""
+
+    def __init__(self, P, dev, sh_degree=0, scale_mean=0.005, keyframes=(0,), cot_seed=1):
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+        from synthetic_scene import keyframe_pose, make_camera, make_cotangents, make_gaussians
+        self.P, self.dev, self.sh_degree = P, dev, sh_degree
+        self.g = make_gaussians(P, make_camera(WIDTH, HEIGHT), seed=0, sh_degree=sh_degree, scale_mean=scale_mean)
+        T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)
+        g = self.g
+        self.means3D, self.shs, self.opac = T(g["means3D"], True), T(g["shs"], True), T(g["opacities"], True)
+        self.scales, self.rots = T(g["scales"], True), T(g["rotations"], True)
+        self.params = [self.means3D, self.shs, self.opac, self.scales, self.rots]      # the rasterizer's gradient-block order
+        self.theta, self.rho = T(np.zeros(3), True), T(np.zeros(3), True)
+        self.means2D = torch.zeros_like(self.means3D, requires_grad=True)             # the caller's screen-space gradient holder
+        self.cams, self.rast = {}, {}
+        for k in keyframes:
+            R_w, t_w = keyframe_pose(k)
+            cam = make_camera(WIDTH, HEIGHT, R=R_w, t=t_w)
+            rs = GaussianRasterizationSettings(
+                image_height=HEIGHT, image_width=WIDTH, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=T([1.0, 1.0, 1.0]), scale_modifier=1.0,
+                viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), projmatrix_raw=T(cam.projmatrix_raw), sh_degree=sh_degree,
+                campos=T(cam.campos), prefiltered=False, debug=False)
+            self.cams[k], self.rast[k] = cam, GaussianRasterizer(rs)
+        gc, gd = make_cotangents(self.cams[keyframes[0]], seed=cot_seed)
+        self.gc, self.gd, self.gcol, self.gdep = gc, gd, T(gc), T(gd)
+
+    def fwd_bwd(self, k):
+        color, radii, depth, opacity, n_touched = self.rast[k](means3D=self.means3D, means2D=self.means2D, opacities=self.opac, shs=self.shs,
+                                                               scales=self.scales, rotations=self.rots, theta=self.theta, rho=self.rho)
+        torch.autograd.backward([color, depth], [self.gcol, self.gdep])
+        return radii
+
+    def view_facts(self, k):
+        """(visible, instances) of keyframe k, from the run itself."""
+        from diff_gaussian_rasterization import _C
+        rs = self.rast[k].raster_settings
+        with torch.no_grad():
+            nr, color, radii, *_ = _C.rasterize_gaussians(rs.bg, self.means3D, torch.Tensor([]), self.opac, self.scales, self.rots, 1.0, torch.Tensor([]),
+                                                          rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy, HEIGHT, WIDTH,
+                                                          self.shs, self.sh_degree, rs.campos, False, False)
+        return int((radii > 0).sum().item()), int(nr)
+
+
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays the only stdout output)"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def timed(step, steps, warmup, barrier):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def run_cfg2(scene, world, rank, steps, warmup, barrier, k):
+    """One view per rank (+ all-reduce when world > 1). Returns (seconds for `steps`, all-reduce mode)."""
+    from mapping_shard import GradBucket
+    bucket = GradBucket(scene.params) if world > 1 else None
+    mode = {}
+
+    def step():
+        for p_ in scene.params + [scene.theta, scene.rho, scene.means2D]:
+            p_.grad = None
+        scene.fwd_bwd(k)
+        if bucket is not None:
+            mode["allreduce"] = bucket.all_reduce_grads()   # in place on the backward's own output range when possible
+    return timed(step, steps, warmup, barrier), mode.get("allreduce"), step
+
+
+def make_cfg5(scene, keyframes):
+    from fused_adam import FusedAdam
+    from mapping_shard import ShardedMappingStep
+    opt = FusedAdam([{"params": [p], "lr": 0.0, "name": n} for p, n in zip(scene.params, ("xyz", "f", "opacity", "scaling", "rotation"))],
+                    lr=0.0, eps=1e-15)      # lr = 0: the full Adam arithmetic runs, the scene (hence the workload) stays put
+    sms = ShardedMappingStep(scene.params, keyframes, lambda k: scene.fwd_bwd(k), optimizer=opt)
+
+    def step():
+        scene.theta.grad = scene.rho.grad = scene.means2D.grad = None
+        sms.step()
+    return sms, step
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the machine's
+    count even inside a container limited to a few CPUs; 256 spinning OpenMP threads on 8 usable cores do not finish)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baselines_in_child(P, sh_degree, scale_mean, timeout_s):
+    """Runs the CPU-baseline leg in a child process with a hard wall-clock limit, so that a slow host can never stall the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--gaussians", str(P), "--sh-degree", str(sh_degree),
+           "--scale-mean", str(scale_mean)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, OMP_WAIT_POLICY="PASSIVE"))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            return d["cpu_baseline"], d["cpu_baseline_port"]
+        why = f"child exited with {r.returncode}: {r.stderr[-300:]}"
+    except subprocess.TimeoutExpired:
+        why = f"did not finish within {timeout_s} s on this host ({usable_cores()} usable cores of {os.cpu_count()})"
+    return {"value": None, "unit": "Gaussians/s", "cores": usable_cores(), "kind": "port", "sample": "not measured: " + why}, None
+
+
+def cpu_baselines(scene_g, cam, gc, gd, P, sh_degree, budget_s):
+    """BASELINE.md baseline A (tile-binned pure-PyTorch CPU rasterizer) on all cores and on one, plus the C port (one core; OpenMP)."""
+    import oracle  # CPU baseline leg only (test infrastructure; never in the product path)
+    from oracle import torch_raster
+    cores = usable_cores()
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), requires_grad=rg)
+    gx, gy = (WIDTH + 15) // 16, (HEIGHT + 15) // 16
+    win = (gx // 2 - 5, gy // 2 - 3, gx // 2 + 5, gy // 2 + 3)            # 10 x 6 = 60 of the 1200 tiles, centred
+    n_win = (win[2] - win[0]) * (win[3] - win[1])
+
+    def torch_once(window):
+        leaves = dict(means3D=T(scene_g["means3D"], True), opacities=T(scene_g["opacities"], True), shs=T(scene_g["shs"], True),
+                      scales=T(scene_g["scales"], True), rotations=T(scene_g["rotations"], True))
+        m2d = torch.zeros(P, 3, requires_grad=True)
+        t0 = time.perf_counter()
+        out = torch_raster.rasterize(leaves["means3D"], m2d, leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"],
+                                     bg=torch.ones(3), viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), campos=T(cam.campos),
+                                     tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, image_height=HEIGHT, image_width=WIDTH, sh_degree=sh_degree,
+                                     tile_window=window)
+        if out[0].requires_grad:                                         # (no tile composited: nothing to back-propagate)
+            torch.autograd.backward([out[0], out[2]], [T(gc), T(gd)])
+        return time.perf_counter() - t0
+
+    def sample(threads, reps):
+        torch.set_num_threads(threads)
+        t_pre = min(torch_once((0, 0, 0, 0)) for _ in range(2))              # per-Gaussian part + tile bookkeeping of ALL tiles, no tile composited
+        t_win = statistics.median(torch_once(win) for _ in range(reps))
+        full = t_pre + (t_win - t_pre) * (gx * gy) / n_win                   # the composited tiles scale linearly with their number
+        return {"value": P / full, "seconds_full_extrapolated": full, "seconds_window": t_win, "seconds_no_tiles": t_pre}
+
+    prev = torch.get_num_threads()
+    note(f"cpu baseline A: torch tile-binned rasterizer, {cores} threads")
+    allc = sample(cores, 5)
+    note(f"  all cores: {allc['seconds_window']:.2f} s per window sample")
+    one = sample(1, 3) if allc["seconds_window"] * 6 < budget_s else None
+    torch.set_num_threads(prev)
+    note("cpu baseline port: C oracle, 1 thread, then OpenMP")
+
+    def port(variant, threads):
+        oracle.set_variant(variant, threads)
+        t1 = time.perf_counter()
+        o, st = oracle.rasterize_forward(bg=np.ones(3, np.float32), means3D=scene_g["means3D"], opacities=scene_g["opacities"], shs=scene_g["shs"],
+                                         scales=scene_g["scales"], rotations=scene_g["rotations"], viewmatrix=cam.viewmatrix,
+                                         projmatrix=cam.projmatrix, campos=cam.campos, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                         image_height=HEIGHT, image_width=WIDTH, sh_degree=sh_degree)
+        oracle.rasterize_backward(st, projmatrix_raw=cam.projmatrix_raw, dL_dcolor=gc, dL_ddepth=gd)
+        return time.perf_counter() - t1
+
+    t_port1 = port("serial", 1)
+    t_omp = min(port("omp", cores) for _ in range(2))
+    oracle.set_variant("serial")
+    base = {"value": allc["value"], "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_raster.py (tile-binned pure-PyTorch CPU rasterizer = BASELINE.md baseline A; this repo's restatement, the reference has "
+                      f"no CPU path), fwd+bwd of the full {P} Gaussians @{WIDTH}x{HEIGHT}: per-Gaussian stage over all P, then a centred window of {n_win} of "
+                      f"{gx * gy} tiles composited and back-propagated, median of 5, extrapolated linearly in the tile count "
+                      f"({allc['seconds_window']:.2f} s per sample -> {allc['seconds_full_extrapolated']:.1f} s for the frame), torch.set_num_threads({cores})",
+            "torch_one_core": None if one is None else {"value": one["value"], "cores": 1, "seconds_full_extrapolated": one["seconds_full_extrapolated"]}}
+    port_line = {"value": P / t_port1, "unit": "Gaussians/s", "cores": 1, "kind": "port",
+                 "sample": f"oracle/gs_oracle.c, one full fwd+bwd of the same workload ({t_port1:.2f} s), single-threaded",
+                 "openmp_all_cores": {"value": P / t_omp, "cores": cores, "seconds": t_omp,
+                                      "note": "libgs_oracle_omp.so: tile and per-Gaussian loops under OpenMP; binning, key sort and preprocess stay serial"}}
+    return base, port_line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--gaussians", type=int, default=P_GAUSS)
-    ap.add_argument("--sh-degree", type=int, default=0)
+    ap.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg5", "long"])
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--keyframes", type=int, default=CFG5_KEYFRAMES)
+    ap.add_argument("--sh-degree", type=int, default=None)
+    ap.add_argument("--scale-mean", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the embedded secondary measurements (config5 / weak_200k / n1_reference)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
+    if args.cpu_baseline_child:        # CPU only: no GPU, no product code
+        from synthetic_scene import make_camera, make_cotangents, make_gaussians
+        cam = make_camera(WIDTH, HEIGHT)
+        P = args.gaussians or CFG2_P
+        g = make_gaussians(P, cam, seed=0, sh_degree=args.sh_degree or 0, scale_mean=args.scale_mean or 0.005)
+        gc, gd = make_cotangents(cam, seed=1)
+        a, b = cpu_baselines(g, cam, gc, gd, P, args.sh_degree or 0, budget_s=60.0)
+        print(json.dumps({"cpu_baseline": a, "cpu_baseline_port": b}), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -72,126 +284,182 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-    from mapping_shard import GradBucket
-    from synthetic_scene import make_camera, make_gaussians, make_cotangents, keyframe_pose
+    from diff_gaussian_rasterization import _C
 
-    P = args.gaussians
-    R_w, t_w = keyframe_pose(rank)  # rank r renders keyframe r of the same scene
-    cam = make_camera(WIDTH, HEIGHT, R=R_w, t=t_w)
-    g = make_gaussians(P, make_camera(WIDTH, HEIGHT), seed=0, sh_degree=args.sh_degree)
-    gc, gd = make_cotangents(cam, seed=1 + rank)
-    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)
-    rs = GaussianRasterizationSettings(
-        image_height=HEIGHT, image_width=WIDTH, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=T([1.0, 1.0, 1.0]),
-        scale_modifier=1.0, viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), projmatrix_raw=T(cam.projmatrix_raw),
-        sh_degree=args.sh_degree, campos=T(cam.campos), prefiltered=False, debug=False)
-    rast = GaussianRasterizer(rs)
-    means3D, shs, opac = T(g["means3D"], True), T(g["shs"], True), T(g["opacities"], True)
-    scales, rots = T(g["scales"], True), T(g["rotations"], True)
-    theta, rho = T(np.zeros(3), True), T(np.zeros(3), True)
-    gcol, gdep = T(gc), T(gd)
-    params = [means3D, shs, opac, scales, rots]   # same order as the rasterizer's gradient block
-    bucket = GradBucket(params) if world > 1 else None
-    stats = {}
-
-    # screen-space gradient holder of the reference's render() (gaussian_renderer/__init__.py:71): an input of the rasterizer,
-    # created once here -- filling it is the caller's work, not part of the rasterizer's forward + backward
-    means2D = torch.zeros_like(means3D, requires_grad=True)
-
-    def step():
-        for p_ in params + [theta, rho, means2D]:
-            p_.grad = None
-        color, radii, depth, opacity, n_touched = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
-                                                       scales=scales, rotations=rots, theta=theta, rho=rho)
-        torch.autograd.backward([color, depth], [gcol, gdep])
-        if bucket is not None:
-            stats["allreduce"] = bucket.all_reduce_grads()   # in place on the backward's own output range when possible
-        stats["radii"] = radii
+    workload = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg5")
+    sh_degree = args.sh_degree if args.sh_degree is not None else (3 if workload == "long" else 0)
+    scale_mean = args.scale_mean if args.scale_mean is not None else (0.03 if workload == "long" else 0.005)
+    N = WIDTH * HEIGHT
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    _C.profile_reset()
-    _C.profile_enable(["render_bwd"])       # 2 event records per step on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    _C.profile_enable(False)
-    dom_ms, dom_calls = _C.profile_read()["render_bwd"]
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def reduce_max(dt):
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
 
-    # per-kernel breakdown in a separate, untimed pass (all kernels timed)
-    _C.profile_reset()
-    _C.profile_enable(True)
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
-    _C.profile_enable(False)
-    kern = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in _C.profile_read().items() if v[1]}  # us per launch
+    def kernel_breakdown(step, reps=5):
+        """per-kernel time (HIP events on the launch stream) in a separate, untimed pass"""
+        _C.profile_reset()
+        _C.profile_enable(True)
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        _C.profile_enable(False)
+        return {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in _C.profile_read().items() if v[1]}  # us per launch
 
+    out = None
+    if workload in ("cfg2", "long"):
+        P = args.gaussians or CFG2_P
+        scene = Scene(P, dev, sh_degree, scale_mean, keyframes=(rank,), cot_seed=1 + rank)
+        note(f"{workload}: P = {P}, world = {world}")
+        # headline: speculative binning (the SLAM loop's steady state); the dominant kernel is timed inside the timed region
+        _, _, step = run_cfg2(scene, world, rank, 0, args.warmup, barrier, rank)
+        _C.profile_reset()
+        _C.profile_enable(["render_bwd"])       # 2 event records per step on the launch stream
+        dt = reduce_max(timed(step, args.steps, 0, barrier))
+        _C.profile_enable(False)
+        dom_ms, dom_calls = _C.profile_read()["render_bwd"]
+        kern = kernel_breakdown(step)
+        note(f"timed region done: {dt / args.steps * 1e3:.4f} ms per step")
+        nospec = None
+        if world == 1:
+            # the same step with the speculation off: the host waits for num_rendered before it allocates and enqueues the binning,
+            # as the reference does (rasterizer_impl.cu:283-284) -- the cost of a frame whose size cannot be predicted
+            _C.set_option("speculate", 0)
+            nospec = timed(step, max(args.steps // 4, 5), 5, barrier) / max(args.steps // 4, 5)
+            _C.set_option("speculate", 1)
+        if rank == 0:
+            V, nr = scene.view_facts(rank)
+            M = int(scene.shs.shape[1])
+            b_total, b_dom = algorithmic_bytes(P, V, nr, N, M)
+            dom_s = dom_ms / max(dom_calls, 1) * 1e-3
+            achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
+            traffic = None
+            tfile = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
+            if os.path.exists(tfile) and workload == "cfg2" and P == CFG2_P:
+                try:
+                    traffic = json.load(open(tfile)).get("render_bwd_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out = {
+                "metric": "rasterized Gaussians/s fwd+bwd @640x480 (200k G)", "value": world * P * args.steps / dt, "unit": "Gaussians/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": (f"configs[1]: {P} static Gaussians, 1 cam @{WIDTH}x{HEIGHT} per GPU, SH degree {sh_degree}, fwd+bwd" if workload == "cfg2" else
+                                        f"SLAM-shaped variant: {P} Gaussians, scale_mean {scale_mean}, SH degree {sh_degree}, 1 cam @{WIDTH}x{HEIGHT}, fwd+bwd")
+                                       + (f", {world} views sharded + RCCL all-reduce of gradients" if world > 1 else ""),
+                           "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding()},
+                "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
+                             "whole_step_algorithmic_bytes": b_total, "whole_step_GBps": b_total / (dt / args.steps) / 1e9,
+                             "pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None,
+                             "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; profiles/r02_*counters*): frac is reported "
+                                     "against the HBM roof because north_star asks for it"},
+                "kernel_us": kern,
+            }
+            if nospec is not None:
+                out["ms_per_step_nonspeculative"] = nospec * 1e3
+        # ---- secondary: a short config #5 iteration on this one GPU (so that the N > 1 lines have a same-workload N = 1 point) ----
+        if world == 1 and workload == "cfg2" and not args.no_secondary:
+            note("secondary: config #5 iteration on one GPU")
+            del scene
+            torch.cuda.empty_cache()
+            s5 = Scene(CFG5_P, dev, 0, 0.005, keyframes=tuple(range(args.keyframes)))
+            sms, step5 = make_cfg5(s5, list(range(args.keyframes)))
+            t5 = timed(step5, 3, 1, barrier) / 3
+            out["config5"] = {"workload": f"configs[4] on ONE GPU: {CFG5_P} Gaussians x {args.keyframes} keyframes, gradients accumulated, fused Adam",
+                              "ms_per_step": t5 * 1e3, "value": CFG5_P * args.keyframes / t5, "unit": "Gaussian-views/s", "steps": 3}
+            del s5, sms
+            torch.cuda.empty_cache()
+    else:   # ---- cfg5 -------------------------------------------------------------------------------------------------------
+        P = args.gaussians or CFG5_P
+        kfs = list(range(args.keyframes))
+        scene = Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs[rank::world]) if world > 1 else tuple(kfs))
+        sms, step = make_cfg5(scene, kfs)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        _C.profile_reset()
+        _C.profile_enable(["render_bwd"])
+        dt = reduce_max(timed(step, args.steps, 0, barrier))
+        _C.profile_enable(False)
+        dom_ms, dom_calls = _C.profile_read()["render_bwd"]
+        kern = kernel_breakdown(step, reps=1)
+        # all-reduce alone (gradients already in the bucket): exposed once per step
+        ar_ms = None
+        if world > 1:
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                sms.bucket.all_reduce_grads()
+            barrier()
+            ar_ms = (time.perf_counter() - t0) / 5 * 1e3
+        facts = [scene.view_facts(k) for k in sms.keyframes]
+        if rank == 0:
+            Vm, Rm = sum(f[0] for f in facts) / len(facts), sum(f[1] for f in facts) / len(facts)
+            M = int(scene.shs.shape[1])
+            b_total, b_dom = algorithmic_bytes(P, Vm, Rm, N, M)
+            dom_s = dom_ms / max(dom_calls, 1) * 1e-3
+            achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
+            out = {
+                "metric": "rasterized Gaussians/s fwd+bwd @640x480 (200k G)", "value": P * len(kfs) * args.steps / dt, "unit": "Gaussians/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"configs[4]: {P} Gaussians, {len(kfs)} synthetic keyframes @{WIDTH}x{HEIGHT} sharded {world}-way ({len(sms.keyframes)} views per rank, "
+                                       f"gradients accumulated locally), ONE all-reduce of {sms.bucket.nbytes} B, fused Adam step; value = Gaussian-views/s",
+                           "views_per_rank": len(sms.keyframes), "allreduce_bytes": sms.bucket.nbytes, "allreduce_mode": sms.mode, "allreduce_ms": ar_ms,
+                           "visible_mean": Vm, "instances_mean": Rm, "pixels": N, "host_binding": _C.binding()},
+                "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
+                             "whole_step_algorithmic_bytes": b_total * len(sms.keyframes)},
+                "kernel_us": kern,
+            }
+        if world > 1 and not args.no_secondary and args.gaussians is None:
+            # the round-1 weak-scaling mode as a secondary figure: one 200k-Gaussian view per rank + all-reduce
+            sw = Scene(CFG2_P, dev, 0, 0.005, keyframes=(rank,), cot_seed=1 + rank)
+            dtw, mode_w, _ = run_cfg2(sw, world, rank, 20, 5, barrier, rank)
+            dtw = reduce_max(dtw)
+            if rank == 0:
+                out["weak_200k"] = {"workload": f"{CFG2_P} Gaussians, one view per rank, all-reduce ({mode_w})", "ms_per_step": dtw / 20 * 1e3,
+                                    "value": world * CFG2_P * 20 / dtw, "scaling": "weak"}
+            del sw
+        if world > 1 and not args.no_secondary:
+            # rank 0 alone runs the whole 64-view iteration: the same-workload single-GPU point the scaling is measured against
+            barrier()
+            if rank == 0:
+                del scene, sms
+                torch.cuda.empty_cache()
+                s1 = Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs))
+                from fused_adam import FusedAdam
+                opt = FusedAdam([{"params": [p], "lr": 0.0} for p in s1.params], lr=0.0, eps=1e-15)
+
+                def step1():
+                    for p_ in s1.params + [s1.theta, s1.rho, s1.means2D]:
+                        p_.grad = None
+                    for k in kfs:
+                        s1.fwd_bwd(k)
+                    opt.step()
+                step1()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    step1()
+                torch.cuda.synchronize()
+                t1 = (time.perf_counter() - t0) / 2
+                out["n1_reference"] = {"ms_per_step": t1 * 1e3, "value": P * len(kfs) / t1, "note": "the same iteration on rank 0's GPU alone, no collective"}
+            barrier()
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and workload in ("cfg2", "long"):
+        out["cpu_baseline"], port = cpu_baselines_in_child(P, sh_degree, scale_mean, args.cpu_baseline_timeout)
+        if port is not None:
+            out["cpu_baseline_port"] = port
     if rank == 0:
-        # workload facts from the run itself
-        with torch.no_grad():
-            nr, color, radii, *_ = _C.rasterize_gaussians(rs.bg, means3D, torch.Tensor([]), opac, scales, rots, 1.0, torch.Tensor([]),
-                                                          rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, rs.tanfovx, rs.tanfovy,
-                                                          HEIGHT, WIDTH, shs, args.sh_degree, rs.campos, False, False)
-        V = int((radii > 0).sum().item())
-        M = int(shs.shape[1])
-        N = WIDTH * HEIGHT
-        b_total, b_dom = algorithmic_bytes(P, V, nr, N, M)
-        dom_s = dom_ms / max(dom_calls, 1) * 1e-3
-        achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tfile) and P == P_GAUSS:
-            try:
-                traffic = json.load(open(tfile)).get("render_bwd_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "rasterized Gaussians/s fwd+bwd @640x480 (200k G)",
-            "value": world * P * args.steps / dt,
-            "unit": "Gaussians/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{P} static Gaussians, 1 cam @{WIDTH}x{HEIGHT} per GPU, SH degree {args.sh_degree}, fwd+bwd"
-                                   + (f", {world} views sharded + RCCL all-reduce of {bucket.nbytes} B grads" if world > 1 else ""),
-                       "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding(),
-                       **({"allreduce": stats.get("allreduce")} if world > 1 else {})},
-            "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
-                         "whole_step_algorithmic_bytes": b_total,
-                         "whole_step_GBps": b_total / (dt / args.steps) / 1e9,
-                         "pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None},
-            "kernel_us": kern,
-        }
-        if not args.no_cpu_baseline:
-            import oracle  # CPU baseline leg only
-
-            t1 = time.perf_counter()
-            o, st = oracle.rasterize_forward(bg=np.ones(3, np.float32), means3D=g["means3D"], opacities=g["opacities"], shs=g["shs"],
-                                             scales=g["scales"], rotations=g["rotations"], viewmatrix=cam.viewmatrix,
-                                             projmatrix=cam.projmatrix, campos=cam.campos, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-                                             image_height=HEIGHT, image_width=WIDTH, sh_degree=args.sh_degree)
-            oracle.rasterize_backward(st, projmatrix_raw=cam.projmatrix_raw, dL_dcolor=gc, dL_ddepth=gd)
-            t_cpu = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": P / t_cpu, "unit": "Gaussians/s", "cores": 1, "kind": "port",
-                                   "sample": f"1 fwd+bwd of the full {P} Gaussians @{WIDTH}x{HEIGHT} workload ({t_cpu:.1f} s), "
-                                             f"oracle/gs_oracle.c single-threaded on {os.cpu_count()} host cores available"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -96,23 +96,44 @@ def test_config5_shape_2m_gaussians_one_shard():
     assert torch.equal(color2, outs[0])
 
 
-@pytest.mark.gpu
-def test_bench_multi_rank_code_path_on_one_gpu():
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks pinned to
-    cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one GPU): exercises rank-dependent keyframes, the in-place
-    all-reduce of the rasterizer's gradient block, the max-over-ranks timing and the single JSON line of rank 0."""
+def _run_bench(extra, nproc=2, port=29617):
     import json
     import subprocess
     import sys
-
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSR_BENCH_DEVICE="0", GSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "20000",
-           "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(nproc)] + extra
+    else:
+        cmd = [sys.executable, os.path.join(repo, "bench.py")] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "all-reduce" in d["config"]["workload"]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_paths_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks pinned to
+    cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one GPU). Default workload at N > 1 = BASELINE config #5 (keyframes
+    sharded, gradients accumulated in the attached bucket, ONE all-reduce, fused Adam) at reduced P; its N = 1 line must agree with
+    the embedded single-GPU reference; the weak-scaling 200k mode stays available as --workload cfg2."""
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--gaussians", "60000", "--keyframes", "8", "--no-cpu-baseline"], nproc=2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    c = d["config"]
+    assert "configs[4]" in c["workload"] and c["views_per_rank"] == 4 and c["allreduce_bytes"] == 60000 * 14 * 4 and c["allreduce_mode"] == "attached"
+    assert d["roofline"]["kernel"] == "render_bwd" and d["roofline"]["achieved"] > 0
+    # both ranks share ONE GPU and the collective goes through gloo (host copies), so the 2-rank step is slower than rank 0 alone
+    assert 0.03 < d["n1_reference"]["ms_per_step"] / d["ms_per_step"] < 3.0, d
+    w = _run_bench(["--steps", "3", "--warmup", "1", "--gaussians", "20000", "--workload", "cfg2", "--no-cpu-baseline"], nproc=2, port=29618)
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["value"] > 0 and "all-reduce" in w["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_carries_config5_and_both_binning_modes():
+    d = _run_bench(["--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--keyframes", "4"], nproc=1)
+    assert d["n_gpus"] == 1 and "configs[1]" in d["config"]["workload"] and d["config"]["instances"] > 500000
+    assert d["ms_per_step_nonspeculative"] >= 0.9 * d["ms_per_step"]
+    assert d["config5"]["ms_per_step"] > 0 and "configs[4]" in d["config5"]["workload"]
