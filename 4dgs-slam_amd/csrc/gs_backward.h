@@ -42,8 +42,12 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     // slots [U0, U1). It is streamed through LDS in coalesced chunks (the whole block loads, every thread then picks its own
     // instances out of LDS, in ascending instance order => fixed summation order). Per-thread scattered 16-byte loads from
     // global memory made this kernel latency-bound before (3 waves per SIMD cannot hide them).
-    constexpr int CH = 512;                      // instances per chunk: 512 x 48 B = 24 KiB (256: +2 us, 1024: +2 us)
-    __shared__ float4 s_slot[CH * 3];
+    // Double buffered: while the block sums chunk c out of one LDS buffer, the global loads of chunk c + 1 are in flight (held in
+    // registers) and go to the other buffer afterwards -- one barrier per chunk, loads overlapped with the sums. With the single
+    // buffer (load, barrier, sum, barrier) the kernel ran at 0.7 TB/s once a block owned several chunks (SLAM-shaped maps: 20-70
+    // instances per Gaussian; profiles/r02_long_lists.json).
+    constexpr int CH = 256;                      // instances per chunk: 256 x 48 B = 12 KiB per buffer
+    __shared__ float4 s_slot[2][CH * 3];
     __shared__ uint32_t s_range[2];
     const uint32_t cnt = visible ? a.tiles_touched[idx] : 0u;
     const uint32_t incl = in_range ? a.point_offsets[idx] : 0u;
@@ -55,19 +59,33 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     const uint32_t U0 = s_range[0], U1 = s_range[1];
     const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], 0).partials;   // partials do not depend on the sorted capacity
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-    for (uint32_t c0 = U0; c0 < U1; c0 += CH) {
-        const uint32_t nch = min((uint32_t)CH, U1 - c0);
+    float4 nx[3];
+    auto fetch = [&](uint32_t c0) {             // this thread's three float4 of the chunk starting at instance c0
+        const uint32_t n3 = min((uint32_t)CH, U1 - c0) * 3u;
         const float4* src = partials + (size_t)c0 * 3;
-        for (uint32_t k = threadIdx.x; k < nch * 3; k += 256) s_slot[k] = src[k];
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; j++) nx[j] = threadIdx.x + 256u * j < n3 ? src[threadIdx.x + 256u * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) s_slot[b][threadIdx.x + 256 * j] = nx[j];
+    };
+    if (U0 < U1) { fetch(U0); stash(0); }
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t c0 = U0; c0 < U1; c0 += CH, buf ^= 1) {
+        const bool more = c0 + CH < U1;
+        if (more) fetch(c0 + CH);
+        const uint32_t nch = min((uint32_t)CH, U1 - c0);
         const uint32_t lo = max(u0, c0), hi = min(u0 + cnt, c0 + nch);
         for (uint32_t u = lo; u < hi; u++) {
-            const float4* sl = s_slot + (u - c0) * 3;
+            const float4* sl = s_slot[buf] + (u - c0) * 3;
             const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
             g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
             g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
             g_b += v2.x; g_d += v2.y;
         }
+        if (more) stash(buf ^ 1);
         __syncthreads();
     }
     if (in_range) {
@@ -80,7 +98,8 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool has_sh = a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr);
+    const bool flow = a.raw.xyz && a.raw.flow_proj1;
+    const bool has_sh = flow ? false : (a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr));
     const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr}
                                 : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr};
     if (!visible) {
@@ -295,7 +314,20 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
             // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
             // effective parameters' gradients of their Gaussian (one Gaussian per slot: plain stores)
             const int sl = raw_slot(a.raw, o);
-            if (sl >= 0) {
+            if (sl >= 0 && flow) {
+                // render_flow (gaussian_renderer/__init__.py:262-284): the colour (g_r, g_g) reaches dx through -ndc(.; proj1) and dx2
+                // through +ndc(.; proj2); the position itself is detached on that path (:262), so dL_dmean3D keeps the geometric part only
+                const f3 base = mk3(a.raw.xyz[3 * o], a.raw.xyz[3 * o + 1], a.raw.xyz[3 * o + 2]);
+                f3 t1 = base, t2 = base;
+                if (a.raw.dx) { t1.x += a.raw.dx[3 * sl]; t1.y += a.raw.dx[3 * sl + 1]; t1.z += a.raw.dx[3 * sl + 2]; }
+                if (a.raw.flow_dx2) { t2.x += a.raw.flow_dx2[3 * sl]; t2.y += a.raw.flow_dx2[3 * sl + 1]; t2.z += a.raw.flow_dx2[3 * sl + 2]; }
+                const f3 j1 = visible ? flow_ndc_vjp(a.raw.flow_proj1, t1, g_r, g_g) : mk3(0.f, 0.f, 0.f);
+                const f3 j2 = visible ? flow_ndc_vjp(a.raw.flow_proj2, t2, g_r, g_g) : mk3(0.f, 0.f, 0.f);
+                if (a.rawg.ddx2) { a.rawg.ddx2[3 * sl] = j2.x; a.rawg.ddx2[3 * sl + 1] = j2.y; a.rawg.ddx2[3 * sl + 2] = j2.z; }
+                if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0] - j1.x; a.rawg.ddx[3 * sl + 1] = dmean[1] - j1.y; a.rawg.ddx[3 * sl + 2] = dmean[2] - j1.z; }
+                if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
+                if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
+            } else if (sl >= 0) {
                 if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0]; a.rawg.ddx[3 * sl + 1] = dmean[1]; a.rawg.ddx[3 * sl + 2] = dmean[2]; }
                 if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
                 if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }

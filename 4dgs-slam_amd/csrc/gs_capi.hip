@@ -279,13 +279,16 @@ static RawInputs to_device_view(const gsr_raw_inputs* in)
         r.xyz = in->xyz; r.log_scales = in->log_scales; r.scale_dim = in->scale_dim; r.raw_rot = in->raw_rotations;
         r.logit_opacity = in->logit_opacity; r.f_dc = in->features_dc; r.f_rest = in->features_rest;
         r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr; r.gather = in->gather;
+        r.flow_dx2 = in->flow_dx2; r.flow_proj1 = in->flow_proj1; r.flow_proj2 = in->flow_proj2;
     }
     return r;
 }
 static bool raw_inputs_ok(const gsr_raw_inputs* in, int M)
 {
+    const bool flow = in->flow_proj1 != nullptr;
+    if (flow && (!in->flow_proj2 || M != 1 || (in->flow_dx2 && !in->dyn_slot))) return false;
     return in->xyz && in->log_scales && (in->scale_dim == 1 || in->scale_dim == 3) && in->raw_rotations && in->logit_opacity &&
-           in->features_dc && (M == 1 || in->features_rest) && ((!in->dx && !in->ds && !in->dr) || in->dyn_slot);
+           (flow || (in->features_dc && (M == 1 || in->features_rest))) && ((!in->dx && !in->ds && !in->dr) || in->dyn_slot);
 }
 
 static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
@@ -381,9 +384,13 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             }
         }
     }
-    const bool speculate = t_speculate && t_last_R_alloc && t_last_max_tile <= (uint32_t)SORT_LDS_CAP && !debug && P > 0;
+    const bool speculate = t_speculate && t_last_R_alloc && !debug && P > 0;
     const size_t cap = speculate ? t_last_R_alloc + t_last_R_alloc / 8 + 4096 : 0;
-    const uint32_t cap_tile = t_last_max_tile * 5 / 4 > (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_LDS_CAP : (uint32_t)SORT_SMALL_CAP;
+    // longest tile list the speculative launches are sized for: decides which sort kernels run (and the chunk grid of the long-list sort)
+    const uint32_t want_tile = t_last_max_tile + t_last_max_tile / 4;
+    const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
+                            : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
+                            : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
     {
         ScopedKernelTimer tm(K_SCAN, stream);
         if (!t_mailbox) {
@@ -401,7 +408,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
 
     // scatter -> sort -> render on a binning buffer laid out for carve_R instances / cap_sorted sorted entries
     auto enqueue_binning_and_render = [&](char* chunk, size_t carve_R, size_t cap_sorted, bool spec, bool any_padding,
-                                          bool long_lists) -> int {
+                                          uint32_t longest_list) -> int {
+        const bool long_lists = longest_list > (uint32_t)SORT_SMALL_CAP;
         const BinningPtrs bin = carve_binning(chunk, carve_R, cap_sorted);
         uint32_t* const chk = spec ? geom.header : nullptr;
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
@@ -421,6 +429,12 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             if (long_lists)
                 hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
                                    bin.keys, bin.inst_gauss, bin.sorted, chk);
+            if (longest_list > (uint32_t)SORT_LDS_CAP) {   // chunk-wise LDS sort + rank by counting (gs_forward.h F4b)
+                const dim3 g((unsigned)T, (longest_list + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP);
+                hipLaunchKernelGGL(sort_long_chunks_kernel, g, dim3(256), 0, stream, img.ranges, bin.keys, chk);
+                hipLaunchKernelGGL(rank_long_chunks_kernel, g, dim3(256), 0, stream, img.ranges, (const uint64_t*)bin.keys,
+                                   (const uint32_t*)bin.inst_gauss, bin.sorted, chk);
+            }
         }
         GSR_STAGE("sort_tiles");
         {   // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
@@ -438,8 +452,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     if (speculate) {
         bchunk = binning_alloc(binning_user, binning_bytes(cap, cap));
         if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
-        // a list longer than SORT_LDS_CAP needs padded segments (R_alloc != R) and pre-filled keys: cap_tile never allows that here
-        const int rc = enqueue_binning_and_render(bchunk, cap, cap, true, false, cap_tile > (uint32_t)SORT_SMALL_CAP);
+        const int rc = enqueue_binning_and_render(bchunk, cap, cap, true, false, cap_tile);
         if (rc) return rc;
     }
     if (speculate && t_lazy) return (int)(cap > 0x7fffffffull ? 0x7fffffffull : cap);   // no wait: see t_lazy
@@ -456,7 +469,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     if (R > 0) {
         bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, (size_t)R_alloc));
         if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
-        const int rc = enqueue_binning_and_render(bchunk, (size_t)R, (size_t)R_alloc, false, R_alloc != R, max_tile_list > (uint32_t)SORT_SMALL_CAP);
+        const int rc = enqueue_binning_and_render(bchunk, (size_t)R, (size_t)R_alloc, false, R_alloc != R, max_tile_list);
         if (rc) return rc;
     } else {
         if (!bchunk) bchunk = binning_alloc(binning_user, binning_bytes(0, 0));
@@ -517,7 +530,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // dL_dtau_sum is given): the kernel then keeps them in registers only. gsr_backward itself requires all of them.
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || (!means3D && !raw) || !viewmatrix ||
         !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || (!dL_dtau && !dL_dtau_sum) ||
-        (raw && (!raw_inputs_ok(raw, M) || !rawg || !dL_dscale || !dL_drot || !rawg->features_dc || (M > 1 && !rawg->features_rest)))) {
+        (raw && (!raw_inputs_ok(raw, M) || !rawg || !dL_dscale || !dL_drot ||
+                 (!raw->flow_proj1 && (!rawg->features_dc || (M > 1 && !rawg->features_rest)))))) {
         g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
@@ -547,7 +561,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
     a.raw = to_device_view(raw);
     a.rawg = RawGrads{};
-    if (raw) { a.rawg.f_dc = rawg->features_dc; a.rawg.f_rest = rawg->features_rest; a.rawg.ddx = rawg->dx; a.rawg.dds = rawg->ds; a.rawg.ddr = rawg->dr; a.rawg.scale_dim = raw->scale_dim; }
+    if (raw) { a.rawg.f_dc = rawg->features_dc; a.rawg.f_rest = rawg->features_rest; a.rawg.ddx = rawg->dx; a.rawg.dds = rawg->ds; a.rawg.ddr = rawg->dr; a.rawg.scale_dim = raw->scale_dim; a.rawg.ddx2 = rawg->dx2; }
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
         hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);

@@ -213,8 +213,10 @@ struct RawInputs {
     const float* xyz; const float* log_scales; int scale_dim; const float* raw_rot; const float* logit_opacity;
     const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;
     const int* gather;   // optional: rasterized Gaussian i reads row gather[i] of the raw tensors (render()'s boolean mask, :179-191)
+    const float* flow_dx2; const float* flow_proj1; const float* flow_proj2;   // flow mode (render_flow, :229-361): see include/gs_rasterizer.h
 };
-struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; };
+struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; float* ddx2; };
+
 struct ShView {    // SH coefficients of one Gaussian: [k] with k = 3 * coefficient + channel
     const float* dc; const float* rest;
     __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
@@ -227,6 +229,26 @@ struct ShOut {
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// ndc(p; M).xy of render_flow (gaussian_renderer/__init__.py:268-282): row-vector convention, w + 1e-7; optionally the 2x3 Jacobian
+// d ndc / d p applied to a cotangent (gu, gv): returns J^T (gu, gv).
+__device__ __forceinline__ void flow_ndc(const float* __restrict__ M, f3 p, float& u, float& v)
+{
+    const float hx = p.x * M[0] + p.y * M[4] + p.z * M[8] + M[12], hy = p.x * M[1] + p.y * M[5] + p.z * M[9] + M[13];
+    const float hw = p.x * M[3] + p.y * M[7] + p.z * M[11] + M[15];
+    const float iw = 1.0f / (hw + 0.0000001f);
+    u = hx * iw; v = hy * iw;
+}
+__device__ __forceinline__ f3 flow_ndc_vjp(const float* __restrict__ M, f3 p, float gu, float gv)
+{
+    float u, v;
+    flow_ndc(M, p, u, v);
+    const float hw = p.x * M[3] + p.y * M[7] + p.z * M[11] + M[15];
+    const float iw = 1.0f / (hw + 0.0000001f);
+    // d u / d p_i = (M[4 i + 0] - u M[4 i + 3]) iw, same for v with column 1
+    return mk3(((M[0] - u * M[3]) * gu + (M[1] - v * M[3]) * gv) * iw, ((M[4] - u * M[7]) * gu + (M[5] - v * M[7]) * gv) * iw,
+               ((M[8] - u * M[11]) * gu + (M[9] - v * M[11]) * gv) * iw);
+}
 
 __device__ __forceinline__ size_t raw_row(const RawInputs& r, size_t i) { return r.gather ? (size_t)r.gather[i] : i; }   // row of the raw tensors
 __device__ __forceinline__ int raw_slot(const RawInputs& r, size_t row) { return r.dyn_slot ? r.dyn_slot[row] : -1; }

@@ -30,12 +30,13 @@ _f, _i, _vp = C.c_float, C.c_int, C.c_void_p
 
 class _RawInputs(C.Structure):     # gsr_raw_inputs
     _fields_ = [("xyz", _vp), ("log_scales", _vp), ("scale_dim", _i), ("raw_rotations", _vp), ("logit_opacity", _vp),
-                ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp), ("gather", _vp)]
+                ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp), ("gather", _vp),
+                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp)]
 
 
 class _RawGrads(C.Structure):      # gsr_raw_grads
     _fields_ = [("xyz", _vp), ("log_scales", _vp), ("raw_rotations", _vp), ("logit_opacity", _vp), ("features_dc", _vp),
-                ("features_rest", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp)]
+                ("features_rest", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp), ("dx2", _vp)]
 
 
 _declared = False
@@ -213,3 +214,88 @@ def rasterize_gaussians_raw(raster_settings, xyz, means2D, log_scales, raw_rotat
         raise RuntimeError("rasterize_gaussians_raw: dx / ds / dr need dyn_slot")
     return _RasterizeGaussiansRaw.apply(xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, dyn_slot,
                                         dx, ds, dr, theta, rho, raster_settings, gather)
+
+
+# ---- render_flow(), fused (gaussian_renderer/__init__.py:229-361 of the reference) ---------------------------------------------------
+class _RasterizeFlowRaw(torch.autograd.Function):
+    """(u, v, mask) flow image of render_flow from raw parameters: the two projections, the NDC difference and the mask channel are
+    computed by preprocess_fwd, rasterized like colors_precomp with bg = 0, and the colour's gradient is pushed through both projections
+    by geometry_bwd. Differentiable in xyz (geometric path only, :261-262,305), d_xyz1 (both paths), d_xyz2 (colour path), d_scaling1,
+    d_rotation1; opacity and the scale / rotation bases are constants (:307,326-334)."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, log_scales, raw_rot, logit_opacity, dyn_slot, dx1, dx2, ds, dr, proj1, proj2, rs):
+        _C._require_device(xyz, "_xyz")
+        dev = xyz.device
+        lib = _lib()
+        P, H, W = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width)
+        img = torch.empty((_C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        color, depth, opacity = img[:_C.NUM_CHANNELS], img[_C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[_C.NUM_CHANNELS + 1:]
+        ints = torch.empty((2, P), dtype=torch.int32, device=dev)
+        radii, n_touched = ints[0], ints[1]
+        geom, binning, imgbuf = _C._Arena(dev), _C._Arena(dev), _C._Arena(dev)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, dx1, ds, dr, keep)
+        desc.features_dc = None
+        desc.flow_dx2, desc.flow_proj1, desc.flow_proj2 = _f32(dx2, "d_xyz2", keep), _f32(proj1, "proj1", keep), _f32(proj2, "proj2", keep)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_forward_raw(
+                geom.cb, None, binning.cb, None, imgbuf.cb, None, P, 0, 1, _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
+                _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.campos, "campos", keep),
+                float(rs.tanfovx), float(rs.tanfovy), color.data_ptr(), depth.data_ptr(), opacity.data_ptr(), radii.data_ptr(),
+                n_touched.data_ptr(), int(bool(rs.debug)), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_forward_raw (flow)")
+        ctx.rs, ctx.num_rendered = rs, rc
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, dyn_slot, dx1, dx2, ds, dr, proj1, proj2, radii, geom.tensor, binning.tensor, imgbuf.tensor)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_depth, _g_opacity, _g_touched):
+        rs = ctx.rs
+        (xyz, log_scales, raw_rot, logit_opacity, dyn_slot, dx1, dx2, ds, dr, proj1, proj2, radii, geom, binning, imgbuf) = ctx.saved_tensors
+        dev = xyz.device
+        lib = _lib()
+        P, H, W, S = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width), int(log_scales.shape[-1])
+        g_color = xyz.new_zeros((3, H, W)) if g_color is None else g_color.to(torch.float32)
+        g_depth = xyz.new_zeros((1, H, W)) if g_depth is None else g_depth.to(torch.float32)
+        # xyz | scratch for the constants' gradients the kernel writes anyway (log-scale, rotation, opacity) | means2D | tau
+        flat = torch.empty((P * (3 + S + 4 + 1 + 3) + 6,), dtype=torch.float32, device=dev)
+        o = 0
+        def take(w_):
+            nonlocal o
+            v = flat[o:o + P * w_]
+            o += P * w_
+            return v
+        g_xyz, g_ls, g_rot, g_logit, g_m2d = take(3).view(P, 3), take(S), take(4), take(1), take(3).view(P, 3)
+        tau = flat[o:o + 6]
+        Z = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
+        g_dx1, g_dx2, g_ds, g_dr = Z(dx1), Z(dx2), Z(ds), Z(dr)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, dx1, ds, dr, keep)
+        desc.features_dc = None
+        desc.flow_dx2, desc.flow_proj1, desc.flow_proj2 = _f32(dx2, "d_xyz2", keep), _f32(proj1, "proj1", keep), _f32(proj2, "proj2", keep)
+        out = _RawGrads()
+        out.xyz, out.log_scales, out.raw_rotations, out.logit_opacity = g_xyz.data_ptr(), g_ls.data_ptr(), g_rot.data_ptr(), g_logit.data_ptr()
+        p = lambda t: None if t is None else t.data_ptr()
+        out.dx, out.ds, out.dr, out.dx2 = p(g_dx1), p(g_ds), p(g_dr), p(g_dx2)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward_raw(
+                P, 0, 1, int(ctx.num_rendered), _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
+                _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.projmatrix_raw, "projmatrix_raw", keep),
+                _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(),
+                imgbuf.data_ptr(), _f32(g_color, "dL_dcolor", keep), _f32(g_depth, "dL_ddepth", keep), g_m2d.data_ptr(), C.byref(out),
+                tau.data_ptr(), int(bool(rs.debug)), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_backward_raw (flow)")
+        # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, dyn_slot, dx1, dx2, ds, dr, proj1, proj2, rs
+        return (g_xyz, g_m2d, None, None, None, None, g_dx1, g_dx2, g_ds, g_dr, None, None, None)
+
+
+def rasterize_flow_raw(raster_settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, dyn_slot, d_xyz1, d_xyz2, d_scaling1, d_rotation1,
+                       proj1, proj2):
+    """render_flow's rasterizer call from raw parameters (see _RasterizeFlowRaw). raster_settings: camera 1, bg = 0, sh_degree 0."""
+    return _RasterizeFlowRaw.apply(xyz, means2D, log_scales, raw_rotations, logit_opacity, dyn_slot, d_xyz1, d_xyz2, d_scaling1, d_rotation1,
+                                   proj1, proj2, raster_settings)

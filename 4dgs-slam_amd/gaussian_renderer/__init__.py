@@ -207,11 +207,49 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     }
 
 
+def _flow_fused_ok(pc) -> bool:
+    if not FUSED_PROLOGUE or _raw is None or os.environ.get("GSR_FUSED_FLOW", "1") == "0":
+        return False
+    try:
+        raws = (pc._xyz, pc._scaling, pc._rotation, pc._opacity)
+        acts = (pc.scaling_activation is torch.exp and pc.opacity_activation is torch.sigmoid and pc.rotation_activation is torch.nn.functional.normalize)
+    except AttributeError:
+        return False
+    # render_flow has no isotropic expansion in the reference (its [P,1] scaling cannot take a [K,3] d_scaling): anisotropic models only
+    return acts and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in raws) and pc._scaling.shape[-1] == 3
+
+
+def _dyn_slot(pc):
+    """int32 slot map of pc.dygs, cached on the mask tensor (it only changes when the model is rebuilt)."""
+    m = pc.dygs
+    s = getattr(m, "_gsr_slot", None)
+    if s is None:
+        s = _raw.dyn_slot_from_mask(m)
+        try:
+            m._gsr_slot = s
+        except Exception:
+            pass
+    return s
+
+
 def render_flow(pc, viewpoint_camera1, viewpoint_camera2, d_xyz1, d_xyz2, d_rotation1, d_scaling1, scaling_modifier=1.0,
                 compute_cov3D_python=False, scale_const=None, d_rot_as_res=True, **kwargs):
     """Rasterize (NDC flow u, NDC flow v, dynamic mask) as colours (reference :229-361). Flow is computed from DETACHED
     canonical positions plus the attached deltas (:262); the rasterized means stay attached to pc.get_xyz (:261,305)."""
     screenspace_points = _screenspace_points(pc)
+    cam2 = viewpoint_camera2 if viewpoint_camera2 is not None else viewpoint_camera1
+    if (_flow_fused_ok(pc) and scale_const is None and not compute_cov3D_python and d_rot_as_res
+            and all(isinstance(t, torch.Tensor) for t in (d_xyz1, d_xyz2, d_rotation1, d_scaling1))):
+        # fused route (diff_gaussian_rasterization/raw.py rasterize_flow_raw): both projections, the NDC flow, the mask channel and all
+        # scatter-adds happen inside preprocess_fwd / geometry_bwd -- ~15 elementwise torch kernels and 4 index_puts per call less,
+        # and the dynamic mapping loop calls this twice per view (utils/slam_backend.py:486,496)
+        rs = _settings(viewpoint_camera1, torch.zeros(3, device=pc.get_xyz.device), scaling_modifier, 0)
+        slot = _dyn_slot(pc)
+        rendered_image, radii, rendered_depth, rendered_alpha, n_touched = _raw.rasterize_flow_raw(
+            rs, pc._xyz, screenspace_points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, d_xyz1, d_xyz2, d_scaling1,
+            d_rotation1, viewpoint_camera1.full_proj_transform, cam2.full_proj_transform)
+        return {"render": rendered_image, "depth": rendered_depth, "alpha": rendered_alpha, "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0, "radii": radii}
     canonical_xyz = pc.get_xyz.clone()
     base = canonical_xyz.detach()
     dxyz1 = _scatter_delta(base, pc.dygs, d_xyz1)

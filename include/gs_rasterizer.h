@@ -122,6 +122,14 @@ typedef struct gsr_raw_inputs {
     const float* dr;             /* [K,4] or NULL */
     const int* gather;           /* [P] or NULL: rasterized Gaussian i is row gather[i] of the tensors above -- the boolean `mask`
                                     selection of render() (gaussian_renderer/__init__.py:179-191), P = number of selected rows */
+    /* Flow mode (flow_proj1 != NULL): render_flow() of gaussian_renderer/__init__.py:229-361. The rasterized colour of a Gaussian is
+     *   (ndc(xyz* + dx2[slot]; flow_proj2) - ndc(xyz* + dx[slot]; flow_proj1)).xy, 1 if slot >= 0 else 0)          (:262-284)
+     * with ndc(p; M) = (p_h M).xy / ((p_h M).w + 1e-7) and xyz* the DETACHED position: the colour's gradient reaches dx and dx2 only,
+     * the geometric gradient of the mean reaches xyz and dx as usual (:261,305). Opacity and the bases of scale / rotation are
+     * constants in this mode (:307,326-334): only the ds / dr gradients are meaningful; features_* are not read (pass NULL, M = 1, D = 0). */
+    const float* flow_dx2;       /* [K,3] second displacement (d_xyz2), or NULL = zero */
+    const float* flow_proj1;     /* [4,4] full_proj_transform of camera 1 (row-vector convention, like projmatrix) */
+    const float* flow_proj2;     /* [4,4] of camera 2 */
 } gsr_raw_inputs;
 
 typedef struct gsr_raw_grads {   /* all fully written (with `gather`: only the selected rows -- zero-fill them first); dx / ds / dr may be
@@ -133,6 +141,7 @@ typedef struct gsr_raw_grads {   /* all fully written (with `gather`: only the s
     float* features_dc;          /* [P,1,3] */
     float* features_rest;        /* [P,M-1,3] (NULL allowed when M == 1) */
     float* dx; float* ds; float* dr;   /* [K,3], [K,3], [K,4]: rows of slots that no Gaussian refers to are left untouched */
+    float* dx2;                  /* [K,3] flow mode: gradient of flow_dx2 (NULL allowed) */
 } gsr_raw_grads;
 
 /* gsr_forward with the inputs described by `in` (no colors_precomp / cov3D_precomp / prefiltered in this variant). */

@@ -112,3 +112,94 @@ def test_end_to_end_fit_reduces_the_loss():
         history.append(float(loss.detach()))
     assert all(np.isfinite(history)) and history[-1] < 0.6 * history[0], (history[0], history[-1])
     assert float(m.denom.max()) == 60 * 3 and float(m.xyz_gradient_accum.sum()) > 0
+
+
+class _RawModelFromGolden:
+    """A reference-shaped model (raw parameters + activations) whose ACTIVATED values are the golden fixture's."""
+
+    def __init__(self, fx, isotropic=False):
+        L = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda", requires_grad=True)
+        self._xyz = L(fx["means3D"])
+        self._scaling = L(np.log(fx["scales"]))
+        self._rotation = L(fx["rotations"])                                   # unit quaternions: normalize() is the identity on them
+        op = fx["opacities"].astype(np.float64)
+        self._opacity = L(np.log(op / (1 - op)))
+        self._features_dc, self._features_rest = L(fx["shs"][:, :1]), L(fx["shs"][:, 1:])
+        self.dygs = torch.tensor(fx["dygs"], device="cuda")
+        self.active_sh_degree, self.max_sh_degree = int(fx["sh_degree"]), int(fx["max_sh_degree"])
+        self.scaling_activation, self.opacity_activation = torch.exp, torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s.scaling_activation(s._scaling))
+    get_rotation = property(lambda s: s.rotation_activation(s._rotation))
+    get_opacity = property(lambda s: s.opacity_activation(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+
+def test_fused_render_flow_reproduces_the_reference_golden(golden_dir):
+    """render_flow through the fused raw route (projections, NDC flow, mask channel, scatter-adds and their chain
+    rules inside the kernels) against golden_render_flow.npz, which was recorded from the reference's UNMODIFIED render_flow()."""
+    import os
+    import gaussian_renderer as gr
+    from test_hip_wrapper_golden import _cam
+    fx = np.load(os.path.join(golden_dir, "golden_render_flow.npz"))
+    W, H = int(fx["W"]), int(fx["H"])
+    cam, cam2 = _cam(fx["cam_k"], W, H, 3.0), _cam(fx["cam2_k"], W, H, 4.0)
+    m = _RawModelFromGolden(fx)
+    assert gr._flow_fused_ok(m)
+    L = lambda k: torch.tensor(fx[k], device="cuda", requires_grad=True)
+    ex = dict(dx=L("dx"), dx2=L("dx2"), ds=L("ds"), dr=L("dr"))
+    calls = {"n": 0}
+    real = gr._raw.rasterize_flow_raw
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    gr._raw.rasterize_flow_raw = spy
+    try:
+        res = gr.render_flow(m, cam, cam2, ex["dx"], ex["dx2"], ex["dr"], ex["ds"])
+    finally:
+        gr._raw.rasterize_flow_raw = real
+    assert calls["n"] == 1                                                  # the fused route was taken
+    ((res["render"] * torch.tensor(fx["gc"], device="cuda")).sum() + (res["depth"] * torch.tensor(fx["gd"], device="cuda")).sum()).backward()
+    for k in ("render", "depth", "alpha"):
+        assert rel_l1(res[k].detach().cpu().numpy(), fx["out_" + k]) <= 1e-4, k
+    assert (res["radii"].cpu().numpy() == fx["out_radii"]).all()
+    assert (res["visibility_filter"].cpu().numpy() == fx["out_visibility_filter"]).all()
+    assert rel_l1(m._xyz.grad.cpu().numpy(), fx["grad_xyz"]) <= 1e-3
+    for name in ("_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+        assert getattr(m, name).grad is None, name                          # constants of render_flow (reference :307,326-334)
+    assert rel_l1(res["viewspace_points"].grad.cpu().numpy(), fx["grad_viewspace"]) <= 1e-3
+    for k, v in ex.items():
+        assert rel_l1(v.grad.cpu().numpy(), fx["extra_" + k]) <= 1e-3, k
+
+
+def test_fused_render_flow_matches_the_torch_chain_at_scale(isotropic=False):
+    import gaussian_renderer as gr
+    cam = make_camera(320, 240)
+    from synthetic_scene import keyframe_pose
+    R2, t2 = keyframe_pose(3)
+    cam_b = make_camera(320, 240, R=R2, t=t2)
+    g = make_gaussians(20000, cam, seed=41, sh_degree=0)
+    gc, gd = make_cotangents(cam, seed=42)
+    out = {}
+    for fused in (False, True):
+        m = _GaussianModel(g, isotropic, 0.25, seed=43)
+        v1, v2 = _camera(cam), _camera(cam_b)
+        K = int(m.dygs.sum())
+        rng = np.random.default_rng(44)
+        mk = lambda n, s: torch.tensor(rng.normal(scale=s, size=(K, n)).astype(np.float32), device="cuda", requires_grad=True)
+        d1, d2, dr, ds = mk(3, 0.02), mk(3, 0.03), mk(4, 0.05), mk(3, 0.001)
+        os_env = __import__("os").environ
+        os_env["GSR_FUSED_FLOW"] = "1" if fused else "0"
+        try:
+            res = gr.render_flow(m, v1, v2, d1, d2, dr, ds)
+        finally:
+            os_env.pop("GSR_FUSED_FLOW", None)
+        ((res["render"] * torch.tensor(gc, device="cuda")).sum() + (res["depth"] * torch.tensor(gd, device="cuda")).sum()).backward()
+        out[fused] = (res, dict(xyz=m._xyz.grad, d1=d1.grad, d2=d2.grad, dr=dr.grad, ds=ds.grad, vs=res["viewspace_points"].grad))
+    for k in ("render", "depth", "alpha"):
+        assert rel_l1(out[True][0][k].detach().cpu().numpy(), out[False][0][k].detach().cpu().numpy()) <= 1e-5, k
+    assert torch.equal(out[True][0]["radii"], out[False][0]["radii"])
+    for k in out[True][1]:
+        assert rel_l1(out[True][1][k].cpu().numpy(), out[False][1][k].cpu().numpy()) <= 3e-4, k

@@ -108,11 +108,12 @@ def test_depth_ties_keep_index_order():
     _check(compare(oh, gh, oo, go))
 
 
-def test_huge_tile_list_uses_global_sort_path():
-    """More than SORT_LDS_CAP (4096) instances in one tile: the power-of-two padded global-memory bitonic path."""
-    cam = make_camera(24, 16)           # 2 tiles, the left one holds most of the 9000 Gaussians
-    P = 9000
+@pytest.mark.parametrize("P", [9000, 21000])
+def test_huge_tile_list_uses_global_sort_path(P):
+    """More than SORT_LDS_CAP (4096) instances in one tile: chunk-wise LDS sort + rank by counting (3 and 6 chunks; the last one partial)."""
+    cam = make_camera(24, 16)           # 2 tiles, the left one holds most of the Gaussians
     g = make_gaussians(P, cam, seed=3, scale_mean=0.004)
+    g["means3D"][::7, 2] = g["means3D"][3, 2]                  # many equal depths: ties must keep the instance order across chunks
     g["means3D"][:, 0] = -np.abs(g["means3D"][:, 0]) * 0.6
     g["opacities"][:] = 0.02                                   # keep transmittance alive through the whole list
     gc, gd = make_cotangents(cam)
