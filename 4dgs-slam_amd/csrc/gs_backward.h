@@ -70,10 +70,42 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 #pragma unroll
         for (int j = 0; j < 3; j++) s_slot[b][threadIdx.x + 256 * j] = nx[j];
     };
-    if (U0 < U1) { fetch(U0); stash(0); }
+    // Blocks whose Gaussians own many instances each (SLAM-shaped maps: 20-70 tiles per Gaussian) do not go through the LDS chunks:
+    // a 256-slot chunk then belongs to three or four Gaussians, i.e. three or four threads walk it one dependent ds_read after the
+    // other while the rest of the block waits (0.5 TB/s at 72 instances per Gaussian). Instead every wave takes its 64 Gaussians in
+    // turn and sums one Gaussian's slots with all lanes (lane l: slots l, l + 64, ...; coalesced 48-byte rows), reduces the ten
+    // values with the transposed butterfly of gs_device.h and hands the totals to the owning lane. Fixed order => still bit-reproducible.
+    constexpr uint32_t HEAVY_SLOTS_PER_GAUSSIAN = 8;
+    const bool heavy_block = (U1 - U0) > 256u * HEAVY_SLOTS_PER_GAUSSIAN;     // uniform
+    if (heavy_block) {
+        const int lane = lane_id();
+        const WaveSelectMasks wsm = wave_select_masks();
+        for (int h = 0; h < 64; h++) {
+            const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
+            if (hc == 0) continue;
+            float s0 = 0.f, s5 = 0.f;
+            f2v a12 = {0.f, 0.f}, a34 = {0.f, 0.f}, a67 = {0.f, 0.f}, a89 = {0.f, 0.f};
+            for (uint32_t k = (uint32_t)lane; k < hc; k += 64) {
+                const float4* sl = partials + (size_t)(hu + k) * 3;
+                const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
+                s0 += v0.x; a12 += f2v{v0.y, v0.z}; a34 += f2v{v0.w, v1.x}; s5 += v1.y; a67 += f2v{v1.z, v1.w}; a89 += f2v{v2.x, v2.y};
+            }
+            unsigned long long dummy_proc = 0; uint32_t dummy_addr;
+            const float tot = wave_sum10_transposed(wsm, s0, a12, a34, s5, a67, a89, dummy_proc, 0, 0u, 0, dummy_addr);
+            // lanes holding total k (wave_sum10_slot_of_lane): 0 -> 2, 1 -> 0, 2 -> 1, 3 -> 32, 4 -> 33, 5 -> 34, 6 -> 16, 7 -> 17, 8 -> 48, 9 -> 49
+            const int ti = __float_as_int(tot);
+            const float t0 = __int_as_float(__builtin_amdgcn_readlane(ti, 2)), t1 = __int_as_float(__builtin_amdgcn_readlane(ti, 0));
+            const float t2 = __int_as_float(__builtin_amdgcn_readlane(ti, 1)), t3 = __int_as_float(__builtin_amdgcn_readlane(ti, 32));
+            const float t4 = __int_as_float(__builtin_amdgcn_readlane(ti, 33)), t5 = __int_as_float(__builtin_amdgcn_readlane(ti, 34));
+            const float t6 = __int_as_float(__builtin_amdgcn_readlane(ti, 16)), t7 = __int_as_float(__builtin_amdgcn_readlane(ti, 17));
+            const float t8 = __int_as_float(__builtin_amdgcn_readlane(ti, 48)), t9 = __int_as_float(__builtin_amdgcn_readlane(ti, 49));
+            if (lane == h) { g_m2x = t0; g_m2y = t1; g_cx = t2; g_cy = t3; g_cw = t4; g_op = t5; g_r = t6; g_g = t7; g_b = t8; g_d = t9; }
+        }
+    }
+    if (!heavy_block && U0 < U1) { fetch(U0); stash(0); }
     __syncthreads();
     int buf = 0;
-    for (uint32_t c0 = U0; c0 < U1; c0 += CH, buf ^= 1) {
+    for (uint32_t c0 = U0; !heavy_block && c0 < U1; c0 += CH, buf ^= 1) {
         const bool more = c0 + CH < U1;
         if (more) fetch(c0 + CH);
         const uint32_t nch = min((uint32_t)CH, U1 - c0);

@@ -426,14 +426,23 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             if (!t_fuse_sort)
                 hipLaunchKernelGGL((sort_tiles_kernel<SORT_SMALL_CAP, 0>), dim3(T), dim3(256), 0, stream, T, img.ranges, bin.keys,
                                    bin.inst_gauss, bin.sorted, chk);
-            if (long_lists)
+            // dev knobs: GSR_LONG_FROM = list length above which the chunk + rank path is taken (default SORT_LDS_CAP; 1024 drops the
+            // one-block-per-tile LDS sort of the 1024..4096 lists), GSR_LONG_CHUNK = its chunk size (1024 / 2048 / 4096)
+            static const uint32_t long_from = getenv("GSR_LONG_FROM") ? (uint32_t)atoi(getenv("GSR_LONG_FROM")) : (uint32_t)SORT_LDS_CAP;
+            static const int long_chunk = getenv("GSR_LONG_CHUNK") ? atoi(getenv("GSR_LONG_CHUNK")) : SORT_LDS_CAP;
+            if (long_lists && long_from > (uint32_t)SORT_SMALL_CAP)
                 hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
                                    bin.keys, bin.inst_gauss, bin.sorted, chk);
-            if (longest_list > (uint32_t)SORT_LDS_CAP) {   // chunk-wise LDS sort + rank by counting (gs_forward.h F4b)
-                const dim3 g((unsigned)T, (longest_list + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP);
-                hipLaunchKernelGGL(sort_long_chunks_kernel, g, dim3(256), 0, stream, img.ranges, bin.keys, chk);
-                hipLaunchKernelGGL(rank_long_chunks_kernel, g, dim3(256), 0, stream, img.ranges, (const uint64_t*)bin.keys,
-                                   (const uint32_t*)bin.inst_gauss, bin.sorted, chk);
+            if (longest_list > long_from) {   // chunk-wise LDS sort + rank by counting (gs_forward.h F4b)
+#define GSR_LONG(CK)                                                                                                                   \
+    do {                                                                                                                              \
+        const dim3 g((unsigned)T, (longest_list + (uint32_t)(CK) - 1) / (uint32_t)(CK));                                               \
+        hipLaunchKernelGGL((sort_long_chunks_kernel<CK>), g, dim3(256), 0, stream, img.ranges, bin.keys, chk, long_from);              \
+        hipLaunchKernelGGL((rank_long_chunks_kernel<CK>), g, dim3(256), 0, stream, img.ranges, (const uint64_t*)bin.keys,               \
+                           (const uint32_t*)bin.inst_gauss, bin.sorted, chk, long_from);                                               \
+    } while (0)
+                if (long_chunk == 1024) GSR_LONG(1024); else if (long_chunk == 2048) GSR_LONG(2048); else GSR_LONG(4096);
+#undef GSR_LONG
             }
         }
         GSR_STAGE("sort_tiles");

@@ -552,6 +552,8 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys)
 __device__ __forceinline__ void bitonic_sort_lds_pow2(uint64_t* keys, uint32_t npad)
 {
     switch (npad) {
+        case 4096: bitonic_sort_lds<4096>(keys); break;
+        case 2048: bitonic_sort_lds<2048>(keys); break;
         case 1024: bitonic_sort_lds<1024>(keys); break;
         case 512: bitonic_sort_lds<512>(keys); break;
         case 256: bitonic_sort_lds<256>(keys); break;
@@ -617,14 +619,16 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2
 // instance id is part of the key). Work grows with (number of chunks)^2 per tile, which stays small next to what the compositing
 // kernels do with such a list; the global-memory bitonic network this replaces took 2.0 ms for 6.5 M instances (now 0.15 ms).
 // grid = (tiles, chunks of the longest list the launch is sized for).
-__global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header)
+template <int CHUNKK>
+__global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header,
+                                                               uint32_t lower)
 {
-    __shared__ uint64_t s_keys[SORT_LDS_CAP];
+    __shared__ uint64_t s_keys[CHUNKK];
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;
     const uint2 r = ranges[blockIdx.x];
-    const uint32_t n = r.y - r.x, c0 = blockIdx.y * (uint32_t)SORT_LDS_CAP;
-    if (n <= (uint32_t)SORT_LDS_CAP || c0 >= n) return;
-    const uint32_t m = min((uint32_t)SORT_LDS_CAP, n - c0), mpad = next_pow2(m);
+    const uint32_t n = r.y - r.x, c0 = blockIdx.y * (uint32_t)CHUNKK;
+    if (n <= lower || c0 >= n) return;
+    const uint32_t m = min((uint32_t)CHUNKK, n - c0), mpad = next_pow2(m);
     uint64_t* seg = keys + r.x + c0;
     for (uint32_t i = threadIdx.x; i < mpad; i += 256) s_keys[i] = i < m ? seg[i] : ~0ull;
     __syncthreads();
@@ -632,24 +636,25 @@ __global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __re
     for (uint32_t i = threadIdx.x; i < m; i += 256) seg[i] = s_keys[i];
 }
 
+template <int CHUNKK>
 __global__ void __launch_bounds__(256) rank_long_chunks_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                                                                const uint32_t* __restrict__ inst_gauss, uint2* __restrict__ sorted,
-                                                               const uint32_t* spec_header)
+                                                               const uint32_t* spec_header, uint32_t lower)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;
     const uint2 r = ranges[blockIdx.x];
-    const uint32_t n = r.y - r.x, c0 = blockIdx.y * (uint32_t)SORT_LDS_CAP;
-    if (n <= (uint32_t)SORT_LDS_CAP || c0 >= n) return;
-    const uint32_t m = min((uint32_t)SORT_LDS_CAP, n - c0);
+    const uint32_t n = r.y - r.x, c0 = blockIdx.y * (uint32_t)CHUNKK;
+    if (n <= lower || c0 >= n) return;
+    const uint32_t m = min((uint32_t)CHUNKK, n - c0);
     const uint64_t* seg = keys + r.x;
-    const uint32_t nchunks = (n + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP;
+    const uint32_t nchunks = (n + (uint32_t)CHUNKK - 1) / (uint32_t)CHUNKK;
     for (uint32_t i = threadIdx.x; i < m; i += 256) {
         const uint64_t key = seg[c0 + i];
         uint32_t rank = i;
         for (uint32_t c = 0; c < nchunks; c++) {
             if (c == blockIdx.y) continue;
-            const uint64_t* other = seg + c * (uint32_t)SORT_LDS_CAP;
-            uint32_t lo = 0, hi = min((uint32_t)SORT_LDS_CAP, n - c * (uint32_t)SORT_LDS_CAP);
+            const uint64_t* other = seg + c * (uint32_t)CHUNKK;
+            uint32_t lo = 0, hi = min((uint32_t)CHUNKK, n - c * (uint32_t)CHUNKK);
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (other[mid] < key) lo = mid + 1; else hi = mid;

@@ -364,3 +364,21 @@ def test_randomised_scene_shapes_back_to_back():
         m = compare(oh, gh, oo, go)
         m.update(P=P, case=(W, H, P, sm, deg))
         _check(m, nt_tol=4)
+
+
+@pytest.mark.gpu
+def test_large_gaussians_many_instances_per_gaussian():
+    """SLAM-shaped map: every Gaussian covers tens of tiles, so geometry_bwd takes its wave-cooperative gather (more than 8 instance
+    slots per Gaussian in a block) and the tile lists run into the thousands; parity with the oracle as everywhere else."""
+    cam = make_camera(208, 160)
+    g = make_gaussians(2600, cam, seed=17, sh_degree=1, scale_mean=0.06)
+    g["opacities"][:] *= 0.25
+    gc, gd = make_cotangents(cam, seed=18)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    oo, st, go = oracle_run(g, cam, bg, gc, gd)
+    assert st.num_rendered > 12 * 2600                          # > 8 slots per Gaussian on average: the heavy path
+    oh, gh = hip_run(g, cam, bg, gc, gd)
+    _check(compare(oh, gh, oo, go))
+    oh2, gh2 = hip_run(g, cam, bg, gc, gd)                      # bit-reproducible
+    for k, v in gh.items():
+        assert v is None or np.array_equal(v, gh2[k]), k
