@@ -52,6 +52,18 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, f
     return mask;
 }
 
+// GSR_EXACT_MATH (csrc/build.sh --exact -> libgs_rasterizer_hip_exact.so, selected with GSR_EXACT_MATH=1): the two tile kernels evaluate a
+// pair exactly like the reference / the fp32 oracle -- power = -0.5 (a dx^2 + c dy^2) - b dx dy in that order, alpha = min(0.99, o *
+// exp(power)) with a correctly rounded exponential (evaluated in double), true division in the backward recurrence -- and the whole
+// library is compiled without floating-point contraction. The default build folds log2(e) and log2(o) into the exponent and uses the
+// hardware's v_exp_f32 / v_rcp_f32 (1 ulp); tests/test_hip_exact_math.py measures what that changes (discrete outputs: none or a
+// handful of threshold flips; images 1e-7). Staging layout in exact mode: s_a = {mean.x, mean.y, a, b}, s_b = {c, o}.
+#ifndef GSR_EXACT_MATH
+#define GSR_EXACT_MATH 0
+#endif
+__device__ __forceinline__ float exact_power(float dx, float dy, float a, float b, float c) { return -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy; }
+__device__ __forceinline__ float exact_exp(float x) { return (float)exp((double)x); }
+
 // j = index of the lowest set bit of m; clears it.  Two SALU instructions (the C idiom m &= m - 1 costs three plus the ff1).
 __device__ __forceinline__ int pop_lowest_bit(unsigned long long& m)
 {
@@ -141,8 +153,13 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             const float2 xy = means2D[e.x];
             const float4 co = conic_opacity[e.x];
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
+#if GSR_EXACT_MATH
+            s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_b[t] = make_float4(co.z, co.w, 0.f, __uint_as_float(e.x));
+#else
             s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
             s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), 0.f, __uint_as_float(e.x));   // log2(opacity): folded into the exponent
+#endif
             s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
         }
 #pragma unroll
@@ -169,9 +186,15 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                 const float4 C4 = s_c[j];
                 const f2 d = f2{A4.x, A4.y} - pxy;
                 // alpha = o exp(power) = exp2(power log2e + log2 o): the opacity rides in the exponent (one multiply less per pair)
+#if GSR_EXACT_MATH
+                const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                           // forward.cu:345
+                const float alpha = fminf(0.99f, B2.y * exact_exp(pw));                             // :353
+                const bool valid = pw <= 0.0f && alpha >= thr;                                      // :346, :354 and "not done"
+#else
                 const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);      // forward.cu:345 (times log2 e) + log2 o
                 const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(pw));                      // :353
                 const bool valid = pw <= B2.y && alpha >= thr;                                      // :346 (power <= 0), :354 and "not done"
+#endif
                 const float test_T = T * (1.0f - alpha);
                 const bool stop = valid && test_T < 0.0001f;                                        // :358-362
                 const bool blend = valid && !stop;
@@ -351,7 +374,12 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
 #pragma unroll
         for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
         s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+#if GSR_EXACT_MATH
+        s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
+        s_b[t] = make_float2(co.z, co.w);
+#else
         s_b[t] = make_float2(-0.5f * LOG2E * co.z, __log2f(co.w));   // log2(opacity): folded into the exponent
+#endif
         s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
         s_d[t] = co;
         s_inst[t] = e.y;
@@ -377,15 +405,26 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         const f2 d = f2{A4.x, A4.y} - pxy;
         // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
         // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
+#if GSR_EXACT_MATH
+        const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                            // :684
+        const float G = B2.y * exact_exp(pw);                                                 // o G: the moments below are those of q = o G dL_dalpha as in the fast path
+        const float alpha = fminf(0.99f, G);                                                  // :688
+        const bool valid = j >= j_thr && pw <= 0.0f && alpha >= 1.0f / 255.0f;              // :678,:685,:689
+#else
         const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
         const float G = __builtin_amdgcn_exp2f(pw);
         const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
         const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
+#endif
         if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
         const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
         const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
         const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
+#if GSR_EXACT_MATH
+        const float inv1ma = 1.0f / (1.f - av);                                                // :700 true division
+#else
         const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
+#endif
         T *= inv1ma;                                                                           // :700
         const float wv = av * T;                                                               // :701 dchannel_dcolor
         const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;

@@ -19,7 +19,10 @@ import os
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_PKG_ROOT, "libgs_rasterizer_hip.so"))
+# GSR_EXACT_MATH=1: the exact-math parity build of the same library (csrc/build.sh --exact); it is driven through ctypes only (the
+# native glue is linked against the product library)
+EXACT_MATH = os.environ.get("GSR_EXACT_MATH", "0") not in ("", "0")
+LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_PKG_ROOT, "libgs_rasterizer_hip_exact.so" if EXACT_MATH else "libgs_rasterizer_hip.so"))
 NUM_CHANNELS = 3  # cuda_rasterizer/config.h:15
 
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
@@ -31,7 +34,7 @@ _lib = None
 # GSR_GLUE=ctypes|native forces one; by default the native glue is used when it has been built.
 _glue = None
 _glue_error = None
-if os.environ.get("GSR_GLUE", "native") != "ctypes":
+if os.environ.get("GSR_GLUE", "native") != "ctypes" and not EXACT_MATH and "GSR_LIB" not in os.environ:
     try:
         from . import _glue  # type: ignore
     except Exception as _e:  # not built (or built for another torch): fall back to ctypes, loudly only if it was requested
