@@ -13,6 +13,7 @@
 // No global 64-bit radix sort, no float atomics, no cooperative-groups block trees.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
@@ -155,11 +156,23 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 // Host mailbox: 8 words of pinned, host-coherent memory per host thread; word 4 carries the sequence number of the
 // forward call whose header (words 0-3) is valid. Plus the allocation size that was enough last time (speculative
 // binning allocation while the GPU is still busy with the preprocess).
-static thread_local uint32_t* t_mailbox = nullptr;       // host pointer
-static thread_local uint32_t* t_mailbox_dev = nullptr;   // device pointer to the same memory
-static thread_local uint32_t t_seq = 0;
-static thread_local size_t t_last_R_alloc = 0;
-static thread_local uint32_t t_last_max_tile = 0;
+// ... all of it per (host thread, device): a thread that renders on several GPUs gets one mailbox and one capacity estimate per device
+// (the mailbox's device pointer is the one hipHostGetDevicePointer returns for THAT device).
+struct SpecState { uint32_t* mailbox = nullptr; uint32_t* mailbox_dev = nullptr; uint32_t seq = 0; size_t last_R_alloc = 0; uint32_t last_max_tile = 0; };
+static thread_local SpecState t_spec[16];
+static thread_local SpecState* t_cur = &t_spec[0];
+static int select_device_state()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    t_cur = &t_spec[dev];
+    return dev;
+}
+#define t_mailbox (t_cur->mailbox)
+#define t_mailbox_dev (t_cur->mailbox_dev)
+#define t_seq (t_cur->seq)
+#define t_last_R_alloc (t_cur->last_R_alloc)
+#define t_last_max_tile (t_cur->last_max_tile)
 static thread_local bool t_use_mailbox = true;
 static thread_local bool t_speculate = true;
 // Lazy mode (gsr_set_option("lazy", 1)): a speculative forward pass returns WITHOUT waiting for the scan kernel's header -- no host
@@ -183,12 +196,15 @@ static void read_option_env()
 static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
 {
     if (t_use_mailbox) {
-        // spin on the mailbox; check the stream now and then so that a faulted / finished stream cannot hang us
+        // spin on the mailbox (the scan kernel is a few microseconds away when the GPU is not backed up); after ~1e5 polls the wait is
+        // evidently long, so the core is yielded between polls; the stream is checked now and then so that a faulted / finished stream
+        // cannot hang us
         for (unsigned long long spins = 0;; spins++) {
             if (__atomic_load_n(&t_mailbox[4], __ATOMIC_ACQUIRE) == seq) {
                 for (int i = 0; i < 4; i++) out[i] = __atomic_load_n(&t_mailbox[i], __ATOMIC_RELAXED);
                 return 0;
             }
+            if (spins > 100000ull) sched_yield();
             if ((spins & 0xFFFFF) == 0xFFFFF) {
                 hipError_t q = hipStreamQuery(stream);
                 if (q == hipSuccess) {   // stream drained: the store must be visible by now, otherwise fall back for good
@@ -236,6 +252,7 @@ int gsr_set_option(const char* name, int value)
 
 int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered)
 {
+    select_device_state();
     if (overflow_count) *overflow_count = t_mailbox ? __atomic_load_n(&t_mailbox[5], __ATOMIC_ACQUIRE) : 0u;
     if (last_num_rendered) *last_num_rendered = t_mailbox ? __atomic_load_n(&t_mailbox[0], __ATOMIC_ACQUIRE) : 0u;
     return 0;
@@ -315,6 +332,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
     const size_t N = (size_t)width * height;
+    select_device_state();
 
     char* gchunk = geometry_alloc(geometry_user, gsr_geometry_buffer_size(P));
     char* ichunk = image_alloc(image_user, gsr_image_buffer_size(width, height, P));

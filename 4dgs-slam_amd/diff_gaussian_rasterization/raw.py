@@ -99,6 +99,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                            tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
         ctx.set_materialize_grads(False)
         ctx.gather = gather
+        ctx.empty = gather is not None and gather.numel() == 0
+        if ctx.empty:
+            # render()'s mask selected nothing (x[mask] with P = 0): like rasterize_points.cu:85 the kernels are skipped -- zero image,
+            # empty radii / n_touched, zero gradients
+            H, W = int(rs.image_height), int(rs.image_width)
+            ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dx, ds, dr)
+            z = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=dev)
+            e = torch.zeros((0,), dtype=torch.int32, device=dev)
+            ctx.mark_non_differentiable(e)
+            return z(_C.NUM_CHANNELS), e, z(1), z(1), e.clone()
         if _C._glue is not None:      # native host glue (csrc/torch_glue.cpp): same calls, marshalled in C++
             with torch.cuda.device(dev):
                 (rc, color, radii, geom_t, bin_t, img_t, depth, opacity, n_touched) = _C._glue.rasterize_gaussians_raw(
@@ -137,6 +147,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, _g_radii, g_depth, _g_opacity, _g_touched):
+        if ctx.empty:
+            xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dx, ds, dr = ctx.saved_tensors
+            Z = lambda t: None if t is None else torch.zeros_like(t)
+            th, rh = ctx.pose_shapes
+            zp = lambda shp: None if shp is None else torch.zeros(shp, dtype=torch.float32, device=xyz.device)
+            return (Z(xyz), torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=xyz.device), Z(log_scales), Z(raw_rot), Z(logit_opacity), Z(f_dc),
+                    Z(f_rest) if f_rest is not None and f_rest.numel() else None, None, Z(dx), Z(ds), Z(dr), zp(th), zp(rh), None, None)
         rs, M = ctx.rs, ctx.M
         (xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii, geom, binning, imgbuf) = ctx.saved_tensors
         dev = xyz.device

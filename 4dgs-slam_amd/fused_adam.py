@@ -48,6 +48,13 @@ class FusedAdam(torch.optim.Adam):
             if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse
                     or not p.is_contiguous() or not g.is_contiguous()):
                 return False
+            st = self.state.get(p, None)
+            if st:          # moments edited from outside (densification surgery, load_state_dict): the kernel reads them through raw pointers
+                for k in ("exp_avg", "exp_avg_sq"):
+                    t = st.get(k)
+                    if (t is None or not t.is_cuda or t.device != p.device or t.dtype != torch.float32 or not t.is_contiguous()
+                            or t.numel() != p.numel()):
+                        return False
         return True
 
     @torch.no_grad()

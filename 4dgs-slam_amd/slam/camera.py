@@ -218,8 +218,8 @@ class Camera(nn.Module):
         self.cam_trans_delta = None
         self.exposure_a = None
         self.exposure_b = None
-        if hasattr(self, "_gsr_loss_cache"):
-            del self._gsr_loss_cache
+        import slam_losses
+        slam_losses.drop_keyframe_constants(self)
 
     def clean_key(self):
         self.grad_mask = None

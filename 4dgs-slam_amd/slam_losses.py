@@ -4,7 +4,9 @@ two weight images; the weighted L1 itself -- value, the cotangents dL/dI and dL/
 the exposure gradients -- is two HIP kernels (include/slam_losses.h) instead of ~20 torch kernels plus their autograd replay.
 
 There is no CPU implementation here: CPU tensors raise, as everywhere in the product path."""
+import collections
 import ctypes as C
+import weakref
 
 import torch
 
@@ -116,25 +118,48 @@ def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None,
     return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold)
 
 
+# Ground-truth-only constants of a frame (device copy of the depth map + four masks, ~10 MB at 640x480). They live in a BOUNDED cache
+# keyed by the viewpoint object, not on the viewpoint: get_loss_tracking runs for every frame, the reference's Camera.clean()
+# (utils/camera_utils.py:438-448) knows nothing about an extra attribute, and an unbounded per-frame cache grows by tens of GB over a
+# sequence. 24 entries cover the mapping window (8) + the two random keyframes + the frame being tracked with room to spare.
+_CONST_CACHE = collections.OrderedDict()
+_CONST_CACHE_MAX = 24
+
+
 def _keyframe_constants(config, viewpoint, device):
-    """Ground-truth depth on the device and the two ground-truth-only masks (slam_utils.py:276-284), cached on the viewpoint:
-    the reference re-uploads the depth map from host memory and rebuilds the masks on every call of every iteration."""
-    key = (id(viewpoint.depth), id(viewpoint.original_image), str(device), float(config["Training"]["rgb_boundary_threshold"]))
-    cache = getattr(viewpoint, "_gsr_loss_cache", None)
-    if cache is None or cache[0] != key:
-        gt_image = viewpoint.original_image.to(device)
+    """(gt_image, gt_depth, rgb mask, depth mask, tracking rgb mask, tracking depth mask) on `device` (slam_utils.py:276-284, 65-77).
+    gt_depth and the depth masks are None for frames without a depth map (monocular)."""
+    grad_mask = getattr(viewpoint, "grad_mask", None)
+    key = (id(viewpoint.depth), id(viewpoint.original_image), str(device), float(config["Training"]["rgb_boundary_threshold"]), id(grad_mask))
+    ent = _CONST_CACHE.get(id(viewpoint))
+    if ent is not None and ent[0]() is viewpoint and ent[1] == key:
+        _CONST_CACHE.move_to_end(id(viewpoint))
+        return ent[2]
+    gt_image = viewpoint.original_image.to(device)
+    rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"])[None].to(torch.float32)
+    gt_depth = dep = t_dep = None
+    if viewpoint.depth is not None:
         gt_depth = torch.as_tensor(viewpoint.depth, dtype=torch.float32, device=device)[None]
-        rgb = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(*gt_depth.shape).to(torch.float32)
         dep = ((gt_depth > 0.01) & (gt_depth < 10000.0)).to(torch.float32)
-        grad_mask = getattr(viewpoint, "grad_mask", None)                  # tracking only (slam_utils.py:70,118-119)
-        t_rgb = rgb * grad_mask.view(*gt_depth.shape) if grad_mask is not None else None
         t_dep = ((gt_depth > 0.01) & (gt_depth < 1000.0)).to(torch.float32)
-        cache = (key, gt_image, gt_depth, rgb, dep, t_rgb, t_dep)
-        try:
-            viewpoint._gsr_loss_cache = cache
-        except Exception:  # pragma: no cover  (immutable stand-in)
-            pass
-    return cache[1:]
+    t_rgb = rgb * grad_mask.view(*rgb.shape) if grad_mask is not None else None           # tracking only (slam_utils.py:70,118-119)
+    data = (gt_image, gt_depth, rgb, dep, t_rgb, t_dep)
+    try:
+        ref = weakref.ref(viewpoint, lambda _r, k=id(viewpoint): _CONST_CACHE.pop(k, None))
+    except TypeError:                                                     # not weak-referenceable: do not cache
+        return data
+    _CONST_CACHE[id(viewpoint)] = (ref, key, data)
+    while len(_CONST_CACHE) > _CONST_CACHE_MAX:
+        _CONST_CACHE.popitem(last=False)
+    return data
+
+
+def drop_keyframe_constants(viewpoint=None):
+    """Forget the cached constants of one viewpoint (or of all): call it where the reference calls Camera.clean()."""
+    if viewpoint is None:
+        _CONST_CACHE.clear()
+    else:
+        _CONST_CACHE.pop(id(viewpoint), None)
 
 
 def mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, dynamic=False, base=None):
@@ -167,10 +192,9 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
     _C._require_device(image, "image")
     gt_image, gt_depth, base_rgb, base_dep, _, _ = _keyframe_constants(config, viewpoint, image.device)
     exposure = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
-    if config["Training"]["monocular"]:
+    if config["Training"]["monocular"]:                                           # never touches the depth map (there is none)
         image_ab = image if initialization else torch.exp(exposure[0]) * image + exposure[1]
-        m = (gt_image.sum(dim=0) > config["Training"]["rgb_boundary_threshold"]).view(1, *gt_image.shape[1:])
-        return torch.abs(image_ab * m - gt_image * m).mean()                     # get_loss_mapping_rgb, :262-272
+        return torch.abs(image_ab * base_rgb - gt_image * base_rgb).mean()       # get_loss_mapping_rgb, :262-272
     if alpha is None:
         alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
     if split:                                                                     # :292-303
@@ -208,10 +232,16 @@ def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=F
     is a debugging aid of the reference and is ignored). The exposure is always applied (:58)."""
     _C._require_device(image, "image")
     gt_image, gt_depth, _, _, t_rgb, t_dep = _keyframe_constants(config, viewpoint, image.device)
-    w_rgb, w_dep = tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, base=(t_rgb, t_dep))
-    if config["Training"]["monocular"]:
+    if t_rgb is None:
+        raise RuntimeError("get_loss_tracking: viewpoint.grad_mask is not set (call compute_grad_mask first, utils/slam_frontend.py:678)")
+    if config["Training"]["monocular"]:                                           # get_loss_tracking_rgb, :64-105: no depth involved
+        w_rgb = t_rgb if mask is None else mask.view(*t_rgb.shape) * t_rgb
+        motion = getattr(viewpoint, "motion_mask", None)
+        if motion is not None and rm_dynamic and viewpoint.uid > 0:
+            w_rgb = motion.view(*t_rgb.shape) * w_rgb
         image_ab = torch.exp(viewpoint.exposure_a) * image + viewpoint.exposure_b
-        return (opacity * torch.abs(image_ab * w_rgb - gt_image * w_rgb)).mean()                   # get_loss_tracking_rgb, :64-105
+        return (opacity * torch.abs(image_ab * w_rgb - gt_image * w_rgb)).mean()
+    w_rgb, w_dep = tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, base=(t_rgb, t_dep))
     alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
     return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, viewpoint.exposure_a, viewpoint.exposure_b, alpha,
                             opacity=opacity, opacity_depth_threshold=0.95)

@@ -203,3 +203,19 @@ def test_fused_render_flow_matches_the_torch_chain_at_scale(isotropic=False):
     assert torch.equal(out[True][0]["radii"], out[False][0]["radii"])
     for k in out[True][1]:
         assert rel_l1(out[True][1][k].cpu().numpy(), out[False][1][k].cpu().numpy()) <= 3e-4, k
+
+
+def test_fused_route_with_an_all_false_mask_returns_the_empty_render():
+    """render(mask = all False) on the fused route must behave like the reference (x[mask] -> P = 0, rasterize_points.cu:85):
+    zero image, empty radii / n_touched, zero gradients -- not an 'invalid argument' error."""
+    import gaussian_renderer as gr
+    cam = make_camera(96, 64)
+    g = make_gaussians(500, cam, seed=3, sh_degree=0)
+    m = _GaussianModel(g, False, 0.3, seed=4)
+    view = _camera(cam)
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+    res = gr.render(view, m, pipe, torch.ones(3, device="cuda"), mask=torch.zeros(500, dtype=torch.bool, device="cuda"))
+    assert res["radii"].numel() == 0 and res["n_touched"].numel() == 0
+    assert float(res["render"].abs().max()) == 0.0 and float(res["depth"].abs().max()) == 0.0
+    (res["render"].sum() + res["depth"].sum()).backward()
+    assert float(m._xyz.grad.abs().sum()) == 0.0 and float(view.cam_rot_delta.grad.abs().sum()) == 0.0
