@@ -258,6 +258,8 @@ class BackEnd:
             loss_network = 0
             loss_mapping = 0
             dynamic = i < iters / 2                                          # :350-355
+            t = self.config["Training"]
+            flow_weight = t["flow_loss"] if dynamic else t.get("flow_loss_fine", t["flow_loss"])
             pkgs, n_touched_acm = [], []
             views = [viewpoint_stack[c] for c in range(len(current_window))]
             extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]
@@ -266,6 +268,8 @@ class BackEnd:
                 pkg = self._render(viewpoint, deltas)
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False)
+                if use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow"):
+                    loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
                 if use_net:
                     w = 1e-3 if k < len(views) else 1e-4                     # :517-519 / :640-643
                     loss_network = loss_network + w * g.deform.deform.arap_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_samp_num=2)
@@ -307,6 +311,37 @@ class BackEnd:
                     g.update_learning_rate(self.iteration_count)
                 g.optimizer.zero_grad(set_to_none=True)
         return gaussian_split
+
+    def find_closest_keyframe(self, uid):
+        """:299-304."""
+        keys = [key for key in self.viewpoints if key < uid]
+        return max(keys) if keys else None
+
+    def _flow_loss(self, viewpoint, deltas, flow_weight):
+        """The optical-flow terms of :479-509: the dynamic subset's projected motion between this keyframe and the closest earlier one,
+        rendered by render_flow (fused route: diff_gaussian_rasterization.raw.rasterize_flow_raw) in both directions, against the
+        dataset's flow on the moving pixels. The reference obtains that flow from RAFT (utils/camera_utils.py:386-417); here the dataset
+        supplies it (slam/dataset.py gt_flow)."""
+        from gaussian_renderer import render_flow
+        closest = self.find_closest_keyframe(viewpoint.uid)
+        if closest is None or deltas[0] is None:
+            return 0.0
+        other = self.viewpoints[closest]
+        if viewpoint.motion_mask is None or other.motion_mask is None:
+            return 0.0
+        g = self.gaussians
+        dx1, ds1, dr1 = deltas
+        dx2, ds2, dr2 = self._deltas(other)
+        flow_back, _ = self.dataset.gt_flow(viewpoint.uid, closest)          # this keyframe -> the earlier one
+        flow_fwd, _ = self.dataset.gt_flow(closest, viewpoint.uid)
+        loss = 0.0
+        pk = render_flow(pc=g, viewpoint_camera1=viewpoint, viewpoint_camera2=other, d_xyz1=dx1, d_xyz2=dx2, d_rotation1=dr1, d_scaling1=ds1)
+        m1 = (~viewpoint.motion_mask)[..., None]
+        loss = loss + flow_weight * torch.abs(flow_back * m1 - pk["render"][:2].permute(1, 2, 0) * m1).mean()
+        pk2 = render_flow(pc=g, viewpoint_camera1=other, viewpoint_camera2=viewpoint, d_xyz1=dx2, d_xyz2=dx1, d_rotation1=dr2, d_scaling1=ds2)
+        m2 = (~other.motion_mask)[..., None]
+        loss = loss + flow_weight * torch.abs(flow_fwd * m2 - pk2["render"][:2].permute(1, 2, 0) * m2).mean()
+        return loss
 
     def color_refinement(self, iteration_total=1500, views_per_iter=10):
         """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""

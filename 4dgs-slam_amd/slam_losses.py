@@ -146,8 +146,8 @@ def _keyframe_constants(config, viewpoint, device):
     data = (gt_image, gt_depth, rgb, dep, t_rgb, t_dep)
     try:
         ref = weakref.ref(viewpoint, lambda _r, k=id(viewpoint): _CONST_CACHE.pop(k, None))
-    except TypeError:                                                     # not weak-referenceable: do not cache
-        return data
+    except TypeError:                                                     # not weak-referenceable (e.g. SimpleNamespace stand-ins): a strong
+        ref = (lambda v=viewpoint: v)                                     # reference; the LRU bound below still caps what is kept alive
     _CONST_CACHE[id(viewpoint)] = (ref, key, data)
     while len(_CONST_CACHE) > _CONST_CACHE_MAX:
         _CONST_CACHE.popitem(last=False)

@@ -9,7 +9,10 @@ With --nodes the deltas of the dynamic Gaussians come from the SC-GS control-nod
 of 512 nodes, RBF weights, local-frame blend) applied per view to leaf tensors standing for the node MLP's outputs -- the
 reference's tensor program (brute-force cdist + topk for pytorch3d's knn_points) in "reference_chain", control_nodes.node_blend in
 "fused" -- and their gradients flow back to the node attributes, radii and weights.
-Prints one JSON line (profiles/r01_mapping_iteration.json, r01_mapping_iteration_nodes.json)."""
+With --flow every view additionally renders the NDC flow towards the previous keyframe and back (render_flow twice, utils/slam_backend.py:
+479-509) with an L1 loss against a stand-in flow field: the torch chain of the reference in "reference_chain", the fused route
+(raw.rasterize_flow_raw) in "fused".
+Prints one JSON line (profiles/r0N_mapping_iteration*.json)."""
 import json, os, sys, time, types
 import numpy as np
 import torch
@@ -25,6 +28,7 @@ import control_nodes as cn
 from tools.bench_control_nodes import torch_program
 
 NODES = "--nodes" in sys.argv
+FLOW = "--flow" in sys.argv      # + the two render_flow calls per view of the dynamic mapping loop (utils/slam_backend.py:486,496)
 
 P, W, H, K = 200_000, 640, 480, 8
 config = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.9}}
@@ -32,7 +36,8 @@ pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=Fals
 bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
 g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
 rng = np.random.default_rng(11)
-out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr" + (" from the control-node warp (512 nodes, K=3)" if NODES else "") + ", mapping loss, densification stats, Adam"}
+out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, 25% dynamic with dx/ds/dr" + (" from the control-node warp (512 nodes, K=3)" if NODES else "")
+                   + (", two render_flow per view" if FLOW else "") + ", mapping loss, densification stats, Adam"}
 for fused in (False, True):
     m = _GaussianModel(g, False, 0.25, seed=2)
     m.max_radii2D = torch.zeros(P, device="cuda"); m.xyz_gradient_accum = torch.zeros(P, 1, device="cuda"); m.denom = torch.zeros(P, 1, device="cuda")
@@ -75,6 +80,9 @@ for fused in (False, True):
         image_ab = torch.exp(vp.exposure_a) * image + vp.exposure_b
         return 0.9 * torch.abs(image_ab * w_rgb - vp.original_image * w_rgb).mean() + 0.1 * torch.abs(depth * w_dep - gt_depth * w_dep).mean()
 
+    flow_target = torch.tensor(rng.normal(scale=0.01, size=(2, H, W)).astype(np.float32), device="cuda")
+    os.environ["GSR_FUSED_FLOW"] = "1" if fused else "0"
+
     def iteration():
         opt.zero_grad(set_to_none=True)
         loss, pkgs = 0.0, []
@@ -84,6 +92,11 @@ for fused in (False, True):
             res = gr.render(v, m, pipe, bg, **d)
             loss = loss + (get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"]) if fused else torch_loss(res["render"], res["depth"], v))
             pkgs.append(res)
+            if FLOW and k > 0:
+                d2 = view_deltas(k - 1) if NODES else deltas[k - 1]
+                f1 = gr.render_flow(m, v, views[k - 1], d["dx"], d2["dx"], d["dr"], d["ds"])
+                f2 = gr.render_flow(m, views[k - 1], v, d2["dx"], d["dx"], d2["dr"], d2["ds"])
+                loss = loss + 3 * torch.abs(flow_target - f1["render"][:2]).mean() + 3 * torch.abs(flow_target + f2["render"][:2]).mean()
         loss.backward()
         with torch.no_grad():
             for res in pkgs:
@@ -107,5 +120,6 @@ for fused in (False, True):
     dt = (time.perf_counter() - t0) / n
     out["fused" if fused else "reference_chain"] = {"ms_per_iteration": dt * 1e3, "gaussian_views_per_s": P * K / dt}
 gr.FUSED_PROLOGUE = True
+os.environ.pop("GSR_FUSED_FLOW", None)
 out["speedup"] = out["reference_chain"]["ms_per_iteration"] / out["fused"]["ms_per_iteration"]
 print(json.dumps(out))
