@@ -549,11 +549,14 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys)
     }
     __syncthreads();
 }
+// MAXN: largest size this call site can see. The unrolled 2048 / 4096 networks are ~20 KB of code each: instantiated inside
+// render_fwd_kernel (whose fused sort never exceeds 1024 keys) they cost that kernel 25 % through instruction-cache misses.
+template <uint32_t MAXN = 4096>
 __device__ __forceinline__ void bitonic_sort_lds_pow2(uint64_t* keys, uint32_t npad)
 {
+    if (MAXN >= 4096 && npad == 4096) { bitonic_sort_lds<(MAXN >= 4096 ? 4096 : 64)>(keys); return; }
+    if (MAXN >= 2048 && npad == 2048) { bitonic_sort_lds<(MAXN >= 2048 ? 2048 : 64)>(keys); return; }
     switch (npad) {
-        case 4096: bitonic_sort_lds<4096>(keys); break;
-        case 2048: bitonic_sort_lds<2048>(keys); break;
         case 1024: bitonic_sort_lds<1024>(keys); break;
         case 512: bitonic_sort_lds<512>(keys); break;
         case 256: bitonic_sort_lds<256>(keys); break;
@@ -572,6 +575,7 @@ constexpr int SORT_SMALL_CAP = 1024;
 // padding 520 keys to 1024 would more than double the work. Instead the list is split into A = the largest power of two <= n
 // and the rest (padded to its own power of two), both halves are sorted, and every key finds its final rank with one binary
 // search in the other half (keys are unique). Ends with the sorted (gaussian, instance) pairs in global memory.
+template <uint32_t MAXN = 4096>
 __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
                                                  uint2* __restrict__ sorted, uint64_t* s_keys)
 {
@@ -581,8 +585,8 @@ __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* 
     const uint32_t B = n - A, Bpad = B ? next_pow2(B) : 0;
     for (uint32_t i = threadIdx.x; i < A + Bpad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
     __syncthreads();
-    bitonic_sort_lds_pow2(s_keys, A);
-    if (B) bitonic_sort_lds_pow2(s_keys + A, Bpad);
+    bitonic_sort_lds_pow2<MAXN>(s_keys, A);
+    if (B) bitonic_sort_lds_pow2<MAXN>(s_keys + A, Bpad);
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint64_t key = s_keys[i];
         const bool in_a = i < A;
@@ -609,7 +613,7 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2
     const uint32_t n = r.y - r.x;
     if (n <= (uint32_t)LOWER) return;                       // empty, or the other instantiation's tile
     if (CAP < SORT_LDS_CAP && n > (uint32_t)CAP) return;
-    if (n <= (uint32_t)CAP) sort_tile_in_lds(r, keys, inst_gauss, sorted, s_keys);
+    if (n <= (uint32_t)CAP) sort_tile_in_lds<(uint32_t)CAP>(r, keys, inst_gauss, sorted, s_keys);
     // n > SORT_LDS_CAP: sort_long_chunks_kernel + rank_long_chunks_kernel
 }
 

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     // sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP> before.
     static_assert(3 * RB * sizeof(float4) >= SORT_SMALL_CAP * sizeof(uint64_t), "key buffer aliases the staging arrays");
     if (keys != nullptr && n > 0 && n <= SORT_SMALL_CAP) {
-        sort_tile_in_lds(range, keys, inst_gauss, sorted_out, reinterpret_cast<uint64_t*>(s_raw));
+        sort_tile_in_lds<SORT_SMALL_CAP>(range, keys, inst_gauss, sorted_out, reinterpret_cast<uint64_t*>(s_raw));
         __syncthreads();                                   // the sorted list (global) and the LDS buffer are reused below
     }
     // Checkpoint of the per-pixel compositing state in front of list entry `boundary` (a multiple of CHUNK): lets the backward

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""gpurun_out/r02 (tools/profile_round2.sh) + gpurun_out/counters_r02 -> profiles/r02_*: rocprofv3 kernel stats, HBM traffic per launch
+(FETCH_SIZE / WRITE_SIZE collected in separate passes, KiB units, gfx950 FETCH_SIZE half-count correction -- MI355X_MICROARCH.md 'HBM'),
+the SQ counters of the tile kernels, and the JSON lines of the benches."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst, tag = os.path.join(REPO, "gpurun_out", "r02"), os.path.join(REPO, "profiles"), "r02"
+
+
+def agg(pattern):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(pattern, recursive=True):
+        for r in csv.DictReader(open(path)):
+            d[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in dd.items()} for k, dd in d.items()}
+
+
+stats_csv = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats = {r["Name"].split("(")[0].replace("void ", "").split("<")[0]: r for r in csv.DictReader(open(stats_csv))}
+fe, wr = agg(os.path.join(src, "pmc_fetch", "**", "*counter_collection.csv")), agg(os.path.join(src, "pmc_write", "**", "*counter_collection.csv"))
+sq = agg(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"))
+out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `bench.py --steps 20 --warmup 5 --no-cpu-baseline "
+                 "--no-secondary`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md); "
+                 "fabric-side counters: Infinity-Cache hits are included", "kernels": {}}
+for k in sorted(fe):
+    if not k.startswith("gsr::"):
+        continue
+    short = k.split("::")[1].replace("_kernel", "")
+    e = {"FETCH_SIZE_KiB": fe[k]["FETCH_SIZE"], "WRITE_SIZE_KiB": wr.get(k, {}).get("WRITE_SIZE"),
+         "hbm_bytes_per_launch": (2 * fe[k]["FETCH_SIZE"] + wr.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024,
+         "rocprof_avg_us": float(stats[k]["AverageNs"]) / 1e3 if k in stats else None}
+    e.update(sq.get(k, {}))
+    out["kernels"][short] = e
+out["render_bwd_bytes_per_launch"] = out["kernels"]["render_bwd"]["hbm_bytes_per_launch"]
+bench = json.load(open(os.path.join(src, "bench.json")))
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+out["render_bwd_traffic_over_algorithmic"] = out["render_bwd_bytes_per_launch"] / alg
+out["whole_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in out["kernels"].values())
+out["whole_step_traffic_over_algorithmic"] = out["whole_step_traffic_bytes"] / bench["roofline"]["whole_step_algorithmic_bytes"]
+json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "tracking_graph.json", "config3.json", "render_wrapper.json", "slam_demo.json",
+             "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('iterationflow', 'iteration_flow').replace('iterationnodesflow', 'iteration_nodes_flow').replace('iterationnodes', 'iteration_nodes')}"))
+subprocess.run([sys.executable, os.path.join(REPO, "tools", "collect_counters.py"), "r02", "r02"], check=True)
+print(json.dumps({k: (round(v["rocprof_avg_us"], 1) if v["rocprof_avg_us"] else None, int(v["hbm_bytes_per_launch"])) for k, v in out["kernels"].items()}))
+print("render_bwd traffic / algorithmic:", round(out["render_bwd_traffic_over_algorithmic"], 2), " whole step:", round(out["whole_step_traffic_over_algorithmic"], 2))

@@ -6,7 +6,7 @@ EXTRA=${2:-}
 cd /tmp && export TMPDIR=/tmp
 O=/root/repo/gpurun_out/counters_$TAG
 rm -rf $O && mkdir -p $O
-B="python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA"
+B="python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $EXTRA"
 pass() {  # name counters...
   local n=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$n -o p -- $B > /dev/null 2> $O/$n.err || echo "pass $n failed: $(tail -1 $O/$n.err)"
