@@ -59,7 +59,7 @@ static inline void carve(char*& p, T*& ptr, size_t count)
 
 struct GeomState {
     uint32_t* header;   // HDR_* words of gs_device.h
-    float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
+    TileRec* rec; float* cov3D; uint8_t* clamped;
     int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
     float* tau_partials;   // [ceil(P/256)][6] per-block sums of dL_dtau (backward)
     static GeomState from(char*& p, size_t P)
@@ -67,7 +67,7 @@ struct GeomState {
         GeomState g;
         const size_t nb = (P + GB - 1) / GB + 1;
         carve(p, g.header, HDR_WORDS);
-        carve(p, g.depths, P); carve(p, g.means2D, P); carve(p, g.conic_opacity, P); carve(p, g.rgb, 3 * P);
+        carve(p, g.rec, P);
         carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
         carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
         carve(p, g.tau_partials, ((P + 255) / 256 + 1) * 6);
@@ -362,7 +362,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
         a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx);   // rasterizer_impl.cu:225-226
         a.prefiltered = prefiltered; a.radii = radii; a.n_touched = n_touched;
-        a.depths = geom.depths; a.means2D = geom.means2D; a.conic_opacity = geom.conic_opacity; a.rgb = geom.rgb; a.cov3D = geom.cov3D;
+        a.rec = geom.rec; a.cov3D = geom.cov3D;
         a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums; a.tile_count = img.tile_count;
         a.flags = flags; a.block_tile_base = lds_hist ? img.block_tile_base : nullptr;
         a.raw = to_device_view(raw);
@@ -386,7 +386,6 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     // the host reads R from the mailbox afterwards, while the GPU is already busy with them. The scan kernel compares the
     // frame's real needs with the speculative capacity and raises FLAG_OVERFLOW if they do not fit: the speculative kernels
     // then exit at once and the host redoes them on an exact-size buffer (also the path of the first call and of debug mode).
-    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:324
     read_option_env();
     if (t_lazy && t_mailbox) {
         // lazy mode never waits, so the capacity estimate is refreshed from whatever header the GPU published last (a few calls old)
@@ -433,8 +432,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
-            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.means2D,
-                               geom.depths, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
+                               geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
                                (uint32_t)carve_R, (uint32_t)cap_sorted);
         }
@@ -466,8 +465,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         GSR_STAGE("sort_tiles");
         {   // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
             ScopedKernelTimer tm(K_RENDER_FWD, stream);
-            hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.means2D,
-                               feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color, out_depth,
+            hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.rec,
+                               background, img.final_T, img.n_contrib, out_color, out_depth,
                                out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
                                (const uint32_t*)bin.inst_gauss, bin.sorted);
         }
@@ -505,7 +504,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         if (P > 0) GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
-                           geom.means2D, feat, geom.conic_opacity, geom.depths, background, img.final_T, img.n_contrib, out_color,
+                           geom.rec, background, img.final_T, img.n_contrib, out_color,
                            out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr);
     }
@@ -566,13 +565,12 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     GeomState geom = GeomState::from(gp, (size_t)P);
     ImageState img = ImageState::from(ip, (size_t)width * height, (size_t)T, 0);
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:387-390
-    const float* feat = colors_precomp ? colors_precomp : geom.rgb;   // rasterizer_impl.cu:401
     if (R > 0) {
         // one block per CHUNK entries of a tile list; sum over tiles of ceil(n / CHUNK) <= R / CHUNK + T, surplus blocks exit
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
         const int grid = R / CHUNK + T;
         hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, img.chunk_base, (const char*)binning_buffer,
-                           (const uint32_t*)geom.header, width, height, background, geom.means2D, geom.conic_opacity, feat, geom.depths,
+                           (const uint32_t*)geom.header, width, height, background, geom.rec,
                            img.final_T, img.final_C, img.n_contrib, dL_dpix, dL_dpix_depth);
     }
     GSR_STAGE("render_bwd");
@@ -706,10 +704,17 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     if (P > 0) GSR_HIP_CHECK(hipMemcpy(hdr, geom.header, sizeof(hdr), hipMemcpyDeviceToHost));
     const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], hdr[HDR_CAP_SORTED]);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
-    D2H(depths, geom.depths, P * sizeof(float));
-    D2H(means2D, geom.means2D, P * 2 * sizeof(float));
-    D2H(conic_opacity, geom.conic_opacity, P * 4 * sizeof(float));
-    D2H(rgb, geom.rgb, P * 3 * sizeof(float));
+    if (P && (depths || means2D || conic_opacity || rgb)) {   // the packed per-Gaussian rows, handed out in the reference's four arrays
+        std::vector<TileRec> rows((size_t)P);
+        GSR_HIP_CHECK(hipMemcpy(rows.data(), geom.rec, (size_t)P * sizeof(TileRec), hipMemcpyDeviceToHost));
+        for (int i = 0; i < P; i++) {
+            const TileRec& r = rows[i];
+            if (depths) depths[i] = r.q0.z;
+            if (means2D) { means2D[2 * i] = r.q0.x; means2D[2 * i + 1] = r.q0.y; }
+            if (conic_opacity) { conic_opacity[4 * i] = r.q1.x; conic_opacity[4 * i + 1] = r.q1.y; conic_opacity[4 * i + 2] = r.q1.z; conic_opacity[4 * i + 3] = r.q0.w; }
+            if (rgb) { rgb[3 * i] = r.q2.x; rgb[3 * i + 1] = r.q2.y; rgb[3 * i + 2] = r.q2.z; }
+        }
+    }
     D2H(cov3D, geom.cov3D, P * 6 * sizeof(float));
     if (clamped && P) {
         std::vector<uint8_t> bits(P);

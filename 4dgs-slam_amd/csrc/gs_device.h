@@ -209,6 +209,16 @@ enum { FLAG_PREFILTERED = 1u, FLAG_OVERFLOW = 2u };   // FLAG_OVERFLOW: the spec
 //   rotations = _rotation / max(|_rotation|, 1e-12) (+ dr[slot]);  opacity = sigmoid(_opacity);  shs = cat(_features_dc, _features_rest)
 // where slot = dyn_slot[i] >= 0 marks the dynamic subset (pc.dygs) the control-node deltas apply to. The backward kernel
 // applies the matching chain rules on its stores (geometry_bwd_kernel).
+// What preprocess_fwd leaves per visible Gaussian for the binning and tile kernels (scatter_instances, render_fwd, render_bwd): ONE
+// 48-byte row -- three 16-byte loads that touch at most two 128-byte lines -- instead of four arrays (means2D, conic_opacity, rgb,
+// depths) = four cache lines per gathered list entry. The gathers were the largest part of both tile kernels' fabric traffic.
+struct __attribute__((aligned(16))) TileRec {
+    float4 q0;   // mean2D.x, mean2D.y, view-space depth, opacity
+    float4 q1;   // conic a, b, c (inverse 2D covariance), unused
+    float4 q2;   // r, g, b (or colors_precomp / the flow colour), unused
+};
+static_assert(sizeof(TileRec) == 48, "TileRec is three float4");
+
 struct RawInputs {
     const float* xyz; const float* log_scales; int scale_dim; const float* raw_rot; const float* logit_opacity;
     const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;

@@ -31,7 +31,7 @@ struct PreprocessArgs {
     float tan_fovx, tan_fovy, focal_x, focal_y;
     int prefiltered;
     int* radii; int* n_touched;
-    float* depths; float2* means2D; float4* conic_opacity; float* rgb; float* cov3D; uint8_t* clamped;
+    TileRec* rec; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* flags;   // flags: zero-filled together with tile_count
     uint32_t* block_tile_base;   // [nblocks][T] when the LDS histogram path is taken, else nullptr
     RawInputs raw;               // raw.xyz != nullptr: read the model's raw parameters instead (fused prologue, gs_device.h)
@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
                 tile_rect(px, py, (int)rad_f, a.gx, a.gy, x0, y0, x1, y1);
                 const int area = (x1 - x0) * (y1 - y0);
                 if (area != 0) {
+                    f3 col;
                     if (a.raw.flow_proj1) {
                         // render_flow's colour (gaussian_renderer/__init__.py:262-284): NDC displacement between the two projections
                         // of the (detached) position moved by dx / dx2, and the dynamic-mask channel
@@ -193,17 +194,19 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
                         float u1, v1, u2, v2;
                         flow_ndc(a.raw.flow_proj1, t1, u1, v1);
                         flow_ndc(a.raw.flow_proj2, t2, u2, v2);
-                        a.rgb[3 * (size_t)idx] = u2 - u1; a.rgb[3 * (size_t)idx + 1] = v2 - v1; a.rgb[3 * (size_t)idx + 2] = sl >= 0 ? 1.0f : 0.0f;
+                        col = mk3(u2 - u1, v2 - v1, sl >= 0 ? 1.0f : 0.0f);
                         a.clamped[idx] = 0;
                     } else if (a.colors_precomp == nullptr) {
                         uint32_t cb;
-                        const f3 c = sh_to_rgb(a.D, sh_view(a.shs, a.raw, (size_t)idx, a.M), p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
-                        a.rgb[3 * (size_t)idx] = c.x; a.rgb[3 * (size_t)idx + 1] = c.y; a.rgb[3 * (size_t)idx + 2] = c.z;
+                        col = sh_to_rgb(a.D, sh_view(a.shs, a.raw, (size_t)idx, a.M), p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
                         a.clamped[idx] = (uint8_t)cb;
+                    } else {
+                        col = mk3(a.colors_precomp[3 * (size_t)idx], a.colors_precomp[3 * (size_t)idx + 1], a.colors_precomp[3 * (size_t)idx + 2]);   // rasterizer_impl.cu:324
                     }
-                    a.depths[idx] = p_view.z;
-                    a.means2D[idx] = make_float2(px, py);
-                    a.conic_opacity[idx] = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, load_opacity(a.opacities, a.raw, (size_t)idx));
+                    TileRec* const rec = a.rec + idx;
+                    rec->q0 = make_float4(px, py, p_view.z, load_opacity(a.opacities, a.raw, (size_t)idx));
+                    rec->q1 = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, 0.f);
+                    rec->q2 = make_float4(col.x, col.y, col.z, 0.f);
                     my_radius = (int)rad_f;
                     touched = (uint32_t)area;
                     rx0 = x0; ry0 = y0; rw = x1 - x0;
@@ -424,8 +427,8 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
 // (tile | depth) sort order (rasterizer_impl.cu:98-108,306-311), ties included.
 // Also materialises the global inclusive scan point_offsets (rasterizer_impl.cu:280).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, int gy, const int* radii, const float2* means2D,
-                                                               const float* depths, const uint32_t* tiles_touched,
+__global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, int gy, const int* radii, const TileRec* rec,
+                                                               const uint32_t* tiles_touched,
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
@@ -460,11 +463,11 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
     int rx0 = 0, ry0 = 0, rw = 1;
     uint32_t dbits = 0;
     if (cnt) {
-        const float2 xy = means2D[idx];
+        const float4 q0 = rec[idx].q0;
         int x1, y1;
-        tile_rect(xy.x, xy.y, radii[idx], gx, gy, rx0, ry0, x1, y1);
+        tile_rect(q0.x, q0.y, radii[idx], gx, gy, rx0, ry0, x1, y1);
         rw = x1 - rx0;
-        dbits = __float_as_uint(depths[idx]);
+        dbits = __float_as_uint(q0.z);
     }
     const uint32_t off_excl = off_incl - cnt;
     wave_expand(cnt, [&](int src, uint32_t k, bool active) {

@@ -84,8 +84,7 @@ __device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned lo
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint2* sorted /* may alias sorted_out */, int W, int H,
-                                                        const float2* __restrict__ means2D, const float* __restrict__ feat,
-                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ depths,
+                                                        const TileRec* __restrict__ rec,
                                                         const float* __restrict__ bg, float* __restrict__ final_T,
                                                         uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                                                         float* __restrict__ out_depth, float* __restrict__ out_opacity,
@@ -150,8 +149,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         uint32_t qm = 0;
         if (base + t < n) {
             const uint2 e = sorted[range.x + base + t];
-            const float2 xy = means2D[e.x];
-            const float4 co = conic_opacity[e.x];
+            const TileRec* const g = rec + e.x;
+            const float4 q0 = g->q0, q1 = g->q1, q2 = g->q2;
+            const float2 xy = make_float2(q0.x, q0.y);
+            const float4 co = make_float4(q1.x, q1.y, q1.z, q0.w);
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #if GSR_EXACT_MATH
             s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
             s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
             s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), 0.f, __uint_as_float(e.x));   // log2(opacity): folded into the exponent
 #endif
-            s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
+            s_c[t] = make_float4(q2.x, q2.y, q2.z, q0.z);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -264,9 +265,8 @@ __device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <
 __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ chunk_base, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
-                                                        const float* __restrict__ bg, const float2* __restrict__ means2D,
-                                                        const float4* __restrict__ conic_opacity, const float* __restrict__ feat,
-                                                        const float* __restrict__ depths, const float* __restrict__ final_T,
+                                                        const float* __restrict__ bg, const TileRec* __restrict__ rec,
+                                                        const float* __restrict__ final_T,
                                                         const float4* __restrict__ final_C, const uint32_t* __restrict__ n_contrib,
                                                         const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth)
 {
@@ -368,8 +368,10 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     if (t < m) {
         const int pos = cend - 1 - t;                                     // 0-based list position, back to front (:656,:677)
         const uint2 e = sorted[range.x + (uint32_t)pos];
-        const float2 xy = means2D[e.x];
-        const float4 co = conic_opacity[e.x];
+        const TileRec* const g = rec + e.x;
+        const float4 q0 = g->q0, q1 = g->q1, q2 = g->q2;
+        const float2 xy = make_float2(q0.x, q0.y);
+        const float4 co = make_float4(q1.x, q1.y, q1.z, q0.w);
         qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #pragma unroll
         for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
 #else
         s_b[t] = make_float2(-0.5f * LOG2E * co.z, __log2f(co.w));   // log2(opacity): folded into the exponent
 #endif
-        s_c[t] = make_float4(feat[3 * (size_t)e.x], feat[3 * (size_t)e.x + 1], feat[3 * (size_t)e.x + 2], depths[e.x]);
+        s_c[t] = make_float4(q2.x, q2.y, q2.z, q0.z);
         s_d[t] = co;
         s_inst[t] = e.y;
     }
