@@ -521,8 +521,17 @@ __device__ __forceinline__ void bitonic_sort_block(KEYS keys, uint32_t npad)
 // The same network with the size as a template parameter: every (k, j) stage is unrolled with its constants folded, which
 // removes the scalar loop control that made up two thirds of the generic version's instructions (sort_tiles was issue-bound:
 // 1205 SALU + 524 branch of 2706 instructions per wave). Used for the LDS sizes 64 .. 1024; 256 threads.
-template <uint32_t N>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys)
+// LDS key array with one unused slot per 8 keys: element i lives at i + (i >> 3). Threads that each hold 8 keys a fixed stride apart
+// (bitonic_sort_lds_reg below) then spread over all banks for every stride; a plain layout puts 16 lanes on one bank pair at stride 1.
+struct PaddedKeys {
+    uint64_t* p;
+    __device__ __forceinline__ uint64_t& operator[](uint32_t i) const { return p[i + (i >> 3)]; }
+    __device__ __forceinline__ PaddedKeys operator+(uint32_t off) const { return PaddedKeys{p + off + (off >> 3)}; }   // off: a multiple of 8
+};
+__host__ __device__ constexpr uint32_t padded_keys_size(uint32_t n) { return n + (n >> 3); }
+
+template <uint32_t N, typename KEYS>
+__device__ __forceinline__ void bitonic_sort_lds(KEYS keys)
 {
 #pragma unroll
     for (uint32_t k = 2; k <= N; k <<= 1) {
@@ -552,20 +561,113 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys)
     }
     __syncthreads();
 }
+// The network again, 2^MS stages per LDS round trip: a thread loads the 2^MS keys that the next MS stages of one merge level exchange
+// among themselves (strides S << (MS-1) .. S), runs those stages in registers and writes the keys back. 2048 keys: 24 passes and
+// block barriers instead of 66, a third of the LDS traffic, ~half the instructions. sort_tiles at 3.5 M instances: 153 -> see
+// profiles/r02_long_lists.json. KEYS must be PaddedKeys (bank spread, above).
+__device__ __forceinline__ void compare_exchange(uint64_t& a, uint64_t& b, bool asc)
+{
+    const bool swap = (a > b) == asc;
+    const uint64_t lo = swap ? b : a, hi = swap ? a : b;
+    a = lo; b = hi;
+}
+__host__ __device__ constexpr int ilog2_c(uint32_t v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+
+// stages with strides S << (MS-1), ..., S of merge level K
+template <uint32_t N, uint32_t K, uint32_t S, int MS>
+__device__ __forceinline__ void bitonic_reg_pass(PaddedKeys keys)
+{
+    constexpr uint32_t G = 1u << MS, NG = N / G;
+    constexpr int b = ilog2_c(S);
+#pragma unroll 1
+    for (uint32_t g = threadIdx.x; g < NG; g += 256) {
+        const uint32_t base = ((g >> b) << (b + MS)) | (g & (S - 1));
+        uint64_t v[G];
+#pragma unroll
+        for (uint32_t a = 0; a < G; a++) v[a] = keys[base + a * S];
+        const bool asc = K >= N || (base & K) == 0;
+#pragma unroll
+        for (int q = MS - 1; q >= 0; q--) {
+#pragma unroll
+            for (uint32_t a = 0; a < G; a++)
+                if (!(a & (1u << q))) compare_exchange(v[a], v[a | (1u << q)], asc);
+        }
+#pragma unroll
+        for (uint32_t a = 0; a < G; a++) keys[base + a * S] = v[a];
+    }
+    __syncthreads();
+}
+template <uint32_t N, int M, uint32_t K, int REM>   // REM: stages of level K still to run (strides 2^(REM-1) .. 1)
+__device__ __forceinline__ void bitonic_reg_level(PaddedKeys keys)
+{
+    if constexpr (REM > 0) {
+        constexpr int ms = (REM % M) ? (REM % M) : M;
+        bitonic_reg_pass<N, K, (1u << (REM - ms)), ms>(keys);
+        bitonic_reg_level<N, M, K, REM - ms>(keys);
+    }
+}
+template <uint32_t N, int M, uint32_t K>
+__device__ __forceinline__ void bitonic_reg_levels(PaddedKeys keys)
+{
+    if constexpr (K <= N) {
+        bitonic_reg_level<N, M, K, ilog2_c(K)>(keys);
+        bitonic_reg_levels<N, M, K * 2>(keys);
+    }
+}
+template <uint32_t N, int M>
+__device__ __forceinline__ void bitonic_sort_lds_reg(PaddedKeys keys)
+{
+    constexpr uint32_t G = 1u << M, NG = N / G;
+    // merge levels 2 .. G: each thread sorts G consecutive keys (ascending or descending as level G wants it) in registers
+#pragma unroll 1
+    for (uint32_t g = threadIdx.x; g < NG; g += 256) {
+        const uint32_t base = g * G;
+        uint64_t v[G];
+#pragma unroll
+        for (uint32_t a = 0; a < G; a++) v[a] = keys[base + a];
+#pragma unroll
+        for (uint32_t k = 2; k <= G; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                for (uint32_t a = 0; a < G; a++)
+                    if (!(a & j)) compare_exchange(v[a], v[a | j], k < G ? (a & k) == 0 : (G >= N || (base & G) == 0));
+            }
+        }
+#pragma unroll
+        for (uint32_t a = 0; a < G; a++) keys[base + a] = v[a];
+    }
+    __syncthreads();
+    bitonic_reg_levels<N, M, 2 * G>(keys);
+}
+
 // MAXN: largest size this call site can see. The unrolled 2048 / 4096 networks are ~20 KB of code each: instantiated inside
 // render_fwd_kernel (whose fused sort never exceeds 1024 keys) they cost that kernel 25 % through instruction-cache misses.
 template <uint32_t MAXN = 4096>
 __device__ __forceinline__ void bitonic_sort_lds_pow2(uint64_t* keys, uint32_t npad)
 {
-    if (MAXN >= 4096 && npad == 4096) { bitonic_sort_lds<(MAXN >= 4096 ? 4096 : 64)>(keys); return; }
-    if (MAXN >= 2048 && npad == 2048) { bitonic_sort_lds<(MAXN >= 2048 ? 2048 : 64)>(keys); return; }
     switch (npad) {
         case 1024: bitonic_sort_lds<1024>(keys); break;
         case 512: bitonic_sort_lds<512>(keys); break;
         case 256: bitonic_sort_lds<256>(keys); break;
         case 128: bitonic_sort_lds<128>(keys); break;
         case 64: bitonic_sort_lds<64>(keys); break;
-        default: bitonic_sort_block<true>(keys, npad); break;   // < 64 or the 2048 / 4096 lists of the large-LDS instantiation
+        default: bitonic_sort_block<true>(keys, npad); break;   // < 64
+    }
+}
+// the padded-layout variant of the kernels that see lists beyond 1024 keys: register-blocked networks from 1024 keys on
+template <uint32_t MAXN = 4096>
+__device__ __forceinline__ void bitonic_sort_lds_pow2(PaddedKeys keys, uint32_t npad)
+{
+    switch (npad) {
+        case 4096: bitonic_sort_lds_reg<4096, 3>(keys); break;
+        case 2048: bitonic_sort_lds_reg<2048, 3>(keys); break;
+        case 1024: bitonic_sort_lds_reg<1024, 2>(keys); break;
+        case 512: bitonic_sort_lds<512>(keys); break;
+        case 256: bitonic_sort_lds<256>(keys); break;
+        case 128: bitonic_sort_lds<128>(keys); break;
+        case 64: bitonic_sort_lds<64>(keys); break;
+        default: bitonic_sort_block<true>(keys, npad); break;   // < 64
     }
 }
 
@@ -578,9 +680,9 @@ constexpr int SORT_SMALL_CAP = 1024;
 // padding 520 keys to 1024 would more than double the work. Instead the list is split into A = the largest power of two <= n
 // and the rest (padded to its own power of two), both halves are sorted, and every key finds its final rank with one binary
 // search in the other half (keys are unique). Ends with the sorted (gaussian, instance) pairs in global memory.
-template <uint32_t MAXN = 4096>
+template <uint32_t MAXN = 4096, typename KEYS = uint64_t*>
 __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
-                                                 uint2* __restrict__ sorted, uint64_t* s_keys)
+                                                 uint2* __restrict__ sorted, KEYS s_keys)
 {
     const uint32_t n = r.y - r.x;
     const uint64_t* seg = keys + r.x;
@@ -593,11 +695,11 @@ __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* 
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint64_t key = s_keys[i];
         const bool in_a = i < A;
-        const uint64_t* other = in_a ? s_keys + A : s_keys;
+        const uint32_t other = in_a ? A : 0u;
         uint32_t lo = 0, hi = in_a ? B : A;              // number of keys of the other half that are smaller
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (other[mid] < key) lo = mid + 1; else hi = mid;
+            if (s_keys[other + mid] < key) lo = mid + 1; else hi = mid;
         }
         const uint32_t rank = (in_a ? i : i - A) + lo;
         const uint32_t u = (uint32_t)key;
@@ -609,14 +711,18 @@ template <int CAP, int LOWER>
 __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
                                                          uint2* sorted, const uint32_t* spec_header)
 {
-    __shared__ uint64_t s_keys[CAP];
+    constexpr bool PAD = CAP > SORT_SMALL_CAP;              // the variant for lists beyond 1024 keys: padded layout, register-blocked networks
+    __shared__ uint64_t s_keys[PAD ? padded_keys_size(CAP) : CAP];
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const uint2 r = ranges[tile];
     const uint32_t n = r.y - r.x;
     if (n <= (uint32_t)LOWER) return;                       // empty, or the other instantiation's tile
     if (CAP < SORT_LDS_CAP && n > (uint32_t)CAP) return;
-    if (n <= (uint32_t)CAP) sort_tile_in_lds<(uint32_t)CAP>(r, keys, inst_gauss, sorted, s_keys);
+    if (n <= (uint32_t)CAP) {
+        if constexpr (PAD) sort_tile_in_lds<(uint32_t)CAP>(r, keys, inst_gauss, sorted, PaddedKeys{s_keys});
+        else sort_tile_in_lds<(uint32_t)CAP>(r, keys, inst_gauss, sorted, s_keys);
+    }
     // n > SORT_LDS_CAP: sort_long_chunks_kernel + rank_long_chunks_kernel
 }
 
@@ -630,7 +736,8 @@ template <int CHUNKK>
 __global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header,
                                                                uint32_t lower)
 {
-    __shared__ uint64_t s_keys[CHUNKK];
+    __shared__ uint64_t s_raw[padded_keys_size(CHUNKK)];
+    const PaddedKeys s_keys{s_raw};
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;
     const uint2 r = ranges[blockIdx.x];
     const uint32_t n = r.y - r.x, c0 = blockIdx.y * (uint32_t)CHUNKK;
