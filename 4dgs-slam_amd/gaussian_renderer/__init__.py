@@ -121,7 +121,7 @@ def _mask_rows(mask):
 
 def _render_fused(viewpoint_camera, pc, bg_color, scaling_modifier, screenspace_points, dx, ds, dr, mask=None, dynamic=False):
     deltas = dx is not None and ds is not None and dr is not None        # the reference applies them only together (:159)
-    slot = _raw.dyn_slot_from_mask(pc.dygs) if deltas else None
+    slot = _dyn_slot(pc) if deltas else None
     f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
     xyz, log_scales, raw_rot = pc._xyz, pc._scaling, pc._rotation
     if dynamic:
@@ -220,15 +220,16 @@ def _flow_fused_ok(pc) -> bool:
 
 
 def _dyn_slot(pc):
-    """int32 slot map of pc.dygs, cached on the mask tensor (it only changes when the model is rebuilt)."""
+    """int32 slot map of pc.dygs, cached on the mask tensor (it only changes when the model is rebuilt or the mask is written)."""
     m = pc.dygs
-    s = getattr(m, "_gsr_slot", None)
-    if s is None:
-        s = _raw.dyn_slot_from_mask(m)
-        try:
-            m._gsr_slot = s
-        except Exception:
-            pass
+    hit = getattr(m, "_gsr_slot", None)
+    if hit is not None and hit[0] == m._version:
+        return hit[1]
+    s = _raw.dyn_slot_from_mask(m)
+    try:
+        m._gsr_slot = (m._version, s)
+    except Exception:
+        pass
     return s
 
 

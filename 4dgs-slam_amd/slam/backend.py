@@ -73,13 +73,13 @@ class BackEnd:
     def _deltas(self, viewpoint, train=True):
         """d_values of :361-373 for the dynamic subset, or (0, 0, None)-style "no deltas" when the network is not initialised."""
         g = self.gaussians
-        if not (self.dynamic_model and g.deform_init and bool(g.dygs.any())):
+        if not (self.dynamic_model and g.deform_init and g.dyn_rows().shape[0] > 0):
             return None, None, None
         time_input = g.deform.deform.expand_time(viewpoint.fid)
         ctx = torch.enable_grad() if train else torch.no_grad()
         with ctx:
             d = g.deform.step(g.get_dygs_xyz.detach(), time_input, iteration=0, feature=None, motion_mask=g.motion_mask,
-                              camera_center=viewpoint.camera_center, time_interval=g.time_interval)
+                              camera_center=viewpoint.camera_center, time_interval=g.time_interval, t_key=viewpoint.time)
         return d["d_xyz"], d["d_scaling"], d["d_rotation"]
 
     def _render(self, viewpoint, deltas):
@@ -122,7 +122,7 @@ class BackEnd:
         if g.deform is None:
             return
         if cur_frame_idx == self.dystart:
-            if not bool(g.dygs.any()):
+            if not g.dyn_rows().shape[0] > 0:
                 return
             g.deform.extend_node_from_point(init_pcl=g.get_dygs_xyz.detach())
             g.deform_init = True
@@ -263,23 +263,34 @@ class BackEnd:
             pkgs, n_touched_acm = [], []
             views = [viewpoint_stack[c] for c in range(len(current_window))]
             extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]
+            with_flow = use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow")
+            if use_net:       # every time sample this iteration asks the node network for, as one batch (deform_model.begin_iteration)
+                nodes, times = g.deform.deform, []
+                for viewpoint in views + extra:
+                    times += nodes.sample_times(viewpoint.time, 5 * g.time_interval, 2)
+                    closest = self.find_closest_keyframe(viewpoint.uid) if with_flow else None
+                    if closest is not None:
+                        times.append(self.viewpoints[closest].time)
+                nodes.begin_iteration(times)
             for k, viewpoint in enumerate(views + extra):
                 deltas = self._deltas(viewpoint) if use_net else (None, None, None)
                 pkg = self._render(viewpoint, deltas)
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False)
-                if use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow"):
+                if with_flow:
                     loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
                 if use_net:
                     w = 1e-3 if k < len(views) else 1e-4                     # :517-519 / :640-643
-                    loss_network = loss_network + w * g.deform.deform.arap_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_samp_num=2)
-                    loss_network = loss_network + w * g.deform.deform.elastic_loss(t=viewpoint.fid, delta_t=5 * g.time_interval)
+                    loss_network = loss_network + w * g.deform.deform.arap_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_samp_num=2, t_key=viewpoint.time)
+                    loss_network = loss_network + w * g.deform.deform.elastic_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_key=viewpoint.time)
                 pkgs.append(pkg)
                 if k < len(views):
                     n_touched_acm.append(pkg["n_touched"])
             loss_mapping = loss_mapping + self._isotropic_loss()
             total = loss_mapping + loss_network if use_net else loss_mapping
             total.backward()
+            if use_net:
+                g.deform.deform.end_iteration()
             gaussian_split = False
             with torch.no_grad():
                 self.occ_aware_visibility = {}

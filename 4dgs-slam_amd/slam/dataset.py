@@ -106,6 +106,7 @@ class SyntheticRGBDDataset:
         self._rng = torch.Generator(device="cpu").manual_seed(seed + 7)
         self.projection_matrix = getProjectionMatrix2(0.01, 100.0, self.cx, self.cy, self.fx, self.fy, width, height).transpose(0, 1).to(self.device)
         self._cache = {}
+        self._flow_cache = {}
 
     def __len__(self):
         return self.num_imgs
@@ -166,7 +167,11 @@ class SyntheticRGBDDataset:
 
     def gt_flow(self, idx_from, idx_to):
         """NDC flow [H,W,2] of frame idx_from's surface points into frame idx_to (what the reference asks RAFT for, scaled as
-        utils/camera_utils.py:412-413 does: pixels / (W, H) * 2), plus a validity mask."""
+        utils/camera_utils.py:412-413 does: pixels / (W, H) * 2), plus a validity mask. Cached per pair, like the reference keeps RAFT's
+        output on the keyframe."""
+        hit = self._flow_cache.get((idx_from, idx_to))
+        if hit is not None:
+            return hit
         color, depth, pose, motion = self[idx_from]
         H, W, dev = self.height, self.width, self.device
         d = torch.as_tensor(depth, device=dev)
@@ -179,4 +184,5 @@ class SyntheticRGBDDataset:
         p2 = pw @ self.poses[idx_to].transpose(0, 1)
         u2, v2 = p2[..., 0] / p2[..., 2] * self.fx + self.cx, p2[..., 1] / p2[..., 2] * self.fy + self.cy
         flow = torch.stack([(u2 - u) / W * 2, (v2 - v) / H * 2], -1)
+        self._flow_cache[(idx_from, idx_to)] = (flow, d > 0)
         return flow, d > 0

@@ -130,7 +130,7 @@ class FrontEnd:
         lr = self.config["Training"]["lr"]
         viewpoint.reset_pose_optimizer()
         static = None
-        if bool(self.gaussians.dygs.any()):
+        if self.gaussians.dyn_rows().shape[0] > 0:
             static = self.gaussians.dygs == False  # noqa: E712  (the reference's expression, :413)
             static._gsr_gather = _raw.gather_from_mask(static)             # one nonzero() per frame instead of one per iteration
         depth = opacity = None

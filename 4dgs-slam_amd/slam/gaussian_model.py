@@ -80,10 +80,28 @@ class GaussianModel:
     get_scaling = property(lambda s: s.scaling_activation(s._scaling))
     get_rotation = property(lambda s: s.rotation_activation(s._rotation))
     get_xyz = property(lambda s: s._xyz)
-    get_dygs_xyz = property(lambda s: s._xyz[s.dygs])
+    get_dygs_xyz = property(lambda s: s._xyz.index_select(0, s.dyn_rows()))
     get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
     get_opacity = property(lambda s: s.opacity_activation(s._opacity))
-    motion_mask = property(lambda s: torch.ones_like(s.get_dygs_xyz[..., :1]))
+    motion_mask = property(lambda s: torch.ones((s.dyn_rows().shape[0], 1), device=s._xyz.device, dtype=s._xyz.dtype))
+
+    # dygs as a property: boolean-mask indexing (`_xyz[dygs]`, GM:123-125) costs a device->host synchronisation per call -- the mapping
+    # loop asks for the dynamic subset several times per view -- so the row indices are kept until the mask is replaced or written.
+    @property
+    def dygs(self):
+        return self._dygs
+
+    @dygs.setter
+    def dygs(self, value):
+        self._dygs = value
+        self._dyn_rows_of = None
+
+    def dyn_rows(self):
+        key = (id(self._dygs), self._dygs._version)
+        if self._dyn_rows_of != key:
+            self._dyn_rows_idx = self._dygs.nonzero(as_tuple=True)[0]
+            self._dyn_rows_of = key
+        return self._dyn_rows_idx
 
     def get_covariance(self, scaling_modifier=1):
         """GM:87-93,146-149 (build_scaling_rotation, strip_symmetric) -- only the compute_cov3D_python branch of render() uses it."""

@@ -13,9 +13,14 @@ for p in (REPO, os.path.join(REPO, "4dgs-slam_amd")):
 from slam.dataset import SyntheticRGBDDataset  # noqa: E402
 from slam.system import SLAM, default_config, merge_config  # noqa: E402
 
+# --only <substring>: run the matching scenarios only; --profile: cProfile each run and print the 25 most expensive functions to stderr
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
+profile = "--profile" in sys.argv
 out = {}
 for name, dyn, graph, frames, wh in (("static_640x480_eager", False, False, 40, (640, 480)), ("static_640x480_graph", False, True, 40, (640, 480)),
                                      ("dynamic_320x240_eager", True, False, 36, (320, 240))):
+    if only not in name:
+        continue
     torch.manual_seed(0)
     ds = SyntheticRGBDDataset(num_frames=frames, width=wh[0], height=wh[1], seed=0, dynamic=dyn, dystart=6 if dyn else None, spacing=0.025 if wh[0] > 320 else 0.03)
     cfg = merge_config(default_config(), {"Training": {"init_itr_num": 400, "init_gaussian_update": 100, "init_gaussian_reset": 200, "tracking_itr_num": 60,
@@ -24,7 +29,15 @@ for name, dyn, graph, frames, wh in (("static_640x480_eager", False, False, 40, 
                                           "Dataset": {"pcd_downsample": 32, "pcd_downsample_init": 8}, "opt_params": {"densify_from_iter": 150},
                                           "model_params": {"dynamic_model": dyn}})
     slam = SLAM(cfg, ds)
-    res = slam.run()
+    if profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        res = pr.runcall(slam.run)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(20)
+    else:
+        res = slam.run()
     res["graph_stats"] = slam.frontend.graph_stats
     res["resolution"] = list(wh)
     out[name] = res
