@@ -56,7 +56,8 @@ def compute_grad_mask(original_image, config):
                 block[block > (th_median * edge_threshold)] = 1
                 block[block <= (th_median * edge_threshold)] = 0
         return img_grad_intensity
-    return img_grad_intensity > img_grad_intensity.median() * edge_threshold
+    flat = img_grad_intensity.reshape(-1)                 # the median through a sort: see frontend.lower_median
+    return img_grad_intensity > torch.sort(flat)[0][(flat.numel() - 1) // 2] * edge_threshold
 
 
 def getProjectionMatrix2(znear, zfar, cx, cy, fx, fy, W, H):

@@ -91,6 +91,9 @@ class SLAM:
         self.gaussians = fe.gaussians
         self.result = {"frames": len(fe.cameras), "keyframes": list(fe.kf_indices), "seconds": dt, "fps": len(fe.cameras) / dt,
                        "gaussians": int(self.gaussians.get_xyz.shape[0])}
+        if fe.init_done_at is not None and len(fe.cameras) > 1:          # frames per second once the map exists (tracking + keyframe mapping)
+            self.result["seconds_init"] = fe.init_done_at - t0
+            self.result["fps_after_init"] = (len(fe.cameras) - 1) / max(1e-9, t0 + dt - fe.init_done_at)
         if self.config["Results"].get("eval_rendering", True):
             self.result["ate_rmse"] = eval_ate(fe.cameras, fe.kf_indices, self.save_dir, 0, final=True, monocular=self.monocular)
             deltas_for = None
