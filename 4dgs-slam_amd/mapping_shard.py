@@ -111,8 +111,9 @@ class GradBucket:
 
     def all_reduce_grads(self, group=None):
         """Sum the parameters' gradients over ranks: in place on the gradients' own storage when they form one range
-        (no pack / unpack copies), through the persistent flat buffer otherwise."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        (no pack / unpack copies), through the persistent flat buffer otherwise. A one-rank group skips the collective unless
+        GSR_FORCE_COLLECTIVE=1 (tests: the RCCL call on the real buffers, on a box with a single GPU)."""
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _force_collective()):
             return "single"
         if getattr(self, "attached", False) and all(p.grad is v for p, v in zip(self.params, self.views)):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -125,6 +126,11 @@ class GradBucket:
         self.all_reduce(group)
         self.unpack()
         return "packed"
+
+
+def _force_collective() -> bool:
+    import os
+    return os.environ.get("GSR_FORCE_COLLECTIVE") == "1"
 
 
 def allreduce_gaussian_grads(params: Iterable[torch.Tensor], group=None, bucket: GradBucket | None = None) -> GradBucket:
@@ -150,7 +156,7 @@ def allreduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch
     (gaussian_model.py:973-977, utils/slam_backend.py:714-721), so before densify_and_prune
         xyz_gradient_accum, denom -> sum over ranks (one collective over both, packed),   max_radii2D -> max over ranks.
     In place; call it only on the iterations that densify (every ``gaussian_update_every``), not every step."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _force_collective()):
         return
     P = xyz_gradient_accum.numel()
     packed = torch.cat([xyz_gradient_accum.reshape(-1), denom.reshape(-1)])

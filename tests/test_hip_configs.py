@@ -232,3 +232,48 @@ def test_bench_single_gpu_line_carries_config5_and_both_binning_modes():
     assert d["n_gpus"] == 1 and "configs[1]" in d["config"]["workload"] and d["config"]["instances"] > 500000
     assert d["ms_per_step_nonspeculative"] >= 0.9 * d["ms_per_step"]
     assert d["config5"]["ms_per_step"] > 0 and "configs[4]" in d["config5"]["workload"]
+
+
+RCCL_ONE_RANK = r'''
+import os, sys
+sys.path[:0] = [os.path.join(r"{repo}", "tests"), r"{repo}", os.path.join(r"{repo}", "4dgs-slam_amd")]
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", GSR_FORCE_COLLECTIVE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))          # backend "nccl" IS RCCL on ROCm
+sys.argv = ["bench.py"]
+import bench
+from mapping_shard import allreduce_densification_stats
+scene = bench.Scene(60000, torch.device("cuda", 0), 0, 0.005, keyframes=(0, 1, 2, 3))
+sms, step = bench.make_cfg5(scene, [0, 1, 2, 3])
+step(); torch.cuda.synchronize()
+mode, flat_rccl = sms.mode, sms.bucket.flat.clone()
+os.environ["GSR_FORCE_COLLECTIVE"] = "0"
+step(); torch.cuda.synchronize()
+assert sms.mode == "single"
+same = bool(torch.equal(flat_rccl, sms.bucket.flat))
+os.environ["GSR_FORCE_COLLECTIVE"] = "1"
+a, d, r = torch.rand(1000, 1, device="cuda"), torch.rand(1000, 1, device="cuda"), torch.rand(1000, device="cuda")
+a0, d0, r0 = a.clone(), d.clone(), r.clone()
+allreduce_densification_stats(a, d, r)
+torch.cuda.synchronize()
+stats_ok = bool(torch.equal(a, a0) and torch.equal(d, d0) and torch.equal(r, r0))
+print("RESULT", mode, same, stats_ok, dist.get_backend(), float(flat_rccl.abs().sum()) > 0)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_all_reduce_on_the_attached_gradient_bucket_one_rank():
+    """The only RCCL exercise a single-GPU box allows: a one-rank "nccl" (= RCCL) group, the sharded mapping step of config #5 with the
+    collective FORCED (GSR_FORCE_COLLECTIVE=1; one rank normally skips it): the all-reduce runs on the gradients' own storage ("attached"
+    mode), in stream order between the last backward and the fused Adam, and leaves exactly the gradients of the step without it; the
+    sum / sum / max reduction of the densification statistics goes through RCCL as well."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK.format(repo=repo)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert res[1:] == ["attached", "True", "True", "nccl", "True"], res
