@@ -72,6 +72,22 @@ __device__ __forceinline__ int pop_lowest_bit(unsigned long long& m)
     return j;
 }
 
+// pop_lowest_bit + row = j * 16 in a VGPR: the byte offset of staged entry j inside every 16-byte-per-entry LDS array. One VALU
+// instruction (the compiler's s_lshl + v_mov pair costs an SALU slot more) and, being volatile, it is neither recomputed nor
+// re-materialised: all LDS reads of a pair use this one register with constant offsets. One asm block: between two separate blocks
+// the hazard recogniser puts an s_nop it cannot prove unnecessary.
+__device__ __forceinline__ int pop_lowest_bit_row16(unsigned long long& m, uint32_t& row)
+{
+    int j;
+    asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0\n\tv_lshlrev_b32 %2, 4, %0" : "=&s"(j), "+s"(m), "=v"(row));
+    return j;
+}
+template <typename T>
+__device__ __forceinline__ T lds_at(const void* array, uint32_t byte_offset)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(array) + byte_offset);
+}
+
 __device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned long long* p)
 {
     const unsigned long long m = *p;
@@ -179,12 +195,16 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         // of a VGPR (s_bcnt1 + v_writelane) and the 64 counts go to LDS with one ds_add per group.
         auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int jbase) {
             int counts = 0;
+            uint32_t last_row = ~0u;                       // lds_row16 of the last entry this group blended into the pixel
+            const float4* const ga = s_a + jbase;          // uniform: folds into the reads' constant offsets
+            const float4* const gb = s_b + jbase;
+            const float4* const gc = s_c + jbase;
             while (m) {
-                const int jj = pop_lowest_bit(m);
-                const int j = jbase + jj;
-                const float4 A4 = s_a[j];
-                const float2 B2 = *reinterpret_cast<const float2*>(&s_b[j]);
-                const float4 C4 = s_c[j];
+                uint32_t row;
+                const int jj = pop_lowest_bit_row16(m, row);
+                const float4 A4 = lds_at<float4>(ga, row);
+                const float2 B2 = lds_at<float2>(gb, row);
+                const float4 C4 = lds_at<float4>(gc, row);
                 const f2 d = f2{A4.x, A4.y} - pxy;
                 // alpha = o exp(power) = exp2(power log2e + log2 o): the opacity rides in the exponent (one multiply less per pair)
 #if GSR_EXACT_MATH
@@ -204,12 +224,14 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                 acc_rg += f2{C4.x, C4.y} * w;                                                       // :364-367
                 acc_bd += f2{C4.z, C4.w} * w;
                 T = blend ? test_T : T;
-                last = blend ? (uint32_t)(base + j + 1) : last;                                     // `contributor`, :338,:376
+                last_row = blend ? row : last_row;                                                  // `contributor`, :338,:376 (resolved below)
                 if (COUNT_TOUCHED.value) {
                     const unsigned long long tm = __builtin_amdgcn_ballot_w64(test_T > (blend ? 0.5f : INF));   // blend && test_T > 0.5, :369-371
                     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(counts) : "s"((int)__popcll(tm)), "s"(jj) : "m0");   // two SGPR operands would exceed the constant bus
                 }
             }
+            // entries are visited in list order, so the group's last blended entry is the pixel's new `last` (1-based list position)
+            last = last_row != ~0u ? (uint32_t)(base + jbase + 1) + (last_row >> 4) : last;
             if (COUNT_TOUCHED.value) {
                 if (counts) __hip_atomic_fetch_add(&s_nt[jbase + lane], counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -289,10 +311,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
-    __shared__ float2 s_b[BB];   // {C, log2 opacity}                                                 (C = -c/2 log2e)
+    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, Gaussian id bits}             (C = -c/2 log2e)
     __shared__ float4 s_c[BB];   // {r, g, b, depth}
-    __shared__ float4 s_d[BB];   // {conic.x, conic.y, conic.z, opacity}: only the per-entry epilogue needs the unscaled conic
-    __shared__ uint32_t s_inst[BB];   // instance id of the entry (its gradient slot)
+    // The three arrays share one index scale, so a pair addresses all of them from ONE VGPR (j * 16 + constant offset): a float2 s_b cost
+    // the loop a second shift + move per pair. The unscaled conic and the opacity, which only the per-entry epilogue needs, are re-read
+    // from the Gaussian's record there (an L2 hit: the staging code above just loaded it) instead of being parked in 2 KiB of LDS.
     // Quadrant totals of ONE 64-entry group (12 floats per (quadrant, entry): three float4 = the three 16-byte pieces of a slot).
     // Sized for a group, not for the whole chunk, the block needs 19.6 KiB of LDS instead of 28.8 and eight blocks share a CU
     // instead of five: a single wave issues one instruction per ~8 cycles on this part (profiles/r02_ubench_issue.json), the SIMD
@@ -378,13 +401,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
 #if GSR_EXACT_MATH
         s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
-        s_b[t] = make_float2(co.z, co.w);
+        s_b[t] = make_float4(co.z, co.w, __uint_as_float(e.y), __uint_as_float(e.x));
 #else
-        s_b[t] = make_float2(-0.5f * LOG2E * co.z, __log2f(co.w));   // log2(opacity): folded into the exponent
+        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), __uint_as_float(e.x));   // log2(opacity): folded into the exponent
 #endif
         s_c[t] = make_float4(q2.x, q2.y, q2.z, q0.z);
-        s_d[t] = co;
-        s_inst[t] = e.y;
     }
     // pos < last_contrib (:678)  <=>  j >= cend - last_contrib, with j the index inside this chunk
     const int j_thr = cend - last_contrib;
@@ -400,10 +421,10 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     int group_base = 0;
     // One (quadrant, entry) pair: entry jj of the current group. (Issuing the LDS reads one iteration ahead was measured: +3 % -- the
     // extra scalar bookkeeping costs more issue slots than the hidden latency returns; the other resident waves already cover it.)
-    auto bwd_pair = [&](int jj) {
+    auto bwd_pair = [&](int jj, uint32_t row) {
         const int j = group_base + jj;
-        const float4 A4 = s_a[j];
-        const float2 B2 = s_b[j];
+        const float4 A4 = lds_at<float4>(s_a + group_base, row);
+        const float2 B2 = lds_at<float2>(s_b + group_base, row);
         const f2 d = f2{A4.x, A4.y} - pxy;
         // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
         // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
@@ -419,7 +440,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
 #endif
         if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-        const float4 C4 = s_c[j];                                                             // {r, g, b, depth}
+        const float4 C4 = lds_at<float4>(s_c + group_base, row);                              // {r, g, b, depth}
         const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
         const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
 #if GSR_EXACT_MATH
@@ -450,7 +471,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
         proc = 0;
         group_base = sw * 64;
-        while (mk) bwd_pair(pop_lowest_bit(mk));
+        while (mk) {
+            uint32_t row;
+            const int jj = pop_lowest_bit_row16(mk, row);
+            bwd_pair(jj, row);
+        }
         if (lane == 0) s_proc[wave][sw] = proc;
         __syncthreads();
         // Group epilogue: add the four quadrants in a fixed order, turn the moments into the reference's gradients and write the
@@ -466,7 +491,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                 }
             }
-            const float4 K4 = s_d[j];                       // {conic.x, conic.y, conic.z, opacity}
+            const float4 sb = s_b[j];
+            const TileRec* const g = rec + __float_as_uint(sb.w);
+            float4 K4 = make_float4(0.f, 0.f, 0.f, 0.f);    // {conic.x, conic.y, conic.z, opacity}: each wave loads the part it uses
+            if (wave == 0) K4 = g->q1;
+            else if (wave == 1) K4.w = g->q0.w;
             float4 o4;
             if (wave == 0)          // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
                 o4 = make_float4(-(K4.x * sum.x + K4.y * sum.y) * (0.5f * W), -(K4.z * sum.y + K4.y * sum.x) * (0.5f * H), -0.5f * sum.z, -0.5f * sum.w);
@@ -474,7 +503,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 o4 = make_float4(-0.5f * sum.x, K4.w > 0.f ? sum.y / K4.w : 0.f, sum.z, sum.w);
             else                    // {b, depth} (:719,:729)
                 o4 = make_float4(sum.x, sum.y, 0.f, 0.f);
-            reinterpret_cast<float4*>(partials)[(size_t)s_inst[j] * 3 + wave] = o4;
+            reinterpret_cast<float4*>(partials)[(size_t)__float_as_uint(sb.z) * 3 + wave] = o4;
         }
         if (sw == 0) __syncthreads();   // s_part is reused by the second group
     }
