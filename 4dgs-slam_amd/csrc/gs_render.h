@@ -311,11 +311,12 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
-    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, Gaussian id bits}             (C = -c/2 log2e)
+    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, opacity}                       (C = -c/2 log2e)
     __shared__ float4 s_c[BB];   // {r, g, b, depth}
     // The three arrays share one index scale, so a pair addresses all of them from ONE VGPR (j * 16 + constant offset): a float2 s_b cost
-    // the loop a second shift + move per pair. The unscaled conic and the opacity, which only the per-entry epilogue needs, are re-read
-    // from the Gaussian's record there (an L2 hit: the staging code above just loaded it) instead of being parked in 2 KiB of LDS.
+    // the loop a second shift + move per pair. The per-entry epilogue needs the unscaled conic: it undoes the scaling of A, B, C (one
+    // rounding, <= 1.5 ulp on the factor of dL_dmean2D; the exact-math build stages the conic unscaled) instead of parking a second
+    // copy in 2 KiB of LDS; re-reading the Gaussian's record there was measured too: +14 MB of fabric traffic per launch.
     // Quadrant totals of ONE 64-entry group (12 floats per (quadrant, entry): three float4 = the three 16-byte pieces of a slot).
     // Sized for a group, not for the whole chunk, the block needs 19.6 KiB of LDS instead of 28.8 and eight blocks share a CU
     // instead of five: a single wave issues one instruction per ~8 cycles on this part (profiles/r02_ubench_issue.json), the SIMD
@@ -401,9 +402,9 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
 #if GSR_EXACT_MATH
         s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
-        s_b[t] = make_float4(co.z, co.w, __uint_as_float(e.y), __uint_as_float(e.x));
+        s_b[t] = make_float4(co.z, co.w, __uint_as_float(e.y), co.w);
 #else
-        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), __uint_as_float(e.x));   // log2(opacity): folded into the exponent
+        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), co.w);   // log2(opacity): folded into the exponent
 #endif
         s_c[t] = make_float4(q2.x, q2.y, q2.z, q0.z);
     }
@@ -492,10 +493,12 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
                 }
             }
             const float4 sb = s_b[j];
-            const TileRec* const g = rec + __float_as_uint(sb.w);
-            float4 K4 = make_float4(0.f, 0.f, 0.f, 0.f);    // {conic.x, conic.y, conic.z, opacity}: each wave loads the part it uses
-            if (wave == 0) K4 = g->q1;
-            else if (wave == 1) K4.w = g->q0.w;
+            const float4 sa = s_a[j];
+#if GSR_EXACT_MATH
+            const float4 K4 = make_float4(sa.z, sa.w, sb.x, sb.w);                                           // {conic.x, conic.y, conic.z, opacity}
+#else
+            const float4 K4 = make_float4(sa.z * (-2.0f / LOG2E), sa.w * (-1.0f / LOG2E), sb.x * (-2.0f / LOG2E), sb.w);
+#endif
             float4 o4;
             if (wave == 0)          // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
                 o4 = make_float4(-(K4.x * sum.x + K4.y * sum.y) * (0.5f * W), -(K4.z * sum.y + K4.y * sum.x) * (0.5f * H), -0.5f * sum.z, -0.5f * sum.w);

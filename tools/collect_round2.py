@@ -52,6 +52,13 @@ for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "track
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('iterationflow', 'iteration_flow').replace('iterationnodesflow', 'iteration_nodes_flow').replace('iterationnodes', 'iteration_nodes')}"))
+# bench.py quotes roofline.traffic from profiles/r02_hbm_traffic.json as committed when it ran; the copies kept here carry this run's figure
+for name in ("bench.json", "bench_under_rocprof.json"):
+    p = os.path.join(dst, f"{tag}_{name}")
+    if os.path.exists(p):
+        b = json.load(open(p))
+        b["roofline"]["traffic"] = out["render_bwd_bytes_per_launch"]
+        json.dump(b, open(p, "w"))
 subprocess.run([sys.executable, os.path.join(REPO, "tools", "collect_counters.py"), "r02", "r02"], check=True)
 print(json.dumps({k: (round(v["rocprof_avg_us"], 1) if v["rocprof_avg_us"] else None, int(v["hbm_bytes_per_launch"])) for k, v in out["kernels"].items()}))
 print("render_bwd traffic / algorithmic:", round(out["render_bwd_traffic_over_algorithmic"], 2), " whole step:", round(out["whole_step_traffic_over_algorithmic"], 2))
