@@ -22,6 +22,11 @@ struct GeomBwdArgs {
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot; float* dL_dtau;
     float* tau_partials;   // optional [nblocks][6]: per-block sums of dL_dtau, so the caller does not have to reduce [P,6]
+    // GSR_BACKWARD_ACCUMULATE: the PARAMETER gradients (dL_dmean3D, dL_dsh, dL_dopacity, dL_dscale, dL_drot; raw mode: their raw
+    // counterparts) are added to what the buffers hold, for visible Gaussians only -- rows of invisible Gaussians are not touched.
+    // A caller that sums several views into one .grad buffer (mapping: 8-64 keyframes per optimizer step) thereby skips both the
+    // zero rows this kernel would write (71 % of 2 M Gaussians at BASELINE config #5) and autograd's read-modify-write of five tensors.
+    int accumulate;
     // Raw mode (raw.xyz != nullptr, see gs_device.h): the inputs are the model's raw parameters and the outputs their gradients:
     // dL_dmean3D -> d/d_xyz, dL_dscale -> d/d_scaling [P,scale_dim], dL_drot -> d/d_rotation, dL_dopacity -> d/d_opacity (logit),
     // rawg.f_dc / f_rest -> d/d_features_*, rawg.ddx / dds / ddr [K,*] -> gradients of the control-node deltas.
@@ -36,6 +41,33 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     const size_t i = (size_t)(in_range ? idx : 0);
     const bool visible = in_range && a.radii[idx] > 0;   // backward.cu:163,443
     const size_t o = in_range && a.raw.xyz ? raw_row(a.raw, i) : i;   // row of the parameter-gradient outputs (raw mode with a mask: the selected row)
+    // Accumulate mode (GeomBwdArgs::accumulate): what the caller's gradient buffers hold for this Gaussian is loaded HERE, so the loads
+    // are in flight while the instance slots are summed and the chain rules evaluated (a read-modify-write at the end of the kernel
+    // left their latency exposed: 116 -> 140 us at 2 M Gaussians). old_*: zero when the mode is off. add_separately: the
+    // addition must not be contracted into the expression that produced the gradient (autograd's accumulation rounds it first).
+    const bool scale1 = a.raw.xyz && a.raw.scale_dim == 1;
+    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
+    float* const dc_out = a.raw.xyz ? (a.rawg.f_dc ? a.rawg.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
+    if (a.accumulate && visible) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
+        old_o = a.dL_dopacity[o];
+        if (a.dL_dscale) {
+            if (scale1) old_s[0] = a.dL_dscale[o];
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) old_s[k] = a.dL_dscale[3 * o + k];
+            }
+        }
+        if (a.dL_drot) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) old_r[k] = a.dL_drot[4 * o + k];
+        }
+        if (dc_out) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) old_c[k] = dc_out[k];
+        }
+    }
 
     // ---- gather: sum this Gaussian's per-instance slots ----------------------------------------------------------
     // Instance ids are a global running count over Gaussians, so the 256 Gaussians of a block own ONE contiguous range of
@@ -123,7 +155,8 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     if (in_range) {
         a.dL_dmean2D[3 * o] = g_m2x; a.dL_dmean2D[3 * o + 1] = g_m2y; a.dL_dmean2D[3 * o + 2] = 0.f;   // z never written, Q14
         if (a.dL_dconic) { a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw; }
-        a.dL_dopacity[o] = a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op;   // raw: through the sigmoid
+        if (visible || !a.accumulate)
+            a.dL_dopacity[o] = add_separately(old_o, a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
         if (a.dL_dcolor) { a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b; }
         if (a.dL_ddepth) a.dL_ddepth[i] = g_d;
     }
@@ -132,10 +165,10 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool flow = a.raw.xyz && a.raw.flow_proj1;
     const bool has_sh = flow ? false : (a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr));
-    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr}
-                                : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr};
+    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}}
+                                : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}};
     if (!visible) {
-        if (has_sh && in_range) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
+        if (has_sh && in_range && !a.accumulate) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
     } else {
         const float* vm = a.viewmatrix;
         const f3 mean = load_mean(a.means3D, a.raw, i);
@@ -252,7 +285,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/ddir
             const int deg = a.D;
             const int used = (deg + 1) * (deg + 1);
-            for (int k = used * 3; k < a.M * 3; k++) dsh[k] = 0.f;
+            if (!a.accumulate) for (int k = used * 3; k < a.M * 3; k++) dsh[k] = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float g = dRGB[k];
@@ -327,20 +360,23 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         }
     }
     if (in_range) {
+        const bool wr = visible || !a.accumulate;     // accumulate mode leaves the rows of invisible Gaussians alone
+        if (wr) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * o + k] = dmean[k];
+            for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * o + k] = add_separately(old_m[k], dmean[k]);
+        }
 #pragma unroll
         for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) if (a.dL_dtau) a.dL_dtau[6 * i + k] = dtau[k];
         if (!a.raw.xyz) {
-            if (a.dL_dscale) {
+            if (a.dL_dscale && wr) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = dscale[k];
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = add_separately(old_s[k], dscale[k]);
             }
-            if (a.dL_drot) {
+            if (a.dL_drot && wr) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = drot[k];
+                for (int k = 0; k < 4; k++) a.dL_drot[4 * i + k] = add_separately(old_r[k], drot[k]);
             }
         } else {
             // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
@@ -364,18 +400,22 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
                 if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
                 if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
             }
-            if (a.raw.scale_dim == 1) {
-                a.dL_dscale[o] = (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[o]);
+            if (!wr) {
+                // accumulate mode, invisible Gaussian: its parameter-gradient rows stay as they are
+            } else if (a.raw.scale_dim == 1) {
+                a.dL_dscale[o] = add_separately(old_s[0], (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[o]));
             } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = dscale[k] * expf(a.raw.log_scales[3 * o + k]);
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = add_separately(old_s[k], dscale[k] * expf(a.raw.log_scales[3 * o + k]));
             }
             const float ra = a.raw.raw_rot[4 * o], rb = a.raw.raw_rot[4 * o + 1], rc = a.raw.raw_rot[4 * o + 2], rd = a.raw.raw_rot[4 * o + 3];
             const float inv = 1.0f / fmaxf(sqrtf(ra * ra + rb * rb + rc * rc + rd * rd), 1e-12f);
             const float qa = ra * inv, qb = rb * inv, qc = rc * inv, qd = rd * inv;
             const float dotg = qa * drot[0] + qb * drot[1] + qc * drot[2] + qd * drot[3];
-            a.dL_drot[4 * o] = (drot[0] - qa * dotg) * inv; a.dL_drot[4 * o + 1] = (drot[1] - qb * dotg) * inv;
-            a.dL_drot[4 * o + 2] = (drot[2] - qc * dotg) * inv; a.dL_drot[4 * o + 3] = (drot[3] - qd * dotg) * inv;
+            if (wr) {
+                a.dL_drot[4 * o] = add_separately(old_r[0], (drot[0] - qa * dotg) * inv); a.dL_drot[4 * o + 1] = add_separately(old_r[1], (drot[1] - qb * dotg) * inv);
+                a.dL_drot[4 * o + 2] = add_separately(old_r[2], (drot[2] - qc * dotg) * inv); a.dL_drot[4 * o + 3] = add_separately(old_r[3], (drot[3] - qd * dotg) * inv);
+            }
         }
     }
     // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with

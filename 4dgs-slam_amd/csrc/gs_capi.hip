@@ -373,7 +373,11 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         GSR_STAGE("preprocess_fwd");
         if (lds_hist) {
             ScopedKernelTimer tm(K_SCAN, stream);
-            hipLaunchKernelGGL(tile_offsets_kernel, dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS), 0, stream, nblocks, T,
+            if (nblocks <= TO_SEGS * 16)
+                hipLaunchKernelGGL((tile_offsets_kernel<TO_SEGS, 16>), dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS), 0, stream, nblocks, T,
+                               img.block_tile_base, img.tile_count);
+            else
+                hipLaunchKernelGGL((tile_offsets_kernel<TO_SEGS_BIG, 32>), dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS_BIG), 0, stream, nblocks, T,
                                img.block_tile_base, img.tile_count);
         }
         GSR_STAGE("tile_offsets");
@@ -550,6 +554,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                  const gsr_raw_inputs* raw, const gsr_raw_grads* rawg)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool accumulate = (debug & GSR_BACKWARD_ACCUMULATE) != 0;     // include/gs_rasterizer.h
+    debug &= 1;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
     if (P == 0) { if (dL_dtau_sum) GSR_HIP_CHECK(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), stream)); return 0; }
     // Intermediate gradients the caller does not want may be NULL (dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D; dL_dtau when
@@ -583,6 +589,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets; a.bin_base = binning_buffer; a.header = geom.header;
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
+    a.accumulate = accumulate ? 1 : 0;
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
     a.raw = to_device_view(raw);
     a.rawg = RawGrads{};

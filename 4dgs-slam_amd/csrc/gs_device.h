@@ -231,9 +231,27 @@ struct ShView {    // SH coefficients of one Gaussian: [k] with k = 3 * coeffici
     const float* dc; const float* rest;
     __device__ __forceinline__ float operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
 };
+// a + b as its own instruction: `a + (x * y)` would otherwise be contracted into one fma (HIP's __fadd_rn is a plain `+` and does not
+// prevent that); the accumulate mode of the backward pass must round the gradient first, as autograd's own accumulation does.
+__device__ __forceinline__ float add_separately(float a, float b)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct ShOut {
     float* dc; float* rest;
-    __device__ __forceinline__ float& operator[](int k) const { return k < 3 ? dc[k] : rest[k - 3]; }
+    bool acc;        // accumulate mode (GSR_BACKWARD_ACCUMULATE): assignments add to what the caller's gradient buffer already holds
+    float old_dc[3]; // ... whose DC part the kernel loaded up front (zero when the mode is off); higher bands are read here
+    struct Ref {
+        float* p; bool acc; float old; bool have_old;
+        __device__ __forceinline__ void operator=(float v) const { *p = have_old ? add_separately(old, v) : (acc ? add_separately(*p, v) : v); }
+    };
+    __device__ __forceinline__ Ref operator[](int k) const
+    {
+        return k < 3 ? Ref{dc + k, acc, old_dc[k], true} : Ref{rest + (k - 3), acc, 0.f, false};
+    }
 };
 
 struct f3 { float x, y, z; };

@@ -247,18 +247,20 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 }
 
 // F1b: column scan of the [nblocks][T] histogram: hist[b][t] <- sum_{b' < b} hist[b'][t], tile_count[t] <- column total.
-// 16 columns x 16 row segments per 256-thread block; a wave reads 4 x 64 contiguous bytes per row.
-constexpr int TO_COLS = 16, TO_SEGS = 16;
-__global__ void __launch_bounds__(TO_COLS * TO_SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
-                                                                         uint32_t* __restrict__ tile_count)
+// 16 columns x SEGS row segments per block; a wave reads 4 x 64 contiguous bytes per row. SEGS = 16 (256 threads) up to 256 Gaussian
+// blocks; SEGS = 64 (1024 threads) beyond, so that a thread's rows still fit in registers (32 x 64 = 2048 blocks = 2.1 M Gaussians:
+// BASELINE config #5 has 1954) -- the serial fall-back loop took 40 us there.
+constexpr int TO_COLS = 16, TO_SEGS = 16, TO_SEGS_BIG = 64;
+template <int SEGS, int RMAX>
+__global__ void __launch_bounds__(TO_COLS * SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
+                                                                      uint32_t* __restrict__ tile_count)
 {
-    __shared__ uint32_t s_seg[TO_SEGS][TO_COLS];
+    __shared__ uint32_t s_seg[SEGS][TO_COLS];
     const int c = threadIdx.x & (TO_COLS - 1), seg = threadIdx.x / TO_COLS;
     const int col = blockIdx.x * TO_COLS + c;
-    const int rows_per_seg = (nblocks + TO_SEGS - 1) / TO_SEGS;
+    const int rows_per_seg = (nblocks + SEGS - 1) / SEGS;
     const int r0 = seg * rows_per_seg, r1 = min(nblocks, r0 + rows_per_seg);
-    constexpr int RMAX = 16;                 // rows a thread keeps in registers: up to 256 Gaussian blocks (262 144 Gaussians) in one pass
-    const bool in_regs = rows_per_seg <= RMAX;
+    const bool in_regs = rows_per_seg <= RMAX;       // rows a thread keeps in registers: one pass over the matrix
     uint32_t v[RMAX];
     uint32_t sum = 0;
     if (col < T) {
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(TO_COLS * TO_SEGS) tile_offsets_kernel(int nbl
     s_seg[seg][c] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
-    for (int k = 0; k < TO_SEGS; k++) { const uint32_t x = s_seg[k][c]; if (k < seg) run += x; total += x; }
+    for (int k = 0; k < SEGS; k++) { const uint32_t x = s_seg[k][c]; if (k < seg) run += x; total += x; }
     if (col < T) {
         if (in_regs) {
 #pragma unroll

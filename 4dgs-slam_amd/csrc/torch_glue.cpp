@@ -101,7 +101,7 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
                                    const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, const torch::Tensor& sh_,
                                    int64_t degree, const torch::Tensor& campos_, const torch::Tensor& geomBuffer, int64_t R,
                                    const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug, bool lean,
-                                   int64_t stream)
+                                   int64_t stream, const std::vector<torch::Tensor>& accumulate_into)
 {
     TORCH_CHECK(means3D_.is_cuda(), "means3D is on '", means3D_.device().str(),
                 "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
@@ -118,8 +118,19 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     // come from SH; cov3D when it comes from scales/rotations) are neither allocated nor written -- 80 of the 148 bytes the
     // geometry kernel stores per Gaussian. The autograd Function asks for this; the reference-shaped entry point does not.
     const bool sh_in = M > 0 && colors_.numel() == 0, cov_in = cov3D_.numel() != 0;
-    const int64_t widths[11] = {3, 3 * M, 1, 3, 4, 3, (lean && sh_in) ? 0 : kChannels, lean ? 0 : 1, lean ? 0 : 4,
-                                (lean && !cov_in) ? 0 : 6, lean ? 0 : 6};
+    // accumulate_into = the caller's five parameter-gradient buffers (means3D, sh, opacity, scales, rotations: fp32, contiguous, the
+    // parameters' sizes): the kernels ADD this view's gradients to them (GSR_BACKWARD_ACCUMULATE) and nothing is allocated for them
+    const bool acc = accumulate_into.size() == 5;
+    TORCH_CHECK(acc || accumulate_into.empty(), "accumulate_into: five gradient buffers or none");
+    const int64_t pw[5] = {3, 3 * M, 1, 3, 4};
+    if (acc) {
+        TORCH_CHECK(sh_in && !cov_in, "accumulate_into needs the SH + scales / rotations inputs");
+        for (int i = 0; i < 5; i++)
+            TORCH_CHECK(accumulate_into[i].is_cuda() && accumulate_into[i].scalar_type() == torch::kFloat32 && accumulate_into[i].is_contiguous() &&
+                        accumulate_into[i].numel() == P * pw[i], "accumulate_into[", i, "]: contiguous fp32 device tensor of ", P * pw[i], " elements expected");
+    }
+    const int64_t widths[11] = {acc ? 0 : 3, acc ? 0 : 3 * M, acc ? 0 : 1, acc ? 0 : 3, acc ? 0 : 4, 3, (lean && sh_in) ? 0 : kChannels, lean ? 0 : 1,
+                                lean ? 0 : 4, (lean && !cov_in) ? 0 : 6, lean ? 0 : 6};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
     torch::Tensor flat = P == 0 ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);
@@ -127,6 +138,7 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     int64_t o = 0;
     for (int i = 0; i < 11; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
     auto shaped = [&](int i, std::vector<int64_t> shape) { return widths[i] ? v[i].view(shape) : v[i]; };   // skipped ones stay empty
+    if (acc) for (int i = 0; i < 5; i++) v[i] = accumulate_into[i];
     torch::Tensor dL_dmeans3D = v[0].view({P, 3}), dL_dsh = v[1].view({P, M, 3}), dL_dopacity = v[2].view({P, 1}),
                   dL_dscales = v[3].view({P, 3}), dL_drotations = v[4].view({P, 4}), dL_dmeans2D = v[5].view({P, 3}),
                   dL_dcolors = shaped(6, {P, kChannels}), dL_ddepths = shaped(7, {P, 1}), dL_dconic = shaped(8, {P, 2, 2}),
@@ -150,7 +162,8 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
             reinterpret_cast<char*>(imageBuffer.data_ptr()), fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), dL_dmeans2D.data_ptr<float>(),
             optr(dL_dconic), dL_dopacity.data_ptr<float>(), optr(dL_dcolors), optr(dL_ddepths),
             dL_dmeans3D.data_ptr<float>(), optr(dL_dcov3D), sh_path ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
-            dL_drotations.data_ptr<float>(), optr(dL_dtau), tau_sum.data_ptr<float>(), debug ? 1 : 0, reinterpret_cast<void*>(stream));
+            dL_drotations.data_ptr<float>(), optr(dL_dtau), tau_sum.data_ptr<float>(), (debug ? 1 : 0) | (acc ? GSR_BACKWARD_ACCUMULATE : 0),
+            reinterpret_cast<void*>(stream));
         if (rc < 0) fail("gsr_backward", rc);
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum);

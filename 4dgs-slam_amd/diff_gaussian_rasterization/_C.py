@@ -208,20 +208,24 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
 
 def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                        viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depths,
-                                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, lean=False):
+                                       sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, lean=False, accumulate_into=None):
     """Same as rasterize_gaussians_backward plus a 10th result: dL_dtau summed over the Gaussians, float32[6] = [rho, theta]
     (the reduction the reference's autograd Function does with torch.sum, __init__.py:152-154, fused into the kernels).
     lean=True: gradients that only feed other gradients inside the kernel are neither allocated nor written and come back
     as empty tensors -- dL_dtau [P,6] always, dL_dcolors when colours come from SH, dL_dcov3D when it comes from scales and
-    rotations (plus the never-returned dL_dconic / dL_ddepth): 80 of the 148 bytes the kernel stores per Gaussian."""
+    rotations (plus the never-returned dL_dconic / dL_ddepth): 80 of the 148 bytes the kernel stores per Gaussian.
+    accumulate_into = (g_means3D, g_sh, g_opacity, g_scales, g_rotations): the caller's gradient buffers (fp32, contiguous); this
+    view's parameter gradients are ADDED to them by the kernels (GSR_BACKWARD_ACCUMULATE, include/gs_rasterizer.h) and the same
+    tensors come back in the result tuple."""
     _require_device(means3D, "means3D")
+    accumulate_into = list(accumulate_into) if accumulate_into is not None else []
     if _glue is not None:
         with torch.cuda.device(means3D.device):
             return _glue.rasterize_gaussians_backward_fused(background, means3D, radii, colors, scales, rotations, float(scale_modifier),
                                                             cov3D_precomp, viewmatrix, projmatrix, projmatrix_raw, float(tan_fovx),
                                                             float(tan_fovy), dL_dout_color, dL_dout_depths, sh, int(degree), campos,
                                                             geomBuffer, int(R), binningBuffer, imageBuffer, bool(debug), bool(lean),
-                                                            _stream(means3D.device))
+                                                            _stream(means3D.device), accumulate_into)
     lib = load_library()
     dev = means3D.device
     P = int(means3D.shape[0])
@@ -232,13 +236,25 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
     # Layout: the five tensors that become the Gaussian parameters' .grad come first, back to back (means3D, sh, opacity,
     # scales, rotations), so mapping_shard.GradBucket can all-reduce them in place as one flat range.
     sh_in, cov_in = M > 0 and colors.numel() == 0, cov3D_precomp.numel() != 0
-    widths = [3, 3 * M, 1, 3, 4, 3, 0 if (lean and sh_in) else NUM_CHANNELS, 0 if lean else 1, 0 if lean else 4,
-              0 if (lean and not cov_in) else 6, 0 if lean else 6]
+    acc = len(accumulate_into) == 5
+    if accumulate_into and not acc:
+        raise ValueError("accumulate_into: five gradient buffers or none")
+    pw = [3, 3 * M, 1, 3, 4]
+    if acc:
+        if not (sh_in and not cov_in):
+            raise ValueError("accumulate_into needs the SH + scales / rotations inputs")
+        for t_, w_ in zip(accumulate_into, pw):
+            if not (t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == P * w_):
+                raise ValueError(f"accumulate_into: contiguous fp32 device tensor of {P * w_} elements expected")
+    widths = [0 if acc else w_ for w_ in pw] + [3, 0 if (lean and sh_in) else NUM_CHANNELS, 0 if lean else 1, 0 if lean else 4,
+                                                 0 if (lean and not cov_in) else 6, 0 if lean else 6]
     flat = (torch.zeros if P == 0 else torch.empty)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
     views, o = [], 0
     for w_ in widths:
         views.append(flat[o:o + P * w_])
         o += P * w_
+    if acc:
+        views[:5] = accumulate_into
     dL_dmeans3D, dL_dsh, dL_dopacity = views[0].view(P, 3), views[1].view(P, M, 3), views[2].view(P, 1)
     dL_dscales, dL_drotations, dL_dmeans2D = views[3].view(P, 3), views[4].view(P, 4), views[5].view(P, 3)
     shaped = lambda i, *shape: views[i].view(*shape) if widths[i] else views[i]     # skipped ones stay empty
@@ -272,7 +288,7 @@ def rasterize_gaussians_backward_fused(background, means3D, radii, colors, scale
                 p(gc, "dL_dout_color"), p(gd, "dL_dout_depth"),
                 dL_dmeans2D.data_ptr(), optr(dL_dconic), dL_dopacity.data_ptr(), optr(dL_dcolors), optr(dL_ddepths),
                 dL_dmeans3D.data_ptr(), optr(dL_dcov3D), dL_dsh.data_ptr() if sh_path else None,
-                dL_dscales.data_ptr(), dL_drotations.data_ptr(), optr(dL_dtau), tau_sum.data_ptr(), int(bool(debug)), stream)
+                dL_dscales.data_ptr(), dL_drotations.data_ptr(), optr(dL_dtau), tau_sum.data_ptr(), int(bool(debug)) | (2 if acc else 0), stream)
         if rc < 0:
             _err(lib, rc, "gsr_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum

@@ -29,9 +29,28 @@ def _call(fn, args, debug, dump_path, message):
         raise
 
 
-def _lean_backward(*args):
+def _lean_backward(*args, accumulate_into=None):
     """Backward without the intermediate per-Gaussian gradients nobody reads here (see _C.rasterize_gaussians_backward_fused)."""
-    return _C.rasterize_gaussians_backward_fused(*args, lean=True)
+    return _C.rasterize_gaussians_backward_fused(*args, lean=True, accumulate_into=accumulate_into)
+
+
+ACCUMULATE_ATTR = "_gsr_accumulate_grad"
+
+
+def _accumulation_targets(params):
+    """Fused gradient accumulation (opt-in: mapping_shard.GradBucket.attach marks the parameters): when all five Gaussian parameter
+    inputs are leaf tensors whose ``.grad`` buffers exist and are marked, the backward kernels ADD this view's gradients to those
+    buffers and the Function returns None for them -- autograd's AccumulateGrad (a read-modify-write of five tensors per view) and the
+    zero rows of invisible Gaussians disappear. Same values as autograd's own accumulation, bit for bit (one fp32 add per element and
+    view, in view order). Not for torch.autograd.grad(): that call wants the gradients returned."""
+    out = []
+    for p in params:
+        g = getattr(p, "grad", None)
+        if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and getattr(p, ACCUMULATE_ATTR, False) and g is not None
+                and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device):
+            return None
+        out.append(g)
+    return out
 
 
 def _pose_grad(vec3, shape):
@@ -62,6 +81,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.pose_shapes = (tuple(theta.shape) if isinstance(theta, torch.Tensor) else None,
                            tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
         ctx.set_materialize_grads(False)   # unused cotangents (opacity, radii, n_touched) arrive as None, not as zero-filled tensors
+        ctx.acc_params = None
+        if colors_precomp.numel() == 0 and cov3Ds_precomp.numel() == 0 and _accumulation_targets((means3D, sh, opacities, scales, rotations)):
+            ctx.acc_params = (means3D, sh, opacities, scales, rotations)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
         return color, radii, depth, opacity, n_touched
 
@@ -78,9 +100,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 *_camera_block(rs), grad_out_color, grad_out_depth, sh, rs.sh_degree, rs.campos,
                 geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
+        targets = _accumulation_targets(ctx.acc_params) if ctx.acc_params is not None else None
+        bw = _lean_backward if targets is None else (lambda *a_: _lean_backward(*a_, accumulate_into=targets))
         (g_means2D, g_colors, g_opacity, g_means3D, g_cov3D, g_sh, g_scales, g_rot, g_tau, tau) = _call(
-            _lean_backward, args, rs.debug, "snapshot_bw.dump",
+            bw, args, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        if targets is not None:      # already added to the parameters' .grad by the kernels
+            g_means3D = g_sh = g_opacity = g_scales = g_rot = None
         # gradients of inputs that were not given (empty tensors in, empty tensors out) are None for autograd
         g_colors = g_colors if g_colors.numel() else None
         g_cov3D = g_cov3D if g_cov3D.numel() else None

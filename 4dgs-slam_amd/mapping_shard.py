@@ -50,11 +50,14 @@ class GradBucket:
         return self.flat.numel() * 4
 
     # ---- persistent gradient storage: the parameters' .grad tensors ARE views of the flat buffer ---------------------------------
-    def attach(self):
+    def attach(self, fused_accumulate: bool = True):
         """Make every parameter's ``.grad`` a view of the flat buffer with the PARAMETER's own strides (so channels-last HexPlane planes,
         whose dense gradient is not one contiguous row-major range, qualify too). autograd accumulates into an existing ``.grad`` in
         place, so after any number of backward passes the flat buffer holds all gradients back to back and ``all_reduce()`` needs no
-        pack / unpack copy. Call ``zero_grads()`` instead of ``optimizer.zero_grad(set_to_none=True)`` between iterations."""
+        pack / unpack copy. Call ``zero_grads()`` instead of ``optimizer.zero_grad(set_to_none=True)`` between iterations.
+        fused_accumulate: additionally mark the parameters so that the rasterizer's backward kernels add each view's gradients to these
+        buffers themselves (diff_gaussian_rasterization.autograd._accumulation_targets) -- no AccumulateGrad pass over five tensors per
+        view, no zero rows for invisible Gaussians. Only for loss.backward() style training; torch.autograd.grad() needs it off."""
         self.views = []
         o = 0
         for p, n in zip(self.params, self.sizes):
@@ -64,6 +67,7 @@ class GradBucket:
             v = torch.as_strided(self.flat, p.shape, p.stride(), o) if p.numel() else self.flat[o:o].view(p.shape)
             self.views.append(v)
             p.grad = v
+            setattr(p, "_gsr_accumulate_grad", bool(fused_accumulate))
             o += n
         self.attached = True
         return self

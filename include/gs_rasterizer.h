@@ -86,7 +86,14 @@ int gsr_backward(int P, int D, int M, int R,
  * Here -- not in gsr_backward -- gradients that only feed other gradients inside the kernel may be NULL and are then not
  * written: dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D, and dL_dtau when dL_dtau_sum is given (80 of the 148 bytes stored
  * per Gaussian). The reference allocates and fills all of them (rasterize_points.cu:160-170) although its autograd Function
- * drops three (DGR/diff_gaussian_rasterization/__init__.py:139-151). */
+ * drops three (DGR/diff_gaussian_rasterization/__init__.py:139-151).
+ * `debug` carries one more bit here and in gsr_backward_raw: GSR_BACKWARD_ACCUMULATE. With it the PARAMETER gradients (dL_dmean3D,
+ * dL_dsh, dL_dopacity, dL_dscale, dL_drot; raw mode: the gsr_raw_grads tensors of the model parameters, not those of the deltas) are
+ * ADDED to what the buffers hold, for visible Gaussians only; rows of invisible Gaussians are not touched and nothing is zero-filled.
+ * A caller that sums the views of one optimizer step into one gradient buffer (the mapping loop: 8-64 keyframes) zero-fills once per
+ * step and thereby skips the zero rows this call would write per view (71 % of the Gaussians at BASELINE config #5) and the
+ * read-modify-write of its own accumulation. dL_dmean2D (a per-view statistic) and the intermediate gradients are still overwritten. */
+#define GSR_BACKWARD_ACCUMULATE 2
 int gsr_backward_fused(int P, int D, int M, int R,
                        const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp,

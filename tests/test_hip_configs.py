@@ -277,3 +277,42 @@ def test_rccl_all_reduce_on_the_attached_gradient_bucket_one_rank():
     assert out.returncode == 0, out.stderr[-3000:]
     res = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert res[1:] == ["attached", "True", "True", "nccl", "True"], res
+
+
+@pytest.mark.gpu
+def test_fused_gradient_accumulation_equals_autograd_accumulation_bitwise():
+    """GSR_BACKWARD_ACCUMULATE through the autograd Function: with the parameters attached to a GradBucket (fused_accumulate=True) the
+    backward kernels add each view's gradients to the bucket themselves and the Function returns None for the five parameters. After
+    three views the bucket must hold, bit for bit, what autograd's own accumulation (fused_accumulate=False) leaves there; rows of
+    Gaussians that no view sees stay zero; the screen-space gradient (a per-view statistic) is still returned per view."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from mapping_shard import GradBucket
+    P = 120_000
+    cam0 = make_camera(640, 480)
+    g = make_gaussians(P, cam0, seed=3)
+    g["means3D"][::7, 2] = -5.0        # one Gaussian in seven behind every camera: invisible in all views
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device="cuda", requires_grad=rg)
+
+    def run(fused):
+        params = [T(g[k], True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        bucket = GradBucket(params).attach(fused_accumulate=fused)
+        bucket.zero_grads()
+        m2d = []
+        for k in (0, 3, 6):
+            R, t = keyframe_pose(k)
+            cam = make_camera(640, 480, R=R, t=t)
+            gc, gd = make_cotangents(cam, seed=k)
+            means2D = torch.zeros_like(params[0], requires_grad=True)
+            color, radii, depth, opacity, n_touched = GaussianRasterizer(_settings(cam))(
+                means3D=params[0], means2D=means2D, opacities=params[2], shs=params[1], scales=params[3], rotations=params[4])
+            ((color * T(gc)).sum() + (depth * T(gd)).sum()).backward()
+            m2d.append(means2D.grad.clone())
+            assert all(p.grad is v for p, v in zip(params, bucket.views))
+        return bucket.flat.clone(), m2d, params
+
+    flat_f, m2d_f, params = run(True)
+    flat_a, m2d_a, _ = run(False)
+    assert torch.equal(flat_f, flat_a)
+    assert all(torch.equal(a, b) for a, b in zip(m2d_f, m2d_a))
+    assert float(flat_f.abs().sum()) > 0 and torch.isfinite(flat_f).all()
+    assert float(params[0].grad[::7].abs().sum()) == 0.0 and float(params[4].grad[::7].abs().sum()) == 0.0
