@@ -41,34 +41,6 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     const size_t i = (size_t)(in_range ? idx : 0);
     const bool visible = in_range && a.radii[idx] > 0;   // backward.cu:163,443
     const size_t o = in_range && a.raw.xyz ? raw_row(a.raw, i) : i;   // row of the parameter-gradient outputs (raw mode with a mask: the selected row)
-    // Accumulate mode (GeomBwdArgs::accumulate): what the caller's gradient buffers hold for this Gaussian is loaded HERE, so the loads
-    // are in flight while the instance slots are summed and the chain rules evaluated (a read-modify-write at the end of the kernel
-    // left their latency exposed: 116 -> 140 us at 2 M Gaussians). old_*: zero when the mode is off. add_separately: the
-    // addition must not be contracted into the expression that produced the gradient (autograd's accumulation rounds it first).
-    const bool scale1 = a.raw.xyz && a.raw.scale_dim == 1;
-    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
-    float* const dc_out = a.raw.xyz ? (a.rawg.f_dc ? a.rawg.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
-    if (a.accumulate && visible) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
-        old_o = a.dL_dopacity[o];
-        if (a.dL_dscale) {
-            if (scale1) old_s[0] = a.dL_dscale[o];
-            else {
-#pragma unroll
-                for (int k = 0; k < 3; k++) old_s[k] = a.dL_dscale[3 * o + k];
-            }
-        }
-        if (a.dL_drot) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) old_r[k] = a.dL_drot[4 * o + k];
-        }
-        if (dc_out) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) old_c[k] = dc_out[k];
-        }
-    }
-
     // ---- gather: sum this Gaussian's per-instance slots ----------------------------------------------------------
     // Instance ids are a global running count over Gaussians, so the 256 Gaussians of a block own ONE contiguous range of
     // slots [U0, U1). It is streamed through LDS in coalesced chunks (the whole block loads, every thread then picks its own
@@ -152,11 +124,39 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         if (more) stash(buf ^ 1);
         __syncthreads();
     }
+    // Accumulate mode (GeomBwdArgs::accumulate): what the caller's gradient buffers hold for this Gaussian is loaded HERE -- after the
+    // instance slots are summed (14 more live registers during that loop cost occupancy), before the chain rules -- so the loads are in
+    // flight while the chain rules are evaluated (a read-modify-write at the end of the kernel
+    // left their latency exposed: 116 -> 140 us at 2 M Gaussians). old_*: zero when the mode is off. add_separately: the
+    // addition must not be contracted into the expression that produced the gradient (autograd's accumulation rounds it first).
+    const bool scale1 = a.raw.xyz && a.raw.scale_dim == 1;
+    float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
+    float* const dc_out = a.raw.xyz ? (a.rawg.f_dc ? a.rawg.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
+    if (a.accumulate && visible) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
+        old_o = a.dL_dopacity[o];
+        if (a.dL_dscale) {
+            if (scale1) old_s[0] = a.dL_dscale[o];
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) old_s[k] = a.dL_dscale[3 * o + k];
+            }
+        }
+        if (a.dL_drot) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) old_r[k] = a.dL_drot[4 * o + k];
+        }
+        if (dc_out) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) old_c[k] = dc_out[k];
+        }
+    }
+
     if (in_range) {
         a.dL_dmean2D[3 * o] = g_m2x; a.dL_dmean2D[3 * o + 1] = g_m2y; a.dL_dmean2D[3 * o + 2] = 0.f;   // z never written, Q14
         if (a.dL_dconic) { a.dL_dconic[4 * i] = g_cx; a.dL_dconic[4 * i + 1] = g_cy; a.dL_dconic[4 * i + 2] = 0.f; a.dL_dconic[4 * i + 3] = g_cw; }
-        if (visible || !a.accumulate)
-            a.dL_dopacity[o] = add_separately(old_o, a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
+        // dL_dopacity is stored with the other parameter gradients at the end (its old value is still in flight in accumulate mode)
         if (a.dL_dcolor) { a.dL_dcolor[3 * i] = g_r; a.dL_dcolor[3 * i + 1] = g_g; a.dL_dcolor[3 * i + 2] = g_b; }
         if (a.dL_ddepth) a.dL_ddepth[i] = g_d;
     }
@@ -361,6 +361,8 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     }
     if (in_range) {
         const bool wr = visible || !a.accumulate;     // accumulate mode leaves the rows of invisible Gaussians alone
+        if (wr)
+            a.dL_dopacity[o] = add_separately(old_o, a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
         if (wr) {
 #pragma unroll
             for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * o + k] = add_separately(old_m[k], dmean[k]);

@@ -246,12 +246,16 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                                  const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, int64_t degree,
                                  const torch::Tensor& campos_, const torch::Tensor& radii_, const torch::Tensor& geomBuffer, int64_t R,
                                  const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug,
-                                 const c10::optional<torch::Tensor>& gather_, int64_t stream)
+                                 const c10::optional<torch::Tensor>& gather_, int64_t stream, const std::vector<torch::Tensor>& accumulate_into)
 {
     const torch::Tensor none;
     const torch::Tensor gather = contig(nz(gather_, none));
     const bool masked = gather.defined() && gather.numel() != 0;
     const int64_t P = xyz_.size(0), S = log_scales_.size(-1);   // P: rows of the raw tensors (= of every gradient)
+    // accumulate_into = the model's six gradient buffers in the optimizer's order (xyz, f_dc, f_rest, opacity, scaling, rotation): the
+    // kernels add this view's gradients to them (GSR_BACKWARD_ACCUMULATE); nothing is allocated or zero-filled for them
+    const bool acc = accumulate_into.size() == 6;
+    TORCH_CHECK(acc || accumulate_into.empty(), "accumulate_into: six gradient buffers or none");
     const int H = (int)dL_dout_color_.size(1), W = (int)dL_dout_color_.size(2);
     const torch::Tensor bg = contig(background), xyz = contig(xyz_), ls = contig(log_scales_), rr = contig(raw_rot_), lo = contig(logit_),
                         fdc = contig(f_dc_), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none)), dx = contig(nz(dx_, none)),
@@ -261,13 +265,19 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                         gd = contig(dL_dout_depths_.scalar_type() == torch::kFloat32 ? dL_dout_depths_ : dL_dout_depths_.to(torch::kFloat32));
     const int64_t M = 1 + (frest.defined() && frest.numel() != 0 ? frest.size(1) : 0);
     auto fopt = xyz.options().dtype(torch::kFloat32);
-    const int64_t widths[7] = {3, 3, 3 * (M - 1), 1, S, 4, 3};
+    const int64_t pw[6] = {3, 3, 3 * (M - 1), 1, S, 4};
+    if (acc)
+        for (int i = 0; i < 6; i++)
+            TORCH_CHECK(accumulate_into[i].is_cuda() && accumulate_into[i].scalar_type() == torch::kFloat32 && accumulate_into[i].is_contiguous() &&
+                        accumulate_into[i].numel() == P * pw[i], "accumulate_into[", i, "]: contiguous fp32 device tensor of ", P * pw[i], " elements expected");
+    const int64_t widths[7] = {acc ? 0 : 3, acc ? 0 : 3, acc ? 0 : 3 * (M - 1), acc ? 0 : 1, acc ? 0 : S, acc ? 0 : 4, 3};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
     torch::Tensor flat = masked ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);   // with a mask only the selected rows are written
     torch::Tensor v[7];
     int64_t o = 0;
     for (int i = 0; i < 7; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
+    if (acc) for (int i = 0; i < 6; i++) v[i] = accumulate_into[i].view({-1});
     torch::Tensor g_xyz = v[0].view({P, 3}), g_fdc = v[1].view({P, 1, 3}), g_frest = v[2].view({P, M - 1, 3}), g_logit = v[3].view(lo.sizes()),
                   g_ls = v[4].view({P, S}), g_rot = v[5].view({P, 4}), g_m2d = v[6].view({P, 3});
     torch::Tensor tau_sum = flat.narrow(0, o, 6);
@@ -286,7 +296,7 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                                     (float)tan_fovy, radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()),
                                     reinterpret_cast<char*>(binningBuffer.data_ptr()), reinterpret_cast<char*>(imageBuffer.data_ptr()),
                                     fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), g_m2d.data_ptr<float>(), &out, tau_sum.data_ptr<float>(),
-                                    debug ? 1 : 0, reinterpret_cast<void*>(stream));
+                                    (debug ? 1 : 0) | (acc ? GSR_BACKWARD_ACCUMULATE : 0), reinterpret_cast<void*>(stream));
     if (rc < 0) fail("gsr_backward_raw", rc);
     return std::make_tuple(g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau_sum);
 }

@@ -89,6 +89,33 @@ def dyn_slot_from_mask(dygs: torch.Tensor) -> torch.Tensor:
     return torch.where(m, torch.cumsum(m.to(torch.int32), 0, dtype=torch.int32) - 1, torch.full_like(m, -1, dtype=torch.int32))
 
 
+def _acc_params(xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot):
+    """The six model parameters in the optimizer's order if every one of them takes part in fused gradient accumulation
+    (autograd._accumulation_targets; f_rest may be absent or empty at SH degree 0), else None."""
+    from .autograd import ACCUMULATE_ATTR
+    ps = (xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot)
+    for k, p in enumerate(ps):
+        if k == 2 and (p is None or p.numel() == 0):
+            continue
+        if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and getattr(p, ACCUMULATE_ATTR, False) and p.grad is not None):
+            return None
+    return ps
+
+
+def _targets(ps, M):
+    """The .grad buffers of _acc_params' tensors at backward time (None: fall back to returning the gradients)."""
+    out = []
+    for k, p in enumerate(ps):
+        if k == 2 and (p is None or p.numel() == 0):
+            out.append(torch.empty((0,), dtype=torch.float32, device=ps[0].device))
+            continue
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or g.device != p.device:
+            return None
+        out.append(g)
+    return out
+
+
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs, gather=None):
@@ -99,6 +126,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                            tuple(rho.shape) if isinstance(rho, torch.Tensor) else None)
         ctx.set_materialize_grads(False)
         ctx.gather = gather
+        ctx.acc_params = _acc_params(xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot)
         ctx.empty = gather is not None and gather.numel() == 0
         if ctx.empty:
             # render()'s mask selected nothing (x[mask] with P = 0): like rasterize_points.cu:85 the kernels are skipped -- zero image,
@@ -150,10 +178,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if ctx.empty:
             xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dx, ds, dr = ctx.saved_tensors
             Z = lambda t: None if t is None else torch.zeros_like(t)
+            if ctx.acc_params is not None and _targets(ctx.acc_params, 1) is not None:
+                Zp = lambda t: None            # accumulating zero into the parameters' .grad: nothing to do
+            else:
+                Zp = Z
             th, rh = ctx.pose_shapes
             zp = lambda shp: None if shp is None else torch.zeros(shp, dtype=torch.float32, device=xyz.device)
-            return (Z(xyz), torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=xyz.device), Z(log_scales), Z(raw_rot), Z(logit_opacity), Z(f_dc),
-                    Z(f_rest) if f_rest is not None and f_rest.numel() else None, None, Z(dx), Z(ds), Z(dr), zp(th), zp(rh), None, None)
+            return (Zp(xyz), torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=xyz.device), Zp(log_scales), Zp(raw_rot), Zp(logit_opacity), Zp(f_dc),
+                    Zp(f_rest) if f_rest is not None and f_rest.numel() else None, None, Z(dx), Z(ds), Z(dr), zp(th), zp(rh), None, None)
         rs, M = ctx.rs, ctx.M
         (xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, radii, geom, binning, imgbuf) = ctx.saved_tensors
         dev = xyz.device
@@ -164,14 +196,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_depth = xyz.new_zeros((1, H, W))
         th_shape, rho_shape = ctx.pose_shapes
         gather = ctx.gather
+        # fused accumulation into the parameters' .grad buffers (autograd._accumulation_targets): the six gradients are then not returned
+        targets = _targets(ctx.acc_params, M) if getattr(ctx, "acc_params", None) is not None else None
         if _C._glue is not None:
             with torch.cuda.device(dev):
                 (g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau) = _C._glue.rasterize_gaussians_raw_backward(
                     rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
                     rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth,
-                    int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), gather, _C._stream(dev))
+                    int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), gather, _C._stream(dev),
+                    targets or [])
             opt = lambda t, src: t if src is not None and src.numel() else None
-            return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, opt(g_dx, dx), opt(g_ds, ds), opt(g_dr, dr),
+            if targets is not None:
+                g_xyz = g_ls = g_rot = g_logit = g_fdc = g_frest = None
+            return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None) else None, None, opt(g_dx, dx), opt(g_ds, ds), opt(g_dr, dr),
                     _pose_grad(tau[3:], th_shape) if th_shape is not None else None,
                     _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None, None, None)
         lib = _lib()
@@ -179,12 +216,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         g_depth = g_depth if g_depth.dtype == torch.float32 else g_depth.to(torch.float32)
         # one allocation; parameter order of the optimizer (gaussian_model.py:404-434), then the screen-space gradient
         widths = [3, 3, 3 * (M - 1), 1, S, 4, 3]
+        if targets is not None:
+            widths[:6] = [0] * 6
         # with a mask only the selected rows are written: the rest of the gradients is zero
         flat = (torch.empty if gather is None else torch.zeros)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
         views, o = [], 0
         for w_ in widths:
             views.append(flat[o:o + P * w_])
             o += P * w_
+        if targets is not None:
+            views[:6] = [t_.view(-1) for t_ in targets]
         g_xyz, g_fdc, g_frest = views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, M - 1, 3)
         g_logit, g_ls, g_rot, g_m2d = views[3].view(logit_opacity.shape), views[4].view(P, S), views[5].view(P, 4), views[6].view(P, 3)
         tau = flat[o:o + 6]
@@ -203,13 +244,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.projmatrix_raw, "projmatrix_raw", keep),
                 _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
                 geom.data_ptr(), binning.data_ptr(), imgbuf.data_ptr(), _f32(g_color, "dL_dcolor", keep), _f32(g_depth, "dL_ddepth", keep),
-                g_m2d.data_ptr(), C.byref(out), tau.data_ptr(), int(bool(rs.debug)), _C._stream(dev))
+                g_m2d.data_ptr(), C.byref(out), tau.data_ptr(), int(bool(rs.debug)) | (2 if targets is not None else 0), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_backward_raw")
+        if targets is not None:
+            g_xyz = g_ls = g_rot = g_logit = g_fdc = g_frest = None
         g_rho = _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None
         g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
         # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
-        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if M > 1 else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
+        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None) else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
 
 
 def gather_from_mask(mask: torch.Tensor) -> torch.Tensor:

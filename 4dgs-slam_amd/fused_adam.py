@@ -38,6 +38,35 @@ def _lib():
 
 
 class FusedAdam(torch.optim.Adam):
+    # ---- fused gradient accumulation (optional) ----------------------------------------------------------------------------------
+    # The mapping loop sums 8-10 views into the parameters' gradients before every step. With this switched on, zero_grad() keeps ONE
+    # flat zero-filled buffer whose views are the parameters' .grad (mapping_shard.GradBucket.attach) instead of dropping the
+    # gradients, and the rasterizer's backward kernels add each view's gradients to it themselves (GSR_BACKWARD_ACCUMULATE,
+    # diff_gaussian_rasterization/autograd.py, raw.py): autograd's AccumulateGrad -- six read-modify-write launches per view -- and the
+    # per-view gradient allocations disappear. Values are those of autograd's accumulation, bit for bit. The densification code
+    # replaces parameters at will: the buffer is rebuilt at the next zero_grad() whenever the parameter list changed.
+    def enable_fused_gradient_accumulation(self, on=True):
+        self._fused_acc = bool(on)
+        self._bucket = None
+        return self
+
+    def zero_grad(self, set_to_none=True):
+        if not getattr(self, "_fused_acc", False):
+            return super().zero_grad(set_to_none)
+        from mapping_shard import GradBucket, _is_dense
+        params, rest = [], []
+        for group in self.param_groups:
+            for p in group["params"]:
+                ok = p.requires_grad and p.numel() and p.is_cuda and p.dtype == torch.float32 and _is_dense(p)
+                (params if ok else rest).append(p)
+        b = getattr(self, "_bucket", None)
+        if b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params)):
+            self._bucket = GradBucket(params).attach(fused_accumulate=True) if params else None     # zero-filled on creation
+        else:
+            b.zero_grads()
+        for p in rest:
+            p.grad = None
+
     def _fusable(self, todo):
         if not todo or len(todo) > _MAX_SEGMENTS:
             return False

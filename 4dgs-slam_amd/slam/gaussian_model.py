@@ -216,6 +216,12 @@ class GaussianModel:
                "opacity": ta.opacity_lr, "scaling": ta.scaling_lr * self.spatial_lr_scale, "rotation": ta.rotation_lr}
         groups = [{"params": [self._params()[n]], "lr": lrs[n], "name": n} for n in self.PARAM_NAMES]
         self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        # the backward kernels add every view's gradients to one persistent buffer (fused_adam.FusedAdam.zero_grad); Training.
+        # fused_grad_accumulation = False restores autograd's own accumulation (same values)
+        fused = True
+        if isinstance(self.config, dict):
+            fused = bool(self.config.get("Training", {}).get("fused_grad_accumulation", True))
+        self.optimizer.enable_fused_gradient_accumulation(fused)
         self.lr_init = ta.position_lr_init * self.spatial_lr_scale
         self.lr_final = ta.position_lr_final * self.spatial_lr_scale
         self.lr_delay_mult = ta.position_lr_delay_mult

@@ -72,6 +72,8 @@ for fused in (False, True):
     groups = [{"params": [p_], "lr": lr, "name": n} for n, p_, lr in (("xyz", m._xyz, 1.6e-4), ("f_dc", m._features_dc, 2.5e-3),
               ("opacity", m._opacity, 0.05), ("scaling", m._scaling, 1e-3), ("rotation", m._rotation, 1e-3))]
     opt = (FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
+    if fused and os.environ.get("GSR_FUSED_ACC", "1") == "1":      # the backward kernels add each view's gradients to one persistent buffer
+        opt.enable_fused_gradient_accumulation()
     gr.FUSED_PROLOGUE = fused
 
     def torch_loss(image, depth, vp):
