@@ -410,6 +410,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     // longest tile list the speculative launches are sized for: decides which sort kernels run (and the chunk grid of the long-list sort)
     const uint32_t want_tile = t_last_max_tile + t_last_max_tile / 4;
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
+                            : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
                             : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
     {
@@ -451,9 +452,16 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             // one-block-per-tile LDS sort of the 1024..4096 lists), GSR_LONG_CHUNK = its chunk size (1024 / 2048 / 4096)
             static const uint32_t long_from = getenv("GSR_LONG_FROM") ? (uint32_t)atoi(getenv("GSR_LONG_FROM")) : (uint32_t)SORT_LDS_CAP;
             static const int long_chunk = getenv("GSR_LONG_CHUNK") ? atoi(getenv("GSR_LONG_CHUNK")) : SORT_LDS_CAP;
-            if (long_lists && long_from > (uint32_t)SORT_SMALL_CAP)
-                hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
-                                   bin.keys, bin.inst_gauss, bin.sorted, chk);
+            if (long_lists && long_from > (uint32_t)SORT_SMALL_CAP) {
+                // one launch: 18 KiB blocks (eight per CU) when no list exceeds 2048 keys, 36 KiB blocks (four per CU) otherwise. Splitting
+                // the tiles between two launches by length was measured: the two tails cost more than the occupancy returns (99 -> 131 us).
+                if (longest_list <= (uint32_t)SORT_MID_CAP)
+                    hipLaunchKernelGGL((sort_tiles_kernel<SORT_MID_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
+                                       bin.keys, bin.inst_gauss, bin.sorted, chk);
+                else
+                    hipLaunchKernelGGL((sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), dim3(T), dim3(256), 0, stream, T, img.ranges,
+                                       bin.keys, bin.inst_gauss, bin.sorted, chk);
+            }
             if (longest_list > long_from) {   // chunk-wise LDS sort + rank by counting (gs_forward.h F4b)
 #define GSR_LONG(CK)                                                                                                                   \
     do {                                                                                                                              \

@@ -678,6 +678,7 @@ __device__ __forceinline__ void bitonic_sort_lds_pow2(PaddedKeys keys, uint32_t 
 // handles those (in LDS up to 4096 keys, in global memory beyond). With the 32 KiB variant alone the 1200 blocks of a
 // 640x480 frame did not fit in one residency round and the kernel took two (40 us -> 20 us).
 constexpr int SORT_SMALL_CAP = 1024;
+constexpr int SORT_MID_CAP = 2048;     // lists of 1025 .. 2048 keys: a block of their own with half the LDS of the SORT_LDS_CAP one
 // Sort of one tile list of n <= CAP keys in LDS (256 threads, s_keys holds CAP keys). A bitonic network wants a power of two;
 // padding 520 keys to 1024 would more than double the work. Instead the list is split into A = the largest power of two <= n
 // and the rest (padded to its own power of two), both halves are sorted, and every key finds its final rank with one binary
