@@ -1403,4 +1403,17 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
     return 0;
 }
 
+int gsr_edge_mask(const float* image, int height, int width, float edge_threshold, float eps, float* intensity, float* median,
+                  unsigned char* mask, void* stream_)
+{
+    if (!image || !intensity || !median || !mask || height < 2 || width < 2) { g_last_error = "gsr_edge_mask: null argument or image smaller than 2x2"; return GSR_ERR_INVALID_ARGUMENT; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int n = height * width;
+    hipLaunchKernelGGL(edge_intensity_kernel, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, stream, image, height, width, eps, intensity);
+    hipLaunchKernelGGL(radix_select_kernel, dim3(1), dim3(1024), 0, stream, (const float*)intensity, n, (n - 1) / 2, median);   // torch.median: the lower one
+    hipLaunchKernelGGL(edge_compare_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)intensity, n, (const float*)median, edge_threshold, mask);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

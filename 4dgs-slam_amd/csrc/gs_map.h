@@ -235,4 +235,67 @@ __global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a)
     }
 }
 
+// ---- edge mask of a frame: Camera.compute_grad_mask, utils/camera_utils.py:205-233 (+ image_gradient / image_gradient_mask,
+// utils/slam_utils.py:5-39), the non-replica branch -------------------------------------------------------------------------------
+// The reference does this with ~25 small torch launches (mean, two grouped conv2d on a reflect-padded image, two more on the validity
+// mask, products, sqrt, median, compare); here: (1) one kernel per pixel -> gradient magnitude, (2) the exact lower median by a 4-pass
+// radix select in one block (what torch.median returns), (3) the compare.
+__device__ __forceinline__ int reflect_index(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ void __launch_bounds__(256) edge_intensity_kernel(const float* __restrict__ image, int H, int W, float eps, float* __restrict__ intensity)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= W || y >= H) return;
+    const size_t N = (size_t)H * W;
+    float p[3][3];
+    bool valid = true;
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const size_t at = (size_t)reflect_index(y + dy - 1, H) * W + reflect_index(x + dx - 1, W);   // F.pad(mode="reflect")
+            const float g = (image[at] + image[N + at] + image[2 * N + at]) / 3.0f;                       // original_image.mean(dim=0)
+            p[dy][dx] = g;
+            valid = valid && fabsf(g) > eps;                                                              // image_gradient_mask: all nine
+        }
+    }
+    // Scharr, normalised by 16 (slam_utils.py:5-22): conv_x = [[3,10,3],[0,0,0],[-3,-10,-3]] -> "v", conv_y = its transpose -> "h"
+    float gv = (1.0f / 16.0f) * ((3.f * p[0][0] + 10.f * p[0][1] + 3.f * p[0][2]) - (3.f * p[2][0] + 10.f * p[2][1] + 3.f * p[2][2]));
+    float gh = (1.0f / 16.0f) * ((3.f * p[0][0] + 10.f * p[1][0] + 3.f * p[2][0]) - (3.f * p[0][2] + 10.f * p[1][2] + 3.f * p[2][2]));
+    if (!valid) { gv = 0.f; gh = 0.f; }
+    intensity[(size_t)y * W + x] = sqrtf(gv * gv + gh * gh);
+}
+
+// k-th smallest (0-based) of n non-negative floats: their bit patterns order like unsigned integers
+__global__ void __launch_bounds__(1024) radix_select_kernel(const float* __restrict__ x, int n, int k, float* __restrict__ out)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_mask, s_k;
+    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_k = (uint32_t)k; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, mask = s_mask;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t u = __float_as_uint(x[i]);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t kk = s_k, b = 0;
+            for (; b < 255; b++) { if (kk < hist[b]) break; kk -= hist[b]; }
+            s_k = kk; s_prefix = prefix | (b << shift); s_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = __uint_as_float(s_prefix);
+}
+
+__global__ void __launch_bounds__(256) edge_compare_kernel(const float* __restrict__ intensity, int n, const float* __restrict__ median, float edge_threshold,
+                                                           unsigned char* __restrict__ mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mask[i] = intensity[i] > median[0] * edge_threshold ? 1 : 0;
+}
+
 }  // namespace gsr

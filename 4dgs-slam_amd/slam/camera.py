@@ -37,10 +37,28 @@ def image_gradient_mask(image, eps=0.01):
     return full, full
 
 
+def compute_grad_mask_hip(original_image, edge_threshold):
+    """The non-replica branch of compute_grad_mask as three HIP launches (gsr_edge_mask, include/slam_map.h) instead of ~25 torch
+    launches (11 ms of host time per frame at 640x480). Returns the bool mask [1,H,W]."""
+    img = original_image if (original_image.dtype == torch.float32 and original_image.is_contiguous()) else original_image.float().contiguous()
+    _, H, W = img.shape
+    scratch = torch.empty((H * W + 1,), dtype=torch.float32, device=img.device)
+    mask = torch.empty((1, H, W), dtype=torch.uint8, device=img.device)
+    L = _lib.lib()
+    with torch.cuda.device(img.device):
+        rc = L.gsr_edge_mask(img.data_ptr(), H, W, float(edge_threshold), 0.01, scratch.data_ptr(), scratch[H * W:].data_ptr(), mask.data_ptr(),
+                             _lib.stream(img.device))
+    _lib.check(rc, "gsr_edge_mask")
+    return mask.view(torch.bool)
+
+
 def compute_grad_mask(original_image, config):
     """utils/camera_utils.py:205-233: pixels whose Scharr gradient magnitude exceeds edge_threshold x the image median (the non-replica
-    branch is the shipped TUM / Bonn configuration; replica's per-block medians are kept as in the reference)."""
+    branch is the shipped TUM / Bonn configuration; replica's per-block medians are kept as in the reference). Device images take the
+    fused kernels; this tensor program is what they are tested against (and what runs on CPU tensors)."""
     edge_threshold = config["Training"]["edge_threshold"]
+    if original_image.is_cuda and config["Dataset"]["type"] != "replica" and original_image.shape[0] == 3:
+        return compute_grad_mask_hip(original_image, edge_threshold)
     gray_img = original_image.mean(dim=0, keepdim=True)
     gray_grad_v, gray_grad_h = image_gradient(gray_img)
     mask_v, mask_h = image_gradient_mask(gray_img)

@@ -91,6 +91,14 @@ typedef struct gsr_camera_step {
 } gsr_camera_step;
 int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
 
+/* ---- edge mask of a frame: Camera.compute_grad_mask, utils/camera_utils.py:205-233 (non-replica branch) with image_gradient /
+ * image_gradient_mask of utils/slam_utils.py:5-39 ---------------------------------------------------------------------------------
+ * image [3,H,W] -> gray = mean over channels; Scharr gradients (normalised by 16) of the reflect-padded gray image, zeroed where any of the
+ * nine neighbours has |gray| <= eps (0.01 in the reference); intensity [H*W] = gradient magnitude; median[1] = torch.median(intensity)
+ * (the lower of the two middle values); mask [H*W] (0 / 1) = intensity > median * edge_threshold. Three launches, no synchronisation. */
+int gsr_edge_mask(const float* image, int height, int width, float edge_threshold, float eps, float* intensity, float* median,
+                  unsigned char* mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

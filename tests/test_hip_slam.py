@@ -335,3 +335,21 @@ def test_slam_with_tracking_graph_matches_eager_quality():
     print(res, st)
     assert st["replayed_frames"] >= 10 and st["captures"] >= 2
     assert res["ate_rmse"] < 0.02 and res["before_opt"]["mean_psnr"] > 22.0, res
+
+
+def test_edge_mask_kernels_match_the_tensor_program():
+    """gsr_edge_mask (Camera.compute_grad_mask on device images) against the tensor program that reproduces the reference's golden mask
+    (tests/test_slam_host.py): same mask up to pixels whose gradient magnitude sits within rounding of the threshold."""
+    from slam import camera as cam_mod
+    torch.manual_seed(0)
+    cfg = {"Training": {"edge_threshold": 1.1}, "Dataset": {"type": "tum"}}
+    for (H, W) in ((480, 640), (61, 45)):
+        img = torch.rand(3, H, W, device="cuda")
+        img = torch.nn.functional.avg_pool2d(img[None], 5, stride=1, padding=2)[0].contiguous()     # some structure, few ties
+        img[:, : H // 5] = 0.0                                                                      # a region below the validity eps
+        got = cam_mod.compute_grad_mask(img, cfg)
+        want = cam_mod.compute_grad_mask(img.cpu(), cfg).cuda()
+        assert got.dtype == torch.bool and got.shape == want.shape
+        mism = int((got != want).sum())
+        assert mism <= 1e-3 * H * W, (H, W, mism)
+        assert 0.2 < float(got.float().mean()) / max(float(want.float().mean()), 1e-9) < 5.0
