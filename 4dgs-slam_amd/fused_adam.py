@@ -47,24 +47,25 @@ class FusedAdam(torch.optim.Adam):
     # replaces parameters at will: the buffer is rebuilt at the next zero_grad() whenever the parameter list changed.
     def enable_fused_gradient_accumulation(self, on=True):
         self._fused_acc = bool(on)
-        self._bucket = None
+        self._bucket, self._bucket_key, self._bucket_rest = None, None, []
         return self
 
     def zero_grad(self, set_to_none=True):
         if not getattr(self, "_fused_acc", False):
             return super().zero_grad(set_to_none)
-        from mapping_shard import GradBucket, _is_dense
-        params, rest = [], []
-        for group in self.param_groups:
-            for p in group["params"]:
-                ok = p.requires_grad and p.numel() and p.is_cuda and p.dtype == torch.float32 and _is_dense(p)
-                (params if ok else rest).append(p)
-        b = getattr(self, "_bucket", None)
-        if b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params)):
+        key = tuple(id(p) for group in self.param_groups for p in group["params"])
+        if key != getattr(self, "_bucket_key", None):          # first call, or densification / an opacity reset replaced parameters
+            from mapping_shard import GradBucket, _is_dense
+            params, rest = [], []
+            for group in self.param_groups:
+                for p in group["params"]:
+                    ok = p.requires_grad and p.numel() and p.is_cuda and p.dtype == torch.float32 and _is_dense(p)
+                    (params if ok else rest).append(p)
             self._bucket = GradBucket(params).attach(fused_accumulate=True) if params else None     # zero-filled on creation
-        else:
-            b.zero_grads()
-        for p in rest:
+            self._bucket_rest, self._bucket_key = rest, key
+        elif self._bucket is not None:
+            self._bucket.zero_grads()
+        for p in self._bucket_rest:
             p.grad = None
 
     def _fusable(self, todo):

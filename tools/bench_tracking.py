@@ -31,7 +31,12 @@ def main():
     for P in (10_000, 50_000, 200_000):
         g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
         pc = GaussianModelStub(g, isotropic=False, dyn_frac=0.0, seed=0)
-        pc.optimizer = None
+        # the map's optimizer as the SLAM loop has it: FusedAdam with fused gradient accumulation (the tracking iteration zeroes its buffer)
+        from fused_adam import FusedAdam
+        pc.optimizer = FusedAdam([{"params": [p_], "lr": 0.0, "name": n_} for n_, p_ in (("xyz", pc._xyz), ("f_dc", pc._features_dc), ("opacity", pc._opacity),
+                                                                                           ("scaling", pc._scaling), ("rotation", pc._rotation))], lr=0.0, eps=1e-15)
+        pc.optimizer.enable_fused_gradient_accumulation()
+        pc.optimizer.zero_grad()
         img = torch.tensor(rng.uniform(0, 1, (3, H, W)).astype(np.float32), device="cuda")
         depth = rng.uniform(0.5, 5, (H, W)).astype(np.float32)
         cam = Camera(1, img, depth, torch.eye(4), proj, fx, fy, cx, cy, fov_from_focal(fx, W), fov_from_focal(fy, H), H, W, 0.0)
