@@ -15,6 +15,7 @@ import torch
 
 from diff_gaussian_rasterization import _C
 from diff_gaussian_rasterization import raw as _raw
+import gaussian_renderer
 from gaussian_renderer import render
 import slam_losses
 
@@ -41,6 +42,10 @@ class TrackingGraph:
             self.static._gsr_gather = _raw.gather_from_mask(self.static)
         self.graph = None
         self.version = self.model_version(gaussians)
+        # straight to the fused rasterizer call when render() would take that route anyway: render()'s extras (a fresh zero tensor for the
+        # screen-space gradients, the visibility mask) are two launches per iteration that tracking never looks at
+        self.direct = gaussian_renderer._fused_prologue_ok(gaussians, pipeline_params, self.static, False) and gaussians.get_xyz.shape[0] > 0
+        self.means2D = torch.zeros_like(gaussians.get_xyz)
 
     @staticmethod
     def model_version(g):
@@ -75,9 +80,15 @@ class TrackingGraph:
     # ---- the iteration ---------------------------------------------------------------------------------------------------
     def iteration(self):
         c = self.cam
-        pkg = render(c, self.gaussians, self.pipe, self.background, dynamic=False, mask=self.static)
+        if self.direct:
+            image, radii, depth, opacity, n_touched = gaussian_renderer._render_fused(c, self.gaussians, self.background, 1.0, self.means2D, None, None,
+                                                                                      None, self.static, False)
+            pkg = {"render": image, "radii": radii, "depth": depth, "opacity": opacity, "n_touched": n_touched}
+        else:
+            pkg = render(c, self.gaussians, self.pipe, self.background, dynamic=False, mask=self.static)
+        # the loss VALUE is never read in this loop: only its gradient is taken
         loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], self.gt_image, self.gt_depth, self.w_rgb, self.w_dep, c.exposure_a,
-                                            c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95)
+                                            c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95, compute_value=False)
         loss.backward()
         c.pose_step(*self.lrs)
         if self.gaussians.optimizer is not None:

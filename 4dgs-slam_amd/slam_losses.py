@@ -50,10 +50,18 @@ def _p(t, keep):
 
 class _WeightedL1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity=None, opacity_thr=0.95):
+    def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity=None, opacity_thr=0.95,
+                compute_value=True):
         _C._require_device(image, "image")
         ctx.alpha, ctx.opacity_thr = float(alpha), float(opacity_thr)
         opacity = None if opacity is None else opacity.detach()
+        if not compute_value:
+            # the caller only back-propagates (a tracking iteration inside a hipGraph): the value's two launches are skipped; the backward
+            # kernels need nothing from them (the workspace is their scratch)
+            loss = torch.empty((), dtype=torch.float32, device=image.device)
+            ws = torch.empty((int(_lib().gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=image.device)
+            ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity)
+            return loss
         if _C._glue is not None:     # native host glue (csrc/torch_glue.cpp)
             with torch.cuda.device(image.device):
                 loss, ws = _C._glue.l1_loss_forward(image.detach(), depth.detach(), gt_image, gt_depth, w_rgb, w_depth,
@@ -87,7 +95,7 @@ class _WeightedL1(torch.autograd.Function):
                     None if exposure_b is None else exposure_b.detach(), ctx.alpha, opacity, ctx.opacity_thr, g, ws, _C._stream(image.device))
             ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
             gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
-            return g_image, g_depth, None, None, None, None, ga, gb, None, None, None
+            return g_image, g_depth, None, None, None, None, ga, gb, None, None, None, None
         lib = _lib()
         H, W = int(image.shape[-2]), int(image.shape[-1])
         dev = image.device
@@ -104,18 +112,20 @@ class _WeightedL1(torch.autograd.Function):
             _C._err(lib, rc, "gsr_l1_loss_backward")
         ga = g_exp[0:1].view(exposure_a.shape) if exposure_a is not None else None
         gb = g_exp[1:2].view(exposure_b.shape) if exposure_b is not None else None
-        return g_image, g_depth, None, None, None, None, ga, gb, None, None, None
+        return g_image, g_depth, None, None, None, None, ga, gb, None, None, None, None
 
 
 def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None, exposure_a=None, exposure_b=None, alpha=0.95,
-                     opacity=None, opacity_depth_threshold=0.95):
+                     opacity=None, opacity_depth_threshold=0.95, compute_value=True):
     """alpha * mean(w_rgb |exp(a) image + b - gt_image|) + (1 - alpha) * mean(w_depth |depth - gt_depth|), differentiable in
     image, depth, exposure_a, exposure_b. image [3,H,W], depth [1,H,W] (or [H,W]), weights [H,W] / [1,H,W] or None.
     opacity (the rendered opacity, tracking loss): w_rgb *= opacity, w_depth *= (opacity > opacity_depth_threshold); it is a
-    constant weight here -- the rasterizer's backward discards the opacity cotangent in any case."""
+    constant weight here -- the rasterizer's backward discards the opacity cotangent in any case.
+    compute_value=False: the returned scalar is uninitialised (for callers that only call .backward() on it)."""
     if (exposure_a is None) != (exposure_b is None):
         raise RuntimeError("weighted_l1_loss: give both exposure parameters or neither")
-    return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold)
+    return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold,
+                             bool(compute_value))
 
 
 # Ground-truth-only constants of a frame (device copy of the depth map + four masks, ~10 MB at 640x480). They live in a BOUNDED cache
