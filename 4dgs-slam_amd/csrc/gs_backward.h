@@ -27,6 +27,10 @@ struct GeomBwdArgs {
     // A caller that sums several views into one .grad buffer (mapping: 8-64 keyframes per optimizer step) thereby skips both the
     // zero rows this kernel would write (71 % of 2 M Gaussians at BASELINE config #5) and autograd's read-modify-write of five tensors.
     int accumulate;
+    // GSR_BACKWARD_POSE_ONLY: nobody wants the Gaussians' parameter gradients (camera tracking: only the pose and the screen-space
+    // gradients are read). Their stores, the covariance -> scale / rotation chain and the SH coefficient gradients are skipped; the
+    // output pointers may be NULL.
+    int pose_only;
     // Raw mode (raw.xyz != nullptr, see gs_device.h): the inputs are the model's raw parameters and the outputs their gradients:
     // dL_dmean3D -> d/d_xyz, dL_dscale -> d/d_scaling [P,scale_dim], dL_drot -> d/d_rotation, dL_dopacity -> d/d_opacity (logit),
     // rawg.f_dc / f_rest -> d/d_features_*, rawg.ddx / dds / ddr [K,*] -> gradients of the control-node deltas.
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     const bool scale1 = a.raw.xyz && a.raw.scale_dim == 1;
     float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
     float* const dc_out = a.raw.xyz ? (a.rawg.f_dc ? a.rawg.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
-    if (a.accumulate && visible) {
+    if (a.accumulate && visible && !a.pose_only) {
 #pragma unroll
         for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
         old_o = a.dL_dopacity[o];
@@ -164,11 +168,11 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool flow = a.raw.xyz && a.raw.flow_proj1;
-    const bool has_sh = flow ? false : (a.raw.xyz ? a.rawg.f_dc != nullptr : (a.shs != nullptr && a.dL_dsh != nullptr));
-    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}}
-                                : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}};
+    const bool has_sh = flow ? false : (a.raw.xyz ? (a.rawg.f_dc != nullptr || a.pose_only != 0) : (a.shs != nullptr && (a.dL_dsh != nullptr || a.pose_only != 0)));   // pose-only: the view-direction term of dL_dtau still needs the SH pass
+    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0}
+                                : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0};
     if (!visible) {
-        if (has_sh && in_range && !a.accumulate) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
+        if (has_sh && in_range && !a.accumulate && !a.pose_only) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
     } else {
         const float* vm = a.viewmatrix;
         const f3 mean = load_mean(a.means3D, a.raw, i);
@@ -331,7 +335,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         }
 
         // ---- backward.cu:350-413: cov3D -> scale, quaternion (no normalisation backward, Q1) ----
-        if (a.scales != nullptr || a.raw.xyz) {
+        if (!a.pose_only && (a.scales != nullptr || a.raw.xyz)) {
             float q4[4], s3[3];
             load_rot(a.rotations, a.raw, i, q4);
             load_scale(a.scales, a.raw, i, s3);
@@ -360,7 +364,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         }
     }
     if (in_range) {
-        const bool wr = visible || !a.accumulate;     // accumulate mode leaves the rows of invisible Gaussians alone
+        const bool wr = !a.pose_only && (visible || !a.accumulate);     // accumulate mode leaves the rows of invisible Gaussians alone
         if (wr)
             a.dL_dopacity[o] = add_separately(old_o, a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
         if (wr) {

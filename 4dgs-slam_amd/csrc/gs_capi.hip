@@ -563,15 +563,16 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool accumulate = (debug & GSR_BACKWARD_ACCUMULATE) != 0;     // include/gs_rasterizer.h
+    const bool pose_only = (debug & GSR_BACKWARD_POSE_ONLY) != 0;
     debug &= 1;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) { g_last_error = "gsr_backward: invalid size"; return GSR_ERR_INVALID_ARGUMENT; }
     if (P == 0) { if (dL_dtau_sum) GSR_HIP_CHECK(hipMemsetAsync(dL_dtau_sum, 0, 6 * sizeof(float), stream)); return 0; }
     // Intermediate gradients the caller does not want may be NULL (dL_dconic, dL_dcolor, dL_ddepth, dL_dcov3D; dL_dtau when
     // dL_dtau_sum is given): the kernel then keeps them in registers only. gsr_backward itself requires all of them.
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !dL_dpix_depth || !background || (!means3D && !raw) || !viewmatrix ||
-        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || !dL_dopacity || !dL_dmean3D || (!dL_dtau && !dL_dtau_sum) ||
-        (raw && (!raw_inputs_ok(raw, M) || !rawg || !dL_dscale || !dL_drot ||
-                 (!raw->flow_proj1 && (!rawg->features_dc || (M > 1 && !rawg->features_rest)))))) {
+        !projmatrix || !projmatrix_raw || !campos || !dL_dmean2D || (!pose_only && (!dL_dopacity || !dL_dmean3D)) || (!dL_dtau && !dL_dtau_sum) ||
+        (raw && (!raw_inputs_ok(raw, M) || !rawg ||
+                 (!pose_only && (!dL_dscale || !dL_drot || (!raw->flow_proj1 && (!rawg->features_dc || (M > 1 && !rawg->features_rest)))))))) {
         g_last_error = "gsr_backward: null argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
@@ -598,6 +599,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth;
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     a.accumulate = accumulate ? 1 : 0;
+    a.pose_only = pose_only ? 1 : 0;
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
     a.raw = to_device_view(raw);
     a.rawg = RawGrads{};

@@ -244,13 +244,17 @@ struct ShOut {
     float* dc; float* rest;
     bool acc;        // accumulate mode (GSR_BACKWARD_ACCUMULATE): assignments add to what the caller's gradient buffer already holds
     float old_dc[3]; // ... whose DC part the kernel loaded up front (zero when the mode is off); higher bands are read here
+    bool skip;       // pose-only backward (GSR_BACKWARD_POSE_ONLY): the coefficient gradients are not stored at all
     struct Ref {
-        float* p; bool acc; float old; bool have_old;
-        __device__ __forceinline__ void operator=(float v) const { *p = have_old ? add_separately(old, v) : (acc ? add_separately(*p, v) : v); }
+        float* p; bool acc; float old; bool have_old; bool skip;
+        __device__ __forceinline__ void operator=(float v) const
+        {
+            if (!skip) *p = have_old ? add_separately(old, v) : (acc ? add_separately(*p, v) : v);
+        }
     };
     __device__ __forceinline__ Ref operator[](int k) const
     {
-        return k < 3 ? Ref{dc + k, acc, old_dc[k], true} : Ref{rest + (k - 3), acc, 0.f, false};
+        return k < 3 ? Ref{dc + k, acc, old_dc[k], true, skip} : Ref{rest + (k - 3), acc, 0.f, false, skip};
     }
 };
 

@@ -246,7 +246,8 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                                  const torch::Tensor& dL_dout_color_, const torch::Tensor& dL_dout_depths_, int64_t degree,
                                  const torch::Tensor& campos_, const torch::Tensor& radii_, const torch::Tensor& geomBuffer, int64_t R,
                                  const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, bool debug,
-                                 const c10::optional<torch::Tensor>& gather_, int64_t stream, const std::vector<torch::Tensor>& accumulate_into)
+                                 const c10::optional<torch::Tensor>& gather_, int64_t stream, const std::vector<torch::Tensor>& accumulate_into,
+                                 bool pose_only)
 {
     const torch::Tensor none;
     const torch::Tensor gather = contig(nz(gather_, none));
@@ -254,8 +255,9 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     const int64_t P = xyz_.size(0), S = log_scales_.size(-1);   // P: rows of the raw tensors (= of every gradient)
     // accumulate_into = the model's six gradient buffers in the optimizer's order (xyz, f_dc, f_rest, opacity, scaling, rotation): the
     // kernels add this view's gradients to them (GSR_BACKWARD_ACCUMULATE); nothing is allocated or zero-filled for them
-    const bool acc = accumulate_into.size() == 6;
-    TORCH_CHECK(acc || accumulate_into.empty(), "accumulate_into: six gradient buffers or none");
+    // pose_only: no parameter gradients at all (GSR_BACKWARD_POSE_ONLY): nothing is allocated for them, empty tensors come back
+    const bool acc = accumulate_into.size() == 6 && !pose_only;
+    TORCH_CHECK(accumulate_into.size() == 6 || accumulate_into.empty(), "accumulate_into: six gradient buffers or none");
     const int H = (int)dL_dout_color_.size(1), W = (int)dL_dout_color_.size(2);
     const torch::Tensor bg = contig(background), xyz = contig(xyz_), ls = contig(log_scales_), rr = contig(raw_rot_), lo = contig(logit_),
                         fdc = contig(f_dc_), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none)), dx = contig(nz(dx_, none)),
@@ -270,7 +272,8 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
         for (int i = 0; i < 6; i++)
             TORCH_CHECK(accumulate_into[i].is_cuda() && accumulate_into[i].scalar_type() == torch::kFloat32 && accumulate_into[i].is_contiguous() &&
                         accumulate_into[i].numel() == P * pw[i], "accumulate_into[", i, "]: contiguous fp32 device tensor of ", P * pw[i], " elements expected");
-    const int64_t widths[7] = {acc ? 0 : 3, acc ? 0 : 3, acc ? 0 : 3 * (M - 1), acc ? 0 : 1, acc ? 0 : S, acc ? 0 : 4, 3};
+    const bool own = !acc && !pose_only;      // the six parameter gradients are allocated here
+    const int64_t widths[7] = {own ? 3 : 0, own ? 3 : 0, own ? 3 * (M - 1) : 0, own ? 1 : 0, own ? S : 0, own ? 4 : 0, 3};
     int64_t total = 6;
     for (int64_t w : widths) total += P * w;
     torch::Tensor flat = masked ? torch::zeros({total}, fopt) : torch::empty({total}, fopt);   // with a mask only the selected rows are written
@@ -278,16 +281,21 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
     int64_t o = 0;
     for (int i = 0; i < 7; i++) { v[i] = flat.narrow(0, o, P * widths[i]); o += P * widths[i]; }
     if (acc) for (int i = 0; i < 6; i++) v[i] = accumulate_into[i].view({-1});
-    torch::Tensor g_xyz = v[0].view({P, 3}), g_fdc = v[1].view({P, 1, 3}), g_frest = v[2].view({P, M - 1, 3}), g_logit = v[3].view(lo.sizes()),
-                  g_ls = v[4].view({P, S}), g_rot = v[5].view({P, 4}), g_m2d = v[6].view({P, 3});
+    torch::Tensor g_xyz = v[0], g_fdc = v[1], g_frest = v[2], g_logit = v[3], g_ls = v[4], g_rot = v[5], g_m2d = v[6].view({P, 3});
+    if (!pose_only) {
+        g_xyz = v[0].view({P, 3}); g_fdc = v[1].view({P, 1, 3}); g_frest = v[2].view({P, M - 1, 3}); g_logit = v[3].view(lo.sizes());
+        g_ls = v[4].view({P, S}); g_rot = v[5].view({P, 4});
+    }
     torch::Tensor tau_sum = flat.narrow(0, o, 6);
     auto zeros_like_opt = [&](const torch::Tensor& t) { return (t.defined() && t.numel() != 0) ? torch::zeros_like(t, fopt) : torch::Tensor(); };
     torch::Tensor g_dx = zeros_like_opt(dx), g_ds = zeros_like_opt(ds), g_dr = zeros_like_opt(dr);
     const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc, frest, slot, dx, ds, dr, gather);
     gsr_raw_grads out{};
-    out.xyz = g_xyz.data_ptr<float>(); out.log_scales = g_ls.data_ptr<float>(); out.raw_rotations = g_rot.data_ptr<float>();
-    out.logit_opacity = g_logit.data_ptr<float>(); out.features_dc = g_fdc.data_ptr<float>();
-    out.features_rest = M > 1 ? g_frest.data_ptr<float>() : nullptr;
+    if (!pose_only) {
+        out.xyz = g_xyz.data_ptr<float>(); out.log_scales = g_ls.data_ptr<float>(); out.raw_rotations = g_rot.data_ptr<float>();
+        out.logit_opacity = g_logit.data_ptr<float>(); out.features_dc = g_fdc.data_ptr<float>();
+        out.features_rest = M > 1 ? g_frest.data_ptr<float>() : nullptr;
+    }
     out.dx = g_dx.defined() ? g_dx.data_ptr<float>() : nullptr; out.ds = g_ds.defined() ? g_ds.data_ptr<float>() : nullptr;
     out.dr = g_dr.defined() ? g_dr.data_ptr<float>() : nullptr;
     TORCH_CHECK(radii.is_cuda() && radii.scalar_type() == torch::kInt32, "radii must be an int32 device tensor");
@@ -296,7 +304,8 @@ rasterize_gaussians_raw_backward(const torch::Tensor& background, const torch::T
                                     (float)tan_fovy, radii.data_ptr<int>(), reinterpret_cast<char*>(geomBuffer.data_ptr()),
                                     reinterpret_cast<char*>(binningBuffer.data_ptr()), reinterpret_cast<char*>(imageBuffer.data_ptr()),
                                     fptr(gc, "dL_dout_color"), fptr(gd, "dL_dout_depth"), g_m2d.data_ptr<float>(), &out, tau_sum.data_ptr<float>(),
-                                    (debug ? 1 : 0) | (acc ? GSR_BACKWARD_ACCUMULATE : 0), reinterpret_cast<void*>(stream));
+                                    (debug ? 1 : 0) | (acc ? GSR_BACKWARD_ACCUMULATE : 0) | (pose_only ? GSR_BACKWARD_POSE_ONLY : 0),
+                                    reinterpret_cast<void*>(stream));
     if (rc < 0) fail("gsr_backward_raw", rc);
     return std::make_tuple(g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau_sum);
 }

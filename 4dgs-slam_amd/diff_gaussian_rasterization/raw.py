@@ -198,17 +198,24 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         gather = ctx.gather
         # fused accumulation into the parameters' .grad buffers (autograd._accumulation_targets): the six gradients are then not returned
         targets = _targets(ctx.acc_params, M) if getattr(ctx, "acc_params", None) is not None else None
+        # nobody asked for a parameter or delta gradient (camera tracking renders detached Gaussians): GSR_BACKWARD_POSE_ONLY
+        pose_only = not any(ctx.needs_input_grad[k] for k in (0, 2, 3, 4, 5, 6, 8, 9, 10))
+        if pose_only:
+            targets = None
         if _C._glue is not None:
             with torch.cuda.device(dev):
                 (g_xyz, g_fdc, g_frest, g_logit, g_ls, g_rot, g_m2d, g_dx, g_ds, g_dr, tau) = _C._glue.rasterize_gaussians_raw_backward(
                     rs.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, float(rs.scale_modifier),
                     rs.viewmatrix, rs.projmatrix, rs.projmatrix_raw, float(rs.tanfovx), float(rs.tanfovy), g_color, g_depth,
                     int(rs.sh_degree), rs.campos, radii, geom, int(ctx.num_rendered), binning, imgbuf, bool(rs.debug), gather, _C._stream(dev),
-                    targets or [])
+                    targets or [], pose_only)
             opt = lambda t, src: t if src is not None and src.numel() else None
-            if targets is not None:
+            if targets is not None or pose_only:
                 g_xyz = g_ls = g_rot = g_logit = g_fdc = g_frest = None
-            return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None) else None, None, opt(g_dx, dx), opt(g_ds, ds), opt(g_dr, dr),
+            if pose_only:
+                g_dx = g_ds = g_dr = None
+            return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None and not pose_only) else None, None,
+                    opt(g_dx, dx) if g_dx is not None else None, opt(g_ds, ds) if g_ds is not None else None, opt(g_dr, dr) if g_dr is not None else None,
                     _pose_grad(tau[3:], th_shape) if th_shape is not None else None,
                     _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None, None, None)
         lib = _lib()
@@ -216,7 +223,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         g_depth = g_depth if g_depth.dtype == torch.float32 else g_depth.to(torch.float32)
         # one allocation; parameter order of the optimizer (gaussian_model.py:404-434), then the screen-space gradient
         widths = [3, 3, 3 * (M - 1), 1, S, 4, 3]
-        if targets is not None:
+        if targets is not None or pose_only:
             widths[:6] = [0] * 6
         # with a mask only the selected rows are written: the rest of the gradients is zero
         flat = (torch.empty if gather is None else torch.zeros)((P * sum(widths) + 6,), dtype=torch.float32, device=dev)
@@ -226,33 +233,39 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             o += P * w_
         if targets is not None:
             views[:6] = [t_.view(-1) for t_ in targets]
-        g_xyz, g_fdc, g_frest = views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, M - 1, 3)
-        g_logit, g_ls, g_rot, g_m2d = views[3].view(logit_opacity.shape), views[4].view(P, S), views[5].view(P, 4), views[6].view(P, 3)
+        g_m2d = views[6].view(P, 3)
+        if not pose_only:
+            g_xyz, g_fdc, g_frest = views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, M - 1, 3)
+            g_logit, g_ls, g_rot = views[3].view(logit_opacity.shape), views[4].view(P, S), views[5].view(P, 4)
         tau = flat[o:o + 6]
         K = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
         g_dx, g_ds, g_dr = K(dx), K(ds), K(dr)
         keep = []
         desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep, gather)
         out = _RawGrads()
-        out.xyz, out.log_scales, out.raw_rotations, out.logit_opacity = g_xyz.data_ptr(), g_ls.data_ptr(), g_rot.data_ptr(), g_logit.data_ptr()
-        out.features_dc, out.features_rest = g_fdc.data_ptr(), (g_frest.data_ptr() if M > 1 else None)
-        out.dx, out.ds, out.dr = (g_dx.data_ptr() if g_dx is not None else None, g_ds.data_ptr() if g_ds is not None else None,
-                                  g_dr.data_ptr() if g_dr is not None else None)
+        if not pose_only:
+            out.xyz, out.log_scales, out.raw_rotations, out.logit_opacity = g_xyz.data_ptr(), g_ls.data_ptr(), g_rot.data_ptr(), g_logit.data_ptr()
+            out.features_dc, out.features_rest = g_fdc.data_ptr(), (g_frest.data_ptr() if M > 1 else None)
+            out.dx, out.ds, out.dr = (g_dx.data_ptr() if g_dx is not None else None, g_ds.data_ptr() if g_ds is not None else None,
+                                      g_dr.data_ptr() if g_dr is not None else None)
         with torch.cuda.device(dev):
             rc = lib.gsr_backward_raw(
                 P if gather is None else int(gather.shape[0]), int(rs.sh_degree), M, int(ctx.num_rendered), _f32(rs.bg, "bg", keep), W, H, C.byref(desc), float(rs.scale_modifier),
                 _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep), _f32(rs.projmatrix_raw, "projmatrix_raw", keep),
                 _f32(rs.campos, "campos", keep), float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(),
                 geom.data_ptr(), binning.data_ptr(), imgbuf.data_ptr(), _f32(g_color, "dL_dcolor", keep), _f32(g_depth, "dL_ddepth", keep),
-                g_m2d.data_ptr(), C.byref(out), tau.data_ptr(), int(bool(rs.debug)) | (2 if targets is not None else 0), _C._stream(dev))
+                g_m2d.data_ptr(), C.byref(out), tau.data_ptr(), int(bool(rs.debug)) | (2 if targets is not None else 0) | (4 if pose_only else 0),
+                _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_backward_raw")
-        if targets is not None:
+        if targets is not None or pose_only:
             g_xyz = g_ls = g_rot = g_logit = g_fdc = g_frest = None
+        if pose_only:
+            g_dx = g_ds = g_dr = None
         g_rho = _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None
         g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
         # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
-        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None) else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
+        return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None and not pose_only) else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
 
 
 def gather_from_mask(mask: torch.Tensor) -> torch.Tensor:

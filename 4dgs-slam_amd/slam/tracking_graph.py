@@ -11,6 +11,8 @@ flag every few iterations. Three things make the iteration capturable:
   * the frame's data (image, depth, loss weights, pose) is COPIED into a static slot per frame, so one captured graph serves every
     frame tracked against the same map; it is re-captured when the map's tensors change (after every keyframe).
 If a frame outgrows the speculative binning capacity during replay (gsr_forward_status), the caller repeats the frame eagerly."""
+import types
+
 import torch
 
 from diff_gaussian_rasterization import _C
@@ -46,6 +48,12 @@ class TrackingGraph:
         # screen-space gradients, the visibility mask) are two launches per iteration that tracking never looks at
         self.direct = gaussian_renderer._fused_prologue_ok(gaussians, pipeline_params, self.static, False) and gaussians.get_xyz.shape[0] > 0
         self.means2D = torch.zeros_like(gaussians.get_xyz)
+        # ... and with DETACHED parameters: tracking reads the pose gradient only, so the backward pass runs in its pose-only mode
+        # (GSR_BACKWARD_POSE_ONLY: no parameter-gradient stores, no covariance -> scale / rotation chain, nothing to zero per iteration)
+        g = gaussians
+        self.frozen = types.SimpleNamespace(_xyz=g._xyz.detach(), _scaling=g._scaling.detach(), _rotation=g._rotation.detach(), _opacity=g._opacity.detach(),
+                                            _features_dc=g._features_dc.detach(), _features_rest=g._features_rest.detach(), dygs=g.dygs,
+                                            active_sh_degree=g.active_sh_degree, get_xyz=g._xyz.detach())
 
     @staticmethod
     def model_version(g):
@@ -81,7 +89,7 @@ class TrackingGraph:
     def iteration(self):
         c = self.cam
         if self.direct:
-            image, radii, depth, opacity, n_touched = gaussian_renderer._render_fused(c, self.gaussians, self.background, 1.0, self.means2D, None, None,
+            image, radii, depth, opacity, n_touched = gaussian_renderer._render_fused(c, self.frozen, self.background, 1.0, self.means2D, None, None,
                                                                                       None, self.static, False)
             pkg = {"render": image, "radii": radii, "depth": depth, "opacity": opacity, "n_touched": n_touched}
         else:
@@ -91,7 +99,7 @@ class TrackingGraph:
                                             c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95, compute_value=False)
         loss.backward()
         c.pose_step(*self.lrs)
-        if self.gaussians.optimizer is not None:
+        if not self.direct and self.gaussians.optimizer is not None:
             self.gaussians.optimizer.zero_grad(set_to_none=True)
         return pkg
 

@@ -94,6 +94,10 @@ int gsr_backward(int P, int D, int M, int R,
  * step and thereby skips the zero rows this call would write per view (71 % of the Gaussians at BASELINE config #5) and the
  * read-modify-write of its own accumulation. dL_dmean2D (a per-view statistic) and the intermediate gradients are still overwritten. */
 #define GSR_BACKWARD_ACCUMULATE 2
+/* GSR_BACKWARD_POSE_ONLY (another bit of `debug`): the caller wants no parameter gradients at all (camera tracking reads only the pose
+ * gradient dL_dtau_sum and dL_dmean2D): dL_dmean3D, dL_dsh, dL_dopacity, dL_dscale, dL_drot (raw mode: every gsr_raw_grads pointer) may be
+ * NULL and are not written; the covariance -> scale / rotation chain is skipped. */
+#define GSR_BACKWARD_POSE_ONLY 4
 int gsr_backward_fused(int P, int D, int M, int R,
                        const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp,

@@ -219,3 +219,36 @@ def test_fused_route_with_an_all_false_mask_returns_the_empty_render():
     assert float(res["render"].abs().max()) == 0.0 and float(res["depth"].abs().max()) == 0.0
     (res["render"].sum() + res["depth"].sum()).backward()
     assert float(m._xyz.grad.abs().sum()) == 0.0 and float(view.cam_rot_delta.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("deg,with_mask,binding", [(0, True, "native"), (3, False, "native"), (1, True, "ctypes")])
+def test_pose_only_backward_gives_the_same_pose_and_screen_space_gradients(deg, with_mask, binding, monkeypatch):
+    """GSR_BACKWARD_POSE_ONLY: rendering DETACHED Gaussians (camera tracking) makes the raw route's backward skip every parameter
+    gradient. The pose gradient -- including the SH view-direction term -- and the screen-space gradient must be bit-identical to the
+    full backward's."""
+    import gaussian_renderer as gr
+    from diff_gaussian_rasterization import _C
+    if binding == "ctypes":
+        monkeypatch.setattr(_C, "_glue", None)
+    cam = make_camera(200, 152)
+    g = make_gaussians(5000, cam, seed=41, sh_degree=deg)
+    gc, gd = make_cotangents(cam, seed=42)
+    bg = torch.tensor([0.1, 0.3, 0.5], device="cuda")
+    out = {}
+    for frozen in (False, True):
+        m = _GaussianModel(g, False, 0.3, seed=43)
+        view = _camera(cam)
+        mask = (m.dygs == False) if with_mask else None   # noqa: E712
+        pc = m
+        if frozen:
+            pc = types.SimpleNamespace(_xyz=m._xyz.detach(), _scaling=m._scaling.detach(), _rotation=m._rotation.detach(), _opacity=m._opacity.detach(),
+                                       _features_dc=m._features_dc.detach(), _features_rest=m._features_rest.detach(), dygs=m.dygs,
+                                       active_sh_degree=m.active_sh_degree)
+        m2d = torch.zeros_like(m._xyz, requires_grad=True)
+        image, radii, depth, opacity, n_touched = gr._render_fused(view, pc, bg, 1.0, m2d, None, None, None, mask, False)
+        ((image * torch.tensor(gc, device="cuda")).sum() + (depth * torch.tensor(gd, device="cuda")).sum()).backward()
+        out[frozen] = (view.cam_rot_delta.grad.clone(), view.cam_trans_delta.grad.clone(), m2d.grad.clone(), m._xyz.grad)
+    assert out[True][3] is None and out[False][3] is not None
+    assert float(out[False][0].abs().sum()) > 0 and float(out[False][1].abs().sum()) > 0
+    for k in range(3):
+        assert torch.equal(out[True][k], out[False][k]), k
