@@ -239,6 +239,21 @@ def test_huge_tile_grid_uses_global_atomic_binning_fallback():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P", [300_000, 2_200_000])
+def test_many_gaussian_blocks_column_scan_variants(P):
+    """More than 256 Gaussian blocks of 1024 (the 64-segment variant of the per-tile column scan keeps up to 2048 block rows in
+    registers; BASELINE config #5 has 1954) and more than 2048 (its serial fall-back): parity with the oracle on a small image, where
+    the oracle stays cheap."""
+    cam = make_camera(128, 96)
+    g = make_gaussians(P, cam, seed=8, scale_mean=0.002)
+    gc, gd = make_cotangents(cam)
+    bg = np.array([0.3, 0.3, 0.3], np.float32)
+    oo, st, go = oracle_run(g, cam, bg, gc, gd)
+    oh, gh = hip_run(g, cam, bg, gc, gd)
+    _check(compare(oh, gh, oo, go), nt_tol=max(8, P // 50_000))
+
+
+@pytest.mark.gpu
 def test_speculative_binning_and_its_overflow_redo():
     """The second forward pass of a host thread is enqueued without waiting for R (buffer sized from the previous frame).
     Same scene again: bitwise the same result as the waited-for first pass. A much larger scene next: the speculative capacity
