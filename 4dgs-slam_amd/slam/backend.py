@@ -39,6 +39,9 @@ class BackEnd:
         self.log = []
 
     def set_hyperparams(self):
+        # Training.loss_values (default False): the mapping loops only back-propagate their losses, so the value's two launches per view are
+        # skipped and -- in the static loop -- every view is back-propagated on its own (same gradient sum, accumulated in view order)
+        self.loss_values = bool(self.config["Training"].get("loss_values", False))
         """:81-105."""
         t = self.config["Training"]
         self.save_results, self.save_dir = self.config["Results"].get("save_results", False), self.config["Results"].get("save_dir")
@@ -96,7 +99,7 @@ class BackEnd:
             self.iteration_count += 1
             pkg = self._render(viewpoint, (None, None, None))
             loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True,
-                                                     rm_dynamic=not (self.dystart == cur_frame_idx))
+                                                     rm_dynamic=not (self.dystart == cur_frame_idx), compute_value=self.loss_values)
             loss_init.backward()
             with torch.no_grad():
                 self._view_stats(pkg)
@@ -130,7 +133,7 @@ class BackEnd:
         for mapping_iteration in range(self.network_init_iters):
             deltas = self._deltas(viewpoint)
             pkg = self._render(viewpoint, deltas)
-            loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True)
+            loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True, compute_value=self.loss_values)
             loss_init.backward()
             with torch.no_grad():
                 self._view_stats(pkg)
@@ -196,17 +199,22 @@ class BackEnd:
             self.last_sent += 1
             loss_mapping = 0
             pkgs, n_touched_acm = [], []
+
+            def add_view(viewpoint):
+                pkg = self._render(viewpoint, (None, None, None))
+                loss = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True,
+                                                    compute_value=self.loss_values)
+                pkgs.append(pkg)
+                if self.loss_values:
+                    return loss
+                loss.backward()                      # this view's gradients now; the rasterizer state of the view is released right away
+                return 0
+
             for cam_idx in range(len(current_window)):
-                viewpoint = viewpoint_stack[cam_idx]
-                pkg = self._render(viewpoint, (None, None, None))
-                loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True)
-                pkgs.append(pkg)
-                n_touched_acm.append(pkg["n_touched"])
+                loss_mapping = loss_mapping + add_view(viewpoint_stack[cam_idx])
+                n_touched_acm.append(pkgs[-1]["n_touched"])
             for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
-                viewpoint = random_viewpoint_stack[cam_idx]
-                pkg = self._render(viewpoint, (None, None, None))
-                loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True)
-                pkgs.append(pkg)
+                loss_mapping = loss_mapping + add_view(random_viewpoint_stack[cam_idx])
             loss_mapping = loss_mapping + self._isotropic_loss()
             loss_mapping.backward()
             gaussian_split = False
@@ -276,7 +284,7 @@ class BackEnd:
                 deltas = self._deltas(viewpoint) if use_net else (None, None, None)
                 pkg = self._render(viewpoint, deltas)
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
-                                                                         rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False)
+                                                                         rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False, compute_value=self.loss_values)
                 if with_flow:
                     loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
                 if use_net:

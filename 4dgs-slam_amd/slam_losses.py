@@ -196,9 +196,10 @@ def mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False
 
 
 def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=False, alpha=None, rm_dynamic=False, mask=None,
-                     dynamic=False, split=False):
+                     dynamic=False, split=False, compute_value=True):
     """utils/slam_utils.py:252-259, same arguments and value. RGB-D, non-split calls (every call of utils/slam_backend.py with
-    the shipped configs) run fused; `monocular` and `split=True` are evaluated with the reference's tensor expression."""
+    the shipped configs) run fused; `monocular` and `split=True` are evaluated with the reference's tensor expression.
+    compute_value=False (fused path only): the scalar is left uninitialised -- for callers that only back-propagate it."""
     _C._require_device(image, "image")
     gt_image, gt_depth, base_rgb, base_dep, _, _ = _keyframe_constants(config, viewpoint, image.device)
     exposure = (None, None) if initialization else (viewpoint.exposure_a, viewpoint.exposure_b)
@@ -216,7 +217,7 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
         l_static, l_dynamic = part(mm), part(~mm)
         return (l_static, 2 * l_dynamic) if dynamic else (l_static, l_dynamic)
     w_rgb, w_dep = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep))
-    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha)
+    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha, compute_value=compute_value)
 
 
 def tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, base=None):

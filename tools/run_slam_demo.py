@@ -26,7 +26,8 @@ for name, dyn, graph, frames, wh in (("static_640x480_eager", False, False, 40, 
     cfg = merge_config(default_config(), {"Training": {"init_itr_num": 400, "init_gaussian_update": 100, "init_gaussian_reset": 200, "tracking_itr_num": 60,
                                                        "static_map_iters": 30, "dynamic_map_iters": 80, "network_init_iters": 50, "gaussian_update_every": 60,
                                                        "gaussian_update_offset": 20, "tracking_graph": graph,
-                                                       "fused_grad_accumulation": os.environ.get("GSR_FUSED_ACC", "1") == "1"},
+                                                       "fused_grad_accumulation": os.environ.get("GSR_FUSED_ACC", "1") == "1",
+                                                       "loss_values": os.environ.get("GSR_LOSS_VALUES", "0") == "1"},
                                           "Dataset": {"pcd_downsample": 32, "pcd_downsample_init": 8}, "opt_params": {"densify_from_iter": 150},
                                           "model_params": {"dynamic_model": dyn}})
     for i in range(len(ds)):          # the sensor stream is "pre-recorded": rendering the synthetic frames is not part of the SLAM time
