@@ -252,3 +252,41 @@ def test_pose_only_backward_gives_the_same_pose_and_screen_space_gradients(deg, 
     assert float(out[False][0].abs().sum()) > 0 and float(out[False][1].abs().sum()) > 0
     for k in range(3):
         assert torch.equal(out[True][k], out[False][k]), k
+
+
+@pytest.mark.parametrize("isotropic,deg,with_mask", [(False, 3, False), (True, 1, True), (False, 0, True)])
+def test_fused_gradient_accumulation_on_the_raw_route_equals_autograd_bitwise(isotropic, deg, with_mask):
+    """FusedAdam.enable_fused_gradient_accumulation(): three views, each back-propagated on its own, summed into the optimizer's flat
+    gradient buffer by the backward kernels (GSR_BACKWARD_ACCUMULATE) -- against autograd's own accumulation of the returned gradients.
+    Higher SH bands (read-modify-write at the store), the isotropic scale column and the mask gather (unselected rows untouched)."""
+    import gaussian_renderer as gr
+    from fused_adam import FusedAdam
+    from util import keyframe_pose
+    cam0 = make_camera(200, 152)
+    g = make_gaussians(6000, cam0, seed=51, sh_degree=deg)
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([0.1, 0.3, 0.5], device="cuda")
+    res = {}
+    for fused in (True, False):
+        m = _GaussianModel(g, isotropic, 0.3, seed=53)
+        names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        tensors = (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)
+        opt = FusedAdam([{"params": [p], "lr": 0.0, "name": n} for n, p in zip(names, tensors) if p.numel()], lr=0.0, eps=1e-15)
+        opt.enable_fused_gradient_accumulation(fused)
+        opt.zero_grad()
+        mask = (m.dygs == False) if with_mask else None   # noqa: E712
+        for k in (0, 2, 5):
+            R, t = keyframe_pose(k)
+            cam = make_camera(200, 152, R=R, t=t)
+            gc, gd = make_cotangents(cam, seed=60 + k)
+            out = gr.render(_camera(cam), m, pipe, bg, mask=mask)
+            ((out["render"] * torch.tensor(gc, device="cuda")).sum() + (out["depth"] * torch.tensor(gd, device="cuda")).sum()).backward()
+        res[fused] = [None if p.grad is None else p.grad.clone() for p in tensors]
+        if fused:
+            assert opt._bucket is not None and all(p.grad is v for p, v in zip(opt._bucket.params, opt._bucket.views))
+    for a, b, n in zip(res[True], res[False], names):
+        if b is None:
+            assert a is None or float(a.abs().sum()) == 0.0, n
+            continue
+        assert a is not None and torch.equal(a, b), (n, float((a - b).abs().max()))
+    assert float(res[True][0].abs().sum()) > 0
