@@ -1418,4 +1418,13 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
     return 0;
 }
 
+int gsr_kabsch_rotations(int n, const float* S, float* R, void* stream_)
+{
+    if (n < 0 || (n > 0 && (!S || !R))) { g_last_error = "gsr_kabsch_rotations: null argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(kabsch_rotation_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream_, n, S, R);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

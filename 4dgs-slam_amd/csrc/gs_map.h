@@ -314,4 +314,58 @@ __global__ void __launch_bounds__(256) edge_compare_kernel(const float* __restri
     if (i < n) mask[i] = intensity[i] > median[0] * edge_threshold ? 1 : 0;
 }
 
+// ---- best-fit rotations of the node graph: estimate_rotation, utils/deform_utils.py:130-166 ----------------------------------------
+// For every 3x3 cross-covariance S (= sum_k w_k e0_k et_k^T over a node's edges) the rotation R = V U^T of its singular value
+// decomposition S = U Sigma V^T, with the column of the SMALLEST singular value flipped when det(V U^T) <= 0 (:157-162): the proper
+// rotation closest to S^T. The reference calls torch.svd on [Nv,3,3] per time sample; here one thread per matrix: Jacobi eigenvectors of
+// S^T S (double precision), u_i = S v_i / sigma_i for the two largest singular values, third axes by cross products -- which IS the
+// reflection rule. S = 0 (the reference zeroes S for unchanged vertices, :148-149) gives the identity.
+__global__ void __launch_bounds__(64) kabsch_rotation_kernel(int n, const float* __restrict__ S_in, float* __restrict__ R_out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double S[3][3], A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[r][c] = (double)S_in[9 * (size_t)i + 3 * r + c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = S[0][r] * S[0][c] + S[1][r] * S[1][c] + S[2][r] * S[2][c];   // S^T S
+    for (int sweep = 0; sweep < 12; sweep++) {                   // cyclic Jacobi: A <- J^T A J, V <- V J
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++) {
+            for (int q = p + 1; q < 3; q++) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+                for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+                for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+            }
+        }
+    }
+    int o[3] = {0, 1, 2};                                        // eigenvalues (sigma^2) in descending order
+    for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (A[o[b]][o[b]] > A[o[a]][o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
+    double v1[3], v2[3], u1[3], u2[3];
+    for (int k = 0; k < 3; k++) { v1[k] = V[k][o[0]]; v2[k] = V[k][o[1]]; }
+    float* R = R_out + 9 * (size_t)i;
+    const double s1 = A[o[0]][o[0]];
+    if (!(s1 > 1e-60)) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.f : 0.f; return; }
+    for (int r = 0; r < 3; r++) { u1[r] = S[r][0] * v1[0] + S[r][1] * v1[1] + S[r][2] * v1[2]; u2[r] = S[r][0] * v2[0] + S[r][1] * v2[1] + S[r][2] * v2[2]; }
+    const double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    for (int r = 0; r < 3; r++) u1[r] /= n1;
+    const double d12 = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+    for (int r = 0; r < 3; r++) u2[r] -= d12 * u1[r];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (!(n2 > 1e-12 * n1)) {                                    // rank one: any unit vector orthogonal to u1 (the reference's choice is the SVD routine's)
+        const int m = fabs(u1[0]) <= fabs(u1[1]) ? (fabs(u1[0]) <= fabs(u1[2]) ? 0 : 2) : (fabs(u1[1]) <= fabs(u1[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[m] = 1.0;
+        const double d = u1[m];
+        for (int r = 0; r < 3; r++) u2[r] = e[r] - d * u1[r];
+        n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    }
+    for (int r = 0; r < 3; r++) u2[r] /= n2;
+    const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = (float)(v1[r] * u1[c] + v2[r] * u2[c] + v3[r] * u3[c]);   // V U^T
+}
+
 }  // namespace gsr

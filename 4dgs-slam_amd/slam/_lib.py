@@ -39,6 +39,8 @@ def lib():
         L.gsr_densify_apply.argtypes = [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(DensifyTensor), _vp, _vp, _i, _vp, _vp, _vp]
         L.gsr_camera_step_launch.restype = _i
         L.gsr_camera_step_launch.argtypes = [C.POINTER(CameraStep), _vp]
+        L.gsr_kabsch_rotations.restype = _i
+        L.gsr_kabsch_rotations.argtypes = [_i, _vp, _vp, _vp]
         L.gsr_edge_mask.restype = _i
         L.gsr_edge_mask.argtypes = [_vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]
         _declared = True

@@ -14,6 +14,8 @@ import torch
 from gaussian_renderer import render
 import slam_losses
 
+from .deform_model import draw_loss_times
+
 
 class BackEnd:
     def __init__(self, config):
@@ -273,13 +275,29 @@ class BackEnd:
             extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]
             with_flow = use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow")
             if use_net:       # every time sample this iteration asks the node network for, as one batch (deform_model.begin_iteration)
-                nodes, times = g.deform.deform, []
-                for viewpoint in views + extra:
-                    times += nodes.sample_times(viewpoint.time, 5 * g.time_interval, 2)
+                nodes, times, plans = g.deform.deform, [], []
+                arap_delta = float(t.get("delta", 5)) * g.time_interval              # :325,:518
+                for k, viewpoint in enumerate(views + extra):
+                    # the regularisers' random time samples (:517-519 window views: ARAP with 4 samples over `delta` intervals; :646-648
+                    # random views: ARAP with 2 samples over 5 intervals; elastic: 8 samples over 5 intervals for both)
+                    window = k < len(views)
+                    plan = draw_loss_times(viewpoint.time, arap_delta if window else 5 * g.time_interval, 4 if window else 2, 5 * g.time_interval)
+                    plans.append(plan)
+                    times += [viewpoint.time] + plan["arap"] + plan["elastic"]
                     closest = self.find_closest_keyframe(viewpoint.uid) if with_flow else None
                     if closest is not None:
                         times.append(self.viewpoints[closest].time)
                 nodes.begin_iteration(times)
+                # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
+                nv = len(views)
+                wts = torch.tensor([1e-3] * nv + [1e-4] * len(extra), dtype=torch.float32, device=self.device)
+                if nodes.node_num >= 3:
+                    reg = (nodes.elastic_loss_batch([p_["elastic"] for p_ in plans]) * wts).sum()
+                    if nv:
+                        reg = reg + (wts[:nv] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[:nv]])).sum()
+                    if len(extra):
+                        reg = reg + (wts[nv:] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[nv:]])).sum()
+                    loss_network = loss_network + reg
             for k, viewpoint in enumerate(views + extra):
                 deltas = self._deltas(viewpoint) if use_net else (None, None, None)
                 pkg = self._render(viewpoint, deltas)
@@ -287,10 +305,6 @@ class BackEnd:
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False, compute_value=self.loss_values)
                 if with_flow:
                     loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
-                if use_net:
-                    w = 1e-3 if k < len(views) else 1e-4                     # :517-519 / :640-643
-                    loss_network = loss_network + w * g.deform.deform.arap_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_samp_num=2, t_key=viewpoint.time)
-                    loss_network = loss_network + w * g.deform.deform.elastic_loss(t=viewpoint.fid, delta_t=5 * g.time_interval, t_key=viewpoint.time)
                 pkgs.append(pkg)
                 if k < len(views):
                     n_touched_acm.append(pkg["n_touched"])

@@ -45,6 +45,86 @@ def farthest_point_sample(xyz, npoint):
     return idx
 
 
+# ---- the node regularisers of SC-GS as the reference runs them (utils/deform_utils.py, utils/time_utils.py:1128-1165) -----------------
+def kabsch_rotations(S):
+    """R = V U^T of S = U Sigma V^T with the reflection rule of estimate_rotation (deform_utils.py:152-162), for [..., 3, 3] matrices:
+    one HIP launch (gsr_kabsch_rotations, include/slam_map.h) instead of torch.svd on thousands of 3x3 matrices."""
+    from . import _lib
+    Sc = S.detach().to(torch.float32).contiguous()
+    R = torch.empty_like(Sc)
+    n = Sc.numel() // 9
+    if n:
+        with torch.cuda.device(Sc.device):
+            _lib.check(_lib.lib().gsr_kabsch_rotations(n, _lib.dev_f32(Sc, "S"), R.data_ptr(), _lib.stream(Sc.device)), "gsr_kabsch_rotations")
+    return R
+
+
+def connectivity_from_points(points, radius=0.1, K=10, least_edge_num=3):
+    """cal_connectivity_from_points (deform_utils.py:58-110, mode 'nn'): the K nearest other points of every point; beyond the first
+    `least_edge_num`, neighbours farther than `radius` are dropped. points [..., Nv, 3] -> (nn_idx [..., Nv, K] int64, keep [..., Nv, K] bool).
+    (The edge weights that function also returns are not used by arap_loss: cal_arap_error is called without them, :1139-1140.)"""
+    pts = points.detach().reshape(-1, points.shape[-2], 3)
+    K = min(K, pts.shape[1] - 1)
+    knn = control_nodes.knn_points(pts, pts, K=K + 1)
+    nn_dist, nn_idx = knn.dists[:, :, 1:], knn.idx[:, :, 1:]
+    keep = torch.ones_like(nn_idx, dtype=torch.bool)
+    keep[:, :, least_edge_num:] = nn_dist[:, :, least_edge_num:] < radius ** 2
+    shape = points.shape[:-1] + (K,)
+    return nn_idx.reshape(shape), keep.reshape(shape)
+
+
+def edge_matrix(verts, nn_idx, keep):
+    """produce_edge_matrix_nfmt (deform_utils.py:35-42): E[i, n] = verts[i] - verts[nn_idx[i, n]] on the kept edges, 0 elsewhere.
+    verts [..., Nv, 3] with nn_idx / keep [..., Nv, K] (same leading dimensions)."""
+    nb = torch.gather(verts[..., None, :, :].expand(*verts.shape[:-2], nn_idx.shape[-2], verts.shape[-2], 3), -2,
+                      nn_idx[..., None].expand(*nn_idx.shape, 3))
+    return (verts[..., :, None, :] - nb) * keep[..., None]
+
+
+def estimate_rotation(E0, Et, weight, rotations=kabsch_rotations):
+    """estimate_rotation (deform_utils.py:130-166) on edge matrices [..., Nv, K, 3]: S = E0^T diag(w) Et, zeroed for vertices none of whose
+    edges changed in some coordinate (:147-149), then the best-fit rotation of every S."""
+    S = torch.einsum("...ka,...k,...kb->...ab", E0, weight, Et)
+    unchanged = (E0 == Et).all(dim=-2).any(dim=-1)
+    S = torch.where(unchanged[..., None, None], torch.zeros_like(S), S)
+    return rotations(S)
+
+
+def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
+    """cal_arap_error (deform_utils.py:177-205) without edge weights (every kept edge weighs 1) and without its random vertex subsample,
+    which only starts above 512 vertices (the node budget). nodes_seq [..., T, Nv, 3]; nn_idx / keep [..., Nv, K] from
+    connectivity_from_points(nodes_seq[..., 0, :, :]). Returns the error per leading index."""
+    w = keep.to(nodes_seq.dtype)
+    E0 = edge_matrix(nodes_seq[..., 0, :, :], nn_idx, keep)
+    err = 0
+    for idx in range(1, nodes_seq.shape[-3]):
+        Et = edge_matrix(nodes_seq[..., idx, :, :], nn_idx, keep)
+        with torch.no_grad():
+            R = estimate_rotation(E0.detach(), Et.detach(), w, rotations)
+        stretch = Et - torch.einsum("...ab,...kb->...ka", R, E0)              # target edges minus the rigidly rotated source edges
+        err = err + (w * stretch.norm(dim=-1) ** 2).sum(dim=(-2, -1))
+    return err
+
+
+def elastic_error(nodes_t, nn_weight, nn_idx):
+    """The body of ControlNodeWarp.elastic_loss (time_utils.py:1160-1165): the variance over time of every edge length to the K nearest
+    nodes, normalised by its own detached value, weighted by the RBF weights. nodes_t [..., M, T, 3]; nn_weight / nn_idx [M, K]."""
+    edge_t = (nodes_t[..., nn_idx, :, :] - nodes_t[..., :, None, :, :]).norm(dim=-1)      # [..., M, K, T]
+    var = edge_t.var(dim=-1)
+    var = var / (var.detach() + 1e-5)
+    return (var * nn_weight).sum(dim=-1).mean(dim=-1)
+
+
+def draw_loss_times(t, arap_delta, arap_samples, elastic_delta, elastic_samples=8):
+    """The time samples ControlNodeWarp.arap_loss (:1129-1132) and elastic_loss (:1145-1149) draw around t, as host floats and in the
+    reference's order of torch.rand calls (CPU generator here, the reference draws on the device)."""
+    ta = t + arap_delta * (float(torch.rand(())) - 0.5)
+    arap = (torch.rand(arap_samples) * arap_delta + ta - 0.5 * arap_delta).tolist()
+    te = t + elastic_delta * (float(torch.rand(())) - 0.5)
+    elastic = (torch.rand(elastic_samples) * elastic_delta + te - 0.5 * elastic_delta).tolist()
+    return {"arap": arap, "elastic": elastic}
+
+
 class ControlNodes(nn.Module):
     def __init__(self, node_num=512, K=3, hidden=128, depth=4, t_multires=6, x_multires=6, d_rot_as_res=True, device="cuda"):
         super().__init__()
@@ -140,46 +220,48 @@ class ControlNodes(nn.Module):
                                        na["d_scaling"], None, K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
         return {"d_xyz": out["d_xyz"], "d_rotation": out["d_rotation"], "d_scaling": out["d_scaling"], "d_opacity": None, "d_color": None}
 
-    def _node_graph(self, K=4):
-        if self._batch is not None and self._graph is not None:     # inside an iteration the nodes do not move
-            return self._graph
-        kk = min(self.node_num - 1, K)
-        nb = control_nodes.knn_points(self.nodes.detach()[None], self.nodes.detach()[None], K=kk + 1).idx[0, :, 1:]
-        if self._batch is not None:
-            self._graph = nb
-        return nb
+    def node_positions(self, times):
+        """nodes + d_xyz(t) for a list of host times -> [M, T, 3] (time_utils.py:1136-1137, 1153-1154); served from the iteration's batched
+        evaluation when there is one."""
+        cols = []
+        for t in times:
+            tt = torch.full((self.node_num, 1), float(t), dtype=torch.float32, device=self.device)
+            cols.append(self.node_deform(tt, t)["d_xyz"])
+        return self.nodes.detach()[:, None, :] + torch.stack(cols, 1)
 
-    @staticmethod
-    def sample_times(t, delta_t, t_samp_num=2):
-        """The time samples arap_loss / elastic_loss evaluate around t (host floats): for begin_iteration."""
-        arap = [t + (s / max(t_samp_num - 1, 1) - 0.5) * 2 * float(delta_t) for s in range(t_samp_num)]
-        return arap + [t, t + float(delta_t)]
-
-    def arap_loss(self, t=None, delta_t=0.05, t_samp_num=2, t_key=None, **_):
-        """:1128-1141, reduced: edge lengths between neighbouring nodes are preserved between time t and t + delta_t."""
-        if self.node_num < 2:
+    def arap_loss(self, times):
+        """ControlNodeWarp.arap_loss (:1128-1141) on the time samples `times` (draw_loss_times): connectivity of the nodes at the first
+        sample (K = 10), then the ARAP error of the other samples against it."""
+        if self.node_num < 3:
             return torch.zeros((), device=self.device)
-        t0 = t.reshape(1, 1) if t is not None else torch.rand(1, 1, device=self.device)
-        nb = self._node_graph()
-        loss = 0.0
-        ref = None
-        for s in range(t_samp_num):
-            off = (s / max(t_samp_num - 1, 1) - 0.5) * 2 * float(delta_t)
-            ts = (t0 + off).expand(self.node_num, 1)
-            p = self.nodes.detach() + self.node_deform(ts, None if t_key is None else t_key + off)["d_xyz"]
-            e = (p[:, None] - p[nb]).norm(dim=-1)
-            if ref is None:
-                ref = e
-            else:
-                loss = loss + (e - ref).abs().mean()
-        return loss
+        return self.arap_loss_batch([times])[0]
 
-    def elastic_loss(self, t=None, delta_t=0.005, t_key=None, **_):
-        """:1143-1165, reduced to a first-order smoothness of the node translations in time."""
-        t0 = t.reshape(1, 1) if t is not None else torch.rand(1, 1, device=self.device)
-        a = self.node_deform(t0.expand(self.node_num, 1), t_key)["d_xyz"]
-        b = self.node_deform((t0 + float(delta_t)).expand(self.node_num, 1), None if t_key is None else t_key + float(delta_t))["d_xyz"]
-        return (a - b).abs().mean()
+    def arap_loss_batch(self, times_per_view):
+        """arap_loss for several views with the same number of samples in one pass: [V] errors."""
+        nodes_seq = torch.stack([self.node_positions(ts).permute(1, 0, 2) for ts in times_per_view])      # [V, T, M, 3]
+        nn_idx, keep = connectivity_from_points(nodes_seq[:, 0], K=10)
+        return arap_error(nodes_seq, nn_idx, keep)
+
+    def _elastic_neighbours(self, K=2):
+        if self._batch is not None and self._graph is not None:     # inside an iteration neither the nodes nor their radii move
+            return self._graph
+        kk = min(K + 1, self.node_num)
+        w, _, idx = control_nodes.cal_nn_weight(self.nodes.detach(), self.nodes.detach(), self._node_radius, self._node_weight, K=kk)
+        out = (w[:, 1:], idx[:, 1:])
+        if self._batch is not None:
+            self._graph = out
+        return out
+
+    def elastic_loss(self, times):
+        """ControlNodeWarp.elastic_loss (:1143-1165, the paper's "APAR" term) on the time samples `times`."""
+        if self.node_num < 3:
+            return torch.zeros((), device=self.device)
+        return self.elastic_loss_batch([times])[0]
+
+    def elastic_loss_batch(self, times_per_view):
+        nodes_t = torch.stack([self.node_positions(ts) for ts in times_per_view])                          # [V, M, T, 3]
+        nn_weight, nn_idx = self._elastic_neighbours()
+        return elastic_error(nodes_t, nn_weight, nn_idx)
 
 
 class DeformModel:

@@ -99,6 +99,11 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
 int gsr_edge_mask(const float* image, int height, int width, float edge_threshold, float eps, float* intensity, float* median,
                   unsigned char* mask, void* stream);
 
+/* ---- best-fit rotations for the ARAP regulariser of the control nodes: estimate_rotation, utils/deform_utils.py:130-166 ----------------
+ * S, R: n row-major 3x3 matrices. R = V U^T of S = U Sigma V^T, with the reference's reflection rule (the column of the smallest singular
+ * value is flipped when det <= 0): always a proper rotation; S = 0 -> identity. One thread per matrix, double precision inside. */
+int gsr_kabsch_rotations(int n, const float* S, float* R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

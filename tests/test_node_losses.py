@@ -1,0 +1,136 @@
+"""The SC-GS node regularisers of the dynamic mapping loop (slam/deform_model.py) against fixtures recorded from the reference's own
+utils/deform_utils.py (cal_connectivity_from_points, estimate_rotation, cal_arap_error) and ControlNodeWarp.arap_loss / elastic_loss
+(tests/golden/make_golden_node_losses.py). CPU: the tensor programs with the rotation solver replaced by torch.svd (the product path has
+no CPU rotation solver); GPU: the product path (HIP k-NN, gsr_kabsch_rotations, HIP RBF weights)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "4dgs-slam_amd"))
+G = np.load(os.path.join(HERE, "golden", "golden_node_losses.npz"))
+
+
+def _svd_rotations(S):
+    """Test stand-in for gsr_kabsch_rotations on CPU: the same definition through torch.svd."""
+    shape, S = S.shape, S.reshape(-1, 3, 3)
+    U, sig, V = torch.svd(S)
+    R = V @ U.transpose(-1, -2)
+    flip = torch.det(R) <= 0
+    if flip.any():
+        Um = U.clone()
+        cols = torch.argmin(sig[flip], dim=-1)
+        idx = torch.nonzero(flip, as_tuple=False).flatten()
+        Um[idx, :, cols] *= -1
+        R[idx] = V[idx] @ Um[idx].transpose(-1, -2)
+    return R.reshape(shape)
+
+
+def _dense(ii, jj, nn, Nv, K=10):
+    nn_idx = torch.zeros((Nv, K), dtype=torch.int64)
+    keep = torch.zeros((Nv, K), dtype=torch.bool)
+    nn_idx[ii, nn] = torch.as_tensor(jj)
+    keep[ii, nn] = True
+    return nn_idx, keep
+
+
+def test_arap_error_and_its_gradient_match_the_reference():
+    from slam.deform_model import arap_error
+    seq = torch.tensor(G["arap_nodes_seq"], requires_grad=True)
+    nn_idx, keep = _dense(G["conn_ii"], G["conn_jj"], G["conn_nn"], seq.shape[1])
+    err = arap_error(seq, nn_idx, keep, rotations=_svd_rotations)
+    err.backward()
+    assert abs(float(err.detach()) - float(G["arap_error"])) <= 2e-5 * abs(float(G["arap_error"]))
+    np.testing.assert_allclose(seq.grad.numpy(), G["arap_grad"], rtol=2e-4, atol=2e-6)
+    # batched form: two copies give the same numbers per leading index
+    both = arap_error(torch.stack([seq.detach(), seq.detach()]), torch.stack([nn_idx, nn_idx]), torch.stack([keep, keep]), rotations=_svd_rotations)
+    assert both.shape == (2,) and torch.allclose(both, err.detach().expand(2), rtol=1e-6)
+
+
+def test_estimate_rotation_matches_the_reference():
+    from slam.deform_model import edge_matrix, estimate_rotation
+    seq = torch.tensor(G["arap_nodes_seq"])
+    nn_idx, keep = _dense(G["conn_ii"], G["conn_jj"], G["conn_nn"], seq.shape[1])
+    E0, E2 = edge_matrix(seq[0], nn_idx, keep), edge_matrix(seq[2], nn_idx, keep)
+    S = torch.einsum("nka,nk,nkb->nab", E0, keep.float(), E2)
+    np.testing.assert_allclose(S.numpy(), G["rot_S"], rtol=1e-5, atol=1e-7)
+    R = estimate_rotation(E0, E2, keep.float(), rotations=_svd_rotations)
+    np.testing.assert_allclose(R.numpy(), G["rot_R"], atol=2e-5)
+    assert int(G["rot_n_reflections"]) > 0
+    np.testing.assert_allclose(_svd_rotations(torch.tensor(G["rot_S_random"])).numpy(), G["rot_R_random"], atol=2e-5)
+
+
+def _motion(times, amp):
+    t = torch.tensor(np.asarray(times, np.float32))[None, :, None]
+    return amp[:, None, :] * torch.sin(9.0 * t + torch.tensor(G["motion_phase"])[:, None, :])
+
+
+def test_elastic_error_matches_the_reference_given_its_neighbours():
+    """elastic_loss' own expression on the recorded motion; the RBF neighbour weights are the GPU test's business (they come from the HIP
+    cal_nn_weight, golden-tested on its own): here they are rebuilt with the reference's formula (time_utils.py:1000-1011)."""
+    from slam.deform_model import elastic_error
+    nodes = torch.tensor(G["warp_nodes"])
+    d = ((nodes[:, None] - nodes[None]) ** 2).sum(-1)
+    nn_dist, nn_idx = torch.topk(d, 3, dim=-1, largest=False, sorted=True)
+    radius, nw = torch.exp(torch.tensor(G["warp_radius_raw"])), torch.sigmoid(torch.tensor(G["warp_weight_raw"]))
+    w = torch.exp(-nn_dist / (2 * radius[nn_idx] ** 2)) * nw[nn_idx][..., 0] + 1e-7
+    w = w / w.sum(-1, keepdim=True)
+    amp = torch.tensor(G["motion_amp"], requires_grad=True)
+    nodes_t = nodes[:, None, :] + _motion(G["elastic_t"], amp)
+    np.testing.assert_allclose(_motion(G["elastic_t"], amp).detach().numpy(), G["elastic_d_xyz"], atol=1e-6)
+    val = elastic_error(nodes_t, w[:, 1:], nn_idx[:, 1:])
+    val.backward()
+    assert abs(float(val) - float(G["elastic_value"])) <= 1e-4 * abs(float(G["elastic_value"]))
+    np.testing.assert_allclose(amp.grad.numpy(), G["elastic_grad_amp"], rtol=2e-3, atol=1e-5)
+
+
+def test_loss_time_samples_follow_the_reference_draws():
+    from slam.deform_model import draw_loss_times
+    torch.manual_seed(5)
+    plan = draw_loss_times(0.4, 0.25, 4, 0.2)
+    np.testing.assert_allclose(plan["arap"], G["arap4_t"], atol=1e-6)          # the reference's arap_loss(t=0.4, delta_t=0.25, t_samp_num=4) after manual_seed(5)
+    assert len(plan["elastic"]) == 8 and all(0.4 - 0.2 <= x <= 0.4 + 0.2 for x in plan["elastic"])
+    torch.manual_seed(5)
+    te = 0.55 + 0.2 * (float(torch.rand(())) - 0.5)
+    np.testing.assert_allclose((torch.rand(8) * 0.2 + te - 0.1).numpy(), G["elastic_t"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_kabsch_kernel_matches_the_reference_rotations():
+    from slam.deform_model import kabsch_rotations
+    for a, b in (("rot_S", "rot_R"), ("rot_S_random", "rot_R_random")):
+        R = kabsch_rotations(torch.tensor(G[a], device="cuda"))
+        np.testing.assert_allclose(R.cpu().numpy(), G[b], atol=2e-5)
+    Z = kabsch_rotations(torch.zeros((3, 3, 3), device="cuda"))
+    assert torch.equal(Z, torch.eye(3, device="cuda").expand(3, 3, 3))
+    R = kabsch_rotations(torch.randn(4, 5, 3, 3, device="cuda"))                      # leading dimensions; proper rotations
+    assert R.shape == (4, 5, 3, 3) and torch.allclose(torch.det(R), torch.ones(4, 5, device="cuda"), atol=1e-5)
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3, device="cuda").expand(4, 5, 3, 3), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_node_regularisers_product_path_matches_the_reference():
+    """ControlNodes.arap_loss / elastic_loss through the HIP k-NN, the HIP rotations and the HIP RBF weights, on the recorded motion and
+    the recorded time samples: values and gradients of the reference's ControlNodeWarp.arap_loss / elastic_loss."""
+    from slam.deform_model import ControlNodes, connectivity_from_points
+    pts = torch.tensor(G["conn_points"], device="cuda")
+    nn_idx, keep = connectivity_from_points(pts, K=10)
+    want_idx, want_keep = _dense(G["conn_ii"], G["conn_jj"], G["conn_nn"], pts.shape[0])
+    assert torch.equal(keep.cpu(), want_keep) and torch.equal(nn_idx.cpu()[want_keep], want_idx[want_keep])
+    cn = ControlNodes(node_num=64, device="cuda")
+    cn.nodes = torch.nn.Parameter(torch.tensor(G["warp_nodes"], device="cuda"))
+    cn._node_radius = torch.nn.Parameter(torch.tensor(G["warp_radius_raw"], device="cuda"))
+    cn._node_weight = torch.nn.Parameter(torch.tensor(G["warp_weight_raw"], device="cuda"))
+    phase = torch.tensor(G["motion_phase"], device="cuda")
+    for name, fn in (("arap4", cn.arap_loss), ("arap2", cn.arap_loss), ("elastic", cn.elastic_loss)):
+        amp = torch.tensor(G["motion_amp"], device="cuda", requires_grad=True)
+        cn.node_deform = lambda t, key=None, amp=amp: {"d_xyz": amp * torch.sin(9.0 * t + phase)}      # the recorded stand-in for the node MLP
+        val = fn([float(x) for x in G[name + "_t"]])
+        val.backward()
+        assert abs(float(val.detach()) - float(G[name + "_value"])) <= 3e-4 * abs(float(G[name + "_value"])), (name, float(val.detach()), float(G[name + "_value"]))
+        np.testing.assert_allclose(amp.grad.cpu().numpy(), G[name + "_grad_amp"], rtol=5e-3, atol=2e-5 * np.abs(G[name + "_grad_amp"]).max())
+        if name == "elastic":
+            np.testing.assert_allclose(cn._node_radius.grad.cpu().numpy(), G["elastic_grad_radius_raw"], rtol=5e-3, atol=1e-6)
