@@ -4,8 +4,9 @@ deform_model.py DeformModel, utils/time_utils.py ControlNodeWarp :788-1300) that
 ``optimizer``. The per-Gaussian half (K nearest nodes, RBF weights, blend and all chain rules) is the HIP kernel set behind
 ``control_nodes.node_blend`` (include/control_nodes.h); the per-NODE half is a small time-conditioned MLP (O(512) rows, torch).
 
-Reduced on purpose: no hash-grid encoders, no node densification / pruning, no hyper-coordinates -- the shipped SLAM configuration
-does not switch them on (arguments.py defaults) and the loops never call them."""
+The network is the reference's DeformNetwork for the shipped flags (8 x 256, 10 + 10 frequencies, local frame); not built: hash-grid
+encoders, node densification / pruning, hyper-coordinates, skinning -- the shipped SLAM configuration does not switch them on
+(arguments.py:107-125) and the loops never call them."""
 import math
 
 import torch
@@ -125,59 +126,105 @@ def draw_loss_times(t, arap_delta, arap_samples, elastic_delta, elastic_samples=
     return {"arap": arap, "elastic": elastic}
 
 
-class ControlNodes(nn.Module):
-    def __init__(self, node_num=512, K=3, hidden=128, depth=4, t_multires=6, x_multires=6, d_rot_as_res=True, device="cuda"):
+class NodeNetwork(nn.Module):
+    """DeformNetwork (utils/time_utils.py:327-470) as ControlNodeWarp builds it with the shipped flags (arguments.py:107-125: is_blender
+    False -> 10 time frequencies, 10 position frequencies, D = 8 layers of W = 256 with the embedding re-injected after layer 4,
+    local_frame True, no opacity / colour heads). Same attribute names as the reference, so its state_dict loads."""
+
+    def __init__(self, D=8, W=256, multires=10, t_multires=10, local_frame=True):
         super().__init__()
-        self.K, self.max_nodes, self.d_rot_as_res = K, node_num, d_rot_as_res
-        self.t_multires, self.x_multires = t_multires, x_multires
+        self.D, self.W, self.multires, self.t_multires, self.local_frame = D, W, multires, t_multires, local_frame
+        self.skips = [D // 2]
+        self.input_ch = 3 * (1 + 2 * multires) + (1 + 2 * t_multires)
+        self.linear = nn.ModuleList([nn.Linear(self.input_ch, W)] +
+                                    [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W) for i in range(D - 1)])
+        self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation = nn.Linear(W, 3), nn.Linear(W, 3), nn.Linear(W, 4)
+        if local_frame:
+            self.local_rotation = nn.Linear(W, 4)
+            nn.init.normal_(self.local_rotation.weight, mean=0, std=1e-4)
+            nn.init.zeros_(self.local_rotation.bias)
+        for layer in self.linear:                                                    # :390-392
+            nn.init.kaiming_uniform_(layer.weight, mode="fan_in", nonlinearity="relu")
+            nn.init.zeros_(layer.bias)
+        nn.init.normal_(self.gaussian_warp.weight, mean=0, std=1e-5)                 # :394-399: (almost) the identity deformation at start
+        nn.init.normal_(self.gaussian_scaling.weight, mean=0, std=1e-8)
+        nn.init.normal_(self.gaussian_rotation.weight, mean=0, std=1e-5)
+        for head in (self.gaussian_warp, self.gaussian_scaling, self.gaussian_rotation):
+            nn.init.zeros_(head.bias)
+
+    def forward(self, x, t):
+        """x [N,3], t [N,1] -> {d_xyz, d_rotation, d_scaling, local_rotation} (:428-470)."""
+        emb = torch.cat([_embed(x, self.multires), _embed(t, self.t_multires)], -1)
+        return self.from_embedding(emb)
+
+    def from_embedding(self, emb):
+        h = emb
+        for i, layer in enumerate(self.linear):
+            h = torch.relu(layer(h))
+            if i in self.skips:
+                h = torch.cat([emb, h], -1)
+        out = {"d_xyz": self.gaussian_warp(h), "d_rotation": self.gaussian_rotation(h), "d_scaling": self.gaussian_scaling(h), "d_opacity": None,
+               "d_color": None}
+        if self.local_frame:
+            out["local_rotation"] = self.local_rotation(h)
+        return out
+
+
+class ControlNodes(nn.Module):
+    """ControlNodeWarp (utils/time_utils.py:788-1300) for the shipped flags: K = 3 nearest of up to 512 nodes, RBF weights with learnt
+    radius and node weight, local-frame translation, residual rotation."""
+
+    def __init__(self, node_num=512, K=3, d_rot_as_res=True, local_frame=True, device="cuda", D=8, W=256):
+        super().__init__()
+        self.K, self.max_nodes, self.d_rot_as_res, self.local_frame = K, node_num, d_rot_as_res, local_frame
         self.device = torch.device(device)
-        in_ch = 3 * (1 + 2 * x_multires) + (1 + 2 * t_multires)
-        layers, c = [], in_ch
-        for _ in range(depth):
-            layers += [nn.Linear(c, hidden), nn.ReLU(inplace=True)]
-            c = hidden
-        self.trunk = nn.Sequential(*layers).to(self.device)
-        self.head = nn.Linear(hidden, 10).to(self.device)           # d_xyz 3 | d_rotation 4 | d_scaling 3
-        nn.init.zeros_(self.head.weight)                             # identity deformation at start (time_utils.py:401-404 normal_(1e-5))
-        nn.init.zeros_(self.head.bias)
+        self.network = NodeNetwork(D=D, W=W, local_frame=local_frame).to(self.device)
         self.nodes = nn.Parameter(torch.zeros(0, 3, device=self.device))
         self._node_radius = nn.Parameter(torch.zeros(0, device=self.device))
         self._node_weight = nn.Parameter(torch.zeros(0, 1, device=self.device))
         self.reg_loss = 0.0
         self.inited = False
-        self._batch = None            # {time_key: [M,10] network output} of the current iteration (begin_iteration)
+        self._batch = None            # {time_key: network outputs [M, .]} of the current iteration (begin_iteration)
         self._graph = None
 
     node_num = property(lambda s: s.nodes.shape[0])
 
+    def trainable_parameters(self):
+        """:844-853 (with_node_weight): the network and the node tensors as two groups."""
+        return [{"params": list(self.network.parameters()), "name": "deform"},
+                {"params": [self.nodes, self._node_radius, self._node_weight], "name": "nodes"}]
+
+    @staticmethod
+    def _initial_radius(init_pcl, n, device):
+        """log(0.1 * scene range + 1e-7) for every node, scene range = max - min over ALL coordinates of the seeding points (:929,:941-945)."""
+        scene_range = init_pcl.max() - init_pcl.min()
+        return torch.log(0.1 * scene_range + 1e-7) * torch.ones(n, dtype=torch.float32, device=device)
+
     @torch.no_grad()
     def init(self, init_pcl, **_):
-        """ControlNodeWarp.init (:904-945): nodes by farthest-point sampling of the dynamic points, radius from the node spacing."""
-        idx = farthest_point_sample(init_pcl.detach(), self.max_nodes)
-        self.nodes = nn.Parameter(init_pcl.detach()[idx].clone())
-        self._reset_radius()
+        """ControlNodeWarp.init (:904-951): every point becomes a node while there are fewer points than the node budget, else
+        farthest-point sampling; radius from the scene range, node weights 0."""
+        pts = init_pcl.detach().float()
+        if self.max_nodes > pts.shape[0]:
+            nodes = pts.clone()
+        else:
+            nodes = pts[farthest_point_sample(pts, self.max_nodes)].clone()
+        self.nodes = nn.Parameter(nodes)
+        self._node_radius = nn.Parameter(self._initial_radius(pts, nodes.shape[0], self.device))
+        self._node_weight = nn.Parameter(torch.zeros(nodes.shape[0], 1, device=self.device))
         self.inited = True
 
     @torch.no_grad()
-    def extend_node(self, init_pcl, **_):
-        """:947-973: add nodes for new dynamic points up to the budget."""
-        room = self.max_nodes - self.node_num
-        if room <= 0 or init_pcl.shape[0] == 0:
-            return
-        idx = farthest_point_sample(init_pcl.detach(), room)
-        self.nodes = nn.Parameter(torch.cat([self.nodes.detach(), init_pcl.detach()[idx]], 0))
-        self._reset_radius()
-
-    def _reset_radius(self):
-        M = self.node_num
-        if M > 1:
-            kk = min(M - 1, 3)
-            d = control_nodes.knn_points(self.nodes.detach()[None], self.nodes.detach()[None], K=kk + 1).dists[0, :, 1:]
-            r = torch.sqrt(d.mean(-1).clamp_min(1e-8))
-        else:
-            r = torch.full((M,), 0.1, device=self.device)
-        self._node_radius = nn.Parameter(torch.log(r))                # exp() activation, :893-895
-        self._node_weight = nn.Parameter(torch.zeros(M, 1, device=self.device))     # sigmoid() activation, :897-898
+    def extend_node(self, init_pcl, sample_number=250, **_):
+        """extend_node (:953-981) + DeformModel.extend_node_from_point (deform_model.py:71-95): new dynamic points add nodes -- all of them
+        while they are fewer than the current node count, else `sample_number` by farthest-point sampling (that branch of the reference
+        dereferences an unset variable; the radius rule of the other branch is used for it here). Returns the new (nodes, radius, weight)
+        rows; the caller appends them and extends the optimizer state."""
+        pts = init_pcl.detach().float()
+        if pts.shape[0] == 0:
+            return None
+        new_nodes = pts.clone() if self.node_num > pts.shape[0] else pts[farthest_point_sample(pts, sample_number)].clone()
+        return new_nodes, self._initial_radius(pts, new_nodes.shape[0], self.device), torch.zeros(new_nodes.shape[0], 1, device=self.device)
 
     def expand_time(self, t):
         """:975-979."""
@@ -192,13 +239,14 @@ class ControlNodes(nn.Module):
         if not keys or self.node_num == 0:
             self._batch = None
             return
-        M = self.node_num
+        M, net = self.node_num, self.network
         tt = torch.tensor(keys, dtype=torch.float32, device=self.device)[:, None]
-        xe = _embed(self.nodes.detach(), self.x_multires)
-        te = _embed(tt, self.t_multires)
-        inp = torch.cat([xe[None].expand(len(keys), M, -1), te[:, None].expand(len(keys), M, -1)], -1)
-        o = self.head(self.trunk(inp.reshape(len(keys) * M, -1))).reshape(len(keys), M, 10)
-        self._batch = {k: o[i] for i, k in enumerate(keys)}
+        xe = _embed(self.nodes.detach(), net.multires)
+        te = _embed(tt, net.t_multires)
+        emb = torch.cat([xe[None].expand(len(keys), M, -1), te[:, None].expand(len(keys), M, -1)], -1)
+        out = net.from_embedding(emb.reshape(len(keys) * M, -1))
+        out = {k: v.reshape(len(keys), M, -1) for k, v in out.items() if v is not None}
+        self._batch = {key: {k: v[i] for k, v in out.items()} for i, key in enumerate(keys)}
         self._graph = None
 
     def end_iteration(self):
@@ -206,18 +254,19 @@ class ControlNodes(nn.Module):
         self._graph = None
 
     def node_deform(self, t, key=None):
-        """:1038-1051: per-node translation / rotation / scale at time t [M,1] (key: the host-side value of t, see begin_iteration)."""
+        """:1038-1051: per-node translation / rotation / scale (/ local rotation) at time t [M,1] (key: the host-side value of t, see
+        begin_iteration)."""
         o = self._batch.get(time_key(key)) if (key is not None and self._batch is not None) else None
         if o is None:
-            h = self.trunk(torch.cat([_embed(self.nodes.detach(), self.x_multires), _embed(t, self.t_multires)], -1))
-            o = self.head(h)
-        return {"d_xyz": o[:, :3], "d_rotation": o[:, 3:7], "d_scaling": o[:, 7:10]}
+            o = self.network(self.nodes.detach(), t)
+        return o
 
     def forward(self, x, t, motion_mask=None, t_key=None, **_):
         """:1192-1258."""
         na = self.node_deform(t, t_key)
         out = control_nodes.node_blend(x, motion_mask, self.nodes, self._node_radius, self._node_weight, na["d_xyz"], na["d_rotation"],
-                                       na["d_scaling"], None, K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
+                                       na["d_scaling"], na.get("local_rotation") if self.local_frame else None, K=min(self.K, self.node_num),
+                                       d_rot_as_res=self.d_rot_as_res, raw=True)
         return {"d_xyz": out["d_xyz"], "d_rotation": out["d_rotation"], "d_scaling": out["d_scaling"], "d_opacity": None, "d_color": None}
 
     def node_positions(self, times):
@@ -265,25 +314,45 @@ class ControlNodes(nn.Module):
 
 
 class DeformModel:
-    """gaussian_splatting/scene/deform_model.py:1-118: holder of the node warp + its optimizer."""
+    """gaussian_splatting/scene/deform_model.py:20-118: holder of the node warp + its optimizer."""
 
-    def __init__(self, K=3, node_num=512, d_rot_as_res=True, lr=1e-3, device="cuda", **_):
-        self.deform = ControlNodes(node_num=node_num, K=K, d_rot_as_res=d_rot_as_res, device=device)
-        self.lr = lr
+    def __init__(self, K=3, node_num=512, d_rot_as_res=True, local_frame=True, lr=None, device="cuda", position_lr_init=0.00016, deform_lr_scale=1.0, **_):
+        self.deform = ControlNodes(node_num=node_num, K=K, d_rot_as_res=d_rot_as_res, local_frame=local_frame, device=device)
+        self.spatial_lr_scale = 5
+        # train_setting (:34-42): Adam(eps 1e-15) at position_lr_init * 5 * deform_lr_scale for both groups; the SLAM loops never call
+        # update_learning_rate, so the rate stays there (arguments.py:127,138)
+        self.lr = position_lr_init * self.spatial_lr_scale * deform_lr_scale if lr is None else lr
         self.optimizer = None
         self.reg_loss = 0.0
 
     def train_setting(self, *_):
-        ps = [p for p in self.deform.parameters()]
-        self.optimizer = torch.optim.Adam(ps, lr=self.lr, eps=1e-15)
+        groups = [{"params": g["params"], "lr": self.lr, "name": g["name"]} for g in self.deform.trainable_parameters()]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
     def step(self, x, time_input, iteration=0, feature=None, motion_mask=None, camera_center=None, time_interval=None, **kw):
-        """deform_model.py:59-70."""
+        """deform_model.py:32-33."""
         return self.deform(x, time_input, motion_mask=motion_mask, t_key=kw.get("t_key"))
 
     def extend_node_from_point(self, init_pcl, **kw):
-        if not self.deform.inited:
-            self.deform.init(init_pcl)
-        else:
-            self.deform.extend_node(init_pcl)
-        self.train_setting()
+        """:71-95: first call initialises the nodes; later calls append the new rows to the three node tensors and extend their Adam
+        moments with zeros."""
+        d = self.deform
+        if not d.inited:
+            d.init(init_pcl)
+            self.train_setting()
+            return
+        new = d.extend_node(init_pcl)
+        if new is None:
+            return
+        names = ("nodes", "_node_radius", "_node_weight")
+        group = next(g for g in self.optimizer.param_groups if g["name"] == "nodes")
+        for i, (name, ext) in enumerate(zip(names, new)):
+            old = group["params"][i]
+            st = self.optimizer.state.pop(old, None)
+            p = nn.Parameter(torch.cat((old.detach(), ext.to(old.dtype)), dim=0).requires_grad_(True))
+            if st is not None and "exp_avg" in st:
+                st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext, dtype=old.dtype)), dim=0)
+                st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext, dtype=old.dtype)), dim=0)
+                self.optimizer.state[p] = st
+            group["params"][i] = p
+            setattr(d, name, p)

@@ -133,5 +133,30 @@ for name, call in (("arap4", lambda: w.arap_loss(t=torch.tensor([0.4]), delta_t=
     if name == "elastic":
         g_r = w._node_radius.grad
         out["elastic_grad_radius_raw"] = g_r.numpy().copy() if g_r is not None else np.zeros(Mw, np.float32)
+# ---- DeformNetwork (time_utils.py:327-470) with the shipped flags, at width 32 to keep the fixture small -----------------------------------
+torch.manual_seed(11)
+net = T.DeformNetwork(is_blender=False, local_frame=True, W=32)
+with torch.no_grad():                        # heads away from their near-zero initialisation, so that every output is exercised
+    for head in (net.gaussian_warp, net.gaussian_scaling, net.gaussian_rotation, net.local_rotation):
+        head.weight.normal_(std=0.2)
+        head.bias.normal_(std=0.1)
+for k, v in net.state_dict().items():
+    out["net_" + k] = v.numpy()
+xn = torch.tensor(rng.uniform(-0.5, 0.5, size=(37, 3)).astype(np.float32), requires_grad=True)
+tn = torch.tensor(rng.uniform(0, 1, size=(37, 1)).astype(np.float32))
+res = net(xn, tn)
+(res["d_xyz"].sum() + 2 * res["d_rotation"].sum() + 3 * res["d_scaling"].sum() + 4 * res["local_rotation"].sum()).backward()
+out["net_x"], out["net_t"] = xn.detach().numpy(), tn.numpy()
+for k in ("d_xyz", "d_rotation", "d_scaling", "local_rotation"):
+    out["net_out_" + k] = res[k].detach().numpy()
+out["net_grad_first_layer"] = net.linear[0].weight.grad.numpy()
+out["net_input_ch"], out["net_skips"] = np.int64(net.input_ch), np.asarray(net.skips)
+# the default construction: initialisation statistics and sizes
+torch.manual_seed(12)
+full = T.DeformNetwork(is_blender=False, local_frame=True)
+out["net_full_shapes"] = np.asarray([list(p.shape) + [0] * (2 - p.dim()) for p in full.state_dict().values()])
+out["net_full_names"] = np.asarray(list(full.state_dict().keys()))
+out["net_full_head_std"] = np.asarray([float(full.gaussian_warp.weight.std()), float(full.gaussian_scaling.weight.std()),
+                                       float(full.gaussian_rotation.weight.std()), float(full.local_rotation.weight.std())])
 np.savez_compressed(os.path.join(HERE, "golden_node_losses.npz"), **out)
 print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})

@@ -134,3 +134,47 @@ def test_node_regularisers_product_path_matches_the_reference():
         np.testing.assert_allclose(amp.grad.cpu().numpy(), G[name + "_grad_amp"], rtol=5e-3, atol=2e-5 * np.abs(G[name + "_grad_amp"]).max())
         if name == "elastic":
             np.testing.assert_allclose(cn._node_radius.grad.cpu().numpy(), G["elastic_grad_radius_raw"], rtol=5e-3, atol=1e-6)
+
+
+def test_node_network_is_the_reference_deform_network():
+    """slam.deform_model.NodeNetwork against the reference's DeformNetwork(is_blender=False, local_frame=True): the reference's state_dict
+    loads by name, outputs and a weight gradient match; the default construction has the reference's layer shapes and head
+    initialisation scales."""
+    from slam.deform_model import NodeNetwork
+    net = NodeNetwork(W=32)
+    sd = {k[4:]: torch.tensor(G[k]) for k in G.files if k.startswith("net_") and "." in k}
+    net.load_state_dict(sd, strict=True)
+    assert net.input_ch == int(G["net_input_ch"]) and list(net.skips) == list(G["net_skips"])
+    out = net(torch.tensor(G["net_x"]), torch.tensor(G["net_t"]))
+    for k in ("d_xyz", "d_rotation", "d_scaling", "local_rotation"):
+        np.testing.assert_allclose(out[k].detach().numpy(), G["net_out_" + k], rtol=2e-5, atol=2e-6)
+    (out["d_xyz"].sum() + 2 * out["d_rotation"].sum() + 3 * out["d_scaling"].sum() + 4 * out["local_rotation"].sum()).backward()
+    np.testing.assert_allclose(net.linear[0].weight.grad.numpy(), G["net_grad_first_layer"], rtol=2e-4, atol=2e-6)
+    torch.manual_seed(12)
+    full = NodeNetwork()
+    names = list(full.state_dict().keys())
+    assert names == [str(n) for n in G["net_full_names"]]
+    shapes = [list(p.shape) + [0] * (2 - p.dim()) for p in full.state_dict().values()]
+    assert shapes == G["net_full_shapes"].tolist()
+    std = [float(full.gaussian_warp.weight.std()), float(full.gaussian_scaling.weight.std()), float(full.gaussian_rotation.weight.std()),
+           float(full.local_rotation.weight.std())]
+    np.testing.assert_allclose(std, G["net_full_head_std"], rtol=0.2)
+
+
+def test_node_initialisation_rules():
+    """ControlNodeWarp.init (:904-951) / extend_node (:953-981): all points while fewer than the budget, radius log(0.1 * range + 1e-7)."""
+    from slam.deform_model import ControlNodes, DeformModel
+    pts = torch.tensor(np.random.default_rng(3).uniform(-0.4, 0.7, size=(40, 3)).astype(np.float32))
+    cn = ControlNodes(node_num=64, device="cpu", W=16)
+    cn.init(pts)
+    assert cn.node_num == 40 and torch.equal(cn.nodes.detach(), pts)
+    want = float(torch.log(0.1 * (pts.max() - pts.min()) + 1e-7))
+    assert torch.allclose(cn._node_radius.detach(), torch.full((40,), want)) and float(cn._node_weight.abs().sum()) == 0.0
+    dm = DeformModel(node_num=64, device="cpu")
+    dm.deform = ControlNodes(node_num=64, device="cpu", W=16)
+    dm.extend_node_from_point(pts)
+    assert abs(dm.lr - 0.00016 * 5) < 1e-12 and [g["name"] for g in dm.optimizer.param_groups] == ["deform", "nodes"]
+    more = pts[:7] + 0.05
+    dm.extend_node_from_point(more)                                     # fewer new points than nodes: all of them are appended
+    assert dm.deform.node_num == 47 and dm.deform._node_radius.shape == (47,) and dm.deform._node_weight.shape == (47, 1)
+    assert dm.optimizer.param_groups[1]["params"][0] is dm.deform.nodes
