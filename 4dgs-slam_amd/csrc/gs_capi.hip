@@ -1399,7 +1399,7 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
     a.p[3] = s->exposure_b; a.g[3] = s->g_exposure_b; a.n[3] = 1; a.lr[3] = s->lr_exposure;
     a.exp_avg = s->exp_avg; a.exp_avg_sq = s->exp_avg_sq; a.step = s->step; a.beta1 = s->beta1; a.beta2 = s->beta2; a.eps = s->eps;
     a.R = s->R; a.T = s->T; a.proj = s->projmatrix; a.view = s->viewmatrix; a.full = s->full_proj; a.campos = s->campos;
-    a.converged = s->converged; a.thr = s->converged_threshold; a.do_pose = s->do_pose;
+    a.converged = s->converged; a.thr = s->converged_threshold; a.do_pose = s->do_pose; a.latch = s->latch;
     hipLaunchKernelGGL(camera_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;

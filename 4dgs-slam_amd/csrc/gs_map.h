@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) densify_apply_kernel(DensifyArgs a)
 struct CameraStepArgs {
     float* p[4]; const float* g[4]; int n[4]; float lr[4];
     float* exp_avg; float* exp_avg_sq; float* step; float beta1, beta2, eps;
-    float* R; float* T; const float* proj; float* view; float* full; float* campos; int* converged; float thr; int do_pose;
+    float* R; float* T; const float* proj; float* view; float* full; float* campos; int* converged; float thr; int do_pose; int latch;
 };
 
 __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* C)
@@ -155,6 +155,8 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
 
 __global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a)
 {
+    if (a.latch && a.converged && a.converged[0]) return;      // converged earlier in this frame's loop: the reference has left the loop by now
+
     const int lane = threadIdx.x;
     // (1) Adam, torch.optim.Adam single-tensor arithmetic (bias corrections in double like torch's _single_tensor_adam)
     bool any_grad = false;

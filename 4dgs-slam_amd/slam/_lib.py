@@ -18,7 +18,7 @@ class CameraStep(C.Structure):          # gsr_camera_step
                 ("exp_avg", _vp), ("exp_avg_sq", _vp), ("step", _vp),
                 ("lr_rot", _f), ("lr_trans", _f), ("lr_exposure", _f), ("beta1", _f), ("beta2", _f), ("eps", _f),
                 ("R", _vp), ("T", _vp), ("projmatrix", _vp), ("viewmatrix", _vp), ("full_proj", _vp), ("campos", _vp),
-                ("converged", _vp), ("converged_threshold", _f), ("do_pose", _i)]
+                ("converged", _vp), ("converged_threshold", _f), ("do_pose", _i), ("latch", _i)]
 
 
 COPY, STATE, XYZ, SCALE = 0, 1, 2, 3

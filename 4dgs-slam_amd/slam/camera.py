@@ -157,7 +157,7 @@ class Camera(nn.Module):
         self._T.copy_(torch.as_tensor(t, dtype=torch.float32).to(self.device))
         self.refresh_matrices()
 
-    def _step_desc(self, grads, lrs, do_pose, threshold):
+    def _step_desc(self, grads, lrs, do_pose, threshold, latch=False):
         d = _lib.CameraStep()
         ptr = lambda t: None if t is None else t.data_ptr()
         d.rot_delta, d.trans_delta = ptr(self.cam_rot_delta), ptr(self.cam_trans_delta)
@@ -171,6 +171,7 @@ class Camera(nn.Module):
         d.R, d.T, d.projmatrix = self._R.data_ptr(), self._T.data_ptr(), self.projection_matrix.data_ptr()
         d.viewmatrix, d.full_proj, d.campos = self._view.data_ptr(), self._full.data_ptr(), self._campos.data_ptr()
         d.converged, d.converged_threshold, d.do_pose = self._converged.data_ptr(), float(threshold), int(do_pose)
+        d.latch = int(bool(latch))
         return d
 
     def refresh_matrices(self):
@@ -181,18 +182,20 @@ class Camera(nn.Module):
     def reset_pose_optimizer(self):
         """A fresh torch.optim.Adam per tracked frame / per keyframe window (utils/slam_frontend.py:376, slam_backend.py:992)."""
         self._adam.zero_()
+        self._converged.zero_()
 
     @torch.no_grad()
-    def pose_step(self, lr_rot, lr_trans, lr_exposure=0.01, optimize_pose=True, optimize_exposure=True, converged_threshold=1e-4):
+    def pose_step(self, lr_rot, lr_trans, lr_exposure=0.01, optimize_pose=True, optimize_exposure=True, converged_threshold=1e-4, latch=False):
         """pose_optimizer.step() + zero_grad() + update_pose(viewpoint) of the tracking / mapping loops (utils/slam_frontend.py:434-440,
         utils/slam_backend.py:748-755) in ONE launch; the gradients are read from .grad and cleared. Returns nothing: read
-        ``converged()`` when the host needs the flag (that is the only synchronisation)."""
+        ``converged()`` when the host needs the flag (that is the only synchronisation). latch=True (tracking): once the flag is set, further
+        steps of the same frame do nothing, so polling it every few iterations ends at the pose the reference's immediate break leaves."""
         g = {}
         if optimize_pose and self.cam_rot_delta.grad is not None and self.cam_trans_delta.grad is not None:
             g["rot"], g["trans"] = self.cam_rot_delta.grad, self.cam_trans_delta.grad
         if optimize_exposure and self.exposure_a.grad is not None and self.exposure_b.grad is not None:
             g["a"], g["b"] = self.exposure_a.grad, self.exposure_b.grad
-        d = self._step_desc(g, (float(lr_rot), float(lr_trans), float(lr_exposure)), optimize_pose, converged_threshold)
+        d = self._step_desc(g, (float(lr_rot), float(lr_trans), float(lr_exposure)), optimize_pose, converged_threshold, latch)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gsr_camera_step_launch(C.byref(d), _lib.stream(self.device)), "gsr_camera_step_launch")
         for p in (self.cam_rot_delta, self.cam_trans_delta, self.exposure_a, self.exposure_b):

@@ -151,7 +151,7 @@ class FrontEnd:
             image, depth, opacity = render_pkg["render"], render_pkg["depth"], render_pkg["opacity"]
             loss_tracking = slam_losses.get_loss_tracking(self.config, image, depth, opacity, viewpoint, rm_dynamic=True, mask=None)
             loss_tracking.backward()
-            viewpoint.pose_step(lr["cam_rot_delta"], lr["cam_trans_delta"], 0.01)      # step + zero_grad + update_pose, :434-440
+            viewpoint.pose_step(lr["cam_rot_delta"], lr["cam_trans_delta"], 0.01, latch=True)      # step + zero_grad + update_pose, :434-440
             self.gaussians.optimizer.zero_grad(set_to_none=True)
             if (tracking_itr + 1) % self.converge_check_every == 0 and viewpoint.converged():
                 break

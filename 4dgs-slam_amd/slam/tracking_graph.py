@@ -98,7 +98,7 @@ class TrackingGraph:
         loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], self.gt_image, self.gt_depth, self.w_rgb, self.w_dep, c.exposure_a,
                                             c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95, compute_value=False)
         loss.backward()
-        c.pose_step(*self.lrs)
+        c.pose_step(*self.lrs, latch=True)
         if not self.direct and self.gaussians.optimizer is not None:
             self.gaussians.optimizer.zero_grad(set_to_none=True)
         return pkg

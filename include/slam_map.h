@@ -88,6 +88,9 @@ typedef struct gsr_camera_step {
     int* converged;       /* [1] */
     float converged_threshold;
     int do_pose;
+    int latch;            /* 1: a launch that finds *converged already set does nothing. The tracking loop breaks as soon as update_pose
+                             reports convergence (utils/slam_frontend.py:441-442); a host that polls the flag only every few iterations
+                             (or replays a hipGraph) gets the same final pose this way. The caller clears *converged per frame. */
 } gsr_camera_step;
 int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
 

@@ -353,3 +353,28 @@ def test_edge_mask_kernels_match_the_tensor_program():
         mism = int((got != want).sum())
         assert mism <= 1e-3 * H * W, (H, W, mism)
         assert 0.2 < float(got.float().mean()) / max(float(want.float().mean()), 1e-9) < 5.0
+
+
+def test_camera_step_convergence_latch():
+    """pose_step(latch=True): once update_pose has reported convergence, further steps of the same frame change nothing -- the pose is the
+    one the reference's immediate `break` (utils/slam_frontend.py:441-442) leaves, however rarely the host polls the flag."""
+    from slam.camera import Camera, getProjectionMatrix2
+    proj = getProjectionMatrix2(0.01, 100.0, 160.0, 120.0, 260.0, 265.0, 320, 240).transpose(0, 1)
+    cam = Camera(3, None, None, torch.eye(4), proj, 260.0, 265.0, 160.0, 120.0, 1.0, 0.8, 240, 320, 0.0)
+    cam.reset_pose_optimizer()
+    g = lambda s: torch.full((3,), s, device="cuda")
+    cam.cam_rot_delta.grad, cam.cam_trans_delta.grad = g(1.0), g(1.0)
+    cam.pose_step(0.003, 0.001, 0.01, optimize_exposure=False, latch=True)          # a real step: not converged
+    assert not cam.converged()
+    cam.cam_rot_delta.grad, cam.cam_trans_delta.grad = g(1.0), g(1.0)
+    cam.pose_step(1e-9, 1e-9, 0.01, optimize_exposure=False, latch=True)            # a vanishing step: |tau| < 1e-4 -> converged
+    assert cam.converged()
+    R1, T1, adam1 = cam.R.clone(), cam.T.clone(), cam._adam.clone()
+    cam.cam_rot_delta.grad, cam.cam_trans_delta.grad = g(5.0), g(-5.0)
+    cam.pose_step(0.5, 0.5, 0.01, optimize_exposure=False, latch=True)              # latched: nothing moves, not even Adam's moments
+    assert torch.equal(cam.R, R1) and torch.equal(cam.T, T1) and torch.equal(cam._adam, adam1) and cam.converged()
+    cam.cam_rot_delta.grad, cam.cam_trans_delta.grad = g(5.0), g(-5.0)
+    cam.pose_step(0.5, 0.5, 0.01, optimize_exposure=False, latch=False)             # without the latch the step is taken
+    assert not torch.equal(cam.T, T1)
+    cam.reset_pose_optimizer()                                                       # next frame: flag cleared
+    assert not cam.converged()
