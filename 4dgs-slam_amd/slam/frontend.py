@@ -134,9 +134,9 @@ class FrontEnd:
         prev = self.cameras[cur_frame_idx - self.use_every_n_frames]
         viewpoint.update_RT(prev.R, prev.T)
         if self.use_tracking_graph and self._track_with_graph(viewpoint):
+            self.median_depth = get_median_depth(self._tgraph.pkg["depth"], self._tgraph.pkg["opacity"])      # the last tracking iteration's render, :461
             with torch.no_grad():
                 render_pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False)
-            self.median_depth = get_median_depth(render_pkg["depth"], render_pkg["opacity"])
             return render_pkg
         self.graph_stats["eager_frames"] += 1
         lr = self.config["Training"]["lr"]

@@ -117,7 +117,8 @@ class TrackingGraph:
         torch.cuda.current_stream(c.device).wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.iteration()
+            self.pkg = self.iteration()          # static outputs: after a replay they hold that iteration's render (depth / opacity of the
+                                                 # last tracking iteration feed get_median_depth, utils/slam_frontend.py:461)
         _C.set_option("lazy", self._lazy_before)      # the flag only matters while host code runs: replays never consult it
         with torch.no_grad():
             for dst, src in zip((c._R, c._T, c._adam, c.exposure_a, c.exposure_b), keep):
