@@ -80,12 +80,22 @@ class BackEnd:
         g = self.gaussians
         if not (self.dynamic_model and g.deform_init and g.dyn_rows().shape[0] > 0):
             return None, None, None
-        time_input = g.deform.deform.expand_time(viewpoint.fid)
+        # inside a mapping iteration (ControlNodes.begin_iteration .. end_iteration) neither the nodes nor the Gaussians move: the deltas of
+        # a time are blended once and shared by the view's render and the flow terms of the views whose partner it is
+        nodes = g.deform.deform
+        cache = getattr(self, "_delta_cache", None) if (train and nodes._batch is not None) else None
+        key = round(float(viewpoint.time), 7)
+        if cache is not None and key in cache:
+            return cache[key]
+        time_input = nodes.expand_time(viewpoint.fid)
         ctx = torch.enable_grad() if train else torch.no_grad()
         with ctx:
             d = g.deform.step(g.get_dygs_xyz.detach(), time_input, iteration=0, feature=None, motion_mask=g.motion_mask,
                               camera_center=viewpoint.camera_center, time_interval=g.time_interval, t_key=viewpoint.time)
-        return d["d_xyz"], d["d_scaling"], d["d_rotation"]
+        out = (d["d_xyz"], d["d_scaling"], d["d_rotation"])
+        if cache is not None:
+            cache[key] = out
+        return out
 
     def _render(self, viewpoint, deltas):
         dx, ds, dr = deltas
@@ -288,6 +298,7 @@ class BackEnd:
                     if closest is not None:
                         times.append(self.viewpoints[closest].time)
                 nodes.begin_iteration(times)
+                self._delta_cache = {}
                 # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
                 nv = len(views)
                 wts = torch.tensor([1e-3] * nv + [1e-4] * len(extra), dtype=torch.float32, device=self.device)
@@ -313,6 +324,7 @@ class BackEnd:
             total.backward()
             if use_net:
                 g.deform.deform.end_iteration()
+                self._delta_cache = None
             gaussian_split = False
             with torch.no_grad():
                 self.occ_aware_visibility = {}
