@@ -178,3 +178,27 @@ def test_node_initialisation_rules():
     dm.extend_node_from_point(more)                                     # fewer new points than nodes: all of them are appended
     assert dm.deform.node_num == 47 and dm.deform._node_radius.shape == (47,) and dm.deform._node_weight.shape == (47, 1)
     assert dm.optimizer.param_groups[1]["params"][0] is dm.deform.nodes
+
+
+def test_batched_node_network_evaluation_equals_the_direct_one():
+    """ControlNodes.begin_iteration: all time samples of an iteration through the network as ONE batch; every later node_deform(t, key)
+    lookup must return what the direct evaluation at that time returns, and the lookups must vanish at end_iteration."""
+    from slam.deform_model import ControlNodes
+    torch.manual_seed(0)
+    cn = ControlNodes(node_num=32, device="cpu", W=16)
+    cn.init(torch.randn(20, 3) * 0.3)
+    with torch.no_grad():
+        for head in (cn.network.gaussian_warp, cn.network.gaussian_rotation, cn.network.gaussian_scaling, cn.network.local_rotation):
+            head.weight.normal_(std=0.3)
+    times = [0.1, 0.25, 0.1 + 0.05, 0.9]
+    cn.begin_iteration(times + [0.25])                       # duplicates collapse
+    assert len(cn._batch) == 4
+    for tv in times:
+        a = cn.node_deform(torch.full((cn.node_num, 1), tv), tv)
+        b = cn.network(cn.nodes.detach(), torch.full((cn.node_num, 1), tv))
+        for k in ("d_xyz", "d_rotation", "d_scaling", "local_rotation"):
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), k
+    pos = cn.node_positions(times)
+    assert pos.shape == (cn.node_num, 4, 3)
+    cn.end_iteration()
+    assert cn._batch is None
