@@ -1,5 +1,5 @@
 cd /root/repo
-python tools/dev_parity.py 2>&1 | grep -v amdgpu.ids | python -c "
+python tests/dev/dev_parity.py 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     try:
