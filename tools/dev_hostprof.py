@@ -1,6 +1,6 @@
 import sys, os, cProfile, pstats, io
-sys.path.insert(0, "/root/repo/tests")
-from util import *
+sys.path.insert(0, "/root/repo/4dgs-slam_amd")
+from synthetic_scene import make_camera, make_gaussians, make_cotangents, keyframe_pose
 import numpy as np, torch
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 cam = make_camera(640, 480); P = int(os.environ.get("P", 10000))
