@@ -37,125 +37,152 @@ struct GeomBwdArgs {
     RawInputs raw; RawGrads rawg;
 };
 
+#if GSR_FWD_TIMING
+__device__ uint32_t g_geo_timing[8 * 4 * 8192];
+#define GEO_TICK(k) do { if (blockIdx.x < 8192 && (threadIdx.x & 63) == 0) g_geo_timing[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEO_TICK(k)
+#endif
+template <bool RAW>
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 {
-    if (a.header[HDR_FLAGS] & FLAG_OVERFLOW) return;   // lazy forward pass that outgrew its buffer: there are no instance slots to sum
+    // RAW: the fused-prologue mode (raw.xyz != nullptr). As a template parameter the plain instantiation is straight-line code: with the
+    // runtime test every parameter load sat in its own uniform branch with its own s_waitcnt behind it.
+    RawInputs R = a.raw; RawGrads RG = a.rawg;
+    if constexpr (!RAW) { R = RawInputs{}; RG = RawGrads{}; }
+    GEO_TICK(0);
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id();
     const bool in_range = idx < a.P;
     const size_t i = (size_t)(in_range ? idx : 0);
-    const bool visible = in_range && a.radii[idx] > 0;   // backward.cu:163,443
-    const size_t o = in_range && a.raw.xyz ? raw_row(a.raw, i) : i;   // row of the parameter-gradient outputs (raw mode with a mask: the selected row)
-    // ---- gather: sum this Gaussian's per-instance slots ----------------------------------------------------------
-    // Instance ids are a global running count over Gaussians, so the 256 Gaussians of a block own ONE contiguous range of
-    // slots [U0, U1). It is streamed through LDS in coalesced chunks (the whole block loads, every thread then picks its own
-    // instances out of LDS, in ascending instance order => fixed summation order). Per-thread scattered 16-byte loads from
-    // global memory made this kernel latency-bound before (3 waves per SIMD cannot hide them).
-    // Double buffered: while the block sums chunk c out of one LDS buffer, the global loads of chunk c + 1 are in flight (held in
-    // registers) and go to the other buffer afterwards -- one barrier per chunk, loads overlapped with the sums. With the single
-    // buffer (load, barrier, sum, barrier) the kernel ran at 0.7 TB/s once a block owned several chunks (SLAM-shaped maps: 20-70
-    // instances per Gaussian; profiles/r02_long_lists.json).
-    constexpr int CH = 256;                      // instances per chunk: 256 x 48 B = 12 KiB per buffer
-    __shared__ float4 s_slot[2][CH * 3];
-    __shared__ uint32_t s_range[2];
-    const uint32_t cnt = visible ? a.tiles_touched[idx] : 0u;
+    // ---- level 1 of the loads: what decides everything else ------------------------------------------------------------------
+    const int radius = in_range ? a.radii[idx] : 0;
+    const uint32_t touched = in_range ? a.tiles_touched[idx] : 0u;
     const uint32_t incl = in_range ? a.point_offsets[idx] : 0u;
-    const uint32_t u0 = incl - (in_range ? a.tiles_touched[idx] : 0u);
-    if (threadIdx.x == 0) s_range[0] = u0;
-    const int last = min(a.P - 1, blockIdx.x * 256 + 255);
-    if (idx == last) s_range[1] = incl;
-    __syncthreads();
-    const uint32_t U0 = s_range[0], U1 = s_range[1];
-    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], 0).partials;   // partials do not depend on the sorted capacity
+    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], a.header[HDR_CAP_SORTED],
+                                                        (size_t)(((a.W + TILE_X - 1) / TILE_X) * ((a.H + TILE_Y - 1) / TILE_Y))).partials;
+    if (a.header[HDR_FLAGS] & FLAG_OVERFLOW) return;     // lazy forward pass that outgrew its buffer: there are no instance slots to sum (tested
+                                                         // HERE, behind the level-1 loads: in front of them it was a global latency of its own)
+    const bool visible = radius > 0;                     // backward.cu:163,443
+    const size_t o = in_range && RAW ? raw_row(R, i) : i;   // row of the parameter-gradient outputs (raw mode with a mask: the selected row)
+    const uint32_t cnt = visible ? touched : 0u;
+    const uint32_t u0 = incl - touched;                  // instance ids are a global running count over Gaussians: this one owns [u0, u0 + cnt)
+    // ---- level 2: EVERYTHING else this thread will read is requested here, in one go: the first chunk of the wave's instance slots,
+    // the Gaussian's parameters and (accumulate mode) what the caller's gradient buffers hold. Round 2 fetched the parameters where the
+    // chain rules first touched them and staged the slots per BLOCK (global -> registers -> LDS -> block barrier -> per-thread ds_read
+    // loops, 3.3 chunks per block at config #2): eight exposed global latencies and four block barriers in a kernel whose 782 blocks
+    // (3 waves per SIMD at 200k Gaussians) have nothing else to cover them with -- 38 000 cycles per wave, 14 500 of them in the chunk loop.
+    // Now the staging is per WAVE: the 64 Gaussians of a wave own one contiguous slot range [W0, W1) (instance ids are a running count),
+    // which the wave copies through a private 6 KiB LDS window in fully coalesced 16-byte loads (128 slots per step, the next step's
+    // loads in flight while the lanes sum the current one) -- no block barrier anywhere in the kernel.
+    constexpr uint32_t COOP = 16;                        // Gaussians with more instances are summed by the whole wave (below)
+    constexpr uint32_t WCH = 128;                        // slots per step of a wave's window
+    __shared__ float4 s_slot[4][WCH * 3];
+    const bool coop = cnt > COOP;
+    const uint32_t ser = coop ? 0u : cnt;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t W0 = __builtin_amdgcn_readfirstlane(u0);                                   // lane 0 of a wave that has any lane in range is in range
+    const uint32_t W1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, min(63, a.P - 1 - (blockIdx.x * 256 + wv * 64)));
+    const bool any_ser = __any(ser > 0);
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-    float4 nx[3];
-    auto fetch = [&](uint32_t c0) {             // this thread's three float4 of the chunk starting at instance c0
-        const uint32_t n3 = min((uint32_t)CH, U1 - c0) * 3u;
+    float4 nx[6];
+    auto fetch_window = [&](uint32_t c0) {      // this lane's six float4 of the window that starts at slot c0
+        const uint32_t n3 = min(WCH, W1 - c0) * 3u;
         const float4* src = partials + (size_t)c0 * 3;
 #pragma unroll
-        for (int j = 0; j < 3; j++) nx[j] = threadIdx.x + 256u * j < n3 ? src[threadIdx.x + 256u * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 6; j++) nx[j] = (uint32_t)lane + 64u * j < n3 ? src[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto stash = [&](int b) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) s_slot[b][threadIdx.x + 256 * j] = nx[j];
-    };
-    // Blocks whose Gaussians own many instances each (SLAM-shaped maps: 20-70 tiles per Gaussian) do not go through the LDS chunks:
-    // a 256-slot chunk then belongs to three or four Gaussians, i.e. three or four threads walk it one dependent ds_read after the
-    // other while the rest of the block waits (0.5 TB/s at 72 instances per Gaussian). Instead every wave takes its 64 Gaussians in
-    // turn and sums one Gaussian's slots with all lanes (lane l: slots l, l + 64, ...; coalesced 48-byte rows), reduces the ten
-    // values with the transposed butterfly of gs_device.h and hands the totals to the owning lane. Fixed order => still bit-reproducible.
-    constexpr uint32_t HEAVY_SLOTS_PER_GAUSSIAN = 8;
-    const bool heavy_block = (U1 - U0) > 256u * HEAVY_SLOTS_PER_GAUSSIAN;     // uniform
-    if (heavy_block) {
-        const int lane = lane_id();
-        const WaveSelectMasks wsm = wave_select_masks();
-        for (int h = 0; h < 64; h++) {
-            const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
-            if (hc == 0) continue;
-            float s0 = 0.f, s5 = 0.f;
-            f2v a12 = {0.f, 0.f}, a34 = {0.f, 0.f}, a67 = {0.f, 0.f}, a89 = {0.f, 0.f};
-            for (uint32_t k = (uint32_t)lane; k < hc; k += 64) {
-                const float4* sl = partials + (size_t)(hu + k) * 3;
-                const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
-                s0 += v0.x; a12 += f2v{v0.y, v0.z}; a34 += f2v{v0.w, v1.x}; s5 += v1.y; a67 += f2v{v1.z, v1.w}; a89 += f2v{v2.x, v2.y};
-            }
-            unsigned long long dummy_proc = 0; uint32_t dummy_addr;
-            const float tot = wave_sum10_transposed(wsm, s0, a12, a34, s5, a67, a89, dummy_proc, 0, 0u, 0, dummy_addr);
-            // lanes holding total k (wave_sum10_slot_of_lane): 0 -> 2, 1 -> 0, 2 -> 1, 3 -> 32, 4 -> 33, 5 -> 34, 6 -> 16, 7 -> 17, 8 -> 48, 9 -> 49
-            const int ti = __float_as_int(tot);
-            const float t0 = __int_as_float(__builtin_amdgcn_readlane(ti, 2)), t1 = __int_as_float(__builtin_amdgcn_readlane(ti, 0));
-            const float t2 = __int_as_float(__builtin_amdgcn_readlane(ti, 1)), t3 = __int_as_float(__builtin_amdgcn_readlane(ti, 32));
-            const float t4 = __int_as_float(__builtin_amdgcn_readlane(ti, 33)), t5 = __int_as_float(__builtin_amdgcn_readlane(ti, 34));
-            const float t6 = __int_as_float(__builtin_amdgcn_readlane(ti, 16)), t7 = __int_as_float(__builtin_amdgcn_readlane(ti, 17));
-            const float t8 = __int_as_float(__builtin_amdgcn_readlane(ti, 48)), t9 = __int_as_float(__builtin_amdgcn_readlane(ti, 49));
-            if (lane == h) { g_m2x = t0; g_m2y = t1; g_cx = t2; g_cy = t3; g_cw = t4; g_op = t5; g_r = t6; g_g = t7; g_b = t8; g_d = t9; }
-        }
-    }
-    if (!heavy_block && U0 < U1) { fetch(U0); stash(0); }
-    __syncthreads();
-    int buf = 0;
-    for (uint32_t c0 = U0; !heavy_block && c0 < U1; c0 += CH, buf ^= 1) {
-        const bool more = c0 + CH < U1;
-        if (more) fetch(c0 + CH);
-        const uint32_t nch = min((uint32_t)CH, U1 - c0);
-        const uint32_t lo = max(u0, c0), hi = min(u0 + cnt, c0 + nch);
-        for (uint32_t u = lo; u < hi; u++) {
-            const float4* sl = s_slot[buf] + (u - c0) * 3;
-            const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
-            g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
-            g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
-            g_b += v2.x; g_d += v2.y;
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-    }
-    // Accumulate mode (GeomBwdArgs::accumulate): what the caller's gradient buffers hold for this Gaussian is loaded HERE -- after the
-    // instance slots are summed (14 more live registers during that loop cost occupancy), before the chain rules -- so the loads are in
-    // flight while the chain rules are evaluated (a read-modify-write at the end of the kernel
-    // left their latency exposed: 116 -> 140 us at 2 M Gaussians). old_*: zero when the mode is off. add_separately: the
-    // addition must not be contracted into the expression that produced the gradient (autograd's accumulation rounds it first).
-    const bool scale1 = a.raw.xyz && a.raw.scale_dim == 1;
+    const bool wave_has_slots = any_ser && W0 < W1;                 // uniform per wave (lanes beyond P take part in the window copy)
+    if (wave_has_slots) fetch_window(W0);
+    const bool scale1 = RAW && R.scale_dim == 1;
+    const bool want_cov_chain = !a.pose_only && (a.scales != nullptr || RAW);
+    f3 mean = mk3(0.f, 0.f, 0.f);
+    float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, s3[3] = {0.f, 0.f, 0.f};
+    uint32_t clamp_bits = 0;
+    // Accumulate mode (GeomBwdArgs::accumulate): the old values ride with the other loads; add_separately: the addition must not be
+    // contracted into the expression that produced the gradient (autograd's accumulation rounds it first). old_*: zero when the mode is off.
     float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
-    float* const dc_out = a.raw.xyz ? (a.rawg.f_dc ? a.rawg.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
-    if (a.accumulate && visible && !a.pose_only) {
+    float* const dc_out = RAW ? (RG.f_dc ? RG.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
+    if (visible) {
+        mean = load_mean(a.means3D, R, i);
 #pragma unroll
-        for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
-        old_o = a.dL_dopacity[o];
-        if (a.dL_dscale) {
-            if (scale1) old_s[0] = a.dL_dscale[o];
-            else {
+        for (int k = 0; k < 6; k++) cov6[k] = a.cov3Ds[6 * i + k];
+        if (want_cov_chain) { load_rot(a.rotations, R, i, q4); load_scale(a.scales, R, i, s3); }
+        clamp_bits = a.clamped[idx];
+        if (a.accumulate && !a.pose_only) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) old_s[k] = a.dL_dscale[3 * o + k];
+            for (int k = 0; k < 3; k++) old_m[k] = a.dL_dmean3D[3 * o + k];
+            old_o = a.dL_dopacity[o];
+            if (a.dL_dscale) {
+                if (scale1) old_s[0] = a.dL_dscale[o];
+                else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) old_s[k] = a.dL_dscale[3 * o + k];
+                }
+            }
+            if (a.dL_drot) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) old_r[k] = a.dL_drot[4 * o + k];
+            }
+            if (dc_out) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) old_c[k] = dc_out[k];
             }
         }
-        if (a.dL_drot) {
+    }
+    GEO_TICK(1);
+    if (wave_has_slots) {
+        float4* const win = s_slot[wv];
+        for (uint32_t c0 = W0; c0 < W1; c0 += WCH) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) old_r[k] = a.dL_drot[4 * o + k];
-        }
-        if (dc_out) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) old_c[k] = dc_out[k];
+            for (int j = 0; j < 6; j++) win[lane + 64 * j] = nx[j];
+            if (c0 + WCH < W1) fetch_window(c0 + WCH);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the window is wave-private: DS operations of one wave execute in order
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t lo = max(u0, c0), hi = min(u0 + ser, min(c0 + WCH, W1));
+            for (uint32_t u = lo; u < hi; u++) {                       // ascending instance order: the order every earlier revision summed in
+                const float4* sl = win + (u - c0) * 3;
+                const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
+                g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
+                g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
+                g_b += v2.x; g_d += v2.y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    GEO_TICK(2);
+    // Gaussians that own many instances (SLAM-shaped maps: 20-70 tiles per Gaussian) are summed by the whole wave, one after the other:
+    // lane l takes slots l, l + 64, ... (coalesced 48-byte rows), the ten values are reduced with the transposed butterfly of
+    // gs_device.h and the totals handed to the owning lane. The rule depends on the Gaussian alone => still bit-reproducible.
+    {
+        unsigned long long cm = __ballot(coop);
+        if (cm) {
+            const WaveSelectMasks wsm = wave_select_masks();
+            while (cm) {
+                const int h = pop_lowest_bit(cm);
+                const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
+                float s0 = 0.f, s5 = 0.f;
+                f2v a12 = {0.f, 0.f}, a34 = {0.f, 0.f}, a67 = {0.f, 0.f}, a89 = {0.f, 0.f};
+                for (uint32_t k = (uint32_t)lane; k < hc; k += 64) {
+                    const float4* sl = partials + (size_t)(hu + k) * 3;
+                    const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
+                    s0 += v0.x; a12 += f2v{v0.y, v0.z}; a34 += f2v{v0.w, v1.x}; s5 += v1.y; a67 += f2v{v1.z, v1.w}; a89 += f2v{v2.x, v2.y};
+                }
+                unsigned long long dummy_proc = 0; uint32_t dummy_addr;
+                const float tot = wave_sum10_transposed(wsm, s0, a12, a34, s5, a67, a89, dummy_proc, 0, 0u, 0, dummy_addr);
+                // lanes holding total k (wave_sum10_slot_of_lane): 0 -> 2, 1 -> 0, 2 -> 1, 3 -> 32, 4 -> 33, 5 -> 34, 6 -> 16, 7 -> 17, 8 -> 48, 9 -> 49
+                const int ti = __float_as_int(tot);
+                const float t0 = __int_as_float(__builtin_amdgcn_readlane(ti, 2)), t1 = __int_as_float(__builtin_amdgcn_readlane(ti, 0));
+                const float t2 = __int_as_float(__builtin_amdgcn_readlane(ti, 1)), t3 = __int_as_float(__builtin_amdgcn_readlane(ti, 32));
+                const float t4 = __int_as_float(__builtin_amdgcn_readlane(ti, 33)), t5 = __int_as_float(__builtin_amdgcn_readlane(ti, 34));
+                const float t6 = __int_as_float(__builtin_amdgcn_readlane(ti, 16)), t7 = __int_as_float(__builtin_amdgcn_readlane(ti, 17));
+                const float t8 = __int_as_float(__builtin_amdgcn_readlane(ti, 48)), t9 = __int_as_float(__builtin_amdgcn_readlane(ti, 49));
+                if (lane == h) { g_m2x = t0; g_m2y = t1; g_cx = t2; g_cy = t3; g_cw = t4; g_op = t5; g_r = t6; g_g = t7; g_b = t8; g_d = t9; }
+            }
+        }
+    }
+    GEO_TICK(3);
 
     if (in_range) {
         a.dL_dmean2D[3 * o] = g_m2x; a.dL_dmean2D[3 * o + 1] = g_m2y; a.dL_dmean2D[3 * o + 2] = 0.f;   // z never written, Q14
@@ -167,18 +194,14 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 
     float dmean[3] = {0.f, 0.f, 0.f}, dtau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool flow = a.raw.xyz && a.raw.flow_proj1;
-    const bool has_sh = flow ? false : (a.raw.xyz ? (a.rawg.f_dc != nullptr || a.pose_only != 0) : (a.shs != nullptr && (a.dL_dsh != nullptr || a.pose_only != 0)));   // pose-only: the view-direction term of dL_dtau still needs the SH pass
-    const ShOut dsh = a.raw.xyz ? ShOut{a.rawg.f_dc + 3 * o, a.rawg.f_rest ? a.rawg.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0}
+    const bool flow = RAW && R.flow_proj1;
+    const bool has_sh = flow ? false : (RAW ? (RG.f_dc != nullptr || a.pose_only != 0) : (a.shs != nullptr && (a.dL_dsh != nullptr || a.pose_only != 0)));   // pose-only: the view-direction term of dL_dtau still needs the SH pass
+    const ShOut dsh = RAW ? ShOut{RG.f_dc + 3 * o, RG.f_rest ? RG.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0}
                                 : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0};
     if (!visible) {
         if (has_sh && in_range && !a.accumulate && !a.pose_only) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
     } else {
         const float* vm = a.viewmatrix;
-        const f3 mean = load_mean(a.means3D, a.raw, i);
-        float cov6[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) cov6[k] = a.cov3Ds[6 * i + k];
 
         // ---- backward.cu:171-346: conic -> cov2D -> (cov3D, t) ----
         const Cov2D cv = cov2d_eval(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov6, vm);
@@ -280,8 +303,8 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 
         // ---- backward.cu:21-145: colour -> SH coefficients and (through the view direction) the mean ----
         if (has_sh) {
-            const ShView sh = sh_view(a.shs, a.raw, i, a.M);
-            const uint32_t cb = a.clamped[idx];
+            const ShView sh = sh_view(a.shs, R, i, a.M);
+            const uint32_t cb = clamp_bits;
             const float dRGB[3] = {(cb & 1u) ? 0.f : g_r, (cb & 2u) ? 0.f : g_g, (cb & 4u) ? 0.f : g_b};   // :32-35
             const f3 dir_orig = mk3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]);
             const float inv = 1.0f / sqrtf(dot3(dir_orig, dir_orig));
@@ -335,10 +358,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         }
 
         // ---- backward.cu:350-413: cov3D -> scale, quaternion (no normalisation backward, Q1) ----
-        if (!a.pose_only && (a.scales != nullptr || a.raw.xyz)) {
-            float q4[4], s3[3];
-            load_rot(a.rotations, a.raw, i, q4);
-            load_scale(a.scales, a.raw, i, s3);
+        if (want_cov_chain) {
             const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
             const float Rq[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                                     {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -363,10 +383,37 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
             drot[3] = 2 * r * (Dm[0][1] - Dm[1][0]) + 2 * x * (Dm[2][0] + Dm[0][2]) + 2 * y * (Dm[1][2] + Dm[2][1]) - 4 * z * (Dm[1][1] + Dm[0][0]);
         }
     }
+    GEO_TICK(4);
+    // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with
+    // torch.sum on [P,6]); the first two levels are folded into this kernel in a fixed order: the wave (transposed butterfly), the
+    // block (four waves through LDS); one row per block, summed by tau_sum_kernel. Folding that last level in as well -- the block
+    // that finishes last, found with a ticket -- was built twice: with an agent-scope release per block (round 2: an L2 write-back on
+    // this multi-XCD part, 100 us) and with write-through row stores + one atomic per block and no fence (round 3: correct, but the
+    // store -> ticket -> row reads chain of the last block is three memory round trips, as long as the second launch it replaces).
+    if (a.tau_partials) {
+        __shared__ float s_tau[4][6];
+        const WaveSelectMasks wsm = wave_select_masks();
+        unsigned long long dummy_proc = 0; uint32_t dummy_addr;
+        const float z = 0.f;
+        const float tot = wave_sum10_transposed(wsm, in_range ? dtau[0] : z, f2v{in_range ? dtau[1] : z, in_range ? dtau[2] : z},
+                                                f2v{in_range ? dtau[3] : z, in_range ? dtau[4] : z}, in_range ? dtau[5] : z, f2v{z, z}, f2v{z, z},
+                                                dummy_proc, 0, 0u, 0, dummy_addr);
+        // lanes holding total k (wave_sum10_slot_of_lane): 0 -> 2, 1 -> 0, 2 -> 1, 3 -> 32, 4 -> 33, 5 -> 34
+        const int wv = threadIdx.x >> 6;
+        if (lane == 2) s_tau[wv][0] = tot;
+        if (lane == 0) s_tau[wv][1] = tot;
+        if (lane == 1) s_tau[wv][2] = tot;
+        if (lane == 32) s_tau[wv][3] = tot;
+        if (lane == 33) s_tau[wv][4] = tot;
+        if (lane == 34) s_tau[wv][5] = tot;
+        __syncthreads();
+        if (threadIdx.x < 6) a.tau_partials[(size_t)blockIdx.x * 6 + threadIdx.x] = (s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + (s_tau[2][threadIdx.x] + s_tau[3][threadIdx.x]);
+    }
+    GEO_TICK(5);
     if (in_range) {
         const bool wr = !a.pose_only && (visible || !a.accumulate);     // accumulate mode leaves the rows of invisible Gaussians alone
         if (wr)
-            a.dL_dopacity[o] = add_separately(old_o, a.raw.xyz ? [&] { const float sg = load_opacity(nullptr, a.raw, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
+            a.dL_dopacity[o] = add_separately(old_o, RAW ? [&] { const float sg = load_opacity(nullptr, R, i); return g_op * sg * (1.0f - sg); }() : g_op);   // raw: through the sigmoid
         if (wr) {
 #pragma unroll
             for (int k = 0; k < 3; k++) a.dL_dmean3D[3 * o + k] = add_separately(old_m[k], dmean[k]);
@@ -375,7 +422,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         for (int k = 0; k < 6; k++) if (a.dL_dcov3D) a.dL_dcov3D[6 * i + k] = dcov[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) if (a.dL_dtau) a.dL_dtau[6 * i + k] = dtau[k];
-        if (!a.raw.xyz) {
+        if (!RAW) {
             if (a.dL_dscale && wr) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) a.dL_dscale[3 * i + k] = add_separately(old_s[k], dscale[k]);
@@ -387,34 +434,34 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
         } else {
             // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
             // effective parameters' gradients of their Gaussian (one Gaussian per slot: plain stores)
-            const int sl = raw_slot(a.raw, o);
+            const int sl = raw_slot(R, o);
             if (sl >= 0 && flow) {
                 // render_flow (gaussian_renderer/__init__.py:262-284): the colour (g_r, g_g) reaches dx through -ndc(.; proj1) and dx2
                 // through +ndc(.; proj2); the position itself is detached on that path (:262), so dL_dmean3D keeps the geometric part only
-                const f3 base = mk3(a.raw.xyz[3 * o], a.raw.xyz[3 * o + 1], a.raw.xyz[3 * o + 2]);
+                const f3 base = mk3(R.xyz[3 * o], R.xyz[3 * o + 1], R.xyz[3 * o + 2]);
                 f3 t1 = base, t2 = base;
-                if (a.raw.dx) { t1.x += a.raw.dx[3 * sl]; t1.y += a.raw.dx[3 * sl + 1]; t1.z += a.raw.dx[3 * sl + 2]; }
-                if (a.raw.flow_dx2) { t2.x += a.raw.flow_dx2[3 * sl]; t2.y += a.raw.flow_dx2[3 * sl + 1]; t2.z += a.raw.flow_dx2[3 * sl + 2]; }
-                const f3 j1 = visible ? flow_ndc_vjp(a.raw.flow_proj1, t1, g_r, g_g) : mk3(0.f, 0.f, 0.f);
-                const f3 j2 = visible ? flow_ndc_vjp(a.raw.flow_proj2, t2, g_r, g_g) : mk3(0.f, 0.f, 0.f);
-                if (a.rawg.ddx2) { a.rawg.ddx2[3 * sl] = j2.x; a.rawg.ddx2[3 * sl + 1] = j2.y; a.rawg.ddx2[3 * sl + 2] = j2.z; }
-                if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0] - j1.x; a.rawg.ddx[3 * sl + 1] = dmean[1] - j1.y; a.rawg.ddx[3 * sl + 2] = dmean[2] - j1.z; }
-                if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
-                if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
+                if (R.dx) { t1.x += R.dx[3 * sl]; t1.y += R.dx[3 * sl + 1]; t1.z += R.dx[3 * sl + 2]; }
+                if (R.flow_dx2) { t2.x += R.flow_dx2[3 * sl]; t2.y += R.flow_dx2[3 * sl + 1]; t2.z += R.flow_dx2[3 * sl + 2]; }
+                const f3 j1 = visible ? flow_ndc_vjp(R.flow_proj1, t1, g_r, g_g) : mk3(0.f, 0.f, 0.f);
+                const f3 j2 = visible ? flow_ndc_vjp(R.flow_proj2, t2, g_r, g_g) : mk3(0.f, 0.f, 0.f);
+                if (RG.ddx2) { RG.ddx2[3 * sl] = j2.x; RG.ddx2[3 * sl + 1] = j2.y; RG.ddx2[3 * sl + 2] = j2.z; }
+                if (RG.ddx) { RG.ddx[3 * sl] = dmean[0] - j1.x; RG.ddx[3 * sl + 1] = dmean[1] - j1.y; RG.ddx[3 * sl + 2] = dmean[2] - j1.z; }
+                if (RG.dds) { RG.dds[3 * sl] = dscale[0]; RG.dds[3 * sl + 1] = dscale[1]; RG.dds[3 * sl + 2] = dscale[2]; }
+                if (RG.ddr) { RG.ddr[4 * sl] = drot[0]; RG.ddr[4 * sl + 1] = drot[1]; RG.ddr[4 * sl + 2] = drot[2]; RG.ddr[4 * sl + 3] = drot[3]; }
             } else if (sl >= 0) {
-                if (a.rawg.ddx) { a.rawg.ddx[3 * sl] = dmean[0]; a.rawg.ddx[3 * sl + 1] = dmean[1]; a.rawg.ddx[3 * sl + 2] = dmean[2]; }
-                if (a.rawg.dds) { a.rawg.dds[3 * sl] = dscale[0]; a.rawg.dds[3 * sl + 1] = dscale[1]; a.rawg.dds[3 * sl + 2] = dscale[2]; }
-                if (a.rawg.ddr) { a.rawg.ddr[4 * sl] = drot[0]; a.rawg.ddr[4 * sl + 1] = drot[1]; a.rawg.ddr[4 * sl + 2] = drot[2]; a.rawg.ddr[4 * sl + 3] = drot[3]; }
+                if (RG.ddx) { RG.ddx[3 * sl] = dmean[0]; RG.ddx[3 * sl + 1] = dmean[1]; RG.ddx[3 * sl + 2] = dmean[2]; }
+                if (RG.dds) { RG.dds[3 * sl] = dscale[0]; RG.dds[3 * sl + 1] = dscale[1]; RG.dds[3 * sl + 2] = dscale[2]; }
+                if (RG.ddr) { RG.ddr[4 * sl] = drot[0]; RG.ddr[4 * sl + 1] = drot[1]; RG.ddr[4 * sl + 2] = drot[2]; RG.ddr[4 * sl + 3] = drot[3]; }
             }
             if (!wr) {
                 // accumulate mode, invisible Gaussian: its parameter-gradient rows stay as they are
-            } else if (a.raw.scale_dim == 1) {
-                a.dL_dscale[o] = add_separately(old_s[0], (dscale[0] + dscale[1] + dscale[2]) * expf(a.raw.log_scales[o]));
+            } else if (R.scale_dim == 1) {
+                a.dL_dscale[o] = add_separately(old_s[0], (dscale[0] + dscale[1] + dscale[2]) * expf(R.log_scales[o]));
             } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = add_separately(old_s[k], dscale[k] * expf(a.raw.log_scales[3 * o + k]));
+                for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = add_separately(old_s[k], dscale[k] * expf(R.log_scales[3 * o + k]));
             }
-            const float ra = a.raw.raw_rot[4 * o], rb = a.raw.raw_rot[4 * o + 1], rc = a.raw.raw_rot[4 * o + 2], rd = a.raw.raw_rot[4 * o + 3];
+            const float ra = R.raw_rot[4 * o], rb = R.raw_rot[4 * o + 1], rc = R.raw_rot[4 * o + 2], rd = R.raw_rot[4 * o + 3];
             const float inv = 1.0f / fmaxf(sqrtf(ra * ra + rb * rb + rc * rc + rd * rd), 1e-12f);
             const float qa = ra * inv, qb = rb * inv, qc = rc * inv, qd = rd * inv;
             const float dotg = qa * drot[0] + qb * drot[1] + qc * drot[2] + qd * drot[3];
@@ -424,24 +471,10 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
             }
         }
     }
-    // The pose gradient is the sum of dL_dtau over all Gaussians (DGR/diff_gaussian_rasterization/__init__.py:152-154 does it with
-    // torch.sum on [P,6]); fold the first level into this kernel: fixed-order wave + block sums, one row per block.
-    if (a.tau_partials) {
-        __shared__ float s_tau[4][6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            float v = in_range ? dtau[k] : 0.f;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane_id() == 0) s_tau[threadIdx.x >> 6][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 6) a.tau_partials[(size_t)blockIdx.x * 6 + threadIdx.x] = (s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + (s_tau[2][threadIdx.x] + s_tau[3][threadIdx.x]);
-    }
+    GEO_TICK(6);
 }
 
-// Second level of the pose-gradient sum: one block, 6 x 64 threads, fixed order. (Folding it into the block of geometry_bwd
-// that finishes last needs an agent-scope release per block -- an L2 write-back on this multi-XCD part -- which cost 100 us.)
+// Last level of the pose-gradient sum: one block, 6 x 64 threads, fixed order.
 __global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
 {
     const int k = threadIdx.x >> 6, lane = lane_id();

@@ -91,9 +91,9 @@ struct ImageState {
         return s;
     }
 };
-static size_t binning_bytes(size_t carve_R, size_t cap_sorted)
+static size_t binning_bytes(size_t carve_R, size_t cap_sorted, size_t ntiles)
 {
-    return (size_t)(carve_binning(nullptr, carve_R, cap_sorted).end - (char*)nullptr) + 256;
+    return (size_t)(carve_binning(nullptr, carve_R, cap_sorted, ntiles).end - (char*)nullptr) + 256;
 }
 template <typename F>
 static size_t required(F&& f)
@@ -236,7 +236,7 @@ size_t gsr_image_buffer_size(int width, int height, int P)
     const size_t T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
     return required([&](char*& p) { ImageState::from(p, (size_t)width * height, T, (size_t)P); });
 }
-size_t gsr_binning_buffer_size(int R_alloc) { return binning_bytes((size_t)R_alloc, (size_t)R_alloc); }
+size_t gsr_binning_buffer_size(int R_alloc) { return binning_bytes((size_t)R_alloc, (size_t)R_alloc, (size_t)65536); }   // sized for frames of up to 65 536 tiles (4096 x 4096 pixels)
 
 int gsr_set_option(const char* name, int value)
 {
@@ -432,7 +432,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     auto enqueue_binning_and_render = [&](char* chunk, size_t carve_R, size_t cap_sorted, bool spec, bool any_padding,
                                           uint32_t longest_list) -> int {
         const bool long_lists = longest_list > (uint32_t)SORT_SMALL_CAP;
-        const BinningPtrs bin = carve_binning(chunk, carve_R, cap_sorted);
+        const BinningPtrs bin = carve_binning(chunk, carve_R, cap_sorted, (size_t)T);
         uint32_t* const chk = spec ? geom.header : nullptr;
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
@@ -480,7 +480,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.rec,
                                background, img.final_T, img.n_contrib, out_color, out_depth,
                                out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
-                               (const uint32_t*)bin.inst_gauss, bin.sorted);
+                               (const uint32_t*)bin.inst_gauss, bin.sorted, (const uint32_t*)img.chunk_base, bin.chunk_info);
         }
         GSR_STAGE("render_fwd");
         return 0;
@@ -488,7 +488,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
 
     char* bchunk = nullptr;
     if (speculate) {
-        bchunk = binning_alloc(binning_user, binning_bytes(cap, cap));
+        bchunk = binning_alloc(binning_user, binning_bytes(cap, cap, (size_t)T));
         if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
         const int rc = enqueue_binning_and_render(bchunk, cap, cap, true, false, cap_tile);
         if (rc) return rc;
@@ -505,12 +505,12 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     if (speculate && !(flg & FLAG_OVERFLOW)) return (int)R;
 
     if (R > 0) {
-        bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, (size_t)R_alloc));
+        bchunk = binning_alloc(binning_user, binning_bytes((size_t)R, (size_t)R_alloc, (size_t)T));
         if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
         const int rc = enqueue_binning_and_render(bchunk, (size_t)R, (size_t)R_alloc, false, R_alloc != R, max_tile_list);
         if (rc) return rc;
     } else {
-        if (!bchunk) bchunk = binning_alloc(binning_user, binning_bytes(0, 0));
+        if (!bchunk) bchunk = binning_alloc(binning_user, binning_bytes(0, 0, (size_t)T));
         if (!bchunk) { g_last_error = "gsr_forward: binning allocation callback returned NULL"; return GSR_ERR_ALLOC; }
         // keep point_offsets defined for debug readers / backward even when nothing is visible
         if (P > 0) GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
@@ -518,7 +518,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
                            geom.rec, background, img.final_T, img.n_contrib, out_color,
                            out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
-                           (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr);
+                           (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -584,7 +584,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         // one block per CHUNK entries of a tile list; sum over tiles of ceil(n / CHUNK) <= R / CHUNK + T, surplus blocks exit
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
         const int grid = R / CHUNK + T;
-        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, img.ranges, img.chunk_base, (const char*)binning_buffer,
+        hipLaunchKernelGGL(render_bwd_kernel, dim3(grid), dim3(RB), 0, stream, T, gx, (const char*)binning_buffer,
                            (const uint32_t*)geom.header, width, height, background, geom.rec,
                            img.final_T, img.final_C, img.n_contrib, dL_dpix, dL_dpix_depth);
     }
@@ -606,7 +606,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (raw) { a.rawg.f_dc = rawg->features_dc; a.rawg.f_rest = rawg->features_rest; a.rawg.ddx = rawg->dx; a.rawg.dds = rawg->ds; a.rawg.ddr = rawg->dr; a.rawg.scale_dim = raw->scale_dim; a.rawg.ddx2 = rawg->dx2; }
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
-        hipLaunchKernelGGL(geometry_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+        if (raw) hipLaunchKernelGGL(geometry_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(geometry_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
         if (dL_dtau_sum)
             hipLaunchKernelGGL(tau_sum_kernel, dim3(1), dim3(384), 0, stream, (P + 255) / 256, geom.tau_partials, dL_dtau_sum);
     }
@@ -705,6 +706,27 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                               dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dtau, nullptr, debug, stream);
 }
 
+#if GSR_FWD_TIMING
+// dev builds only (-DGSR_FWD_TIMING=1): per-wave cycle accounting of the last render_fwd launch, 8 words per (tile, quadrant wave)
+int gsr_debug_fwd_timing(unsigned int* out, int nwords)
+{
+    GSR_HIP_CHECK(hipDeviceSynchronize());
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_timing), (size_t)nwords * sizeof(uint32_t)));
+    return 0;
+}
+int gsr_debug_geo_timing(unsigned int* out, int nwords)
+{
+    GSR_HIP_CHECK(hipDeviceSynchronize());
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_geo_timing), (size_t)nwords * sizeof(uint32_t)));
+    return 0;
+}
+int gsr_debug_bwd_timing(unsigned int* out, int nwords)
+{
+    GSR_HIP_CHECK(hipDeviceSynchronize());
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_timing), (size_t)nwords * sizeof(uint32_t)));
+    return 0;
+}
+#endif
 int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_buffer, const char* binning_buffer,
                          const char* image_buffer, float* depths, float* means2D, float* conic_opacity, float* rgb, float* cov3D,
                          unsigned char* clamped, uint32_t* tiles_touched, uint32_t* point_offsets, float* final_T, uint32_t* n_contrib,
@@ -719,7 +741,7 @@ int gsr_debug_read_state(int P, int R, int width, int height, const char* geom_b
     ImageState img = ImageState::from(ip, N, (size_t)T, 0);
     uint32_t hdr[HDR_WORDS] = {0};
     if (P > 0) GSR_HIP_CHECK(hipMemcpy(hdr, geom.header, sizeof(hdr), hipMemcpyDeviceToHost));
-    const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], hdr[HDR_CAP_SORTED]);
+    const BinningPtrs bin = carve_binning(bp, hdr[HDR_CARVE_R], hdr[HDR_CAP_SORTED], (size_t)T);
 #define D2H(dst, src, bytes) do { if ((dst) && (bytes)) GSR_HIP_CHECK(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost)); } while (0)
     if (P && (depths || means2D || conic_opacity || rgb)) {   // the packed per-Gaussian rows, handed out in the reference's four arrays
         std::vector<TileRec> rows((size_t)P);

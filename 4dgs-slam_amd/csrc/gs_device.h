@@ -174,7 +174,7 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 }
 
 // ---- the binning scratch buffer (the reference's BinningState, rasterizer_impl.h:55-66) --------------------------------
-// inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap] | ckpt, each 256-byte
+// chunk_info | inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap] | ckpt, each 256-byte
 // aligned. ckpt = per-pixel compositing state (T, r, g, b, depth) at every CHUNK-th entry of every tile list, written by the
 // forward tile kernel: with it the backward pass can start anywhere in a list (see render_bwd_kernel).
 // carve_R is the instance count the buffer was LAID OUT for: the exact R when the host waited for it before allocating, or
@@ -182,11 +182,17 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 // so the backward kernels derive their pointers on the device and the host never has to know which of the two it was.
 constexpr int CHUNK = 128;              // entries of a tile list per backward work item
 constexpr int CKPT_FLOATS = 5 * TILE_X * TILE_Y;   // one checkpoint: 5 planes of 256 pixels
-struct BinningPtrs { uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
-__host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted)
+// Work items of render_bwd_kernel: one 16-byte record per CHUNK-entry piece of a tile list, {tile, position of the piece in sorted[],
+// entries in it | bit 16 = more entries follow in the list, list position of its first entry}, written by the forward tile kernel at
+// the index of the backward BLOCK that will take the piece (the XCD banding is applied by the writer). A frame has at most
+// R / CHUNK + tiles pieces.
+struct BinningPtrs { uint4* chunk_info; uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
+__host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted, size_t ntiles)
 {
     BinningPtrs b;
     uintptr_t p = (reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255);
+    b.chunk_info = reinterpret_cast<uint4*>(p);      // FIRST, at an offset that depends on nothing: render_bwd reads its entry without the header
+    p = (p + (cap_sorted / CHUNK + ntiles + 2) * sizeof(uint4) + 255) & ~uintptr_t(255);
     b.inst_gauss = reinterpret_cast<uint32_t*>(p);
     p = (p + carve_R * sizeof(uint32_t) + 255) & ~uintptr_t(255);
     b.partials = reinterpret_cast<float4*>(p);
@@ -339,6 +345,16 @@ __device__ __forceinline__ int xcd_tile_of_block(int b, int ntiles)
     const int xcd = b & 7, k = b >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + k;
+}
+
+// ... and its inverse: the block that xcd_tile_of_block() sends to tile / work item `id`
+__device__ __forceinline__ int xcd_block_of_tile(int id, int ntiles)
+{
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int head = r * (q + 1);
+    if (id < head) return (id % (q + 1)) * 8 + id / (q + 1);
+    const int rest = id - head;
+    return (rest % q) * 8 + r + rest / q;
 }
 
 }  // namespace gsr

@@ -3,6 +3,10 @@
 #pragma once
 #include "gs_device.h"
 
+#ifndef GSR_FUSED_SORT_M
+#define GSR_FUSED_SORT_M 2   // stages per LDS round trip (2^M keys per thread) of the fused sort networks for 256 / 512 keys
+#endif
+
 namespace gsr {
 
 // Gaussians are processed in blocks of GB = 1024 threads. When the tile grid fits in LDS (T <= HIST_LDS_TILES) each block
@@ -673,6 +677,20 @@ __device__ __forceinline__ void bitonic_sort_lds_pow2(PaddedKeys keys, uint32_t 
     }
 }
 
+// the fused sort of render_fwd_kernel (lists of up to 1024 keys, one block per tile, every tile of the frame sorting at the same time):
+// the phase is bound by its chain of dependent LDS round trips, not by bandwidth or issue, so the register-blocked networks (two
+// stages per round trip) are taken from 256 keys on
+__device__ __forceinline__ void bitonic_sort_lds_pow2_fused(PaddedKeys keys, uint32_t npad)
+{
+    switch (npad) {
+        case 1024: bitonic_sort_lds_reg<1024, 2>(keys); break;
+        case 512: bitonic_sort_lds_reg<512, GSR_FUSED_SORT_M>(keys); break;
+        case 256: bitonic_sort_lds_reg<256, GSR_FUSED_SORT_M>(keys); break;
+        case 128: bitonic_sort_lds<128>(keys); break;
+        case 64: bitonic_sort_lds<64>(keys); break;
+        default: bitonic_sort_block<true>(keys, npad); break;   // < 64
+    }
+}
 // Two instantiations: CAP = SORT_SMALL_CAP (8 KiB of LDS: every tile of a 1200-tile frame sorts concurrently) handles the
 // lists of up to 1024 keys; CAP = SORT_LDS_CAP (32 KiB, only 4 blocks per CU) is launched only when some list is longer and
 // handles those (in LDS up to 4096 keys, in global memory beyond). With the 32 KiB variant alone the 1200 blocks of a
@@ -685,16 +703,24 @@ constexpr int SORT_MID_CAP = 2048;     // lists of 1025 .. 2048 keys: a block of
 // search in the other half (keys are unique). Ends with the sorted (gaussian, instance) pairs in global memory.
 template <uint32_t MAXN = 4096, typename KEYS = uint64_t*>
 __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
-                                                 uint2* __restrict__ sorted, KEYS s_keys)
+                                                 uint2* __restrict__ sorted, KEYS s_keys, uint32_t* dbg_ticks = nullptr)
 {
     const uint32_t n = r.y - r.x;
     const uint64_t* seg = keys + r.x;
-    const uint32_t A = n <= 1 ? n : (1u << (31 - __clz((int)n)));
-    const uint32_t B = n - A, Bpad = B ? next_pow2(B) : 0;
+    // lists of up to 64 keys are padded to one power of two (a padded key array wants the second half to start at a multiple of 8)
+    const uint32_t A = n <= 64 ? next_pow2(n) : (1u << (31 - __clz((int)n)));
+    const uint32_t B = n > A ? n - A : 0u, Bpad = B ? max(8u, next_pow2(B)) : 0u;
     for (uint32_t i = threadIdx.x; i < A + Bpad; i += 256) s_keys[i] = i < n ? seg[i] : ~0ull;
     __syncthreads();
-    bitonic_sort_lds_pow2<MAXN>(s_keys, A);
-    if (B) bitonic_sort_lds_pow2<MAXN>(s_keys + A, Bpad);
+    if (dbg_ticks) dbg_ticks[0] = (uint32_t)__builtin_amdgcn_s_memtime();
+    if constexpr (MAXN == 0) {      // render_fwd_kernel's fused sort
+        bitonic_sort_lds_pow2_fused(s_keys, A);
+        if (B) bitonic_sort_lds_pow2_fused(s_keys + A, Bpad);
+    } else {
+        bitonic_sort_lds_pow2<MAXN>(s_keys, A);
+        if (B) bitonic_sort_lds_pow2<MAXN>(s_keys + A, Bpad);
+    }
+    if (dbg_ticks) dbg_ticks[1] = (uint32_t)__builtin_amdgcn_s_memtime();
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint64_t key = s_keys[i];
         const bool in_a = i < A;

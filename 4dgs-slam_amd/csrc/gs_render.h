@@ -17,6 +17,7 @@
 namespace gsr {
 
 constexpr int RB = 256;   // entries per staged batch == threads per block
+constexpr int IDX_STRIDE = 70;   // per (quadrant wave, 64-entry group) index list: 64 rows + 4 the prefetch may touch + the read-ahead of the list itself
 typedef float f2 __attribute__((ext_vector_type(2)));   // arithmetic on f2 lowers to v_pk_{add,mul,fma}_f32: two fp32 ops per issue slot
 
 // Which of the four 8x8 quadrants of tile (tx,ty) can a Gaussian contribute to at all?
@@ -82,6 +83,14 @@ __device__ __forceinline__ int pop_lowest_bit_row16(unsigned long long& m, uint3
     asm volatile("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0\n\tv_lshlrev_b32 %2, 4, %0" : "=&s"(j), "+s"(m), "=v"(row));
     return j;
 }
+// mask ? a : b per lane, as the one VALU instruction it is (opaque to the optimiser: see render_fwd_kernel's pair loop)
+typedef unsigned long long lanemask;
+__device__ __forceinline__ float lane_select(lanemask m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
 template <typename T>
 __device__ __forceinline__ T lds_at(const void* array, uint32_t byte_offset)
 {
@@ -95,6 +104,18 @@ __device__ __forceinline__ unsigned long long lds_mask_uniform(const unsigned lo
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// GSR_FWD_TIMING (dev builds only): per-wave cycle accounting of render_fwd_kernel, read back with gsr_debug_fwd_timing().
+#ifndef GSR_FWD_TIMING
+#define GSR_FWD_TIMING 0
+#endif
+#if GSR_FWD_TIMING
+__device__ uint32_t g_fwd_timing[8 * 4 * 8192];
+__device__ uint32_t g_bwd_timing[8 * 4 * 8192];
+#define FWD_TICK() ((uint32_t)__builtin_amdgcn_s_memtime())
+#define FWD_T(...) __VA_ARGS__
+#else
+#define FWD_T(...)
+#endif
 // ------------------------------------------------------------------------------------------------------------------
 // F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
 // ------------------------------------------------------------------------------------------------------------------
@@ -107,7 +128,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         int* __restrict__ n_touched, float4* __restrict__ final_C,
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
-                                                        uint2* sorted_out)
+                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[3 * RB * sizeof(float4)];
@@ -116,6 +137,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     float4* const s_c = s_b + RB;                            // {r, g, b, depth}: two packed FMAs per blended entry
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
     __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
+    __shared__ __attribute__((aligned(8))) uint32_t s_idx[4][4][IDX_STRIDE];   // [quadrant wave][64-entry group]: LDS row offsets of the entries its mask keeps
 
     const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
@@ -136,14 +158,32 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    if (chunk_info != nullptr) {    // work items of render_bwd_kernel: this tile's CHUNK-entry pieces (gs_device.h)
+        const uint32_t cb = chunk_base[tile], nchunks = chunk_base[ntiles];
+        for (int c = t; c * CHUNK < n; c += RB) {
+            const int cstart = c * CHUNK, m = min(CHUNK, n - cstart);
+            chunk_info[xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)] =
+                make_uint4((uint32_t)tile, range.x + (uint32_t)cstart, (uint32_t)m | (cstart + m < n ? 0x10000u : 0u), (uint32_t)cstart);
+        }
+    }
+    FWD_T(uint32_t tk0 = FWD_TICK(); uint32_t tk_sort = 0, tk_stage = 0, tk_list = 0, tk_pair = 0, tk_wait = 0, n_pairs = 0, n_batches = 0; uint32_t tk_mark = tk0;)
     // keys != nullptr: this block first sorts its own tile list (the staging arrays double as the key buffer) -- one kernel and
     // one GPU drain/fill less per frame than a separate sort launch; lists beyond the LDS capacity were sorted by
     // sort_tiles_kernel<SORT_LDS_CAP, SORT_SMALL_CAP> before.
-    static_assert(3 * RB * sizeof(float4) >= SORT_SMALL_CAP * sizeof(uint64_t), "key buffer aliases the staging arrays");
+    static_assert(3 * RB * sizeof(float4) >= padded_keys_size(SORT_SMALL_CAP) * sizeof(uint64_t), "key buffer aliases the staging arrays");
     if (keys != nullptr && n > 0 && n <= SORT_SMALL_CAP) {
-        sort_tile_in_lds<SORT_SMALL_CAP>(range, keys, inst_gauss, sorted_out, reinterpret_cast<uint64_t*>(s_raw));
+#if GSR_FWD_TIMING
+        uint32_t st[2] = {0, 0};
+        sort_tile_in_lds<0>(range, keys, inst_gauss, sorted_out, PaddedKeys{reinterpret_cast<uint64_t*>(s_raw)}, st);
+        const uint32_t tk_s2 = FWD_TICK();
+        __syncthreads();
+        tk_list = st[0] - tk0; n_batches = st[1] - st[0]; tk_wait = tk_s2 - st[1];      // dev: key load | network | rank + gather + store (reuses three report slots)
+#else
+        sort_tile_in_lds<0>(range, keys, inst_gauss, sorted_out, PaddedKeys{reinterpret_cast<uint64_t*>(s_raw)});
         __syncthreads();                                   // the sorted list (global) and the LDS buffer are reused below
+#endif
     }
+    FWD_T(tk_sort = FWD_TICK() - tk0; tk_mark = FWD_TICK();)
     // Checkpoint of the per-pixel compositing state in front of list entry `boundary` (a multiple of CHUNK): lets the backward
     // pass start at any chunk of the list instead of walking the whole list from its end (render_bwd_kernel). Five coalesced
     // 256-byte stores per wave and CHUNK entries. A wave whose pixels are all saturated stops writing them: the backward
@@ -156,6 +196,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 
     for (int base = 0; base < n; base += RB) {
         const int all_done = __syncthreads_and(thr > 1.0f);       // forward.cu:318-320 (also orders the LDS reuse below)
+        FWD_T(tk_mark = FWD_TICK();)
         {   // flush the previous batch's n_touched increments: one global atomic per (tile, Gaussian), off the hot loop
             const int c = s_nt[t];
             if (c) { atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c); s_nt[t] = 0; }
@@ -189,61 +230,114 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
         // VALU->SALU round trip (measured: 111 -> 86 us), and pixels that are done blend nothing anyway.
         // Per 64-entry group the wave re-votes two things: whether any of its pixels is still unsaturated (else it skips the
         // group), and whether any pixel still has T > 0.5 -- only then can an entry bump n_touched (forward.cu:369-371), and
-        // the loop variant without that bookkeeping is shorter. Every instruction (VALU, SALU, LDS, branch alike) costs this
-        // kernel one 4-cycle issue slot per SIMD, so they are counted alike.
+        // the loop variant without that bookkeeping is shorter.
         // n_touched bookkeeping: the wave visits each entry of the group once, so the count of entry jj is WRITTEN into lane jj
         // of a VGPR (s_bcnt1 + v_writelane) and the 64 counts go to LDS with one ds_add per group.
-        auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int jbase) {
+        //
+        // The pair loop is software-pipelined over a compacted INDEX LIST: only ~3 waves per SIMD exist for a 640x480 frame (4 800
+        // in all), so nothing but the wave itself can cover its LDS latency. Each quadrant wave first turns its four ballot masks
+        // into four lists of LDS row offsets (v_mbcnt ranks, one ds_write per group); the loop is then counted, takes two entries
+        // per trip, and issues the reads of the NEXT trip (rows known from the list, fetched one trip further ahead) before it
+        // evaluates the current one. With the s_ff1 walk the row of the next entry was only known after the SALU pop, and every
+        // pair paid the full ds_read latency in front of its first FMA.
+        FWD_T(tk_stage += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
+        int cnt4[4];
+#pragma unroll
+        for (int sw = 0; sw < 4; sw++) {
+            const unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
+            cnt4[sw] = (int)__popcll(mk);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            uint32_t* const L = &s_idx[wave][sw][0];
+            if ((mk >> lane) & 1ull) L[pos] = (uint32_t)(sw * 64 + lane) * 16u;
+            if (lane < 4) L[cnt4[sw] + lane] = 0u;             // rows the prefetch may touch behind the list's end (never consumed)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // the lists are wave-private: DS operations of one wave execute in order
+        __builtin_amdgcn_wave_barrier();
+        struct Entry { float4 A4; float2 B2; float4 C4; uint32_t row; };
+        auto fetch = [&](uint32_t row) {
+            Entry e;
+            e.A4 = lds_at<float4>(s_a, row);
+            e.B2 = lds_at<float2>(s_b, row);
+            e.C4 = lds_at<float4>(s_c, row);
+            e.row = row;
+            return e;
+        };
+        auto composite = [&](auto COUNT_TOUCHED, unsigned long long m, int sw, int cnt) {
             int counts = 0;
-            uint32_t last_row = ~0u;                       // lds_row16 of the last entry this group blended into the pixel
-            const float4* const ga = s_a + jbase;          // uniform: folds into the reads' constant offsets
-            const float4* const gb = s_b + jbase;
-            const float4* const gc = s_c + jbase;
-            while (m) {
-                uint32_t row;
-                const int jj = pop_lowest_bit_row16(m, row);
-                const float4 A4 = lds_at<float4>(ga, row);
-                const float2 B2 = lds_at<float2>(gb, row);
-                const float4 C4 = lds_at<float4>(gc, row);
+            uint32_t last_row = ~0u;                       // LDS row offset of the last entry this group blended into the pixel
+            const uint32_t* const L = &s_idx[wave][sw][0];
+            auto pair = [&](const Entry& e) {
+                const float4 A4 = e.A4; const float2 B2 = e.B2; const float4 C4 = e.C4;
                 const f2 d = f2{A4.x, A4.y} - pxy;
                 // alpha = o exp(power) = exp2(power log2e + log2 o): the opacity rides in the exponent (one multiply less per pair)
 #if GSR_EXACT_MATH
                 const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                           // forward.cu:345
                 const float alpha = fminf(0.99f, B2.y * exact_exp(pw));                             // :353
-                const bool valid = pw <= 0.0f && alpha >= thr;                                      // :346, :354 and "not done"
+                const lanemask validm = __builtin_amdgcn_ballot_w64(pw <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= thr);   // :346, :354 and "not done"
 #else
                 const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);      // forward.cu:345 (times log2 e) + log2 o
                 const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(pw));                      // :353
-                const bool valid = pw <= B2.y && alpha >= thr;                                      // :346 (power <= 0), :354 and "not done"
+                const lanemask validm = __builtin_amdgcn_ballot_w64(pw <= B2.y) & __builtin_amdgcn_ballot_w64(alpha >= thr);   // :346 (power <= 0), :354 and "not done"
 #endif
+                // lane masks and selects spelled out (v_cmp -> SGPR pair, s_and / s_xor, v_cndmask): left to itself hipcc turns the selects of
+                // the loop's last pair into divergent branches (s_and_saveexec + two blocks)
                 const float test_T = T * (1.0f - alpha);
-                const bool stop = valid && test_T < 0.0001f;                                        // :358-362
-                const bool blend = valid && !stop;
-                thr = stop ? INF : thr;
-                const float w = blend ? alpha * T : 0.0f;
+                const lanemask stopm = validm & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);    // :358-362
+                const lanemask blendm = validm ^ stopm;
+                thr = lane_select(stopm, INF, thr);
+                const float w = lane_select(blendm, alpha * T, 0.0f);
                 acc_rg += f2{C4.x, C4.y} * w;                                                       // :364-367
                 acc_bd += f2{C4.z, C4.w} * w;
-                T = blend ? test_T : T;
-                last_row = blend ? row : last_row;                                                  // `contributor`, :338,:376 (resolved below)
+                T = lane_select(blendm, test_T, T);
+                last_row = __float_as_uint(lane_select(blendm, __uint_as_float(e.row), __uint_as_float(last_row)));   // `contributor`, :338,:376 (resolved below)
                 if (COUNT_TOUCHED.value) {
-                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(test_T > (blend ? 0.5f : INF));   // blend && test_T > 0.5, :369-371
-                    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(counts) : "s"((int)__popcll(tm)), "s"(jj) : "m0");   // two SGPR operands would exceed the constant bus
+                    const int jj = pop_lowest_bit(m);       // the list is in bit order: the mask walk names the same entry
+                    const lanemask tm = blendm & __builtin_amdgcn_ballot_w64(test_T > 0.5f);             // blend && test_T > 0.5, :369-371
+                    counts = lane == jj ? (int)__popcll(tm) : counts;      // plain VALU select: no m0 / v_writelane (whose two scalar operands exceed the constant bus)
                 }
+            };
+            // ping-pong: entry k in register set A, entry k + 1 in set B; each set is refilled right after its pair has been evaluated,
+            // i.e. one full pair evaluation before it is needed again; the rows come from the list two entries ahead
+            uint2 ic = *reinterpret_cast<const uint2*>(L);          // rows of entries 0, 1
+            uint2 in = *reinterpret_cast<const uint2*>(L + 2);      // rows of entries 2, 3
+            Entry e0 = fetch(ic.x), e1 = fetch(ic.y);
+            for (int k = 0; k + 1 < cnt; k += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                const uint2 in2 = *reinterpret_cast<const uint2*>(L + k + 4);   // issued first: DS results return in order, so the copy below
+                __builtin_amdgcn_sched_barrier(0);                              // waits for this read only, not for the entry reads behind it
+                pair(e0);
+                e0 = fetch(in.x);
+                __builtin_amdgcn_sched_barrier(0);
+                pair(e1);
+                e1 = fetch(in.y);
+                in = in2;
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (cnt & 1) pair(e0);
             // entries are visited in list order, so the group's last blended entry is the pixel's new `last` (1-based list position)
-            last = last_row != ~0u ? (uint32_t)(base + jbase + 1) + (last_row >> 4) : last;
+            last = last_row != ~0u ? (uint32_t)(base + 1) + (last_row >> 4) : last;
             if (COUNT_TOUCHED.value) {
-                if (counts) __hip_atomic_fetch_add(&s_nt[jbase + lane], counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (counts) __hip_atomic_fetch_add(&s_nt[sw * 64 + lane], counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
+        FWD_T(tk_mark = FWD_TICK();)
         for (int sw = 0; sw < 4; sw++) {
             if (__all(thr > 1.0f)) break;
             if (sw == 2 && base + CHUNK < n) write_checkpoint(base + CHUNK);
-            const unsigned long long m = lds_mask_uniform(&s_mask[wave][sw]);
-            if (__any(thr < 1.0f && T > 0.5f)) composite(std::true_type{}, m, sw * 64);
-            else composite(std::false_type{}, m, sw * 64);
+            const int cnt = sw == 0 ? cnt4[0] : sw == 1 ? cnt4[1] : sw == 2 ? cnt4[2] : cnt4[3];
+            if (cnt == 0) continue;
+            FWD_T(n_pairs += cnt;)
+            if (__any(thr < 1.0f && T > 0.5f)) composite(std::true_type{}, lds_mask_uniform(&s_mask[wave][sw]), sw, cnt);
+            else composite(std::false_type{}, 0ull, sw, cnt);
         }
+        FWD_T(tk_pair += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     }
+#if GSR_FWD_TIMING
+    if (lane == 0 && tile < 8192) {
+        uint32_t* o = g_fwd_timing + (size_t)(tile * 4 + wave) * 8;
+        o[0] = FWD_TICK() - tk0; o[1] = tk_sort; o[2] = tk_stage; o[3] = tk_list; o[4] = tk_pair; o[5] = n_pairs; o[6] = n_batches; o[7] = tk_wait;
+    }
+#endif
     __syncthreads();
     {
         const int c = s_nt[t];
@@ -284,8 +378,7 @@ constexpr int PART_STRIDE = 12;   // floats per (quadrant, entry) in s_part: {M1
 // the order in which the three float4 pieces of the gradient slot consume them
 __device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <= 5 ? k - 1 : k); }
 
-__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
-                                                        const uint32_t* __restrict__ chunk_base, const char* bin_base,
+__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
                                                         const float* __restrict__ bg, const TileRec* __restrict__ rec,
                                                         const float* __restrict__ final_T,
@@ -295,19 +388,16 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     // ---- which (tile, chunk) is this block? The grid is an upper bound (R / CHUNK + tiles); surplus blocks leave.
     // The XCD banding is computed over the REAL number of chunks: banding over the grid (an upper bound) put every surplus id
     // into the last XCD's band, which then ran out of work while the other seven still had a quarter of theirs.
+    FWD_T(const uint32_t tk0 = FWD_TICK(); uint32_t tk_search = 0, tk_state = 0, tk_stage = 0, tk_pair = 0, tk_epi = 0, n_pairs = 0; uint32_t tk_mark = tk0;)
+    // The block's work item and the header are two INDEPENDENT loads (the item table sits at offset 0 of the binning buffer and is indexed by
+    // the block id: the forward pass applied the XCD banding when it wrote it). Round 2 searched chunk_base for the tile -- eleven dependent
+    // scalar loads -- and then read ranges / chunk_base: seven global latencies before the first list entry could be requested, now two.
+    const uint4 item = reinterpret_cast<const uint4*>(((reinterpret_cast<uintptr_t>(bin_base) + 255) & ~uintptr_t(255)))[blockIdx.x];
     const uint32_t nchunks = header[HDR_CHUNKS];
-    if (blockIdx.x >= nchunks || (header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // overflow: a lazy forward pass whose lists were never built
-    const uint32_t cid = (uint32_t)xcd_tile_of_block(blockIdx.x, (int)nchunks);   // neighbouring chunks (same or adjacent tiles) share an XCD's L2
-    int tile;
-    {   // largest t with chunk_base[t] <= cid (uniform binary search, scalar loads)
-        int lo = 0, hi = ntiles;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (chunk_base[mid] <= cid) lo = mid; else hi = mid;
-        }
-        tile = lo;
-    }
-    const BinningPtrs bin = carve_binning(const_cast<char*>(bin_base), header[HDR_CARVE_R], header[HDR_CAP_SORTED]);   // uniform: SALU
+    if (blockIdx.x >= nchunks || (header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // surplus block (its item is stale), or a lazy forward pass whose lists were never built
+    const BinningPtrs bin = carve_binning(const_cast<char*>(bin_base), header[HDR_CARVE_R], header[HDR_CAP_SORTED], (size_t)ntiles);   // uniform: SALU
+    const int tile = (int)__builtin_amdgcn_readfirstlane(item.x);
+    FWD_T(tk_search = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
     __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
@@ -331,15 +421,34 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const int px = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
     const int py = ty * TILE_Y + (wave >> 1) * 8 + (lane >> 3);
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const int chunk = (int)(cid - chunk_base[tile]);
-    const int cstart = chunk * CHUNK, cend = min(n, cstart + CHUNK);   // list positions [cstart, cend) of this tile, front to back
-    const int m = cend - cstart;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(item.y);          // position of list entry cstart in sorted[]
+    const int m = (int)(__builtin_amdgcn_readfirstlane(item.z) & 0xFFFFu);
+    const bool more_behind = (__builtin_amdgcn_readfirstlane(item.z) & 0x10000u) != 0;
+    const int cstart = (int)__builtin_amdgcn_readfirstlane(item.w), cend = cstart + m;   // list positions [cstart, cend) of this tile, front to back
 
     const bool inside = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
+    // Every global load of the prologue is issued here, in one go, before anything waits: the list entry (whose Gaussian record is the only
+    // load that depends on another one), the pixel's forward results and cotangents, and the checkpoint at the chunk's back end. Taken in
+    // program order (contributor count -> block vote -> pixel state -> list entry -> record) they cost five global latencies in a row.
+    uint2 e = make_uint2(0u, 0u);
+    if (t < m) e = sorted[first + (uint32_t)(m - 1 - t)];                    // 0-based list position cend-1-t, back to front (:656,:677)
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
+    const float Tfin = inside ? final_T[pix] : 0.f;                          // backward.cu:617-623
+    const float gr = inside ? dL_dpix[pix] : 0.f;                            // :629-635
+    const float gg = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
+    const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
+    const float gd = inside ? dL_dpix_depth[pix] : 0.f;
+    const bool have_ckpt = inside && more_behind;                            // a checkpoint exists in front of entry cend (it may be stale: see below)
+    float4 Cf = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ck[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (have_ckpt) {
+        const float* c = bin.ckpt + (size_t)(((first - (uint32_t)cstart) >> 7) + (uint32_t)(cend >> 7)) * CKPT_FLOATS + t;
+        Cf = final_C[pix];
+        ck[0] = c[0]; ck[1] = c[256]; ck[2] = c[512]; ck[3] = c[768]; ck[4] = c[1024];
+    }
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+    if (t < m) { const TileRec* const g = rec + e.x; q0 = g->q0; q1 = g->q1; q2 = g->q2; }
     {   // deepest list position any pixel of this quadrant blended; a chunk behind all four has nothing to do (its instances'
         // slots must still be written: zero)
         int wm = last_contrib;
@@ -350,7 +459,6 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     __syncthreads();
     if (max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) <= cstart) {
         if (t < m) {
-            const uint2 e = sorted[range.x + (uint32_t)(cend - 1 - t)];
             float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e.y * 3;
             slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -359,7 +467,8 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
 
     // ---- per-pixel state at the BACK end of the chunk (the pass walks the chunk back to front, backward.cu:656,677) --------
     //   T  = transmittance in front of entry `cend`:  the forward pass's checkpoint there, or the final value for a pixel that
-    //        blended nothing at or behind cend (in particular for the last chunk of the list);
+    //        blended nothing at or behind cend (in particular for the last chunk of the list; the forward pass stops writing
+    //        checkpoints once a quadrant is saturated, so the loaded one is only used when the pixel blended behind it);
     //   Sb = T_final (bg . g) + sum over the blended entries at or behind cend of alpha_k T_k (c_k . g)
     //      = (C_final - C_checkpoint) . g + T_final (bg . g),   C = the forward pass's running colour / depth sums.
     // The reference carries the normalised "colour behind" accum_rec[3] + accum_rec_depth and last_alpha/last_color (:714-728)
@@ -369,18 +478,11 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     // since both T and Sb are available at every chunk boundary, every chunk of a list is an independent block: ~5000 short
     // blocks instead of 1200 long ones, which the hardware dispatcher balances over the CUs (with one block per tile the
     // kernel lasted as long as its slowest tile, 1.5x the mean).
-    const float Tfin = inside ? final_T[pix] : 0.f;                          // backward.cu:617-623
-    const float gr = inside ? dL_dpix[pix] : 0.f;                            // :629-635
-    const float gg = inside ? dL_dpix[(size_t)H * W + pix] : 0.f;
-    const float gb = inside ? dL_dpix[2 * (size_t)H * W + pix] : 0.f;
-    const float gd = inside ? dL_dpix_depth[pix] : 0.f;
     const float bgdot = bg[0] * gr + bg[1] * gg + bg[2] * gb;                // :738-742
     float T = Tfin, Sb = Tfin * bgdot;
-    if (inside && cend < n && last_contrib > cend) {
-        const float* c = bin.ckpt + (size_t)((range.x >> 7) + (uint32_t)(cend >> 7)) * CKPT_FLOATS + t;
-        const float4 Cf = final_C[pix];
-        T = c[0];
-        Sb += (Cf.x - c[256]) * gr + (Cf.y - c[512]) * gg + (Cf.z - c[768]) * gb + (Cf.w - c[1024]) * gd;
+    if (have_ckpt && last_contrib > cend) {
+        T = ck[0];
+        Sb += (Cf.x - ck[1]) * gr + (Cf.y - ck[2]) * gg + (Cf.z - ck[3]) * gb + (Cf.w - ck[4]) * gd;
     }
     const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
     // which of the ten sums this lane ends up holding after the transposed reduction
@@ -388,12 +490,10 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
     const uint32_t part_lane = (uint32_t)(wave * (GRP * PART_STRIDE) + part_pos_of_sum(fi)) * 4u;   // this lane's byte offset into s_part for entry 0 of a group
     const WaveSelectMasks wsm = wave_select_masks();
 
+    FWD_T(tk_state = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     uint32_t qm = 0;
     if (t < m) {
-        const int pos = cend - 1 - t;                                     // 0-based list position, back to front (:656,:677)
-        const uint2 e = sorted[range.x + (uint32_t)pos];
-        const TileRec* const g = rec + e.x;
-        const float4 q0 = g->q0, q1 = g->q1, q2 = g->q2;
+        const int pos = cend - 1 - t;
         const float2 xy = make_float2(q0.x, q0.y);
         const float4 co = make_float4(q1.x, q1.y, q1.z, q0.w);
         qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
@@ -418,6 +518,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         }
     }
     __syncthreads();
+    FWD_T(tk_stage = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     unsigned long long proc = 0;
     int group_base = 0;
     // One (quadrant, entry) pair: entry jj of the current group. (Issuing the LDS reads one iteration ahead was measured: +3 % -- the
@@ -478,6 +579,7 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             bwd_pair(jj, row);
         }
         if (lane == 0) s_proc[wave][sw] = proc;
+        FWD_T(tk_pair += FWD_TICK() - tk_mark; tk_mark = FWD_TICK(); n_pairs += (uint32_t)__popcll(lds_mask_uniform(&s_mask[wave][sw]));)
         __syncthreads();
         // Group epilogue: add the four quadrants in a fixed order, turn the moments into the reference's gradients and write the
         // group's instance slots (12 floats, 48 B each). Wave w produces the w-th 16-byte piece of the 64 slots (one ds_read_b128
@@ -509,7 +611,14 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
             reinterpret_cast<float4*>(partials)[(size_t)__float_as_uint(sb.z) * 3 + wave] = o4;
         }
         if (sw == 0) __syncthreads();   // s_part is reused by the second group
+        FWD_T(tk_epi += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     }
+#if GSR_FWD_TIMING
+    if (lane == 0 && blockIdx.x < 8192) {
+        uint32_t* o = g_bwd_timing + (size_t)(blockIdx.x * 4 + wave) * 8;
+        o[0] = FWD_TICK() - tk0; o[1] = tk_search; o[2] = tk_state; o[3] = tk_stage; o[4] = tk_pair; o[5] = n_pairs; o[6] = tk_epi; o[7] = tk0;
+    }
+#endif
 }
 
 }  // namespace gsr
