@@ -353,6 +353,9 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         GSR_HIP_CHECK(hipMemsetAsync(flags, 0, sizeof(uint32_t), stream));
 
     const int nblocks = (P + GB - 1) / GB;
+    // small launches are latency-bound: the per-Gaussian kernels then request every row they may need up front (gs_forward.h)
+    static const int eager_max = getenv("GSR_EAGER_MAX") ? atoi(getenv("GSR_EAGER_MAX")) : 512 * 1024;
+    const int eager = P <= eager_max ? 1 : 0;
     if (P > 0) {
         PreprocessArgs a;
         a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.gx = gx; a.gy = gy;
@@ -368,7 +371,9 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         a.raw = to_device_view(raw);
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
-            hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
+            a.eager = eager;
+            if (raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
+            else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
         if (lds_hist) {
@@ -440,7 +445,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
-                               (uint32_t)carve_R, (uint32_t)cap_sorted);
+                               (uint32_t)carve_R, (uint32_t)cap_sorted, eager);
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here
@@ -712,6 +717,13 @@ int gsr_debug_fwd_timing(unsigned int* out, int nwords)
 {
     GSR_HIP_CHECK(hipDeviceSynchronize());
     GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fwd_timing), (size_t)nwords * sizeof(uint32_t)));
+    return 0;
+}
+int gsr_debug_pre_timing(unsigned int* out, int nwords, int which)
+{
+    GSR_HIP_CHECK(hipDeviceSynchronize());
+    if (which == 0) GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pre_timing), (size_t)nwords * sizeof(uint32_t)));
+    else GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sca_timing), (size_t)nwords * sizeof(uint32_t)));
     return 0;
 }
 int gsr_debug_geo_timing(unsigned int* out, int nwords)

@@ -34,6 +34,7 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* cam_pos;
     float tan_fovx, tan_fovy, focal_x, focal_y;
     int prefiltered;
+    int eager;                   // request every per-Gaussian row up front (small launches: latency-bound); 0 = rows of culled Gaussians are never read
     int* radii; int* n_touched;
     TileRec* rec; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* flags;   // flags: zero-filled together with tile_count
@@ -101,7 +102,13 @@ __device__ __forceinline__ Cov2D cov2d_eval(f3 mean, float fx, float fy, float t
 }
 
 // forward.cu:22-73. sh points at this Gaussian's [M,3] coefficients. Returns rgb (>=0) and the 3 clamp flags as bits.
-__device__ __forceinline__ f3 sh_to_rgb(int deg, const ShView sh, f3 pos, f3 campos, uint32_t& clamp_bits)
+// SH coefficients with the DC band already in registers (preprocess_fwd loads it together with the other per-Gaussian rows)
+struct ShRegs {
+    float d0, d1, d2; const float* rest;
+    __device__ __forceinline__ float operator[](int k) const { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : rest[k - 3]; }
+};
+template <typename SH>
+__device__ __forceinline__ f3 sh_to_rgb(int deg, const SH sh, f3 pos, f3 campos, uint32_t& clamp_bits)
 {
     f3 dir = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
     const float inv = 1.0f / sqrtf(dot3(dir, dir));
@@ -130,25 +137,71 @@ __device__ __forceinline__ f3 sh_to_rgb(int deg, const ShView sh, f3 pos, f3 cam
     return mk3(fmaxf(res[0], 0.f), fmaxf(res[1], 0.f), fmaxf(res[2], 0.f));
 }
 
+#ifndef GSR_FWD_TIMING
+#define GSR_FWD_TIMING 0
+#endif
+#if GSR_FWD_TIMING
+__device__ uint32_t g_pre_timing[8 * 16 * 2048];
+__device__ uint32_t g_sca_timing[8 * 16 * 2048];
+#define PRE_TICK(arr, k) do { if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0) arr[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PRE_TICK(arr, k)
+#endif
+// RAW: the fused-prologue mode (raw.xyz != nullptr) as a template parameter, so that the plain instantiation is straight-line code.
+// Loads: the mean first; then -- `eager` launches (up to ~0.5 M Gaussians: a handful of waves per SIMD, nothing to hide a latency
+// behind) -- scale, rotation, opacity and the DC colour of EVERY Gaussian in one go, so that a visible Gaussian pays two global
+// latencies instead of four (mean -> scale / rotation -> colour -> opacity); large launches keep the lazy order, which spares the
+// culled Gaussians' rows (71 % of 2 M at BASELINE config #5) and has enough waves in flight.
+template <bool RAW>
 __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 {
+    RawInputs R = a.raw;
+    if constexpr (!RAW) R = RawInputs{};
     const int idx = blockIdx.x * GB + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     __shared__ uint32_t s_wave_sum[GB / 64];
     extern __shared__ uint32_t s_hist[];   // [T] when a.block_tile_base != nullptr
     const int T = a.gx * a.gy;
     const bool lds_hist = a.block_tile_base != nullptr;
+    PRE_TICK(g_pre_timing, 0);
     if (lds_hist) {
         for (int t = threadIdx.x; t < T; t += GB) s_hist[t] = 0;
         __syncthreads();
     }
+    PRE_TICK(g_pre_timing, 1);
 
     uint32_t touched = 0;
     int rx0 = 0, ry0 = 0, rw = 0;
     if (idx < a.P) {
         int my_radius = 0;
         if (a.n_touched) a.n_touched[idx] = 0;
-        const f3 p = load_mean(a.means3D, a.raw, (size_t)idx);
+        const f3 p = load_mean(a.means3D, R, (size_t)idx);
+        const bool flow = RAW && R.flow_proj1 != nullptr;
+        const bool eager = a.eager != 0;
+        float s3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, cov6[6], opac = 0.f, dc[3] = {0.f, 0.f, 0.f};
+        auto load_shape = [&]() {
+            if (a.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) cov6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+            } else {
+                load_scale(a.scales, R, (size_t)idx, s3);
+                load_rot(a.rotations, R, (size_t)idx, q4);
+            }
+        };
+        const ShView shv = sh_view(a.shs, R, (size_t)idx, a.M);
+        auto load_look = [&]() {
+            opac = load_opacity(a.opacities, R, (size_t)idx);
+            if (!flow) {
+                if (a.colors_precomp != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dc[k] = a.colors_precomp[3 * (size_t)idx + k];   // rasterizer_impl.cu:324
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dc[k] = shv.dc[k];
+                }
+            }
+        };
+        if (eager) { load_shape(); load_look(); }
         const f3 p_view = xform_point_4x3(p, a.viewmatrix);
         // near cull only (auxiliary.h:139-164); a culled point under `prefiltered` is an error (:156-160)
         if (p_view.z <= 0.2f) {
@@ -159,14 +212,8 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
             const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
             const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
             const float p_w = 1.0f / (hw + 0.0000001f);  // forward.cu:201
-            float cov6[6];
-            if (a.cov3D_precomp) {
-#pragma unroll
-                for (int k = 0; k < 6; k++) cov6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
-            } else {
-                float s3[3], q4[4];
-                load_scale(a.scales, a.raw, (size_t)idx, s3);
-                load_rot(a.rotations, a.raw, (size_t)idx, q4);
+            if (!eager) load_shape();
+            if (!a.cov3D_precomp) {
                 cov3d_from_scale_rot(s3, a.scale_modifier, q4, cov6);
 #pragma unroll
                 for (int k = 0; k < 6; k++) a.cov3D[6 * (size_t)idx + k] = cov6[k];
@@ -183,32 +230,33 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
                 tile_rect(px, py, (int)rad_f, a.gx, a.gy, x0, y0, x1, y1);
                 const int area = (x1 - x0) * (y1 - y0);
                 if (area != 0) {
+                    if (!eager) load_look();
                     f3 col;
-                    if (a.raw.flow_proj1) {
+                    if (flow) {
                         // render_flow's colour (gaussian_renderer/__init__.py:262-284): NDC displacement between the two projections
                         // of the (detached) position moved by dx / dx2, and the dynamic-mask channel
-                        const size_t row = raw_row(a.raw, (size_t)idx);
-                        const int sl = raw_slot(a.raw, row);
-                        const f3 base = mk3(a.raw.xyz[3 * row], a.raw.xyz[3 * row + 1], a.raw.xyz[3 * row + 2]);
+                        const size_t row = raw_row(R, (size_t)idx);
+                        const int sl = raw_slot(R, row);
+                        const f3 base = mk3(R.xyz[3 * row], R.xyz[3 * row + 1], R.xyz[3 * row + 2]);
                         f3 t1 = base, t2 = base;
                         if (sl >= 0) {
-                            if (a.raw.dx) { t1.x += a.raw.dx[3 * sl]; t1.y += a.raw.dx[3 * sl + 1]; t1.z += a.raw.dx[3 * sl + 2]; }
-                            if (a.raw.flow_dx2) { t2.x += a.raw.flow_dx2[3 * sl]; t2.y += a.raw.flow_dx2[3 * sl + 1]; t2.z += a.raw.flow_dx2[3 * sl + 2]; }
+                            if (R.dx) { t1.x += R.dx[3 * sl]; t1.y += R.dx[3 * sl + 1]; t1.z += R.dx[3 * sl + 2]; }
+                            if (R.flow_dx2) { t2.x += R.flow_dx2[3 * sl]; t2.y += R.flow_dx2[3 * sl + 1]; t2.z += R.flow_dx2[3 * sl + 2]; }
                         }
                         float u1, v1, u2, v2;
-                        flow_ndc(a.raw.flow_proj1, t1, u1, v1);
-                        flow_ndc(a.raw.flow_proj2, t2, u2, v2);
+                        flow_ndc(R.flow_proj1, t1, u1, v1);
+                        flow_ndc(R.flow_proj2, t2, u2, v2);
                         col = mk3(u2 - u1, v2 - v1, sl >= 0 ? 1.0f : 0.0f);
                         a.clamped[idx] = 0;
                     } else if (a.colors_precomp == nullptr) {
                         uint32_t cb;
-                        col = sh_to_rgb(a.D, sh_view(a.shs, a.raw, (size_t)idx, a.M), p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
+                        col = sh_to_rgb(a.D, ShRegs{dc[0], dc[1], dc[2], shv.rest}, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
                         a.clamped[idx] = (uint8_t)cb;
                     } else {
-                        col = mk3(a.colors_precomp[3 * (size_t)idx], a.colors_precomp[3 * (size_t)idx + 1], a.colors_precomp[3 * (size_t)idx + 2]);   // rasterizer_impl.cu:324
+                        col = mk3(dc[0], dc[1], dc[2]);
                     }
                     TileRec* const rec = a.rec + idx;
-                    rec->q0 = make_float4(px, py, p_view.z, load_opacity(a.opacities, a.raw, (size_t)idx));
+                    rec->q0 = make_float4(px, py, p_view.z, opac);
                     rec->q1 = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, 0.f);
                     rec->q2 = make_float4(col.x, col.y, col.z, 0.f);
                     my_radius = (int)rad_f;
@@ -220,6 +268,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
         a.radii[idx] = my_radius;
         a.tiles_touched[idx] = touched;
     }
+    PRE_TICK(g_pre_timing, 2);
     // (a) per-tile histogram: every (Gaussian, tile) instance adds one to its tile's counter.
     wave_expand(touched, [&](int src, uint32_t k, bool active) {
         const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
@@ -229,6 +278,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
             else atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * CTR_STRIDE], 1u);
         }
     });
+    PRE_TICK(g_pre_timing, 3);
     // (b) block partial sum
     uint32_t s = touched;
 #pragma unroll
@@ -244,10 +294,12 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
     //     blocks (= the block's sub-range inside the tile's segment) and a column total. Plain coalesced stores: an earlier
     //     version reserved the sub-ranges with one returning atomic per (block, tile), and those ~215 k agent-scope atomics
     //     (executed at the memory side on this multi-XCD part) cost more than the rest of the kernel.
+    PRE_TICK(g_pre_timing, 4);
     if (lds_hist) {
         uint32_t* row = a.block_tile_base + (size_t)blockIdx.x * T;
         for (int t = threadIdx.x; t < T; t += GB) row[t] = s_hist[t];
     }
+    PRE_TICK(g_pre_timing, 5);
 }
 
 // F1b: column scan of the [nblocks][T] histogram: hist[b][t] <- sum_{b' < b} hist[b'][t], tile_count[t] <- column total.
@@ -438,7 +490,7 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager)
 {
     if (speculative) {
         if (header[HDR_FLAGS] & FLAG_OVERFLOW) return;          // uniform: the buffer behind keys/inst_gauss is too small for this frame
@@ -448,6 +500,7 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
         header[HDR_FLAGS] &= ~(uint32_t)FLAG_OVERFLOW;          // this IS the redo of a frame that outgrew its speculative buffer: the
                                                                 // backward kernels must not mistake it for a lazy frame without lists
     }
+    PRE_TICK(g_sca_timing, 0);
     const int idx = blockIdx.x * GB + threadIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     __shared__ uint32_t s_wave_sum[GB / 64];
@@ -455,6 +508,11 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
     const int T = gx * gy;
     const bool lds_path = block_tile_base != nullptr;
     const uint32_t cnt = idx < P ? tiles_touched[idx] : 0u;
+    // eager (small launches, latency-bound): the Gaussian's record and radius are requested together with its instance count instead of
+    // behind it (rows of culled Gaussians hold no data: loaded, never used)
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int my_radius = 0;
+    if (eager && idx < P) { q0 = rec[idx].q0; my_radius = radii[idx]; }
     const uint32_t incl = wave_inclusive_scan(cnt);
     if (lane == 63) s_wave_sum[wave] = incl;
     if (lds_path) {
@@ -462,6 +520,7 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
         for (int t = threadIdx.x; t < T; t += GB) s_pos[t] = ranges[t].x + row[t];
     }
     __syncthreads();
+    PRE_TICK(g_sca_timing, 1);
     uint32_t wbase = block_base[blockIdx.x];
     for (int w = 0; w < wave; w++) wbase += s_wave_sum[w];
     const uint32_t off_incl = wbase + incl;
@@ -469,13 +528,14 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
     int rx0 = 0, ry0 = 0, rw = 1;
     uint32_t dbits = 0;
     if (cnt) {
-        const float4 q0 = rec[idx].q0;
+        if (!eager) { q0 = rec[idx].q0; my_radius = radii[idx]; }
         int x1, y1;
-        tile_rect(q0.x, q0.y, radii[idx], gx, gy, rx0, ry0, x1, y1);
+        tile_rect(q0.x, q0.y, my_radius, gx, gy, rx0, ry0, x1, y1);
         rw = x1 - rx0;
         dbits = __float_as_uint(q0.z);
     }
     const uint32_t off_excl = off_incl - cnt;
+    PRE_TICK(g_sca_timing, 2);
     wave_expand(cnt, [&](int src, uint32_t k, bool active) {
         const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
         const uint32_t sd = __shfl(dbits, src, 64), so = __shfl(off_excl, src, 64);
@@ -489,6 +549,7 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
             inst_gauss[u] = (uint32_t)g;
         }
     });
+    PRE_TICK(g_sca_timing, 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -54,3 +54,14 @@ g = g[:nb]
 d = np.diff(g[..., :7], axis=-1)
 print("geometry_bwd blocks", nb, "phase means (meta+barrier, first slots, slot sums, param loads+math, stores, tau):", d.reshape(-1, 6).mean(0).round(0).tolist())
 print("geometry_bwd: wave lifetime mean %.0f; kernel span %.0f cycles; start spread %.0f" % ((g[..., 6] - g[..., 0]).mean(), g[..., 6].max() - g[..., 0].min(), g[..., 0].max() - g[..., 0].min()))
+
+# ---- preprocess_fwd / scatter_instances (1024-thread blocks: 16 waves) ----
+lib.gsr_debug_pre_timing.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+nb = (200_000 + 1023) // 1024
+buf2 = (ctypes.c_uint32 * (2048 * 16 * 8))()
+for which, name, nt in ((0, "preprocess_fwd (zero hist, per-Gaussian, histogram, block sum, row publish)", 6), (1, "scatter_instances (s_pos fill, prep, expand+write)", 4)):
+    assert lib.gsr_debug_pre_timing(buf2, 2048 * 16 * 8, which) == 0
+    q = np.frombuffer(buf2, np.uint32).reshape(2048, 16, 8).astype(np.int64)[:nb - 1]
+    d = np.diff(q[..., :nt], axis=-1)
+    print(name, "phase means:", d.reshape(-1, nt - 1).mean(0).round(0).tolist(), "wave lifetime %.0f" % (q[..., nt - 1] - q[..., 0]).mean(),
+          "block span mean %.0f" % (q[..., nt - 1].max(axis=1) - q[..., 0].min(axis=1)).mean())
