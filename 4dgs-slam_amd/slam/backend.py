@@ -170,29 +170,16 @@ class BackEnd:
             viewpoint.pose_step(lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
                                 optimize_pose=cam_idx < self.frames_to_optimize, optimize_exposure=True)
 
-    def _prune_by_covisibility(self, current_window):
-        """:663-696 / :1140-1170: the monocular-only pruning; RGB-D just marks the map as initialised."""
-        if len(current_window) == self.config["Training"]["window_size"]:
-            prune_mode, prune_coviz = self.config["Training"]["prune_mode"], 3
-            g = self.gaussians
-            g.n_obs.fill_(0)
-            for _, visibility in self.occ_aware_visibility.items():
-                g.n_obs += visibility.to(g.n_obs.dtype)
-            to_prune = None
-            if prune_mode == "odometry":
-                to_prune = g.n_obs < 3
-            if prune_mode == "slam":
-                sorted_window = sorted(current_window, reverse=True)
-                mask = g.unique_kfIDs >= sorted_window[2]
-                if not self.initialized:
-                    mask = g.unique_kfIDs >= 0
-                to_prune = torch.logical_and(g.n_obs <= prune_coviz, mask)
-            if to_prune is not None and self.monocular:
-                g.prune_points(to_prune)
-                for idx in current_window:
-                    self.occ_aware_visibility[idx] = self.occ_aware_visibility[idx][~to_prune]
-            if not self.initialized:
-                self.initialized = True
+    def _window_full_bookkeeping(self, current_window):
+        """What remains of the reference's covisibility pruning (:663-696 / :1140-1170) for RGB-D input: once the window is full, the
+        per-Gaussian observation counts are refreshed (one stacked reduction over the window's visibility sets) and the map counts as
+        initialised. The pruning itself applies to monocular input only, which this back-end does not take (slam/frontend.py refuses it)."""
+        if len(current_window) != self.config["Training"]["window_size"]:
+            return
+        g = self.gaussians
+        if self.occ_aware_visibility:
+            g.n_obs.copy_(torch.stack([v != 0 for v in self.occ_aware_visibility.values()]).sum(dim=0).to(g.n_obs.dtype))
+        self.initialized = True
 
     def _isotropic_loss(self):
         scaling = self.gaussians.get_scaling
@@ -235,7 +222,7 @@ class BackEnd:
                 for idx in range(len(current_window)):
                     self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
                 if prune:
-                    self._prune_by_covisibility(current_window)
+                    self._window_full_bookkeeping(current_window)
                     self.gaussians.optimizer.zero_grad(set_to_none=True)
                     self._clear_camera_grads(viewpoint_stack)
                     return False
@@ -331,7 +318,7 @@ class BackEnd:
                 for idx in range(len(current_window)):
                     self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
                 if prune:
-                    self._prune_by_covisibility(current_window)
+                    self._window_full_bookkeeping(current_window)
                     g.optimizer.zero_grad(set_to_none=True)
                     if use_net:
                         g.deform.optimizer.zero_grad(set_to_none=True)

@@ -1,32 +1,34 @@
-"""Tracking front-end -- the counterpart of the reference's ``utils/slam_frontend.py`` FrontEnd for RGB-D input, single process
-(its ``single_thread: True`` schedule: the front-end waits for the back-end after every keyframe, :664-666). Same methods and the
-same decisions: add_new_keyframe (:128-187), initialize (:189-207), tracking (:335-470), is_keyframe (:472-499), add_to_window
-(:501-562), the run loop (:603-833). GUI / wandb / queue plumbing is out of scope; the back-end is called directly.
+"""Tracking front-end for RGB-D input, single process -- the role of the reference's ``utils/slam_frontend.py`` FrontEnd in its
+``single_thread: True`` schedule (the front-end hands every keyframe to the back-end and waits for it, :664-666). The public methods
+keep the reference's names and meaning (add_new_keyframe :128-187, initialize :189-207, tracking :335-470, is_keyframe :472-499,
+add_to_window :501-562, run :603-833) so that code written against it keeps working; the GUI / wandb / queue plumbing does not exist
+here, the back-end is called directly.
 
-What changed underneath: every tracking iteration is render (fused prologue, static Gaussians gathered inside the kernels) -> fused
-tracking loss -> backward -> ONE camera-step launch (Adam on pose + exposure, update_pose, matrices; Camera.pose_step). The only
-host synchronisations per frame are the convergence poll (every ``converge_check_every`` iterations; the reference synchronises
-every iteration, :440) and the median depth / visibility reads of the keyframe test."""
-import numpy as np
+How a frame is processed:
+
+  track      the pose is optimised against the static Gaussians by ``slam/tracking_graph.TrackingGraph`` -- render (fused prologue,
+             static rows gathered inside the kernels, Gaussians DETACHED so that the backward pass runs pose-only) -> fused tracking
+             loss -> backward -> ONE camera-step launch (Adam on pose + exposure, update_pose, matrices) -- either replayed as a
+             captured hipGraph (``Training.tracking_graph``) or called eagerly; the host only polls the convergence latch every
+             ``converge_check_every`` iterations (the reference synchronises every iteration, :440);
+  decide     one device-side statistics vector per frame (visibility overlap with the newest keyframe, distance to it) decides
+             whether the frame becomes a keyframe (``slam/keyframes.py``; ONE host transfer per frame);
+  insert     the window update is computed on the device and read back as two indices; the back-end maps the new keyframe.
+"""
 import time
 
 import torch
 
 from gaussian_renderer import render
-import slam_losses
-from diff_gaussian_rasterization import raw as _raw
 
+from . import keyframes as kf
 from .camera import Camera
 from .eval_utils import eval_ate, save_gaussians
 
 
-def getWorld2View2(R, t):
-    """gaussian_splatting/utils/graphics_utils.py:38-50 with the default translate / scale."""
-    Rt = torch.zeros((4, 4), device=R.device)
-    Rt[:3, :3] = R
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    return Rt
+@torch.no_grad()
+def render_without_grad(viewpoint, gaussians, pipe, background):
+    return render(viewpoint, gaussians, pipe, background, dynamic=False)
 
 
 def lower_median(x):
@@ -53,30 +55,23 @@ def get_median_depth(depth, opacity=None, mask=None, return_std=False):
 
 
 class FrontEnd:
-    def __init__(self, config):
-        self.config = config
-        self.background = None
-        self.pipeline_params = None
-        self.backend = None
-        self.dataset = None
-        self.initialized = False
-        self.kf_indices = []
-        self.monocular = config["Training"].get("monocular", False)
-        self.iteration_count = 0
-        self.occ_aware_visibility = {}
-        self.current_window = []
-        self.reset = True
-        self.use_every_n_frames = 1
-        self.gaussians = None
-        self.cameras = dict()
-        self.device = "cuda:0"
-        self.dynamic_model = config["model_params"]["dynamic_model"]
-        self.dynamic_objects = 0
-        self.dystart = 0
-        self.median_depth = 1.0
-        self.converge_check_every = int(config["Training"].get("converge_check_every", 5))
-        self.use_tracking_graph = bool(config["Training"].get("tracking_graph", False))     # slam/tracking_graph.py
-        self._tgraph = None
+    MIN_KEYFRAME_GAP = 5          # a keyframe at the latest every five frames (utils/slam_frontend.py:739)
+
+    def __init__(self, config: dict):
+        training, self.config = config["Training"], config
+        self.monocular, self.dynamic_model = training.get("monocular", False), config["model_params"]["dynamic_model"]
+        self.converge_check_every = int(training.get("converge_check_every", 5))
+        self.use_tracking_graph = bool(training.get("tracking_graph", False))     # slam/tracking_graph.py
+        self.device = torch.device("cuda", 0)
+        # wired by slam/system.py
+        self.background = self.pipeline_params = self.backend = self.dataset = self.gaussians = None
+        # map / trajectory state (the attribute names are the reference's: the back-end and the evaluation read them)
+        self.cameras, self.kf_indices, self.current_window, self.occ_aware_visibility = {}, [], [], {}
+        self.initialized, self.reset = False, True
+        self.median_depth, self.use_every_n_frames, self.iteration_count = 1.0, 1, 0
+        self.dynamic_objects = self.dystart = 0
+        # bookkeeping
+        self._tracker = None
         self.graph_stats = {"captures": 0, "replayed_frames": 0, "eager_frames": 0, "overflow_redos": 0}
         self.log = []
         self.init_done_at = None
@@ -89,185 +84,143 @@ class FrontEnd:
         self.tracking_itr_num, self.kf_interval = t["tracking_itr_num"], t["kf_interval"]
         self.window_size, self.single_thread = t["window_size"], t.get("single_thread", True)
 
-    # ---- keyframe depth (:128-187, RGB-D branch) ---------------------------------------------------------------------
-    def add_new_keyframe(self, cur_frame_idx, depth=None, opacity=None, init=False):
-        if self.monocular:
-            raise NotImplementedError("monocular initialisation (utils/slam_frontend.py:135-178) is not part of the RGB-D configurations shipped")
-        self.kf_indices.append(cur_frame_idx)
-        viewpoint = self.cameras[cur_frame_idx]
-        gt_img = viewpoint.original_image.to(self.device)
-        valid_rgb = (gt_img.sum(dim=0) > self.config["Training"]["rgb_boundary_threshold"])
-        initial_depth = viewpoint.depth_device().clone()
-        initial_depth.masked_fill_(~valid_rgb, 0)                           # :180-181 (masked_fill: no host round trip, unlike x[mask] = 0)
-        if self.dynamic_model and viewpoint.motion_mask is not None:
-            initial_depth.masked_fill_(~viewpoint.motion_mask, 0)           # :185-186: seed the static map from static pixels only
-        return initial_depth
+    @property
+    def thresholds(self):
+        return kf.KeyframeThresholds.from_config(self.config)
 
-    def initialize(self, cur_frame_idx, viewpoint):
+    # ---- keyframe depth (:128-187, RGB-D branch) ---------------------------------------------------------------------
+    def add_new_keyframe(self, frame_idx, depth=None, opacity=None, init=False):
+        if self.monocular:         # (utils/slam_frontend.py:135-178 is not part of the RGB-D configurations shipped)
+            raise NotImplementedError("monocular initialisation is not built: RGB-D input only")
+        self.kf_indices += [frame_idx]
+        viewpoint = self.cameras[frame_idx]
+        gt_img = viewpoint.original_image.to(self.device)
+        usable = gt_img.sum(dim=0) > self.config["Training"]["rgb_boundary_threshold"]
+        if self.dynamic_model and viewpoint.motion_mask is not None:
+            usable = usable & viewpoint.motion_mask                       # :185-186: seed the static map from static pixels only
+        return viewpoint.depth_device() * usable                          # :180-181 (no host round trip, unlike x[mask] = 0)
+
+    def initialize(self, frame_idx, viewpoint):
         """:189-207."""
-        self.initialized = not self.monocular
         self.kf_indices, self.iteration_count, self.occ_aware_visibility, self.current_window = [], 0, {}, []
+        self.initialized, self.reset = not self.monocular, False
         viewpoint.update_RT(viewpoint.R_gt, viewpoint.T_gt)               # first frame at the ground-truth pose
-        depth_map = self.add_new_keyframe(cur_frame_idx, init=True)
-        self.sync_backend(self.backend.handle_init(cur_frame_idx, viewpoint, depth_map))
-        self.reset = False
+        seed_depth = self.add_new_keyframe(frame_idx, init=True)
+        self.sync_backend(self.backend.handle_init(frame_idx, viewpoint, seed_depth))
 
     # ---- tracking (:335-470) -------------------------------------------------------------------------------------------
-    def _track_with_graph(self, viewpoint):
-        """The tracking loop as hipGraph replays (slam/tracking_graph.py). Returns False if the frame has to be redone eagerly."""
+    def _tracker_for_current_map(self, viewpoint):
+        """The TrackingGraph of the current map version (its static slot, the detached Gaussians and -- if asked for -- the captured
+        graph); rebuilt whenever the back-end replaced the model's tensors."""
         from .tracking_graph import TrackingGraph
-        if self._tgraph is None or self._tgraph.version != TrackingGraph.model_version(self.gaussians):
-            self._tgraph = TrackingGraph(self.gaussians, self.pipeline_params, self.background, self.config, viewpoint)
-            self._tgraph.load(viewpoint)
-            self._tgraph.capture()
-            self.graph_stats["captures"] += 1
-        self._tgraph.load(viewpoint)
-        _, ok = self._tgraph.run(self.tracking_itr_num, self.converge_check_every)
-        if ok:
-            self._tgraph.store(viewpoint)
-            self.graph_stats["replayed_frames"] += 1
-        else:
-            self.graph_stats["overflow_redos"] += 1
-        return ok
+        if self._tracker is None or self._tracker.version != TrackingGraph.model_version(self.gaussians):
+            self._tracker = TrackingGraph(self.gaussians, self.pipeline_params, self.background, self.config, viewpoint)
+            if self.use_tracking_graph:
+                self._tracker.load(viewpoint)
+                self._tracker.capture()
+                self.graph_stats["captures"] += 1
+        return self._tracker
 
-    def tracking(self, cur_frame_idx, viewpoint, last_keyframe_idx):
-        prev = self.cameras[cur_frame_idx - self.use_every_n_frames]
-        viewpoint.update_RT(prev.R, prev.T)
-        if self.use_tracking_graph and self._track_with_graph(viewpoint):
-            self.median_depth = get_median_depth(self._tgraph.pkg["depth"], self._tgraph.pkg["opacity"])      # the last tracking iteration's render, :461
-            with torch.no_grad():
-                render_pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False)
-            return render_pkg
-        self.graph_stats["eager_frames"] += 1
-        lr = self.config["Training"]["lr"]
-        viewpoint.reset_pose_optimizer()
-        static = None
-        if self.gaussians.dyn_rows().shape[0] > 0:
-            static = self.gaussians.dygs == False  # noqa: E712  (the reference's expression, :413)
-            static._gsr_gather = _raw.gather_from_mask(static)             # one nonzero() per frame instead of one per iteration
-        depth = opacity = None
-        for tracking_itr in range(self.tracking_itr_num):
-            render_pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False, mask=static)
-            image, depth, opacity = render_pkg["render"], render_pkg["depth"], render_pkg["opacity"]
-            loss_tracking = slam_losses.get_loss_tracking(self.config, image, depth, opacity, viewpoint, rm_dynamic=True, mask=None)
-            loss_tracking.backward()
-            viewpoint.pose_step(lr["cam_rot_delta"], lr["cam_trans_delta"], 0.01, latch=True)      # step + zero_grad + update_pose, :434-440
-            self.gaussians.optimizer.zero_grad(set_to_none=True)
-            if (tracking_itr + 1) % self.converge_check_every == 0 and viewpoint.converged():
-                break
-        self.median_depth = get_median_depth(depth, opacity)
-        with torch.no_grad():
-            render_pkg = render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False)
-        return render_pkg
+    def tracking(self, frame_idx, viewpoint, last_keyframe_idx=None):
+        previous = self.cameras[frame_idx - self.use_every_n_frames]
+        viewpoint.update_RT(previous.R, previous.T)
+        tracker = self._tracker_for_current_map(viewpoint)
+        tracker.load(viewpoint)
+        replayed = False
+        if self.use_tracking_graph:
+            _, replayed = tracker.run(self.tracking_itr_num, self.converge_check_every)
+            self.graph_stats["replayed_frames" if replayed else "overflow_redos"] += 1
+            if not replayed:
+                tracker.load(viewpoint)          # the frame outgrew the captured graph's binning buffer: start over, eagerly
+        if replayed:
+            pkg = tracker.pkg                    # the captured iteration's static outputs: the last replay's render
+        else:                                    # eager: the same iteration, launch by launch
+            self.graph_stats["eager_frames"] += 1
+            for it in range(self.tracking_itr_num):
+                pkg = tracker.iteration()
+                if (it + 1) % self.converge_check_every == 0 and tracker.cam.converged():
+                    break
+        tracker.store(viewpoint)
+        self.median_depth = get_median_depth(pkg["depth"], pkg["opacity"])        # :461
+        return render_without_grad(viewpoint, self.gaussians, self.pipeline_params, self.background)
 
-    # ---- keyframe management (:472-562), restated decision by decision ------------------------------------------------
+    # ---- keyframe management (:472-562): the decisions of the reference, computed by slam/keyframes.py -------------------------
     def is_keyframe(self, cur_frame_idx, last_keyframe_idx, cur_frame_visibility_filter, occ_aware_visibility):
-        t = self.config["Training"]
-        curr_frame, last_kf = self.cameras[cur_frame_idx], self.cameras[last_keyframe_idx]
-        pose_CW = getWorld2View2(curr_frame.R, curr_frame.T)
-        last_kf_WC = torch.linalg.inv(getWorld2View2(last_kf.R, last_kf.T))
-        dist = torch.norm((pose_CW @ last_kf_WC)[0:3, 3])
-        dist_check = dist > t["kf_translation"] * self.median_depth
-        dist_check2 = dist > t["kf_min_translation"] * self.median_depth
-        union = torch.logical_or(cur_frame_visibility_filter, occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-        intersection = torch.logical_and(cur_frame_visibility_filter, occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-        point_ratio_2 = intersection / union
-        return bool((point_ratio_2 < t["kf_overlap"] and dist_check2) or dist_check)
+        stats = kf.frame_statistics(self.cameras[cur_frame_idx], self.cameras[last_keyframe_idx], cur_frame_visibility_filter,
+                                    occ_aware_visibility[last_keyframe_idx])
+        return bool(kf.keyframe_decision(stats, self.median_depth, self.thresholds))
 
     def add_to_window(self, cur_frame_idx, cur_frame_visibility_filter, occ_aware_visibility, window):
-        N_dont_touch = 2
-        window = [cur_frame_idx] + window
-        curr_frame = self.cameras[cur_frame_idx]
-        to_remove = []
-        removed_frame = None
-        for i in range(N_dont_touch, len(window)):
-            kf_idx = window[i]
-            intersection = torch.logical_and(cur_frame_visibility_filter, occ_aware_visibility[kf_idx]).count_nonzero()      # Szymkiewicz-Simpson
-            denom = min(cur_frame_visibility_filter.count_nonzero(), occ_aware_visibility[kf_idx].count_nonzero())
-            point_ratio_2 = intersection / denom
-            cut_off = self.config["Training"]["kf_cutoff"] if "kf_cutoff" in self.config["Training"] else 0.4
-            if not self.initialized:
-                cut_off = 0.4
-            if point_ratio_2 <= cut_off:
-                to_remove.append(kf_idx)
-        if to_remove:
-            window.remove(to_remove[-1])
-            removed_frame = to_remove[-1]
-        kf_0_WC = torch.linalg.inv(getWorld2View2(curr_frame.R, curr_frame.T))
-        if len(window) > self.config["Training"]["window_size"]:
-            inv_dist = []
-            for i in range(N_dont_touch, len(window)):
-                inv_dists = []
-                kf_i = self.cameras[window[i]]
-                kf_i_CW = getWorld2View2(kf_i.R, kf_i.T)
-                for j in range(N_dont_touch, len(window)):
-                    if i == j:
-                        continue
-                    kf_j = self.cameras[window[j]]
-                    T_CiCj = kf_i_CW @ torch.linalg.inv(getWorld2View2(kf_j.R, kf_j.T))
-                    inv_dists.append(1.0 / (torch.norm(T_CiCj[0:3, 3]) + 1e-6).item())
-                T_CiC0 = kf_i_CW @ kf_0_WC
-                k = torch.sqrt(torch.norm(T_CiC0[0:3, 3])).item()
-                inv_dist.append(k * sum(inv_dists))
-            idx = int(np.argmax(inv_dist))
-            removed_frame = window[N_dont_touch + idx]
-            window.remove(removed_frame)
-        return window, removed_frame
+        thr = self.thresholds
+        old = list(window)
+        cutoff = thr.cutoff if self.initialized else 0.4                  # :523-529
+        drop = kf.window_evictions(self.cameras[cur_frame_idx], [self.cameras[k] for k in old], cur_frame_visibility_filter,
+                                   kf.visibility_matrix(occ_aware_visibility, old, cur_frame_visibility_filter), cutoff, thr.window_size)
+        low, crowded = (int(v) for v in drop.tolist())                    # the one host transfer of the window update
+        gone = [old[j] for j in (low, crowded) if j >= 0]
+        removed = gone[-1] if gone else None
+        return [cur_frame_idx] + [k for k in old if k not in gone], removed
 
     def sync_backend(self, data):
         """:582-590 (single process: the Gaussians are shared, not cloned)."""
-        self.gaussians = data[1]
-        self.occ_aware_visibility = data[2]
-        for kf_id, kf_R, kf_T in data[3]:
-            self.cameras[kf_id].update_RT(kf_R.clone(), kf_T.clone())
+        _, self.gaussians, self.occ_aware_visibility, poses = data[:4]
+        for frame, R, T in poses:
+            self.cameras[frame].update_RT(R.clone(), T.clone())
 
-    def cleanup(self, cur_frame_idx):
-        self.cameras[cur_frame_idx].clean()
+    def cleanup(self, frame_idx):
+        self.cameras[frame_idx].clean()
 
     # ---- main loop (:603-833, single-thread schedule) ----------------------------------------------------------------------
+    def _wants_keyframe(self, cur_frame_idx, newest_kf, frames_since_kf, visibility):
+        """Keyframe decision of one tracked frame; returns (decision, overlap ratio for the log or None)."""
+        stats = kf.frame_statistics(self.cameras[cur_frame_idx], self.cameras[newest_kf], visibility, self.occ_aware_visibility[newest_kf])
+        by_motion = kf.keyframe_decision(stats, self.median_depth, self.thresholds)
+        iou, by_motion = torch.stack([stats[0], by_motion.to(stats.dtype)]).tolist()                  # the one host transfer of the decision
+        by_motion = by_motion > 0.5
+        due = frames_since_kf >= self.kf_interval
+        reported = None
+        if len(self.current_window) < self.window_size:                   # while the window fills up only the overlap counts (:716-728)
+            wanted, reported = due and iou < self.thresholds.overlap, iou
+        else:
+            wanted = by_motion
+        if self.single_thread:
+            wanted = due and wanted
+        forced = cur_frame_idx - newest_kf >= self.MIN_KEYFRAME_GAP or cur_frame_idx == self.dystart
+        new_object = self.dataset.dynamic_objects > self.dynamic_objects and cur_frame_idx > 0
+        return bool(wanted or forced or new_object), reported
+
+    def _insert_keyframe(self, cur_frame_idx, viewpoint, visibility, render_pkg, overlap):
+        self.current_window, _ = self.add_to_window(cur_frame_idx, visibility, self.occ_aware_visibility, self.current_window)
+        depth_map = self.add_new_keyframe(cur_frame_idx, depth=render_pkg["depth"], opacity=render_pkg["opacity"], init=False)
+        self.sync_backend(self.backend.handle_keyframe(cur_frame_idx, viewpoint, self.current_window, depth_map, True, False))
+        self.log.append(("keyframe", cur_frame_idx, overlap))
+        viewpoint.clean_key()
+        if self.save_results and self.save_trj and len(self.kf_indices) % self.save_trj_kf_intv == 0:
+            eval_ate(self.cameras, self.kf_indices, self.save_dir, cur_frame_idx, monocular=self.monocular)
+
     def run(self, max_frames=None):
-        cur_frame_idx, last_keyframe_idx = 0, 0
-        projection_matrix = self.dataset.projection_matrix
         n_frames = len(self.dataset) if max_frames is None else min(max_frames, len(self.dataset))
-        while cur_frame_idx < n_frames:
-            viewpoint = Camera.init_from_dataset(self.dataset, cur_frame_idx, projection_matrix)
+        previous_kf = 0                                   # the window's newest keyframe as of the previous frame
+        for cur_frame_idx in range(n_frames):
+            viewpoint = Camera.init_from_dataset(self.dataset, cur_frame_idx, self.dataset.projection_matrix)
             viewpoint.compute_grad_mask(self.config)
             self.cameras[cur_frame_idx] = viewpoint
-            if self.reset:
+            if self.reset:                                # first frame: build the map from it
                 self.initialize(cur_frame_idx, viewpoint)
-                self.current_window.append(cur_frame_idx)
-                cur_frame_idx += 1
+                self.current_window += [cur_frame_idx]
                 torch.cuda.synchronize(self.device)
-                self.init_done_at = time.perf_counter()       # map initialisation (hundreds of iterations on one frame) is reported apart
+                self.init_done_at = time.perf_counter()   # map initialisation (hundreds of iterations on one frame) is reported apart
                 continue
-            self.initialized = self.initialized or (len(self.current_window) == self.window_size)
-            render_pkg = self.tracking(cur_frame_idx, viewpoint, last_keyframe_idx)
-            check_time = (cur_frame_idx - last_keyframe_idx) >= self.kf_interval
-            last_keyframe_idx = self.current_window[0]
-            curr_visibility = (render_pkg["n_touched"] > 0).long()
-            create_kf = self.is_keyframe(cur_frame_idx, last_keyframe_idx, curr_visibility, self.occ_aware_visibility)
-            point_ratio = None
-            if len(self.current_window) < self.window_size:
-                union = torch.logical_or(curr_visibility, self.occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-                intersection = torch.logical_and(curr_visibility, self.occ_aware_visibility[last_keyframe_idx]).count_nonzero()
-                point_ratio = intersection / union
-                create_kf = bool(check_time and point_ratio < self.config["Training"]["kf_overlap"])
-            if self.single_thread:
-                create_kf = check_time and create_kf
-            create_kf = ((cur_frame_idx - last_keyframe_idx) >= 5) or create_kf or cur_frame_idx == self.dystart        # :739
-            if self.dataset.dynamic_objects > self.dynamic_objects and cur_frame_idx > 0:
-                create_kf = True
-            if create_kf:
-                self.current_window, removed = self.add_to_window(cur_frame_idx, curr_visibility, self.occ_aware_visibility, self.current_window)
-                depth_map = self.add_new_keyframe(cur_frame_idx, depth=render_pkg["depth"], opacity=render_pkg["opacity"], init=False)
-                self.sync_backend(self.backend.handle_keyframe(cur_frame_idx, viewpoint, self.current_window, depth_map, True, False))
-                self.log.append(("keyframe", cur_frame_idx, None if point_ratio is None else float(point_ratio)))
-                self.cameras[cur_frame_idx].clean_key()
-                if self.save_results and self.save_trj and len(self.kf_indices) % self.save_trj_kf_intv == 0:
-                    eval_ate(self.cameras, self.kf_indices, self.save_dir, cur_frame_idx, monocular=self.monocular)
+            self.initialized = self.initialized or len(self.current_window) == self.window_size
+            render_pkg = self.tracking(cur_frame_idx, viewpoint, previous_kf)
+            frames_since_kf = cur_frame_idx - previous_kf
+            previous_kf = newest_kf = self.current_window[0]
+            visibility = (render_pkg["n_touched"] > 0).long()
+            wanted, overlap = self._wants_keyframe(cur_frame_idx, newest_kf, frames_since_kf, visibility)
+            if wanted:
+                self._insert_keyframe(cur_frame_idx, viewpoint, visibility, render_pkg, overlap)
             else:
                 self.cleanup(cur_frame_idx)
-            cur_frame_idx += 1
             self.dynamic_objects = self.dataset.dynamic_objects
         if self.save_results and self.save_dir:
             eval_ate(self.cameras, self.kf_indices, self.save_dir, 0, final=True, monocular=self.monocular)
