@@ -170,6 +170,115 @@ def allreduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
 
 
+class ViewShard:
+    """Who renders which view of a mapping iteration, and the collectives that put the pieces back together.
+
+    Every rank holds a replica of the map and runs the SAME host program (same window, same random draws: seed every rank alike); a view
+    with index k in the iteration's view list is rendered, back-propagated and pose-stepped by rank ``k % world`` only. Per iteration:
+
+        reduce_gradients()    ONE all-reduce(sum) of the Gaussian gradients (the optimizer's flat bucket when FusedAdam keeps one) and one
+                              of the deformation / node network's, before the optimizer steps -- every replica then applies the same update;
+        sync_cameras()        the window cameras' poses and exposures, owner -> everyone (14 floats per camera, one small all-reduce);
+    and only on the iterations that need them:
+        reduce_statistics()   densification statistics: sum / sum / max over ranks, before densify_and_prune;
+        union()               a visibility mask OR-ed over ranks (opacity reset of the Gaussians no view saw);
+        gather_rows()         per-view rows (n_touched > 0 of the window keyframes) from their owners to everyone.
+    With one rank (or no process group) every method is a no-op that returns its input."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self._net_bucket = None
+        self.collectives = 0
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1
+
+    def owns(self, index: int) -> bool:
+        return index % self.world == self.rank
+
+    def owner(self, index: int) -> int:
+        return index % self.world
+
+    def _sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
+        return t
+
+    def reduce_gradients(self, optimizer, network_params=()):
+        """Gaussian gradients through the optimizer's flat bucket when it has one (FusedAdam with fused accumulation: the kernels already
+        summed this rank's views into it), else packed; parameters a rank has no gradient for count as zero. The network's gradients
+        ride a second bucket (different lifetime: the Gaussian bucket is rebuilt by every densification)."""
+        if not self.active:
+            return
+        bucket = getattr(optimizer, "_bucket", None)
+        params = [p for g_ in optimizer.param_groups for p in g_["params"]] if optimizer is not None else []
+        if optimizer is None:
+            pass
+        elif bucket is not None and getattr(bucket, "attached", False) and all(p.grad is v for p, v in zip(bucket.params, bucket.views)) \
+                and len(bucket.params) == len(params):
+            self._sum(bucket.flat)
+        else:
+            b = GradBucket(params)
+            b.pack()
+            self._sum(b.flat)
+            b.unpack()
+        net = [p for p in network_params if p.requires_grad]
+        if net:
+            key = tuple(id(p) for p in net)
+            if self._net_bucket is None or self._net_bucket[0] != key:
+                self._net_bucket = (key, GradBucket(net))
+            b = self._net_bucket[1]
+            b.pack()
+            self._sum(b.flat)
+            b.unpack()
+
+    def reduce_statistics(self, gaussians):
+        if self.active:
+            allreduce_densification_stats(gaussians.xyz_gradient_accum, gaussians.denom, gaussians.max_radii2D, self.group)
+            self.collectives += 2
+
+    def union(self, mask):
+        if not self.active:
+            return mask
+        m = mask.to(torch.int32)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        self.collectives += 1
+        return m.to(mask.dtype)
+
+    def gather_rows(self, rows, count, like):
+        """rows: {index: 1-D tensor} for the indices this rank owns, each shaped and typed like `like`; returns the list of all `count` rows."""
+        if not self.active:
+            return [rows[k] for k in range(count)]
+        full = torch.zeros((count,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+        for k, r in rows.items():
+            full[k] = r
+        self._sum(full)
+        return [full[k] for k in range(count)]
+
+    def sync_cameras(self, cameras):
+        """cameras: the iteration's view list (index = ownership index). Owner -> everyone: R, T, exposure_a, exposure_b."""
+        if not self.active or not cameras:
+            return
+        dev = cameras[0].R.device
+        pack = torch.zeros((len(cameras), 14), dtype=torch.float32, device=dev)
+        for k, c in enumerate(cameras):
+            if self.owns(k):
+                pack[k, :9] = c.R.reshape(-1)
+                pack[k, 9:12] = c.T.reshape(-1)
+                pack[k, 12] = c.exposure_a.detach().reshape(-1)[0]
+                pack[k, 13] = c.exposure_b.detach().reshape(-1)[0]
+        self._sum(pack)
+        with torch.no_grad():
+            for k, c in enumerate(cameras):
+                if not self.owns(k):
+                    c.update_RT(pack[k, :9].view(3, 3).clone(), pack[k, 9:12].clone())
+                    c.exposure_a.copy_(pack[k, 12].view_as(c.exposure_a))
+                    c.exposure_b.copy_(pack[k, 13].view_as(c.exposure_b))
+
+
 class ShardedMappingStep:
     """One mapping iteration over a set of keyframes, view-sharded (BASELINE config #5):
 

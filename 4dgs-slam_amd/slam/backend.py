@@ -4,14 +4,23 @@ control-node warp), color_refinement (:777-862) and the message handlers of run(
 
 Per mapping iteration: every window keyframe is rendered through the fused prologue, the mapping loss is the fused weighted L1, the
 densification statistics of a view are one launch, pose / exposure updates are one launch per camera, the six Gaussian groups are
-stepped by FusedAdam, and densify_and_prune rebuilds the model with one launch (slam/gaussian_model.py). The view-sharded multi-GPU
-form of the same iteration is mapping_shard.ShardedMappingStep; this class drives one GPU."""
+stepped by FusedAdam, and densify_and_prune rebuilds the model with one launch (slam/gaussian_model.py).
+
+Multi-GPU (north_star: "the mapping backend's per-keyframe render+backward is sharded across GPUs"): with a process group
+up, every rank runs this class on a replica of the map and the views of an iteration -- window keyframes, then the random ones -- are
+rendered, back-propagated and pose-stepped by rank ``index % world`` only (mapping_shard.ViewShard). Before the optimizers step, the
+Gaussian gradients (the optimizer's flat bucket: the backward kernels already summed the rank's views into it) and the node network's are
+all-reduced; the densification statistics, the visibility union of the opacity reset and the window keyframes' visibility rows are
+reduced only on the iterations that use them; the window cameras' poses / exposures travel owner -> everyone once per iteration (14
+floats each). The view-independent terms (isotropic-scale regulariser, ARAP / elastic node regularisers) are added on rank 0. All ranks
+must be seeded alike: they take the same random draws (extra keyframes, time samples, split noise)."""
 import random
 
 import numpy as np
 import torch
 
 from gaussian_renderer import render
+import mapping_shard
 import slam_losses
 
 from .deform_model import draw_loss_times
@@ -39,6 +48,18 @@ class BackEnd:
         self.pose_lr_scale = 0.5
         self.frames_to_optimize = config["Training"]["pose_window"]
         self.log = []
+        self._view_shard = None
+
+    @property
+    def shard(self):
+        """View ownership + collectives of the current process group (a no-op object in a single process)."""
+        if self._view_shard is None:
+            self._view_shard = mapping_shard.ViewShard()
+        return self._view_shard
+
+    def attach_process_group(self, group=None):
+        self._view_shard = mapping_shard.ViewShard(group)
+        return self._view_shard
 
     def set_hyperparams(self):
         # Training.loss_values (default False): the mapping loops only back-propagate their losses, so the value's two launches per view are
@@ -149,11 +170,16 @@ class BackEnd:
             loss_init.backward()
             with torch.no_grad():
                 self._view_stats(pkg)
+                if mapping_iteration % self.init_gaussian_update == 0:           # :209-215 (iteration 0 with the shipped schedule)
+                    g.densify_and_prune(self.opt_params.densify_grad_threshold, self.init_gaussian_th, self.init_gaussian_extent, None)
                 g.deform.optimizer.step()
                 g.deform.optimizer.zero_grad(set_to_none=True)
                 if update_gaussians:
                     g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
+        if pkg["n_touched"].shape[0] != g.get_xyz.shape[0]:                       # the model was rebuilt after the last render
+            with torch.no_grad():
+                pkg = self._render(viewpoint, self._deltas(viewpoint, train=False))
         self.occ_aware_visibility[cur_frame_idx] = (pkg["n_touched"] > 0).long()
 
     # ---- window optimisation --------------------------------------------------------------------------------------------
@@ -162,6 +188,8 @@ class BackEnd:
         lr = self.config["Training"]["lr"]
         for cam_idx in range(len(current_window)):
             viewpoint = viewpoint_stack[cam_idx]
+            if not self.shard.owns(cam_idx):          # another rank rendered this view: it holds the gradient and takes the step
+                continue
             if viewpoint.uid == 0:
                 for p in (viewpoint.cam_rot_delta, viewpoint.cam_trans_delta, viewpoint.exposure_a, viewpoint.exposure_b):
                     if p is not None:
@@ -169,6 +197,23 @@ class BackEnd:
                 continue
             viewpoint.pose_step(lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
                                 optimize_pose=cam_idx < self.frames_to_optimize, optimize_exposure=True)
+        self.shard.sync_cameras(viewpoint_stack[:len(current_window)])
+
+    def _publish_visibility(self, current_window, rows):
+        """occ_aware_visibility of the window keyframes (:661-665) from the rows their owners hold."""
+        like = torch.zeros(self.gaussians.get_xyz.shape[0], dtype=torch.int64, device=self.gaussians.get_xyz.device)
+        if rows:
+            like = torch.zeros_like(next(iter(rows.values())))
+        full = self.shard.gather_rows(rows, len(current_window), like)
+        self.occ_aware_visibility = {current_window[idx]: full[idx] for idx in range(len(current_window))}
+
+    def _reset_opacity_of_unseen(self, pkgs):
+        """reset_opacity_nonvisible (:722-728) with the visibility filters of ALL views of the iteration, whoever rendered them."""
+        g = self.gaussians
+        seen = torch.zeros(g.get_xyz.shape[0], dtype=torch.bool, device=g.get_xyz.device)
+        for p in pkgs:
+            seen |= p["visibility_filter"]
+        g.reset_opacity_nonvisible([self.shard.union(seen)])
 
     def _window_full_bookkeeping(self, current_window):
         """What remains of the reference's covisibility pruning (:663-696 / :1140-1170) for RGB-D input: once the window is full, the
@@ -193,34 +238,36 @@ class BackEnd:
         window_set = set(current_window)
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
         gaussian_split = False
-        for _ in range(iters):
+        shard = self.shard
+        for it in range(iters):
             self.iteration_count += 1
             self.last_sent += 1
             loss_mapping = 0
-            pkgs, n_touched_acm = [], []
-
-            def add_view(viewpoint):
+            pkgs, touched_rows = [], {}
+            extras = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]      # the same draw on every rank
+            for k, viewpoint in enumerate(viewpoint_stack + extras):
+                if not shard.owns(k):
+                    continue
                 pkg = self._render(viewpoint, (None, None, None))
                 loss = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True,
                                                     compute_value=self.loss_values)
                 pkgs.append(pkg)
+                if k < len(viewpoint_stack):
+                    touched_rows[k] = (pkg["n_touched"] > 0).long()
                 if self.loss_values:
-                    return loss
-                loss.backward()                      # this view's gradients now; the rasterizer state of the view is released right away
-                return 0
-
-            for cam_idx in range(len(current_window)):
-                loss_mapping = loss_mapping + add_view(viewpoint_stack[cam_idx])
-                n_touched_acm.append(pkgs[-1]["n_touched"])
-            for cam_idx in torch.randperm(len(random_viewpoint_stack))[:2]:
-                loss_mapping = loss_mapping + add_view(random_viewpoint_stack[cam_idx])
-            loss_mapping = loss_mapping + self._isotropic_loss()
-            loss_mapping.backward()
+                    loss_mapping = loss_mapping + loss
+                else:
+                    loss.backward()                  # this view's gradients now; the rasterizer state of the view is released right away
+            if shard.rank == 0:
+                loss_mapping = loss_mapping + self._isotropic_loss()
+            if torch.is_tensor(loss_mapping) and loss_mapping.requires_grad:
+                loss_mapping.backward()
+            shard.reduce_gradients(self.gaussians.optimizer)
             gaussian_split = False
             with torch.no_grad():
-                self.occ_aware_visibility = {}
-                for idx in range(len(current_window)):
-                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                last = it == iters - 1
+                if prune or last or shard.world == 1:
+                    self._publish_visibility(current_window, touched_rows)
                 if prune:
                     self._window_full_bookkeeping(current_window)
                     self.gaussians.optimizer.zero_grad(set_to_none=True)
@@ -230,15 +277,17 @@ class BackEnd:
                     self._view_stats(pkg)
                 update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
                 if update_gaussian:
+                    shard.reduce_statistics(self.gaussians)
                     self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
                     gaussian_split = True
                 if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian:
-                    self.gaussians.reset_opacity_nonvisible([p["visibility_filter"] for p in pkgs])
+                    self._reset_opacity_of_unseen(pkgs)
                     gaussian_split = True
                 self.gaussians.optimizer.step()                 # rebuilt parameters have no gradient yet and are skipped, like in the reference
                 self.gaussians.optimizer.zero_grad(set_to_none=True)
                 self.gaussians.update_learning_rate(self.iteration_count)
                 self._pose_updates(viewpoint_stack, current_window)
+                self._clear_camera_grads(extras)
         return gaussian_split
 
     def _clear_camera_grads(self, cams):
@@ -249,7 +298,9 @@ class BackEnd:
 
     def map(self, current_window, prune=False, iters=1, dynamic_network=False):
         """:306-774 with the control-node warp on the dynamic subset. The optical-flow term of the reference (:479-509) needs RAFT;
-        when the dataset can supply a flow (``dataset.gt_flow``) the same term is formed with render_flow, otherwise it is skipped."""
+        when the dataset can supply a flow (``dataset.gt_flow``) the same term is formed with render_flow, otherwise it is skipped.
+        Not reproduced: the reference optimises ``current_window[:3]`` plus the keyframes Camera.keyframe_selection_overlap picks
+        (:310-318) and draws its random views from the complement of THAT set; here the whole window is optimised, as in map_static."""
         if len(current_window) == 0:
             return
         g = self.gaussians
@@ -258,6 +309,7 @@ class BackEnd:
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
         use_net = dynamic_network and g.deform_init
         gaussian_split = False
+        shard = self.shard
         for i in range(iters):
             if i > 100:
                 self.iteration_count += 1                                   # :337-338
@@ -267,29 +319,33 @@ class BackEnd:
             dynamic = i < iters / 2                                          # :350-355
             t = self.config["Training"]
             flow_weight = t["flow_loss"] if dynamic else t.get("flow_loss_fine", t["flow_loss"])
-            pkgs, n_touched_acm = [], []
-            views = [viewpoint_stack[c] for c in range(len(current_window))]
-            extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]
+            pkgs, touched_rows = [], {}
+            views = list(viewpoint_stack)
+            extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]      # the same draw on every rank
             with_flow = use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow")
-            if use_net:       # every time sample this iteration asks the node network for, as one batch (deform_model.begin_iteration)
+            if use_net:       # every time sample this rank asks the node network for in this iteration, as one batch (deform_model.begin_iteration)
                 nodes, times, plans = g.deform.deform, [], []
                 arap_delta = float(t.get("delta", 5)) * g.time_interval              # :325,:518
                 for k, viewpoint in enumerate(views + extra):
                     # the regularisers' random time samples (:517-519 window views: ARAP with 4 samples over `delta` intervals; :646-648
-                    # random views: ARAP with 2 samples over 5 intervals; elastic: 8 samples over 5 intervals for both)
+                    # random views: ARAP with 2 samples over 5 intervals; elastic: 8 samples over 5 intervals for both). Drawn on every
+                    # rank (the ranks' random streams stay in step); the regularisers themselves are rank 0's.
                     window = k < len(views)
                     plan = draw_loss_times(viewpoint.time, arap_delta if window else 5 * g.time_interval, 4 if window else 2, 5 * g.time_interval)
                     plans.append(plan)
-                    times += [viewpoint.time] + plan["arap"] + plan["elastic"]
-                    closest = self.find_closest_keyframe(viewpoint.uid) if with_flow else None
+                    if shard.owns(k):
+                        times.append(viewpoint.time)
+                    if shard.rank == 0:
+                        times += plan["arap"] + plan["elastic"]
+                    closest = self.find_closest_keyframe(viewpoint.uid) if (with_flow and shard.owns(k)) else None
                     if closest is not None:
                         times.append(self.viewpoints[closest].time)
                 nodes.begin_iteration(times)
                 self._delta_cache = {}
                 # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
                 nv = len(views)
-                wts = torch.tensor([1e-3] * nv + [1e-4] * len(extra), dtype=torch.float32, device=self.device)
-                if nodes.node_num >= 3:
+                if nodes.node_num >= 3 and shard.rank == 0:
+                    wts = torch.tensor([1e-3] * nv + [1e-4] * len(extra), dtype=torch.float32, device=self.device)
                     reg = (nodes.elastic_loss_batch([p_["elastic"] for p_ in plans]) * wts).sum()
                     if nv:
                         reg = reg + (wts[:nv] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[:nv]])).sum()
@@ -297,6 +353,8 @@ class BackEnd:
                         reg = reg + (wts[nv:] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[nv:]])).sum()
                     loss_network = loss_network + reg
             for k, viewpoint in enumerate(views + extra):
+                if not shard.owns(k):
+                    continue
                 deltas = self._deltas(viewpoint) if use_net else (None, None, None)
                 pkg = self._render(viewpoint, deltas)
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
@@ -305,18 +363,21 @@ class BackEnd:
                     loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
                 pkgs.append(pkg)
                 if k < len(views):
-                    n_touched_acm.append(pkg["n_touched"])
-            loss_mapping = loss_mapping + self._isotropic_loss()
+                    touched_rows[k] = (pkg["n_touched"] > 0).long()
+            if shard.rank == 0:
+                loss_mapping = loss_mapping + self._isotropic_loss()
             total = loss_mapping + loss_network if use_net else loss_mapping
-            total.backward()
+            if torch.is_tensor(total) and total.requires_grad:
+                total.backward()
             if use_net:
                 g.deform.deform.end_iteration()
                 self._delta_cache = None
+            # (the Gaussians only step after the network's warm-up, :765-770: before that their gradients are dropped unreduced)
+            shard.reduce_gradients(g.optimizer if i > 100 else None, [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else ())
             gaussian_split = False
             with torch.no_grad():
-                self.occ_aware_visibility = {}
-                for idx in range(len(current_window)):
-                    self.occ_aware_visibility[current_window[idx]] = (n_touched_acm[idx] > 0).long()
+                if prune or i == iters - 1 or shard.world == 1:
+                    self._publish_visibility(current_window, touched_rows)
                 if prune:
                     self._window_full_bookkeeping(current_window)
                     g.optimizer.zero_grad(set_to_none=True)
@@ -328,10 +389,11 @@ class BackEnd:
                     self._view_stats(pkg)
                 update_gaussian = (self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset) and i > 100
                 if update_gaussian:
+                    shard.reduce_statistics(g)
                     g.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
                     gaussian_split = True
                 if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian and i > 100:
-                    g.reset_opacity_nonvisible([p["visibility_filter"] for p in pkgs])
+                    self._reset_opacity_of_unseen(pkgs)
                     gaussian_split = True
                 self._pose_updates(viewpoint_stack, current_window)
                 self._clear_camera_grads(extra)
@@ -379,9 +441,12 @@ class BackEnd:
         """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""
         lam = self.opt_params.lambda_dssim
         ids = list(self.viewpoints.keys())
+        shard = self.shard
         for iteration in range(1, iteration_total + 1):
             loss = 0
-            for idx in random.sample(ids, min(views_per_iter, len(ids))):
+            for k, idx in enumerate(random.sample(ids, min(views_per_iter, len(ids)))):      # the same draw on every rank
+                if not shard.owns(k):
+                    continue
                 cam = self.viewpoints[idx]
                 pkg = self._render(cam, self._deltas(cam))
                 image = torch.exp(cam.exposure_a) * pkg["render"] + cam.exposure_b
@@ -392,8 +457,11 @@ class BackEnd:
                 gt_depth = cam.depth_device()[None]
                 dm = (gt_depth > 0.01) if mm is None else (gt_depth > 0.01) & mm[None]
                 loss = loss + 0.1 * torch.abs(pkg["depth"] * dm - gt_depth * dm).mean()
-            loss = loss + self._isotropic_loss()
-            loss.backward()
+            if shard.rank == 0:
+                loss = loss + self._isotropic_loss()
+            if torch.is_tensor(loss) and loss.requires_grad:
+                loss.backward()
+            shard.reduce_gradients(self.gaussians.optimizer)
             with torch.no_grad():
                 self.gaussians.optimizer.step()
                 self.gaussians.optimizer.zero_grad(set_to_none=True)

@@ -273,7 +273,7 @@ class GaussianModel:
         assert len(extra) == 3 * (self.max_sh_degree + 1) ** 2 - 3
         f_extra = np.stack([col[n] for n in extra], axis=1).reshape(P, 3, (self.max_sh_degree + 1) ** 2 - 1) if extra else np.zeros((P, 3, 0), np.float32)
         sc = sorted((n for n in names if n.startswith("scale_")), key=lambda x: int(x.split("_")[-1]))
-        rt = sorted((n for n in names if n.startswith("rot")), key=lambda x: int(x.split("_")[-1]))
+        rt = sorted((n for n in names if n.startswith("rot_")), key=lambda x: int(x.split("_")[-1]))
         self._xyz = nn.Parameter(T(xyz).requires_grad_(True))
         self._features_dc = nn.Parameter(T(f_dc).transpose(1, 2).contiguous().requires_grad_(True))
         self._features_rest = nn.Parameter(T(f_extra).transpose(1, 2).contiguous().requires_grad_(True))
@@ -285,6 +285,11 @@ class GaussianModel:
         self.max_radii2D = torch.zeros((P,), device=dev)
         self.unique_kfIDs = torch.zeros((P,), dtype=torch.int32, device=dev)
         self.n_obs = torch.zeros((P,), dtype=torch.int32, device=dev)
+        # densification statistics and the optimizer belong to the tensors that were just replaced: fresh statistics, and the optimizer
+        # (if one was set up) is dropped -- call training_setup() again before training the loaded map
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.optimizer = None
 
     # ---- optimizer-state surgery (GM:734-865) -----------------------------------------------------------------------------
     def _group(self, name):

@@ -58,7 +58,7 @@ class _WeightedL1(torch.autograd.Function):
         if not compute_value:
             # the caller only back-propagates (a tracking iteration inside a hipGraph): the value's two launches are skipped; the backward
             # kernels need nothing from them (the workspace is their scratch)
-            loss = torch.empty((), dtype=torch.float32, device=image.device)
+            loss = torch.zeros((), dtype=torch.float32, device=image.device)     # a defined placeholder (NOT the loss): sums and logs stay finite
             ws = torch.empty((int(_lib().gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=image.device)
             ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity)
             return loss
