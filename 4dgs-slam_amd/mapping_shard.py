@@ -10,12 +10,13 @@ the rank that owns the view (utils/slam_backend.py:955-992).
 Backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` in the CPU tests. One flat bucket, one collective per step:
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a single large all-reduce beats many small ones.
 
-Why there is ONE exposed all-reduce and nothing overlapped with it: the sum over views is linear, every parameter's gradient is
-complete only when the LAST view's geometry kernel has run (the fused K8+K9 kernel writes all five tensors at once), and the optimizer
-needs the reduced sum before the next forward pass. Splitting the exchange (reduce the first n-1 views early, the last one at the
-end) moves no bytes off the critical path: a full-size exchange still follows the last backward. SURVEY.md 8e's "start the
-all-reduce of SH / opacity while K8/K9 run" would overlap with ~0.3 ms of a ~1.3 ms exchange at config #5 (2 M Gaussians); it is not
-built. `GradBucket.attach()` removes the other cost -- pack / unpack copies -- for every parameter layout, channels-last included.
+What can overlap with that all-reduce: the sum over views is linear, every parameter's gradient is complete only when the LAST view's
+geometry kernel has run (the fused K8+K9 kernel writes all five tensors at once), and the optimizer needs the reduced sum before the
+next forward pass -- so a full-size exchange always follows the last backward pass. ``ShardedMappingStep(overlap=True)`` nevertheless
+splits the exchange in two (the first n - 1 views' sum goes out asynchronously while the last view renders into a second bucket):
+it hides the first collective's start-up and rank imbalance, not bytes; it is off by default and ``bench.py`` reports both forms when it
+runs on more than one GPU. `GradBucket.attach()` removes the other cost -- pack / unpack copies -- for every parameter layout,
+channels-last included.
 """
 from __future__ import annotations
 
@@ -289,7 +290,7 @@ class ShardedMappingStep:
 
     ``params`` in the optimizer's order; ``view_fn(k)`` must leave pose / exposure gradients alone (they belong to the owner)."""
 
-    def __init__(self, params, keyframe_ids, view_fn, optimizer=None, group=None):
+    def __init__(self, params, keyframe_ids, view_fn, optimizer=None, group=None, overlap=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -297,13 +298,42 @@ class ShardedMappingStep:
         self.view_fn = view_fn
         self.optimizer = optimizer
         self.bucket = GradBucket(params).attach()
+        # overlap (SURVEY.md 8e "Overlap"): the exchange in two pieces -- the sum of this rank's first n - 1 views is all-reduced
+        # asynchronously WHILE the last view renders into a second bucket, which is reduced behind it; the two reduced pieces are added.
+        # What it buys is bounded: the second piece is as large as the whole bucket, so the bytes behind the last backward pass are the
+        # same; only the latency of the first collective's start-up and any imbalance between ranks hide behind the last view.
+        self.overlap = bool(overlap) and len(self.keyframes) >= 2
+        self.last_bucket = GradBucket(params) if self.overlap else None
         self.mode = None
+        self.allreduce_calls = 0
+
+    def _collectives_on(self):
+        return dist.is_available() and dist.is_initialized() and (self.world > 1 or _force_collective())
 
     def step(self):
-        self.bucket.zero_grads()
-        for k in self.keyframes:
-            self.view_fn(k)
-        self.mode = self.bucket.all_reduce_grads(self.group)
+        if not self.overlap:
+            self.bucket.zero_grads()
+            for k in self.keyframes:
+                self.view_fn(k)
+            self.mode = self.bucket.all_reduce_grads(self.group)
+            self.allreduce_calls += 0 if self.mode == "single" else 1
+        else:
+            first, last = self.bucket, self.last_bucket
+            first.attach()
+            first.flat.zero_()
+            for k in self.keyframes[:-1]:
+                self.view_fn(k)
+            work = dist.all_reduce(first.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self._collectives_on() else None
+            last.attach()                                    # the parameters' .grad now point into the second bucket
+            last.flat.zero_()
+            self.view_fn(self.keyframes[-1])
+            if self._collectives_on():
+                dist.all_reduce(last.flat, op=dist.ReduceOp.SUM, group=self.group)
+                work.wait()
+                self.allreduce_calls += 2
+            first.flat.add_(last.flat)
+            first.attach()                                   # the optimizer reads the total through the parameters' .grad
+            self.mode = "two-piece"
         if self.optimizer is not None:
             self.optimizer.step()
         return self.mode

@@ -18,7 +18,10 @@ One JSON line on rank 0 with `roofline` (dominant kernel = render_bwd, HIP event
 `cpu_baseline` (BASELINE.md's baseline A: the tile-binned pure-PyTorch CPU rasterizer oracle/torch_raster.py on all host cores; the
 single-core figure, and the C port single-threaded and under OpenMP, ride along). The oracle package is imported ONLY for that leg,
 outside the timed region. At N = 1 the line also carries a short cfg5 measurement (`config5`), at N > 1 a short weak-scaling
-cfg2 measurement (`weak_200k`) and rank 0's single-GPU time for the same cfg5 iteration (`n1_reference`).
+cfg2 measurement (`weak_200k`), rank 0's single-GPU time for the same cfg5 iteration (`n1_reference`) with `speedup_vs_n1` / `efficiency`
+derived from it, the ranks that took part (`ranks_seen`), the all-reduce alone (`allreduce_ms`) and the step with the exchange in two
+overlapped pieces (`two_piece_exchange_ms_per_step`). The N > 1 lines name their metric "Gaussian-views/s": a different workload and
+unit than the N = 1 headline, whose same-workload point is `config5` (N = 1) / `n1_reference` (N > 1).
 """
 import argparse
 import json
@@ -94,6 +97,36 @@ class Scene:
         return int((radii > 0).sum().item()), int(nr)
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (4dgs-slam_amd/csrc/*, include/*): identifies the code a committed PMC traffic figure belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(PKG, "csrc"), os.path.join(REPO, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".h", ".hip", ".cpp", ".sh")):
+                h.update(name.encode())
+                h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel="render_bwd"):
+    """HBM traffic per launch of the dominant kernel from the newest committed PMC collection (profiles/r*_hbm_traffic.json; a run under
+    rocprofv3 --pmc cannot be part of a timed bench) -- used ONLY if the file was collected on exactly these kernel sources."""
+    import glob
+    digest = csrc_digest()
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        src = {"file": os.path.relpath(f, REPO), "collected_at_head": d.get("head"), "collected_on_csrc_sha256": d.get("csrc_sha256"), "bench_csrc_sha256": digest}
+        if d.get("csrc_sha256") == digest:
+            return d.get(f"{kernel}_bytes_per_launch"), src
+        src["refused"] = "collected on different kernel sources: not quoted"
+        return None, src
+    return None, {"file": None, "bench_csrc_sha256": digest}
+
+
 def note(msg):
     """progress on stderr (the JSON line on stdout stays the only stdout output)"""
     if os.environ.get("RANK", "0") == "0":
@@ -126,12 +159,16 @@ def run_cfg2(scene, world, rank, steps, warmup, barrier, k):
     return timed(step, steps, warmup, barrier), mode.get("allreduce"), step
 
 
-def make_cfg5(scene, keyframes):
+def make_cfg5(scene, keyframes, overlap=False, local=False):
+    """The config #5 iteration. local=True: every keyframe on THIS rank, no collective (the single-GPU point of the scaling curve)."""
     from fused_adam import FusedAdam
     from mapping_shard import ShardedMappingStep
     opt = FusedAdam([{"params": [p], "lr": 0.0, "name": n} for p, n in zip(scene.params, ("xyz", "f", "opacity", "scaling", "rotation"))],
                     lr=0.0, eps=1e-15)      # lr = 0: the full Adam arithmetic runs, the scene (hence the workload) stays put
-    sms = ShardedMappingStep(scene.params, keyframes, lambda k: scene.fwd_bwd(k), optimizer=opt)
+    sms = ShardedMappingStep(scene.params, keyframes, lambda k: scene.fwd_bwd(k), optimizer=opt, overlap=overlap)
+    if local:
+        sms.world, sms.rank, sms.keyframes, sms.overlap = 1, 0, list(keyframes), False
+        sms.bucket.all_reduce_grads = lambda group=None: "single"
 
     def step():
         scene.theta.grad = scene.rho.grad = scene.means2D.grad = None
@@ -207,9 +244,15 @@ def cpu_baselines(scene_g, cam, gc, gd, P, sh_degree, budget_s):
 
     prev = torch.get_num_threads()
     note(f"cpu baseline A: torch tile-binned rasterizer, {cores} threads")
-    allc = sample(cores, 5)
-    note(f"  all cores: {allc['seconds_window']:.2f} s per window sample")
-    one = sample(1, 3) if allc["seconds_window"] * 6 < budget_s else None
+    allc = sample(cores, 3)
+    note(f"  all cores: {allc['seconds_window']:.2f} s per window sample -> {allc['seconds_full_extrapolated']:.1f} s estimated for the frame")
+    # the whole frame, measured (not extrapolated), when the estimate says it fits the budget; the window estimate stays as a cross-check
+    full_measured = None
+    if allc["seconds_full_extrapolated"] < 0.6 * budget_s:
+        torch.set_num_threads(cores)
+        full_measured = torch_once(None)
+        note(f"  full frame measured: {full_measured:.2f} s")
+    one = sample(1, 3) if allc["seconds_window"] * 6 + (full_measured or 0) < budget_s else None
     torch.set_num_threads(prev)
     note("cpu baseline port: C oracle, 1 thread, then OpenMP")
 
@@ -226,11 +269,19 @@ def cpu_baselines(scene_g, cam, gc, gd, P, sh_degree, budget_s):
     t_port1 = port("serial", 1)
     t_omp = min(port("omp", cores) for _ in range(2))
     oracle.set_variant("serial")
-    base = {"value": allc["value"], "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_raster.py (tile-binned pure-PyTorch CPU rasterizer = BASELINE.md baseline A; this repo's restatement, the reference has "
-                      f"no CPU path), fwd+bwd of the full {P} Gaussians @{WIDTH}x{HEIGHT}: per-Gaussian stage over all P, then a centred window of {n_win} of "
-                      f"{gx * gy} tiles composited and back-propagated, median of 5, extrapolated linearly in the tile count "
-                      f"({allc['seconds_window']:.2f} s per sample -> {allc['seconds_full_extrapolated']:.1f} s for the frame), torch.set_num_threads({cores})",
+    what = (f"oracle/torch_raster.py (tile-binned pure-PyTorch CPU rasterizer = BASELINE.md baseline A; this repo's restatement, the reference has "
+            f"no CPU path), fwd+bwd of the full {P} Gaussians @{WIDTH}x{HEIGHT}, torch.set_num_threads({cores}): ")
+    if full_measured is not None:
+        value = P / full_measured
+        what += (f"ONE full frame measured ({full_measured:.2f} s, all {gx * gy} tiles composited and back-propagated); cross-check: a centred window of "
+                 f"{n_win} tiles extrapolated linearly in the tile count gives {allc['seconds_full_extrapolated']:.1f} s")
+    else:
+        value = allc["value"]
+        what += (f"per-Gaussian stage over all P, then a centred window of {n_win} of {gx * gy} tiles composited and back-propagated, median of 3, "
+                 f"EXTRAPOLATED linearly in the tile count ({allc['seconds_window']:.2f} s per sample -> {allc['seconds_full_extrapolated']:.1f} s for "
+                 f"the frame: the full frame did not fit the time budget on this host)")
+    base = {"value": value, "unit": "Gaussians/s", "cores": cores, "kind": "port", "sample": what,
+            "seconds_full_frame_measured": full_measured, "seconds_full_frame_window_estimate": allc["seconds_full_extrapolated"],
             "torch_one_core": None if one is None else {"value": one["value"], "cores": 1, "seconds_full_extrapolated": one["seconds_full_extrapolated"]}}
     port_line = {"value": P / t_port1, "unit": "Gaussians/s", "cores": 1, "kind": "port",
                  "sample": f"oracle/gs_oracle.c, one full fwd+bwd of the same workload ({t_port1:.2f} s), single-threaded",
@@ -260,7 +311,7 @@ def main():
         P = args.gaussians or CFG2_P
         g = make_gaussians(P, cam, seed=0, sh_degree=args.sh_degree or 0, scale_mean=args.scale_mean or 0.005)
         gc, gd = make_cotangents(cam, seed=1)
-        a, b = cpu_baselines(g, cam, gc, gd, P, args.sh_degree or 0, budget_s=60.0)
+        a, b = cpu_baselines(g, cam, gc, gd, P, args.sh_degree or 0, budget_s=90.0)
         print(json.dumps({"cpu_baseline": a, "cpu_baseline_port": b}), flush=True)
         return
 
@@ -340,13 +391,7 @@ def main():
             b_total, b_dom = algorithmic_bytes(P, V, nr, N, M)
             dom_s = dom_ms / max(dom_calls, 1) * 1e-3
             achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
-            traffic = None
-            tfile = os.path.join(REPO, "profiles", "r02_hbm_traffic.json")
-            if os.path.exists(tfile) and workload == "cfg2" and P == CFG2_P:
-                try:
-                    traffic = json.load(open(tfile)).get("render_bwd_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            traffic, traffic_source = (committed_traffic("render_bwd") if workload == "cfg2" and P == CFG2_P else (None, None))
             out = {
                 "metric": "rasterized Gaussians/s fwd+bwd @640x480 (200k G)", "value": world * P * args.steps / dt, "unit": "Gaussians/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -356,10 +401,11 @@ def main():
                                        + (f", {world} views sharded + RCCL all-reduce of gradients" if world > 1 else ""),
                            "visible": V, "instances": nr, "pixels": N, "host_binding": _C.binding()},
                 "roofline": {"bound": "hbm", "kernel": "render_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                             "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
                              "whole_step_algorithmic_bytes": b_total, "whole_step_GBps": b_total / (dt / args.steps) / 1e9,
                              "pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None,
-                             "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; profiles/r02_*counters*): frac is reported "
+                             "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; profiles/r03_phase_cycles.json): frac is reported "
                                      "against the HBM roof because north_star asks for it"},
                 "kernel_us": kern,
             }
@@ -400,6 +446,17 @@ def main():
                 sms.bucket.all_reduce_grads()
             barrier()
             ar_ms = (time.perf_counter() - t0) / 5 * 1e3
+        # who took part (an all-gather of rank ids over RCCL), and the same step with the exchange in two pieces (mapping_shard: overlap)
+        ranks_seen, two_piece_ms = [0], None
+        if world > 1:
+            ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+            ranks_seen = sorted(int(t.item()) for t in ids)
+            if len(sms.keyframes) >= 2:
+                sms2, step2 = make_cfg5(scene, kfs, overlap=True)
+                two_piece_ms = reduce_max(timed(step2, max(2, args.steps // 2), 1, barrier)) / max(2, args.steps // 2) * 1e3
+                del sms2
+                sms.bucket.attach()
         facts = [scene.view_facts(k) for k in sms.keyframes]
         if rank == 0:
             Vm, Rm = sum(f[0] for f in facts) / len(facts), sum(f[1] for f in facts) / len(facts)
@@ -408,9 +465,11 @@ def main():
             dom_s = dom_ms / max(dom_calls, 1) * 1e-3
             achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
             out = {
-                "metric": "rasterized Gaussians/s fwd+bwd @640x480 (200k G)", "value": P * len(kfs) * args.steps / dt, "unit": "Gaussians/s",
+                "metric": f"rasterized Gaussian-views/s fwd+bwd @640x480 ({P // 1000}k G x {len(kfs)} keyframes, view-sharded mapping iteration incl. all-reduce + Adam)",
+                "value": P * len(kfs) * args.steps / dt, "unit": "Gaussian-views/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "ranks_seen": ranks_seen, "allreduce_ms": ar_ms, "two_piece_exchange_ms_per_step": two_piece_ms,
                 "config": {"workload": f"configs[4]: {P} Gaussians, {len(kfs)} synthetic keyframes @{WIDTH}x{HEIGHT} sharded {world}-way ({len(sms.keyframes)} views per rank, "
                                        f"gradients accumulated locally), ONE all-reduce of {sms.bucket.nbytes} B, fused Adam step; value = Gaussian-views/s",
                            "views_per_rank": len(sms.keyframes), "allreduce_bytes": sms.bucket.nbytes, "allreduce_mode": sms.mode, "allreduce_ms": ar_ms,
@@ -436,15 +495,7 @@ def main():
                 del scene, sms
                 torch.cuda.empty_cache()
                 s1 = Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs))
-                from fused_adam import FusedAdam
-                opt = FusedAdam([{"params": [p], "lr": 0.0} for p in s1.params], lr=0.0, eps=1e-15)
-
-                def step1():
-                    for p_ in s1.params + [s1.theta, s1.rho, s1.means2D]:
-                        p_.grad = None
-                    for k in kfs:
-                        s1.fwd_bwd(k)
-                    opt.step()
+                _, step1 = make_cfg5(s1, kfs, local=True)           # the same code path (attached bucket, fused accumulation, fused Adam)
                 step1()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -453,6 +504,8 @@ def main():
                 torch.cuda.synchronize()
                 t1 = (time.perf_counter() - t0) / 2
                 out["n1_reference"] = {"ms_per_step": t1 * 1e3, "value": P * len(kfs) / t1, "note": "the same iteration on rank 0's GPU alone, no collective"}
+                out["speedup_vs_n1"] = t1 * 1e3 / out["ms_per_step"]
+                out["efficiency"] = out["speedup_vs_n1"] / world
             barrier()
 
     if rank == 0 and not args.no_cpu_baseline and world == 1 and workload in ("cfg2", "long"):

@@ -222,6 +222,11 @@ def test_bench_multi_rank_code_paths_on_one_gpu():
     assert d["roofline"]["kernel"] == "render_bwd" and d["roofline"]["achieved"] > 0
     # both ranks share ONE GPU and the collective goes through gloo (host copies), so the 2-rank step is slower than rank 0 alone
     assert 0.03 < d["n1_reference"]["ms_per_step"] / d["ms_per_step"] < 3.0, d
+    # what a scaling curve needs on every N > 1 line: who took part, the same-workload single-GPU point and the ratios derived from it,
+    # the collective alone, the two-piece (overlapped) form of the exchange; and a metric string that names the unit of `value`
+    assert d["ranks_seen"] == [0, 1] and "Gaussian-views/s" in d["metric"] and d["unit"] == "Gaussian-views/s"
+    assert abs(d["speedup_vs_n1"] - d["n1_reference"]["ms_per_step"] / d["ms_per_step"]) < 1e-9 and abs(d["efficiency"] - d["speedup_vs_n1"] / 2) < 1e-9
+    assert d["allreduce_ms"] > 0 and d["two_piece_exchange_ms_per_step"] > 0
     w = _run_bench(["--steps", "3", "--warmup", "1", "--gaussians", "20000", "--workload", "cfg2", "--no-cpu-baseline"], nproc=2, port=29618)
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["value"] > 0 and "all-reduce" in w["config"]["workload"]
 

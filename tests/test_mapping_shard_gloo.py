@@ -217,3 +217,50 @@ def test_sharded_mapping_step_and_stats_reduction_two_ranks():
     np.testing.assert_allclose(acc, np.full((10, 1), 3.0))                 # 1 + 2
     np.testing.assert_allclose(den, np.full((10, 1), 4.0))                 # 1 + 3
     np.testing.assert_allclose(rad, np.maximum(np.arange(10.0), -np.arange(10.0) + 3))
+
+
+# ---- the exchange in two pieces (first n - 1 views reduced asynchronously while the last view runs) equals the single exchange ---------
+def _two_piece_worker(rank, world, port, ret):
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapping_shard import ShardedMappingStep
+    out = {}
+    for overlap in (False, True):
+        g = torch.Generator().manual_seed(0)                   # identical replicas on every rank, and for both forms
+        a = torch.nn.Parameter(torch.randn(40, 3, generator=g))
+        planes = torch.nn.Parameter(torch.randn(1, 4, 6, 5, generator=g).contiguous(memory_format=torch.channels_last))
+        opt = torch.optim.Adam([a, planes], lr=0.05)
+
+        def view_fn(k, a=a, planes=planes):
+            (torch.sin(a * (k + 1)).sum() + (planes ** 3).sum() * (0.1 * k + 0.2)).backward()
+
+        step = ShardedMappingStep([a, planes], list(range(8)), view_fn, optimizer=opt, overlap=overlap)
+        modes = [step.step() for _ in range(3)]
+        out[overlap] = (modes, a.detach().numpy().copy(), planes.detach().numpy().copy(), step.allreduce_calls, planes.grad.stride() == planes.stride())
+    if rank == 0:
+        ret.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_piece_exchange_equals_single_exchange():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29300 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_two_piece_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = ret.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one, two = out[False], out[True]
+    assert one[0] == ["attached"] * 3 and two[0] == ["two-piece"] * 3
+    assert one[3] == 3 and two[3] == 6                       # one collective per step vs two (the first of them asynchronous)
+    assert two[4]                                            # the channels-last gradient kept the parameter's strides
+    np.testing.assert_allclose(two[1], one[1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(two[2], one[2], rtol=1e-5, atol=1e-6)
