@@ -44,7 +44,7 @@ __device__ uint32_t g_geo_timing[8 * 4 * 8192];
 #define GEO_TICK(k)
 #endif
 template <bool RAW>
-__global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
+__device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
 {
     // RAW: the fused-prologue mode (raw.xyz != nullptr). As a template parameter the plain instantiation is straight-line code: with the
     // runtime test every parameter load sat in its own uniform branch with its own s_waitcnt behind it.
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 }
 
 // Last level of the pose-gradient sum: one block, 6 x 64 threads, fixed order.
-__global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
+__device__ __forceinline__ void tau_sum_body(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
 {
     const int k = threadIdx.x >> 6, lane = lane_id();
     float v = 0.f;
@@ -483,6 +483,19 @@ __global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* 
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if (lane == 0) out6[k] = v;
+}
+
+// ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
+// several views) ----------------------------------------------------------------------------------------------------------------------
+template <bool RAW>
+__global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
+{
+    geometry_bwd_body<RAW>(a);
+}
+
+__global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)
+{
+    tau_sum_body(nblocks, partials, out6);
 }
 
 }  // namespace gsr

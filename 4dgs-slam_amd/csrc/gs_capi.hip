@@ -24,6 +24,7 @@
 #include "../../include/gs_rasterizer.h"
 #include "../../include/simple_knn.h"
 #include "gs_backward.h"
+#include "gs_views.h"
 #include "gs_knn.h"
 #include "gs_loss.h"
 #include "gs_hexplane.h"
@@ -48,49 +49,6 @@ static thread_local std::string g_last_error;
         }                                                                                                \
     } while (0)
 
-// ---- scratch carving (same idea as rasterizer_impl.h:22-27 `obtain`, 256-byte aligned) -------------------------
-template <typename T>
-static inline void carve(char*& p, T*& ptr, size_t count)
-{
-    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
-    ptr = reinterpret_cast<T*>(a);
-    p = reinterpret_cast<char*>(ptr + count);
-}
-
-struct GeomState {
-    uint32_t* header;   // HDR_* words of gs_device.h
-    TileRec* rec; float* cov3D; uint8_t* clamped;
-    int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
-    float* tau_partials;   // [ceil(P/256)][6] per-block sums of dL_dtau (backward)
-    static GeomState from(char*& p, size_t P)
-    {
-        GeomState g;
-        const size_t nb = (P + GB - 1) / GB + 1;
-        carve(p, g.header, HDR_WORDS);
-        carve(p, g.rec, P);
-        carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
-        carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
-        carve(p, g.tau_partials, ((P + 255) / 256 + 1) * 6);
-        return g;
-    }
-};
-static inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
-struct ImageState {
-    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
-    float4* final_C;        // per pixel: colour / depth sums without the background term (render_bwd's chunk start-up needs them)
-    uint32_t* chunk_base;   // [T + 1] exclusive scan of ceil(tile list length / CHUNK)
-    uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
-    static ImageState from(char*& p, size_t N, size_t T, size_t P)
-    {
-        ImageState s;
-        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
-        // the flag word sits behind the per-tile counters (index T*CTR_STRIDE)
-        carve(p, s.tile_count, T * CTR_STRIDE + 64);
-        carve(p, s.tile_cursor, T * CTR_STRIDE);
-        carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
-        return s;
-    }
-};
 static size_t binning_bytes(size_t carve_R, size_t cap_sorted, size_t ntiles)
 {
     return (size_t)(carve_binning(nullptr, carve_R, cap_sorted, ntiles).end - (char*)nullptr) + 256;
@@ -158,14 +116,16 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 // binning allocation while the GPU is still busy with the preprocess).
 // ... all of it per (host thread, device): a thread that renders on several GPUs gets one mailbox and one capacity estimate per device
 // (the mailbox's device pointer is the one hipHostGetDevicePointer returns for THAT device).
+// ... and per view SLOT of the multi-view entry point (slot 0 = the single-view calls): the v-th view of consecutive mapping iterations
+// looks alike, the views of one iteration do not.
 struct SpecState { uint32_t* mailbox = nullptr; uint32_t* mailbox_dev = nullptr; uint32_t seq = 0; size_t last_R_alloc = 0; uint32_t last_max_tile = 0; };
-static thread_local SpecState t_spec[16];
-static thread_local SpecState* t_cur = &t_spec[0];
-static int select_device_state()
+static thread_local SpecState t_spec[16][MAX_VIEWS + 1];
+static thread_local SpecState* t_cur = &t_spec[0][0];
+static int select_device_state(int slot = 0)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    t_cur = &t_spec[dev];
+    t_cur = &t_spec[dev][slot];
     return dev;
 }
 #define t_mailbox (t_cur->mailbox)
@@ -183,6 +143,7 @@ static thread_local bool t_speculate = true;
 // bumped: a caller that uses lazy mode polls gsr_forward_status() at a convenient point and repeats the affected work eagerly.
 static thread_local bool t_lazy = false;
 static thread_local bool t_options_read = false;
+static thread_local unsigned t_views_batched = 0;
 static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] != '0' : true;   // sort short tile lists inside render_fwd
 static void read_option_env()
 {
@@ -191,6 +152,16 @@ static void read_option_env()
     if (const char* e = getenv("GSR_MAILBOX")) t_use_mailbox = e[0] != '0';
     if (const char* e = getenv("GSR_SPECULATE")) t_speculate = e[0] != '0';
     if (const char* e = getenv("GSR_LAZY")) t_lazy = e[0] != '0';
+}
+
+static int ensure_mailbox()
+{
+    if (!t_mailbox) {
+        GSR_HIP_CHECK(hipHostMalloc((void**)&t_mailbox, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
+        memset(t_mailbox, 0, 8 * sizeof(uint32_t));
+        GSR_HIP_CHECK(hipHostGetDevicePointer((void**)&t_mailbox_dev, t_mailbox, 0));
+    }
+    return 0;
 }
 
 static int wait_for_header(hipStream_t stream, const uint32_t* device_header, uint32_t seq, uint32_t out[4])
@@ -243,6 +214,7 @@ int gsr_set_option(const char* name, int value)
     read_option_env();
     if (!name) { g_last_error = "gsr_set_option: null name"; return GSR_ERR_INVALID_ARGUMENT; }
     const std::string n(name);
+    if (n == "views_batched") return (int)t_views_batched;     // read-only: multi-view calls of this thread that took the one-launch-per-stage path
     bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
     if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
@@ -313,7 +285,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                 const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                 const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream_, const gsr_raw_inputs* raw)
+                float* out_depth, float* out_opacity, int* radii, int* n_touched, int debug, void* stream_, const gsr_raw_inputs* raw, int slot = 0)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc) {
@@ -332,7 +304,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     }
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y, T = gx * gy;
     const size_t N = (size_t)width * height;
-    select_device_state();
+    select_device_state(slot);
 
     char* gchunk = geometry_alloc(geometry_user, gsr_geometry_buffer_size(P));
     char* ichunk = image_alloc(image_user, gsr_image_buffer_size(width, height, P));
@@ -420,11 +392,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                             : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
     {
         ScopedKernelTimer tm(K_SCAN, stream);
-        if (!t_mailbox) {
-            GSR_HIP_CHECK(hipHostMalloc((void**)&t_mailbox, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable));
-            memset(t_mailbox, 0, 8 * sizeof(uint32_t));
-            GSR_HIP_CHECK(hipHostGetDevicePointer((void**)&t_mailbox_dev, t_mailbox, 0));
-        }
+        { const int rc = ensure_mailbox(); if (rc) return rc; }
         if (++t_seq == 0) t_seq = 1;
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
                            img.ranges, img.tile_cursor, prefiltered ? flags : (const uint32_t*)nullptr, (uint32_t)cap, cap_tile, img.chunk_base,
@@ -556,6 +524,223 @@ int gsr_forward_raw(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_
 }
 
 }  // extern "C"
+
+// ---- multi-view entry point (include/gs_rasterizer.h, csrc/gs_views.h) ------------------------------------------------------------------
+namespace {
+struct CapturedAlloc { gsr_alloc_fn fn; void* user; char* got; };
+char* captured_alloc(void* u, size_t bytes)
+{
+    CapturedAlloc* c = static_cast<CapturedAlloc*>(u);
+    c->got = c->fn(c->user, bytes);
+    return c->got;
+}
+ViewDims view_dims(int P, int width, int height)
+{
+    ViewDims d;
+    d.P = P; d.W = width; d.H = height; d.gx = (width + TILE_X - 1) / TILE_X; d.gy = (height + TILE_Y - 1) / TILE_Y; d.T = d.gx * d.gy;
+    d.nblocks = (P + GB - 1) / GB;
+    return d;
+}
+}  // namespace
+
+static int forward_one_view(gsr_view& vw, int slot, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc, int P, int D, int M,
+                            const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier, float tan_fovx, float tan_fovy,
+                            int debug, void* stream)
+{
+    gsr_raw_inputs one = *in;
+    one.dx = vw.dx; one.ds = vw.ds; one.dr = vw.dr;
+    CapturedAlloc g{geometry_alloc, vw.geometry_user, nullptr}, b{binning_alloc, vw.binning_user, nullptr}, i{image_alloc, vw.image_user, nullptr};
+    const int rc = forward_impl(captured_alloc, &g, captured_alloc, &b, captured_alloc, &i, P, D, M, background, width, height, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, scale_modifier, nullptr, nullptr, vw.viewmatrix, vw.projmatrix, vw.cam_pos, tan_fovx, tan_fovy, 0, vw.out_color,
+                                vw.out_depth, vw.out_opacity, vw.radii, vw.n_touched, debug, stream, &one, slot);
+    if (rc < 0) return rc;
+    vw.geom_buffer = g.got; vw.binning_buffer = b.got; vw.image_buffer = i.got; vw.num_rendered = rc;
+    return 0;
+}
+
+extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc, int P, int D, int M,
+                                 const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier, float tan_fovx,
+                                 float tan_fovy, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V < 1 || V > MAX_VIEWS || !views || !in || P <= 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc || !background ||
+        M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M || in->gather || in->flow_proj1) {
+        g_last_error = "gsr_forward_views: invalid argument (1 <= V <= GSR_MAX_VIEWS, P > 0, raw inputs without gather / flow mode)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    for (int v = 0; v < V; v++) {
+        const gsr_view& w = views[v];
+        gsr_raw_inputs probe = *in; probe.dx = w.dx; probe.ds = w.ds; probe.dr = w.dr;
+        if (!w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.out_color || !w.out_depth || !w.out_opacity || !w.radii || !w.n_touched || !raw_inputs_ok(&probe, M)) {
+            g_last_error = "gsr_forward_views: null / inconsistent view descriptor"; return GSR_ERR_INVALID_ARGUMENT;
+        }
+    }
+    const ViewDims d = view_dims(P, width, height);
+    read_option_env();
+    // the batched path needs a capacity estimate for every slot (the first iteration of a window goes view by view and leaves one)
+    const int dev = select_device_state(0);
+    bool batched = !debug && t_speculate && use_lds_hist((size_t)d.T) && V > 1;
+    for (int v = 0; v < V && batched; v++) batched = t_spec[dev][v + 1].last_R_alloc != 0;
+    if (!batched) {
+        for (int v = 0; v < V; v++) {
+            const int rc = forward_one_view(views[v], v + 1, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier,
+                                            tan_fovx, tan_fovy, debug, stream_);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    static const int eager_max = getenv("GSR_EAGER_MAX") ? atoi(getenv("GSR_EAGER_MAX")) : 512 * 1024;
+    t_views_batched++;
+    ViewTable t;
+    memset(&t, 0, sizeof(t));
+    uint32_t want_tile = 0;
+    for (int v = 0; v < V; v++) want_tile = std::max(want_tile, t_spec[dev][v + 1].last_max_tile);
+    want_tile += want_tile / 4;
+    const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
+                            : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
+                            : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
+                            : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
+    for (int v = 0; v < V; v++) {
+        gsr_view& w = views[v];
+        select_device_state(v + 1);
+        { const int rc = ensure_mailbox(); if (rc) return rc; }
+        if (++t_seq == 0) t_seq = 1;
+        const size_t cap = t_last_R_alloc + t_last_R_alloc / 8 + 4096;
+        w.geom_buffer = geometry_alloc(w.geometry_user, gsr_geometry_buffer_size(P));
+        w.image_buffer = image_alloc(w.image_user, gsr_image_buffer_size(width, height, P));
+        w.binning_buffer = binning_alloc(w.binning_user, binning_bytes(cap, cap, (size_t)d.T));
+        if (!w.geom_buffer || !w.image_buffer || !w.binning_buffer) { g_last_error = "gsr_forward_views: allocation callback returned NULL"; return GSR_ERR_ALLOC; }
+        ViewSlot& s = t.v[v];
+        s.viewmatrix = w.viewmatrix; s.projmatrix = w.projmatrix; s.projmatrix_raw = w.projmatrix_raw; s.cam_pos = w.cam_pos;
+        s.dx = w.dx; s.ds = w.ds; s.dr = w.dr;
+        s.geom = w.geom_buffer; s.image = w.image_buffer; s.binning = w.binning_buffer;
+        s.out_color = w.out_color; s.out_depth = w.out_depth; s.out_opacity = w.out_opacity; s.radii = w.radii; s.n_touched = w.n_touched;
+        s.mailbox = t_use_mailbox ? t_mailbox_dev : nullptr; s.cap = (uint32_t)std::min<size_t>(cap, 0x7fffffffu); s.cap_tile = cap_tile; s.seq = t_seq;
+    }
+    PreprocessArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.gx = d.gx; a.gy = d.gy;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx);
+    a.prefiltered = 0; a.eager = P <= eager_max ? 1 : 0;
+    a.raw = to_device_view(in);
+    const dim3 gv((unsigned)d.nblocks, (unsigned)V), tv((unsigned)d.T, (unsigned)V);
+    const size_t hist_lds_bytes = (size_t)d.T * sizeof(uint32_t);
+    {
+        ScopedKernelTimer tm(K_PREPROCESS, stream);
+        hipLaunchKernelGGL(preprocess_views_kernel<true>, gv, dim3(GB), hist_lds_bytes, stream, a, t, d);
+    }
+    {
+        ScopedKernelTimer tm(K_SCAN, stream);
+        const dim3 go((unsigned)((d.T + TO_COLS - 1) / TO_COLS), (unsigned)V);
+        if (d.nblocks <= TO_SEGS * 16) hipLaunchKernelGGL((tile_offsets_views_kernel<TO_SEGS, 16>), go, dim3(TO_COLS * TO_SEGS), 0, stream, t, d);
+        else hipLaunchKernelGGL((tile_offsets_views_kernel<TO_SEGS_BIG, 32>), go, dim3(TO_COLS * TO_SEGS_BIG), 0, stream, t, d);
+        hipLaunchKernelGGL(scan_views_kernel, dim3(1, (unsigned)V), dim3(1024), 0, stream, t, d);
+    }
+    {
+        ScopedKernelTimer tm(K_SCATTER, stream);
+        hipLaunchKernelGGL(scatter_views_kernel, gv, dim3(GB), hist_lds_bytes, stream, t, d, a.eager);
+    }
+    if (!t_fuse_sort || cap_tile > (uint32_t)SORT_SMALL_CAP) {
+        ScopedKernelTimer tm(K_SORT, stream);
+        if (!t_fuse_sort) hipLaunchKernelGGL((sort_tiles_views_kernel<SORT_SMALL_CAP, 0>), tv, dim3(256), 0, stream, t, d);
+        if (cap_tile > (uint32_t)SORT_SMALL_CAP) {
+            if (cap_tile <= (uint32_t)SORT_MID_CAP) hipLaunchKernelGGL((sort_tiles_views_kernel<SORT_MID_CAP, SORT_SMALL_CAP>), tv, dim3(256), 0, stream, t, d);
+            else hipLaunchKernelGGL((sort_tiles_views_kernel<SORT_LDS_CAP, SORT_SMALL_CAP>), tv, dim3(256), 0, stream, t, d);
+        }
+        if (cap_tile > (uint32_t)SORT_LDS_CAP) {
+            const dim3 gl((unsigned)d.T, (cap_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP, (unsigned)V);
+            hipLaunchKernelGGL((sort_long_chunks_views_kernel<SORT_LDS_CAP>), gl, dim3(256), 0, stream, t, d, (uint32_t)SORT_LDS_CAP);
+            hipLaunchKernelGGL((rank_long_chunks_views_kernel<SORT_LDS_CAP>), gl, dim3(256), 0, stream, t, d, (uint32_t)SORT_LDS_CAP);
+        }
+    }
+    {
+        ScopedKernelTimer tm(K_RENDER_FWD, stream);
+        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0);
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    // one wait per view (they are all long done by the time the host has enqueued the tile kernels); a view that outgrew its capacity is
+    // redone through the single-view path, which allocates exactly
+    for (int v = 0; v < V; v++) {
+        gsr_view& w = views[v];
+        select_device_state(v + 1);
+        if (t_lazy) { w.num_rendered = (int)t.v[v].cap; continue; }
+        uint32_t hdr[4];
+        char* gp = w.geom_buffer;
+        const GeomState geom = GeomState::from(gp, (size_t)P);
+        { const int rc = wait_for_header(stream, geom.header, t.v[v].seq, hdr); if (rc) return rc; }
+        const uint32_t R = hdr[HDR_R], flg = hdr[HDR_FLAGS], R_alloc = hdr[HDR_R_ALLOC];
+        if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward_views: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
+        t_last_R_alloc = R_alloc > R ? R_alloc : R;
+        t_last_max_tile = hdr[HDR_MAX_TILE];
+        w.num_rendered = (int)R;
+        if (flg & FLAG_OVERFLOW) {
+            const int rc = forward_one_view(w, v + 1, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier, tan_fovx,
+                                            tan_fovy, debug, stream_);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" size_t gsr_views_scratch_size(int V, int P, int M, int scale_dim)
+{
+    return (size_t)V * (part_layout((size_t)P, M, scale_dim).total * sizeof(float) + 256) + 256;
+}
+
+extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in,
+                                  float scale_modifier, float tan_fovx, float tan_fovy, const gsr_raw_grads* out, char* scratch, int debug, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool accumulate = (debug & GSR_BACKWARD_ACCUMULATE) != 0, pose_only = (debug & GSR_BACKWARD_POSE_ONLY) != 0;
+    if (V < 1 || V > MAX_VIEWS || !views || !in || P <= 0 || width <= 0 || height <= 0 || !background || in->gather || in->flow_proj1 ||
+        (!pose_only && (!out || !scratch || !out->xyz || !out->log_scales || !out->raw_rotations || !out->logit_opacity || !out->features_dc || (M > 1 && !out->features_rest)))) {
+        g_last_error = "gsr_backward_views: invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const ViewDims d = view_dims(P, width, height);
+    ViewTable t;
+    memset(&t, 0, sizeof(t));
+    const PartLayout L = part_layout((size_t)P, M, in->scale_dim);
+    const size_t row_bytes = (L.total * sizeof(float) + 255) & ~size_t(255);
+    char* sp = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~uintptr_t(255));
+    int max_R = 0;
+    for (int v = 0; v < V; v++) {
+        const gsr_view& w = views[v];
+        if (!w.geom_buffer || !w.binning_buffer || !w.image_buffer || !w.dL_dcolor || !w.dL_ddepth || !w.dL_dmean2D || !w.viewmatrix || !w.projmatrix ||
+            !w.projmatrix_raw || !w.cam_pos || !w.radii) { g_last_error = "gsr_backward_views: null view argument"; return GSR_ERR_INVALID_ARGUMENT; }
+        ViewSlot& s = t.v[v];
+        s.viewmatrix = w.viewmatrix; s.projmatrix = w.projmatrix; s.projmatrix_raw = w.projmatrix_raw; s.cam_pos = w.cam_pos;
+        s.dx = w.dx; s.ds = w.ds; s.dr = w.dr;
+        s.geom = w.geom_buffer; s.image = w.image_buffer; s.binning = w.binning_buffer; s.radii = w.radii;
+        s.dL_dpix = w.dL_dcolor; s.dL_dpix_depth = w.dL_ddepth; s.dL_dmean2D = w.dL_dmean2D; s.ddx = w.ddx; s.dds = w.dds; s.ddr = w.ddr; s.tau_sum = w.dL_dtau_sum;
+        s.part = pose_only ? nullptr : reinterpret_cast<float*>(sp + (size_t)v * row_bytes);
+        s.cap = (uint32_t)std::max(0, w.num_rendered);
+        max_R = std::max(max_R, w.num_rendered);
+    }
+    {
+        ScopedKernelTimer tm(K_RENDER_BWD, stream);
+        if (max_R > 0)
+            hipLaunchKernelGGL(render_bwd_views_kernel, dim3((unsigned)(max_R / CHUNK + d.T), (unsigned)V), dim3(RB), 0, stream, t, d, background);
+    }
+    GeomBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.scale_modifier = scale_modifier;
+    a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+    a.pose_only = pose_only ? 1 : 0;
+    a.raw = to_device_view(in);
+    a.rawg = RawGrads{};
+    a.rawg.scale_dim = in->scale_dim;
+    {
+        ScopedKernelTimer tm(K_GEOM_BWD, stream);
+        hipLaunchKernelGGL(geometry_bwd_views_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)V), dim3(256), 0, stream, a, t, d);
+        hipLaunchKernelGGL(tau_sum_views_kernel, dim3(1, (unsigned)V), dim3(384), 0, stream, t, d);
+        if (!pose_only) {
+            ReduceTargets r{out->xyz, out->features_dc, out->features_rest, out->logit_opacity, out->log_scales, out->raw_rotations};
+            hipLaunchKernelGGL(views_reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, V, t, P, M, in->scale_dim, r, accumulate ? 1 : 0);
+        }
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,

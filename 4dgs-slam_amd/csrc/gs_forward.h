@@ -21,6 +21,52 @@ constexpr int HIST_LDS_TILES = 12288;   // 48 KiB of dynamic LDS
 // one line serialise in the L2 atomic unit -- packed (32 counters per line) the histogram cost 85 us at 200k Gaussians.
 constexpr int CTR_STRIDE = 32;
 
+// ---- the geometry and image scratch buffers (rasterizer_impl.h:22-27 `obtain`, 256-byte aligned carves) -------------------------
+// __host__ __device__: the host lays a view's buffers out when it launches the single-view kernels; the multi-view kernels
+// (gs_views.h) derive the same pointers on the device from the buffers' base addresses.
+template <typename T>
+__host__ __device__ inline void carve(char*& p, T*& ptr, size_t count)
+{
+    uintptr_t a = (reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255);
+    ptr = reinterpret_cast<T*>(a);
+    p = reinterpret_cast<char*>(ptr + count);
+}
+
+struct GeomState {
+    uint32_t* header;   // HDR_* words of gs_device.h
+    TileRec* rec; float* cov3D; uint8_t* clamped;
+    int* internal_radii; uint32_t* tiles_touched; uint32_t* point_offsets; uint32_t* block_sums; uint32_t* block_base;
+    float* tau_partials;   // [ceil(P/256)][6] per-block sums of dL_dtau (backward)
+    __host__ __device__ static GeomState from(char*& p, size_t P)
+    {
+        GeomState g;
+        const size_t nb = (P + GB - 1) / GB + 1;
+        carve(p, g.header, HDR_WORDS);
+        carve(p, g.rec, P);
+        carve(p, g.cov3D, 6 * P); carve(p, g.clamped, P); carve(p, g.internal_radii, P);
+        carve(p, g.tiles_touched, P); carve(p, g.point_offsets, P); carve(p, g.block_sums, nb); carve(p, g.block_base, nb);
+        carve(p, g.tau_partials, ((P + 255) / 256 + 1) * 6);
+        return g;
+    }
+};
+__host__ __device__ inline bool use_lds_hist(size_t T) { return T <= (size_t)HIST_LDS_TILES; }
+struct ImageState {
+    float* final_T; uint32_t* n_contrib; uint2* ranges; uint32_t* tile_count; uint32_t* tile_cursor;
+    float4* final_C;        // per pixel: colour / depth sums without the background term (render_bwd's chunk start-up needs them)
+    uint32_t* chunk_base;   // [T + 1] exclusive scan of ceil(tile list length / CHUNK)
+    uint32_t* block_tile_base;   // forward-only binning scratch [ceil(P/GB)][T]; last, so backward (which passes P = 0) never needs it
+    __host__ __device__ static ImageState from(char*& p, size_t N, size_t T, size_t P)
+    {
+        ImageState s;
+        carve(p, s.final_T, N); carve(p, s.n_contrib, N); carve(p, s.ranges, T); carve(p, s.final_C, N); carve(p, s.chunk_base, T + 1);
+        // the flag word sits behind the per-tile counters (index T*CTR_STRIDE)
+        carve(p, s.tile_count, T * CTR_STRIDE + 64);
+        carve(p, s.tile_cursor, T * CTR_STRIDE);
+        carve(p, s.block_tile_base, use_lds_hist(T) ? ((P + GB - 1) / GB) * T : 0);
+        return s;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // F1: per-Gaussian preprocess (DGR/cuda_rasterizer/forward.cu:157-258) fused with
 //     (a) the per-tile instance histogram (replaces the global 64-bit radix sort's first pass) and
@@ -153,7 +199,7 @@ __device__ uint32_t g_sca_timing[8 * 16 * 2048];
 // latencies instead of four (mean -> scale / rotation -> colour -> opacity); large launches keep the lazy order, which spares the
 // culled Gaussians' rows (71 % of 2 M at BASELINE config #5) and has enough waves in flight.
 template <bool RAW>
-__global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
+__device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
 {
     RawInputs R = a.raw;
     if constexpr (!RAW) R = RawInputs{};
@@ -308,7 +354,7 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 // BASELINE config #5 has 1954) -- the serial fall-back loop took 40 us there.
 constexpr int TO_COLS = 16, TO_SEGS = 16, TO_SEGS_BIG = 64;
 template <int SEGS, int RMAX>
-__global__ void __launch_bounds__(TO_COLS * SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
+__device__ __forceinline__ void tile_offsets_body(int nblocks, int T, uint32_t* __restrict__ hist,
                                                                       uint32_t* __restrict__ tile_count)
 {
     __shared__ uint32_t s_seg[SEGS][TO_COLS];
@@ -403,7 +449,7 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan64(unsigned lon
 // One pass over max(nblocks, ntiles) elements, 1024 at a time, carries three exclusive scans at once: the per-block instance
 // sums (32 bit) and, packed into one 64-bit value, the (padded) tile counts (low word) and the tile chunk counts (high word).
 // Three separate block scans cost 15 block barriers and three rounds of dependent loads on the critical path of every frame.
-__global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
+__device__ __forceinline__ void scan_body(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
                                                     int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
                                                     const uint32_t* flags, uint32_t cap_R, uint32_t cap_tile_list,
                                                     uint32_t* chunk_base, uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
@@ -485,7 +531,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t*
 // (tile | depth) sort order (rasterizer_impl.cu:98-108,306-311), ties included.
 // Also materialises the global inclusive scan point_offsets (rasterizer_impl.cu:280).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, int gy, const int* radii, const TileRec* rec,
+__device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, const int* radii, const TileRec* rec,
                                                                const uint32_t* tiles_touched,
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
@@ -798,7 +844,7 @@ __device__ __forceinline__ void sort_tile_in_lds(const uint2 r, const uint64_t* 
 }
 
 template <int CAP, int LOWER>
-__global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
+__device__ __forceinline__ void sort_tiles_body(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
                                                          uint2* sorted, const uint32_t* spec_header)
 {
     constexpr bool PAD = CAP > SORT_SMALL_CAP;              // the variant for lists beyond 1024 keys: padded layout, register-blocked networks
@@ -823,7 +869,7 @@ __global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2
 // kernels do with such a list; the global-memory bitonic network this replaces took 2.0 ms for 6.5 M instances (now 0.15 ms).
 // grid = (tiles, chunks of the longest list the launch is sized for).
 template <int CHUNKK>
-__global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header,
+__device__ __forceinline__ void sort_long_chunks_body(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header,
                                                                uint32_t lower)
 {
     __shared__ uint64_t s_raw[padded_keys_size(CHUNKK)];
@@ -841,7 +887,7 @@ __global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __re
 }
 
 template <int CHUNKK>
-__global__ void __launch_bounds__(256) rank_long_chunks_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+__device__ __forceinline__ void rank_long_chunks_body(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
                                                                const uint32_t* __restrict__ inst_gauss, uint2* __restrict__ sorted,
                                                                const uint32_t* spec_header, uint32_t lower)
 {
@@ -877,6 +923,61 @@ __global__ void mark_visible_kernel(int P, const float* means3D, const float* vi
     if (idx >= P) return;
     const f3 pv = xform_point_4x3(mk3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]), viewmatrix);
     present[idx] = pv.z > 0.2f ? 1 : 0;
+}
+
+// ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
+// several views) ----------------------------------------------------------------------------------------------------------------------
+template <bool RAW>
+__global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
+{
+    preprocess_fwd_body<RAW>(a);
+}
+
+template <int SEGS, int RMAX>
+__global__ void __launch_bounds__(TO_COLS * SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
+                                                                      uint32_t* __restrict__ tile_count)
+{
+    tile_offsets_body<SEGS, RMAX>(nblocks, T, hist, tile_count);
+}
+
+__global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
+                                                    int ntiles, const uint32_t* tile_count, uint2* ranges, uint32_t* tile_cursor,
+                                                    const uint32_t* flags, uint32_t cap_R, uint32_t cap_tile_list,
+                                                    uint32_t* chunk_base, uint32_t* header, uint32_t* host_mailbox, uint32_t seq)
+{
+    scan_body(nblocks, block_sums, block_base, ntiles, tile_count, ranges, tile_cursor, flags, cap_R, cap_tile_list, chunk_base, header, host_mailbox, seq);
+}
+
+__global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, int gy, const int* radii, const TileRec* rec,
+                                                               const uint32_t* tiles_touched,
+                                                               const uint32_t* block_base, uint32_t* point_offsets,
+                                                               uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
+                                                               uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager)
+{
+    scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager);
+}
+
+template <int CAP, int LOWER>
+__global__ void __launch_bounds__(256) sort_tiles_kernel(int ntiles, const uint2* ranges, uint64_t* keys, const uint32_t* inst_gauss,
+                                                         uint2* sorted, const uint32_t* spec_header)
+{
+    sort_tiles_body<CAP, LOWER>(ntiles, ranges, keys, inst_gauss, sorted, spec_header);
+}
+
+template <int CHUNKK>
+__global__ void __launch_bounds__(256) sort_long_chunks_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys, const uint32_t* spec_header,
+                                                               uint32_t lower)
+{
+    sort_long_chunks_body<CHUNKK>(ranges, keys, spec_header, lower);
+}
+
+template <int CHUNKK>
+__global__ void __launch_bounds__(256) rank_long_chunks_kernel(const uint2* __restrict__ ranges, const uint64_t* __restrict__ keys,
+                                                               const uint32_t* __restrict__ inst_gauss, uint2* __restrict__ sorted,
+                                                               const uint32_t* spec_header, uint32_t lower)
+{
+    rank_long_chunks_body<CHUNKK>(ranges, keys, inst_gauss, sorted, spec_header, lower);
 }
 
 }  // namespace gsr

@@ -119,7 +119,7 @@ __device__ uint32_t g_bwd_timing[8 * 4 * 8192];
 // ------------------------------------------------------------------------------------------------------------------
 // F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+__device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint2* sorted /* may alias sorted_out */, int W, int H,
                                                         const TileRec* __restrict__ rec,
                                                         const float* __restrict__ bg, float* __restrict__ final_T,
@@ -378,7 +378,7 @@ constexpr int PART_STRIDE = 12;   // floats per (quadrant, entry) in s_part: {M1
 // the order in which the three float4 pieces of the gradient slot consume them
 __device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <= 5 ? k - 1 : k); }
 
-__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
+__device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
                                                         const float* __restrict__ bg, const TileRec* __restrict__ rec,
                                                         const float* __restrict__ final_T,
@@ -619,6 +619,32 @@ __global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, cons
         o[0] = FWD_TICK() - tk0; o[1] = tk_search; o[2] = tk_state; o[3] = tk_stage; o[4] = tk_pair; o[5] = n_pairs; o[6] = tk_epi; o[7] = tk0;
     }
 #endif
+}
+
+// ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
+// several views) ----------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint2* sorted /* may alias sorted_out */, int W, int H,
+                                                        const TileRec* __restrict__ rec,
+                                                        const float* __restrict__ bg, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_opacity,
+                                                        int* __restrict__ n_touched, float4* __restrict__ final_C,
+                                                        float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
+                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info)
+{
+    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info);
+}
+
+__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
+                                                        const uint32_t* __restrict__ header, int W, int H,
+                                                        const float* __restrict__ bg, const TileRec* __restrict__ rec,
+                                                        const float* __restrict__ final_T,
+                                                        const float4* __restrict__ final_C, const uint32_t* __restrict__ n_contrib,
+                                                        const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpix_depth)
+{
+    render_bwd_body(ntiles, gx, bin_base, header, W, H, bg, rec, final_T, final_C, n_contrib, dL_dpix, dL_dpix_depth);
 }
 
 }  // namespace gsr

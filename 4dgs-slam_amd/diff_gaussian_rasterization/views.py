@@ -1,0 +1,232 @@
+"""The views of one mapping iteration through the multi-view entry point (include/gs_rasterizer.h: gsr_forward_views /
+gsr_backward_views; csrc/gs_views.h): the same Gaussians rendered from V cameras with ONE launch per pipeline stage, and back-propagated
+the same way. Per view the results are those of raw.rasterize_gaussians_raw; the parameter gradients are the sum over the views in
+view order (with fused accumulation -- FusedAdam's attached bucket -- exactly what V single-view backward passes leave in the buffers).
+
+    outs = rasterize_views_raw(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest,
+                               dyn_slot=..., deltas=[(dx, ds, dr) | None per view], poses=[(theta, rho) per view])
+    outs[v] = (color[3,H,W], radii[P], depth[1,H,W], opacity[1,H,W], n_touched[P])
+
+settings: one GaussianRasterizationSettings per view (same image size, field of view, background, SH degree and scale modifier).
+means2D: one zeros [P,3] tensor per view whose .grad receives that view's screen-space gradient."""
+import ctypes as C
+
+import torch
+
+from . import _C
+from .autograd import _pose_grad
+from .raw import _RawGrads, _RawInputs, _acc_params, _describe, _f32, _targets
+
+MAX_VIEWS = 12
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+
+class _View(C.Structure):       # gsr_view
+    _fields_ = [("viewmatrix", _vp), ("projmatrix", _vp), ("projmatrix_raw", _vp), ("cam_pos", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp),
+                ("out_color", _vp), ("out_depth", _vp), ("out_opacity", _vp), ("radii", _vp), ("n_touched", _vp),
+                ("geometry_user", _vp), ("binning_user", _vp), ("image_user", _vp),
+                ("geom_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("num_rendered", _i),
+                ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dmean2D", _vp), ("ddx", _vp), ("dds", _vp), ("ddr", _vp), ("dL_dtau_sum", _vp)]
+
+
+_declared = False
+_arenas = {}            # id -> tensor holder of the allocations of the call in flight (the C callbacks name them by id)
+
+
+def _alloc(user, nbytes):
+    h = _arenas[int(user)]
+    h["t"] = torch.empty(int(nbytes), dtype=torch.uint8, device=h["dev"])
+    return h["t"].data_ptr()
+
+
+_alloc_cb = _C._ALLOC_FN(_alloc)
+
+
+def _lib():
+    global _declared
+    lib = _C.load_library()
+    if not _declared:
+        lib.gsr_forward_views.restype = _i
+        lib.gsr_forward_views.argtypes = [_i, C.POINTER(_View), _C._ALLOC_FN, _C._ALLOC_FN, _C._ALLOC_FN, _i, _i, _i, _vp, _i, _i,
+                                          C.POINTER(_RawInputs), _f, _f, _f, _i, _vp]
+        lib.gsr_views_scratch_size.restype = C.c_size_t
+        lib.gsr_views_scratch_size.argtypes = [_i, _i, _i, _i]
+        lib.gsr_backward_views.restype = _i
+        lib.gsr_backward_views.argtypes = [_i, C.POINTER(_View), _i, _i, _i, _vp, _i, _i, C.POINTER(_RawInputs), _f, _f, _f,
+                                           C.POINTER(_RawGrads), _vp, _i, _vp]
+        _declared = True
+    return lib
+
+
+class _RasterizeViewsRaw(torch.autograd.Function):
+    """inputs: xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, settings (list), then six per view:
+    means2D, dx, ds, dr, theta, rho. outputs: five per view: color, radii, depth, opacity, n_touched."""
+
+    @staticmethod
+    def forward(ctx, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, settings, *per_view):
+        _C._require_device(xyz, "_xyz")
+        lib = _lib()
+        dev, V = xyz.device, len(settings)
+        rs0 = settings[0]
+        P, H, W = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width)
+        M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
+        ctx.settings, ctx.V, ctx.M = settings, V, M
+        ctx.set_materialize_grads(False)
+        ctx.acc_params = _acc_params(xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot)
+        ctx.pose_shapes = [(tuple(per_view[6 * v + 4].shape) if isinstance(per_view[6 * v + 4], torch.Tensor) else None,
+                            tuple(per_view[6 * v + 5].shape) if isinstance(per_view[6 * v + 5], torch.Tensor) else None) for v in range(V)]
+        img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, None, None, None, keep)
+        views = (_View * V)()
+        base = id(ctx) & 0x3FFFFFFFFFFF
+        holders = []
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            _, dx, ds, dr = per_view[6 * v: 6 * v + 4]
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            w.dx, w.ds, w.dr = _f32(dx, "dx", keep), _f32(ds, "ds", keep), _f32(dr, "dr", keep)
+            w.out_color, w.out_depth = img[v, :_C.NUM_CHANNELS].data_ptr(), img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1].data_ptr()
+            w.out_opacity, w.radii, w.n_touched = img[v, _C.NUM_CHANNELS + 1:].data_ptr(), ints[v, 0].data_ptr(), ints[v, 1].data_ptr()
+            hs = [{"dev": dev, "t": None} for _ in range(3)]
+            holders.append(hs)
+            for k, h in enumerate(hs):
+                _arenas[base + 3 * v + k] = h
+            w.geometry_user, w.binning_user, w.image_user = base + 3 * v, base + 3 * v + 1, base + 3 * v + 2
+        try:
+            with torch.cuda.device(dev):
+                rc = lib.gsr_forward_views(V, views, _alloc_cb, _alloc_cb, _alloc_cb, P, int(rs0.sh_degree), M, _f32(rs0.bg, "bg", keep), W, H,
+                                           C.byref(desc), float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), int(bool(rs0.debug)),
+                                           _C._stream(dev))
+        finally:
+            for v in range(V):
+                for k in range(3):
+                    _arenas.pop(base + 3 * v + k, None)
+        if rc < 0:
+            _C._err(lib, rc, "gsr_forward_views")
+        ctx.num_rendered = [int(views[v].num_rendered) for v in range(V)]
+        state = [holders[v][k]["t"] for v in range(V) for k in range(3)]          # geometry, binning, image per view
+        deltas = [per_view[6 * v + k] for v in range(V) for k in (1, 2, 3)]
+        ctx.n_state = len(state)
+        ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, ints, *state, *deltas)
+        outs = []
+        for v in range(V):
+            outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
+            ctx.mark_non_differentiable(outs[-4], outs[-1])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib()
+        V, M, settings = ctx.V, ctx.M, ctx.settings
+        saved = ctx.saved_tensors
+        xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, ints = saved[:8]
+        state = saved[8:8 + ctx.n_state]
+        deltas = saved[8 + ctx.n_state:]
+        dev = xyz.device
+        rs0 = settings[0]
+        P, H, W, S = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width), int(log_scales.shape[-1])
+        targets = _targets(ctx.acc_params, M) if ctx.acc_params is not None else None
+        param_idx = (0, 1, 2, 3, 4, 5)
+        delta_needed = any(ctx.needs_input_grad[8 + 6 * v + k] for v in range(V) for k in (1, 2, 3))
+        pose_only = not any(ctx.needs_input_grad[k] for k in param_idx) and not delta_needed
+        if pose_only:
+            targets = None
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, None, None, None, keep)
+        widths = [3, 3, 3 * (M - 1), 1, S, 4]
+        if targets is not None or pose_only:
+            own = None
+            gviews = [t_.view(-1) for t_ in targets] if targets is not None else [None] * 6
+        else:
+            own = torch.empty((P * sum(widths),), dtype=torch.float32, device=dev)
+            gviews, o = [], 0
+            for w_ in widths:
+                gviews.append(own[o:o + P * w_])
+                o += P * w_
+        out = _RawGrads()
+        if not pose_only:
+            out.xyz, out.features_dc, out.features_rest = gviews[0].data_ptr(), gviews[1].data_ptr(), (gviews[2].data_ptr() if M > 1 else None)
+            out.logit_opacity, out.log_scales, out.raw_rotations = gviews[3].data_ptr(), gviews[4].data_ptr(), gviews[5].data_ptr()
+        per_view_out = torch.empty((V, P * 3 + 6), dtype=torch.float32, device=dev)      # screen-space gradient + pose sum per view
+        views = (_View * V)()
+        zc = zd = None
+        delta_grads = []
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            g_color, g_depth = grads[5 * v], grads[5 * v + 2]
+            if g_color is None:
+                zc = torch.zeros((3, H, W), dtype=torch.float32, device=dev) if zc is None else zc
+                g_color = zc
+            if g_depth is None:
+                zd = torch.zeros((1, H, W), dtype=torch.float32, device=dev) if zd is None else zd
+                g_depth = zd
+            dx, ds, dr = deltas[3 * v: 3 * v + 3]
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            w.dx, w.ds, w.dr = _f32(dx, "dx", keep), _f32(ds, "ds", keep), _f32(dr, "dr", keep)
+            w.radii = ints[v, 0].data_ptr()
+            w.geom_buffer, w.binning_buffer, w.image_buffer = state[3 * v].data_ptr(), state[3 * v + 1].data_ptr(), state[3 * v + 2].data_ptr()
+            w.num_rendered = ctx.num_rendered[v]
+            w.dL_dcolor, w.dL_ddepth = _f32(g_color.to(torch.float32), "dL_dcolor", keep), _f32(g_depth.to(torch.float32), "dL_ddepth", keep)
+            w.dL_dmean2D, w.dL_dtau_sum = per_view_out[v, :P * 3].data_ptr(), per_view_out[v, P * 3:].data_ptr()
+            K = lambda t: None if (t is None or t.numel() == 0 or pose_only) else torch.zeros_like(t, dtype=torch.float32)
+            gd = (K(dx), K(ds), K(dr))
+            delta_grads.append(gd)
+            w.ddx, w.dds, w.ddr = (None if g is None else g.data_ptr() for g in gd)
+        scratch = None
+        if not pose_only:
+            scratch = torch.empty((int(lib.gsr_views_scratch_size(V, P, M, S)),), dtype=torch.uint8, device=dev)
+        flags = int(bool(rs0.debug)) | (2 if targets is not None else 0) | (4 if pose_only else 0)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward_views(V, views, P, int(rs0.sh_degree), M, _f32(rs0.bg, "bg", keep), W, H, C.byref(desc), float(rs0.scale_modifier),
+                                        float(rs0.tanfovx), float(rs0.tanfovy), C.byref(out), None if scratch is None else scratch.data_ptr(), flags,
+                                        _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_backward_views")
+        if own is not None:
+            g_xyz, g_fdc, g_frest = gviews[0].view(P, 3), gviews[1].view(P, 1, 3), (gviews[2].view(P, M - 1, 3) if M > 1 else None)
+            g_logit, g_ls, g_rot = gviews[3].view(logit_opacity.shape), gviews[4].view(P, S), gviews[5].view(P, 4)
+        else:
+            g_xyz = g_fdc = g_frest = g_logit = g_ls = g_rot = None
+        res = [g_xyz, g_ls, g_rot, g_logit, g_fdc, g_frest, None, None]
+        for v in range(V):
+            th_shape, rho_shape = ctx.pose_shapes[v]
+            tau = per_view_out[v, P * 3:]
+            gdx, gds, gdr = delta_grads[v]
+            res += [per_view_out[v, :P * 3].view(P, 3), gdx, gds, gdr,
+                    _pose_grad(tau[3:], th_shape) if th_shape is not None else None, _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None]
+        return tuple(res)
+
+
+def views_supported(settings):
+    """Same image, field of view, background TENSOR (the same object / storage), SH degree, scale modifier and debug flag for every view,
+    and no more than MAX_VIEWS."""
+    if not (1 <= len(settings) <= MAX_VIEWS):
+        return False
+    a = settings[0]
+    return all(int(s.image_height) == int(a.image_height) and int(s.image_width) == int(a.image_width) and float(s.tanfovx) == float(a.tanfovx)
+               and float(s.tanfovy) == float(a.tanfovy) and int(s.sh_degree) == int(a.sh_degree) and float(s.scale_modifier) == float(a.scale_modifier)
+               and bool(s.debug) == bool(a.debug) and (s.bg is a.bg or s.bg.data_ptr() == a.bg.data_ptr()) for s in settings)   # (no value comparison:
+    # torch.equal would synchronise with the device on every call; callers pass the one background tensor of the system)
+
+
+def rasterize_views_raw(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest=None, dyn_slot=None,
+                        deltas=None, poses=None):
+    V = len(settings)
+    if xyz.shape[0] == 0:
+        raise RuntimeError("rasterize_views_raw: empty model")
+    if not views_supported(settings):
+        raise RuntimeError("rasterize_views_raw: the views must share image size, field of view, background, SH degree and scale modifier")
+    deltas = deltas or [None] * V
+    poses = poses or [(None, None)] * V
+    flat = []
+    for v in range(V):
+        dx, ds, dr = deltas[v] if deltas[v] is not None else (None, None, None)
+        if (dx is not None or ds is not None or dr is not None) and dyn_slot is None:
+            raise RuntimeError("rasterize_views_raw: dx / ds / dr need dyn_slot")
+        flat += [means2D[v], dx, ds, dr, poses[v][0], poses[v][1]]
+    outs = _RasterizeViewsRaw.apply(xyz, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, dyn_slot, list(settings), *flat)
+    return [tuple(outs[5 * v: 5 * v + 5]) for v in range(V)]

@@ -20,6 +20,10 @@ try:   # the MI355X package has the fused prologue; the CPU oracle stand-in used
     from diff_gaussian_rasterization import raw as _raw
 except Exception:  # pragma: no cover
     _raw = None
+try:   # ... and the multi-view entry point
+    from diff_gaussian_rasterization import views as _views
+except Exception:  # pragma: no cover
+    _views = None
 
 # render() hands the model's RAW parameters to the rasterizer when it can (diff_gaussian_rasterization/raw.py): the
 # activations, the delta scatter and their autograd replay then run inside the kernels. GSR_FUSED_PROLOGUE=0 (or setting this
@@ -205,6 +209,38 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         "opacity": opacity,
         "n_touched": n_touched,
     }
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, deltas=None):
+    """render() of several cameras of one mapping iteration at once: a list of render()'s dicts, one per camera.
+
+    The mapping back-end renders the same Gaussians from every window keyframe and two random ones before each optimizer step
+    (utils/slam_backend.py:357,526,657); with the fused prologue available those views go through the multi-view entry point
+    (diff_gaussian_rasterization/views.py: one launch per pipeline stage for all of them), otherwise -- Python-side SH / covariance,
+    a single camera, more than views.MAX_VIEWS, cameras of different size -- one render() call per camera. ``deltas``: per camera
+    None or the (dx, ds, dr) tensors of the dynamic subset; values and gradients are those of the per-camera calls."""
+    cams = list(viewpoint_cameras)
+    deltas = list(deltas) if deltas is not None else [None] * len(cams)
+    per_camera = lambda: [render(c, pc, pipe, bg_color, scaling_modifier, dx=d[0] if d else None, ds=d[1] if d else None, dr=d[2] if d else None)
+                          for c, d in zip(cams, deltas)]
+    if pc.get_xyz.shape[0] == 0 or len(cams) < 2 or _views is None or os.environ.get("GSR_MULTI_VIEW", "1") == "0":
+        return per_camera()
+    if not _fused_prologue_ok(pc, pipe, None, False):
+        return per_camera()
+    for d in deltas:
+        if d is not None and not (len(d) == 3 and all(isinstance(v, torch.Tensor) for v in d)):
+            return per_camera()
+    settings = [_settings(c, bg_color, scaling_modifier, pc.active_sh_degree) for c in cams]
+    if not _views.views_supported(settings):
+        return per_camera()
+    points = [_screenspace_points(pc) for _ in cams]
+    any_delta = any(d is not None for d in deltas)
+    f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
+    outs = _views.rasterize_views_raw(settings, pc._xyz, points, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, f_rest,
+                                      dyn_slot=_dyn_slot(pc) if any_delta else None, deltas=deltas,
+                                      poses=[(c.cam_rot_delta, c.cam_trans_delta) for c in cams])
+    return [{"render": o[0], "viewspace_points": pts, "visibility_filter": o[1] > 0, "radii": o[1], "depth": o[2], "opacity": o[3], "n_touched": o[4]}
+            for o, pts in zip(outs, points)]
 
 
 def _flow_fused_ok(pc) -> bool:

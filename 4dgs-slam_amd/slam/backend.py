@@ -19,7 +19,7 @@ import random
 import numpy as np
 import torch
 
-from gaussian_renderer import render
+from gaussian_renderer import render, render_views
 import mapping_shard
 import slam_losses
 
@@ -121,6 +121,13 @@ class BackEnd:
     def _render(self, viewpoint, deltas):
         dx, ds, dr = deltas
         return render(viewpoint, self.gaussians, self.pipeline_params, self.background, dynamic=False, dx=dx, ds=ds, dr=dr)
+
+    def _render_many(self, viewpoints, deltas_list):
+        """The iteration's views of this rank in one go (gaussian_renderer.render_views: one launch per pipeline stage for all of them)."""
+        if len(viewpoints) == 0:
+            return []
+        return render_views(viewpoints, self.gaussians, self.pipeline_params, self.background,
+                            deltas=[None if d[0] is None else d for d in deltas_list])
 
     def _view_stats(self, pkg):
         self.gaussians.add_view_stats(pkg["viewspace_points"], pkg["radii"])
@@ -245,19 +252,15 @@ class BackEnd:
             loss_mapping = 0
             pkgs, touched_rows = [], {}
             extras = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]      # the same draw on every rank
-            for k, viewpoint in enumerate(viewpoint_stack + extras):
-                if not shard.owns(k):
-                    continue
-                pkg = self._render(viewpoint, (None, None, None))
+            mine = [(k, viewpoint) for k, viewpoint in enumerate(viewpoint_stack + extras) if shard.owns(k)]
+            rendered = self._render_many([v for _, v in mine], [(None, None, None)] * len(mine))
+            for (k, viewpoint), pkg in zip(mine, rendered):
                 loss = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True,
                                                     compute_value=self.loss_values)
                 pkgs.append(pkg)
                 if k < len(viewpoint_stack):
                     touched_rows[k] = (pkg["n_touched"] > 0).long()
-                if self.loss_values:
-                    loss_mapping = loss_mapping + loss
-                else:
-                    loss.backward()                  # this view's gradients now; the rasterizer state of the view is released right away
+                loss_mapping = loss_mapping + loss        # ONE backward for all views: the multi-view backward pass takes them together
             if shard.rank == 0:
                 loss_mapping = loss_mapping + self._isotropic_loss()
             if torch.is_tensor(loss_mapping) and loss_mapping.requires_grad:
@@ -352,11 +355,10 @@ class BackEnd:
                     if len(extra):
                         reg = reg + (wts[nv:] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[nv:]])).sum()
                     loss_network = loss_network + reg
-            for k, viewpoint in enumerate(views + extra):
-                if not shard.owns(k):
-                    continue
-                deltas = self._deltas(viewpoint) if use_net else (None, None, None)
-                pkg = self._render(viewpoint, deltas)
+            mine = [(k, viewpoint) for k, viewpoint in enumerate(views + extra) if shard.owns(k)]
+            mine_deltas = [self._deltas(viewpoint) if use_net else (None, None, None) for _, viewpoint in mine]
+            rendered = self._render_many([v for _, v in mine], mine_deltas)
+            for (k, viewpoint), deltas, pkg in zip(mine, mine_deltas, rendered):
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False, compute_value=self.loss_values)
                 if with_flow:

@@ -176,6 +176,35 @@ int gsr_backward_raw(int P, int D, int M, int R,
                      float* dL_dmean2D, const gsr_raw_grads* out, float* dL_dtau_sum,
                      int debug, void* stream);
 
+/* ---- multi-view entry point: the views of ONE mapping iteration in one launch per pipeline stage ---------------------------------
+ * The mapping back-end renders the same Gaussians from every window keyframe plus two random ones and back-propagates all of them
+ * before one optimizer step (utils/slam_backend.py:357,526,657,768-771). gsr_forward_views / gsr_backward_views take the raw model
+ * parameters once (gsr_raw_inputs; `gather` and the flow mode are not available here) and V <= GSR_MAX_VIEWS view descriptors; every
+ * stage of the pipeline is launched once with the view as a second grid dimension. Results per view are those of gsr_forward_raw /
+ * gsr_backward_raw; the parameter gradients of `out` are the sum over the views, added in view order with one rounding per view --
+ * with GSR_BACKWARD_ACCUMULATE exactly what V consecutive gsr_backward_raw calls in accumulate mode leave in the buffers.
+ * Binning capacities are speculated per view slot (the v-th view of consecutive calls is assumed to look alike); the first call of a
+ * slot, debug mode and frames that outgrow their capacity go through the single-view path inside the call. */
+#define GSR_MAX_VIEWS 12
+typedef struct gsr_view {
+    const float* viewmatrix; const float* projmatrix; const float* projmatrix_raw; const float* cam_pos;   /* [16], [16], [16], [3] */
+    const float* dx; const float* ds; const float* dr;   /* this view's deltas of the dynamic subset ([K,3], [K,3], [K,4]) or NULL; the
+                                                            dx / ds / dr of the shared descriptor are ignored, its dyn_slot applies */
+    float* out_color; float* out_depth; float* out_opacity; int* radii; int* n_touched;      /* forward outputs, as in gsr_forward */
+    void* geometry_user; void* binning_user; void* image_user;                              /* user pointers of this view's allocations */
+    char* geom_buffer; char* binning_buffer; char* image_buffer; int num_rendered;          /* filled by gsr_forward_views; pass back unchanged */
+    const float* dL_dcolor; const float* dL_ddepth;                                         /* backward: cotangents [3,H,W], [1,H,W] */
+    float* dL_dmean2D; float* ddx; float* dds; float* ddr; float* dL_dtau_sum;              /* backward: per-view gradients ([P,3]; deltas; [6]); ddx / dds / ddr / dL_dtau_sum may be NULL */
+} gsr_view;
+int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc,
+                      int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier,
+                      float tan_fovx, float tan_fovy, int debug, void* stream);
+/* scratch: device memory of gsr_views_scratch_size() bytes (one row of parameter gradients per view); not needed with GSR_BACKWARD_POSE_ONLY */
+size_t gsr_views_scratch_size(int V, int P, int M, int scale_dim);
+int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, const float* background, int width, int height,
+                       const gsr_raw_inputs* in, float scale_modifier, float tan_fovx, float tan_fovy,
+                       const gsr_raw_grads* out, char* scratch, int debug, void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:20-22 / rasterizer_impl.cu:54-66,141-153): present[i] = (z_view > 0.2). */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      unsigned char* present, void* stream);

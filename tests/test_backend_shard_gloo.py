@@ -121,6 +121,7 @@ def run_backend(iters, window, all_kfs):
     b.gaussian_th = b.gaussian_extent = b.size_threshold = 0.0
     b.viewpoints = {k: ToyCamera(k) for k in all_kfs}
     b._render = types.MethodType(toy_render, b)
+    b._render_many = lambda cams, deltas: [toy_render(b, c, d) for c, d in zip(cams, deltas)]       # (the product's is one multi-view launch chain)
     be.slam_losses = types.SimpleNamespace(get_loss_mapping=toy_loss)
     b.map_static(window, iters=iters)
     b.map_static(window, prune=True)

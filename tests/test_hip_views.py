@@ -1,0 +1,155 @@
+"""The multi-view entry point (gsr_forward_views / gsr_backward_views; diff_gaussian_rasterization/views.py, gaussian_renderer.render_views):
+V views of one Gaussian set in one launch per pipeline stage must give, per view, what V single-view calls give -- images, radii,
+n_touched, screen-space and pose gradients bit for bit -- and parameter gradients equal to the sum over the views added in view order
+(bitwise what V consecutive backward passes leave in an attached gradient bucket)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "4dgs-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(P=20000, V=5, W=320, H=240, M=1, iso=False, dyn=True, scale_mean=0.02, seed=0):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    from synthetic_scene import keyframe_pose, make_camera, make_gaussians
+    dev = torch.device("cuda", 0)
+    g = make_gaussians(P, make_camera(W, H), seed=seed, sh_degree=0, scale_mean=scale_mean)
+    T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    par = {"xyz": T(g["means3D"], True), "log_scales": T(np.log(g["scales"][:, :1] if iso else g["scales"]), True),
+           "rot": T(g["rotations"] * 1.7, True), "logit": T(np.log(g["opacities"] / (1 - g["opacities"] + 1e-6) + 1e-6).reshape(P, 1), True),
+           "f_dc": T(g["shs"][:, :1], True),
+           "f_rest": (torch.randn((P, M - 1, 3), generator=gen) * 0.1).to(dev).requires_grad_(True)}
+    settings, cots = [], []
+    bg = T([1.0, 1.0, 1.0])
+    for k in range(V):
+        R_w, t_w = keyframe_pose(2 * k)
+        cam = make_camera(W, H, R=R_w, t=t_w)
+        settings.append(GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, T(cam.viewmatrix), T(cam.projmatrix),
+                                                      T(cam.projmatrix_raw), int(round((M ** 0.5))) - 1, T(cam.campos), False, False))
+        cots.append(((torch.randn((3, H, W), generator=gen) / (3 * H * W)).to(dev), (torch.randn((1, H, W), generator=gen) / (H * W)).to(dev)))
+    slot = deltas = None
+    if dyn:
+        dyn_mask = torch.zeros(P, dtype=torch.bool)
+        dyn_mask[torch.randperm(P, generator=gen)[: P // 4]] = True
+        K = int(dyn_mask.sum())
+        slot = torch.full((P,), -1, dtype=torch.int32)
+        slot[dyn_mask] = torch.arange(K, dtype=torch.int32)
+        slot = slot.to(dev)
+        deltas = [tuple((torch.randn((K, c), generator=gen) * s).to(dev).requires_grad_(True) for c, s in ((3, 0.01), (3, 0.001), (4, 0.01))) for _ in range(V)]
+    poses = [(torch.zeros(3, device=dev, requires_grad=True), torch.zeros(3, device=dev, requires_grad=True)) for _ in range(V)]
+    return par, settings, cots, slot, deltas, poses
+
+
+def _single(par, settings, cots, slot, deltas, poses, bucket=None):
+    """V single-view calls, back-propagated one after the other (the per-view route of the mapping loop)."""
+    from diff_gaussian_rasterization import raw
+    outs, m2d = [], []
+    P = par["xyz"].shape[0]
+    for v, rs in enumerate(settings):
+        pts = torch.zeros((P, 3), device=par["xyz"].device, requires_grad=True)
+        d = deltas[v] if deltas else (None, None, None)
+        o = raw.rasterize_gaussians_raw(rs, par["xyz"], pts, par["log_scales"], par["rot"], par["logit"], par["f_dc"],
+                                        par["f_rest"] if par["f_rest"].shape[1] else None, slot, d[0], d[1], d[2], poses[v][0], poses[v][1])
+        torch.autograd.backward([o[0], o[2]], list(cots[v]))
+        outs.append(o)
+        m2d.append(pts)
+    return outs, m2d
+
+
+def _multi(par, settings, cots, slot, deltas, poses):
+    from diff_gaussian_rasterization import views
+    P = par["xyz"].shape[0]
+    m2d = [torch.zeros((P, 3), device=par["xyz"].device, requires_grad=True) for _ in settings]
+    outs = views.rasterize_views_raw(settings, par["xyz"], m2d, par["log_scales"], par["rot"], par["logit"], par["f_dc"],
+                                     par["f_rest"] if par["f_rest"].shape[1] else None, slot, deltas, poses)
+    torch.autograd.backward([o[k] for o in outs for k in (0, 2)], [c for cv in cots for c in cv])
+    return outs, m2d
+
+
+def _clear(par, deltas, poses):
+    for t in par.values():
+        t.grad = None
+    for d in (deltas or []):
+        for t in d:
+            t.grad = None
+    for th, rh in poses:
+        th.grad = rh.grad = None
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(M=4, dyn=False), dict(iso=True, scale_mean=0.05, V=3), dict(P=3000, V=10, W=160, H=120)])
+def test_views_equal_single_view_calls(kw):
+    par, settings, cots, slot, deltas, poses = _scene(**kw)
+    names = list(par)
+    # ---- reference: per-view calls with fused accumulation into an attached bucket (what the mapping loop does today)
+    from mapping_shard import GradBucket
+    plist = [par["xyz"], par["f_dc"], par["f_rest"], par["logit"], par["log_scales"], par["rot"]]
+    plist = [p for p in plist if p.numel()]
+    bucket = GradBucket(plist).attach()
+    from diff_gaussian_rasterization import _C
+    batched0 = _C.set_option("views_batched")
+    for rep in range(2):                                  # the second round takes the batched path (capacity estimates exist by then)
+        bucket.zero_grads()
+        _clear({}, deltas, poses)
+        o1, m1 = _single(par, settings, cots, slot, deltas, poses)
+        ref = {"bucket": bucket.flat.clone(), "m2d": [p.grad.clone() for p in m1], "img": [tuple(t.clone() for t in o) for o in o1],
+               "d": [[t.grad.clone() for t in d] for d in (deltas or [])], "pose": [(th.grad.clone(), rh.grad.clone()) for th, rh in poses]}
+        bucket.zero_grads()
+        _clear({}, deltas, poses)
+        o2, m2 = _multi(par, settings, cots, slot, deltas, poses)
+        torch.cuda.synchronize()
+        for v in range(len(settings)):
+            for k in range(5):
+                assert torch.equal(o2[v][k], ref["img"][v][k]), (rep, v, k)
+            assert torch.equal(m2[v].grad, ref["m2d"][v]), (rep, v)
+            assert torch.equal(poses[v][0].grad, ref["pose"][v][0]) and torch.equal(poses[v][1].grad, ref["pose"][v][1]), (rep, v)
+            for a, b in zip((deltas or [[]] * len(settings))[v], (ref["d"] or [[]] * len(settings))[v]):
+                assert torch.equal(a.grad, b), (rep, v)
+        assert torch.equal(bucket.flat, ref["bucket"]), (rep, float((bucket.flat - ref["bucket"]).abs().max()))
+    assert _C.set_option("views_batched") >= batched0 + 1            # a slot's first call goes view by view (no capacity estimate yet), later ones batched
+
+
+def test_views_without_accumulation_match_autograd_sum():
+    """No attached bucket: the parameter gradients are returned and must equal autograd's sum of the per-view gradients."""
+    par, settings, cots, slot, deltas, poses = _scene(P=8000, V=4)
+    for rep in range(2):
+        _clear(par, deltas, poses)
+        _single(par, settings, cots, slot, deltas, poses)
+        ref = {k: t.grad.clone() for k, t in par.items() if t.grad is not None}
+        _clear(par, deltas, poses)
+        _multi(par, settings, cots, slot, deltas, poses)
+        for k, want in ref.items():
+            got = par[k].grad
+            assert torch.allclose(got, want, rtol=1e-5, atol=1e-9), (rep, k, float((got - want).abs().max()))
+
+
+def test_render_views_matches_render():
+    """gaussian_renderer.render_views == [render(cam) for cam in cams] on a small SLAM model (dict keys, values, gradients)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_hip_slam import _mapping_state
+    from gaussian_renderer import render, render_views
+    slam, window = _mapping_state()
+    be = slam.backend
+    cams = [be.viewpoints[k] for k in window]
+    g = be.gaussians
+    for rep in range(2):
+        g.optimizer.zero_grad(set_to_none=True)
+        a = [render(c, g, slam.pipeline_params, slam.background) for c in cams]
+        sum((p["render"].mean() + p["depth"].mean()) for p in a).backward()
+        ga = g._xyz.grad.clone()
+        g.optimizer.zero_grad(set_to_none=True)
+        b = render_views(cams, g, slam.pipeline_params, slam.background)
+        sum((p["render"].mean() + p["depth"].mean()) for p in b).backward()
+        for pa, pb in zip(a, b):
+            assert set(pa) == set(pb)
+            for k in ("render", "depth", "opacity", "radii", "n_touched", "visibility_filter"):
+                assert torch.equal(pa[k], pb[k]), (rep, k)
+        assert torch.allclose(g._xyz.grad, ga, rtol=1e-5, atol=1e-10)
