@@ -313,8 +313,13 @@ class BackEnd:
         use_net = dynamic_network and g.deform_init
         gaussian_split = False
         shard = self.shard
+        # The reference runs this loop for 200 iterations and lets the Gaussians (their optimizer step, densification, the iteration
+        # counter) take part only after the first 100 (:337-338,:765-770): the node network warms up alone. A shorter schedule keeps that
+        # proportion -- with the literal 100 a 60- or 80-iteration schedule would never step the Gaussians of a new keyframe at all
+        # (round 2's demo and test schedules did exactly that: 24 dB on the dynamic sequence against 41 dB on the static one).
+        warm = 100 if iters >= 200 else int(self.config["Training"].get("network_warmup_iters", iters // 2))
         for i in range(iters):
-            if i > 100:
+            if i > warm:
                 self.iteration_count += 1                                   # :337-338
             self.last_sent += 1
             loss_network = 0
@@ -375,7 +380,7 @@ class BackEnd:
                 g.deform.deform.end_iteration()
                 self._delta_cache = None
             # (the Gaussians only step after the network's warm-up, :765-770: before that their gradients are dropped unreduced)
-            shard.reduce_gradients(g.optimizer if i > 100 else None, [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else ())
+            shard.reduce_gradients(g.optimizer if i > warm else None, [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else ())
             gaussian_split = False
             with torch.no_grad():
                 if prune or i == iters - 1 or shard.world == 1:
@@ -389,12 +394,12 @@ class BackEnd:
                     return False
                 for pkg in pkgs:
                     self._view_stats(pkg)
-                update_gaussian = (self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset) and i > 100
+                update_gaussian = (self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset) and i > warm
                 if update_gaussian:
                     shard.reduce_statistics(g)
                     g.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
                     gaussian_split = True
-                if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian and i > 100:
+                if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian and i > warm:
                     self._reset_opacity_of_unseen(pkgs)
                     gaussian_split = True
                 self._pose_updates(viewpoint_stack, current_window)
@@ -402,7 +407,7 @@ class BackEnd:
                 if use_net:
                     g.deform.optimizer.step()
                     g.deform.optimizer.zero_grad(set_to_none=True)
-                if i > 100:                                                  # :765-770
+                if i > warm:                                                  # :765-770
                     g.optimizer.step()
                     g.update_learning_rate(self.iteration_count)
                 g.optimizer.zero_grad(set_to_none=True)

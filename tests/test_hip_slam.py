@@ -244,9 +244,10 @@ def test_slam_static_sequence_end_to_end(tmp_path):
     print(res)
     assert res["frames"] == 32 and len(res["keyframes"]) >= 4
     # the trajectory moves ~19 cm in total; an untracked (constant-pose) estimate has an ATE of several cm
-    assert res["ate_rmse"] < 0.02, res
-    assert res["before_opt"]["mean_psnr"] > 22.0 and res["before_opt"]["l1_depth"] < 0.05, res
-    assert res["gaussians"] > 5000
+    # bars ~20 % off the measured values (ATE 10.2 mm, PSNR 34.8 dB, depth L1 17 mm with this reduced schedule): a regression shows
+    assert res["ate_rmse"] < 0.0125, res
+    assert res["before_opt"]["mean_psnr"] > 33.8 and res["before_opt"]["l1_depth"] < 0.0205, res
+    assert res["gaussians"] > 9000
     # the saved map loads back (PLY with the dygs column)
     from slam.gaussian_model import GaussianModel
     gm = GaussianModel(0, config=slam.config)
@@ -267,8 +268,34 @@ def test_slam_dynamic_sequence_end_to_end():
     print(res)
     g = slam.gaussians
     assert res["frames"] == 30 and g.deform_init and int(g.dygs.sum()) > 50
-    assert res["ate_rmse"] < 0.015, res
-    assert res["before_opt"]["mean_psnr"] > 20.0, res
+    assert res["ate_rmse"] < 0.0096, res                  # measured 7.9 mm / 28.1 dB / 28 mm with this reduced schedule
+    assert res["before_opt"]["mean_psnr"] > 27.2 and res["before_opt"]["l1_depth"] < 0.034, res
+
+
+def test_config4_stand_in_at_the_reference_schedule(tmp_path):
+    """BASELINE config #4 (`slam.py --eval --dynamic` on TUM fr3_sitting) needs the TUM data, YOLO and RAFT weights, none of which exist
+    offline; this is its asset-free stand-in AT THE REFERENCE'S SCHEDULE: 640x480, 40 frames with a moving object from frame 6,
+    configs/rgbd/tum/base_config.yaml value by value (init 1050 iterations, 100 tracking iterations per frame with the convergence latch,
+    200 dynamic mapping iterations per keyframe, window 8, pcd_downsample 128), the tracking graph, then color_refinement and
+    eval_rendering. Measured on MI355X: ATE 3.3 mm, PSNR 30.2 dB -> 35.9 dB after refinement, depth L1 30 mm -> 15 mm, 34 s."""
+    from slam.dataset import SyntheticRGBDDataset
+    from slam.system import SLAM, default_config, merge_config
+    torch.manual_seed(0)
+    ds = SyntheticRGBDDataset(num_frames=40, width=640, height=480, seed=0, dynamic=True, dystart=6, spacing=0.025)
+    cfg = merge_config(default_config(), {"Training": {"tracking_graph": True}, "model_params": {"dynamic_model": True}})
+    t = cfg["Training"]
+    assert (t["init_itr_num"], t["tracking_itr_num"], t["mapping_itr_num"], t["window_size"], t["kf_interval"]) == (1050, 100, 50, 8, 5)
+    slam = SLAM(cfg, ds, save_dir=str(tmp_path))
+    res = slam.run(color_refinement_iters=200)
+    print(res)
+    g = slam.gaussians
+    assert res["frames"] == 40 and len(res["keyframes"]) >= 8 and g.deform_init and int(g.dygs.sum()) > 50
+    assert slam.backend.dynamic_map_iters == 200 and slam.frontend.graph_stats["replayed_frames"] >= 35
+    assert res["ate_rmse"] < 0.0040, res
+    b, a = res["before_opt"], res["after_opt"]
+    assert b["mean_psnr"] > 29.2 and b["l1_depth"] < 0.036 and b["mean_ssim"] > 0.90, res
+    assert a["mean_psnr"] > 34.9 and a["l1_depth"] < 0.018 and a["mean_ssim"] > 0.95, res                  # colour refinement did its job
+    assert os.path.exists(os.path.join(str(tmp_path), "point_cloud/final/point_cloud.ply"))
 
 
 def _tracking_fixture(P_scale=1.0):
@@ -334,7 +361,7 @@ def test_slam_with_tracking_graph_matches_eager_quality():
     st = slam.frontend.graph_stats
     print(res, st)
     assert st["replayed_frames"] >= 10 and st["captures"] >= 2
-    assert res["ate_rmse"] < 0.02 and res["before_opt"]["mean_psnr"] > 22.0, res
+    assert res["ate_rmse"] < 0.014 and res["before_opt"]["mean_psnr"] > 27.3, res        # measured 11.6 mm / 28.3 dB (16 frames only)
 
 
 def test_edge_mask_kernels_match_the_tensor_program():
