@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, f
 #ifndef GSR_EXACT_MATH
 #define GSR_EXACT_MATH 0
 #endif
+
 __device__ __forceinline__ float exact_power(float dx, float dy, float a, float b, float c) { return -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy; }
 __device__ __forceinline__ float exact_exp(float x) { return (float)exp((double)x); }
 

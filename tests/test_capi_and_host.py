@@ -55,6 +55,15 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     lib.gsr_adam_step.argtypes = [i, vp, vp]
     assert lib.gsr_adam_step(9, None, None) == -1 and lib.gsr_adam_step(0, None, None) == 0
     assert lib.gsr_l1_loss_workspace_size() > 0
+    # the multi-view entry point rejects bad arguments before it touches the device
+    assert {"gsr_forward_views", "gsr_backward_views", "gsr_views_scratch_size"} <= syms
+    lib.gsr_forward_views.restype = i
+    lib.gsr_forward_views.argtypes = [i, vp, vp, vp, vp, i, i, i, vp, i, i, vp, f, f, f, i, vp]
+    assert lib.gsr_forward_views(0, None, None, None, None, 10, 0, 1, None, 64, 64, None, 1.0, 1.0, 1.0, 0, None) == -1
+    assert b"gsr_forward_views" in lib.gsr_last_error()
+    lib.gsr_views_scratch_size.restype = ctypes.c_size_t
+    lib.gsr_views_scratch_size.argtypes = [i, i, i, i]
+    assert lib.gsr_views_scratch_size(10, 1000, 1, 3) >= 10 * 1000 * 14 * 4
     # deformation_field.h
     import hexplane
     i64 = ctypes.c_int64
