@@ -98,14 +98,14 @@ class Scene:
 
 
 def csrc_digest():
-    """sha256 over the kernel sources (4dgs-slam_amd/csrc/*, include/*): identifies the code a committed PMC traffic figure belongs to."""
+    """sha256 over the device sources (4dgs-slam_amd/csrc/*.h, *.hip): identifies the kernels a committed PMC traffic figure belongs to."""
     import hashlib
     h = hashlib.sha256()
-    for d in (os.path.join(PKG, "csrc"), os.path.join(REPO, "include")):
-        for name in sorted(os.listdir(d)):
-            if name.endswith((".h", ".hip", ".cpp", ".sh")):
-                h.update(name.encode())
-                h.update(open(os.path.join(d, name), "rb").read())
+    d = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/r02 (tools/profile_round2.sh) + gpurun_out/counters_r02 -> profiles/r02_*: rocprofv3 kernel stats, HBM traffic per launch
+"""gpurun_out/<tag> (tools/profile_round2.sh / profile_round3.sh) + gpurun_out/counters_<tag> -> profiles/<tag>_* (tag = argv[1], default r02): rocprofv3 kernel stats, HBM traffic per launch
 (FETCH_SIZE / WRITE_SIZE collected in separate passes, KiB units, gfx950 FETCH_SIZE half-count correction -- MI355X_MICROARCH.md 'HBM'),
 the SQ counters of the tile kernels, and the JSON lines of the benches."""
 import collections
@@ -12,7 +12,9 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst, tag = os.path.join(REPO, "gpurun_out", "r02"), os.path.join(REPO, "profiles"), "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(REPO, "gpurun_out", tag), os.path.join(REPO, "profiles")
+sys.path.insert(0, REPO)
 
 
 def agg(pattern):
@@ -41,6 +43,10 @@ for k in sorted(fe):
     e.update(sq.get(k, {}))
     out["kernels"][short] = e
 out["render_bwd_bytes_per_launch"] = out["kernels"]["render_bwd"]["hbm_bytes_per_launch"]
+# provenance: bench.py quotes this figure only when it runs on the kernel sources it was collected on (bench.csrc_digest)
+import bench as bench_module
+out["csrc_sha256"] = bench_module.csrc_digest()
+out["head"] = subprocess.run(["git", "-C", REPO, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 bench = json.load(open(os.path.join(src, "bench.json")))
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 out["render_bwd_traffic_over_algorithmic"] = out["render_bwd_bytes_per_launch"] / alg
@@ -48,7 +54,8 @@ out["whole_step_traffic_bytes"] = sum(v["hbm_bytes_per_launch"] for v in out["ke
 out["whole_step_traffic_over_algorithmic"] = out["whole_step_traffic_bytes"] / bench["roofline"]["whole_step_algorithmic_bytes"]
 json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "tracking_graph.json", "config3.json", "render_wrapper.json", "slam_demo.json",
-             "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json"):
+             "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json",
+             "phase_cycles.json", "views.json", "views_deltas.json", "views_100k.json", "backend_map.jsonl"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('iterationflow', 'iteration_flow').replace('iterationnodesflow', 'iteration_nodes_flow').replace('iterationnodes', 'iteration_nodes')}"))
@@ -59,6 +66,6 @@ for name in ("bench.json", "bench_under_rocprof.json"):
         b = json.load(open(p))
         b["roofline"]["traffic"] = out["render_bwd_bytes_per_launch"]
         json.dump(b, open(p, "w"))
-subprocess.run([sys.executable, os.path.join(REPO, "tools", "collect_counters.py"), "r02", "r02"], check=True)
+subprocess.run([sys.executable, os.path.join(REPO, "tools", "collect_counters.py"), tag, tag], check=True)
 print(json.dumps({k: (round(v["rocprof_avg_us"], 1) if v["rocprof_avg_us"] else None, int(v["hbm_bytes_per_launch"])) for k, v in out["kernels"].items()}))
 print("render_bwd traffic / algorithmic:", round(out["render_bwd_traffic_over_algorithmic"], 2), " whole step:", round(out["whole_step_traffic_over_algorithmic"], 2))
