@@ -1631,7 +1631,14 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
     hipStream_t stream = (hipStream_t)stream_;
     const int n = height * width;
     hipLaunchKernelGGL(edge_intensity_kernel, dim3((width + 15) / 16, (height + 15) / 16), dim3(256), 0, stream, image, height, width, eps, intensity);
-    hipLaunchKernelGGL(radix_select_kernel, dim3(1), dim3(1024), 0, stream, (const float*)intensity, n, (n - 1) / 2, median);   // torch.median: the lower one
+    // scratch of the radix select (260 words per device, allocated once; the selects of one device are stream-ordered by their callers)
+    static uint32_t* select_state[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!select_state[dev]) GSR_HIP_CHECK(hipMalloc((void**)&select_state[dev], 260 * sizeof(uint32_t)));
+    GSR_HIP_CHECK(hipMemsetAsync(select_state[dev], 0, 260 * sizeof(uint32_t), stream));
+    for (int shift = 24; shift >= 0; shift -= 8)      // torch.median: the lower one of the two middle elements
+        hipLaunchKernelGGL(radix_select_pass_kernel, dim3(SELECT_BLOCKS), dim3(1024), 0, stream, (const float*)intensity, n, (n - 1) / 2, shift, select_state[dev], median);
     hipLaunchKernelGGL(edge_compare_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)intensity, n, (const float*)median, edge_threshold, mask);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;

@@ -268,45 +268,62 @@ __global__ void __launch_bounds__(256) edge_intensity_kernel(const float* __rest
     intensity[(size_t)y * W + x] = sqrtf(gv * gv + gh * gh);
 }
 
-// k-th smallest (0-based) of n non-negative floats: their bit patterns order like unsigned integers
-__global__ void __launch_bounds__(1024) radix_select_kernel(const float* __restrict__ x, int n, int k, float* __restrict__ out)
+// k-th smallest (0-based) of n non-negative floats: their bit patterns order like unsigned integers. Radix select, one launch per 8-bit
+// digit (most significant first): every block histograms the digit of its slice's candidates in LDS (the top digit of an image's
+// gradient magnitudes falls into a handful of bins: there one atomic per (wave, distinct digit) instead of 64 serialised ones on the
+// same word), adds its bins to the global histogram, and the block that arrives last (ticket) picks the bin that holds the k-th
+// element and narrows (prefix, mask, k) for the next launch. state: {prefix, mask, k, ticket, hist[256]}, zero before the first launch.
+// (Round 2 ran ONE block over the whole image four times: 1.9 ms per 640x480 frame on textured input.)
+constexpr int SELECT_BLOCKS = 64;
+__global__ void __launch_bounds__(1024) radix_select_pass_kernel(const float* __restrict__ x, int n, int k0, int shift, uint32_t* __restrict__ state,
+                                                                 float* __restrict__ out)
 {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_mask, s_k;
-    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_k = (uint32_t)k; }
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t prefix = s_prefix, mask = s_mask;
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + (int)threadIdx.x;
-            const uint32_t u = i < n ? __float_as_uint(x[i]) : 0u;
-            bool todo = i < n && (u & mask) == prefix;
-            const uint32_t d = (u >> shift) & 255u;
-            if (shift >= 16) {
-                // the high digits of an image's gradient magnitudes fall into a handful of bins: one atomic per (wave, distinct digit) instead
-                // of 64 serialised ones on the same LDS word (342 -> 60 us per frame)
-                unsigned long long left = __ballot(todo);
-                while (left) {
-                    const uint32_t d0 = (uint32_t)__shfl((int)d, (int)__builtin_ctzll(left), 64);
-                    const unsigned long long same = __ballot(todo && d == d0);
-                    if (todo && d == d0 && (int)__builtin_ctzll(same) == (int)(threadIdx.x & 63)) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
-                    left &= ~same;
-                    todo = todo && d != d0;
-                }
-            } else if (todo) {
-                atomicAdd(&hist[d], 1u);
+    __shared__ uint32_t s_last;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t prefix = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t mask = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = blockIdx.x * 1024; i0 < n; i0 += SELECT_BLOCKS * 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        const uint32_t u = i < n ? __float_as_uint(x[i]) : 0u;
+        bool todo = i < n && (u & mask) == prefix;
+        const uint32_t d = (u >> shift) & 255u;
+        if (shift >= 24) {
+            unsigned long long left = __ballot(todo);
+            while (left) {
+                const uint32_t d0 = (uint32_t)__shfl((int)d, (int)__builtin_ctzll(left), 64);
+                const unsigned long long same = __ballot(todo && d == d0);
+                if (todo && d == d0 && (int)__builtin_ctzll(same) == (int)(threadIdx.x & 63)) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+                left &= ~same;
+                todo = todo && d != d0;
             }
+        } else if (todo) {
+            atomicAdd(&hist[d], 1u);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t kk = s_k, b = 0;
-            for (; b < 255; b++) { if (kk < hist[b]) break; kk -= hist[b]; }
-            s_k = kk; s_prefix = prefix | (b << shift); s_mask = mask | (255u << shift);
-        }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = __uint_as_float(s_prefix);
+    __syncthreads();
+    if (threadIdx.x < 256 && hist[threadIdx.x]) __hip_atomic_fetch_add(&state[4 + threadIdx.x], hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                           // (every wave waits for its own atomics' returns before the barrier releases it)
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(&state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < 256) hist[threadIdx.x] = __hip_atomic_load(&state[4 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t kk = shift >= 24 ? (uint32_t)k0 : __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = 0;
+        for (; b < 255; b++) { if (kk < hist[b]) break; kk -= hist[b]; }
+        const uint32_t np = prefix | (b << shift);
+        __hip_atomic_store(&state[0], np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[1], mask | (255u << shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[2], kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (shift == 0) out[0] = __uint_as_float(np);
+    }
+    if (threadIdx.x < 256) __hip_atomic_store(&state[4 + threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next digit
 }
 
 __global__ void __launch_bounds__(256) edge_compare_kernel(const float* __restrict__ intensity, int n, const float* __restrict__ median, float edge_threshold,
