@@ -233,15 +233,17 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         // group), and whether any pixel still has T > 0.5 -- only then can an entry bump n_touched (forward.cu:369-371), and
         // the loop variant without that bookkeeping is shorter.
         // n_touched bookkeeping: the wave visits each entry of the group once, so the count of entry jj is WRITTEN into lane jj
-        // of a VGPR (s_bcnt1 + v_writelane) and the 64 counts go to LDS with one ds_add per group.
+        // of a VGPR (s_bcnt1, then a plain lane == jj select: v_writelane would need m0, which inline asm must not clobber) and the
+        // 64 counts go to LDS with one ds_add per group.
         //
-        // The pair loop is software-pipelined over a compacted INDEX LIST: only ~3 waves per SIMD exist for a 640x480 frame (4 800
-        // in all), so nothing but the wave itself can cover its LDS latency. Each quadrant wave first turns its four ballot masks
-        // into four lists of LDS row offsets (v_mbcnt ranks, one ds_write per group); the loop is then counted, takes two entries
-        // per trip, and issues the reads of the NEXT trip (rows known from the list, fetched one trip further ahead) before it
-        // evaluates the current one. With the s_ff1 walk the row of the next entry was only known after the SALU pop, and every
-        // pair paid the full ds_read latency in front of its first FMA.
-        FWD_T(tk_stage += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
+        // The pair loop runs over a compacted INDEX LIST and is software-pipelined: each quadrant wave first turns its four ballot masks
+        // into four lists of LDS row offsets (v_mbcnt ranks, one ds_write per group); the loop is then counted, keeps two entries in
+        // flight (register sets A / B, each refilled right after its pair has been evaluated) and reads the rows two entries ahead,
+        // so no pair waits for its ds_reads. What that bought is small (69 -> 67 us): per-wave cycle accounting (tools/phase_cycles.py,
+        // profiles/r03_phase_cycles.json) shows this phase at ~310 cycles per pair and wave with 4.7 waves per SIMD all in it at once
+        // = ~2 cycles per wave-instruction per SIMD: the SIMDs' issue rate, not latency, bounds the pair phase. Chunk-parallel
+        // compositing (one block per 128 entries) would therefore add its 40 % of extra pair work on top of an
+        // already saturated phase; what idles the chip is the SORT phase in front of it (every tile sorts at the same time).
         int cnt4[4];
 #pragma unroll
         for (int sw = 0; sw < 4; sw++) {
