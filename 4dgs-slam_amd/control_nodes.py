@@ -34,6 +34,8 @@ def _lib():
         i64, vp, i = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
         lib.gsr_knn_points.restype = i
         lib.gsr_knn_points.argtypes = [i64, i64, i, i, vp, vp, vp, vp, vp]
+        lib.gsr_knn_points_batch.restype = i
+        lib.gsr_knn_points_batch.argtypes = [i64, i64, i64, i, i, vp, vp, vp, vp, vp]
         lib.gsr_node_blend_forward.restype = i
         lib.gsr_node_blend_forward.argtypes = [ctypes.POINTER(_Blend), vp, vp, vp, vp, vp, vp, vp]
         lib.gsr_node_blend_workspace_size.restype = ctypes.c_size_t
@@ -66,11 +68,9 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = 
     idx = torch.empty((B, N, K), dtype=torch.int64, device=a.device)
     lib = _lib()
     with torch.cuda.device(a.device):
-        for bi in range(B):
-            rc = lib.gsr_knn_points(N, b.shape[1], D, K, a[bi].data_ptr(), b[bi].data_ptr(), dists[bi].data_ptr(), idx[bi].data_ptr(),
-                                    _C._stream(a.device))
-            if rc < 0:
-                _C._err(lib, rc, "gsr_knn_points")
+        rc = lib.gsr_knn_points_batch(B, N, b.shape[1], D, K, a.data_ptr(), b.data_ptr(), dists.data_ptr(), idx.data_ptr(), _C._stream(a.device))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_knn_points_batch")
     knn = None
     if return_nn:
         knn = torch.gather(p2[:, None].expand(-1, N, -1, -1), 2, idx[..., None].expand(-1, -1, -1, D))

@@ -1424,6 +1424,29 @@ int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* f
 }
 
 // ---- SC-GS control nodes (include/control_nodes.h) ------------------------------------------------------------------------------
+int gsr_knn_points_batch(int64_t B, int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B < 0 || B > 65535 || n < 0 || m < 0 || D < 1 || D > GSR_KNN_MAX_DIM || K < 1 || K > GSR_KNN_MAX_K || (B > 0 && n > 0 && (!p1 || !dist2 || !idx)) ||
+        (B > 0 && m > 0 && !p2)) {
+        g_last_error = "gsr_knn_points_batch: null / invalid argument (0 <= B <= 65535, 1 <= D <= 32, 1 <= K <= 32)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (B == 0 || n == 0) return 0;
+    if (D <= 4 && K > 4 && m <= 64 * 16) {            // small candidate sets, longer lists: one wave per query, all batch elements in one launch
+        const dim3 grid((unsigned)((n + NODE_BLOCK / 64 - 1) / (NODE_BLOCK / 64)), (unsigned)B), block(NODE_BLOCK);
+#define GSR_KNNW(C) hipLaunchKernelGGL((knn_points3_wave_kernel<C>), grid, block, 0, stream, n, m, D, K, p1, p2, dist2, idx)
+        if (m <= 64 * 4) GSR_KNNW(4); else if (m <= 64 * 8) GSR_KNNW(8); else GSR_KNNW(16);
+#undef GSR_KNNW
+        GSR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    for (int64_t b = 0; b < B; b++) {
+        const int rc = gsr_knn_points(n, m, D, K, p1 + b * n * D, p2 ? p2 + b * m * D : p2, dist2 + b * n * K, idx + b * n * K, stream_);
+        if (rc < 0) return rc;
+    }
+    return 0;
+}
+
 int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

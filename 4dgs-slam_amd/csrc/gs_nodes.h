@@ -23,14 +23,18 @@ constexpr int NODE_BATCH = 8;             // LDS reads in flight per lane in the
 constexpr int NODE_GRAD = 21;             // per node: trans 3, rot 4, scale 3, frame 9, radius 1, weight 1
 constexpr int NODE_LDS_MAX = 720;         // backward keeps m * 21 floats in LDS up to this many nodes (< 64 KB)
 
-// sorted insertion of (d, j) into the ascending list bd[0..K): strict <, so among equal distances the earlier index stays first
+// sorted insertion of (d, j) into the ascending list bd[0..K): strict < for the new entry, so among equal distances the earlier index
+// stays first; from the slot it takes on, every older entry moves down one place unconditionally (comparing the displaced entry
+// again would let it fall behind a later entry of the same distance)
 template <int KMAX>
 __device__ __forceinline__ void topk_insert(float (&bd)[KMAX], int (&bi)[KMAX], const int K, float d, int j)
 {
+    bool placed = false;
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         if (k < K) {
-            const bool sw = d < bd[k];
+            const bool sw = placed || d < bd[k];
+            placed = sw;
             const float td = sw ? bd[k] : d;
             const int ti = sw ? bi[k] : j;
             bd[k] = sw ? d : bd[k];
@@ -54,9 +58,11 @@ __device__ __forceinline__ float topk_worst(const float (&bd)[KMAX], const int K
 template <int K>
 __device__ __forceinline__ void topk_insert_exact(float (&bd)[K], int (&bi)[K], float d, int j)
 {
+    bool placed = false;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const bool sw = d < bd[k];
+        const bool sw = placed || d < bd[k];
+        placed = sw;
         const float td = sw ? bd[k] : d;
         const int ti = sw ? bi[k] : j;
         bd[k] = sw ? d : bd[k];
@@ -141,6 +147,61 @@ knn_points3_kernel(const int64_t n, const int64_t m, const int D, const int K, c
             dist2[i * K + k] = ok ? bd[k] : 0.f;
             idx[i * K + k] = ok ? bi[k] : 0;
         }
+    }
+}
+
+// The same for small candidate sets and longer lists (m <= 64 * CMAX, K > 4), batched: ONE WAVE per query. The thread-per-query kernel
+// above needs n >> 10^4 queries to fill the chip and pays a divergent register insertion per accepted candidate; the ARAP term of the
+// dynamic mapping loop asks for the 11 nearest of 512 nodes for 512 queries x ~10 time samples per iteration (deform_utils.py:74) --
+// 2 blocks of work per call, 385 us each. Here a lane holds candidates lane, lane + 64, ... as 64-bit keys (distance bits << 32 | index:
+// distances are >= +0, so their bit patterns order like the values, and the index breaks ties the way the insertion lists do), and
+// the K nearest are K rounds of "lane minimum -> wave minimum -> knock out". Same distance arithmetic, same order, same padding.
+template <int CMAX>
+__global__ void __launch_bounds__(NODE_BLOCK)
+knn_points3_wave_kernel(const int64_t n, const int64_t m, const int D, const int K, const float* __restrict__ p1, const float* __restrict__ p2,
+                        float* __restrict__ dist2, int64_t* __restrict__ idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (NODE_BLOCK / 64) + (threadIdx.x >> 6);
+    if (i >= n) return;                                            // wave-uniform
+    const int64_t b = blockIdx.y;
+    p1 += (b * n + i) * D; p2 += b * m * D; dist2 += (b * n + i) * K; idx += (b * n + i) * K;
+    float x[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) x[d] = d < D ? p1[d] : 0.f;
+    constexpr unsigned long long NONE = ~0ull;
+    unsigned long long key[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; c++) {
+        const int j = c * 64 + lane;
+        key[c] = NONE;
+        if (j < m) {
+            float q[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) q[d] = d < D ? p2[(int64_t)j * D + d] : 0.f;
+            const float tx = x[0] - q[0], ty = x[1] - q[1], tz = x[2] - q[2], tw = x[3] - q[3];
+            const float d2 = fmaf(tw, tw, fmaf(tz, tz, fmaf(ty, ty, tx * tx)));
+            if (d2 == d2) key[c] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;        // a NaN distance is never accepted
+        }
+    }
+    unsigned long long mine = NONE;                                // lane k keeps the k-th nearest
+    for (int k = 0; k < K; k++) {
+        unsigned long long w = key[0];
+#pragma unroll
+        for (int c = 1; c < CMAX; c++) w = key[c] < w ? key[c] : w;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const unsigned long long o = __shfl_xor(w, s);
+            w = o < w ? o : w;
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) key[c] = key[c] == w ? NONE : key[c];
+        if (lane == k) mine = w;
+    }
+    if (lane < K) {
+        const bool ok = mine != NONE;
+        dist2[lane] = ok ? __uint_as_float((unsigned)(mine >> 32)) : 0.f;
+        idx[lane] = ok ? (int64_t)(mine & 0xffffffffull) : 0;
     }
 }
 

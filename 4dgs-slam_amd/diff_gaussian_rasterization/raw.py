@@ -238,8 +238,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_xyz, g_fdc, g_frest = views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, M - 1, 3)
             g_logit, g_ls, g_rot = views[3].view(logit_opacity.shape), views[4].view(P, S), views[5].view(P, 4)
         tau = flat[o:o + 6]
-        K = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
-        g_dx, g_ds, g_dr = K(dx), K(ds), K(dr)
+        g_dx, g_ds, g_dr = _zero_grads_like(dx, ds, dr)
         keep = []
         desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, keep, gather)
         out = _RawGrads()
@@ -266,6 +265,23 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
         # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
         return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None and not pose_only) else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
+
+
+def _zero_grads_like(*tensors):
+    """Zero-filled fp32 gradient buffers for the given (optional) tensors out of ONE allocation and ONE fill: the kernels only write the
+    rows of visible Gaussians, and four separate zeros_like calls are four launches per backward pass."""
+    live = [t for t in tensors if t is not None and t.numel()]
+    if not live:
+        return [None] * len(tensors)
+    flat = torch.zeros((sum(t.numel() for t in live),), dtype=torch.float32, device=live[0].device)
+    out, o = [], 0
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            out.append(None)
+        else:
+            out.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+    return out
 
 
 def gather_from_mask(mask: torch.Tensor) -> torch.Tensor:
@@ -344,8 +360,7 @@ class _RasterizeFlowRaw(torch.autograd.Function):
             return v
         g_xyz, g_ls, g_rot, g_logit, g_m2d = take(3).view(P, 3), take(S), take(4), take(1), take(3).view(P, 3)
         tau = flat[o:o + 6]
-        Z = lambda t: None if t is None or t.numel() == 0 else torch.zeros_like(t, dtype=torch.float32)
-        g_dx1, g_dx2, g_ds, g_dr = Z(dx1), Z(dx2), Z(ds), Z(dr)
+        g_dx1, g_dx2, g_ds, g_dr = _zero_grads_like(dx1, dx2, ds, dr)
         keep = []
         desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, dx1, ds, dr, keep)
         desc.features_dc = None

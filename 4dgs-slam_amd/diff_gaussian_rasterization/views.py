@@ -15,7 +15,7 @@ import torch
 
 from . import _C
 from .autograd import _pose_grad
-from .raw import _RawGrads, _RawInputs, _acc_params, _describe, _f32, _targets
+from .raw import _RawGrads, _RawInputs, _acc_params, _describe, _f32, _targets, _zero_grads_like
 
 MAX_VIEWS = 12
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
@@ -154,6 +154,7 @@ class _RasterizeViewsRaw(torch.autograd.Function):
         views = (_View * V)()
         zc = zd = None
         delta_grads = []
+        zero_deltas = [None] * (3 * V) if pose_only else _zero_grads_like(*deltas[:3 * V])      # one allocation, one fill for all views
         for v in range(V):
             rs, w = settings[v], views[v]
             g_color, g_depth = grads[5 * v], grads[5 * v + 2]
@@ -172,8 +173,7 @@ class _RasterizeViewsRaw(torch.autograd.Function):
             w.num_rendered = ctx.num_rendered[v]
             w.dL_dcolor, w.dL_ddepth = _f32(g_color.to(torch.float32), "dL_dcolor", keep), _f32(g_depth.to(torch.float32), "dL_ddepth", keep)
             w.dL_dmean2D, w.dL_dtau_sum = per_view_out[v, :P * 3].data_ptr(), per_view_out[v, P * 3:].data_ptr()
-            K = lambda t: None if (t is None or t.numel() == 0 or pose_only) else torch.zeros_like(t, dtype=torch.float32)
-            gd = (K(dx), K(ds), K(dr))
+            gd = tuple(zero_deltas[3 * v: 3 * v + 3])
             delta_grads.append(gd)
             w.ddx, w.dds, w.ddr = (None if g is None else g.data_ptr() for g in gd)
         scratch = None

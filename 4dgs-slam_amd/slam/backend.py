@@ -49,6 +49,7 @@ class BackEnd:
         self.frames_to_optimize = config["Training"]["pose_window"]
         self.log = []
         self._view_shard = None
+        self._flow_targets = {}          # (keyframe, earlier keyframe) -> masked flow targets of _flow_loss
 
     @property
     def shard(self):
@@ -91,6 +92,7 @@ class BackEnd:
     def reset(self):
         """:143-157."""
         self.iteration_count, self.occ_aware_visibility, self.viewpoints, self.current_window = 0, {}, {}, []
+        self._flow_targets = {}
         self.initialized = not self.monocular
         if self.gaussians.get_xyz.shape[0]:
             self.gaussians.prune_points(self.gaussians.unique_kfIDs >= 0)
@@ -332,7 +334,7 @@ class BackEnd:
             extra = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]      # the same draw on every rank
             with_flow = use_net and flow_weight > 0 and hasattr(self.dataset, "gt_flow")
             if use_net:       # every time sample this rank asks the node network for in this iteration, as one batch (deform_model.begin_iteration)
-                nodes, times, plans = g.deform.deform, [], []
+                nodes, times, sample_times, plans = g.deform.deform, [], [], []
                 arap_delta = float(t.get("delta", 5)) * g.time_interval              # :325,:518
                 for k, viewpoint in enumerate(views + extra):
                     # the regularisers' random time samples (:517-519 window views: ARAP with 4 samples over `delta` intervals; :646-648
@@ -344,11 +346,11 @@ class BackEnd:
                     if shard.owns(k):
                         times.append(viewpoint.time)
                     if shard.rank == 0:
-                        times += plan["arap"] + plan["elastic"]
+                        sample_times += plan["arap"] + plan["elastic"]
                     closest = self.find_closest_keyframe(viewpoint.uid) if (with_flow and shard.owns(k)) else None
                     if closest is not None:
                         times.append(self.viewpoints[closest].time)
-                nodes.begin_iteration(times)
+                nodes.begin_iteration(times, positions_only=sample_times)
                 self._delta_cache = {}
                 # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
                 nv = len(views)
@@ -433,16 +435,20 @@ class BackEnd:
         g = self.gaussians
         dx1, ds1, dr1 = deltas
         dx2, ds2, dr2 = self._deltas(other)
-        flow_back, _ = self.dataset.gt_flow(viewpoint.uid, closest)          # this keyframe -> the earlier one
-        flow_fwd, _ = self.dataset.gt_flow(closest, viewpoint.uid)
-        loss = 0.0
+        # constants of the keyframe pair: the flow on the moving pixels and their mask in the renderer's [C,H,W] layout (:486-488,:503-505
+        # mask both sides of the difference by ~motion_mask; with a 0 / 1 mask that is the masked target minus the masked rendering)
+        cache = self._flow_targets
+        hit = cache.get((viewpoint.uid, closest))
+        if hit is None:
+            def target(flow, mask):
+                m = (~mask).to(torch.float32)[None]
+                return (flow.permute(2, 0, 1) * m).contiguous(), m
+            hit = cache[(viewpoint.uid, closest)] = target(self.dataset.gt_flow(viewpoint.uid, closest)[0], viewpoint.motion_mask) + \
+                target(self.dataset.gt_flow(closest, viewpoint.uid)[0], other.motion_mask)          # this keyframe -> the earlier one, and back
+        t_back, m1, t_fwd, m2 = hit
         pk = render_flow(pc=g, viewpoint_camera1=viewpoint, viewpoint_camera2=other, d_xyz1=dx1, d_xyz2=dx2, d_rotation1=dr1, d_scaling1=ds1)
-        m1 = (~viewpoint.motion_mask)[..., None]
-        loss = loss + flow_weight * torch.abs(flow_back * m1 - pk["render"][:2].permute(1, 2, 0) * m1).mean()
         pk2 = render_flow(pc=g, viewpoint_camera1=other, viewpoint_camera2=viewpoint, d_xyz1=dx2, d_xyz2=dx1, d_rotation1=dr2, d_scaling1=ds2)
-        m2 = (~other.motion_mask)[..., None]
-        loss = loss + flow_weight * torch.abs(flow_fwd * m2 - pk2["render"][:2].permute(1, 2, 0) * m2).mean()
-        return loss
+        return flow_weight * ((t_back - pk["render"][:2] * m1).abs().mean() + (t_fwd - pk2["render"][:2] * m2).abs().mean())
 
     def color_refinement(self, iteration_total=1500, views_per_iter=10):
         """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""

@@ -76,9 +76,14 @@ def connectivity_from_points(points, radius=0.1, K=10, least_edge_num=3):
 
 def edge_matrix(verts, nn_idx, keep):
     """produce_edge_matrix_nfmt (deform_utils.py:35-42): E[i, n] = verts[i] - verts[nn_idx[i, n]] on the kept edges, 0 elsewhere.
-    verts [..., Nv, 3] with nn_idx / keep [..., Nv, K] (same leading dimensions)."""
-    nb = torch.gather(verts[..., None, :, :].expand(*verts.shape[:-2], nn_idx.shape[-2], verts.shape[-2], 3), -2,
-                      nn_idx[..., None].expand(*nn_idx.shape, 3))
+    verts [..., Nv, 3] with nn_idx / keep [..., Nv, K] (leading dimensions broadcast against those of verts)."""
+    lead = verts.shape[:-2]
+    Nv, K = nn_idx.shape[-2:]
+    flat = verts.reshape(-1, verts.shape[-2], 3)
+    # a gather along the vertex axis of the [B, Nv, 3] table itself: its backward scatters into a table of that size (gathering from a
+    # view expanded to [B, Nv, Nv, 3] would zero-fill, scatter into and reduce 3 MB per time sample at 512 nodes)
+    idx = nn_idx.expand(*lead, Nv, K).reshape(-1, Nv * K, 1).expand(-1, -1, 3)
+    nb = torch.gather(flat, 1, idx).reshape(*lead, Nv, K, 3)
     return (verts[..., :, None, :] - nb) * keep[..., None]
 
 
@@ -94,17 +99,17 @@ def estimate_rotation(E0, Et, weight, rotations=kabsch_rotations):
 def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
     """cal_arap_error (deform_utils.py:177-205) without edge weights (every kept edge weighs 1) and without its random vertex subsample,
     which only starts above 512 vertices (the node budget). nodes_seq [..., T, Nv, 3]; nn_idx / keep [..., Nv, K] from
-    connectivity_from_points(nodes_seq[..., 0, :, :]). Returns the error per leading index."""
+    connectivity_from_points(nodes_seq[..., 0, :, :]). Returns the error per leading index. The reference loops over the samples
+    1 .. T-1 (:190-204); here they are one more tensor axis (same terms, summed in one reduction)."""
+    if nodes_seq.shape[-3] < 2:
+        return torch.zeros(nodes_seq.shape[:-3], dtype=nodes_seq.dtype, device=nodes_seq.device)
     w = keep.to(nodes_seq.dtype)
-    E0 = edge_matrix(nodes_seq[..., 0, :, :], nn_idx, keep)
-    err = 0
-    for idx in range(1, nodes_seq.shape[-3]):
-        Et = edge_matrix(nodes_seq[..., idx, :, :], nn_idx, keep)
-        with torch.no_grad():
-            R = estimate_rotation(E0.detach(), Et.detach(), w, rotations)
-        stretch = Et - torch.einsum("...ab,...kb->...ka", R, E0)              # target edges minus the rigidly rotated source edges
-        err = err + (w * stretch.norm(dim=-1) ** 2).sum(dim=(-2, -1))
-    return err
+    E = edge_matrix(nodes_seq, nn_idx[..., None, :, :], keep[..., None, :, :])          # [..., T, Nv, K, 3]
+    E0, Et = E[..., :1, :, :, :], E[..., 1:, :, :, :]
+    with torch.no_grad():
+        R = estimate_rotation(E0.detach(), Et.detach(), w[..., None, :, :], rotations)  # [..., T-1, Nv, 3, 3]
+    stretch = Et - torch.einsum("...ab,...kb->...ka", R, E0)                            # target edges minus the rigidly rotated source edges
+    return (w[..., None, :, :] * stretch.square().sum(dim=-1)).sum(dim=(-3, -2, -1))
 
 
 def elastic_error(nodes_t, nn_weight, nn_idx):
@@ -157,12 +162,16 @@ class NodeNetwork(nn.Module):
         emb = torch.cat([_embed(x, self.multires), _embed(t, self.t_multires)], -1)
         return self.from_embedding(emb)
 
-    def from_embedding(self, emb):
+    def trunk(self, emb):
         h = emb
         for i, layer in enumerate(self.linear):
             h = torch.relu(layer(h))
             if i in self.skips:
                 h = torch.cat([emb, h], -1)
+        return h
+
+    def from_embedding(self, emb):
+        h = self.trunk(emb)
         out = {"d_xyz": self.gaussian_warp(h), "d_rotation": self.gaussian_rotation(h), "d_scaling": self.gaussian_scaling(h), "d_opacity": None,
                "d_color": None}
         if self.local_frame:
@@ -234,8 +243,13 @@ class ControlNodes(nn.Module):
     # A dynamic mapping iteration (utils/slam_backend.py:336-771) asks the node network for 4-6 time samples per view (the view's
     # deltas, its flow partner's, the ARAP / elastic samples around it): ~60 evaluations of a 512-row MLP, ~40 launches each, plus
     # their backward. The nodes and weights only change at optimizer.step(), so all samples of an iteration are ONE batch.
-    def begin_iteration(self, times):
-        keys = sorted({time_key(t) for t in times})
+    def begin_iteration(self, times, positions_only=()):
+        """`times`: samples whose every head is needed (a view's deltas, its flow partner's); `positions_only`: samples of which only the
+        node positions are read (the ARAP / elastic regularisers) -- the trunk runs on all of them, the translation head too, the rotation /
+        scaling / local-frame heads on the first group only."""
+        full = sorted({time_key(t) for t in times})
+        rest = sorted({time_key(t) for t in positions_only} - set(full))
+        keys = full + rest
         if not keys or self.node_num == 0:
             self._batch = None
             return
@@ -244,9 +258,20 @@ class ControlNodes(nn.Module):
         xe = _embed(self.nodes.detach(), net.multires)
         te = _embed(tt, net.t_multires)
         emb = torch.cat([xe[None].expand(len(keys), M, -1), te[:, None].expand(len(keys), M, -1)], -1)
-        out = net.from_embedding(emb.reshape(len(keys) * M, -1))
-        out = {k: v.reshape(len(keys), M, -1) for k, v in out.items() if v is not None}
-        self._batch = {key: {k: v[i] for k, v in out.items()} for i, key in enumerate(keys)}
+        h = net.trunk(emb.reshape(len(keys) * M, -1))
+        # unbind, not out[i]: one backward node per head (a stack of the slices' gradients) instead of one per slice, each of which would
+        # zero-fill and accumulate a buffer of the whole batch (~250 launches per iteration at 90 time samples)
+        self._batch = {key: {} for key in keys}
+        for i, row in enumerate(net.gaussian_warp(h).reshape(len(keys), M, 3).unbind(0)):
+            self._batch[keys[i]]["d_xyz"] = row
+        if full:
+            hf = h[:len(full) * M]
+            heads = {"d_rotation": net.gaussian_rotation, "d_scaling": net.gaussian_scaling}
+            if net.local_frame:
+                heads["local_rotation"] = net.local_rotation
+            for name, head in heads.items():
+                for i, row in enumerate(head(hf).reshape(len(full), M, -1).unbind(0)):
+                    self._batch[full[i]][name] = row
         self._graph = None
 
     def end_iteration(self):
@@ -257,7 +282,7 @@ class ControlNodes(nn.Module):
         """:1038-1051: per-node translation / rotation / scale (/ local rotation) at time t [M,1] (key: the host-side value of t, see
         begin_iteration)."""
         o = self._batch.get(time_key(key)) if (key is not None and self._batch is not None) else None
-        if o is None:
+        if o is None or "d_rotation" not in o:            # not part of the iteration's batch (or batched for its positions only)
             o = self.network(self.nodes.detach(), t)
         return o
 
@@ -274,8 +299,10 @@ class ControlNodes(nn.Module):
         evaluation when there is one."""
         cols = []
         for t in times:
-            tt = torch.full((self.node_num, 1), float(t), dtype=torch.float32, device=self.device)
-            cols.append(self.node_deform(tt, t)["d_xyz"])
+            o = self._batch.get(time_key(t)) if self._batch is not None else None
+            if o is None:
+                o = self.node_deform(torch.full((self.node_num, 1), float(t), dtype=torch.float32, device=self.device))
+            cols.append(o["d_xyz"])
         return self.nodes.detach()[:, None, :] + torch.stack(cols, 1)
 
     def arap_loss(self, times):

@@ -32,6 +32,9 @@ extern "C" {
  * first.  dist2 [n, K] fp32, idx [n, K] int64.  If m < K the missing entries are dist2 = 0, idx = 0 (pytorch3d's padding).
  * 1 <= K <= 32, 1 <= D <= 32. */
 int gsr_knn_points(int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream);
+/* The batched form, pytorch3d.ops.knn_points(p1 [B, n, D], p2 [B, m, D], K) with equal lengths (utils/deform_utils.py:74 calls it on
+ * [B, Nv, 3] node positions): B independent searches in one call, outputs [B, n, K]. Same results as B calls of gsr_knn_points. */
+int gsr_knn_points_batch(int64_t B, int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream);
 
 typedef struct gsr_node_blend {
     int64_t n;                    /* Gaussians */

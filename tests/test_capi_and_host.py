@@ -93,6 +93,8 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     cl = control_nodes._lib()
     assert cl.gsr_knn_points(10, 10, 3, 33, None, None, None, None, None) == -1 and b"gsr_knn_points" in lib.gsr_last_error()
     assert cl.gsr_knn_points(0, 10, 3, 3, None, None, None, None, None) == -1          # p2 null with m > 0
+    assert cl.gsr_knn_points_batch(2, 10, 10, 3, 33, None, None, None, None, None) == -1 and b"gsr_knn_points_batch" in lib.gsr_last_error()
+    assert cl.gsr_knn_points_batch(0, 10, 10, 3, 3, None, None, None, None, None) == 0     # an empty batch is not an error
     blend = control_nodes._Blend(n=4, m=0, K=3, node_stride=3)
     assert cl.gsr_node_blend_forward(ctypes.byref(blend), None, None, None, None, None, None, None) == -1 and b"no control nodes" in lib.gsr_last_error()
     blend = control_nodes._Blend(n=4, m=8, K=9, node_stride=3)

@@ -57,6 +57,37 @@ def test_knn_points_against_oracle(n, m, D, K):
     assert torch.equal(out.knn[0, :, :kk], p2[0][out.idx[0, :, :kk]])
 
 
+@pytest.mark.parametrize("B,n,m,D,K", [(7, 512, 512, 3, 11), (3, 700, 1024, 3, 16), (2, 100, 300, 4, 32), (4, 65, 5, 2, 9), (5, 300, 2000, 3, 11), (3, 400, 600, 3, 3)])
+def test_knn_points_batched_equals_one_call_per_element(B, n, m, D, K):
+    """pytorch3d's batched form (deform_utils.py:74) in one call; small candidate sets with K > 4 take the wave-per-query kernel, whose lists
+    must be those of the thread-per-query kernel bit for bit (same distance arithmetic, ties to the lower index)."""
+    import ctypes
+    rng = np.random.default_rng(B * n + m)
+    p1 = torch.tensor(rng.normal(size=(B, n, D)).astype(np.float32), device=DEV)
+    p2 = torch.tensor(rng.normal(size=(B, m, D)).astype(np.float32), device=DEV)
+    p2[:, 1::7] = p2[:, ::7][:, :p2[:, 1::7].shape[1]]               # exact duplicates among the candidates: ties
+    out = cn.knn_points(p1, p2, K=K)
+    lib = cn._lib()
+    for b in range(B):
+        d1 = torch.empty((n, K), dtype=torch.float32, device=DEV)
+        i1 = torch.empty((n, K), dtype=torch.int64, device=DEV)
+        assert lib.gsr_knn_points(n, m, D, K, p1[b].data_ptr(), p2[b].data_ptr(), d1.data_ptr(), i1.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out.idx[b], i1) and torch.equal(out.dists[b], d1)
+    kk = min(K, m)
+    tie = out.dists[..., 1:kk] == out.dists[..., :kk - 1]            # among equal distances the lower index comes first (both kernels)
+    assert bool(tie.any()) and bool((out.idx[..., 1:kk] > out.idx[..., :kk - 1])[tie].all())
+    ref = torch.cdist(p1.double(), p2.double()) ** 2
+    want = ref.topk(kk, dim=-1, largest=False).values
+    assert torch.allclose(out.dists[..., :kk].double(), want, rtol=1e-5, atol=1e-6)
+    if K <= 4:
+        return
+    nan = p1.clone()
+    nan[0, 0, 0] = float("nan")                                      # a query with a NaN coordinate accepts nothing: pytorch3d's padding
+    got = cn.knn_points(nan, p2, K=K)
+    assert torch.all(got.idx[0, 0] == 0) and torch.all(got.dists[0, 0] == 0) and torch.equal(got.idx[0, 1:], out.idx[0, 1:])
+
+
 def test_knn_points_golden_trajectories_and_self_match():
     p = torch.tensor(G["knn_traj/p"], device=DEV)
     out = cn.knn_points(p, p, None, None, K=9)

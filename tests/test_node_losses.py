@@ -202,3 +202,21 @@ def test_batched_node_network_evaluation_equals_the_direct_one():
     assert pos.shape == (cn.node_num, 4, 3)
     cn.end_iteration()
     assert cn._batch is None
+    # samples of which only the positions are read (the regularisers'): the trunk and the translation head see them, the other heads
+    # do not; asking for every head of such a sample falls back to the direct evaluation; values and gradients are those of separate calls
+    extra = [0.4, 0.55, 0.1]                                  # 0.1 is also a full sample
+    cn.begin_iteration(times[:2], positions_only=extra)
+    assert set(cn._batch) == {0.1, 0.25, 0.4, 0.55} and set(cn._batch[0.4]) == {"d_xyz"} and "d_rotation" in cn._batch[0.1]
+    pos = cn.node_positions([0.4, 0.55, 0.1])
+    full = cn.node_deform(torch.full((cn.node_num, 1), 0.4), 0.4)
+    loss = pos.square().sum() + cn.node_deform(None, 0.25)["d_rotation"].sum() + full["d_scaling"].sum()
+    loss.backward()
+    got = [None if p.grad is None else p.grad.clone() for p in cn.network.parameters()]
+    cn.end_iteration()
+    cn.network.zero_grad()
+    direct = lambda tv: cn.network(cn.nodes.detach(), torch.full((cn.node_num, 1), tv))
+    want_pos = cn.nodes.detach()[:, None, :] + torch.stack([direct(tv)["d_xyz"] for tv in (0.4, 0.55, 0.1)], 1)
+    assert torch.allclose(pos, want_pos, rtol=1e-5, atol=1e-6)
+    (want_pos.square().sum() + direct(0.25)["d_rotation"].sum() + direct(0.4)["d_scaling"].sum()).backward()
+    for a, b in zip(got, cn.network.parameters()):
+        assert (a is None and b.grad is None) or torch.allclose(a, b.grad, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Dev probe: which source lines of a mapping iteration launch how many device kernels? Runs the SLAM demo for a few keyframes, then
+`BackEnd.map(iters=N)` (or map_static with --static) under torch.profiler (with_stack) and attributes every kernel launch to the innermost
+frame inside this repo. Usage: python tools/dev_dyn_ops.py [--static] [--iters 6] [--frames 17] [--wh 320 240]"""
+import collections
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "4dgs-slam_amd")):
+    sys.path.insert(0, p)
+from slam.dataset import SyntheticRGBDDataset  # noqa: E402
+from slam.system import SLAM, default_config, merge_config  # noqa: E402
+
+
+def arg(name, default, n=1):
+    if name not in sys.argv:
+        return default
+    i = sys.argv.index(name)
+    vals = [int(v) for v in sys.argv[i + 1:i + 1 + n]]
+    return vals[0] if n == 1 else vals
+
+
+dyn = "--static" not in sys.argv
+iters, frames, wh = arg("--iters", 6), arg("--frames", 17), arg("--wh", [320, 240], 2)
+torch.manual_seed(0)
+ds = SyntheticRGBDDataset(num_frames=frames, width=wh[0], height=wh[1], seed=0, dynamic=dyn, dystart=6 if dyn else None, spacing=0.03)
+cfg = merge_config(default_config(), {"Training": {"init_itr_num": 400, "init_gaussian_update": 100, "init_gaussian_reset": 200, "tracking_itr_num": 60,
+                                                   "static_map_iters": 30, "dynamic_map_iters": 80, "network_init_iters": 50, "gaussian_update_every": 60,
+                                                   "gaussian_update_offset": 20, "tracking_graph": True},
+                                      "Dataset": {"pcd_downsample": 32, "pcd_downsample_init": 8}, "opt_params": {"densify_from_iter": 150},
+                                      "model_params": {"dynamic_model": dyn}})
+for i in range(len(ds)):
+    ds[i]
+slam = SLAM(cfg, ds)
+slam.run()
+be = slam.backend
+window = list(be.current_window)
+run = (lambda n: be.map(window, iters=n, dynamic_network=True)) if dyn else (lambda n: be.map_static(window, iters=n))
+run(3)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+run(iters)
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / iters
+from torch.profiler import profile, ProfilerActivity  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+    run(iters)
+    torch.cuda.synchronize()
+by_line, by_op, ktime = collections.Counter(), collections.Counter(), collections.Counter()
+LAUNCH = ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync", "hipGraphLaunch", "hipModuleLaunchKernel", "hipExtLaunchKernel")
+for e in prof.events():
+    if e.device_type.name != "CPU":
+        ktime[e.name[:70]] += getattr(e, "device_time", 0) or getattr(e, "cuda_time", 0)
+        continue
+    if not e.name.startswith(LAUNCH):
+        continue
+    p, op, where = e.cpu_parent, None, None          # walk up to the aten op / python frame that caused this launch
+    top = e
+    while p is not None:
+        if op is None and (p.name.startswith("aten::") or "Backward" in p.name):
+            op = p.name
+        if where is None:
+            for fr in (p.stack or []):
+                if "4dgs-slam_amd" in fr and "torch/" not in fr:
+                    where = fr.split("4dgs-slam_amd/")[-1]
+                    break
+        top, p = p, p.cpu_parent
+    if where is None:
+        where = "(no python frame) " + top.name[:60]
+    by_line[where] += 1
+    by_op[(op or top.name)[:60]] += 1
+n_launch = sum(by_line.values())
+out = {"dynamic": dyn, "resolution": wh, "gaussians": int(be.gaussians.get_xyz.shape[0]), "window": len(window), "ms_per_iteration": wall * 1e3,
+       "launches_per_iteration": n_launch / iters,
+       "by_source_line_per_iteration": {k: round(v / iters, 1) for k, v in by_line.most_common(50)},
+       "by_op_per_iteration": {k: round(v / iters, 1) for k, v in by_op.most_common(40)},
+       "device_us_per_iteration_by_kernel": {k: round(v / iters, 1) for k, v in ktime.most_common(30)},
+       "device_us_per_iteration": round(sum(ktime.values()) / iters, 1)}
+print(json.dumps(out, indent=1))

@@ -14,7 +14,7 @@ cd $R
 bash tools/profile_counters.sh r03 > /dev/null 2>&1
 timeout 400 python bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
 if [ -f 4dgs-slam_amd/_timing/libgs_timing.so ]; then
-  GSR_GLUE=ctypes GSR_LIB=$R/4dgs-slam_amd/_timing/libgs_timing.so python tools/dev_fwd_timing.py --json > $O/phase_cycles.json 2> /dev/null
+  GSR_GLUE=ctypes GSR_LIB=$R/4dgs-slam_amd/_timing/libgs_timing.so python tools/phase_cycles.py --json > $O/phase_cycles.json 2> /dev/null
 fi
 python tools/bench_views.py 2> /dev/null | tail -1 > $O/views.json
 python tools/bench_views.py --dyn 2> /dev/null | tail -1 > $O/views_deltas.json

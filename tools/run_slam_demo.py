@@ -18,7 +18,8 @@ only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
 profile = "--profile" in sys.argv
 out = {}
 for name, dyn, graph, frames, wh in (("static_640x480_eager", False, False, 40, (640, 480)), ("static_640x480_graph", False, True, 40, (640, 480)),
-                                     ("dynamic_320x240_eager", True, False, 36, (320, 240)), ("dynamic_320x240_graph", True, True, 36, (320, 240))):
+                                     ("dynamic_320x240_eager", True, False, 36, (320, 240)), ("dynamic_320x240_graph", True, True, 36, (320, 240)),
+                                     ("dynamic_640x480_graph", True, True, 36, (640, 480))):
     if only not in name:
         continue
     torch.manual_seed(0)
