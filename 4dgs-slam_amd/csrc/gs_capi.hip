@@ -1093,6 +1093,47 @@ int gsr_l1_loss_backward(int width, int height, const float* image, const float*
 }
 
 
+static int masked_l1_args(MaskedL1Args& a, int n_terms, const gsr_masked_l1_term* terms, int width, int height, int channels, int image_channels,
+                          float scale, bool backward, const char* who)
+{
+    static thread_local std::string msg;
+    bool ok = n_terms >= 1 && n_terms <= MASKED_L1_MAX_TERMS && terms && width > 0 && height > 0 && channels >= 1 && channels <= image_channels;
+    for (int t = 0; ok && t < n_terms; t++) ok = terms[t].image && terms[t].target && terms[t].mask && (!backward || terms[t].dL_dimage);
+    if (!ok) { msg = std::string(who) + ": null / invalid argument (1 <= n_terms <= 4, 1 <= channels <= image_channels)"; g_last_error = msg.c_str(); return GSR_ERR_INVALID_ARGUMENT; }
+    a = MaskedL1Args{};
+    a.n_terms = n_terms; a.N = width * height; a.C = channels; a.Cimg = image_channels;
+    for (int t = 0; t < n_terms; t++) { a.image[t] = terms[t].image; a.target[t] = terms[t].target; a.mask[t] = terms[t].mask; a.dL_dimage[t] = terms[t].dL_dimage; }
+    a.coeff = scale / ((float)channels * (float)a.N);
+    return 0;
+}
+
+int gsr_masked_l1_forward(int n_terms, const gsr_masked_l1_term* terms, int width, int height, int channels, int image_channels, float scale,
+                          float* loss, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    MaskedL1Args a;
+    const int rc = masked_l1_args(a, n_terms, terms, width, height, channels, image_channels, scale, false, "gsr_masked_l1_forward");
+    if (rc < 0) return rc;
+    if (!loss || !workspace) { g_last_error = "gsr_masked_l1_forward: null loss / workspace"; return GSR_ERR_INVALID_ARGUMENT; }
+    float* partials = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(masked_l1_fwd_kernel, dim3(LOSS_BLOCKS), dim3(LOSS_THREADS), 0, stream, a, partials);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, stream, (const float*)partials, 1, loss);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_masked_l1_backward(int n_terms, const gsr_masked_l1_term* terms, int width, int height, int channels, int image_channels, float scale,
+                           const float* upstream, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    MaskedL1Args a;
+    const int rc = masked_l1_args(a, n_terms, terms, width, height, channels, image_channels, scale, true, "gsr_masked_l1_backward");
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(LOSS_BLOCKS, (unsigned)n_terms), dim3(LOSS_THREADS), 0, stream, a, upstream);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---- fused Adam (include/slam_losses.h) ---------------------------------------------------------------------------
 int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream_)
 {

@@ -91,6 +91,45 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, c
 
 
 
+// ---- masked L1 against a constant target, several images per call (the optical-flow terms of the dynamic mapping loop) -----------
+//   L = scale * sum_terms mean_{c < C, p}( | target[c,p] - image[c,p] * mask[p] | )
+// utils/slam_backend.py:486-488,503-505 form this with bitwise_not / unsqueeze / 2 mul / permute / sub / abs / mean / mul per direction
+// and as many autograd nodes back; a keyframe's two directions are two terms of one call here. The image has `Cimg` >= C channels
+// (render_flow's third channel is the dynamic mask: no loss, zero gradient).
+constexpr int MASKED_L1_MAX_TERMS = 4;
+struct MaskedL1Args {
+    int n_terms, N, C, Cimg;
+    const float* image[MASKED_L1_MAX_TERMS]; const float* target[MASKED_L1_MAX_TERMS]; const float* mask[MASKED_L1_MAX_TERMS];
+    float* dL_dimage[MASKED_L1_MAX_TERMS];
+    float coeff;                              // scale / (C N)
+};
+
+__global__ void __launch_bounds__(LOSS_THREADS) masked_l1_fwd_kernel(MaskedL1Args a, float* __restrict__ partials)
+{
+    __shared__ float s_tmp[LOSS_THREADS / 64];
+    float acc = 0.f;
+    for (int t = 0; t < a.n_terms; t++) {
+        for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
+            const float m = a.mask[t][p];
+            for (int c = 0; c < a.C; c++) acc += fabsf(a.target[t][(size_t)c * a.N + p] - a.image[t][(size_t)c * a.N + p] * m);
+        }
+    }
+    const float s = block_sum_fixed(acc * a.coeff, s_tmp);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(LOSS_THREADS) masked_l1_bwd_kernel(MaskedL1Args a, const float* __restrict__ upstream)
+{
+    const float g = (upstream ? upstream[0] : 1.f) * a.coeff;
+    float* const out = a.dL_dimage[blockIdx.y];
+    const float* const img = a.image[blockIdx.y]; const float* const tgt = a.target[blockIdx.y]; const float* const msk = a.mask[blockIdx.y];
+    for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < a.N; p += LOSS_BLOCKS * LOSS_THREADS) {
+        const float m = msk[p];
+        for (int c = 0; c < a.Cimg; c++)
+            out[(size_t)c * a.N + p] = c < a.C ? -g * m * sgn(tgt[(size_t)c * a.N + p] - img[(size_t)c * a.N + p] * m) : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Fused Adam step over several parameter tensors in ONE launch (second half): the reference steps six
 // groups (xyz, f_dc, f_rest, opacity, scaling, rotation; scene/gaussian_model.py:404-447, torch.optim.Adam(lr=0, eps=1e-15))

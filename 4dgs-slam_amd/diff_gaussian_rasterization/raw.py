@@ -191,9 +191,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         dev = xyz.device
         P, H, W, S = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width), int(log_scales.shape[-1])
         if g_color is None:
-            g_color = xyz.new_zeros((3, H, W))
+            g_color = _zero_cotangent(3, H, W, dev)
         if g_depth is None:
-            g_depth = xyz.new_zeros((1, H, W))
+            g_depth = _zero_cotangent(1, H, W, dev)
         th_shape, rho_shape = ctx.pose_shapes
         gather = ctx.gather
         # fused accumulation into the parameters' .grad buffers (autograd._accumulation_targets): the six gradients are then not returned
@@ -265,6 +265,21 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         g_theta = _pose_grad(tau[3:], th_shape) if th_shape is not None else None
         # inputs: xyz, means2D, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, dx, ds, dr, theta, rho, rs
         return (g_xyz, g_m2d, g_ls, g_rot, g_logit, g_fdc, g_frest if (M > 1 and targets is None and not pose_only) else None, None, g_dx, g_ds, g_dr, g_theta, g_rho, None, None)
+
+
+_ZERO_COTANGENT = {}
+
+
+def _zero_cotangent(channels, H, W, device):
+    """A read-only zero image standing in for the cotangent of an output the loss did not use (the kernels only read it): one tensor per
+    shape and device instead of a zero-fill per backward pass."""
+    key = (channels, H, W, device.type, device.index)
+    hit = _ZERO_COTANGENT.get(key)
+    if hit is None:
+        if len(_ZERO_COTANGENT) > 16:
+            _ZERO_COTANGENT.clear()
+        hit = _ZERO_COTANGENT[key] = torch.zeros((channels, H, W), dtype=torch.float32, device=device)
+    return hit
 
 
 def _zero_grads_like(*tensors):
@@ -348,8 +363,8 @@ class _RasterizeFlowRaw(torch.autograd.Function):
         dev = xyz.device
         lib = _lib()
         P, H, W, S = int(xyz.shape[0]), int(rs.image_height), int(rs.image_width), int(log_scales.shape[-1])
-        g_color = xyz.new_zeros((3, H, W)) if g_color is None else g_color.to(torch.float32)
-        g_depth = xyz.new_zeros((1, H, W)) if g_depth is None else g_depth.to(torch.float32)
+        g_color = _zero_cotangent(3, H, W, dev) if g_color is None else g_color.to(torch.float32)
+        g_depth = _zero_cotangent(1, H, W, dev) if g_depth is None else g_depth.to(torch.float32)
         # xyz | scratch for the constants' gradients the kernel writes anyway (log-scale, rotation, opacity) | means2D | tau
         flat = torch.empty((P * (3 + S + 4 + 1 + 3) + 6,), dtype=torch.float32, device=dev)
         o = 0

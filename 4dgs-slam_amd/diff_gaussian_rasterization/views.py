@@ -15,7 +15,7 @@ import torch
 
 from . import _C
 from .autograd import _pose_grad
-from .raw import _RawGrads, _RawInputs, _acc_params, _describe, _f32, _targets, _zero_grads_like
+from .raw import _RawGrads, _RawInputs, _acc_params, _describe, _f32, _targets, _zero_cotangent, _zero_grads_like
 
 MAX_VIEWS = 12
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
@@ -152,18 +152,15 @@ class _RasterizeViewsRaw(torch.autograd.Function):
             out.logit_opacity, out.log_scales, out.raw_rotations = gviews[3].data_ptr(), gviews[4].data_ptr(), gviews[5].data_ptr()
         per_view_out = torch.empty((V, P * 3 + 6), dtype=torch.float32, device=dev)      # screen-space gradient + pose sum per view
         views = (_View * V)()
-        zc = zd = None
         delta_grads = []
         zero_deltas = [None] * (3 * V) if pose_only else _zero_grads_like(*deltas[:3 * V])      # one allocation, one fill for all views
         for v in range(V):
             rs, w = settings[v], views[v]
             g_color, g_depth = grads[5 * v], grads[5 * v + 2]
             if g_color is None:
-                zc = torch.zeros((3, H, W), dtype=torch.float32, device=dev) if zc is None else zc
-                g_color = zc
+                g_color = _zero_cotangent(3, H, W, dev)
             if g_depth is None:
-                zd = torch.zeros((1, H, W), dtype=torch.float32, device=dev) if zd is None else zd
-                g_depth = zd
+                g_depth = _zero_cotangent(1, H, W, dev)
             dx, ds, dr = deltas[3 * v: 3 * v + 3]
             w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
             w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)

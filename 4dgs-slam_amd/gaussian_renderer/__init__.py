@@ -64,6 +64,29 @@ def _screenspace_points(pc):
     return pts
 
 
+class _RenderPackage(dict):
+    """render()'s dict whose "visibility_filter" (radii > 0) is formed when somebody reads it: the batched callers of the mapping back-end
+    never do, and one comparison launch per view and per flow direction is ~25 launches of a dynamic mapping iteration."""
+
+    def __missing__(self, key):
+        if key != "visibility_filter":
+            raise KeyError(key)
+        value = self["radii"] > 0
+        self[key] = value
+        return value
+
+
+_ZERO_BG = {}
+
+
+def _zero_background(device):
+    """The (0, 0, 0) background of render_flow, one tensor per device (never written)."""
+    key = (device.type, device.index)
+    if key not in _ZERO_BG:
+        _ZERO_BG[key] = torch.zeros(3, device=device)
+    return _ZERO_BG[key]
+
+
 def _settings(cam, bg, scaling_modifier, sh_degree):
     return GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
@@ -233,13 +256,14 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
     settings = [_settings(c, bg_color, scaling_modifier, pc.active_sh_degree) for c in cams]
     if not _views.views_supported(settings):
         return per_camera()
-    points = [_screenspace_points(pc) for _ in cams]
+    block = torch.zeros((len(cams),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)    # one fill for all views
+    points = [block[v].requires_grad_(True) for v in range(len(cams))]     # leaves: .grad receives the view's dL/d(NDC mean) (reference :69-78)
     any_delta = any(d is not None for d in deltas)
     f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
     outs = _views.rasterize_views_raw(settings, pc._xyz, points, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, f_rest,
                                       dyn_slot=_dyn_slot(pc) if any_delta else None, deltas=deltas,
                                       poses=[(c.cam_rot_delta, c.cam_trans_delta) for c in cams])
-    return [{"render": o[0], "viewspace_points": pts, "visibility_filter": o[1] > 0, "radii": o[1], "depth": o[2], "opacity": o[3], "n_touched": o[4]}
+    return [_RenderPackage({"render": o[0], "viewspace_points": pts, "radii": o[1], "depth": o[2], "opacity": o[3], "n_touched": o[4]})
             for o, pts in zip(outs, points)]
 
 
@@ -273,20 +297,22 @@ def render_flow(pc, viewpoint_camera1, viewpoint_camera2, d_xyz1, d_xyz2, d_rota
                 compute_cov3D_python=False, scale_const=None, d_rot_as_res=True, **kwargs):
     """Rasterize (NDC flow u, NDC flow v, dynamic mask) as colours (reference :229-361). Flow is computed from DETACHED
     canonical positions plus the attached deltas (:262); the rasterized means stay attached to pc.get_xyz (:261,305)."""
-    screenspace_points = _screenspace_points(pc)
     cam2 = viewpoint_camera2 if viewpoint_camera2 is not None else viewpoint_camera1
-    if (_flow_fused_ok(pc) and scale_const is None and not compute_cov3D_python and d_rot_as_res
-            and all(isinstance(t, torch.Tensor) for t in (d_xyz1, d_xyz2, d_rotation1, d_scaling1))):
+    fused = (_flow_fused_ok(pc) and scale_const is None and not compute_cov3D_python and d_rot_as_res
+             and all(isinstance(t, torch.Tensor) for t in (d_xyz1, d_xyz2, d_rotation1, d_scaling1)))
+    # (fused: a plain zero leaf -- the reference's `zeros_like(..) + 0` with retain_grad is one more launch each way for the same .grad)
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True) if fused else _screenspace_points(pc)
+    if fused:
         # fused route (diff_gaussian_rasterization/raw.py rasterize_flow_raw): both projections, the NDC flow, the mask channel and all
         # scatter-adds happen inside preprocess_fwd / geometry_bwd -- ~15 elementwise torch kernels and 4 index_puts per call less,
         # and the dynamic mapping loop calls this twice per view (utils/slam_backend.py:486,496)
-        rs = _settings(viewpoint_camera1, torch.zeros(3, device=pc.get_xyz.device), scaling_modifier, 0)
+        rs = _settings(viewpoint_camera1, _zero_background(pc.get_xyz.device), scaling_modifier, 0)
         slot = _dyn_slot(pc)
         rendered_image, radii, rendered_depth, rendered_alpha, n_touched = _raw.rasterize_flow_raw(
             rs, pc._xyz, screenspace_points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, d_xyz1, d_xyz2, d_scaling1,
             d_rotation1, viewpoint_camera1.full_proj_transform, cam2.full_proj_transform)
-        return {"render": rendered_image, "depth": rendered_depth, "alpha": rendered_alpha, "viewspace_points": screenspace_points,
-                "visibility_filter": radii > 0, "radii": radii}
+        return _RenderPackage({"render": rendered_image, "depth": rendered_depth, "alpha": rendered_alpha, "viewspace_points": screenspace_points,
+                               "radii": radii})
     canonical_xyz = pc.get_xyz.clone()
     base = canonical_xyz.detach()
     dxyz1 = _scatter_delta(base, pc.dygs, d_xyz1)

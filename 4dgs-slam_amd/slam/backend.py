@@ -448,7 +448,7 @@ class BackEnd:
         t_back, m1, t_fwd, m2 = hit
         pk = render_flow(pc=g, viewpoint_camera1=viewpoint, viewpoint_camera2=other, d_xyz1=dx1, d_xyz2=dx2, d_rotation1=dr1, d_scaling1=ds1)
         pk2 = render_flow(pc=g, viewpoint_camera1=other, viewpoint_camera2=viewpoint, d_xyz1=dx2, d_xyz2=dx1, d_rotation1=dr2, d_scaling1=ds2)
-        return flow_weight * ((t_back - pk["render"][:2] * m1).abs().mean() + (t_fwd - pk2["render"][:2] * m2).abs().mean())
+        return slam_losses.masked_l1(flow_weight, [(pk["render"], t_back, m1), (pk2["render"], t_fwd, m2)], channels=2)
 
     def color_refinement(self, iteration_total=1500, views_per_iter=10):
         """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""

@@ -294,16 +294,22 @@ class ControlNodes(nn.Module):
                                        d_rot_as_res=self.d_rot_as_res, raw=True)
         return {"d_xyz": out["d_xyz"], "d_rotation": out["d_rotation"], "d_scaling": out["d_scaling"], "d_opacity": None, "d_color": None}
 
+    def _d_xyz_at(self, t):
+        o = self._batch.get(time_key(t)) if self._batch is not None else None
+        if o is None:
+            o = self.node_deform(torch.full((self.node_num, 1), float(t), dtype=torch.float32, device=self.device))
+        return o["d_xyz"]
+
     def node_positions(self, times):
         """nodes + d_xyz(t) for a list of host times -> [M, T, 3] (time_utils.py:1136-1137, 1153-1154); served from the iteration's batched
         evaluation when there is one."""
-        cols = []
-        for t in times:
-            o = self._batch.get(time_key(t)) if self._batch is not None else None
-            if o is None:
-                o = self.node_deform(torch.full((self.node_num, 1), float(t), dtype=torch.float32, device=self.device))
-            cols.append(o["d_xyz"])
-        return self.nodes.detach()[:, None, :] + torch.stack(cols, 1)
+        return self.nodes.detach()[:, None, :] + torch.stack([self._d_xyz_at(t) for t in times], 1)
+
+    def node_positions_many(self, times_per_view):
+        """The same for several equally long lists of times in one stack + one add: [V, T, M, 3]."""
+        V, T = len(times_per_view), len(times_per_view[0])
+        flat = torch.stack([self._d_xyz_at(t) for ts in times_per_view for t in ts])
+        return self.nodes.detach() + flat.reshape(V, T, self.node_num, 3)
 
     def arap_loss(self, times):
         """ControlNodeWarp.arap_loss (:1128-1141) on the time samples `times` (draw_loss_times): connectivity of the nodes at the first
@@ -314,7 +320,7 @@ class ControlNodes(nn.Module):
 
     def arap_loss_batch(self, times_per_view):
         """arap_loss for several views with the same number of samples in one pass: [V] errors."""
-        nodes_seq = torch.stack([self.node_positions(ts).permute(1, 0, 2) for ts in times_per_view])      # [V, T, M, 3]
+        nodes_seq = self.node_positions_many(times_per_view)                                               # [V, T, M, 3]
         nn_idx, keep = connectivity_from_points(nodes_seq[:, 0], K=10)
         return arap_error(nodes_seq, nn_idx, keep)
 
@@ -335,7 +341,7 @@ class ControlNodes(nn.Module):
         return self.elastic_loss_batch([times])[0]
 
     def elastic_loss_batch(self, times_per_view):
-        nodes_t = torch.stack([self.node_positions(ts) for ts in times_per_view])                          # [V, M, T, 3]
+        nodes_t = self.node_positions_many(times_per_view).permute(0, 2, 1, 3)                             # [V, M, T, 3]
         nn_weight, nn_idx = self._elastic_neighbours()
         return elastic_error(nodes_t, nn_weight, nn_idx)
 

@@ -15,6 +15,10 @@ from diff_gaussian_rasterization import _C
 _declared = False
 
 
+class _MaskedTerm(C.Structure):      # gsr_masked_l1_term, include/slam_losses.h
+    _fields_ = [("image", C.c_void_p), ("target", C.c_void_p), ("mask", C.c_void_p), ("dL_dimage", C.c_void_p)]
+
+
 def _lib():
     global _declared
     lib = _C.load_library()
@@ -25,6 +29,10 @@ def _lib():
         lib.gsr_l1_loss_forward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp]
         lib.gsr_l1_loss_backward.restype = i
         lib.gsr_l1_loss_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp, f, vp, f, vp, vp, vp, vp, vp, vp]
+        lib.gsr_masked_l1_forward.restype = i
+        lib.gsr_masked_l1_forward.argtypes = [i, C.POINTER(_MaskedTerm), i, i, i, i, f, vp, vp, vp]
+        lib.gsr_masked_l1_backward.restype = i
+        lib.gsr_masked_l1_backward.argtypes = [i, C.POINTER(_MaskedTerm), i, i, i, i, f, vp, vp]
         lib.gsr_ssim_workspace_size.restype = C.c_size_t
         lib.gsr_ssim_workspace_size.argtypes = [i, i, i]
         lib.gsr_ssim_forward.restype = i
@@ -126,6 +134,62 @@ def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None,
         raise RuntimeError("weighted_l1_loss: give both exposure parameters or neither")
     return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold,
                              bool(compute_value))
+
+
+class _MaskedL1(torch.autograd.Function):
+    """scale * sum_terms mean(|target - image[:C] * mask|) over up to four (image, target, mask) terms: two launches forward, one back."""
+
+    @staticmethod
+    def forward(ctx, scale, channels, *ops):
+        images, targets, masks = ops[0::3], ops[1::3], ops[2::3]
+        lib = _lib()
+        dev = images[0].device
+        Cimg, H, W = (int(v) for v in images[0].shape)
+        keep = []
+        terms = (_MaskedTerm * len(images))()
+        for t, (im, tg, mk) in enumerate(zip(images, targets, masks)):
+            if tuple(im.shape) != (Cimg, H, W) or tg.numel() != channels * H * W or mk.numel() != H * W:
+                raise RuntimeError(f"masked_l1: term {t}: image {tuple(im.shape)}, target {tuple(tg.shape)}, mask {tuple(mk.shape)}")
+            terms[t].image, terms[t].target, terms[t].mask = _p(im, keep), _p(tg, keep), _p(mk, keep)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ws = torch.empty((int(lib.gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_masked_l1_forward(len(images), terms, W, H, int(channels), Cimg, float(scale), loss.data_ptr(), ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_masked_l1_forward")
+        ctx.scale, ctx.channels = float(scale), int(channels)
+        ctx.save_for_backward(*keep)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ops = ctx.saved_tensors
+        lib = _lib()
+        n = len(ops) // 3
+        dev = ops[0].device
+        Cimg, H, W = (int(v) for v in ops[0].shape)
+        grads = torch.empty((n, Cimg, H, W), dtype=torch.float32, device=dev)
+        terms = (_MaskedTerm * n)()
+        for t in range(n):
+            terms[t].image, terms[t].target, terms[t].mask = ops[3 * t].data_ptr(), ops[3 * t + 1].data_ptr(), ops[3 * t + 2].data_ptr()
+            terms[t].dL_dimage = grads[t].data_ptr()
+        keep = []
+        with torch.cuda.device(dev):
+            rc = lib.gsr_masked_l1_backward(n, terms, W, H, ctx.channels, Cimg, ctx.scale, _p(g, keep), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_masked_l1_backward")
+        out = [None, None]
+        for t in range(n):
+            out += [grads[t], None, None]
+        return tuple(out)
+
+
+def masked_l1(scale, terms, channels):
+    """scale * sum over `terms` = [(image [Cimg,H,W], target [channels,H,W], mask [H,W] or [1,H,W]), ...] (at most four) of
+    mean(|target - image[:channels] * mask|): the optical-flow terms of the dynamic mapping loop (utils/slam_backend.py:479-509) in one
+    forward and one backward call. Differentiable in the images only; targets and masks are constants (fp32, the target already masked)."""
+    flat = [t for term in terms for t in term]
+    return _MaskedL1.apply(float(scale), int(channels), *flat)
 
 
 # Ground-truth-only constants of a frame (device copy of the depth map + four masks, ~10 MB at 640x480). They live in a BOUNDED cache

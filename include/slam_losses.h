@@ -35,6 +35,19 @@ int gsr_l1_loss_backward(int width, int height, const float* image, const float*
                          const float* w_rgb, const float* w_depth, const float* exposure_a, const float* exposure_b, float alpha,
                          const float* opacity, float opacity_depth_threshold, const float* upstream, float* dL_dimage, float* dL_ddepth, float* dL_dexposure, char* workspace, void* stream);
 
+/* ---- masked L1 against a constant target (the optical-flow terms of the dynamic mapping loop, utils/slam_backend.py:479-509) ------
+ *   loss[0] = scale * sum_terms mean_{c < channels, p}( | target[c,p] - image[c,p] * mask[p] | )
+ * image [image_channels,H,W] is a rendering (render_flow: u, v, dynamic mask -> channels = 2 of image_channels = 3), target
+ * [channels,H,W] and mask [H,W] (0 / 1 floats) are constants of a keyframe pair (the flow already multiplied by the mask). Up to 4
+ * terms per call: a keyframe's two flow directions are one forward (2 launches) and one backward launch. The backward call writes
+ * every term's dL_dimage [image_channels,H,W] (zeros in the channels beyond `channels`), multiplied by upstream[0] (NULL = 1).
+ * workspace: gsr_l1_loss_workspace_size() bytes. */
+typedef struct gsr_masked_l1_term { const float* image; const float* target; const float* mask; float* dL_dimage; } gsr_masked_l1_term;
+int gsr_masked_l1_forward(int n_terms, const gsr_masked_l1_term* terms, int width, int height, int channels, int image_channels, float scale,
+                          float* loss, char* workspace, void* stream);
+int gsr_masked_l1_backward(int n_terms, const gsr_masked_l1_term* terms, int width, int height, int channels, int image_channels, float scale,
+                           const float* upstream, void* stream);
+
 /* ---- fused SSIM ("optional SSIM") ---------------------------------------------------------------
  * gaussian_splatting/utils/loss_utils.py:46-111 (ssim, size_average=True, window 11, sigma 1.5, zero padding, per channel) as the
  * mapping / colour-refinement losses use it (utils/slam_backend.py:636,824-832): ssim_mean[0] = mean of the SSIM map of img1

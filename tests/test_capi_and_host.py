@@ -51,6 +51,11 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     lib.gsr_l1_loss_forward.argtypes = [i, i] + [vp] * 8 + [f, vp, f, vp, vp, vp]
     assert lib.gsr_l1_loss_forward(64, 64, None, None, None, None, None, None, None, None, 0.9, None, 0.95, None, None, None) == -1
     assert b"gsr_l1_loss_forward" in lib.gsr_last_error()
+    import slam_losses
+    sl = slam_losses._lib()
+    assert sl.gsr_masked_l1_forward(5, None, 64, 64, 2, 3, 1.0, None, None, None) == -1 and b"gsr_masked_l1_forward" in lib.gsr_last_error()
+    term = (slam_losses._MaskedTerm * 1)()
+    assert sl.gsr_masked_l1_backward(1, term, 64, 64, 4, 3, 1.0, None, None) == -1 and b"gsr_masked_l1_backward" in lib.gsr_last_error()
     lib.gsr_adam_step.restype = i
     lib.gsr_adam_step.argtypes = [i, vp, vp]
     assert lib.gsr_adam_step(9, None, None) == -1 and lib.gsr_adam_step(0, None, None) == 0

@@ -149,7 +149,7 @@ def test_render_views_matches_render():
         b = render_views(cams, g, slam.pipeline_params, slam.background)
         sum((p["render"].mean() + p["depth"].mean()) for p in b).backward()
         for pa, pb in zip(a, b):
-            assert set(pa) == set(pb)
+            assert set(pa) - {"visibility_filter"} == set(pb) - {"visibility_filter"}     # (render_views forms radii > 0 when it is read)
             for k in ("render", "depth", "opacity", "radii", "n_touched", "visibility_filter"):
                 assert torch.equal(pa[k], pb[k]), (rep, k)
         assert torch.allclose(g._xyz.grad, ga, rtol=1e-5, atol=1e-10)

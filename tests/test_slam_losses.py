@@ -93,6 +93,41 @@ def test_fused_loss_scales_with_the_upstream_gradient_and_is_reproducible():
     assert all(torch.allclose(3.0 * x, y, rtol=1e-6, atol=0) for x, y in zip(grads[0], grads[2]))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("terms,H,W", [(2, 48, 64), (1, 37, 53), (4, 480, 640)])
+def test_masked_l1_equals_the_flow_terms_expression(terms, H, W):
+    """The optical-flow terms as the reference writes them (utils/slam_backend.py:486-488,503-505):
+    flow_weight * |flow * ~mask[..., None] - render[:2].permute(1, 2, 0) * ~mask[..., None]|.mean(), summed over the directions."""
+    from slam_losses import masked_l1
+
+    g = torch.Generator(device="cpu").manual_seed(terms * H)
+    weight = 0.37
+    renders = [torch.randn(3, H, W, generator=g).cuda().requires_grad_(True) for _ in range(terms)]
+    flows = [torch.randn(H, W, 2, generator=g).cuda() for _ in range(terms)]
+    moving = [(torch.rand(H, W, generator=g) < 0.3).cuda() for _ in range(terms)]
+    want = 0.0
+    for r, f, m in zip(renders, flows, moving):
+        keep = (~m)[..., None]
+        want = want + weight * torch.abs(f * keep - r[:2].permute(1, 2, 0) * keep).mean()
+    (want * 2.0).backward()
+    want_grads = [r.grad.clone() for r in renders]
+    for r in renders:
+        r.grad = None
+    packed = []
+    for r, f, m in zip(renders, flows, moving):
+        mk = (~m).to(torch.float32)[None]
+        packed.append((r, (f.permute(2, 0, 1) * mk).contiguous(), mk))
+    got = masked_l1(weight, packed, channels=2)
+    (got * 2.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    for r, wg in zip(renders, want_grads):
+        assert torch.allclose(r.grad, wg, rtol=1e-6, atol=1e-12) and float(r.grad[2].abs().max()) == 0.0
+    again = masked_l1(weight, packed, channels=2)
+    assert torch.equal(again, got)                                                     # fixed summation order
+    with pytest.raises(RuntimeError):
+        masked_l1(weight, [(renders[0], packed[0][1][:1], packed[0][2])], channels=2)
+
+
 TCASES = [str(c) for c in FX["tracking_cases"]]
 
 

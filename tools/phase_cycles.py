@@ -13,8 +13,13 @@ import torch
 import bench
 from diff_gaussian_rasterization import _C
 
-P, W, H = 200_000, 640, 480
-scene = bench.Scene(P, torch.device("cuda", 0), 0, 0.005, keyframes=(0,))
+def _opt(name, default, cast):
+    return cast(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
+# --gaussians / --scale-mean: another workload, e.g. a SLAM-sized map of few, large Gaussians (30000, 0.03: ~60 tiles per Gaussian)
+P, W, H = _opt("--gaussians", 200_000, int), 640, 480
+scene = bench.Scene(P, torch.device("cuda", 0), 0, _opt("--scale-mean", 0.005, float), keyframes=(0,))
 for _ in range(5):
     scene.fwd_bwd(0)
 torch.cuda.synchronize()
@@ -54,7 +59,7 @@ out["geometry_bwd"]["wave_lifetime"] = round(float((g[..., 6] - g[..., 0]).mean(
 nb = (P + 1023) // 1024
 for which, key, labels in ((0, "preprocess_fwd", ["zero_histogram", "per_gaussian", "tile_histogram", "block_sum", "publish_row"]),
                            (1, "scatter_instances", ["segment_cursors", "record_and_rect", "expand_and_write_keys"])):
-    q = read("gsr_debug_pre_timing", 2048 * 16 * 8, which).reshape(2048, 16, 8).astype(np.int64)[:nb - 1]
+    q = read("gsr_debug_pre_timing", 2048 * 16 * 8, which).reshape(2048, 16, 8).astype(np.int64)[:max(1, nb - 1)]
     nt = len(labels) + 1
     d = np.diff(q[..., :nt], axis=-1).reshape(-1, nt - 1).mean(0)
     out[key] = dict(zip(labels, [round(float(x), 1) for x in d]))
