@@ -119,7 +119,7 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 // ... and per view SLOT of the multi-view entry point (slot 0 = the single-view calls): the v-th view of consecutive mapping iterations
 // looks alike, the views of one iteration do not.
 struct SpecState { uint32_t* mailbox = nullptr; uint32_t* mailbox_dev = nullptr; uint32_t seq = 0; size_t last_R_alloc = 0; uint32_t last_max_tile = 0; };
-static thread_local SpecState t_spec[16][MAX_VIEWS + 1];
+static thread_local SpecState t_spec[16][2 * MAX_VIEWS + 1];   // [device][0 = single-view calls | 1..V views of a batch | MAX_VIEWS+1.. views of a flow batch]
 static thread_local SpecState* t_cur = &t_spec[0][0];
 static int select_device_state(int slot = 0)
 {
@@ -549,6 +549,7 @@ static int forward_one_view(gsr_view& vw, int slot, gsr_alloc_fn geometry_alloc,
 {
     gsr_raw_inputs one = *in;
     one.dx = vw.dx; one.ds = vw.ds; one.dr = vw.dr;
+    one.flow_dx2 = vw.flow_dx2; one.flow_proj1 = vw.flow_proj1; one.flow_proj2 = vw.flow_proj2;
     CapturedAlloc g{geometry_alloc, vw.geometry_user, nullptr}, b{binning_alloc, vw.binning_user, nullptr}, i{image_alloc, vw.image_user, nullptr};
     const int rc = forward_impl(captured_alloc, &g, captured_alloc, &b, captured_alloc, &i, P, D, M, background, width, height, nullptr, nullptr, nullptr, nullptr,
                                 nullptr, scale_modifier, nullptr, nullptr, vw.viewmatrix, vw.projmatrix, vw.cam_pos, tan_fovx, tan_fovy, 0, vw.out_color,
@@ -565,24 +566,28 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     hipStream_t stream = (hipStream_t)stream_;
     if (V < 1 || V > MAX_VIEWS || !views || !in || P <= 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc || !background ||
         M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M || in->gather || in->flow_proj1) {
-        g_last_error = "gsr_forward_views: invalid argument (1 <= V <= GSR_MAX_VIEWS, P > 0, raw inputs without gather / flow mode)"; return GSR_ERR_INVALID_ARGUMENT;
+        g_last_error = "gsr_forward_views: invalid argument (1 <= V <= GSR_MAX_VIEWS, P > 0, raw inputs without gather; flow mode is per view)"; return GSR_ERR_INVALID_ARGUMENT;
     }
+    const bool flow = views[0].flow_proj1 != nullptr;      // render_flow views: every view of the call, or none
     for (int v = 0; v < V; v++) {
         const gsr_view& w = views[v];
         gsr_raw_inputs probe = *in; probe.dx = w.dx; probe.ds = w.ds; probe.dr = w.dr;
-        if (!w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.out_color || !w.out_depth || !w.out_opacity || !w.radii || !w.n_touched || !raw_inputs_ok(&probe, M)) {
+        probe.flow_dx2 = w.flow_dx2; probe.flow_proj1 = w.flow_proj1; probe.flow_proj2 = w.flow_proj2;
+        if (!w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.out_color || !w.out_depth || !w.out_opacity || !w.radii || !w.n_touched ||
+            (w.flow_proj1 != nullptr) != flow || !raw_inputs_ok(&probe, M)) {
             g_last_error = "gsr_forward_views: null / inconsistent view descriptor"; return GSR_ERR_INVALID_ARGUMENT;
         }
     }
+    const int slot0 = flow ? MAX_VIEWS + 1 : 1;            // flow batches keep their own capacity estimates: their v-th view is another camera
     const ViewDims d = view_dims(P, width, height);
     read_option_env();
     // the batched path needs a capacity estimate for every slot (the first iteration of a window goes view by view and leaves one)
     const int dev = select_device_state(0);
     bool batched = !debug && t_speculate && use_lds_hist((size_t)d.T) && V > 1;
-    for (int v = 0; v < V && batched; v++) batched = t_spec[dev][v + 1].last_R_alloc != 0;
+    for (int v = 0; v < V && batched; v++) batched = t_spec[dev][slot0 + v].last_R_alloc != 0;
     if (!batched) {
         for (int v = 0; v < V; v++) {
-            const int rc = forward_one_view(views[v], v + 1, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier,
+            const int rc = forward_one_view(views[v], slot0 + v, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier,
                                             tan_fovx, tan_fovy, debug, stream_);
             if (rc) return rc;
         }
@@ -593,7 +598,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     ViewTable t;
     memset(&t, 0, sizeof(t));
     uint32_t want_tile = 0;
-    for (int v = 0; v < V; v++) want_tile = std::max(want_tile, t_spec[dev][v + 1].last_max_tile);
+    for (int v = 0; v < V; v++) want_tile = std::max(want_tile, t_spec[dev][slot0 + v].last_max_tile);
     want_tile += want_tile / 4;
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
@@ -601,7 +606,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
                             : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
     for (int v = 0; v < V; v++) {
         gsr_view& w = views[v];
-        select_device_state(v + 1);
+        select_device_state(slot0 + v);
         { const int rc = ensure_mailbox(); if (rc) return rc; }
         if (++t_seq == 0) t_seq = 1;
         const size_t cap = t_last_R_alloc + t_last_R_alloc / 8 + 4096;
@@ -612,6 +617,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
         ViewSlot& s = t.v[v];
         s.viewmatrix = w.viewmatrix; s.projmatrix = w.projmatrix; s.projmatrix_raw = w.projmatrix_raw; s.cam_pos = w.cam_pos;
         s.dx = w.dx; s.ds = w.ds; s.dr = w.dr;
+        s.flow_dx2 = w.flow_dx2; s.flow_proj1 = w.flow_proj1; s.flow_proj2 = w.flow_proj2;
         s.geom = w.geom_buffer; s.image = w.image_buffer; s.binning = w.binning_buffer;
         s.out_color = w.out_color; s.out_depth = w.out_depth; s.out_opacity = w.out_opacity; s.radii = w.radii; s.n_touched = w.n_touched;
         s.mailbox = t_use_mailbox ? t_mailbox_dev : nullptr; s.cap = (uint32_t)std::min<size_t>(cap, 0x7fffffffu); s.cap_tile = cap_tile; s.seq = t_seq;
@@ -662,7 +668,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     // redone through the single-view path, which allocates exactly
     for (int v = 0; v < V; v++) {
         gsr_view& w = views[v];
-        select_device_state(v + 1);
+        select_device_state(slot0 + v);
         if (t_lazy) { w.num_rendered = (int)t.v[v].cap; continue; }
         uint32_t hdr[4];
         char* gp = w.geom_buffer;
@@ -674,7 +680,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
         t_last_max_tile = hdr[HDR_MAX_TILE];
         w.num_rendered = (int)R;
         if (flg & FLAG_OVERFLOW) {
-            const int rc = forward_one_view(w, v + 1, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier, tan_fovx,
+            const int rc = forward_one_view(w, slot0 + v, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier, tan_fovx,
                                             tan_fovy, debug, stream_);
             if (rc) return rc;
         }
@@ -692,8 +698,10 @@ extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, c
 {
     hipStream_t stream = (hipStream_t)stream_;
     const bool accumulate = (debug & GSR_BACKWARD_ACCUMULATE) != 0, pose_only = (debug & GSR_BACKWARD_POSE_ONLY) != 0;
+    const bool flow = views && V >= 1 && views[0].flow_proj1 != nullptr;      // flow views: only out->xyz is required (constants otherwise, :307,326-334)
     if (V < 1 || V > MAX_VIEWS || !views || !in || P <= 0 || width <= 0 || height <= 0 || !background || in->gather || in->flow_proj1 ||
-        (!pose_only && (!out || !scratch || !out->xyz || !out->log_scales || !out->raw_rotations || !out->logit_opacity || !out->features_dc || (M > 1 && !out->features_rest)))) {
+        (!pose_only && (!out || !scratch || !out->xyz ||
+                        (!flow && (!out->log_scales || !out->raw_rotations || !out->logit_opacity || !out->features_dc || (M > 1 && !out->features_rest)))))) {
         g_last_error = "gsr_backward_views: invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
     const ViewDims d = view_dims(P, width, height);
@@ -706,10 +714,13 @@ extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, c
     for (int v = 0; v < V; v++) {
         const gsr_view& w = views[v];
         if (!w.geom_buffer || !w.binning_buffer || !w.image_buffer || !w.dL_dcolor || !w.dL_ddepth || !w.dL_dmean2D || !w.viewmatrix || !w.projmatrix ||
-            !w.projmatrix_raw || !w.cam_pos || !w.radii) { g_last_error = "gsr_backward_views: null view argument"; return GSR_ERR_INVALID_ARGUMENT; }
+            !w.projmatrix_raw || !w.cam_pos || !w.radii || (w.flow_proj1 != nullptr) != flow || (flow && !w.flow_proj2)) {
+            g_last_error = "gsr_backward_views: null / inconsistent view argument"; return GSR_ERR_INVALID_ARGUMENT;
+        }
         ViewSlot& s = t.v[v];
         s.viewmatrix = w.viewmatrix; s.projmatrix = w.projmatrix; s.projmatrix_raw = w.projmatrix_raw; s.cam_pos = w.cam_pos;
         s.dx = w.dx; s.ds = w.ds; s.dr = w.dr;
+        s.flow_dx2 = w.flow_dx2; s.flow_proj1 = w.flow_proj1; s.flow_proj2 = w.flow_proj2; s.ddx2 = w.ddx2;
         s.geom = w.geom_buffer; s.image = w.image_buffer; s.binning = w.binning_buffer; s.radii = w.radii;
         s.dL_dpix = w.dL_dcolor; s.dL_dpix_depth = w.dL_ddepth; s.dL_dmean2D = w.dL_dmean2D; s.ddx = w.ddx; s.dds = w.dds; s.ddr = w.ddr; s.tau_sum = w.dL_dtau_sum;
         s.part = pose_only ? nullptr : reinterpret_cast<float*>(sp + (size_t)v * row_bytes);

@@ -27,8 +27,12 @@ struct ViewSlot {
     float* dL_dmean2D; float* ddx; float* dds; float* ddr; float* tau_sum;  // per-view gradients (screen space, deltas, pose)
     float* part;                                                            // scratch row of this view's parameter gradients
     uint32_t* mailbox; uint32_t cap; uint32_t cap_tile; uint32_t seq;
+    // flow mode (render_flow, gs_rasterizer.h gsr_raw_inputs.flow_*): this view's second displacement and the two projections; ddx2 its gradient
+    const float* flow_dx2; const float* flow_proj1; const float* flow_proj2; float* ddx2;
 };
 struct ViewTable { ViewSlot v[MAX_VIEWS]; };
+static_assert(sizeof(ViewTable) + sizeof(PreprocessArgs) + 64 <= 4096 && sizeof(ViewTable) + sizeof(GeomBwdArgs) + 64 <= 4096,
+              "the view table travels by value in the kernel arguments (4 KB)");
 
 struct ViewDims { int P, W, H, gx, gy, T, nblocks; };
 
@@ -48,6 +52,7 @@ __global__ void __launch_bounds__(GB) preprocess_views_kernel(PreprocessArgs a, 
     const ImageState img = view_image(s, d);
     a.viewmatrix = s.viewmatrix; a.projmatrix = s.projmatrix; a.cam_pos = s.cam_pos;
     a.raw.dx = s.dx; a.raw.ds = s.ds; a.raw.dr = s.dr;
+    a.raw.flow_dx2 = s.flow_dx2; a.raw.flow_proj1 = s.flow_proj1; a.raw.flow_proj2 = s.flow_proj2;
     a.radii = s.radii; a.n_touched = s.n_touched;
     a.rec = geom.rec; a.cov3D = geom.cov3D; a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums;
     a.tile_count = img.tile_count; a.flags = img.tile_count + (size_t)d.T * CTR_STRIDE; a.block_tile_base = img.block_tile_base;
@@ -149,15 +154,16 @@ __global__ void __launch_bounds__(256) geometry_bwd_views_kernel(GeomBwdArgs a, 
     const GeomState geom = view_geom(s, d.P);
     a.viewmatrix = s.viewmatrix; a.projmatrix = s.projmatrix; a.projmatrix_raw = s.projmatrix_raw; a.campos = s.cam_pos;
     a.raw.dx = s.dx; a.raw.ds = s.ds; a.raw.dr = s.dr;
+    a.raw.flow_dx2 = s.flow_dx2; a.raw.flow_proj1 = s.flow_proj1; a.raw.flow_proj2 = s.flow_proj2;
     a.radii = s.radii; a.clamped = geom.clamped; a.cov3Ds = geom.cov3D; a.tiles_touched = geom.tiles_touched; a.point_offsets = geom.point_offsets;
     a.bin_base = s.binning; a.header = geom.header;
     a.dL_dmean2D = s.dL_dmean2D;
-    a.rawg.ddx = s.ddx; a.rawg.dds = s.dds; a.rawg.ddr = s.ddr;
+    a.rawg.ddx = s.ddx; a.rawg.dds = s.dds; a.rawg.ddr = s.ddr; a.rawg.ddx2 = s.ddx2;
     a.tau_partials = s.tau_sum ? geom.tau_partials : nullptr;
     a.accumulate = 0;                                    // a full row per view; views_reduce_kernel does the (ordered) accumulation
     if (!a.pose_only) {
         const PartLayout L = part_layout((size_t)a.P, a.M, a.raw.scale_dim);
-        a.dL_dmean3D = s.part + L.xyz; a.rawg.f_dc = s.part + L.f_dc; a.rawg.f_rest = a.M > 1 ? s.part + L.f_rest : nullptr;
+        a.dL_dmean3D = s.part + L.xyz; a.rawg.f_dc = s.flow_proj1 ? nullptr : s.part + L.f_dc; a.rawg.f_rest = a.M > 1 ? s.part + L.f_rest : nullptr;
         a.dL_dopacity = s.part + L.opacity; a.dL_dscale = s.part + L.scaling; a.dL_drot = s.part + L.rotation;
     }
     geometry_bwd_body<RAW>(a);
@@ -183,6 +189,7 @@ __global__ void __launch_bounds__(256) views_reduce_kernel(int V, ViewTable t, i
     for (int v = 0; v < V; v++) seen |= (t.v[v].radii[i] > 0 ? 1u : 0u) << v;
     if (!seen && accumulate) return;                     // accumulate mode leaves the rows of Gaussians no view saw alone
     auto fold = [&](float* dst, size_t base, int width) {
+        if (!dst) return;                                 // a gradient the caller did not ask for (flow mode: everything but the positions)
         for (int k = 0; k < width; k++) {
             float acc = accumulate ? dst[(size_t)i * width + k] : 0.f;
             bool first = !accumulate;

@@ -26,7 +26,8 @@ class _View(C.Structure):       # gsr_view
                 ("out_color", _vp), ("out_depth", _vp), ("out_opacity", _vp), ("radii", _vp), ("n_touched", _vp),
                 ("geometry_user", _vp), ("binning_user", _vp), ("image_user", _vp),
                 ("geom_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("num_rendered", _i),
-                ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dmean2D", _vp), ("ddx", _vp), ("dds", _vp), ("ddr", _vp), ("dL_dtau_sum", _vp)]
+                ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dmean2D", _vp), ("ddx", _vp), ("dds", _vp), ("ddr", _vp), ("dL_dtau_sum", _vp),
+                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp), ("ddx2", _vp)]
 
 
 _declared = False
@@ -196,6 +197,130 @@ class _RasterizeViewsRaw(torch.autograd.Function):
             res += [per_view_out[v, :P * 3].view(P, 3), gdx, gds, gdr,
                     _pose_grad(tau[3:], th_shape) if th_shape is not None else None, _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None]
         return tuple(res)
+
+
+class _RasterizeFlowViewsRaw(torch.autograd.Function):
+    """render_flow (raw.rasterize_flow_raw) for several (camera 1, camera 2) pairs of one mapping iteration at once.
+    inputs: xyz, log_scales, raw_rot, logit_opacity, dyn_slot, settings (list, camera 1 of every pair), then seven per view:
+    means2D, d_xyz1, d_xyz2, d_scaling1, d_rotation1, proj1, proj2. outputs: five per view: color (u, v, mask), radii, depth, opacity,
+    n_touched. Differentiable like the single call: xyz (geometric path; summed over the views in view order), d_xyz1, d_xyz2,
+    d_scaling1, d_rotation1 per view."""
+
+    @staticmethod
+    def forward(ctx, xyz, log_scales, raw_rot, logit_opacity, dyn_slot, settings, *per_view):
+        _C._require_device(xyz, "_xyz")
+        lib = _lib()
+        dev, V = xyz.device, len(settings)
+        rs0 = settings[0]
+        P, H, W = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width)
+        ctx.settings, ctx.V = settings, V
+        ctx.set_materialize_grads(False)
+        img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, None, None, None, keep)
+        desc.features_dc = None
+        views = (_View * V)()
+        base = id(ctx) & 0x3FFFFFFFFFFF
+        holders = []
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            _, dx1, dx2, ds, dr, proj1, proj2 = per_view[7 * v: 7 * v + 7]
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            w.dx, w.ds, w.dr = _f32(dx1, "d_xyz1", keep), _f32(ds, "d_scaling1", keep), _f32(dr, "d_rotation1", keep)
+            w.flow_dx2, w.flow_proj1, w.flow_proj2 = _f32(dx2, "d_xyz2", keep), _f32(proj1, "proj1", keep), _f32(proj2, "proj2", keep)
+            w.out_color, w.out_depth = img[v, :_C.NUM_CHANNELS].data_ptr(), img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1].data_ptr()
+            w.out_opacity, w.radii, w.n_touched = img[v, _C.NUM_CHANNELS + 1:].data_ptr(), ints[v, 0].data_ptr(), ints[v, 1].data_ptr()
+            hs = [{"dev": dev, "t": None} for _ in range(3)]
+            holders.append(hs)
+            for k, h in enumerate(hs):
+                _arenas[base + 3 * v + k] = h
+            w.geometry_user, w.binning_user, w.image_user = base + 3 * v, base + 3 * v + 1, base + 3 * v + 2
+        try:
+            with torch.cuda.device(dev):
+                rc = lib.gsr_forward_views(V, views, _alloc_cb, _alloc_cb, _alloc_cb, P, 0, 1, _f32(rs0.bg, "bg", keep), W, H, C.byref(desc),
+                                           float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), int(bool(rs0.debug)), _C._stream(dev))
+        finally:
+            for v in range(V):
+                for k in range(3):
+                    _arenas.pop(base + 3 * v + k, None)
+        if rc < 0:
+            _C._err(lib, rc, "gsr_forward_views (flow)")
+        ctx.num_rendered = [int(views[v].num_rendered) for v in range(V)]
+        state = [holders[v][k]["t"] for v in range(V) for k in range(3)]
+        ctx.n_state = len(state)
+        ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, dyn_slot, ints, *state, *[per_view[7 * v + k] for v in range(V) for k in range(1, 7)])
+        outs = []
+        for v in range(V):
+            outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
+            ctx.mark_non_differentiable(outs[-4], outs[-1])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib()
+        V, settings = ctx.V, ctx.settings
+        saved = ctx.saved_tensors
+        xyz, log_scales, raw_rot, logit_opacity, dyn_slot, ints = saved[:6]
+        state = saved[6:6 + ctx.n_state]
+        rest = saved[6 + ctx.n_state:]                      # per view: dx1, dx2, ds, dr, proj1, proj2
+        dev = xyz.device
+        rs0 = settings[0]
+        P, H, W, S = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width), int(log_scales.shape[-1])
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, None, None, None, keep)
+        desc.features_dc = None
+        g_xyz = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        out = _RawGrads()
+        out.xyz = g_xyz.data_ptr()
+        per_view_out = torch.empty((V, P * 3 + 6), dtype=torch.float32, device=dev)      # screen-space gradient + (unused) pose sum per view
+        zero = _zero_grads_like(*[rest[6 * v + k] for v in range(V) for k in range(4)])   # one fill for every view's delta gradients
+        views = (_View * V)()
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            g_color, g_depth = grads[5 * v], grads[5 * v + 2]
+            g_color = _zero_cotangent(3, H, W, dev) if g_color is None else g_color
+            g_depth = _zero_cotangent(1, H, W, dev) if g_depth is None else g_depth
+            dx1, dx2, ds, dr, proj1, proj2 = rest[6 * v: 6 * v + 6]
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            w.dx, w.ds, w.dr = _f32(dx1, "d_xyz1", keep), _f32(ds, "d_scaling1", keep), _f32(dr, "d_rotation1", keep)
+            w.flow_dx2, w.flow_proj1, w.flow_proj2 = _f32(dx2, "d_xyz2", keep), _f32(proj1, "proj1", keep), _f32(proj2, "proj2", keep)
+            w.radii = ints[v, 0].data_ptr()
+            w.geom_buffer, w.binning_buffer, w.image_buffer = state[3 * v].data_ptr(), state[3 * v + 1].data_ptr(), state[3 * v + 2].data_ptr()
+            w.num_rendered = ctx.num_rendered[v]
+            w.dL_dcolor, w.dL_ddepth = _f32(g_color.to(torch.float32), "dL_dcolor", keep), _f32(g_depth.to(torch.float32), "dL_ddepth", keep)
+            w.dL_dmean2D, w.dL_dtau_sum = per_view_out[v, :P * 3].data_ptr(), per_view_out[v, P * 3:].data_ptr()
+            gd1, gd2, gds, gdr = zero[4 * v: 4 * v + 4]
+            w.ddx, w.ddx2, w.dds, w.ddr = (None if g is None else g.data_ptr() for g in (gd1, gd2, gds, gdr))
+        scratch = torch.empty((int(lib.gsr_views_scratch_size(V, P, 1, S)),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward_views(V, views, P, 0, 1, _f32(rs0.bg, "bg", keep), W, H, C.byref(desc), float(rs0.scale_modifier),
+                                        float(rs0.tanfovx), float(rs0.tanfovy), C.byref(out), scratch.data_ptr(), int(bool(rs0.debug)), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_backward_views (flow)")
+        res = [g_xyz, None, None, None, None, None]
+        for v in range(V):
+            gd1, gd2, gds, gdr = zero[4 * v: 4 * v + 4]
+            res += [per_view_out[v, :P * 3].view(P, 3), gd1, gd2, gds, gdr, None, None]
+        return tuple(res)
+
+
+def rasterize_flow_views_raw(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, dyn_slot, flows):
+    """flows[v] = (d_xyz1, d_xyz2, d_scaling1, d_rotation1, proj1, proj2) of the v-th (camera 1 -> camera 2) pair; settings[v] describes
+    camera 1 (bg = 0, sh_degree 0). Returns the tuples raw.rasterize_flow_raw returns, one per pair."""
+    V = len(settings)
+    if xyz.shape[0] == 0:
+        raise RuntimeError("rasterize_flow_views_raw: empty model")
+    if not views_supported(settings) or dyn_slot is None:
+        raise RuntimeError("rasterize_flow_views_raw: the views must share image size, field of view and background, and need dyn_slot")
+    flat = []
+    for v in range(V):
+        dx1, dx2, ds, dr, proj1, proj2 = flows[v]
+        flat += [means2D[v], dx1, dx2, ds, dr, proj1, proj2]
+    outs = _RasterizeFlowViewsRaw.apply(xyz, log_scales, raw_rotations, logit_opacity, dyn_slot, list(settings), *flat)
+    return [tuple(outs[5 * v: 5 * v + 5]) for v in range(V)]
 
 
 def views_supported(settings):

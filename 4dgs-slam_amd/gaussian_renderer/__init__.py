@@ -293,6 +293,34 @@ def _dyn_slot(pc):
     return s
 
 
+def render_flow_views(pc, requests, scaling_modifier=1.0):
+    """render_flow for several (camera 1, camera 2) pairs of one mapping iteration: requests[i] = (viewpoint_camera1, viewpoint_camera2,
+    d_xyz1, d_xyz2, d_rotation1, d_scaling1), the arguments of render_flow in its order; returns render_flow's dict per request. The
+    dynamic mapping loop renders two flow images per window keyframe before each optimizer step (utils/slam_backend.py:486,496); with
+    the fused route available they go through the multi-view entry point in groups of up to views.MAX_VIEWS (one launch per pipeline
+    stage per group), otherwise one render_flow call each."""
+    requests = list(requests)
+    single = lambda: [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in requests]
+    if (len(requests) < 2 or _views is None or os.environ.get("GSR_MULTI_VIEW", "1") == "0" or not _flow_fused_ok(pc) or pc.get_xyz.shape[0] == 0
+            or not all(isinstance(t, torch.Tensor) for r in requests for t in r[2:])):
+        return single()
+    bg = _zero_background(pc.get_xyz.device)
+    settings = [_settings(r[0], bg, scaling_modifier, 0) for r in requests]
+    slot = _dyn_slot(pc)
+    out = []
+    for lo in range(0, len(requests), _views.MAX_VIEWS):
+        part, rs = requests[lo:lo + _views.MAX_VIEWS], settings[lo:lo + _views.MAX_VIEWS]
+        block = torch.zeros((len(part),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
+        points = [block[v].requires_grad_(True) for v in range(len(part))]
+        flows = [(dx1, dx2, ds1, dr1, c1.full_proj_transform, (c2 if c2 is not None else c1).full_proj_transform) for c1, c2, dx1, dx2, dr1, ds1 in part]
+        if len(part) == 1 or not _views.views_supported(rs):           # (cameras of different size / field of view: one call each)
+            out += [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in part]
+            continue
+        res = _views.rasterize_flow_views_raw(rs, pc._xyz, points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, flows)
+        out += [_RenderPackage({"render": o[0], "depth": o[2], "alpha": o[3], "viewspace_points": pts, "radii": o[1]}) for o, pts in zip(res, points)]
+    return out
+
+
 def render_flow(pc, viewpoint_camera1, viewpoint_camera2, d_xyz1, d_xyz2, d_rotation1, d_scaling1, scaling_modifier=1.0,
                 compute_cov3D_python=False, scale_const=None, d_rot_as_res=True, **kwargs):
     """Rasterize (NDC flow u, NDC flow v, dynamic mask) as colours (reference :229-361). Flow is computed from DETACHED

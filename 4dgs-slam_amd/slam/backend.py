@@ -368,11 +368,11 @@ class BackEnd:
             for (k, viewpoint), deltas, pkg in zip(mine, mine_deltas, rendered):
                 loss_mapping = loss_mapping + slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"],
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False, compute_value=self.loss_values)
-                if with_flow:
-                    loss_network = loss_network + self._flow_loss(viewpoint, deltas, flow_weight)
                 pkgs.append(pkg)
                 if k < len(views):
                     touched_rows[k] = (pkg["n_touched"] > 0).long()
+            if with_flow:
+                loss_network = loss_network + self._flow_losses([(viewpoint, deltas) for (_, viewpoint), deltas in zip(mine, mine_deltas)], flow_weight)
             if shard.rank == 0:
                 loss_mapping = loss_mapping + self._isotropic_loss()
             total = loss_mapping + loss_network if use_net else loss_mapping
@@ -420,35 +420,43 @@ class BackEnd:
         keys = [key for key in self.viewpoints if key < uid]
         return max(keys) if keys else None
 
-    def _flow_loss(self, viewpoint, deltas, flow_weight):
-        """The optical-flow terms of :479-509: the dynamic subset's projected motion between this keyframe and the closest earlier one,
-        rendered by render_flow (fused route: diff_gaussian_rasterization.raw.rasterize_flow_raw) in both directions, against the
-        dataset's flow on the moving pixels. The reference obtains that flow from RAFT (utils/camera_utils.py:386-417); here the dataset
-        supplies it (slam/dataset.py gt_flow)."""
-        from gaussian_renderer import render_flow
-        closest = self.find_closest_keyframe(viewpoint.uid)
-        if closest is None or deltas[0] is None:
+    def _flow_losses(self, views_and_deltas, flow_weight):
+        """The optical-flow terms of :479-509 for the views of one iteration: the dynamic subset's projected motion between a keyframe
+        and the closest earlier one, rendered by render_flow in both directions, against the dataset's flow on the moving pixels. The
+        reference obtains that flow from RAFT (utils/camera_utils.py:386-417); here the dataset supplies it (slam/dataset.py gt_flow).
+        All flow images of the iteration are ONE multi-view call (gaussian_renderer.render_flow_views), a pair's two L1 terms one fused
+        loss (slam_losses.masked_l1)."""
+        from gaussian_renderer import render_flow_views
+        requests, pairs = [], []
+        for viewpoint, deltas in views_and_deltas:
+            closest = self.find_closest_keyframe(viewpoint.uid)
+            if closest is None or deltas[0] is None:
+                continue
+            other = self.viewpoints[closest]
+            if viewpoint.motion_mask is None or other.motion_mask is None:
+                continue
+            dx1, ds1, dr1 = deltas
+            dx2, ds2, dr2 = self._deltas(other)
+            # constants of the keyframe pair: the flow on the moving pixels and their mask in the renderer's [C,H,W] layout (:486-488,
+            # :503-505 mask both sides of the difference by ~motion_mask; with a 0 / 1 mask: the masked target minus the masked rendering)
+            hit = self._flow_targets.get((viewpoint.uid, closest))
+            if hit is None:
+                def target(flow, mask):
+                    m = (~mask).to(torch.float32)[None]
+                    return (flow.permute(2, 0, 1) * m).contiguous(), m
+                hit = self._flow_targets[(viewpoint.uid, closest)] = \
+                    target(self.dataset.gt_flow(viewpoint.uid, closest)[0], viewpoint.motion_mask) + \
+                    target(self.dataset.gt_flow(closest, viewpoint.uid)[0], other.motion_mask)      # this keyframe -> the earlier one, and back
+            requests.append((viewpoint, other, dx1, dx2, dr1, ds1))
+            requests.append((other, viewpoint, dx2, dx1, dr2, ds2))
+            pairs.append(hit)
+        if not requests:
             return 0.0
-        other = self.viewpoints[closest]
-        if viewpoint.motion_mask is None or other.motion_mask is None:
-            return 0.0
-        g = self.gaussians
-        dx1, ds1, dr1 = deltas
-        dx2, ds2, dr2 = self._deltas(other)
-        # constants of the keyframe pair: the flow on the moving pixels and their mask in the renderer's [C,H,W] layout (:486-488,:503-505
-        # mask both sides of the difference by ~motion_mask; with a 0 / 1 mask that is the masked target minus the masked rendering)
-        cache = self._flow_targets
-        hit = cache.get((viewpoint.uid, closest))
-        if hit is None:
-            def target(flow, mask):
-                m = (~mask).to(torch.float32)[None]
-                return (flow.permute(2, 0, 1) * m).contiguous(), m
-            hit = cache[(viewpoint.uid, closest)] = target(self.dataset.gt_flow(viewpoint.uid, closest)[0], viewpoint.motion_mask) + \
-                target(self.dataset.gt_flow(closest, viewpoint.uid)[0], other.motion_mask)          # this keyframe -> the earlier one, and back
-        t_back, m1, t_fwd, m2 = hit
-        pk = render_flow(pc=g, viewpoint_camera1=viewpoint, viewpoint_camera2=other, d_xyz1=dx1, d_xyz2=dx2, d_rotation1=dr1, d_scaling1=ds1)
-        pk2 = render_flow(pc=g, viewpoint_camera1=other, viewpoint_camera2=viewpoint, d_xyz1=dx2, d_xyz2=dx1, d_rotation1=dr2, d_scaling1=ds2)
-        return slam_losses.masked_l1(flow_weight, [(pk["render"], t_back, m1), (pk2["render"], t_fwd, m2)], channels=2)
+        rendered = render_flow_views(self.gaussians, requests)
+        loss = 0.0
+        for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
+            loss = loss + slam_losses.masked_l1(flow_weight, [(rendered[2 * k]["render"], t_back, m1), (rendered[2 * k + 1]["render"], t_fwd, m2)], channels=2)
+        return loss
 
     def color_refinement(self, iteration_total=1500, views_per_iter=10):
         """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""

@@ -179,7 +179,7 @@ int gsr_backward_raw(int P, int D, int M, int R,
 /* ---- multi-view entry point: the views of ONE mapping iteration in one launch per pipeline stage ---------------------------------
  * The mapping back-end renders the same Gaussians from every window keyframe plus two random ones and back-propagates all of them
  * before one optimizer step (utils/slam_backend.py:357,526,657,768-771). gsr_forward_views / gsr_backward_views take the raw model
- * parameters once (gsr_raw_inputs; `gather` and the flow mode are not available here) and V <= GSR_MAX_VIEWS view descriptors; every
+ * parameters once (gsr_raw_inputs; `gather` is not available here, the flow mode is chosen per call through the views) and V <= GSR_MAX_VIEWS view descriptors; every
  * stage of the pipeline is launched once with the view as a second grid dimension. Results per view are those of gsr_forward_raw /
  * gsr_backward_raw; the parameter gradients of `out` are the sum over the views, added in view order with one rounding per view --
  * with GSR_BACKWARD_ACCUMULATE exactly what V consecutive gsr_backward_raw calls in accumulate mode leave in the buffers.
@@ -195,6 +195,11 @@ typedef struct gsr_view {
     char* geom_buffer; char* binning_buffer; char* image_buffer; int num_rendered;          /* filled by gsr_forward_views; pass back unchanged */
     const float* dL_dcolor; const float* dL_ddepth;                                         /* backward: cotangents [3,H,W], [1,H,W] */
     float* dL_dmean2D; float* ddx; float* dds; float* ddr; float* dL_dtau_sum;              /* backward: per-view gradients ([P,3]; deltas; [6]); ddx / dds / ddr / dL_dtau_sum may be NULL */
+    /* flow views (render_flow, see gsr_raw_inputs.flow_*): set for EVERY view of a call or for none. The colour of such a view is the NDC
+     * flow of the dynamic subset between (x + dx; flow_proj1) and (x + flow_dx2; flow_proj2) plus the mask channel; use D = 0, M = 1, a zero
+     * background; features_dc of the shared descriptor may be NULL. In gsr_backward_views only out->xyz is required then (the other
+     * parameters are constants of render_flow); ddx2 [K,3] receives the gradient of flow_dx2 (may be NULL). */
+    const float* flow_dx2; const float* flow_proj1; const float* flow_proj2; float* ddx2;
 } gsr_view;
 int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc,
                       int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier,

@@ -153,3 +153,52 @@ def test_render_views_matches_render():
             for k in ("render", "depth", "opacity", "radii", "n_touched", "visibility_filter"):
                 assert torch.equal(pa[k], pb[k]), (rep, k)
         assert torch.allclose(g._xyz.grad, ga, rtol=1e-5, atol=1e-10)
+
+
+@pytest.mark.parametrize("V", [2, 7, 12])
+def test_flow_views_equal_single_flow_calls(V):
+    """render_flow's rasterizer call for V (camera 1 -> camera 2) pairs through the multi-view entry point: per view the flow image, radii,
+    screen-space gradient and the four delta gradients of raw.rasterize_flow_raw bit for bit; the position gradient is the sum over the views."""
+    from diff_gaussian_rasterization import _C, raw, views
+    par, settings, cots, slot, deltas, _ = _scene(P=12000, V=V, W=256, H=192, scale_mean=0.02, seed=5)
+    dev = par["xyz"].device
+    P = par["xyz"].shape[0]
+    K = int((slot >= 0).sum())
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    zero_bg = torch.zeros(3, device=dev)
+    settings = [rs._replace(bg=zero_bg, sh_degree=0) for rs in settings]
+    dx2 = [(torch.randn((K, 3), generator=gen) * 0.02).to(dev).requires_grad_(True) for _ in range(V)]
+    flows = [(deltas[v][0], dx2[v], deltas[v][1], deltas[v][2], settings[v].projmatrix, settings[(v + 1) % V].projmatrix) for v in range(V)]
+    leaves = [par["xyz"]] + [t for v in range(V) for t in (deltas[v][0], dx2[v], deltas[v][1], deltas[v][2])]
+
+    def clear():
+        for t in leaves:
+            t.grad = None
+
+    # one call per view
+    clear()
+    ref, ref_pts = [], []
+    for v in range(V):
+        pts = torch.zeros((P, 3), device=dev, requires_grad=True)
+        o = raw.rasterize_flow_raw(settings[v], par["xyz"], pts, par["log_scales"].detach(), par["rot"].detach(), par["logit"].detach(), slot,
+                                   flows[v][0], flows[v][1], flows[v][2], flows[v][3], flows[v][4], flows[v][5])
+        torch.autograd.backward([o[0]], [cots[v][0]])
+        ref.append(o)
+        ref_pts.append(pts)
+    ref_grads = [t.grad.clone() for t in leaves]
+    # all views at once (twice: the first call of a slot goes view by view inside the entry point and leaves the capacity estimates)
+    for rep in range(2):
+        clear()
+        m2d = [torch.zeros((P, 3), device=dev, requires_grad=True) for _ in range(V)]
+        before = _C.set_option("views_batched")
+        outs = views.rasterize_flow_views_raw(settings, par["xyz"], m2d, par["log_scales"].detach(), par["rot"].detach(), par["logit"].detach(), slot, flows)
+        torch.autograd.backward([o[0] for o in outs], [c[0] for c in cots])
+        for v in range(V):
+            for k in range(5):
+                assert torch.equal(outs[v][k], ref[v][k]), (rep, v, k)
+            assert torch.equal(m2d[v].grad, ref_pts[v].grad), (rep, v)
+        for t, want in zip(leaves[1:], ref_grads[1:]):
+            assert torch.equal(t.grad, want), rep
+        assert torch.allclose(par["xyz"].grad, ref_grads[0], rtol=1e-5, atol=1e-9), rep
+    assert _C.set_option("views_batched") > before                              # the second call took the batched path
+    assert float(ref[0][0][:2].detach().abs().max()) > 0 and par["log_scales"].grad is None
