@@ -210,6 +210,7 @@ class BackEnd:
 
     def _publish_visibility(self, current_window, rows):
         """occ_aware_visibility of the window keyframes (:661-665) from the rows their owners hold."""
+        rows = {k: (n_touched > 0).long() for k, n_touched in rows.items()}
         like = torch.zeros(self.gaussians.get_xyz.shape[0], dtype=torch.int64, device=self.gaussians.get_xyz.device)
         if rows:
             like = torch.zeros_like(next(iter(rows.values())))
@@ -234,6 +235,14 @@ class BackEnd:
         if self.occ_aware_visibility:
             g.n_obs.copy_(torch.stack([v != 0 for v in self.occ_aware_visibility.values()]).sum(dim=0).to(g.n_obs.dtype))
         self.initialized = True
+
+    def _regulariser_weights(self, n_window, n_random):
+        """1e-3 per window view, 1e-4 per random keyframe (:520-524,:649-652) as a device vector, built once per (window size, extras):
+        a torch.tensor(..., device=) per iteration is a blocking pageable copy (~0.2 ms behind a busy queue)."""
+        cache = self.__dict__.setdefault("_reg_weight_cache", {})
+        if (n_window, n_random) not in cache:
+            cache[(n_window, n_random)] = torch.tensor([1e-3] * n_window + [1e-4] * n_random, dtype=torch.float32, device=self.device)
+        return cache[(n_window, n_random)]
 
     def _isotropic_loss(self):
         scaling = self.gaussians.get_scaling
@@ -261,7 +270,7 @@ class BackEnd:
                                                     compute_value=self.loss_values)
                 pkgs.append(pkg)
                 if k < len(viewpoint_stack):
-                    touched_rows[k] = (pkg["n_touched"] > 0).long()
+                    touched_rows[k] = pkg["n_touched"]            # (turned into a 0 / 1 row when it is published)
                 loss_mapping = loss_mapping + loss        # ONE backward for all views: the multi-view backward pass takes them together
             if shard.rank == 0:
                 loss_mapping = loss_mapping + self._isotropic_loss()
@@ -271,7 +280,7 @@ class BackEnd:
             gaussian_split = False
             with torch.no_grad():
                 last = it == iters - 1
-                if prune or last or shard.world == 1:
+                if prune or last:                      # (every iteration overwrites the previous one's rows: only the last ones are ever read)
                     self._publish_visibility(current_window, touched_rows)
                 if prune:
                     self._window_full_bookkeeping(current_window)
@@ -355,7 +364,7 @@ class BackEnd:
                 # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
                 nv = len(views)
                 if nodes.node_num >= 3 and shard.rank == 0:
-                    wts = torch.tensor([1e-3] * nv + [1e-4] * len(extra), dtype=torch.float32, device=self.device)
+                    wts = self._regulariser_weights(nv, len(extra))
                     reg = (nodes.elastic_loss_batch([p_["elastic"] for p_ in plans]) * wts).sum()
                     if nv:
                         reg = reg + (wts[:nv] * nodes.arap_loss_batch([p_["arap"] for p_ in plans[:nv]])).sum()
@@ -370,7 +379,7 @@ class BackEnd:
                                                                          rm_dynamic=not dynamic_network, dynamic=dynamic if use_net else False, compute_value=self.loss_values)
                 pkgs.append(pkg)
                 if k < len(views):
-                    touched_rows[k] = (pkg["n_touched"] > 0).long()
+                    touched_rows[k] = pkg["n_touched"]            # (turned into a 0 / 1 row when it is published)
             if with_flow:
                 loss_network = loss_network + self._flow_losses([(viewpoint, deltas) for (_, viewpoint), deltas in zip(mine, mine_deltas)], flow_weight)
             if shard.rank == 0:
@@ -385,7 +394,7 @@ class BackEnd:
             shard.reduce_gradients(g.optimizer if i > warm else None, [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else ())
             gaussian_split = False
             with torch.no_grad():
-                if prune or i == iters - 1 or shard.world == 1:
+                if prune or i == iters - 1:
                     self._publish_visibility(current_window, touched_rows)
                 if prune:
                     self._window_full_bookkeeping(current_window)

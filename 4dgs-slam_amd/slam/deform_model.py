@@ -254,7 +254,7 @@ class ControlNodes(nn.Module):
             self._batch = None
             return
         M, net = self.node_num, self.network
-        tt = torch.tensor(keys, dtype=torch.float32, device=self.device)[:, None]
+        tt = self._upload(keys)[:, None]
         xe = _embed(self.nodes.detach(), net.multires)
         te = _embed(tt, net.t_multires)
         emb = torch.cat([xe[None].expand(len(keys), M, -1), te[:, None].expand(len(keys), M, -1)], -1)
@@ -273,6 +273,28 @@ class ControlNodes(nn.Module):
                 for i, row in enumerate(head(hf).reshape(len(full), M, -1).unbind(0)):
                     self._batch[full[i]][name] = row
         self._graph = None
+
+    def _upload(self, values):
+        """A list of host floats as a device vector without blocking: through a small ring of pinned staging buffers (torch.tensor(...,
+        device=) is a synchronous pageable copy: ~0.2 ms per call behind a busy queue, once per mapping iteration)."""
+        if self.device.type != "cuda":
+            return torch.tensor(values, dtype=torch.float32, device=self.device)
+        ring = self.__dict__.setdefault("_staging", {"slots": [], "next": 0})
+        if len(ring["slots"]) < 8:
+            ring["slots"].append([torch.empty(1024, dtype=torch.float32).pin_memory(), None])
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["next"] % 8]
+            ring["next"] += 1
+            slot[1].synchronize()                          # the copy that last used this buffer (eight uploads ago) has long finished
+        n = len(values)
+        if n > slot[0].numel():
+            return torch.tensor(values, dtype=torch.float32, device=self.device)
+        slot[0][:n] = torch.tensor(values, dtype=torch.float32)
+        out = slot[0][:n].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
 
     def end_iteration(self):
         self._batch = None

@@ -222,7 +222,7 @@ def _keyframe_constants(config, viewpoint, device):
         ref = weakref.ref(viewpoint, lambda _r, k=id(viewpoint): _CONST_CACHE.pop(k, None))
     except TypeError:                                                     # not weak-referenceable (e.g. SimpleNamespace stand-ins): a strong
         ref = (lambda v=viewpoint: v)                                     # reference; the LRU bound below still caps what is kept alive
-    _CONST_CACHE[id(viewpoint)] = (ref, key, data)
+    _CONST_CACHE[id(viewpoint)] = (ref, key, data, {})        # {}: loss weights derived from `data` (get_loss_mapping)
     while len(_CONST_CACHE) > _CONST_CACHE_MAX:
         _CONST_CACHE.popitem(last=False)
     return data
@@ -280,7 +280,16 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
                             + (1 - alpha) * torch.abs(sel * w_dep * depth - sel * w_dep * gt_depth).mean())
         l_static, l_dynamic = part(mm), part(~mm)
         return (l_static, 2 * l_dynamic) if dynamic else (l_static, l_dynamic)
-    w_rgb, w_dep = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep))
+    # the weights are constants of (keyframe, flags, masks): formed once, not per call (2-4 image-sized launches per view and iteration)
+    motion = getattr(viewpoint, "motion_mask", None)
+    wkey = (bool(rm_dynamic), bool(dynamic), id(mask), getattr(mask, "_version", None), id(motion), getattr(motion, "_version", None))
+    derived = _CONST_CACHE[id(viewpoint)][3]
+    hit = derived.get(wkey)
+    if hit is None:
+        if len(derived) >= 8:
+            derived.clear()
+        hit = derived[wkey] = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep)) + (mask, motion)
+    w_rgb, w_dep = hit[0], hit[1]
     return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha, compute_value=compute_value)
 
 

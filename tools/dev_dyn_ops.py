@@ -47,6 +47,17 @@ t0 = time.perf_counter()
 run(iters)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / iters
+if "--cprofile" in sys.argv:          # host side only: where does the Python time of an iteration go?
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.runcall(run, iters * 3)
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr, stream=sys.stdout)
+    print("ms per iteration (unprofiled): %.3f" % (wall * 1e3))
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(45)
+    raise SystemExit(0)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
