@@ -160,6 +160,59 @@ __device__ __forceinline__ void wave_expand(uint32_t cnt, F&& f)
     }
 }
 
+// Visit the (Gaussian, tile) instances of the wave's 64 Gaussians (lane l: `cnt` tiles, the rectangle [x0, x0 + w) x [y0, ...), row
+// major) without wave_expand's search: every 64 instances of its lane-parallel walk over the concatenated lists cost a six-step binary
+// search of dependent cross-lane reads (~800 cycles), and a SLAM map's 30-60 tiles per Gaussian made that loop two thirds of
+// preprocess_fwd and nine tenths of scatter_instances.
+//   wave_visit_small: Gaussians of up to INSTANCES_SMALL tiles -- every lane walks its OWN rectangle, incrementally, no cross-lane
+//       traffic: f(own_lane, lane, k, tx, ty), <= INSTANCES_SMALL trips. Consecutive lanes then touch unrelated addresses, so this is
+//       for callbacks that only hit LDS (the tile histogram); scatter_instances, which writes inst_gauss[u], keeps wave_expand for them.
+//   wave_visit_large: the larger ones, one at a time -- the source's fields are wave-uniform (v_readlane), the 64 lanes take 64
+//       consecutive tiles per trip: f(uniform_source, src, k, tx, ty).
+// f runs only for real instances (no `active` guard needed) and must not contain wave-level operations.
+constexpr uint32_t INSTANCES_SMALL = 32;
+struct own_lane { static constexpr bool uniform = false; };
+struct uniform_source { static constexpr bool uniform = true; };
+template <typename TAG, typename T>
+__device__ __forceinline__ T of_source(TAG, T v, int src)
+{
+    if constexpr (TAG::uniform) {
+        static_assert(sizeof(T) == 4, "32-bit fields only");
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+    } else {
+        return v;
+    }
+}
+template <typename F>
+__device__ __forceinline__ void wave_visit_small(uint32_t cnt, int x0, int y0, int w, F&& f)
+{
+    const uint32_t n = cnt <= INSTANCES_SMALL ? cnt : 0u;
+    int tx = x0, ty = y0;
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0ull; k++) {
+        if (k < n) f(own_lane{}, lane_id(), k, tx, ty);
+        if (++tx == x0 + w) { tx = x0; ty++; }
+    }
+}
+template <typename F>
+__device__ __forceinline__ void wave_visit_large(uint32_t cnt, int x0, int y0, int w, F&& f)
+{
+    const int lane = lane_id();
+    unsigned long long large = __builtin_amdgcn_ballot_w64(cnt > INSTANCES_SMALL);
+    while (large) {
+        const int src = (int)__builtin_ctzll(large);
+        large &= large - 1;
+        const uint32_t c = of_source(uniform_source{}, cnt, src);
+        const int sx0 = of_source(uniform_source{}, x0, src), sy0 = of_source(uniform_source{}, y0, src), sw = max(1, of_source(uniform_source{}, w, src));
+        const float inv = 1.0f / (float)sw;
+        for (uint32_t k = (uint32_t)lane; k < c; k += 64) {
+            int q = (int)(((float)k + 0.5f) * inv);            // k / sw for k < 2^22, one step of correction either way
+            q -= (uint32_t)(q * sw) > k ? 1 : 0;
+            q += (uint32_t)((q + 1) * sw) <= k ? 1 : 0;
+            f(uniform_source{}, src, k, sx0 + (int)(k - (uint32_t)(q * sw)), sy0 + q);
+        }
+    }
+}
+
 // ---- small geometry helpers (reference semantics cited at the call sites) --------------------------------------
 // DGR/cuda_rasterizer/auxiliary.h:41-44 evaluates in double because of its 1.0 / 0.5 literals; so do we.
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * S - 1.0) * 0.5); }

@@ -316,14 +316,12 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
     }
     PRE_TICK(g_pre_timing, 2);
     // (a) per-tile histogram: every (Gaussian, tile) instance adds one to its tile's counter.
-    wave_expand(touched, [&](int src, uint32_t k, bool active) {
-        const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
-        const int ty = sy0 + (int)(k / (uint32_t)sw), tx = sx0 + (int)(k % (uint32_t)sw);
-        if (active) {
-            if (lds_hist) atomicAdd(&s_hist[ty * a.gx + tx], 1u);
-            else atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * CTR_STRIDE], 1u);
-        }
-    });
+    auto count_tile = [&](auto, int, uint32_t, int tx, int ty) {
+        if (lds_hist) atomicAdd(&s_hist[ty * a.gx + tx], 1u);
+        else atomicAdd(&a.tile_count[(size_t)(ty * a.gx + tx) * CTR_STRIDE], 1u);
+    };
+    wave_visit_small(touched, rx0, ry0, max(1, rw), count_tile);
+    wave_visit_large(touched, rx0, ry0, max(1, rw), count_tile);
     PRE_TICK(g_pre_timing, 3);
     // (b) block partial sum
     uint32_t s = touched;
@@ -582,18 +580,22 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
     }
     const uint32_t off_excl = off_incl - cnt;
     PRE_TICK(g_sca_timing, 2);
-    wave_expand(cnt, [&](int src, uint32_t k, bool active) {
+    auto emit = [&](int src, uint32_t sd, uint32_t u, int tx, int ty) {
+        const int g = (blockIdx.x * GB + (wave << 6)) + src;
+        const uint32_t pos = lds_path ? atomicAdd(&s_pos[ty * gx + tx], 1u)
+                                      : atomicAdd(&tile_cursor[(size_t)(ty * gx + tx) * CTR_STRIDE], 1u);
+        keys[pos] = ((uint64_t)sd << 32) | (uint64_t)u;
+        inst_gauss[u] = (uint32_t)g;
+    };
+    // Gaussians of few tiles through the lane-parallel walk (consecutive lanes write consecutive inst_gauss entries), the large ones
+    // one at a time with their fields in scalar registers (gs_device.h)
+    wave_expand(cnt <= INSTANCES_SMALL ? cnt : 0u, [&](int src, uint32_t k, bool active) {
         const int sx0 = __shfl(rx0, src, 64), sy0 = __shfl(ry0, src, 64), sw = max(1, __shfl(rw, src, 64));
         const uint32_t sd = __shfl(dbits, src, 64), so = __shfl(off_excl, src, 64);
-        if (active) {
-            const int g = (blockIdx.x * GB + (wave << 6)) + src;
-            const int ty = sy0 + (int)(k / (uint32_t)sw), tx = sx0 + (int)(k % (uint32_t)sw);
-            const uint32_t u = so + k;
-            const uint32_t pos = lds_path ? atomicAdd(&s_pos[ty * gx + tx], 1u)
-                                          : atomicAdd(&tile_cursor[(size_t)(ty * gx + tx) * CTR_STRIDE], 1u);
-            keys[pos] = ((uint64_t)sd << 32) | (uint64_t)u;
-            inst_gauss[u] = (uint32_t)g;
-        }
+        if (active) emit(src, sd, so + k, sx0 + (int)(k % (uint32_t)sw), sy0 + (int)(k / (uint32_t)sw));
+    });
+    wave_visit_large(cnt, rx0, ry0, max(1, rw), [&](auto tag, int src, uint32_t k, int tx, int ty) {
+        emit(src, of_source(tag, dbits, src), of_source(tag, off_excl, src) + k, tx, ty);
     });
     PRE_TICK(g_sca_timing, 3);
 }
