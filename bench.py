@@ -97,15 +97,19 @@ class Scene:
         return int((radii > 0).sum().item()), int(nr)
 
 
+STEP_KERNEL_SOURCES = ("gs_device.h", "gs_forward.h", "gs_render.h", "gs_backward.h", "gs_views.h")
+
+
 def csrc_digest():
-    """sha256 over the device sources (4dgs-slam_amd/csrc/*.h, *.hip): identifies the kernels a committed PMC traffic figure belongs to."""
+    """sha256 over the device sources of the step's kernels (4dgs-slam_amd/csrc/: preprocess / binning / sort / render / backward bodies and
+    their multi-view wrappers): identifies the kernels a committed PMC traffic figure belongs to. The other headers (losses, control nodes,
+    HexPlane, SLAM map kernels) and the host side in gs_capi.hip do not change what a launch of these kernels moves."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(PKG, "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in STEP_KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

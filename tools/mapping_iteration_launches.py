@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Dev probe: which source lines of a mapping iteration launch how many device kernels? Runs the SLAM demo for a few keyframes, then
 `BackEnd.map(iters=N)` (or map_static with --static) under torch.profiler (with_stack) and attributes every kernel launch to the innermost
-frame inside this repo. Usage: python tools/dev_dyn_ops.py [--static] [--iters 6] [--frames 17] [--wh 320 240]"""
+frame inside this repo. Usage: python tools/mapping_iteration_launches.py [--static] [--iters 6] [--frames 17] [--wh 320 240]"""
 import collections
 import json
 import os

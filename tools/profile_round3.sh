@@ -16,6 +16,9 @@ timeout 400 python bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.
 if [ -f 4dgs-slam_amd/_timing/libgs_timing.so ]; then
   GSR_GLUE=ctypes GSR_LIB=$R/4dgs-slam_amd/_timing/libgs_timing.so python tools/phase_cycles.py --json > $O/phase_cycles.json 2> /dev/null
 fi
+if [ -f 4dgs-slam_amd/_timing/libgs_timing.so ]; then
+  GSR_GLUE=ctypes GSR_LIB=$R/4dgs-slam_amd/_timing/libgs_timing.so python tools/phase_cycles.py --gaussians 30000 --scale-mean 0.03 --json > $O/phase_cycles_slam_scale.json 2> /dev/null
+fi
 python tools/bench_views.py 2> /dev/null | tail -1 > $O/views.json
 python tools/bench_views.py --dyn 2> /dev/null | tail -1 > $O/views_deltas.json
 python tools/bench_views.py --gaussians 100000 --scale-mean 0.01 2> /dev/null | tail -1 > $O/views_100k.json
@@ -27,6 +30,8 @@ python tools/bench_config3.py --fused-only 2> /dev/null | tail -1 > $O/config3.j
 python tools/bench_render_wrapper.py 2> /dev/null | tail -1 > $O/render_wrapper.json
 for a in "" "--flow" "--nodes" "--nodes --flow"; do python tools/bench_mapping_iteration.py $a 2>/dev/null | tail -1 > "$O/mapping_iteration$(echo $a | tr -d ' -').json"; done
 python tools/run_slam_demo.py > $O/slam_demo.json 2> $O/slam_demo.err
+python tools/mapping_iteration_launches.py --wh 640 480 > $O/mapping_iteration_launches_dynamic.json 2> /dev/null
+python tools/mapping_iteration_launches.py --static --wh 640 480 > $O/mapping_iteration_launches_static.json 2> /dev/null
 fi
 # keep what the collector reads; the traces themselves are bulky
 find $O $R/gpurun_out/counters_r03 -type f \( -name '*kernel_trace.csv' -o -name '*agent_info.csv' -o -name '*.db' -o -name '*.rocpd' \) -delete
