@@ -277,7 +277,8 @@ def test_config4_stand_in_at_the_reference_schedule(tmp_path):
     offline; this is its asset-free stand-in AT THE REFERENCE'S SCHEDULE: 640x480, 40 frames with a moving object from frame 6,
     configs/rgbd/tum/base_config.yaml value by value (init 1050 iterations, 100 tracking iterations per frame with the convergence latch,
     200 dynamic mapping iterations per keyframe, window 8, pcd_downsample 128), the tracking graph, then color_refinement and
-    eval_rendering. Measured on MI355X: ATE 3.3 mm, PSNR 30.2 dB -> 35.9 dB after refinement, depth L1 30 mm -> 15 mm, 34 s."""
+    eval_rendering. Measured on MI355X (tools/run_config4_stand_in.py -> profiles/r03_config4_stand_in.json): ATE 3.4 mm, PSNR 30.5 dB ->
+    36.7 dB after refinement, depth L1 26 mm -> 13 mm, 16 s (2.5 fps; 34 s before round 3's work on the dynamic mapping iteration)."""
     from slam.dataset import SyntheticRGBDDataset
     from slam.system import SLAM, default_config, merge_config
     torch.manual_seed(0)
