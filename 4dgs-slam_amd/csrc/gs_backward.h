@@ -93,7 +93,15 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         for (int j = 0; j < 6; j++) nx[j] = (uint32_t)lane + 64u * j < n3 ? src[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     const bool wave_has_slots = any_ser && W0 < W1;                 // uniform per wave (lanes beyond P take part in the window copy)
-    if (wave_has_slots) fetch_window(W0);
+    // Only windows that hold a slot of a serially summed Gaussian are copied: on a SLAM-sized map most of a wave's range belongs to
+    // Gaussians of > COOP instances, which the cooperative path below reads straight from global memory (85 % of 3 000 slots per wave
+    // at 30 k Gaussians x 48 tiles went through LDS for nothing: 36 k cycles per wave).
+    auto next_needed_window = [&](uint32_t c0) {                    // first window start >= c0 some lane sums from, or >= W1 (wave-uniform)
+        while (c0 < W1 && !__any(max(u0, c0) < min(u0 + ser, min(c0 + WCH, W1)))) c0 += WCH;
+        return c0;
+    };
+    const uint32_t first_window = wave_has_slots ? next_needed_window(W0) : W1;
+    if (first_window < W1) fetch_window(first_window);
     const bool scale1 = RAW && R.scale_dim == 1;
     const bool want_cov_chain = !a.pose_only && (a.scales != nullptr || RAW);
     f3 mean = mk3(0.f, 0.f, 0.f);
@@ -131,12 +139,13 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         }
     }
     GEO_TICK(1);
-    if (wave_has_slots) {
+    if (first_window < W1) {
         float4* const win = s_slot[wv];
-        for (uint32_t c0 = W0; c0 < W1; c0 += WCH) {
+        for (uint32_t c0 = first_window, cn; c0 < W1; c0 = cn) {
 #pragma unroll
             for (int j = 0; j < 6; j++) win[lane + 64 * j] = nx[j];
-            if (c0 + WCH < W1) fetch_window(c0 + WCH);
+            cn = next_needed_window(c0 + WCH);
+            if (cn < W1) fetch_window(cn);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the window is wave-private: DS operations of one wave execute in order
             __builtin_amdgcn_wave_barrier();
             const uint32_t lo = max(u0, c0), hi = min(u0 + ser, min(c0 + WCH, W1));
@@ -159,15 +168,37 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         unsigned long long cm = __ballot(coop);
         if (cm) {
             const WaveSelectMasks wsm = wave_select_masks();
-            while (cm) {
-                const int h = pop_lowest_bit(cm);
-                const uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
+            // the first 64 slots of the NEXT Gaussian are requested before the current one is reduced: one at a time, every Gaussian
+            // paid a full global latency in front of its butterfly (~1 100 cycles each, 51 k cycles per wave on a SLAM-sized map)
+            int h = pop_lowest_bit(cm);
+            uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 p0 = zero4, p1 = zero4, p2 = zero4;
+            bool pv = (uint32_t)lane < hc;
+            if (pv) { const float4* sl = partials + (size_t)(hu + (uint32_t)lane) * 3; p0 = sl[0]; p1 = sl[1]; p2 = sl[2]; }
+            for (;;) {
+                const bool more = cm != 0ull;
+                int h2 = 0;
+                uint32_t hc2 = 0, hu2 = 0;
+                float4 q0 = zero4, q1 = zero4, q2 = zero4;
+                bool qv = false;
+                if (more) {
+                    h2 = pop_lowest_bit(cm);
+                    hc2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h2); hu2 = (uint32_t)__builtin_amdgcn_readlane((int)u0, h2);
+                    qv = (uint32_t)lane < hc2;
+                    if (qv) { const float4* sl = partials + (size_t)(hu2 + (uint32_t)lane) * 3; q0 = sl[0]; q1 = sl[1]; q2 = sl[2]; }
+                }
                 float s0 = 0.f, s5 = 0.f;
                 f2v a12 = {0.f, 0.f}, a34 = {0.f, 0.f}, a67 = {0.f, 0.f}, a89 = {0.f, 0.f};
-                for (uint32_t k = (uint32_t)lane; k < hc; k += 64) {
+                if (pv) { s0 += p0.x; a12 += f2v{p0.y, p0.z}; a34 += f2v{p0.w, p1.x}; s5 += p1.y; a67 += f2v{p1.z, p1.w}; a89 += f2v{p2.x, p2.y}; }
+                for (uint32_t k = (uint32_t)lane + 64u; k < hc; k += 128) {       // two trips' loads in flight (same summation order)
+                    const bool two = k + 64u < hc;
                     const float4* sl = partials + (size_t)(hu + k) * 3;
                     const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
+                    float4 w0 = zero4, w1 = zero4, w2 = zero4;
+                    if (two) { w0 = sl[192]; w1 = sl[193]; w2 = sl[194]; }
                     s0 += v0.x; a12 += f2v{v0.y, v0.z}; a34 += f2v{v0.w, v1.x}; s5 += v1.y; a67 += f2v{v1.z, v1.w}; a89 += f2v{v2.x, v2.y};
+                    if (two) { s0 += w0.x; a12 += f2v{w0.y, w0.z}; a34 += f2v{w0.w, w1.x}; s5 += w1.y; a67 += f2v{w1.z, w1.w}; a89 += f2v{w2.x, w2.y}; }
                 }
                 unsigned long long dummy_proc = 0; uint32_t dummy_addr;
                 const float tot = wave_sum10_transposed(wsm, s0, a12, a34, s5, a67, a89, dummy_proc, 0, 0u, 0, dummy_addr);
@@ -179,6 +210,8 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
                 const float t6 = __int_as_float(__builtin_amdgcn_readlane(ti, 16)), t7 = __int_as_float(__builtin_amdgcn_readlane(ti, 17));
                 const float t8 = __int_as_float(__builtin_amdgcn_readlane(ti, 48)), t9 = __int_as_float(__builtin_amdgcn_readlane(ti, 49));
                 if (lane == h) { g_m2x = t0; g_m2y = t1; g_cx = t2; g_cy = t3; g_cw = t4; g_op = t5; g_r = t6; g_g = t7; g_b = t8; g_d = t9; }
+                if (!more) break;
+                h = h2; hc = hc2; hu = hu2; p0 = q0; p1 = q1; p2 = q2; pv = qv;
             }
         }
     }

@@ -159,14 +159,6 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (chunk_info != nullptr) {    // work items of render_bwd_kernel: this tile's CHUNK-entry pieces (gs_device.h)
-        const uint32_t cb = chunk_base[tile], nchunks = chunk_base[ntiles];
-        for (int c = t; c * CHUNK < n; c += RB) {
-            const int cstart = c * CHUNK, m = min(CHUNK, n - cstart);
-            chunk_info[xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)] =
-                make_uint4((uint32_t)tile, range.x + (uint32_t)cstart, (uint32_t)m | (cstart + m < n ? 0x10000u : 0u), (uint32_t)cstart);
-        }
-    }
     FWD_T(uint32_t tk0 = FWD_TICK(); uint32_t tk_sort = 0, tk_stage = 0, tk_list = 0, tk_pair = 0, tk_wait = 0, n_pairs = 0, n_batches = 0; uint32_t tk_mark = tk0;)
     // keys != nullptr: this block first sorts its own tile list (the staging arrays double as the key buffer) -- one kernel and
     // one GPU drain/fill less per frame than a separate sort launch; lists beyond the LDS capacity were sorted by
@@ -346,6 +338,27 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         const int c = s_nt[t];
         if (c) atomicAdd(&n_touched[__float_as_uint(s_b[t].w)], c);
     }
+    if (chunk_info != nullptr) {
+        // Work items of render_bwd_kernel: this tile's CHUNK-entry pieces (gs_device.h), written at the block index that kernel's XCD
+        // banding gives the chunk. Bit 16: more entries behind (a checkpoint exists at the chunk's back end); bit 17: NO pixel of the
+        // tile blended an entry at or behind the chunk's first -- the backward block then only zeroes the chunk's slots and never
+        // requests pixel state, checkpoint or records (on long lists most chunks lie behind every pixel's saturation point: issuing
+        // the whole prologue for them doubled render_bwd's time at 3.5-14 M instances).
+        __shared__ int s_deepest[4];
+        int wm = (int)last;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, __shfl_xor(wm, d, 64));
+        if (lane == 0) s_deepest[wave] = wm;
+        __syncthreads();
+        const int deepest = max(max(s_deepest[0], s_deepest[1]), max(s_deepest[2], s_deepest[3]));
+        const uint32_t cb = chunk_base[tile], nchunks = chunk_base[ntiles];
+        for (int c = t; c * CHUNK < n; c += RB) {
+            const int cstart = c * CHUNK, m = min(CHUNK, n - cstart);
+            chunk_info[xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)] =
+                make_uint4((uint32_t)tile, range.x + (uint32_t)cstart,
+                           (uint32_t)m | (cstart + m < n ? 0x10000u : 0u) | (deepest <= cstart ? 0x20000u : 0u), (uint32_t)cstart);
+        }
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = T;
@@ -429,6 +442,14 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     const bool more_behind = (__builtin_amdgcn_readfirstlane(item.z) & 0x10000u) != 0;
     const int cstart = (int)__builtin_amdgcn_readfirstlane(item.w), cend = cstart + m;   // list positions [cstart, cend) of this tile, front to back
 
+    if (__builtin_amdgcn_readfirstlane(item.z) & 0x20000u) {                 // nothing of this chunk was blended by any pixel of the tile: its
+        if (t < m) {                                                         // instances' slots must still be written (zero), nothing else is read
+            const uint2 e0 = sorted[first + (uint32_t)(m - 1 - t)];
+            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e0.y * 3;
+            slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const bool inside = px < W && py < H;
     const size_t pix = (size_t)py * W + px;
     // Every global load of the prologue is issued here, in one go, before anything waits: the list entry (whose Gaussian record is the only
