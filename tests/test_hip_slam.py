@@ -277,8 +277,8 @@ def test_config4_stand_in_at_the_reference_schedule(tmp_path):
     offline; this is its asset-free stand-in AT THE REFERENCE'S SCHEDULE: 640x480, 40 frames with a moving object from frame 6,
     configs/rgbd/tum/base_config.yaml value by value (init 1050 iterations, 100 tracking iterations per frame with the convergence latch,
     200 dynamic mapping iterations per keyframe, window 8, pcd_downsample 128), the tracking graph, then color_refinement and
-    eval_rendering. Measured on MI355X (tools/run_config4_stand_in.py -> profiles/r03_config4_stand_in.json): ATE 3.4 mm, PSNR 30.5 dB ->
-    36.7 dB after refinement, depth L1 26 mm -> 13 mm, 16 s (2.5 fps; 34 s before round 3's work on the dynamic mapping iteration)."""
+    eval_rendering. Measured on MI355X (tools/run_config4_stand_in.py -> profiles/r03_config4_stand_in.json): ATE 3.3-3.4 mm, PSNR 30.0-30.5 dB ->
+    35.9-36.7 dB after refinement, depth L1 26-32 mm -> 13-17 mm, 15-16 s (2.5-2.65 fps; 34 s before round 3's work on the dynamic mapping iteration)."""
     from slam.dataset import SyntheticRGBDDataset
     from slam.system import SLAM, default_config, merge_config
     torch.manual_seed(0)
@@ -294,8 +294,10 @@ def test_config4_stand_in_at_the_reference_schedule(tmp_path):
     assert slam.backend.dynamic_map_iters == 200 and slam.frontend.graph_stats["replayed_frames"] >= 35
     assert res["ate_rmse"] < 0.0040, res
     b, a = res["before_opt"], res["after_opt"]
-    assert b["mean_psnr"] > 29.2 and b["l1_depth"] < 0.036 and b["mean_ssim"] > 0.90, res
-    assert a["mean_psnr"] > 34.9 and a["l1_depth"] < 0.018 and a["mean_ssim"] > 0.95, res                  # colour refinement did its job
+    # (two recorded runs: 30.0 / 30.5 dB, 32 / 26 mm before refinement, 35.9 / 36.7 dB, 17 / 13 mm after: torch's index_put / scatter_add
+    # backward passes in the regularisers are not run-to-run deterministic; the bars sit ~20 % beyond the worse run)
+    assert b["mean_psnr"] > 29.0 and b["l1_depth"] < 0.038 and b["mean_ssim"] > 0.90, res
+    assert a["mean_psnr"] > 34.5 and a["l1_depth"] < 0.020 and a["mean_ssim"] > 0.95, res                  # colour refinement did its job
     assert os.path.exists(os.path.join(str(tmp_path), "point_cloud/final/point_cloud.ply"))
 
 
