@@ -450,6 +450,8 @@ class BackEnd:
             # :503-505 mask both sides of the difference by ~motion_mask; with a 0 / 1 mask: the masked target minus the masked rendering)
             hit = self._flow_targets.get((viewpoint.uid, closest))
             if hit is None:
+                while len(self._flow_targets) >= 4 * max(1, int(self.config["Training"].get("window_size", 8))):   # ~7 MB per pair at 640x480: keep
+                    self._flow_targets.pop(next(iter(self._flow_targets)))                                            # the window's, drop the oldest
                 def target(flow, mask):
                     m = (~mask).to(torch.float32)[None]
                     return (flow.permute(2, 0, 1) * m).contiguous(), m

@@ -165,3 +165,15 @@ def test_missing_library_is_a_loud_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_C, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _C.load_library()
+
+
+def test_render_package_forms_the_visibility_filter_when_it_is_read():
+    """gaussian_renderer.render_views / render_flow_views return render()'s dict without the `radii > 0` launch nobody in the batched
+    mapping loop reads; indexing the key forms (and keeps) it."""
+    import torch
+    import gaussian_renderer as gr
+    pkg = gr._RenderPackage({"radii": torch.tensor([0, 3, 0, 1])})
+    assert "visibility_filter" not in pkg
+    assert pkg["visibility_filter"].tolist() == [False, True, False, True] and "visibility_filter" in pkg
+    with pytest.raises(KeyError):
+        pkg["depth"]
