@@ -163,6 +163,49 @@ def run_cfg2(scene, world, rank, steps, warmup, barrier, k):
     return timed(step, steps, warmup, barrier), mode.get("allreduce"), step
 
 
+def graph_replayed_step(scene, k, steps):
+    """The SAME forward + backward captured once as a hipGraph -- the rasterizer's lazy mode, no host wait inside the step (what the SLAM
+    front-end's tracking loop runs, slam/tracking_graph.py) -- and replayed `steps` times: the step with the host out of the loop.
+    Reported beside the headline (whose eager step depends on the box's host speed), never instead of it. Returns a dict or None."""
+    from diff_gaussian_rasterization import _C
+    leaves = scene.params + [scene.theta, scene.rho, scene.means2D]
+    lazy_before = _C.set_option("lazy", 1)
+    try:
+        side = torch.cuda.Stream(device=scene.dev)
+        side.wait_stream(torch.cuda.current_stream(scene.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # allocator warm-up + the capacity estimate lazy mode sizes its buffers from
+                for p_ in leaves:
+                    p_.grad = None
+                scene.fwd_bwd(k)
+        torch.cuda.current_stream(scene.dev).wait_stream(side)
+        for p_ in leaves:
+            p_.grad = None
+        overflow_before = _C.forward_status()[0]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            scene.fwd_bwd(k)
+    except Exception as exc:                        # a capture that fails must not cost the bench its line
+        note(f"graph-replayed step skipped: {type(exc).__name__}: {exc}")
+        return None
+    finally:
+        _C.set_option("lazy", lazy_before)
+    for _ in range(5):
+        graph.replay()
+    torch.cuda.synchronize(scene.dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize(scene.dev)
+    dt = (time.perf_counter() - t0) / steps
+    ok = _C.forward_status()[0] == overflow_before  # no replay outgrew its (captured) binning capacity
+    for p_ in leaves:
+        p_.grad = None
+    del graph
+    return {"ms_per_step": dt * 1e3, "value": scene.P / dt, "unit": "Gaussians/s", "steps": steps, "overflow_free": bool(ok),
+            "what": "the same forward + backward captured as ONE hipGraph (lazy forward: no host wait) and replayed: host out of the loop"}
+
+
 def make_cfg5(scene, keyframes, overlap=False, local=False):
     """The config #5 iteration. local=True: every keyframe on THIS rank, no collective (the single-GPU point of the scaling curve)."""
     from fused_adam import FusedAdam
@@ -415,6 +458,10 @@ def main():
             }
             if nospec is not None:
                 out["ms_per_step_nonspeculative"] = nospec * 1e3
+            if world == 1 and not args.no_secondary:
+                replayed = graph_replayed_step(scene, rank, max(args.steps, 20))
+                if replayed is not None:
+                    out["graph_replay"] = replayed
         # ---- secondary: a short config #5 iteration on this one GPU (so that the N > 1 lines have a same-workload N = 1 point) ----
         if world == 1 and workload == "cfg2" and not args.no_secondary:
             note("secondary: config #5 iteration on one GPU")

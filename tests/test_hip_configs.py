@@ -237,6 +237,9 @@ def test_bench_single_gpu_line_carries_config5_and_both_binning_modes():
     assert d["n_gpus"] == 1 and "configs[1]" in d["config"]["workload"] and d["config"]["instances"] > 500000
     assert d["ms_per_step_nonspeculative"] >= 0.5 * d["ms_per_step"]          # (10 timed steps: box noise alone moves either number by 20 %)
     assert d["config5"]["ms_per_step"] > 0 and "configs[4]" in d["config5"]["workload"]
+    # the same step replayed as one hipGraph (host out of the loop): present, overflow-free, not slower than the eager step beyond noise
+    g = d["graph_replay"]
+    assert g["overflow_free"] and 0 < g["ms_per_step"] < 1.5 * d["ms_per_step"], d
 
 
 RCCL_ONE_RANK = r'''
