@@ -16,7 +16,6 @@ floats each). The view-independent terms (isotropic-scale regulariser, ARAP / el
 must be seeded alike: they take the same random draws (extra keyframes, time samples, split noise)."""
 import random
 
-import numpy as np
 import torch
 
 from gaussian_renderer import render, render_views

@@ -7,7 +7,6 @@ deform_model.py DeformModel, utils/time_utils.py ControlNodeWarp :788-1300) that
 The network is the reference's DeformNetwork for the shipped flags (8 x 256, 10 + 10 frequencies, local frame); not built: hash-grid
 encoders, node densification / pruning, hyper-coordinates, skinning -- the shipped SLAM configuration does not switch them on
 (arguments.py:107-125) and the loops never call them."""
-import math
 
 import torch
 from torch import nn
