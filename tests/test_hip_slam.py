@@ -268,8 +268,10 @@ def test_slam_dynamic_sequence_end_to_end():
     print(res)
     g = slam.gaussians
     assert res["frames"] == 30 and g.deform_init and int(g.dygs.sum()) > 50
-    assert res["ate_rmse"] < 0.0096, res                  # measured 7.9 mm / 28.1 dB / 28 mm with this reduced schedule
-    assert res["before_opt"]["mean_psnr"] > 27.2 and res["before_opt"]["l1_depth"] < 0.034, res
+    # measured over several runs with this reduced schedule: 7.9 mm, 27.6 - 28.1 dB, 28 - 29 mm (the regularisers' index_put / scatter_add
+    # backward passes are not run-to-run deterministic; the static run is)
+    assert res["ate_rmse"] < 0.0096, res
+    assert res["before_opt"]["mean_psnr"] > 26.6 and res["before_opt"]["l1_depth"] < 0.035, res
 
 
 def test_config4_stand_in_at_the_reference_schedule(tmp_path):
