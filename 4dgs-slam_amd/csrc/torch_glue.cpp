@@ -169,6 +169,92 @@ rasterize_gaussians_backward_fused(const torch::Tensor& background, const torch:
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau, tau_sum);
 }
 
+// ---- the autograd node of GaussianRasterizer in C++ (diff_gaussian_rasterization/autograd.py _RasterizeGaussians is the same node in
+// Python and stays the reference path: debug mode, fused gradient accumulation and the ctypes binding go through it). A forward +
+// backward of BASELINE config #2 is 0.24 ms of GPU time; the Python node costs ~75 us of host time per step on top of the two calls
+// above (Function.apply, ctx bookkeeping, argument tuples, the backward trampoline), which a slow host cannot hide behind the 80 us of
+// GPU work between the binning mailbox and the backward launches. Inputs 0-9 are the reference's differentiable inputs in its order
+// (DGR/diff_gaussian_rasterization/__init__.py:44-56), the rest are the raster settings.
+namespace {
+struct RasterizeNode : public torch::autograd::Function<RasterizeNode> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const torch::Tensor& means3D, const torch::Tensor& means2D,
+                                                  const torch::Tensor& sh, const torch::Tensor& colors, const torch::Tensor& opacities,
+                                                  const torch::Tensor& scales, const torch::Tensor& rotations, const torch::Tensor& cov3D,
+                                                  const torch::Tensor& theta, const torch::Tensor& rho, const torch::Tensor& bg,
+                                                  double scale_modifier, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+                                                  const torch::Tensor& projmatrix_raw, double tan_fovx, double tan_fovy, int64_t H, int64_t W,
+                                                  int64_t degree, const torch::Tensor& campos, bool prefiltered, int64_t stream)
+    {
+        (void)means2D;
+        auto r = rasterize_gaussians(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix, projmatrix, projmatrix_raw,
+                                     tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, false, stream);
+        ctx->saved_data["R"] = (int64_t)std::get<0>(r);
+        ctx->saved_data["scale_modifier"] = scale_modifier;
+        ctx->saved_data["tan_fovx"] = tan_fovx;
+        ctx->saved_data["tan_fovy"] = tan_fovy;
+        ctx->saved_data["degree"] = degree;
+        ctx->saved_data["stream"] = stream;
+        ctx->saved_data["theta_3"] = theta.defined() && theta.numel() == 3;
+        ctx->saved_data["rho_3"] = rho.defined() && rho.numel() == 3;
+        ctx->saved_data["theta_shape"] = theta.defined() ? theta.sizes().vec() : std::vector<int64_t>{};
+        ctx->saved_data["rho_shape"] = rho.defined() ? rho.sizes().vec() : std::vector<int64_t>{};
+        const torch::Tensor &color = std::get<1>(r), &radii = std::get<2>(r), &depth = std::get<6>(r), &opacity = std::get<7>(r), &n_touched = std::get<8>(r);
+        ctx->save_for_backward({colors, means3D, scales, rotations, cov3D, radii, sh, std::get<3>(r), std::get<4>(r), std::get<5>(r), bg, viewmatrix,
+                                projmatrix, projmatrix_raw, campos});
+        ctx->mark_non_differentiable({radii, n_touched});
+        ctx->set_materialize_grads(false);        // unused cotangents (opacity, radii, n_touched) arrive undefined, not zero-filled
+        return {color, radii, depth, opacity, n_touched};
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        const auto sv = ctx->get_saved_variables();
+        const torch::Tensor &colors = sv[0], &means3D = sv[1], &scales = sv[2], &rotations = sv[3], &cov3D = sv[4], &radii = sv[5], &sh = sv[6],
+                            &geom = sv[7], &binning = sv[8], &img = sv[9], &bg = sv[10], &view = sv[11], &proj = sv[12], &proj_raw = sv[13], &campos = sv[14];
+        auto fopt = means3D.options().dtype(torch::kFloat32);
+        torch::Tensor g_color = g[0], g_depth = g[2];
+        // the image size is that of whichever cotangent arrived; with neither there is nothing to back-propagate
+        if (!g_color.defined() && !g_depth.defined()) return torch::autograd::variable_list(23);
+        const int64_t h = g_color.defined() ? g_color.size(1) : g_depth.size(1), w = g_color.defined() ? g_color.size(2) : g_depth.size(2);
+        if (!g_color.defined()) g_color = torch::zeros({kChannels, h, w}, fopt);
+        if (!g_depth.defined()) g_depth = torch::zeros({1, h, w}, fopt);
+        auto r = rasterize_gaussians_backward_fused(bg, means3D, radii, colors, scales, rotations, ctx->saved_data["scale_modifier"].toDouble(), cov3D, view, proj,
+                                                    proj_raw, ctx->saved_data["tan_fovx"].toDouble(), ctx->saved_data["tan_fovy"].toDouble(), g_color, g_depth, sh,
+                                                    ctx->saved_data["degree"].toInt(), campos, geom, ctx->saved_data["R"].toInt(), binning, img, false, true,
+                                                    ctx->saved_data["stream"].toInt(), {});
+        const torch::Tensor& tau = std::get<9>(r);
+        auto pose = [&](int64_t at, const char* is3, const char* shape) {     // a 3-element input gets its gradient in its own shape, else [1,3]
+            torch::Tensor v = tau.narrow(0, at, 3);
+            return ctx->saved_data[is3].toBool() ? v.view(ctx->saved_data[shape].toIntVector()) : v.view({1, 3});
+        };
+        auto some = [](const torch::Tensor& t) { return t.numel() ? t : torch::Tensor(); };     // gradients of inputs that were not given: undefined
+        torch::autograd::variable_list out(23);
+        out[0] = std::get<3>(r);            // means3D
+        out[1] = std::get<0>(r);            // means2D
+        out[2] = some(std::get<5>(r));      // sh
+        out[3] = some(std::get<1>(r));      // colors_precomp
+        out[4] = std::get<2>(r);            // opacities
+        out[5] = some(std::get<6>(r));      // scales
+        out[6] = some(std::get<7>(r));      // rotations
+        out[7] = some(std::get<4>(r));      // cov3D_precomp
+        out[8] = pose(3, "theta_3", "theta_shape");
+        out[9] = pose(0, "rho_3", "rho_shape");
+        return out;
+    }
+};
+}  // namespace
+
+std::vector<torch::Tensor> rasterize_autograd(const torch::Tensor& means3D, const torch::Tensor& means2D, const torch::Tensor& sh, const torch::Tensor& colors,
+                                              const torch::Tensor& opacities, const torch::Tensor& scales, const torch::Tensor& rotations,
+                                              const torch::Tensor& cov3D, const torch::Tensor& theta, const torch::Tensor& rho, const torch::Tensor& bg,
+                                              double scale_modifier, const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix,
+                                              const torch::Tensor& projmatrix_raw, double tan_fovx, double tan_fovy, int64_t H, int64_t W, int64_t degree,
+                                              const torch::Tensor& campos, bool prefiltered, int64_t stream)
+{
+    return RasterizeNode::apply(means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, theta, rho, bg, scale_modifier, viewmatrix, projmatrix,
+                                projmatrix_raw, tan_fovx, tan_fovy, H, W, degree, campos, prefiltered, stream);
+}
+
 // ---- fused prologue: gsr_forward_raw / gsr_backward_raw, see diff_gaussian_rasterization/raw.py ----
 namespace {
 const torch::Tensor& nz(const c10::optional<torch::Tensor>& t, const torch::Tensor& empty) { return t.has_value() ? *t : empty; }
@@ -674,6 +760,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("rasterize_gaussians", &rasterize_gaussians);
     m.def("rasterize_gaussians_backward_fused", &rasterize_gaussians_backward_fused);
+    m.def("rasterize_autograd", &rasterize_autograd);
     m.def("rasterize_gaussians_raw", &rasterize_gaussians_raw);
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
     m.def("l1_loss_forward", &l1_loss_forward);

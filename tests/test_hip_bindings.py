@@ -73,3 +73,48 @@ def test_native_and_ctypes_bindings_agree_bitwise():
     a, b = _run("native"), _run("ctypes")
     assert a["binding"] == "native" and b["binding"] == "ctypes"
     assert a["digest"] == b["digest"]
+
+
+def test_cpp_autograd_node_equals_the_python_node_bitwise():
+    """GaussianRasterizer's autograd node exists twice: in Python (autograd.py, the reference path) and in C++ (torch_glue.cpp RasterizeNode,
+    taken when the native glue is loaded). Same calls underneath: images, radii, n_touched and every gradient must agree bit for bit --
+    SH input with pose parameters of shape (3,), and precomputed colours with [1,3] pose parameters."""
+    sys.path[:0] = [os.path.join(REPO, "tests"), REPO, os.path.join(REPO, "4dgs-slam_amd")]
+    import numpy as np
+    import torch
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    from util import make_camera, make_cotangents, make_gaussians
+    if _C._glue is None or not hasattr(_C._glue, "rasterize_autograd"):
+        pytest.skip("native glue not built")
+    cam = make_camera(200, 152)
+    g = make_gaussians(6000, cam, seed=11, sh_degree=1)
+    gc, gd = make_cotangents(cam, seed=12)
+    T = lambda a: torch.tensor(np.asarray(a, np.float32), device="cuda")
+    rs = dgr.GaussianRasterizationSettings(cam.H, cam.W, cam.tanfovx, cam.tanfovy, T([0.2, 0.1, 0.3]), 1.0, T(cam.viewmatrix), T(cam.projmatrix),
+                                           T(cam.projmatrix_raw), 1, T(cam.campos), False, False)
+
+    def run(native, precomputed):
+        dgr._NATIVE_NODE = native
+        leaf = lambda a: T(a).requires_grad_(True)
+        p = {"means3D": leaf(g["means3D"]), "opacities": leaf(g["opacities"]), "scales": leaf(g["scales"]), "rotations": leaf(g["rotations"])}
+        if precomputed:
+            p["colors_precomp"] = leaf(np.random.default_rng(5).uniform(0, 1, (6000, 3)))
+            pose = {"theta": torch.zeros((1, 3), device="cuda", requires_grad=True), "rho": torch.zeros((1, 3), device="cuda", requires_grad=True)}
+        else:
+            p["shs"] = leaf(g["shs"])
+            pose = {"theta": torch.zeros(3, device="cuda", requires_grad=True), "rho": torch.zeros(3, device="cuda", requires_grad=True)}
+        m2d = torch.zeros((6000, 3), device="cuda", requires_grad=True)
+        out = dgr.GaussianRasterizer(rs)(means2D=m2d, **p, **pose)
+        torch.autograd.backward([out[0], out[2]], [T(gc), T(gd)])
+        assert out[1].dtype == torch.int32 and not out[1].requires_grad and not out[4].requires_grad
+        return list(out) + [m2d.grad] + [t.grad for t in p.values()] + [t.grad for t in pose.values()]
+
+    try:
+        for precomputed in (False, True):
+            a, b = run(True, precomputed), run(False, precomputed)
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert x.shape == y.shape and torch.equal(x, y)
+    finally:
+        dgr._NATIVE_NODE = True
