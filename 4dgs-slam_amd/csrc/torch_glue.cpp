@@ -452,6 +452,72 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
     return std::make_tuple(g_image, g_depth, g_exp);
 }
 
+// The autograd node of slam_losses.weighted_l1_loss in C++ (the Python node _WeightedL1 stays the reference path and serves the ctypes
+// binding): the mapping loops call it once per view and iteration, so the Python node's apply / ctx / backward trampoline (~30 us each
+// way) was a quarter of a static mapping iteration's host time. Undefined tensors stand for the optional inputs that were not given.
+namespace {
+using OptTensor = c10::optional<torch::Tensor>;
+OptTensor opt_of(const torch::Tensor& t) { return t.defined() ? OptTensor(t) : c10::nullopt; }
+torch::Tensor detached(const OptTensor& t) { return (t.has_value() && t->defined()) ? t->detach() : torch::Tensor(); }
+
+struct WeightedL1Node : public torch::autograd::Function<WeightedL1Node> {
+    // (optional inputs travel as c10::optional: the autograd machinery records layout / device of every Tensor argument, an undefined one has neither)
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image,
+                                 const torch::Tensor& gt_depth, const OptTensor& w_rgb, const OptTensor& w_depth, const OptTensor& exposure_a,
+                                 const OptTensor& exposure_b, double alpha, const OptTensor& opacity, double opacity_thr, bool compute_value, int64_t stream)
+    {
+        const torch::Tensor img = image.detach(), dep = depth.detach(), ea = detached(exposure_a), eb = detached(exposure_b), op = detached(opacity);
+        const torch::Tensor wr = detached(w_rgb), wd = detached(w_depth);
+        torch::Tensor loss, ws;
+        if (compute_value) {
+            std::tie(loss, ws) = l1_loss_forward(img, dep, gt_image, gt_depth, opt_of(wr), opt_of(wd), opt_of(ea), opt_of(eb), alpha, opt_of(op), opacity_thr, stream);
+        } else {        // the caller only back-propagates: a defined placeholder (NOT the loss), the backward kernels need nothing from the forward pass
+            TORCH_CHECK(image.is_cuda(), "image is on '", image.device().str(),
+                        "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
+            loss = torch::zeros({}, image.options().dtype(torch::kFloat32));
+            ws = torch::empty({(int64_t)gsr_l1_loss_workspace_size()}, image.options().dtype(torch::kUInt8));
+        }
+        ctx->saved_data["alpha"] = alpha;
+        ctx->saved_data["opacity_thr"] = opacity_thr;
+        ctx->saved_data["stream"] = stream;
+        ctx->saved_data["mask"] = (int64_t)((wr.defined() ? 1 : 0) | (wd.defined() ? 2 : 0) | (ea.defined() ? 4 : 0) | (op.defined() ? 8 : 0));
+        std::vector<torch::Tensor> keep = {img, dep, gt_image, gt_depth, ws};
+        for (const torch::Tensor& t : {wr, wd, ea, eb, op}) if (t.defined()) keep.push_back(t);
+        ctx->save_for_backward(keep);
+        return loss;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g)
+    {
+        const auto sv = ctx->get_saved_variables();
+        torch::autograd::variable_list out(13);
+        if (!g[0].defined()) return out;
+        const int64_t mask = ctx->saved_data["mask"].toInt();
+        size_t at = 5;
+        auto next = [&](int64_t bit) { return (mask & bit) ? sv[at++] : torch::Tensor(); };
+        const torch::Tensor wr = next(1), wd = next(2), ea = next(4), eb = (mask & 4) ? sv[at++] : torch::Tensor(), op = next(8);
+        auto r = l1_loss_backward(sv[0], sv[1], sv[2], sv[3], opt_of(wr), opt_of(wd), opt_of(ea), opt_of(eb), ctx->saved_data["alpha"].toDouble(), opt_of(op),
+                                  ctx->saved_data["opacity_thr"].toDouble(), g[0], sv[4], ctx->saved_data["stream"].toInt());
+        out[0] = std::get<0>(r);
+        out[1] = std::get<1>(r);
+        const torch::Tensor& g_exp = std::get<2>(r);
+        if (g_exp.defined() && ea.defined()) {
+            out[6] = g_exp.narrow(0, 0, 1).view(ea.sizes());
+            out[7] = g_exp.narrow(0, 1, 1).view(eb.sizes());
+        }
+        return out;
+    }
+};
+}  // namespace
+
+torch::Tensor weighted_l1_autograd(const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image, const torch::Tensor& gt_depth,
+                                   const c10::optional<torch::Tensor>& w_rgb, const c10::optional<torch::Tensor>& w_depth,
+                                   const c10::optional<torch::Tensor>& exposure_a, const c10::optional<torch::Tensor>& exposure_b, double alpha,
+                                   const c10::optional<torch::Tensor>& opacity, double opacity_thr, bool compute_value, int64_t stream)
+{
+    return WeightedL1Node::apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_thr, compute_value, stream);
+}
+
 // ---- fused SSIM (include/slam_losses.h) ----
 std::tuple<torch::Tensor, torch::Tensor> ssim_forward(const torch::Tensor& img1_, const torch::Tensor& img2_, const c10::optional<torch::Tensor>& mask_,
                                                        int64_t stream)
@@ -765,6 +831,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
     m.def("l1_loss_forward", &l1_loss_forward);
     m.def("l1_loss_backward", &l1_loss_backward);
+    m.def("weighted_l1_autograd", &weighted_l1_autograd);
     m.def("ssim_forward", &ssim_forward);
     m.def("ssim_backward", &ssim_backward);
     m.def("mark_visible", &mark_visible);

@@ -13,6 +13,7 @@ import torch
 from diff_gaussian_rasterization import _C
 
 _declared = False
+_NATIVE_NODE = __import__("os").environ.get("GSR_NATIVE_AUTOGRAD", "1") != "0"
 
 
 class _MaskedTerm(C.Structure):      # gsr_masked_l1_term, include/slam_losses.h
@@ -132,6 +133,12 @@ def weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb=None, w_depth=None,
     compute_value=False: the returned scalar is uninitialised (for callers that only call .backward() on it)."""
     if (exposure_a is None) != (exposure_b is None):
         raise RuntimeError("weighted_l1_loss: give both exposure parameters or neither")
+    glue = _C._glue
+    if (_NATIVE_NODE and glue is not None and hasattr(glue, "weighted_l1_autograd") and image.is_cuda and image.dtype == torch.float32
+            and image.device.index == torch.cuda.current_device()):
+        # the same node in C++ (csrc/torch_glue.cpp WeightedL1Node): one call per view and mapping iteration, ~30 us less host time each way
+        return glue.weighted_l1_autograd(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, float(alpha), opacity,
+                                         float(opacity_depth_threshold), bool(compute_value), _C._stream(image.device))
     return _WeightedL1.apply(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity, opacity_depth_threshold,
                              bool(compute_value))
 

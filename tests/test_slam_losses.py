@@ -220,3 +220,39 @@ def test_fused_densification_stats_match_the_reference_expressions():
     add_densification_stats(g, vs, radii)
     assert torch.equal(g.max_radii2D, want.max_radii2D) and torch.equal(g.denom, want.denom)
     assert torch.allclose(g.xyz_gradient_accum, want.xyz_gradient_accum, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute_value", [True, False])
+def test_cpp_loss_node_equals_the_python_node_bitwise(compute_value):
+    """weighted_l1_loss's autograd node in C++ (torch_glue.cpp WeightedL1Node) against the Python node: same value, same gradients, with
+    and without exposure parameters / opacity / weights, and in the back-propagate-only mode."""
+    import slam_losses
+    from diff_gaussian_rasterization import _C
+    if _C._glue is None or not hasattr(_C._glue, "weighted_l1_autograd"):
+        pytest.skip("native glue not built")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    H, W = 60, 84
+    R = lambda *s: torch.rand(*s, generator=g).cuda()
+
+    def run(native, variant):
+        slam_losses._NATIVE_NODE = native
+        image, depth = R(3, H, W).requires_grad_(True), R(1, H, W).requires_grad_(True)
+        kw = {}
+        if variant >= 1:
+            kw.update(exposure_a=torch.tensor([0.05], device="cuda", requires_grad=True), exposure_b=torch.tensor([-0.02], device="cuda", requires_grad=True))
+        if variant >= 2:
+            kw.update(w_rgb=(R(1, H, W) > 0.3).float(), w_depth=(R(1, H, W) > 0.5).float() * 2, opacity=R(1, H, W))
+        loss = slam_losses.weighted_l1_loss(image, depth, R(3, H, W), R(1, H, W), alpha=0.9, compute_value=compute_value, **kw)
+        (loss * 1.7).backward()
+        return [loss.detach(), image.grad, depth.grad] + [kw[k].grad for k in ("exposure_a", "exposure_b") if k in kw]
+
+    try:
+        for variant in (0, 1, 2):
+            g.manual_seed(3 + variant)
+            a = run(True, variant)
+            g.manual_seed(3 + variant)
+            b = run(False, variant)
+            assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b)), variant
+    finally:
+        slam_losses._NATIVE_NODE = True
