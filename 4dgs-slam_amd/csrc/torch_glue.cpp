@@ -10,6 +10,7 @@
 // Pure C++ (no device code, no HIP headers): the stream is passed in as an integer by the Python caller.
 #include <torch/extension.h>
 
+#include <cstring>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -452,6 +453,179 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> l1_loss_backward(
     return std::make_tuple(g_image, g_depth, g_exp);
 }
 
+// ---- the multi-view entry point (gsr_forward_views / gsr_backward_views): the marshalling of diff_gaussian_rasterization/views.py in C++.
+// The autograd Functions stay in Python (they resolve the fused-accumulation targets and hold the per-call context); what moves here is
+// the per-view descriptor table, the three allocation callbacks per view and ~25 pointer extractions per view -- 0.3 ms of host time per
+// call with ctypes at 6-10 views, once forward and once backward per mapping iteration. Per-view optional tensors travel as lists of
+// optionals (None = not given); flow_* lists are empty unless the call renders flow views.
+namespace {
+using TensorVec = std::vector<torch::Tensor>;
+using OptVec = std::vector<c10::optional<torch::Tensor>>;
+
+const float* opt_at(const OptVec& v, size_t i, TensorVec& keep, const char* name)
+{
+    if (i >= v.size() || !v[i].has_value() || !v[i]->defined() || v[i]->numel() == 0) return nullptr;
+    torch::Tensor t = v[i]->detach();
+    if (t.scalar_type() != torch::kFloat32) t = t.to(torch::kFloat32);
+    t = t.contiguous();
+    keep.push_back(t);
+    return fptr(t, name);
+}
+const float* need_at(const TensorVec& v, size_t i, TensorVec& keep, const char* name)
+{
+    TORCH_CHECK(i < v.size() && v[i].defined(), name, ": one tensor per view expected");
+    torch::Tensor t = v[i].detach().contiguous();
+    keep.push_back(t);
+    return fptr(t, name);
+}
+void fill_view_cameras(std::vector<gsr_view>& views, const TensorVec& view, const TensorVec& proj, const TensorVec& proj_raw, const TensorVec& campos,
+                       const OptVec& dx, const OptVec& ds, const OptVec& dr, const OptVec& flow_dx2, const OptVec& flow_proj1, const OptVec& flow_proj2,
+                       TensorVec& keep)
+{
+    for (size_t v = 0; v < views.size(); v++) {
+        gsr_view& w = views[v];
+        w.viewmatrix = need_at(view, v, keep, "viewmatrix"); w.projmatrix = need_at(proj, v, keep, "projmatrix");
+        w.projmatrix_raw = need_at(proj_raw, v, keep, "projmatrix_raw"); w.cam_pos = need_at(campos, v, keep, "campos");
+        w.dx = opt_at(dx, v, keep, "dx"); w.ds = opt_at(ds, v, keep, "ds"); w.dr = opt_at(dr, v, keep, "dr");
+        w.flow_dx2 = opt_at(flow_dx2, v, keep, "d_xyz2"); w.flow_proj1 = opt_at(flow_proj1, v, keep, "proj1"); w.flow_proj2 = opt_at(flow_proj2, v, keep, "proj2");
+    }
+}
+}  // namespace
+
+// returns (img [V, C+2, H, W]: colour | depth | opacity per view, ints [V, 2, P]: radii | n_touched, num_rendered per view, the 3 V scratch buffers)
+std::tuple<torch::Tensor, torch::Tensor, std::vector<int64_t>, TensorVec>
+rasterize_views_forward(const torch::Tensor& background, const torch::Tensor& xyz_, const torch::Tensor& log_scales_, const torch::Tensor& raw_rot_,
+                        const torch::Tensor& logit_, const c10::optional<torch::Tensor>& f_dc_, const c10::optional<torch::Tensor>& f_rest_,
+                        const c10::optional<torch::Tensor>& dyn_slot_, const TensorVec& view, const TensorVec& proj, const TensorVec& proj_raw,
+                        const TensorVec& campos, const OptVec& dx, const OptVec& ds, const OptVec& dr, const OptVec& flow_dx2, const OptVec& flow_proj1,
+                        const OptVec& flow_proj2, double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W, int64_t degree, bool debug,
+                        int64_t stream)
+{
+    TORCH_CHECK(xyz_.dim() == 2 && xyz_.size(1) == 3 && xyz_.size(0) > 0 && xyz_.is_cuda(), "_xyz must be a (num_points > 0, 3) tensor on a HIP device");
+    const int V = (int)view.size(), P = (int)xyz_.size(0);
+    const torch::Tensor none;
+    TensorVec keep;
+    auto fopt = xyz_.options().dtype(torch::kFloat32);
+    torch::Tensor img = torch::empty({V, kChannels + 2, H, W}, fopt);
+    torch::Tensor ints = torch::empty({V, 2, P}, xyz_.options().dtype(torch::kInt32));
+    TensorVec state(3 * (size_t)V);
+    for (auto& t : state) t = torch::empty({0}, xyz_.options().dtype(torch::kUInt8));
+    const torch::Tensor bg = contig(background.detach()), xyz = contig(xyz_.detach()), ls = contig(log_scales_.detach()), rr = contig(raw_rot_.detach()),
+                        lo = contig(logit_.detach()), fdc = contig(nz(f_dc_, none)), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none));
+    const int M = 1 + (frest.defined() && frest.numel() != 0 ? (int)frest.size(1) : 0);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc.defined() ? fdc.detach() : fdc, frest.defined() ? frest.detach() : frest, slot, none, none, none, none);
+    std::vector<gsr_view> views((size_t)V);
+    memset(views.data(), 0, sizeof(gsr_view) * (size_t)V);
+    fill_view_cameras(views, view, proj, proj_raw, campos, dx, ds, dr, flow_dx2, flow_proj1, flow_proj2, keep);
+    for (int v = 0; v < V; v++) {
+        gsr_view& w = views[(size_t)v];
+        float* base = img.data_ptr<float>() + (size_t)v * (kChannels + 2) * H * W;
+        w.out_color = base; w.out_depth = base + (size_t)kChannels * H * W; w.out_opacity = base + (size_t)(kChannels + 1) * H * W;
+        w.radii = ints.data_ptr<int>() + (size_t)v * 2 * P; w.n_touched = w.radii + P;
+        w.geometry_user = &state[3 * (size_t)v]; w.binning_user = &state[3 * (size_t)v + 1]; w.image_user = &state[3 * (size_t)v + 2];
+    }
+    const int rc = gsr_forward_views(V, views.data(), resize_cb, resize_cb, resize_cb, P, (int)degree, M, fptr(bg, "bg"), (int)W, (int)H, &in, (float)scale_modifier,
+                                     (float)tan_fovx, (float)tan_fovy, debug ? 1 : 0, reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_forward_views", rc);
+    std::vector<int64_t> rendered((size_t)V);
+    for (int v = 0; v < V; v++) rendered[(size_t)v] = views[(size_t)v].num_rendered;
+    return std::make_tuple(img, ints, rendered, state);
+}
+
+// targets: the six parameter-gradient buffers the kernels add to / write (xyz, f_dc, f_rest, logit, log_scales, raw_rot; f_rest may be empty),
+// or an empty list = allocate them here (flow views: xyz only). Returns (the six parameter gradients or undefined, per_view [V, 3 P + 6]:
+// screen-space gradient | pose sum, the delta gradients per view: dx, dx2, ds, dr (undefined where the view has no such input)).
+std::tuple<TensorVec, torch::Tensor, TensorVec>
+rasterize_views_backward(const torch::Tensor& background, const torch::Tensor& xyz_, const torch::Tensor& log_scales_, const torch::Tensor& raw_rot_,
+                         const torch::Tensor& logit_, const c10::optional<torch::Tensor>& f_dc_, const c10::optional<torch::Tensor>& f_rest_,
+                         const c10::optional<torch::Tensor>& dyn_slot_, const TensorVec& view, const TensorVec& proj, const TensorVec& proj_raw,
+                         const TensorVec& campos, const OptVec& dx, const OptVec& ds, const OptVec& dr, const OptVec& flow_dx2, const OptVec& flow_proj1,
+                         const OptVec& flow_proj2, double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W, int64_t degree,
+                         const torch::Tensor& ints, const TensorVec& state, const std::vector<int64_t>& rendered, const TensorVec& g_color,
+                         const TensorVec& g_depth, const TensorVec& targets, bool accumulate, bool pose_only, bool debug, int64_t stream)
+{
+    const int V = (int)view.size(), P = (int)xyz_.size(0), S = (int)log_scales_.size(-1);
+    const bool flow = !flow_proj1.empty();
+    const torch::Tensor none;
+    TensorVec keep;
+    auto fopt = xyz_.options().dtype(torch::kFloat32);
+    const torch::Tensor bg = contig(background.detach()), xyz = contig(xyz_.detach()), ls = contig(log_scales_.detach()), rr = contig(raw_rot_.detach()),
+                        lo = contig(logit_.detach()), fdc = contig(nz(f_dc_, none)), frest = contig(nz(f_rest_, none)), slot = contig(nz(dyn_slot_, none));
+    const int M = 1 + (frest.defined() && frest.numel() != 0 ? (int)frest.size(1) : 0);
+    const gsr_raw_inputs in = describe(xyz, ls, rr, lo, fdc.defined() ? fdc.detach() : fdc, frest.defined() ? frest.detach() : frest, slot, none, none, none, none);
+    // parameter gradients
+    TensorVec grads(6);
+    gsr_raw_grads out{};
+    if (!pose_only) {
+        if (!targets.empty()) {
+            TORCH_CHECK(targets.size() == 6, "targets: six gradient buffers or none");
+            out.xyz = targets[0].data_ptr<float>(); out.features_dc = targets[1].data_ptr<float>();
+            out.features_rest = (M > 1 && targets[2].numel()) ? targets[2].data_ptr<float>() : nullptr;
+            out.logit_opacity = targets[3].data_ptr<float>(); out.log_scales = targets[4].data_ptr<float>(); out.raw_rotations = targets[5].data_ptr<float>();
+        } else if (flow) {
+            grads[0] = torch::empty({P, 3}, fopt);
+            out.xyz = grads[0].data_ptr<float>();
+        } else {
+            const int64_t widths[6] = {3, 3, 3 * (M - 1), 1, S, 4};
+            int64_t total = 0;
+            for (int64_t w_ : widths) total += (int64_t)P * w_;
+            torch::Tensor own = torch::empty({total}, fopt);
+            int64_t o = 0;
+            for (int i = 0; i < 6; i++) { grads[(size_t)i] = own.narrow(0, o, (int64_t)P * widths[i]); o += (int64_t)P * widths[i]; }
+            out.xyz = grads[0].data_ptr<float>(); out.features_dc = grads[1].data_ptr<float>(); out.features_rest = M > 1 ? grads[2].data_ptr<float>() : nullptr;
+            out.logit_opacity = grads[3].data_ptr<float>(); out.log_scales = grads[4].data_ptr<float>(); out.raw_rotations = grads[5].data_ptr<float>();
+        }
+    }
+    torch::Tensor per_view = torch::empty({V, (int64_t)P * 3 + 6}, fopt);
+    // delta gradients: one allocation, one fill for all views (the kernels only write the rows of visible Gaussians)
+    TensorVec delta(4 * (size_t)V);
+    if (!pose_only) {
+        int64_t total = 0;
+        auto count = [&](const OptVec& v, size_t i) { return (i < v.size() && v[i].has_value() && v[i]->defined()) ? v[i]->numel() : (int64_t)0; };
+        for (size_t v = 0; v < (size_t)V; v++) total += count(dx, v) + count(flow_dx2, v) + count(ds, v) + count(dr, v);
+        if (total) {
+            torch::Tensor flat = torch::zeros({total}, fopt);
+            int64_t o = 0;
+            auto take = [&](const OptVec& src, size_t i) {
+                const int64_t n = count(src, i);
+                if (!n) return torch::Tensor();
+                torch::Tensor t = flat.narrow(0, o, n).view((*src[i]).sizes());
+                o += n;
+                return t;
+            };
+            for (size_t v = 0; v < (size_t)V; v++) { delta[4 * v] = take(dx, v); delta[4 * v + 1] = take(flow_dx2, v); delta[4 * v + 2] = take(ds, v); delta[4 * v + 3] = take(dr, v); }
+        }
+    }
+    std::vector<gsr_view> views((size_t)V);
+    memset(views.data(), 0, sizeof(gsr_view) * (size_t)V);
+    fill_view_cameras(views, view, proj, proj_raw, campos, dx, ds, dr, flow_dx2, flow_proj1, flow_proj2, keep);
+    TORCH_CHECK((int)state.size() == 3 * V && (int)rendered.size() == V && (int)g_color.size() == V && (int)g_depth.size() == V, "one entry per view expected");
+    for (int v = 0; v < V; v++) {
+        gsr_view& w = views[(size_t)v];
+        w.radii = const_cast<int*>(ints.data_ptr<int>()) + (size_t)v * 2 * P;
+        w.geom_buffer = reinterpret_cast<char*>(state[3 * (size_t)v].data_ptr()); w.binning_buffer = reinterpret_cast<char*>(state[3 * (size_t)v + 1].data_ptr());
+        w.image_buffer = reinterpret_cast<char*>(state[3 * (size_t)v + 2].data_ptr());
+        w.num_rendered = (int)rendered[(size_t)v];
+        auto cot = [&](const torch::Tensor& t, const char* name) {
+            torch::Tensor c = t.scalar_type() == torch::kFloat32 ? t : t.to(torch::kFloat32);
+            c = c.contiguous();
+            keep.push_back(c);
+            return fptr(c, name);
+        };
+        w.dL_dcolor = cot(g_color[(size_t)v], "dL_dcolor"); w.dL_ddepth = cot(g_depth[(size_t)v], "dL_ddepth");
+        w.dL_dmean2D = per_view.data_ptr<float>() + (size_t)v * ((size_t)P * 3 + 6); w.dL_dtau_sum = w.dL_dmean2D + (size_t)P * 3;
+        auto dp = [&](const torch::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; };
+        w.ddx = dp(delta[4 * (size_t)v]); w.ddx2 = dp(delta[4 * (size_t)v + 1]); w.dds = dp(delta[4 * (size_t)v + 2]); w.ddr = dp(delta[4 * (size_t)v + 3]);
+    }
+    torch::Tensor scratch;
+    if (!pose_only) scratch = torch::empty({(int64_t)gsr_views_scratch_size(V, P, M, S)}, xyz_.options().dtype(torch::kUInt8));
+    const int flags = (debug ? 1 : 0) | (accumulate ? GSR_BACKWARD_ACCUMULATE : 0) | (pose_only ? GSR_BACKWARD_POSE_ONLY : 0);
+    const int rc = gsr_backward_views(V, views.data(), P, (int)degree, M, fptr(bg, "bg"), (int)W, (int)H, &in, (float)scale_modifier, (float)tan_fovx, (float)tan_fovy,
+                                      &out, scratch.defined() ? reinterpret_cast<char*>(scratch.data_ptr()) : nullptr, flags, reinterpret_cast<void*>(stream));
+    if (rc < 0) fail("gsr_backward_views", rc);
+    return std::make_tuple(grads, per_view, delta);
+}
+
 // The autograd node of slam_losses.weighted_l1_loss in C++ (the Python node _WeightedL1 stays the reference path and serves the ctypes
 // binding): the mapping loops call it once per view and iteration, so the Python node's apply / ctx / backward trampoline (~30 us each
 // way) was a quarter of a static mapping iteration's host time. Undefined tensors stand for the optional inputs that were not given.
@@ -832,6 +1006,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("l1_loss_forward", &l1_loss_forward);
     m.def("l1_loss_backward", &l1_loss_backward);
     m.def("weighted_l1_autograd", &weighted_l1_autograd);
+    m.def("rasterize_views_forward", &rasterize_views_forward);
+    m.def("rasterize_views_backward", &rasterize_views_backward);
     m.def("ssim_forward", &ssim_forward);
     m.def("ssim_backward", &ssim_backward);
     m.def("mark_visible", &mark_visible);

@@ -10,6 +10,7 @@ view order (with fused accumulation -- FusedAdam's attached bucket -- exactly wh
 settings: one GaussianRasterizationSettings per view (same image size, field of view, background, SH degree and scale modifier).
 means2D: one zeros [P,3] tensor per view whose .grad receives that view's screen-space gradient."""
 import ctypes as C
+import os
 
 import torch
 
@@ -59,6 +60,20 @@ def _lib():
     return lib
 
 
+_NATIVE_MARSHALLING = os.environ.get("GSR_NATIVE_VIEWS", "1") != "0"
+
+
+def _glue():
+    """The native glue's marshalling of the two calls (csrc/torch_glue.cpp rasterize_views_forward / _backward), or None: the ctypes code
+    below does the same job in Python (~0.3 ms of host time per call at 6-10 views) and remains the reference path."""
+    g = _C._glue
+    return g if (_NATIVE_MARSHALLING and g is not None and hasattr(g, "rasterize_views_forward")) else None
+
+
+def _camera_lists(settings):
+    return ([rs.viewmatrix for rs in settings], [rs.projmatrix for rs in settings], [rs.projmatrix_raw for rs in settings], [rs.campos for rs in settings])
+
+
 class _RasterizeViewsRaw(torch.autograd.Function):
     """inputs: xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, settings (list), then six per view:
     means2D, dx, ds, dr, theta, rho. outputs: five per view: color, radii, depth, opacity, n_touched."""
@@ -76,6 +91,23 @@ class _RasterizeViewsRaw(torch.autograd.Function):
         ctx.acc_params = _acc_params(xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot)
         ctx.pose_shapes = [(tuple(per_view[6 * v + 4].shape) if isinstance(per_view[6 * v + 4], torch.Tensor) else None,
                             tuple(per_view[6 * v + 5].shape) if isinstance(per_view[6 * v + 5], torch.Tensor) else None) for v in range(V)]
+        glue = _glue()
+        if glue is not None:
+            cams = _camera_lists(settings)
+            with torch.cuda.device(dev):
+                img, ints, rendered, state = glue.rasterize_views_forward(
+                    rs0.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest if (f_rest is not None and f_rest.numel()) else None, dyn_slot, *cams,
+                    [per_view[6 * v + 1] for v in range(V)], [per_view[6 * v + 2] for v in range(V)], [per_view[6 * v + 3] for v in range(V)], [], [], [],
+                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, int(rs0.sh_degree), bool(rs0.debug), _C._stream(dev))
+            ctx.num_rendered = [int(r) for r in rendered]
+            deltas = [per_view[6 * v + k] for v in range(V) for k in (1, 2, 3)]
+            ctx.n_state = len(state)
+            ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, ints, *state, *deltas)
+            outs = []
+            for v in range(V):
+                outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
+                ctx.mark_non_differentiable(outs[-4], outs[-1])
+            return tuple(outs)
         img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
         ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
         keep = []
@@ -135,6 +167,27 @@ class _RasterizeViewsRaw(torch.autograd.Function):
         pose_only = not any(ctx.needs_input_grad[k] for k in param_idx) and not delta_needed
         if pose_only:
             targets = None
+        glue = _glue()
+        if glue is not None:
+            cot = lambda g_, c: _zero_cotangent(c, H, W, dev) if g_ is None else g_
+            with torch.cuda.device(dev):
+                pg, per_view_out, dl = glue.rasterize_views_backward(
+                    rs0.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest if (f_rest is not None and f_rest.numel()) else None, dyn_slot,
+                    *_camera_lists(settings), [deltas[3 * v] for v in range(V)], [deltas[3 * v + 1] for v in range(V)], [deltas[3 * v + 2] for v in range(V)],
+                    [], [], [], float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, int(rs0.sh_degree), ints, list(state),
+                    ctx.num_rendered, [cot(grads[5 * v], 3) for v in range(V)], [cot(grads[5 * v + 2], 1) for v in range(V)],
+                    [t_.view(-1) for t_ in targets] if targets is not None else [], targets is not None, pose_only, bool(rs0.debug), _C._stream(dev))
+            if targets is not None or pose_only:
+                res = [None] * 8
+            else:
+                res = [pg[0].view(P, 3), pg[4].view(P, S), pg[5].view(P, 4), pg[3].view(logit_opacity.shape), pg[1].view(P, 1, 3),
+                       pg[2].view(P, M - 1, 3) if M > 1 else None, None, None]
+            for v in range(V):
+                th_shape, rho_shape = ctx.pose_shapes[v]
+                tau = per_view_out[v, P * 3:]
+                res += [per_view_out[v, :P * 3].view(P, 3), dl[4 * v], dl[4 * v + 2], dl[4 * v + 3],
+                        _pose_grad(tau[3:], th_shape) if th_shape is not None else None, _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None]
+            return tuple(res)
         keep = []
         desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, dyn_slot, None, None, None, keep)
         widths = [3, 3, 3 * (M - 1), 1, S, 4]
@@ -215,6 +268,21 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
         P, H, W = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width)
         ctx.settings, ctx.V = settings, V
         ctx.set_materialize_grads(False)
+        glue = _glue()
+        if glue is not None:
+            col = lambda k: [per_view[7 * v + k] for v in range(V)]
+            with torch.cuda.device(dev):
+                img, ints, rendered, state = glue.rasterize_views_forward(
+                    rs0.bg, xyz, log_scales, raw_rot, logit_opacity, None, None, dyn_slot, *_camera_lists(settings), col(1), col(3), col(4), col(2), col(5), col(6),
+                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, 0, bool(rs0.debug), _C._stream(dev))
+            ctx.num_rendered = [int(r) for r in rendered]
+            ctx.n_state = len(state)
+            ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, dyn_slot, ints, *state, *[per_view[7 * v + k] for v in range(V) for k in range(1, 7)])
+            outs = []
+            for v in range(V):
+                outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
+                ctx.mark_non_differentiable(outs[-4], outs[-1])
+            return tuple(outs)
         img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
         ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
         keep = []
@@ -268,6 +336,19 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
         dev = xyz.device
         rs0 = settings[0]
         P, H, W, S = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width), int(log_scales.shape[-1])
+        glue = _glue()
+        if glue is not None:
+            col = lambda k: [rest[6 * v + k] for v in range(V)]          # per view: dx1, dx2, ds, dr, proj1, proj2
+            cot = lambda g_, c: _zero_cotangent(c, H, W, dev) if g_ is None else g_
+            with torch.cuda.device(dev):
+                pg, per_view_out, dl = glue.rasterize_views_backward(
+                    rs0.bg, xyz, log_scales, raw_rot, logit_opacity, None, None, dyn_slot, *_camera_lists(settings), col(0), col(2), col(3), col(1), col(4), col(5),
+                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, 0, ints, list(state), ctx.num_rendered,
+                    [cot(grads[5 * v], 3) for v in range(V)], [cot(grads[5 * v + 2], 1) for v in range(V)], [], False, False, bool(rs0.debug), _C._stream(dev))
+            res = [pg[0], None, None, None, None, None]
+            for v in range(V):
+                res += [per_view_out[v, :P * 3].view(P, 3), dl[4 * v], dl[4 * v + 1], dl[4 * v + 2], dl[4 * v + 3], None, None]
+            return tuple(res)
         keep = []
         desc = _describe(xyz, log_scales, raw_rot, logit_opacity, xyz, None, dyn_slot, None, None, None, keep)
         desc.features_dc = None

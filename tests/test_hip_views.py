@@ -202,3 +202,45 @@ def test_flow_views_equal_single_flow_calls(V):
         assert torch.allclose(par["xyz"].grad, ref_grads[0], rtol=1e-5, atol=1e-9), rep
     assert _C.set_option("views_batched") > before                              # the second call took the batched path
     assert float(ref[0][0][:2].detach().abs().max()) > 0 and par["log_scales"].grad is None
+
+
+def test_native_and_ctypes_marshalling_of_the_views_calls_agree_bitwise():
+    """The two calls are marshalled twice: by the native glue (torch_glue.cpp rasterize_views_forward / _backward, the default when the glue
+    is built) and by ctypes in views.py. Same kernels underneath: outputs and every gradient bit for bit, plain views and flow views."""
+    from diff_gaussian_rasterization import _C, views
+    if views._glue() is None:
+        pytest.skip("native glue not built")
+    par, settings, cots, slot, deltas, poses = _scene(P=9000, V=6, W=256, H=192, M=4, seed=3)
+    dev = par["xyz"].device
+    P = par["xyz"].shape[0]
+    K = int((slot >= 0).sum())
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    dx2 = [(torch.randn((K, 3), generator=gen) * 0.02).to(dev).requires_grad_(True) for _ in settings]
+    zero_bg = torch.zeros(3, device=dev)
+    fsettings = [rs._replace(bg=zero_bg, sh_degree=0) for rs in settings]
+    flows = [(deltas[v][0], dx2[v], deltas[v][1], deltas[v][2], fsettings[v].projmatrix, fsettings[(v + 1) % len(settings)].projmatrix) for v in range(len(settings))]
+    leaves = list(par.values()) + [t for d in deltas for t in d] + dx2 + [t for p_ in poses for t in p_]
+
+    def run(native):
+        views._NATIVE_MARSHALLING = native
+        got = []
+        for rep in range(2):                 # (the second round takes the batched path)
+            for t in leaves:
+                t.grad = None
+            outs, m2d = _multi(par, settings, cots, slot, deltas, poses)
+            got = [t for o in outs for t in o] + [m.grad for m in m2d] + [t.grad for t in leaves if t.grad is not None]
+            for t in leaves:
+                t.grad = None
+            pts = [torch.zeros((P, 3), device=dev, requires_grad=True) for _ in settings]
+            fo = views.rasterize_flow_views_raw(fsettings, par["xyz"], pts, par["log_scales"].detach(), par["rot"].detach(), par["logit"].detach(), slot, flows)
+            torch.autograd.backward([o[0] for o in fo], [c[0] for c in cots])
+            got += [t for o in fo for t in o] + [m.grad for m in pts] + [t.grad for t in [par["xyz"]] + [d[0] for d in deltas] + dx2]
+        return got
+
+    try:
+        a, b = run(True), run(False)
+        assert len(a) == len(b) and len(a) > 60
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y)
+    finally:
+        views._NATIVE_MARSHALLING = True
