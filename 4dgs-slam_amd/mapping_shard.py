@@ -259,6 +259,25 @@ class ViewShard:
         self._sum(full)
         return [full[k] for k in range(count)]
 
+    def replicate_gradients(self, params, src=0):
+        """Every rank takes rank `src`'s gradients of `params`. For loops that every rank runs REDUNDANTLY on the same view (the node
+        network's fit at the first dynamic keyframe): torch's index_put / scatter_add backward passes are not run-to-run deterministic,
+        Adam with eps = 1e-15 turns noise-level differences of near-zero gradients into full-size steps, and replicas that stepped on
+        their own copies drift apart (3e-4 on the network's weights over a 15-frame run)."""
+        if not self.active:
+            return
+        have = [p for p in params if p.grad is not None]
+        if not have:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in have])
+        dist.broadcast(flat, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        self.collectives += 1
+        o = 0
+        for p in have:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+
     def sync_cameras(self, cameras):
         """cameras: the iteration's view list (index = ownership index). Owner -> everyone: R, T, exposure_a, exposure_b."""
         if not self.active or not cameras:
