@@ -42,6 +42,12 @@ def _lib():
         lib.gsr_node_blend_workspace_size.argtypes = [i64, ctypes.c_int32]
         lib.gsr_node_blend_backward.restype = i
         lib.gsr_node_blend_backward.argtypes = [ctypes.POINTER(_Blend)] + [vp] * 15
+        lib.gsr_node_blend_forward_batch.restype = i
+        lib.gsr_node_blend_forward_batch.argtypes = [ctypes.POINTER(_Blend), i, vp, vp, vp, vp, vp, vp, vp]
+        lib.gsr_node_blend_workspace_size_batch.restype = ctypes.c_size_t
+        lib.gsr_node_blend_workspace_size_batch.argtypes = [i64, ctypes.c_int32, i]
+        lib.gsr_node_blend_backward_batch.restype = i
+        lib.gsr_node_blend_backward_batch.argtypes = [ctypes.POINTER(_Blend), i] + [vp] * 15
         _lib_cache = lib
     return _lib_cache
 
@@ -185,6 +191,89 @@ class _NodeBlend(torch.autograd.Function):
             _C._err(lib, rc, "gsr_node_blend_backward")
         # inputs: x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation, K, residual, raw
         return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local, None, None, None
+
+
+class _NodeBlendBatch(torch.autograd.Function):
+    """B blends of the same Gaussians and nodes with B sets of node attributes in one launch per stage (gsr_node_blend_*_batch): the
+    views and flow partners of one mapping iteration. Inputs: x [n,3], motion_mask [n] | None, nodes [m,>=3], node_radius [m], node_weight
+    [m] | None, node_trans [B,m,3], node_rot [B,m,4], node_scale [B,m,3], local_rotation [B,m,4] | None. Outputs d_xyz [B,n,3],
+    d_rotation [B,n,4], d_scaling [B,n,3]."""
+
+    @staticmethod
+    def forward(ctx, x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation, K, rot_as_residual, raw):
+        if not 1 <= K <= BLEND_MAX_K:
+            raise ValueError(f"node blend: K = {K} outside 1..{BLEND_MAX_K}")
+        x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius").reshape(-1)
+        n, m, B = x.shape[0], nodes.shape[0], node_trans.shape[0]
+        if x.dim() != 2 or x.shape[1] != 3 or nodes.dim() != 2 or nodes.shape[1] < 3 or node_trans.dim() != 3:
+            raise ValueError(f"node blend batch expects x [N, 3], nodes [M, >=3], node_trans [B, M, 3]; got {tuple(x.shape)}, {tuple(nodes.shape)}, {tuple(node_trans.shape)}")
+        opt = lambda t, name, shape: None if t is None else _checked(_f32(t, name), name, shape)
+        motion_mask = opt(motion_mask, "motion_mask", None)
+        if motion_mask is not None and motion_mask.numel() != n:
+            raise ValueError(f"motion_mask must have one value per Gaussian ({n}), got {tuple(motion_mask.shape)}")
+        node_weight = None if node_weight is None else _f32(node_weight, "node_weight").reshape(-1)
+        if node_radius.numel() != m or (node_weight is not None and node_weight.numel() != m):
+            raise ValueError("node_radius / node_weight must have one value per node")
+        keep = dict(x=x, motion_mask=motion_mask, nodes=nodes, node_radius=node_radius, node_weight=node_weight,
+                    node_trans=opt(node_trans, "node_trans", (B, m, 3)), node_rot=opt(node_rot, "node_rot", (B, m, 4)),
+                    node_scale=opt(node_scale, "node_scale", (B, m, 3)), node_local_rotation=opt(local_rotation, "local_rotation", (B, m, 4)))
+        scalars = dict(n=n, m=m, K=K, local_frame=int(local_rotation is not None), rot_as_residual=int(bool(rot_as_residual)),
+                       node_stride=nodes.shape[1], flags=(RADIUS_IS_LOG | WEIGHT_IS_LOGIT) if raw else 0)
+        a = _Blend(**scalars)
+        for k, t in keep.items():
+            setattr(a, k, t.data_ptr() if t is not None else None)
+        dev = x.device
+        w = torch.empty((n, K), dtype=torch.float32, device=dev)
+        dist = torch.empty((n, K), dtype=torch.float32, device=dev)
+        idx = torch.empty((n, K), dtype=torch.int64, device=dev)
+        outs = [torch.empty((B, n, c), dtype=torch.float32, device=dev) for c in (3, 4, 3)]
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_forward_batch(ctypes.byref(a), B, w.data_ptr(), dist.data_ptr(), idx.data_ptr(), *(o.data_ptr() for o in outs), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_forward_batch")
+        ctx.keep, ctx.scalars, ctx.saved, ctx.B = keep, scalars, (w, dist, idx), B
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_scale):
+        keep, sc, B = ctx.keep, ctx.scalars, ctx.B
+        n, m = sc["n"], sc["m"]
+        w, dist, idx = ctx.saved
+        dev = w.device
+        a = _Blend(**sc)
+        for k, t in keep.items():
+            setattr(a, k, t.data_ptr() if t is not None else None)
+        cot = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_xyz, g_rot, g_scale = cot(g_xyz), cot(g_rot), cot(g_scale)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_radius = new(B, m)
+        g_weight = new(B, m) if keep["node_weight"] is not None else None
+        g_trans, g_nrot, g_nscale = new(B, m, 3), new(B, m, 4), new(B, m, 3)
+        g_local = new(B, m, 4) if keep["node_local_rotation"] is not None else None
+        lib = _lib()
+        ws = torch.empty((lib.gsr_node_blend_workspace_size_batch(n, m, B),), dtype=torch.uint8, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_backward_batch(ctypes.byref(a), B, w.data_ptr(), dist.data_ptr(), idx.data_ptr(), p(g_xyz), p(g_rot), p(g_scale), None,
+                                                   p(g_trans), p(g_nrot), p(g_nscale), p(g_local), p(g_radius), p(g_weight), ws.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_backward_batch")
+        # radius / weight are shared by the B blends: their gradient is the sum of the rows
+        g_radius = g_radius.sum(0).view(ctx.keep["node_radius"].shape)
+        g_weight = None if g_weight is None else g_weight.sum(0)
+        # inputs: x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation, K, residual, raw
+        return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local, None, None, None
+
+
+def node_blend_batch(x, motion_mask, nodes, node_radius, node_weight, node_trans, node_rot, node_scale, local_rotation=None, K: int = 3,
+                     d_rot_as_res: bool = True, raw: bool = True):
+    """node_blend for B sets of node attributes at once: node_trans [B, M, 3], node_rot [B, M, 4], node_scale [B, M, 3], local_rotation
+    [B, M, 4] | None -> (d_xyz [B, N, 3], d_rotation [B, N, 4], d_scaling [B, N, 3]). Values and gradients are those of B node_blend calls
+    (the radius / weight gradients are their sum)."""
+    return _NodeBlendBatch.apply(x, motion_mask, nodes, node_radius.reshape(-1), _flat(node_weight), node_trans, node_rot, node_scale, local_rotation,
+                                 K, d_rot_as_res, raw)
 
 
 def _checked(t, name, shape):

@@ -1546,12 +1546,19 @@ static int node_blend_check(const gsr_node_blend* a, const char* who)
 int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_dist, int64_t* nn_idx, float* d_xyz, float* d_rotation,
                            float* d_scaling, void* stream_)
 {
+    return gsr_node_blend_forward_batch(a, 1, nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling, stream_);
+}
+
+int gsr_node_blend_forward_batch(const gsr_node_blend* a, int B, float* nn_weight, float* nn_dist, int64_t* nn_idx, float* d_xyz, float* d_rotation,
+                                 float* d_scaling, void* stream_)
+{
     if (int rc = node_blend_check(a, "gsr_node_blend_forward")) return rc;
+    if (B < 1 || B > 65535 || (B > 1 && !a->node_trans)) { g_last_error = "gsr_node_blend_forward_batch: 1 <= B <= 65535, B > 1 needs node attributes"; return GSR_ERR_INVALID_ARGUMENT; }
     if (a->n == 0) return 0;
     if (!nn_weight || !nn_dist || !nn_idx || (a->node_trans && (!d_xyz || !d_rotation || !d_scaling))) {
         g_last_error = "gsr_node_blend_forward: null output"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    const dim3 grid((unsigned)((a->n + NODE_BLOCK - 1) / NODE_BLOCK)), block(NODE_BLOCK);
+    const dim3 grid((unsigned)((a->n + NODE_BLOCK - 1) / NODE_BLOCK), (unsigned)B), block(NODE_BLOCK);
 #define GSR_BLEND_FWD(KMAX, EXACT) hipLaunchKernelGGL((node_blend_fwd_kernel<KMAX, EXACT>), grid, block, 0, (hipStream_t)stream_, *a, nn_weight, nn_dist, nn_idx, d_xyz, d_rotation, d_scaling)
     switch (a->K) {
     case 1: GSR_BLEND_FWD(1, true); break;
@@ -1567,11 +1574,22 @@ int gsr_node_blend_forward(const gsr_node_blend* a, float* nn_weight, float* nn_
 
 static int node_bwd_blocks(int64_t n) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, (n + NODE_BLOCK - 1) / NODE_BLOCK)); }
 
+static size_t node_ws_floats(int64_t n, int32_t m)      // per batch element: block partials + the summed row, a multiple of 64 floats
+{
+    const size_t rows = m <= NODE_LDS_MAX ? (size_t)node_bwd_blocks(n) : 1;
+    return (((rows + 1) * (size_t)m * NODE_GRAD) + 63) & ~size_t(63);
+}
+
 size_t gsr_node_blend_workspace_size(int64_t n, int32_t m)
 {
     if (m < 1) return 256;
-    const size_t rows = m <= NODE_LDS_MAX ? (size_t)node_bwd_blocks(n) : 1;
-    return (rows + 1) * (size_t)m * NODE_GRAD * sizeof(float) + 256;   // block partials + the summed row
+    return node_ws_floats(n, m) * sizeof(float) + 256;
+}
+
+size_t gsr_node_blend_workspace_size_batch(int64_t n, int32_t m, int B)
+{
+    if (m < 1 || B < 1) return 256;
+    return (size_t)B * node_ws_floats(n, m) * sizeof(float) + 256;
 }
 
 int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
@@ -1579,23 +1597,38 @@ int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, con
                             float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
                             float* g_node_weight, char* workspace, void* stream_)
 {
+    return gsr_node_blend_backward_batch(a, 1, nn_weight, nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, g_node_trans, g_node_rot, g_node_scale,
+                                         g_node_frame, g_node_radius, g_node_weight, workspace, stream_);
+}
+
+int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
+                                  const float* g_xyz, const float* g_rotation, const float* g_scaling, const float* g_nn_weight,
+                                  float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
+                                  float* g_node_weight, char* workspace, void* stream_)
+{
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = node_blend_check(a, "gsr_node_blend_backward")) return rc;
+    if (B < 1 || B > 65535 || (B > 1 && (g_nn_weight || !a->node_trans))) {
+        g_last_error = "gsr_node_blend_backward_batch: 1 <= B <= 65535; B > 1 needs node attributes and takes no direct cotangent of nn_weight"; return GSR_ERR_INVALID_ARGUMENT;
+    }
     if (!workspace || (a->n > 0 && (!nn_weight || !nn_dist || !nn_idx))) { g_last_error = "gsr_node_blend_backward: null workspace / saved tensors"; return GSR_ERR_INVALID_ARGUMENT; }
-    float* partial = reinterpret_cast<float*>(workspace);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
     const int total = a->m * NODE_GRAD;
     const bool use_lds = a->m <= NODE_LDS_MAX;
     const int G = use_lds ? node_bwd_blocks(a->n) : 1;
-    if (!use_lds || a->n == 0) GSR_HIP_CHECK(hipMemsetAsync(partial, 0, (size_t)total * sizeof(float), stream));
+    const size_t stride = node_ws_floats(a->n, a->m);
+    if (!use_lds || a->n == 0) {
+        for (int b = 0; b < B; b++) GSR_HIP_CHECK(hipMemsetAsync(partial + (size_t)b * stride, 0, (size_t)total * sizeof(float), stream));
+    }
     if (a->n > 0) {
         const int blocks = node_bwd_blocks(a->n);
-        hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
-                           nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0);
+        hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks, (unsigned)B), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
+                           nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0, stride);
     }
     float* summed = partial + (size_t)G * total;
-    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, G, total, (const float*)partial, summed);
-    hipLaunchKernelGGL(node_grad_finalize_kernel, dim3((a->m + 255) / 256), dim3(256), 0, stream, *a, (const float*)summed, g_node_trans, g_node_rot,
-                       g_node_scale, g_node_frame, g_node_radius, g_node_weight);
+    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256, (unsigned)B), dim3(256), 0, stream, G, total, (const float*)partial, summed, stride);
+    hipLaunchKernelGGL(node_grad_finalize_kernel, dim3((a->m + 255) / 256, (unsigned)B), dim3(256), 0, stream, *a, (const float*)summed, g_node_trans, g_node_rot,
+                       g_node_scale, g_node_frame, g_node_radius, g_node_weight, stride);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -284,13 +284,29 @@ __device__ __forceinline__ float node_weight_of(const gsr_node_blend& a, int j)
     return (a.flags & GSR_NODE_WEIGHT_IS_LOGIT) ? 1.f / (1.f + expf(-v)) : v;
 }
 
+// Batched blends (gsr_node_blend_*_batch): blockIdx.y selects one of B sets of node attributes [B, m, .] -- the time samples of one
+// mapping iteration, same Gaussians, same nodes. With gridDim.y = 1 this is the plain call.
+__device__ __forceinline__ gsr_node_blend batch_element(gsr_node_blend a, int b)
+{
+    const size_t m = (size_t)a.m;
+    if (a.node_trans) a.node_trans += (size_t)b * m * 3;
+    if (a.node_rot) a.node_rot += (size_t)b * m * 4;
+    if (a.node_scale) a.node_scale += (size_t)b * m * 3;
+    if (a.node_frame) a.node_frame += (size_t)b * m * 9;
+    if (a.node_local_rotation) a.node_local_rotation += (size_t)b * m * 4;
+    return a;
+}
+
 // ---- cal_nn_weight + blend ------------------------------------------------------------------------------------------------------
 template <int KMAX, bool EXACT>
 __global__ void __launch_bounds__(NODE_BLOCK)
-node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, float* __restrict__ nn_dist, int64_t* __restrict__ nn_idx,
+node_blend_fwd_kernel(const gsr_node_blend a_, float* __restrict__ nn_weight, float* __restrict__ nn_dist, int64_t* __restrict__ nn_idx,
                       float* __restrict__ d_xyz, float* __restrict__ d_rotation, float* __restrict__ d_scaling)
 {
     __shared__ float4 s_pos4[NODE_CHUNK4];
+    const gsr_node_blend a = batch_element(a_, (int)blockIdx.y);
+    const bool first = blockIdx.y == 0;                  // the neighbours and weights are the same for every batch element: written once
+    if (d_xyz) { d_xyz += (size_t)blockIdx.y * a.n * 3; d_rotation += (size_t)blockIdx.y * a.n * 4; d_scaling += (size_t)blockIdx.y * a.n * 3; }
     const int64_t i = (int64_t)blockIdx.x * NODE_BLOCK + threadIdx.x;
     const int K = a.K;
     float x[4] = {0.f, 0.f, 0.f, 0.f};
@@ -328,9 +344,11 @@ node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, flo
     for (int k = 0; k < KMAX; k++) {
         if (k < K) {
             w[k] *= invS;
-            nn_weight[i * K + k] = w[k];
-            nn_dist[i * K + k] = bd[k];
-            nn_idx[i * K + k] = bi[k];
+            if (first) {
+                nn_weight[i * K + k] = w[k];
+                nn_dist[i * K + k] = bd[k];
+                nn_idx[i * K + k] = bi[k];
+            }
         }
     }
     if (!a.node_trans) return;
@@ -374,12 +392,18 @@ node_blend_fwd_kernel(const gsr_node_blend a, float* __restrict__ nn_weight, flo
 
 // partial: [gridDim.x][m * NODE_GRAD]; use_lds = 0: every block adds into row 0 with global atomics (caller zeroed it)
 __global__ void __launch_bounds__(NODE_BLOCK)
-node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weight, const float* __restrict__ nn_dist,
+node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weight, const float* __restrict__ nn_dist,
                       const int64_t* __restrict__ nn_idx, const float* __restrict__ g_xyz, const float* __restrict__ g_rotation,
-                      const float* __restrict__ g_scaling, const float* __restrict__ g_nn_weight, float* __restrict__ partial, const int use_lds)
+                      const float* __restrict__ g_scaling, const float* __restrict__ g_nn_weight, float* __restrict__ partial, const int use_lds,
+                      const size_t batch_stride /* floats of workspace per batch element */)
 {
     constexpr int KMAX = GSR_BLEND_MAX_K;
     extern __shared__ float s_acc[];                              // [m][NODE_GRAD] when use_lds
+    const gsr_node_blend a = batch_element(a_, (int)blockIdx.y);
+    if (g_xyz) g_xyz += (size_t)blockIdx.y * a.n * 3;
+    if (g_rotation) g_rotation += (size_t)blockIdx.y * a.n * 4;
+    if (g_scaling) g_scaling += (size_t)blockIdx.y * a.n * 3;
+    partial += (size_t)blockIdx.y * batch_stride;
     const int K = a.K;
     const int total = a.m * NODE_GRAD;
     if (use_lds) {
@@ -477,10 +501,12 @@ node_blend_bwd_kernel(const gsr_node_blend a, const float* __restrict__ nn_weigh
 
 // summed[e] = sum over the G partial rows of element e (node j, component c = e % 21), fixed order
 __global__ void __launch_bounds__(256)
-node_grad_reduce_kernel(const int G, const int total, const float* __restrict__ partial, float* __restrict__ summed)
+node_grad_reduce_kernel(const int G, const int total, const float* __restrict__ partial, float* __restrict__ summed, const size_t batch_stride)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
+    partial += (size_t)blockIdx.y * batch_stride;
+    summed += (size_t)blockIdx.y * batch_stride;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = 0;
     for (; b + 3 < G; b += 4) {
@@ -495,11 +521,23 @@ node_grad_reduce_kernel(const int G, const int total, const float* __restrict__ 
 
 // one thread per node: hand the 21 sums out, through the chain rules of the per-node activations where the inputs were raw
 __global__ void __launch_bounds__(256)
-node_grad_finalize_kernel(const gsr_node_blend a, const float* __restrict__ summed, float* __restrict__ g_trans, float* __restrict__ g_rot,
-                          float* __restrict__ g_scale, float* __restrict__ g_frame, float* __restrict__ g_radius, float* __restrict__ g_weight)
+node_grad_finalize_kernel(const gsr_node_blend a_, const float* __restrict__ summed, float* __restrict__ g_trans, float* __restrict__ g_rot,
+                          float* __restrict__ g_scale, float* __restrict__ g_frame, float* __restrict__ g_radius, float* __restrict__ g_weight,
+                          const size_t batch_stride)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    const gsr_node_blend a = batch_element(a_, (int)blockIdx.y);
     if (j >= a.m) return;
+    {   // every output is [B, m, .]: radius / weight gradients per batch element too (the caller sums them over B)
+        const size_t b = blockIdx.y, m = (size_t)a.m;
+        summed += b * batch_stride;
+        if (g_trans) g_trans += b * m * 3;
+        if (g_rot) g_rot += b * m * 4;
+        if (g_scale) g_scale += b * m * 3;
+        if (g_frame) g_frame += b * m * (a.node_local_rotation ? 4 : 9);
+        if (g_radius) g_radius += b * m;
+        if (g_weight) g_weight += b * m;
+    }
     const float* s = summed + (size_t)j * NODE_GRAD;
     if (g_trans) { g_trans[3 * j] = s[0]; g_trans[3 * j + 1] = s[1]; g_trans[3 * j + 2] = s[2]; }
     if (g_rot) { g_rot[4 * j] = s[3]; g_rot[4 * j + 1] = s[4]; g_rot[4 * j + 2] = s[5]; g_rot[4 * j + 3] = s[6]; }

@@ -360,7 +360,7 @@ class BackEnd:
                     closest = self.find_closest_keyframe(viewpoint.uid) if (with_flow and shard.owns(k)) else None
                     if closest is not None:
                         times.append(self.viewpoints[closest].time)
-                nodes.begin_iteration(times, positions_only=sample_times)
+                nodes.begin_iteration(times, positions_only=sample_times, blend=(g.get_dygs_xyz.detach(), g.motion_mask))
                 self._delta_cache = {}
                 # the two regularisers for all views at once (per view: 1e-3 in the window, 1e-4 for the random keyframes)
                 nv = len(views)

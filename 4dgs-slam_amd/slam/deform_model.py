@@ -193,6 +193,7 @@ class ControlNodes(nn.Module):
         self.reg_loss = 0.0
         self.inited = False
         self._batch = None            # {time_key: network outputs [M, .]} of the current iteration (begin_iteration)
+        self._blended = None          # the Gaussians' deltas at the iteration's full samples, from one batched blend (begin_iteration(blend=...))
         self._graph = None
 
     node_num = property(lambda s: s.nodes.shape[0])
@@ -242,10 +243,12 @@ class ControlNodes(nn.Module):
     # A dynamic mapping iteration (utils/slam_backend.py:336-771) asks the node network for 4-6 time samples per view (the view's
     # deltas, its flow partner's, the ARAP / elastic samples around it): ~60 evaluations of a 512-row MLP, ~40 launches each, plus
     # their backward. The nodes and weights only change at optimizer.step(), so all samples of an iteration are ONE batch.
-    def begin_iteration(self, times, positions_only=()):
+    def begin_iteration(self, times, positions_only=(), blend=None):
         """`times`: samples whose every head is needed (a view's deltas, its flow partner's); `positions_only`: samples of which only the
         node positions are read (the ARAP / elastic regularisers) -- the trunk runs on all of them, the translation head too, the rotation /
-        scaling / local-frame heads on the first group only."""
+        scaling / local-frame heads on the first group only. `blend` = (x, motion_mask): also warp these Gaussians at every sample of the
+        first group, all in ONE blend launch each way (control_nodes.node_blend_batch) instead of one per view and flow partner; forward()
+        then serves those samples from the batch."""
         full = sorted({time_key(t) for t in times})
         rest = sorted({time_key(t) for t in positions_only} - set(full))
         keys = full + rest
@@ -261,16 +264,28 @@ class ControlNodes(nn.Module):
         # unbind, not out[i]: one backward node per head (a stack of the slices' gradients) instead of one per slice, each of which would
         # zero-fill and accumulate a buffer of the whole batch (~250 launches per iteration at 90 time samples)
         self._batch = {key: {} for key in keys}
-        for i, row in enumerate(net.gaussian_warp(h).reshape(len(keys), M, 3).unbind(0)):
+        self._blended = None
+        d_xyz_all = net.gaussian_warp(h).reshape(len(keys), M, 3)
+        for i, row in enumerate(d_xyz_all.unbind(0)):
             self._batch[keys[i]]["d_xyz"] = row
         if full:
             hf = h[:len(full) * M]
             heads = {"d_rotation": net.gaussian_rotation, "d_scaling": net.gaussian_scaling}
             if net.local_frame:
                 heads["local_rotation"] = net.local_rotation
-            for name, head in heads.items():
-                for i, row in enumerate(head(hf).reshape(len(full), M, -1).unbind(0)):
+            stacked = {name: head(hf).reshape(len(full), M, -1) for name, head in heads.items()}
+            for name, t in stacked.items():
+                for i, row in enumerate(t.unbind(0)):
                     self._batch[full[i]][name] = row
+            if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
+                x, motion_mask = blend
+                out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, d_xyz_all[:len(full)],
+                                                     stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
+                                                     K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
+                rows = [t.unbind(0) for t in out]
+                self._blended = {"n": int(x.shape[0]), "masked": motion_mask is not None,
+                                 "rows": {key: {"d_xyz": rows[0][i], "d_rotation": rows[1][i], "d_scaling": rows[2][i], "d_opacity": None, "d_color": None}
+                                          for i, key in enumerate(full)}}
         self._graph = None
 
     def _upload(self, values):
@@ -298,6 +313,7 @@ class ControlNodes(nn.Module):
     def end_iteration(self):
         self._batch = None
         self._graph = None
+        self._blended = None
 
     def node_deform(self, t, key=None):
         """:1038-1051: per-node translation / rotation / scale (/ local rotation) at time t [M,1] (key: the host-side value of t, see
@@ -309,6 +325,13 @@ class ControlNodes(nn.Module):
 
     def forward(self, x, t, motion_mask=None, t_key=None, **_):
         """:1192-1258."""
+        b = self._blended
+        # (between begin_iteration and end_iteration neither the Gaussians nor the nodes move -- the caller's contract, as for the batched
+        # network evaluation: the positions are the ones begin_iteration(blend=...) was given; only their count is checked)
+        if b is not None and t_key is not None and b["n"] == int(x.shape[0]) and b["masked"] == (motion_mask is not None):
+            hit = b["rows"].get(time_key(t_key))
+            if hit is not None:                               # warped with the iteration's other samples in one launch (begin_iteration)
+                return hit
         na = self.node_deform(t, t_key)
         out = control_nodes.node_blend(x, motion_mask, self.nodes, self._node_radius, self._node_weight, na["d_xyz"], na["d_rotation"],
                                        na["d_scaling"], na.get("local_rotation") if self.local_frame else None, K=min(self.K, self.node_num),

@@ -74,6 +74,20 @@ int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, con
                             float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
                             float* g_node_weight, char* workspace, void* stream);
 
+/* B blends of the SAME Gaussians and nodes with B sets of node attributes -- the time samples of one mapping iteration
+ * (utils/slam_backend.py:361-373 calls the warp once per view and flow partner) -- in one launch per stage. node_trans / node_rot /
+ * node_scale / node_local_rotation (or node_frame) of the descriptor hold [B, m, .]; d_xyz [B, n, 3], d_rotation [B, n, 4], d_scaling
+ * [B, n, 3]; nn_weight / nn_dist / nn_idx are those of a single blend (they do not depend on the attributes). Backward: cotangents
+ * [B, n, .] (g_nn_weight must be NULL for B > 1), node gradients [B, m, .] including g_node_radius / g_node_weight [B, m] -- the
+ * radius and weight are shared by the B blends, the caller sums their rows. B = 1 is gsr_node_blend_forward / _backward. */
+int gsr_node_blend_forward_batch(const gsr_node_blend* a, int B, float* nn_weight, float* nn_dist, int64_t* nn_idx, float* d_xyz, float* d_rotation,
+                                 float* d_scaling, void* stream);
+size_t gsr_node_blend_workspace_size_batch(int64_t n, int32_t m, int B);
+int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
+                                  const float* g_xyz, const float* g_rotation, const float* g_scaling, const float* g_nn_weight,
+                                  float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
+                                  float* g_node_weight, char* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

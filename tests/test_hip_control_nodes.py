@@ -174,3 +174,39 @@ def test_edge_cases_and_errors():
         cn.knn_points(d["x"][None], d["nodes"][None], torch.tensor([5]), None, K=3)
     with pytest.raises(Exception, match="HIP device|no CPU"):
         cn.knn_points(d["x"][None].cpu(), d["nodes"][None].cpu(), K=3)
+
+
+@pytest.mark.parametrize("B,n,m,local_frame,with_weight,with_mask", [(12, 2500, 512, True, True, True), (3, 700, 900, False, False, False), (1, 300, 64, True, True, False)])
+def test_node_blend_batch_equals_one_blend_per_sample(B, n, m, local_frame, with_weight, with_mask):
+    """gsr_node_blend_forward_batch / _backward_batch: B sets of node attributes (the time samples of one mapping iteration) blended onto
+    the same Gaussians in one launch per stage. Outputs are those of B node_blend calls bit for bit, the per-sample node
+    gradients to rounding (the blocks accumulate with LDS float atomics), the radius / weight gradients are the sum of the B calls'."""
+    g = torch.Generator(device="cpu").manual_seed(B * n + m)
+    R = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)
+    x, nodes = R(n, 3), R(m, 3)
+    radius = (R(m, sc=0.2) - 1.0).requires_grad_(True)
+    weight = R(m, 1, sc=0.5).requires_grad_(True) if with_weight else None
+    mask = (torch.rand(n, 1, generator=g) > 0.2).float().to(DEV) if with_mask else None
+    attrs = [R(B, m, 3, sc=0.05).requires_grad_(True), R(B, m, 4, sc=0.05).requires_grad_(True), R(B, m, 3, sc=0.01).requires_grad_(True)]
+    local = R(B, m, 4, sc=0.1).requires_grad_(True) if local_frame else None
+    cots = [R(B, n, 3), R(B, n, 4), R(B, n, 3)]
+    leaves = [radius] + ([weight] if with_weight else []) + attrs + ([local] if local_frame else [])
+
+    out = cn.node_blend_batch(x, mask, nodes, radius, weight, attrs[0], attrs[1], attrs[2], local, K=3, d_rot_as_res=True, raw=True)
+    torch.autograd.backward(list(out), cots)
+    got = [t.detach().clone() for t in out] + [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    singles = []
+    for b in range(B):
+        r = cn.node_blend(x, mask, nodes, radius, weight, attrs[0][b], attrs[1][b], attrs[2][b], None if local is None else local[b], K=3, d_rot_as_res=True, raw=True)
+        torch.autograd.backward([r["d_xyz"], r["d_rotation"], r["d_scaling"]], [c[b] for c in cots])
+        singles.append(r)
+    for k, name in enumerate(("d_xyz", "d_rotation", "d_scaling")):
+        assert torch.equal(got[k], torch.stack([s_[name] for s_ in singles]))
+    want = [t.grad for t in leaves]
+    n_shared = 1 + int(with_weight)
+    for a, b_ in zip(got[3:3 + n_shared], want[:n_shared]):          # radius / weight: summed over the samples (another association)
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-7)
+    for a, b_ in zip(got[3 + n_shared:], want[n_shared:]):           # per-sample node gradients (LDS float atomics inside a block: order-dependent rounding)
+        assert a.shape == b_.shape and torch.allclose(a, b_, rtol=1e-4, atol=1e-6)
