@@ -105,6 +105,12 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     blend = control_nodes._Blend(n=4, m=8, K=9, node_stride=3)
     assert cl.gsr_node_blend_backward(ctypes.byref(blend), *([None] * 15)) == -1 and b"K outside" in lib.gsr_last_error()
     assert cl.gsr_node_blend_workspace_size(100000, 512) >= 512 * 21 * 4 * 2
+    # the batched forms: B sets of node attributes per call
+    blend = control_nodes._Blend(n=4, m=8, K=3, node_stride=3, x=4096, nodes=4096, node_radius=4096)      # (never dereferenced: the calls return at the batch checks)
+    assert cl.gsr_node_blend_forward_batch(ctypes.byref(blend), 0, *([None] * 7)) == -1 and b"1 <= B" in lib.gsr_last_error()
+    assert cl.gsr_node_blend_forward_batch(ctypes.byref(blend), 3, *([None] * 7)) == -1 and b"needs node attributes" in lib.gsr_last_error()
+    assert cl.gsr_node_blend_backward_batch(ctypes.byref(blend), 2, *([None] * 15)) == -1 and b"gsr_node_blend_backward_batch" in lib.gsr_last_error()
+    assert cl.gsr_node_blend_workspace_size_batch(1000, 512, 12) >= 12 * (cl.gsr_node_blend_workspace_size(1000, 512) - 256)
 
 
 def test_public_names_and_settings_fields_match_reference():
