@@ -142,6 +142,13 @@ static thread_local bool t_speculate = true;
 // of that frame exit at once (outputs / gradients of THAT call are undefined) and the sticky overflow counter in the mailbox is
 // bumped: a caller that uses lazy mode polls gsr_forward_status() at a convenient point and repeats the affected work eagerly.
 static thread_local bool t_lazy = false;
+static thread_local int t_cap_margin_permille = 125;   // head room of a speculative binning buffer over the last frame's count (gsr_set_option)
+static thread_local int t_cap_test_shrink_permille = 0; // TEST facility: > 0 lays speculative buffers out for that fraction of the last count (forces overflows)
+static inline size_t spec_capacity(size_t last)
+{
+    if (t_cap_test_shrink_permille > 0) return (size_t)((unsigned long long)last * (unsigned)t_cap_test_shrink_permille / 1000ull) + 1;
+    return last + (size_t)((unsigned long long)last * (unsigned)t_cap_margin_permille / 1000ull) + 4096;
+}
 static thread_local bool t_options_read = false;
 static thread_local unsigned t_views_batched = 0;
 static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] != '0' : true;   // sort short tile lists inside render_fwd
@@ -215,8 +222,18 @@ int gsr_set_option(const char* name, int value)
     if (!name) { g_last_error = "gsr_set_option: null name"; return GSR_ERR_INVALID_ARGUMENT; }
     const std::string n(name);
     if (n == "views_batched") return (int)t_views_batched;     // read-only: multi-view calls of this thread that took the one-launch-per-stage path
+    if (n == "cap_margin_permille") {
+        const int old_margin = t_cap_margin_permille;
+        if (value >= 0) t_cap_margin_permille = value > 4000 ? 4000 : value;
+        return old_margin;
+    }
+    if (n == "cap_test_shrink_permille") {
+        const int old_shrink = t_cap_test_shrink_permille;
+        if (value >= 0) t_cap_test_shrink_permille = value > 1000 ? 1000 : value;
+        return old_shrink;
+    }
     bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
-    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox)"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;
@@ -227,6 +244,17 @@ int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rend
     select_device_state();
     if (overflow_count) *overflow_count = t_mailbox ? __atomic_load_n(&t_mailbox[5], __ATOMIC_ACQUIRE) : 0u;
     if (last_num_rendered) *last_num_rendered = t_mailbox ? __atomic_load_n(&t_mailbox[0], __ATOMIC_ACQUIRE) : 0u;
+    return 0;
+}
+
+int gsr_forward_status_views(unsigned int* overflow_count_total)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    unsigned int total = 0;
+    for (int slot = 0; slot < 2 * MAX_VIEWS + 1; slot++)
+        if (const uint32_t* mb = t_spec[dev][slot].mailbox) total += __atomic_load_n(&mb[5], __ATOMIC_ACQUIRE);
+    if (overflow_count_total) *overflow_count_total = total;
     return 0;
 }
 
@@ -383,9 +411,9 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         }
     }
     const bool speculate = t_speculate && t_last_R_alloc && !debug && P > 0;
-    const size_t cap = speculate ? t_last_R_alloc + t_last_R_alloc / 8 + 4096 : 0;
+    const size_t cap = speculate ? spec_capacity(t_last_R_alloc) : 0;
     // longest tile list the speculative launches are sized for: decides which sort kernels run (and the chunk grid of the long-list sort)
-    const uint32_t want_tile = t_last_max_tile + t_last_max_tile / 4;
+    const uint32_t want_tile = t_last_max_tile + (uint32_t)((unsigned long long)t_last_max_tile * (unsigned)std::max(250, t_cap_margin_permille) / 1000ull);
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
@@ -599,7 +627,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     memset(&t, 0, sizeof(t));
     uint32_t want_tile = 0;
     for (int v = 0; v < V; v++) want_tile = std::max(want_tile, t_spec[dev][slot0 + v].last_max_tile);
-    want_tile += want_tile / 4;
+    want_tile += (uint32_t)((unsigned long long)want_tile * (unsigned)std::max(250, t_cap_margin_permille) / 1000ull);
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
@@ -609,7 +637,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
         select_device_state(slot0 + v);
         { const int rc = ensure_mailbox(); if (rc) return rc; }
         if (++t_seq == 0) t_seq = 1;
-        const size_t cap = t_last_R_alloc + t_last_R_alloc / 8 + 4096;
+        const size_t cap = spec_capacity(t_last_R_alloc);
         w.geom_buffer = geometry_alloc(w.geometry_user, gsr_geometry_buffer_size(P));
         w.image_buffer = image_alloc(w.image_user, gsr_image_buffer_size(width, height, P));
         w.binning_buffer = binning_alloc(w.binning_user, binning_bytes(cap, cap, (size_t)d.T));
@@ -1146,21 +1174,29 @@ int gsr_masked_l1_backward(int n_terms, const gsr_masked_l1_term* terms, int wid
 }
 
 // ---- fused Adam (include/slam_losses.h) ---------------------------------------------------------------------------
-int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream_)
+void gsr_adam_coefficients(double lr, double beta1, double beta2, int step, float out[2])
+{
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    out[0] = (float)(lr / bc1); out[1] = (float)(1.0 / sqrt(bc2));
+}
+
+static int adam_step_impl(int nseg, const gsr_adam_segment* segs, const float* coefficients, bool scheduled, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (nseg < 0 || nseg > ADAM_MAX_SEGMENTS || (nseg > 0 && !segs)) { g_last_error = "gsr_adam_step: 0..8 segments"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (scheduled && nseg > 0 && !coefficients) { g_last_error = "gsr_adam_step_scheduled: null coefficients"; return GSR_ERR_INVALID_ARGUMENT; }
     AdamArgs a;
-    a.nseg = nseg; a.total = 0;
+    a.nseg = nseg; a.total = 0; a.coef = scheduled ? coefficients : nullptr;
     for (int k = 0; k < nseg; k++) {
         const gsr_adam_segment& h = segs[k];
         if (h.n && (!h.param || !h.grad || !h.exp_avg || !h.exp_avg_sq)) { g_last_error = "gsr_adam_step: null pointer"; return GSR_ERR_INVALID_ARGUMENT; }
-        if (h.step < 1) { g_last_error = "gsr_adam_step: step counts from 1"; return GSR_ERR_INVALID_ARGUMENT; }
+        if (!scheduled && h.step < 1) { g_last_error = "gsr_adam_step: step counts from 1"; return GSR_ERR_INVALID_ARGUMENT; }
         a.start[k] = a.total;
         AdamSegment& d = a.seg[k];
         d.param = h.param; d.grad = h.grad; d.exp_avg = h.exp_avg; d.exp_avg_sq = h.exp_avg_sq; d.n = h.n;
-        const double bc1 = 1.0 - pow(h.beta1_d, (double)h.step), bc2 = 1.0 - pow(h.beta2_d, (double)h.step);
-        d.step_size = (float)((double)h.lr / bc1); d.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); d.eps = h.eps; d.beta2 = h.beta2;
+        float c[2] = {0.f, 0.f};
+        if (!scheduled) gsr_adam_coefficients((double)h.lr, h.beta1_d, h.beta2_d, h.step, c);
+        d.step_size = c[0]; d.inv_bc2_sqrt = c[1]; d.eps = h.eps; d.beta2 = h.beta2;
         d.one_minus_beta1 = (float)(1.0 - h.beta1_d); d.one_minus_beta2 = (float)(1.0 - h.beta2_d);
         a.total += h.n;
     }
@@ -1170,6 +1206,11 @@ int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream_)
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
+}
+int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream) { return adam_step_impl(nseg, segs, nullptr, false, stream); }
+int gsr_adam_step_scheduled(int nseg, const gsr_adam_segment* segs, const float* coefficients, void* stream)
+{
+    return adam_step_impl(nseg, segs, coefficients, true, stream);
 }
 
 
@@ -1710,7 +1751,7 @@ int gsr_densify_apply(int P, const int* flags, const int* offsets, int n_keep, i
     return 0;
 }
 
-int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
+static int camera_step_args(const gsr_camera_step* s, CameraStepArgs& a)
 {
     if (!s || !s->R || !s->T || !s->viewmatrix || (s->full_proj && !s->projmatrix)) { g_last_error = "gsr_camera_step_launch: null pose / output"; return GSR_ERR_INVALID_ARGUMENT; }
     const bool any_grad = s->g_rot_delta || s->g_trans_delta || s->g_exposure_a || s->g_exposure_b;
@@ -1719,7 +1760,6 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
         (s->do_pose && (!s->rot_delta || !s->trans_delta))) {
         g_last_error = "gsr_camera_step_launch: gradient / pose step without its parameter"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    CameraStepArgs a;
     a.p[0] = s->rot_delta; a.g[0] = s->g_rot_delta; a.n[0] = 3; a.lr[0] = s->lr_rot;
     a.p[1] = s->trans_delta; a.g[1] = s->g_trans_delta; a.n[1] = 3; a.lr[1] = s->lr_trans;
     a.p[2] = s->exposure_a; a.g[2] = s->g_exposure_a; a.n[2] = 1; a.lr[2] = s->lr_exposure;
@@ -1727,7 +1767,53 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
     a.exp_avg = s->exp_avg; a.exp_avg_sq = s->exp_avg_sq; a.step = s->step; a.beta1 = s->beta1; a.beta2 = s->beta2; a.eps = s->eps;
     a.R = s->R; a.T = s->T; a.proj = s->projmatrix; a.view = s->viewmatrix; a.full = s->full_proj; a.campos = s->campos;
     a.converged = s->converged; a.thr = s->converged_threshold; a.do_pose = s->do_pose; a.latch = s->latch;
+    return 0;
+}
+
+int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
+{
+    CameraStepArgs a;
+    { const int rc = camera_step_args(s, a); if (rc) return rc; }
     hipLaunchKernelGGL(camera_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_camera_steps_launch(int n, const gsr_camera_step* steps, void* stream_)
+{
+    if (n < 0 || n > CAMERA_STEPS_MAX || (n > 0 && !steps)) { g_last_error = "gsr_camera_steps_launch: 0..12 cameras"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return 0;
+    CameraStepsArgs all;
+    memset(&all, 0, sizeof(all));
+    for (int k = 0; k < n; k++) { const int rc = camera_step_args(&steps[k], all.c[k]); if (rc) return rc; }
+    hipLaunchKernelGGL(camera_steps_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream_, all);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_schedule_advance(int* counter, const unsigned int* table, int row_words, int rows, unsigned int* current, void* stream_)
+{
+    if (!counter || !table || !current || row_words < 1 || rows < 1) { g_last_error = "gsr_schedule_advance: null / empty argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    hipLaunchKernelGGL(schedule_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, counter, (const uint32_t*)table, row_words, rows, (uint32_t*)current);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_slot_gather(int n_slots, const gsr_keyframe_entry* table, const int* index, const gsr_keyframe_entry* dst, int pixels, void* stream_)
+{
+    if (n_slots < 0 || n_slots > SLOTS_MAX || pixels < 1 || (n_slots > 0 && (!table || !index || !dst))) {
+        g_last_error = "gsr_slot_gather: 0..4 slots, device table / index and a host array of destinations"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n_slots == 0) return 0;
+    static_assert(sizeof(gsr_keyframe_entry) == sizeof(KeyframeEntry), "gsr_keyframe_entry layout");
+    SlotGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_slots = n_slots; a.pixels = pixels; a.table = reinterpret_cast<const KeyframeEntry*>(table); a.index = index;
+    for (int s = 0; s < n_slots; s++) {
+        if (!dst[s].viewmatrix || !dst[s].full_proj || !dst[s].campos) { g_last_error = "gsr_slot_gather: a slot needs viewmatrix / full_proj / campos buffers"; return GSR_ERR_INVALID_ARGUMENT; }
+        memcpy(&a.dst[s], &dst[s], sizeof(KeyframeEntry));
+    }
+    hipLaunchKernelGGL(slot_gather_kernel, dim3(SLOT_GATHER_BLOCKS, (unsigned)n_slots), dim3(256), 0, (hipStream_t)stream_, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

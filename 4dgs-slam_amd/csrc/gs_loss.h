@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(LOSS_THREADS) masked_l1_bwd_kernel(MaskedL1Arg
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int ADAM_MAX_SEGMENTS = 8;
 struct AdamSegment { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; unsigned long long n; float step_size, inv_bc2_sqrt, eps, beta2, one_minus_beta1, one_minus_beta2; };   // 1 - beta evaluated in double on the host, as torch does
-struct AdamArgs { int nseg; unsigned long long total; unsigned long long start[ADAM_MAX_SEGMENTS + 1]; AdamSegment seg[ADAM_MAX_SEGMENTS]; };
+struct AdamArgs { int nseg; unsigned long long total; unsigned long long start[ADAM_MAX_SEGMENTS + 1]; AdamSegment seg[ADAM_MAX_SEGMENTS];
+                  const float* coef; };   // coef != nullptr (gsr_adam_step_scheduled): step_size / inv_bc2_sqrt of segment k are coef[2k], coef[2k+1] in DEVICE memory
 
 __global__ void __launch_bounds__(256) adam_step_kernel(AdamArgs a)
 {
@@ -154,7 +155,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamArgs a)
         m = m + (gr - m) * g.one_minus_beta1;
         v = v * g.beta2 + g.one_minus_beta2 * gr * gr;
         g.exp_avg[i] = m; g.exp_avg_sq[i] = v;
-        g.param[i] = g.param[i] - g.step_size * (m / (sqrtf(v) * g.inv_bc2_sqrt + g.eps));
+        const float step_size = a.coef ? a.coef[2 * s] : g.step_size, inv_bc2_sqrt = a.coef ? a.coef[2 * s + 1] : g.inv_bc2_sqrt;
+        g.param[i] = g.param[i] - step_size * (m / (sqrtf(v) * inv_bc2_sqrt + g.eps));
     }
 }
 

@@ -153,7 +153,7 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
-__global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a)
+__device__ __forceinline__ void camera_step_body(const CameraStepArgs& a)
 {
     if (a.latch && a.converged && a.converged[0]) return;      // converged earlier in this frame's loop: the reference has left the loop by now
 
@@ -235,6 +235,60 @@ __global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a)
     if (a.campos) {   // camera centre = -R^T T  (= inverse(view)[3, :3])
         for (int c = 0; c < 3; c++) a.campos[c] = -(Rm[c] * Tv[0] + Rm[3 + c] * Tv[1] + Rm[6 + c] * Tv[2]);
     }
+}
+
+__global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a) { camera_step_body(a); }
+
+// the window keyframes of a mapping iteration in one launch: block k steps camera k
+constexpr int CAMERA_STEPS_MAX = 12;
+struct CameraStepsArgs { CameraStepArgs c[CAMERA_STEPS_MAX]; };
+__global__ void __launch_bounds__(64) camera_steps_kernel(CameraStepsArgs a) { camera_step_body(a.c[blockIdx.x]); }
+
+// ---- device-side schedule + keyframe slots of a graph-captured mapping iteration (include/slam_map.h) ---------------------------
+__global__ void __launch_bounds__(64) schedule_advance_kernel(int* __restrict__ counter, const uint32_t* __restrict__ table, int row_words, int rows,
+                                                              uint32_t* __restrict__ current)
+{
+    const int it = counter[0];
+    const int row = it < 0 ? 0 : (it < rows ? it : rows - 1);
+    for (int k = threadIdx.x; k < row_words; k += 64) current[k] = table[(size_t)row * row_words + k];
+    __syncthreads();
+    if (threadIdx.x == 0) counter[0] = it + 1;
+}
+
+struct KeyframeEntry { float* view; float* full; float* campos; float* exposure_a; float* exposure_b; float* gt_image; float* gt_depth; float* w_rgb; float* w_depth; };
+constexpr int SLOTS_MAX = 4, SLOT_GATHER_BLOCKS = 120;
+struct SlotGatherArgs { int n_slots; int pixels; const KeyframeEntry* table; const int* index; KeyframeEntry dst[SLOTS_MAX]; };
+
+__device__ __forceinline__ void slot_copy(float* __restrict__ dst, const float* __restrict__ src, size_t n, size_t tid, size_t nthreads)
+{
+    if (!dst || !src) return;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+        const size_t n4 = n / 4;
+        const float4* s4 = reinterpret_cast<const float4*>(src); float4* d4 = reinterpret_cast<float4*>(dst);
+        for (size_t i = tid; i < n4; i += nthreads) d4[i] = s4[i];
+        for (size_t i = n4 * 4 + tid; i < n; i += nthreads) dst[i] = src[i];
+    } else {
+        for (size_t i = tid; i < n; i += nthreads) dst[i] = src[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) slot_gather_kernel(SlotGatherArgs a)
+{
+    const int s = blockIdx.y;
+    const KeyframeEntry e = a.table[a.index[s]];
+    const KeyframeEntry& d = a.dst[s];
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < 16) { d.view[t] = e.view[t]; d.full[t] = e.full[t]; }
+        if (t < 3) d.campos[t] = e.campos[t];
+        if (t == 0) { if (d.exposure_a && e.exposure_a) d.exposure_a[0] = e.exposure_a[0]; if (d.exposure_b && e.exposure_b) d.exposure_b[0] = e.exposure_b[0]; }
+    }
+    const size_t N = (size_t)a.pixels;
+    slot_copy(d.gt_image, e.gt_image, 3 * N, tid, nt);
+    slot_copy(d.gt_depth, e.gt_depth, N, tid, nt);
+    slot_copy(d.w_rgb, e.w_rgb, N, tid, nt);
+    slot_copy(d.w_depth, e.w_depth, N, tid, nt);
 }
 
 // ---- edge mask of a frame: Camera.compute_grad_mask, utils/camera_utils.py:205-233 (+ image_gradient / image_gradient_mask,

@@ -91,12 +91,23 @@ def load_library():
     lib.gsr_set_option.argtypes = [C.c_char_p, i]
     lib.gsr_forward_status.restype = i
     lib.gsr_forward_status.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    lib.gsr_forward_status_views.restype = i
+    lib.gsr_forward_status_views.argtypes = [C.POINTER(C.c_uint)]
     _lib = lib
     return lib
 
 
+def forward_status_views() -> int:
+    """The sticky overflow counter summed over the single-view slot and every view slot of the multi-view entry point (never blocks)."""
+    lib = load_library()
+    a = C.c_uint(0)
+    lib.gsr_forward_status_views(C.byref(a))
+    return int(a.value)
+
+
 def set_option(name: str, value: int = -1) -> int:
-    """gsr_set_option (include/gs_rasterizer.h): "speculate" | "lazy" | "mailbox"; returns the previous value (value < 0: query)."""
+    """gsr_set_option (include/gs_rasterizer.h): "speculate" | "lazy" | "mailbox" | "cap_margin_permille"; returns the previous value
+    (value < 0: query)."""
     lib = load_library()
     rc = lib.gsr_set_option(name.encode(), int(value))
     if rc < 0:

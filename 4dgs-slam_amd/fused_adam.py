@@ -33,6 +33,10 @@ def _lib():
     if not _declared:
         lib.gsr_adam_step.restype = C.c_int
         lib.gsr_adam_step.argtypes = [C.c_int, C.POINTER(_Segment), C.c_void_p]
+        lib.gsr_adam_step_scheduled.restype = C.c_int
+        lib.gsr_adam_step_scheduled.argtypes = [C.c_int, C.POINTER(_Segment), C.c_void_p, C.c_void_p]
+        lib.gsr_adam_coefficients.restype = None
+        lib.gsr_adam_coefficients.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_float)]
         _declared = True
     return lib
 
@@ -87,32 +91,78 @@ class FusedAdam(torch.optim.Adam):
                         return False
         return True
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        todo = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
-        if not self._fusable(todo):
-            return super().step(closure)
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
+    def _todo(self):
+        return [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
+
+    def _segments(self, todo, advance):
         segs = (_Segment * len(todo))()
-        dev = todo[0][1].device
         for k, (group, p) in enumerate(todo):
             st = self.state[p]
             if len(st) == 0:          # lazy state initialisation, as torch.optim.Adam does it
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] += 1
+            if advance:
+                st["step"] += 1
             b1, b2 = group["betas"]
             s = segs[k]
             s.param, s.grad, s.exp_avg, s.exp_avg_sq = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             s.n, s.lr, s.beta2, s.eps, s.step = p.numel(), float(group["lr"]), float(b2), float(group["eps"]), int(st["step"])
             s.beta1_d, s.beta2_d = float(b1), float(b2)
+        return segs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        todo = self._todo()
+        if not self._fusable(todo):
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        segs = self._segments(todo, advance=True)
+        dev = todo[0][1].device
         lib = _lib()
         with torch.cuda.device(dev):
             rc = lib.gsr_adam_step(len(todo), segs, _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_adam_step")
         return loss
+
+    # ---- the step inside a captured graph (slam/mapping_graph.py) --------------------------------------------------------------------
+    # A hipGraph that contains optimizer.step() is replayed for many iterations, but the bias corrections (and the xyz learning rate) change
+    # with every step: the kernel then reads its two step-dependent coefficients per parameter tensor from DEVICE memory
+    # (gsr_adam_step_scheduled), which the caller fills per iteration from a precomputed schedule. The arithmetic is step()'s, bit for bit.
+    def scheduled_segments(self):
+        """The (group, parameter) pairs a scheduled step covers, in segment order; None when the fused kernel cannot take them."""
+        todo = self._todo()
+        if not self._fusable(todo):
+            return None
+        for _, p in todo:                       # the moments must exist before a capture (step() creates them lazily)
+            if len(self.state[p]) == 0:
+                return None
+        return todo
+
+    @staticmethod
+    def coefficients(lr, betas, step):
+        """(lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as fp32, evaluated by the library exactly as gsr_adam_step evaluates them."""
+        lib = _lib()
+        out = (C.c_float * 2)()
+        lib.gsr_adam_coefficients(float(lr), float(betas[0]), float(betas[1]), int(step), out)
+        return float(out[0]), float(out[1])
+
+    @torch.no_grad()
+    def step_scheduled(self, todo, coefficients):
+        """One step over `todo` (scheduled_segments()) with the coefficients at the device address `coefficients` ([len(todo), 2] fp32).
+        Does NOT advance state["step"]: the caller adds the number of executed iterations afterwards (advance_steps)."""
+        segs = self._segments(todo, advance=False)
+        dev = todo[0][1].device
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_adam_step_scheduled(len(todo), segs, int(coefficients), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_adam_step_scheduled")
+
+    def advance_steps(self, todo, n):
+        for _, p in todo:
+            self.state[p]["step"] += n

@@ -21,6 +21,11 @@ class CameraStep(C.Structure):          # gsr_camera_step
                 ("converged", _vp), ("converged_threshold", _f), ("do_pose", _i), ("latch", _i)]
 
 
+class KeyframeEntry(C.Structure):       # gsr_keyframe_entry
+    _fields_ = [(n, _vp) for n in ("viewmatrix", "full_proj", "campos", "exposure_a", "exposure_b", "gt_image", "gt_depth", "w_rgb", "w_depth")]
+
+
+CAMERA_STEPS_MAX, SLOTS_MAX = 12, 4
 COPY, STATE, XYZ, SCALE = 0, 1, 2, 3
 _declared = False
 
@@ -39,6 +44,12 @@ def lib():
         L.gsr_densify_apply.argtypes = [_i, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(DensifyTensor), _vp, _vp, _i, _vp, _vp, _vp]
         L.gsr_camera_step_launch.restype = _i
         L.gsr_camera_step_launch.argtypes = [C.POINTER(CameraStep), _vp]
+        L.gsr_camera_steps_launch.restype = _i
+        L.gsr_camera_steps_launch.argtypes = [_i, C.POINTER(CameraStep), _vp]
+        L.gsr_schedule_advance.restype = _i
+        L.gsr_schedule_advance.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
+        L.gsr_slot_gather.restype = _i
+        L.gsr_slot_gather.argtypes = [_i, _vp, _vp, C.POINTER(KeyframeEntry), _i, _vp]
         L.gsr_kabsch_rotations.restype = _i
         L.gsr_kabsch_rotations.argtypes = [_i, _vp, _vp, _vp]
         L.gsr_edge_mask.restype = _i

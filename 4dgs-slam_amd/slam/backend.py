@@ -15,6 +15,7 @@ reduced only on the iterations that use them; the window cameras' poses / exposu
 floats each). The view-independent terms (isotropic-scale regulariser, ARAP / elastic node regularisers) are added on rank 0. All ranks
 must be seeded alike: they take the same random draws (extra keyframes, time samples, split noise)."""
 import random
+import time
 
 import torch
 
@@ -194,8 +195,10 @@ class BackEnd:
 
     # ---- window optimisation --------------------------------------------------------------------------------------------
     def _pose_updates(self, viewpoint_stack, current_window):
-        """keyframe_optimizers.step() + update_pose of :748-755 / :1213-1222: one camera-step launch per window keyframe."""
+        """keyframe_optimizers.step() + update_pose of :748-755 / :1213-1222: ONE camera-step launch for the window keyframes this rank owns
+        (Camera.pose_steps; objects without it -- test doubles -- are stepped one by one)."""
         lr = self.config["Training"]["lr"]
+        batch = []
         for cam_idx in range(len(current_window)):
             viewpoint = viewpoint_stack[cam_idx]
             if not self.shard.owns(cam_idx):          # another rank rendered this view: it holds the gradient and takes the step
@@ -205,8 +208,14 @@ class BackEnd:
                     if p is not None:
                         p.grad = None
                 continue
-            viewpoint.pose_step(lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
-                                optimize_pose=cam_idx < self.frames_to_optimize, optimize_exposure=True)
+            req = (viewpoint, lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
+                   cam_idx < self.frames_to_optimize, True)
+            if hasattr(type(viewpoint), "pose_steps"):
+                batch.append(req)
+            else:
+                viewpoint.pose_step(req[1], req[2], req[3], optimize_pose=req[4], optimize_exposure=True)
+        if batch:
+            type(batch[0][0]).pose_steps(batch)
         self.shard.sync_cameras(viewpoint_stack[:len(current_window)])
 
     def _publish_visibility(self, current_window, rows):
@@ -250,60 +259,191 @@ class BackEnd:
         return 10 * torch.abs(scaling - scaling.mean(dim=1).view(-1, 1)).mean()            # :653-655
 
     def map_static(self, current_window, prune=False, iters=1):
-        """:1013-1224."""
+        """:1013-1224. Runs of plain iterations -- no densification, no opacity reset, one process -- go through a captured hipGraph
+        (slam/mapping_graph.py: same arithmetic, one replay per iteration instead of ~55 launches from Python); ``Training.mapping_graph =
+        False`` keeps every iteration eager."""
         if len(current_window) == 0:
             return
         viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
         window_set = set(current_window)
         random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
         gaussian_split = False
-        shard = self.shard
-        for it in range(iters):
-            self.iteration_count += 1
-            self.last_sent += 1
-            loss_mapping = 0
-            pkgs, touched_rows = [], {}
-            extras = [random_viewpoint_stack[c] for c in torch.randperm(len(random_viewpoint_stack))[:2]]      # the same draw on every rank
-            mine = [(k, viewpoint) for k, viewpoint in enumerate(viewpoint_stack + extras) if shard.owns(k)]
-            rendered = self._render_many([v for _, v in mine], [(None, None, None)] * len(mine))
-            for (k, viewpoint), pkg in zip(mine, rendered):
-                loss = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True,
-                                                    compute_value=self.loss_values)
-                pkgs.append(pkg)
-                if k < len(viewpoint_stack):
-                    touched_rows[k] = pkg["n_touched"]            # (turned into a 0 / 1 row when it is published)
-                loss_mapping = loss_mapping + loss        # ONE backward for all views: the multi-view backward pass takes them together
-            if shard.rank == 0:
-                loss_mapping = loss_mapping + self._isotropic_loss()
-            if torch.is_tensor(loss_mapping) and loss_mapping.requires_grad:
-                loss_mapping.backward()
-            shard.reduce_gradients(self.gaussians.optimizer)
-            gaussian_split = False
-            with torch.no_grad():
-                last = it == iters - 1
-                if prune or last:                      # (every iteration overwrites the previous one's rows: only the last ones are ever read)
-                    self._publish_visibility(current_window, touched_rows)
-                if prune:
-                    self._window_full_bookkeeping(current_window)
-                    self.gaussians.optimizer.zero_grad(set_to_none=True)
-                    self._clear_camera_grads(viewpoint_stack)
-                    return False
-                for pkg in pkgs:
-                    self._view_stats(pkg)
-                update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
-                if update_gaussian:
-                    shard.reduce_statistics(self.gaussians)
-                    self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
-                    gaussian_split = True
-                if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian:
-                    self._reset_opacity_of_unseen(pkgs)
-                    gaussian_split = True
-                self.gaussians.optimizer.step()                 # rebuilt parameters have no gradient yet and are skipped, like in the reference
-                self.gaussians.optimizer.zero_grad(set_to_none=True)
-                self.gaussians.update_learning_rate(self.iteration_count)
-                self._pose_updates(viewpoint_stack, current_window)
-                self._clear_camera_grads(extras)
+        it = 0
+        while it < iters:
+            run = self._plain_run_length(it, iters, prune)
+            if run >= self.graph_min_run and self._graph_ok(viewpoint_stack):
+                done = self._map_static_graph_run(current_window, viewpoint_stack, random_viewpoint_stack, run, last=(it + run == iters))
+                if done:
+                    it += done
+                    gaussian_split = False
+                    continue
+            gaussian_split = self._map_static_iteration(current_window, viewpoint_stack, random_viewpoint_stack, prune, last=(it == iters - 1))
+            if prune:
+                return False
+            it += 1
         return gaussian_split
+
+    def _draw_extras(self, n_candidates):
+        """The two random keyframes of an iteration (:1031-1037), as indices into the non-window keyframes; the same draw on every rank."""
+        return [int(c) for c in torch.randperm(n_candidates)[:2]]
+
+    def _map_static_iteration(self, current_window, viewpoint_stack, random_viewpoint_stack, prune, last, extras_idx=None):
+        """One iteration of :1013-1224, launched piece by piece."""
+        shard = self.shard
+        self.iteration_count += 1
+        self.last_sent += 1
+        loss_mapping = 0
+        pkgs, touched_rows = [], {}
+        if extras_idx is None:
+            extras_idx = self._draw_extras(len(random_viewpoint_stack))
+        extras = [random_viewpoint_stack[c] for c in extras_idx]
+        mine = [(k, viewpoint) for k, viewpoint in enumerate(viewpoint_stack + extras) if shard.owns(k)]
+        rendered = self._render_many([v for _, v in mine], [(None, None, None)] * len(mine))
+        for (k, viewpoint), pkg in zip(mine, rendered):
+            loss = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], rm_dynamic=True,
+                                                compute_value=self.loss_values)
+            pkgs.append(pkg)
+            if k < len(viewpoint_stack):
+                touched_rows[k] = pkg["n_touched"]            # (turned into a 0 / 1 row when it is published)
+            loss_mapping = loss_mapping + loss        # ONE backward for all views: the multi-view backward pass takes them together
+        if shard.rank == 0:
+            loss_mapping = loss_mapping + self._isotropic_loss()
+        if torch.is_tensor(loss_mapping) and loss_mapping.requires_grad:
+            loss_mapping.backward()
+        shard.reduce_gradients(self.gaussians.optimizer)
+        gaussian_split = False
+        with torch.no_grad():
+            if prune or last:                      # (every iteration overwrites the previous one's rows: only the last ones are ever read)
+                self._publish_visibility(current_window, touched_rows)
+            if prune:
+                self._window_full_bookkeeping(current_window)
+                self.gaussians.optimizer.zero_grad(set_to_none=True)
+                self._clear_camera_grads(viewpoint_stack)
+                return False
+            for pkg in pkgs:
+                self._view_stats(pkg)
+            update_gaussian = self.iteration_count % self.gaussian_update_every == self.gaussian_update_offset
+            if update_gaussian:
+                shard.reduce_statistics(self.gaussians)
+                self.gaussians.densify_and_prune(self.opt_params.densify_grad_threshold, self.gaussian_th, self.gaussian_extent, self.size_threshold)
+                gaussian_split = True
+            if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian:
+                self._reset_opacity_of_unseen(pkgs)
+                gaussian_split = True
+            self.gaussians.optimizer.step()                 # rebuilt parameters have no gradient yet and are skipped, like in the reference
+            self.gaussians.optimizer.zero_grad(set_to_none=True)
+            self.gaussians.update_learning_rate(self.iteration_count)
+            self._pose_updates(viewpoint_stack, current_window)
+            self._clear_camera_grads(extras)
+        return gaussian_split
+
+    # ---- runs of plain iterations as hipGraph replays (slam/mapping_graph.py) ---------------------------------------------------------------
+    graph_min_run = 6           # a capture costs about two eager iterations of host time: shorter runs stay eager
+    graph_warmup = 2            # iterations of a run executed directly before the capture (the first may still go view by view, gsr_forward_views)
+
+    def _plain_run_length(self, it, iters, prune):
+        """How many iterations from `it` on neither densify nor reset opacities (those replace the model's tensors and run eagerly)."""
+        if prune or not self._graphs_enabled():
+            return 0
+        n = 0
+        while it + n < iters:
+            count = self.iteration_count + n + 1
+            if count % self.gaussian_update_every == self.gaussian_update_offset or count % self.gaussian_reset == 0:
+                break
+            n += 1
+        return n
+
+    def _graphs_enabled(self):
+        cfg = self.config["Training"].get("mapping_graph", True)
+        return bool(cfg) and not self.shard.active and not self.loss_values and str(self.device).startswith("cuda") and not getattr(self, "_graph_broken", False)
+
+    def _graph_ok(self, viewpoint_stack):
+        from .camera import Camera
+        g = self.gaussians
+        return (all(isinstance(v, Camera) and v.depth is not None for v in viewpoint_stack) and g.get_xyz.shape[0] > 0
+                and getattr(g.optimizer, "_fused_acc", False) and not self.config["Training"].get("monocular", False))
+
+    @property
+    def keyframe_operands(self):
+        if getattr(self, "_kf_operands", None) is None:
+            from .mapping_graph import KeyframeOperands
+            self._kf_operands = KeyframeOperands()
+        return self._kf_operands
+
+    def _map_static_graph_run(self, current_window, viewpoint_stack, random_viewpoint_stack, run, last):
+        """`run` plain iterations: draws up front, `graph_warmup` iterations executed directly, one capture, run - warm-up replays. Returns
+        the number of iterations done (0: nothing was executed, the caller goes on eagerly)."""
+        from .mapping_graph import MappingGraph
+        from diff_gaussian_rasterization import _C
+        g = self.gaussians
+        stats = self.__dict__.setdefault("graph_stats", {"runs": 0, "replays": 0, "direct": 0, "redone": 0, "failed": 0})
+        if g.optimizer.scheduled_segments() is None:         # (no gradient buffers / moments yet: the eager iteration creates them)
+            return 0
+        rng_state = torch.get_rng_state()
+        draws = [self._draw_extras(len(random_viewpoint_stack)) for _ in range(run)]
+        count0 = self.iteration_count
+        try:
+            mg = MappingGraph(self, current_window, viewpoint_stack, random_viewpoint_stack, draws, count0)
+        except RuntimeError as e:
+            torch.set_rng_state(rng_state)
+            self._graph_note(stats, e)
+            return 0
+        warm = min(self.graph_warmup, run)
+        mg.warm_up(warm)
+        overflow0 = _C.forward_status_views()     # (the directly executed iterations waited for their headers and redid what overflowed themselves)
+        if run > warm:
+            mg.snapshot()
+            try:
+                t_cap = time.perf_counter()
+                mg.capture()
+                stats["capture_ms"] = stats.get("capture_ms", 0.0) + (time.perf_counter() - t_cap) * 1e3
+            except Exception as e:        # a capture that fails leaves the iterations done so far valid: finish the run eagerly, stop capturing
+                self._graph_broken = True
+                torch.cuda.synchronize(mg.device)
+                mg.restore()
+                g.optimizer.zero_grad(set_to_none=True)
+                self._clear_camera_grads(list(viewpoint_stack) + mg.slots)
+                self._graph_note(stats, e)
+                self._finish_run(mg, draws, mg.executed)
+                self._run_eagerly(current_window, viewpoint_stack, random_viewpoint_stack, draws[mg.executed:], last)
+                return run
+            mg.replay(run - warm)
+            torch.cuda.current_stream(mg.device).synchronize()
+            if _C.forward_status_views() != overflow0:          # a replayed view outgrew its binning buffer: undo the replays, redo them eagerly
+                mg.restore()
+                stats["redone"] += run - warm
+                self._finish_run(mg, draws, warm)
+                self._run_eagerly(current_window, viewpoint_stack, random_viewpoint_stack, draws[warm:], last)
+                mg.release()
+                return run
+        stats["runs"] += 1
+        stats["direct"] += warm
+        stats["replays"] += run - warm
+        self._finish_run(mg, draws, run)
+        if last:
+            with torch.no_grad():
+                self._publish_visibility(current_window, {k: mg.pkgs[k]["n_touched"] for k in range(len(viewpoint_stack))})
+        mg.release()
+        return run
+
+    def _finish_run(self, mg, draws, n):
+        """Host-side state after `n` graph iterations: what n eager iterations would have left (counters, Adam's step counts, learning rate)."""
+        g = self.gaussians
+        self.iteration_count += n
+        self.last_sent += n
+        g.optimizer.advance_steps(mg.todo, n)
+        if n:
+            g.update_learning_rate(self.iteration_count)
+
+    def _run_eagerly(self, current_window, viewpoint_stack, random_viewpoint_stack, draws, last):
+        for j, extras_idx in enumerate(draws):
+            self._map_static_iteration(current_window, viewpoint_stack, random_viewpoint_stack, False, last and j == len(draws) - 1, extras_idx=extras_idx)
+
+    def _graph_note(self, stats, error):
+        stats["failed"] += 1
+        stats["last_error"] = f"{type(error).__name__}: {error}"
+        if self.config["Training"].get("mapping_graph") == "strict":
+            raise error
 
     def _clear_camera_grads(self, cams):
         for v in cams:

@@ -204,6 +204,30 @@ class Camera(nn.Module):
     def converged(self) -> bool:
         return bool(self._converged.item())
 
+    @staticmethod
+    @torch.no_grad()
+    def pose_steps(requests):
+        """pose_step() of several cameras in ONE launch (gsr_camera_steps_launch): requests = [(camera, lr_rot, lr_trans, lr_exposure,
+        optimize_pose, optimize_exposure)]. The window keyframes of a mapping iteration are stepped together (utils/slam_backend.py:748-755,
+        :1213-1222); per camera the arithmetic is pose_step's."""
+        requests = list(requests)
+        for lo in range(0, len(requests), _lib.CAMERA_STEPS_MAX):
+            part = requests[lo:lo + _lib.CAMERA_STEPS_MAX]
+            arr = (_lib.CameraStep * len(part))()
+            for k, (cam, lr_rot, lr_trans, lr_exposure, optimize_pose, optimize_exposure) in enumerate(part):
+                g = {}
+                if optimize_pose and cam.cam_rot_delta.grad is not None and cam.cam_trans_delta.grad is not None:
+                    g["rot"], g["trans"] = cam.cam_rot_delta.grad, cam.cam_trans_delta.grad
+                if optimize_exposure and cam.exposure_a.grad is not None and cam.exposure_b.grad is not None:
+                    g["a"], g["b"] = cam.exposure_a.grad, cam.exposure_b.grad
+                arr[k] = cam._step_desc(g, (float(lr_rot), float(lr_trans), float(lr_exposure)), optimize_pose, 1e-4, False)
+            dev = part[0][0].device
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().gsr_camera_steps_launch(len(part), arr, _lib.stream(dev)), "gsr_camera_steps_launch")
+            for cam, *_ in part:
+                for p in (cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b):
+                    p.grad = None
+
     # ---- matrices the renderer reads (utils/camera_utils.py:124-148) -----------------------------------------------------
     @property
     def world_view_transform(self):

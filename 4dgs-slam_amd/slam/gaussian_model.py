@@ -227,12 +227,16 @@ class GaussianModel:
         self.lr_delay_mult = ta.position_lr_delay_mult
         self.max_steps = ta.position_lr_max_steps
 
+    def xyz_lr_at(self, iteration):
+        """The position learning rate update_learning_rate(iteration) sets (GM:492-505)."""
+        return helper(iteration, lr_init=self.lr_init, lr_final=self.lr_final, lr_delay_mult=self.lr_delay_mult, max_steps=self.max_steps)
+
     def update_learning_rate(self, iteration):
         """GM:492-505."""
         lr = None
         for group in self.optimizer.param_groups:
             if group["name"] == "xyz":
-                lr = helper(iteration, lr_init=self.lr_init, lr_final=self.lr_final, lr_delay_mult=self.lr_delay_mult, max_steps=self.max_steps)
+                lr = self.xyz_lr_at(iteration)
                 group["lr"] = lr
         return lr
 

@@ -287,7 +287,12 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
                             + (1 - alpha) * torch.abs(sel * w_dep * depth - sel * w_dep * gt_depth).mean())
         l_static, l_dynamic = part(mm), part(~mm)
         return (l_static, 2 * l_dynamic) if dynamic else (l_static, l_dynamic)
-    # the weights are constants of (keyframe, flags, masks): formed once, not per call (2-4 image-sized launches per view and iteration)
+    w_rgb, w_dep = _cached_mapping_weights(config, viewpoint, gt_image, gt_depth, base_rgb, base_dep, rm_dynamic, mask, dynamic)
+    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha, compute_value=compute_value)
+
+
+def _cached_mapping_weights(config, viewpoint, gt_image, gt_depth, base_rgb, base_dep, rm_dynamic, mask, dynamic):
+    """The weights are constants of (keyframe, flags, masks): formed once, not per call (2-4 image-sized launches per view and iteration)."""
     motion = getattr(viewpoint, "motion_mask", None)
     wkey = (bool(rm_dynamic), bool(dynamic), id(mask), getattr(mask, "_version", None), id(motion), getattr(motion, "_version", None))
     derived = _CONST_CACHE[id(viewpoint)][3]
@@ -296,8 +301,19 @@ def get_loss_mapping(config, image, depth, viewpoint, opacity, initialization=Fa
         if len(derived) >= 8:
             derived.clear()
         hit = derived[wkey] = mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic, mask, dynamic, base=(base_rgb, base_dep)) + (mask, motion)
-    w_rgb, w_dep = hit[0], hit[1]
-    return weighted_l1_loss(image, depth, gt_image, gt_depth, w_rgb, w_dep, exposure[0], exposure[1], alpha, compute_value=compute_value)
+    return hit[0], hit[1]
+
+
+def mapping_loss_operands(config, viewpoint, device, rm_dynamic=False, mask=None, dynamic=False):
+    """(gt_image [3,H,W], gt_depth [1,H,W], w_rgb [1,H,W], w_depth [1,H,W], alpha): the constant operands the fused get_loss_mapping call of
+    this keyframe hands to weighted_l1_loss -- the SAME tensors (values and, while the constants' cache holds the keyframe, storage). The
+    graph-captured mapping iteration (slam/mapping_graph.py) keeps them per keyframe and calls weighted_l1_loss itself. RGB-D only."""
+    if config["Training"]["monocular"]:
+        raise RuntimeError("mapping_loss_operands: RGB-D keyframes only")
+    gt_image, gt_depth, base_rgb, base_dep, _, _ = _keyframe_constants(config, viewpoint, device)
+    w_rgb, w_dep = _cached_mapping_weights(config, viewpoint, gt_image, gt_depth, base_rgb, base_dep, rm_dynamic, mask, dynamic)
+    alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
+    return gt_image, gt_depth, w_rgb, w_dep, alpha
 
 
 def tracking_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, base=None):

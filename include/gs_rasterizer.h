@@ -243,11 +243,19 @@ int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
  *                on the device. Needed to capture forward + backward in a hipGraph. A frame that outgrows the capacity leaves its
  *                outputs undefined and bumps the overflow counter of gsr_forward_status(): poll it and redo that work with lazy = 0.
  *   "mailbox"   (default 1): read the header through pinned host memory instead of a blocking copy.
+ *   "cap_margin_permille" (default 125): head room of a speculative binning buffer over the previous frame's instance count, in
+ *                1/1000. A caller that captures many iterations of an OPTIMISATION in a hipGraph (slam/mapping_graph.py: the buffer
+ *                is laid out once, the Gaussians then move and grow for 20-200 replays) raises it for the capture.
+ *   "cap_test_shrink_permille" (default 0 = off): TEST facility -- lay speculative buffers out for this fraction of the previous
+ *                frame's count, so that overflows (and the callers' recovery paths) can be provoked deliberately.
  * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX set the initial values. */
 int gsr_set_option(const char* name, int value);
 /* overflow_count: number of forward passes of this thread whose speculative capacity was too small (sticky);
  * last_num_rendered: num_rendered of the most recent forward pass the GPU has finished binning. Never blocks. */
 int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered);
+/* The same sticky counter summed over the single-view slot AND every view slot of gsr_forward_views / its flow batches (each slot has
+ * its own mailbox) on the current device. Never blocks. */
+int gsr_forward_status_views(unsigned int* overflow_count_total);
 
 /* Thread-local text of the last error. */
 const char* gsr_last_error(void);

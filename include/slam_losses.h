@@ -72,6 +72,13 @@ typedef struct gsr_adam_segment {
     int step;                                                              /* step count AFTER this step (>= 1): bias corrections */
 } gsr_adam_segment;
 int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream);
+/* The two step-dependent coefficients of a segment as gsr_adam_step evaluates them on the host (double arithmetic like torch):
+ * out[0] = (float)(lr / (1 - beta1^step)), out[1] = (float)(1 / sqrt(1 - beta2^step)). */
+void gsr_adam_coefficients(double lr, double beta1, double beta2, int step, float out[2]);
+/* gsr_adam_step with those two coefficients read from DEVICE memory (coefficients[2 * k], [2 * k + 1] for segment k) when the kernel
+ * runs; segs[k].lr / .step are ignored. Lets a hipGraph that contains the optimizer step be replayed for many iterations: the host (or
+ * gsr_schedule_advance, slam_map.h) rewrites 2 * nseg floats per iteration instead of re-capturing. Same arithmetic, bit for bit. */
+int gsr_adam_step_scheduled(int nseg, const gsr_adam_segment* segs, const float* coefficients, void* stream);
 
 /* ---- densification statistics of one rendered view in one launch ----------------------------------------------------------
  * utils/slam_backend.py:712-720 + scene/gaussian_model.py:973-977 (add_densification_stats): for every Gaussian with radii > 0

@@ -94,6 +94,30 @@ typedef struct gsr_camera_step {
 } gsr_camera_step;
 int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
 
+/* Several camera steps in ONE launch (block k = steps[k]); n <= GSR_CAMERA_STEPS_MAX. The window keyframes of a mapping iteration
+ * (utils/slam_backend.py:748-755, :1213-1222) are stepped together. Same arithmetic per camera as gsr_camera_step_launch. */
+#define GSR_CAMERA_STEPS_MAX 12
+int gsr_camera_steps_launch(int n, const gsr_camera_step* steps /* host array */, void* stream);
+
+/* ---- a mapping iteration as ONE hipGraph (utils/slam_backend.py:1013-1224; slam/mapping_graph.py) ----------------------------------
+ * A captured graph cannot take new host values per replay. What changes from one mapping iteration to the next -- WHICH two random
+ * keyframes are rendered besides the window (:1031-1037) and the step-dependent Adam coefficients / learning rates -- therefore lives in
+ * a device-side SCHEDULE: `rows` rows of `row_words` 32-bit words, written by the host once for a run of iterations.
+ *   gsr_schedule_advance: current[0 .. row_words) = table[min(*counter, rows - 1)][..]; *counter += 1.       (one tiny launch)
+ * The rest of the graph reads `current` (keyframe indices as int32, coefficients as float).
+ *   gsr_slot_gather: for slot s < n_slots: e = table[index[s]] (a device array of gsr_keyframe_entry, one per candidate keyframe, holding
+ *   DEVICE pointers to that keyframe's persistent buffers); copy its camera block (viewmatrix 16, full_proj 16, campos 3, exposure_a 1,
+ *   exposure_b 1 floats) and its ground truth / loss-weight images (gt_image [3 * pixels], gt_depth, w_rgb, w_depth [pixels] each) into
+ *   the slot's own persistent buffers dst[s]. The graph renders and scores the SLOTS; which keyframe fills them is an index write. */
+typedef struct gsr_keyframe_entry {
+    float* viewmatrix; float* full_proj; float* campos; float* exposure_a; float* exposure_b;
+    float* gt_image; float* gt_depth; float* w_rgb; float* w_depth;
+} gsr_keyframe_entry;
+#define GSR_SLOTS_MAX 4
+int gsr_schedule_advance(int* counter, const unsigned int* table, int row_words, int rows, unsigned int* current, void* stream);
+int gsr_slot_gather(int n_slots, const gsr_keyframe_entry* table /* device */, const int* index /* device, n_slots */,
+                    const gsr_keyframe_entry* dst /* host array, n_slots */, int pixels, void* stream);
+
 /* ---- edge mask of a frame: Camera.compute_grad_mask, utils/camera_utils.py:205-233 (non-replica branch) with image_gradient /
  * image_gradient_mask of utils/slam_utils.py:5-39 ---------------------------------------------------------------------------------
  * image [3,H,W] -> gray = mean over channels; Scharr gradients (normalised by 16) of the reflect-padded gray image, zeroed where any of the

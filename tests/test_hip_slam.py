@@ -413,14 +413,14 @@ def test_camera_step_convergence_latch():
 
 
 # ---- view-sharded back-end on the real kernels: two gloo ranks on ONE GPU vs one process ----------------------------------------------
-def _mapping_state(n_kf=5):
+def _mapping_state(n_kf=5, **training):
     """A small mapped scene with `n_kf` keyframes in the back-end (frames at their ground-truth poses), built deterministically."""
     from slam.camera import Camera
     from slam.dataset import SyntheticRGBDDataset
     from slam.system import SLAM
     torch.manual_seed(0)
     ds = SyntheticRGBDDataset(num_frames=2 * n_kf, width=160, height=120, seed=0)
-    cfg = _quick_config(init_itr_num=60, gaussian_update_every=4, gaussian_update_offset=2)
+    cfg = _quick_config(**{**dict(init_itr_num=60, gaussian_update_every=4, gaussian_update_offset=2), **training})
     slam = SLAM(cfg, ds)
     slam.frontend.run(max_frames=1)                      # one view: every rank does the same work, the replicas stay identical
     fe, be = slam.frontend, slam.backend
@@ -433,6 +433,84 @@ def _mapping_state(n_kf=5):
         be.add_next_kf(idx, cam, depth_map=fe.add_new_keyframe(idx))
         cam.reset_pose_optimizer()
     return slam, [idx for idx in range(2 * n_kf - 2, 0, -2)][:4]        # window: the four newest; keyframe 0 stays outside as a "random" view
+
+
+def _map_static_outcome(graph, iters=50):
+    slam, window = _mapping_state(n_kf=7, gaussian_update_every=30, gaussian_update_offset=12, mapping_graph="strict" if graph else False)
+    be = slam.backend
+    # perturb the window poses a little so that the pose steps have something to do
+    for k, idx in enumerate(window):
+        cam = be.viewpoints[idx]
+        cam.update_RT(cam.R_gt, cam.T_gt + torch.tensor([0.004 * (k + 1), -0.003, 0.002], device=cam.T_gt.device))
+    be.map_static(window, iters=iters)
+    be.map_static(window, prune=True)
+    torch.cuda.synchronize()
+    g = be.gaussians
+    out = {"params": [p.detach().clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)],
+           "moments": [g.optimizer.state[p][k].clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation) for k in ("exp_avg", "exp_avg_sq")],
+           "steps": [float(g.optimizer.state[p]["step"]) for p in (g._xyz, g._opacity)],
+           "lr": [grp["lr"] for grp in g.optimizer.param_groups],
+           "stats": [g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone()],
+           "poses": {k: (v.R.clone(), v.T.clone(), v.exposure_a.detach().clone(), v.exposure_b.detach().clone(), v._adam.clone()) for k, v in be.viewpoints.items()},
+           "visibility": {k: v.clone() for k, v in be.occ_aware_visibility.items()}, "count": (be.iteration_count, be.last_sent),
+           "graph_stats": getattr(be, "graph_stats", None)}
+    return out, window
+
+
+def test_static_mapping_iterations_as_hip_graph_are_bit_identical_to_eager():
+    """BackEnd.map_static() with its plain iterations replayed as ONE hipGraph each (slam/mapping_graph.py: device-side
+    schedule for the random keyframes and the Adam coefficients, keyframe slots, scheduled Adam, lazy multi-view forward) must leave
+    bit-identical parameters, Adam moments, densification statistics, poses, exposures and covisibility rows to the eager loop over 50
+    iterations with two densifications in between (iterations 12 and 42 run eagerly and end a run)."""
+    eager, window = _map_static_outcome(False)
+    graph, _ = _map_static_outcome(True)
+    st = graph["graph_stats"]
+    print(st)
+    assert eager["graph_stats"] is None
+    assert st is not None and st["runs"] == 3 and st["replays"] >= 40 and st["failed"] == 0 and st["redone"] == 0, st
+    assert eager["count"] == graph["count"] and eager["steps"] == graph["steps"] and eager["lr"] == graph["lr"]
+    for name in ("params", "moments", "stats"):
+        for a, b in zip(eager[name], graph[name]):
+            assert a.shape == b.shape and torch.equal(a, b), name
+    assert set(eager["poses"]) == set(graph["poses"])
+    for k in eager["poses"]:
+        for a, b in zip(eager["poses"][k], graph["poses"][k]):
+            assert torch.equal(a, b), k
+    for k in window:
+        assert torch.equal(eager["visibility"][k], graph["visibility"][k])
+    # ... and the poses did move (the comparison is not of two no-ops)
+    moved = [float((graph["poses"][k][4]).abs().max()) for k in window if k != 0]
+    assert max(moved) > 0
+
+
+def test_mapping_graph_run_that_outgrows_its_buffers_is_redone_eagerly():
+    """A replayed frame that needs more instance slots than the captured buffers hold bumps the sticky overflow counters
+    (gsr_forward_status_views); the run is undone from its snapshot and repeated eagerly -- same result as the eager loop. The overflow is
+    provoked with the library's test option cap_test_shrink_permille (buffers laid out for half of the last frame's instances)."""
+    from diff_gaussian_rasterization import _C
+    eager, window = _map_static_outcome(False, iters=10)
+    slam, window = _mapping_state(n_kf=7, gaussian_update_every=30, gaussian_update_offset=12, mapping_graph="strict")
+    be = slam.backend
+    for k, idx in enumerate(window):
+        cam = be.viewpoints[idx]
+        cam.update_RT(cam.R_gt, cam.T_gt + torch.tensor([0.004 * (k + 1), -0.003, 0.002], device=cam.T_gt.device))
+    before = _C.forward_status_views()
+    _C.set_option("cap_test_shrink_permille", 500)
+    try:
+        be.map_static(window, iters=10)
+    finally:
+        _C.set_option("cap_test_shrink_permille", 0)
+    be.map_static(window, prune=True)
+    torch.cuda.synchronize()
+    st = be.graph_stats
+    print(st, _C.forward_status_views() - before)
+    assert _C.forward_status_views() > before and st["redone"] == 8 and st["runs"] == 0, st
+    g = be.gaussians
+    for a, b in zip(eager["params"], (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)):
+        assert torch.equal(a, b.detach())
+    for k in eager["poses"]:
+        assert torch.equal(eager["poses"][k][0], be.viewpoints[k].R) and torch.equal(eager["poses"][k][1], be.viewpoints[k].T)
+    assert eager["count"] == (be.iteration_count, be.last_sent)
 
 
 def _shard_worker(rank, world, port, ret):

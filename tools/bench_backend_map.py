@@ -26,6 +26,8 @@ for idx in range(2, 2 * n_kf, 2):
     be.add_next_kf(idx, cam, depth_map=fe.add_new_keyframe(idx))
     cam.reset_pose_optimizer()
 window = [idx for idx in range(2 * n_kf - 2, 0, -2)][:8]
+if "--eager" in sys.argv:
+    cfg["Training"]["mapping_graph"] = False          # every iteration launched from Python (round 3's loop)
 be.map_static(window, iters=10)
 torch.cuda.synchronize()
 ms0 = torch.cuda.memory_stats()
@@ -34,6 +36,15 @@ iters = 60
 be.map_static(window, iters=iters)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / iters * 1e3
+graph_stats = dict(getattr(be, "graph_stats", {}) or {})
+# the replays alone: a second 60-iteration call minus its capture
+c0 = graph_stats.get("capture_ms", 0.0)
+t0 = time.perf_counter()
+be.map_static(window, iters=iters)
+torch.cuda.synchronize()
+dt2 = (time.perf_counter() - t0) * 1e3
+graph_stats2 = dict(getattr(be, "graph_stats", {}) or {})
+replay_ms = (dt2 - (graph_stats2.get("capture_ms", 0.0) - c0)) / iters
 ms1 = torch.cuda.memory_stats()
 print({k: ms1[k] - ms0[k] for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}, "reserved MB", ms1["reserved_bytes.all.current"] >> 20, file=sys.stderr)
 from diff_gaussian_rasterization import _C
@@ -46,4 +57,5 @@ if "--profile" in sys.argv:
     pr = cProfile.Profile(); pr.enable(); be.map_static(window, iters=20); torch.cuda.synchronize(); pr.disable()
     pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
 print(json.dumps({"kernel_us_per_iteration": kern, "multi_view": os.environ.get("GSR_MULTI_VIEW", "1") != "0", "gaussians": int(be.gaussians.get_xyz.shape[0]), "views_per_iteration": len(window) + 2,
-                  "ms_per_mapping_iteration": dt}))
+                  "ms_per_mapping_iteration": dt, "ms_per_mapping_iteration_without_capture": replay_ms, "graph_stats": graph_stats2,
+                  "mode": "eager" if "--eager" in sys.argv else "graph"}))

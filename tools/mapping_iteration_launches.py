@@ -43,6 +43,19 @@ window = list(be.current_window)
 run = (lambda n: be.map(window, iters=n, dynamic_network=True)) if dyn else (lambda n: be.map_static(window, iters=n))
 run(3)
 torch.cuda.synchronize()
+graph_wall = None
+if not dyn and "--eager" not in sys.argv:          # the plain static iterations as hipGraph replays (slam/mapping_graph.py): wall time of 60 of them
+    t0 = time.perf_counter()
+    run(60)
+    torch.cuda.synchronize()
+    graph_wall = {"ms_per_iteration_incl_capture": (time.perf_counter() - t0) / 60 * 1e3, "graph_stats": dict(getattr(be, "graph_stats", {}) or {})}
+    c0 = graph_wall["graph_stats"].get("capture_ms", 0.0)
+    t0 = time.perf_counter()
+    run(60)
+    torch.cuda.synchronize()
+    graph_wall["ms_per_iteration_without_capture"] = ((time.perf_counter() - t0) * 1e3 - (be.graph_stats.get("capture_ms", 0.0) - c0)) / 60
+    cfg["Training"]["mapping_graph"] = False           # the census below is of the eager iteration (what one replay replaces)
+    be.config["Training"]["mapping_graph"] = False
 t0 = time.perf_counter()
 run(iters)
 torch.cuda.synchronize()
@@ -87,7 +100,7 @@ for e in prof.events():
     by_line[where] += 1
     by_op[(op or top.name)[:60]] += 1
 n_launch = sum(by_line.values())
-out = {"dynamic": dyn, "resolution": wh, "gaussians": int(be.gaussians.get_xyz.shape[0]), "window": len(window), "ms_per_iteration": wall * 1e3,
+out = {"graph": graph_wall, "dynamic": dyn, "resolution": wh, "gaussians": int(be.gaussians.get_xyz.shape[0]), "window": len(window), "ms_per_iteration": wall * 1e3,
        "launches_per_iteration": n_launch / iters,
        "by_source_line_per_iteration": {k: round(v / iters, 1) for k, v in by_line.most_common(50)},
        "by_op_per_iteration": {k: round(v / iters, 1) for k, v in by_op.most_common(40)},
