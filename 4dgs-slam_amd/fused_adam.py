@@ -148,7 +148,8 @@ class FusedAdam(torch.optim.Adam):
         """(lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as fp32, evaluated by the library exactly as gsr_adam_step evaluates them."""
         lib = _lib()
         out = (C.c_float * 2)()
-        lib.gsr_adam_coefficients(float(lr), float(betas[0]), float(betas[1]), int(step), out)
+        lr = C.c_float(float(lr)).value        # step() hands the learning rate over as an fp32 field of gsr_adam_segment: the same rounding here
+        lib.gsr_adam_coefficients(lr, float(betas[0]), float(betas[1]), int(step), out)
         return float(out[0]), float(out[1])
 
     @torch.no_grad()
@@ -162,6 +163,46 @@ class FusedAdam(torch.optim.Adam):
             rc = lib.gsr_adam_step_scheduled(len(todo), segs, int(coefficients), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_adam_step_scheduled")
+
+    # ---- the step on one rank's slice of a flat parameter buffer (mapping_shard.ShardedMappingStep, exchange="reduce_scatter") ------------
+    @torch.no_grad()
+    def step_slice(self, param_bucket, lo, hi):
+        """Adam on the elements [lo, hi) of ``param_bucket.flat`` only (the parameters are views of it, their gradients views of a flat
+        gradient buffer with the same layout): one fused launch over the pieces of the parameter tensors that fall into the range. Every
+        parameter's step count advances (all ranks keep the same counters); moments outside the range are left alone."""
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        segs = (_Segment * _MAX_SEGMENTS)()
+        n_seg, dev = 0, None
+        for p, off in zip(param_bucket.params, param_bucket.offsets):
+            if p.grad is None:
+                continue
+            group = group_of[id(p)]
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            a, b = max(lo, off), min(hi, off + p.numel())
+            if a >= b:
+                continue
+            if (group["amsgrad"] or group["weight_decay"] != 0 or group["maximize"] or not p.is_cuda or not p.is_contiguous()
+                    or not p.grad.is_contiguous() or n_seg >= _MAX_SEGMENTS):
+                raise RuntimeError("FusedAdam.step_slice: plain Adam on contiguous float32 device tensors, at most 8 pieces")
+            s, shift = segs[n_seg], 4 * (a - off)
+            s.param, s.grad = p.data_ptr() + shift, p.grad.data_ptr() + shift
+            s.exp_avg, s.exp_avg_sq = st["exp_avg"].data_ptr() + shift, st["exp_avg_sq"].data_ptr() + shift
+            b1, b2 = group["betas"]
+            s.n, s.lr, s.beta2, s.eps, s.step = b - a, float(group["lr"]), float(b2), float(group["eps"]), int(st["step"])
+            s.beta1_d, s.beta2_d = float(b1), float(b2)
+            n_seg, dev = n_seg + 1, p.device
+        if n_seg == 0:
+            return
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_adam_step(n_seg, segs, _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_adam_step (slice)")
 
     def advance_steps(self, todo, n):
         for _, p in todo:

@@ -34,10 +34,12 @@ def shard_keyframes(keyframe_ids: Sequence[int], rank: int, world_size: int) -> 
 class GradBucket:
     """Persistent flat fp32 buffer holding the gradients of a fixed parameter list, all-reduced in one call."""
 
-    def __init__(self, params: Iterable[torch.Tensor]):
+    def __init__(self, params: Iterable[torch.Tensor], pad_to: int = 1):
         self.params = [p for p in params]
         self.sizes = [p.numel() for p in self.params]
         total = sum(self.sizes)
+        self.used = total
+        total = (total + pad_to - 1) // pad_to * pad_to          # (reduce-scatter needs equal pieces: zero padding behind the last tensor)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views = []
@@ -131,6 +133,29 @@ class GradBucket:
         self.all_reduce(group)
         self.unpack()
         return "packed"
+
+
+class ParamBucket:
+    """The PARAMETERS of a fixed list back to back in one flat fp32 buffer (each parameter's .data becomes a view of it, same values), laid
+    out like GradBucket lays out their gradients: what an all-gather of updated parameter slices needs (reduce-scatter exchange below)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], pad_to: int = 1):
+        self.params = [p for p in params]
+        self.sizes = [p.numel() for p in self.params]
+        total = (sum(self.sizes) + pad_to - 1) // pad_to * pad_to
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
+        o = 0
+        with torch.no_grad():
+            for p, n in zip(self.params, self.sizes):
+                if not p.is_contiguous() or p.dtype != torch.float32:
+                    raise ValueError("ParamBucket: contiguous float32 parameters only")
+                v = self.flat[o:o + n].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.offsets.append(o)
+                o += n
 
 
 def _force_collective() -> bool:
@@ -309,14 +334,41 @@ class ShardedMappingStep:
 
     ``params`` in the optimizer's order; ``view_fn(k)`` must leave pose / exposure gradients alone (they belong to the owner)."""
 
-    def __init__(self, params, keyframe_ids, view_fn, optimizer=None, group=None, overlap=False):
+    def __init__(self, params, keyframe_ids, view_fn, optimizer=None, group=None, overlap=False, exchange="all_reduce", views_fn=None, local=False):
+        """exchange = "all_reduce" (default): every rank receives the full gradient sum and steps its whole replica.
+        exchange = "reduce_scatter" (SURVEY.md 8e's alternative): reduce-scatter of the gradient bucket -> the optimizer steps only this
+        rank's 1/world slice of the flat parameter buffer (FusedAdam.step_slice) -> all-gather of the updated parameter slices. The same
+        2 (N - 1) / N bucket sizes cross every link, but only the reduce-scatter half stands between the last backward pass and the
+        optimizer, Adam's traffic is divided by N, and on a full xGMI mesh both halves are direct exchanges (every rank sends piece r to rank r)
+        instead of a ring. Needs an optimizer with step_slice (FusedAdam; the CPU tests pass a plain-torch stand-in). Moments outside a
+        rank's slice are never touched on that rank.
+        views_fn: optional callable taking the LIST of this rank's keyframes (the multi-view entry point renders and back-propagates them
+        with one launch per pipeline stage); when absent, view_fn is called per keyframe.
+        local: ignore the process group -- every keyframe on this rank, no collective (the single-GPU point of a scaling curve, run by one
+        rank of a larger job)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.local = bool(local)
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized() and not local) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.keyframes = shard_keyframes(list(keyframe_ids), self.rank, self.world)
         self.view_fn = view_fn
+        self.views_fn = views_fn
         self.optimizer = optimizer
-        self.bucket = GradBucket(params).attach()
+        if exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("ShardedMappingStep: exchange must be 'all_reduce' or 'reduce_scatter'")
+        self.exchange = exchange
+        params = list(params)
+        if exchange == "reduce_scatter":
+            if overlap:
+                raise ValueError("ShardedMappingStep: the two-piece overlap belongs to the all-reduce exchange")
+            if optimizer is None or not hasattr(optimizer, "step_slice"):
+                raise ValueError("ShardedMappingStep: exchange='reduce_scatter' needs an optimizer with step_slice(param_bucket, lo, hi)")
+            self.param_bucket = ParamBucket(params, pad_to=self.world)
+            self.bucket = GradBucket(params, pad_to=self.world).attach()
+            piece = self.bucket.flat.numel() // self.world
+            self.slice = (self.rank * piece, (self.rank + 1) * piece)
+        else:
+            self.bucket = GradBucket(params).attach()
         # overlap (SURVEY.md 8e "Overlap"): the exchange in two pieces -- the sum of this rank's first n - 1 views is all-reduced
         # asynchronously WHILE the last view renders into a second bucket, which is reduced behind it; the two reduced pieces are added.
         # What it buys is bounded: the second piece is as large as the whole bucket, so the bytes behind the last backward pass are the
@@ -327,25 +379,43 @@ class ShardedMappingStep:
         self.allreduce_calls = 0
 
     def _collectives_on(self):
-        return dist.is_available() and dist.is_initialized() and (self.world > 1 or _force_collective())
+        return not self.local and dist.is_available() and dist.is_initialized() and (self.world > 1 or _force_collective())
+
+    def _render_mine(self, keyframes):
+        if self.views_fn is not None:
+            if keyframes:
+                self.views_fn(list(keyframes))
+        else:
+            for k in keyframes:
+                self.view_fn(k)
 
     def step(self):
+        if self.exchange == "reduce_scatter":
+            self.bucket.zero_grads()
+            self._render_mine(self.keyframes)
+            lo, hi = self.slice
+            if self._collectives_on():
+                dist.reduce_scatter_tensor(self.bucket.flat[lo:hi], self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.allreduce_calls += 1
+            self.optimizer.step_slice(self.param_bucket, lo, hi)
+            if self._collectives_on():
+                dist.all_gather_into_tensor(self.param_bucket.flat, self.param_bucket.flat[lo:hi], group=self.group)
+            self.mode = "reduce-scatter" if self._collectives_on() else "single"
+            return self.mode
         if not self.overlap:
             self.bucket.zero_grads()
-            for k in self.keyframes:
-                self.view_fn(k)
-            self.mode = self.bucket.all_reduce_grads(self.group)
+            self._render_mine(self.keyframes)
+            self.mode = "single" if self.local else self.bucket.all_reduce_grads(self.group)
             self.allreduce_calls += 0 if self.mode == "single" else 1
         else:
             first, last = self.bucket, self.last_bucket
             first.attach()
             first.flat.zero_()
-            for k in self.keyframes[:-1]:
-                self.view_fn(k)
+            self._render_mine(self.keyframes[:-1])
             work = dist.all_reduce(first.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self._collectives_on() else None
             last.attach()                                    # the parameters' .grad now point into the second bucket
             last.flat.zero_()
-            self.view_fn(self.keyframes[-1])
+            self._render_mine(self.keyframes[-1:])
             if self._collectives_on():
                 dist.all_reduce(last.flat, op=dist.ReduceOp.SUM, group=self.group)
                 work.wait()

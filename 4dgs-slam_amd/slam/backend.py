@@ -363,6 +363,19 @@ class BackEnd:
         return (all(isinstance(v, Camera) and v.depth is not None for v in viewpoint_stack) and g.get_xyz.shape[0] > 0
                 and getattr(g.optimizer, "_fused_acc", False) and not self.config["Training"].get("monocular", False))
 
+    def graph_streams(self, dev):
+        """(warm-up stream, capture stream) of the mapping graphs, created once per device."""
+        cache = self.__dict__.setdefault("_graph_streams", {})
+        if dev not in cache:
+            cache[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return cache[dev]
+
+    def graph_pool(self, dev):
+        cache = self.__dict__.setdefault("_graph_pools", {})
+        if dev not in cache:
+            cache[dev] = torch.cuda.graph_pool_handle()
+        return cache[dev]
+
     @property
     def keyframe_operands(self):
         if getattr(self, "_kf_operands", None) is None:
@@ -397,6 +410,7 @@ class BackEnd:
                 t_cap = time.perf_counter()
                 mg.capture()
                 stats["capture_ms"] = stats.get("capture_ms", 0.0) + (time.perf_counter() - t_cap) * 1e3
+                stats["last_capture_parts_ms"] = [round(v, 3) for v in getattr(mg, "capture_parts_ms", ())]     # begin, host pass, end + instantiate, hipMallocs
             except Exception as e:        # a capture that fails leaves the iterations done so far valid: finish the run eagerly, stop capturing
                 self._graph_broken = True
                 torch.cuda.synchronize(mg.device)

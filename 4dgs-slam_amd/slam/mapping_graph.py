@@ -130,6 +130,7 @@ class MappingGraph:
     # ---- the iteration (one code path: run directly, or captured and replayed) ---------------------------------------------------------------
     def iteration(self):
         be, g, dev = self.backend, self.backend.gaussians, self.device
+        self.pkgs = None            # (the previous iteration's autograd graph dies here, not while the next one is being built)
         L = _lib.lib()
         with torch.cuda.device(dev):
             _lib.check(L.gsr_schedule_advance(self.counter.data_ptr(), self.table.data_ptr(), self.row_words, self.rows, self.current.data_ptr(),
@@ -161,7 +162,7 @@ class MappingGraph:
         """`n` iterations executed directly, on a side stream (torch's capture protocol: autograd's stream bookkeeping must have seen the
         stream family the capture will use). They are iterations like any other: rows 0..n-1 of the schedule."""
         dev = self.device
-        s = torch.cuda.Stream(device=dev)
+        s = self.backend.graph_streams(dev)[0]
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(n):
@@ -170,15 +171,35 @@ class MappingGraph:
         torch.cuda.current_stream(dev).wait_stream(s)
 
     def capture(self):
+        """Capture one iteration. Not through ``torch.cuda.graph``: its __enter__ runs gc.collect() and empties the allocator's cache -- tens of
+        milliseconds per capture at SLAM sizes, and every mapping call captures anew (the map's tensors change with every keyframe). All
+        captures of a back-end share ONE private memory pool; the previous graph is kept alive until this capture has begun, so the pool
+        (and its blocks) survive from capture to capture."""
+        be, dev = self.backend, self.device
         lazy_before = _C.set_option("lazy", 1)
         margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+        s = be.graph_streams(dev)[1]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        self.graph = torch.cuda.CUDAGraph()
+        import time
+        t0 = time.perf_counter()
+        a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         try:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.iteration()
+            with torch.cuda.stream(s):
+                self.graph.capture_begin(pool=be.graph_pool(dev))
+                t1 = time.perf_counter()
+                try:
+                    self.iteration()
+                finally:
+                    t2 = time.perf_counter()
+                    self.graph.capture_end()
+            t3 = time.perf_counter()
+            self.capture_parts_ms = ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - a0)
         finally:
             _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
             _C.set_option("cap_margin_permille", margin_before)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
         return self
 
     def replay(self, n):

@@ -97,6 +97,64 @@ class Scene:
         return int((radii > 0).sum().item()), int(nr)
 
 
+class RawScene:
+    """The same synthetic scene held as the GaussianModel's RAW parameters (log-scales, unnormalised quaternions, logit opacities, SH DC),
+    rendered through the multi-view entry point (gsr_forward_views / gsr_backward_views: one launch per pipeline stage for up to
+    views.MAX_VIEWS keyframes) -- what BackEnd.map_static / map call per mapping iteration. Same images and gradient sums as Scene's
+    view-by-view calls up to the activations' chain rules being applied inside the kernels."""
+
+    def __init__(self, P, dev, scale_mean=0.005, keyframes=(0,), cot_seed=1, views_per_call=8):
+        from diff_gaussian_rasterization import GaussianRasterizationSettings
+        from synthetic_scene import keyframe_pose, make_camera, make_cotangents, make_gaussians
+        self.P, self.dev, self.sh_degree, self.views_per_call = P, dev, 0, views_per_call
+        g = self.g = make_gaussians(P, make_camera(WIDTH, HEIGHT), seed=0, sh_degree=0, scale_mean=scale_mean)
+        T = lambda a, rg=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)
+        op = np.clip(g["opacities"].astype(np.float64), 1e-6, 1 - 1e-6)
+        self.xyz, self.f_dc = T(g["means3D"], True), T(g["shs"][:, :1, :], True)
+        self.opacity, self.scaling, self.rotation = T(np.log(op / (1 - op)), True), T(np.log(g["scales"]), True), T(g["rotations"], True)
+        self.params = [self.xyz, self.f_dc, self.opacity, self.scaling, self.rotation]          # the optimizer's order (GM:404-434)
+        self.bg = T([1.0, 1.0, 1.0])
+        self.cams, self.settings, self.poses = {}, {}, {}
+        for k in keyframes:
+            R_w, t_w = keyframe_pose(k)
+            cam = make_camera(WIDTH, HEIGHT, R=R_w, t=t_w)
+            self.cams[k] = cam
+            self.settings[k] = GaussianRasterizationSettings(
+                image_height=HEIGHT, image_width=WIDTH, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=self.bg, scale_modifier=1.0,
+                viewmatrix=T(cam.viewmatrix), projmatrix=T(cam.projmatrix), projmatrix_raw=T(cam.projmatrix_raw), sh_degree=0,
+                campos=T(cam.campos), prefiltered=False, debug=False)
+            self.poses[k] = (T(np.zeros(3), True), T(np.zeros(3), True))
+        gc, gd = make_cotangents(self.cams[keyframes[0]], seed=cot_seed)
+        self.gcol, self.gdep = T(gc), T(gd)
+        self.batched_calls = 0
+
+    def fwd_bwd_views(self, ks):
+        from diff_gaussian_rasterization import _C, views
+        for lo in range(0, len(ks), self.views_per_call):
+            part = ks[lo:lo + self.views_per_call]
+            block = torch.zeros((len(part), self.P, 3), device=self.dev)
+            pts = [block[v].requires_grad_(True) for v in range(len(part))]
+            outs = views.rasterize_views_raw([self.settings[k] for k in part], self.xyz, pts, self.scaling, self.rotation, self.opacity, self.f_dc,
+                                             None, poses=[self.poses[k] for k in part])
+            tensors, grads = [], []
+            for o in outs:
+                tensors += [o[0], o[2]]
+                grads += [self.gcol, self.gdep]
+            torch.autograd.backward(tensors, grads)
+            for k in part:
+                self.poses[k][0].grad = self.poses[k][1].grad = None
+        self.batched_calls = _C.set_option("views_batched")
+
+    def view_facts(self, k):
+        from diff_gaussian_rasterization import raw
+        with torch.no_grad():
+            out = raw.rasterize_gaussians_raw(self.settings[k], self.xyz.detach(), torch.zeros_like(self.xyz), self.scaling.detach(), self.rotation.detach(),
+                                              self.opacity.detach(), self.f_dc.detach(), None, None, None, None, None, None, None)
+            torch.cuda.synchronize(self.dev)
+        from diff_gaussian_rasterization import _C
+        return int((out[1] > 0).sum().item()), int(_C.forward_status()[1])
+
+
 STEP_KERNEL_SOURCES = ("gs_device.h", "gs_forward.h", "gs_render.h", "gs_backward.h", "gs_views.h")
 
 
@@ -206,19 +264,20 @@ def graph_replayed_step(scene, k, steps):
             "what": "the same forward + backward captured as ONE hipGraph (lazy forward: no host wait) and replayed: host out of the loop"}
 
 
-def make_cfg5(scene, keyframes, overlap=False, local=False):
-    """The config #5 iteration. local=True: every keyframe on THIS rank, no collective (the single-GPU point of the scaling curve)."""
+def make_cfg5(scene, keyframes, overlap=False, local=False, exchange="all_reduce"):
+    """The config #5 iteration. local=True: every keyframe on THIS rank, no collective (the single-GPU point of the scaling curve).
+    A RawScene goes through the multi-view entry point (this rank's keyframes in groups of 8 per call), a Scene view by view."""
     from fused_adam import FusedAdam
     from mapping_shard import ShardedMappingStep
     opt = FusedAdam([{"params": [p], "lr": 0.0, "name": n} for p, n in zip(scene.params, ("xyz", "f", "opacity", "scaling", "rotation"))],
                     lr=0.0, eps=1e-15)      # lr = 0: the full Adam arithmetic runs, the scene (hence the workload) stays put
-    sms = ShardedMappingStep(scene.params, keyframes, lambda k: scene.fwd_bwd(k), optimizer=opt, overlap=overlap)
-    if local:
-        sms.world, sms.rank, sms.keyframes, sms.overlap = 1, 0, list(keyframes), False
-        sms.bucket.all_reduce_grads = lambda group=None: "single"
+    multi = isinstance(scene, RawScene)
+    sms = ShardedMappingStep(scene.params, keyframes, None if multi else (lambda k: scene.fwd_bwd(k)), optimizer=opt, overlap=overlap,
+                             exchange=exchange, views_fn=(lambda ks: scene.fwd_bwd_views(ks)) if multi else None, local=local)
 
     def step():
-        scene.theta.grad = scene.rho.grad = scene.means2D.grad = None
+        if not multi:
+            scene.theta.grad = scene.rho.grad = scene.means2D.grad = None
         sms.step()
     return sms, step
 
@@ -347,6 +406,9 @@ def main():
     ap.add_argument("--keyframes", type=int, default=CFG5_KEYFRAMES)
     ap.add_argument("--sh-degree", type=int, default=None)
     ap.add_argument("--scale-mean", type=float, default=None)
+    ap.add_argument("--exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="cfg5: one all-reduce of the gradient bucket (default) or reduce-scatter -> Adam on the local slice -> all-gather of parameters")
+    ap.add_argument("--view-by-view", action="store_true", help="cfg5: one rasterizer call per keyframe (round 3's step) instead of the multi-view entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the embedded secondary measurements (config5 / weak_200k / n1_reference)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -366,7 +428,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        # `python bench.py --gpus N`: become the launcher -- N ranks of this same command under torch.distributed.run, one per GPU; rank 0's JSON
+        # line is the only stdout output of the children, and it is passed through unchanged
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        note(f"self-launch: {' '.join(cmd)}")
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # test hooks (tests/test_hip_configs.py runs the N > 1 code path on a 1-GPU box): GSR_BENCH_DEVICE pins every rank to one
@@ -467,18 +539,29 @@ def main():
             note("secondary: config #5 iteration on one GPU")
             del scene
             torch.cuda.empty_cache()
-            s5 = Scene(CFG5_P, dev, 0, 0.005, keyframes=tuple(range(args.keyframes)))
-            sms, step5 = make_cfg5(s5, list(range(args.keyframes)))
-            t5 = timed(step5, 3, 1, barrier) / 3
-            out["config5"] = {"workload": f"configs[4] on ONE GPU: {CFG5_P} Gaussians x {args.keyframes} keyframes, gradients accumulated, fused Adam",
-                              "ms_per_step": t5 * 1e3, "value": CFG5_P * args.keyframes / t5, "unit": "Gaussian-views/s", "steps": 3}
+            kfs5 = list(range(args.keyframes))
+            s5 = RawScene(CFG5_P, dev, 0.005, keyframes=tuple(kfs5))
+            sms, step5 = make_cfg5(s5, kfs5)
+            t5 = timed(step5, 3, 2, barrier) / 3
+            out["config5"] = {"workload": f"configs[4] on ONE GPU: {CFG5_P} Gaussians x {args.keyframes} keyframes through the multi-view entry point "
+                                          f"({s5.views_per_call} views per call), gradients accumulated, fused Adam",
+                              "ms_per_step": t5 * 1e3, "value": CFG5_P * args.keyframes / t5, "unit": "Gaussian-views/s", "steps": 3,
+                              "multi_view_calls_batched": s5.batched_calls}
+            del s5, sms
+            torch.cuda.empty_cache()
+            s5 = Scene(CFG5_P, dev, 0, 0.005, keyframes=tuple(kfs5))              # round 3's step beside it: one rasterizer call per keyframe
+            sms, step5 = make_cfg5(s5, kfs5)
+            t5v = timed(step5, 2, 1, barrier) / 2
+            out["config5"]["view_by_view_ms_per_step"] = t5v * 1e3
             del s5, sms
             torch.cuda.empty_cache()
     else:   # ---- cfg5 -------------------------------------------------------------------------------------------------------
         P = args.gaussians or CFG5_P
         kfs = list(range(args.keyframes))
-        scene = Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs[rank::world]) if world > 1 else tuple(kfs))
-        sms, step = make_cfg5(scene, kfs)
+        mine = tuple(kfs[rank::world]) if world > 1 else tuple(kfs)
+        multi_view = not args.view_by_view and sh_degree == 0
+        scene = RawScene(P, dev, scale_mean, keyframes=mine) if multi_view else Scene(P, dev, sh_degree, scale_mean, keyframes=mine)
+        sms, step = make_cfg5(scene, kfs, exchange=args.exchange)
         for _ in range(args.warmup):
             step()
         barrier()
@@ -503,15 +586,23 @@ def main():
             ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
             ranks_seen = sorted(int(t.item()) for t in ids)
-            if len(sms.keyframes) >= 2:
+            if len(sms.keyframes) >= 2 and args.exchange == "all_reduce":
                 sms2, step2 = make_cfg5(scene, kfs, overlap=True)
                 two_piece_ms = reduce_max(timed(step2, max(2, args.steps // 2), 1, barrier)) / max(2, args.steps // 2) * 1e3
                 del sms2
                 sms.bucket.attach()
+        # the other exchange beside the chosen one: reduce-scatter -> Adam on the local slice -> all-gather of the parameters
+        other_ms, other = None, ("reduce_scatter" if args.exchange == "all_reduce" else "all_reduce")
+        if world > 1 and not args.no_secondary:
+            sms3, step3 = make_cfg5(scene, kfs, exchange=other)
+            other_ms = reduce_max(timed(step3, max(2, args.steps // 2), 1, barrier)) / max(2, args.steps // 2) * 1e3
+            del sms3
+            if args.exchange == "all_reduce":
+                sms.bucket.attach()
         facts = [scene.view_facts(k) for k in sms.keyframes]
         if rank == 0:
             Vm, Rm = sum(f[0] for f in facts) / len(facts), sum(f[1] for f in facts) / len(facts)
-            M = int(scene.shs.shape[1])
+            M = int(scene.shs.shape[1]) if hasattr(scene, "shs") else 1
             b_total, b_dom = algorithmic_bytes(P, Vm, Rm, N, M)
             dom_s = dom_ms / max(dom_calls, 1) * 1e-3
             achieved = b_dom / dom_s / 1e9 if dom_s > 0 else 0.0
@@ -521,6 +612,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "ranks_seen": ranks_seen, "allreduce_ms": ar_ms, "two_piece_exchange_ms_per_step": two_piece_ms,
+                "exchange": args.exchange, f"{other}_exchange_ms_per_step": other_ms,
+                "multi_view": bool(multi_view), "views_per_call": getattr(scene, "views_per_call", 1),
                 "config": {"workload": f"configs[4]: {P} Gaussians, {len(kfs)} synthetic keyframes @{WIDTH}x{HEIGHT} sharded {world}-way ({len(sms.keyframes)} views per rank, "
                                        f"gradients accumulated locally), ONE all-reduce of {sms.bucket.nbytes} B, fused Adam step; value = Gaussian-views/s",
                            "views_per_rank": len(sms.keyframes), "allreduce_bytes": sms.bucket.nbytes, "allreduce_mode": sms.mode, "allreduce_ms": ar_ms,
@@ -545,8 +638,8 @@ def main():
             if rank == 0:
                 del scene, sms
                 torch.cuda.empty_cache()
-                s1 = Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs))
-                _, step1 = make_cfg5(s1, kfs, local=True)           # the same code path (attached bucket, fused accumulation, fused Adam)
+                s1 = RawScene(P, dev, scale_mean, keyframes=tuple(kfs)) if multi_view else Scene(P, dev, sh_degree, scale_mean, keyframes=tuple(kfs))
+                _, step1 = make_cfg5(s1, kfs, local=True)           # the same code path (multi-view calls, attached bucket, fused accumulation, fused Adam)
                 step1()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

@@ -197,9 +197,11 @@ def _run_bench(extra, nproc=2, port=29617):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSR_BENCH_DEVICE="0", GSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if nproc > 1:
+    if nproc > 1 and port is not None:     # as torch.distributed.run launches it ...
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(nproc)] + extra
+    elif nproc > 1:                         # ... and as a plain `python bench.py --gpus N`: bench.py spawns its own ranks
+        cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(nproc)] + extra
     else:
         cmd = [sys.executable, os.path.join(repo, "bench.py")] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -215,10 +217,16 @@ def test_bench_multi_rank_code_paths_on_one_gpu():
     cuda:0 and gloo instead of RCCL (RCCL refuses two ranks on one GPU). Default workload at N > 1 = BASELINE config #5 (keyframes
     sharded, gradients accumulated in the attached bucket, ONE all-reduce, fused Adam) at reduced P; its N = 1 line must agree with
     the embedded single-GPU reference; the weak-scaling 200k mode stays available as --workload cfg2."""
-    d = _run_bench(["--steps", "2", "--warmup", "1", "--gaussians", "60000", "--keyframes", "8", "--no-cpu-baseline"], nproc=2)
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--gaussians", "60000", "--keyframes", "8", "--no-cpu-baseline"], nproc=2, port=None)   # plain `python bench.py --gpus 2`
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     c = d["config"]
     assert "configs[4]" in c["workload"] and c["views_per_rank"] == 4 and c["allreduce_bytes"] == 60000 * 14 * 4 and c["allreduce_mode"] == "attached"
+    # the step goes through the multi-view entry point (4 views of a rank in one call), and the other exchange -- reduce-scatter, Adam on the
+    # local slice, all-gather of the parameters -- is timed beside the all-reduce
+    assert d["multi_view"] and d["exchange"] == "all_reduce" and d["reduce_scatter_exchange_ms_per_step"] > 0
+    r = _run_bench(["--steps", "2", "--warmup", "1", "--gaussians", "60000", "--keyframes", "8", "--no-cpu-baseline", "--no-secondary", "--exchange", "reduce_scatter"],
+                   nproc=2, port=29619)
+    assert r["exchange"] == "reduce_scatter" and r["config"]["allreduce_mode"] == "reduce-scatter" and r["value"] > 0
     assert d["roofline"]["kernel"] == "render_bwd" and d["roofline"]["achieved"] > 0
     # both ranks share ONE GPU and the collective goes through gloo (host copies), so the 2-rank step is slower than rank 0 alone
     assert 0.03 < d["n1_reference"]["ms_per_step"] / d["ms_per_step"] < 3.0, d
@@ -237,6 +245,7 @@ def test_bench_single_gpu_line_carries_config5_and_both_binning_modes():
     assert d["n_gpus"] == 1 and "configs[1]" in d["config"]["workload"] and d["config"]["instances"] > 500000
     assert d["ms_per_step_nonspeculative"] >= 0.5 * d["ms_per_step"]          # (10 timed steps: box noise alone moves either number by 20 %)
     assert d["config5"]["ms_per_step"] > 0 and "configs[4]" in d["config5"]["workload"]
+    assert d["config5"]["multi_view_calls_batched"] > 0 and d["config5"]["view_by_view_ms_per_step"] > 0      # the multi-view step, round 3's beside it
     # the same step replayed as one hipGraph (host out of the loop): present, overflow-free, not slower than the eager step beyond noise
     g = d["graph_replay"]
     assert g["overflow_free"] and 0 < g["ms_per_step"] < 1.5 * d["ms_per_step"], d

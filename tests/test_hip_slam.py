@@ -435,52 +435,76 @@ def _mapping_state(n_kf=5, **training):
     return slam, [idx for idx in range(2 * n_kf - 2, 0, -2)][:4]        # window: the four newest; keyframe 0 stays outside as a "random" view
 
 
-def _map_static_outcome(graph, iters=50):
+def _map_static_state(be):
+    g = be.gaussians
+    ps = (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)
+    return {"params": [p.detach().clone() for p in ps],
+            "moments": [g.optimizer.state[p][k].clone() for p in ps for k in ("exp_avg", "exp_avg_sq")],
+            "steps": [float(g.optimizer.state[p]["step"]) for p in (g._xyz, g._opacity)],
+            "lr": [grp["lr"] for grp in g.optimizer.param_groups],
+            "stats": [g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone()],
+            "poses": {k: (v.R.clone(), v.T.clone(), v.exposure_a.detach().clone(), v.exposure_b.detach().clone(), v._adam.clone()) for k, v in be.viewpoints.items()},
+            "visibility": {k: v.clone() for k, v in be.occ_aware_visibility.items()}, "count": (be.iteration_count, be.last_sent),
+            "graph_stats": dict(getattr(be, "graph_stats", None) or {}) or None}
+
+
+def _map_static_outcome(graph, calls=(50,)):
+    """States after consecutive map_static calls of the given lengths (+ the pruning call after the last)."""
     slam, window = _mapping_state(n_kf=7, gaussian_update_every=30, gaussian_update_offset=12, mapping_graph="strict" if graph else False)
     be = slam.backend
     # perturb the window poses a little so that the pose steps have something to do
     for k, idx in enumerate(window):
         cam = be.viewpoints[idx]
         cam.update_RT(cam.R_gt, cam.T_gt + torch.tensor([0.004 * (k + 1), -0.003, 0.002], device=cam.T_gt.device))
-    be.map_static(window, iters=iters)
+    out = []
+    for n in calls:
+        be.map_static(window, iters=n)
+        torch.cuda.synchronize()
+        out.append(_map_static_state(be))
     be.map_static(window, prune=True)
     torch.cuda.synchronize()
-    g = be.gaussians
-    out = {"params": [p.detach().clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)],
-           "moments": [g.optimizer.state[p][k].clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation) for k in ("exp_avg", "exp_avg_sq")],
-           "steps": [float(g.optimizer.state[p]["step"]) for p in (g._xyz, g._opacity)],
-           "lr": [grp["lr"] for grp in g.optimizer.param_groups],
-           "stats": [g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone()],
-           "poses": {k: (v.R.clone(), v.T.clone(), v.exposure_a.detach().clone(), v.exposure_b.detach().clone(), v._adam.clone()) for k, v in be.viewpoints.items()},
-           "visibility": {k: v.clone() for k, v in be.occ_aware_visibility.items()}, "count": (be.iteration_count, be.last_sent),
-           "graph_stats": getattr(be, "graph_stats", None)}
+    out.append(_map_static_state(be))
     return out, window
+
+
+def _first_difference(eager, graph, window):
+    """None, or a description of the first thing that differs between two _map_static_state dicts."""
+    if eager["count"] != graph["count"] or eager["steps"] != graph["steps"] or eager["lr"] != graph["lr"]:
+        return f"host state: {eager['count']} {graph['count']} {eager['steps']} {graph['steps']} {eager['lr']} {graph['lr']}"
+    for name in ("params", "moments", "stats"):
+        for i, (a, b) in enumerate(zip(eager[name], graph[name])):
+            if a.shape != b.shape:
+                return f"{name}[{i}]: shapes {tuple(a.shape)} {tuple(b.shape)}"
+            if not torch.equal(a, b):
+                return f"{name}[{i}]: max |diff| {float((a - b).abs().max()):.3e}, {int((a != b).sum())} of {a.numel()} elements"
+    for k in eager["poses"]:
+        for i, (a, b) in enumerate(zip(eager["poses"][k], graph["poses"][k])):
+            if not torch.equal(a, b):
+                return f"pose of keyframe {k}, item {i}: max |diff| {float((a - b).abs().max()):.3e}"
+    for k in window:
+        if not torch.equal(eager["visibility"][k], graph["visibility"][k]):
+            return f"visibility row of keyframe {k}"
+    return None
 
 
 def test_static_mapping_iterations_as_hip_graph_are_bit_identical_to_eager():
     """BackEnd.map_static() with its plain iterations replayed as ONE hipGraph each (slam/mapping_graph.py: device-side
     schedule for the random keyframes and the Adam coefficients, keyframe slots, scheduled Adam, lazy multi-view forward) must leave
     bit-identical parameters, Adam moments, densification statistics, poses, exposures and covisibility rows to the eager loop over 50
-    iterations with two densifications in between (iterations 12 and 42 run eagerly and end a run)."""
-    eager, window = _map_static_outcome(False)
-    graph, _ = _map_static_outcome(True)
-    st = graph["graph_stats"]
+    iterations -- compared after 10 (one plain run), 30 and 50 iterations (a densification at iterations 12 and 42: those run eagerly
+    and end a run) and after the pruning call."""
+    calls = (10, 20, 20)
+    eager, window = _map_static_outcome(False, calls)
+    graph, _ = _map_static_outcome(True, calls)
+    st = graph[-1]["graph_stats"]
     print(st)
-    assert eager["graph_stats"] is None
-    assert st is not None and st["runs"] == 3 and st["replays"] >= 40 and st["failed"] == 0 and st["redone"] == 0, st
-    assert eager["count"] == graph["count"] and eager["steps"] == graph["steps"] and eager["lr"] == graph["lr"]
-    for name in ("params", "moments", "stats"):
-        for a, b in zip(eager[name], graph[name]):
-            assert a.shape == b.shape and torch.equal(a, b), name
-    assert set(eager["poses"]) == set(graph["poses"])
-    for k in eager["poses"]:
-        for a, b in zip(eager["poses"][k], graph["poses"][k]):
-            assert torch.equal(a, b), k
-    for k in window:
-        assert torch.equal(eager["visibility"][k], graph["visibility"][k])
+    assert eager[-1]["graph_stats"] is None
+    diffs = [_first_difference(e, g, window) for e, g in zip(eager, graph)]
+    assert diffs == [None] * len(diffs), diffs
+    assert st is not None and st["runs"] == 4 and st["replays"] >= 36 and st["failed"] == 0 and st["redone"] == 0, st
+    assert eager[-1]["count"][0] - eager[0]["count"][0] == 41
     # ... and the poses did move (the comparison is not of two no-ops)
-    moved = [float((graph["poses"][k][4]).abs().max()) for k in window if k != 0]
-    assert max(moved) > 0
+    assert max(float(graph[-1]["poses"][k][4].abs().max()) for k in window if k != 0) > 0
 
 
 def test_mapping_graph_run_that_outgrows_its_buffers_is_redone_eagerly():
@@ -488,7 +512,8 @@ def test_mapping_graph_run_that_outgrows_its_buffers_is_redone_eagerly():
     (gsr_forward_status_views); the run is undone from its snapshot and repeated eagerly -- same result as the eager loop. The overflow is
     provoked with the library's test option cap_test_shrink_permille (buffers laid out for half of the last frame's instances)."""
     from diff_gaussian_rasterization import _C
-    eager, window = _map_static_outcome(False, iters=10)
+    eager, window = _map_static_outcome(False, (10,))
+    eager = eager[-1]
     slam, window = _mapping_state(n_kf=7, gaussian_update_every=30, gaussian_update_offset=12, mapping_graph="strict")
     be = slam.backend
     for k, idx in enumerate(window):
@@ -504,7 +529,7 @@ def test_mapping_graph_run_that_outgrows_its_buffers_is_redone_eagerly():
     torch.cuda.synchronize()
     st = be.graph_stats
     print(st, _C.forward_status_views() - before)
-    assert _C.forward_status_views() > before and st["redone"] == 8 and st["runs"] == 0, st
+    assert _C.forward_status_views() > before and st["redone"] >= 6 and st["runs"] == 0, st      # (the first iteration of the call creates Adam's moments eagerly)
     g = be.gaussians
     for a, b in zip(eager["params"], (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)):
         assert torch.equal(a, b.detach())

@@ -309,3 +309,104 @@ def test_replicate_gradients_gives_every_rank_rank_zeros():
     q.grad = torch.full((3,), 2.0)
     solo.replicate_gradients([q])
     assert solo.collectives == 0 and float(q.grad.sum()) == 6.0
+
+
+# ---- SURVEY.md 8e's alternative exchange: reduce-scatter -> Adam on the local 1/N slice -> all-gather of the parameters ----------------------
+class _FlatAdam:
+    """Test double of FusedAdam's two entry points on CPU tensors: plain Adam arithmetic on a range of the flat parameter / gradient
+    buffers (step_slice), or on everything (step). Moments live in flat buffers of its own."""
+
+    def __init__(self, params, lr=0.05, betas=(0.9, 0.999), eps=1e-8):
+        self.params, self.lr, self.betas, self.eps, self.t = list(params), lr, betas, eps, 0
+        n = sum(p.numel() for p in self.params)
+        self.m, self.v = torch.zeros(n + 8), torch.zeros(n + 8)
+
+    def _apply(self, p_flat, g_flat, lo, hi):
+        b1, b2 = self.betas
+        m, v = self.m[lo:hi], self.v[lo:hi]
+        g = g_flat[lo:hi]
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p_flat[lo:hi] -= (self.lr / (1 - b1 ** self.t)) * m / (v.sqrt() / (1 - b2 ** self.t) ** 0.5 + self.eps)
+
+    @torch.no_grad()
+    def step_slice(self, param_bucket, lo, hi):
+        self.t += 1
+        g_flat = torch.cat([p.grad.reshape(-1) for p in param_bucket.params])
+        g_flat = torch.cat([g_flat, torch.zeros(param_bucket.flat.numel() - g_flat.numel())])
+        self._apply(param_bucket.flat, g_flat, lo, hi)
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            flat = p.data.view(-1)
+            b1, b2 = self.betas
+            m, v, g = self.m[o:o + n], self.v[o:o + n], p.grad.reshape(-1)
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            flat -= (self.lr / (1 - b1 ** self.t)) * m / (v.sqrt() / (1 - b2 ** self.t) ** 0.5 + self.eps)
+            o += n
+
+
+def _exchange_worker(rank, world, port, ret):
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapping_shard import ShardedMappingStep
+    out = {}
+    for exchange in ("all_reduce", "reduce_scatter"):
+        g = torch.Generator().manual_seed(0)                   # identical replicas on every rank, and for both exchanges
+        a = torch.nn.Parameter(torch.randn(41, 3, generator=g))
+        b = torch.nn.Parameter(torch.randn(7, generator=g))
+        c = torch.nn.Parameter(torch.randn(7, 3, generator=g))            # 151 elements in all: padded to 152 for two equal pieces
+        opt = _FlatAdam([a, b, c])
+        seen = []
+
+        def views_fn(ks, a=a, b=b, c=c, seen=seen):             # the multi-view form: this rank's keyframes in ONE call
+            seen.append(list(ks))
+            for k in ks:
+                (torch.sin(a * (k + 1)).sum() + (b ** 3).sum() * (0.1 * k + 0.2) + torch.cos(c * 0.5 * (k + 1)).sum()).backward()
+
+        step = ShardedMappingStep([a, b, c], list(range(8)), None, optimizer=opt, exchange=exchange, views_fn=views_fn)
+        modes = [step.step() for _ in range(3)]
+        out[exchange] = (modes, [t.detach().numpy().copy() for t in (a, b, c)], step.allreduce_calls, seen[0],
+                         getattr(step, "slice", None), int(step.bucket.flat.numel()))
+    ret.put((rank, out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_reduce_scatter_exchange_equals_all_reduce_exchange():
+    """reduce-scatter -> optimizer on this rank's 1/N slice of the flat parameter buffer -> all-gather of the parameters
+    must leave every rank with the parameters the all-reduce exchange leaves, after 3 steps, and both must equal one process."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29100 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    solo = ctx.Queue()
+    _exchange_worker(0, 1, port + 1, solo)
+    one = solo.get(timeout=10)[1]
+    assert one["all_reduce"][0] == ["single"] * 3 and one["reduce_scatter"][0] == ["single"] * 3
+    for rank in (0, 1):
+        ar, rs = got[rank]["all_reduce"], got[rank]["reduce_scatter"]
+        assert ar[0] == ["attached"] * 3 and rs[0] == ["reduce-scatter"] * 3
+        assert rs[3] == [rank, rank + 2, rank + 4, rank + 6]              # this rank's keyframes arrived as one list
+        assert rs[5] == 152 and rs[4] == (76 * rank, 76 * (rank + 1))      # padded bucket, equal pieces
+        for x, y, z in zip(ar[1], rs[1], one["all_reduce"][1]):
+            np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-7)         # the two exchanges agree ...
+            np.testing.assert_allclose(x, z, rtol=1e-5, atol=1e-6)         # ... and equal the single process
+    for x, y in zip(got[0]["reduce_scatter"][1], got[1]["reduce_scatter"][1]):
+        assert np.array_equal(x, y)                                        # the replicas hold the same parameters after the all-gather
