@@ -106,7 +106,7 @@ class _RasterizeViewsRaw(torch.autograd.Function):
             outs = []
             for v in range(V):
                 outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
-                ctx.mark_non_differentiable(outs[-4], outs[-1])
+            ctx.mark_non_differentiable(*[outs[5 * v + k] for v in range(V) for k in (1, 4)])      # every view's radii and n_touched, in ONE call (a call replaces the set)
             return tuple(outs)
         img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
         ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
@@ -147,7 +147,7 @@ class _RasterizeViewsRaw(torch.autograd.Function):
         outs = []
         for v in range(V):
             outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
-            ctx.mark_non_differentiable(outs[-4], outs[-1])
+        ctx.mark_non_differentiable(*[outs[5 * v + k] for v in range(V) for k in (1, 4)])
         return tuple(outs)
 
     @staticmethod
@@ -281,7 +281,7 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
             outs = []
             for v in range(V):
                 outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
-                ctx.mark_non_differentiable(outs[-4], outs[-1])
+            ctx.mark_non_differentiable(*[outs[5 * v + k] for v in range(V) for k in (1, 4)])      # every view's radii and n_touched, in ONE call (a call replaces the set)
             return tuple(outs)
         img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
         ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
@@ -322,7 +322,7 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
         outs = []
         for v in range(V):
             outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
-            ctx.mark_non_differentiable(outs[-4], outs[-1])
+        ctx.mark_non_differentiable(*[outs[5 * v + k] for v in range(V) for k in (1, 4)])
         return tuple(outs)
 
     @staticmethod

@@ -235,8 +235,10 @@ class ViewShard:
 
     def reduce_gradients(self, optimizer, network_params=()):
         """Gaussian gradients through the optimizer's flat bucket when it has one (FusedAdam with fused accumulation: the kernels already
-        summed this rank's views into it), else packed; parameters a rank has no gradient for count as zero. The network's gradients
-        ride a second bucket (different lifetime: the Gaussian bucket is rebuilt by every densification)."""
+        summed this rank's views into it), else through a cached packing bucket; the network's gradients ride a second bucket (different
+        lifetime: the Gaussian bucket is rebuilt by every densification) -- in place when attach_network() made the gradients views of it,
+        packed otherwise. A parameter that has no gradient on ANY rank keeps ``grad = None`` (no optimizer state is created for it, as in a
+        single process); every rank must take the same path (checked on the packed path, which costs one small collective)."""
         if not self.active:
             return
         bucket = getattr(optimizer, "_bucket", None)
@@ -247,19 +249,60 @@ class ViewShard:
                 and len(bucket.params) == len(params):
             self._sum(bucket.flat)
         else:
-            b = GradBucket(params)
-            b.pack()
-            self._sum(b.flat)
-            b.unpack()
+            self._packed_sum("_gauss_pack", params)
         net = [p for p in network_params if p.requires_grad]
         if net:
-            key = tuple(id(p) for p in net)
-            if self._net_bucket is None or self._net_bucket[0] != key:
-                self._net_bucket = (key, GradBucket(net))
-            b = self._net_bucket[1]
-            b.pack()
-            self._sum(b.flat)
-            b.unpack()
+            hit = self._net_bucket
+            if hit is not None and hit[0] == tuple(id(p) for p in net) and getattr(hit[1], "attached", False) \
+                    and all(p.grad is v for p, v in zip(hit[1].params, hit[1].views)):
+                self._sum(hit[1].flat)
+            else:
+                self._packed_sum("_net_pack", net)
+
+    def _packed_sum(self, slot, params):
+        """pack -> all-reduce -> unpack through a bucket cached per parameter list; gradients that are None everywhere stay None."""
+        key = tuple(id(p) for p in params)
+        hit = self.__dict__.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, GradBucket(params))
+            self.__dict__[slot] = hit
+        b = hit[1]
+        had = torch.tensor([1.0] + [1.0 if p.grad is not None else 0.0 for p in params], device=b.flat.device)
+        dist.all_reduce(had, op=dist.ReduceOp.SUM, group=self.group)          # [ranks on this path | ranks holding a gradient, per parameter]
+        self.collectives += 1
+        if int(had[0].item()) != self.world:
+            raise RuntimeError("ViewShard.reduce_gradients: the ranks disagree on how the gradients are exchanged (attached bucket vs packed)")
+        b.pack()
+        self._sum(b.flat)
+        for p, v, n in zip(b.params, b.views, had[1:].tolist()):
+            if n == 0:
+                p.grad = None
+            elif p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+    def attach_network(self, params):
+        """Make the network parameters' .grad views of one persistent flat bucket (GradBucket.attach without the rasterizer's fused
+        accumulation): autograd accumulates into them in place and reduce_gradients all-reduces the bucket as it stands -- no pack / unpack
+        of ~20 tensors per iteration. Use zero_network_grads() in place of optimizer.zero_grad(set_to_none=True). No-op with one rank."""
+        net = [p for p in params if p.requires_grad]
+        if not self.active or not net:
+            return None
+        key = tuple(id(p) for p in net)
+        if self._net_bucket is None or self._net_bucket[0] != key:
+            self._net_bucket = (key, GradBucket(net))
+        b = self._net_bucket[1]
+        b.flat.zero_()
+        b.attach(fused_accumulate=False)
+        return b
+
+    def zero_network_grads(self, optimizer):
+        hit = self._net_bucket
+        if self.active and hit is not None and getattr(hit[1], "attached", False):
+            hit[1].zero_grads()
+        else:
+            optimizer.zero_grad(set_to_none=True)
 
     def reduce_statistics(self, gaussians):
         if self.active:
@@ -282,6 +325,25 @@ class ViewShard:
         for k, r in rows.items():
             full[k] = r
         self._sum(full)
+        return [full[k] for k in range(count)]
+
+    def gather_mask_rows(self, rows, count, length, device):
+        """gather_rows for 0 / 1 rows (the window keyframes' visibility, 1 bit per Gaussian and keyframe): every rank packs the
+        rows it owns 8 to a byte, the packed [count, length / 8] matrix is summed over ranks (each row has ONE owner, the others contribute
+        zeros) and unpacked -- 64x fewer bytes than the int64 rows. Returns `count` int64 rows of 0 / 1."""
+        if not self.active:
+            return [(rows[k] != 0).long() for k in range(count)]
+        nbytes = (length + 7) // 8
+        weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=device)
+        packed = torch.zeros((count, nbytes), dtype=torch.int32, device=device)
+        for k, r in rows.items():
+            bits = torch.zeros(nbytes * 8, dtype=torch.int32, device=device)
+            bits[:length] = (r != 0).to(torch.int32)
+            packed[k] = (bits.view(nbytes, 8) * weights).sum(dim=1)
+        packed = packed.to(torch.uint8)
+        self._sum(packed)
+        bits = (packed.to(torch.int32)[:, :, None] // weights) % 2                     # [count, nbytes, 8]
+        full = bits.reshape(count, nbytes * 8)[:, :length].long()
         return [full[k] for k in range(count)]
 
     def replicate_gradients(self, params, src=0):

@@ -194,38 +194,48 @@ class BackEnd:
         self.occ_aware_visibility[cur_frame_idx] = (pkg["n_touched"] > 0).long()
 
     # ---- window optimisation --------------------------------------------------------------------------------------------
-    def _pose_updates(self, viewpoint_stack, current_window):
+    def _pose_updates(self, viewpoint_stack, current_window, positions=None):
         """keyframe_optimizers.step() + update_pose of :748-755 / :1213-1222: ONE camera-step launch for the window keyframes this rank owns
-        (Camera.pose_steps; objects without it -- test doubles -- are stepped one by one)."""
+        (Camera.pose_steps; objects without it -- test doubles -- are stepped one by one). positions (map(): the views are key_opt, not the
+        window): per view its index in the window or None -- a view outside the window has no optimizer in the reference (:955-992) and
+        only drops its camera gradients; the pose is optimised for the views whose WINDOW position is below frames_to_optimize."""
         lr = self.config["Training"]["lr"]
         batch = []
-        for cam_idx in range(len(current_window)):
+        for cam_idx in range(min(len(current_window), len(viewpoint_stack))):
             viewpoint = viewpoint_stack[cam_idx]
             if not self.shard.owns(cam_idx):          # another rank rendered this view: it holds the gradient and takes the step
                 continue
-            if viewpoint.uid == 0:
+            position = cam_idx if positions is None else positions[cam_idx]
+            if viewpoint.uid == 0 or position is None:
                 for p in (viewpoint.cam_rot_delta, viewpoint.cam_trans_delta, viewpoint.exposure_a, viewpoint.exposure_b):
                     if p is not None:
                         p.grad = None
                 continue
             req = (viewpoint, lr["cam_rot_delta"] * self.pose_lr_scale, lr["cam_trans_delta"] * self.pose_lr_scale, 0.01,
-                   cam_idx < self.frames_to_optimize, True)
+                   position < self.frames_to_optimize, True)
             if hasattr(type(viewpoint), "pose_steps"):
                 batch.append(req)
             else:
                 viewpoint.pose_step(req[1], req[2], req[3], optimize_pose=req[4], optimize_exposure=True)
         if batch:
             type(batch[0][0]).pose_steps(batch)
-        self.shard.sync_cameras(viewpoint_stack[:len(current_window)])
+        self.shard.sync_cameras(viewpoint_stack[:min(len(current_window), len(viewpoint_stack))])
 
-    def _publish_visibility(self, current_window, rows):
-        """occ_aware_visibility of the window keyframes (:661-665) from the rows their owners hold."""
-        rows = {k: (n_touched > 0).long() for k, n_touched in rows.items()}
+    def _publish_visibility(self, current_window, rows, n_views=None):
+        """occ_aware_visibility of the window keyframes (:661-665) from the rows their owners hold. n_views (map(): fewer optimised views
+        than window entries, where the reference's loop would run off its list): the window entries beyond it keep their previous row
+        when it still fits the model, else an empty one."""
+        n_views = len(current_window) if n_views is None else min(n_views, len(current_window))
+        rows = {k: (n_touched > 0).long() for k, n_touched in rows.items() if k < n_views}
         like = torch.zeros(self.gaussians.get_xyz.shape[0], dtype=torch.int64, device=self.gaussians.get_xyz.device)
         if rows:
             like = torch.zeros_like(next(iter(rows.values())))
-        full = self.shard.gather_rows(rows, len(current_window), like)
-        self.occ_aware_visibility = {current_window[idx]: full[idx] for idx in range(len(current_window))}
+        full = self.shard.gather_mask_rows(rows, n_views, int(like.shape[0]), like.device)       # 1 bit per Gaussian and keyframe on the wire
+        previous = self.occ_aware_visibility
+        self.occ_aware_visibility = {current_window[idx]: full[idx] for idx in range(n_views)}
+        for kf_idx in current_window[n_views:]:
+            old = previous.get(kf_idx)
+            self.occ_aware_visibility[kf_idx] = old if (old is not None and old.shape == like.shape) else torch.zeros_like(like)
 
     def _reset_opacity_of_unseen(self, pkgs):
         """reset_opacity_nonvisible (:722-728) with the visibility filters of ALL views of the iteration, whoever rendered them."""
@@ -468,14 +478,26 @@ class BackEnd:
     def map(self, current_window, prune=False, iters=1, dynamic_network=False):
         """:306-774 with the control-node warp on the dynamic subset. The optical-flow term of the reference (:479-509) needs RAFT;
         when the dataset can supply a flow (``dataset.gt_flow``) the same term is formed with render_flow, otherwise it is skipped.
-        Not reproduced: the reference optimises ``current_window[:3]`` plus the keyframes Camera.keyframe_selection_overlap picks
-        (:310-318) and draws its random views from the complement of THAT set; here the whole window is optimised, as in map_static."""
+        The optimised views are the reference's ``key_opt`` (:310-318): the three newest window keyframes plus up to five older keyframes
+        chosen by their overlap with the newest one (slam/keyframes.keyframe_selection_overlap), of which the loop walks the first
+        len(current_window) (:357-358); the two random views per iteration come from the complement of key_opt. Two consequences the
+        reference has and this keeps: the covisibility row published under ``current_window[idx]`` is the one of view ``key_opt[idx]``
+        (:661-665), and only views that sit in the window have camera parameters to step (the keyframe optimizers are built from the
+        window, :955-992) -- a selected keyframe outside the window is rendered for the map's sake alone."""
         if len(current_window) == 0:
             return
         g = self.gaussians
-        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in current_window]
-        window_set = set(current_window)
-        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in window_set]
+        key_opt = list(current_window[:3])
+        if len(current_window) > 3:
+            from .keyframes import keyframe_selection_overlap
+            ds = self.dataset
+            key_opt += keyframe_selection_overlap(self.viewpoints[current_window[0]], self.viewpoints, self.viewpoints[current_window[2]].uid,
+                                                  (ds.fx, ds.fy, ds.cx, ds.cy, ds.width, ds.height))
+        self.last_key_opt = list(key_opt)
+        viewpoint_stack = [self.viewpoints[kf_idx] for kf_idx in key_opt][:len(current_window)]
+        window_position = {kf_idx: p for p, kf_idx in enumerate(current_window)}
+        key_set = set(key_opt)
+        random_viewpoint_stack = [v for idx, v in self.viewpoints.items() if idx not in key_set]
         use_net = dynamic_network and g.deform_init
         gaussian_split = False
         shard = self.shard
@@ -483,7 +505,10 @@ class BackEnd:
         # counter) take part only after the first 100 (:337-338,:765-770): the node network warms up alone. A shorter schedule keeps that
         # proportion -- with the literal 100 a 60- or 80-iteration schedule would never step the Gaussians of a new keyframe at all
         # (round 2's demo and test schedules did exactly that: 24 dB on the dynamic sequence against 41 dB on the static one).
-        warm = 100 if iters >= 200 else int(self.config["Training"].get("network_warmup_iters", iters // 2))
+        warm = self.network_warmup(iters)
+        net_params = [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else []
+        if use_net:
+            shard.attach_network(net_params)           # (sharded runs: the network's gradients live in one flat bucket, reduced in place)
         for i in range(iters):
             if i > warm:
                 self.iteration_count += 1                                   # :337-338
@@ -546,16 +571,16 @@ class BackEnd:
                 g.deform.deform.end_iteration()
                 self._delta_cache = None
             # (the Gaussians only step after the network's warm-up, :765-770: before that their gradients are dropped unreduced)
-            shard.reduce_gradients(g.optimizer if i > warm else None, [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else ())
+            shard.reduce_gradients(g.optimizer if i > warm else None, net_params)
             gaussian_split = False
             with torch.no_grad():
                 if prune or i == iters - 1:
-                    self._publish_visibility(current_window, touched_rows)
+                    self._publish_visibility(current_window, touched_rows, n_views=len(views))
                 if prune:
                     self._window_full_bookkeeping(current_window)
                     g.optimizer.zero_grad(set_to_none=True)
                     if use_net:
-                        g.deform.optimizer.zero_grad(set_to_none=True)
+                        shard.zero_network_grads(g.deform.optimizer)
                     self._clear_camera_grads(views + extra)
                     return False
                 for pkg in pkgs:
@@ -568,16 +593,27 @@ class BackEnd:
                 if (self.iteration_count % self.gaussian_reset) == 0 and not update_gaussian and i > warm:
                     self._reset_opacity_of_unseen(pkgs)
                     gaussian_split = True
-                self._pose_updates(viewpoint_stack, current_window)
+                self._pose_updates(viewpoint_stack, current_window, positions=[window_position.get(v.uid) for v in viewpoint_stack])
                 self._clear_camera_grads(extra)
                 if use_net:
                     g.deform.optimizer.step()
-                    g.deform.optimizer.zero_grad(set_to_none=True)
+                    shard.zero_network_grads(g.deform.optimizer)
                 if i > warm:                                                  # :765-770
                     g.optimizer.step()
                     g.update_learning_rate(self.iteration_count)
                 g.optimizer.zero_grad(set_to_none=True)
         return gaussian_split
+
+    def network_warmup(self, iters):
+        """How many iterations of a map(iters) call the node network trains alone before the Gaussians take part (their optimizer step,
+        densification and the iteration counter start at iteration warm + 1). The reference hard-codes ``i > 100`` for its 200-iteration call
+        (:337-338,:765-770); the same literal here for any schedule of 200 iterations or more. INTENTIONAL DEVIATION for shorter schedules
+        (demos, tests): half of the call, or ``Training.network_warmup_iters`` when the configuration sets it -- with the literal 100 a
+        60- or 80-iteration call would never step the Gaussians of a new keyframe at all. The one-iteration calls (prune=True) are not
+        affected either way: iteration 0 never exceeds any warm-up."""
+        if iters >= 200:
+            return 100
+        return int(self.config["Training"].get("network_warmup_iters", iters // 2))
 
     def find_closest_keyframe(self, uid):
         """:299-304."""

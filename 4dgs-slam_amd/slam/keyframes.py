@@ -17,6 +17,7 @@ two-element transfer. The reference walks the window with Python loops and synch
 """
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 
 
@@ -99,3 +100,61 @@ def window_evictions(new_cam, old_cams, new_visibility, old_visibility, cutoff, 
     score = torch.where(alive, score, torch.full_like(score, -float("inf")))
     crowded = torch.where(over & alive.any(), score.argmax(), none)
     return torch.stack([low, crowded])
+
+
+# ---- co-visible older keyframes of the dynamic mapping loop: Camera.keyframe_selection_overlap (utils/camera_utils.py:319-365) ------------
+def backprojected_points(depth, R, T, fx, fy, cx, cy):
+    """World-space points of every pixel with depth > 0 of a keyframe at pose [R | T] (world-to-camera), as get_pointcloud builds them
+    (utils/camera_utils.py:236-265) -- INCLUDING its duplicate filter: the points are rounded to 0.1 mm, their absolute values compared,
+    and every point whose rounded |x|, |y|, |z| coincide with another point's (or with the origin's) is dropped, all copies of it (the
+    reference's comment says "remove points at camera origin"; torch.unique(return_counts) + isin does more than that). [N, 3] on the
+    depth map's device."""
+    depth = torch.as_tensor(depth, dtype=torch.float32)
+    dev = depth.device
+    v, u = torch.where(depth > 0)
+    z = depth[v, u]
+    cam = torch.stack(((u - cx) / fx * z, (v - cy) / fy * z, z), dim=-1)
+    R = torch.as_tensor(R, dtype=torch.float32, device=dev)
+    T = torch.as_tensor(T, dtype=torch.float32, device=dev)
+    pts = (cam - T) @ R                                          # c2w = [R^T | -R^T T]:  R^T (p - T), row-vector form
+    A = torch.abs(torch.round(pts, decimals=4))
+    _, idx, counts = torch.cat([A, torch.zeros((1, 3), device=dev)], dim=0).unique(dim=0, return_inverse=True, return_counts=True)
+    keep = counts[idx[:A.shape[0]]] == 1
+    return pts[keep]
+
+
+def overlap_fractions(points, Rs, Ts, fx, fy, cx, cy, width, height, edge=20):
+    """For K candidate keyframes with poses Rs [K,3,3], Ts [K,3]: the fraction of `points` [N,3] that project inside the image minus an
+    `edge`-pixel border, in front of the camera (:339-355) -- ONE batched projection, a [K] float32 device tensor."""
+    pc = torch.einsum("kij,nj->kni", Rs, points) + Ts[:, None, :]                 # [K, N, 3] camera-frame points
+    z = pc[..., 2] + 1e-5
+    px, py = (fx * pc[..., 0] + cx * pc[..., 2]) / z, (fy * pc[..., 1] + cy * pc[..., 2]) / z
+    inside = (px < width - edge) & (px > edge) & (py < height - edge) & (py > edge) & (z > 0)
+    return inside.sum(dim=1) / points.shape[0]
+
+
+def keyframe_selection_overlap(newest, viewpoints, time, intrinsics, pose_window=3, permutation=None):
+    """Camera.keyframe_selection_overlap(dataset, viewpoints, time) of keyframe `newest` (utils/camera_utils.py:319-365): the keyframes with
+    id < `time`, ordered by the fraction of `newest`'s depth samples they see (descending, ties in the dictionary's order), those with a
+    fraction of zero dropped, then a random permutation of that list cut to 8 - pose_window entries. The reference permutes with numpy's
+    global generator (``np.random.permutation``); here the default draw comes from torch's CPU generator like every other random choice of
+    the back-end (the ranks of a sharded run are seeded alike through torch.manual_seed) -- pass ``permutation=np.random.permutation`` for
+    the reference's stream. intrinsics = (fx, fy, cx, cy, width, height).
+    All candidates are projected in one batched operation on the device of the depth map; ONE host transfer (their fractions)."""
+    fx, fy, cx, cy, width, height = intrinsics
+    ids = [k for k in viewpoints if k < time]
+    if not ids:
+        return []
+    depth = newest.depth_device() if hasattr(newest, "depth_device") else torch.as_tensor(newest.depth, dtype=torch.float32)
+    pts = backprojected_points(depth, newest.R, newest.T, fx, fy, cx, cy)
+    if pts.shape[0] == 0:
+        return []
+    dev = pts.device
+    Rs = torch.stack([torch.as_tensor(viewpoints[k].R, dtype=torch.float32).to(dev) for k in ids])
+    Ts = torch.stack([torch.as_tensor(viewpoints[k].T, dtype=torch.float32).to(dev) for k in ids])
+    frac = overlap_fractions(pts, Rs, Ts, fx, fy, cx, cy, width, height).tolist()
+    order = sorted(range(len(ids)), key=lambda i: frac[i], reverse=True)          # (stable: ties keep the dictionary's order, like sorted() there)
+    selected = np.array([ids[i] for i in order if frac[i] > 0.0])
+    if permutation is None:
+        permutation = lambda a: a[torch.randperm(len(a)).numpy()]
+    return [int(k) for k in permutation(selected)[:8 - pose_window]]

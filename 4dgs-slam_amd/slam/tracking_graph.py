@@ -57,8 +57,10 @@ class TrackingGraph:
 
     @staticmethod
     def model_version(g):
-        """Changes whenever the tensors a captured graph points at are replaced."""
-        return tuple(int(t.data_ptr()) for t in (g._xyz, g._scaling, g._rotation, g._opacity, g._features_dc)) + (int(g._xyz.shape[0]),)
+        """Changes whenever what a captured graph (or the snapshot an eager tracker took) depends on is replaced: the parameter tensors, the SH
+        coefficients of higher degree, the active SH degree, the dynamic-subset mask (its storage and its in-place version)."""
+        return (tuple(int(t.data_ptr()) for t in (g._xyz, g._scaling, g._rotation, g._opacity, g._features_dc, g._features_rest, g.dygs))
+                + (int(g._xyz.shape[0]), int(g.active_sh_degree), int(g.dygs._version)))
 
     # ---- per frame -----------------------------------------------------------------------------------------------------
     @torch.no_grad()

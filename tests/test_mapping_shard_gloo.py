@@ -410,3 +410,71 @@ def test_reduce_scatter_exchange_equals_all_reduce_exchange():
             np.testing.assert_allclose(x, z, rtol=1e-5, atol=1e-6)         # ... and equal the single process
     for x, y in zip(got[0]["reduce_scatter"][1], got[1]["reduce_scatter"][1]):
         assert np.array_equal(x, y)                                        # the replicas hold the same parameters after the all-gather
+
+
+# ---- ViewShard.reduce_gradients: packed path (cached bucket, "None stays None") and the attached network bucket; bit-packed visibility rows ----
+def _viewshard_worker(rank, world, port, ret):
+    for p in (REPO, PKG, os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapping_shard import ViewShard
+    shard = ViewShard()
+    g = torch.Generator().manual_seed(1)
+    a, b, c = (torch.nn.Parameter(torch.randn(5, 3, generator=g)), torch.nn.Parameter(torch.randn(4, generator=g)), torch.nn.Parameter(torch.randn(2, 2, generator=g)))
+    opt = torch.optim.Adam([a, b, c], lr=0.1)
+    # packed path: c has no gradient on either rank, b only on rank 1
+    ((a * (rank + 1)).sum()).backward()
+    if rank == 1:
+        (b * 3.0).sum().backward()
+    shard.reduce_gradients(opt)
+    bucket_1 = shard.__dict__["_gauss_pack"][1]
+    packed = (a.grad.clone(), None if b.grad is None else b.grad.clone(), c.grad is None)
+    opt.step()
+    state_has_c = c in opt.state and len(opt.state[c]) > 0
+    opt.zero_grad(set_to_none=True)
+    ((a * 2.0).sum()).backward()
+    shard.reduce_gradients(opt)
+    same_bucket = shard.__dict__["_gauss_pack"][1] is bucket_1                      # cached, not rebuilt per iteration
+    # attached network bucket: gradients accumulate in place, reduced without packing
+    net = [torch.nn.Parameter(torch.ones(3, 2)), torch.nn.Parameter(torch.ones(4))]
+    nb = shard.attach_network(net)
+    views = [p.grad for p in net]
+    ((net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum()).backward()
+    still_views = all(p.grad is v for p, v in zip(net, views))
+    before = shard.collectives
+    shard.reduce_gradients(None, net)
+    attached = (net[0].grad.clone(), net[1].grad.clone(), shard.collectives - before, still_views)
+    shard.zero_network_grads(torch.optim.SGD(net, lr=0.1))
+    zeroed = float(nb.flat.abs().sum()) == 0.0 and all(p.grad is v for p, v in zip(net, views))
+    # bit-packed 0 / 1 rows: 3 rows of 21 flags, owner = index % world
+    rows_all = [(torch.arange(21) % (k + 2) == 0).long() for k in range(3)]
+    got = shard.gather_mask_rows({k: rows_all[k] for k in range(3) if shard.owns(k)}, 3, 21, torch.device("cpu"))
+    rows_ok = all(torch.equal(r, w) for r, w in zip(got, rows_all))
+    N = lambda t: None if t is None else (t.numpy().copy() if torch.is_tensor(t) else t)          # (tensors do not survive the queue once the worker exits)
+    ret.put((rank, tuple(N(t) for t in packed), state_has_c, same_bucket, tuple(N(t) for t in attached), zeroed, rows_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_viewshard_packed_and_attached_network_paths_and_bit_packed_rows():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29250 + (os.getpid() % 40)
+    procs = [ctx.Process(target=_viewshard_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (ret.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        packed, state_has_c, same_bucket, attached, zeroed, rows_ok = got[rank]
+        assert np.array_equal(packed[0], np.full((5, 3), 3.0, np.float32))           # 1 + 2
+        assert packed[1] is not None and np.array_equal(packed[1], np.full((4,), 3.0, np.float32))   # rank 1's gradient reached rank 0
+        assert packed[2] and not state_has_c                                         # no gradient anywhere: stays None, no Adam state created
+        assert same_bucket
+        assert np.array_equal(attached[0], np.full((3, 2), 3.0, np.float32)) and np.array_equal(attached[1], np.full((4,), 30.0, np.float32))
+        assert attached[2] == 1 and attached[3]                                      # ONE collective, on the gradients' own storage
+        assert zeroed and rows_ok

@@ -128,3 +128,43 @@ def test_slam_map_symbols_and_argument_checks():
     assert L.gsr_densify_select(10, None, None, None, 2, None, 0.1, 0.1, 0.1, 0.1, None, None) < 0
     assert L.gsr_densify_apply(10, None, None, 1, 0, 0, 0, 40, None, None, None, 3, None, None, None) < 0
     assert L.gsr_camera_step_launch(None, None) < 0
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_keyframe_selection_overlap_matches_reference(case):
+    """slam.keyframes.keyframe_selection_overlap (one batched projection of the newest keyframe's depth samples into every older keyframe)
+    against the reference's own Camera.keyframe_selection_overlap (utils/camera_utils.py:319-365; tests/golden/make_golden_keyframe_overlap.py):
+    the candidate order the permutation sees, and the selection under the same numpy seed. Case b has the newest keyframe at the identity
+    pose with a centred principal point: get_pointcloud's duplicate filter then drops all but 32 of 2 741 points -- reproduced."""
+    from slam import keyframes as kf
+    K = np.load(os.path.join(REPO, "tests", "golden", "golden_keyframe_overlap.npz"))
+    ids = [int(i) for i in K[case + "_ids"]]
+    cams = {i: types.SimpleNamespace(uid=i, R=torch.tensor(K[case + "_R"][k]), T=torch.tensor(K[case + "_T"][k])) for k, i in enumerate(ids)}
+    me = cams[int(K[case + "_self"])]
+    me.depth = K[case + "_depth"]
+    fx, fy, cx, cy, W, H = K[case + "_intr"]
+    intr = (fx, fy, cx, cy, int(W), int(H))
+    by_overlap = kf.keyframe_selection_overlap(me, cams, int(K[case + "_time"]), intr, pose_window=-100, permutation=lambda a: a)
+    assert by_overlap == [int(v) for v in K[case + "_sorted"]]
+    assert 5 not in by_overlap                                   # the keyframe that looks the other way sees nothing
+    np.random.seed(int(K[case + "_seed"]))
+    assert kf.keyframe_selection_overlap(me, cams, int(K[case + "_time"]), intr, permutation=np.random.permutation) == [int(v) for v in K[case + "_selected"]]
+    torch.manual_seed(3)                                         # the default draw: torch's generator, a permutation of the same candidates
+    mine = kf.keyframe_selection_overlap(me, cams, int(K[case + "_time"]), intr)
+    assert len(mine) == min(5, len(by_overlap)) and set(mine) <= set(by_overlap) and len(set(mine)) == len(mine)
+    assert kf.keyframe_selection_overlap(me, cams, 0, intr) == []     # nothing older than `time`
+    if case == "b":
+        k = ids.index(int(K["b_self"]))
+        pts = kf.backprojected_points(torch.tensor(K["b_depth"]), torch.tensor(K["b_R"][k]), torch.tensor(K["b_T"][k]), fx, fy, cx, cy)
+        assert pts.shape[0] == 32 and int((K["b_depth"] > 0).sum()) == 2741
+
+
+def test_network_warmup_schedule_is_pinned():
+    """BackEnd.network_warmup(iters) -- the reference's literal 100 for its 200-iteration call (utils/slam_backend.py:337-338,
+    :765-770), proportional (an intentional, documented deviation) for shorter schedules, overridable by Training.network_warmup_iters."""
+    from slam.backend import BackEnd
+    cfg = {"Training": {"pose_window": 3, "monocular": False}, "model_params": {"dynamic_model": True}}
+    be = BackEnd(cfg)
+    assert [be.network_warmup(n) for n in (1, 10, 80, 199, 200, 300)] == [0, 5, 40, 99, 100, 100]
+    cfg["Training"]["network_warmup_iters"] = 7
+    assert [be.network_warmup(n) for n in (1, 10, 80, 200)] == [7, 7, 7, 100]        # the reference-length call keeps the reference's literal
