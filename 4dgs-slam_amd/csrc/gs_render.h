@@ -387,9 +387,24 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
 //    every CHUNK entries, so every chunk can be differentiated on its own (details at the state set-up below).
 // Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef GSR_BWD_TRANSPOSE
+#define GSR_BWD_TRANSPOSE 1     // 0: round 3's transposed-butterfly reduction per pair (kept for A/B runs and as the fallback)
+#endif
+constexpr int TB = 8;       // entries per batch of the LDS-transposed reduction
+// value of lane (lane & ~7) + I: the I-th lane of this lane's group of eight (ds_swizzle in bit-mask mode: and_mask 0x18, or_mask I inside
+// each half of the wave; the LDS crossbar moves the data, no LDS memory is touched)
+template <int I>
+__device__ __forceinline__ float row_broadcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (I << 5)));
+}
 constexpr int BB = CHUNK;   // entries per block of the backward kernel
 constexpr int GRP = 64;     // entries per group: the quadrant totals in LDS cover one group at a time
+#if GSR_BWD_TRANSPOSE
+constexpr int PART_STRIDE = 10;   // floats per (quadrant, entry) in s_part: {M1x, M1y, M2xx, M2xy | M2yy, sum q, r, g | b, depth} (40-byte rows: 8-byte aligned pieces)
+#else
 constexpr int PART_STRIDE = 12;   // floats per (quadrant, entry) in s_part: {M1x, M1y, M2xx, M2xy | M2yy, sum q, r, g | b, depth, -, -}
+#endif
 // position of sum k (wave_sum10 slot numbering: 0 s_op, 1 M1x, 2 M1y, 3 M2xx, 4 M2xy, 5 M2yy, 6 r, 7 g, 8 b, 9 depth) inside an s_part row:
 // the order in which the three float4 pieces of the gradient slot consume them
 __device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <= 5 ? k - 1 : k); }
@@ -431,6 +446,15 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     __shared__ unsigned long long s_mask[4][2];
     __shared__ unsigned long long s_proc[4][2];   // [quadrant][64-entry group]: entries whose totals the quadrant wave actually wrote
     __shared__ int s_wmax[4];
+#ifdef GSR_BWD_LDS_PAD
+    __shared__ int s_pad[GSR_BWD_LDS_PAD / 4];    // dev experiment: occupancy at a larger LDS footprint
+    if (header[HDR_FLAGS] == 0xdeadbeefu) s_pad[threadIdx.x] = 1;
+#endif
+#if GSR_BWD_TRANSPOSE
+    // Wave-private transposition area (round 4): the per-(pixel, entry) weights of a batch of TB entries, written with lane = pixel and
+    // read back with lane = (pixel row, entry) -- see the pair loop. Row stride TB + 1 float2: both access patterns are bank-conflict free.
+    __shared__ __attribute__((aligned(16))) float2 s_wq[4][64 * (TB + 1)];
+#endif
 
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
@@ -593,15 +617,129 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         const float tot = wave_sum10_transposed<PART_STRIDE * 4>(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd, proc, jj, part_lane, jj, lds_addr);
         *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + lds_addr) = tot;
     };
+#if GSR_BWD_TRANSPOSE
+    // ---- round 4: the per-entry sums over the quadrant's 64 pixels WITHOUT cross-lane traffic in the pair loop -----------------------------
+    // The reduction above costs a pair 23 VALU instructions + 8 permlane swaps (5-8 issue cycles each, profiles/r02_ubench_issue.json) -- 40 %
+    // of the loop. Instead, a pair only WRITES its two per-pixel weights (q = o G dL_dalpha and wv = alpha T) to a wave-private LDS matrix
+    // [pixel][entry of the batch]; after TB = 8 entries the wave reads the matrix back TRANSPOSED -- lane (row h, entry c) walks the 8 pixels
+    // of quadrant row h for entry c -- and accumulates the ten sums as plain per-lane FMAs: every moment is q times a polynomial in
+    // (dx, dy), dy is constant along a row, so the row needs S0 = sum q, S1 = sum q dx, S2 = sum q dx^2 (M1y = dy S0, M2xy = dy S1,
+    // M2yy = dy^2 S0) and the four colour sums wv * cotangent: 10 instructions per (pixel, entry), i.e. per PAIR (8 lanes share an entry).
+    // The eight rows of an entry are then added with ONE halving butterfly per batch (9 swaps + 12 adds for 8 entries, not per entry).
+    // Sums are formed in a fixed order: bit-reproducible like before (the order differs from round 3's, so the last bits do too).
+    const int c7 = lane & 7, hrow = lane >> 3;
+    // two planes (q, wv) of [pixel][TB + 1] floats: a pair writes one float per plane (ds_write2_b32), the transposed pass reads the values of
+    // two neighbouring pixels with one ds_read2_b32 into a register PAIR -- its arithmetic is packed (v_pk_*: two pixels per instruction)
+    constexpr int PLANE = 64 * (TB + 1);
+    float* const wq_base = reinterpret_cast<float*>(&s_wq[wave][0]);
+    char* const wq_write = reinterpret_cast<char*>(wq_base + lane * (TB + 1));
+    const float* const wq_read = wq_base + hrow * 8 * (TB + 1) + c7;
+    // the cotangents of the eight pixels of this lane's row, fetched ONCE per block from the lanes that own the pixels (ds_swizzle: the LDS
+    // crossbar, no LDS memory), as pixel PAIRS per channel: 32 registers instead of a second LDS matrix
+    f2 grow_r[4], grow_g[4], grow_b[4], grow_d[4];
+#define GSR_ROW_COT(k)                                                                                                                        \
+    grow_r[k] = f2{row_broadcast<2 * k>(gr), row_broadcast<2 * k + 1>(gr)}; grow_g[k] = f2{row_broadcast<2 * k>(gg), row_broadcast<2 * k + 1>(gg)};   \
+    grow_b[k] = f2{row_broadcast<2 * k>(gb), row_broadcast<2 * k + 1>(gb)}; grow_d[k] = f2{row_broadcast<2 * k>(gd), row_broadcast<2 * k + 1>(gd)};
+    GSR_ROW_COT(0) GSR_ROW_COT(1) GSR_ROW_COT(2) GSR_ROW_COT(3)
+#undef GSR_ROW_COT
+    const float x0qf = (float)(tx * TILE_X + (wave & 1) * 8), pyrow = (float)(ty * TILE_Y + (wave >> 1) * 8 + hrow);
+    const uint32_t part_gid = (uint32_t)(((lane >> 5) & 1) * 2 + ((lane >> 4) & 1));                   // which three of the twelve row values this lane ends with
+    char* const part_write = reinterpret_cast<char*>(&s_part[wave][0][0]) + part_gid * 12u;
+    uint32_t jrow = 0;          // lanes with (lane & 7) == c: 16 x the group-relative index of the entry in batch slot c (its LDS row offset)
+    int nslot = 0;              // filled slots of the current batch (uniform)
+    auto bwd_pair_t = [&](int jj, uint32_t row) {
+        const int j = group_base + jj;
+        const float4 A4 = lds_at<float4>(s_a + group_base, row);
+        const float2 B2 = lds_at<float2>(s_b + group_base, row);
+        const f2 d = f2{A4.x, A4.y} - pxy;
+#if GSR_EXACT_MATH
+        const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                            // :684
+        const float G = B2.y * exact_exp(pw);
+        const float alpha = fminf(0.99f, G);                                                  // :688
+        const bool valid = j >= j_thr && pw <= 0.0f && alpha >= 1.0f / 255.0f;              // :678,:685,:689
+#else
+        const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
+        const float G = __builtin_amdgcn_exp2f(pw);
+        const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
+        const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
+#endif
+        if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
+        const float4 C4 = lds_at<float4>(s_c + group_base, row);                              // {r, g, b, depth}
+        const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
+        const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
+#if GSR_EXACT_MATH
+        const float inv1ma = 1.0f / (1.f - av);                                                // :700 true division
+#else
+        const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
+#endif
+        T *= inv1ma;                                                                           // :700
+        const float wv = av * T;                                                               // :701 dchannel_dcolor
+        const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
+        const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
+        const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
+        Sb += wv * cg;
+        const float q = Gv * dL_dalpha;       // = o G dL_dalpha
+        float* const w = reinterpret_cast<float*>(wq_write + nslot * 4);
+        w[0] = q; w[PLANE] = wv;                                                               // one ds_write2_b32
+        jrow = c7 == nslot ? row : jrow;
+        asm("s_bitset1_b64 %0, %1" : "+s"(proc) : "s"(jj));
+        nslot++;
+    };
+    auto flush_batch = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the matrix is wave-private: DS operations of one wave execute in order
+        __builtin_amdgcn_wave_barrier();
+        const float2 mean = lds_at<float2>(s_a + group_base, jrow);
+        const float dxb = mean.x - x0qf, dy = mean.y - pyrow;
+        f2 S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f}, cr = {0.f, 0.f}, cg2 = {0.f, 0.f}, cb = {0.f, 0.f}, cd = {0.f, 0.f};
+        f2 dx2 = {dxb, dxb - 1.0f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                  // pixels 2k, 2k + 1 of the row
+            const float* r = wq_read + 2 * k * (TB + 1);
+            const f2 q2 = {r[0], r[TB + 1]}, w2 = {r[PLANE], r[PLANE + TB + 1]};
+            const f2 tq = q2 * dx2;
+            S0 += q2; S1 += tq; S2 += tq * dx2;
+            cr += grow_r[k] * w2; cg2 += grow_g[k] * w2; cb += grow_b[k] * w2; cd += grow_d[k] * w2;
+            dx2 -= f2{2.0f, 2.0f};
+        }
+        const float s0 = S0.x + S0.y, s1 = S1.x + S1.y, s2 = S2.x + S2.y;
+        // the row's twelve values in s_part order: {M1x, M1y, M2xx | M2xy, M2yy, sum q | r, g, b | depth, -, -}
+        float V[12] = {s1, dy * s0, s2, dy * s1, dy * dy * s0, s0, cr.x + cr.y, cg2.x + cg2.y, cb.x + cb.y, cd.x + cd.y, 0.f, 0.f};
+        // add the eight rows (lane bits 3-5): halve the value set at bits 5 and 4 (a lane keeps 6, then 3 of the 12), plain add at bit 3
+#pragma unroll
+        for (int k = 0; k < 6; k++) { lane_swap32(V[k], V[k + 6]); V[k] += V[k + 6]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lane_swap16(V[k], V[k + 3]); V[k] += V[k + 3]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) V[k] += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(V[k]), 0x128, 0xf, 0xf, false));   // row_ror:8
+        if ((lane & 8) == 0 && c7 < nslot) {
+            float* o = reinterpret_cast<float*>(part_write + (jrow >> 4) * (uint32_t)(PART_STRIDE * 4));
+            o[0] = V[0];
+            if (part_gid != 3u) { o[1] = V[1]; o[2] = V[2]; }        // (the fourth triple is {depth, -, -}: the row ends behind its first value)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nslot = 0;
+    };
+#endif
     for (int sw = 0; sw < 2; sw++) {
         unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
         proc = 0;
         group_base = sw * 64;
+#if GSR_BWD_TRANSPOSE
+        for (int left = (int)__popcll(mk); left > 0; left--) {          // counted: a scalar compare per trip (`while (mk)` compiled to a VALU 64-bit compare)
+            uint32_t row;
+            const int jj = pop_lowest_bit_row16(mk, row);
+            bwd_pair_t(jj, row);
+            if (nslot == TB) flush_batch();
+        }
+        if (nslot) flush_batch();
+#else
         while (mk) {
             uint32_t row;
             const int jj = pop_lowest_bit_row16(mk, row);
             bwd_pair(jj, row);
         }
+#endif
         if (lane == 0) s_proc[wave][sw] = proc;
         FWD_T(tk_pair += FWD_TICK() - tk_mark; tk_mark = FWD_TICK(); n_pairs += (uint32_t)__popcll(lds_mask_uniform(&s_mask[wave][sw]));)
         __syncthreads();
@@ -614,7 +752,13 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if ((s_proc[q][sw] >> lane) & 1ull) {
+#if GSR_BWD_TRANSPOSE
+                    const float2 v0 = *reinterpret_cast<const float2*>(&s_part[q][lane][4 * wave]);                 // 40-byte rows: two 8-byte reads
+                    const float2 v1 = wave < 2 ? *reinterpret_cast<const float2*>(&s_part[q][lane][4 * wave + 2]) : make_float2(0.f, 0.f);
+                    const float4 v = make_float4(v0.x, v0.y, v1.x, v1.y);
+#else
                     const float4 v = *reinterpret_cast<const float4*>(&s_part[q][lane][4 * wave]);
+#endif
                     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                 }
             }
@@ -661,7 +805,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
     render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info);
 }
 
-__global__ void __launch_bounds__(RB) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
+#ifndef GSR_BWD_WAVES
+#define GSR_BWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
                                                         const float* __restrict__ bg, const TileRec* __restrict__ rec,
                                                         const float* __restrict__ final_T,

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewD
                     (const uint32_t*)img.chunk_base, bin.chunk_info);
 }
 
-__global__ void __launch_bounds__(RB) render_bwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg)
+__global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg)
 {
     const ViewSlot& s = t.v[blockIdx.y];
     if (blockIdx.x >= s.cap / (uint32_t)CHUNK + (uint32_t)d.T) return;   // the grid is sized for the largest view (s.cap: this view's num_rendered):
