@@ -48,6 +48,12 @@ def _lib():
         lib.gsr_node_blend_workspace_size_batch.argtypes = [i64, ctypes.c_int32, i]
         lib.gsr_node_blend_backward_batch.restype = i
         lib.gsr_node_blend_backward_batch.argtypes = [ctypes.POINTER(_Blend), i] + [vp] * 15
+        lib.gsr_index_csr_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_index_csr_workspace_size.argtypes = [i, i, i]
+        lib.gsr_index_csr.restype = i
+        lib.gsr_index_csr.argtypes = [i, i, i, vp, vp, vp]
+        lib.gsr_segment_sum.restype = i
+        lib.gsr_segment_sum.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
         _lib_cache = lib
     return _lib_cache
 
@@ -81,6 +87,62 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = 
     if return_nn:
         knn = torch.gather(p2[:, None].expand(-1, N, -1, -1), 2, idx[..., None].expand(-1, -1, -1, D))
     return _KNN(dists, idx, knn)
+
+
+class IndexSets:
+    """S index sets idx [S, E] (int64, values in [0, Nv)) together with their reverse lists (gsr_index_csr): what gather_rows needs to
+    run its backward pass as an ORDERED segment sum. Build it once per index array, use it for every gather through that array."""
+
+    def __init__(self, idx, n_targets):
+        _C._require_device(idx, "idx")
+        if idx.dtype != torch.int64 or idx.dim() != 2:
+            raise ValueError("IndexSets: idx must be an int64 [S, E] device tensor")
+        self.idx = idx.contiguous()
+        self.S, self.E, self.Nv = int(idx.shape[0]), int(idx.shape[1]), int(n_targets)
+        lib = _lib()
+        self.csr = torch.empty((int(lib.gsr_index_csr_workspace_size(self.S, self.E, self.Nv)),), dtype=torch.uint8, device=idx.device)
+        with torch.cuda.device(idx.device):
+            rc = lib.gsr_index_csr(self.S, self.E, self.Nv, self.idx.data_ptr(), self.csr.data_ptr(), _C._stream(idx.device))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_index_csr")
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, sets, set_of_b):
+        # table [B, Nv, C]; out[b, e, :] = table[b, idx[set_of_b[b], e], :]
+        B, Nv, Cn = table.shape
+        idx = sets.idx if set_of_b is None else sets.idx.index_select(0, set_of_b.long())
+        idx = idx if idx.shape[0] == B else idx.expand(B, -1)
+        ctx.sets, ctx.set_of_b, ctx.shape = sets, set_of_b, (B, Nv, Cn)
+        return torch.gather(table, 1, idx[:, :, None].expand(-1, -1, Cn))
+
+    @staticmethod
+    def backward(ctx, g):
+        sets, (B, Nv, Cn) = ctx.sets, ctx.shape
+        g = g.to(torch.float32).contiguous()
+        out = torch.empty((B, Nv, Cn), dtype=torch.float32, device=g.device)
+        lib = _lib()
+        sob = None if ctx.set_of_b is None else ctx.set_of_b.to(torch.int32).contiguous()
+        with torch.cuda.device(g.device):
+            rc = lib.gsr_segment_sum(B, sets.S, sets.E, Cn, Nv, g.data_ptr(), sets.csr.data_ptr(), None if sob is None else sob.data_ptr(), out.data_ptr(),
+                                     _C._stream(g.device))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_segment_sum")
+        return out, None, None
+
+
+def gather_rows(table, sets: IndexSets, set_of_b=None):
+    """out[b, e, :] = table[b, idx[s, e], :] with s = set_of_b[b] (int tensor [B]; None: the one set, or one set per batch element when
+    S == B) -- torch.gather's values, but a BACKWARD pass that adds the incoming rows of a target in a fixed order (gsr_segment_sum) instead of
+    torch's scatter_add with float atomics: bit-reproducible gradients. table [B, Nv, C] fp32 on the device."""
+    if table.dim() != 3 or table.shape[1] != sets.Nv:
+        raise ValueError(f"gather_rows: table {tuple(table.shape)} does not match the index sets ({sets.Nv} targets)")
+    if set_of_b is None and sets.S not in (1, table.shape[0]):
+        raise ValueError("gather_rows: give set_of_b when the number of index sets is neither 1 nor the batch size")
+    if set_of_b is None and sets.S == table.shape[0] and sets.S > 1:
+        set_of_b = torch.arange(sets.S, device=table.device, dtype=torch.int32)
+    return _GatherRows.apply(table, sets, set_of_b)
 
 
 def quaternion_to_matrix(q):

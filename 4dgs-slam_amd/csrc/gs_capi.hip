@@ -1618,19 +1618,60 @@ static int node_bwd_blocks(int64_t n) { return (int)std::min<int64_t>(256, std::
 static size_t node_ws_floats(int64_t n, int32_t m)      // per batch element: block partials + the summed row, a multiple of 64 floats
 {
     const size_t rows = m <= NODE_LDS_MAX ? (size_t)node_bwd_blocks(n) : 1;
-    return (((rows + 1) * (size_t)m * NODE_GRAD) + 63) & ~size_t(63);
+    const size_t atomics_route = (rows + 1) * (size_t)m * NODE_GRAD;
+    const size_t ordered_route = ((size_t)n * NODE_DET_MAX_K + (size_t)m) * NODE_GRAD;        // per-(Gaussian, k) contributions + the summed row
+    return (std::max(atomics_route, ordered_route) + 63) & ~size_t(63);
+}
+static size_t node_ws_shared_bytes(int64_t n, int32_t m)  // once per call (any batch size): order[n K], seg[m][2], cursor -- the reverse lists of nn_idx
+{
+    return (((size_t)n * NODE_DET_MAX_K + 2 * (size_t)m + 64) * sizeof(int) + 255) & ~size_t(255);
 }
 
 size_t gsr_node_blend_workspace_size(int64_t n, int32_t m)
 {
     if (m < 1) return 256;
-    return node_ws_floats(n, m) * sizeof(float) + 256;
+    return node_ws_floats(n, m) * sizeof(float) + node_ws_shared_bytes(n, m) + 512;
 }
 
 size_t gsr_node_blend_workspace_size_batch(int64_t n, int32_t m, int B)
 {
     if (m < 1 || B < 1) return 256;
-    return (size_t)B * node_ws_floats(n, m) * sizeof(float) + 256;
+    return (size_t)B * node_ws_floats(n, m) * sizeof(float) + node_ws_shared_bytes(n, m) + 512;
+}
+
+/* ---- deterministic scatter-add through an index array (include/control_nodes.h) ------------------------------------------------------ */
+size_t gsr_index_csr_workspace_size(int S, int E, int Nv) { return ((size_t)S * ((size_t)E + 2 * (size_t)Nv + 1) * sizeof(int)) + 512; }
+
+static void index_csr_carve(char* workspace, int S, int E, int Nv, int*& order, int*& seg, int*& cursor)
+{
+    int* p = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+    cursor = p; order = p + ((S + 63) & ~63); seg = order + (size_t)S * E;
+}
+
+int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (S < 1 || S > 65535 || E < 0 || Nv < 1 || !workspace || (E > 0 && !idx)) { g_last_error = "gsr_index_csr: invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    int *order, *seg, *cursor;
+    index_csr_carve(workspace, S, E, Nv, order, seg, cursor);
+    GSR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)S * sizeof(int), stream));
+    hipLaunchKernelGGL(index_csr_kernel, dim3((unsigned)((Nv + 3) / 4), (unsigned)S), dim3(256), 0, stream, E, Nv, idx, order, seg, cursor);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B < 0 || S < 1 || E < 0 || C < 1 || Nv < 1 || !csr_workspace || (B > 0 && (!out || (E > 0 && !g)))) { g_last_error = "gsr_segment_sum: invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (B == 0) return 0;
+    int *order, *seg, *cursor;
+    index_csr_carve(const_cast<char*>(csr_workspace), S, E, Nv, order, seg, cursor);
+    const size_t total = (size_t)B * Nv * C;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, B, E, C, Nv, g, (size_t)E * C, (const int*)order, (const int*)seg,
+                       set_of_b, out, (size_t)Nv * C);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int gsr_node_blend_backward(const gsr_node_blend* a, const float* nn_weight, const float* nn_dist, const int64_t* nn_idx,
@@ -1656,18 +1697,38 @@ int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* n
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
     const int total = a->m * NODE_GRAD;
     const bool use_lds = a->m <= NODE_LDS_MAX;
-    const int G = use_lds ? node_bwd_blocks(a->n) : 1;
     const size_t stride = node_ws_floats(a->n, a->m);
-    if (!use_lds || a->n == 0) {
-        for (int b = 0; b < B; b++) GSR_HIP_CHECK(hipMemsetAsync(partial + (size_t)b * stride, 0, (size_t)total * sizeof(float), stream));
+    // K <= 4 (every shipped call): the ordered route -- contributions written per (Gaussian, k), summed per node in the order of the Gaussians
+    // (index_csr_kernel + segment_sum_kernel above): bit-reproducible. GSR_NODE_ATOMICS=1 keeps round 3's LDS-atomic accumulation.
+    static const bool force_atomics = getenv("GSR_NODE_ATOMICS") && getenv("GSR_NODE_ATOMICS")[0] == '1';
+    const bool ordered = a->K <= NODE_DET_MAX_K && a->n > 0 && !force_atomics;
+    float* summed;
+    if (ordered) {
+        const int E = (int)(a->n * a->K);
+        float* contrib = partial;                                  // [B][E][21], batch stride `stride`
+        summed = partial + (size_t)E * NODE_GRAD;
+        char* shared = reinterpret_cast<char*>(partial + (size_t)B * stride);
+        hipLaunchKernelGGL(node_blend_bwd_kernel, dim3((unsigned)node_bwd_blocks(a->n), (unsigned)B), dim3(NODE_BLOCK), 0, stream, *a, nn_weight,
+                           nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, 0, stride, contrib, stride);
+        if (int rc = gsr_index_csr(1, E, a->m, nn_idx, shared, stream_)) return rc;
+        int *order, *seg, *cursor;
+        index_csr_carve(shared, 1, E, a->m, order, seg, cursor);
+        const size_t nthreads = (size_t)B * a->m * NODE_GRAD;
+        hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, B, E, NODE_GRAD, a->m, (const float*)contrib, stride,
+                           (const int*)order, (const int*)seg, (const int*)nullptr, summed, stride);
+    } else {
+        const int G = use_lds ? node_bwd_blocks(a->n) : 1;
+        if (!use_lds || a->n == 0) {
+            for (int b = 0; b < B; b++) GSR_HIP_CHECK(hipMemsetAsync(partial + (size_t)b * stride, 0, (size_t)total * sizeof(float), stream));
+        }
+        if (a->n > 0) {
+            const int blocks = node_bwd_blocks(a->n);
+            hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks, (unsigned)B), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
+                               nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0, stride, (float*)nullptr, (size_t)0);
+        }
+        summed = partial + (size_t)G * total;
+        hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256, (unsigned)B), dim3(256), 0, stream, G, total, (const float*)partial, summed, stride);
     }
-    if (a->n > 0) {
-        const int blocks = node_bwd_blocks(a->n);
-        hipLaunchKernelGGL(node_blend_bwd_kernel, dim3(blocks, (unsigned)B), dim3(NODE_BLOCK), use_lds ? (size_t)total * sizeof(float) : 0, stream, *a, nn_weight,
-                           nn_dist, nn_idx, g_xyz, g_rotation, g_scaling, g_nn_weight, partial, use_lds ? 1 : 0, stride);
-    }
-    float* summed = partial + (size_t)G * total;
-    hipLaunchKernelGGL(node_grad_reduce_kernel, dim3((total + 255) / 256, (unsigned)B), dim3(256), 0, stream, G, total, (const float*)partial, summed, stride);
     hipLaunchKernelGGL(node_grad_finalize_kernel, dim3((a->m + 255) / 256, (unsigned)B), dim3(256), 0, stream, *a, (const float*)summed, g_node_trans, g_node_rot,
                        g_node_scale, g_node_frame, g_node_radius, g_node_weight, stride);
     GSR_HIP_CHECK(hipGetLastError());

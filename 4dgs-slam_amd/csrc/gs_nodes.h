@@ -21,6 +21,7 @@ constexpr int NODE_CHUNK = 4096;          // generic kNN: floats*3 staged per pa
 constexpr int NODE_CHUNK4 = 2048;         // 3-D scans: nodes staged per pass as float4 (32 KB of LDS)
 constexpr int NODE_BATCH = 8;             // LDS reads in flight per lane in the 3-D scan
 constexpr int NODE_GRAD = 21;             // per node: trans 3, rot 4, scale 3, frame 9, radius 1, weight 1
+constexpr int NODE_DET_MAX_K = 4;       // the ordered (bit-reproducible) backward route covers K <= 4: every call of the SLAM loop (K = 3)
 constexpr int NODE_LDS_MAX = 720;         // backward keeps m * 21 floats in LDS up to this many nodes (< 64 KB)
 
 // sorted insertion of (d, j) into the ascending list bd[0..K): strict < for the new entry, so among equal distances the earlier index
@@ -390,12 +391,66 @@ node_blend_fwd_kernel(const gsr_node_blend a_, float* __restrict__ nn_weight, fl
     }
 }
 
-// partial: [gridDim.x][m * NODE_GRAD]; use_lds = 0: every block adds into row 0 with global atomics (caller zeroed it)
+// ---- deterministic scatter-add: the reverse lists of an index array, then ordered segment sums (round 4) ----------------------------------
+// Several backward passes of the dynamic mapping loop are scatter-adds through an index array -- a Gaussian's gradient goes to its K nearest
+// control nodes (node_blend_bwd), a node's to its K nearest neighbours (the ARAP / elastic regularisers' gathers). Float atomics (LDS or
+// global, here or inside torch's index_put / scatter_add backward) add in whatever order the hardware schedules them: the sums differ in the
+// last bits from run to run, and Adam with eps = 1e-15 turns that into visibly different maps. Instead:
+//   index_csr_kernel     one WAVE per (index set s, target v): scans idx[s][0..E) in order, counts its matches, reserves a segment of
+//                        order[s][..] (an integer atomic: WHERE the segment lies varies, its content does not) and writes the matching
+//                        positions e in increasing order;  seg[s][v] = {begin, count}
+//   segment_sum_kernel   one thread per (batch b, target v, channel c): out[b][v][c] = sum over the segment, in that order, of g[b][e][c]
+// -- a fixed summation order, bit-reproducible results.
+__global__ void __launch_bounds__(256)
+index_csr_kernel(const int E, const int Nv, const int64_t* __restrict__ idx, int* __restrict__ order, int* __restrict__ seg, int* __restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6), s = blockIdx.y;
+    if (v >= Nv) return;
+    idx += (size_t)s * E; order += (size_t)s * E;
+    int count = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + lane;
+        count += (int)__popcll(__ballot(e < E && idx[e] == (int64_t)v));
+    }
+    int base = 0;
+    if (lane == 0) base = count ? atomicAdd(&cursor[s], count) : 0;
+    base = __shfl(base, 0, 64);
+    int running = 0;
+    for (int e0 = 0; e0 < E && running < count; e0 += 64) {
+        const int e = e0 + lane;
+        const bool hit = e < E && idx[e] == (int64_t)v;
+        const unsigned long long m = __ballot(hit);
+        if (hit) order[base + running + (int)__popcll(m & ((1ull << lane) - 1ull))] = e;
+        running += (int)__popcll(m);
+    }
+    if (lane == 0) { seg[2 * ((size_t)s * Nv + v)] = base; seg[2 * ((size_t)s * Nv + v) + 1] = count; }
+}
+
+__global__ void __launch_bounds__(256)
+segment_sum_kernel(const int B, const int E, const int C, const int Nv, const float* __restrict__ g, const size_t g_batch_stride,
+                   const int* __restrict__ order, const int* __restrict__ seg, const int* __restrict__ set_of_b, float* __restrict__ out,
+                   const size_t out_batch_stride)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)B * Nv * C) return;
+    const int c = (int)(t % C), v = (int)((t / C) % Nv), b = (int)(t / ((size_t)C * Nv));
+    const int s = set_of_b ? set_of_b[b] : 0;
+    const int begin = seg[2 * ((size_t)s * Nv + v)], count = seg[2 * ((size_t)s * Nv + v) + 1];
+    const int* o = order + (size_t)s * E + begin;
+    const float* gb = g + (size_t)b * g_batch_stride;
+    float acc = 0.f;
+    for (int k = 0; k < count; k++) acc += gb[(size_t)o[k] * C + c];
+    out[(size_t)b * out_batch_stride + (size_t)v * C + c] = acc;
+}
+
+// partial: [gridDim.x][m * NODE_GRAD]; use_lds = 0: every block adds into row 0 with global atomics (caller zeroed it).
+// contrib != nullptr (the deterministic route, K <= 4): nothing is accumulated here; the 21 values a Gaussian sends to its k-th node are
+// WRITTEN to contrib[b][(i K + k)][0..21) and summed per node by index_csr_kernel + segment_sum_kernel over nn_idx.
 __global__ void __launch_bounds__(NODE_BLOCK)
 node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weight, const float* __restrict__ nn_dist,
                       const int64_t* __restrict__ nn_idx, const float* __restrict__ g_xyz, const float* __restrict__ g_rotation,
                       const float* __restrict__ g_scaling, const float* __restrict__ g_nn_weight, float* __restrict__ partial, const int use_lds,
-                      const size_t batch_stride /* floats of workspace per batch element */)
+                      const size_t batch_stride /* floats of workspace per batch element */, float* __restrict__ contrib, const size_t contrib_stride)
 {
     constexpr int KMAX = GSR_BLEND_MAX_K;
     extern __shared__ float s_acc[];                              // [m][NODE_GRAD] when use_lds
@@ -404,14 +459,17 @@ node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weig
     if (g_rotation) g_rotation += (size_t)blockIdx.y * a.n * 4;
     if (g_scaling) g_scaling += (size_t)blockIdx.y * a.n * 3;
     partial += (size_t)blockIdx.y * batch_stride;
+    if (contrib) contrib += (size_t)blockIdx.y * contrib_stride;
     const int K = a.K;
     const int total = a.m * NODE_GRAD;
-    if (use_lds) {
+    if (use_lds && !contrib) {
         for (int e = threadIdx.x; e < total; e += NODE_BLOCK) s_acc[e] = 0.f;
         __syncthreads();
     }
     float* acc = use_lds ? s_acc : partial;
+    float* crow = nullptr;                                         // contrib row of the (Gaussian, k) pair being processed
     auto add = [&](int e, float v) {
+        if (contrib) { crow[e % NODE_GRAD] = v; return; }          // every component is written exactly once per pair (zero rows are pre-filled below)
         if (v == 0.f) return;
         if (use_lds) __hip_atomic_fetch_add(&s_acc[e], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else unsafeAtomicAdd(&acc[e], v);
@@ -438,6 +496,11 @@ node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weig
                 idx[k] = j;
                 w[k] = nn_weight[i * K + k];
                 float g = g_nn_weight ? g_nn_weight[i * K + k] : 0.f;
+                if (contrib) {
+                    crow = contrib + ((size_t)i * K + k) * NODE_GRAD;
+#pragma unroll
+                    for (int c = 0; c < NODE_GRAD; c++) crow[c] = 0.f;
+                }
                 if (blend) {
                     const float* tr = a.node_trans + 3 * (size_t)j;
                     const float* qr = a.node_rot + 4 * (size_t)j;
@@ -487,12 +550,13 @@ node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weig
             if (k < K) {
                 const float du = (G[k] - Gw) * invS;
                 const float r = node_radius_of(a, idx[k]);
+                if (contrib) crow = contrib + ((size_t)i * K + k) * NODE_GRAD;
                 add(idx[k] * NODE_GRAD + 19, du * nw[k] * e[k] * nn_dist[i * K + k] / (r * r * r));      // d e / d r = e d / r^3
                 if (a.node_weight) add(idx[k] * NODE_GRAD + 20, du * e[k]);
             }
         }
     }
-    if (use_lds) {
+    if (use_lds && !contrib) {
         __syncthreads();
         float* row = partial + (size_t)blockIdx.x * total;
         for (int e = threadIdx.x; e < total; e += NODE_BLOCK) row[e] = s_acc[e];

@@ -209,7 +209,9 @@ class ViewShard:
         reduce_statistics()   densification statistics: sum / sum / max over ranks, before densify_and_prune;
         union()               a visibility mask OR-ed over ranks (opacity reset of the Gaussians no view saw);
         gather_rows()         per-view rows (n_touched > 0 of the window keyframes) from their owners to everyone.
-    With one rank (or no process group) every method is a no-op that returns its input."""
+    With one rank (or no process group) every method is a no-op that returns its input. (Round 3 also had replicate_gradients(): loops that
+    every rank runs redundantly stepped on rank 0's gradients, because torch's scatter backward passes were not reproducible. The dynamic
+    branch is bit-reproducible now -- control_nodes.gather_rows, the ordered node-blend backward -- and the broadcast is gone.)"""
 
     def __init__(self, group=None):
         self.group = group
@@ -345,25 +347,6 @@ class ViewShard:
         bits = (packed.to(torch.int32)[:, :, None] // weights) % 2                     # [count, nbytes, 8]
         full = bits.reshape(count, nbytes * 8)[:, :length].long()
         return [full[k] for k in range(count)]
-
-    def replicate_gradients(self, params, src=0):
-        """Every rank takes rank `src`'s gradients of `params`. For loops that every rank runs REDUNDANTLY on the same view (the node
-        network's fit at the first dynamic keyframe): torch's index_put / scatter_add backward passes are not run-to-run deterministic,
-        Adam with eps = 1e-15 turns noise-level differences of near-zero gradients into full-size steps, and replicas that stepped on
-        their own copies drift apart (3e-4 on the network's weights over a 15-frame run)."""
-        if not self.active:
-            return
-        have = [p for p in params if p.grad is not None]
-        if not have:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in have])
-        dist.broadcast(flat, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
-        self.collectives += 1
-        o = 0
-        for p in have:
-            n = p.grad.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p.grad))
-            o += n
 
     def sync_cameras(self, cameras):
         """cameras: the iteration's view list (index = ownership index). Owner -> everyone: R, T, exposure_a, exposure_b."""

@@ -177,8 +177,8 @@ class BackEnd:
             pkg = self._render(viewpoint, deltas)
             loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True, compute_value=self.loss_values)
             loss_init.backward()
-            # (every rank fits the network on this one view: all of them step on rank 0's gradients, see ViewShard.replicate_gradients)
-            self.shard.replicate_gradients([p for grp in g.deform.optimizer.param_groups for p in grp["params"]])
+            # (every rank fits the network on this one view, redundantly: the loop is bit-reproducible since round 4 -- ordered scatter sums in
+            # the node blend's backward and in the regularisers' gathers -- so the replicas stay identical without exchanging anything)
             with torch.no_grad():
                 self._view_stats(pkg)
                 if mapping_iteration % self.init_gaussian_update == 0:           # :209-215 (iteration 0 with the shipped schedule)

@@ -79,6 +79,17 @@ def edge_matrix(verts, nn_idx, keep):
     lead = verts.shape[:-2]
     Nv, K = nn_idx.shape[-2:]
     flat = verts.reshape(-1, verts.shape[-2], 3)
+    if flat.is_cuda and flat.dtype == torch.float32:
+        # device tensors: control_nodes.gather_rows -- the same values, and a backward pass that adds a vertex's incoming edge gradients in a
+        # FIXED order (gsr_index_csr + gsr_segment_sum) where torch.gather's backward is a scatter_add with float atomics (not reproducible)
+        sets_idx = nn_idx.reshape(-1, Nv * K)                                     # one index set per distinct leading index of nn_idx
+        S, B = sets_idx.shape[0], flat.shape[0]
+        sets = control_nodes.IndexSets(sets_idx, Nv)
+        set_of_b = None
+        if S > 1 and S != B:                                                      # nn_idx broadcasts over trailing leading axes of verts (the time samples)
+            set_of_b = torch.arange(S, device=flat.device, dtype=torch.int32).repeat_interleave(B // S)
+        nb = control_nodes.gather_rows(flat, sets, set_of_b).reshape(*lead, Nv, K, 3)
+        return (verts[..., :, None, :] - nb) * keep[..., None]
     # a gather along the vertex axis of the [B, Nv, 3] table itself: its backward scatters into a table of that size (gathering from a
     # view expanded to [B, Nv, Nv, 3] would zero-fill, scatter into and reduce 3 MB per time sample at 512 nodes)
     idx = nn_idx.expand(*lead, Nv, K).reshape(-1, Nv * K, 1).expand(-1, -1, 3)
@@ -114,7 +125,16 @@ def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
 def elastic_error(nodes_t, nn_weight, nn_idx):
     """The body of ControlNodeWarp.elastic_loss (time_utils.py:1160-1165): the variance over time of every edge length to the K nearest
     nodes, normalised by its own detached value, weighted by the RBF weights. nodes_t [..., M, T, 3]; nn_weight / nn_idx [M, K]."""
-    edge_t = (nodes_t[..., nn_idx, :, :] - nodes_t[..., :, None, :, :]).norm(dim=-1)      # [..., M, K, T]
+    if nodes_t.is_cuda and nodes_t.dtype == torch.float32:
+        # (device tensors: the neighbour rows through control_nodes.gather_rows -- advanced indexing's backward is an index_put with float atomics)
+        M, K = nn_idx.shape
+        T = nodes_t.shape[-2]
+        lead = nodes_t.shape[:-3]
+        flat = nodes_t.reshape(-1, M, T * 3)
+        nb = control_nodes.gather_rows(flat, control_nodes.IndexSets(nn_idx.reshape(1, M * K), M)).reshape(*lead, M, K, T, 3)
+        edge_t = (nb - nodes_t[..., :, None, :, :]).norm(dim=-1)                          # [..., M, K, T]
+    else:
+        edge_t = (nodes_t[..., nn_idx, :, :] - nodes_t[..., :, None, :, :]).norm(dim=-1)      # [..., M, K, T]
     var = edge_t.var(dim=-1)
     var = var / (var.detach() + 1e-5)
     return (var * nn_weight).sum(dim=-1).mean(dim=-1)

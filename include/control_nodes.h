@@ -88,6 +88,19 @@ int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* n
                                   float* g_node_trans, float* g_node_rot, float* g_node_scale, float* g_node_frame, float* g_node_radius,
                                   float* g_node_weight, char* workspace, void* stream);
 
+/* ---- deterministic scatter-add through an index array (round 4) ------------------------------------------------------------------------
+ * The backward pass of a gather out[b][e][:] = table[b][idx[s(b)][e]][:] is a scatter-add; torch's scatter_add / index_put backward and any
+ * float-atomic kernel add in hardware order, i.e. not bit-reproducibly. These two calls do it in a FIXED order:
+ *   gsr_index_csr     for S index sets idx [S, E] (int64, values in [0, Nv)): per set and target v the positions e with idx[e] == v, in
+ *                     increasing e, laid out in `workspace` (gsr_index_csr_workspace_size bytes); one wave per (set, target);
+ *   gsr_segment_sum   out[b][v][c] = sum over those positions, in that order, of g[b][e][c]   (g [B, E, C], out [B, Nv, C]; set_of_b [B]
+ *                     int32 names the index set of batch element b, NULL = set 0 for all).
+ * Used by the node blend's backward (a Gaussian's gradient goes to its K nearest nodes; gsr_node_blend_backward* takes this route for K <= 4
+ * by itself) and by the gathers of the ARAP / elastic node regularisers (utils/deform_utils.py:35-42, utils/time_utils.py:1160-1165). */
+size_t gsr_index_csr_workspace_size(int S, int E, int Nv);
+int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, void* stream);
+int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

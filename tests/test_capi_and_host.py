@@ -110,7 +110,25 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert cl.gsr_node_blend_forward_batch(ctypes.byref(blend), 0, *([None] * 7)) == -1 and b"1 <= B" in lib.gsr_last_error()
     assert cl.gsr_node_blend_forward_batch(ctypes.byref(blend), 3, *([None] * 7)) == -1 and b"needs node attributes" in lib.gsr_last_error()
     assert cl.gsr_node_blend_backward_batch(ctypes.byref(blend), 2, *([None] * 15)) == -1 and b"gsr_node_blend_backward_batch" in lib.gsr_last_error()
-    assert cl.gsr_node_blend_workspace_size_batch(1000, 512, 12) >= 12 * (cl.gsr_node_blend_workspace_size(1000, 512) - 256)
+    one, twelve = cl.gsr_node_blend_workspace_size_batch(1000, 512, 1), cl.gsr_node_blend_workspace_size_batch(1000, 512, 12)
+    assert twelve >= 12 * (1000 * 3 + 512) * 21 * 4 and one < twelve < 12 * one          # per element: contributions + summed row; the reverse lists once per call
+    # round 4: ordered scatter sums, the device-side schedule / keyframe slots of the mapping graph, batched camera steps, scheduled Adam
+    cl.gsr_index_csr_workspace_size.restype = ctypes.c_size_t
+    assert cl.gsr_index_csr_workspace_size(7, 5120, 512) >= 7 * (5120 + 2 * 512) * 4
+    assert cl.gsr_index_csr(0, 10, 4, None, None, None) == -1 and b"gsr_index_csr" in lib.gsr_last_error()
+    assert cl.gsr_segment_sum(2, 1, 10, 3, 4, None, None, None, None, None) == -1 and b"gsr_segment_sum" in lib.gsr_last_error()
+    assert cl.gsr_schedule_advance(None, None, 4, 2, None, None) == -1 and b"gsr_schedule_advance" in lib.gsr_last_error()
+    assert cl.gsr_slot_gather(5, None, None, None, 100, None) == -1 and b"gsr_slot_gather" in lib.gsr_last_error()
+    assert cl.gsr_slot_gather(0, None, None, None, 100, None) == 0                        # no slots: nothing to do
+    assert cl.gsr_camera_steps_launch(13, None, None) == -1 and b"0..12 cameras" in lib.gsr_last_error()
+    assert cl.gsr_camera_steps_launch(0, None, None) == 0
+    assert cl.gsr_adam_step_scheduled(1, None, None, None) == -1
+    out2 = (ctypes.c_float * 2)()
+    cl.gsr_adam_coefficients.restype = None
+    cl.gsr_adam_coefficients.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    cl.gsr_adam_coefficients(0.01, 0.9, 0.999, 3, out2)
+    assert abs(out2[0] - 0.01 / (1 - 0.9 ** 3)) < 1e-8 and abs(out2[1] - (1 - 0.999 ** 3) ** -0.5) < 1e-4
+    assert cl.gsr_forward_status_views(None) == 0
 
 
 def test_public_names_and_settings_fields_match_reference():

@@ -266,51 +266,6 @@ def test_two_piece_exchange_equals_single_exchange():
     np.testing.assert_allclose(two[2], one[2], rtol=1e-5, atol=1e-6)
 
 
-def _replicate_worker(rank, world, port, ret):
-    for p in (REPO, PKG, os.path.join(REPO, "tests")):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from mapping_shard import ViewShard
-    shard = ViewShard()
-    torch.manual_seed(5)
-    params = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
-    params[0].grad = torch.full((4, 3), float(rank + 1))
-    params[1].grad = torch.arange(7, dtype=torch.float32) * (rank + 1)          # params[2] has no gradient on either rank: left alone
-    shard.replicate_gradients(params)
-    ret.put((rank, params[0].grad.numpy().copy(), params[1].grad.numpy().copy(), params[2].grad is None, shard.collectives))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_replicate_gradients_gives_every_rank_rank_zeros():
-    """ViewShard.replicate_gradients: loops every rank runs redundantly (the node network's first fit) step on rank 0's gradients, so that
-    non-deterministic backward passes cannot let the replicas drift apart; a no-op in a single process."""
-    ctx = mp.get_context("spawn")
-    ret = ctx.Queue()
-    port = 29950 + (os.getpid() % 40)
-    procs = [ctx.Process(target=_replicate_worker, args=(r, 2, port, ret)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict((r[0], r[1:]) for r in (ret.get(timeout=300) for _ in range(2)))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank in (0, 1):
-        g0, g1, none2, ncoll = got[rank]
-        assert np.array_equal(g0, np.full((4, 3), 1.0, np.float32)) and np.array_equal(g1, np.arange(7, dtype=np.float32)) and none2 and ncoll == 1
-    for p in (REPO, PKG):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    from mapping_shard import ViewShard
-    solo = ViewShard()
-    q = torch.nn.Parameter(torch.ones(3))
-    q.grad = torch.full((3,), 2.0)
-    solo.replicate_gradients([q])
-    assert solo.collectives == 0 and float(q.grad.sum()) == 6.0
-
-
 # ---- SURVEY.md 8e's alternative exchange: reduce-scatter -> Adam on the local 1/N slice -> all-gather of the parameters ----------------------
 class _FlatAdam:
     """Test double of FusedAdam's two entry points on CPU tensors: plain Adam arithmetic on a range of the flat parameter / gradient

@@ -219,4 +219,6 @@ def test_batched_node_network_evaluation_equals_the_direct_one():
     assert torch.allclose(pos, want_pos, rtol=1e-5, atol=1e-6)
     (want_pos.square().sum() + direct(0.25)["d_rotation"].sum() + direct(0.4)["d_scaling"].sum()).backward()
     for a, b in zip(got, cn.network.parameters()):
-        assert (a is None and b.grad is None) or torch.allclose(a, b.grad, rtol=1e-4, atol=1e-6)
+        # (sums over ~2 000 rows in a different order: the absolute slack scales with the gradient's magnitude -- a host with another BLAS
+        # threading, e.g. the GPU box's, needs it)
+        assert (a is None and b.grad is None) or torch.allclose(a, b.grad, rtol=1e-4, atol=1e-6 + 2e-5 * float(b.grad.abs().max()))
