@@ -786,17 +786,174 @@ __device__ __forceinline__ void bitonic_sort_lds_pow2(PaddedKeys keys, uint32_t 
     }
 }
 
+// ---- round 4: the network in REGISTERS, partners fetched across lanes ---------------------------------------------------------------
+// Every stage of the LDS networks above is a round trip through LDS (write, wait, read, wait) and most of them a block barrier; with every
+// tile of the frame sorting at the same moment nothing hides that latency, and the phase is a third of render_fwd's wave lifetime
+// (profiles/r03_phase_cycles.json: 19.5 k of 104 k cycles for ~520 keys). Here a wave OWNS a contiguous block of 64 R keys (R = N / 256 keys
+// per lane, key index e = 64 R wave + 64 r + lane) and keeps them in registers for the whole network:
+//   stride J < 64      the partner sits in another lane of the same wave: its key comes through the LDS crossbar (ds_swizzle xor-J inside
+//                      32 lanes, ds_bpermute for J = 32) -- no LDS memory, no barrier -- and BOTH lanes of a pair compare; one keeps the
+//                      smaller key, the other the larger (mask = compare result XOR a per-stage constant: literal lane masks);
+//   stride 64 .. 32 R  both keys in this thread's registers: compare-exchange;
+//   stride >= 64 R     another wave: one LDS round trip with a block barrier (3 of the 45 stages at 512 keys, 24 barriers before).
+// Same comparator network, same result; keys are unique (the instance id is part of the key), padding keys (~0) compare equal among themselves
+// and stay at the end.
+struct Key64 { uint32_t lo, hi; };
+// m ? a : b per lane with the lane mask in an SGPR pair, as the ONE v_cndmask it is (written as `(m >> lane) & 1 ? a : b` hipcc rebuilds a
+// per-lane bool with five VALU instructions)
+__device__ __forceinline__ uint32_t mask_select(unsigned long long m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ unsigned long long opaque_mask(unsigned long long m)      // a constant the optimiser must keep in SGPRs
+{
+    asm volatile("" : "+s"(m));
+    return m;
+}
+__device__ __forceinline__ bool key_less(const Key64 a, const Key64 b)
+{
+    return (((uint64_t)a.hi << 32) | a.lo) < (((uint64_t)b.hi << 32) | b.lo);
+}
+// value of lane (lane ^ J), VALU only (no LDS-pipe latency): DPP for the strides inside a row of 16 lanes -- quad_perm for 1 and 2, row_ror:8
+// for 8, and 4 = row_half_mirror (lane ^ 7) followed by a reversed quad (lane ^ 3) --, gfx950's half-wave / row swaps for 16 and 32
+template <uint32_t J>
+__device__ __forceinline__ uint32_t lane_xor_value(uint32_t v)
+{
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "lane stride");
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);          // quad_perm:[1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm:[2,3,0,1]
+    else if constexpr (J == 4) {
+        const int m = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);                              // row_half_mirror
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x1B, 0xf, 0xf, false);                                 // quad_perm:[3,2,1,0]
+    } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // r[0] = rows {0, 0, 2, 2}, r[1] = rows {1, 1, 3, 3}
+        return mask_select(opaque_mask(0xFFFF0000FFFF0000ull), r[0], r[1]);         // odd rows read r[0]
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // r[0] = halves {0, 0}, r[1] = halves {1, 1}
+        return mask_select(opaque_mask(0xFFFFFFFF00000000ull), r[0], r[1]);         // the upper half reads r[0]
+    }
+}
+__host__ __device__ constexpr unsigned long long lane_bit_mask(uint32_t bit)      // lanes whose index has `bit` set (bit < 64)
+{
+    unsigned long long m = 0;
+    for (uint32_t l = 0; l < 64; l++) if (l & bit) m |= 1ull << l;
+    return m;
+}
+
+template <uint32_t N, uint32_t R, uint32_t K, uint32_t J, typename KEYS>
+__device__ __forceinline__ void wave_bitonic_stage(Key64 (&v)[R], const uint32_t ebase /* 64 R wave */, KEYS s_keys, const bool active)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if constexpr (J < 64) {
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) {
+            Key64 p;
+            p.lo = lane_xor_value<J>(v[r].lo); p.hi = lane_xor_value<J>(v[r].hi);
+            // keep the larger key iff (e & J != 0) != (e & K != 0): K < 64 -> a literal lane mask, else uniform for this (wave, r)
+            unsigned long long keep_max = lane_bit_mask(J);
+            if constexpr (K < 64) keep_max ^= lane_bit_mask(K);
+            else if (K < N && ((ebase + 64u * r) & K)) keep_max = ~keep_max;
+            const unsigned long long less = __builtin_amdgcn_ballot_w64(key_less(p, v[r]));
+            const unsigned long long take = less ^ keep_max;             // keep-min lanes take a smaller partner, keep-max lanes a not-smaller one
+            // (the lane mask goes straight into v_cndmask: written as `(take >> lane) & 1 ? .. : ..` hipcc rebuilds a per-lane bool with five VALU ops)
+            v[r].lo = mask_select(take, p.lo, v[r].lo); v[r].hi = mask_select(take, p.hi, v[r].hi);
+        }
+    } else if constexpr (J < 64 * R) {
+        constexpr uint32_t m = J / 64;
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) {
+            if (!(r & m)) {
+                const bool asc = K >= N || ((ebase + 64u * r) & K) == 0;
+                const bool swap = key_less(v[r | m], v[r]) == asc;
+                const Key64 a = v[r], b = v[r | m];
+                v[r] = swap ? b : a; v[r | m] = swap ? a : b;
+            }
+        }
+    } else {
+        // another wave holds the partner: through LDS (every thread writes its keys, reads the partner's, keeps one of the two)
+        if (active) {
+#pragma unroll
+            for (uint32_t r = 0; r < R; r++) s_keys[ebase + 64u * r + lane] = ((uint64_t)v[r].hi << 32) | v[r].lo;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (uint32_t r = 0; r < R; r++) {
+                const uint32_t e = ebase + 64u * r + lane;
+                const uint64_t pk = s_keys[e ^ J];
+                const Key64 p{(uint32_t)pk, (uint32_t)(pk >> 32)};
+                const bool keep_max = ((e & J) != 0) != (K < N && (e & K) != 0);
+                const bool t = key_less(p, v[r]) != keep_max;
+                v[r].lo = t ? p.lo : v[r].lo; v[r].hi = t ? p.hi : v[r].hi;
+            }
+        }
+        __syncthreads();
+    }
+}
+template <uint32_t N, uint32_t R, uint32_t K, uint32_t J, typename KEYS>
+__device__ __forceinline__ void wave_bitonic_level(Key64 (&v)[R], const uint32_t ebase, KEYS s_keys, const bool active)
+{
+    if constexpr (J >= 1) {
+        wave_bitonic_stage<N, R, K, J>(v, ebase, s_keys, active);
+        wave_bitonic_level<N, R, K, J / 2>(v, ebase, s_keys, active);
+    }
+}
+template <uint32_t N, uint32_t R, uint32_t K, typename KEYS>
+__device__ __forceinline__ void wave_bitonic_levels(Key64 (&v)[R], const uint32_t ebase, KEYS s_keys, const bool active)
+{
+    if constexpr (K <= N) {
+        wave_bitonic_level<N, R, K, K / 2>(v, ebase, s_keys, active);
+        wave_bitonic_levels<N, R, K * 2>(v, ebase, s_keys, active);
+    }
+}
+// sorts s_keys[0 .. N) (N = 64 .. 1024, a power of two; filled and barriered by the caller) ascending, in place; 256 threads, all must call
+template <uint32_t N, typename KEYS>
+__device__ __forceinline__ void wave_bitonic_sort(KEYS s_keys)
+{
+    constexpr uint32_t R = N >= 256 ? N / 256 : 1;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;   // (uniform: the stage masks live in SGPRs)
+    const uint32_t ebase = 64u * R * wave;
+    const bool active = ebase < N;                       // N < 256: only the first N / 64 waves hold keys (the others still take part in barriers)
+    Key64 v[R];
+#pragma unroll
+    for (uint32_t r = 0; r < R; r++) {
+        const uint64_t k = active ? (uint64_t)s_keys[ebase + 64u * r + lane] : ~0ull;
+        v[r] = Key64{(uint32_t)k, (uint32_t)(k >> 32)};
+    }
+    if constexpr (N > 64 * R) __syncthreads();           // (the cross-wave stages overwrite s_keys)
+    wave_bitonic_levels<N, R, 2>(v, ebase, s_keys, active);
+    if (active) {
+#pragma unroll
+        for (uint32_t r = 0; r < R; r++) s_keys[ebase + 64u * r + lane] = ((uint64_t)v[r].hi << 32) | v[r].lo;
+    }
+    __syncthreads();
+}
+
 // the fused sort of render_fwd_kernel (lists of up to 1024 keys, one block per tile, every tile of the frame sorting at the same time):
 // the phase is bound by its chain of dependent LDS round trips, not by bandwidth or issue, so the register-blocked networks (two
 // stages per round trip) are taken from 256 keys on
+#ifndef GSR_WAVE_SORT
+#define GSR_WAVE_SORT 1     // 0: round 3's LDS networks in the fused sort (A/B runs)
+#endif
 __device__ __forceinline__ void bitonic_sort_lds_pow2_fused(PaddedKeys keys, uint32_t npad)
 {
     switch (npad) {
+#if GSR_WAVE_SORT
+        case 1024: bitonic_sort_lds_reg<1024, 2>(keys); break;
+        case 512: wave_bitonic_sort<512>(keys); break;
+        case 256: wave_bitonic_sort<256>(keys); break;
+        case 128: wave_bitonic_sort<128>(keys); break;
+        case 64: wave_bitonic_sort<64>(keys); break;
+#else
         case 1024: bitonic_sort_lds_reg<1024, 2>(keys); break;
         case 512: bitonic_sort_lds_reg<512, GSR_FUSED_SORT_M>(keys); break;
         case 256: bitonic_sort_lds_reg<256, GSR_FUSED_SORT_M>(keys); break;
         case 128: bitonic_sort_lds<128>(keys); break;
         case 64: bitonic_sort_lds<64>(keys); break;
+#endif
         default: bitonic_sort_block<true>(keys, npad); break;   // < 64
     }
 }

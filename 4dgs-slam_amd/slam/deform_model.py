@@ -424,7 +424,10 @@ class DeformModel:
 
     def train_setting(self, *_):
         groups = [{"params": g["params"], "lr": self.lr, "name": g["name"]} for g in self.deform.trainable_parameters()]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # fused=True on the device: ONE multi-tensor kernel for the ~25 network tensors instead of torch's foreach chain (~14 launches,
+        # 0.14 ms of device time per mapping iteration); the same Adam arithmetic
+        on_device = all(p.is_cuda for g in groups for p in g["params"])
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if on_device else {}))
 
     def step(self, x, time_input, iteration=0, feature=None, motion_mask=None, camera_center=None, time_interval=None, **kw):
         """deform_model.py:32-33."""
