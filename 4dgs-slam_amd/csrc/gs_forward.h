@@ -909,11 +909,11 @@ __device__ __forceinline__ void wave_bitonic_levels(Key64 (&v)[R], const uint32_
         wave_bitonic_levels<N, R, K * 2>(v, ebase, s_keys, active);
     }
 }
-// sorts s_keys[0 .. N) (N = 64 .. 1024, a power of two; filled and barriered by the caller) ascending, in place; 256 threads, all must call
-template <uint32_t N, typename KEYS>
+// sorts s_keys[0 .. N) (N = 64 .. 1024, a power of two; filled and barriered by the caller) ascending, in place; NT threads, all must call
+template <uint32_t N, typename KEYS, uint32_t NT = 256>
 __device__ __forceinline__ void wave_bitonic_sort(KEYS s_keys)
 {
-    constexpr uint32_t R = N >= 256 ? N / 256 : 1;
+    constexpr uint32_t R = N >= NT ? N / NT : 1;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;   // (uniform: the stage masks live in SGPRs)
     const uint32_t ebase = 64u * R * wave;
     const bool active = ebase < N;                       // N < 256: only the first N / 64 waves hold keys (the others still take part in barriers)

@@ -404,24 +404,35 @@ node_blend_fwd_kernel(const gsr_node_blend a_, float* __restrict__ nn_weight, fl
 __global__ void __launch_bounds__(256)
 index_csr_kernel(const int E, const int Nv, const int64_t* __restrict__ idx, int* __restrict__ order, int* __restrict__ seg, int* __restrict__ cursor)
 {
+    // U chunks of 64 entries per trip, all loads of a trip issued before the first compare: a trip costs ONE L2 latency instead of U (the
+    // scan is a chain of dependent loads otherwise: 145 us per mapping iteration before, at 512 targets x 6 000 entries)
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6), s = blockIdx.y;
     if (v >= Nv) return;
     idx += (size_t)s * E; order += (size_t)s * E;
     int count = 0;
-    for (int e0 = 0; e0 < E; e0 += 64) {
-        const int e = e0 + lane;
-        count += (int)__popcll(__ballot(e < E && idx[e] == (int64_t)v));
+    for (int e0 = 0; e0 < E; e0 += 64 * U) {
+        int64_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + 64 * u + lane; w[u] = e < E ? idx[e] : (int64_t)-1; }
+#pragma unroll
+        for (int u = 0; u < U; u++) count += (int)__popcll(__ballot(w[u] == (int64_t)v));
     }
     int base = 0;
     if (lane == 0) base = count ? atomicAdd(&cursor[s], count) : 0;
     base = __shfl(base, 0, 64);
     int running = 0;
-    for (int e0 = 0; e0 < E && running < count; e0 += 64) {
-        const int e = e0 + lane;
-        const bool hit = e < E && idx[e] == (int64_t)v;
-        const unsigned long long m = __ballot(hit);
-        if (hit) order[base + running + (int)__popcll(m & ((1ull << lane) - 1ull))] = e;
-        running += (int)__popcll(m);
+    for (int e0 = 0; e0 < E && running < count; e0 += 64 * U) {
+        int64_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + 64 * u + lane; w[u] = e < E ? idx[e] : (int64_t)-1; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool hit = w[u] == (int64_t)v;
+            const unsigned long long m = __ballot(hit);
+            if (hit) order[base + running + (int)__popcll(m & ((1ull << lane) - 1ull))] = e0 + 64 * u + lane;
+            running += (int)__popcll(m);
+        }
     }
     if (lane == 0) { seg[2 * ((size_t)s * Nv + v)] = base; seg[2 * ((size_t)s * Nv + v) + 1] = count; }
 }

@@ -56,7 +56,8 @@ json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1
 for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "tracking_graph.json", "config3.json", "render_wrapper.json", "slam_demo.json",
              "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json",
              "phase_cycles.json", "phase_cycles_slam_scale.json", "views.json", "views_deltas.json", "views_100k.json", "backend_map.jsonl",
-             "mapping_iteration_launches_dynamic.json", "mapping_iteration_launches_static.json"):
+             "mapping_iteration_launches_dynamic.json", "mapping_iteration_launches_static.json", "dynamic_reproducibility.txt",
+             "bench_two_ranks_one_gpu_gloo.json", "config4_stand_in.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('iterationflow', 'iteration_flow').replace('iterationnodesflow', 'iteration_nodes_flow').replace('iterationnodes', 'iteration_nodes')}"))
