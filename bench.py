@@ -189,6 +189,47 @@ def committed_traffic(kernel="render_bwd"):
     return None, {"file": None, "bench_csrc_sha256": digest}
 
 
+def committed_issue():
+    """What actually bounds the two tile kernels -- instruction issue, not HBM -- from the newest committed counter collection
+    (profiles/r*_tile_kernel_counters.json: SQ passes + rocprofv3's derived metrics of this same workload), quoted under the same digest rule
+    as the traffic figure: VALUBusy, mean resident waves per SIMD, wave-instructions per (quadrant, Gaussian) pair."""
+    import glob
+    digest = csrc_digest()
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_tile_kernel_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        src = {"file": os.path.relpath(f, REPO), "collected_on_csrc_sha256": d.get("csrc_sha256"), "bench_csrc_sha256": digest}
+        if d.get("csrc_sha256") != digest:
+            src["refused"] = "collected on different kernel sources: not quoted"
+            return {"source": src}
+        out = {"source": src, "bound": "SIMD instruction issue (a wave64 VALU instruction occupies its SIMD for >= 2 cycles; a single wave issues one "
+                                       "instruction per ~9 cycles)"}
+        for k in ("render_fwd", "render_bwd"):
+            e = d["kernels"].get(k, {})
+            der = e.get("derived", {})
+            ipw = der.get("instr_per_wave", {})
+            out[k] = {"VALUBusy_percent": e.get("VALUBusy"), "OccupancyPercent": e.get("OccupancyPercent"),
+                      "mean_waves_per_simd": der.get("mean_waves_per_simd"), "valu_busy_2cycle_view": der.get("valu_busy_2cycle_view"),
+                      "wave_instructions_per_wave": {n: ipw.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
+                      "waves": e.get("SQ_WAVES")}
+        # (quadrant, Gaussian) pairs per wave from the cycle-accounting build of the same sources, when it was collected with them
+        pc = f.replace("_tile_kernel_counters.json", "_phase_cycles.json")
+        try:
+            ph = json.load(open(pc))
+            if ph.get("csrc_sha256") == digest:
+                for k, key in (("render_fwd", "pairs"), ("render_bwd", "candidate_pairs")):
+                    pairs = ph[k][key]
+                    ipw = out[k]["wave_instructions_per_wave"]
+                    out[k]["pairs_per_wave"] = pairs
+                    out[k]["wave_instructions_per_pair"] = sum(v for v in ipw.values() if v) / pairs if pairs else None
+        except Exception:
+            pass
+        return out
+    return {"source": {"file": None, "bench_csrc_sha256": digest}}
+
+
 def note(msg):
     """progress on stderr (the JSON line on stdout stays the only stdout output)"""
     if os.environ.get("RANK", "0") == "0":
@@ -524,8 +565,9 @@ def main():
                              "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
                              "whole_step_algorithmic_bytes": b_total, "whole_step_GBps": b_total / (dt / args.steps) / 1e9,
                              "pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None,
-                             "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; profiles/r03_phase_cycles.json): frac is reported "
-                                     "against the HBM roof because north_star asks for it"},
+                             "issue": committed_issue() if workload == "cfg2" and P == CFG2_P else None,
+                             "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; `issue` carries the counters that say so): frac is "
+                                     "reported against the HBM roof because north_star asks for it"},
                 "kernel_us": kern,
             }
             if nospec is not None:

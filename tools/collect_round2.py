@@ -69,5 +69,22 @@ for name in ("bench.json", "bench_under_rocprof.json"):
         b["roofline"]["traffic"] = out["render_bwd_bytes_per_launch"]
         json.dump(b, open(p, "w"))
 subprocess.run([sys.executable, os.path.join(REPO, "tools", "collect_counters.py"), tag, tag], check=True)
+# provenance for bench.py's roofline.issue: the counters belong to the kernel sources they were collected on
+cp = os.path.join(dst, f"{tag}_tile_kernel_counters.json")
+if os.path.exists(cp):
+    c = json.load(open(cp))
+    c["csrc_sha256"], c["head"] = out["csrc_sha256"], out["head"]
+    json.dump(c, open(cp, "w"), indent=1)
+for name in ("phase_cycles.json", "phase_cycles_slam_scale.json"):
+    pp = os.path.join(dst, f"{tag}_{name}")
+    if os.path.exists(pp):
+        c = json.load(open(pp))
+        c["csrc_sha256"], c["head"] = out["csrc_sha256"], out["head"]
+        json.dump(c, open(pp, "w"), indent=1)
+# stdout of a multi-rank bench carries the ranks' transport chatter besides the line: keep the line
+tp = os.path.join(dst, f"{tag}_bench_two_ranks_one_gpu_gloo.json")
+if os.path.exists(tp):
+    lines = [l for l in open(tp).read().splitlines() if l.startswith("{")]
+    open(tp, "w").write((lines[-1] if lines else "") + "\n")
 print(json.dumps({k: (round(v["rocprof_avg_us"], 1) if v["rocprof_avg_us"] else None, int(v["hbm_bytes_per_launch"])) for k, v in out["kernels"].items()}))
 print("render_bwd traffic / algorithmic:", round(out["render_bwd_traffic_over_algorithmic"], 2), " whole step:", round(out["whole_step_traffic_over_algorithmic"], 2))
