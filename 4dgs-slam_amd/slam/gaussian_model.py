@@ -32,6 +32,14 @@ from .ply_io import read_ply, write_ply
 C0 = 0.28209479177387814
 
 
+def np_median(x):
+    """numpy's median of a device tensor as a host float: the mean of the two middle values for an even count (torch.median returns the
+    lower one)."""
+    xs = torch.sort(x.reshape(-1))[0]
+    n = xs.numel()
+    return float((xs[(n - 1) // 2] + xs[n // 2]) * 0.5) if n else float("nan")
+
+
 def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
@@ -146,7 +154,7 @@ class GaussianModel:
         point_size = ds["point_size"]
         if ds.get("adaptive_pointsize", False):
             sensor = cam.depth_device()
-            point_size = min(0.05, point_size * float(torch.median(sensor[sensor > 0.1])))          # :192-194
+            point_size = min(0.05, point_size * np_median(sensor[sensor > 0.1]))                   # :192-194 (np.median: the MEAN of the two middle values)
         depth = depth.contiguous()
         # Open3D: depth_trunc = 100 zeroes everything beyond, project_valid_depth_only keeps d > 0, random_down_sample(1 / factor)
         # keeps int(n / factor) points drawn without replacement (:195-215)

@@ -174,6 +174,46 @@ def test_camera_step_adam_tracks_torch_adam():
         assert not cam.converged()
 
 
+@pytest.mark.parametrize("case", ["aniso", "iso"])
+def test_seed_from_rgbd_matches_the_reference_arithmetic(case):
+    """gsr_seed_from_rgbd against golden_seed.npz: the reference's own create_pcd_from_image / create_pcd_from_image_and_depth
+    (gaussian_model.py:153-255) run under the import harness with stand-ins for Open3D and simple_knn (tests/golden/make_golden_seed.py).
+    PINNED by it: exposure + clamp + byte quantisation of the colours, RGB2SH, the adaptive point size, the world-to-camera convention, the
+    scale rule (clamp, point size, isotropic / repeated), rotations, opacities. NOT pinned (the reference delegates them to packages that
+    are absent here; the stand-ins implement their documented behaviour): Open3D's pinhole back-projection and random_down_sample's draw
+    -- the drawn pixels are recorded and handed to the kernel --, and distCUDA2 (exact 3-NN mean; the kernel's k-NN is tested against
+    oracle/knn_oracle.c separately)."""
+    from slam.camera import Camera, getProjectionMatrix2
+    from slam.gaussian_model import GaussianModel
+    S = np.load(os.path.join(REPO, "tests", "golden", "golden_seed.npz"))
+    g = lambda k: S[f"{case}_{k}"]
+    depth, image = g("depth"), torch.tensor(g("image"), device="cuda")
+    H, W = depth.shape
+    fx, fy, cx, cy = (float(v) for v in g("intr"))
+    proj = getProjectionMatrix2(0.01, 100.0, cx, cy, fx, fy, W, H).transpose(0, 1)
+    cam = Camera(0, image, depth, torch.eye(4), proj, fx, fy, cx, cy, 1.0, 0.8, H, W, 0.0)
+    cam.update_RT(torch.tensor(g("R")), torch.tensor(g("T")))
+    with torch.no_grad():
+        cam.exposure_a.fill_(float(g("exposure")[0]))
+        cam.exposure_b.fill_(float(g("exposure")[1]))
+    cfg = {"Dataset": {"pcd_downsample": 4, "pcd_downsample_init": 2, "point_size": 0.01, "adaptive_pointsize": True, "sensor_type": "depth"}}
+    gm = GaussianModel(0, config=cfg)
+    gm.isotropic = case == "iso"
+    # the adaptive point size as create_pcd_from_image_and_depth computes it on the device (:192-194) equals the reference's numpy median rule
+    from slam.gaussian_model import np_median
+    sensor = cam.depth_device()
+    point_size = min(0.05, 0.01 * np_median(sensor[sensor > 0.1]))
+    assert abs(point_size - float(g("point_size"))) < 1e-8        # (the generator's numpy 2 forms 0.01 * median in fp32, this in double)
+    pix = torch.tensor(g("pix"), dtype=torch.int32, device="cuda")
+    dev_depth = torch.tensor(np.where(depth > 100.0, 0.0, depth).astype(np.float32), device="cuda")
+    xyz, feats, scales, rots, opac = gm.seed_from_pixels(cam, image, dev_depth, pix, point_size)
+    np.testing.assert_allclose(xyz.cpu().numpy(), g("xyz"), atol=2e-5)
+    np.testing.assert_allclose(feats[:, :, 0].cpu().numpy(), g("features_dc"), atol=1e-5)
+    assert feats.shape == (len(g("pix")), 3, 1)
+    np.testing.assert_allclose(scales.cpu().numpy(), g("scales"), atol=2e-5, rtol=1e-5)
+    assert np.array_equal(rots.cpu().numpy(), g("rots")) and np.array_equal(opac.cpu().numpy(), g("opacities"))
+
+
 def test_seed_from_rgbd_matches_restatement():
     """Open3D's create_from_rgbd_image + the reference's attribute initialisation (gaussian_model.py:185-255) restated in numpy."""
     import types
