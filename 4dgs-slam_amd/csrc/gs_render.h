@@ -387,9 +387,6 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
 //    every CHUNK entries, so every chunk can be differentiated on its own (details at the state set-up below).
 // Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef GSR_BWD_TRANSPOSE
-#define GSR_BWD_TRANSPOSE 1     // 0: round 3's transposed-butterfly reduction per pair (kept for A/B runs and as the fallback)
-#endif
 constexpr int TB = 8;       // entries per batch of the LDS-transposed reduction
 // value of lane (lane & ~7) + I: the I-th lane of this lane's group of eight (ds_swizzle in bit-mask mode: and_mask 0x18, or_mask I inside
 // each half of the wave; the LDS crossbar moves the data, no LDS memory is touched)
@@ -399,15 +396,8 @@ __device__ __forceinline__ float row_broadcast(float v)
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (I << 5)));
 }
 constexpr int BB = CHUNK;   // entries per block of the backward kernel
-constexpr int GRP = 64;     // entries per group: the quadrant totals in LDS cover one group at a time
-#if GSR_BWD_TRANSPOSE
+constexpr int GRP = 64;     // entries per group: the staging arrays and the quadrant totals in LDS cover one group at a time
 constexpr int PART_STRIDE = 10;   // floats per (quadrant, entry) in s_part: {M1x, M1y, M2xx, M2xy | M2yy, sum q, r, g | b, depth} (40-byte rows: 8-byte aligned pieces)
-#else
-constexpr int PART_STRIDE = 12;   // floats per (quadrant, entry) in s_part: {M1x, M1y, M2xx, M2xy | M2yy, sum q, r, g | b, depth, -, -}
-#endif
-// position of sum k (wave_sum10 slot numbering: 0 s_op, 1 M1x, 2 M1y, 3 M2xx, 4 M2xy, 5 M2yy, 6 r, 7 g, 8 b, 9 depth) inside an s_part row:
-// the order in which the three float4 pieces of the gradient slot consume them
-__device__ __forceinline__ int part_pos_of_sum(int k) { return k == 0 ? 5 : (k <= 5 ? k - 1 : k); }
 
 __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
@@ -431,30 +421,26 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     FWD_T(tk_search = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     const uint2* __restrict__ sorted = bin.sorted;
     float* __restrict__ partials = reinterpret_cast<float*>(bin.partials);
-    __shared__ float4 s_a[BB];   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
-    __shared__ float4 s_b[BB];   // {C, log2 opacity, instance id bits, opacity}                       (C = -c/2 log2e)
-    __shared__ float4 s_c[BB];   // {r, g, b, depth}
+    __shared__ float4 s_a[GRP];  // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy  (A = -a/2 log2e, B = -b log2e)
+    __shared__ float4 s_b[GRP];  // {C, log2 opacity, -, -}                                             (C = -c/2 log2e)
+    __shared__ float4 s_c[GRP];  // {r, g, b, depth}
     // The three arrays share one index scale, so a pair addresses all of them from ONE VGPR (j * 16 + constant offset): a float2 s_b cost
-    // the loop a second shift + move per pair. The per-entry epilogue needs the unscaled conic: it undoes the scaling of A, B, C (one
-    // rounding, <= 1.5 ulp on the factor of dL_dmean2D; the exact-math build stages the conic unscaled) instead of parking a second
-    // copy in 2 KiB of LDS; re-reading the Gaussian's record there was measured too: +14 MB of fabric traffic per launch.
-    // Quadrant totals of ONE 64-entry group (12 floats per (quadrant, entry): three float4 = the three 16-byte pieces of a slot).
-    // Sized for a group, not for the whole chunk, the block needs 19.6 KiB of LDS instead of 28.8 and eight blocks share a CU
-    // instead of five: a single wave issues one instruction per ~8 cycles on this part (profiles/r02_ubench_issue.json), the SIMD
-    // needs four READY waves to keep its VALU busy, and 42 % of this kernel's wave-cycles are parked on memory or barriers.
+    // the loop a second shift + move per pair.
+    // LDS budget (round 4): the staging arrays hold ONE 64-entry group. Thread t < 128 loads and prepares entry t of the chunk up front
+    // (one global round trip for the whole chunk) but only the first group goes to LDS at once; the threads of wave 1 keep their entry in
+    // twelve registers and store it when the first group's pair loops are done. Together with the transposition area below that is
+    // 31.1 KiB per block: FIVE blocks share a CU. With both groups staged (34.1 KiB, four blocks) the kernel took 102-104 us; the footprint
+    // alone is worth 10 % (profiles/r04_*: half of this kernel's wave-cycles are parked on memory, LDS or barriers, and a single wave issues
+    // one instruction per ~8 cycles, so every resident wave counts). Splitting the TOTALS into 32-entry groups instead was built and
+    // measured: bit-identical, 5 blocks per CU, but four more barriers and twice the partial batches -- 108 us.
+    // Quadrant totals of ONE 64-entry group (10 floats per (quadrant, entry): the values of the three 16-byte pieces of a slot).
     __shared__ __attribute__((aligned(16))) float s_part[4][GRP][PART_STRIDE];
     __shared__ unsigned long long s_mask[4][2];
-    __shared__ unsigned long long s_proc[4][2];   // [quadrant][64-entry group]: entries whose totals the quadrant wave actually wrote
+    __shared__ unsigned long long s_proc[4];      // [quadrant]: entries of the current group whose totals the quadrant wave actually wrote
     __shared__ int s_wmax[4];
-#ifdef GSR_BWD_LDS_PAD
-    __shared__ int s_pad[GSR_BWD_LDS_PAD / 4];    // dev experiment: occupancy at a larger LDS footprint
-    if (header[HDR_FLAGS] == 0xdeadbeefu) s_pad[threadIdx.x] = 1;
-#endif
-#if GSR_BWD_TRANSPOSE
     // Wave-private transposition area (round 4): the per-(pixel, entry) weights of a batch of TB entries, written with lane = pixel and
     // read back with lane = (pixel row, entry) -- see the pair loop. Row stride TB + 1 float2: both access patterns are bank-conflict free.
     __shared__ __attribute__((aligned(16))) float2 s_wq[4][64 * (TB + 1)];
-#endif
 
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
@@ -533,13 +519,10 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         Sb += (Cf.x - ck[1]) * gr + (Cf.y - ck[2]) * gg + (Cf.z - ck[3]) * gb + (Cf.w - ck[4]) * gd;
     }
     const f2 pxy = {pxf, pyf}, g_rg = {gr, gg}, g_bd = {gb, gd};
-    // which of the ten sums this lane ends up holding after the transposed reduction
-    const int fi = wave_sum10_slot_of_lane(lane);
-    const uint32_t part_lane = (uint32_t)(wave * (GRP * PART_STRIDE) + part_pos_of_sum(fi)) * 4u;   // this lane's byte offset into s_part for entry 0 of a group
-    const WaveSelectMasks wsm = wave_select_masks();
 
     FWD_T(tk_state = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     uint32_t qm = 0;
+    float4 st_a = make_float4(0.f, 0.f, 0.f, 0.f), st_b = st_a, st_c = st_a;   // this thread's entry, prepared: what s_a / s_b / s_c hold + {instance id, opacity}
     if (t < m) {
         const int pos = cend - 1 - t;
         const float2 xy = make_float2(q0.x, q0.y);
@@ -547,14 +530,15 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
 #pragma unroll
         for (int q = 0; q < 4; q++) if (pos >= s_wmax[q]) qm &= ~(1u << q);   // behind everything this quadrant blended (:678)
-        s_a[t] = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
 #if GSR_EXACT_MATH
-        s_a[t] = make_float4(xy.x, xy.y, co.x, co.y);
-        s_b[t] = make_float4(co.z, co.w, __uint_as_float(e.y), co.w);
+        st_a = make_float4(xy.x, xy.y, co.x, co.y);
+        st_b = make_float4(co.z, co.w, __uint_as_float(e.y), co.w);
 #else
-        s_b[t] = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), co.w);   // log2(opacity): folded into the exponent
+        st_a = make_float4(xy.x, xy.y, -0.5f * LOG2E * co.x, -LOG2E * co.y);
+        st_b = make_float4(-0.5f * LOG2E * co.z, __log2f(co.w), __uint_as_float(e.y), co.w);   // log2(opacity): folded into the exponent
 #endif
-        s_c[t] = make_float4(q2.x, q2.y, q2.z, q0.z);
+        st_c = make_float4(q2.x, q2.y, q2.z, q0.z);
+        if (t < GRP) { s_a[t] = st_a; s_b[t] = st_b; s_c[t] = st_c; }
     }
     // pos < last_contrib (:678)  <=>  j >= cend - last_contrib, with j the index inside this chunk
     const int j_thr = cend - last_contrib;
@@ -569,55 +553,6 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     FWD_T(tk_stage = FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
     unsigned long long proc = 0;
     int group_base = 0;
-    // One (quadrant, entry) pair: entry jj of the current group. (Issuing the LDS reads one iteration ahead was measured: +3 % -- the
-    // extra scalar bookkeeping costs more issue slots than the hidden latency returns; the other resident waves already cover it.)
-    auto bwd_pair = [&](int jj, uint32_t row) {
-        const int j = group_base + jj;
-        const float4 A4 = lds_at<float4>(s_a + group_base, row);
-        const float2 B2 = lds_at<float2>(s_b + group_base, row);
-        const f2 d = f2{A4.x, A4.y} - pxy;
-        // E = o G = exp2(power log2e + log2 o): the opacity rides in the exponent. Everything the pair contributes is a moment of
-        // q = E dL_dalpha (:746-757); dL_dopacity = sum G dL_dalpha = (sum q) / o is rescaled once per entry after the reduction.
-#if GSR_EXACT_MATH
-        const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                            // :684
-        const float G = B2.y * exact_exp(pw);                                                 // o G: the moments below are those of q = o G dL_dalpha as in the fast path
-        const float alpha = fminf(0.99f, G);                                                  // :688
-        const bool valid = j >= j_thr && pw <= 0.0f && alpha >= 1.0f / 255.0f;              // :678,:685,:689
-#else
-        const float pw = d.x * (A4.z * d.x + A4.w * d.y) + (B2.x * d.y * d.y + B2.y);       // :684 (times log2 e) + log2 o
-        const float G = __builtin_amdgcn_exp2f(pw);
-        const float alpha = fminf(0.99f, G);                                                  // :688 (clamp has no gradient mask, Q23)
-        const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
-#endif
-        if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-        const float4 C4 = lds_at<float4>(s_c + group_base, row);                              // {r, g, b, depth}
-        const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
-        const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
-#if GSR_EXACT_MATH
-        const float inv1ma = 1.0f / (1.f - av);                                                // :700 true division
-#else
-        const float inv1ma = __builtin_amdgcn_rcpf(1.f - av);
-#endif
-        T *= inv1ma;                                                                           // :700
-        const float wv = av * T;                                                               // :701 dchannel_dcolor
-        const f2 cgp = f2{C4.x, C4.y} * g_rg + f2{C4.z, C4.w} * g_bd;
-        const float cg = cgp.x + cgp.y;                                                        // colour.dL_dpixel + depth*dL_ddepth
-        const float dL_dalpha = cg * T - Sb * inv1ma;                                          // :718-743, see above
-        Sb += wv * cg;
-        // Everything geometric is a moment of q = o G dL_dalpha over the quadrant (:746-757):
-        //   dL_dopacity = sum G dL_dalpha;  dL_dmean2D = -(a M1x + b M1y, c M1y + b M1x) (x W/2, H/2);
-        //   dL_dconic = -1/2 (M2xx, M2xy, M2yy).  The linear combinations are applied after the reduction.
-        const float q = Gv * dL_dalpha;       // = o G dL_dalpha
-        const float s_op = q;
-        const f2 q1 = d * q;                  // (q dx, q dy)
-        const f2 q2 = d * q1.x;               // (q dx dx, q dx dy)
-        const f2 c_rg = g_rg * wv, c_bd = g_bd * wv;
-        // every lane ends with one of the ten totals and stores it: lanes that share a slot hold the same value
-        uint32_t lds_addr;
-        const float tot = wave_sum10_transposed<PART_STRIDE * 4>(wsm, s_op, q1, q2, q1.y * d.y, c_rg, c_bd, proc, jj, part_lane, jj, lds_addr);
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(&s_part[0][0][0]) + lds_addr) = tot;
-    };
-#if GSR_BWD_TRANSPOSE
     // ---- round 4: the per-entry sums over the quadrant's 64 pixels WITHOUT cross-lane traffic in the pair loop -----------------------------
     // The reduction above costs a pair 23 VALU instructions + 8 permlane swaps (5-8 issue cycles each, profiles/r02_ubench_issue.json) -- 40 %
     // of the loop. Instead, a pair only WRITES its two per-pixel weights (q = o G dL_dalpha and wv = alpha T) to a wave-private LDS matrix
@@ -649,8 +584,8 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     int nslot = 0;              // filled slots of the current batch (uniform)
     auto bwd_pair_t = [&](int jj, uint32_t row) {
         const int j = group_base + jj;
-        const float4 A4 = lds_at<float4>(s_a + group_base, row);
-        const float2 B2 = lds_at<float2>(s_b + group_base, row);
+        const float4 A4 = lds_at<float4>(s_a, row);
+        const float2 B2 = lds_at<float2>(s_b, row);
         const f2 d = f2{A4.x, A4.y} - pxy;
 #if GSR_EXACT_MATH
         const float pw = exact_power(d.x, d.y, A4.z, A4.w, B2.x);                            // :684
@@ -664,7 +599,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         const bool valid = j >= j_thr && pw <= B2.y && alpha >= 1.0f / 255.0f;              // :678,:685 (power <= 0),:689
 #endif
         if (!__any(valid)) return;            // the reference's skip_counter shortcut (:691-697); the entry stays out of `proc`
-        const float4 C4 = lds_at<float4>(s_c + group_base, row);                              // {r, g, b, depth}
+        const float4 C4 = lds_at<float4>(s_c, row);                              // {r, g, b, depth}
         const float av = valid ? alpha : 0.f;                                                 // an invalid pair blends nothing
         const float Gv = valid ? G : 0.f;             // G may be +inf where power > 0: keep it out of the products
 #if GSR_EXACT_MATH
@@ -688,7 +623,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     auto flush_batch = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the matrix is wave-private: DS operations of one wave execute in order
         __builtin_amdgcn_wave_barrier();
-        const float2 mean = lds_at<float2>(s_a + group_base, jrow);
+        const float2 mean = lds_at<float2>(s_a, jrow);
         const float dxb = mean.x - x0qf, dy = mean.y - pyrow;
         f2 S0 = {0.f, 0.f}, S1 = {0.f, 0.f}, S2 = {0.f, 0.f}, cr = {0.f, 0.f}, cg2 = {0.f, 0.f}, cb = {0.f, 0.f}, cd = {0.f, 0.f};
         f2 dx2 = {dxb, dxb - 1.0f};
@@ -720,12 +655,11 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         __builtin_amdgcn_wave_barrier();
         nslot = 0;
     };
-#endif
-    for (int sw = 0; sw < 2; sw++) {
+    for (int sw = 0; sw < BB / GRP; sw++) {
         unsigned long long mk = lds_mask_uniform(&s_mask[wave][sw]);
         proc = 0;
-        group_base = sw * 64;
-#if GSR_BWD_TRANSPOSE
+        group_base = sw * GRP;
+        FWD_T(n_pairs += (uint32_t)__popcll(mk);)
         for (int left = (int)__popcll(mk); left > 0; left--) {          // counted: a scalar compare per trip (`while (mk)` compiled to a VALU 64-bit compare)
             uint32_t row;
             const int jj = pop_lowest_bit_row16(mk, row);
@@ -733,53 +667,45 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
             if (nslot == TB) flush_batch();
         }
         if (nslot) flush_batch();
-#else
-        while (mk) {
-            uint32_t row;
-            const int jj = pop_lowest_bit_row16(mk, row);
-            bwd_pair(jj, row);
-        }
-#endif
-        if (lane == 0) s_proc[wave][sw] = proc;
-        FWD_T(tk_pair += FWD_TICK() - tk_mark; tk_mark = FWD_TICK(); n_pairs += (uint32_t)__popcll(lds_mask_uniform(&s_mask[wave][sw]));)
+        if (lane == 0) s_proc[wave] = proc;
+        FWD_T(tk_pair += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
         __syncthreads();
-        // Group epilogue: add the four quadrants in a fixed order, turn the moments into the reference's gradients and write the
-        // group's instance slots (12 floats, 48 B each). Wave w produces the w-th 16-byte piece of the 64 slots (one ds_read_b128
-        // per quadrant, one 16-byte store); wave 3 has nothing to do.
-        const int j = sw * GRP + lane;
-        if (wave < 3 && j < m) {
-            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Group epilogue, by the wave whose threads prepared the group's entries (wave sw: thread = entry, its conic, opacity and instance
+        // id are still in registers): add the four quadrants in a fixed order, turn the moments into the reference's gradients and write the
+        // entry's instance slot (12 floats, 48 B). Meanwhile wave 1 stages the second group (the first one's rows are dead: every wave has
+        // left its pair loop).
+        if (wave == sw) {
+            if (t < m) {
+                float sum[PART_STRIDE];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if ((s_proc[q][sw] >> lane) & 1ull) {
-#if GSR_BWD_TRANSPOSE
-                    const float2 v0 = *reinterpret_cast<const float2*>(&s_part[q][lane][4 * wave]);                 // 40-byte rows: two 8-byte reads
-                    const float2 v1 = wave < 2 ? *reinterpret_cast<const float2*>(&s_part[q][lane][4 * wave + 2]) : make_float2(0.f, 0.f);
-                    const float4 v = make_float4(v0.x, v0.y, v1.x, v1.y);
-#else
-                    const float4 v = *reinterpret_cast<const float4*>(&s_part[q][lane][4 * wave]);
-#endif
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                for (int k = 0; k < PART_STRIDE; k++) sum[k] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if ((s_proc[q] >> lane) & 1ull) {
+                        const float2* r = reinterpret_cast<const float2*>(&s_part[q][lane][0]);          // 40-byte rows: five 8-byte reads
+#pragma unroll
+                        for (int k = 0; k < PART_STRIDE / 2; k++) { const float2 v = r[k]; sum[2 * k] += v.x; sum[2 * k + 1] += v.y; }
+                    }
                 }
-            }
-            const float4 sb = s_b[j];
-            const float4 sa = s_a[j];
 #if GSR_EXACT_MATH
-            const float4 K4 = make_float4(sa.z, sa.w, sb.x, sb.w);                                           // {conic.x, conic.y, conic.z, opacity}
+                const float4 K4 = make_float4(st_a.z, st_a.w, st_b.x, st_b.w);                                   // {conic.x, conic.y, conic.z, opacity}
 #else
-            const float4 K4 = make_float4(sa.z * (-2.0f / LOG2E), sa.w * (-1.0f / LOG2E), sb.x * (-2.0f / LOG2E), sb.w);
+                // the unscaled conic: undoes the scaling of A, B, C (one rounding, <= 1.5 ulp on the factor of dL_dmean2D)
+                const float4 K4 = make_float4(st_a.z * (-2.0f / LOG2E), st_a.w * (-1.0f / LOG2E), st_b.x * (-2.0f / LOG2E), st_b.w);
 #endif
-            float4 o4;
-            if (wave == 0)          // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
-                o4 = make_float4(-(K4.x * sum.x + K4.y * sum.y) * (0.5f * W), -(K4.z * sum.y + K4.y * sum.x) * (0.5f * H), -0.5f * sum.z, -0.5f * sum.w);
-            else if (wave == 1)     // {M2yy, sum q, r, g} -> dL_dconic.w (:756), dL_dopacity = sum q / o = sum G dL_dalpha (:757; o = 0 blends nowhere), colour r, g (:719)
-                o4 = make_float4(-0.5f * sum.x, K4.w > 0.f ? sum.y / K4.w : 0.f, sum.z, sum.w);
-            else                    // {b, depth} (:719,:729)
-                o4 = make_float4(sum.x, sum.y, 0.f, 0.f);
-            reinterpret_cast<float4*>(partials)[(size_t)__float_as_uint(sb.z) * 3 + wave] = o4;
+                float4* const slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(st_b.z) * 3;
+                // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
+                slot[0] = make_float4(-(K4.x * sum[0] + K4.y * sum[1]) * (0.5f * W), -(K4.z * sum[1] + K4.y * sum[0]) * (0.5f * H), -0.5f * sum[2], -0.5f * sum[3]);
+                // {M2yy, sum q, r, g} -> dL_dconic.w (:756), dL_dopacity = sum q / o = sum G dL_dalpha (:757; o = 0 blends nowhere), colour r, g (:719)
+                slot[1] = make_float4(-0.5f * sum[4], K4.w > 0.f ? sum[5] / K4.w : 0.f, sum[6], sum[7]);
+                slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                                                  // {b, depth} (:719,:729)
+            }
+        } else if (sw == 0 && wave == 1 && t < m) {
+            s_a[lane] = st_a; s_b[lane] = st_b; s_c[lane] = st_c;
         }
-        if (sw == 0) __syncthreads();   // s_part is reused by the second group
         FWD_T(tk_epi += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
+        if (m <= GRP) break;            // a short chunk: no second group
+        if (sw == 0) __syncthreads();   // the second group is staged; s_part and s_proc are free again
     }
 #if GSR_FWD_TIMING
     if (lane == 0 && blockIdx.x < 8192) {
@@ -806,7 +732,7 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
 }
 
 #ifndef GSR_BWD_WAVES
-#define GSR_BWD_WAVES 4
+#define GSR_BWD_WAVES 5
 #endif
 __global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_kernel(int ntiles, int gx, const char* bin_base,
                                                         const uint32_t* __restrict__ header, int W, int H,
