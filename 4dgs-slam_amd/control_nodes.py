@@ -178,7 +178,11 @@ class _NodeBlend(torch.autograd.Function):
                 w, dist, idx, d_xyz, d_rot, d_scale = glue.node_blend_forward(*args, _C._stream(x.device))
             except RuntimeError as e:
                 raise ValueError(str(e)) from e
-            ctx.glue_args, ctx.saved = args, (w, dist, idx)
+            # (w, dist, idx are OUTPUTS: kept through save_for_backward -- as plain attributes of ctx they form a reference cycle output ->
+            # grad_fn -> ctx -> output that only the cyclic collector breaks, and the whole upstream graph, the network's AccumulateGrad
+            # nodes included, lingers until then)
+            ctx.glue_args = args
+            ctx.save_for_backward(w, dist, idx)
             ctx.mark_non_differentiable(dist, idx)
             return w, dist, idx, d_xyz, d_rot, d_scale
         x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius").reshape(-1)
@@ -214,7 +218,8 @@ class _NodeBlend(torch.autograd.Function):
                                             *(o.data_ptr() if o is not None else None for o in outs), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_node_blend_forward")
-        ctx.keep, ctx.scalars, ctx.saved, ctx.glue_args = keep, scalars, (w, dist, idx), None
+        ctx.keep, ctx.scalars, ctx.glue_args = keep, scalars, None
+        ctx.save_for_backward(w, dist, idx)
         ctx.mark_non_differentiable(dist, idx)
         empty = torch.empty(0, device=dev)
         return (w, dist, idx, *(o if o is not None else empty for o in outs))
@@ -222,14 +227,14 @@ class _NodeBlend(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_w, _g_dist, _g_idx, g_xyz, g_rot, g_scale):
         if ctx.glue_args is not None:
-            w, dist, idx = ctx.saved
+            w, dist, idx = ctx.saved_tensors
             some = lambda g: g if g is not None and g.numel() else None
             g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local = _C._glue.node_blend_backward(
                 *ctx.glue_args, w, dist, idx, some(g_w), some(g_xyz), some(g_rot), some(g_scale), _C._stream(w.device))
             return None, None, None, g_radius, g_weight, g_trans, g_nrot, g_nscale, g_local, None, None, None
         keep, sc = ctx.keep, ctx.scalars
         n, m = sc["n"], sc["m"]
-        w, dist, idx = ctx.saved
+        w, dist, idx = ctx.saved_tensors
         dev = w.device
         blend = keep["node_trans"] is not None
         a = _Blend(**sc)

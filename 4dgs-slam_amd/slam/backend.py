@@ -501,6 +501,14 @@ class BackEnd:
         use_net = dynamic_network and g.deform_init
         gaussian_split = False
         shard = self.shard
+        if use_net and not prune:
+            # the normal case -- one process, real keyframes -- runs in the fixed layout of slam/dynamic_graph.py: the same terms as the loop
+            # below with the network's batch laid out by position, and its runs of plain iterations replayed as hipGraphs
+            from . import dynamic_graph
+            if dynamic_graph.eligible(self, viewpoint_stack, random_viewpoint_stack):
+                call = dynamic_graph.DynamicMapping(self, current_window, viewpoint_stack, [window_position.get(v.uid) for v in viewpoint_stack],
+                                                    random_viewpoint_stack, iters, self.network_warmup(iters))
+                return call.execute()
         # The reference runs this loop for 200 iterations and lets the Gaussians (their optimizer step, densification, the iteration
         # counter) take part only after the first 100 (:337-338,:765-770): the node network warms up alone. A shorter schedule keeps that
         # proportion -- with the literal 100 a 60- or 80-iteration schedule would never step the Gaussians of a new keyframe at all

@@ -308,6 +308,68 @@ class ControlNodes(nn.Module):
                                           for i, key in enumerate(full)}}
         self._graph = None
 
+    def begin_iteration_indexed(self, tt, n_full, blend=None):
+        """begin_iteration for samples named by POSITION instead of by host value: `tt` is a device vector of times (float32 [n]); the first
+        `n_full` need every head (and, with `blend` = (x, motion_mask), the Gaussians' deltas), the others only the node positions. The
+        layout is the caller's and fixed -- no sorting, no merging of equal values -- which is what lets the times come from device
+        memory the host never reads (slam/dynamic_graph.py: the random keyframes' times, the regularisers' random samples of a captured
+        iteration). Returns {"d_xyz_all" [n, M, 3], "n_full", "heads" {name: [n_full, M, .]}, "blended" (rows of d_xyz, d_rotation,
+        d_scaling per full sample) or None}."""
+        M, net = self.node_num, self.network
+        n = int(tt.shape[0])
+        xe = _embed(self.nodes.detach(), net.multires)
+        te = _embed(tt.reshape(n, 1), net.t_multires)
+        emb = torch.cat([xe[None].expand(n, M, -1), te[:, None].expand(n, M, -1)], -1)
+        h = net.trunk(emb.reshape(n * M, -1))
+        d_xyz_all = net.gaussian_warp(h).reshape(n, M, 3)
+        it = {"d_xyz_all": d_xyz_all, "n_full": int(n_full), "heads": {}, "blended": None}
+        if n_full:
+            hf = h[:n_full * M]
+            heads = {"d_rotation": net.gaussian_rotation, "d_scaling": net.gaussian_scaling}
+            if net.local_frame:
+                heads["local_rotation"] = net.local_rotation
+            stacked = it["heads"] = {name: head(hf).reshape(n_full, M, -1) for name, head in heads.items()}
+            if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
+                x, motion_mask = blend
+                out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, d_xyz_all[:n_full],
+                                                     stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
+                                                     K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
+                it["blended"] = [t.unbind(0) for t in out]
+        self._batch, self._blended, self._graph = {}, None, None       # ("inside an iteration": _elastic_neighbours keeps its graph until end_iteration)
+        return it
+
+    def regularisers_indexed(self, it, n_window, n_extra, weights, window_samples=(4, 8), extra_samples=(2, 8)):
+        """The ARAP and elastic terms of a dynamic mapping iteration (utils/slam_backend.py:517-524,646-652) from an indexed batch whose
+        position-only samples are laid out view by view, a view's ARAP samples in front of its elastic ones: n_window views with
+        window_samples = (4, 8), then n_extra random keyframes with extra_samples = (2, 8). `weights` [n_window + n_extra]: 1e-3 / 1e-4.
+        The same terms as arap_loss_batch / elastic_loss_batch on lists of host times, read as slices of the batch instead of stacks."""
+        M = self.node_num
+        base = self.nodes.detach()
+        d = it["d_xyz_all"][it["n_full"]:]
+        wa, we = window_samples
+        ea, ee = extra_samples
+        nw = n_window * (wa + we)
+        parts_e, reg = [], 0
+        w = e = None
+        if n_window:
+            w = base + d[:nw].reshape(n_window, wa + we, M, 3)
+            parts_e.append(w[:, wa:])
+        if n_extra:
+            e = base + d[nw:nw + n_extra * (ea + ee)].reshape(n_extra, ea + ee, M, 3)
+            parts_e.append(e[:, ea:])
+        nodes_t = (parts_e[0] if len(parts_e) == 1 else torch.cat(parts_e, 0)).permute(0, 2, 1, 3)             # [V, M, T, 3]
+        nn_weight, nn_idx = self._elastic_neighbours()
+        reg = (elastic_error(nodes_t, nn_weight, nn_idx) * weights).sum()
+        if n_window:
+            seq = w[:, :wa]
+            nn_i, keep = connectivity_from_points(seq[:, 0], K=10)
+            reg = reg + (weights[:n_window] * arap_error(seq, nn_i, keep)).sum()
+        if n_extra:
+            seq = e[:, :ea]
+            nn_i, keep = connectivity_from_points(seq[:, 0], K=10)
+            reg = reg + (weights[n_window:] * arap_error(seq, nn_i, keep)).sum()
+        return reg
+
     def _upload(self, values):
         """A list of host floats as a device vector without blocking: through a small ring of pinned staging buffers (torch.tensor(...,
         device=) is a synchronous pageable copy: ~0.2 ms per call behind a busy queue, once per mapping iteration)."""
@@ -427,7 +489,8 @@ class DeformModel:
         # fused=True on the device: ONE multi-tensor kernel for the ~25 network tensors instead of torch's foreach chain (~14 launches,
         # 0.14 ms of device time per mapping iteration); the same Adam arithmetic
         on_device = all(p.is_cuda for g in groups for p in g["params"])
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True} if on_device else {}))
+        # capturable: the step counters live on the device and the step can be recorded in a hipGraph (slam/dynamic_graph.py); same arithmetic
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True, "capturable": True} if on_device else {}))
 
     def step(self, x, time_input, iteration=0, feature=None, motion_mask=None, camera_center=None, time_interval=None, **kw):
         """deform_model.py:32-33."""

@@ -1,0 +1,484 @@
+"""The DYNAMIC mapping call (utils/slam_backend.py:306-774, BackEnd.map with the control-node network) in a fixed layout, its runs of plain
+iterations as hipGraph replays (second half; slam/mapping_graph.py is the static counterpart).
+
+A dynamic iteration is: node network on ~100 time samples -> node blend at the views' times -> two regularisers on the random samples ->
+multi-view render (window views + 2 random keyframes) -> fused mapping losses -> 2 flow renders per view + flow losses -> ONE backward ->
+statistics -> camera steps -> Adam on the network (and, in the second half of the call, on the Gaussians). Eager: ~370 launches from Python
+and autograd, 6.4 ms of wall time for 5.0 ms of device time (profiles/r04_mapping_iteration_launches_dynamic.json).
+
+What the host decides per iteration in the reference -- and what therefore had to move into device memory before an iteration could be
+recorded once and replayed:
+
+  * which two RANDOM keyframes are rendered (:344-349): two persistent *slots* (camera + ground truth + loss weights, filled by
+    gsr_slot_gather from a device table of the candidates' buffer addresses, slam/mapping_graph.py) -- plus, here, the slot's TIME, its
+    flow PARTNER (the closest earlier keyframe, :299-304,:479-509: a second slot camera) and the pair's flow targets (six image planes,
+    moved by a second gather through the same entry point), and the partner's time;
+  * the random TIME SAMPLES of the two regularisers (:517-519,:646-648; 12 per window view, 10 per random keyframe): drawn on the host
+    for a whole run up front -- the same torch.rand calls in the same order as iteration by iteration -- and stored as a row of the
+    device-side schedule next to the slot indices and Adam's coefficients (gsr_schedule_advance copies row `counter` into the block the
+    iteration reads);
+  * the ORDER of the network's batch: the eager loop (BackEnd.map's body, kept for sharded runs and test doubles) names time samples by
+    their host value, sorts and merges them; here the layout is fixed -- [the window views' and their partners' times, merged and sorted
+    once per call | slot 0's time, its partner's | slot 1's ... | the samples, view by view in drawing order] -- and consumers address
+    rows by position (ControlNodes.begin_iteration_indexed / regularisers_indexed). Same terms, summed in another order.
+
+``iteration()`` is ONE code path: executed directly -- every iteration when ``Training.mapping_graph`` is off, the warm-up iterations of a
+run, the iterations that densify or reset opacities (those replace the model's tensors: they end a run) -- or captured once and replayed.
+Direct and replayed iterations are bit-identical (tests/test_hip_slam.py). The call's two halves (:350-355: the loss weights double on the
+moving pixels in the first half; :337-338,:765-770: the Gaussians only step in the second) are different graphs: a run never crosses the
+boundary. A replayed forward pass that outgrows its binning buffer is detected after the run (sticky overflow counters); the run is then
+undone from a snapshot and repeated directly."""
+import time
+
+import numpy as np
+import torch
+
+from diff_gaussian_rasterization import _C
+import slam_losses
+
+from . import _lib
+from .camera import Camera
+from .deform_model import draw_loss_times, time_key
+from .mapping_graph import CAPTURE_MARGIN_PERMILLE, N_INDEX_WORDS
+
+WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
+
+
+def eligible(be, views, candidates):
+    """Can this map() call run in the fixed layout? (Else BackEnd.map's eager body takes it: sharded runs, test doubles, monocular input,
+    fewer than three nodes, keyframes without a motion mask.)"""
+    g, t = be.gaussians, be.config["Training"]
+    if not t.get("dynamic_fixed_layout", True) or be.shard.active or be.loss_values or t.get("monocular", False):
+        return False
+    if not str(be.device).startswith("cuda") or g.deform is None or not g.deform_init or g.get_xyz.shape[0] == 0:
+        return False
+    if g.deform.deform.node_num < 3 or g.dyn_rows().shape[0] == 0 or not getattr(g.optimizer, "_fused_acc", False):
+        return False
+    return all(isinstance(v, Camera) and v.depth is not None and v.motion_mask is not None for v in list(views) + list(candidates))
+
+
+class _Run:
+    """`rows` consecutive iterations of one phase: their schedule in device memory."""
+    __slots__ = ("i0", "rows", "dyn", "stepping", "with_flow", "flow_weight", "layout", "tables", "todo", "table", "row_words", "coef_lo", "samples_lo",
+                 "n_rest", "current", "count0", "draws")
+
+
+class DynamicMapping:
+    """One BackEnd.map(current_window, iters, dynamic_network=True) call (see the module docstring)."""
+
+    def __init__(self, backend, current_window, views, positions, candidates, iters, warm):
+        be = self.be = backend
+        self.g = be.gaussians
+        self.nodes = self.g.deform.deform
+        self.current_window, self.views, self.positions, self.candidates = list(current_window), list(views), list(positions), list(candidates)
+        self.iters, self.warm = int(iters), int(warm)
+        dev = self.device = self.views[0].device
+        proto = self.views[0]
+        self.H, self.W = int(proto.image_height), int(proto.image_width)
+        self.pixels = self.H * self.W
+        t = be.config["Training"]
+        self.flow_weights = {True: float(t["flow_loss"]), False: float(t.get("flow_loss_fine", t["flow_loss"]))}
+        self.has_flow_data = hasattr(be.dataset, "gt_flow")
+        self.n_slots = min(N_INDEX_WORDS, len(self.candidates))
+        any_flow = self.has_flow_data and max(self.flow_weights.values()) > 0
+        mk = lambda uid: Camera(uid, None, None, torch.eye(4), proto.projection_matrix, proto.fx, proto.fy, proto.cx, proto.cy, proto.FoVx, proto.FoVy,
+                                self.H, self.W, 0.0, None, device=dev)
+        z = lambda c: torch.zeros((c, self.H, self.W), device=dev)
+        self.slots = [mk(-1 - s) for s in range(self.n_slots)]
+        self.slot_ops = [(z(3), z(1), z(1), z(1)) for _ in range(self.n_slots)]
+        self.partner_slots = [mk(-101 - s) for s in range(self.n_slots)] if any_flow else []
+        self.partner_flow = [z(6) for _ in range(self.n_slots)] if any_flow else []
+        self.slot_dst = self._entries([(c, o) for c, o in zip(self.slots, self.slot_ops)])
+        self.partner_dst = self._entries([(c, (f[0:3], f[3:4], f[4:5], f[5:6])) for c, f in zip(self.partner_slots, self.partner_flow)])
+        self._zero6 = None
+        self._layouts, self._tables = {}, {}
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.run, self.graph, self.pkgs = None, None, None
+        self.stats = be.__dict__.setdefault("dynamic_graph_stats", {"runs": 0, "replays": 0, "direct": 0, "special": 0, "redone": 0, "failed": 0})
+
+    @staticmethod
+    def _entries(pairs):
+        if not pairs:
+            return None
+        arr = (_lib.KeyframeEntry * len(pairs))()
+        for d, (cam, ops) in zip(arr, pairs):
+            d.viewmatrix, d.full_proj, d.campos = cam._view.data_ptr(), cam._full.data_ptr(), cam._campos.data_ptr()
+            d.exposure_a, d.exposure_b = cam.exposure_a.data_ptr(), cam.exposure_b.data_ptr()
+            d.gt_image, d.gt_depth, d.w_rgb, d.w_depth = (t.data_ptr() for t in ops)
+        return arr
+
+    # ---- per-call constants --------------------------------------------------------------------------------------------------------------
+    def phase(self, i):
+        """(the loss weights double on the moving pixels, :350-355; the Gaussians take part, :337-338,:765-770)"""
+        return (i < self.iters / 2, i > self.warm)
+
+    def with_flow(self, dyn):
+        return self.has_flow_data and self.flow_weights[dyn] > 0
+
+    def partner_of(self, v):
+        """The keyframe the flow terms of `v` are formed with (:299-304,:479-509), or None."""
+        closest = self.be.find_closest_keyframe(v.uid)
+        if closest is None:
+            return None
+        other = self.be.viewpoints[closest]
+        return other if (v.motion_mask is not None and other.motion_mask is not None) else None
+
+    def flow6(self, v, other):
+        """The constants of a keyframe pair's flow terms as ONE [6, H, W] tensor: planes 0-1 the flow v -> other on v's moving pixels, 2 their
+        mask, 3 the mask of `other`, 4-5 the flow other -> v on other's moving pixels (:486-488,:503-505 mask both sides of the difference by
+        ~motion_mask; with a 0 / 1 mask: the masked target minus the masked rendering). The plane order is the one gsr_slot_gather moves as
+        (gt_image[3], gt_depth, w_rgb, w_depth). One entry per keyframe (its partner never changes), ~7 MB at 640x480, kept for the run."""
+        cache = self.be.__dict__.setdefault("_flow_targets6", {})
+        hit = cache.get((v.uid, other.uid))
+        if hit is None:
+            ds = self.be.dataset
+            m1 = (~v.motion_mask).to(torch.float32)[None]
+            m2 = (~other.motion_mask).to(torch.float32)[None]
+            back = ds.gt_flow(v.uid, other.uid)[0].permute(2, 0, 1) * m1
+            fwd = ds.gt_flow(other.uid, v.uid)[0].permute(2, 0, 1) * m2
+            hit = cache[(v.uid, other.uid)] = torch.cat([back, m1, m2, fwd], 0).to(self.device, torch.float32).contiguous()
+        return hit
+
+    def layout(self, with_flow):
+        hit = self._layouts.get(with_flow)
+        if hit is None:
+            partners = [self.partner_of(v) if with_flow else None for v in self.views]
+            keys = sorted({time_key(v.time) for v in self.views} | {time_key(p.time) for p in partners if p is not None})
+            index = {k: i for i, k in enumerate(keys)}
+            epf = 2 if with_flow else 1                        # batch entries per slot: its time (and its partner's)
+            n_w = len(keys)
+            hit = self._layouts[with_flow] = {
+                "partners": partners, "n_w": n_w, "epf": epf, "n_full": n_w + self.n_slots * epf,
+                "view_idx": [index[time_key(v.time)] for v in self.views] + [n_w + e * epf for e in range(self.n_slots)],
+                "partner_idx": [None if p is None else index[time_key(p.time)] for p in partners],
+                "flow6": [None if p is None else self.flow6(v, p) for v, p in zip(self.views, partners)],
+                "wtimes": torch.tensor(keys, dtype=torch.float32).to(self.device)}
+        return hit
+
+    def tables(self, dyn, with_flow):
+        """Per candidate keyframe, in device memory: the addresses gsr_slot_gather copies from (camera + loss operands; partner camera + flow
+        targets) and the (own, partner) times."""
+        hit = self._tables.get((dyn, with_flow))
+        if hit is None:
+            be, dev = self.be, self.device
+            store, cfg = be.keyframe_operands, be.config
+            rows, prow, times, keep = [], [], [], []
+            for c in self.candidates:
+                ops = store.get(cfg, c, dev, rm_dynamic=False, dynamic=dyn)
+                for tns in ops[:4]:
+                    if tns.dtype != torch.float32 or not tns.is_contiguous():
+                        raise RuntimeError("DynamicMapping: loss operands must be contiguous float32 tensors")
+                keep.append(ops)
+                rows.append([c.world_view_transform.data_ptr(), c.full_proj_transform.data_ptr(), c.camera_center.data_ptr(), c.exposure_a.data_ptr(),
+                             c.exposure_b.data_ptr(), ops[0].data_ptr(), ops[1].data_ptr(), ops[2].data_ptr(), ops[3].data_ptr()])
+                if with_flow:
+                    p = self.partner_of(c)
+                    if p is None:               # no earlier keyframe: the candidate stands in for its partner with an all-zero target and mask --
+                        p = c                   # both flow terms and their gradients are exactly zero
+                        if self._zero6 is None:
+                            self._zero6 = torch.zeros((6, self.H, self.W), device=dev)
+                        f6 = self._zero6
+                    else:
+                        f6 = self.flow6(c, p)
+                    keep.append(f6)
+                    step = self.pixels * 4
+                    prow.append([p.world_view_transform.data_ptr(), p.full_proj_transform.data_ptr(), p.camera_center.data_ptr(), p.exposure_a.data_ptr(),
+                                 p.exposure_b.data_ptr(), f6.data_ptr(), f6.data_ptr() + 3 * step, f6.data_ptr() + 4 * step, f6.data_ptr() + 5 * step])
+                    times.append([time_key(c.time), time_key(p.time)])
+                else:
+                    times.append([time_key(c.time)])
+            up = lambda a, dt: torch.tensor(a, dtype=dt).pin_memory().to(dev, non_blocking=True)
+            hit = self._tables[(dyn, with_flow)] = {
+                "keep": keep, "kf": up(rows, torch.int64) if rows else None, "partner": up(prow, torch.int64) if prow else None,
+                "times": up(times, torch.float32) if times else None}
+        return hit
+
+    # ---- a run's schedule -------------------------------------------------------------------------------------------------------------------
+    def make_run(self, i0, rows, phase):
+        """Draw what the iterations i0 .. i0 + rows - 1 draw, in their order (:344-349 torch.randperm for the random keyframes, then per view
+        the regularisers' torch.rand calls, deform_model.draw_loss_times), and lay it out as the run's device-side schedule."""
+        be, g = self.be, self.g
+        r = _Run()
+        r.i0, r.rows, (r.dyn, r.stepping) = i0, rows, phase
+        r.with_flow = self.with_flow(r.dyn)
+        r.flow_weight = self.flow_weights[r.dyn]
+        r.layout, r.tables = self.layout(r.with_flow), self.tables(r.dyn, r.with_flow)
+        t = be.config["Training"]
+        ti = g.time_interval
+        arap_delta = float(t.get("delta", 5)) * ti                                    # :325,:518
+        nv = len(self.views)
+        r.draws = []
+        for _ in range(rows):
+            extra_idx = [int(c) for c in torch.randperm(len(self.candidates))[:2]]
+            samples = []
+            for k, v in enumerate(self.views + [self.candidates[c] for c in extra_idx]):
+                window = k < nv
+                plan = draw_loss_times(v.time, arap_delta if window else 5 * ti, WINDOW_SAMPLES[0] if window else EXTRA_SAMPLES[0], 5 * ti)
+                samples += [time_key(x) for x in plan["arap"] + plan["elastic"]]
+            r.draws.append((extra_idx, samples))
+        r.n_rest = nv * sum(WINDOW_SAMPLES) + self.n_slots * sum(EXTRA_SAMPLES)
+        opt = g.optimizer
+        r.todo = opt.scheduled_segments() if r.stepping else None
+        n_coef = 2 * len(r.todo) if r.todo else 0
+        r.coef_lo, r.samples_lo = N_INDEX_WORDS, N_INDEX_WORDS + n_coef
+        r.row_words = r.samples_lo + r.n_rest
+        r.count0 = be.iteration_count
+        table = np.zeros((rows, r.row_words), dtype=np.uint32)
+        fl = table.view(np.float32)
+        for j, (extra_idx, samples) in enumerate(r.draws):
+            for s, c in enumerate(extra_idx[:N_INDEX_WORDS]):
+                table[j, s] = c
+            for k, (group, p) in enumerate(r.todo or ()):
+                lr = group["lr"]
+                if j > 0 and group.get("name") == "xyz":          # update_learning_rate(iteration_count) ran after the previous step (GM:492-505)
+                    lr = g.xyz_lr_at(r.count0 + j)
+                fl[j, r.coef_lo + 2 * k], fl[j, r.coef_lo + 2 * k + 1] = opt.coefficients(lr, group["betas"], int(opt.state[p]["step"]) + j + 1)
+            fl[j, r.samples_lo:] = np.asarray(samples, dtype=np.float32)
+        r.table = torch.from_numpy(table.view(np.int32)).pin_memory().to(self.device, non_blocking=True)
+        r.current = torch.zeros(r.row_words, dtype=torch.int32, device=self.device)
+        self.counter.zero_()
+        self.run, self.graph = r, None
+        return r
+
+    # ---- the iteration (one code path: run directly, or captured and replayed) ---------------------------------------------------------------
+    def iteration(self, special=None):
+        """`special` (direct execution only): {"last": bool} for an iteration that may densify / reset opacities -- it decides that on the
+        host like the eager loop and takes a plain optimizer step (the model's tensors may have been replaced)."""
+        be, g, nodes, r, dev = self.be, self.g, self.nodes, self.run, self.device
+        lay, tab = r.layout, r.tables
+        self.pkgs = None            # (the previous iteration's autograd graph dies here, not while the next one is being built)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            _lib.check(L.gsr_schedule_advance(self.counter.data_ptr(), r.table.data_ptr(), r.row_words, r.rows, r.current.data_ptr(), _lib.stream(dev)),
+                       "gsr_schedule_advance")
+            if self.n_slots:
+                _lib.check(L.gsr_slot_gather(self.n_slots, tab["kf"].data_ptr(), r.current.data_ptr(), self.slot_dst, self.pixels, _lib.stream(dev)),
+                           "gsr_slot_gather")
+                if r.with_flow:
+                    _lib.check(L.gsr_slot_gather(self.n_slots, tab["partner"].data_ptr(), r.current.data_ptr(), self.partner_dst, self.pixels,
+                                                 _lib.stream(dev)), "gsr_slot_gather")
+        # ---- the iteration's time samples, in the fixed layout ------------------------------------------------------------------------------
+        parts = [lay["wtimes"]]
+        if self.n_slots:
+            parts.append(tab["times"].index_select(0, r.current[:self.n_slots].long()).reshape(-1))
+        parts.append(r.current.view(torch.float32)[r.samples_lo:r.samples_lo + r.n_rest])
+        it = nodes.begin_iteration_indexed(torch.cat(parts), lay["n_full"], blend=(g.get_dygs_xyz.detach(), g.motion_mask))
+        nv, ne = len(self.views), self.n_slots
+        loss_network = 0 + nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
+        rows = it["blended"]
+        deltas_at = lambda i: (rows[0][i], rows[2][i], rows[1][i])                    # (d_xyz, d_scaling, d_rotation) of full sample i
+        views = self.views + self.slots
+        deltas = [deltas_at(i) for i in lay["view_idx"]]
+        cfg = be.config
+        ops = [be.keyframe_operands.get(cfg, v, dev, rm_dynamic=False, dynamic=r.dyn) for v in self.views]
+        ops += [o + (ops[0][4],) for o in self.slot_ops]
+        rendered = be._render_many(views, deltas)
+        loss_mapping = 0
+        for v, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):
+            loss_mapping = loss_mapping + slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, v.exposure_a,
+                                                                       v.exposure_b, alpha, compute_value=False)
+        if r.with_flow:
+            from gaussian_renderer import render_flow_views
+            requests, pairs = [], []
+            for k, v in enumerate(views):
+                if k < nv:
+                    other, f6 = lay["partners"][k], lay["flow6"][k]
+                    if other is None:
+                        continue
+                    d2 = deltas_at(lay["partner_idx"][k])
+                else:
+                    other, f6 = self.partner_slots[k - nv], self.partner_flow[k - nv]
+                    d2 = deltas_at(lay["view_idx"][k] + 1)
+                (dx1, ds1, dr1), (dx2, ds2, dr2) = deltas[k], d2
+                requests += [(v, other, dx1, dx2, dr1, ds1), (other, v, dx2, dx1, dr2, ds2)]      # this keyframe -> the earlier one, and back
+                pairs.append((f6[0:2], f6[2:3], f6[4:6], f6[3:4]))
+            if requests:
+                flows = render_flow_views(g, requests)
+                loss = 0.0
+                for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
+                    loss = loss + slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
+                                                        channels=2)
+                loss_network = loss_network + loss
+        loss_mapping = loss_mapping + be._isotropic_loss()
+        (loss_mapping + loss_network).backward()
+        nodes.end_iteration()
+        split = False
+        with torch.no_grad():
+            if special is not None and special.get("last"):           # (before a densification changes the row count, like the eager loop)
+                be._publish_visibility(self.current_window, {k: rendered[k]["n_touched"] for k in range(nv)}, n_views=nv)
+            for pkg in rendered:
+                be._view_stats(pkg)
+            if special is not None and r.stepping:
+                count = be.iteration_count
+                update_gaussian = count % be.gaussian_update_every == be.gaussian_update_offset
+                if update_gaussian:
+                    g.densify_and_prune(be.opt_params.densify_grad_threshold, be.gaussian_th, be.gaussian_extent, be.size_threshold)
+                    split = True
+                if count % be.gaussian_reset == 0 and not update_gaussian:
+                    be._reset_opacity_of_unseen(rendered)
+                    split = True
+            be._pose_updates(self.views, self.current_window, positions=self.positions)
+            be._clear_camera_grads(self.slots + self.partner_slots)
+            g.deform.optimizer.step()
+            g.deform.optimizer.zero_grad(set_to_none=True)
+            if r.stepping:                                                    # :765-770
+                if special is None:
+                    g.optimizer.step_scheduled(r.todo, r.current[r.coef_lo:].data_ptr())
+                else:
+                    g.optimizer.step()
+                    g.update_learning_rate(be.iteration_count)
+            g.optimizer.zero_grad(set_to_none=True)
+        self.pkgs = rendered
+        return split
+
+    # ---- executing a run ---------------------------------------------------------------------------------------------------------------
+    def finish(self, n):
+        """Host-side state after `n` plain iterations of the current run: what n eager iterations would have left."""
+        be, g, r = self.be, self.g, self.run
+        be.last_sent += n
+        if r.stepping and n:
+            be.iteration_count += n
+            g.optimizer.advance_steps(r.todo, n)
+            g.update_learning_rate(be.iteration_count)
+
+    def direct(self, n):
+        for _ in range(n):
+            self.iteration()
+        self.stats["direct"] += n
+
+    def warm_up(self, n):
+        """`n` iterations executed directly on a side stream (torch's capture protocol: autograd's stream bookkeeping must have seen the
+        stream family the capture will use)."""
+        dev = self.device
+        s = self.be.graph_streams(dev)[0]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(n):
+                self.iteration()
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+    def capture(self):
+        """(raw capture API on a persistent side stream and ONE private memory pool per back-end: see MappingGraph.capture)"""
+        be, dev = self.be, self.device
+        lazy_before = _C.set_option("lazy", 1)
+        margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+        s = be.graph_streams(dev)[1]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.stream(s):
+                self.graph.capture_begin(pool=be.graph_pool(dev))
+                try:
+                    self.iteration()
+                finally:
+                    self.graph.capture_end()
+        finally:
+            _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
+            _C.set_option("cap_margin_permille", margin_before)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
+
+    def snapshot(self):
+        g, r = self.g, self.run
+        tensors = [p for grp in g.optimizer.param_groups for p in grp["params"]]
+        if r.todo:
+            tensors += [g.optimizer.state[p][k] for _, p in r.todo for k in ("exp_avg", "exp_avg_sq")]
+        net = g.deform.optimizer
+        for grp in net.param_groups:
+            for p in grp["params"]:
+                tensors.append(p)
+                tensors += [v for v in net.state.get(p, {}).values() if torch.is_tensor(v)]
+        tensors += [g.xyz_gradient_accum, g.denom, g.max_radii2D, self.counter]
+        for v in self.views:
+            tensors += [v._R, v._T, v._adam, v._converged, v.exposure_a, v.exposure_b, v.cam_rot_delta, v.cam_trans_delta]
+        with torch.no_grad():
+            self._snap = [(t, t.detach().clone()) for t in tensors]
+
+    def restore(self):
+        with torch.no_grad():
+            for t, c in self._snap:
+                t.detach().copy_(c)
+            for v in self.views:
+                v.refresh_matrices()
+
+    def plain_run(self, rows, last):
+        """A run of plain iterations: replays of one captured iteration when the run is long enough and graphs are on, else direct."""
+        be, r = self.be, self.run
+        use_graph = (be._graphs_enabled() and rows >= be.graph_min_run and not getattr(be, "_dynamic_graph_broken", False)
+                     and (not r.stepping or r.todo is not None))
+        if not use_graph:
+            self.direct(rows)
+            self.finish(rows)
+            return
+        warm = min(be.graph_warmup, rows)
+        self.warm_up(warm)
+        self.stats["direct"] += warm
+        overflow0 = _C.forward_status_views()
+        self.snapshot()
+        try:
+            t0 = time.perf_counter()
+            self.capture()
+            self.stats["capture_ms"] = self.stats.get("capture_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        except Exception as e:        # a capture that fails leaves the iterations done so far valid: finish the run directly, stop capturing
+            be._dynamic_graph_broken = True
+            torch.cuda.synchronize(self.device)
+            self.restore()
+            self.g.optimizer.zero_grad(set_to_none=True)
+            self.g.deform.optimizer.zero_grad(set_to_none=True)
+            be._clear_camera_grads(self.views + self.slots + self.partner_slots)
+            self.stats["failed"] += 1
+            self.stats["last_error"] = f"{type(e).__name__}: {e}"
+            if be.config["Training"].get("mapping_graph") == "strict":
+                raise
+            self.graph = None
+            self.direct(rows - warm)
+            self.finish(rows)
+            return
+        for _ in range(rows - warm):
+            self.graph.replay()
+        torch.cuda.current_stream(self.device).synchronize()
+        if _C.forward_status_views() != overflow0:          # a replayed view outgrew its binning buffer: undo the replays, redo them directly
+            self.restore()
+            self.stats["redone"] += rows - warm
+            self.graph = None
+            self.direct(rows - warm)
+        else:
+            self.stats["replays"] += rows - warm
+            self.stats["runs"] += 1
+        self.finish(rows)
+
+    def execute(self):
+        """All iterations of the call. Returns gaussian_split of the last one (:336,:745)."""
+        be, g = self.be, self.g
+        i, split = 0, False
+        nv = len(self.views)
+        while i < self.iters:
+            ph = self.phase(i)
+            stepping = ph[1]
+
+            def special_at(k, count):          # does iteration k (whose iteration_count would be `count`) densify, reset, or lack Adam moments?
+                return stepping and (count % be.gaussian_update_every == be.gaussian_update_offset or count % be.gaussian_reset == 0)
+
+            count = be.iteration_count + (1 if stepping else 0)
+            needs_state = stepping and g.optimizer.scheduled_segments() is None
+            if special_at(i, count) or needs_state:
+                if stepping:
+                    be.iteration_count += 1                                      # :337-338
+                be.last_sent += 1
+                self.make_run(i, 1, ph)
+                split = self.iteration(special={"last": i == self.iters - 1})
+                self.stats["special"] += 1
+                i += 1
+                continue
+            rows = 0
+            while i + rows < self.iters and self.phase(i + rows) == ph and not special_at(i + rows, count + rows):
+                rows += 1
+            self.make_run(i, rows, ph)
+            self.plain_run(rows, last=(i + rows == self.iters))
+            split = False
+            i += rows
+            if i == self.iters:
+                with torch.no_grad():
+                    be._publish_visibility(self.current_window, {k: self.pkgs[k]["n_touched"] for k in range(nv)}, n_views=nv)
+        self.run, self.graph, self.pkgs, self._snap = None, None, None, None
+        return split
