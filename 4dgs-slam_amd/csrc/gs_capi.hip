@@ -119,7 +119,10 @@ static int debug_sync(int debug, hipStream_t s, const char* what)
 // ... and per view SLOT of the multi-view entry point (slot 0 = the single-view calls): the v-th view of consecutive mapping iterations
 // looks alike, the views of one iteration do not.
 struct SpecState { uint32_t* mailbox = nullptr; uint32_t* mailbox_dev = nullptr; uint32_t seq = 0; size_t last_R_alloc = 0; uint32_t last_max_tile = 0; };
-static thread_local SpecState t_spec[16][2 * MAX_VIEWS + 1];   // [device][0 = single-view calls | 1..V views of a batch | MAX_VIEWS+1.. views of a flow batch]
+constexpr int VIEW_SLOT_GROUPS = 4;                             // gsr_set_option("view_slot_group", g): a caller that splits one iteration's views over several calls names the call
+constexpr int SPEC_SLOTS = 1 + 2 * MAX_VIEWS * VIEW_SLOT_GROUPS;
+static thread_local SpecState t_spec[16][SPEC_SLOTS];   // [device][0 = single-view calls | per group: 1..V views of a batch | MAX_VIEWS+1.. views of a flow batch]
+static thread_local int t_view_slot_group = 0;
 static thread_local SpecState* t_cur = &t_spec[0][0];
 static int select_device_state(int slot = 0)
 {
@@ -143,6 +146,8 @@ static thread_local bool t_speculate = true;
 // bumped: a caller that uses lazy mode polls gsr_forward_status() at a convenient point and repeats the affected work eagerly.
 static thread_local bool t_lazy = false;
 static thread_local int t_cap_margin_permille = 125;   // head room of a speculative binning buffer over the last frame's count (gsr_set_option)
+static thread_local int t_cap_tile_margin_permille = -1;  // head room of the longest tile list (which picks the sort kernels); < 0: max(250, cap_margin_permille)
+static inline unsigned tile_margin() { return (unsigned)(t_cap_tile_margin_permille >= 0 ? t_cap_tile_margin_permille : std::max(250, t_cap_margin_permille)); }
 static thread_local int t_cap_test_shrink_permille = 0; // TEST facility: > 0 lays speculative buffers out for that fraction of the last count (forces overflows)
 static inline size_t spec_capacity(size_t last)
 {
@@ -227,13 +232,24 @@ int gsr_set_option(const char* name, int value)
         if (value >= 0) t_cap_margin_permille = value > 4000 ? 4000 : value;
         return old_margin;
     }
+    if (n == "cap_tile_margin_permille") {
+        const int old_margin = t_cap_tile_margin_permille < 0 ? 1000000 : t_cap_tile_margin_permille;      // 1000000 = "follow cap_margin_permille"
+        if (value >= 1000000) t_cap_tile_margin_permille = -1;
+        else if (value >= 0) t_cap_tile_margin_permille = value > 16000 ? 16000 : value;
+        return old_margin;
+    }
+    if (n == "view_slot_group") {
+        const int old_group = t_view_slot_group;
+        if (value >= 0) t_view_slot_group = value >= VIEW_SLOT_GROUPS ? VIEW_SLOT_GROUPS - 1 : value;
+        return old_group;
+    }
     if (n == "cap_test_shrink_permille") {
         const int old_shrink = t_cap_test_shrink_permille;
         if (value >= 0) t_cap_test_shrink_permille = value > 1000 ? 1000 : value;
         return old_shrink;
     }
     bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
-    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille)"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;
@@ -252,10 +268,25 @@ int gsr_forward_status_views(unsigned int* overflow_count_total)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     unsigned int total = 0;
-    for (int slot = 0; slot < 2 * MAX_VIEWS + 1; slot++)
+    for (int slot = 0; slot < SPEC_SLOTS; slot++)
         if (const uint32_t* mb = t_spec[dev][slot].mailbox) total += __atomic_load_n(&mb[5], __ATOMIC_ACQUIRE);
     if (overflow_count_total) *overflow_count_total = total;
     return 0;
+}
+
+/* Dev: per view slot of this thread and device, 8 words: mailbox R, flags, R_alloc, max tile, seq, overflow count | the host's estimates
+ * last_R_alloc, last_max_tile. out: [slots][8]; returns the number of slots. */
+int gsr_debug_view_slots(unsigned int* out, int max_slots)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    const int n = max_slots < SPEC_SLOTS ? max_slots : SPEC_SLOTS;
+    for (int slot = 0; slot < n; slot++) {
+        const SpecState& s = t_spec[dev][slot];
+        for (int k = 0; k < 6; k++) out[slot * 8 + k] = s.mailbox ? __atomic_load_n(&s.mailbox[k], __ATOMIC_ACQUIRE) : 0u;
+        out[slot * 8 + 6] = (unsigned int)s.last_R_alloc; out[slot * 8 + 7] = s.last_max_tile;
+    }
+    return n;
 }
 
 int gsr_profile_enable(int kernel_mask) { g_prof.mask = (unsigned)kernel_mask; return K_COUNT; }
@@ -413,7 +444,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     const bool speculate = t_speculate && t_last_R_alloc && !debug && P > 0;
     const size_t cap = speculate ? spec_capacity(t_last_R_alloc) : 0;
     // longest tile list the speculative launches are sized for: decides which sort kernels run (and the chunk grid of the long-list sort)
-    const uint32_t want_tile = t_last_max_tile + (uint32_t)((unsigned long long)t_last_max_tile * (unsigned)std::max(250, t_cap_margin_permille) / 1000ull);
+    const uint32_t want_tile = t_last_max_tile + (uint32_t)((unsigned long long)t_last_max_tile * tile_margin() / 1000ull);
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
@@ -606,7 +637,10 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
             g_last_error = "gsr_forward_views: null / inconsistent view descriptor"; return GSR_ERR_INVALID_ARGUMENT;
         }
     }
-    const int slot0 = flow ? MAX_VIEWS + 1 : 1;            // flow batches keep their own capacity estimates: their v-th view is another camera
+    // flow batches keep their own capacity estimates (their v-th view is another camera), and so does every call of an iteration that needs
+    // several (view_slot_group): a slot shared by two calls per iteration sees its estimate flip between two cameras -- eager calls then redo
+    // the view through the single-view path every time, captured ones overflow at every replay
+    const int slot0 = 1 + t_view_slot_group * 2 * MAX_VIEWS + (flow ? MAX_VIEWS : 0);
     const ViewDims d = view_dims(P, width, height);
     read_option_env();
     // the batched path needs a capacity estimate for every slot (the first iteration of a window goes view by view and leaves one)
@@ -627,7 +661,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     memset(&t, 0, sizeof(t));
     uint32_t want_tile = 0;
     for (int v = 0; v < V; v++) want_tile = std::max(want_tile, t_spec[dev][slot0 + v].last_max_tile);
-    want_tile += (uint32_t)((unsigned long long)want_tile * (unsigned)std::max(250, t_cap_margin_permille) / 1000ull);
+    want_tile += (uint32_t)((unsigned long long)want_tile * tile_margin() / 1000ull);
     const uint32_t cap_tile = want_tile <= (uint32_t)SORT_SMALL_CAP ? (uint32_t)SORT_SMALL_CAP
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP

@@ -310,15 +310,23 @@ def render_flow_views(pc, requests, scaling_modifier=1.0):
     out = []
     for lo in range(0, len(requests), _views.MAX_VIEWS):
         part, rs = requests[lo:lo + _views.MAX_VIEWS], settings[lo:lo + _views.MAX_VIEWS]
-        block = torch.zeros((len(part),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
-        points = [block[v].requires_grad_(True) for v in range(len(part))]
-        flows = [(dx1, dx2, ds1, dr1, c1.full_proj_transform, (c2 if c2 is not None else c1).full_proj_transform) for c1, c2, dx1, dx2, dr1, ds1 in part]
-        if len(part) == 1 or not _views.views_supported(rs):           # (cameras of different size / field of view: one call each)
-            out += [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in part]
-            continue
-        res = _views.rasterize_flow_views_raw(rs, pc._xyz, points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, flows)
-        out += [_RenderPackage({"render": o[0], "depth": o[2], "alpha": o[3], "viewspace_points": pts, "radii": o[1]}) for o, pts in zip(res, points)]
+        # (the chunks of one iteration keep separate capacity estimates per view: include/gs_rasterizer.h "view_slot_group")
+        group_before = _views._C.set_option("view_slot_group", lo // _views.MAX_VIEWS)
+        try:
+            out += _render_flow_chunk(pc, part, rs, slot, scaling_modifier)
+        finally:
+            _views._C.set_option("view_slot_group", group_before)
     return out
+
+
+def _render_flow_chunk(pc, part, rs, slot, scaling_modifier):
+    if len(part) == 1 or not _views.views_supported(rs):           # (cameras of different size / field of view: one call each)
+        return [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in part]
+    block = torch.zeros((len(part),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
+    points = [block[v].requires_grad_(True) for v in range(len(part))]
+    flows = [(dx1, dx2, ds1, dr1, c1.full_proj_transform, (c2 if c2 is not None else c1).full_proj_transform) for c1, c2, dx1, dx2, dr1, ds1 in part]
+    res = _views.rasterize_flow_views_raw(rs, pc._xyz, points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, flows)
+    return [_RenderPackage({"render": o[0], "depth": o[2], "alpha": o[3], "viewspace_points": pts, "radii": o[1]}) for o, pts in zip(res, points)]
 
 
 def render_flow(pc, viewpoint_camera1, viewpoint_camera2, d_xyz1, d_xyz2, d_rotation1, d_scaling1, scaling_modifier=1.0,

@@ -350,6 +350,7 @@ class BackEnd:
     # ---- runs of plain iterations as hipGraph replays (slam/mapping_graph.py) ---------------------------------------------------------------
     graph_min_run = 6           # a capture costs about two eager iterations of host time: shorter runs stay eager
     graph_warmup = 2            # iterations of a run executed directly before the capture (the first may still go view by view, gsr_forward_views)
+    dynamic_graph_warmup = 1    # the same for a run of the dynamic call (slam/dynamic_graph.py): its views have capacity estimates from the calls before
 
     def _plain_run_length(self, it, iters, prune):
         """How many iterations from `it` on neither densify nor reset opacities (those replace the model's tensors and run eagerly)."""

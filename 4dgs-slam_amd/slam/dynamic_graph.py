@@ -39,7 +39,7 @@ import slam_losses
 from . import _lib
 from .camera import Camera
 from .deform_model import draw_loss_times, time_key
-from .mapping_graph import CAPTURE_MARGIN_PERMILLE, N_INDEX_WORDS
+from .mapping_graph import CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE, N_INDEX_WORDS
 
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
@@ -362,6 +362,7 @@ class DynamicMapping:
         be, dev = self.be, self.device
         lazy_before = _C.set_option("lazy", 1)
         margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+        tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
         s = be.graph_streams(dev)[1]
         s.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
@@ -375,6 +376,7 @@ class DynamicMapping:
         finally:
             _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
             _C.set_option("cap_margin_permille", margin_before)
+            _C.set_option("cap_tile_margin_permille", tile_before)
         torch.cuda.current_stream(dev).wait_stream(s)
         be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
 
@@ -410,7 +412,7 @@ class DynamicMapping:
             self.direct(rows)
             self.finish(rows)
             return
-        warm = min(be.graph_warmup, rows)
+        warm = min(be.dynamic_graph_warmup, rows)
         self.warm_up(warm)
         self.stats["direct"] += warm
         overflow0 = _C.forward_status_views()

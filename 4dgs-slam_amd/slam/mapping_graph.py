@@ -33,6 +33,7 @@ from .camera import Camera
 
 N_INDEX_WORDS = 2            # random keyframes per iteration (utils/slam_backend.py:1031-1037)
 CAPTURE_MARGIN_PERMILLE = 500
+CAPTURE_TILE_MARGIN_PERMILLE = 3000     # the longest tile list may grow 4x during the replays (see include/gs_rasterizer.h)
 
 
 class KeyframeOperands:
@@ -178,6 +179,7 @@ class MappingGraph:
         be, dev = self.backend, self.device
         lazy_before = _C.set_option("lazy", 1)
         margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+        tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
         s = be.graph_streams(dev)[1]
         s.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
@@ -198,6 +200,7 @@ class MappingGraph:
         finally:
             _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
             _C.set_option("cap_margin_permille", margin_before)
+            _C.set_option("cap_tile_margin_permille", tile_before)
         torch.cuda.current_stream(dev).wait_stream(s)
         be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
         return self

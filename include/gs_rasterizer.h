@@ -246,6 +246,14 @@ int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
  *   "cap_margin_permille" (default 125): head room of a speculative binning buffer over the previous frame's instance count, in
  *                1/1000. A caller that captures many iterations of an OPTIMISATION in a hipGraph (slam/mapping_graph.py: the buffer
  *                is laid out once, the Gaussians then move and grow for 20-200 replays) raises it for the capture.
+ *   "cap_tile_margin_permille" (default: max(250, cap_margin_permille)): head room of the LONGEST TILE LIST over the previous frame's,
+ *                which selects the sort kernels a speculative forward pass enqueues. A tile list can double where the instance count
+ *                moves by a few percent (a dynamic object's Gaussians piling up while the node network trains): captures raise it
+ *                separately. The value 1000000 stands for the default, when set and when returned.
+ *   "view_slot_group" (default 0; 0..3): which of an iteration's gsr_forward_views calls the next calls are. The capacity estimate and
+ *                the mailbox of a view are kept per (group, flow / plain, position in the call): a caller that needs several calls per
+ *                iteration (more than GSR_MAX_VIEWS flow renders) numbers them, or the v-th view of two calls would share -- and spoil -- one
+ *                estimate.
  *   "cap_test_shrink_permille" (default 0 = off): TEST facility -- lay speculative buffers out for this fraction of the previous
  *                frame's count, so that overflows (and the callers' recovery paths) can be provoked deliberately.
  * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX set the initial values. */
