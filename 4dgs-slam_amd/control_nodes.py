@@ -54,6 +54,10 @@ def _lib():
         lib.gsr_index_csr.argtypes = [i, i, i, vp, vp, vp]
         lib.gsr_segment_sum.restype = i
         lib.gsr_segment_sum.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
+        lib.gsr_relu_backward_bias_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_relu_backward_bias_workspace_size.argtypes = [i, i]
+        lib.gsr_relu_backward_bias.restype = i
+        lib.gsr_relu_backward_bias.argtypes = [i, i, vp, vp, vp, vp, vp, vp]
         _lib_cache = lib
     return _lib_cache
 
@@ -143,6 +147,28 @@ def gather_rows(table, sets: IndexSets, set_of_b=None):
     if set_of_b is None and sets.S == table.shape[0] and sets.S > 1:
         set_of_b = torch.arange(sets.S, device=table.device, dtype=torch.int32)
     return _GatherRows.apply(table, sets, set_of_b)
+
+
+RELU_BIAS_COLS = (64, 128, 256, 512, 1024)
+
+
+def relu_backward_bias(dY, Y):
+    """(G, dbias) of a layer y = relu(x W^T + b): G = dY * (Y > 0) and dbias = G.sum(0), in one pass over dY and Y (gsr_relu_backward_bias,
+    include/control_nodes.h) with the column sums formed in a fixed order. dY, Y [rows, cols] fp32 on the device, cols in RELU_BIAS_COLS."""
+    _C._require_device(dY, "dY")
+    if dY.dim() != 2 or dY.shape != Y.shape or dY.dtype != torch.float32 or Y.dtype != torch.float32 or int(dY.shape[1]) not in RELU_BIAS_COLS:
+        raise ValueError(f"relu_backward_bias expects two fp32 [rows, cols] tensors with cols in {RELU_BIAS_COLS}, got {tuple(dY.shape)} and {tuple(Y.shape)}")
+    dY, Y = dY.contiguous(), Y.contiguous()
+    rows, cols = int(dY.shape[0]), int(dY.shape[1])
+    G = torch.empty_like(dY)
+    db = torch.empty((cols,), dtype=torch.float32, device=dY.device)
+    lib = _lib()
+    ws = torch.empty((max(16, int(lib.gsr_relu_backward_bias_workspace_size(rows, cols))),), dtype=torch.uint8, device=dY.device)
+    with torch.cuda.device(dY.device):
+        rc = lib.gsr_relu_backward_bias(rows, cols, dY.data_ptr(), Y.data_ptr(), G.data_ptr(), db.data_ptr(), ws.data_ptr(), _C._stream(dY.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_relu_backward_bias")
+    return G, db
 
 
 def quaternion_to_matrix(q):

@@ -1694,6 +1694,27 @@ int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, voi
     return 0;
 }
 
+size_t gsr_relu_backward_bias_workspace_size(int rows, int cols)
+{
+    return rows > 0 && cols > 0 ? (size_t)((rows + RELU_BAND - 1) / RELU_BAND) * (size_t)cols * sizeof(float) : 0;
+}
+
+int gsr_relu_backward_bias(int rows, int cols, const float* dY, const float* Y, float* G, float* dbias, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool cols_ok = cols == 64 || cols == 128 || cols == 256 || cols == 512 || cols == 1024;
+    if (rows < 0 || !cols_ok || !dbias || (rows > 0 && (!dY || !Y || !G || !workspace))) {
+        g_last_error = "gsr_relu_backward_bias: invalid argument (cols in {64, 128, 256, 512, 1024}; 16-byte aligned rows)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)G | (uintptr_t)workspace) & 15) { g_last_error = "gsr_relu_backward_bias: buffers must be 16-byte aligned"; return GSR_ERR_INVALID_ARGUMENT; }
+    const int bands = (rows + RELU_BAND - 1) / RELU_BAND;
+    if (bands > 0) hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3((unsigned)bands), dim3(256), 0, stream, rows, cols, dY, Y, G, reinterpret_cast<float*>(workspace));
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, bands, cols, reinterpret_cast<const float*>(workspace), dbias);
+    const int debug = 0;
+    GSR_STAGE("gsr_relu_backward_bias");
+    return 0;
+}
+
 int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

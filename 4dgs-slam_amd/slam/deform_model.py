@@ -8,6 +8,8 @@ The network is the reference's DeformNetwork for the shipped flags (8 x 256, 10 
 encoders, node densification / pruning, hyper-coordinates, skinning -- the shipped SLAM configuration does not switch them on
 (arguments.py:107-125) and the loops never call them."""
 
+import os
+
 import torch
 from torch import nn
 
@@ -150,6 +152,49 @@ def draw_loss_times(t, arap_delta, arap_samples, elastic_delta, elastic_samples=
     return {"arap": arap, "elastic": elastic}
 
 
+class _FusedTrunk(torch.autograd.Function):
+    """NodeNetwork.trunk on the device as ONE autograd node: D layers y = relu(x W^T + b) with the embedding re-injected behind layer `skip`
+    (utils/time_utils.py:428-452). What autograd's op-by-op version spends besides the GEMMs on ~50 000 rows x 256 columns -- a separate
+    ReLU pass per layer, threshold_backward + a column reduction per layer on the way back, the concatenation of the skip connection and the
+    slice / zero-fill of its gradient: 1.1 of the dynamic mapping iteration's 5.0 ms -- is folded away here:
+      * forward: bias + ReLU ride in the GEMM's epilogue (torch._addmm_activation -> hipBLASLt RELU_BIAS);
+      * the skip connection's concatenation is kept (one GEMM on [emb | h] is cheaper than two into one accumulator), its backward half is
+        not: the gradient of the concatenated input is only formed for its h columns (G W[:, E:]);
+      * backward: G = dY [y > 0] and the bias gradient in one pass (control_nodes.relu_backward_bias, fixed summation order), then the
+        two GEMMs dW = G^T x and dx = G W; the embedding needs no gradient (node positions are detached, times are data).
+    Values are those of the op-by-op trunk; gradients differ from it by the order of the bias gradient's sum only."""
+
+    @staticmethod
+    def forward(ctx, emb, skip, *params):
+        D = len(params) // 2
+        E = emb.shape[1]
+        inputs, outs, h = [], [], emb
+        for i in range(D):
+            W, b = params[2 * i], params[2 * i + 1]
+            inputs.append(h)
+            h = torch._addmm_activation(b, h, W.t(), use_gelu=False)
+            outs.append(h)
+            if i == skip:
+                h = torch.cat([emb, h], -1)                  # (:447-448: the next layer's input)
+        ctx.skip, ctx.D, ctx.E = skip, D, E
+        ctx.save_for_backward(*params[0::2], *inputs, *outs)  # (the last output is saved as an output: no reference cycle)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        D, E, skip = ctx.D, ctx.E, ctx.skip
+        saved = ctx.saved_tensors
+        Ws, inputs, outs = saved[:D], saved[D:2 * D], saved[2 * D:]
+        grads = [None] * (2 * D)
+        g = g.contiguous()
+        for i in reversed(range(D)):
+            G, db = control_nodes.relu_backward_bias(g, outs[i])
+            grads[2 * i], grads[2 * i + 1] = G.t().mm(inputs[i]), db
+            if i > 0:
+                g = G.mm(Ws[i][:, E:] if i == skip + 1 else Ws[i])      # (the embedding half of the skip input needs no gradient)
+        return (None, None, *grads)
+
+
 class NodeNetwork(nn.Module):
     """DeformNetwork (utils/time_utils.py:327-470) as ControlNodeWarp builds it with the shipped flags (arguments.py:107-125: is_blender
     False -> 10 time frequencies, 10 position frequencies, D = 8 layers of W = 256 with the embedding re-injected after layer 4,
@@ -182,6 +227,10 @@ class NodeNetwork(nn.Module):
         return self.from_embedding(emb)
 
     def trunk(self, emb):
+        if (emb.is_cuda and emb.dtype == torch.float32 and emb.dim() == 2 and self.W in control_nodes.RELU_BIAS_COLS and len(self.skips) == 1
+                and 0 <= self.skips[0] < self.D - 1 and not emb.requires_grad and os.environ.get("GSR_FUSED_TRUNK", "1") != "0"):
+            params = [t for layer in self.linear for t in (layer.weight, layer.bias)]
+            return _FusedTrunk.apply(emb, self.skips[0], *params)
         h = emb
         for i, layer in enumerate(self.linear):
             h = torch.relu(layer(h))

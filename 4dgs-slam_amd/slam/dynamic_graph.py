@@ -28,6 +28,7 @@ Direct and replayed iterations are bit-identical (tests/test_hip_slam.py). The c
 moving pixels in the first half; :337-338,:765-770: the Gaussians only step in the second) are different graphs: a run never crosses the
 boundary. A replayed forward pass that outgrows its binning buffer is detected after the run (sticky overflow counters); the run is then
 undone from a snapshot and repeated directly."""
+import os
 import time
 
 import numpy as np
@@ -39,8 +40,12 @@ import slam_losses
 from . import _lib
 from .camera import Camera
 from .deform_model import draw_loss_times, time_key
-from .mapping_graph import CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE, N_INDEX_WORDS
+from .mapping_graph import N_INDEX_WORDS
 
+# Head room of the binning buffers a captured iteration lays out (include/gs_rasterizer.h): while the node network trains alone (first half
+# of a call) the moving object's Gaussians can swell and pile up for a few iterations -- measured: instance counts +10 %, the longest tile
+# list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
+CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
 

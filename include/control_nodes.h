@@ -97,6 +97,13 @@ int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* n
  *                     int32 names the index set of batch element b, NULL = set 0 for all).
  * Used by the node blend's backward (a Gaussian's gradient goes to its K nearest nodes; gsr_node_blend_backward* takes this route for K <= 4
  * by itself) and by the gathers of the ARAP / elastic node regularisers (utils/deform_utils.py:35-42, utils/time_utils.py:1160-1165). */
+/* The non-GEMM half of a trunk layer's backward pass, y = relu(x W^T + b) on `rows` x `cols` row-major fp32 matrices (the node network,
+ * utils/time_utils.py:327-470: eight such layers on ~50 000 rows per mapping iteration): G = dY . [Y > 0] and dbias[c] = sum over rows of
+ * G[r][c], in ONE pass over dY and Y plus a few-microsecond finalisation; the sums are formed in a fixed order (bit-reproducible).
+ * cols in {64, 128, 256, 512, 1024}; all buffers 16-byte aligned; workspace: gsr_relu_backward_bias_workspace_size(rows, cols) bytes. */
+size_t gsr_relu_backward_bias_workspace_size(int rows, int cols);
+int gsr_relu_backward_bias(int rows, int cols, const float* dY, const float* Y, float* G, float* dbias, char* workspace, void* stream);
+
 size_t gsr_index_csr_workspace_size(int S, int E, int Nv);
 int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, void* stream);
 int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream);

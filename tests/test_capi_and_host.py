@@ -117,6 +117,10 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert cl.gsr_index_csr_workspace_size(7, 5120, 512) >= 7 * (5120 + 2 * 512) * 4
     assert cl.gsr_index_csr(0, 10, 4, None, None, None) == -1 and b"gsr_index_csr" in lib.gsr_last_error()
     assert cl.gsr_segment_sum(2, 1, 10, 3, 4, None, None, None, None, None) == -1 and b"gsr_segment_sum" in lib.gsr_last_error()
+    cl.gsr_relu_backward_bias_workspace_size.restype = ctypes.c_size_t
+    assert cl.gsr_relu_backward_bias_workspace_size(50_000, 256) == ((50_000 + 63) // 64) * 256 * 4 and cl.gsr_relu_backward_bias_workspace_size(0, 256) == 0
+    assert cl.gsr_relu_backward_bias(10, 100, None, None, None, None, None, None) == -1 and b"gsr_relu_backward_bias" in lib.gsr_last_error()
+    assert cl.gsr_relu_backward_bias(10, 256, None, None, None, None, None, None) == -1
     assert cl.gsr_schedule_advance(None, None, 4, 2, None, None) == -1 and b"gsr_schedule_advance" in lib.gsr_last_error()
     assert cl.gsr_slot_gather(5, None, None, None, 100, None) == -1 and b"gsr_slot_gather" in lib.gsr_last_error()
     assert cl.gsr_slot_gather(0, None, None, None, 100, None) == 0                        # no slots: nothing to do

@@ -210,3 +210,49 @@ def test_node_blend_batch_equals_one_blend_per_sample(B, n, m, local_frame, with
         assert torch.allclose(a, b_, rtol=1e-4, atol=1e-7)
     for a, b_ in zip(got[3 + n_shared:], want[n_shared:]):           # per-sample node gradients (LDS float atomics inside a block: order-dependent rounding)
         assert a.shape == b_.shape and torch.allclose(a, b_, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,cols", [(50_000, 256), (77, 64), (1, 1024), (0, 256)])
+def test_relu_backward_bias_matches_torch_and_is_reproducible(rows, cols):
+    """gsr_relu_backward_bias: G = dY [Y > 0] exactly, the bias gradient = G's column sums (another association than torch's reduction:
+    compared in fp64), the same bits on every call."""
+    g = torch.Generator(device="cpu").manual_seed(rows + cols)
+    dY = torch.randn(rows, cols, generator=g).to(DEV)
+    Y = torch.relu(torch.randn(rows, cols, generator=g)).to(DEV)
+    G, db = cn.relu_backward_bias(dY, Y)
+    assert torch.equal(G, dY * (Y > 0))
+    want = (dY.double() * (Y > 0)).sum(0)
+    assert torch.allclose(db.double(), want, rtol=1e-5, atol=1e-4 * max(1.0, rows ** 0.5))
+    G2, db2 = cn.relu_backward_bias(dY, Y)
+    assert torch.equal(db, db2) and torch.equal(G, G2)
+    with pytest.raises(ValueError):
+        cn.relu_backward_bias(dY[:, :-1] if cols > 1 else dY, Y[:, :-1] if cols > 1 else Y[:0])
+
+
+def test_fused_trunk_equals_the_op_by_op_trunk():
+    """NodeNetwork.trunk on the device (_FusedTrunk: ReLU in the GEMM epilogue, two-GEMM skip layer, one-pass ReLU-backward + bias gradient)
+    against the same network evaluated op by op (what runs on CPU tensors): values equal to GEMM rounding, every gradient to 1e-3 of its norm."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "4dgs-slam_amd"))
+    from slam.deform_model import NodeNetwork
+    torch.manual_seed(3)
+    net = NodeNetwork().to(DEV)
+    emb = torch.randn(6000, net.input_ch, device=DEV)
+    cot = torch.randn(6000, net.W, device=DEV)
+    h = net.trunk(emb)
+    assert type(h.grad_fn).__name__.startswith("_FusedTrunk")
+    h.backward(cot)
+    got = [p.grad.clone() for layer in net.linear for p in (layer.weight, layer.bias)]
+    net.zero_grad(set_to_none=True)
+    x = emb
+    for i, layer in enumerate(net.linear):
+        x = torch.relu(layer(x))
+        if i in net.skips:
+            x = torch.cat([emb, x], -1)
+    assert torch.allclose(h, x, rtol=1e-4, atol=1e-4)
+    x.backward(cot)
+    want = [p.grad for layer in net.linear for p in (layer.weight, layer.bias)]
+    # (a pre-activation within rounding of zero may land on the other side of the ReLU in the two evaluations -- a handful of the 1.5 M do, and
+    # each moves single gradient entries by a visible amount: the comparison is of the tensors as wholes)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and float((a - b).norm()) <= 1e-3 * float(b.norm()), (tuple(a.shape), float((a - b).norm() / b.norm()))
