@@ -117,7 +117,7 @@ def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
         return torch.zeros(nodes_seq.shape[:-3], dtype=nodes_seq.dtype, device=nodes_seq.device)
     w = keep.to(nodes_seq.dtype)
     E = edge_matrix(nodes_seq, nn_idx[..., None, :, :], keep[..., None, :, :])          # [..., T, Nv, K, 3]
-    E0, Et = E[..., :1, :, :, :], E[..., 1:, :, :, :]
+    E0, Et = E.split([1, E.shape[-4] - 1], -4)
     with torch.no_grad():
         R = estimate_rotation(E0.detach(), Et.detach(), w[..., None, :, :], rotations)  # [..., T-1, Nv, 3, 3]
     stretch = Et - torch.einsum("...ab,...kb->...ka", R, E0)                            # target edges minus the rigidly rotated source edges
@@ -370,14 +370,19 @@ class ControlNodes(nn.Module):
         te = _embed(tt.reshape(n, 1), net.t_multires)
         emb = torch.cat([xe[None].expand(n, M, -1), te[:, None].expand(n, M, -1)], -1)
         h = net.trunk(emb.reshape(n * M, -1))
-        d_xyz_all = net.gaussian_warp(h).reshape(n, M, 3)
+        # the heads as ONE linear layer on all rows (their weights concatenated: [3 + 4 + 3 (+ 4), W]) -- four GEMMs forward and eight backward
+        # become one and two, and the gradient of `h` is formed once instead of per head on row slices that autograd zero-fills, copies and
+        # adds back at full size; the rotation / scaling / local-frame columns of the position-only rows are computed and never read
+        heads = [("d_xyz", net.gaussian_warp), ("d_rotation", net.gaussian_rotation), ("d_scaling", net.gaussian_scaling)]
+        if net.local_frame:
+            heads.append(("local_rotation", net.local_rotation))
+        W_all = torch.cat([m.weight for _, m in heads], 0)
+        b_all = torch.cat([m.bias for _, m in heads], 0)
+        cols = torch.addmm(b_all, h, W_all.t()).reshape(n, M, -1).split([m.weight.shape[0] for _, m in heads], -1)
+        d_xyz_all = cols[0]
         it = {"d_xyz_all": d_xyz_all, "n_full": int(n_full), "heads": {}, "blended": None}
         if n_full:
-            hf = h[:n_full * M]
-            heads = {"d_rotation": net.gaussian_rotation, "d_scaling": net.gaussian_scaling}
-            if net.local_frame:
-                heads["local_rotation"] = net.local_rotation
-            stacked = it["heads"] = {name: head(hf).reshape(n_full, M, -1) for name, head in heads.items()}
+            stacked = it["heads"] = {name: c[:n_full] for (name, _), c in list(zip(heads, cols))[1:]}
             if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
                 x, motion_mask = blend
                 out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, d_xyz_all[:n_full],
@@ -394,29 +399,29 @@ class ControlNodes(nn.Module):
         The same terms as arap_loss_batch / elastic_loss_batch on lists of host times, read as slices of the batch instead of stacks."""
         M = self.node_num
         base = self.nodes.detach()
-        d = it["d_xyz_all"][it["n_full"]:]
         wa, we = window_samples
         ea, ee = extra_samples
-        nw = n_window * (wa + we)
+        nw, nx = n_window * (wa + we), n_extra * (ea + ee)
+        # (split, not slices: one backward node that concatenates the pieces' gradients instead of a zero-fill + copy per slice)
+        n_all = int(it["d_xyz_all"].shape[0])
+        pieces = it["d_xyz_all"].split([it["n_full"], nw, nx] + ([n_all - it["n_full"] - nw - nx] if n_all > it["n_full"] + nw + nx else []), 0)
         parts_e, reg = [], 0
-        w = e = None
+        w_a = w_e = e_a = e_e = None
         if n_window:
-            w = base + d[:nw].reshape(n_window, wa + we, M, 3)
-            parts_e.append(w[:, wa:])
+            w_a, w_e = (base + pieces[1].reshape(n_window, wa + we, M, 3)).split([wa, we], 1)
+            parts_e.append(w_e)
         if n_extra:
-            e = base + d[nw:nw + n_extra * (ea + ee)].reshape(n_extra, ea + ee, M, 3)
-            parts_e.append(e[:, ea:])
+            e_a, e_e = (base + pieces[2].reshape(n_extra, ea + ee, M, 3)).split([ea, ee], 1)
+            parts_e.append(e_e)
         nodes_t = (parts_e[0] if len(parts_e) == 1 else torch.cat(parts_e, 0)).permute(0, 2, 1, 3)             # [V, M, T, 3]
         nn_weight, nn_idx = self._elastic_neighbours()
         reg = (elastic_error(nodes_t, nn_weight, nn_idx) * weights).sum()
         if n_window:
-            seq = w[:, :wa]
-            nn_i, keep = connectivity_from_points(seq[:, 0], K=10)
-            reg = reg + (weights[:n_window] * arap_error(seq, nn_i, keep)).sum()
+            nn_i, keep = connectivity_from_points(w_a[:, 0], K=10)
+            reg = reg + (weights[:n_window] * arap_error(w_a, nn_i, keep)).sum()
         if n_extra:
-            seq = e[:, :ea]
-            nn_i, keep = connectivity_from_points(seq[:, 0], K=10)
-            reg = reg + (weights[n_window:] * arap_error(seq, nn_i, keep)).sum()
+            nn_i, keep = connectivity_from_points(e_a[:, 0], K=10)
+            reg = reg + (weights[n_window:] * arap_error(e_a, nn_i, keep)).sum()
         return reg
 
     def _upload(self, values):

@@ -368,6 +368,8 @@ class DynamicMapping:
         lazy_before = _C.set_option("lazy", 1)
         margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
         tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
+        # TEST facility (Training.graph_test_shrink_permille): lay the captured buffers out too small, so that replays overflow
+        shrink_before = _C.set_option("cap_test_shrink_permille", int(be.config["Training"].get("graph_test_shrink_permille", 0)))
         s = be.graph_streams(dev)[1]
         s.wait_stream(torch.cuda.current_stream(dev))
         self.graph = torch.cuda.CUDAGraph()
@@ -382,6 +384,7 @@ class DynamicMapping:
             _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
             _C.set_option("cap_margin_permille", margin_before)
             _C.set_option("cap_tile_margin_permille", tile_before)
+            _C.set_option("cap_test_shrink_permille", shrink_before)
         torch.cuda.current_stream(dev).wait_stream(s)
         be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
 
