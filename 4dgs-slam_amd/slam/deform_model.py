@@ -8,6 +8,7 @@ The network is the reference's DeformNetwork for the shipped flags (8 x 256, 10 
 encoders, node densification / pruning, hyper-coordinates, skinning -- the shipped SLAM configuration does not switch them on
 (arguments.py:107-125) and the loops never call them."""
 
+import functools
 import os
 
 import torch
@@ -152,20 +153,46 @@ def draw_loss_times(t, arap_delta, arap_samples, elastic_delta, elastic_samples=
     return {"arap": arap, "elastic": elastic}
 
 
+@functools.lru_cache(maxsize=256)
+def _row_groups(R, target=2048):
+    """Into how many equal parts to split R rows so that a part has about `target` rows: the divisor g of R with R / g closest to the target
+    (within a factor of two of it), else 1."""
+    best, best_err = 1, None
+    for g in range(max(1, R // (2 * target)), R // (target // 2) + 2):
+        if g > 0 and R % g == 0:
+            err = abs(R // g - target)
+            if best_err is None or err < best_err:
+                best, best_err = g, err
+    return best
+
+
+def _grad_weight(G, X):
+    """dW = G^T X for G [R, out], X [R, in] with the rows split into equal parts of ~2 000: ONE batched GEMM + a sum over the parts. As a
+    single GEMM the library tiles the [out, in] = 256 x 256 result into 32 workgroups and walks all R rows in each -- 224 of the 256 CUs
+    idle, 35-40 TFLOP/s (118 us per layer at R = 33 280); as 13-26 independent products of 1 280-2 560 rows it runs at 81-83 TFLOP/s (52 us;
+    tools/dev_dw_gemm.py: parts of 512 rows or fewer are slow again, the library then picks one 256 x 256 tile per part). The parts are added
+    in a fixed order."""
+    R = G.shape[0]
+    groups = _row_groups(R)
+    if groups > 1 and G.is_contiguous() and X.is_contiguous():
+        return torch.bmm(G.view(groups, R // groups, -1).transpose(1, 2), X.view(groups, R // groups, -1)).sum(0)
+    return G.t().mm(X)
+
+
 class _FusedTrunk(torch.autograd.Function):
-    """NodeNetwork.trunk on the device as ONE autograd node: D layers y = relu(x W^T + b) with the embedding re-injected behind layer `skip`
-    (utils/time_utils.py:428-452). What autograd's op-by-op version spends besides the GEMMs on ~50 000 rows x 256 columns -- a separate
-    ReLU pass per layer, threshold_backward + a column reduction per layer on the way back, the concatenation of the skip connection and the
-    slice / zero-fill of its gradient: 1.1 of the dynamic mapping iteration's 5.0 ms -- is folded away here:
+    """The node network on the device as ONE autograd node: D layers y = relu(x W^T + b) with the embedding re-injected behind layer `skip`
+    (utils/time_utils.py:428-452), then all heads as one linear layer [sum of head widths, W] without activation. What autograd's op-by-op
+    version spends besides the forward / input-gradient GEMMs on ~30-70 000 rows x 256 columns is folded away or re-shaped here:
       * forward: bias + ReLU ride in the GEMM's epilogue (torch._addmm_activation -> hipBLASLt RELU_BIAS);
-      * the skip connection's concatenation is kept (one GEMM on [emb | h] is cheaper than two into one accumulator), its backward half is
-        not: the gradient of the concatenated input is only formed for its h columns (G W[:, E:]);
-      * backward: G = dY [y > 0] and the bias gradient in one pass (control_nodes.relu_backward_bias, fixed summation order), then the
-        two GEMMs dW = G^T x and dx = G W; the embedding needs no gradient (node positions are detached, times are data).
-    Values are those of the op-by-op trunk; gradients differ from it by the order of the bias gradient's sum only."""
+      * backward: G = dY [y > 0] and the bias gradient in one pass (control_nodes.relu_backward_bias, fixed summation order);
+      * the weight gradients G^T x -- as single GEMMs the slowest kernels of the iteration (256 x 256 results: 32 workgroups) -- are batched
+        over row groups (_grad_weight);
+      * the skip connection's concatenation is kept (one GEMM on [emb | h]), its backward half is not: the gradient of the concatenated
+        input is only formed for its h columns (G W[:, E:]); the embedding needs no gradient (node positions are detached, times are data).
+    Values are those of the op-by-op network; gradients differ from it by summation order only."""
 
     @staticmethod
-    def forward(ctx, emb, skip, *params):
+    def forward(ctx, emb, skip, W_heads, b_heads, *params):
         D = len(params) // 2
         E = emb.shape[1]
         inputs, outs, h = [], [], emb
@@ -176,23 +203,27 @@ class _FusedTrunk(torch.autograd.Function):
             outs.append(h)
             if i == skip:
                 h = torch.cat([emb, h], -1)                  # (:447-448: the next layer's input)
+        out = torch.addmm(b_heads, h, W_heads.t())
         ctx.skip, ctx.D, ctx.E = skip, D, E
-        ctx.save_for_backward(*params[0::2], *inputs, *outs)  # (the last output is saved as an output: no reference cycle)
-        return h
+        ctx.save_for_backward(W_heads, *params[0::2], *inputs, *outs)
+        return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_out):
         D, E, skip = ctx.D, ctx.E, ctx.skip
         saved = ctx.saved_tensors
-        Ws, inputs, outs = saved[:D], saved[D:2 * D], saved[2 * D:]
+        W_heads, Ws, inputs, outs = saved[0], saved[1:1 + D], saved[1 + D:1 + 2 * D], saved[1 + 2 * D:]
         grads = [None] * (2 * D)
-        g = g.contiguous()
+        g_out = g_out.contiguous()
+        h_last = outs[D - 1]
+        gW_heads, gb_heads = _grad_weight(g_out, h_last), g_out.sum(0)
+        g = g_out.mm(W_heads)
         for i in reversed(range(D)):
             G, db = control_nodes.relu_backward_bias(g, outs[i])
-            grads[2 * i], grads[2 * i + 1] = G.t().mm(inputs[i]), db
+            grads[2 * i], grads[2 * i + 1] = _grad_weight(G, inputs[i]), db
             if i > 0:
                 g = G.mm(Ws[i][:, E:] if i == skip + 1 else Ws[i])      # (the embedding half of the skip input needs no gradient)
-        return (None, None, *grads)
+        return (None, None, gW_heads, gb_heads, *grads)
 
 
 class NodeNetwork(nn.Module):
@@ -226,11 +257,30 @@ class NodeNetwork(nn.Module):
         emb = torch.cat([_embed(x, self.multires), _embed(t, self.t_multires)], -1)
         return self.from_embedding(emb)
 
-    def trunk(self, emb):
-        if (emb.is_cuda and emb.dtype == torch.float32 and emb.dim() == 2 and self.W in control_nodes.RELU_BIAS_COLS and len(self.skips) == 1
-                and 0 <= self.skips[0] < self.D - 1 and not emb.requires_grad and os.environ.get("GSR_FUSED_TRUNK", "1") != "0"):
+    def fused_ok(self, emb):
+        return (emb.is_cuda and emb.dtype == torch.float32 and emb.dim() == 2 and self.W in control_nodes.RELU_BIAS_COLS and len(self.skips) == 1
+                and 0 <= self.skips[0] < self.D - 1 and not emb.requires_grad and os.environ.get("GSR_FUSED_TRUNK", "1") != "0")
+
+    def heads(self):
+        """[(output name, layer)] in the column order of heads_from_embedding."""
+        hs = [("d_xyz", self.gaussian_warp), ("d_rotation", self.gaussian_rotation), ("d_scaling", self.gaussian_scaling)]
+        if self.local_frame:
+            hs.append(("local_rotation", self.local_rotation))
+        return hs
+
+    def heads_from_embedding(self, emb):
+        """All heads of all rows of `emb` as ONE matrix [rows, 3 + 4 + 3 (+ 4)] (columns in heads() order): the heads as one linear layer on
+        the trunk's output -- four GEMMs forward and eight backward become one and two, and the trunk's output gradient is formed once.
+        On the device the whole network is one autograd node (_FusedTrunk)."""
+        hs = self.heads()
+        W_all = torch.cat([m.weight for _, m in hs], 0)
+        b_all = torch.cat([m.bias for _, m in hs], 0)
+        if self.fused_ok(emb):
             params = [t for layer in self.linear for t in (layer.weight, layer.bias)]
-            return _FusedTrunk.apply(emb, self.skips[0], *params)
+            return _FusedTrunk.apply(emb, self.skips[0], W_all, b_all, *params)
+        return torch.addmm(b_all, self.trunk(emb), W_all.t())
+
+    def trunk(self, emb):
         h = emb
         for i, layer in enumerate(self.linear):
             h = torch.relu(layer(h))
@@ -369,16 +419,10 @@ class ControlNodes(nn.Module):
         xe = _embed(self.nodes.detach(), net.multires)
         te = _embed(tt.reshape(n, 1), net.t_multires)
         emb = torch.cat([xe[None].expand(n, M, -1), te[:, None].expand(n, M, -1)], -1)
-        h = net.trunk(emb.reshape(n * M, -1))
-        # the heads as ONE linear layer on all rows (their weights concatenated: [3 + 4 + 3 (+ 4), W]) -- four GEMMs forward and eight backward
-        # become one and two, and the gradient of `h` is formed once instead of per head on row slices that autograd zero-fills, copies and
-        # adds back at full size; the rotation / scaling / local-frame columns of the position-only rows are computed and never read
-        heads = [("d_xyz", net.gaussian_warp), ("d_rotation", net.gaussian_rotation), ("d_scaling", net.gaussian_scaling)]
-        if net.local_frame:
-            heads.append(("local_rotation", net.local_rotation))
-        W_all = torch.cat([m.weight for _, m in heads], 0)
-        b_all = torch.cat([m.bias for _, m in heads], 0)
-        cols = torch.addmm(b_all, h, W_all.t()).reshape(n, M, -1).split([m.weight.shape[0] for _, m in heads], -1)
+        # (the heads as ONE linear layer on all rows: the rotation / scaling / local-frame columns of the position-only rows are computed and
+        # never read -- 11 of 14 columns of a [rows, 256] x [256, 14] product)
+        heads = net.heads()
+        cols = net.heads_from_embedding(emb.reshape(n * M, -1)).reshape(n, M, -1).split([m.weight.shape[0] for _, m in heads], -1)
         d_xyz_all = cols[0]
         it = {"d_xyz_all": d_xyz_all, "n_full": int(n_full), "heads": {}, "blended": None}
         if n_full:

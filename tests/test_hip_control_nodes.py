@@ -229,30 +229,32 @@ def test_relu_backward_bias_matches_torch_and_is_reproducible(rows, cols):
         cn.relu_backward_bias(dY[:, :-1] if cols > 1 else dY, Y[:, :-1] if cols > 1 else Y[:0])
 
 
-def test_fused_trunk_equals_the_op_by_op_trunk():
-    """NodeNetwork.trunk on the device (_FusedTrunk: ReLU in the GEMM epilogue, two-GEMM skip layer, one-pass ReLU-backward + bias gradient)
-    against the same network evaluated op by op (what runs on CPU tensors): values equal to GEMM rounding, every gradient to 1e-3 of its norm."""
+def test_fused_network_equals_the_op_by_op_network():
+    """NodeNetwork.heads_from_embedding on the device (_FusedTrunk: ReLU in the GEMM epilogue, one-pass ReLU-backward + bias gradient, weight
+    gradients batched over row groups, all heads as one layer) against the same network evaluated op by op (what runs on CPU tensors):
+    values equal to GEMM rounding, every gradient to 1e-3 of its norm."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "4dgs-slam_amd"))
     from slam.deform_model import NodeNetwork
     torch.manual_seed(3)
     net = NodeNetwork().to(DEV)
-    emb = torch.randn(6000, net.input_ch, device=DEV)
-    cot = torch.randn(6000, net.W, device=DEV)
-    h = net.trunk(emb)
-    assert type(h.grad_fn).__name__.startswith("_FusedTrunk")
-    h.backward(cot)
-    got = [p.grad.clone() for layer in net.linear for p in (layer.weight, layer.bias)]
-    net.zero_grad(set_to_none=True)
-    x = emb
-    for i, layer in enumerate(net.linear):
-        x = torch.relu(layer(x))
-        if i in net.skips:
-            x = torch.cat([emb, x], -1)
-    assert torch.allclose(h, x, rtol=1e-4, atol=1e-4)
-    x.backward(cot)
-    want = [p.grad for layer in net.linear for p in (layer.weight, layer.bias)]
-    # (a pre-activation within rounding of zero may land on the other side of the ReLU in the two evaluations -- a handful of the 1.5 M do, and
-    # each moves single gradient entries by a visible amount: the comparison is of the tensors as wholes)
-    for a, b in zip(got, want):
-        assert a.shape == b.shape and float((a - b).norm()) <= 1e-3 * float(b.norm()), (tuple(a.shape), float((a - b).norm() / b.norm()))
+    for _, head in net.heads():                                  # (the shipped initialisation makes the heads ~0: give them something to propagate)
+        torch.nn.init.normal_(head.weight, std=0.05)
+    params = [p for layer in list(net.linear) + [m for _, m in net.heads()] for p in (layer.weight, layer.bias)]
+    for rows in (6000, 33280, 6007):                             # (6007 is prime: the weight gradients fall back to single GEMMs)
+        emb, cot = torch.randn(rows, net.input_ch, device=DEV), torch.randn(rows, 14, device=DEV)
+        net.zero_grad(set_to_none=True)
+        out = net.heads_from_embedding(emb)
+        assert type(out.grad_fn).__name__.startswith("_FusedTrunk") and out.shape == (rows, 14)
+        out.backward(cot)
+        got = [p.grad.clone() for p in params]
+        net.zero_grad(set_to_none=True)
+        h = net.trunk(emb)
+        want_out = torch.cat([m(h) for _, m in net.heads()], -1)
+        assert torch.allclose(out, want_out, rtol=1e-4, atol=1e-4)
+        want_out.backward(cot)
+        # (a pre-activation within rounding of zero may land on the other side of the ReLU in the two evaluations -- a handful of the 1.5 M do,
+        # and each moves single gradient entries by a visible amount: the comparison is of the tensors as wholes)
+        for a, p in zip(got, params):
+            b = p.grad
+            assert a.shape == b.shape and float((a - b).norm()) <= 1e-3 * float(b.norm()), (rows, tuple(a.shape), float((a - b).norm() / b.norm()))

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_hip_control_nodes.py -x -q -k "relu or trunk" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_hip_control_nodes.py -x -q -k "relu or fused_network" 2>&1 | tail -2
 for cfg in "1 2000,7000" "0 2000,7000"; do
   set -- $cfg
   GSR_FUSED_TRUNK=$1 GSR_DYN_MARGINS=$2 timeout 600 python tools/mapping_iteration_launches.py --wh 640 480 2>/dev/null | python -c "

@@ -77,10 +77,13 @@ if "--cprofile" in sys.argv:          # host side only: where does the Python ti
     st.sort_stats("cumulative").print_stats(45)
     raise SystemExit(0)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes="--ops" in sys.argv,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     run(iters)
     torch.cuda.synchronize()
+if "--ops" in sys.argv:              # which ops (with their input shapes) own the device time
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=45, max_name_column_width=60, max_shapes_column_width=90),
+          file=sys.stderr)
 by_line, by_op, ktime = collections.Counter(), collections.Counter(), collections.Counter()
 LAUNCH = ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync", "hipGraphLaunch", "hipModuleLaunchKernel", "hipExtLaunchKernel")
 for e in prof.events():
