@@ -136,13 +136,26 @@ class BackEnd:
 
     # ---- map initialisation (:237-296) -----------------------------------------------------------------------------------
     def initialize_map(self, cur_frame_idx, viewpoint):
+        """:237-296. Runs of plain iterations -- between the densifications (every init_gaussian_update iterations) and the opacity resets --
+        are replayed as hipGraphs (slam/mapping_graph.InitGraph: the same arithmetic, one replay per iteration)."""
         pkg = None
-        for mapping_iteration in range(self.init_itr_num):
+        rm_dynamic = not (self.dystart == cur_frame_idx)
+        mapping_iteration = 0
+        while mapping_iteration < self.init_itr_num:
+            run = self._plain_init_run(mapping_iteration)
+            if run >= self.graph_min_run and self._graphs_enabled() and self._graph_ok([viewpoint]):
+                pkg = None         # (lets the last eager iteration's autograd graph go: its AccumulateGrad nodes belong to the default stream)
+                done_pkg = self._initialize_map_graph_run(viewpoint, rm_dynamic, run)
+                if done_pkg is not None:
+                    pkg = done_pkg
+                    mapping_iteration += run
+                    continue
             self.iteration_count += 1
             pkg = self._render(viewpoint, (None, None, None))
-            loss_init = slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True,
-                                                     rm_dynamic=not (self.dystart == cur_frame_idx), compute_value=self.loss_values)
-            loss_init.backward()
+            # (no name for the loss: a local that outlives the iteration keeps its autograd graph -- and the default-stream AccumulateGrad nodes of
+            # the camera parameters -- alive into the next graph run's capture)
+            slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True,
+                                         rm_dynamic=rm_dynamic, compute_value=self.loss_values).backward()
             with torch.no_grad():
                 self._view_stats(pkg)
                 if mapping_iteration % self.init_gaussian_update == 0:
@@ -151,7 +164,72 @@ class BackEnd:
                     self.gaussians.reset_opacity()
                 self.gaussians.optimizer.step()
                 self.gaussians.optimizer.zero_grad(set_to_none=True)
+            mapping_iteration += 1
         self.occ_aware_visibility[cur_frame_idx] = (self._final_touched(viewpoint, pkg) > 0).long()
+        return pkg
+
+    def _plain_init_run(self, mapping_iteration):
+        """How many iterations of initialize_map from `mapping_iteration` on neither densify nor reset opacities."""
+        n = 0
+        while mapping_iteration + n < self.init_itr_num:
+            count = self.iteration_count + n + 1
+            if (mapping_iteration + n) % self.init_gaussian_update == 0 or count == self.init_gaussian_reset or count == self.opt_params.densify_from_iter:
+                break
+            n += 1
+        return n
+
+    def _initialize_map_graph_run(self, viewpoint, rm_dynamic, run):
+        """`run` plain iterations of initialize_map as warm-up + capture + replays; returns the last render package, or None when nothing was
+        executed (the caller goes on eagerly)."""
+        from .mapping_graph import InitGraph
+        from diff_gaussian_rasterization import _C
+        g = self.gaussians
+        stats = self.__dict__.setdefault("init_graph_stats", {"runs": 0, "replays": 0, "direct": 0, "redone": 0, "failed": 0})
+        if getattr(self, "_init_graph_broken", False) or g.optimizer.scheduled_segments() is None:
+            return None
+        try:
+            ig = InitGraph(self, viewpoint, rm_dynamic, run)
+        except RuntimeError as e:
+            self._graph_note(stats, e)
+            return None
+        warm = min(self.graph_warmup, run)
+        ig.warm_up(warm)
+        done = warm
+        if run > warm:
+            overflow0 = _C.forward_status()[0]
+            ig.snapshot()
+            try:
+                ig.capture()
+                ig.replay(run - warm)
+                torch.cuda.current_stream(ig.device).synchronize()
+                ok = _C.forward_status()[0] == overflow0
+            except Exception as e:        # a failed capture leaves the warm-up valid: the rest of the run goes on eagerly, no more captures
+                self._init_graph_broken = True
+                torch.cuda.synchronize(ig.device)
+                self._graph_note(stats, e)
+                ok = False
+            if ok:
+                done = run
+                stats["replays"] += run - warm
+                stats["runs"] += 1
+            else:                          # a replayed frame outgrew its binning buffer (or the capture failed): undo, let the eager loop repeat
+                ig.restore()
+                g.optimizer.zero_grad(set_to_none=True)
+                stats["redone"] += run - warm
+        stats["direct"] += warm
+        self.iteration_count += done
+        g.optimizer.advance_steps(ig.todo, done)
+        pkg = ig.pkg if done == run else None
+        if done < run:                     # finish the run eagerly, iteration by iteration (plain ones: no densification inside a run)
+            for _ in range(run - done):
+                self.iteration_count += 1
+                pkg = self._render(viewpoint, (None, None, None))
+                slam_losses.get_loss_mapping(self.config, pkg["render"], pkg["depth"], viewpoint, pkg["opacity"], initialization=True,
+                                             rm_dynamic=rm_dynamic, compute_value=self.loss_values).backward()
+                with torch.no_grad():
+                    self._view_stats(pkg)
+                    g.optimizer.step()
+                    g.optimizer.zero_grad(set_to_none=True)
         return pkg
 
     def _final_touched(self, viewpoint, pkg):

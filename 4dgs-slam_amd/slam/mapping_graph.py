@@ -231,3 +231,104 @@ class MappingGraph:
 
     def release(self):
         self.graph, self.pkgs, self._snap = None, None, None
+
+
+class InitGraph:
+    """A run of plain iterations of BackEnd.initialize_map (utils/slam_backend.py:237-296: one view, the mapping loss without exposure, Adam
+    on the Gaussians; no camera step, no regulariser, a constant learning rate) as hipGraph replays: the single-view counterpart of
+    MappingGraph. The schedule rows only carry Adam's coefficients. ``iteration()`` is one code path -- executed directly for the warm-up,
+    captured once, replayed; iterations that densify or reset opacities stay in initialize_map's eager loop and end a run."""
+
+    def __init__(self, backend, viewpoint, rm_dynamic, rows):
+        be = self.backend = backend
+        g = be.gaussians
+        self.viewpoint, self.rows = viewpoint, int(rows)
+        dev = self.device = viewpoint.device
+        self.ops = be.keyframe_operands.get(be.config, viewpoint, dev, rm_dynamic=rm_dynamic, dynamic=False)
+        opt = g.optimizer
+        self.todo = opt.scheduled_segments()
+        if self.todo is None:
+            raise RuntimeError("InitGraph: the optimizer state does not fit the fused scheduled step (run one eager iteration first)")
+        self.row_words = 2 * len(self.todo)
+        table = np.zeros((self.rows, self.row_words), dtype=np.float32)
+        for j in range(self.rows):
+            for k, (group, p) in enumerate(self.todo):
+                table[j, 2 * k], table[j, 2 * k + 1] = opt.coefficients(group["lr"], group["betas"], int(opt.state[p]["step"]) + j + 1)
+        self.table = torch.from_numpy(table.view(np.int32)).pin_memory().to(dev, non_blocking=True)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.current = torch.zeros(self.row_words, dtype=torch.int32, device=dev)
+        self.graph, self.pkg, self.executed = None, None, 0
+
+    def iteration(self):
+        be, g, dev, v = self.backend, self.backend.gaussians, self.device, self.viewpoint
+        self.pkg = None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().gsr_schedule_advance(self.counter.data_ptr(), self.table.data_ptr(), self.row_words, self.rows, self.current.data_ptr(),
+                                                       _lib.stream(dev)), "gsr_schedule_advance")
+        pkg = be._render(v, (None, None, None))
+        gt_image, gt_depth, w_rgb, w_dep, alpha = self.ops
+        loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, None, None, alpha, compute_value=False)
+        loss.backward()
+        with torch.no_grad():
+            be._view_stats(pkg)
+            g.optimizer.step_scheduled(self.todo, self.current.data_ptr())
+            g.optimizer.zero_grad(set_to_none=True)
+        # (the view's camera parameters keep accumulating their gradients, as in the eager loop and in the reference, whose initialize_map
+        # never clears them: in place, into the tensors the warm-up iterations left -- which is why the snapshot covers them)
+        self.pkg = pkg
+        return pkg
+
+    def warm_up(self, n):
+        dev = self.device
+        s = self.backend.graph_streams(dev)[0]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(n):
+                self.iteration()
+                self.executed += 1
+        torch.cuda.current_stream(dev).wait_stream(s)
+
+    def capture(self):
+        """(see MappingGraph.capture)"""
+        be, dev = self.backend, self.device
+        lazy_before = _C.set_option("lazy", 1)
+        margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+        tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
+        s = be.graph_streams(dev)[1]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.stream(s):
+                self.graph.capture_begin(pool=be.graph_pool(dev))
+                try:
+                    self.iteration()
+                finally:
+                    self.graph.capture_end()
+        finally:
+            _C.set_option("lazy", lazy_before)
+            _C.set_option("cap_margin_permille", margin_before)
+            _C.set_option("cap_tile_margin_permille", tile_before)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        be._graph_keepalive = self.graph
+        return self
+
+    def replay(self, n):
+        for _ in range(n):
+            self.graph.replay()
+        self.executed += n
+
+    def snapshot(self):
+        g = self.backend.gaussians
+        tensors = [p for _, p in self.todo] + [g.optimizer.state[p][k] for _, p in self.todo for k in ("exp_avg", "exp_avg_sq")]
+        tensors += [g.xyz_gradient_accum, g.denom, g.max_radii2D, self.counter]
+        v = self.viewpoint
+        tensors += [p.grad for p in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b) if p is not None and p.grad is not None]
+        with torch.no_grad():
+            self._snap = [(t, t.detach().clone()) for t in tensors]
+        self._snap_executed = self.executed
+
+    def restore(self):
+        with torch.no_grad():
+            for t, c in self._snap:
+                t.detach().copy_(c)
+        self.executed = self._snap_executed

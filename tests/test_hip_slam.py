@@ -547,6 +547,37 @@ def test_static_mapping_iterations_as_hip_graph_are_bit_identical_to_eager():
     assert max(float(graph[-1]["poses"][k][4].abs().max()) for k in window if k != 0) > 0
 
 
+def _initialisation_outcome(graph, **training):
+    from slam.dataset import SyntheticRGBDDataset
+    from slam.system import SLAM
+    torch.manual_seed(0)
+    ds = SyntheticRGBDDataset(num_frames=4, width=320, height=240, seed=0)
+    slam = SLAM(_quick_config(mapping_graph=graph, init_itr_num=260, init_gaussian_update=100, init_gaussian_reset=120, **training), ds)
+    slam.frontend.run(max_frames=1)
+    torch.cuda.synchronize()
+    be, g = slam.backend, slam.gaussians
+    cam = be.viewpoints[0]
+    state = [p.detach().clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)]
+    state += [g.optimizer.state[p][k].clone() for grp in g.optimizer.param_groups for p in grp["params"] if p in g.optimizer.state for k in ("exp_avg", "exp_avg_sq")]
+    state += [g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone(), be.occ_aware_visibility[0].clone()]
+    state += [p.grad.clone() for p in (cam.cam_rot_delta, cam.cam_trans_delta) if p.grad is not None]
+    steps = [float(g.optimizer.state[p]["step"]) for grp in g.optimizer.param_groups for p in grp["params"] if p in g.optimizer.state]
+    return state, steps, be.iteration_count, dict(getattr(be, "init_graph_stats", {}) or {})
+
+
+def test_initialize_map_as_hip_graph_is_bit_identical_to_eager():
+    """BackEnd.initialize_map (utils/slam_backend.py:237-296) with its runs of plain iterations replayed as hipGraphs (mapping_graph.InitGraph)
+    against the eager loop: 260 iterations with three densifications and an opacity reset in between must leave the same map, moments, step
+    counts, densification statistics, covisibility row and accumulated camera gradients, bit for bit."""
+    a, steps_a, count_a, stats = _initialisation_outcome("strict")
+    assert stats["runs"] >= 3 and stats["replays"] >= 200 and stats["failed"] == 0 and stats["redone"] == 0, stats
+    b, steps_b, count_b, stats_b = _initialisation_outcome(False)
+    assert not stats_b or stats_b["replays"] == 0
+    assert steps_a == steps_b and count_a == count_b and len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and torch.equal(x, y), (i, tuple(x.shape), tuple(y.shape))
+
+
 def test_mapping_graph_run_that_outgrows_its_buffers_is_redone_eagerly():
     """A replayed frame that needs more instance slots than the captured buffers hold bumps the sticky overflow counters
     (gsr_forward_status_views); the run is undone from its snapshot and repeated eagerly -- same result as the eager loop. The overflow is
