@@ -1954,6 +1954,55 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
     return 0;
 }
 
+int gsr_arap_forward(int V, int T, int M, int K, const float* p, const float* nb, const float* keep, float* R, float* partial, void* stream_)
+{
+    if (V < 0 || T < 2 || M < 0 || K < 1 || ((size_t)V * M > 0 && (!p || !nb || !keep || !R || !partial))) {
+        g_last_error = "gsr_arap_forward: invalid argument (T >= 2, K >= 1, no null buffers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)V * (T - 1) * M;
+    if (n > 0x7fffffffull) { g_last_error = "gsr_arap_forward: too many (view, sample, node) triples"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (n) hipLaunchKernelGGL(arap_forward_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, V, T, M, K, p, nb, keep, R, partial);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_arap_backward(int V, int T, int M, int K, const float* p, const float* nb, const float* keep, const float* R, const float* g_partial,
+                      float* dp, float* dnb, void* stream_)
+{
+    if (V < 0 || T < 2 || M < 0 || K < 1 || ((size_t)V * M > 0 && (!p || !nb || !keep || !R || !g_partial || !dp || !dnb))) {
+        g_last_error = "gsr_arap_backward: invalid argument (T >= 2, K >= 1, no null buffers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)V * M;
+    if (n) hipLaunchKernelGGL(arap_backward_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, V, T, M, K, p, nb, keep, R, g_partial, dp, dnb);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_elastic_forward(int V, int M, int K, int T, const float* x, const float* nb, float* ratio, void* stream_)
+{
+    if (V < 0 || M < 0 || K < 1 || T < 2 || T > ELASTIC_MAX_T || ((size_t)V * M > 0 && (!x || !nb || !ratio))) {
+        g_last_error = "gsr_elastic_forward: invalid argument (2 <= T <= 16, K >= 1, no null buffers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)V * M * K;
+    if (n) hipLaunchKernelGGL(elastic_forward_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, (int)n, M, K, T, x, nb, ratio);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_elastic_backward(int V, int M, int K, int T, const float* x, const float* nb, const float* g_ratio, float* dx, float* dnb, void* stream_)
+{
+    if (V < 0 || M < 0 || K < 1 || T < 2 || T > ELASTIC_MAX_T || ((size_t)V * M > 0 && (!x || !nb || !g_ratio || !dx || !dnb))) {
+        g_last_error = "gsr_elastic_backward: invalid argument (2 <= T <= 16, K >= 1, no null buffers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)V * M * K, nx = (size_t)V * M * T * 3;
+    if (n) {
+        hipLaunchKernelGGL(elastic_backward_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, (int)n, M, K, T, x, nb, g_ratio, dnb);
+        hipLaunchKernelGGL(elastic_backward_self_kernel, dim3((unsigned)((nx + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, (int)nx, K, T * 3, dnb, dx);
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int gsr_kabsch_rotations(int n, const float* S, float* R, void* stream_)
 {
     if (n < 0 || (n > 0 && (!S || !R))) { g_last_error = "gsr_kabsch_rotations: null argument"; return GSR_ERR_INVALID_ARGUMENT; }

@@ -393,12 +393,9 @@ __global__ void __launch_bounds__(256) edge_compare_kernel(const float* __restri
 // rotation closest to S^T. The reference calls torch.svd on [Nv,3,3] per time sample; here one thread per matrix: Jacobi eigenvectors of
 // S^T S (double precision), u_i = S v_i / sigma_i for the two largest singular values, third axes by cross products -- which IS the
 // reflection rule. S = 0 (the reference zeroes S for unchanged vertices, :148-149) gives the identity.
-__global__ void __launch_bounds__(64) kabsch_rotation_kernel(int n, const float* __restrict__ S_in, float* __restrict__ R_out)
+__device__ inline void kabsch_rotation(const double S[3][3], float* __restrict__ R)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    double S[3][3], A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[r][c] = (double)S_in[9 * (size_t)i + 3 * r + c];
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = S[0][r] * S[0][c] + S[1][r] * S[1][c] + S[2][r] * S[2][c];   // S^T S
     for (int sweep = 0; sweep < 12; sweep++) {                   // cyclic Jacobi: A <- J^T A J, V <- V J
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
@@ -419,7 +416,6 @@ __global__ void __launch_bounds__(64) kabsch_rotation_kernel(int n, const float*
     for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (A[o[b]][o[b]] > A[o[a]][o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
     double v1[3], v2[3], u1[3], u2[3];
     for (int k = 0; k < 3; k++) { v1[k] = V[k][o[0]]; v2[k] = V[k][o[1]]; }
-    float* R = R_out + 9 * (size_t)i;
     const double s1 = A[o[0]][o[0]];
     if (!(s1 > 1e-60)) { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.f : 0.f; return; }
     for (int r = 0; r < 3; r++) { u1[r] = S[r][0] * v1[0] + S[r][1] * v1[1] + S[r][2] * v1[2]; u2[r] = S[r][0] * v2[0] + S[r][1] * v2[1] + S[r][2] * v2[2]; }
@@ -439,6 +435,164 @@ __global__ void __launch_bounds__(64) kabsch_rotation_kernel(int n, const float*
     const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
     const double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = (float)(v1[r] * u1[c] + v2[r] * u2[c] + v3[r] * u3[c]);   // V U^T
+}
+
+__global__ void __launch_bounds__(64) kabsch_rotation_kernel(int n, const float* __restrict__ S_in, float* __restrict__ R_out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double S[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[r][c] = (double)S_in[9 * (size_t)i + 3 * r + c];
+    kabsch_rotation(S, R_out + 9 * (size_t)i);
+}
+
+// ---- the two regularisers of the node graph as one kernel each way (round 4) -------------------------------------------------------------
+// ARAP (cal_arap_error, utils/deform_utils.py:177-205, without edge weights): for V views x T time samples x M nodes with K neighbours each,
+//   E_t[k] = (p_t - nb_t[k]) keep[k];  S = sum_k E_0[k] E_t[k]^T (zero when, in some coordinate, no edge changed, :147-149);  R = kabsch(S);
+//   partial[v][t-1][m] = sum_k keep[k] |E_t[k] - R E_0[k]|^2            (R is a constant of the backward pass, :190-204 detach it)
+// as the op-by-op tensor program: gather, subtract, mask, einsum, compare, where, a Kabsch launch, einsum, subtract, square, two sums -- and
+// twice as many kernels on the way back, each on ~10^5 values: launch latency, not work. One thread per (view, sample, node) here; the
+// backward kernel takes one thread per (view, node) and walks the samples, so the first sample's gradient (every E_0) needs no atomics.
+// p [V][T][M][3], nb [V][T][M][K][3] (the neighbours' positions, gathered by the caller: control_nodes.gather_rows, whose backward is the
+// ordered scatter), keep [V][M][K] (0 / 1), R [V][T-1][M][9], partial [V][T-1][M].
+__global__ void __launch_bounds__(64) arap_forward_kernel(int V, int T, int M, int K, const float* __restrict__ p, const float* __restrict__ nb,
+                                                          const float* __restrict__ keep, float* __restrict__ R_out, float* __restrict__ partial)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= V * (T - 1) * M) return;
+    const int m = i % M, t = 1 + (i / M) % (T - 1), v = i / (M * (T - 1));
+    const float* p0 = p + ((size_t)(v * T) * M + m) * 3, * pt = p + ((size_t)(v * T + t) * M + m) * 3;
+    const float* n0 = nb + ((size_t)(v * T) * M + m) * K * 3, * nt = nb + ((size_t)(v * T + t) * M + m) * K * 3;
+    const float* kp = keep + ((size_t)v * M + m) * K;
+    double S[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    bool same[3] = {true, true, true};
+    for (int k = 0; k < K; k++) {
+        const float w = kp[k];
+        float e0[3], et[3];
+        for (int c = 0; c < 3; c++) { e0[c] = (p0[c] - n0[3 * k + c]) * w; et[c] = (pt[c] - nt[3 * k + c]) * w; same[c] = same[c] && e0[c] == et[c]; }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[a][b] += (double)(e0[a] * w) * (double)et[b];
+    }
+    if (same[0] || same[1] || same[2]) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[a][b] = 0.0;
+    float R[9];
+    {   // (the op-by-op version hands Kabsch an fp32 S: round here too, so that both see the same matrix)
+        double Sf[3][3];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Sf[a][b] = (double)(float)S[a][b];
+        kabsch_rotation(Sf, R);
+    }
+    float acc = 0.f;
+    for (int k = 0; k < K; k++) {
+        const float w = kp[k];
+        float e0[3], et[3];
+        for (int c = 0; c < 3; c++) { e0[c] = (p0[c] - n0[3 * k + c]) * w; et[c] = (pt[c] - nt[3 * k + c]) * w; }
+        float q = 0.f;
+        for (int a = 0; a < 3; a++) { const float r = et[a] - (R[3 * a] * e0[0] + R[3 * a + 1] * e0[1] + R[3 * a + 2] * e0[2]); q += r * r; }
+        acc += w * q;
+    }
+    for (int c = 0; c < 9; c++) R_out[9 * (size_t)i + c] = R[c];
+    partial[i] = acc;
+}
+
+// g [V][T-1][M] (cotangent of partial) -> dp [V][T][M][3], dnb [V][T][M][K][3] (both fully written)
+__global__ void __launch_bounds__(64) arap_backward_kernel(int V, int T, int M, int K, const float* __restrict__ p, const float* __restrict__ nb,
+                                                           const float* __restrict__ keep, const float* __restrict__ R_in, const float* __restrict__ g,
+                                                           float* __restrict__ dp, float* __restrict__ dnb)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= V * M) return;
+    const int m = i % M, v = i / M;
+    const float* kp = keep + ((size_t)v * M + m) * K;
+    const float* p0 = p + ((size_t)(v * T) * M + m) * 3;
+    const float* n0 = nb + ((size_t)(v * T) * M + m) * K * 3;
+    float* dn0 = dnb + ((size_t)(v * T) * M + m) * K * 3;
+    float dp0[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k++) for (int c = 0; c < 3; c++) dn0[3 * k + c] = 0.f;
+    for (int t = 1; t < T; t++) {
+        const size_t j = ((size_t)v * (T - 1) + (t - 1)) * M + m;
+        const float* R = R_in + 9 * j;
+        const float gj = g[j];
+        const float* pt = p + ((size_t)(v * T + t) * M + m) * 3;
+        const float* nt = nb + ((size_t)(v * T + t) * M + m) * K * 3;
+        float* dnt = dnb + ((size_t)(v * T + t) * M + m) * K * 3;
+        float dpt[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < K; k++) {
+            const float w = kp[k];
+            float e0[3], et[3], r[3];
+            for (int c = 0; c < 3; c++) { e0[c] = (p0[c] - n0[3 * k + c]) * w; et[c] = (pt[c] - nt[3 * k + c]) * w; }
+            for (int a = 0; a < 3; a++) r[a] = et[a] - (R[3 * a] * e0[0] + R[3 * a + 1] * e0[1] + R[3 * a + 2] * e0[2]);
+            const float cf = 2.0f * w * gj;
+            for (int c = 0; c < 3; c++) {
+                const float det = cf * r[c] * w;                                                   // d / d E_t, through the mask
+                const float de0 = -cf * (R[c] * r[0] + R[3 + c] * r[1] + R[6 + c] * r[2]) * w;    // d / d E_0 = -R^T r
+                dpt[c] += det; dnt[3 * k + c] = -det;
+                dp0[c] += de0; dn0[3 * k + c] -= de0;
+            }
+        }
+        float* o = dp + ((size_t)(v * T + t) * M + m) * 3;
+        o[0] = dpt[0]; o[1] = dpt[1]; o[2] = dpt[2];
+    }
+    float* o = dp + ((size_t)(v * T) * M + m) * 3;
+    o[0] = dp0[0]; o[1] = dp0[1]; o[2] = dp0[2];
+}
+
+// Elastic term (ControlNodeWarp.elastic_loss, utils/time_utils.py:1160-1165): per (view, node, neighbour) the UNBIASED variance over the T time
+// samples of the edge length |nb_t - x_t|, divided by its own detached value + 1e-5. x [V][M][T][3], nb [V][M][K][T][3] -> ratio [V][M][K]
+// (the caller weighs it with the RBF weights, sums the neighbours and averages the nodes: small tensor ops that carry the weights' gradient).
+constexpr int ELASTIC_MAX_T = 16;
+__global__ void __launch_bounds__(64) elastic_forward_kernel(int n, int M, int K, int T, const float* __restrict__ x, const float* __restrict__ nb,
+                                                             float* __restrict__ ratio)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;           // (v, m, k)
+    if (i >= n) return;
+    const float* xs = x + (size_t)(i / K) * T * 3;
+    const float* ns = nb + (size_t)i * T * 3;
+    float e[ELASTIC_MAX_T], mean = 0.f;
+    for (int t = 0; t < T; t++) {
+        const float a = ns[3 * t] - xs[3 * t], b = ns[3 * t + 1] - xs[3 * t + 1], c = ns[3 * t + 2] - xs[3 * t + 2];
+        e[t] = sqrtf(a * a + b * b + c * c);
+        mean += e[t];
+    }
+    mean /= (float)T;
+    float var = 0.f;
+    for (int t = 0; t < T; t++) var += (e[t] - mean) * (e[t] - mean);
+    var /= (float)(T - 1);
+    ratio[i] = var / (var + 1e-5f);
+}
+
+// g [V][M][K] -> dnb [V][M][K][T][3] (fully written) and dx_parts [V][M][K][T][3]'s negative: dx[v][m][t] = -sum_k dnb[v][m][k][t] is formed by
+// the second kernel in neighbour order
+__global__ void __launch_bounds__(64) elastic_backward_kernel(int n, int M, int K, int T, const float* __restrict__ x, const float* __restrict__ nb,
+                                                              const float* __restrict__ g, float* __restrict__ dnb)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* xs = x + (size_t)(i / K) * T * 3;
+    const float* ns = nb + (size_t)i * T * 3;
+    float* o = dnb + (size_t)i * T * 3;
+    float e[ELASTIC_MAX_T], mean = 0.f;
+    for (int t = 0; t < T; t++) {
+        const float a = ns[3 * t] - xs[3 * t], b = ns[3 * t + 1] - xs[3 * t + 1], c = ns[3 * t + 2] - xs[3 * t + 2];
+        e[t] = sqrtf(a * a + b * b + c * c);
+        mean += e[t];
+    }
+    mean /= (float)T;
+    float var = 0.f;
+    for (int t = 0; t < T; t++) var += (e[t] - mean) * (e[t] - mean);
+    var /= (float)(T - 1);
+    const float dvar = g[i] / (var + 1e-5f);                                   // the denominator is detached
+    for (int t = 0; t < T; t++) {
+        const float de = dvar * 2.0f * (e[t] - mean) / (float)(T - 1);
+        const float s = e[t] > 0.f ? de / e[t] : 0.f;                            // d |d| / d d = d / |d| (0 at d = 0, like torch's norm)
+        for (int c = 0; c < 3; c++) o[3 * t + c] = s * (ns[3 * t + c] - xs[3 * t + c]);
+    }
+}
+__global__ void __launch_bounds__(64) elastic_backward_self_kernel(int n, int K, int T3, const float* __restrict__ dnb, float* __restrict__ dx)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;           // (v, m, t, c) flattened: n = V M T 3
+    if (i >= n) return;
+    const int vm = i / T3, tc = i % T3;
+    float acc = 0.f;
+    for (int k = 0; k < K; k++) acc -= dnb[((size_t)vm * K + k) * T3 + tc];
+    dx[i] = acc;
 }
 
 }  // namespace gsr

@@ -50,6 +50,14 @@ def lib():
         L.gsr_schedule_advance.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
         L.gsr_slot_gather.restype = _i
         L.gsr_slot_gather.argtypes = [_i, _vp, _vp, C.POINTER(KeyframeEntry), _i, _vp]
+        L.gsr_arap_forward.restype = _i
+        L.gsr_arap_forward.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.gsr_arap_backward.restype = _i
+        L.gsr_arap_backward.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.gsr_elastic_forward.restype = _i
+        L.gsr_elastic_forward.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp]
+        L.gsr_elastic_backward.restype = _i
+        L.gsr_elastic_backward.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
         L.gsr_kabsch_rotations.restype = _i
         L.gsr_kabsch_rotations.argtypes = [_i, _vp, _vp, _vp]
         L.gsr_edge_mask.restype = _i

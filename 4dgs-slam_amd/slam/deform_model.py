@@ -100,6 +100,67 @@ def edge_matrix(verts, nn_idx, keep):
     return (verts[..., :, None, :] - nb) * keep[..., None]
 
 
+class _ArapTerm(torch.autograd.Function):
+    """partial[v, t-1, m] = sum_k keep |E_t - R E_0|^2 of arap_error in one launch each way (gsr_arap_forward / _backward, include/slam_map.h):
+    p [V, T, M, 3], nb [V, T, M, K, 3] (the gathered neighbours), keep [V, M, K] float."""
+
+    @staticmethod
+    def forward(ctx, p, nb, keep):
+        from . import _lib
+        V, T, M, K = (int(v) for v in nb.shape[:4])
+        p, nb, keep = p.contiguous(), nb.contiguous(), keep.contiguous()
+        R = torch.empty((V, T - 1, M, 9), dtype=torch.float32, device=p.device)
+        partial = torch.empty((V, T - 1, M), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().gsr_arap_forward(V, T, M, K, p.data_ptr(), nb.data_ptr(), keep.data_ptr(), R.data_ptr(), partial.data_ptr(),
+                                                   _lib.stream(p.device)), "gsr_arap_forward")
+        ctx.save_for_backward(p, nb, keep, R)
+        return partial
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        p, nb, keep, R = ctx.saved_tensors
+        V, T, M, K = (int(v) for v in nb.shape[:4])
+        g = g.to(torch.float32).contiguous()
+        dp, dnb = torch.empty_like(p), torch.empty_like(nb)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().gsr_arap_backward(V, T, M, K, p.data_ptr(), nb.data_ptr(), keep.data_ptr(), R.data_ptr(), g.data_ptr(), dp.data_ptr(),
+                                                    dnb.data_ptr(), _lib.stream(p.device)), "gsr_arap_backward")
+        return dp, dnb, None
+
+
+class _ElasticRatio(torch.autograd.Function):
+    """ratio[v, m, k] = var_t |nb - x| / (its detached value + 1e-5) of elastic_error in one launch forward, two back (gsr_elastic_forward /
+    _backward): x [V, M, T, 3], nb [V, M, K, T, 3]."""
+
+    @staticmethod
+    def forward(ctx, x, nb):
+        from . import _lib
+        V, M, K, T = (int(v) for v in nb.shape[:4])
+        x, nb = x.contiguous(), nb.contiguous()
+        ratio = torch.empty((V, M, K), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().gsr_elastic_forward(V, M, K, T, x.data_ptr(), nb.data_ptr(), ratio.data_ptr(), _lib.stream(x.device)), "gsr_elastic_forward")
+        ctx.save_for_backward(x, nb)
+        return ratio
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        x, nb = ctx.saved_tensors
+        V, M, K, T = (int(v) for v in nb.shape[:4])
+        g = g.to(torch.float32).contiguous()
+        dx, dnb = torch.empty_like(x), torch.empty_like(nb)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().gsr_elastic_backward(V, M, K, T, x.data_ptr(), nb.data_ptr(), g.data_ptr(), dx.data_ptr(), dnb.data_ptr(),
+                                                       _lib.stream(x.device)), "gsr_elastic_backward")
+        return dx, dnb
+
+
+FUSED_REGULARISERS = os.environ.get("GSR_FUSED_REGULARISERS", "1") != "0"
+
+
 def estimate_rotation(E0, Et, weight, rotations=kabsch_rotations):
     """estimate_rotation (deform_utils.py:130-166) on edge matrices [..., Nv, K, 3]: S = E0^T diag(w) Et, zeroed for vertices none of whose
     edges changed in some coordinate (:147-149), then the best-fit rotation of every S."""
@@ -116,6 +177,16 @@ def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
     1 .. T-1 (:190-204); here they are one more tensor axis (same terms, summed in one reduction)."""
     if nodes_seq.shape[-3] < 2:
         return torch.zeros(nodes_seq.shape[:-3], dtype=nodes_seq.dtype, device=nodes_seq.device)
+    if (FUSED_REGULARISERS and rotations is kabsch_rotations and nodes_seq.is_cuda and nodes_seq.dtype == torch.float32 and nodes_seq.dim() == 4
+            and nn_idx.dim() == 3 and nn_idx.shape[0] == nodes_seq.shape[0]):
+        # device tensors [V, T, M, 3] with one neighbour set per view: the neighbours through control_nodes.gather_rows (ordered backward),
+        # everything per (view, sample, node) -- edges, cross-covariance, Kabsch, the error and all of its backward -- in one launch each way
+        V, T, M, _ = nodes_seq.shape
+        K = nn_idx.shape[-1]
+        sets = control_nodes.IndexSets(nn_idx.reshape(V, M * K), M)
+        set_of_b = torch.arange(V, device=nodes_seq.device, dtype=torch.int32).repeat_interleave(T) if V > 1 else None
+        nb = control_nodes.gather_rows(nodes_seq.reshape(V * T, M, 3), sets, set_of_b).reshape(V, T, M, K, 3)
+        return _ArapTerm.apply(nodes_seq, nb, keep.to(torch.float32)).sum(dim=(1, 2))
     w = keep.to(nodes_seq.dtype)
     E = edge_matrix(nodes_seq, nn_idx[..., None, :, :], keep[..., None, :, :])          # [..., T, Nv, K, 3]
     E0, Et = E.split([1, E.shape[-4] - 1], -4)
@@ -135,6 +206,9 @@ def elastic_error(nodes_t, nn_weight, nn_idx):
         lead = nodes_t.shape[:-3]
         flat = nodes_t.reshape(-1, M, T * 3)
         nb = control_nodes.gather_rows(flat, control_nodes.IndexSets(nn_idx.reshape(1, M * K), M)).reshape(*lead, M, K, T, 3)
+        if FUSED_REGULARISERS and len(lead) == 1 and 2 <= T <= 16:
+            ratio = _ElasticRatio.apply(flat.reshape(lead[0], M, T, 3), nb)            # [V, M, K]: the variance and its normalisation, fused
+            return (ratio * nn_weight).sum(dim=-1).mean(dim=-1)
         edge_t = (nb - nodes_t[..., :, None, :, :]).norm(dim=-1)                          # [..., M, K, T]
     else:
         edge_t = (nodes_t[..., nn_idx, :, :] - nodes_t[..., :, None, :, :]).norm(dim=-1)      # [..., M, K, T]

@@ -131,6 +131,21 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
  * value is flipped when det <= 0): always a proper rotation; S = 0 -> identity. One thread per matrix, double precision inside. */
 int gsr_kabsch_rotations(int n, const float* S, float* R, void* stream);
 
+/* The node graph's two regularisers, one launch each way (round 4). The caller gathers the neighbours' positions (a gather whose backward is an
+ * ordered scatter: gsr_index_csr + gsr_segment_sum) and reduces the per-node results; everything per (view, sample, node) happens here.
+ *   ARAP (cal_arap_error, utils/deform_utils.py:177-205, no edge weights): p [V][T][M][3] node positions at T time samples of V views,
+ *     nb [V][T][M][K][3] their K neighbours' positions, keep [V][M][K] 0 / 1 (cal_connectivity_from_points' radius rule).
+ *     E_t[k] = (p_t - nb_t[k]) keep[k]; S = sum_k E_0[k] E_t[k]^T, zeroed when no edge changed in some coordinate (:147-149); R = V U^T of S's
+ *     SVD with the reflection rule (gsr_kabsch_rotations' arithmetic); partial[v][t-1][m] = sum_k keep[k] |E_t[k] - R E_0[k]|^2.
+ *     R [V][T-1][M][9] is kept for the backward pass, where it is a constant (:190-204).  g_partial: cotangent of partial.
+ *   Elastic (ControlNodeWarp.elastic_loss, utils/time_utils.py:1160-1165): x [V][M][T][3], nb [V][M][K][T][3] ->
+ *     ratio[v][m][k] = var_t |nb_t - x_t| / (the same value, detached, + 1e-5), unbiased variance, 2 <= T <= 16. */
+int gsr_arap_forward(int V, int T, int M, int K, const float* p, const float* nb, const float* keep, float* R, float* partial, void* stream);
+int gsr_arap_backward(int V, int T, int M, int K, const float* p, const float* nb, const float* keep, const float* R, const float* g_partial,
+                      float* dp, float* dnb, void* stream);
+int gsr_elastic_forward(int V, int M, int K, int T, const float* x, const float* nb, float* ratio, void* stream);
+int gsr_elastic_backward(int V, int M, int K, int T, const float* x, const float* nb, const float* g_ratio, float* dx, float* dnb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

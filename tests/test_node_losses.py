@@ -222,3 +222,35 @@ def test_batched_node_network_evaluation_equals_the_direct_one():
         # (sums over ~2 000 rows in a different order: the absolute slack scales with the gradient's magnitude -- a host with another BLAS
         # threading, e.g. the GPU box's, needs it)
         assert (a is None and b.grad is None) or torch.allclose(a, b.grad, rtol=1e-4, atol=1e-6 + 2e-5 * float(b.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_fused_regularisers_equal_the_op_by_op_ones():
+    """arap_error / elastic_error on the device through the one-launch kernels (gsr_arap_forward / _backward, gsr_elastic_forward / _backward)
+    against the tensor programs they replace (the ones the CPU tests compare with the reference): several views, values and gradients."""
+    from slam import deform_model as dm
+    g = torch.Generator().manual_seed(5)
+    V, T, M = 3, 4, 200
+    base = torch.randn(M, 3, generator=g) * 0.3
+    motion = (torch.randn(V, T, M, 3, generator=g) * 0.02).cuda()
+    weights = torch.rand(M, 2, generator=g).cuda().requires_grad_(True)
+    results = {}
+    for fused in (True, False):
+        dm.FUSED_REGULARISERS = fused
+        try:
+            d = motion.clone().requires_grad_(True)
+            seq = base.cuda() + d
+            nn_idx, keep = dm.connectivity_from_points(seq[:, 0], K=10, radius=0.25)
+            arap = dm.arap_error(seq, nn_idx, keep)
+            knn = dm.control_nodes.knn_points(base.cuda()[None], base.cuda()[None], K=3).idx[0, :, 1:]
+            elastic = dm.elastic_error(seq.permute(0, 2, 1, 3), weights, knn)
+            (arap * torch.tensor([1.0, 0.5, 2.0], device="cuda")).sum().backward(retain_graph=True)
+            ga = d.grad.clone(); d.grad = None
+            (elastic * torch.tensor([1.0, 0.5, 2.0], device="cuda")).sum().backward()
+            results[fused] = (arap.detach(), elastic.detach(), ga, d.grad.clone(), weights.grad.clone())
+            weights.grad = None
+        finally:
+            dm.FUSED_REGULARISERS = True
+    assert bool(keep.any()) and not bool(keep.all())
+    for name, a, b in zip(("arap", "elastic", "d arap", "d elastic", "d weights"), results[True], results[False]):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))
