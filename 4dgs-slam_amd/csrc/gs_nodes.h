@@ -493,8 +493,17 @@ colsum_finalize_kernel(const int bands, const int cols, const float* __restrict_
     __shared__ float s_p[16][17];
     const int cl = threadIdx.x & 15, p = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     float acc = 0.f;
-    if (c < cols)
-        for (int b = p; b < bands; b += 16) acc += partial[(size_t)b * cols + c];
+    if (c < cols) {
+        int b = p;
+        for (; b + 7 * 16 < bands; b += 8 * 16) {            // eight loads in flight per trip (the adds stay in band order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(b + 16 * u) * cols + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; b < bands; b += 16) acc += partial[(size_t)b * cols + c];
+    }
     s_p[p][cl] = acc;
     __syncthreads();
     if (p == 0 && c < cols) {
