@@ -250,6 +250,12 @@ class BackEnd:
             g.deform.extend_node_from_point(init_pcl=g.get_dygs_xyz.detach())
             g.deform_init = True
         pkg = None
+        from . import dynamic_graph
+        if dynamic_graph.NetworkInit.eligible(self, viewpoint, update_gaussians):
+            # the normal case: the loop in the indexed layout of slam/dynamic_graph.py, its iterations after the first as hipGraph replays
+            pkg = dynamic_graph.NetworkInit(self, viewpoint).run(self.network_init_iters)
+            self._finish_network_init(cur_frame_idx, viewpoint, pkg)
+            return
         for mapping_iteration in range(self.network_init_iters):
             deltas = self._deltas(viewpoint)
             pkg = self._render(viewpoint, deltas)
@@ -266,7 +272,10 @@ class BackEnd:
                 if update_gaussians:
                     g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
-        if pkg["n_touched"].shape[0] != g.get_xyz.shape[0]:                       # the model was rebuilt after the last render
+        self._finish_network_init(cur_frame_idx, viewpoint, pkg)
+
+    def _finish_network_init(self, cur_frame_idx, viewpoint, pkg):
+        if pkg is None or pkg["n_touched"].shape[0] != self.gaussians.get_xyz.shape[0]:      # the model was rebuilt after the last render
             with torch.no_grad():
                 pkg = self._render(viewpoint, self._deltas(viewpoint, train=False))
         self.occ_aware_visibility[cur_frame_idx] = (pkg["n_touched"] > 0).long()

@@ -411,7 +411,7 @@ class DynamicMapping:
             for v in self.views:
                 v.refresh_matrices()
 
-    def plain_run(self, rows, last):
+    def plain_run(self, rows):
         """A run of plain iterations: replays of one captured iteration when the run is long enough and graphs are on, else direct."""
         be, r = self.be, self.run
         use_graph = (be._graphs_enabled() and rows >= be.graph_min_run and not getattr(be, "_dynamic_graph_broken", False)
@@ -484,7 +484,7 @@ class DynamicMapping:
             while i + rows < self.iters and self.phase(i + rows) == ph and not special_at(i + rows, count + rows):
                 rows += 1
             self.make_run(i, rows, ph)
-            self.plain_run(rows, last=(i + rows == self.iters))
+            self.plain_run(rows)
             split = False
             i += rows
             if i == self.iters:
@@ -492,3 +492,137 @@ class DynamicMapping:
                     be._publish_visibility(self.current_window, {k: self.pkgs[k]["n_touched"] for k in range(nv)}, n_views=nv)
         self.run, self.graph, self.pkgs, self._snap = None, None, None, None
         return split
+
+
+class NetworkInit:
+    """BackEnd.initialize_network's loop (utils/slam_backend.py:160-234: the node network fitted on ONE view -- network, blend, render, the
+    mapping loss without exposure, backward, Adam on the network) in the indexed layout (one time sample, every head), its iterations after the
+    first -- which may densify -- as hipGraph replays. ``iteration()`` is one code path, executed directly or captured and replayed."""
+
+    def __init__(self, backend, viewpoint):
+        be = self.be = backend
+        self.g, self.viewpoint = be.gaussians, viewpoint
+        self.nodes = self.g.deform.deform
+        dev = self.device = viewpoint.device
+        self.ops = be.keyframe_operands.get(be.config, viewpoint, dev, rm_dynamic=False, dynamic=False)
+        self.time = torch.tensor([time_key(viewpoint.time)], dtype=torch.float32).to(dev)
+        self.graph, self.pkg = None, None
+        self.stats = be.__dict__.setdefault("network_init_graph_stats", {"runs": 0, "replays": 0, "direct": 0, "redone": 0, "failed": 0})
+
+    @staticmethod
+    def eligible(be, viewpoint, update_gaussians):
+        g, t = be.gaussians, be.config["Training"]
+        return (t.get("dynamic_fixed_layout", True) and not update_gaussians and not be.shard.active and not be.loss_values and not t.get("monocular", False)
+                and str(be.device).startswith("cuda") and isinstance(viewpoint, Camera) and viewpoint.depth is not None and g.deform_init
+                and g.deform.deform.node_num >= 1 and g.dyn_rows().shape[0] > 0 and getattr(g.optimizer, "_fused_acc", False))
+
+    def iteration(self, densify=False):
+        be, g, nodes, v = self.be, self.g, self.nodes, self.viewpoint
+        self.pkg = None
+        it = nodes.begin_iteration_indexed(self.time, 1, blend=(g.get_dygs_xyz.detach(), g.motion_mask))
+        rows = it["blended"]
+        pkg = be._render(v, (rows[0][0], rows[2][0], rows[1][0]))
+        gt_image, gt_depth, w_rgb, w_dep, alpha = self.ops
+        slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, None, None, alpha, compute_value=False).backward()
+        nodes.end_iteration()
+        with torch.no_grad():
+            be._view_stats(pkg)
+            if densify:                                                            # :209-215 (iteration 0 with the shipped schedule)
+                g.densify_and_prune(be.opt_params.densify_grad_threshold, be.init_gaussian_th, be.init_gaussian_extent, None)
+            g.deform.optimizer.step()
+            g.deform.optimizer.zero_grad(set_to_none=True)
+            g.optimizer.zero_grad(set_to_none=True)
+        # (the view's camera parameters keep accumulating their gradients, as in the reference: see mapping_graph.InitGraph)
+        self.pkg = pkg
+        return pkg
+
+    def _snapshot(self):
+        g, v = self.g, self.viewpoint
+        net = g.deform.optimizer
+        tensors = []
+        for grp in net.param_groups:
+            for p in grp["params"]:
+                tensors.append(p)
+                tensors += [s for s in net.state.get(p, {}).values() if torch.is_tensor(s)]
+        tensors += [g.xyz_gradient_accum, g.denom, g.max_radii2D]
+        tensors += [p.grad for p in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b) if p is not None and p.grad is not None]
+        with torch.no_grad():
+            return [(t, t.detach().clone()) for t in tensors]
+
+    def run(self, iterations):
+        """All iterations of the loop; returns the last render package."""
+        be, dev = self.be, self.device
+        i = 0
+        while i < iterations:
+            if i % be.init_gaussian_update == 0:
+                self.iteration(densify=True)
+                self.stats["direct"] += 1
+                i += 1
+                continue
+            rows = 0
+            while i + rows < iterations and (i + rows) % be.init_gaussian_update != 0:
+                rows += 1
+            if not (be._graphs_enabled() and rows >= be.graph_min_run and not getattr(be, "_network_init_graph_broken", False)):
+                for _ in range(rows):
+                    self.iteration()
+                self.stats["direct"] += rows
+                i += rows
+                continue
+            warm = min(be.dynamic_graph_warmup, rows)
+            s0, s1 = be.graph_streams(dev)
+            s0.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s0):
+                for _ in range(warm):
+                    self.iteration()
+            torch.cuda.current_stream(dev).wait_stream(s0)
+            self.stats["direct"] += warm
+            overflow0 = _C.forward_status()[0]
+            snap = self._snapshot()
+            ok = True
+            lazy_before = _C.set_option("lazy", 1)
+            margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
+            tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
+            try:
+                s1.wait_stream(torch.cuda.current_stream(dev))
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(s1):
+                    self.graph.capture_begin(pool=be.graph_pool(dev))
+                    try:
+                        self.iteration()
+                    finally:
+                        self.graph.capture_end()
+                torch.cuda.current_stream(dev).wait_stream(s1)
+                be._graph_keepalive = self.graph
+            except Exception as e:
+                be._network_init_graph_broken = True
+                torch.cuda.synchronize(dev)
+                self.stats["failed"] += 1
+                self.stats["last_error"] = f"{type(e).__name__}: {e}"
+                if be.config["Training"].get("mapping_graph") == "strict":
+                    raise
+                ok = False
+            finally:
+                _C.set_option("lazy", lazy_before)
+                _C.set_option("cap_margin_permille", margin_before)
+                _C.set_option("cap_tile_margin_permille", tile_before)
+            if ok:
+                for _ in range(rows - warm):
+                    self.graph.replay()
+                torch.cuda.current_stream(dev).synchronize()
+                ok = _C.forward_status()[0] == overflow0
+            if ok:
+                self.stats["replays"] += rows - warm
+                self.stats["runs"] += 1
+            else:                               # undo whatever the capture / the replays did, repeat directly
+                with torch.no_grad():
+                    for t, c in snap:
+                        t.detach().copy_(c)
+                self.g.optimizer.zero_grad(set_to_none=True)
+                self.g.deform.optimizer.zero_grad(set_to_none=True)
+                self.graph = None
+                self.stats["redone"] += rows - warm
+                for _ in range(rows - warm):
+                    self.iteration()
+            i += rows
+        pkg, self.graph = self.pkg, None
+        return pkg

@@ -20,8 +20,6 @@ The host draws the random keyframes for the whole run up front -- the same ``tor
 ``iteration()`` is ONE code path: executed directly for the warm-up iterations of a run, captured once, then replayed. Results are
 bit-identical to the eager loop (tests/test_hip_slam.py). A replayed forward pass that outgrows its (generously sized) binning buffer is
 detected after the run through the sticky overflow counters; the run is then undone from a snapshot and repeated eagerly."""
-import ctypes as C
-
 import numpy as np
 import torch
 

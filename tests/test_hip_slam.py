@@ -726,7 +726,10 @@ def test_dynamic_mapping_iterations_as_hip_graphs_are_bit_identical_to_direct_ex
     a = _short_dynamic_run(mapping_graph="strict", tracking_graph=False)
     stats = dict(a[3].backend.dynamic_graph_stats)
     assert stats["runs"] >= 4 and stats["replays"] >= 40 and stats["failed"] == 0 and stats["redone"] == 0, stats
+    ni = dict(a[3].backend.network_init_graph_stats)            # (initialize_network's loop, slam/dynamic_graph.NetworkInit, is part of the same run)
+    assert ni["runs"] >= 1 and ni["replays"] >= 10 and ni["failed"] == 0 and ni["redone"] == 0, ni
     b = _directly_executed_dynamic_run()
+    assert b[3].backend.network_init_graph_stats["replays"] == 0
     assert b[3].backend.dynamic_graph_stats["replays"] == 0 and b[3].backend.dynamic_graph_stats["direct"] > 0
     assert a[0]["gaussians"] == b[0]["gaussians"] and a[0]["keyframes"] == b[0]["keyframes"]
     for name, xs, ys in (("gaussians", a[1], b[1]), ("network", a[2], b[2])):

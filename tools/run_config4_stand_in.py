@@ -32,7 +32,8 @@ res["schedule"] = {k: t[k] for k in ("init_itr_num", "tracking_itr_num", "mappin
 res["schedule"]["dynamic_map_iters"] = slam.backend.dynamic_map_iters
 res["graph_stats"] = slam.frontend.graph_stats
 res["mapping_graph_stats"] = {"static": dict(getattr(slam.backend, "graph_stats", {}) or {}), "dynamic": dict(getattr(slam.backend, "dynamic_graph_stats", {}) or {}),
-                              "initialize_map": dict(getattr(slam.backend, "init_graph_stats", {}) or {})}
+                              "initialize_map": dict(getattr(slam.backend, "init_graph_stats", {}) or {}),
+                              "initialize_network": dict(getattr(slam.backend, "network_init_graph_stats", {}) or {})}
 res["dynamic_gaussians"] = int(slam.gaussians.dygs.sum())
 res["nodes"] = int(slam.gaussians.deform.deform.node_num)
 print(json.dumps(res, indent=1, default=lambda o: o if isinstance(o, (int, float, str)) else str(o)))

@@ -45,7 +45,8 @@ for name, dyn, graph, frames, wh in (("static_640x480_eager", False, False, 40, 
         res = slam.run()
     res["graph_stats"] = slam.frontend.graph_stats
     res["mapping_graph_stats"] = {"static": dict(getattr(slam.backend, "graph_stats", {}) or {}), "dynamic": dict(getattr(slam.backend, "dynamic_graph_stats", {}) or {}),
-                              "initialize_map": dict(getattr(slam.backend, "init_graph_stats", {}) or {})}
+                              "initialize_map": dict(getattr(slam.backend, "init_graph_stats", {}) or {}),
+                              "initialize_network": dict(getattr(slam.backend, "network_init_graph_stats", {}) or {})}
     res["resolution"] = list(wh)
     out[name] = res
 print(json.dumps(out, indent=1))
