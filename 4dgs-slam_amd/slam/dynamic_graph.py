@@ -46,6 +46,7 @@ from .mapping_graph import N_INDEX_WORDS
 # of a call) the moving object's Gaussians can swell and pile up for a few iterations -- measured: instance counts +10 %, the longest tile
 # list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
 CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
+FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (~7 MB each at 640x480); dropped ones are formed again on demand
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
 
@@ -96,7 +97,7 @@ class DynamicMapping:
         self.slot_dst = self._entries([(c, o) for c, o in zip(self.slots, self.slot_ops)])
         self.partner_dst = self._entries([(c, (f[0:3], f[3:4], f[4:5], f[5:6])) for c, f in zip(self.partner_slots, self.partner_flow)])
         self._zero6 = None
-        self._layouts, self._tables = {}, {}
+        self._layouts, self._tables, self._window_ops = {}, {}, {}
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.run, self.graph, self.pkgs = None, None, None
         self.stats = be.__dict__.setdefault("dynamic_graph_stats", {"runs": 0, "replays": 0, "direct": 0, "special": 0, "redone": 0, "failed": 0})
@@ -132,7 +133,7 @@ class DynamicMapping:
         """The constants of a keyframe pair's flow terms as ONE [6, H, W] tensor: planes 0-1 the flow v -> other on v's moving pixels, 2 their
         mask, 3 the mask of `other`, 4-5 the flow other -> v on other's moving pixels (:486-488,:503-505 mask both sides of the difference by
         ~motion_mask; with a 0 / 1 mask: the masked target minus the masked rendering). The plane order is the one gsr_slot_gather moves as
-        (gt_image[3], gt_depth, w_rgb, w_depth). One entry per keyframe (its partner never changes), ~7 MB at 640x480, kept for the run."""
+        (gt_image[3], gt_depth, w_rgb, w_depth). One entry per keyframe (its partner never changes), ~7 MB at 640x480, in a bounded store."""
         cache = self.be.__dict__.setdefault("_flow_targets6", {})
         hit = cache.get((v.uid, other.uid))
         if hit is None:
@@ -141,6 +142,8 @@ class DynamicMapping:
             m2 = (~other.motion_mask).to(torch.float32)[None]
             back = ds.gt_flow(v.uid, other.uid)[0].permute(2, 0, 1) * m1
             fwd = ds.gt_flow(other.uid, v.uid)[0].permute(2, 0, 1) * m2
+            while len(cache) >= FLOW_TARGET_CACHE_MAX:          # oldest first; the tables of a running call hold what they point at
+                cache.pop(next(iter(cache)))
             hit = cache[(v.uid, other.uid)] = torch.cat([back, m1, m2, fwd], 0).to(self.device, torch.float32).contiguous()
         return hit
 
@@ -275,8 +278,10 @@ class DynamicMapping:
         views = self.views + self.slots
         deltas = [deltas_at(i) for i in lay["view_idx"]]
         cfg = be.config
-        ops = [be.keyframe_operands.get(cfg, v, dev, rm_dynamic=False, dynamic=r.dyn) for v in self.views]
-        ops += [o + (ops[0][4],) for o in self.slot_ops]
+        ops = self._window_ops.get(r.dyn)          # (held by the call: a captured iteration points at these buffers)
+        if ops is None:
+            ops = self._window_ops[r.dyn] = [be.keyframe_operands.get(cfg, v, dev, rm_dynamic=False, dynamic=r.dyn) for v in self.views]
+        ops = ops + [o + (ops[0][4],) for o in self.slot_ops]
         rendered = be._render_many(views, deltas)
         loss_mapping = 0
         for v, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):

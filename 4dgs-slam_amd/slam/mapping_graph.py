@@ -38,6 +38,8 @@ class KeyframeOperands:
     """Per keyframe: the constant operands of its mapping loss (ground truth, weights), held so that their device addresses stay valid for
     the graphs that point at them (slam_losses keeps only a bounded cache)."""
 
+    MAX_ENTRIES = 1024          # ~7 MB each at 640x480: what is dropped is formed again on demand
+
     def __init__(self):
         self._held = {}
 
@@ -47,8 +49,11 @@ class KeyframeOperands:
         key = (id(viewpoint), bool(rm_dynamic), bool(dynamic))
         hit = self._held.get(key)
         if hit is not None and hit[0] is viewpoint:
+            self._held[key] = self._held.pop(key)           # (most recently used last)
             return hit[1]
         ops = slam_losses.mapping_loss_operands(config, viewpoint, device, rm_dynamic=rm_dynamic, dynamic=dynamic)
+        while len(self._held) >= self.MAX_ENTRIES:          # oldest first; a graph that still points at an entry's buffers holds them itself
+            self._held.pop(next(iter(self._held)))
         self._held[key] = (viewpoint, ops)
         return ops
 
