@@ -254,3 +254,23 @@ def test_fused_regularisers_equal_the_op_by_op_ones():
     assert bool(keep.any()) and not bool(keep.all())
     for name, a, b in zip(("arap", "elastic", "d arap", "d elastic", "d weights"), results[True], results[False]):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(b.abs().max())), (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_row_groups_and_the_one_layer_heads_on_cpu():
+    """Host logic of the fused node network: the row-group choice of the batched weight-gradient GEMMs (a divisor of the row count with about
+    2 000 rows per group, else one group) and, on CPU tensors, heads_from_embedding = the four head layers applied to the op-by-op trunk."""
+    from slam.deform_model import NodeNetwork, _row_groups
+    for rows, want in ((33280, 16), (69632, 34), (6000, 3), (6007, 1), (512, 1), (71680, 35)):
+        g = _row_groups(rows)
+        assert g == want and rows % g == 0 and (g == 1 or 1024 <= rows // g <= 4096), (rows, g)
+    torch.manual_seed(1)
+    net = NodeNetwork()
+    for _, head in net.heads():
+        torch.nn.init.normal_(head.weight, std=0.05)
+    emb = torch.randn(50, net.input_ch)
+    out = net.heads_from_embedding(emb)
+    h = net.trunk(emb)
+    want = torch.cat([m(h) for _, m in net.heads()], -1)
+    assert out.shape == (50, 14) and torch.allclose(out, want, atol=1e-6)
+    d = net.from_embedding(emb)
+    assert torch.allclose(d["d_xyz"], want[:, :3], atol=1e-6) and torch.allclose(d["local_rotation"], want[:, 10:], atol=1e-6)
