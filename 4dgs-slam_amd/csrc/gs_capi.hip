@@ -123,6 +123,9 @@ constexpr int VIEW_SLOT_GROUPS = 4;                             // gsr_set_optio
 constexpr int SPEC_SLOTS = 1 + 2 * MAX_VIEWS * VIEW_SLOT_GROUPS;
 static thread_local SpecState t_spec[16][SPEC_SLOTS];   // [device][0 = single-view calls | per group: 1..V views of a batch | MAX_VIEWS+1.. views of a flow batch]
 static thread_local int t_view_slot_group = 0;
+// gsr_set_flow_clips: per view of the NEXT flow gsr_forward_views call of this thread, a device pointer to its tile rectangle (or null)
+static thread_local const int* t_view_clips[MAX_VIEWS] = {};
+static thread_local const int* t_clip_single = nullptr;     // the same for a view that goes through the single-view path inside that call
 static thread_local SpecState* t_cur = &t_spec[0][0];
 static int select_device_state(int slot = 0)
 {
@@ -255,6 +258,13 @@ int gsr_set_option(const char* name, int value)
     return old;
 }
 
+int gsr_set_flow_clips(int V, const int* const* clips)
+{
+    if (V < 0 || V > MAX_VIEWS) { g_last_error = "gsr_set_flow_clips: 0 <= V <= GSR_MAX_VIEWS"; return GSR_ERR_INVALID_ARGUMENT; }
+    for (int v = 0; v < MAX_VIEWS; v++) t_view_clips[v] = (clips && v < V) ? clips[v] : nullptr;
+    return 0;
+}
+
 int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered)
 {
     select_device_state();
@@ -328,6 +338,7 @@ static RawInputs to_device_view(const gsr_raw_inputs* in)
         r.logit_opacity = in->logit_opacity; r.f_dc = in->features_dc; r.f_rest = in->features_rest;
         r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr; r.gather = in->gather;
         r.flow_dx2 = in->flow_dx2; r.flow_proj1 = in->flow_proj1; r.flow_proj2 = in->flow_proj2;
+        r.flow_clip = in->flow_proj1 ? t_clip_single : nullptr;
     }
     return r;
 }
@@ -532,7 +543,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     const uint32_t R = hdr[HDR_R], flg = hdr[HDR_FLAGS], R_alloc = hdr[HDR_R_ALLOC], max_tile_list = hdr[HDR_MAX_TILE];
     if (flg & FLAG_PREFILTERED) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return GSR_ERR_PREFILTERED; }
     if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
-    t_last_R_alloc = R_alloc > R ? R_alloc : R;
+    t_last_R_alloc = std::max<size_t>(1, R_alloc > R ? R_alloc : R);     // (never 0: 0 means "no estimate yet"; a frame may legitimately have no instance)
     t_last_max_tile = max_tile_list;
     if (speculate && !(flg & FLAG_OVERFLOW)) return (int)R;
 
@@ -641,6 +652,8 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     // several (view_slot_group): a slot shared by two calls per iteration sees its estimate flip between two cameras -- eager calls then redo
     // the view through the single-view path every time, captured ones overflow at every replay
     const int slot0 = 1 + t_view_slot_group * 2 * MAX_VIEWS + (flow ? MAX_VIEWS : 0);
+    const int* clips[MAX_VIEWS];                             // gsr_set_flow_clips: consumed by this call (flow calls only)
+    for (int v = 0; v < MAX_VIEWS; v++) { clips[v] = flow ? t_view_clips[v] : nullptr; if (flow) t_view_clips[v] = nullptr; }
     const ViewDims d = view_dims(P, width, height);
     read_option_env();
     // the batched path needs a capacity estimate for every slot (the first iteration of a window goes view by view and leaves one)
@@ -649,8 +662,10 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     for (int v = 0; v < V && batched; v++) batched = t_spec[dev][slot0 + v].last_R_alloc != 0;
     if (!batched) {
         for (int v = 0; v < V; v++) {
+            t_clip_single = clips[v];
             const int rc = forward_one_view(views[v], slot0 + v, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier,
                                             tan_fovx, tan_fovy, debug, stream_);
+            t_clip_single = nullptr;
             if (rc) return rc;
         }
         return 0;
@@ -679,7 +694,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
         ViewSlot& s = t.v[v];
         s.viewmatrix = w.viewmatrix; s.projmatrix = w.projmatrix; s.projmatrix_raw = w.projmatrix_raw; s.cam_pos = w.cam_pos;
         s.dx = w.dx; s.ds = w.ds; s.dr = w.dr;
-        s.flow_dx2 = w.flow_dx2; s.flow_proj1 = w.flow_proj1; s.flow_proj2 = w.flow_proj2;
+        s.flow_dx2 = w.flow_dx2; s.flow_proj1 = w.flow_proj1; s.flow_proj2 = w.flow_proj2; s.flow_clip = clips[v];
         s.geom = w.geom_buffer; s.image = w.image_buffer; s.binning = w.binning_buffer;
         s.out_color = w.out_color; s.out_depth = w.out_depth; s.out_opacity = w.out_opacity; s.radii = w.radii; s.n_touched = w.n_touched;
         s.mailbox = t_use_mailbox ? t_mailbox_dev : nullptr; s.cap = (uint32_t)std::min<size_t>(cap, 0x7fffffffu); s.cap_tile = cap_tile; s.seq = t_seq;
@@ -738,12 +753,14 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
         { const int rc = wait_for_header(stream, geom.header, t.v[v].seq, hdr); if (rc) return rc; }
         const uint32_t R = hdr[HDR_R], flg = hdr[HDR_FLAGS], R_alloc = hdr[HDR_R_ALLOC];
         if (R > 0x7fffffffu || R_alloc > 0x7fffffffu) { g_last_error = "gsr_forward_views: more than 2^31 instances"; return GSR_ERR_INVALID_ARGUMENT; }
-        t_last_R_alloc = R_alloc > R ? R_alloc : R;
+        t_last_R_alloc = std::max<size_t>(1, R_alloc > R ? R_alloc : R);
         t_last_max_tile = hdr[HDR_MAX_TILE];
         w.num_rendered = (int)R;
         if (flg & FLAG_OVERFLOW) {
+            t_clip_single = clips[v];
             const int rc = forward_one_view(w, slot0 + v, geometry_alloc, binning_alloc, image_alloc, P, D, M, background, width, height, in, scale_modifier, tan_fovx,
                                             tan_fovy, debug, stream_);
+            t_clip_single = nullptr;
             if (rc) return rc;
         }
     }

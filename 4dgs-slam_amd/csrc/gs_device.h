@@ -283,6 +283,7 @@ struct RawInputs {
     const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;
     const int* gather;   // optional: rasterized Gaussian i reads row gather[i] of the raw tensors (render()'s boolean mask, :179-191)
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2;   // flow mode (render_flow, :229-361): see include/gs_rasterizer.h
+    const int* flow_clip;        // flow mode, optional: tile rectangle [x0, y0, x1, y1) outside of which nothing is needed (gsr_set_flow_clips)
 };
 struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; float* ddx2; };
 

@@ -274,7 +274,15 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
                 const float px = ndc2pix(hx * p_w, a.W), py = ndc2pix(hy * p_w, a.H);
                 int x0, y0, x1, y1;
                 tile_rect(px, py, (int)rad_f, a.gx, a.gy, x0, y0, x1, y1);
-                const int area = (x1 - x0) * (y1 - y0);
+                int area = (x1 - x0) * (y1 - y0);
+                if constexpr (RAW) {
+                    // a flow view whose caller only reads the tiles of a rectangle (the keyframe's moving pixels: the flow loss is masked to
+                    // them): a Gaussian none of whose tiles lies inside contributes to no pixel that is read -- it is culled like one off screen
+                    if (flow && R.flow_clip != nullptr) {
+                        const int* c = R.flow_clip;
+                        if (x1 <= c[0] || x0 >= c[2] || y1 <= c[1] || y0 >= c[3]) area = 0;
+                    }
+                }
                 if (area != 0) {
                     if (!eager) load_look();
                     f3 col;

@@ -29,6 +29,7 @@ struct ViewSlot {
     uint32_t* mailbox; uint32_t cap; uint32_t cap_tile; uint32_t seq;
     // flow mode (render_flow, gs_rasterizer.h gsr_raw_inputs.flow_*): this view's second displacement and the two projections; ddx2 its gradient
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2; float* ddx2;
+    const int* flow_clip;                                                   // optional tile rectangle of a flow view (gsr_set_flow_clips)
 };
 struct ViewTable { ViewSlot v[MAX_VIEWS]; };
 static_assert(sizeof(ViewTable) + sizeof(PreprocessArgs) + 64 <= 4096 && sizeof(ViewTable) + sizeof(GeomBwdArgs) + 64 <= 4096,
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(GB) preprocess_views_kernel(PreprocessArgs a, 
     const ImageState img = view_image(s, d);
     a.viewmatrix = s.viewmatrix; a.projmatrix = s.projmatrix; a.cam_pos = s.cam_pos;
     a.raw.dx = s.dx; a.raw.ds = s.ds; a.raw.dr = s.dr;
-    a.raw.flow_dx2 = s.flow_dx2; a.raw.flow_proj1 = s.flow_proj1; a.raw.flow_proj2 = s.flow_proj2;
+    a.raw.flow_dx2 = s.flow_dx2; a.raw.flow_proj1 = s.flow_proj1; a.raw.flow_proj2 = s.flow_proj2; a.raw.flow_clip = s.flow_clip;
     a.radii = s.radii; a.n_touched = s.n_touched;
     a.rec = geom.rec; a.cov3D = geom.cov3D; a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums;
     a.tile_count = img.tile_count; a.flags = img.tile_count + (size_t)d.T * CTR_STRIDE; a.block_tile_base = img.block_tile_base;

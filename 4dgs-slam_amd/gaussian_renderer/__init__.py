@@ -293,12 +293,14 @@ def _dyn_slot(pc):
     return s
 
 
-def render_flow_views(pc, requests, scaling_modifier=1.0):
+def render_flow_views(pc, requests, scaling_modifier=1.0, clips=None):
     """render_flow for several (camera 1, camera 2) pairs of one mapping iteration: requests[i] = (viewpoint_camera1, viewpoint_camera2,
     d_xyz1, d_xyz2, d_rotation1, d_scaling1), the arguments of render_flow in its order; returns render_flow's dict per request. The
     dynamic mapping loop renders two flow images per window keyframe before each optimizer step (utils/slam_backend.py:486,496); with
     the fused route available they go through the multi-view entry point in groups of up to views.MAX_VIEWS (one launch per pipeline
-    stage per group), otherwise one render_flow call each."""
+    stage per group), otherwise one render_flow call each. ``clips``: per request None or an int32 [4] device tensor, the tile rectangle
+    [x0, y0, x1, y1) the caller will read of that image (its loss mask's bounding box): Gaussians outside it are culled on the batched route
+    (gsr_set_flow_clips; pixels inside the rectangle and the gradients of a loss confined to them are unchanged)."""
     requests = list(requests)
     single = lambda: [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in requests]
     if (len(requests) < 2 or _views is None or os.environ.get("GSR_MULTI_VIEW", "1") == "0" or not _flow_fused_ok(pc) or pc.get_xyz.shape[0] == 0
@@ -313,6 +315,8 @@ def render_flow_views(pc, requests, scaling_modifier=1.0):
         # (the chunks of one iteration keep separate capacity estimates per view: include/gs_rasterizer.h "view_slot_group")
         group_before = _views._C.set_option("view_slot_group", lo // _views.MAX_VIEWS)
         try:
+            if clips is not None and len(part) > 1 and _views.views_supported(rs):
+                _views._C.set_flow_clips(list(clips[lo:lo + _views.MAX_VIEWS]))
             out += _render_flow_chunk(pc, part, rs, slot, scaling_modifier)
         finally:
             _views._C.set_option("view_slot_group", group_before)

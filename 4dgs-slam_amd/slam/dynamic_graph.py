@@ -46,6 +46,7 @@ from .mapping_graph import N_INDEX_WORDS
 # of a call) the moving object's Gaussians can swell and pile up for a few iterations -- measured: instance counts +10 %, the longest tile
 # list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
 CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
+FLOW_CLIPS = os.environ.get("GSR_FLOW_CLIPS", "1") != "0"      # render the flow images only where the flow loss reads them (gsr_set_flow_clips)
 FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (~7 MB each at 640x480); dropped ones are formed again on demand
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
@@ -97,6 +98,7 @@ class DynamicMapping:
         self.slot_dst = self._entries([(c, o) for c, o in zip(self.slots, self.slot_ops)])
         self.partner_dst = self._entries([(c, (f[0:3], f[3:4], f[4:5], f[5:6])) for c, f in zip(self.partner_slots, self.partner_flow)])
         self._zero6 = None
+        self.slot_clips = torch.zeros((max(1, self.n_slots), 8), dtype=torch.int32, device=dev)       # per slot: its rectangle, its partner's
         self._layouts, self._tables, self._window_ops = {}, {}, {}
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.run, self.graph, self.pkgs = None, None, None
@@ -147,6 +149,20 @@ class DynamicMapping:
             hit = cache[(v.uid, other.uid)] = torch.cat([back, m1, m2, fwd], 0).to(self.device, torch.float32).contiguous()
         return hit
 
+    def flow_clip(self, v):
+        """The tile rectangle [x0, y0, x1, y1) (16-pixel tiles) around keyframe v's MOVING pixels -- all its flow loss reads of the flow image
+        rendered from v -- as an int32 [4] device tensor (gsr_set_flow_clips); one host read per keyframe, kept."""
+        cache = self.be.__dict__.setdefault("_flow_clips", {})
+        hit = cache.get(v.uid)
+        if hit is None:
+            moving = ~v.motion_mask
+            ys, xs = moving.any(dim=1).nonzero().flatten(), moving.any(dim=0).nonzero().flatten()
+            rect = [0, 0, 0, 0] if ys.numel() == 0 else [int(xs[0]) // 16, int(ys[0]) // 16, int(xs[-1]) // 16 + 1, int(ys[-1]) // 16 + 1]
+            while len(cache) >= 4 * FLOW_TARGET_CACHE_MAX:
+                cache.pop(next(iter(cache)))
+            hit = cache[v.uid] = torch.tensor(rect, dtype=torch.int32).to(self.device)
+        return hit
+
     def layout(self, with_flow):
         hit = self._layouts.get(with_flow)
         if hit is None:
@@ -160,6 +176,7 @@ class DynamicMapping:
                 "view_idx": [index[time_key(v.time)] for v in self.views] + [n_w + e * epf for e in range(self.n_slots)],
                 "partner_idx": [None if p is None else index[time_key(p.time)] for p in partners],
                 "flow6": [None if p is None else self.flow6(v, p) for v, p in zip(self.views, partners)],
+                "clips": [None if p is None else (self.flow_clip(v), self.flow_clip(p)) for v, p in zip(self.views, partners)],
                 "wtimes": torch.tensor(keys, dtype=torch.float32).to(self.device)}
         return hit
 
@@ -170,7 +187,7 @@ class DynamicMapping:
         if hit is None:
             be, dev = self.be, self.device
             store, cfg = be.keyframe_operands, be.config
-            rows, prow, times, keep = [], [], [], []
+            rows, prow, times, keep, clip_rows = [], [], [], [], []
             for c in self.candidates:
                 ops = store.get(cfg, c, dev, rm_dynamic=False, dynamic=dyn)
                 for tns in ops[:4]:
@@ -193,12 +210,14 @@ class DynamicMapping:
                     prow.append([p.world_view_transform.data_ptr(), p.full_proj_transform.data_ptr(), p.camera_center.data_ptr(), p.exposure_a.data_ptr(),
                                  p.exposure_b.data_ptr(), f6.data_ptr(), f6.data_ptr() + 3 * step, f6.data_ptr() + 4 * step, f6.data_ptr() + 5 * step])
                     times.append([time_key(c.time), time_key(p.time)])
+                    # (rows 2 c and 2 c + 1: the rectangles the two flow images of the pair are read in; the stand-in pair reads nothing)
+                    clip_rows += [self.flow_clip(c), self.flow_clip(p)] if p is not c else [torch.zeros(4, dtype=torch.int32, device=dev)] * 2
                 else:
                     times.append([time_key(c.time)])
             up = lambda a, dt: torch.tensor(a, dtype=dt).pin_memory().to(dev, non_blocking=True)
             hit = self._tables[(dyn, with_flow)] = {
                 "keep": keep, "kf": up(rows, torch.int64) if rows else None, "partner": up(prow, torch.int64) if prow else None,
-                "times": up(times, torch.float32) if times else None}
+                "times": up(times, torch.float32) if times else None, "clips": torch.stack(clip_rows).reshape(len(self.candidates), 8) if clip_rows else None}
         return hit
 
     # ---- a run's schedule -------------------------------------------------------------------------------------------------------------------
@@ -289,21 +308,25 @@ class DynamicMapping:
                                                                        v.exposure_b, alpha, compute_value=False)
         if r.with_flow:
             from gaussian_renderer import render_flow_views
-            requests, pairs = [], []
+            requests, pairs, clips = [], [], []
+            if self.n_slots and tab["clips"] is not None:
+                torch.index_select(tab["clips"], 0, r.current[:self.n_slots].long(), out=self.slot_clips[:self.n_slots])
             for k, v in enumerate(views):
                 if k < nv:
                     other, f6 = lay["partners"][k], lay["flow6"][k]
                     if other is None:
                         continue
                     d2 = deltas_at(lay["partner_idx"][k])
+                    clips += list(lay["clips"][k])
                 else:
                     other, f6 = self.partner_slots[k - nv], self.partner_flow[k - nv]
                     d2 = deltas_at(lay["view_idx"][k] + 1)
+                    clips += [self.slot_clips[k - nv, 0:4], self.slot_clips[k - nv, 4:8]]
                 (dx1, ds1, dr1), (dx2, ds2, dr2) = deltas[k], d2
                 requests += [(v, other, dx1, dx2, dr1, ds1), (other, v, dx2, dx1, dr2, ds2)]      # this keyframe -> the earlier one, and back
                 pairs.append((f6[0:2], f6[2:3], f6[4:6], f6[3:4]))
             if requests:
-                flows = render_flow_views(g, requests)
+                flows = render_flow_views(g, requests, clips=clips if FLOW_CLIPS else None)
                 loss = 0.0
                 for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
                     loss = loss + slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],

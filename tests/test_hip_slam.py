@@ -702,6 +702,21 @@ def _directly_executed_dynamic_run():
     return _DIRECT_DYNAMIC_RUN[0]
 
 
+def test_flow_images_rendered_only_where_the_loss_reads_them_leave_the_run_unchanged(monkeypatch):
+    """gsr_set_flow_clips: the dynamic mapping call renders every flow image with the Gaussians outside the tile rectangle of its loss mask
+    (the keyframe's moving pixels) culled. The flow loss reads nothing else of the image, so a whole dynamic SLAM run must end bit-identical
+    with and without the clips."""
+    from slam import dynamic_graph
+    b = _directly_executed_dynamic_run()                       # (clips on: the default)
+    monkeypatch.setattr(dynamic_graph, "FLOW_CLIPS", False)
+    a = _short_dynamic_run(mapping_graph=False, tracking_graph=False)
+    assert a[0]["gaussians"] == b[0]["gaussians"] and a[0]["keyframes"] == b[0]["keyframes"]
+    for name, xs, ys in (("gaussians", a[1], b[1]), ("network", a[2], b[2])):
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            assert x.shape == y.shape and torch.equal(x, y), (name, i, float((x - y).abs().max()))
+    assert a[0]["ate_rmse"] == b[0]["ate_rmse"] and a[0]["before_opt"]["mean_psnr"] == b[0]["before_opt"]["mean_psnr"]
+
+
 def test_dynamic_graph_run_that_outgrows_its_buffers_is_redone_directly():
     """The dynamic graphs' recovery path: with the captured binning buffers laid out for half of the last frame's instances
     (Training.graph_test_shrink_permille -> cap_test_shrink_permille during the capture) every replayed view overflows; each run must be
