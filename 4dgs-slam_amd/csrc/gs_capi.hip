@@ -483,7 +483,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
-                               (uint32_t)carve_R, (uint32_t)cap_sorted, eager);
+                               (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr);
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here

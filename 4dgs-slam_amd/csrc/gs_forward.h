@@ -277,10 +277,12 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
                 int area = (x1 - x0) * (y1 - y0);
                 if constexpr (RAW) {
                     // a flow view whose caller only reads the tiles of a rectangle (the keyframe's moving pixels: the flow loss is masked to
-                    // them): a Gaussian none of whose tiles lies inside contributes to no pixel that is read -- it is culled like one off screen
+                    // them): the Gaussian's tile rectangle is clipped to it -- no instance in a tile that is not read, none at all (culled like
+                    // a Gaussian off screen) when nothing is left; scatter_instances_body clips the same way
                     if (flow && R.flow_clip != nullptr) {
                         const int* c = R.flow_clip;
-                        if (x1 <= c[0] || x0 >= c[2] || y1 <= c[1] || y0 >= c[3]) area = 0;
+                        x0 = max(x0, c[0]); y0 = max(y0, c[1]); x1 = min(x1, c[2]); y1 = min(y1, c[3]);
+                        area = (x1 > x0 && y1 > y0) ? (x1 - x0) * (y1 - y0) : 0;
                     }
                 }
                 if (area != 0) {
@@ -542,7 +544,7 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip = nullptr)
 {
     if (speculative) {
         if (header[HDR_FLAGS] & FLAG_OVERFLOW) return;          // uniform: the buffer behind keys/inst_gauss is too small for this frame
@@ -583,6 +585,7 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
         if (!eager) { q0 = rec[idx].q0; my_radius = radii[idx]; }
         int x1, y1;
         tile_rect(q0.x, q0.y, my_radius, gx, gy, rx0, ry0, x1, y1);
+        if (clip) { rx0 = max(rx0, clip[0]); ry0 = max(ry0, clip[1]); x1 = min(x1, clip[2]); }      // (a flow view's rectangle: as in preprocess_fwd_body)
         rw = x1 - rx0;
         dbits = __float_as_uint(q0.z);
     }
@@ -1120,9 +1123,9 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip)
 {
-    scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager);
+    scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager, clip);
 }
 
 template <int CAP, int LOWER>

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(GB) scatter_views_kernel(ViewTable t, ViewDims
     const ImageState img = view_image(s, d);
     const BinningPtrs bin = view_binning(s, d);
     scatter_instances_body(d.P, d.gx, d.gy, s.radii, geom.rec, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
-                           img.block_tile_base, bin.keys, bin.inst_gauss, geom.header, 1, s.cap, s.cap, eager);
+                           img.block_tile_base, bin.keys, bin.inst_gauss, geom.header, 1, s.cap, s.cap, eager, s.flow_clip);
 }
 
 template <int CAP, int LOWER>

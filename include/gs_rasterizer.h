@@ -206,8 +206,8 @@ int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_a
                       float tan_fovx, float tan_fovy, int debug, void* stream);
 /* Flow views whose caller only reads part of the image (the flow loss of utils/slam_backend.py:479-509 is masked to the keyframe's moving
  * pixels): clips[v] = DEVICE pointer to four ints, the tile rectangle [x0, y0, x1, y1) (16-pixel tiles, half open) that view v is read in, or
- * NULL. Applies to the NEXT flow call of gsr_forward_views on this thread and is consumed by it. A Gaussian none of whose tiles lies inside
- * the rectangle is culled like one off screen (radius 0, no instances, no gradient): every pixel inside the rectangle -- and every gradient
+ * NULL. Applies to the NEXT flow call of gsr_forward_views on this thread and is consumed by it. A Gaussian's tile rectangle is clipped to
+ * it (no instance in a tile outside; none at all -- radius 0, no gradient -- when nothing is left): every pixel inside the rectangle -- and every gradient
  * of a loss that only reads such pixels -- is unchanged, bit for bit; pixels outside are undefined (whatever the remaining Gaussians leave).
  * The pointers are read by the kernels: a captured call keeps reading the same addresses on replay. */
 int gsr_set_flow_clips(int V, const int* const* clips);
