@@ -327,6 +327,8 @@ class DynamicMapping:
                 pairs.append((f6[0:2], f6[2:3], f6[4:6], f6[3:4]))
             if requests:
                 flows = render_flow_views(g, requests, clips=clips if FLOW_CLIPS else None)
+                if FLOW_CLIPS and be.config["Training"].get("flow_clip_check") and not torch.cuda.is_current_stream_capturing():
+                    self._check_flow_clips(requests, pairs, clips, flows)          # TEST facility: the same terms without the clips
                 loss = 0.0
                 for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
                     loss = loss + slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
@@ -363,6 +365,36 @@ class DynamicMapping:
             g.optimizer.zero_grad(set_to_none=True)
         self.pkgs = rendered
         return split
+
+    def _check_flow_clips(self, requests, pairs, clips, flows):
+        """TEST facility (Training.flow_clip_check): render the iteration's flow images again WITHOUT the clips and record, in
+        backend.flow_clip_checks, whether the masked images are equal, how far the gradients of the flow loss are apart (relative to their
+        largest entry) and how many Gaussians each variant rasterized."""
+        from gaussian_renderer import render_flow_views
+        be, g, r = self.be, self.g, self.run
+
+        def grads_of(cl):
+            fl = render_flow_views(g, requests, clips=cl)
+            loss = 0.0
+            for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
+                loss = loss + slam_losses.masked_l1(r.flow_weight, [(fl[2 * k]["render"], t_back, m1), (fl[2 * k + 1]["render"], t_fwd, m2)], channels=2)
+            leaves = [g._xyz] + [t for rq in requests for t in rq[2:]]
+            out = torch.autograd.grad(loss, leaves, allow_unused=True)
+            g.optimizer.zero_grad(set_to_none=True)
+            return fl, out
+        _, ga = grads_of(clips)
+        ref, gb = grads_of(None)
+        rel = 0.0
+        for x, y in zip(ga, gb):
+            if x is not None and y is not None and float(y.abs().max()) > 0:
+                rel = max(rel, float((x - y).abs().max() / y.abs().max()))
+        same = True
+        with torch.no_grad():
+            for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
+                for j, m in ((2 * k, m1), (2 * k + 1, m2)):
+                    same = same and torch.equal(flows[j]["render"][:2] * m, ref[j]["render"][:2] * m)
+            drawn = (sum(int((f["radii"] > 0).sum()) for f in flows), sum(int((f["radii"] > 0).sum()) for f in ref))
+        be.__dict__.setdefault("flow_clip_checks", []).append({"masked_images_equal": same, "gradient_rel_diff": rel, "gaussians_drawn": drawn})
 
     # ---- executing a run ---------------------------------------------------------------------------------------------------------------
     def finish(self, n):

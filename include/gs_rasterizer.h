@@ -207,8 +207,9 @@ int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_a
 /* Flow views whose caller only reads part of the image (the flow loss of utils/slam_backend.py:479-509 is masked to the keyframe's moving
  * pixels): clips[v] = DEVICE pointer to four ints, the tile rectangle [x0, y0, x1, y1) (16-pixel tiles, half open) that view v is read in, or
  * NULL. Applies to the NEXT flow call of gsr_forward_views on this thread and is consumed by it. A Gaussian's tile rectangle is clipped to
- * it (no instance in a tile outside; none at all -- radius 0, no gradient -- when nothing is left): every pixel inside the rectangle -- and every gradient
- * of a loss that only reads such pixels -- is unchanged, bit for bit; pixels outside are undefined (whatever the remaining Gaussians leave).
+ * it (no instance in a tile outside; none at all -- radius 0, no gradient -- when nothing is left): every pixel inside the rectangle is
+ * unchanged, bit for bit, and every gradient of a loss that only reads such pixels up to the order in which a Gaussian's (now fewer)
+ * instance slots are added (~1e-9 relative); pixels outside are undefined (whatever the remaining Gaussians leave).
  * The pointers are read by the kernels: a captured call keeps reading the same addresses on replay. */
 int gsr_set_flow_clips(int V, const int* const* clips);
 /* scratch: device memory of gsr_views_scratch_size() bytes (one row of parameter gradients per view); not needed with GSR_BACKWARD_POSE_ONLY */

@@ -702,19 +702,24 @@ def _directly_executed_dynamic_run():
     return _DIRECT_DYNAMIC_RUN[0]
 
 
-def test_flow_images_rendered_only_where_the_loss_reads_them_leave_the_run_unchanged(monkeypatch):
-    """gsr_set_flow_clips: the dynamic mapping call renders every flow image with the Gaussians outside the tile rectangle of its loss mask
-    (the keyframe's moving pixels) culled. The flow loss reads nothing else of the image, so a whole dynamic SLAM run must end bit-identical
-    with and without the clips."""
-    from slam import dynamic_graph
-    b = _directly_executed_dynamic_run()                       # (clips on: the default)
-    monkeypatch.setattr(dynamic_graph, "FLOW_CLIPS", False)
-    a = _short_dynamic_run(mapping_graph=False, tracking_graph=False)
-    assert a[0]["gaussians"] == b[0]["gaussians"] and a[0]["keyframes"] == b[0]["keyframes"]
-    for name, xs, ys in (("gaussians", a[1], b[1]), ("network", a[2], b[2])):
-        for i, (x, y) in enumerate(zip(xs, ys)):
-            assert x.shape == y.shape and torch.equal(x, y), (name, i, float((x - y).abs().max()))
-    assert a[0]["ate_rmse"] == b[0]["ate_rmse"] and a[0]["before_opt"]["mean_psnr"] == b[0]["before_opt"]["mean_psnr"]
+def test_flow_images_are_rendered_only_where_the_loss_reads_them():
+    """gsr_set_flow_clips: the dynamic mapping call renders every flow image with the Gaussians' tile rectangles clipped to the rectangle of
+    its loss mask (the keyframe's moving pixels). Checked inside a real run (Training.flow_clip_check renders every direct iteration's flow
+    images again without the clips): the masked images are EQUAL, the gradients of the flow loss agree to rounding (the per-Gaussian sums
+    of instance slots lose exact zeros, which regroups a tree sum), and the clips really remove work."""
+    from slam.dataset import SyntheticRGBDDataset
+    from slam.system import SLAM
+    torch.manual_seed(0)
+    ds = SyntheticRGBDDataset(num_frames=13, width=320, height=240, seed=1, dynamic=True, dystart=6)
+    slam = SLAM(_quick_config(dynamic=True, dynamic_map_iters=6, network_init_iters=10, init_itr_num=120, mapping_graph=False, tracking_graph=False,
+                              flow_clip_check=True), ds)
+    slam.run()
+    checks = slam.backend.flow_clip_checks
+    assert len(checks) >= 6
+    assert all(c["masked_images_equal"] for c in checks)
+    assert max(c["gradient_rel_diff"] for c in checks) < 1e-6, max(c["gradient_rel_diff"] for c in checks)
+    clipped, full = sum(c["gaussians_drawn"][0] for c in checks), sum(c["gaussians_drawn"][1] for c in checks)
+    assert clipped < 0.9 * full, (clipped, full)
 
 
 def test_dynamic_graph_run_that_outgrows_its_buffers_is_redone_directly():

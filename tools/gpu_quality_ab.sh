@@ -1,11 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-run() { timeout 300 python tools/dev_quality_ab.py 36 320 240 2>/dev/null | grep QUALITY; }
-TAG=default run
-TAG=no_fused_reg GSR_FUSED_REGULARISERS=0 run
-TAG=no_fused_trunk GSR_FUSED_TRUNK=0 run
-TAG=neither GSR_FUSED_REGULARISERS=0 GSR_FUSED_TRUNK=0 run
-TAG=old_layout TRAINING='{"dynamic_fixed_layout": false}' run
-TAG=no_graphs TRAINING='{"mapping_graph": false}' run
-TAG=dyn60 DYN_ITERS=60 run
-TAG=dyn60_old_layout DYN_ITERS=60 TRAINING='{"dynamic_fixed_layout": false}' run
+for c in 1 0; do GSR_FLOW_CLIPS=$c timeout 600 python tools/run_slam_demo.py --only dynamic_320x240_graph 2>/dev/null | python -c "
+import json,sys
+d=json.load(sys.stdin)
+for k,v in d.items(): print('clips=$c', k, round(v['seconds'],3), v['before_opt']['mean_psnr'], v['ate_rmse'], v['gaussians'], v['mapping_graph_stats']['dynamic'])
+"; done
