@@ -54,6 +54,10 @@ def _lib():
         lib.gsr_index_csr.argtypes = [i, i, i, vp, vp, vp]
         lib.gsr_segment_sum.restype = i
         lib.gsr_segment_sum.argtypes = [i, i, i, i, i, vp, vp, vp, vp, vp]
+        lib.gsr_node_embedding.restype = i
+        lib.gsr_node_embedding.argtypes = [i, i, i, i, vp, i, vp, vp, vp, vp]
+        lib.gsr_node_embedding_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_node_embedding_workspace_size.argtypes = [i, i, i, i]
         lib.gsr_relu_backward_bias_workspace_size.restype = ctypes.c_size_t
         lib.gsr_relu_backward_bias_workspace_size.argtypes = [i, i]
         lib.gsr_relu_backward_bias.restype = i
@@ -147,6 +151,25 @@ def gather_rows(table, sets: IndexSets, set_of_b=None):
     if set_of_b is None and sets.S == table.shape[0] and sets.S > 1:
         set_of_b = torch.arange(sets.S, device=table.device, dtype=torch.int32)
     return _GatherRows.apply(table, sets, set_of_b)
+
+
+def node_embedding(nodes, times, n_freq_x, n_freq_t):
+    """[n * M, 3 (1 + 2 Fx) + 1 + 2 Ft]: the node network's input for every (time sample, node) pair in one launch (gsr_node_embedding,
+    include/control_nodes.h). nodes [M, 3] and times [n] fp32 on the device; no gradient (node positions are detached, times are data)."""
+    _C._require_device(nodes, "nodes")
+    nodes, times = _f32(nodes, "nodes"), _f32(times.reshape(-1), "times")
+    if nodes.dim() != 2 or nodes.shape[1] < 3:
+        raise ValueError(f"node_embedding expects nodes [M, >=3], got {tuple(nodes.shape)}")
+    n, M = int(times.shape[0]), int(nodes.shape[0])
+    out = torch.empty((n * M, 3 * (1 + 2 * n_freq_x) + 1 + 2 * n_freq_t), dtype=torch.float32, device=nodes.device)
+    lib = _lib()
+    ws = torch.empty((int(lib.gsr_node_embedding_workspace_size(n, M, int(n_freq_x), int(n_freq_t))),), dtype=torch.uint8, device=nodes.device)
+    with torch.cuda.device(nodes.device):
+        rc = lib.gsr_node_embedding(n, M, int(n_freq_x), int(n_freq_t), nodes.data_ptr(), int(nodes.shape[1]), times.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                    _C._stream(nodes.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_node_embedding")
+    return out
 
 
 RELU_BIAS_COLS = (64, 128, 256, 512, 1024)

@@ -1711,6 +1711,27 @@ int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, voi
     return 0;
 }
 
+size_t gsr_node_embedding_workspace_size(int n, int M, int Fx, int Ft)
+{
+    return n >= 0 && M >= 0 && Fx >= 0 && Ft >= 0 ? ((size_t)M * 3 * (1 + 2 * Fx) + (size_t)n * (1 + 2 * Ft)) * sizeof(float) + 16 : 0;
+}
+
+int gsr_node_embedding(int n, int M, int Fx, int Ft, const float* nodes, int node_stride, const float* times, float* out, char* workspace, void* stream_)
+{
+    if (n < 0 || M < 0 || Fx < 0 || Fx > 24 || Ft < 0 || Ft > 24 || node_stride < 3 || ((size_t)n * M > 0 && (!nodes || !times || !out || !workspace))) {
+        g_last_error = "gsr_node_embedding: invalid argument (0 <= frequencies <= 24, node_stride >= 3, no null buffers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const int Wx = 3 * (1 + 2 * Fx), Wt = 1 + 2 * Ft;
+    const size_t total = (size_t)n * M * (Wx + Wt), small = (size_t)M * Wx + (size_t)n * Wt;
+    if (total) {
+        float* tables = reinterpret_cast<float*>(workspace);
+        hipLaunchKernelGGL(node_embedding_tables_kernel, dim3((unsigned)((small + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, n, M, Fx, Ft, nodes, node_stride, times, tables);
+        hipLaunchKernelGGL(node_embedding_expand_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, n, M, Wx, Wt, (const float*)tables, out);
+    }
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 size_t gsr_relu_backward_bias_workspace_size(int rows, int cols)
 {
     return rows > 0 && cols > 0 ? (size_t)((rows + RELU_BAND - 1) / RELU_BAND) * (size_t)cols * sizeof(float) : 0;

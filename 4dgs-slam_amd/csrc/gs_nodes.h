@@ -454,6 +454,42 @@ segment_sum_kernel(const int B, const int E, const int C, const int Nv, const fl
     out[(size_t)b * out_batch_stride + (size_t)v * C + c] = acc;
 }
 
+// ---- the node network's input (DeformNetwork's embedders, utils/time_utils.py:208-273: include_input, log-spaced sin / cos) for n time
+// samples x M nodes in one launch: row (i, m) = [x_m, sin(2^0 x_m), cos(2^0 x_m), ..., | t_i, sin(2^0 t_i), cos(2^0 t_i), ...]. As tensor
+// ops that is two embeddings of four launches each, two expands and a concatenation on the way to the same [n M, 3 (1 + 2 Fx) + 1 + 2 Ft]
+// matrix. sinf / cosf (not the fast intrinsics: the values feed a network whose state_dict is the reference's).
+// two launches: the embeddings of the M nodes and of the n times once each ([M][Wx] and [n][Wt] in `tables`), then their broadcast
+__global__ void __launch_bounds__(256)
+node_embedding_tables_kernel(const int n, const int M, const int Fx, const int Ft, const float* __restrict__ nodes, const int node_stride,
+                             const float* __restrict__ tt, float* __restrict__ tables)
+{
+    const int Wx = 3 * (1 + 2 * Fx), Wt = 1 + 2 * Ft;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * Wx + n * Wt) return;
+    int k, C;
+    float x;
+    if (e < M * Wx) { k = e % Wx; C = 3; x = nodes[(size_t)(e / Wx) * node_stride + k % 3]; }
+    else { const int r = e - M * Wx; k = r % Wt; C = 1; x = tt[r / Wt]; }
+    const int blk = k / C;                                 // blk 0: the input itself; 1 + 2 f: sin of frequency f; 2 + 2 f: cos
+    float v = x;
+    if (blk) {
+        const float a = x * (float)(1u << ((blk - 1) >> 1));
+        v = ((blk - 1) & 1) ? cosf(a) : sinf(a);
+    }
+    tables[e] = v;
+}
+__global__ void __launch_bounds__(256)
+node_embedding_expand_kernel(const int n, const int M, const int Wx, const int Wt, const float* __restrict__ tables, float* __restrict__ out)
+{
+    const int Wd = Wx + Wt;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * M * Wd) return;
+    const int col = (int)(e % Wd);
+    const size_t row = e / Wd;
+    const int m = (int)(row % M), i = (int)(row / M);
+    out[e] = col < Wx ? tables[(size_t)m * Wx + col] : tables[(size_t)M * Wx + (size_t)i * Wt + (col - Wx)];
+}
+
 // ---- the node network's trunk layer, backward half that is not a GEMM (slam/deform_model.py NodeNetwork.trunk) -------------------------------
 // A layer is y = relu(x W^T + b) on ~50 000 rows x 256 columns. Its backward pass needs G = dY . [y > 0] (then dW = G^T x and dx = G W are
 // GEMMs) and db = column sums of G. As torch ops that is threshold_backward (read dY, y; write G) plus a column reduction that reads G again

@@ -490,9 +490,12 @@ class ControlNodes(nn.Module):
         d_scaling per full sample) or None}."""
         M, net = self.node_num, self.network
         n = int(tt.shape[0])
-        xe = _embed(self.nodes.detach(), net.multires)
-        te = _embed(tt.reshape(n, 1), net.t_multires)
-        emb = torch.cat([xe[None].expand(n, M, -1), te[:, None].expand(n, M, -1)], -1)
+        if self.nodes.is_cuda and self.nodes.dtype == torch.float32 and os.environ.get("GSR_FUSED_EMBEDDING", "1") != "0":
+            emb = control_nodes.node_embedding(self.nodes.detach(), tt, net.multires, net.t_multires)      # one launch instead of ~13
+        else:
+            xe = _embed(self.nodes.detach(), net.multires)
+            te = _embed(tt.reshape(n, 1), net.t_multires)
+            emb = torch.cat([xe[None].expand(n, M, -1), te[:, None].expand(n, M, -1)], -1)
         # (the heads as ONE linear layer on all rows: the rotation / scaling / local-frame columns of the position-only rows are computed and
         # never read -- 11 of 14 columns of a [rows, 256] x [256, 14] product)
         heads = net.heads()

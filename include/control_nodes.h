@@ -97,6 +97,13 @@ int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* n
  *                     int32 names the index set of batch element b, NULL = set 0 for all).
  * Used by the node blend's backward (a Gaussian's gradient goes to its K nearest nodes; gsr_node_blend_backward* takes this route for K <= 4
  * by itself) and by the gathers of the ARAP / elastic node regularisers (utils/deform_utils.py:35-42, utils/time_utils.py:1160-1165). */
+/* The node network's input for n time samples x M nodes (DeformNetwork's two embedders, utils/time_utils.py:208-273,428-436: include_input,
+ * frequencies 2^0 .. 2^(F-1), order x, sin f0, cos f0, sin f1, ...): out [n * M, 3 (1 + 2 Fx) + (1 + 2 Ft)] row-major, row i * M + m =
+ * [embed(nodes[m]) | embed(times[i])]. nodes [M, node_stride >= 3], times [n]; all on the device; workspace (device):
+ * gsr_node_embedding_workspace_size bytes. Two launches: every sin / cos once, then the broadcast. */
+size_t gsr_node_embedding_workspace_size(int n, int M, int Fx, int Ft);
+int gsr_node_embedding(int n, int M, int Fx, int Ft, const float* nodes, int node_stride, const float* times, float* out, char* workspace, void* stream);
+
 /* The non-GEMM half of a trunk layer's backward pass, y = relu(x W^T + b) on `rows` x `cols` row-major fp32 matrices (the node network,
  * utils/time_utils.py:327-470: eight such layers on ~50 000 rows per mapping iteration): G = dY . [Y > 0] and dbias[c] = sum over rows of
  * G[r][c], in ONE pass over dY and Y plus a few-microsecond finalisation; the sums are formed in a fixed order (bit-reproducible).

@@ -258,3 +258,20 @@ def test_fused_network_equals_the_op_by_op_network():
         for a, p in zip(got, params):
             b = p.grad
             assert a.shape == b.shape and float((a - b).norm()) <= 1e-3 * float(b.norm()), (rows, tuple(a.shape), float((a - b).norm() / b.norm()))
+
+
+def test_node_embedding_equals_the_tensor_program():
+    """gsr_node_embedding: the node network's [n * M, 84] input in one launch against the reference's embedders as tensor ops
+    (slam.deform_model._embed, which the CPU tests compare with the reference's DeformNetwork): equal to 1 ulp of sin / cos."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "4dgs-slam_amd"))
+    from slam.deform_model import _embed
+    g = torch.Generator().manual_seed(2)
+    nodes, tt = (torch.randn(137, 3, generator=g) * 0.7).to(DEV), torch.rand(9, generator=g).to(DEV)
+    got = cn.node_embedding(nodes, tt, 10, 10)
+    xe, te = _embed(nodes, 10), _embed(tt.reshape(9, 1), 10)
+    want = torch.cat([xe[None].expand(9, 137, -1), te[:, None].expand(9, 137, -1)], -1).reshape(9 * 137, -1)
+    assert got.shape == want.shape == (9 * 137, 84)
+    assert torch.equal(got[:, :3], want[:, :3]) and torch.equal(got[:, 63], want[:, 63])
+    assert float((got - want).abs().max()) <= 2e-6          # |sin|, |cos| <= 1: an ulp or two of the library functions at arguments up to 512 x
+    assert cn.node_embedding(nodes, tt[:0], 10, 10).shape == (0, 84)
