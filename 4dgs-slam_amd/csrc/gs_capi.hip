@@ -1992,6 +1992,27 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
     return 0;
 }
 
+size_t gsr_isotropic_loss_workspace_size(int P) { return P > 0 ? (size_t)((P + 255) / 256) * sizeof(float) + 16 : 16; }
+
+int gsr_isotropic_loss_forward(int P, const float* raw_scales, float* loss, char* workspace, void* stream_)
+{
+    if (P < 0 || !loss || !workspace || (P > 0 && !raw_scales)) { g_last_error = "gsr_isotropic_loss_forward: invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    const int nb = (P + 255) / 256;
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (nb) hipLaunchKernelGGL(isotropic_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream_, P, raw_scales, partial);
+    hipLaunchKernelGGL(isotropic_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, nb, P, (const float*)partial, loss);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_isotropic_loss_backward(int P, const float* raw_scales, const float* g_loss, float* d_raw_scales, void* stream_)
+{
+    if (P < 0 || (P > 0 && (!raw_scales || !g_loss || !d_raw_scales))) { g_last_error = "gsr_isotropic_loss_backward: invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (P) hipLaunchKernelGGL(isotropic_backward_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, P, raw_scales, g_loss, d_raw_scales);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int gsr_arap_forward(int V, int T, int M, int K, const float* p, const float* nb, const float* keep, float* R, float* partial, void* stream_)
 {
     if (V < 0 || T < 2 || M < 0 || K < 1 || ((size_t)V * M > 0 && (!p || !nb || !keep || !R || !partial))) {

@@ -595,4 +595,48 @@ __global__ void __launch_bounds__(64) elastic_backward_self_kernel(int n, int K,
     dx[i] = acc;
 }
 
+// ---- the isotropic regulariser of the mapping loops (utils/slam_backend.py:653-655, :1189-1191): 10 * mean |s - mean_k s| over the [P, 3]
+// activated scales s = exp(raw). As tensor ops: exp, mean, sub, abs, mean, mul and their backward -- a dozen launches per mapping iteration on
+// a tensor of a few hundred KB. Forward: per-block sums in a fixed order, then ONE block adds them (in order) and scales; backward: one launch.
+__global__ void __launch_bounds__(256) isotropic_partial_kernel(int P, const float* __restrict__ raw, float* __restrict__ partial)
+{
+    __shared__ float s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < P) {
+        const float a = expf(raw[3 * (size_t)i]), b = expf(raw[3 * (size_t)i + 1]), c = expf(raw[3 * (size_t)i + 2]);
+        const float m = (a + b + c) / 3.0f;
+        v = fabsf(a - m) + fabsf(b - m) + fabsf(c - m);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ void __launch_bounds__(256) isotropic_finalize_kernel(int nblocks, int P, const float* __restrict__ partial, float* __restrict__ loss)
+{
+    __shared__ float s_p[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partial[b];
+    s_p[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 256; k++) t += s_p[k];
+        loss[0] = P > 0 ? 10.0f * t / (3.0f * (float)P) : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) isotropic_backward_kernel(int P, const float* __restrict__ raw, const float* __restrict__ g_loss, float* __restrict__ d_raw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float a = expf(raw[3 * (size_t)i]), b = expf(raw[3 * (size_t)i + 1]), c = expf(raw[3 * (size_t)i + 2]);
+    const float m = (a + b + c) / 3.0f;
+    auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+    const float sa = sgn(a - m), sb = sgn(b - m), sc = sgn(c - m), sm = (sa + sb + sc) / 3.0f;
+    const float k = g_loss[0] * 10.0f / (3.0f * (float)P);
+    d_raw[3 * (size_t)i] = k * (sa - sm) * a; d_raw[3 * (size_t)i + 1] = k * (sb - sm) * b; d_raw[3 * (size_t)i + 2] = k * (sc - sm) * c;
+}
+
 }  // namespace gsr

@@ -50,6 +50,12 @@ def lib():
         L.gsr_schedule_advance.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
         L.gsr_slot_gather.restype = _i
         L.gsr_slot_gather.argtypes = [_i, _vp, _vp, C.POINTER(KeyframeEntry), _i, _vp]
+        L.gsr_isotropic_loss_workspace_size.restype = C.c_size_t
+        L.gsr_isotropic_loss_workspace_size.argtypes = [_i]
+        L.gsr_isotropic_loss_forward.restype = _i
+        L.gsr_isotropic_loss_forward.argtypes = [_i, _vp, _vp, _vp, _vp]
+        L.gsr_isotropic_loss_backward.restype = _i
+        L.gsr_isotropic_loss_backward.argtypes = [_i, _vp, _vp, _vp, _vp]
         L.gsr_arap_forward.restype = _i
         L.gsr_arap_forward.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
         L.gsr_arap_backward.restype = _i

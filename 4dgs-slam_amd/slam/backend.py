@@ -14,6 +14,7 @@ all-reduced; the densification statistics, the visibility union of the opacity r
 reduced only on the iterations that use them; the window cameras' poses / exposures travel owner -> everyone once per iteration (14
 floats each). The view-independent terms (isotropic-scale regulariser, ARAP / elastic node regularisers) are added on rank 0. All ranks
 must be seeded alike: they take the same random draws (extra keyframes, time samples, split noise)."""
+import os
 import random
 import time
 
@@ -24,6 +25,35 @@ import mapping_shard
 import slam_losses
 
 from .deform_model import draw_loss_times
+
+
+class _IsotropicLoss(torch.autograd.Function):
+    """10 * mean |s - mean_k s| of the [P, 3] scales s = exp(raw) (utils/slam_backend.py:653-655) through gsr_isotropic_loss_forward /
+    _backward (include/slam_map.h): the dozen launches of the tensor expression and its backward as three; sums in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, raw):
+        from . import _lib
+        raw_c = raw.detach().contiguous()
+        P = int(raw_c.shape[0])
+        L = _lib.lib()
+        loss = torch.empty((), dtype=torch.float32, device=raw.device)
+        ws = torch.empty((int(L.gsr_isotropic_loss_workspace_size(P)),), dtype=torch.uint8, device=raw.device)
+        with torch.cuda.device(raw.device):
+            _lib.check(L.gsr_isotropic_loss_forward(P, raw_c.data_ptr(), loss.data_ptr(), ws.data_ptr(), _lib.stream(raw.device)), "gsr_isotropic_loss_forward")
+        ctx.save_for_backward(raw_c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        (raw_c,) = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        out = torch.empty_like(raw_c)
+        with torch.cuda.device(raw_c.device):
+            _lib.check(_lib.lib().gsr_isotropic_loss_backward(int(raw_c.shape[0]), raw_c.data_ptr(), g.data_ptr(), out.data_ptr(), _lib.stream(raw_c.device)),
+                       "gsr_isotropic_loss_backward")
+        return out
 
 
 class BackEnd:
@@ -352,7 +382,12 @@ class BackEnd:
         return cache[(n_window, n_random)]
 
     def _isotropic_loss(self):
-        scaling = self.gaussians.get_scaling
+        g = self.gaussians
+        raw = g._scaling
+        if (raw.is_cuda and raw.dtype == torch.float32 and raw.dim() == 2 and raw.shape[1] == 3 and g.scaling_activation is torch.exp
+                and os.environ.get("GSR_FUSED_ISOTROPIC", "1") != "0"):
+            return _IsotropicLoss.apply(raw)                                                # two launches forward, one back
+        scaling = g.get_scaling
         return 10 * torch.abs(scaling - scaling.mean(dim=1).view(-1, 1)).mean()            # :653-655
 
     def map_static(self, current_window, prune=False, iters=1):
@@ -466,6 +501,13 @@ class BackEnd:
         cache = self.__dict__.setdefault("_graph_streams", {})
         if dev not in cache:
             cache[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return cache[dev]
+
+    def unit_gradient(self, dev):
+        """A scalar 1 on `dev`: the gradient the graph iterations hand every loss term (torch.autograd.backward with several roots)."""
+        cache = self.__dict__.setdefault("_unit_gradients", {})
+        if dev not in cache:
+            cache[dev] = torch.ones((), dtype=torch.float32, device=dev)
         return cache[dev]
 
     def graph_pool(self, dev):

@@ -291,7 +291,7 @@ class DynamicMapping:
         parts.append(r.current.view(torch.float32)[r.samples_lo:r.samples_lo + r.n_rest])
         it = nodes.begin_iteration_indexed(torch.cat(parts), lay["n_full"], blend=(g.get_dygs_xyz.detach(), g.motion_mask))
         nv, ne = len(self.views), self.n_slots
-        loss_network = 0 + nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
+        loss_network = nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
         rows = it["blended"]
         deltas_at = lambda i: (rows[0][i], rows[2][i], rows[1][i])                    # (d_xyz, d_scaling, d_rotation) of full sample i
         views = self.views + self.slots
@@ -302,10 +302,12 @@ class DynamicMapping:
             ops = self._window_ops[r.dyn] = [be.keyframe_operands.get(cfg, v, dev, rm_dynamic=False, dynamic=r.dyn) for v in self.views]
         ops = ops + [o + (ops[0][4],) for o in self.slot_ops]
         rendered = be._render_many(views, deltas)
-        loss_mapping = 0
+        # The iteration's loss is a sum of terms whose VALUE nobody reads (the fused losses leave it uninitialised): instead of adding them up --
+        # a launch per term -- every term is a root of ONE backward pass with the gradient 1 (be.unit_gradient): the same gradients, exactly
+        terms = [loss_network]
         for v, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):
-            loss_mapping = loss_mapping + slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, v.exposure_a,
-                                                                       v.exposure_b, alpha, compute_value=False)
+            terms.append(slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, v.exposure_a,
+                                                      v.exposure_b, alpha, compute_value=False))
         if r.with_flow:
             from gaussian_renderer import render_flow_views
             requests, pairs, clips = [], [], []
@@ -329,13 +331,11 @@ class DynamicMapping:
                 flows = render_flow_views(g, requests, clips=clips if FLOW_CLIPS else None)
                 if FLOW_CLIPS and be.config["Training"].get("flow_clip_check") and not torch.cuda.is_current_stream_capturing():
                     self._check_flow_clips(requests, pairs, clips, flows)          # TEST facility: the same terms without the clips
-                loss = 0.0
                 for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
-                    loss = loss + slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
-                                                        channels=2)
-                loss_network = loss_network + loss
-        loss_mapping = loss_mapping + be._isotropic_loss()
-        (loss_mapping + loss_network).backward()
+                    terms.append(slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
+                                                       channels=2))
+        terms.append(be._isotropic_loss())
+        torch.autograd.backward(terms, [be.unit_gradient(dev)] * len(terms))
         nodes.end_iteration()
         split = False
         with torch.no_grad():

@@ -145,13 +145,12 @@ class MappingGraph:
         views = self.window + self.slots
         ops = list(self.window_ops) + [o + (self.alpha,) for o in self.slot_ops]
         rendered = be._render_many(views, [(None, None, None)] * len(views))
-        loss_mapping = 0
-        for viewpoint, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):
-            loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, viewpoint.exposure_a, viewpoint.exposure_b,
-                                                alpha, compute_value=False)
-            loss_mapping = loss_mapping + loss
-        loss_mapping = loss_mapping + be._isotropic_loss()
-        loss_mapping.backward()
+        # (every term a root of ONE backward pass with the gradient 1 instead of a sum nobody reads: see DynamicMapping.iteration)
+        terms = [slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, viewpoint.exposure_a, viewpoint.exposure_b,
+                                              alpha, compute_value=False)
+                 for viewpoint, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops)]
+        terms.append(be._isotropic_loss())
+        torch.autograd.backward(terms, [be.unit_gradient(dev)] * len(terms))
         with torch.no_grad():
             for pkg in rendered:
                 be._view_stats(pkg)

@@ -131,6 +131,13 @@ int gsr_edge_mask(const float* image, int height, int width, float edge_threshol
  * value is flipped when det <= 0): always a proper rotation; S = 0 -> identity. One thread per matrix, double precision inside. */
 int gsr_kabsch_rotations(int n, const float* S, float* R, void* stream);
 
+/* The isotropic regulariser of the mapping loops (utils/slam_backend.py:653-655,:1189-1191): loss = 10 * mean over [P, 3] of |s - mean_k s|,
+ * s = exp(raw_scales), raw_scales [P, 3] (the model's _scaling). Forward: per-block sums + an ordered finalisation (workspace:
+ * gsr_isotropic_loss_workspace_size(P) bytes); backward: d_raw_scales [P, 3] for the upstream gradient g_loss (one device float). */
+size_t gsr_isotropic_loss_workspace_size(int P);
+int gsr_isotropic_loss_forward(int P, const float* raw_scales, float* loss, char* workspace, void* stream);
+int gsr_isotropic_loss_backward(int P, const float* raw_scales, const float* g_loss, float* d_raw_scales, void* stream);
+
 /* The node graph's two regularisers, one launch each way (round 4). The caller gathers the neighbours' positions (a gather whose backward is an
  * ordered scatter: gsr_index_csr + gsr_segment_sum) and reduces the per-node results; everything per (view, sample, node) happens here.
  *   ARAP (cal_arap_error, utils/deform_utils.py:177-205, no edge weights): p [V][T][M][3] node positions at T time samples of V views,

@@ -852,3 +852,24 @@ def test_slam_loop_through_the_ctypes_binding():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSR_GLUE="ctypes"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RESULT" in r.stdout
+
+
+def test_fused_isotropic_loss_equals_the_tensor_expression():
+    """gsr_isotropic_loss_forward / _backward against 10 * |s - mean_k s|.mean() on s = exp(raw): value and gradient, repeatable bits."""
+    from slam.backend import _IsotropicLoss
+    g = torch.Generator().manual_seed(4)
+    raw = (torch.randn(70_001, 3, generator=g) * 0.8 - 3.0).cuda().requires_grad_(True)
+    raw.data[:5] = raw.data[:5, :1]                                 # a few exactly isotropic rows: |0| has gradient 0
+    loss = _IsotropicLoss.apply(raw) * 0.7
+    loss.backward()
+    got, got_g = loss.detach().clone(), raw.grad.clone()
+    raw.grad = None
+    s = torch.exp(raw)
+    want = 10 * torch.abs(s - s.mean(dim=1).view(-1, 1)).mean() * 0.7
+    want.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    assert torch.allclose(got_g, raw.grad, rtol=1e-5, atol=1e-12) and float(got_g[:5].abs().max()) == 0.0
+    raw.grad = None
+    again = _IsotropicLoss.apply(raw) * 0.7
+    assert torch.equal(again.detach(), got)
+    assert float(_IsotropicLoss.apply(raw[:0].detach().requires_grad_(True))) == 0.0
