@@ -292,11 +292,24 @@ class _FusedTrunk(torch.autograd.Function):
         h_last = outs[D - 1]
         gW_heads, gb_heads = _grad_weight(g_out, h_last), g_out.sum(0)
         g = g_out.mm(W_heads)
+        # the weight gradients of the layers of one shape (six of the eight are [W, W]) are batched products into ONE buffer, summed over their
+        # row groups by one launch at the end instead of one per layer (they feed nothing on the way back)
+        R = int(g_out.shape[0])
+        groups = _row_groups(R)
+        same = [i for i in range(D) if tuple(Ws[i].shape) == tuple(Ws[D - 1].shape) and inputs[i].is_contiguous()] if groups > 1 else []
+        buf = g_out.new_empty((len(same), groups) + tuple(Ws[D - 1].shape)) if len(same) > 1 else None
         for i in reversed(range(D)):
             G, db = control_nodes.relu_backward_bias(g, outs[i])
-            grads[2 * i], grads[2 * i + 1] = _grad_weight(G, inputs[i]), db
+            if buf is not None and i in same:
+                torch.bmm(G.view(groups, R // groups, -1).transpose(1, 2), inputs[i].view(groups, R // groups, -1), out=buf[same.index(i)])
+            else:
+                grads[2 * i] = _grad_weight(G, inputs[i])
+            grads[2 * i + 1] = db
             if i > 0:
                 g = G.mm(Ws[i][:, E:] if i == skip + 1 else Ws[i])      # (the embedding half of the skip input needs no gradient)
+        if buf is not None:
+            for j, dW in enumerate(buf.sum(1).unbind(0)):
+                grads[2 * same[j]] = dW
         return (None, None, gW_heads, gb_heads, *grads)
 
 
