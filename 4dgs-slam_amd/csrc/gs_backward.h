@@ -43,7 +43,7 @@ __device__ uint32_t g_geo_timing[8 * 4 * 8192];
 #else
 #define GEO_TICK(k)
 #endif
-template <bool RAW>
+template <bool RAW, bool PRE = false>     // PRE: deformation-network deltas in front of the activations (RawInputs::delta_mode = 1)
 __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
 {
     // RAW: the fused-prologue mode (raw.xyz != nullptr). As a template parameter the plain instantiation is straight-line code: with the
@@ -112,10 +112,10 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     float old_m[3] = {0.f, 0.f, 0.f}, old_s[3] = {0.f, 0.f, 0.f}, old_r[4] = {0.f, 0.f, 0.f, 0.f}, old_o = 0.f, old_c[3] = {0.f, 0.f, 0.f};
     float* const dc_out = RAW ? (RG.f_dc ? RG.f_dc + 3 * o : nullptr) : (a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr);
     if (visible) {
-        mean = load_mean(a.means3D, R, i);
+        mean = load_mean<PRE>(a.means3D, R, i);
 #pragma unroll
         for (int k = 0; k < 6; k++) cov6[k] = a.cov3Ds[6 * i + k];
-        if (want_cov_chain) { load_rot(a.rotations, R, i, q4); load_scale(a.scales, R, i, s3); }
+        if (want_cov_chain) { load_rot<PRE>(a.rotations, R, i, q4); load_scale<PRE>(a.scales, R, i, s3); }
         clamp_bits = a.clamped[idx];
         if (a.accumulate && !a.pose_only) {
 #pragma unroll
@@ -467,6 +467,39 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         } else {
             // chain rules of the fused prologue (gaussian_model.py:60-68): exp, normalize; the deltas' gradients are the
             // effective parameters' gradients of their Gaussian (one Gaussian per slot: plain stores)
+            if constexpr (PRE) {
+                // deformation-network deltas (added in front of the activations): the effective raw parameters are _scaling + ds and
+                // _rotation + dr; a delta's gradient is its parameter's gradient of this view (before any accumulation). Every row of
+                // ddx / dds / ddr is written (zeros for the Gaussians this view does not see).
+                const int sl = pre_slot(R, o);
+                const float* pds = sl >= 0 && R.ds ? R.ds + (size_t)pre_stride(R, 3) * sl : nullptr;
+                const float* pdr = sl >= 0 && R.dr ? R.dr + (size_t)pre_stride(R, 4) * sl : nullptr;
+                float gls[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) gls[k] = visible ? dscale[k] * expf(R.log_scales[R.scale_dim == 1 ? o : 3 * o + k] + (pds ? pds[k] : 0.f)) : 0.f;
+                float ra = R.raw_rot[4 * o], rb = R.raw_rot[4 * o + 1], rc = R.raw_rot[4 * o + 2], rd = R.raw_rot[4 * o + 3];
+                if (pdr) { ra += pdr[0]; rb += pdr[1]; rc += pdr[2]; rd += pdr[3]; }
+                const float inv = 1.0f / fmaxf(sqrtf(ra * ra + rb * rb + rc * rc + rd * rd), 1e-12f);
+                const float qa = ra * inv, qb = rb * inv, qc = rc * inv, qd = rd * inv;
+                const float dotg = qa * drot[0] + qb * drot[1] + qc * drot[2] + qd * drot[3];
+                const float gr[4] = {(drot[0] - qa * dotg) * inv, (drot[1] - qb * dotg) * inv, (drot[2] - qc * dotg) * inv, (drot[3] - qd * dotg) * inv};
+                if (wr) {
+                    if (R.scale_dim == 1) a.dL_dscale[o] = add_separately(old_s[0], gls[0] + gls[1] + gls[2]);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) a.dL_dscale[3 * o + k] = add_separately(old_s[k], gls[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) a.dL_drot[4 * o + k] = add_separately(old_r[k], gr[k]);
+                }
+                if (sl >= 0) {
+                    const int w3 = pre_stride(R, 3), w4 = pre_stride(R, 4);
+                    if (RG.ddx) { float* d = RG.ddx + (size_t)w3 * sl; d[0] = dmean[0]; d[1] = dmean[1]; d[2] = dmean[2]; }
+                    if (RG.dds) { float* d = RG.dds + (size_t)w3 * sl; d[0] = gls[0]; d[1] = gls[1]; d[2] = gls[2]; }
+                    if (RG.ddr) { float* d = RG.ddr + (size_t)w4 * sl; d[0] = gr[0]; d[1] = gr[1]; d[2] = gr[2]; d[3] = gr[3]; }
+                }
+                return;
+            }
             const int sl = raw_slot(R, o);
             if (sl >= 0 && flow) {
                 // render_flow (gaussian_renderer/__init__.py:262-284): the colour (g_r, g_g) reaches dx through -ndc(.; proj1) and dx2
@@ -520,10 +553,10 @@ __device__ __forceinline__ void tau_sum_body(int nblocks, const float* __restric
 
 // ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
 // several views) ----------------------------------------------------------------------------------------------------------------------
-template <bool RAW>
+template <bool RAW, bool PRE = false>
 __global__ void __launch_bounds__(256) geometry_bwd_kernel(GeomBwdArgs a)
 {
-    geometry_bwd_body<RAW>(a);
+    geometry_bwd_body<RAW, PRE>(a);
 }
 
 __global__ void __launch_bounds__(384) tau_sum_kernel(int nblocks, const float* __restrict__ partials, float* __restrict__ out6)

@@ -339,15 +339,18 @@ static RawInputs to_device_view(const gsr_raw_inputs* in)
         r.dyn_slot = in->dyn_slot; r.dx = in->dx; r.ds = in->ds; r.dr = in->dr; r.gather = in->gather;
         r.flow_dx2 = in->flow_dx2; r.flow_proj1 = in->flow_proj1; r.flow_proj2 = in->flow_proj2;
         r.flow_clip = in->flow_proj1 ? t_clip_single : nullptr;
+        r.delta_mode = in->delta_mode; r.delta_stride = in->delta_stride;
     }
     return r;
 }
 static bool raw_inputs_ok(const gsr_raw_inputs* in, int M)
 {
     const bool flow = in->flow_proj1 != nullptr;
-    if (flow && (!in->flow_proj2 || M != 1 || (in->flow_dx2 && !in->dyn_slot))) return false;
+    if (flow && (!in->flow_proj2 || M != 1 || (in->flow_dx2 && !in->dyn_slot) || in->delta_mode || in->delta_stride)) return false;
+    if ((in->delta_mode != 0 && in->delta_mode != 1) || in->delta_stride < 0 || (in->delta_stride && (in->delta_stride < 4 || !in->delta_mode)) ||
+        (in->delta_mode && in->gather)) return false;
     return in->xyz && in->log_scales && (in->scale_dim == 1 || in->scale_dim == 3) && in->raw_rotations && in->logit_opacity &&
-           (flow || (in->features_dc && (M == 1 || in->features_rest))) && ((!in->dx && !in->ds && !in->dr) || in->dyn_slot);
+           (flow || (in->features_dc && (M == 1 || in->features_rest))) && ((!in->dx && !in->ds && !in->dr) || in->dyn_slot || in->delta_mode);
 }
 
 static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user,
@@ -414,7 +417,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
             a.eager = eager;
-            if (raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
+            if (raw && raw->delta_mode) hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
+            else if (raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
             else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
@@ -710,7 +714,8 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     const size_t hist_lds_bytes = (size_t)d.T * sizeof(uint32_t);
     {
         ScopedKernelTimer tm(K_PREPROCESS, stream);
-        hipLaunchKernelGGL(preprocess_views_kernel<true>, gv, dim3(GB), hist_lds_bytes, stream, a, t, d);
+        if (in->delta_mode) hipLaunchKernelGGL((preprocess_views_kernel<true, true>), gv, dim3(GB), hist_lds_bytes, stream, a, t, d);
+        else hipLaunchKernelGGL(preprocess_views_kernel<true>, gv, dim3(GB), hist_lds_bytes, stream, a, t, d);
     }
     {
         ScopedKernelTimer tm(K_SCAN, stream);
@@ -821,7 +826,8 @@ extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, c
     a.rawg.scale_dim = in->scale_dim;
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
-        hipLaunchKernelGGL(geometry_bwd_views_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)V), dim3(256), 0, stream, a, t, d);
+        if (in->delta_mode) hipLaunchKernelGGL((geometry_bwd_views_kernel<true, true>), dim3((unsigned)((P + 255) / 256), (unsigned)V), dim3(256), 0, stream, a, t, d);
+        else hipLaunchKernelGGL(geometry_bwd_views_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)V), dim3(256), 0, stream, a, t, d);
         hipLaunchKernelGGL(tau_sum_views_kernel, dim3(1, (unsigned)V), dim3(384), 0, stream, t, d);
         if (!pose_only) {
             ReduceTargets r{out->xyz, out->features_dc, out->features_rest, out->logit_opacity, out->log_scales, out->raw_rotations};
@@ -886,7 +892,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     if (raw) { a.rawg.f_dc = rawg->features_dc; a.rawg.f_rest = rawg->features_rest; a.rawg.ddx = rawg->dx; a.rawg.dds = rawg->ds; a.rawg.ddr = rawg->dr; a.rawg.scale_dim = raw->scale_dim; a.rawg.ddx2 = rawg->dx2; }
     {
         ScopedKernelTimer tm(K_GEOM_BWD, stream);
-        if (raw) hipLaunchKernelGGL(geometry_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
+        if (raw && raw->delta_mode) hipLaunchKernelGGL((geometry_bwd_kernel<true, true>), dim3((P + 255) / 256), dim3(256), 0, stream, a);
+        else if (raw) hipLaunchKernelGGL(geometry_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(geometry_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
         if (dL_dtau_sum)
             hipLaunchKernelGGL(tau_sum_kernel, dim3(1), dim3(384), 0, stream, (P + 255) / 256, geom.tau_partials, dL_dtau_sum);
@@ -1441,6 +1448,121 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
         break;
     switch (C) { GSR_HEXSORT_CASE(8) GSR_HEXSORT_CASE(16) GSR_HEXSORT_CASE(32) GSR_HEXSORT_CASE(64) }
 #undef GSR_HEXSORT_CASE
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- the views of one mapping iteration (include/deformation_field.h) ----------------------------------------------------------------
+static int hexplane_views_check(const gsr_hexplane_field* f, int64_t n, const float* xyz, int V, const float* times, const char* who)
+{
+    static const float some_time = 0.f;
+    if (int rc = hexplane_check(f, n, xyz, &some_time, who)) return rc;
+    if (V < 1 || V > GSR_HEXPLANE_MAX_VIEWS || !times) {
+        static thread_local std::string msg;
+        msg = std::string(who) + ": 1 <= V <= GSR_HEXPLANE_MAX_VIEWS times (host pointer) expected"; g_last_error = msg.c_str();
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    return 0;
+}
+static HexTimes hex_times(int V, const float* times)
+{
+    HexTimes tv{};
+    tv.V = V;
+    for (int v = 0; v < V; v++) tv.t[v] = times[v];
+    return tv;
+}
+
+int gsr_hexplane_forward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
+                               float* features, void* stream_)
+{
+    if (int rc = hexplane_views_check(field, n, xyz, V, times, "gsr_hexplane_forward_views")) return rc;
+    if (n == 0) return 0;
+    if (!features) { g_last_error = "gsr_hexplane_forward_views: null features"; return GSR_ERR_INVALID_ARGUMENT; }
+    const gsr_hexplane_field& f = *field;
+    const HexTimes tv = hex_times(V, times);
+    const int lpp = f.feat_dim / 4;
+    const dim3 grid((unsigned)((n + HEX_BLOCK / lpp - 1) / (HEX_BLOCK / lpp))), block(HEX_BLOCK);
+    hipStream_t stream = (hipStream_t)stream_;
+#define GSR_HEXV_CASE(LPP)                                                                                                              \
+    case LPP:                                                                                                                           \
+        if (f.channels_last) hipLaunchKernelGGL((hexplane_fwd_views_kernel<LPP, HEX_VEC>), grid, block, 0, stream, f, n, xyz, xyz_stride, tv, features);   \
+        else hipLaunchKernelGGL((hexplane_fwd_views_kernel<LPP, HEX_PLANAR>), grid, block, 0, stream, f, n, xyz, xyz_stride, tv, features);               \
+        break;
+    switch (lpp) { GSR_HEXV_CASE(2) GSR_HEXV_CASE(4) GSR_HEXV_CASE(8) GSR_HEXV_CASE(16) }
+#undef GSR_HEXV_CASE
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static size_t hexviews_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, int V, char* base, HexSortWs* ws, HexViewsWs* vw)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    const size_t nb = (size_t)P.key_off[6], row = (size_t)f.num_levels * f.feat_dim;
+    HexSortWs w{};
+    HexViewsWs v{};
+    w.count = reinterpret_cast<uint32_t*>(take(nb * sizeof(uint32_t)));
+    w.block_sums = reinterpret_cast<uint32_t*>(take((nb / (1024 * HEXSORT_SCAN_ITEMS) + 1) * sizeof(uint32_t)));
+    w.header = reinterpret_cast<uint32_t*>(take(256));
+    w.coords = reinterpret_cast<float4*>(take((size_t)n * sizeof(float4)));
+    w.key = reinterpret_cast<uint32_t*>(take((size_t)6 * n * sizeof(uint32_t)));
+    w.rank = reinterpret_cast<int*>(take((size_t)6 * n * sizeof(int)));
+    w.scoords = reinterpret_cast<float4*>(take((size_t)6 * n * sizeof(float4)));
+    v.gs_sp = reinterpret_cast<float*>(take((size_t)3 * n * row * sizeof(float)));
+    v.gs_t = reinterpret_cast<float*>(take((size_t)3 * V * n * row * sizeof(float)));
+    if (ws) *ws = w;
+    if (vw) *vw = v;
+    return off + 256;
+}
+
+size_t gsr_hexplane_backward_views_workspace_size(const gsr_hexplane_field* field, int64_t n, int V)
+{
+    if (!field || n <= 0 || V < 1 || V > GSR_HEXPLANE_MAX_VIEWS || field->num_levels < 1 || field->num_levels > GSR_HEXPLANE_MAX_LEVELS ||
+        !hexsort_supported(*field, n)) return 0;
+    HexSortPlan P;
+    hexsort_plan(*field, &P);
+    return hexviews_carve(*field, P, n, V, nullptr, nullptr, nullptr);
+}
+
+int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
+                                const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = hexplane_views_check(field, n, xyz, V, times, "gsr_hexplane_backward_views")) return rc;
+    if (n == 0) return 0;
+    const gsr_hexplane_field& f = *field;
+    if (!dL_dfeatures || !workspace || !hexsort_supported(f, n)) {
+        g_last_error = "gsr_hexplane_backward_views: null cotangent / workspace, or a geometry the sorted algorithm does not cover (see gsr_hexplane_backward_views_workspace_size)";
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const HexTimes tv = hex_times(V, times);
+    HexSortPlan P;
+    hexsort_plan(f, &P);
+    HexSortWs ws;
+    HexViewsWs vw;
+    hexviews_carve(f, P, n, V, workspace, &ws, &vw);
+    const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
+    GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, (const float*)nullptr, (int64_t)0,
+                       (const float*)nullptr);
+    hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
+    hipLaunchKernelGGL(hexsort_scan_top_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, scan_blocks, ws.header);
+    hipLaunchKernelGGL(hexsort_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, ws.count, nb, (const uint32_t*)ws.block_sums);
+    hipLaunchKernelGGL(hexsort_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, n);
+    const int C = f.feat_dim, ppb = HEX_BLOCK / C;
+    const dim3 g1((unsigned)((n + ppb - 1) / ppb));
+    const int gpw = C >= 64 ? 1 : 64 / C;                        // groups per wave (hexsort_phase2_views_kernel)
+    const int64_t chunks2 = (n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    const int64_t groups = (int64_t)(3 + 3 * ((V + HEXSORT_VIEW_BATCH - 1) / HEXSORT_VIEW_BATCH)) * ((chunks2 + gpw - 1) / gpw) * gpw;
+    const dim3 g2((unsigned)((groups + 256 / C - 1) / (256 / C)));
+#define GSR_HEXVB_CASE(CC)                                                                                                              \
+    case CC:                                                                                                                             \
+        hipLaunchKernelGGL((hexsort_phase1_views_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz);   \
+        if (f.num_levels <= 4) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, vw, tv, n);      \
+        else hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, vw, tv, n);  \
+        break;
+    switch (C) { GSR_HEXVB_CASE(8) GSR_HEXVB_CASE(16) GSR_HEXVB_CASE(32) GSR_HEXVB_CASE(64) }
+#undef GSR_HEXVB_CASE
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -284,6 +284,12 @@ struct RawInputs {
     const int* gather;   // optional: rasterized Gaussian i reads row gather[i] of the raw tensors (render()'s boolean mask, :179-191)
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2;   // flow mode (render_flow, :229-361): see include/gs_rasterizer.h
     const int* flow_clip;        // flow mode, optional: tile rectangle [x0, y0, x1, y1) outside of which nothing is needed (gsr_set_flow_clips)
+    // delta_mode 1 (kernels instantiated with PRE = true): dx / ds / dr are the outputs of the 4DGaussians deformation network
+    // (gaussian_renderer/__init__.py:149-157, utils/deformation.py:113-149), added to the RAW parameters IN FRONT of the activations:
+    // scales = exp(_scaling + ds), rotations = normalize(_rotation + dr) -- not the control-node deltas of :159-174, which are added behind
+    // them (mode 0). Then dyn_slot may be null (Gaussian i takes row i) and delta_stride is the number of floats between consecutive rows of
+    // dx, ds AND dr (0: compact 3 / 3 / 4), so that the three can be column ranges of one [K, 10] network output.
+    int delta_mode; int delta_stride;
 };
 struct RawGrads { float* f_dc; float* f_rest; float* ddx; float* dds; float* ddr; int scale_dim; float* ddx2; };
 
@@ -344,33 +350,57 @@ __device__ __forceinline__ f3 flow_ndc_vjp(const float* __restrict__ M, f3 p, fl
 
 __device__ __forceinline__ size_t raw_row(const RawInputs& r, size_t i) { return r.gather ? (size_t)r.gather[i] : i; }   // row of the raw tensors
 __device__ __forceinline__ int raw_slot(const RawInputs& r, size_t row) { return r.dyn_slot ? r.dyn_slot[row] : -1; }
+// PRE (delta_mode 1): row of the network's output that belongs to raw row `row`, and the distance between rows of a delta tensor
+__device__ __forceinline__ int pre_slot(const RawInputs& r, size_t row) { return r.dyn_slot ? r.dyn_slot[row] : (int)row; }
+__device__ __forceinline__ int pre_stride(const RawInputs& r, int width) { return r.delta_stride ? r.delta_stride : width; }
+template <bool PRE = false>
 __device__ __forceinline__ f3 load_mean(const float* means3D, const RawInputs& r, size_t i)
 {
     if (!r.xyz) return mk3(means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
     i = raw_row(r, i);
     f3 m = mk3(r.xyz[3 * i], r.xyz[3 * i + 1], r.xyz[3 * i + 2]);
+    if constexpr (PRE) {
+        const int sl = pre_slot(r, i);
+        if (sl >= 0 && r.dx) { const float* d = r.dx + (size_t)pre_stride(r, 3) * sl; m.x += d[0]; m.y += d[1]; m.z += d[2]; }
+        return m;
+    }
     const int sl = raw_slot(r, i);
     if (sl >= 0 && r.dx) { m.x += r.dx[3 * sl]; m.y += r.dx[3 * sl + 1]; m.z += r.dx[3 * sl + 2]; }
     return m;
 }
+template <bool PRE = false>
 __device__ __forceinline__ void load_scale(const float* scales, const RawInputs& r, size_t i, float s[3])
 {
     if (!r.xyz) { s[0] = scales[3 * i]; s[1] = scales[3 * i + 1]; s[2] = scales[3 * i + 2]; return; }
     i = raw_row(r, i);
+    if constexpr (PRE) {                         // exp(_scaling.repeat(1, 3) + ds) (gaussian_renderer/__init__.py:150-155)
+        const int sl = pre_slot(r, i);
+        const float* d = sl >= 0 && r.ds ? r.ds + (size_t)pre_stride(r, 3) * sl : nullptr;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s[k] = expf(r.log_scales[r.scale_dim == 1 ? i : 3 * i + k] + (d ? d[k] : 0.f));
+        return;
+    }
     if (r.scale_dim == 1) { s[0] = s[1] = s[2] = expf(r.log_scales[i]); }
     else { s[0] = expf(r.log_scales[3 * i]); s[1] = expf(r.log_scales[3 * i + 1]); s[2] = expf(r.log_scales[3 * i + 2]); }
     const int sl = raw_slot(r, i);
     if (sl >= 0 && r.ds) { s[0] += r.ds[3 * sl]; s[1] += r.ds[3 * sl + 1]; s[2] += r.ds[3 * sl + 2]; }
 }
+template <bool PRE = false>
 __device__ __forceinline__ void load_rot(const float* rotations, const RawInputs& r, size_t i, float q[4])
 {
     if (!r.xyz) { q[0] = rotations[4 * i]; q[1] = rotations[4 * i + 1]; q[2] = rotations[4 * i + 2]; q[3] = rotations[4 * i + 3]; return; }
     i = raw_row(r, i);
-    const float a = r.raw_rot[4 * i], b = r.raw_rot[4 * i + 1], c = r.raw_rot[4 * i + 2], d = r.raw_rot[4 * i + 3];
+    float a = r.raw_rot[4 * i], b = r.raw_rot[4 * i + 1], c = r.raw_rot[4 * i + 2], d = r.raw_rot[4 * i + 3];
+    if constexpr (PRE) {                         // normalize(_rotation + dr) (:156)
+        const int sl = pre_slot(r, i);
+        if (sl >= 0 && r.dr) { const float* e = r.dr + (size_t)pre_stride(r, 4) * sl; a += e[0]; b += e[1]; c += e[2]; d += e[3]; }
+    }
     const float inv = 1.0f / fmaxf(sqrtf(a * a + b * b + c * c + d * d), 1e-12f);     // torch.nn.functional.normalize
     q[0] = a * inv; q[1] = b * inv; q[2] = c * inv; q[3] = d * inv;
-    const int sl = raw_slot(r, i);
-    if (sl >= 0 && r.dr) { q[0] += r.dr[4 * sl]; q[1] += r.dr[4 * sl + 1]; q[2] += r.dr[4 * sl + 2]; q[3] += r.dr[4 * sl + 3]; }
+    if constexpr (!PRE) {
+        const int sl = raw_slot(r, i);
+        if (sl >= 0 && r.dr) { q[0] += r.dr[4 * sl]; q[1] += r.dr[4 * sl + 1]; q[2] += r.dr[4 * sl + 2]; q[3] += r.dr[4 * sl + 3]; }
+    }
 }
 __device__ __forceinline__ float load_opacity(const float* opacities, const RawInputs& r, size_t i)
 {

@@ -198,7 +198,7 @@ __device__ uint32_t g_sca_timing[8 * 16 * 2048];
 // behind) -- scale, rotation, opacity and the DC colour of EVERY Gaussian in one go, so that a visible Gaussian pays two global
 // latencies instead of four (mean -> scale / rotation -> colour -> opacity); large launches keep the lazy order, which spares the
 // culled Gaussians' rows (71 % of 2 M at BASELINE config #5) and has enough waves in flight.
-template <bool RAW>
+template <bool RAW, bool PRE = false>     // PRE: deformation-network deltas in front of the activations (RawInputs::delta_mode = 1)
 __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
 {
     RawInputs R = a.raw;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
     if (idx < a.P) {
         int my_radius = 0;
         if (a.n_touched) a.n_touched[idx] = 0;
-        const f3 p = load_mean(a.means3D, R, (size_t)idx);
+        const f3 p = load_mean<PRE>(a.means3D, R, (size_t)idx);
         const bool flow = RAW && R.flow_proj1 != nullptr;
         const bool eager = a.eager != 0;
         float s3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f}, cov6[6], opac = 0.f, dc[3] = {0.f, 0.f, 0.f};
@@ -230,8 +230,8 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
 #pragma unroll
                 for (int k = 0; k < 6; k++) cov6[k] = a.cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                load_scale(a.scales, R, (size_t)idx, s3);
-                load_rot(a.rotations, R, (size_t)idx, q4);
+                load_scale<PRE>(a.scales, R, (size_t)idx, s3);
+                load_rot<PRE>(a.rotations, R, (size_t)idx, q4);
             }
         };
         const ShView shv = sh_view(a.shs, R, (size_t)idx, a.M);
@@ -1097,10 +1097,10 @@ __global__ void mark_visible_kernel(int P, const float* means3D, const float* vi
 
 // ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
 // several views) ----------------------------------------------------------------------------------------------------------------------
-template <bool RAW>
+template <bool RAW, bool PRE = false>
 __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 {
-    preprocess_fwd_body<RAW>(a);
+    preprocess_fwd_body<RAW, PRE>(a);
 }
 
 template <int SEGS, int RMAX>

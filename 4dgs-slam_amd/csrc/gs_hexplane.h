@@ -140,6 +140,55 @@ hexplane_fwd_kernel(const gsr_hexplane_field f, const int64_t n, const float* __
     }
 }
 
+// ---- the views of one mapping iteration in one launch --------------------------------------------------------------------------------
+// The mapping back-end evaluates the field at the SAME positions for every keyframe of an iteration, each with its own time
+// (gaussian_renderer/__init__.py:112,149-157: `time = torch.tensor(viewpoint_camera.time).repeat(P, 1)`). Of the six samples of a level the
+// three spatial planes (xy, xz, yz) depend on the position only: they are gathered ONCE per point and level -- they are the scattered,
+// HBM-sized part of the field (128 of its 136 MB) -- and only the three time planes, whose rows of one time fit in L2 (2 rows x 960
+// columns x 128 B x 3 planes = 0.7 MB per view), are sampled per view. The product is formed in the reference's plane order
+// (hexplane.py:93-103), so every view's features are bit-identical to hexplane_fwd_kernel's.
+constexpr int HEX_MAX_VIEWS = 12;
+typedef float hex_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void hex_stream_store4(float* dst, float4 v)
+{
+    hex_f4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<hex_f4*>(dst));
+}
+struct HexTimes { int V; float t[HEX_MAX_VIEWS]; };
+
+template <int LPP, int CL>
+__global__ void __launch_bounds__(HEX_BLOCK)
+hexplane_fwd_views_kernel(const gsr_hexplane_field f, const int64_t n, const float* __restrict__ xyz, const int64_t xyz_stride,
+                          const HexTimes tv, float* __restrict__ features)
+{
+    constexpr int C = 4 * LPP;
+    const int sub = threadIdx.x % LPP;
+    const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / LPP) + threadIdx.x / LPP;
+    if (i >= n) return;
+    const float zero_time = 0.f;
+    const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, &zero_time);
+    const int64_t row = (int64_t)f.num_levels * C;
+    float* out = features + i * row + 4 * sub;
+    for (int l = 0; l < f.num_levels; l++) {
+        const gsr_hexplane_level& L = f.levels[l];
+        HexAxis ax[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ax[k] = hex_axis(p.c[k], L.res[k]);
+        const float4 s0 = hex_sample<CL>(L.planes[0], ax[0], ax[1], L.res[0], L.res[1], C, sub);
+        const float4 s1 = hex_sample<CL>(L.planes[1], ax[0], ax[2], L.res[0], L.res[2], C, sub);
+        const float4 s3 = hex_sample<CL>(L.planes[3], ax[1], ax[2], L.res[1], L.res[2], C, sub);
+        const float4 s01 = (make_float4(1.f, 1.f, 1.f, 1.f) * s0) * s1;
+        for (int v = 0; v < tv.V; v++) {
+            const HexAxis at = hex_axis(tv.t[v], L.res[3]);
+            const float4 s2 = hex_sample<CL>(L.planes[2], ax[0], at, L.res[0], L.res[3], C, sub);
+            const float4 s4 = hex_sample<CL>(L.planes[4], ax[1], at, L.res[1], L.res[3], C, sub);
+            const float4 s5 = hex_sample<CL>(L.planes[5], ax[2], at, L.res[2], L.res[3], C, sub);
+            const float4 prod = (((s01 * s2) * s3) * s4) * s5;
+            hex_stream_store4(out + (int64_t)v * n * row + (size_t)l * C, prod);    // read once, by the MLP: keep the planes in L2
+        }
+    }
+}
+
 __device__ __forceinline__ void hex_atomic_add4(float* __restrict__ g, size_t off, size_t cstride, float4 v)
 {
     unsafeAtomicAdd(g + off, v.x);

@@ -72,22 +72,26 @@ hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexS
     if (i >= n) return;
     // A point whose cotangent row is exactly zero (a Gaussian the view does not see) adds nothing to any plane: it is left out of the
     // sort altogether, so everything after this kernel costs in proportion to the points that carry a gradient.
-    const float4* row = reinterpret_cast<const float4*>(dL_dfeatures + i * ((int64_t)f.num_levels * f.feat_dim));
-    int active = 0;
-    for (int e = sub; e < f.num_levels * f.feat_dim / 4; e += 8) {
-        const float4 v = row[e];
-        active |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    // (the batched-views caller passes no cotangent: with up to 12 views per point nearly every point is seen by one of them)
+    int active = dL_dfeatures ? 0 : 1;
+    if (dL_dfeatures) {
+        const float4* row = reinterpret_cast<const float4*>(dL_dfeatures + i * ((int64_t)f.num_levels * f.feat_dim));
+        for (int e = sub; e < f.num_levels * f.feat_dim / 4; e += 8) {
+            const float4 v = row[e];
+            active |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        }
+        active |= __shfl_xor(active, 1, 64);
+        active |= __shfl_xor(active, 2, 64);
+        active |= __shfl_xor(active, 4, 64);
     }
-    active |= __shfl_xor(active, 1, 64);
-    active |= __shfl_xor(active, 2, 64);
-    active |= __shfl_xor(active, 4, 64);
     if (sub != 0) return;
     if (!active) {
 #pragma unroll
         for (int pl = 0; pl < 6; pl++) ws.key[(size_t)pl * n + i] = 0xFFFFFFFFu;
         return;
     }
-    const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time + i * time_stride);
+    const float zero_time = 0.f;       // time == nullptr (batched views): the time families are sorted along their spatial coordinate only
+    const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time ? time + i * time_stride : &zero_time);
     ws.coords[i] = make_float4(p.c[0], p.c[1], p.c[2], p.c[3]);
     int i0[4];
 #pragma unroll
@@ -260,24 +264,15 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
 }
 
 // ---- phase 2: run-length accumulation along the sorted order --------------------------------------------------------------------------
+// One group of C lanes (one channel each) walks `cnt` consecutive sorted points of plane family `pl`: coordinates `sc[k]` (with the time
+// replaced by `t_fixed` when `fix_t`: the batched-views caller sorts once for all views), dL/dsample rows `gsrow[k * L * C + l * C]`.
 template <int C, int LMAX>
-__global__ void __launch_bounds__(256)
-hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n)
+__device__ __forceinline__ void hexsort_phase2_walk(const gsr_hexplane_field& f, const int pl, const float4* __restrict__ sc,
+                                                    const float* __restrict__ gsrow, const int cnt, const bool fix_t, const float t_fixed)
 {
-    constexpr int GROUPS = 256 / C;
     const int ch = threadIdx.x % C;
-    const int64_t na = ws.header[0] / 6;                          // points that were sorted (non-zero cotangent); the grid covers n
-    const int64_t chunks_per_family = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / C;
-    if (gid >= 6 * chunks_per_family) return;
-    const int pl = (int)(gid / chunks_per_family);
-    const int64_t first = (gid - pl * chunks_per_family) * HEXSORT_CHUNK;
-    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
     const int c0 = hex_c0(pl), c1 = hex_c1(pl);
     const int L = f.num_levels;
-    const float4* sc = ws.scoords + (size_t)pl * na + first;
-    const float* gsrow = ws.gs + ((size_t)pl * na + first) * L * C + ch;
-
     float acc[LMAX][4];
     int cx[LMAX], cy[LMAX];
 #pragma unroll
@@ -313,7 +308,7 @@ hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
         cc_next = sc[kn];
 #pragma unroll
         for (int l = 0; l < LMAX; l++) g_next[l] = l < L ? gsrow[((size_t)kn * L + l) * C] : 0.f;
-        const float c[4] = {cc.x, cc.y, cc.z, cc.w};
+        const float c[4] = {cc.x, cc.y, cc.z, fix_t ? t_fixed : cc.w};
 #pragma unroll
         for (int l = 0; l < LMAX; l++) {
             if (l < L) {
@@ -335,6 +330,286 @@ hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
 #pragma unroll
     for (int l = 0; l < LMAX; l++) {
         if (l < L) flush(l);
+    }
+}
+
+template <int C, int LMAX>
+__global__ void __launch_bounds__(256)
+hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n)
+{
+    constexpr int GROUPS = 256 / C;
+    const int ch = threadIdx.x % C;
+    const int64_t na = ws.header[0] / 6;                          // points that were sorted (non-zero cotangent); the grid covers n
+    const int64_t chunks_per_family = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / C;
+    if (gid >= 6 * chunks_per_family) return;
+    const int pl = (int)(gid / chunks_per_family);
+    const int64_t first = (gid - pl * chunks_per_family) * HEXSORT_CHUNK;
+    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
+    hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * na + first, ws.gs + ((size_t)pl * na + first) * f.num_levels * C + ch, cnt, false, 0.f);
+}
+
+// ---- the views of one mapping iteration: one sort, one spatial scatter (gsr_hexplane_backward_views) ----------------------------------
+// Every keyframe of an iteration evaluates the field at the same positions with its own time. The cells a point falls into therefore do
+// not depend on the view: ONE counting sort serves all of them (the time families are keyed by their spatial coordinate alone -- a view's
+// time selects the same two rows of cells for every point). Phase 1 handles a point for all views at once: the three spatial planes'
+// corners are gathered once per level, dL/dsample of a SPATIAL plane is summed over the views in registers (view order) before it is
+// written to the point's sorted slot -- one spatial scatter per iteration instead of one per view, and an eighth of the atomics --, and only
+// the time planes' dL/dsample is staged per view. Phase 2 is the same run-length walk over 3 + 3 V streams.
+struct HexViewsWs {
+    float* gs_sp;     // [3][n][L][C]     dL/dsample of the xy, xz, yz planes, summed over the views, in the family's sorted order
+    float* gs_t;      // [3][V][n][L][C]  dL/dsample of the xt, yt, zt planes per view, in the order of the x / y / z family
+};
+
+template <int C>
+__global__ void __launch_bounds__(HEX_BLOCK)
+hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n,
+                            const float* __restrict__ xyz, const int64_t xyz_stride, const float* __restrict__ dL_dfeatures,
+                            float* __restrict__ dL_dxyz)
+{
+    const int ch = threadIdx.x % C;
+    const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / C) + threadIdx.x / C;
+    if (i >= n) return;
+    const float zero_time = 0.f;
+    const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, &zero_time);
+    const int L = f.num_levels, V = tv.V;
+    const size_t row = (size_t)L * C;
+    constexpr int SP[3] = {0, 1, 3}, TP[3] = {2, 4, 5};           // plane numbers of the spatial / time families
+    size_t sp_slot[3], t_slot[3];                                 // this lane's element of the point's row in each family's sorted order
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        sp_slot[j] = ((size_t)j * n + ((size_t)ws.rank[(size_t)SP[j] * n + i] - (size_t)SP[j] * n)) * row + ch;
+        t_slot[j] = ((size_t)j * V * n + ((size_t)ws.rank[(size_t)TP[j] * n + i] - (size_t)TP[j] * n)) * row + ch;
+    }
+    const float* gout = dL_dfeatures + (size_t)i * row + ch;
+    float gc[3] = {0.f, 0.f, 0.f};
+    for (int l = 0; l < L; l++) {
+        const gsr_hexplane_level& Lv = f.levels[l];
+        HexAxis ax[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ax[k] = hex_axis(p.c[k], Lv.res[k]);
+        float cs[3][4], ss[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int c0 = hex_c0(SP[j]), c1 = hex_c1(SP[j]);
+            const int W = Lv.res[c0];
+            const HexAxis& X = ax[c0];
+            const HexAxis& Y = ax[c1];
+            const int x1 = X.has1 ? X.i0 + 1 : X.i0, y1 = Y.has1 ? Y.i0 + 1 : Y.i0;
+            const float* plane = Lv.planes[SP[j]];
+            cs[j][0] = plane[((size_t)Y.i0 * W + X.i0) * C + ch];
+            cs[j][1] = plane[((size_t)Y.i0 * W + x1) * C + ch];
+            cs[j][2] = plane[((size_t)y1 * W + X.i0) * C + ch];
+            cs[j][3] = plane[((size_t)y1 * W + x1) * C + ch];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const HexAxis& X = ax[hex_c0(SP[j])];
+            const HexAxis& Y = ax[hex_c1(SP[j])];
+            const float wx1 = X.has1 ? X.w1 : 0.f, wy1 = Y.has1 ? Y.w1 : 0.f;
+            float v = cs[j][0] * (X.w0 * Y.w0);
+            v = fmaf(cs[j][1], wx1 * Y.w0, v);
+            v = fmaf(cs[j][2], X.w0 * wy1, v);
+            ss[j] = fmaf(cs[j][3], wx1 * wy1, v);
+        }
+        float Gs[3] = {0.f, 0.f, 0.f};
+        const int Wt = Lv.res[3];
+        for (int v = 0; v < V; v++) {
+            const HexAxis T = hex_axis(tv.t[v], Wt);
+            const int t1 = T.has1 ? T.i0 + 1 : T.i0;
+            const float wt1 = T.has1 ? T.w1 : 0.f;
+            float ct[3][4], st[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {                         // plane (k, t): width res[k], height res[t]
+                const int W = Lv.res[j];
+                const HexAxis& X = ax[j];
+                const int x1 = X.has1 ? X.i0 + 1 : X.i0;
+                const float* plane = Lv.planes[TP[j]];
+                ct[j][0] = plane[((size_t)T.i0 * W + X.i0) * C + ch];
+                ct[j][1] = plane[((size_t)T.i0 * W + x1) * C + ch];
+                ct[j][2] = plane[((size_t)t1 * W + X.i0) * C + ch];
+                ct[j][3] = plane[((size_t)t1 * W + x1) * C + ch];
+            }
+            const float g = gout[(size_t)v * n * row + (size_t)l * C];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const HexAxis& X = ax[j];
+                const float wx1 = X.has1 ? X.w1 : 0.f;
+                float s_ = ct[j][0] * (X.w0 * T.w0);
+                s_ = fmaf(ct[j][1], wx1 * T.w0, s_);
+                s_ = fmaf(ct[j][2], X.w0 * wt1, s_);
+                st[j] = fmaf(ct[j][3], wx1 * wt1, s_);
+            }
+            // plane order of the product (hexplane.py:93-103): xy, xz, xt, yz, yt, zt
+            const float s[6] = {ss[0], ss[1], st[0], ss[2], st[1], st[2]};
+            float suffix[6];
+            suffix[5] = 1.f;
+#pragma unroll
+            for (int pl = 4; pl >= 0; pl--) suffix[pl] = suffix[pl + 1] * s[pl + 1];
+            float prefix = g, gs[6];
+#pragma unroll
+            for (int pl = 0; pl < 6; pl++) { gs[pl] = prefix * suffix[pl]; prefix *= s[pl]; }
+            Gs[0] += gs[0]; Gs[1] += gs[1]; Gs[2] += gs[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const float gt = gs[TP[j]];
+                __builtin_nontemporal_store(gt, &vw.gs_t[t_slot[j] + (size_t)v * n * row + (size_t)l * C]);
+                if (dL_dxyz) {                                    // the time itself receives no gradient
+                    const HexAxis& X = ax[j];
+                    const float nw = ct[j][0] * gt, ne = X.has1 ? ct[j][1] * gt : 0.f, sw = T.has1 ? ct[j][2] * gt : 0.f;
+                    const float se = X.has1 && T.has1 ? ct[j][3] * gt : 0.f;
+                    gc[j] += ((ne - nw) * T.w0 + (se - sw) * T.w1) * X.dmult;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int c0 = hex_c0(SP[j]), c1 = hex_c1(SP[j]);
+            const HexAxis& X = ax[c0];
+            const HexAxis& Y = ax[c1];
+            const float gsp = Gs[j];
+            __builtin_nontemporal_store(gsp, &vw.gs_sp[sp_slot[j] + (size_t)l * C]);
+            if (dL_dxyz) {
+                const float nw = cs[j][0] * gsp, ne = X.has1 ? cs[j][1] * gsp : 0.f, sw = Y.has1 ? cs[j][2] * gsp : 0.f;
+                const float se = X.has1 && Y.has1 ? cs[j][3] * gsp : 0.f;
+                gc[c0] += ((ne - nw) * Y.w0 + (se - sw) * Y.w1) * X.dmult;
+                gc[c1] += ((sw - nw) * X.w0 + (se - ne) * X.w1) * Y.dmult;
+            }
+        }
+    }
+    if (dL_dxyz) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int d = 1; d < C; d <<= 1) gc[k] += __shfl_xor(gc[k], d, 64);
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dL_dxyz[3 * i + k] = gc[k] * p.dscale[k];
+        }
+    }
+}
+
+// A time family's walk for up to VB views at once. The weights along the family's spatial coordinate are the same for every view, and a
+// view's time is the same for every point: per (view, level) the two sums  sum gs * w0,  sum gs * w1  over a run of points that share the
+// spatial cell are all there is -- the two time rows' weights are applied when the run is flushed (4 atomics). One coordinate load and VB * L
+// independent 128-byte row loads per step and group: the single-view walk (one load per level in flight, 24 of 27 streams at 8 views) ran at
+// the latency of its own loads (4.3 ms for 6.9 GB at config #3).
+template <int C, int LMAX, int VB>
+__device__ __forceinline__ void hexsort_phase2_time_walk(const gsr_hexplane_field& f, const int j, const float4* __restrict__ sc,
+                                                         const float* __restrict__ gsrow, const size_t view_stride, const int nv,
+                                                         const float* __restrict__ times, const int cnt)
+{
+    const int ch = threadIdx.x % C;
+    const int pl = j == 0 ? 2 : 3 + j;                            // planes (x,t) = 2, (y,t) = 4, (z,t) = 5
+    const int L = f.num_levels;
+    float acc[VB][LMAX][2];
+    int cx[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; l++) {
+        cx[l] = -1;
+#pragma unroll
+        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
+    }
+    auto flush = [&](int l) {
+        const gsr_hexplane_level& Lv = f.levels[l];
+        float* gp = Lv.grad_planes[pl];
+        const int W = Lv.res[j], H = Lv.res[3];
+        if (gp && cx[l] >= 0) {
+            const bool x1 = cx[l] + 1 < W;
+#pragma unroll
+            for (int v = 0; v < VB; v++) {
+                if (v < nv) {
+                    const HexAxis T = hex_axis(times[v], H);
+                    float* t = gp + ((size_t)T.i0 * W + cx[l]) * C + ch;
+                    const float a0 = acc[v][l][0], a1 = acc[v][l][1];
+                    if (a0 != 0.f) unsafeAtomicAdd(t, a0 * T.w0);
+                    if (x1 && a1 != 0.f) unsafeAtomicAdd(t + C, a1 * T.w0);
+                    if (T.has1 && a0 != 0.f) unsafeAtomicAdd(t + (size_t)W * C, a0 * T.w1);
+                    if (T.has1 && x1 && a1 != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, a1 * T.w1);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
+    };
+    auto coord = [&](const float4& c) { return j == 0 ? c.x : (j == 1 ? c.y : c.z); };
+    float c_next = coord(sc[0]);
+    float g_next[VB][LMAX];
+#pragma unroll
+    for (int v = 0; v < VB; v++) {
+#pragma unroll
+        for (int l = 0; l < LMAX; l++) g_next[v][l] = (l < L && v < nv) ? gsrow[(size_t)v * view_stride + (size_t)l * C] : 0.f;
+    }
+    for (int k = 0; k < cnt; k++) {
+        const float c = c_next;
+        float g_cur[VB][LMAX];
+#pragma unroll
+        for (int v = 0; v < VB; v++) {
+#pragma unroll
+            for (int l = 0; l < LMAX; l++) g_cur[v][l] = g_next[v][l];
+        }
+        const int kn = min(k + 1, cnt - 1);
+        c_next = coord(sc[kn]);
+#pragma unroll
+        for (int v = 0; v < VB; v++) {
+#pragma unroll
+            for (int l = 0; l < LMAX; l++) g_next[v][l] = (l < L && v < nv) ? gsrow[(size_t)v * view_stride + ((size_t)kn * L + l) * C] : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < LMAX; l++) {
+            if (l < L) {
+                const HexAxis X = hex_axis(c, f.levels[l].res[j]);
+                if (X.i0 != cx[l]) {
+                    flush(l);
+                    cx[l] = X.i0;
+                }
+#pragma unroll
+                for (int v = 0; v < VB; v++) {
+                    acc[v][l][0] = fmaf(g_cur[v][l], X.w0, acc[v][l][0]);
+                    acc[v][l][1] = fmaf(g_cur[v][l], X.w1, acc[v][l][1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; l++) {
+        if (l < L) flush(l);
+    }
+}
+
+// stream s < 3: spatial family (planes 0, 1, 3); stream 3 + 3 b + j: time family j (planes 2, 4, 5) of the views [VB b, VB b + VB)
+constexpr int HEXSORT_VIEW_BATCH = 4;
+template <int C, int LMAX>
+__global__ void __launch_bounds__(256)
+hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n)
+{
+    constexpr int GROUPS = 256 / C, VB = HEXSORT_VIEW_BATCH;
+    const int ch = threadIdx.x % C;
+    const int64_t chunks = (n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    constexpr int GPW = C >= 64 ? 1 : 64 / C;                     // groups per wave: they take the same stream (one code path per wave) ...
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / C;
+    const int batches = (tv.V + VB - 1) / VB;
+    const int streams = 3 + 3 * batches;
+    const int64_t wave_chunks = (chunks + GPW - 1) / GPW;
+    const int64_t w = gid / GPW;
+    if (w >= streams * wave_chunks) return;
+    // ... and consecutive waves different streams of the same chunks: the waves in flight at one moment then spread their atomics over all
+    // planes (and a time family's few rows of cells are not hammered by every wave at once)
+    const int st = (int)(w % streams);
+    const int64_t chunk = (w / streams) * GPW + gid % GPW;
+    if (chunk >= chunks) return;
+    const int64_t first = chunk * HEXSORT_CHUNK;
+    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, n - first);
+    const size_t row = (size_t)f.num_levels * C;
+    if (st < 3) {
+        const int pl = st == 2 ? 3 : st;
+        hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * n + first, vw.gs_sp + ((size_t)st * n + first) * row + ch, cnt, false, 0.f);
+    } else {
+        const int b = (st - 3) / 3, j = (st - 3) % 3;
+        const int pl = j == 0 ? 2 : 3 + j, v0 = b * VB;
+        hexsort_phase2_time_walk<C, LMAX, VB>(f, j, ws.scoords + (size_t)pl * n + first, vw.gs_t + (((size_t)j * tv.V + v0) * n + first) * row + ch,
+                                              (size_t)n * row, min(VB, tv.V - v0), tv.t + v0, cnt);
     }
 }
 

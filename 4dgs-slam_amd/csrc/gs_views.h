@@ -45,7 +45,7 @@ __device__ __forceinline__ ImageState view_image(const ViewSlot& s, const ViewDi
 }
 __device__ __forceinline__ BinningPtrs view_binning(const ViewSlot& s, const ViewDims& d) { return carve_binning(s.binning, s.cap, s.cap, (size_t)d.T); }
 
-template <bool RAW>
+template <bool RAW, bool PRE = false>
 __global__ void __launch_bounds__(GB) preprocess_views_kernel(PreprocessArgs a, ViewTable t, ViewDims d)
 {
     const ViewSlot& s = t.v[blockIdx.y];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(GB) preprocess_views_kernel(PreprocessArgs a, 
     a.radii = s.radii; a.n_touched = s.n_touched;
     a.rec = geom.rec; a.cov3D = geom.cov3D; a.clamped = geom.clamped; a.tiles_touched = geom.tiles_touched; a.block_sums = geom.block_sums;
     a.tile_count = img.tile_count; a.flags = img.tile_count + (size_t)d.T * CTR_STRIDE; a.block_tile_base = img.block_tile_base;
-    preprocess_fwd_body<RAW>(a);
+    preprocess_fwd_body<RAW, PRE>(a);
 }
 
 template <int SEGS, int RMAX>
@@ -148,7 +148,7 @@ __host__ __device__ inline PartLayout part_layout(size_t P, int M, int S)
     return L;
 }
 
-template <bool RAW>
+template <bool RAW, bool PRE = false>
 __global__ void __launch_bounds__(256) geometry_bwd_views_kernel(GeomBwdArgs a, ViewTable t, ViewDims d)
 {
     const ViewSlot& s = t.v[blockIdx.y];
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) geometry_bwd_views_kernel(GeomBwdArgs a, 
         a.dL_dmean3D = s.part + L.xyz; a.rawg.f_dc = s.flow_proj1 ? nullptr : s.part + L.f_dc; a.rawg.f_rest = a.M > 1 ? s.part + L.f_rest : nullptr;
         a.dL_dopacity = s.part + L.opacity; a.dL_dscale = s.part + L.scaling; a.dL_drot = s.part + L.rotation;
     }
-    geometry_bwd_body<RAW>(a);
+    geometry_bwd_body<RAW, PRE>(a);
 }
 
 __global__ void __launch_bounds__(384) tau_sum_views_kernel(ViewTable t, ViewDims d)

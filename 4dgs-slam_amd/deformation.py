@@ -240,6 +240,23 @@ class Deformation(nn.Module):
                 and not (self.no_grid or a.static_mlp or a.no_dx or a.no_ds or a.no_dr or a.apply_rotation) and self.grid_pe == 0
                 and self.grid.feat_dim % 16 == 0 and self.grid.feat_dim <= 128)
 
+    def forward_views(self, points, times):
+        """(dx | ds | dr) [V, n, 10] of forward_dynamic for the SAME points at the V times of one mapping iteration's keyframes
+        (gaussian_renderer/__init__.py:112,149-157 call the network once per keyframe with `time.repeat(n, 1)`): the field through
+        HexPlaneField.forward_views, the MLP once over all V * n rows. None when the shipped structure does not apply (caller: one
+        forward_dynamic per view). The rasterizer adds the deltas to the raw parameters itself (gsr_raw_inputs.delta_mode = 1)."""
+        if not self._fused_mlp_ok(points) or points.shape[0] == 0:
+            return None
+        feat = self.grid.forward_views(points[:, :3], times)
+        if feat is None:
+            return None
+        V, n, F_ = feat.shape
+        heads = (self.pos_deform, self.scales_deform, self.rotations_deform)
+        params = [self.feature_out[0].weight, self.feature_out[0].bias]
+        for h in heads:
+            params += [h[1].weight, h[1].bias, h[3].weight, h[3].bias]
+        return _FusedDeformMLP.apply(feat.view(V * n, F_), *params).view(V, n, 10)
+
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
         if self._fused_mlp_ok(rays_pts_emb):
             feat = self.grid(rays_pts_emb[:, :3], time_emb.to(device=rays_pts_emb.device)[:, :1])
@@ -338,6 +355,10 @@ class deform_network(nn.Module):
 
     def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, times_sel=None):
         return self.deformation_net(point, scales, rotations, opacity, shs, None, times_sel)
+
+    def forward_views(self, point, times):
+        """[V, n, 10] = (dx | ds | dr) of forward_dynamic(point, ..., times_sel = times[v]) for every v, or None (see Deformation.forward_views)."""
+        return self.deformation_net.forward_views(point, times)
 
     def get_mlp_parameters(self):
         return self.deformation_net.get_mlp_parameters() + list(self.timenet.parameters())

@@ -31,7 +31,7 @@ _f, _i, _vp = C.c_float, C.c_int, C.c_void_p
 class _RawInputs(C.Structure):     # gsr_raw_inputs
     _fields_ = [("xyz", _vp), ("log_scales", _vp), ("scale_dim", _i), ("raw_rotations", _vp), ("logit_opacity", _vp),
                 ("features_dc", _vp), ("features_rest", _vp), ("dyn_slot", _vp), ("dx", _vp), ("ds", _vp), ("dr", _vp), ("gather", _vp),
-                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp)]
+                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp), ("delta_mode", _i), ("delta_stride", _i)]
 
 
 class _RawGrads(C.Structure):      # gsr_raw_grads

@@ -252,6 +252,158 @@ class _RasterizeViewsRaw(torch.autograd.Function):
         return tuple(res)
 
 
+class _RasterizeViewsNet(torch.autograd.Function):
+    """The V keyframes of one mapping iteration of render(dynamic=True) (gaussian_renderer/__init__.py:149-157): the same Gaussians, every
+    view moved by its own output of the 4DGaussians deformation network. inputs: xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest,
+    net_out [V, P, 10] = (dx | ds | dr) per view (deformation.deform_network.forward_views), settings (list), then three per view: means2D,
+    theta, rho. outputs: five per view, as _RasterizeViewsRaw. The deltas are added IN FRONT of the activations inside the kernels
+    (gsr_raw_inputs.delta_mode = 1, delta_stride = 10: no [P, 3] / [P, 4] copies of the network's output, and its gradient comes back as
+    one [V, P, 10] tensor that the fused MLP's backward reads as it is)."""
+
+    @staticmethod
+    def forward(ctx, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, net_out, settings, *per_view):
+        _C._require_device(xyz, "_xyz")
+        lib = _lib()
+        dev, V = xyz.device, len(settings)
+        rs0 = settings[0]
+        P, H, W = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width)
+        if net_out.dtype != torch.float32 or tuple(net_out.shape) != (V, P, 10):
+            raise RuntimeError(f"net_out must be float32 [{V}, {P}, 10], got {net_out.dtype} {tuple(net_out.shape)}")
+        _C._require_device(net_out, "net_out")
+        net_out = net_out.contiguous()
+        M = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() else 0)
+        ctx.settings, ctx.V, ctx.M = settings, V, M
+        ctx.set_materialize_grads(False)
+        ctx.acc_params = _acc_params(xyz, f_dc, f_rest, logit_opacity, log_scales, raw_rot)
+        ctx.pose_shapes = [(tuple(per_view[3 * v + 1].shape) if isinstance(per_view[3 * v + 1], torch.Tensor) else None,
+                            tuple(per_view[3 * v + 2].shape) if isinstance(per_view[3 * v + 2], torch.Tensor) else None) for v in range(V)]
+        img = torch.empty((V, _C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        ints = torch.empty((V, 2, P), dtype=torch.int32, device=dev)
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, None, None, None, None, keep)
+        desc.delta_mode, desc.delta_stride = 1, 10
+        views = (_View * V)()
+        base = id(ctx) & 0x3FFFFFFFFFFF
+        holders = []
+        net_ptr = net_out.data_ptr()
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            row0 = net_ptr + 4 * 10 * P * v
+            w.dx, w.ds, w.dr = row0, row0 + 12, row0 + 24
+            w.out_color, w.out_depth = img[v, :_C.NUM_CHANNELS].data_ptr(), img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1].data_ptr()
+            w.out_opacity, w.radii, w.n_touched = img[v, _C.NUM_CHANNELS + 1:].data_ptr(), ints[v, 0].data_ptr(), ints[v, 1].data_ptr()
+            hs = [{"dev": dev, "t": None} for _ in range(3)]
+            holders.append(hs)
+            for k, h in enumerate(hs):
+                _arenas[base + 3 * v + k] = h
+            w.geometry_user, w.binning_user, w.image_user = base + 3 * v, base + 3 * v + 1, base + 3 * v + 2
+        try:
+            with torch.cuda.device(dev):
+                rc = lib.gsr_forward_views(V, views, _alloc_cb, _alloc_cb, _alloc_cb, P, int(rs0.sh_degree), M, _f32(rs0.bg, "bg", keep), W, H,
+                                           C.byref(desc), float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), int(bool(rs0.debug)),
+                                           _C._stream(dev))
+        finally:
+            for v in range(V):
+                for k in range(3):
+                    _arenas.pop(base + 3 * v + k, None)
+        if rc < 0:
+            _C._err(lib, rc, "gsr_forward_views (network deltas)")
+        ctx.num_rendered = [int(views[v].num_rendered) for v in range(V)]
+        state = [holders[v][k]["t"] for v in range(V) for k in range(3)]
+        ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, net_out, ints, *state)
+        outs = []
+        for v in range(V):
+            outs += [img[v, :_C.NUM_CHANNELS], ints[v, 0], img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[v, _C.NUM_CHANNELS + 1:], ints[v, 1]]
+        ctx.mark_non_differentiable(*[outs[5 * v + k] for v in range(V) for k in (1, 4)])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib()
+        V, M, settings = ctx.V, ctx.M, ctx.settings
+        saved = ctx.saved_tensors
+        xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, net_out, ints = saved[:8]
+        state = saved[8:]
+        dev = xyz.device
+        rs0 = settings[0]
+        P, H, W, S = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width), int(log_scales.shape[-1])
+        targets = _targets(ctx.acc_params, M) if ctx.acc_params is not None else None
+        keep = []
+        desc = _describe(xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest, None, None, None, None, keep)
+        desc.delta_mode, desc.delta_stride = 1, 10
+        widths = [3, 3, 3 * (M - 1), 1, S, 4]
+        if targets is not None:
+            own = None
+            gviews = [t_.view(-1) for t_ in targets]
+        else:
+            own = torch.empty((P * sum(widths),), dtype=torch.float32, device=dev)
+            gviews, o = [], 0
+            for w_ in widths:
+                gviews.append(own[o:o + P * w_])
+                o += P * w_
+        out = _RawGrads()
+        out.xyz, out.features_dc, out.features_rest = gviews[0].data_ptr(), gviews[1].data_ptr(), (gviews[2].data_ptr() if M > 1 else None)
+        out.logit_opacity, out.log_scales, out.raw_rotations = gviews[3].data_ptr(), gviews[4].data_ptr(), gviews[5].data_ptr()
+        per_view_out = torch.empty((V, P * 3 + 6), dtype=torch.float32, device=dev)      # screen-space gradient + pose sum per view
+        g_net = torch.empty_like(net_out)             # every row is written: geometry_bwd stores zeros for the Gaussians a view does not see
+        views = (_View * V)()
+        net_ptr, gnet_ptr = net_out.data_ptr(), g_net.data_ptr()
+        for v in range(V):
+            rs, w = settings[v], views[v]
+            g_color, g_depth = grads[5 * v], grads[5 * v + 2]
+            if g_color is None:
+                g_color = _zero_cotangent(3, H, W, dev)
+            if g_depth is None:
+                g_depth = _zero_cotangent(1, H, W, dev)
+            w.viewmatrix, w.projmatrix = _f32(rs.viewmatrix, "viewmatrix", keep), _f32(rs.projmatrix, "projmatrix", keep)
+            w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
+            row0, grow0 = net_ptr + 4 * 10 * P * v, gnet_ptr + 4 * 10 * P * v
+            w.dx, w.ds, w.dr = row0, row0 + 12, row0 + 24
+            w.ddx, w.dds, w.ddr = grow0, grow0 + 12, grow0 + 24
+            w.radii = ints[v, 0].data_ptr()
+            w.geom_buffer, w.binning_buffer, w.image_buffer = state[3 * v].data_ptr(), state[3 * v + 1].data_ptr(), state[3 * v + 2].data_ptr()
+            w.num_rendered = ctx.num_rendered[v]
+            w.dL_dcolor, w.dL_ddepth = _f32(g_color.to(torch.float32), "dL_dcolor", keep), _f32(g_depth.to(torch.float32), "dL_ddepth", keep)
+            w.dL_dmean2D, w.dL_dtau_sum = per_view_out[v, :P * 3].data_ptr(), per_view_out[v, P * 3:].data_ptr()
+        scratch = torch.empty((int(lib.gsr_views_scratch_size(V, P, M, S)),), dtype=torch.uint8, device=dev)
+        flags = int(bool(rs0.debug)) | (2 if targets is not None else 0)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_backward_views(V, views, P, int(rs0.sh_degree), M, _f32(rs0.bg, "bg", keep), W, H, C.byref(desc), float(rs0.scale_modifier),
+                                        float(rs0.tanfovx), float(rs0.tanfovy), C.byref(out), scratch.data_ptr(), flags, _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_backward_views (network deltas)")
+        if own is not None:
+            res = [gviews[0].view(P, 3), gviews[4].view(P, S), gviews[5].view(P, 4), gviews[3].view(logit_opacity.shape), gviews[1].view(P, 1, 3),
+                   gviews[2].view(P, M - 1, 3) if M > 1 else None, g_net, None]
+        else:
+            res = [None, None, None, None, None, None, g_net, None]
+        for v in range(V):
+            th_shape, rho_shape = ctx.pose_shapes[v]
+            tau = per_view_out[v, P * 3:]
+            res += [per_view_out[v, :P * 3].view(P, 3), _pose_grad(tau[3:], th_shape) if th_shape is not None else None,
+                    _pose_grad(tau[:3], rho_shape) if rho_shape is not None else None]
+        return tuple(res)
+
+
+def rasterize_views_net(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, net_out, poses=None):
+    """render(dynamic=True) of V cameras at once: net_out [V, P, 10] is the deformation network's (dx | ds | dr) per camera
+    (deform_network.forward_views); the result per camera is that of raw.rasterize_gaussians_raw on (xyz + dx, log_scales + ds,
+    raw_rotations + dr), see _RasterizeViewsNet."""
+    V = len(settings)
+    if xyz.shape[0] == 0:
+        raise RuntimeError("rasterize_views_net: empty model")
+    if not views_supported(settings):
+        raise RuntimeError("rasterize_views_net: the views must share image size, field of view, background, SH degree and scale modifier")
+    poses = poses or [(None, None)] * V
+    flat = []
+    for v in range(V):
+        flat += [means2D[v], poses[v][0], poses[v][1]]
+    outs = _RasterizeViewsNet.apply(xyz, log_scales, raw_rotations, logit_opacity, features_dc, features_rest, net_out, list(settings), *flat)
+    return [tuple(outs[5 * v: 5 * v + 5]) for v in range(V)]
+
+
 class _RasterizeFlowViewsRaw(torch.autograd.Function):
     """render_flow (raw.rasterize_flow_raw) for several (camera 1, camera 2) pairs of one mapping iteration at once.
     inputs: xyz, log_scales, raw_rot, logit_opacity, dyn_slot, settings (list, camera 1 of every pair), then seven per view:

@@ -234,8 +234,36 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     }
 
 
-def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, deltas=None):
+def _render_views_dynamic(cams, pc, pipe, bg_color, scaling_modifier):
+    """render(dynamic=True) of the cameras of one mapping iteration at once, or None when the batched route does not apply: the 4DGaussians
+    deformation network is evaluated ONCE for all cameras' times (deform_network.forward_views: the position-only planes of the HexPlane
+    field gathered once per Gaussian, one sort and one spatial scatter on the way back, the MLP over all V * P rows), and its [V, P, 10]
+    output goes to the multi-view rasterizer entry point as per-view deltas in front of the activations (views.rasterize_views_net)."""
+    if (_views is None or os.environ.get("GSR_MULTI_VIEW", "1") == "0" or os.environ.get("GSR_DYNAMIC_VIEWS", "1") == "0" or len(cams) < 2
+            or len(cams) > _views.MAX_VIEWS or not _fused_prologue_ok(pc, pipe, None, True)):
+        return None
+    net = getattr(pc, "_deformation", None)
+    if net is None or not hasattr(net, "forward_views"):
+        return None
+    settings = [_settings(c, bg_color, scaling_modifier, pc.active_sh_degree) for c in cams]
+    if not _views.views_supported(settings):
+        return None
+    net_out = net.forward_views(pc.get_xyz, [float(c.time) for c in cams])
+    if net_out is None:
+        return None
+    block = torch.zeros((len(cams),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
+    points = [block[v].requires_grad_(True) for v in range(len(cams))]
+    f_rest = pc._features_rest if pc._features_rest.shape[1] > 0 else None
+    outs = _views.rasterize_views_net(settings, pc._xyz, points, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, f_rest, net_out,
+                                      poses=[(c.cam_rot_delta, c.cam_trans_delta) for c in cams])
+    return [_RenderPackage({"render": o[0], "viewspace_points": pts, "radii": o[1], "depth": o[2], "opacity": o[3], "n_touched": o[4]})
+            for o, pts in zip(outs, points)]
+
+
+def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, deltas=None, dynamic=False):
     """render() of several cameras of one mapping iteration at once: a list of render()'s dicts, one per camera.
+    ``dynamic``: render(dynamic=True) -- every camera's Gaussians moved by the deformation network at the camera's time (not combined with
+    ``deltas``, like the fused single-camera route); batched through _render_views_dynamic when that applies, else one render() per camera.
 
     The mapping back-end renders the same Gaussians from every window keyframe and two random ones before each optimizer step
     (utils/slam_backend.py:357,526,657); with the fused prologue available those views go through the multi-view entry point
@@ -243,6 +271,12 @@ def render_views(viewpoint_cameras, pc, pipe, bg_color: torch.Tensor, scaling_mo
     a single camera, more than views.MAX_VIEWS, cameras of different size -- one render() call per camera. ``deltas``: per camera
     None or the (dx, ds, dr) tensors of the dynamic subset; values and gradients are those of the per-camera calls."""
     cams = list(viewpoint_cameras)
+    if dynamic:
+        if deltas is not None and any(d is not None for d in deltas):
+            return [render(c, pc, pipe, bg_color, scaling_modifier, dynamic=True, dx=d[0] if d else None, ds=d[1] if d else None, dr=d[2] if d else None)
+                    for c, d in zip(cams, deltas)]
+        batched = _render_views_dynamic(cams, pc, pipe, bg_color, scaling_modifier) if pc.get_xyz.shape[0] else None
+        return batched if batched is not None else [render(c, pc, pipe, bg_color, scaling_modifier, dynamic=True) for c in cams]
     deltas = list(deltas) if deltas is not None else [None] * len(cams)
     per_camera = lambda: [render(c, pc, pipe, bg_color, scaling_modifier, dx=d[0] if d else None, ds=d[1] if d else None, dr=d[2] if d else None)
                           for c, d in zip(cams, deltas)]

@@ -45,6 +45,13 @@ def _lib():
         lib.gsr_hexplane_backward.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, vp, i64, vp, vp, vp, vp]
         lib.gsr_hexplane_backward_workspace_size.restype = ctypes.c_size_t
         lib.gsr_hexplane_backward_workspace_size.argtypes = [ctypes.POINTER(_Field), i64]
+        f32p = ctypes.POINTER(ctypes.c_float)
+        lib.gsr_hexplane_forward_views.restype = ctypes.c_int
+        lib.gsr_hexplane_forward_views.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, ctypes.c_int, f32p, vp, vp]
+        lib.gsr_hexplane_backward_views_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_hexplane_backward_views_workspace_size.argtypes = [ctypes.POINTER(_Field), i64, ctypes.c_int]
+        lib.gsr_hexplane_backward_views.restype = ctypes.c_int
+        lib.gsr_hexplane_backward_views.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, ctypes.c_int, f32p, vp, vp, vp, vp]
         _lib_cache = lib
     return _lib_cache
 
@@ -213,6 +220,93 @@ class _HexPlaneFeatures(torch.autograd.Function):
         return (gxyz, None, None, None, *views)
 
 
+MAX_VIEWS = 12          # GSR_HEXPLANE_MAX_VIEWS
+
+
+class _HexPlaneFeaturesViews(torch.autograd.Function):
+    """features [V, n, L*C] of the SAME points xyz [n, >=3] at V times (Python floats): the field of every keyframe of one mapping
+    iteration (gaussian_renderer/__init__.py:112,149-157) in one launch per direction -- the spatial planes gathered once per point, one
+    counting sort and one spatial scatter for all views (include/deformation_field.h gsr_hexplane_*_views). View v is bit-identical to
+    _HexPlaneFeatures at time times[v]; the gradients are those of V single calls up to summation order."""
+
+    @staticmethod
+    def forward(ctx, xyz, times, aabb, n_levels, *planes):
+        _C._require_device(xyz, "pts")
+        if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] < 3:
+            raise ValueError(f"HexPlane expects fp32 pts [n, 3], got {xyz.dtype} {tuple(xyz.shape)}")
+        if xyz.stride(1) != 1:
+            xyz = xyz.contiguous()
+        V = len(times)
+        if not 1 <= V <= MAX_VIEWS:
+            raise ValueError(f"1..{MAX_VIEWS} times expected, got {V}")
+        levels = [[p.detach() for p in planes[6 * l:6 * l + 6]] for l in range(n_levels)]
+        n, C = xyz.shape[0], levels[0][0].shape[1]
+        out = torch.empty((V, n, n_levels * C), dtype=torch.float32, device=xyz.device)
+        field = _describe(levels, aabb)
+        tv = (ctypes.c_float * V)(*[float(t) for t in times])
+        lib = _lib()
+        with torch.cuda.device(xyz.device):
+            rc = lib.gsr_hexplane_forward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, tv, out.data_ptr(), _C._stream(xyz.device))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_hexplane_forward_views")
+        ctx.save_for_backward(xyz, aabb if aabb is not None else torch.empty(0), *planes)
+        ctx.n_levels, ctx.has_aabb, ctx.times = n_levels, aabb is not None, tv
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xyz, aabb, *planes = ctx.saved_tensors
+        n_levels, V, n = ctx.n_levels, len(ctx.times), xyz.shape[0]
+        aabb = aabb if ctx.has_aabb else None
+        levels = [[p.detach() for p in planes[6 * l:6 * l + 6]] for l in range(n_levels)]
+        need_plane = list(ctx.needs_input_grad[4:])
+        sizes = [p.numel() if need else 0 for p, need in zip(planes, need_plane)]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=g.device)          # one fill for every plane gradient
+        views, o = [], 0
+        for p, need, sz in zip(planes, need_plane, sizes):
+            views.append(torch.as_strided(flat, p.shape, p.stride(), o) if need else None)
+            o += sz
+        grads = [views[6 * l:6 * l + 6] for l in range(n_levels)]
+        g = g.contiguous()
+        gxyz = torch.empty((n, 3), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        field = _describe(levels, aabb, grads)
+        lib = _lib()
+        size = lib.gsr_hexplane_backward_views_workspace_size(ctypes.byref(field), n, V) if n else 0
+        if n and size == 0:
+            raise RuntimeError("hexplane_features_views: this plane geometry is not covered by the batched backward (channels-last planes, "
+                               "resolutions <= 1024); evaluate the views one by one with hexplane_features")
+        if n:
+            ws = torch.empty(size, dtype=torch.uint8, device=g.device)
+            with torch.cuda.device(g.device):
+                rc = lib.gsr_hexplane_backward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, ctx.times, g.data_ptr(),
+                                                     gxyz.data_ptr() if gxyz is not None else None, ws.data_ptr(), _C._stream(g.device))
+            if rc < 0:
+                _C._err(lib, rc, "gsr_hexplane_backward_views")
+        if gxyz is not None and xyz.shape[1] > 3:
+            full = torch.zeros_like(xyz)
+            full[:, :3] = gxyz
+            gxyz = full
+        return (gxyz, None, None, None, *views)
+
+
+def views_supported(ms_grids, n_views) -> bool:
+    """Whether hexplane_features_views covers this field: channels-last planes of at most 1024 texels a side, 1..MAX_VIEWS views."""
+    flat = ms_grids.flat if isinstance(ms_grids, _PlaneList) else [p for lv in ms_grids for p in lv]
+    try:
+        return (1 <= n_views <= MAX_VIEWS and all(p.is_cuda and p.dtype == torch.float32 and _plane_layout(p) == 1 and max(p.shape[2:]) <= 1024 for p in flat)
+                and flat[0].shape[1] in (8, 16, 32, 64))
+    except ValueError:
+        return False
+
+
+def hexplane_features_views(pts, times, aabb, ms_grids) -> torch.Tensor:
+    """[V, n, L*C]: hexplane_features(pts, full((n, 1), times[v]), aabb, ms_grids) for every v, batched (see _HexPlaneFeaturesViews)."""
+    if isinstance(ms_grids, _PlaneList):
+        return _HexPlaneFeaturesViews.apply(pts, tuple(times), aabb, ms_grids.n_levels, *ms_grids.flat)
+    levels = [list(g) for g in ms_grids]
+    return _HexPlaneFeaturesViews.apply(pts, tuple(times), aabb, len(levels), *[p for lv in levels for p in lv])
+
+
 def hexplane_features(pts, timestamps, aabb, ms_grids) -> torch.Tensor:
     """Fused normalize_aabb + interpolate_ms_features(concat_features=True).  aabb None: pts are already normalised."""
     if isinstance(ms_grids, _PlaneList):                              # prepared by HexPlaneField: no nn.ParameterList walk per call
@@ -309,3 +403,12 @@ class HexPlaneField(nn.Module):
 
     def forward(self, pts: torch.Tensor, timestamps: Optional[torch.Tensor] = None):
         return self.get_density(pts, timestamps)
+
+    def forward_views(self, pts: torch.Tensor, times):
+        """[V, n, feat_dim]: forward(pts, time = times[v]) for the V keyframes of one mapping iteration in one launch; None when the
+        batched kernels do not cover this field (the caller then evaluates view by view)."""
+        planes = _PlaneList(self.grids)
+        pts = pts.reshape(-1, pts.shape[-1])
+        if not views_supported(planes, len(times)) or pts.shape[0] == 0 or not pts.is_cuda:
+            return None
+        return hexplane_features_views(pts, times, self.aabb, planes)

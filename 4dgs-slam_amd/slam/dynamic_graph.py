@@ -47,6 +47,7 @@ from .mapping_graph import N_INDEX_WORDS
 # list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
 CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
 FLOW_CLIPS = os.environ.get("GSR_FLOW_CLIPS", "1") != "0"      # render the flow images only where the flow loss reads them (gsr_set_flow_clips)
+FLOW_TARGET_BUDGET_FRACTION = 0.03  # ... and at most this share of the device memory free when the first target is formed
 FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (~7 MB each at 640x480); dropped ones are formed again on demand
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
@@ -144,9 +145,17 @@ class DynamicMapping:
             m2 = (~other.motion_mask).to(torch.float32)[None]
             back = ds.gt_flow(v.uid, other.uid)[0].permute(2, 0, 1) * m1
             fwd = ds.gt_flow(other.uid, v.uid)[0].permute(2, 0, 1) * m2
-            while len(cache) >= FLOW_TARGET_CACHE_MAX:          # oldest first; the tables of a running call hold what they point at
+            hit = torch.cat([back, m1, m2, fwd], 0).to(self.device, torch.float32).contiguous()
+            # bounded by bytes (a share of the memory free at the first use) as well as by count; oldest first; the tables of a running call
+            # hold what they point at
+            budget = self.be.__dict__.get("_flow_targets6_budget")
+            if budget is None:
+                from .mapping_graph import device_store_budget
+                budget = self.be.__dict__["_flow_targets6_budget"] = device_store_budget(self.device, FLOW_TARGET_BUDGET_FRACTION)
+            each = hit.numel() * hit.element_size()
+            while cache and (len(cache) >= FLOW_TARGET_CACHE_MAX or (len(cache) + 1) * each > budget):
                 cache.pop(next(iter(cache)))
-            hit = cache[(v.uid, other.uid)] = torch.cat([back, m1, m2, fwd], 0).to(self.device, torch.float32).contiguous()
+            cache[(v.uid, other.uid)] = hit
         return hit
 
     def flow_clip(self, v):

@@ -123,14 +123,23 @@ def backprojected_points(depth, R, T, fx, fy, cx, cy):
     return pts[keep]
 
 
+OVERLAP_GROUP = 16      # candidate keyframes per batched projection of overlap_fractions
+
+
 def overlap_fractions(points, Rs, Ts, fx, fy, cx, cy, width, height, edge=20):
     """For K candidate keyframes with poses Rs [K,3,3], Ts [K,3]: the fraction of `points` [N,3] that project inside the image minus an
-    `edge`-pixel border, in front of the camera (:339-355) -- ONE batched projection, a [K] float32 device tensor."""
-    pc = torch.einsum("kij,nj->kni", Rs, points) + Ts[:, None, :]                 # [K, N, 3] camera-frame points
-    z = pc[..., 2] + 1e-5
-    px, py = (fx * pc[..., 0] + cx * pc[..., 2]) / z, (fy * pc[..., 1] + cy * pc[..., 2]) / z
-    inside = (px < width - edge) & (px > edge) & (py < height - edge) & (py > edge) & (z > 0)
-    return inside.sum(dim=1) / points.shape[0]
+    `edge`-pixel border, in front of the camera (:339-355) -- a [K] float32 device tensor. The candidates are projected in groups of
+    `OVERLAP_GROUP` (the [k, N, 3] camera-frame points and their [k, N] temporaries are the peak: ~40 bytes per point and candidate, i.e.
+    0.2 GB per group at 307 200 points; the reference loops per keyframe -- O(N) -- and a run of a few hundred keyframes must not need
+    gigabytes here), the group results concatenated on the device: still one host transfer for the caller."""
+    fractions = []
+    for lo in range(0, Rs.shape[0], OVERLAP_GROUP):
+        pc = torch.einsum("kij,nj->kni", Rs[lo:lo + OVERLAP_GROUP], points) + Ts[lo:lo + OVERLAP_GROUP, None, :]   # [k, N, 3]
+        z = pc[..., 2] + 1e-5
+        px, py = (fx * pc[..., 0] + cx * pc[..., 2]) / z, (fy * pc[..., 1] + cy * pc[..., 2]) / z
+        inside = (px < width - edge) & (px > edge) & (py < height - edge) & (py > edge) & (z > 0)
+        fractions.append(inside.sum(dim=1) / points.shape[0])
+    return fractions[0] if len(fractions) == 1 else torch.cat(fractions)
 
 
 def keyframe_selection_overlap(newest, viewpoints, time, intrinsics, pose_window=3, permutation=None):

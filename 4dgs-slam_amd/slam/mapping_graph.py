@@ -34,35 +34,76 @@ CAPTURE_MARGIN_PERMILLE = 500
 CAPTURE_TILE_MARGIN_PERMILLE = 3000     # the longest tile list may grow 4x during the replays (see include/gs_rasterizer.h)
 
 
+def device_store_budget(device, fraction, floor_bytes=256 << 20):
+    """Bytes a per-keyframe store may hold on `device`: `fraction` of the memory that is free right now (never less than floor_bytes)."""
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return floor_bytes
+    return max(int(free * fraction), floor_bytes)
+
+
 class KeyframeOperands:
     """Per keyframe: the constant operands of its mapping loss (ground truth, weights), held so that their device addresses stay valid for
-    the graphs that point at them (slam_losses keeps only a bounded cache)."""
+    the graphs that point at them (slam_losses keeps only a bounded cache).
 
-    MAX_ENTRIES = 1024          # ~7 MB each at 640x480: what is dropped is formed again on demand
+    One entry per keyframe: the ground-truth image and depth ONCE, the loss weights per (rm_dynamic, dynamic) flag variant (a weight pair is
+    2.4 MB at 640x480, the ground truth 4.9 MB -- three variants used to hold three copies of it once slam_losses' constants cache had
+    evicted the keyframe). The store is bounded by BYTES -- BUDGET_FRACTION of the device memory free at its first use, least recently used
+    keyframe first -- and follows Camera.clean() through slam_losses.drop_keyframe_constants. What is dropped is formed again on demand; a
+    graph that still points at an entry's buffers holds the tensors itself."""
+
+    BUDGET_FRACTION = 0.05
 
     def __init__(self):
-        self._held = {}
+        self._held = {}                 # id(viewpoint) -> [viewpoint, gt_image, gt_depth, {(rm_dynamic, dynamic): (w_rgb, w_depth, alpha)}, bytes]
+        self._bytes, self._budget = 0, None
+        slam_losses.on_drop_keyframe_constants(self.drop)
+
+    @staticmethod
+    def _nbytes(*tensors):
+        return sum(t.numel() * t.element_size() for t in tensors if isinstance(t, torch.Tensor))
 
     def get(self, config, viewpoint, device, rm_dynamic=True, dynamic=False):
         """(gt_image, gt_depth, w_rgb, w_depth, alpha) of slam_losses.mapping_loss_operands, computed once per (keyframe, flags) and held:
         a keyframe's ground truth and masks never change. The eager loop's get_loss_mapping forms the same values."""
-        key = (id(viewpoint), bool(rm_dynamic), bool(dynamic))
-        hit = self._held.get(key)
-        if hit is not None and hit[0] is viewpoint:
-            self._held[key] = self._held.pop(key)           # (most recently used last)
-            return hit[1]
-        ops = slam_losses.mapping_loss_operands(config, viewpoint, device, rm_dynamic=rm_dynamic, dynamic=dynamic)
-        while len(self._held) >= self.MAX_ENTRIES:          # oldest first; a graph that still points at an entry's buffers holds them itself
-            self._held.pop(next(iter(self._held)))
-        self._held[key] = (viewpoint, ops)
-        return ops
+        flags = (bool(rm_dynamic), bool(dynamic))
+        ent = self._held.get(id(viewpoint))
+        if ent is not None and ent[0] is not viewpoint:     # the id was recycled by another object
+            self.drop(ent[0])
+            ent = None
+        if ent is not None and flags in ent[3]:
+            self._held[id(viewpoint)] = self._held.pop(id(viewpoint))           # (most recently used last)
+            w = ent[3][flags]
+            return ent[1], ent[2], w[0], w[1], w[2]
+        gt_image, gt_depth, w_rgb, w_dep, alpha = slam_losses.mapping_loss_operands(config, viewpoint, device, rm_dynamic=rm_dynamic, dynamic=dynamic)
+        if ent is None:
+            ent = self._held[id(viewpoint)] = [viewpoint, gt_image, gt_depth, {}, self._nbytes(gt_image, gt_depth)]
+            self._bytes += ent[4]
+        else:
+            self._held[id(viewpoint)] = self._held.pop(id(viewpoint))
+        ent[3][flags] = (w_rgb, w_dep, alpha)
+        extra = self._nbytes(w_rgb, w_dep)
+        ent[4] += extra
+        self._bytes += extra
+        if self._budget is None:
+            self._budget = device_store_budget(device, self.BUDGET_FRACTION)
+        while self._bytes > self._budget and len(self._held) > 1:          # least recently used first, never the entry just returned
+            oldest = next(iter(self._held))
+            self._bytes -= self._held.pop(oldest)[4]
+        return ent[1], ent[2], w_rgb, w_dep, alpha
 
     def drop(self, viewpoint=None):
         if viewpoint is None:
             self._held.clear()
+            self._bytes = 0
         else:
-            for key in [k for k in self._held if k[0] == id(viewpoint)]:
-                del self._held[key]
+            ent = self._held.pop(id(viewpoint), None)
+            if ent is not None:
+                self._bytes -= ent[4]
+
+    def held_bytes(self):
+        return self._bytes
 
 
 class MappingGraph:

@@ -235,12 +235,27 @@ def _keyframe_constants(config, viewpoint, device):
     return data
 
 
+_DROP_LISTENERS = []          # weak references to callables(viewpoint | None): other per-keyframe stores that follow Camera.clean()
+
+
+def on_drop_keyframe_constants(method):
+    """Register a bound method to be called by drop_keyframe_constants with the same argument (held weakly: a store that dies unregisters)."""
+    _DROP_LISTENERS.append(weakref.WeakMethod(method))
+
+
 def drop_keyframe_constants(viewpoint=None):
-    """Forget the cached constants of one viewpoint (or of all): call it where the reference calls Camera.clean()."""
+    """Forget the cached constants of one viewpoint (or of all): call it where the reference calls Camera.clean(). Stores registered through
+    on_drop_keyframe_constants (the graphs' per-keyframe operands, slam/mapping_graph.py) drop their entries of that viewpoint too."""
     if viewpoint is None:
         _CONST_CACHE.clear()
     else:
         _CONST_CACHE.pop(id(viewpoint), None)
+    for ref in list(_DROP_LISTENERS):
+        fn = ref()
+        if fn is None:
+            _DROP_LISTENERS.remove(ref)
+        else:
+            fn(viewpoint)
 
 
 def mapping_loss_weights(config, viewpoint, gt_image, gt_depth, rm_dynamic=False, mask=None, dynamic=False, base=None):

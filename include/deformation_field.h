@@ -69,6 +69,24 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
  * many points share texels.  workspace NULL = one float atomic per (point, corner), no extra memory. */
 size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int64_t n);
 
+/* ---- the views of one mapping iteration at once ---------------------------------------------------------------------------------
+ * The mapping back-end calls the field once per keyframe of an iteration with the SAME positions and one time per keyframe
+ * (gaussian_renderer/__init__.py:112,149-157; utils/slam_backend.py:357,526,657). Per level the field is the product of three planes that
+ * depend on the position only (xy, xz, yz) and three that depend on one coordinate and the time (hexplane.py:93-103). These calls take V <=
+ * GSR_HEXPLANE_MAX_VIEWS times (HOST pointer, copied into the kernel arguments) and
+ *   forward:  gather the spatial planes once per point, the time planes per view; features [V][n][L*C], view v bit-identical to
+ *             gsr_hexplane_forward(xyz, time = times[v]);
+ *   backward: dL_dfeatures [V][n][L*C]; ONE counting sort of the points for all views, dL/dsample of the spatial planes summed over the
+ *             views in registers before the (single) spatial scatter, the time planes' per view; accumulates into grad_planes like V
+ *             gsr_hexplane_backward calls, WRITES dL_dxyz [n,3] = the sum over the views. Needs channels-last planes, resolutions
+ *             <= 1024 and a workspace of gsr_hexplane_backward_views_workspace_size() bytes (0 = unsupported geometry: call view by view). */
+#define GSR_HEXPLANE_MAX_VIEWS 12
+int gsr_hexplane_forward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
+                               float* features, void* stream);
+size_t gsr_hexplane_backward_views_workspace_size(const gsr_hexplane_field* field, int64_t n, int V);
+int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
+                                const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream);
+
 /* ---- weight gradient of the deformation MLP's dense layers ----------------------------------------------------------------
  * utils/deformation.py:58-70 builds the network from nn.Linear layers (width 64, inputs <= 128) applied to every point; their
  * weight gradients are GEMMs with a tiny output and a reduction over all n points, the shape vendor GEMMs handle worst.

@@ -141,6 +141,15 @@ typedef struct gsr_raw_inputs {
     const float* flow_dx2;       /* [K,3] second displacement (d_xyz2), or NULL = zero */
     const float* flow_proj1;     /* [4,4] full_proj_transform of camera 1 (row-vector convention, like projmatrix) */
     const float* flow_proj2;     /* [4,4] of camera 2 */
+    /* Deformation-network deltas (render(dynamic=True), gaussian_renderer/__init__.py:149-157: the 4DGaussians deform_network returns
+     * means3D + dx, _scaling + ds, _rotation + dr and render() applies the activations to THOSE): delta_mode = 1 adds dx / ds / dr in
+     * front of the activations -- scales = exp(_scaling + ds), rotations = normalize(_rotation + dr) -- instead of behind them
+     * (delta_mode = 0, the control-node deltas of :159-174). With delta_mode = 1 dyn_slot may be NULL: Gaussian i then takes row i.
+     * The gradients of dx / ds / dr follow the same convention. Not combined with the flow mode.
+     * delta_stride: floats between consecutive rows of dx, of ds and of dr, and of their gradients (0 = compact: 3, 3, 4) -- with
+     * delta_stride = 10 the three are the column ranges [0,3), [3,6), [6,10) of the network's [K, 10] output (include/deformation_field.h). */
+    int delta_mode;
+    int delta_stride;
 } gsr_raw_inputs;
 
 typedef struct gsr_raw_grads {   /* all fully written (with `gather`: only the selected rows -- zero-fill them first); dx / ds / dr may be

@@ -423,3 +423,141 @@ def test_points_without_gradient_are_skipped_correctly(monkeypatch):
     assert set(gp0) == set(gp1)
     for k in gp0:
         assert rel(gp1[k], gp0[k]) < 2e-4, (k, rel(gp1[k], gp0[k]))
+
+
+# ---- the views of one mapping iteration at once (gsr_hexplane_*_views, deform_network.forward_views, render_views(dynamic=True)) --------
+def _shipped_field(bounds=1.6, multires=(1, 2, 4, 8), seed=0):
+    torch.manual_seed(seed)
+    field = hexplane.HexPlaneField(bounds, {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [64, 64, 64, 25]},
+                                   list(multires)).to(DEV)
+    with torch.no_grad():
+        for lv in field.grids:
+            for p in lv:
+                p.copy_(torch.empty_like(p).uniform_(0.2, 1.2))        # the time planes start at exactly 1: give them structure
+    return field
+
+
+@pytest.mark.parametrize("n,V", [(1, 1), (3000, 8), (70000, 12), (60000, 2)])
+def test_batched_time_field_equals_per_view_field(n, V, monkeypatch):
+    """HexPlaneField.forward_views (spatial planes gathered once, one sort + one spatial scatter for all views) against V calls of the
+    single-view field at the same points: values BIT-identical (the product keeps the reference's plane order), plane and position
+    gradients <= 1e-5 rel-L1 (sums regroup). Points outside the aabb, times outside [-1, 1], whole zero cotangent rows (Gaussians a view
+    does not see) included."""
+    field = _shipped_field()
+    g = torch.Generator(device="cpu").manual_seed(n + V)
+    pts = (torch.rand((n, 3), generator=g) * 4.0 - 2.0).to(DEV).requires_grad_(True)
+    times = [float(t) for t in np.linspace(-1.2, 1.2, V)] if V > 1 else [0.3]
+    cot = torch.randn((V, n, field.feat_dim), generator=g).to(DEV)
+    cot[:, torch.rand(n, generator=g).to(DEV) < 0.2] = 0.0                 # points no view sees
+    if V > 1:
+        cot[1, torch.rand(n, generator=g).to(DEV) < 0.5] = 0.0             # ... and points one view does not see
+    batched = field.forward_views(pts, times)
+    assert batched is not None and batched.shape == (V, n, field.feat_dim)
+    (batched * cot).sum().backward()
+    gb = {"pts": pts.grad.clone(), **{k: p.grad.clone() for k, p in field.named_parameters() if p.grad is not None}}
+    pts.grad = None
+    for p in field.parameters():
+        p.grad = None
+    loss = 0.0
+    for v, t in enumerate(times):
+        f_v = field(pts, torch.full((n, 1), t, device=DEV))
+        assert torch.equal(f_v, batched[v]), v
+        loss = loss + (f_v * cot[v]).sum()
+    loss.backward()
+    gs = {"pts": pts.grad, **{k: p.grad for k, p in field.named_parameters() if p.grad is not None}}
+    assert set(gb) == set(gs) and len(gs) == 1 + 24
+    for k in gs:
+        assert gb[k].shape == gs[k].shape and gb[k].stride() == gs[k].stride(), k
+        assert rel(gb[k], gs[k]) < 1e-5, (k, rel(gb[k], gs[k]))
+    assert torch.equal(gb["pts"] == 0, gs["pts"] == 0)                    # exact zeros where the clamp / the border stop the gradient
+
+
+def test_batched_time_field_reproduces_reference_golden():
+    """golden_deformation.npz (the reference's own HexPlaneField) through the batched entry point, as a one-view and a two-view call."""
+    levels = golden_field("channels_last")
+    pts = torch.tensor(G["field/pts"], device=DEV, requires_grad=True)
+    time = torch.tensor(G["field/time"], device=DEV)
+    if float(time.min()) != float(time.max()):
+        pytest.skip("the golden call uses per-point times")
+    t = float(time[0])
+    feat = hexplane.hexplane_features_views(pts, [t, t], torch.tensor(G["field/aabb"], device=DEV), levels)
+    assert rel(feat[0], G["field/features"]) < 1e-6 and torch.equal(feat[0], feat[1])
+    (feat[0] * torch.tensor(G["field/cotangent"], device=DEV)).sum().backward()
+    assert rel(pts.grad, G["field/g_pts"]) < 1e-5
+    for l in range(2):
+        for p in range(6):
+            assert rel(levels[l][p].grad, G[f"field/g_plane_{l}_{p}"]) < 1e-5, (l, p)
+
+
+def test_batched_field_rejects_what_it_does_not_cover():
+    field = _shipped_field(multires=(1,))
+    pts = torch.rand((10, 3), device=DEV)
+    with pytest.raises(ValueError):
+        hexplane.hexplane_features_views(pts, [0.0] * 13, field.aabb, hexplane._PlaneList(field.grids))
+    planar = [[p.detach().contiguous() for p in lv] for lv in field.grids]
+    assert not hexplane.views_supported(planar, 2) and hexplane.views_supported(hexplane._PlaneList(field.grids), 2)
+    out = hexplane.hexplane_features_views(pts, [0.1, 0.2], field.aabb, planar)      # the forward handles the reference's layout too
+    for v, t in enumerate((0.1, 0.2)):
+        assert torch.equal(out[v], hexplane.hexplane_features(pts, torch.full((10, 1), t, device=DEV), field.aabb, planar))
+
+
+@pytest.mark.parametrize("iso", [False, True])
+def test_render_views_dynamic_equals_per_camera_render_dynamic(iso):
+    """render_views(dynamic=True): ONE evaluation of the deformation network for all cameras' times + the multi-view rasterizer with the
+    network's output as deltas in front of the activations (gsr_raw_inputs.delta_mode = 1, delta_stride = 10) against one
+    render(dynamic=True) per camera. Run twice: the first call of a view slot goes through the single-view kernels inside gsr_forward_views,
+    the second through the batched ones."""
+    import types
+    import gaussian_renderer
+    from synthetic_scene import keyframe_pose
+    from util import make_camera, make_gaussians
+    from test_hip_fused_prologue import _GaussianModel, _camera
+    W, H, V, P = 160, 120, 4, 3000
+    pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([1.0, 1.0, 1.0], device=DEV)
+    torch.manual_seed(0)
+    net = deformation.deform_network(hidden_params(multires=[1, 2], bounds=8.0), DEV).to(DEV)
+    with torch.no_grad():
+        for p_ in net.get_grid_parameters():
+            p_.copy_(torch.empty_like(p_).uniform_(0.05, 0.3))
+    cam0 = make_camera(W, H)
+
+    def scene():
+        pc = _GaussianModel(make_gaussians(P, cam0, seed=2), isotropic=iso, dyn_frac=0.0, seed=3)
+        pc._deformation = net
+        views = []
+        for k in range(V):
+            R_w, t_w = keyframe_pose(k)
+            v = _camera(make_camera(W, H, R=R_w, t=t_w))
+            v.time = k / (V - 1) * 1.6 - 0.8
+            views.append(v)
+        return pc, views
+
+    def grads_of(pc, views, outs):
+        for p in net.parameters():
+            p.grad = None
+        loss = sum((o["render"] * (1.0 + 0.1 * k)).mean() + 0.1 * o["depth"].mean() for k, o in enumerate(outs))
+        loss.backward()
+        g = {"xyz": pc._xyz.grad, "scaling": pc._scaling.grad, "rotation": pc._rotation.grad, "opacity": pc._opacity.grad, "f_dc": pc._features_dc.grad}
+        for k, v in enumerate(views):
+            g[f"theta{k}"], g[f"rho{k}"], g[f"m2d{k}"] = v.cam_rot_delta.grad, v.cam_trans_delta.grad, outs[k]["viewspace_points"].grad
+        g.update({"net." + k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None})
+        return g
+
+    pc, views = scene()
+    ref_outs = [gaussian_renderer.render(v, pc, pipe, bg, dynamic=True) for v in views]
+    ref = grads_of(pc, views, ref_outs)
+    for attempt in range(2):
+        pc, views = scene()
+        outs = gaussian_renderer.render_views(views, pc, pipe, bg, dynamic=True)
+        assert isinstance(outs[0], gaussian_renderer._RenderPackage)             # the batched route was taken
+        for o, r in zip(outs, ref_outs):
+            assert torch.equal(o["radii"], r["radii"]) and torch.equal(o["n_touched"], r["n_touched"])
+            assert rel(o["render"], r["render"]) < 1e-6 and rel(o["depth"], r["depth"]) < 1e-6 and rel(o["opacity"], r["opacity"]) < 1e-6
+        got = grads_of(pc, views, outs)
+        assert set(got) == set(ref)
+        for k in ref:
+            if float(ref[k].abs().max()) < 1e-12:
+                assert float(got[k].abs().max()) < 1e-9, k
+            else:
+                assert rel(got[k], ref[k]) < (1e-4 if k.startswith("net.") else 2e-5), (attempt, k, rel(got[k], ref[k]))

@@ -168,3 +168,54 @@ def test_network_warmup_schedule_is_pinned():
     assert [be.network_warmup(n) for n in (1, 10, 80, 199, 200, 300)] == [0, 5, 40, 99, 100, 100]
     cfg["Training"]["network_warmup_iters"] = 7
     assert [be.network_warmup(n) for n in (1, 10, 80, 200)] == [7, 7, 7, 100]        # the reference-length call keeps the reference's literal
+
+
+def test_overlap_fractions_in_groups_equal_one_batched_projection(monkeypatch):
+    """The candidates are projected OVERLAP_GROUP at a time (bounded peak memory): same fractions as one einsum over all of them."""
+    from slam import keyframes as kf
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand((5000, 3), generator=g) * torch.tensor([4.0, 3.0, 5.0]) - torch.tensor([2.0, 1.5, 0.0])
+    K = 37
+    ang = torch.rand(K, generator=g) * 0.6 - 0.3
+    Rs = torch.stack([torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=torch.float32) for a in ang.tolist()])
+    Ts = torch.rand((K, 3), generator=g) - 0.5
+    args = (pts, Rs, Ts, 300.0, 300.0, 160.0, 120.0, 320, 240)
+    monkeypatch.setattr(kf, "OVERLAP_GROUP", 1000)
+    whole = kf.overlap_fractions(*args)
+    for group in (1, 16, 37):
+        monkeypatch.setattr(kf, "OVERLAP_GROUP", group)
+        part = kf.overlap_fractions(*args)
+        assert part.shape == (K,) and torch.equal(part, whole), group
+    assert 0.0 < float(whole.mean()) < 1.0
+
+
+def test_keyframe_operand_store_is_bounded_by_bytes_and_shares_ground_truth(monkeypatch):
+    """slam.mapping_graph.KeyframeOperands: one ground-truth copy per keyframe whatever the flag variant, a byte budget with
+    least-recently-used eviction, and Camera.clean()'s hook (slam_losses.drop_keyframe_constants) drops the keyframe's entry."""
+    import slam_losses
+    from slam import mapping_graph as mg
+    calls = []
+
+    def fake_operands(config, viewpoint, device, rm_dynamic=False, mask=None, dynamic=False):
+        calls.append((viewpoint.uid, rm_dynamic, dynamic))
+        return (torch.full((3, 4, 4), float(viewpoint.uid)), torch.zeros((1, 4, 4)), torch.full((1, 4, 4), float(rm_dynamic)),
+                torch.full((1, 4, 4), float(dynamic)), 0.9)
+
+    monkeypatch.setattr(slam_losses, "mapping_loss_operands", fake_operands)
+    monkeypatch.setattr(mg, "device_store_budget", lambda device, fraction, floor_bytes=0: 3 * (4 * 16 * 4 + 2 * 16 * 4) + 10)   # three one-variant keyframes
+    store = mg.KeyframeOperands()
+    cams = [types.SimpleNamespace(uid=k) for k in range(5)]
+    a = store.get({}, cams[0], "cpu", rm_dynamic=True, dynamic=False)
+    b = store.get({}, cams[0], "cpu", rm_dynamic=False, dynamic=True)
+    assert a[0] is b[0] and a[1] is b[1] and a[2] is not b[2]                  # ground truth once, weights per variant
+    assert store.get({}, cams[0], "cpu", rm_dynamic=True, dynamic=False)[2] is a[2] and len(calls) == 2
+    assert store.held_bytes() == 4 * 16 * 4 + 2 * (2 * 16 * 4)
+    for c in cams[1:4]:
+        store.get({}, c, "cpu")
+    assert id(cams[0]) not in store._held and store.held_bytes() <= store._budget          # the oldest keyframe went first
+    assert store.get({}, cams[0], "cpu", rm_dynamic=True, dynamic=False)[0] is not a[0]    # ... and is formed again on demand
+    held = store.held_bytes()
+    slam_losses.drop_keyframe_constants(cams[3])                               # what Camera.clean() calls
+    assert id(cams[3]) not in store._held and store.held_bytes() < held
+    slam_losses.drop_keyframe_constants(None)
+    assert store.held_bytes() == 0 and not store._held

@@ -5,8 +5,11 @@
 network.  Reports the end-to-end iteration time and Gaussians x views / s for
   "reference_program": the reference's tensor program for the field (24 F.grid_sample per call) and nn.Linear layers, torch loss,
                        torch.optim.Adam, torch prologue -- around this repo's rasterizer;
-  "fused":             HIP field + split-K weight gradients, fused loss, FusedAdam.
-Prints one JSON line (profiles/r01_config3.json).  usage: python tools/bench_config3.py [--P 500000] [--views 8] [--iters 5]"""
+  "fused":             HIP field + fused MLP, fused loss, FusedAdam -- one render(dynamic=True) per keyframe (rounds 1-4);
+  "batched":           the keyframes of the iteration at once (round 5): render_views(dynamic=True) -- the deformation network evaluated once
+                       for all times (spatial planes gathered once per Gaussian, one sort + one spatial scatter on the way back, the MLP over
+                       all V * P rows), the multi-view rasterizer with the network's output as per-view deltas; fused Adam on the network.
+Prints one JSON line (profiles/r05_config3.json).  usage: python tools/bench_config3.py [--P 500000] [--views 8] [--iters 5] [--modes fused,batched]"""
 import argparse, json, os, sys, time, types
 import numpy as np
 import torch
@@ -28,7 +31,9 @@ ap.add_argument("--P", type=int, default=500_000)
 ap.add_argument("--views", type=int, default=8)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--fused-only", action="store_true")
+ap.add_argument("--modes", default=None, help="comma list of reference_program, fused, batched (default: all three; --fused-only: fused, batched)")
 a = ap.parse_args()
+modes = a.modes.split(",") if a.modes else (["fused", "batched"] if a.fused_only else ["reference_program", "fused", "batched"])
 P, W, H, K = a.P, 640, 480, a.views
 config = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.9}}
 pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
@@ -38,7 +43,8 @@ rng = np.random.default_rng(11)
 out = {"workload": f"{K} keyframes x {P} Gaussians @{W}x{H}, render(dynamic=True) through the HexPlane deformation network, pose grads, "
                    "mapping loss, Adam (Gaussians + network)"}
 orig_features = hexplane.hexplane_features
-for fused in ((True,) if a.fused_only else (False, True)):
+for mode in modes:
+    fused, batched = mode != "reference_program", mode == "batched"
     torch.manual_seed(0)
     m = _GaussianModel(g, False, 0.0, seed=2)
     net = deformation.deform_network(hidden_params(bounds=8.0), "cuda").to("cuda")   # aabb that holds the synthetic scene (z up to 6)
@@ -60,7 +66,7 @@ for fused in ((True,) if a.fused_only else (False, True)):
               ("opacity", m._opacity, 0.05), ("scaling", m._scaling, 1e-3), ("rotation", m._rotation, 1e-3))]
     opt = (FusedAdam if fused else torch.optim.Adam)(groups, lr=0.0, eps=1e-15)
     net_params = [p_ for p_ in net.parameters() if p_.requires_grad]
-    net_opt = torch.optim.Adam(net_params, lr=1.6e-4, eps=1e-15)
+    net_opt = torch.optim.Adam(net_params, lr=1.6e-4, eps=1e-15, fused=True) if batched else torch.optim.Adam(net_params, lr=1.6e-4, eps=1e-15)
     if fused:
         hexplane.hexplane_features = orig_features
     else:                                                        # the reference's field program + plain nn.Linear
@@ -79,9 +85,13 @@ for fused in ((True,) if a.fused_only else (False, True)):
         opt.zero_grad(set_to_none=True)
         net_opt.zero_grad(set_to_none=True)
         loss = 0.0
-        for v in views:
-            res = gr.render(v, m, pipe, bg, dynamic=True)
-            loss = loss + (get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"]) if fused else torch_loss(res["render"], res["depth"], v))
+        if batched:
+            for v, res in zip(views, gr.render_views(views, m, pipe, bg, dynamic=True)):
+                loss = loss + get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"])
+        else:
+            for v in views:
+                res = gr.render(v, m, pipe, bg, dynamic=True)
+                loss = loss + (get_loss_mapping(config, res["render"], res["depth"], v, res["opacity"]) if fused else torch_loss(res["render"], res["depth"], v))
         loss.backward()
         opt.step()
         net_opt.step()
@@ -94,7 +104,7 @@ for fused in ((True,) if a.fused_only else (False, True)):
         iteration()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
-    key = "fused" if fused else "reference_program"
+    key = mode
     out[key + "_ms_per_iteration"] = round(dt * 1e3, 2)
     out[key + "_ms_per_view"] = round(dt * 1e3 / K, 3)
     out[key + "_gaussian_views_per_s"] = round(P * K / dt)
@@ -102,7 +112,9 @@ for fused in ((True,) if a.fused_only else (False, True)):
     del m, net, opt, net_opt, views
     torch.cuda.empty_cache()
 hexplane.hexplane_features = orig_features
-if not a.fused_only:
+if "reference_program" in modes and "fused" in modes:
     out["speedup"] = round(out["reference_program_ms_per_iteration"] / out["fused_ms_per_iteration"], 2)
+if "batched" in modes and "fused" in modes:
+    out["batched_over_fused"] = round(out["fused_ms_per_iteration"] / out["batched_ms_per_iteration"], 2)
 out["peak_memory_GB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
 print(json.dumps(out))
