@@ -1430,7 +1430,7 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
     GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
     const dim3 per_point((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, time, time_stride,
-                       dL_dfeatures);
+                       dL_dfeatures, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
     hipLaunchKernelGGL(hexsort_scan_top_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, scan_blocks, ws.header);
     hipLaunchKernelGGL(hexsort_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, ws.count, nb, (const uint32_t*)ws.block_sums);
@@ -1525,7 +1525,7 @@ size_t gsr_hexplane_backward_views_workspace_size(const gsr_hexplane_field* fiel
 }
 
 int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
-                                const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream_)
+                                const float* dL_dfeatures, const uint32_t* view_mask, float* dL_dxyz, char* workspace, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = hexplane_views_check(field, n, xyz, V, times, "gsr_hexplane_backward_views")) return rc;
@@ -1544,22 +1544,30 @@ int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, cons
     const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
     GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, (const float*)nullptr, (int64_t)0,
-                       (const float*)nullptr);
+                       (const float*)nullptr, view_mask);
     hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
     hipLaunchKernelGGL(hexsort_scan_top_kernel, dim3(1), dim3(1024), 0, stream, ws.block_sums, scan_blocks, ws.header);
     hipLaunchKernelGGL(hexsort_scan_apply_kernel, dim3(scan_blocks), dim3(1024), 0, stream, ws.count, nb, (const uint32_t*)ws.block_sums);
     hipLaunchKernelGGL(hexsort_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, n);
     const int C = f.feat_dim, ppb = HEX_BLOCK / C;
     const dim3 g1((unsigned)((n + ppb - 1) / ppb));
+    const int dbg = getenv("GSR_HEXV_DEBUG") ? atoi(getenv("GSR_HEXV_DEBUG")) : 0;   // development: 1 = skip the spatial streams, 2 = skip the time streams
     const int gpw = C >= 64 ? 1 : 64 / C;                        // groups per wave (hexsort_phase2_views_kernel)
     const int64_t chunks2 = (n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
-    const int64_t groups = (int64_t)(3 + 3 * ((V + HEXSORT_VIEW_BATCH - 1) / HEXSORT_VIEW_BATCH)) * ((chunks2 + gpw - 1) / gpw) * gpw;
+    const int64_t groups = (int64_t)3 * ((chunks2 + gpw - 1) / gpw) * gpw;
     const dim3 g2((unsigned)((groups + 256 / C - 1) / (256 / C)));
+    const int per_block = (256 / C) * HEXT_ROUNDS;               // chunks per block of the time families' kernel
+    const dim3 g3((unsigned)((chunks2 + per_block - 1) / per_block), (unsigned)(3 * ((V + HEXT_VB - 1) / HEXT_VB)));
 #define GSR_HEXVB_CASE(CC)                                                                                                              \
     case CC:                                                                                                                             \
         hipLaunchKernelGGL((hexsort_phase1_views_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz);   \
-        if (f.num_levels <= 4) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, vw, tv, n);      \
-        else hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, vw, tv, n);  \
+        if (f.num_levels <= 4) {                                                                                                        \
+            if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, vw, n);            \
+            if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, 4>), g3, dim3(256), 0, stream, f, ws, vw, tv, n);         \
+        } else {                                                                                                                        \
+            if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, vw, n);       \
+            if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g3, dim3(256), 0, stream, f, ws, vw, tv, n);    \
+        }                                                                                                                               \
         break;
     switch (C) { GSR_HEXVB_CASE(8) GSR_HEXVB_CASE(16) GSR_HEXVB_CASE(32) GSR_HEXVB_CASE(64) }
 #undef GSR_HEXVB_CASE
@@ -1666,12 +1674,41 @@ size_t gsr_deform_mlp_workspace_size(int in_dim)
     return (size_t)MLP_BWD_BLOCKS * gsr_deform_mlp_grad_count(in_dim) * sizeof(float) + 256;
 }
 
+size_t gsr_row_mask_workspace_size(int V, int64_t n)
+{
+    if (V < 1 || n < 0) return 256;
+    return (size_t)V * (size_t)((n + ROWMASK_BLOCK - 1) / ROWMASK_BLOCK) * sizeof(uint32_t) + 256;
+}
+
+int gsr_row_mask(int V, int64_t n, int width, const float* g, uint32_t* view_mask, int32_t* rows, int32_t* n_rows, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (V < 1 || V > 32 || n < 0 || width < 1 || (int64_t)V * n >= ((int64_t)1 << 31) || !n_rows || !workspace || (n > 0 && (!g || !view_mask || !rows))) {
+        g_last_error = "gsr_row_mask: invalid argument (1 <= V <= 32, V n < 2^31, non-null pointers)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) { GSR_HIP_CHECK(hipMemsetAsync(n_rows, 0, sizeof(int32_t), stream)); return 0; }
+    const int nb = (int)((n + ROWMASK_BLOCK - 1) / ROWMASK_BLOCK);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+    hipLaunchKernelGGL(rowmask_count_kernel, dim3(nb), dim3(ROWMASK_BLOCK), 0, stream, V, n, width, g, view_mask, counts);
+    hipLaunchKernelGGL(rowmask_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, V * nb, n_rows);
+    hipLaunchKernelGGL(rowmask_list_kernel, dim3(nb), dim3(ROWMASK_BLOCK), 0, stream, V, n, (const uint32_t*)view_mask, (const uint32_t*)counts, rows);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
                             float* grads, char* workspace, void* stream_)
+{
+    return gsr_deform_mlp_backward_rows(mlp, n, features, dout, dfeatures, grads, workspace, nullptr, nullptr, stream_);
+}
+
+int gsr_deform_mlp_backward_rows(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
+                                 float* grads, char* workspace, const int32_t* rows, const int32_t* n_rows, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     MlpWeights w;
     if (int rc = mlp_fill(mlp, &w, "gsr_deform_mlp_backward")) return rc;
+    if ((rows != nullptr) != (n_rows != nullptr)) { g_last_error = "gsr_deform_mlp_backward_rows: rows and n_rows go together"; return GSR_ERR_INVALID_ARGUMENT; }
     if (n < 0 || !grads || !workspace || (n > 0 && (!features || !dout || !dfeatures))) {
         g_last_error = "gsr_deform_mlp_backward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
@@ -1680,7 +1717,7 @@ int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* f
     const int blocks = (int)std::min<int64_t>(MLP_BWD_BLOCKS, (n + MLPB_TILE - 1) / MLPB_TILE);
     float* partial = reinterpret_cast<float*>(workspace);
     switch (w.in_dim / 16) {
-#define GSR_MLPB_CASE(NT) case NT: hipLaunchKernelGGL((deform_mlp_bwd_kernel<NT>), dim3(blocks), dim3(MLPB_BLOCK), 0, stream, n, features, dout, w, dfeatures, partial); break;
+#define GSR_MLPB_CASE(NT) case NT: hipLaunchKernelGGL((deform_mlp_bwd_kernel<NT>), dim3(blocks), dim3(MLPB_BLOCK), 0, stream, n, features, dout, w, dfeatures, partial, rows, n_rows); break;
         GSR_MLPB_CASE(1) GSR_MLPB_CASE(2) GSR_MLPB_CASE(3) GSR_MLPB_CASE(4) GSR_MLPB_CASE(5) GSR_MLPB_CASE(6) GSR_MLPB_CASE(7) GSR_MLPB_CASE(8)
 #undef GSR_MLPB_CASE
     }

@@ -64,7 +64,8 @@ __device__ __forceinline__ uint32_t hexsort_key(const HexSortPlan& P, int c0, in
 // ---- phase 0a: normalised coordinates, cell keys, histogram ----------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexSortWs ws, const int64_t n, const float* __restrict__ xyz,
-                     const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures)
+                     const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures,
+                     const uint32_t* __restrict__ view_mask)
 {
     // eight lanes per point: they read the point's cotangent row together (coalesced float4 loads), lane 0 of the group then bins it
     const int sub = threadIdx.x & 7;
@@ -72,8 +73,9 @@ hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexS
     if (i >= n) return;
     // A point whose cotangent row is exactly zero (a Gaussian the view does not see) adds nothing to any plane: it is left out of the
     // sort altogether, so everything after this kernel costs in proportion to the points that carry a gradient.
-    // (the batched-views caller passes no cotangent: with up to 12 views per point nearly every point is seen by one of them)
-    int active = dL_dfeatures ? 0 : 1;
+    // (the batched-views caller passes no cotangent but, optionally, the views whose cotangent row of the point is not zero, bit v = view v)
+    const uint32_t vbits = view_mask ? view_mask[i] : 0xFFFFFFFFu;
+    int active = dL_dfeatures ? 0 : (vbits != 0u);
     if (dL_dfeatures) {
         const float4* row = reinterpret_cast<const float4*>(dL_dfeatures + i * ((int64_t)f.num_levels * f.feat_dim));
         for (int e = sub; e < f.num_levels * f.feat_dim / 4; e += 8) {
@@ -92,7 +94,9 @@ hexsort_count_kernel(const gsr_hexplane_field f, const HexSortPlan P, const HexS
     }
     const float zero_time = 0.f;       // time == nullptr (batched views): the time families are sorted along their spatial coordinate only
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time ? time + i * time_stride : &zero_time);
-    ws.coords[i] = make_float4(p.c[0], p.c[1], p.c[2], p.c[3]);
+    // batched views: the fourth component carries the point's view bits to the sorted order instead of a time (the walks take the time from
+    // the view)
+    ws.coords[i] = make_float4(p.c[0], p.c[1], p.c[2], time ? p.c[3] : __uint_as_float(vbits));
     int i0[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) i0[k] = hex_axis(p.c[k], P.fine[k]).i0;
@@ -349,6 +353,64 @@ hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
     hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * na + first, ws.gs + ((size_t)pl * na + first) * f.num_levels * C + ch, cnt, false, 0.f);
 }
 
+// ---- which rows of a batch's cotangent are not zero (gsr_row_mask) ---------------------------------------------------------------------
+// g [V][n][width]: bit v of view_mask[i] = some element of row (v, i) is non-zero; rows[] = the flat indices v n + i of those rows in
+// ascending order (deterministic: per-(view, block) counts, one scan, ranks inside the block). A mapping iteration's Gaussians mostly
+// receive NO gradient from a given view (BASELINE config #3: 63 % of the 8 x 500k rows -- outside the frustum, or behind a saturated pixel):
+// the deformation MLP's backward then runs over the listed rows only, and the field's backward skips the others by the bit.
+constexpr int ROWMASK_BLOCK = 256;
+__device__ __forceinline__ bool rowmask_nonzero(const float* __restrict__ r, int width)
+{
+    bool nz = false;
+    for (int k = 0; k < width; k++) nz |= r[k] != 0.f;
+    return nz;
+}
+__global__ void __launch_bounds__(ROWMASK_BLOCK)
+rowmask_count_kernel(const int V, const int64_t n, const int width, const float* __restrict__ g, uint32_t* __restrict__ view_mask,
+                     uint32_t* __restrict__ block_counts /*[V][gridDim.x]*/)
+{
+    __shared__ uint32_t s_cnt[ROWMASK_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * ROWMASK_BLOCK + threadIdx.x;
+    uint32_t bits = 0;
+    for (int v = 0; v < V; v++) {
+        const bool nz = i < n && rowmask_nonzero(g + ((size_t)v * n + i) * width, width);
+        bits |= (nz ? 1u : 0u) << v;
+        const unsigned long long b = __ballot(nz);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) block_counts[(size_t)v * gridDim.x + blockIdx.x] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        __syncthreads();
+    }
+    if (i < n) view_mask[i] = bits;
+}
+__global__ void __launch_bounds__(1024)
+rowmask_scan_kernel(uint32_t* __restrict__ block_counts, const int count, int32_t* __restrict__ n_rows)
+{
+    __shared__ uint32_t s_tmp[17];
+    const uint32_t total = block_exclusive_scan_1024(count, [&](int b) { return block_counts[b]; },
+                                                     [&](int b, uint32_t ex, uint32_t) { block_counts[b] = ex; }, s_tmp);
+    if (threadIdx.x == 0) n_rows[0] = (int32_t)total;
+}
+__global__ void __launch_bounds__(ROWMASK_BLOCK)
+rowmask_list_kernel(const int V, const int64_t n, const uint32_t* __restrict__ view_mask, const uint32_t* __restrict__ block_offsets,
+                    int32_t* __restrict__ rows)
+{
+    __shared__ uint32_t s_cnt[ROWMASK_BLOCK / 64];
+    const int64_t i = (int64_t)blockIdx.x * ROWMASK_BLOCK + threadIdx.x;
+    const uint32_t bits = i < n ? view_mask[i] : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int v = 0; v < V; v++) {
+        const bool nz = (bits >> v) & 1u;
+        const unsigned long long b = __ballot(nz);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += s_cnt[w];
+        if (nz) rows[block_offsets[(size_t)v * gridDim.x + blockIdx.x] + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (int32_t)((int64_t)v * n + i);
+        __syncthreads();
+    }
+}
+
 // ---- the views of one mapping iteration: one sort, one spatial scatter (gsr_hexplane_backward_views) ----------------------------------
 // Every keyframe of an iteration evaluates the field at the same positions with its own time. The cells a point falls into therefore do
 // not depend on the view: ONE counting sort serves all of them (the time families are keyed by their spatial coordinate alone -- a view's
@@ -370,16 +432,22 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
     const int ch = threadIdx.x % C;
     const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / C) + threadIdx.x / C;
     if (i >= n) return;
+    if (ws.rank[i] < 0) {                                         // no view's cotangent reaches this point: nothing to gather, nothing to hand over
+        if (dL_dxyz && ch < 3) dL_dxyz[3 * i + ch] = 0.f;
+        return;
+    }
+    const uint32_t vbits = __float_as_uint(ws.coords[i].w);       // views whose cotangent row of this point is not zero
     const float zero_time = 0.f;
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, &zero_time);
     const int L = f.num_levels, V = tv.V;
     const size_t row = (size_t)L * C;
+    const size_t na = ws.header[0] / 6;                           // points that were sorted: family pl owns the slots [pl na, (pl + 1) na)
     constexpr int SP[3] = {0, 1, 3}, TP[3] = {2, 4, 5};           // plane numbers of the spatial / time families
     size_t sp_slot[3], t_slot[3];                                 // this lane's element of the point's row in each family's sorted order
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        sp_slot[j] = ((size_t)j * n + ((size_t)ws.rank[(size_t)SP[j] * n + i] - (size_t)SP[j] * n)) * row + ch;
-        t_slot[j] = ((size_t)j * V * n + ((size_t)ws.rank[(size_t)TP[j] * n + i] - (size_t)TP[j] * n)) * row + ch;
+        sp_slot[j] = ((size_t)j * n + ((size_t)ws.rank[(size_t)SP[j] * n + i] - (size_t)SP[j] * na)) * row + ch;
+        t_slot[j] = ((size_t)j * V * n + ((size_t)ws.rank[(size_t)TP[j] * n + i] - (size_t)TP[j] * na)) * row + ch;
     }
     const float* gout = dL_dfeatures + (size_t)i * row + ch;
     float gc[3] = {0.f, 0.f, 0.f};
@@ -415,6 +483,7 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
         float Gs[3] = {0.f, 0.f, 0.f};
         const int Wt = Lv.res[3];
         for (int v = 0; v < V; v++) {
+            if (!((vbits >> v) & 1u)) continue;                   // a zero row: nothing to add, and phase 2 skips the slot by the same bit
             const HexAxis T = hex_axis(tv.t[v], Wt);
             const int t1 = T.has1 ? T.i0 + 1 : T.i0;
             const float wt1 = T.has1 ? T.w1 : 0.f;
@@ -490,19 +559,46 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
     }
 }
 
-// A time family's walk for up to VB views at once. The weights along the family's spatial coordinate are the same for every view, and a
-// view's time is the same for every point: per (view, level) the two sums  sum gs * w0,  sum gs * w1  over a run of points that share the
-// spatial cell are all there is -- the two time rows' weights are applied when the run is flushed (4 atomics). One coordinate load and VB * L
-// independent 128-byte row loads per step and group: the single-view walk (one load per level in flight, 24 of 27 streams at 8 views) ran at
-// the latency of its own loads (4.3 ms for 6.9 GB at config #3).
-template <int C, int LMAX, int VB>
-__device__ __forceinline__ void hexsort_phase2_time_walk(const gsr_hexplane_field& f, const int j, const float4* __restrict__ sc,
-                                                         const float* __restrict__ gsrow, const size_t view_stride, const int nv,
-                                                         const float* __restrict__ times, const int cnt)
+// ---- phase 2 of the TIME families, all views ----------------------------------------------------------------------------------------
+// The weights along a time family's spatial coordinate are the same for every view, and a view's time is the same for every point: per
+// (view, level) the sums  sum gs * w0 -> column cx,  sum gs * w1 -> column cx + 1  over the points of a spatial cell are all there is; the two
+// time rows' weights are applied once, at the very end. Because the points are sorted along that coordinate, a block that walks
+// HEXT_ROUNDS * GROUPS consecutive chunks stays inside a few columns of every level: it sums into an LDS window of HEXT_WIN columns per
+// (view, level) -- a run's two sums with ds_add_f32, a few per chunk -- and issues the global float atomics ONCE per column it touched.
+// Measured first (config #3, 500k points x 8 views): the generic walk with its 4 atomics per run spent 6.4 ms in these streams at 1 TB/s --
+// a view's rows of one time are 2 x 960 texels that every wave in flight was hitting at once, and on this part a wave's loads queue behind
+// its outstanding atomics.
+constexpr int HEXT_VB = 4;        // views per block
+constexpr int HEXT_ROUNDS = 4;    // chunks per group
+constexpr int HEXT_WIN = 16;      // columns of the LDS window per level (runs outside it go to global memory directly)
+
+template <int C, int LMAX>
+__global__ void __launch_bounds__(256)
+hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n)
 {
-    const int ch = threadIdx.x % C;
+    constexpr int GROUPS = 256 / C, VB = HEXT_VB;
+    __shared__ float s_acc[VB][LMAX][HEXT_WIN][C];
+    const int ch = threadIdx.x % C, grp = threadIdx.x / C;
+    const int j = blockIdx.y % 3, v0 = (blockIdx.y / 3) * VB;     // family (x, y, z) and first view of this block
+    const int nv = min(VB, tv.V - v0);
     const int pl = j == 0 ? 2 : 3 + j;                            // planes (x,t) = 2, (y,t) = 4, (z,t) = 5
     const int L = f.num_levels;
+    const size_t row = (size_t)L * C, view_stride = (size_t)n * row;
+    const int64_t na = ws.header[0] / 6;                          // points that were sorted (some view's cotangent reaches them); the grid covers n
+    const int64_t chunks = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    const int64_t chunk0 = (int64_t)blockIdx.x * (GROUPS * HEXT_ROUNDS);
+    if (chunk0 >= chunks) return;
+    const float4* __restrict__ sc = ws.scoords + (size_t)pl * na;
+    const float* __restrict__ gs = vw.gs_t + ((size_t)j * tv.V + v0) * view_stride + ch;
+    auto coord = [&](const float4& c) { return j == 0 ? c.x : (j == 1 ? c.y : c.z); };
+    for (int e = threadIdx.x; e < VB * LMAX * HEXT_WIN * C; e += 256) (&s_acc[0][0][0][0])[e] = 0.f;
+    int col0[LMAX];                                               // first column of the window: the cell of the block's first point
+    {
+        const float c_first = coord(sc[chunk0 * HEXSORT_CHUNK]);
+#pragma unroll
+        for (int l = 0; l < LMAX; l++) col0[l] = l < L ? hex_axis(c_first, f.levels[l].res[j]).i0 : 0;
+    }
+    __syncthreads();
     float acc[VB][LMAX][2];
     int cx[LMAX];
 #pragma unroll
@@ -511,106 +607,133 @@ __device__ __forceinline__ void hexsort_phase2_time_walk(const gsr_hexplane_fiel
 #pragma unroll
         for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
     }
-    auto flush = [&](int l) {
-        const gsr_hexplane_level& Lv = f.levels[l];
-        float* gp = Lv.grad_planes[pl];
-        const int W = Lv.res[j], H = Lv.res[3];
-        if (gp && cx[l] >= 0) {
-            const bool x1 = cx[l] + 1 < W;
+    auto flush = [&](int l) {                                     // the run of level l ends: its sums go to the window (or, outside it, to memory)
+        if (cx[l] >= 0) {
+            const gsr_hexplane_level& Lv = f.levels[l];
+            const int W = Lv.res[j], rel = cx[l] - col0[l];
+            const bool x1 = cx[l] + 1 < W;                          // safe_add_2d: a column outside the plane receives nothing
+            if (rel >= 0 && rel + 1 < HEXT_WIN) {
 #pragma unroll
-            for (int v = 0; v < VB; v++) {
-                if (v < nv) {
-                    const HexAxis T = hex_axis(times[v], H);
-                    float* t = gp + ((size_t)T.i0 * W + cx[l]) * C + ch;
-                    const float a0 = acc[v][l][0], a1 = acc[v][l][1];
-                    if (a0 != 0.f) unsafeAtomicAdd(t, a0 * T.w0);
-                    if (x1 && a1 != 0.f) unsafeAtomicAdd(t + C, a1 * T.w0);
-                    if (T.has1 && a0 != 0.f) unsafeAtomicAdd(t + (size_t)W * C, a0 * T.w1);
-                    if (T.has1 && x1 && a1 != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, a1 * T.w1);
+                for (int v = 0; v < VB; v++) {
+                    if (acc[v][l][0] != 0.f) atomicAdd(&s_acc[v][l][rel][ch], acc[v][l][0]);
+                    if (x1 && acc[v][l][1] != 0.f) atomicAdd(&s_acc[v][l][rel + 1][ch], acc[v][l][1]);
+                }
+            } else {
+                float* gp = Lv.grad_planes[pl];
+#pragma unroll
+                for (int v = 0; v < VB; v++) {
+                    if (gp && v < nv) {
+                        const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
+                        float* t = gp + ((size_t)T.i0 * W + cx[l]) * C + ch;
+                        const float a0 = acc[v][l][0], a1 = acc[v][l][1];
+                        if (a0 != 0.f) unsafeAtomicAdd(t, a0 * T.w0);
+                        if (x1 && a1 != 0.f) unsafeAtomicAdd(t + C, a1 * T.w0);
+                        if (T.has1 && a0 != 0.f) unsafeAtomicAdd(t + (size_t)W * C, a0 * T.w1);
+                        if (T.has1 && x1 && a1 != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, a1 * T.w1);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
     };
-    auto coord = [&](const float4& c) { return j == 0 ? c.x : (j == 1 ? c.y : c.z); };
-    float c_next = coord(sc[0]);
-    float g_next[VB][LMAX];
-#pragma unroll
-    for (int v = 0; v < VB; v++) {
-#pragma unroll
-        for (int l = 0; l < LMAX; l++) g_next[v][l] = (l < L && v < nv) ? gsrow[(size_t)v * view_stride + (size_t)l * C] : 0.f;
-    }
-    for (int k = 0; k < cnt; k++) {
-        const float c = c_next;
-        float g_cur[VB][LMAX];
-#pragma unroll
-        for (int v = 0; v < VB; v++) {
-#pragma unroll
-            for (int l = 0; l < LMAX; l++) g_cur[v][l] = g_next[v][l];
-        }
-        const int kn = min(k + 1, cnt - 1);
-        c_next = coord(sc[kn]);
+    for (int r = 0; r < HEXT_ROUNDS; r++) {
+        const int64_t chunk = chunk0 + (int64_t)r * GROUPS + grp;  // the groups of a block walk neighbouring chunks at the same time
+        if (chunk >= chunks) break;
+        const int64_t first = chunk * HEXSORT_CHUNK;
+        const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
+        const float4* __restrict__ scc = sc + first;
+        const float* __restrict__ gsrow = gs + (size_t)first * row;
+        // the loads of point k + 1 (one coordinate + view bits, VB * L rows) are in flight while point k is processed; the rows of views whose
+        // bit is clear were never written (phase 1 skipped them) and are not read
+        float4 cc0 = scc[0];
+        float c_next = coord(cc0);
+        uint32_t bits = __float_as_uint(cc0.w) >> v0;
+        float g_next[VB][LMAX];
 #pragma unroll
         for (int v = 0; v < VB; v++) {
 #pragma unroll
-            for (int l = 0; l < LMAX; l++) g_next[v][l] = (l < L && v < nv) ? gsrow[(size_t)v * view_stride + ((size_t)kn * L + l) * C] : 0.f;
+            for (int l = 0; l < LMAX; l++) g_next[v][l] = (l < L && v < nv && ((bits >> v) & 1u)) ? gsrow[(size_t)v * view_stride + (size_t)l * C] : 0.f;
         }
+        for (int k = 0; k < cnt; k++) {
+            const float c = c_next;
+            float g_cur[VB][LMAX];
 #pragma unroll
-        for (int l = 0; l < LMAX; l++) {
-            if (l < L) {
-                const HexAxis X = hex_axis(c, f.levels[l].res[j]);
-                if (X.i0 != cx[l]) {
-                    flush(l);
-                    cx[l] = X.i0;
-                }
+            for (int v = 0; v < VB; v++) {
 #pragma unroll
-                for (int v = 0; v < VB; v++) {
-                    acc[v][l][0] = fmaf(g_cur[v][l], X.w0, acc[v][l][0]);
-                    acc[v][l][1] = fmaf(g_cur[v][l], X.w1, acc[v][l][1]);
+                for (int l = 0; l < LMAX; l++) g_cur[v][l] = g_next[v][l];
+            }
+            const int kn = min(k + 1, cnt - 1);
+            const float4 ccn = scc[kn];
+            c_next = coord(ccn);
+            bits = __float_as_uint(ccn.w) >> v0;
+#pragma unroll
+            for (int v = 0; v < VB; v++) {
+#pragma unroll
+                for (int l = 0; l < LMAX; l++)
+                    g_next[v][l] = (l < L && v < nv && ((bits >> v) & 1u)) ? gsrow[(size_t)v * view_stride + ((size_t)kn * L + l) * C] : 0.f;
+            }
+#pragma unroll
+            for (int l = 0; l < LMAX; l++) {
+                if (l < L) {
+                    const HexAxis X = hex_axis(c, f.levels[l].res[j]);
+                    if (X.i0 != cx[l]) {
+                        flush(l);
+                        cx[l] = X.i0;
+                    }
+#pragma unroll
+                    for (int v = 0; v < VB; v++) {
+                        acc[v][l][0] = fmaf(g_cur[v][l], X.w0, acc[v][l][0]);
+                        acc[v][l][1] = fmaf(g_cur[v][l], X.w1, acc[v][l][1]);
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int l = 0; l < LMAX; l++) {
-        if (l < L) flush(l);
+        for (int l = 0; l < LMAX; l++) {
+            if (l < L) { flush(l); cx[l] = -1; }
+        }
+    }
+    __syncthreads();
+    // the window -> the two time rows of every view: one pair of atomics per (view, level, column) the block touched
+    for (int e = grp; e < VB * LMAX * HEXT_WIN; e += GROUPS) {
+        const int v = e / (LMAX * HEXT_WIN), l = (e / HEXT_WIN) % LMAX, rel = e % HEXT_WIN;
+        if (v >= nv || l >= L) continue;
+        const float a = s_acc[v][l][rel][ch];
+        const gsr_hexplane_level& Lv = f.levels[l];
+        float* gp = Lv.grad_planes[pl];
+        const int W = Lv.res[j], col = col0[l] + rel;
+        if (a == 0.f || !gp || col >= W) continue;
+        const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
+        float* t = gp + ((size_t)T.i0 * W + col) * C + ch;
+        unsafeAtomicAdd(t, a * T.w0);
+        if (T.has1) unsafeAtomicAdd(t + (size_t)W * C, a * T.w1);
     }
 }
 
-// stream s < 3: spatial family (planes 0, 1, 3); stream 3 + 3 b + j: time family j (planes 2, 4, 5) of the views [VB b, VB b + VB)
-constexpr int HEXSORT_VIEW_BATCH = 4;
+// the spatial families (planes 0, 1, 3), whose dL/dsample phase 1 summed over the views: the generic walk, one stream per family
 template <int C, int LMAX>
 __global__ void __launch_bounds__(256)
-hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n)
+hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const int64_t n)
 {
-    constexpr int GROUPS = 256 / C, VB = HEXSORT_VIEW_BATCH;
-    const int ch = threadIdx.x % C;
-    const int64_t chunks = (n + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
+    constexpr int GROUPS = 256 / C;
     constexpr int GPW = C >= 64 ? 1 : 64 / C;                     // groups per wave: they take the same stream (one code path per wave) ...
+    const int ch = threadIdx.x % C;
+    const int64_t na = ws.header[0] / 6;                          // points that were sorted; the grid covers n
+    const int64_t chunks = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
     const int64_t gid = (int64_t)blockIdx.x * GROUPS + threadIdx.x / C;
-    const int batches = (tv.V + VB - 1) / VB;
-    const int streams = 3 + 3 * batches;
     const int64_t wave_chunks = (chunks + GPW - 1) / GPW;
     const int64_t w = gid / GPW;
-    if (w >= streams * wave_chunks) return;
-    // ... and consecutive waves different streams of the same chunks: the waves in flight at one moment then spread their atomics over all
-    // planes (and a time family's few rows of cells are not hammered by every wave at once)
-    const int st = (int)(w % streams);
-    const int64_t chunk = (w / streams) * GPW + gid % GPW;
+    if (w >= 3 * wave_chunks) return;
+    // ... and consecutive waves different streams of the same chunks: the waves in flight at one moment spread their atomics over the planes
+    const int st = (int)(w % 3);
+    const int64_t chunk = (w / 3) * GPW + gid % GPW;
     if (chunk >= chunks) return;
     const int64_t first = chunk * HEXSORT_CHUNK;
-    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, n - first);
+    const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
     const size_t row = (size_t)f.num_levels * C;
-    if (st < 3) {
-        const int pl = st == 2 ? 3 : st;
-        hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * n + first, vw.gs_sp + ((size_t)st * n + first) * row + ch, cnt, false, 0.f);
-    } else {
-        const int b = (st - 3) / 3, j = (st - 3) % 3;
-        const int pl = j == 0 ? 2 : 3 + j, v0 = b * VB;
-        hexsort_phase2_time_walk<C, LMAX, VB>(f, j, ws.scoords + (size_t)pl * n + first, vw.gs_t + (((size_t)j * tv.V + v0) * n + first) * row + ch,
-                                              (size_t)n * row, min(VB, tv.V - v0), tv.t + v0, cnt);
-    }
+    const int pl = st == 2 ? 3 : st;
+    hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * na + first, vw.gs_sp + ((size_t)st * n + first) * row + ch, cnt, false, 0.f);
 }
 
 }  // namespace gsr

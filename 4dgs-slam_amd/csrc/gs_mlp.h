@@ -25,7 +25,8 @@ namespace gsr {
 constexpr int MLP_W = 64;                 // network width (arguments/__init__.py: net_width = 64)
 constexpr int MLP_HEADS = 3;
 constexpr int MLP_OUT = 10;               // 3 + 3 + 4
-constexpr int MLP_BLOCK = 256;            // forward: 4 waves x 16 points per iteration, one persistent block per CU (weights in LDS)
+constexpr int MLP_BLOCK = 512;            // forward: 8 waves x 16 points per iteration, one persistent block per CU (weights in LDS; two waves per
+                                          // SIMD: one runs MFMAs while the other sits at a barrier or waits for its tile -- 4 waves: 2.0 ms at config #3's 4 M rows)
 constexpr int MLP_TILE = MLP_BLOCK / 64 * 16;
 constexpr int MLP_LDA = MLP_W + 4;        // LDS row stride of a [16][64] tile (floats): 16-byte aligned, conflict-free float4 reads
 
@@ -213,10 +214,14 @@ constexpr int MLPB_TILE = 64;             // points per block iteration
 
 template <int NT_IN>                      // in_dim / 16
 __global__ void __launch_bounds__(MLPB_BLOCK)
-deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const float* __restrict__ dout, const MlpWeights w,
-                      float* __restrict__ dfeat, float* __restrict__ partial)
+deform_mlp_bwd_kernel(const int64_t n_all, const float* __restrict__ feat, const float* __restrict__ dout, const MlpWeights w,
+                      float* __restrict__ dfeat, float* __restrict__ partial, const int32_t* __restrict__ rows, const int32_t* __restrict__ n_rows)
 {
+    // rows != nullptr: only the listed rows of feat / dout / dfeat take part (gsr_deform_mlp_backward_rows: the rows of a batch whose
+    // cotangent is not zero, in ascending order); the block then walks the LIST 64 entries at a time and every row access goes through it.
+    const int64_t n = rows ? (int64_t)*n_rows : n_all;
     constexpr int IN = 16 * NT_IN;
+    __shared__ int64_t s_row[MLPB_TILE];                                          // row of feat / dout / dfeat of the tile's points (-1: none)
     __shared__ __attribute__((aligned(16))) float s_W0[MLP_W][IN + 4];          // W0 (h0 recompute and dF); the features for dW0 are re-read from L2
     __shared__ __attribute__((aligned(16))) float s_a[MLPB_TILE][MLP_LDA];      // a = relu(h0)
     __shared__ __attribute__((aligned(16))) float s_v[MLPB_TILE][MLP_LDA];      // v_j = relu(u_j), one head at a time
@@ -263,20 +268,28 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t pblk = tile * MLPB_TILE;
         const int r0 = wave * 16;                                 // this wave's rows of the block tile
-        const int64_t prow = pblk + r0 + i;
+        if (threadIdx.x < MLPB_TILE) {
+            const int64_t e = pblk + threadIdx.x;
+            s_row[threadIdx.x] = e < n ? (rows ? (int64_t)rows[e] : e) : -1;
+        }
+        __syncthreads();
+        const int64_t prow = s_row[r0 + i];
         // stage dout (zero beyond n: those rows then contribute nothing anywhere)
         int nonzero = 0;
         for (int e = threadIdx.x; e < MLPB_TILE * MLP_OUT; e += MLPB_BLOCK) {
             const int r = e / MLP_OUT, c = e - r * MLP_OUT;
-            const float v = pblk + r < n ? dout[(pblk + r) * MLP_OUT + c] : 0.f;
+            const int64_t pr = s_row[r];
+            const float v = pr >= 0 ? dout[pr * MLP_OUT + c] : 0.f;
             s_o[r][c] = v;
             nonzero |= v != 0.f;
         }
         if (!__syncthreads_or(nonzero)) {                         // 64 points no gradient reaches (Gaussians the view does not see): dF = 0
             for (int e = threadIdx.x; e < MLPB_TILE * IN / 4; e += MLPB_BLOCK) {
                 const int r = e / (IN / 4), c = e - r * (IN / 4);
-                if (pblk + r < n) *reinterpret_cast<float4*>(dfeat + (pblk + r) * IN + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int64_t pr = s_row[r];
+                if (pr >= 0) *reinterpret_cast<float4*>(dfeat + pr * IN + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            __syncthreads();                                      // s_row is rewritten by the next iteration
             continue;
         }
         // ---- recompute h0 = F W0^T + b0 for the wave's 16 points; keep the features and a = relu(h0) in LDS ----
@@ -285,7 +298,7 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         for (int t = 0; t < 4; t++) acc1[t] = f32x4{bias0[t], bias0[t], bias0[t], bias0[t]};
 #pragma unroll
         for (int S = 0; S < NT_IN; S++) {
-            const float4 a4 = prow < n ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a4 = prow >= 0 ? *reinterpret_cast<const float4*>(feat + prow * IN + 16 * S + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 b4[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) b4[t] = *reinterpret_cast<const float4*>(&s_W0[16 * t + i][16 * S + 4 * q]);
@@ -373,7 +386,7 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
         for (int S = 0; S < MLPB_TILE / 4; S++) {
             const int pt = 4 * S + q;
             const float ad = s_d[pt][16 * wave + i];
-            const int64_t pg = min(pblk + pt, n - 1);                 // rows beyond n have dh0 = 0: any valid row will do
+            const int64_t pg = s_row[pt] >= 0 ? s_row[pt] : s_row[0];  // rows beyond n have dh0 = 0: any valid row will do (the tile's first is one)
             float fb[NT_IN];                                          // the block read these rows a moment ago: L2
 #pragma unroll
             for (int t = 0; t < NT_IN; t++) fb[t] = feat[pg * IN + 16 * t + i];
@@ -404,8 +417,8 @@ deform_mlp_bwd_kernel(const int64_t n, const float* __restrict__ feat, const flo
                 if (t0 + t < NT_IN) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int64_t p = pblk + r0 + 4 * q + r;
-                        if (p < n) dfeat[p * IN + 16 * (t0 + t) + i] = accf[t][r];
+                        const int64_t p = s_row[r0 + 4 * q + r];
+                        if (p >= 0) dfeat[p * IN + 16 * (t0 + t) + i] = accf[t][r];
                     }
                 }
             }

@@ -47,6 +47,12 @@ def _lib():
         lib.gsr_deform_mlp_grad_count.argtypes = [i]
         lib.gsr_deform_mlp_workspace_size.restype = ctypes.c_size_t
         lib.gsr_deform_mlp_workspace_size.argtypes = [i]
+        lib.gsr_deform_mlp_backward_rows.restype = i
+        lib.gsr_deform_mlp_backward_rows.argtypes = [ctypes.POINTER(_Mlp), i64, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.gsr_row_mask_workspace_size.restype = ctypes.c_size_t
+        lib.gsr_row_mask_workspace_size.argtypes = [i, i64]
+        lib.gsr_row_mask.restype = i
+        lib.gsr_row_mask.argtypes = [i, i64, i, vp, vp, vp, vp, vp, vp]
         _lib_cache = lib
     return _lib_cache
 
@@ -145,6 +151,109 @@ class _FusedDeformMLP(torch.autograd.Function):
             grads.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
         return (dfeat if ctx.needs_input_grad[0] else None, *grads)
+
+
+class _DeformViews(torch.autograd.Function):
+    """out [V, n, 10] = (dx | ds | dr) of the shipped deformation network for the SAME points at the V times of one mapping iteration's keyframes
+    (gaussian_renderer/__init__.py:112,149-157 call it once per keyframe): ONE autograd node for the HexPlane field of all views
+    (hexplane._HexPlaneFeaturesViews' kernels) and the MLP over all V * n rows.
+
+    Backward: most (view, Gaussian) rows of the cotangent are exactly zero -- the Gaussian is outside that view's frustum or behind saturated
+    pixels (63 % of the 8 x 500k rows at BASELINE config #3) -- and a zero row contributes nothing to any gradient. gsr_row_mask lists the
+    others; the MLP's backward runs over the list only (gsr_deform_mlp_backward_rows) and the field's backward skips the unlisted rows by
+    their view bit (gsr_hexplane_backward_views' view_mask); nothing is synchronised with the host. GSR_ROW_MASK=0 processes every row.
+
+    inputs: xyz [n, >= 3], times (tuple of floats), aabb, n_levels, then the 6 * n_levels planes, then the 14 MLP tensors (W0, b0, and
+    W1, b1, W2, b2 of the position, scale and rotation heads)."""
+
+    @staticmethod
+    def forward(ctx, xyz, times, aabb, n_levels, *tensors):
+        import hexplane as hp
+        planes, params = tensors[:6 * n_levels], tuple(p.detach().contiguous() for p in tensors[6 * n_levels:])
+        _C._require_device(xyz, "pts")
+        if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] < 3:
+            raise ValueError(f"the deformation network expects fp32 points [n, 3], got {xyz.dtype} {tuple(xyz.shape)}")
+        if xyz.stride(1) != 1:
+            xyz = xyz.contiguous()
+        V, n, dev = len(times), xyz.shape[0], xyz.device
+        levels = [[p.detach() for p in planes[6 * l:6 * l + 6]] for l in range(n_levels)]
+        in_dim = n_levels * levels[0][0].shape[1]
+        feat = torch.empty((V, n, in_dim), dtype=torch.float32, device=dev)
+        out = torch.empty((V, n, 10), dtype=torch.float32, device=dev)
+        field = hp._describe(levels, aabb)
+        tv = (ctypes.c_float * V)(*[float(t) for t in times])
+        hl, lib = hp._lib(), _lib()
+        m = _FusedDeformMLP._describe(in_dim, params)
+        with torch.cuda.device(dev):
+            rc = hl.gsr_hexplane_forward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, tv, feat.data_ptr(), _C._stream(dev))
+            if rc < 0:
+                _C._err(hl, rc, "gsr_hexplane_forward_views")
+            rc = lib.gsr_deform_mlp_forward(ctypes.byref(m), V * n, feat.data_ptr(), out.data_ptr(), _C._stream(dev))
+            if rc < 0:
+                _C._err(lib, rc, "gsr_deform_mlp_forward")
+        ctx.save_for_backward(xyz, aabb if aabb is not None else torch.empty(0), feat, *planes, *params)
+        ctx.n_levels, ctx.has_aabb, ctx.times = n_levels, aabb is not None, tv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import hexplane as hp
+        xyz, aabb, feat, *rest = ctx.saved_tensors
+        n_levels = ctx.n_levels
+        planes, params = rest[:6 * n_levels], rest[6 * n_levels:]
+        aabb = aabb if ctx.has_aabb else None
+        V, n, in_dim = feat.shape
+        dev = feat.device
+        dout = dout.contiguous()
+        hl, lib = hp._lib(), _lib()
+        stream = _C._stream(dev)
+        m = _FusedDeformMLP._describe(in_dim, params)
+        dfeat = torch.empty((V, n, in_dim), dtype=torch.float32, device=dev)         # rows that are not listed stay unwritten and are never read
+        flat_g = torch.empty((lib.gsr_deform_mlp_grad_count(in_dim),), dtype=torch.float32, device=dev)
+        ws_mlp = torch.empty((lib.gsr_deform_mlp_workspace_size(in_dim),), dtype=torch.uint8, device=dev)
+        use_mask = os.environ.get("GSR_ROW_MASK", "1") != "0" and V <= 32 and V * n < 2 ** 31
+        mask = rows = None
+        with torch.cuda.device(dev):
+            if use_mask:
+                mask = torch.empty((n,), dtype=torch.int32, device=dev)
+                rows = torch.empty((V * n + 1,), dtype=torch.int32, device=dev)       # the list, then its length
+                ws_rows = torch.empty((lib.gsr_row_mask_workspace_size(V, n),), dtype=torch.uint8, device=dev)
+                rc = lib.gsr_row_mask(V, n, 10, dout.data_ptr(), mask.data_ptr(), rows.data_ptr(), rows[V * n:].data_ptr(), ws_rows.data_ptr(), stream)
+                if rc < 0:
+                    _C._err(lib, rc, "gsr_row_mask")
+            rc = lib.gsr_deform_mlp_backward_rows(ctypes.byref(m), V * n, feat.data_ptr(), dout.data_ptr(), dfeat.data_ptr(), flat_g.data_ptr(), ws_mlp.data_ptr(),
+                                                  rows.data_ptr() if use_mask else None, rows[V * n:].data_ptr() if use_mask else None, stream)
+            if rc < 0:
+                _C._err(lib, rc, "gsr_deform_mlp_backward_rows")
+        mlp_grads, off = [], 0
+        for p in params:
+            mlp_grads.append(flat_g[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        # ---- the field, all views ----
+        levels = [[p.detach() for p in planes[6 * l:6 * l + 6]] for l in range(n_levels)]
+        need_plane = list(ctx.needs_input_grad[4:4 + 6 * n_levels])
+        sizes = [p.numel() if need else 0 for p, need in zip(planes, need_plane)]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)               # one fill for every plane gradient
+        views, o = [], 0
+        for p, need, sz in zip(planes, need_plane, sizes):
+            views.append(torch.as_strided(flat, p.shape, p.stride(), o) if need else None)
+            o += sz
+        gxyz = torch.empty((n, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        field = hp._describe(levels, aabb, [views[6 * l:6 * l + 6] for l in range(n_levels)])
+        size = hl.gsr_hexplane_backward_views_workspace_size(ctypes.byref(field), n, V)
+        if size == 0:
+            raise RuntimeError("deform_network.forward_views: plane geometry not covered by the batched field backward")
+        ws = torch.empty(size, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = hl.gsr_hexplane_backward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, ctx.times, dfeat.data_ptr(),
+                                                mask.data_ptr() if use_mask else None, gxyz.data_ptr() if gxyz is not None else None, ws.data_ptr(), stream)
+        if rc < 0:
+            _C._err(hl, rc, "gsr_hexplane_backward_views")
+        if gxyz is not None and xyz.shape[1] > 3:
+            full = torch.zeros_like(xyz)
+            full[:, :3] = gxyz
+            gxyz = full
+        return (gxyz, None, None, None, *views, *mlp_grads)
 
 
 class PointwiseLinear(nn.Linear):
@@ -247,15 +356,15 @@ class Deformation(nn.Module):
         forward_dynamic per view). The rasterizer adds the deltas to the raw parameters itself (gsr_raw_inputs.delta_mode = 1)."""
         if not self._fused_mlp_ok(points) or points.shape[0] == 0:
             return None
-        feat = self.grid.forward_views(points[:, :3], times)
-        if feat is None:
+        import hexplane as hp
+        planes = hp._PlaneList(self.grid.grids)
+        if not hp.views_supported(planes, len(times)):
             return None
-        V, n, F_ = feat.shape
         heads = (self.pos_deform, self.scales_deform, self.rotations_deform)
         params = [self.feature_out[0].weight, self.feature_out[0].bias]
         for h in heads:
             params += [h[1].weight, h[1].bias, h[3].weight, h[3].bias]
-        return _FusedDeformMLP.apply(feat.view(V * n, F_), *params).view(V, n, 10)
+        return _DeformViews.apply(points[:, :3], tuple(float(t) for t in times), self.grid.aabb, planes.n_levels, *planes.flat, *params)
 
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb):
         if self._fused_mlp_ok(rays_pts_emb):

@@ -374,6 +374,8 @@ class _RasterizeViewsNet(torch.autograd.Function):
                                         float(rs0.tanfovx), float(rs0.tanfovy), C.byref(out), scratch.data_ptr(), flags, _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_backward_views (network deltas)")
+        if os.environ.get("GSR_DEBUG_ZERO_ROWS"):            # development: how many (view, Gaussian) pairs receive no gradient at all
+            print("zero rows of the network cotangent:", float((g_net.abs().amax(dim=-1) == 0).float().mean()), flush=True)
         if own is not None:
             res = [gviews[0].view(P, 3), gviews[4].view(P, S), gviews[5].view(P, 4), gviews[3].view(logit_opacity.shape), gviews[1].view(P, 1, 3),
                    gviews[2].view(P, M - 1, 3) if M > 1 else None, g_net, None]

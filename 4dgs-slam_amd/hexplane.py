@@ -51,7 +51,7 @@ def _lib():
         lib.gsr_hexplane_backward_views_workspace_size.restype = ctypes.c_size_t
         lib.gsr_hexplane_backward_views_workspace_size.argtypes = [ctypes.POINTER(_Field), i64, ctypes.c_int]
         lib.gsr_hexplane_backward_views.restype = ctypes.c_int
-        lib.gsr_hexplane_backward_views.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, ctypes.c_int, f32p, vp, vp, vp, vp]
+        lib.gsr_hexplane_backward_views.argtypes = [ctypes.POINTER(_Field), i64, vp, i64, ctypes.c_int, f32p, vp, vp, vp, vp, vp]
         _lib_cache = lib
     return _lib_cache
 
@@ -278,7 +278,7 @@ class _HexPlaneFeaturesViews(torch.autograd.Function):
         if n:
             ws = torch.empty(size, dtype=torch.uint8, device=g.device)
             with torch.cuda.device(g.device):
-                rc = lib.gsr_hexplane_backward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, ctx.times, g.data_ptr(),
+                rc = lib.gsr_hexplane_backward_views(ctypes.byref(field), n, xyz.data_ptr(), xyz.stride(0), V, ctx.times, g.data_ptr(), None,
                                                      gxyz.data_ptr() if gxyz is not None else None, ws.data_ptr(), _C._stream(g.device))
             if rc < 0:
                 _C._err(lib, rc, "gsr_hexplane_backward_views")

@@ -84,8 +84,18 @@ size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int
 int gsr_hexplane_forward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
                                float* features, void* stream);
 size_t gsr_hexplane_backward_views_workspace_size(const gsr_hexplane_field* field, int64_t n, int V);
+/* view_mask (device, [n] or NULL): bit v of view_mask[i] clear = row (v, i) of dL_dfeatures is ZERO and is not read (it may be uninitialised
+ * memory: gsr_deform_mlp_backward_rows does not write the rows it was not given); points whose bits are all clear are left out of the sort.
+ * NULL = every row is read. gsr_row_mask below builds the mask from the network's [V][n][10] cotangent. */
 int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
-                                const float* dL_dfeatures, float* dL_dxyz, char* workspace, void* stream);
+                                const float* dL_dfeatures, const uint32_t* view_mask, float* dL_dxyz, char* workspace, void* stream);
+
+/* Which rows of a batched cotangent g [V][n][width] are not zero -- in a mapping iteration most (view, Gaussian) pairs receive no gradient at
+ * all (outside the frustum, or behind saturated pixels: 63 % at BASELINE config #3). view_mask[i] bit v = row (v, i) has a non-zero element;
+ * rows[] = the flat row indices v n + i of those rows in ascending order, n_rows[0] (DEVICE memory) their number; rows must hold V n
+ * entries. Deterministic. V <= 32, V n < 2^31; workspace: gsr_row_mask_workspace_size(V, n) bytes. */
+size_t gsr_row_mask_workspace_size(int V, int64_t n);
+int gsr_row_mask(int V, int64_t n, int width, const float* g, uint32_t* view_mask, int32_t* rows, int32_t* n_rows, char* workspace, void* stream);
 
 /* ---- weight gradient of the deformation MLP's dense layers ----------------------------------------------------------------
  * utils/deformation.py:58-70 builds the network from nn.Linear layers (width 64, inputs <= 128) applied to every point; their
@@ -120,6 +130,11 @@ size_t gsr_deform_mlp_grad_count(int in_dim);
 size_t gsr_deform_mlp_workspace_size(int in_dim);
 int gsr_deform_mlp_backward(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
                             float* grads, char* workspace, void* stream);
+/* The same over a LIST of rows (gsr_row_mask): only rows[0 .. n_rows[0]) of features / dout are read and only those rows of dfeatures are
+ * WRITTEN -- the rows of a zero cotangent contribute nothing to any gradient and their dfeatures would be zero; n_rows is read on the device
+ * (no host synchronisation). rows = n_rows = NULL: every row, as gsr_deform_mlp_backward. n = number of rows of the arrays. */
+int gsr_deform_mlp_backward_rows(const gsr_deform_mlp* mlp, int64_t n, const float* features, const float* dout, float* dfeatures,
+                                 float* grads, char* workspace, const int32_t* rows, const int32_t* n_rows, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -501,12 +501,83 @@ def test_batched_field_rejects_what_it_does_not_cover():
         assert torch.equal(out[v], hexplane.hexplane_features(pts, torch.full((10, 1), t, device=DEV), field.aabb, planar))
 
 
+@pytest.mark.parametrize("n,V,zero_frac", [(1, 1, 0.0), (5000, 3, 0.6), (40000, 12, 0.9), (3000, 8, 1.0)])
+def test_network_views_with_and_without_the_row_mask(n, V, zero_frac, monkeypatch):
+    """deform_network.forward_views (ONE autograd node: field of all views + MLP over V * n rows). Its backward lists the rows of the
+    cotangent that are not zero (gsr_row_mask), runs the MLP's backward over the list (gsr_deform_mlp_backward_rows) and lets the field skip the
+    others by their view bit: same gradients as with every row processed (GSR_ROW_MASK=0), which in turn are those of V forward_dynamic
+    calls. zero_frac 1.0: no row at all is listed."""
+    torch.manual_seed(1)
+    net = deformation.deform_network(hidden_params(multires=[1, 2], bounds=1.6), DEV).to(DEV)
+    with torch.no_grad():
+        for p_ in net.get_grid_parameters():
+            p_.copy_(torch.empty_like(p_).uniform_(0.2, 1.2))
+    g = torch.Generator(device="cpu").manual_seed(7 * n + V)
+    base = (torch.rand((n, 3), generator=g) * 3.6 - 1.8).to(DEV)
+    times = [float(t) for t in np.linspace(-0.9, 0.9, V)] if V > 1 else [0.25]
+    cot = torch.randn((V, n, 10), generator=g).to(DEV)
+    cot[(torch.rand((V, n), generator=g) < zero_frac).to(DEV)] = 0.0
+    if n > 100:
+        cot[:, :70] = 0.0                                                     # whole 64-row tiles of the list's neighbourhood, points no view lists
+    results = {}
+    for mode in ("1", "0", "per_view"):
+        monkeypatch.setenv("GSR_ROW_MASK", "0" if mode == "0" else "1")
+        pts = base.clone().requires_grad_(True)
+        for p_ in net.parameters():
+            p_.grad = None
+        if mode == "per_view":
+            zeros3, zeros4 = torch.zeros((n, 3), device=DEV), torch.zeros((n, 4), device=DEV)
+            outs = []
+            for t in times:
+                _, _, _, dx, ds, dr = net(pts, zeros3, zeros4, None, None, torch.full((n, 1), t, device=DEV))
+                outs.append(torch.cat((dx, ds, dr), dim=1))
+            out = torch.stack(outs)
+        else:
+            out = net.forward_views(pts, times)
+        assert out is not None and out.shape == (V, n, 10)
+        (out * cot).sum().backward()
+        results[mode] = (out.detach(), {"pts": pts.grad.clone(), **{k: p_.grad.clone() for k, p_ in net.named_parameters() if p_.grad is not None}})
+    assert torch.equal(results["1"][0], results["0"][0]) and rel(results["1"][0], results["per_view"][0]) < 1e-6
+    for other, tol in (("0", 2e-6), ("per_view", 1e-4)):
+        ga, gb = results["1"][1], results[other][1]
+        assert set(ga) == set(gb)
+        for k in gb:
+            if float(gb[k].abs().max()) == 0.0:
+                assert float(ga[k].abs().max()) == 0.0, (other, k)
+            else:
+                assert rel(ga[k], gb[k]) < tol, (other, k, rel(ga[k], gb[k]))
+
+
+def test_row_mask_lists_the_nonzero_rows_in_order():
+    """gsr_row_mask against torch: view bits per point, the flat indices of the non-zero rows in ascending order, their count on the device."""
+    import ctypes
+    lib = deformation._lib()
+    for V, n, width in ((1, 1, 10), (3, 1000, 10), (12, 70001, 10), (32, 257, 4)):
+        g = torch.randn((V, n, width), device=DEV)
+        g[torch.rand((V, n), device=DEV) < 0.7] = 0.0
+        g[0, 0] = 0.0
+        g[V - 1, n - 1, width - 1] = 1.0                                       # a row whose only non-zero element is its last
+        mask = torch.empty((n,), dtype=torch.int32, device=DEV)
+        rows = torch.full((V * n + 1,), -7, dtype=torch.int32, device=DEV)
+        ws = torch.empty((lib.gsr_row_mask_workspace_size(V, n),), dtype=torch.uint8, device=DEV)
+        rc = lib.gsr_row_mask(V, n, width, g.data_ptr(), mask.data_ptr(), rows.data_ptr(), rows[V * n:].data_ptr(), ws.data_ptr(), None)
+        assert rc == 0
+        nz = (g != 0).any(dim=-1)                                               # [V, n]
+        want = nz.flatten().nonzero().flatten().to(torch.int32)
+        assert int(rows[V * n]) == want.numel() and torch.equal(rows[:want.numel()], want)
+        bits = sum((nz[v].to(torch.int64) << v) for v in range(V))
+        assert torch.equal(mask.to(torch.int64) & 0xFFFFFFFF, bits)
+    assert lib.gsr_row_mask(33, 10, 10, g.data_ptr(), mask.data_ptr(), rows.data_ptr(), rows.data_ptr(), ws.data_ptr(), None) < 0
+
+
+@pytest.mark.parametrize("row_mask", ["1", "0"])
 @pytest.mark.parametrize("iso", [False, True])
-def test_render_views_dynamic_equals_per_camera_render_dynamic(iso):
+def test_render_views_dynamic_equals_per_camera_render_dynamic(iso, row_mask, monkeypatch):
     """render_views(dynamic=True): ONE evaluation of the deformation network for all cameras' times + the multi-view rasterizer with the
     network's output as deltas in front of the activations (gsr_raw_inputs.delta_mode = 1, delta_stride = 10) against one
-    render(dynamic=True) per camera. Run twice: the first call of a view slot goes through the single-view kernels inside gsr_forward_views,
-    the second through the batched ones."""
+    render(dynamic=True) per camera, with the backward's row list on and off. Run twice: the first call of a view slot goes through the
+    single-view kernels inside gsr_forward_views, the second through the batched ones."""
+    monkeypatch.setenv("GSR_ROW_MASK", row_mask)
     import types
     import gaussian_renderer
     from synthetic_scene import keyframe_pose
