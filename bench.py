@@ -597,6 +597,20 @@ def main():
             out["config5"]["view_by_view_ms_per_step"] = t5v * 1e3
             del s5, sms
             torch.cuda.empty_cache()
+        # ---- secondary: BASELINE config #3 (500k Gaussians + the HexPlane deformation network, 8 keyframes, pose gradients) on this one GPU ----
+        if world == 1 and workload == "cfg2" and not args.no_secondary:
+            note("secondary: config #3 iteration (deformation network, 8 keyframes)")
+            try:
+                from tools.bench_config3 import measure as measure_config3
+                c3 = measure_config3(["fused", "batched"], iters=3)
+                out["config3"] = {"workload": "configs[2]: " + c3["workload"] + "; `batched`: the keyframes of the iteration through the deformation "
+                                              "producer and the multi-view rasterizer at once (render_views(dynamic=True)), `per_view`: one render(dynamic=True) "
+                                              "per keyframe (rounds 1-4)",
+                                  "ms_per_step": c3["batched_ms_per_iteration"], "value": c3["batched_gaussian_views_per_s"], "unit": "Gaussian-views/s", "steps": 3,
+                                  "per_view_ms_per_step": c3["fused_ms_per_iteration"], "peak_memory_GB": c3["peak_memory_GB"]}
+            except Exception as e:      # the headline line must not depend on the secondary
+                out["config3"] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
     else:   # ---- cfg5 -------------------------------------------------------------------------------------------------------
         P = args.gaussians or CFG5_P
         kfs = list(range(args.keyframes))

@@ -111,3 +111,66 @@ def test_randomised_scene_sweep_exact_build_has_no_discrete_mismatch():
                 assert r["radii"] == 0 and r["n_touched"] == 0, r
             else:
                 assert r["radii"] <= 1 and r["n_touched"] <= max(3, 2e-3 * r["P"]), r
+
+
+VIEWS_DYNAMIC = r'''
+import json, os, sys, types
+sys.path[:0] = [os.path.join(r"{repo}", "tests"), r"{repo}", os.path.join(r"{repo}", "4dgs-slam_amd")]
+import numpy as np, torch
+import deformation, gaussian_renderer as gr
+from synthetic_scene import keyframe_pose, GaussianModelStub, camera_namespace
+from util import make_camera, make_gaussians
+P, W, H, V = 60000, 320, 240, 4
+pipe = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False)
+bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
+torch.manual_seed(0)
+net = deformation.deform_network(deformation.default_hidden_params(bounds=8.0, multires=[1, 2]), "cuda").to("cuda")
+with torch.no_grad():
+    for p_ in net.get_grid_parameters():
+        p_.mul_(0.05)
+g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
+def run(batched):
+    pc = GaussianModelStub(g, False, 0.0, seed=2); pc._deformation = net
+    views = []
+    for k in range(V):
+        R_w, t_w = keyframe_pose(k)
+        v = camera_namespace(make_camera(W, H, R=R_w, t=t_w)); v.time = k / (V - 1) * 2 - 1
+        views.append(v)
+    outs = gr.render_views(views, pc, pipe, bg, dynamic=True) if batched else [gr.render(v, pc, pipe, bg, dynamic=True) for v in views]
+    assert isinstance(outs[0], gr._RenderPackage) == batched
+    (sum((o["render"] * (1 + 0.1 * k)).mean() + 0.1 * o["depth"].mean() for k, o in enumerate(outs))).backward()
+    return outs, pc, views
+o0, p0, v0 = run(False)
+res = dict(image=0.0, depth=0.0, m2d=0.0, pose=0.0, xyz=0.0)
+for attempt in range(2):
+    o1, p1, v1 = run(True)
+    for k in range(V):
+        res["image"] = max(res["image"], float((o1[k]["render"] - o0[k]["render"]).abs().max()))
+        res["depth"] = max(res["depth"], float((o1[k]["depth"] - o0[k]["depth"]).abs().max()))
+        res["m2d"] = max(res["m2d"], float((o1[k]["viewspace_points"].grad - o0[k]["viewspace_points"].grad).abs().max()))
+        res["pose"] = max(res["pose"], float((v1[k].cam_trans_delta.grad - v0[k].cam_trans_delta.grad).abs().max()),
+                          float((v1[k].cam_rot_delta.grad - v0[k].cam_rot_delta.grad).abs().max()))
+    res["xyz"] = max(res["xyz"], float(((p1._xyz.grad - p0._xyz.grad).abs().sum() / p0._xyz.grad.abs().sum())))
+print("RESULT " + json.dumps(res))
+'''
+
+
+def test_network_deltas_in_the_kernels_are_bit_identical_to_pre_added_parameters_in_the_exact_build():
+    """render_views(dynamic=True) hands the deformation network's output to the rasterizer as deltas IN FRONT of the activations
+    (gsr_raw_inputs.delta_mode = 1); one render(dynamic=True) per camera adds them in torch and passes the sums as raw parameters. The two are
+    the same arithmetic -- in the exact-math build (no fp contraction) images, depth, screen-space and pose gradients are bit-identical. The
+    default build instantiates the delta kernels separately and hipcc contracts a*b+c differently there: ~1e-7 relative per Gaussian, isolated
+    pixels up to a few 1e-4 where a Gaussian's cut-off flips, which is why the fast-build tests compare with tolerances."""
+    env = dict(os.environ)
+    env.pop("GSR_LIB", None)
+    out = {}
+    for exact in ("1", "0"):
+        env["GSR_EXACT_MATH"] = exact
+        r = subprocess.run([sys.executable, "-c", VIEWS_DYNAMIC.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[exact] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    print(out)
+    ex, fast = out["1"], out["0"]
+    assert ex["image"] == 0.0 and ex["depth"] == 0.0 and ex["m2d"] == 0.0 and ex["pose"] == 0.0, ex
+    assert ex["xyz"] <= 1e-6, ex                                   # (the network's input gradient: the field's sums regroup)
+    assert fast["image"] <= 2e-3 and fast["xyz"] <= 1e-4, fast
