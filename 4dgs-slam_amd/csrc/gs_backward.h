@@ -232,7 +232,12 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     const ShOut dsh = RAW ? ShOut{RG.f_dc + 3 * o, RG.f_rest ? RG.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0}
                                 : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0};
     if (!visible) {
-        if (has_sh && in_range && !a.accumulate && !a.pose_only) for (int k = 0; k < a.M * 3; k++) dsh[k] = 0.f;
+        // (plain stores, not dsh[k] with a run-time k: that indexed dsh.old_dc dynamically and sent the whole struct to scratch memory -- the
+        // 48 bytes per lane this kernel carried for three rounds)
+        if (has_sh && in_range && !a.accumulate && !a.pose_only) {
+            dsh.dc[0] = 0.f; dsh.dc[1] = 0.f; dsh.dc[2] = 0.f;
+            for (int k = 3; k < a.M * 3; k++) dsh.rest[k - 3] = 0.f;
+        }
     } else {
         const float* vm = a.viewmatrix;
 
@@ -345,7 +350,7 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/ddir
             const int deg = a.D;
             const int used = (deg + 1) * (deg + 1);
-            if (!a.accumulate) for (int k = used * 3; k < a.M * 3; k++) dsh[k] = 0.f;
+            if (!a.accumulate && !a.pose_only) for (int k = used * 3; k < a.M * 3; k++) dsh.rest[k - 3] = 0.f;   // bands above the active degree (k >= 3: plain stores, see above)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float g = dRGB[k];

@@ -320,7 +320,7 @@ struct ShOut {
     };
     __device__ __forceinline__ Ref operator[](int k) const
     {
-        return k < 3 ? Ref{dc + k, acc, old_dc[k], true, skip} : Ref{rest + (k - 3), acc, 0.f, false, skip};
+        return k < 3 ? Ref{dc + k, acc, old_dc[k], true, skip} : Ref{rest + (k - 3), acc, 0.f, false, skip};   // k: a compile-time constant at every call site
     }
 };
 

@@ -499,7 +499,7 @@ rasterize_views_forward(const torch::Tensor& background, const torch::Tensor& xy
                         const c10::optional<torch::Tensor>& dyn_slot_, const TensorVec& view, const TensorVec& proj, const TensorVec& proj_raw,
                         const TensorVec& campos, const OptVec& dx, const OptVec& ds, const OptVec& dr, const OptVec& flow_dx2, const OptVec& flow_proj1,
                         const OptVec& flow_proj2, double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W, int64_t degree, bool debug,
-                        int64_t stream)
+                        int64_t stream, const OptVec& flow_clips)
 {
     TORCH_CHECK(xyz_.dim() == 2 && xyz_.size(1) == 3 && xyz_.size(0) > 0 && xyz_.is_cuda(), "_xyz must be a (num_points > 0, 3) tensor on a HIP device");
     const int V = (int)view.size(), P = (int)xyz_.size(0);
@@ -523,6 +523,11 @@ rasterize_views_forward(const torch::Tensor& background, const torch::Tensor& xy
         w.out_color = base; w.out_depth = base + (size_t)kChannels * H * W; w.out_opacity = base + (size_t)(kChannels + 1) * H * W;
         w.radii = ints.data_ptr<int>() + (size_t)v * 2 * P; w.n_touched = w.radii + P;
         w.geometry_user = &state[3 * (size_t)v]; w.binning_user = &state[3 * (size_t)v + 1]; w.image_user = &state[3 * (size_t)v + 2];
+        if ((size_t)v < flow_clips.size() && flow_clips[(size_t)v].has_value() && flow_clips[(size_t)v]->defined()) {   // gsr_view.flow_clip: int32 [4] on the device
+            const torch::Tensor& c = *flow_clips[(size_t)v];
+            TORCH_CHECK(c.is_cuda() && c.scalar_type() == torch::kInt32 && c.numel() == 4 && c.is_contiguous(), "flow clip: int32 [4] contiguous device tensor");
+            w.flow_clip = c.data_ptr<int>();
+        }
     }
     const int rc = gsr_forward_views(V, views.data(), resize_cb, resize_cb, resize_cb, P, (int)degree, M, fptr(bg, "bg"), (int)W, (int)H, &in, (float)scale_modifier,
                                      (float)tan_fovx, (float)tan_fovy, debug ? 1 : 0, reinterpret_cast<void*>(stream));

@@ -28,7 +28,7 @@ class _View(C.Structure):       # gsr_view
                 ("geometry_user", _vp), ("binning_user", _vp), ("image_user", _vp),
                 ("geom_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("num_rendered", _i),
                 ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dmean2D", _vp), ("ddx", _vp), ("dds", _vp), ("ddr", _vp), ("dL_dtau_sum", _vp),
-                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp), ("ddx2", _vp)]
+                ("flow_dx2", _vp), ("flow_proj1", _vp), ("flow_proj2", _vp), ("ddx2", _vp), ("flow_clip", _vp)]
 
 
 _declared = False
@@ -98,7 +98,7 @@ class _RasterizeViewsRaw(torch.autograd.Function):
                 img, ints, rendered, state = glue.rasterize_views_forward(
                     rs0.bg, xyz, log_scales, raw_rot, logit_opacity, f_dc, f_rest if (f_rest is not None and f_rest.numel()) else None, dyn_slot, *cams,
                     [per_view[6 * v + 1] for v in range(V)], [per_view[6 * v + 2] for v in range(V)], [per_view[6 * v + 3] for v in range(V)], [], [], [],
-                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, int(rs0.sh_degree), bool(rs0.debug), _C._stream(dev))
+                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, int(rs0.sh_degree), bool(rs0.debug), _C._stream(dev), [])
             ctx.num_rendered = [int(r) for r in rendered]
             deltas = [per_view[6 * v + k] for v in range(V) for k in (1, 2, 3)]
             ctx.n_state = len(state)
@@ -414,13 +414,18 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
     d_scaling1, d_rotation1 per view."""
 
     @staticmethod
-    def forward(ctx, xyz, log_scales, raw_rot, logit_opacity, dyn_slot, settings, *per_view):
+    def forward(ctx, xyz, log_scales, raw_rot, logit_opacity, dyn_slot, settings, clips, *per_view):
         _C._require_device(xyz, "_xyz")
         lib = _lib()
         dev, V = xyz.device, len(settings)
         rs0 = settings[0]
         P, H, W = int(xyz.shape[0]), int(rs0.image_height), int(rs0.image_width)
         ctx.settings, ctx.V = settings, V
+        clips = list(clips) if clips is not None else [None] * V      # per view: int32 [4] device tensor (gsr_view.flow_clip) or None
+        for c in clips:
+            if c is not None and not (isinstance(c, torch.Tensor) and c.is_cuda and c.dtype == torch.int32 and c.numel() == 4 and c.is_contiguous()):
+                raise ValueError("flow clips: int32 [4] contiguous device tensors (or None)")
+        ctx.clips = clips                                             # the kernels of a captured call keep reading these addresses
         ctx.set_materialize_grads(False)
         glue = _glue()
         if glue is not None:
@@ -428,7 +433,7 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
             with torch.cuda.device(dev):
                 img, ints, rendered, state = glue.rasterize_views_forward(
                     rs0.bg, xyz, log_scales, raw_rot, logit_opacity, None, None, dyn_slot, *_camera_lists(settings), col(1), col(3), col(4), col(2), col(5), col(6),
-                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, 0, bool(rs0.debug), _C._stream(dev))
+                    float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, 0, bool(rs0.debug), _C._stream(dev), clips)
             ctx.num_rendered = [int(r) for r in rendered]
             ctx.n_state = len(state)
             ctx.save_for_backward(xyz, log_scales, raw_rot, logit_opacity, dyn_slot, ints, *state, *[per_view[7 * v + k] for v in range(V) for k in range(1, 7)])
@@ -452,6 +457,7 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
             w.projmatrix_raw, w.cam_pos = _f32(rs.projmatrix_raw, "projmatrix_raw", keep), _f32(rs.campos, "campos", keep)
             w.dx, w.ds, w.dr = _f32(dx1, "d_xyz1", keep), _f32(ds, "d_scaling1", keep), _f32(dr, "d_rotation1", keep)
             w.flow_dx2, w.flow_proj1, w.flow_proj2 = _f32(dx2, "d_xyz2", keep), _f32(proj1, "proj1", keep), _f32(proj2, "proj2", keep)
+            w.flow_clip = clips[v].data_ptr() if clips[v] is not None else None
             w.out_color, w.out_depth = img[v, :_C.NUM_CHANNELS].data_ptr(), img[v, _C.NUM_CHANNELS:_C.NUM_CHANNELS + 1].data_ptr()
             w.out_opacity, w.radii, w.n_touched = img[v, _C.NUM_CHANNELS + 1:].data_ptr(), ints[v, 0].data_ptr(), ints[v, 1].data_ptr()
             hs = [{"dev": dev, "t": None} for _ in range(3)]
@@ -499,7 +505,7 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
                     rs0.bg, xyz, log_scales, raw_rot, logit_opacity, None, None, dyn_slot, *_camera_lists(settings), col(0), col(2), col(3), col(1), col(4), col(5),
                     float(rs0.scale_modifier), float(rs0.tanfovx), float(rs0.tanfovy), H, W, 0, ints, list(state), ctx.num_rendered,
                     [cot(grads[5 * v], 3) for v in range(V)], [cot(grads[5 * v + 2], 1) for v in range(V)], [], False, False, bool(rs0.debug), _C._stream(dev))
-            res = [pg[0], None, None, None, None, None]
+            res = [pg[0], None, None, None, None, None, None]
             for v in range(V):
                 res += [per_view_out[v, :P * 3].view(P, 3), dl[4 * v], dl[4 * v + 1], dl[4 * v + 2], dl[4 * v + 3], None, None]
             return tuple(res)
@@ -535,16 +541,17 @@ class _RasterizeFlowViewsRaw(torch.autograd.Function):
                                         float(rs0.tanfovx), float(rs0.tanfovy), C.byref(out), scratch.data_ptr(), int(bool(rs0.debug)), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_backward_views (flow)")
-        res = [g_xyz, None, None, None, None, None]
+        res = [g_xyz, None, None, None, None, None, None]
         for v in range(V):
             gd1, gd2, gds, gdr = zero[4 * v: 4 * v + 4]
             res += [per_view_out[v, :P * 3].view(P, 3), gd1, gd2, gds, gdr, None, None]
         return tuple(res)
 
 
-def rasterize_flow_views_raw(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, dyn_slot, flows):
+def rasterize_flow_views_raw(settings, xyz, means2D, log_scales, raw_rotations, logit_opacity, dyn_slot, flows, clips=None):
     """flows[v] = (d_xyz1, d_xyz2, d_scaling1, d_rotation1, proj1, proj2) of the v-th (camera 1 -> camera 2) pair; settings[v] describes
-    camera 1 (bg = 0, sh_degree 0). Returns the tuples raw.rasterize_flow_raw returns, one per pair."""
+    camera 1 (bg = 0, sh_degree 0). clips[v]: None or an int32 [4] device tensor, the tile rectangle [x0, y0, x1, y1) the caller reads of that
+    image (gsr_view.flow_clip). Returns the tuples raw.rasterize_flow_raw returns, one per pair."""
     V = len(settings)
     if xyz.shape[0] == 0:
         raise RuntimeError("rasterize_flow_views_raw: empty model")
@@ -554,7 +561,7 @@ def rasterize_flow_views_raw(settings, xyz, means2D, log_scales, raw_rotations, 
     for v in range(V):
         dx1, dx2, ds, dr, proj1, proj2 = flows[v]
         flat += [means2D[v], dx1, dx2, ds, dr, proj1, proj2]
-    outs = _RasterizeFlowViewsRaw.apply(xyz, log_scales, raw_rotations, logit_opacity, dyn_slot, list(settings), *flat)
+    outs = _RasterizeFlowViewsRaw.apply(xyz, log_scales, raw_rotations, logit_opacity, dyn_slot, list(settings), clips, *flat)
     return [tuple(outs[5 * v: 5 * v + 5]) for v in range(V)]
 
 

@@ -334,7 +334,8 @@ def render_flow_views(pc, requests, scaling_modifier=1.0, clips=None):
     the fused route available they go through the multi-view entry point in groups of up to views.MAX_VIEWS (one launch per pipeline
     stage per group), otherwise one render_flow call each. ``clips``: per request None or an int32 [4] device tensor, the tile rectangle
     [x0, y0, x1, y1) the caller will read of that image (its loss mask's bounding box): Gaussians outside it are culled on the batched route
-    (gsr_set_flow_clips; pixels inside the rectangle and the gradients of a loss confined to them are unchanged)."""
+    (gsr_view.flow_clip -- an argument of the call, nothing is left behind if it raises; pixels inside the rectangle and the gradients of a loss
+    confined to them are unchanged)."""
     requests = list(requests)
     single = lambda: [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in requests]
     if (len(requests) < 2 or _views is None or os.environ.get("GSR_MULTI_VIEW", "1") == "0" or not _flow_fused_ok(pc) or pc.get_xyz.shape[0] == 0
@@ -349,21 +350,19 @@ def render_flow_views(pc, requests, scaling_modifier=1.0, clips=None):
         # (the chunks of one iteration keep separate capacity estimates per view: include/gs_rasterizer.h "view_slot_group")
         group_before = _views._C.set_option("view_slot_group", lo // _views.MAX_VIEWS)
         try:
-            if clips is not None and len(part) > 1 and _views.views_supported(rs):
-                _views._C.set_flow_clips(list(clips[lo:lo + _views.MAX_VIEWS]))
-            out += _render_flow_chunk(pc, part, rs, slot, scaling_modifier)
+            out += _render_flow_chunk(pc, part, rs, slot, scaling_modifier, None if clips is None else list(clips[lo:lo + _views.MAX_VIEWS]))
         finally:
             _views._C.set_option("view_slot_group", group_before)
     return out
 
 
-def _render_flow_chunk(pc, part, rs, slot, scaling_modifier):
+def _render_flow_chunk(pc, part, rs, slot, scaling_modifier, clips=None):
     if len(part) == 1 or not _views.views_supported(rs):           # (cameras of different size / field of view: one call each)
         return [render_flow(pc, c1, c2, dx1, dx2, dr1, ds1, scaling_modifier=scaling_modifier) for c1, c2, dx1, dx2, dr1, ds1 in part]
     block = torch.zeros((len(part),) + tuple(pc.get_xyz.shape), dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
     points = [block[v].requires_grad_(True) for v in range(len(part))]
     flows = [(dx1, dx2, ds1, dr1, c1.full_proj_transform, (c2 if c2 is not None else c1).full_proj_transform) for c1, c2, dx1, dx2, dr1, ds1 in part]
-    res = _views.rasterize_flow_views_raw(rs, pc._xyz, points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, flows)
+    res = _views.rasterize_flow_views_raw(rs, pc._xyz, points, pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach(), slot, flows, clips=clips)
     return [_RenderPackage({"render": o[0], "depth": o[2], "alpha": o[3], "viewspace_points": pts, "radii": o[1]}) for o, pts in zip(res, points)]
 
 

@@ -46,7 +46,7 @@ from .mapping_graph import N_INDEX_WORDS
 # of a call) the moving object's Gaussians can swell and pile up for a few iterations -- measured: instance counts +10 %, the longest tile
 # list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
 CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
-FLOW_CLIPS = os.environ.get("GSR_FLOW_CLIPS", "1") != "0"      # render the flow images only where the flow loss reads them (gsr_set_flow_clips)
+FLOW_CLIPS = os.environ.get("GSR_FLOW_CLIPS", "1") != "0"      # render the flow images only where the flow loss reads them (gsr_view.flow_clip)
 FLOW_TARGET_BUDGET_FRACTION = 0.03  # ... and at most this share of the device memory free when the first target is formed
 FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (~7 MB each at 640x480); dropped ones are formed again on demand
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
@@ -160,7 +160,7 @@ class DynamicMapping:
 
     def flow_clip(self, v):
         """The tile rectangle [x0, y0, x1, y1) (16-pixel tiles) around keyframe v's MOVING pixels -- all its flow loss reads of the flow image
-        rendered from v -- as an int32 [4] device tensor (gsr_set_flow_clips); one host read per keyframe, kept."""
+        rendered from v -- as an int32 [4] device tensor (gsr_view.flow_clip); one host read per keyframe, kept."""
         cache = self.be.__dict__.setdefault("_flow_clips", {})
         hit = cache.get(v.uid)
         if hit is None:

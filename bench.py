@@ -214,6 +214,32 @@ def committed_issue():
                       "mean_waves_per_simd": der.get("mean_waves_per_simd"), "valu_busy_2cycle_view": der.get("valu_busy_2cycle_view"),
                       "wave_instructions_per_wave": {n: ipw.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
                       "waves": e.get("SQ_WAVES")}
+        # the fraction of the ISSUE roof the kernel runs at: wave-instructions per SIMD x the cycles one of them costs a SIMD at the measured
+        # occupancy (profiles/r02_ubench_issue.json, independent v_fma_f32: 8.5 / 4.25 / 3.0 / 2.42 cycles at 1 / 2 / 3 / 4 waves per SIMD,
+        # interpolated) / the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs) -- the binding roof of the tile kernels, next to the HBM `frac`
+        try:
+            ub = json.load(open(os.path.join(REPO, "profiles", "r02_ubench_issue.json")))
+            cpi = next(r for r in ub["results"] if r["op"].startswith("v_fma_f32 independent"))["cycles_per_wave_instruction_per_simd"]
+            table = sorted((float(k.split()[0]), float(v)) for k, v in cpi.items())
+            def cycles_per_instruction(occ):
+                occ = min(max(occ, table[0][0]), table[-1][0])
+                for (x0, y0), (x1, y1) in zip(table, table[1:]):
+                    if x0 <= occ <= x1:
+                        return y0 + (y1 - y0) * (occ - x0) / (x1 - x0)
+                return table[-1][1]
+            for k in ("render_fwd", "render_bwd"):
+                e = d["kernels"].get(k, {})
+                n_instr = sum(e.get(c, 0) or 0 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"))
+                cycles = (e.get("GRBM_GUI_ACTIVE") or 0) / 8.0
+                occ = out[k].get("mean_waves_per_simd")
+                if n_instr and cycles and occ:
+                    c = cycles_per_instruction(float(occ))
+                    out[k]["issue_frac"] = n_instr / 1024.0 * c / cycles
+                    out[k]["issue_frac_inputs"] = {"wave_instructions_per_simd": n_instr / 1024.0, "cycles_per_wave_instruction_at_occupancy": c, "kernel_cycles": cycles}
+            if "issue_frac" in out.get("render_bwd", {}):
+                out["frac"] = out["render_bwd"]["issue_frac"]          # roofline.issue.frac: the dominant kernel's
+        except Exception:
+            pass
         # (quadrant, Gaussian) pairs per wave from the cycle-accounting build of the same sources, when it was collected with them
         pc = f.replace("_tile_kernel_counters.json", "_phase_cycles.json")
         try:
@@ -564,12 +590,18 @@ def main():
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                              "algorithmic_bytes_per_launch": b_dom, "kernel_us": dom_s * 1e6,
                              "whole_step_algorithmic_bytes": b_total, "whole_step_GBps": b_total / (dt / args.steps) / 1e9,
-                             "pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None,
+                             # nominal: every instance x the 256 pixels of its tile; the kernel EVALUATES the (quadrant, Gaussian) pairs its ballots
+                             # let through (issue.render_bwd.pairs_per_wave x waves x 64 lanes: ~37 % of the nominal count at config #2)
+                             "nominal_pair_evals_per_s_bwd": nr * 256 / dom_s if dom_s > 0 else None,
                              "issue": committed_issue() if workload == "cfg2" and P == CFG2_P else None,
                              "note": "the tile kernels are instruction-issue bound, not HBM bound (DESIGN.md 4; `issue` carries the counters that say so): frac is "
                                      "reported against the HBM roof because north_star asks for it"},
                 "kernel_us": kern,
             }
+            iss = out["roofline"].get("issue") or {}
+            rb = iss.get("render_bwd") or {}
+            if rb.get("pairs_per_wave") and rb.get("waves") and dom_s > 0:
+                out["roofline"]["evaluated_pair_evals_per_s_bwd"] = rb["pairs_per_wave"] * rb["waves"] * 64 / dom_s
             if nospec is not None:
                 out["ms_per_step_nonspeculative"] = nospec * 1e3
             if world == 1 and not args.no_secondary:
@@ -626,6 +658,14 @@ def main():
         dt = reduce_max(timed(step, args.steps, 0, barrier))
         _C.profile_enable(False)
         dom_ms, dom_calls = _C.profile_read()["render_bwd"]
+        # what every rank holds after the timed steps (sum of |parameter|, float64): equal on all ranks if the exchange kept them in step, and --
+        # same seeds, same step count -- equal between the all-reduce and the reduce-scatter exchange up to summation order
+        param_digests = None
+        if world > 1:
+            mine_d = torch.stack([p.detach().double().abs().sum() for p in scene.params]).sum().reshape(1)
+            every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(every, mine_d)
+            param_digests = [float(t.item()) for t in every]
         kern = kernel_breakdown(step, reps=1)
         # all-reduce alone (gradients already in the bucket): exposed once per step
         ar_ms = None
@@ -667,7 +707,7 @@ def main():
                 "value": P * len(kfs) * args.steps / dt, "unit": "Gaussian-views/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "ranks_seen": ranks_seen, "allreduce_ms": ar_ms, "two_piece_exchange_ms_per_step": two_piece_ms,
+                "ranks_seen": ranks_seen, "allreduce_ms": ar_ms, "two_piece_exchange_ms_per_step": two_piece_ms, "param_digests": param_digests,
                 "exchange": args.exchange, f"{other}_exchange_ms_per_step": other_ms,
                 "multi_view": bool(multi_view), "views_per_call": getattr(scene, "views_per_call", 1),
                 "config": {"workload": f"configs[4]: {P} Gaussians, {len(kfs)} synthetic keyframes @{WIDTH}x{HEIGHT} sharded {world}-way ({len(sms.keyframes)} views per rank, "

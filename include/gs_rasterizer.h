@@ -209,17 +209,21 @@ typedef struct gsr_view {
      * background; features_dc of the shared descriptor may be NULL. In gsr_backward_views only out->xyz is required then (the other
      * parameters are constants of render_flow); ddx2 [K,3] receives the gradient of flow_dx2 (may be NULL). */
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2; float* ddx2;
+    /* flow views whose caller only reads part of the image (the flow loss of utils/slam_backend.py:479-509 is masked to the keyframe's moving
+     * pixels): DEVICE pointer to four ints, the tile rectangle [x0, y0, x1, y1) (16-pixel tiles, half open) this view is read in, or NULL = the
+     * whole image. A Gaussian's tile rectangle is clipped to it (no instance in a tile outside; none at all -- radius 0, no gradient -- when
+     * nothing is left): every pixel inside the rectangle is unchanged, bit for bit, and every gradient of a loss that only reads such pixels up
+     * to the order in which a Gaussian's (now fewer) instance slots are added (~1e-9 relative); pixels outside are undefined (whatever the
+     * remaining Gaussians leave). The pointer is read by the kernels: a captured call keeps reading the same address on replay. */
+    const int* flow_clip;
 } gsr_view;
 int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc,
                       int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier,
                       float tan_fovx, float tan_fovy, int debug, void* stream);
-/* Flow views whose caller only reads part of the image (the flow loss of utils/slam_backend.py:479-509 is masked to the keyframe's moving
- * pixels): clips[v] = DEVICE pointer to four ints, the tile rectangle [x0, y0, x1, y1) (16-pixel tiles, half open) that view v is read in, or
- * NULL. Applies to the NEXT flow call of gsr_forward_views on this thread and is consumed by it. A Gaussian's tile rectangle is clipped to
- * it (no instance in a tile outside; none at all -- radius 0, no gradient -- when nothing is left): every pixel inside the rectangle is
- * unchanged, bit for bit, and every gradient of a loss that only reads such pixels up to the order in which a Gaussian's (now fewer)
- * instance slots are added (~1e-9 relative); pixels outside are undefined (whatever the remaining Gaussians leave).
- * The pointers are read by the kernels: a captured call keeps reading the same addresses on replay. */
+/* DEPRECATED in favour of gsr_view.flow_clip (round 4's interface, kept for callers that fill gsr_view without that field): clips[v] for the NEXT
+ * gsr_forward_views call of this thread, used for a view whose own flow_clip is NULL. The pending clips are taken and cleared at the very top of
+ * EVERY gsr_forward_views call -- flow or not, valid arguments or not -- so that a call that fails, or a caller that raises between the two
+ * calls, cannot leave rectangles behind for an unrelated later batch. */
 int gsr_set_flow_clips(int V, const int* const* clips);
 /* scratch: device memory of gsr_views_scratch_size() bytes (one row of parameter gradients per view); not needed with GSR_BACKWARD_POSE_ONLY */
 size_t gsr_views_scratch_size(int V, int P, int M, int scale_dim);

@@ -258,12 +258,14 @@ def test_config5_shape_2m_gaussians_one_shard():
     assert torch.equal(color2, outs[0])
 
 
-def _run_bench(extra, nproc=2, port=29617):
+def _run_bench(extra, nproc=2, port=29617, rccl=False):
     import json
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSR_BENCH_DEVICE="0", GSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if rccl:                                # one GPU per rank, backend "nccl" (= RCCL): what the driver's scaling run uses
+        env.pop("GSR_BENCH_DEVICE"), env.pop("GSR_DIST_BACKEND")
     if nproc > 1 and port is not None:     # as torch.distributed.run launches it ...
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(nproc)] + extra
@@ -276,6 +278,22 @@ def _run_bench(extra, nproc=2, port=29617):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (dormant on the 1-GPU test boxes)")
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` with one GPU per rank over RCCL (backend "nccl"): both ranks take part, the collective is timed, every rank
+    holds the same parameters after the steps, and the two exchanges -- one all-reduce of the gradient bucket, or reduce-scatter -> Adam on the
+    local slice -> all-gather of the parameters (utils/slam_backend.py:357,526,657,768-771 is the loop being sharded) -- leave the
+    same parameters. Skipped where only one GPU is visible; the gloo twin on one GPU is the test below."""
+    common = ["--steps", "2", "--warmup", "1", "--gaussians", "60000", "--keyframes", "8", "--no-cpu-baseline", "--no-secondary"]
+    a = _run_bench(common, nproc=2, port=None, rccl=True)
+    assert a["n_gpus"] == 2 and a["ranks_seen"] == [0, 1] and a["allreduce_ms"] > 0 and a["exchange"] == "all_reduce" and a["value"] > 0
+    assert len(a["param_digests"]) == 2 and a["param_digests"][0] == a["param_digests"][1]
+    b = _run_bench(common + ["--exchange", "reduce_scatter"], nproc=2, port=29621, rccl=True)
+    assert b["ranks_seen"] == [0, 1] and b["exchange"] == "reduce_scatter" and b["param_digests"][0] == b["param_digests"][1]
+    assert abs(a["param_digests"][0] - b["param_digests"][0]) <= 1e-7 * abs(a["param_digests"][0])
 
 
 @pytest.mark.gpu
@@ -302,6 +320,8 @@ def test_bench_multi_rank_code_paths_on_one_gpu():
     assert d["ranks_seen"] == [0, 1] and "Gaussian-views/s" in d["metric"] and d["unit"] == "Gaussian-views/s"
     assert abs(d["speedup_vs_n1"] - d["n1_reference"]["ms_per_step"] / d["ms_per_step"]) < 1e-9 and abs(d["efficiency"] - d["speedup_vs_n1"] / 2) < 1e-9
     assert d["allreduce_ms"] > 0 and d["two_piece_exchange_ms_per_step"] > 0
+    assert len(d["param_digests"]) == 2 and d["param_digests"][0] == d["param_digests"][1]          # both ranks hold the same parameters
+    assert r["param_digests"][0] == r["param_digests"][1] and abs(r["param_digests"][0] - d["param_digests"][0]) <= 1e-7 * abs(d["param_digests"][0])
     w = _run_bench(["--steps", "3", "--warmup", "1", "--gaussians", "20000", "--workload", "cfg2", "--no-cpu-baseline"], nproc=2, port=29618)
     assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["value"] > 0 and "all-reduce" in w["config"]["workload"]
 
@@ -316,6 +336,11 @@ def test_bench_single_gpu_line_carries_config5_and_both_binning_modes():
     # the same step replayed as one hipGraph (host out of the loop): present, overflow-free, not slower than the eager step beyond noise
     g = d["graph_replay"]
     assert g["overflow_free"] and 0 < g["ms_per_step"] < 1.5 * d["ms_per_step"], d
+    # BASELINE config #3 beside it: the batched keyframes (round 5) and the per-view iteration of rounds 1-4
+    c3 = d["config3"]
+    assert "configs[2]" in c3["workload"] and 0 < c3["ms_per_step"] < c3["per_view_ms_per_step"] and c3["unit"] == "Gaussian-views/s", c3
+    # the roofline block names the pair rates for what they are
+    assert "nominal_pair_evals_per_s_bwd" in d["roofline"] and "pair_evals_per_s_bwd" not in d["roofline"]
 
 
 RCCL_ONE_RANK = r'''
