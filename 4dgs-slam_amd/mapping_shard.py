@@ -239,8 +239,9 @@ class ViewShard:
         """Gaussian gradients through the optimizer's flat bucket when it has one (FusedAdam with fused accumulation: the kernels already
         summed this rank's views into it), else through a cached packing bucket; the network's gradients ride a second bucket (different
         lifetime: the Gaussian bucket is rebuilt by every densification) -- in place when attach_network() made the gradients views of it,
-        packed otherwise. A parameter that has no gradient on ANY rank keeps ``grad = None`` (no optimizer state is created for it, as in a
-        single process); every rank must take the same path (checked on the packed path, which costs one small collective)."""
+        packed otherwise. On the PACKED path a parameter that has no gradient on ANY rank keeps ``grad = None`` (no optimizer state is created
+        for it, as in a single process); attach_network() attaches only parameters that already received a gradient for the same reason.
+        Every rank must take the same path for the same parameters (a precondition: see _packed_sum)."""
         if not self.active:
             return
         bucket = getattr(optimizer, "_bucket", None)
@@ -255,29 +256,69 @@ class ViewShard:
         net = [p for p in network_params if p.requires_grad]
         if net:
             hit = self._net_bucket
+            dead = self.__dict__.setdefault("_net_no_grad", set())
             if hit is not None and hit[0] == tuple(id(p) for p in net) and getattr(hit[1], "attached", False) \
-                    and all(p.grad is v for p, v in zip(hit[1].params, hit[1].views)):
+                    and all(p.grad is v for p, v in zip(hit[1].params, hit[1].views)) and all(p.grad is None for p in net if id(p) in dead):
                 self._sum(hit[1].flat)
+                if not getattr(hit[1], "_liveness_checked", False):
+                    self._drop_untouched(net, hit[1])
             else:
+                dead.difference_update(id(p) for p in net if p.grad is not None)      # a parameter that was left out has a gradient after all
                 self._packed_sum("_net_pack", net)
 
+    def _drop_untouched(self, net, bucket):
+        """Once per attached network bucket, after its first reduction: a parameter whose gradient is exactly zero on EVERY rank did not take
+        part in the loss (the detached `nodes` group, heads the configuration switches off). An attached view is zero rather than None, so
+        Adam would step such a parameter with g = 0 and create state for it, which a single process (grad None: skipped) does not -- the
+        parameter leaves the bucket and its .grad becomes None again. One host read per bucket lifetime. Should it receive a gradient later
+        (a head that only a later phase uses), reduce_gradients notices, takes the packed path for that iteration and the next
+        attach_network() includes it again."""
+        bucket._liveness_checked = True
+        if not bucket.params:
+            return
+        peak = torch.stack([v.abs().amax() if v.numel() else v.new_zeros(()) for v in bucket.views]).tolist()
+        gone = [p for p, z in zip(bucket.params, peak) if z == 0.0]
+        if not gone:
+            return
+        kept = {id(p): v.clone() for p, v in zip(bucket.params, bucket.views)}
+        self._net_no_grad.update(id(p) for p in gone)
+        for p in gone:
+            p.grad = None
+            if hasattr(p, "_gsr_accumulate_grad"):
+                delattr(p, "_gsr_accumulate_grad")
+        self._net_bucket = None
+        nb = self.attach_network(net)
+        if nb is not None:
+            nb._liveness_checked = True
+            for p, v in zip(nb.params, nb.views):
+                v.copy_(kept[id(p)])
+
     def _packed_sum(self, slot, params):
-        """pack -> all-reduce -> unpack through a bucket cached per parameter list; gradients that are None everywhere stay None."""
+        """pack -> ONE all-reduce -> unpack through a bucket cached per parameter list; gradients that are None on every rank stay None.
+        Which parameters hold a gradient anywhere travels IN the same collective (one flag per parameter behind the packed gradients), and the
+        host reads the flags back only if THIS rank has a parameter without a gradient -- the usual iteration (every rank runs the same graph,
+        every parameter has one) costs no extra collective and no host synchronisation. Precondition (documented, not checkable from inside:
+        mismatched collectives hang or fail in the backend rather than raise here): every rank takes the same path -- attached bucket or packed
+        -- for the same parameter list in the same iteration."""
         key = tuple(id(p) for p in params)
         hit = self.__dict__.get(slot)
         if hit is None or hit[0] != key:
-            hit = (key, GradBucket(params))
+            b = GradBucket(params)
+            hit = (key, b, torch.zeros(b.flat.numel() + len(params), dtype=torch.float32, device=b.flat.device))
             self.__dict__[slot] = hit
-        b = hit[1]
-        had = torch.tensor([1.0] + [1.0 if p.grad is not None else 0.0 for p in params], device=b.flat.device)
-        dist.all_reduce(had, op=dist.ReduceOp.SUM, group=self.group)          # [ranks on this path | ranks holding a gradient, per parameter]
-        self.collectives += 1
-        if int(had[0].item()) != self.world:
-            raise RuntimeError("ViewShard.reduce_gradients: the ranks disagree on how the gradients are exchanged (attached bucket vs packed)")
+        b, wire = hit[1], hit[2]
+        n = b.flat.numel()
         b.pack()
-        self._sum(b.flat)
-        for p, v, n in zip(b.params, b.views, had[1:].tolist()):
-            if n == 0:
+        wire[:n].copy_(b.flat)
+        missing = [k for k, p in enumerate(params) if p.grad is None]
+        wire[n:].fill_(1.0)
+        if missing:
+            wire[n:][torch.tensor(missing, device=wire.device)] = 0.0
+        self._sum(wire)
+        b.flat.copy_(wire[:n])
+        holders = wire[n:].tolist() if missing else None           # (host read only when some local gradient is None)
+        for k, (p, v) in enumerate(zip(b.params, b.views)):
+            if holders is not None and holders[k] == 0:
                 p.grad = None
             elif p.grad is None:
                 p.grad = v.clone()
@@ -288,11 +329,15 @@ class ViewShard:
         """Make the network parameters' .grad views of one persistent flat bucket (GradBucket.attach without the rasterizer's fused
         accumulation): autograd accumulates into them in place and reduce_gradients all-reduces the bucket as it stands -- no pack / unpack
         of ~20 tensors per iteration. Use zero_network_grads() in place of optimizer.zero_grad(set_to_none=True). No-op with one rank."""
-        net = [p for p in params if p.requires_grad]
+        # only parameters that RECEIVE gradients: an attached view is zero rather than None, and Adam would step a parameter the loss never
+        # reaches with g = 0 and create state for it; which ones those are is found after the first reduction (_drop_untouched)
+        every = [p for p in params if p.requires_grad]
+        dead = self.__dict__.setdefault("_net_no_grad", set())
+        net = [p for p in every if id(p) not in dead]
         if not self.active or not net:
             return None
-        key = tuple(id(p) for p in net)
-        if self._net_bucket is None or self._net_bucket[0] != key:
+        key = tuple(id(p) for p in every)
+        if self._net_bucket is None or self._net_bucket[0] != key or [id(p) for p in self._net_bucket[1].params] != [id(p) for p in net]:
             self._net_bucket = (key, GradBucket(net))
         b = self._net_bucket[1]
         b.flat.zero_()

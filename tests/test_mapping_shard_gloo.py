@@ -393,16 +393,33 @@ def _viewshard_worker(rank, world, port, ret):
     shard.reduce_gradients(opt)
     same_bucket = shard.__dict__["_gauss_pack"][1] is bucket_1                      # cached, not rebuilt per iteration
     # attached network bucket: gradients accumulate in place, reduced without packing
-    net = [torch.nn.Parameter(torch.ones(3, 2)), torch.nn.Parameter(torch.ones(4))]
+    # (the third parameter never receives a gradient -- the detached `nodes` group of the deform model: it must end with grad None and no
+    # optimizer state, as in a single process, and leave the bucket after the first reduction)
+    net = [torch.nn.Parameter(torch.ones(3, 2)), torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(5))]
     nb = shard.attach_network(net)
     views = [p.grad for p in net]
     ((net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum()).backward()
     still_views = all(p.grad is v for p, v in zip(net, views))
     before = shard.collectives
     shard.reduce_gradients(None, net)
-    attached = (net[0].grad.clone(), net[1].grad.clone(), shard.collectives - before, still_views)
-    shard.zero_network_grads(torch.optim.SGD(net, lr=0.1))
-    zeroed = float(nb.flat.abs().sum()) == 0.0 and all(p.grad is v for p, v in zip(net, views))
+    nb = shard._net_bucket[1]
+    net_opt = torch.optim.Adam(net, lr=0.1)
+    net_opt.step()
+    untouched_ok = net[2].grad is None and len(nb.params) == 2 and len(net_opt.state.get(net[2], {})) == 0 and float(net[2].detach().sum()) == 5.0
+    attached = (net[0].grad.clone(), net[1].grad.clone(), shard.collectives - before, still_views and untouched_ok)
+    views = [p.grad for p in net[:2]]
+    shard.zero_network_grads(net_opt)
+    zeroed = float(nb.flat.abs().sum()) == 0.0 and all(p.grad is v for p, v in zip(net[:2], views)) and net[2].grad is None
+    # second iteration: still the attached path (one collective), the left-out parameter still None
+    ((net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum()).backward()
+    before = shard.collectives
+    shard.reduce_gradients(None, net)
+    zeroed = zeroed and shard.collectives - before == 1 and net[2].grad is None and float(net[0].grad.sum()) == 18.0
+    # ... and if it does receive a gradient later, that iteration goes through the packed path and nothing is lost
+    shard.zero_network_grads(net_opt)
+    (net[2] * (rank + 1)).sum().backward()
+    shard.reduce_gradients(None, net)
+    zeroed = zeroed and net[2].grad is not None and float(net[2].grad.sum()) == 15.0 and id(net[2]) not in shard._net_no_grad
     # bit-packed 0 / 1 rows: 3 rows of 21 flags, owner = index % world
     rows_all = [(torch.arange(21) % (k + 2) == 0).long() for k in range(3)]
     got = shard.gather_mask_rows({k: rows_all[k] for k in range(3) if shard.owns(k)}, 3, 21, torch.device("cpu"))
