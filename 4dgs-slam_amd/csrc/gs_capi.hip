@@ -152,10 +152,11 @@ static thread_local int t_cap_margin_permille = 125;   // head room of a specula
 static thread_local int t_cap_tile_margin_permille = -1;  // head room of the longest tile list (which picks the sort kernels); < 0: max(250, cap_margin_permille)
 static inline unsigned tile_margin() { return (unsigned)(t_cap_tile_margin_permille >= 0 ? t_cap_tile_margin_permille : std::max(250, t_cap_margin_permille)); }
 static thread_local int t_cap_test_shrink_permille = 0; // TEST facility: > 0 lays speculative buffers out for that fraction of the last count (forces overflows)
+static thread_local int t_cap_floor = 0;               // smallest speculative capacity, in instances (gsr_set_option "cap_floor")
 static inline size_t spec_capacity(size_t last)
 {
     if (t_cap_test_shrink_permille > 0) return (size_t)((unsigned long long)last * (unsigned)t_cap_test_shrink_permille / 1000ull) + 1;
-    return last + (size_t)((unsigned long long)last * (unsigned)t_cap_margin_permille / 1000ull) + 4096;
+    return std::max(last + (size_t)((unsigned long long)last * (unsigned)t_cap_margin_permille / 1000ull) + 4096, (size_t)t_cap_floor);
 }
 static thread_local bool t_options_read = false;
 static thread_local unsigned t_views_batched = 0;
@@ -246,13 +247,18 @@ int gsr_set_option(const char* name, int value)
         if (value >= 0) t_view_slot_group = value >= VIEW_SLOT_GROUPS ? VIEW_SLOT_GROUPS - 1 : value;
         return old_group;
     }
+    if (n == "cap_floor") {
+        const int old_floor = t_cap_floor;
+        if (value >= 0) t_cap_floor = value > (1 << 26) ? (1 << 26) : value;
+        return old_floor;
+    }
     if (n == "cap_test_shrink_permille") {
         const int old_shrink = t_cap_test_shrink_permille;
         if (value >= 0) t_cap_test_shrink_permille = value > 1000 ? 1000 : value;
         return old_shrink;
     }
     bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
-    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille, cap_tile_margin_permille, cap_floor, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;

@@ -135,6 +135,18 @@ def set_flow_clips(clips):
         _err(lib, rc, "gsr_set_flow_clips")
 
 
+def debug_view_slots(max_slots: int = 8):
+    """Per capacity slot of this thread (0 = single-view calls, then the view slots of the multi-view entry point): what the GPU last
+    reported -- num_rendered, flags, R_alloc, longest tile list, sequence number, sticky overflow count -- and the estimates the next
+    speculative layout starts from (gsr_debug_view_slots; never blocks)."""
+    lib = load_library()
+    buf = (C.c_uint * (8 * max_slots))()
+    lib.gsr_debug_view_slots.argtypes = [C.POINTER(C.c_uint), C.c_int]
+    n = lib.gsr_debug_view_slots(buf, max_slots)
+    keys = ("num_rendered", "flags", "R_alloc", "longest_tile", "seq", "overflows", "estimate_R_alloc", "estimate_longest_tile")
+    return [dict(zip(keys, (int(buf[8 * k + j]) for j in range(8)))) for k in range(max(0, n))]
+
+
 def forward_status():
     """(overflow_count, last_num_rendered) of this thread's forward passes; never blocks (gsr_forward_status)."""
     lib = load_library()

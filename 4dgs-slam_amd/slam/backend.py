@@ -228,11 +228,17 @@ class BackEnd:
         if run > warm:
             overflow0 = _C.forward_status()[0]
             ig.snapshot()
+            before = _C.debug_view_slots(1)[0]
             try:
                 ig.capture()
                 ig.replay(run - warm)
                 torch.cuda.current_stream(ig.device).synchronize()
                 ok = _C.forward_status()[0] == overflow0
+                if not ok:      # what outgrew what (kept in the statistics: the capture margins of slam/mapping_graph.py are sized from these)
+                    after = _C.debug_view_slots(1)[0]
+                    stats.setdefault("overflow_causes", []).append({"iteration": int(self.iteration_count), "run": int(run), "gaussians": int(g.get_xyz.shape[0]),
+                                                                    "estimate_R": before["estimate_R_alloc"], "estimate_longest_tile": before["estimate_longest_tile"],
+                                                                    "overflowing_R_alloc": after["R_alloc"], "overflowing_longest_tile": after["longest_tile"]})
             except Exception as e:        # a failed capture leaves the warm-up valid: the rest of the run goes on eagerly, no more captures
                 self._init_graph_broken = True
                 torch.cuda.synchronize(ig.device)

@@ -46,6 +46,10 @@ from .mapping_graph import N_INDEX_WORDS
 # of a call) the moving object's Gaussians can swell and pile up for a few iterations -- measured: instance counts +10 %, the longest tile
 # list x 2-4 -- and every overflow costs the whole run (undone, repeated directly).
 CAPTURE_MARGIN_PERMILLE, CAPTURE_TILE_MARGIN_PERMILLE = (int(v) for v in os.environ.get("GSR_DYN_MARGINS", "2000,7000").split(","))
+# the slots of an iteration's two random keyframes (and their flow renders) show another keyframe on every replay: the instance count at
+# capture says little about the next draw (flow slot: 7 042 at capture, > 25 000 later = the 3x margin overrun, 99 iterations redone in the
+# config #4 stand-in, 39 of 400 in the census) -- a floor in instances (~70 B each: 9 MB per view) instead of a ratio alone
+CAPTURE_FLOOR_INSTANCES = int(os.environ.get("GSR_DYN_CAP_FLOOR", "131072"))
 FLOW_CLIPS = os.environ.get("GSR_FLOW_CLIPS", "1") != "0"      # render the flow images only where the flow loss reads them (gsr_view.flow_clip)
 FLOW_TARGET_BUDGET_FRACTION = 0.03  # ... and at most this share of the device memory free when the first target is formed
 FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (~7 MB each at 640x480); dropped ones are formed again on demand
@@ -437,6 +441,7 @@ class DynamicMapping:
         lazy_before = _C.set_option("lazy", 1)
         margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
         tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
+        floor_before = _C.set_option("cap_floor", CAPTURE_FLOOR_INSTANCES)
         # TEST facility (Training.graph_test_shrink_permille): lay the captured buffers out too small, so that replays overflow
         shrink_before = _C.set_option("cap_test_shrink_permille", int(be.config["Training"].get("graph_test_shrink_permille", 0)))
         s = be.graph_streams(dev)[1]
@@ -453,6 +458,7 @@ class DynamicMapping:
             _C.set_option("lazy", lazy_before)       # the flags only matter while host code runs: replays never consult them
             _C.set_option("cap_margin_permille", margin_before)
             _C.set_option("cap_tile_margin_permille", tile_before)
+            _C.set_option("cap_floor", floor_before)
             _C.set_option("cap_test_shrink_permille", shrink_before)
         torch.cuda.current_stream(dev).wait_stream(s)
         be._graph_keepalive = self.graph             # (drops the previous run's graph: the pool now belongs to this one)
@@ -493,6 +499,7 @@ class DynamicMapping:
         self.warm_up(warm)
         self.stats["direct"] += warm
         overflow0 = _C.forward_status_views()
+        slots_before = _C.debug_view_slots(100)
         self.snapshot()
         try:
             t0 = time.perf_counter()
@@ -517,6 +524,12 @@ class DynamicMapping:
             self.graph.replay()
         torch.cuda.current_stream(self.device).synchronize()
         if _C.forward_status_views() != overflow0:          # a replayed view outgrew its binning buffer: undo the replays, redo them directly
+            # (which slot outgrew what, kept in the statistics: slots whose overflow counter moved, with the estimates the layout started from)
+            slots_after = _C.debug_view_slots(100)
+            moved = [dict(slot=k, **{n: a[n] for n in ("R_alloc", "longest_tile", "estimate_R_alloc", "estimate_longest_tile")},
+                          captured_estimate_R=b["estimate_R_alloc"], captured_estimate_tile=b["estimate_longest_tile"])
+                     for k, (a, b) in enumerate(zip(slots_after, slots_before)) if a["overflows"] != b["overflows"]]
+            self.stats.setdefault("overflow_causes", []).append({"rows": int(rows - warm), "gaussians": int(self.g.get_xyz.shape[0]), "slots": moved[:6]})
             self.restore()
             self.stats["redone"] += rows - warm
             self.graph = None
@@ -651,6 +664,7 @@ class NetworkInit:
             lazy_before = _C.set_option("lazy", 1)
             margin_before = _C.set_option("cap_margin_permille", CAPTURE_MARGIN_PERMILLE)
             tile_before = _C.set_option("cap_tile_margin_permille", CAPTURE_TILE_MARGIN_PERMILLE)
+            floor_before = _C.set_option("cap_floor", CAPTURE_FLOOR_INSTANCES)
             try:
                 s1.wait_stream(torch.cuda.current_stream(dev))
                 self.graph = torch.cuda.CUDAGraph()
@@ -674,6 +688,7 @@ class NetworkInit:
                 _C.set_option("lazy", lazy_before)
                 _C.set_option("cap_margin_permille", margin_before)
                 _C.set_option("cap_tile_margin_permille", tile_before)
+                _C.set_option("cap_floor", floor_before)
             if ok:
                 for _ in range(rows - warm):
                     self.graph.replay()

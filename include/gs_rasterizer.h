@@ -271,6 +271,11 @@ int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
  *                which selects the sort kernels a speculative forward pass enqueues. A tile list can double where the instance count
  *                moves by a few percent (a dynamic object's Gaussians piling up while the node network trains): captures raise it
  *                separately. The value 1000000 stands for the default, when set and when returned.
+ *   "cap_floor" (default 0): smallest capacity, in instances, a speculative binning buffer is laid out for whatever the previous frame needed.
+ *                A view slot that a captured iteration fills with a DIFFERENT keyframe on every replay (the two random keyframes of a mapping
+ *                iteration and their flow renders, utils/slam_backend.py:1031-1037) has no meaningful "previous frame": the estimate is one
+ *                candidate's count, another candidate may need three times as much (measured: 7 042 instances at capture, > 25 000 at a later
+ *                replay). Such captures set a floor (a few MB per view) instead of trusting a ratio.
  *   "view_slot_group" (default 0; 0..3): which of an iteration's gsr_forward_views calls the next calls are. The capacity estimate and
  *                the mailbox of a view are kept per (group, flow / plain, position in the call): a caller that needs several calls per
  *                iteration (more than GSR_MAX_VIEWS flow renders) numbers them, or the v-th view of two calls would share -- and spoil -- one
