@@ -31,6 +31,8 @@
 #include "gs_hexplane_binned.h"
 #include "gs_linear.h"
 #include "gs_mlp.h"
+#include "gs_dense.h"
+#include "../../include/dense_layers.h"
 #include "gs_nodes.h"
 #include "../../include/slam_losses.h"
 #include "../../include/slam_map.h"
@@ -1732,6 +1734,81 @@ int gsr_deform_mlp_backward_rows(const gsr_deform_mlp* mlp, int64_t n, const flo
 #undef GSR_MLPB_CASE
     }
     hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, blocks, total, (const float*)partial, grads);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- fp32-accurate dense layers on the bf16 matrix cores (include/dense_layers.h) ---------------------------------------------------------
+static inline int round_up_int(int v, int m) { return (v + m - 1) / m * m; }
+
+size_t gsr_dense_planes_size(int rows, int cols)
+{
+    if (rows < 1 || cols < 1) return 0;
+    return (size_t)3 * round_up_int(rows, DENSE_BN) * round_up_int(cols, DENSE_BK) * sizeof(unsigned short);
+}
+
+int gsr_dense_split(int N, int K, const float* W, int ldw, int k0, int transposed, void* planes, void* stream_)
+{
+    if (N < 1 || K < 1 || !W || !planes || ldw < k0 + K || k0 < 0) { g_last_error = "gsr_dense_split: invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
+    const int rows = transposed ? K : N, cols = transposed ? N : K;
+    const int rows_pad = round_up_int(rows, DENSE_BN), cols_pad = round_up_int(cols, DENSE_BK);
+    const int64_t count = (int64_t)rows_pad * cols_pad;
+    hipLaunchKernelGGL(dense_split_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, N, K, W, ldw, k0, transposed ? 1 : 0,
+                       reinterpret_cast<unsigned short*>(planes), rows_pad, cols_pad);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_dense_forward(int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias, int relu,
+                      float* Y, int ldy, void* stream_)
+{
+    if (M < 0 || N < 1 || K < 1 || !planes || (M > 0 && (!X || !Y)) || ldx < K || ldy < N || (gate && ldgate < K)) {
+        g_last_error = "gsr_dense_forward: invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (M == 0) return 0;
+    const int Npad = round_up_int(N, DENSE_BN), Kpad = round_up_int(K, DENSE_BK);
+    const int vec = (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (!gate || ((ldgate % 4 == 0) && reinterpret_cast<uintptr_t>(gate) % 16 == 0));
+    // 16-byte output stores through an LDS transposition when every row piece is whole and aligned (the trunk's layers), else element stores
+    const int vec_out = (N % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0) && (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
+    const dim3 grid((unsigned)((M + DENSE_BM - 1) / DENSE_BM), (unsigned)(Npad / DENSE_BN));
+    hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(DENSE_THREADS), 0, (hipStream_t)stream_, M, N, K, X, ldx, gate, ldgate,
+                       reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, vec_out ? 1 : 0);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static void dense_wgrad_plan(int M, int N, int K, int* slices, int* rows_per_slice)
+{
+    const int tiles = ((N + DENSE_BM - 1) / DENSE_BM) * ((K + DENSE_BN - 1) / DENSE_BN);
+    int s = std::max(1, 512 / std::max(1, tiles));                             // ~two blocks per CU
+    s = std::min(s, std::max(1, (M + 4 * DENSE_WG_ROWS - 1) / (4 * DENSE_WG_ROWS)));   // at least four steps per slice
+    const int rps = round_up_int((M + s - 1) / s, DENSE_WG_ROWS);
+    *rows_per_slice = std::max(rps, DENSE_WG_ROWS);
+    *slices = std::max(1, (M + *rows_per_slice - 1) / *rows_per_slice);
+}
+
+size_t gsr_dense_wgrad_workspace_size(int M, int N, int K)
+{
+    if (M < 1 || N < 1 || K < 1) return 256;
+    int slices, rps;
+    dense_wgrad_plan(M, N, K, &slices, &rps);
+    return (size_t)slices * N * K * sizeof(float) + 256;
+}
+
+int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* gate, int ldgate, const float* X, int ldx, float* dW, int lddw,
+                    char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || N < 1 || K < 1 || !dW || lddw < K || (M > 0 && (!G || !X || !workspace)) || ldg < N || ldx < K || (gate && ldgate < N)) {
+        g_last_error = "gsr_dense_wgrad: invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (M == 0) { GSR_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, stream)); return 0; }
+    int slices, rps;
+    dense_wgrad_plan(M, N, K, &slices, &rps);
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+    const dim3 grid((unsigned)((N + DENSE_BM - 1) / DENSE_BM), (unsigned)((K + DENSE_BN - 1) / DENSE_BN), (unsigned)slices);
+    hipLaunchKernelGGL(dense_wgrad_kernel, grid, dim3(DENSE_THREADS), 0, stream, M, N, K, G, ldg, gate, ldgate, X, ldx, rps, partial);
+    hipLaunchKernelGGL(dense_wgrad_sum_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), 0, stream, slices, N * K, (const float*)partial, K, dW, lddw);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,347 @@
+// gs_dense.h -- fp32-accurate dense layers on the bf16 matrix cores (include/dense_layers.h): the node network's trunk.
+//
+// Reference: utils/time_utils.py:327-476 (DeformNetwork: D = 8 layers of W = 256 on 20-70 000 rows per mapping iteration, the embedding
+// re-injected behind layer 4). As fp32 GEMMs (hipBLASLt: v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate, 1/16 of the bf16 matrix rate)
+// they were 1.0 of the dynamic mapping iteration's 2.7 ms of device time, at 82-98 TFLOP/s.
+//
+// Here every fp32 operand is split into THREE bf16 terms, x = hi + mid + lo with hi = x truncated to bf16 (8 significant bits), mid = (x - hi)
+// truncated, lo = (x - hi - mid) truncated: together the 24 bits of an fp32 significand, the remainders exact. A product x w is evaluated as
+// the six cross terms of weight >= 2^-16 -- hi hi, hi mid, mid hi, hi lo, mid mid, lo hi -- on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation; the three dropped terms are below 2^-24 |x w| each (1.8e-7 relative in all: one and a half fp32 ulps, the size of an fp32
+// GEMM's own rounding). Six MFMA products at 16x the fp32 rate: 2.7x the fp32 matrix peak at equal utilisation, and the result is an fp32 GEMM
+// for every purpose of the parity tests (values 1e-6, the golden node losses unchanged at their tolerances).
+//
+// Kernels:  dense_split_kernel     W [N, K] fp32 -> bf16 planes [3][Npad][Kpad] (and / or of W^T), zero padded, once per optimizer step;
+//           dense_fwd_kernel       Y = act(X W^T + b) with W pre-split: 128 x 128 tile per block, X split while it is staged;
+//                                  also the input gradient dX = G W (W^T's planes as the weight);
+//           dense_wgrad_kernel     dW = G^T X over a slice of the rows (both operands split while staged, transposed through LDS);
+//           dense_wgrad_sum_kernel the slices' partial results added in a fixed order.
+//
+// STATUS (round 5, tools/dev_dense.py on an MI355X; library = hipBLASLt fp32 through torch): correct to fp32-GEMM accuracy everywhere
+// (tests/test_hip_dense.py), faster than the library only on long batches --
+//     rows      forward 256x256      input gradient      weight gradient (library: one GEMM / row groups of ~2000)
+//     33 280    41.5 vs 46.1 us      52.6 vs 45.4 us     82.8 vs 113.6 / 44.6 us
+//     66 560    65.1 vs 111.3        82.2 vs 90.0        142 vs 214 / ~90
+//     133 120   113 vs 163 (154 TFLOP/s fp32-equivalent = 0.37 of the bf16 matrix peak after the six-fold expansion)
+// At the node network's batch of the SLAM runs (~33k rows: 260 row tiles for 256 CUs, eight K steps per block) a block lives ~40 us for ~5 us
+// of matrix work: the one-step prefetch does not cover an HBM miss, and a two-step prefetch (second register set) spilled and was slower.
+// The trunk therefore still runs on the library (slam/deform_model._FusedTrunk); what would make this the faster path at that size is a
+// layer-fused kernel that keeps a row tile's activations in LDS across the eight layers (no operand fetch from HBM inside the K loop).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+typedef short dense_frag __attribute__((ext_vector_type(8)));   // 8 bf16 = one A / B operand of v_mfma_f32_16x16x32_bf16
+typedef float dense_acc __attribute__((ext_vector_type(4)));
+typedef uint32_t dense_u4 __attribute__((ext_vector_type(4)));     // 16 bytes as a native vector (arrays of HIP's uint4 struct went to scratch memory)
+
+constexpr int DENSE_BM = 128, DENSE_BN = 128, DENSE_BK = 32;   // block tile; a K step is one MFMA deep
+constexpr int DENSE_THREADS = 256;                              // four waves, 2 x 2, 64 x 64 outputs each
+constexpr int DENSE_ROW_B = 64;                                 // bytes per staged row: 32 bf16 in four 16-byte chunks
+// byte offset of chunk `q` (eight k) of staged row `row`: the chunks of a row are permuted by (row >> 1) & 3 -- with that the 16-byte fragment
+// reads of a wave (ds_read_b128 serves lanes {0-3, 12-15, 20-27}, ... together: rows and chunks mixed) and the staging stores (eight
+// consecutive lanes: two rows x four chunks, or eight rows of one chunk) are all bank-conflict free without padding (checked by enumeration)
+__device__ __forceinline__ int dense_off(int row, int q) { return row * DENSE_ROW_B + 16 * (q ^ ((row >> 1) & 3)); }
+
+// x -> (hi, mid, lo) as the upper halves of three fp32 words (truncation: every remainder is exact)
+__device__ __forceinline__ void dense_split(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo)
+{
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xFFFF0000u;
+}
+__device__ __forceinline__ uint32_t dense_pack(uint32_t even, uint32_t odd) { return (even >> 16) | odd; }   // two bf16: element 2j low, 2j + 1 high
+
+// eight consecutive fp32 -> three 16-byte fragments (one per plane)
+__device__ __forceinline__ void dense_split8(const float (&x)[8], dense_u4& h, dense_u4& m, dense_u4& l)
+{
+    uint32_t a[8], b[8], c[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) dense_split(x[e], a[e], b[e], c[e]);
+    h = dense_u4{dense_pack(a[0], a[1]), dense_pack(a[2], a[3]), dense_pack(a[4], a[5]), dense_pack(a[6], a[7])};
+    m = dense_u4{dense_pack(b[0], b[1]), dense_pack(b[2], b[3]), dense_pack(b[4], b[5]), dense_pack(b[6], b[7])};
+    l = dense_u4{dense_pack(c[0], c[1]), dense_pack(c[2], c[3]), dense_pack(c[4], c[5]), dense_pack(c[6], c[7])};
+}
+
+__device__ __forceinline__ dense_frag dense_ld_frag(const unsigned char* p)
+{
+    return *reinterpret_cast<const dense_frag*>(p);
+}
+
+// the six products of one row tile with FOUR column tiles for one K step: consecutive MFMAs go to different accumulators (a dependent
+// v_mfma_f32_16x16x32_bf16 waits for its predecessor's passes; four in between hide that), smallest terms first
+__device__ __forceinline__ void dense_mfma6x4(const dense_frag (&a)[3], const dense_frag (&b)[4][3], dense_acc (&c)[4])
+{
+#define GSR_DENSE_TERM(PA, PB)                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA], b[j][PB], c[j], 0, 0, 0);
+    GSR_DENSE_TERM(2, 0) GSR_DENSE_TERM(0, 2) GSR_DENSE_TERM(1, 1) GSR_DENSE_TERM(1, 0) GSR_DENSE_TERM(0, 1) GSR_DENSE_TERM(0, 0)
+#undef GSR_DENSE_TERM
+}
+
+// ---- weights -> bf16 planes ------------------------------------------------------------------------------------------------------------
+// planes[p][n][k], n < Npad, k < Kpad (multiples of 128 / 32), = plane p of W[n][k0 + k] (zero beyond N / K); transposed = 1 writes the planes of
+// the TRANSPOSE instead: planes[p][k][n] with k < Kpad' = round_up(K, 128) rows and n < Npad' = round_up(N, 32) columns.
+__global__ void __launch_bounds__(256)
+dense_split_kernel(const int N, const int K, const float* __restrict__ W, const int ldw, const int k0, const int transposed,
+                   unsigned short* __restrict__ planes, const int rows_pad, const int cols_pad)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)rows_pad * cols_pad) return;
+    const int r = (int)(e / cols_pad), c = (int)(e % cols_pad);
+    const int n = transposed ? c : r, k = transposed ? r : c;
+    const float x = (n < N && k < K) ? W[(size_t)n * ldw + k0 + k] : 0.f;
+    uint32_t hi, mid, lo;
+    dense_split(x, hi, mid, lo);
+    const size_t plane = (size_t)rows_pad * cols_pad;
+    planes[e] = (unsigned short)(hi >> 16);
+    planes[plane + e] = (unsigned short)(mid >> 16);
+    planes[2 * plane + e] = (unsigned short)(lo >> 16);
+}
+
+// ---- Y [M, N] = act(X [M, K] W^T + bias), W given as planes [3][Npad][Kpad] -----------------------------------------------------------------
+// X: row stride ldx floats, optional gate: X is read as x * (gate > 0) (the ReLU mask of the layer that produced the cotangent, so that the
+// input-gradient product consumes dY and the layer's output directly). relu: max(., 0) on the way out.
+__global__ void __launch_bounds__(DENSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // two blocks per CU: 256 registers per lane, no spills
+dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict__ X, const int ldx, const float* __restrict__ gate, const int ldgate,
+                 const unsigned short* __restrict__ planes, const int Npad, const int Kpad, const float* __restrict__ bias, const int relu,
+                 float* __restrict__ Y, const int ldy, const int vec, const int vec_out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[3][DENSE_BM * DENSE_ROW_B];
+    __shared__ __attribute__((aligned(16))) unsigned char s_b[3][DENSE_BN * DENSE_ROW_B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * DENSE_BM, n0 = blockIdx.y * DENSE_BN;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;        // this wave's 64 x 64 corner of the block tile
+    const int fi = lane & 15, fq = lane >> 4;                      // fragment row / column and its group of eight k
+    dense_acc acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+
+    // staging assignment: item = (row, group of eight k); 128 rows x 4 groups = 512 items, two per thread. The next step's operands are
+    // requested before this step's products are issued. (Requesting X two steps ahead -- a second set of staging registers, the loop unrolled
+    // by two -- was built and measured: 256 registers, spills, 41 -> 54 us at 33k rows.)
+    const int steps = Kpad / DENSE_BK;
+    float xa[2][8];
+    dense_u4 wb[2][3];
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            const int m = m0 + row, k = s * DENSE_BK + 8 * g;
+            const float* src = X + (size_t)m * ldx + k;
+            const float* gsrc = gate ? gate + (size_t)m * ldgate + k : nullptr;
+            if (vec && m < M && k + 8 <= K) {                        // the usual case: two 16-byte loads (the host checked the alignment)
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                xa[it][0] = v0.x; xa[it][1] = v0.y; xa[it][2] = v0.z; xa[it][3] = v0.w;
+                xa[it][4] = v1.x; xa[it][5] = v1.y; xa[it][6] = v1.z; xa[it][7] = v1.w;
+                if (gate) {
+                    const float4 g0 = *reinterpret_cast<const float4*>(gsrc), g1 = *reinterpret_cast<const float4*>(gsrc + 4);
+                    xa[it][0] = g0.x > 0.f ? xa[it][0] : 0.f; xa[it][1] = g0.y > 0.f ? xa[it][1] : 0.f;
+                    xa[it][2] = g0.z > 0.f ? xa[it][2] : 0.f; xa[it][3] = g0.w > 0.f ? xa[it][3] : 0.f;
+                    xa[it][4] = g1.x > 0.f ? xa[it][4] : 0.f; xa[it][5] = g1.y > 0.f ? xa[it][5] : 0.f;
+                    xa[it][6] = g1.z > 0.f ? xa[it][6] : 0.f; xa[it][7] = g1.w > 0.f ? xa[it][7] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const bool ok = m < M && k + e < K;
+                    float v = ok ? src[e] : 0.f;
+                    if (gate) v = (ok && gsrc[e] > 0.f) ? v : 0.f;
+                    xa[it][e] = v;
+                }
+            }
+            const size_t off = (size_t)(n0 + row) * Kpad + k;        // planes are padded: always in range
+            const size_t plane = (size_t)Npad * Kpad;
+#pragma unroll
+            for (int p = 0; p < 3; p++) wb[it][p] = *reinterpret_cast<const dense_u4*>(planes + p * plane + off);
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            dense_u4 h, m_, l;
+            dense_split8(xa[it], h, m_, l);
+            const int o = dense_off(row, g);
+            *reinterpret_cast<dense_u4*>(&s_a[0][o]) = h;
+            *reinterpret_cast<dense_u4*>(&s_a[1][o]) = m_;
+            *reinterpret_cast<dense_u4*>(&s_a[2][o]) = l;
+#pragma unroll
+            for (int p = 0; p < 3; p++) *reinterpret_cast<dense_u4*>(&s_b[p][o]) = wb[it][p];
+        }
+    };
+    fetch(0);
+    for (int s = 0; s < steps; s++) {
+        __syncthreads();                      // the previous step's fragments have been read
+        stage();
+        __syncthreads();
+        if (s + 1 < steps) fetch(s + 1);      // in flight while this step's products run
+        dense_frag b[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(&s_b[p][dense_off(wn + 16 * j + fi, fq)]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dense_frag a[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(&s_a[p][dense_off(wm + 16 * i + fi, fq)]);
+            dense_mfma6x4(a, b, acc[i]);
+        }
+    }
+    // C layout: column = lane & 15, rows 4 (lane >> 4) + r. A wave's 16 x 64 slab goes through a wave-private LDS tile so that the stores are
+    // 16 bytes per lane and 256 contiguous bytes per row (straight from the accumulators a store instruction wrote four 64-byte pieces)
+    if (vec_out) {
+        __syncthreads();                                          // the last step's fragments have been read: the staging arrays are free
+        float* slab = reinterpret_cast<float*>(&s_a[0][0]) + wave * (16 * 68);          // 4 x 4.25 KB inside s_a (30 KB)
+        const int col4 = 4 * (lane & 15), nn = n0 + wn + col4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && nn + 3 < N) bv = *reinterpret_cast<const float4*>(bias + nn);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int row = 4 * t + (lane >> 4), m = m0 + wm + 16 * i + row;
+                float4 v = *reinterpret_cast<const float4*>(&slab[row * 68 + col4]);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (m < M && nn + 3 < N) *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = n0 + wn + 16 * j + fi;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + wm + 16 * i + 4 * fq + r;
+                if (m < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    Y[(size_t)m * ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- dW [N, K] = G^T X over the rows [r0, r1) of this block's slice ---------------------------------------------------------------------------
+// G [M, N] (row stride ldg; optional gate as above: G = g * (gate > 0)), X [M, K] (ldx). grid = (N tiles of 128, K tiles of 128, slices);
+// partial [slices][N][K] fp32; dense_wgrad_sum_kernel adds the slices in order. The MFMA's reduction index is the ROW: both operands are
+// staged transposed -- a thread reads sixteen rows of one column (coalesced across the wave: consecutive columns) and writes them as two
+// 16-byte fragments per plane.
+constexpr int DENSE_WG_ROWS = 32;       // rows per step = one MFMA's depth
+__global__ void __launch_bounds__(DENSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dense_wgrad_kernel(const int M, const int N, const int K, const float* __restrict__ G, const int ldg, const float* __restrict__ gate, const int ldgate,
+                   const float* __restrict__ X, const int ldx, const int rows_per_slice, float* __restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[3][DENSE_BM * DENSE_ROW_B];   // [plane][n][32 rows]
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[3][DENSE_BN * DENSE_ROW_B];   // [plane][k][32 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * DENSE_BM, k0 = blockIdx.y * DENSE_BN;
+    const int r_begin = blockIdx.z * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int fi = lane & 15, fq = lane >> 4;
+    dense_acc acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+    // staging: thread = (column c = tid & 127, half h = tid >> 7): rows 16 h .. 16 h + 15 of the step, of G's column n0 + c and X's column k0 + c
+    const int c = tid & 127, h = tid >> 7;
+    float gv[16], xv[16];
+    auto fetch = [&](int r0) {
+        const int n = n0 + c, k = k0 + c;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = r0 + 16 * h + e;
+            const bool okr = r < r_end;
+            float g = (okr && n < N) ? G[(size_t)r * ldg + n] : 0.f;
+            if (gate) g = (okr && n < N && gate[(size_t)r * ldgate + n] > 0.f) ? g : 0.f;
+            gv[e] = g;
+            xv[e] = (okr && k < K) ? X[(size_t)r * ldx + k] : 0.f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { a8[e] = gv[8 * half + e]; b8[e] = xv[8 * half + e]; }
+            dense_u4 hh, mm, ll;
+            const int o = dense_off(c, 2 * h + half);                 // rows 16 h + 8 half .. + 7 of this column
+            dense_split8(a8, hh, mm, ll);
+            *reinterpret_cast<dense_u4*>(&s_g[0][o]) = hh; *reinterpret_cast<dense_u4*>(&s_g[1][o]) = mm; *reinterpret_cast<dense_u4*>(&s_g[2][o]) = ll;
+            dense_split8(b8, hh, mm, ll);
+            *reinterpret_cast<dense_u4*>(&s_x[0][o]) = hh; *reinterpret_cast<dense_u4*>(&s_x[1][o]) = mm; *reinterpret_cast<dense_u4*>(&s_x[2][o]) = ll;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += DENSE_WG_ROWS) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (r0 + DENSE_WG_ROWS < r_end) fetch(r0 + DENSE_WG_ROWS);
+        dense_frag b[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(&s_x[p][dense_off(wn + 16 * j + fi, fq)]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dense_frag a[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(&s_g[p][dense_off(wm + 16 * i + fi, fq)]);
+            dense_mfma6x4(a, b, acc[i]);
+        }
+    }
+    float* out = partial + (size_t)blockIdx.z * N * K;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = k0 + wn + 16 * j + fi;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int n = n0 + wm + 16 * i + 4 * fq + r;
+                if (n < N) out[(size_t)n * K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+dense_wgrad_sum_kernel(const int slices, const int count, const float* __restrict__ partial, const int K, float* __restrict__ dW, const int lddw)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < slices; b += 4) {
+        s0 += partial[(size_t)b * count + e];
+        s1 += partial[(size_t)(b + 1) * count + e];
+        s2 += partial[(size_t)(b + 2) * count + e];
+        s3 += partial[(size_t)(b + 3) * count + e];
+    }
+    for (; b < slices; b++) s0 += partial[(size_t)b * count + e];
+    dW[(size_t)(e / K) * lddw + e % K] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace gsr

@@ -1,0 +1,108 @@
+"""fp32-accurate dense layers on the bf16 matrix cores (include/dense_layers.h, csrc/gs_dense.h): host side.
+
+The node network's trunk (utils/time_utils.py:327-476: eight layers of width 256 over every (node, time sample) row of a mapping iteration) is
+GEMM-shaped work that the fp32 matrix instructions run at the fp32 VECTOR rate. Here an fp32 operand travels as three bf16 terms (24 bits of
+significand, split by truncation) and a product as its six largest cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the results
+are fp32 GEMM results (what is dropped is below 2e-7 of |x w| per product), at up to 2.7x the fp32 matrix rate.
+
+    planes = split_weight(W)                          # once per optimizer step: bf16 planes of W [N, K] ...
+    planes_t = split_weight(W, transposed=True)       # ... and of its transpose (for the input gradient)
+    Y = dense_forward(X, planes, N, K, bias, relu=True)
+    dX = dense_forward(G, planes_t, K, N)             # G W
+    dW = dense_wgrad(G, X)                            # G^T X, deterministic
+
+There is no CPU path: tensors must be fp32 on a HIP device."""
+import ctypes as C
+
+import torch
+
+from diff_gaussian_rasterization import _C
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = _C.load_library()
+    if not _declared:
+        i, vp = C.c_int, C.c_void_p
+        lib.gsr_dense_planes_size.restype = C.c_size_t
+        lib.gsr_dense_planes_size.argtypes = [i, i]
+        lib.gsr_dense_split.restype = i
+        lib.gsr_dense_split.argtypes = [i, i, vp, i, i, i, vp, vp]
+        lib.gsr_dense_forward.restype = i
+        lib.gsr_dense_forward.argtypes = [i, i, i, vp, i, vp, i, vp, vp, i, vp, i, vp]
+        lib.gsr_dense_wgrad_workspace_size.restype = C.c_size_t
+        lib.gsr_dense_wgrad_workspace_size.argtypes = [i, i, i]
+        lib.gsr_dense_wgrad.restype = i
+        lib.gsr_dense_wgrad.argtypes = [i, i, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
+        _declared = True
+    return lib
+
+
+def _rows(t, name):
+    _C._require_device(t, name)
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: fp32 [rows, cols] with unit column stride expected, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def split_weight(W, k0=0, K=None, transposed=False, out=None):
+    """bf16 planes (a uint8 tensor) of W[:, k0:k0 + K] ([N, K], nn.Linear layout) for dense_forward -- or of its transpose."""
+    W = _rows(W, "weight")
+    N = int(W.shape[0])
+    K = int(W.shape[1]) - k0 if K is None else int(K)
+    lib = _lib()
+    rows, cols = (K, N) if transposed else (N, K)
+    size = int(lib.gsr_dense_planes_size(rows, cols))
+    if out is None or out.numel() != size:
+        out = torch.empty((size,), dtype=torch.uint8, device=W.device)
+    with torch.cuda.device(W.device):
+        rc = lib.gsr_dense_split(N, K, W.data_ptr(), int(W.stride(0)), int(k0), 1 if transposed else 0, out.data_ptr(), _C._stream(W.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_split")
+    return out
+
+
+def dense_forward(X, planes, N, K, bias=None, relu=False, gate=None, out=None):
+    """Y [M, N] = act(X[:, :K] Wt + bias) for the split weight `planes` (N outputs, K inputs); gate [M, K]: X is read as X * (gate > 0)."""
+    X = _rows(X, "X")
+    M = int(X.shape[0])
+    if int(X.shape[1]) < K:
+        raise ValueError(f"X has {X.shape[1]} columns, the weight {K} inputs")
+    if gate is not None:
+        gate = _rows(gate, "gate")
+        if gate.shape[0] != M or gate.shape[1] < K:
+            raise ValueError("gate must cover X")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=X.device)
+    lib = _lib()
+    with torch.cuda.device(X.device):
+        rc = lib.gsr_dense_forward(M, int(N), int(K), X.data_ptr(), int(X.stride(0)) if M > 1 else max(int(X.shape[1]), K),
+                                   None if gate is None else gate.data_ptr(), 0 if gate is None else (int(gate.stride(0)) if M > 1 else int(gate.shape[1])),
+                                   planes.data_ptr(), None if bias is None else bias.data_ptr(), 1 if relu else 0, out.data_ptr(),
+                                   int(out.stride(0)) if M > 1 else int(out.shape[1]), _C._stream(X.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_forward")
+    return out
+
+
+def dense_wgrad(G, X, gate=None, out=None):
+    """dW [N, K] = G^T X for G [M, N] (optionally gated: G * (gate > 0)) and X [M, K]; deterministic (row slices added in a fixed order)."""
+    G, X = _rows(G, "G"), _rows(X, "X")
+    M, N, K = int(G.shape[0]), int(G.shape[1]), int(X.shape[1])
+    if int(X.shape[0]) != M:
+        raise ValueError("G and X must have the same number of rows")
+    if gate is not None:
+        gate = _rows(gate, "gate")
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=G.device)
+    lib = _lib()
+    ws = torch.empty((int(lib.gsr_dense_wgrad_workspace_size(M, N, K)),), dtype=torch.uint8, device=G.device)
+    ld = lambda t: int(t.stride(0)) if M > 1 else int(t.shape[1])
+    with torch.cuda.device(G.device):
+        rc = lib.gsr_dense_wgrad(M, N, K, G.data_ptr(), ld(G), None if gate is None else gate.data_ptr(), 0 if gate is None else ld(gate), X.data_ptr(), ld(X),
+                                 out.data_ptr(), int(out.stride(0)), ws.data_ptr(), _C._stream(G.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_wgrad")
+    return out

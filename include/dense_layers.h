@@ -1,0 +1,45 @@
+/*
+ * dense_layers.h -- C ABI of the fp32-accurate dense layers on the bf16 matrix cores (libgs_rasterizer_hip.so): the trunk of the node
+ * network the dynamic mapping loop trains (utils/time_utils.py:327-476 DeformNetwork: eight layers of width 256 on every (node, time sample)
+ * row of an iteration; utils/slam_backend.py:361-371 evaluates it per keyframe).
+ *
+ * An fp32 value is carried as three bf16 terms (hi + mid + lo = the 24 bits of its significand, by truncation: the remainders are exact) and a
+ * product as its six cross terms of weight >= 2^-16, accumulated in fp32 by v_mfma_f32_16x16x32_bf16; what is dropped is below 2e-7 of |x w|
+ * per product -- the results are fp32 GEMM results for every test of this repository -- at up to 2.7x the fp32 matrix rate.
+ * Non-finite inputs: a +-inf operand yields NaN where an fp32 GEMM yields +-inf (inf - inf in the split).
+ *
+ * All pointers are DEVICE pointers; fp32 matrices are row-major with explicit row strides (in floats). Returns 0 or a negative GSR_ERR_* code.
+ */
+#ifndef DENSE_LAYERS_H_INCLUDED
+#define DENSE_LAYERS_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The split form of a weight matrix W [N, K] (nn.Linear.weight: [out, in]; columns k0 .. k0 + K of a wider matrix with row stride ldw):
+ * `planes` receives three zero-padded bf16 planes [round_up(N, 128)][round_up(K, 32)] -- the weight of  Y = X W^T  -- or, with transposed != 0,
+ * the planes [round_up(K, 128)][round_up(N, 32)] of W^T -- the weight of the input gradient  dX = G W.  gsr_dense_planes_size(rows, cols) bytes
+ * for a weight of `rows` outputs and `cols` inputs. To be redone whenever W changes (once per optimizer step). */
+size_t gsr_dense_planes_size(int rows, int cols);
+int gsr_dense_split(int N, int K, const float* W, int ldw, int k0, int transposed, void* planes, void* stream);
+
+/* Y [M, N] = act(X [M, K] Wt + bias): planes = the split weight with N outputs and K inputs (gsr_dense_split), bias [N] or NULL, relu != 0:
+ * max(., 0). gate [M, K] or NULL: X is read as X * (gate > 0) -- the ReLU mask of the layer whose output `gate` is, so that the input-gradient
+ * product consumes the upstream cotangent directly. */
+int gsr_dense_forward(int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias, int relu,
+                      float* Y, int ldy, void* stream);
+
+/* dW [N, K] = G^T X  for G [M, N] (optionally gated like X above: gate [M, N]) and X [M, K]; the rows are cut into slices whose partial products
+ * are added in a fixed order (deterministic). workspace: gsr_dense_wgrad_workspace_size(M, N, K) bytes. */
+size_t gsr_dense_wgrad_workspace_size(int M, int N, int K);
+int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* gate, int ldgate, const float* X, int ldx, float* dW, int lddw,
+                    char* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
