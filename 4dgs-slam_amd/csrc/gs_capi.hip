@@ -1813,6 +1813,31 @@ int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* g
     return 0;
 }
 
+int gsr_trunk_forward(const gsr_trunk* t, int R, const float* emb, float* const* outs, const int* ldo, float* heads, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!t || R < 0 || t->E < 1 || t->E > TR_EPAD || t->n_head_outputs < 1 || t->n_head_outputs > 16 || !outs || !ldo || (R > 0 && (!emb || !heads))) {
+        g_last_error = "gsr_trunk_forward: invalid argument (embedding width 1..96, 1..16 head outputs)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    TrunkArgs a{};
+    a.R = R; a.E = t->E; a.NH = t->n_head_outputs; a.emb = emb; a.heads = heads;
+    for (int k = 0; k < 10; k++) { if (!t->planes[k]) { g_last_error = "gsr_trunk_forward: null weight planes"; return GSR_ERR_INVALID_ARGUMENT; } a.planes[k] = reinterpret_cast<const unsigned short*>(t->planes[k]); }
+    for (int k = 0; k < 9; k++) { if (!t->bias[k] || reinterpret_cast<uintptr_t>(t->bias[k]) % 16) { g_last_error = "gsr_trunk_forward: null / unaligned bias"; return GSR_ERR_INVALID_ARGUMENT; } a.bias[k] = t->bias[k]; }
+    for (int l = 0; l < TR_LAYERS; l++) {
+        if (!outs[l] || ldo[l] < TR_W || ldo[l] % 4 || reinterpret_cast<uintptr_t>(outs[l]) % 16) { g_last_error = "gsr_trunk_forward: layer outputs must be 16-byte aligned rows of >= 256 floats"; return GSR_ERR_INVALID_ARGUMENT; }
+        a.outs[l] = outs[l]; a.ldo[l] = ldo[l];
+    }
+    if (R == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(trunk_fwd_kernel, dim3((unsigned)((R + TR_BM - 1) / TR_BM)), dim3(256), TR_LDS_BYTES, stream, a);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---- SC-GS control nodes (include/control_nodes.h) ------------------------------------------------------------------------------
 int gsr_knn_points_batch(int64_t B, int64_t n, int64_t m, int D, int K, const float* p1, const float* p2, float* dist2, int64_t* idx, void* stream_)
 {

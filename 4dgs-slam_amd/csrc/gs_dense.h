@@ -25,8 +25,11 @@
 //     133 120   113 vs 163 (154 TFLOP/s fp32-equivalent = 0.37 of the bf16 matrix peak after the six-fold expansion)
 // At the node network's batch of the SLAM runs (~33k rows: 260 row tiles for 256 CUs, eight K steps per block) a block lives ~40 us for ~5 us
 // of matrix work: the one-step prefetch does not cover an HBM miss, and a two-step prefetch (second register set) spilled and was slower.
-// The trunk therefore still runs on the library (slam/deform_model._FusedTrunk); what would make this the faster path at that size is a
-// layer-fused kernel that keeps a row tile's activations in LDS across the eight layers (no operand fetch from HBM inside the K loop).
+// The trunk therefore still runs on the library (slam/deform_model._FusedTrunk). The layer-fused form -- trunk_fwd_kernel at the end of this
+// file: a 64-row tile's activations resident in LDS across the eight layers, no operand from HBM inside a K loop -- was built as well:
+// correct (tests), 420 vs 389 us (library) at 33 k rows, 696 vs 875 at 66 k. It is bound by its weight stream: three bf16 planes of a
+// 64 x 256 tile fill the LDS, so every 64 rows re-read the whole network's planes from L2 (48 KB per block and K step, 1.5 GB per forward at
+// 33 k rows). Opt-in (GSR_LAYER_FUSED_TRUNK=1).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -342,6 +345,167 @@ dense_wgrad_sum_kernel(const int slices, const int count, const float* __restric
     }
     for (; b < slices; b++) s0 += partial[(size_t)b * count + e];
     dW[(size_t)(e / K) * lddw + e % K] = (s0 + s1) + (s2 + s3);
+}
+
+
+// ---- the node network's trunk, forward, layer-fused -------------------------------------------------------------------------------------------
+// utils/time_utils.py:428-452 with the shipped structure: eight layers y = relu(x W^T + b) of width 256, the embedding (width E <= 96)
+// re-injected behind layer 4 (layer 5 reads [emb | h]), then all heads as one linear layer. One block carries a 64-row tile through ALL
+// layers: the tile's activations stay in LDS as three bf16 planes (96 KB, XOR-swizzled rows), the embedding's planes beside them (42 KB);
+// a wave owns 64 output columns and fetches its weight fragments straight from L2 in MFMA layout (the planes of gsr_dense_split, 3.1 MB for
+// the whole network: no LDS, no barrier on the weight side, one step of prefetch in registers); after a layer's products every wave turns its
+// 64 x 64 accumulators into bias + ReLU'd fp32 rows through a private LDS slab (16-byte stores of the layer's output, which the backward pass
+// reads) and into the next layer's bf16 planes. Per layer: two block barriers. No operand comes from HBM inside a K loop -- what the per-layer
+// kernels above wait for at this batch size.
+constexpr int TR_BM = 64, TR_W = 256, TR_EPAD = 96, TR_LAYERS = 8, TR_SKIP = 4;
+constexpr int TR_ACT_ROW_B = 512, TR_ACT_PLANE_B = TR_BM * TR_ACT_ROW_B;          // 32 KB per plane
+constexpr int TR_EMB_ROW_B = 224, TR_EMB_PLANE_B = TR_BM * TR_EMB_ROW_B;          // 12 chunks + 2 of padding: conflict-free fragment reads
+constexpr int TR_SLAB_FLOATS = 16 * 68;
+constexpr int TR_LDS_BYTES = 3 * TR_ACT_PLANE_B + 3 * TR_EMB_PLANE_B + 4 * TR_SLAB_FLOATS * 4;
+
+struct TrunkArgs {
+    int R, E, NH;                                   // rows, embedding width, head outputs (<= 16)
+    const float* emb;                               // [R, E]
+    const unsigned short* planes[10];               // L0 (K = 96), L1 .. L4, L5 embedding columns (K = 96), L5 trunk columns, L6, L7, heads
+    const float* bias[9];                           // eight layers, heads
+    float* outs[TR_LAYERS]; int ldo[TR_LAYERS];     // the layers' outputs (post-ReLU), row strides in floats
+    float* heads;                                   // [R, NH]
+};
+
+__device__ __forceinline__ int tr_act_off(int row, int chunk) { return row * TR_ACT_ROW_B + 16 * (chunk ^ (row & 15)); }
+
+// acc += A(src planes in LDS) x B(planes in L2)^T over `steps` K steps; EMB selects the embedding's planes as the A operand
+template <bool EMB>
+__device__ __forceinline__ void trunk_products(dense_acc (&acc)[4][4], const unsigned char* __restrict__ src, const unsigned short* __restrict__ planes,
+                                               const int Kpad, const int steps, const int wn, const int fi, const int fq)
+{
+    const size_t plane = (size_t)TR_W * Kpad;
+    dense_frag b[4][3], bn[4][3];
+    auto load_b = [&](int s, dense_frag (&dst)[4][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) dst[j][p] = *reinterpret_cast<const dense_frag*>(planes + p * plane + (size_t)(wn + 16 * j + fi) * Kpad + 32 * s + 8 * fq);
+    };
+    load_b(0, bn);
+    for (int s = 0; s < steps; s++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) b[j][p] = bn[j][p];
+        if (s + 1 < steps) load_b(s + 1, bn);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dense_frag a[3];
+            const int row = 16 * i + fi;
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+                a[p] = EMB ? dense_ld_frag(src + p * TR_EMB_PLANE_B + row * TR_EMB_ROW_B + 16 * (4 * s + fq))
+                           : dense_ld_frag(src + p * TR_ACT_PLANE_B + tr_act_off(row, 4 * s + fq));
+            dense_mfma6x4(a, b, acc[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+trunk_fwd_kernel(const TrunkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tr_lds[];
+    unsigned char* const act = tr_lds;
+    unsigned char* const embp = tr_lds + 3 * TR_ACT_PLANE_B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const slab = reinterpret_cast<float*>(tr_lds + 3 * TR_ACT_PLANE_B + 3 * TR_EMB_PLANE_B) + wave * TR_SLAB_FLOATS;
+    const int m0 = blockIdx.x * TR_BM, wn = 64 * wave, fi = lane & 15, fq = lane >> 4;
+
+    // ---- the tile's embedding rows -> bf16 planes (12 chunks of eight k per row; zero beyond E and beyond R) ----
+    for (int item = tid; item < TR_BM * (TR_EPAD / 8); item += 256) {
+        const int row = item / (TR_EPAD / 8), ch = item % (TR_EPAD / 8), m = m0 + row;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = (m < a.R && 8 * ch + e < a.E) ? a.emb[(size_t)m * a.E + 8 * ch + e] : 0.f;
+        dense_u4 h, md, l;
+        dense_split8(x, h, md, l);
+        const int o = row * TR_EMB_ROW_B + 16 * ch;
+        *reinterpret_cast<dense_u4*>(embp + o) = h;
+        *reinterpret_cast<dense_u4*>(embp + TR_EMB_PLANE_B + o) = md;
+        *reinterpret_cast<dense_u4*>(embp + 2 * TR_EMB_PLANE_B + o) = l;
+    }
+    __syncthreads();
+
+    for (int layer = 0; layer < TR_LAYERS; layer++) {
+        dense_acc acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+        if (layer == 0) {
+            trunk_products<true>(acc, embp, a.planes[0], TR_EPAD, TR_EPAD / 32, wn, fi, fq);
+        } else if (layer == TR_SKIP + 1) {                        // [emb | h]: the embedding columns of the weight, then the trunk columns
+            trunk_products<true>(acc, embp, a.planes[5], TR_EPAD, TR_EPAD / 32, wn, fi, fq);
+            trunk_products<false>(acc, act, a.planes[6], TR_W, TR_W / 32, wn, fi, fq);
+        } else {
+            trunk_products<false>(acc, act, a.planes[layer <= TR_SKIP ? layer : layer + 1], TR_W, TR_W / 32, wn, fi, fq);
+        }
+        __syncthreads();                                          // every wave has read the activations this layer consumed
+        // ---- bias + ReLU; the layer's output to memory (fp32) and to the planes of the next layer's input ----
+        const int col4 = 4 * (lane & 15);
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias[layer] + wn + col4);
+        float* const out = a.outs[layer];
+        const int ldo = a.ldo[layer];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();                      // (the slab is this wave's own: LDS accesses of one wave are served in order)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int row = 16 * i + 4 * t + (lane >> 4), m = m0 + row;
+                float4 v = *reinterpret_cast<const float4*>(&slab[(4 * t + (lane >> 4)) * 68 + col4]);
+                v.x = fmaxf(v.x + bv.x, 0.f); v.y = fmaxf(v.y + bv.y, 0.f); v.z = fmaxf(v.z + bv.z, 0.f); v.w = fmaxf(v.w + bv.w, 0.f);
+                if (m < a.R) *reinterpret_cast<float4*>(out + (size_t)m * ldo + wn + col4) = v;
+                uint32_t h0, m_0, l0, h1, m_1, l1, h2, m_2, l2, h3, m_3, l3;
+                dense_split(v.x, h0, m_0, l0); dense_split(v.y, h1, m_1, l1); dense_split(v.z, h2, m_2, l2); dense_split(v.w, h3, m_3, l3);
+                const int o = tr_act_off(row, (wn + col4) >> 3) + 2 * (col4 & 7);          // four bf16 = 8 bytes inside the chunk of eight
+                *reinterpret_cast<uint2*>(act + o) = make_uint2(dense_pack(h0, h1), dense_pack(h2, h3));
+                *reinterpret_cast<uint2*>(act + TR_ACT_PLANE_B + o) = make_uint2(dense_pack(m_0, m_1), dense_pack(m_2, m_3));
+                *reinterpret_cast<uint2*>(act + 2 * TR_ACT_PLANE_B + o) = make_uint2(dense_pack(l0, l1), dense_pack(l2, l3));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();                                          // the next layer's input is complete
+    }
+
+    // ---- the heads: one 16-column tile; wave w takes rows 16 w .. 16 w + 15 ----
+    {
+        dense_acc acc = dense_acc{0.f, 0.f, 0.f, 0.f};
+        const unsigned short* planes = a.planes[9];
+        const size_t plane = (size_t)DENSE_BN * TR_W;             // the heads' planes are padded to 128 rows
+        for (int s = 0; s < TR_W / 32; s++) {
+            dense_frag af[3], bf[3];
+            const int row = 16 * wave + fi;
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                af[p] = dense_ld_frag(act + p * TR_ACT_PLANE_B + tr_act_off(row, 4 * s + fq));
+                bf[p] = *reinterpret_cast<const dense_frag*>(planes + p * plane + (size_t)fi * TR_W + 32 * s + 8 * fq);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], acc, 0, 0, 0);
+        }
+        if (fi < a.NH) {
+            const float bh = a.bias[8][fi];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 16 * wave + 4 * fq + r;
+                if (m < a.R) a.heads[(size_t)m * a.NH + fi] = acc[r] + bh;
+            }
+        }
+    }
 }
 
 }  // namespace gsr

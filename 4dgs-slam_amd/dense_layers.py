@@ -21,6 +21,10 @@ from diff_gaussian_rasterization import _C
 _declared = False
 
 
+class _Trunk(C.Structure):          # gsr_trunk
+    _fields_ = [("E", C.c_int32), ("n_head_outputs", C.c_int32), ("planes", C.c_void_p * 10), ("bias", C.c_void_p * 9)]
+
+
 def _lib():
     global _declared
     lib = _C.load_library()
@@ -36,6 +40,8 @@ def _lib():
         lib.gsr_dense_wgrad_workspace_size.argtypes = [i, i, i]
         lib.gsr_dense_wgrad.restype = i
         lib.gsr_dense_wgrad.argtypes = [i, i, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
+        lib.gsr_trunk_forward.restype = i
+        lib.gsr_trunk_forward.argtypes = [C.POINTER(_Trunk), i, vp, C.POINTER(C.c_void_p), C.POINTER(i), vp, vp]
         _declared = True
     return lib
 
@@ -106,3 +112,51 @@ def dense_wgrad(G, X, gate=None, out=None):
     if rc < 0:
         _C._err(lib, rc, "gsr_dense_wgrad")
     return out
+
+
+TRUNK_LAYERS, TRUNK_WIDTH, TRUNK_SKIP, TRUNK_MAX_EMBEDDING, TRUNK_MAX_HEAD_OUTPUTS = 8, 256, 4, 96, 16
+
+
+def trunk_supported(emb, weights, skip, W_heads):
+    """Whether gsr_trunk_forward covers this network: the shipped structure (eight layers of width 256, the embedding re-injected behind layer
+    4), an embedding of at most 96 columns whose width is a multiple of 4 (16-byte rows of the [emb | h] buffer), at most 16 head outputs."""
+    E = int(emb.shape[1])
+    return (len(weights) == TRUNK_LAYERS and skip == TRUNK_SKIP and E <= TRUNK_MAX_EMBEDDING and E % 4 == 0 and int(W_heads.shape[0]) <= TRUNK_MAX_HEAD_OUTPUTS
+            and tuple(weights[0].shape) == (TRUNK_WIDTH, E) and tuple(weights[skip + 1].shape) == (TRUNK_WIDTH, E + TRUNK_WIDTH) and int(W_heads.shape[1]) == TRUNK_WIDTH
+            and all(tuple(weights[k].shape) == (TRUNK_WIDTH, TRUNK_WIDTH) for k in range(1, TRUNK_LAYERS) if k != skip + 1))
+
+
+def trunk_forward(emb, weights, biases, W_heads, b_heads):
+    """The node network's trunk and heads in ONE launch (gsr_trunk_forward): returns (heads [R, n], inputs, outs) where outs[l] is layer l's
+    output (post-ReLU) and inputs[l] the matrix layer l read -- emb, outs[l - 1], or for layer 5 the [R, E + 256] matrix [emb | outs[4]]
+    (outs[4] is a column range of it) -- exactly what the layer-by-layer forward keeps for the backward pass. The weights are split into their
+    bf16 planes on every call (they change with every optimizer step; ten small launches)."""
+    emb = _rows(emb, "emb").contiguous()
+    R, E = int(emb.shape[0]), int(emb.shape[1])
+    dev = emb.device
+    skip = TRUNK_SKIP
+    planes = [split_weight(weights[0])]
+    planes += [split_weight(weights[k]) for k in range(1, skip + 1)]
+    planes += [split_weight(weights[skip + 1], k0=0, K=E), split_weight(weights[skip + 1], k0=E, K=TRUNK_WIDTH)]
+    planes += [split_weight(weights[k]) for k in range(skip + 2, TRUNK_LAYERS)]
+    planes.append(split_weight(W_heads))
+    cat = torch.empty((R, E + TRUNK_WIDTH), dtype=torch.float32, device=dev)
+    cat[:, :E] = emb
+    outs = [cat[:, E:] if k == skip else torch.empty((R, TRUNK_WIDTH), dtype=torch.float32, device=dev) for k in range(TRUNK_LAYERS)]
+    heads = torch.empty((R, int(W_heads.shape[0])), dtype=torch.float32, device=dev)
+    t = _Trunk()
+    t.E, t.n_head_outputs = E, int(W_heads.shape[0])
+    bs = [b.contiguous() for b in biases] + [b_heads.contiguous()]
+    for k, pl in enumerate(planes):
+        t.planes[k] = pl.data_ptr()
+    for k, b in enumerate(bs):
+        t.bias[k] = b.data_ptr()
+    out_ptrs = (C.c_void_p * TRUNK_LAYERS)(*[o.data_ptr() for o in outs])
+    ldo = (C.c_int * TRUNK_LAYERS)(*[int(o.stride(0)) if R > 1 else int(E + TRUNK_WIDTH if k == skip else TRUNK_WIDTH) for k, o in enumerate(outs)])
+    lib = _lib()
+    with torch.cuda.device(dev):
+        rc = lib.gsr_trunk_forward(C.byref(t), R, emb.data_ptr(), out_ptrs, ldo, heads.data_ptr(), _C._stream(dev))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_trunk_forward")
+    inputs = [emb] + [outs[k - 1] if k != skip + 1 else cat for k in range(1, TRUNK_LAYERS)]
+    return heads, inputs, outs

@@ -253,6 +253,9 @@ def _grad_weight(G, X):
     return G.t().mm(X)
 
 
+LAYER_FUSED_TRUNK = os.environ.get("GSR_LAYER_FUSED_TRUNK", "0") == "1"
+
+
 class _FusedTrunk(torch.autograd.Function):
     """The node network on the device as ONE autograd node: D layers y = relu(x W^T + b) with the embedding re-injected behind layer `skip`
     (utils/time_utils.py:428-452), then all heads as one linear layer [sum of head widths, W] without activation. What autograd's op-by-op
@@ -269,6 +272,17 @@ class _FusedTrunk(torch.autograd.Function):
     def forward(ctx, emb, skip, W_heads, b_heads, *params):
         D = len(params) // 2
         E = emb.shape[1]
+        if LAYER_FUSED_TRUNK:
+            # opt-in (GSR_LAYER_FUSED_TRUNK=1): the eight layers + heads as ONE launch on the bf16 matrix cores with fp32-accurate three-term
+            # operands (include/dense_layers.h gsr_trunk_forward). Same values to fp32-GEMM accuracy; faster than the library from ~50 k rows
+            # (696 vs 875 us at 66 k), slower at the SLAM runs' ~33 k (420 vs 389 us): off by default. The backward pass below is unchanged.
+            import dense_layers
+            Ws, bs = list(params[0::2]), list(params[1::2])
+            if dense_layers.trunk_supported(emb, Ws, skip, W_heads):
+                out, inputs, outs = dense_layers.trunk_forward(emb, [w.detach() for w in Ws], [b.detach() for b in bs], W_heads.detach(), b_heads.detach())
+                ctx.skip, ctx.D, ctx.E = skip, D, E
+                ctx.save_for_backward(W_heads, *params[0::2], *inputs, *outs)
+                return out
         inputs, outs, h = [], [], emb
         for i in range(D):
             W, b = params[2 * i], params[2 * i + 1]

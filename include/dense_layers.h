@@ -39,6 +39,25 @@ size_t gsr_dense_wgrad_workspace_size(int M, int N, int K);
 int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* gate, int ldgate, const float* X, int ldx, float* dW, int lddw,
                     char* workspace, void* stream);
 
+/* ---- the node network's trunk, forward, as ONE launch ------------------------------------------------------------------------------------
+ * utils/time_utils.py:428-452 with the shipped structure: eight layers y = relu(x W^T + b) of width 256 on the embedding emb [R, E] (E <= 96),
+ * the embedding re-injected behind layer 4 (layer 5's weight is [256, E + 256] and reads [emb | h]), then all heads as one linear layer of
+ * n_head_outputs <= 16 columns. A 64-row tile's activations stay in LDS across the layers; weights come from L2 as the planes of
+ * gsr_dense_split:
+ *   planes[0]      layer 0's weight [256, E]                      planes[1..4]  layers 1..4 [256, 256]
+ *   planes[5], [6] layer 5's weight, columns [0, E) and [E, E + 256)            planes[7], [8]  layers 6, 7
+ *   planes[9]      the heads' weight [n_head_outputs, 256]
+ * bias[0..7] the layers' (256 floats, 16-byte aligned), bias[8] the heads'. outs[l] receives layer l's output (post-ReLU, fp32, row stride
+ * ldo[l] floats, 16-byte aligned rows: the backward pass reads them; outs[4] may point INTO a [R, E + 256] buffer at column E so that layer
+ * 5's input exists as one matrix), heads [R, n_head_outputs]. */
+typedef struct gsr_trunk {
+    int32_t E;
+    int32_t n_head_outputs;
+    const void* planes[10];
+    const float* bias[9];
+} gsr_trunk;
+int gsr_trunk_forward(const gsr_trunk* trunk, int R, const float* emb, float* const* outs, const int* ldo, float* heads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

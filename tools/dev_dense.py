@@ -39,3 +39,33 @@ for (N, K) in ((256, 84), (256, 256), (256, 340)):
     e = out[f"{N}x{K}"]
     e["tflops_fp32_equivalent_forward"] = round(2.0 * R * N * K / e["forward_us"] / 1e6, 1)
 print(json.dumps(out))
+# ---- the whole trunk forward: one layer-fused launch (+ ten weight splits) against the library's eight GEMMs with ReLU epilogue + heads ----
+import numpy as np
+E, W, D, skip = 84, 256, 8, 4
+emb = torch.randn((R, E), device=dev)
+Ws = [torch.randn((W, E if k == 0 else (E + W if k == skip + 1 else W)), device=dev) * 0.06 for k in range(D)]
+bs = [torch.randn((W,), device=dev) * 0.1 for _ in range(D)]
+Wh, bh = torch.randn((14, W), device=dev) * 0.05, torch.randn((14,), device=dev)
+def lib_forward():
+    h = emb
+    for k in range(D):
+        h = torch._addmm_activation(bs[k], h, Ws[k].t(), use_gelu=False)
+        if k == skip:
+            h = torch.cat([emb, h], -1)
+    return torch.addmm(bh, h, Wh.t())
+def replayed(f, n=20):
+    """f captured as a hipGraph and replayed: device time without the host's launch overhead (what the SLAM loops' replays see)"""
+    f(); torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        f()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        f()
+    return timed(g.replay, n)
+print(json.dumps({"rows": R, "trunk_forward_fused_us": round(timed(lambda: dl.trunk_forward(emb, Ws, bs, Wh, bh), 10), 1),
+                  "trunk_forward_library_us": round(timed(lib_forward, 10), 1),
+                  "replayed_trunk_forward_fused_us": round(replayed(lambda: dl.trunk_forward(emb, Ws, bs, Wh, bh)), 1),
+                  "replayed_trunk_forward_library_us": round(replayed(lib_forward), 1)}))
