@@ -1527,10 +1527,16 @@ static size_t hexviews_carve(const gsr_hexplane_field& f, const HexSortPlan& P, 
     return off + 256;
 }
 
+static bool hexviews_supported(const gsr_hexplane_field& f, int64_t n)
+{
+    // (the time families' LDS window is [4 views][4 or 8 levels][16 columns][C] floats: 64 channels with more than four levels would be 128 KB)
+    return hexsort_supported(f, n) && !(f.feat_dim == 64 && f.num_levels > 4);
+}
+
 size_t gsr_hexplane_backward_views_workspace_size(const gsr_hexplane_field* field, int64_t n, int V)
 {
     if (!field || n <= 0 || V < 1 || V > GSR_HEXPLANE_MAX_VIEWS || field->num_levels < 1 || field->num_levels > GSR_HEXPLANE_MAX_LEVELS ||
-        !hexsort_supported(*field, n)) return 0;
+        !hexviews_supported(*field, n)) return 0;
     HexSortPlan P;
     hexsort_plan(*field, &P);
     return hexviews_carve(*field, P, n, V, nullptr, nullptr, nullptr);
@@ -1543,7 +1549,7 @@ int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, cons
     if (int rc = hexplane_views_check(field, n, xyz, V, times, "gsr_hexplane_backward_views")) return rc;
     if (n == 0) return 0;
     const gsr_hexplane_field& f = *field;
-    if (!dL_dfeatures || !workspace || !hexsort_supported(f, n)) {
+    if (!dL_dfeatures || !workspace || !hexviews_supported(f, n)) {
         g_last_error = "gsr_hexplane_backward_views: null cotangent / workspace, or a geometry the sorted algorithm does not cover (see gsr_hexplane_backward_views_workspace_size)";
         return GSR_ERR_INVALID_ARGUMENT;
     }

@@ -294,7 +294,7 @@ def views_supported(ms_grids, n_views) -> bool:
     flat = ms_grids.flat if isinstance(ms_grids, _PlaneList) else [p for lv in ms_grids for p in lv]
     try:
         return (1 <= n_views <= MAX_VIEWS and all(p.is_cuda and p.dtype == torch.float32 and _plane_layout(p) == 1 and max(p.shape[2:]) <= 1024 for p in flat)
-                and flat[0].shape[1] in (8, 16, 32, 64))
+                and flat[0].shape[1] in (8, 16, 32, 64) and not (flat[0].shape[1] == 64 and len(flat) > 24))
     except ValueError:
         return False
 
