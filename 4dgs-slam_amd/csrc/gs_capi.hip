@@ -1765,20 +1765,88 @@ int gsr_dense_split(int N, int K, const float* W, int ldw, int k0, int transpose
     return 0;
 }
 
-int gsr_dense_forward(int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias, int relu,
-                      float* Y, int ldy, void* stream_)
+static int dense_forward_launch(const char* who, int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias,
+                                int relu, float* Y, int ldy, const float* mask, int ldmask, float* colsum_out, char* workspace, void* stream_)
 {
-    if (M < 0 || N < 1 || K < 1 || !planes || (M > 0 && (!X || !Y)) || ldx < K || ldy < N || (gate && ldgate < K)) {
-        g_last_error = "gsr_dense_forward: invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || N < 1 || K < 1 || !planes || (M > 0 && (!X || !Y)) || ldx < K || ldy < N || (gate && ldgate < K) || (mask && ldmask < N)) {
+        g_last_error = std::string(who) + ": invalid argument"; return GSR_ERR_INVALID_ARGUMENT;
     }
-    if (M == 0) return 0;
+    if (M == 0) {
+        if (colsum_out) GSR_HIP_CHECK(hipMemsetAsync(colsum_out, 0, (size_t)N * sizeof(float), stream));
+        return 0;
+    }
     const int Npad = round_up_int(N, DENSE_BN), Kpad = round_up_int(K, DENSE_BK);
     const int vec = (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (!gate || ((ldgate % 4 == 0) && reinterpret_cast<uintptr_t>(gate) % 16 == 0));
     // 16-byte output stores through an LDS transposition when every row piece is whole and aligned (the trunk's layers), else element stores
-    const int vec_out = (N % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0) && (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0);
-    const dim3 grid((unsigned)((M + DENSE_BM - 1) / DENSE_BM), (unsigned)(Npad / DENSE_BN));
-    hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(DENSE_THREADS), 0, (hipStream_t)stream_, M, N, K, X, ldx, gate, ldgate,
-                       reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, vec_out ? 1 : 0);
+    const int vec_out = (N % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0) && (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
+                        (!mask || ((ldmask % 4 == 0) && reinterpret_cast<uintptr_t>(mask) % 16 == 0));
+    if (colsum_out && (!vec_out || !workspace || (reinterpret_cast<uintptr_t>(workspace) % 16))) {
+        g_last_error = std::string(who) + ": the column sums need N % 4 == 0, 16-byte aligned rows of Y / mask and a 16-byte aligned workspace"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    static const int forced_bt = getenv("GSR_DENSE_ROW_TILES") ? atoi(getenv("GSR_DENSE_ROW_TILES")) : 0;      // (development: 2 .. 10)
+    float* partial = colsum_out ? reinterpret_cast<float*>(workspace) : nullptr;
+    // full-width outputs (the network's layers): one block of eight waves per CU, two LDS stages (dense_fwd8_kernel); GSR_DENSE_WIDE=0: the
+    // 128-column kernel
+    static const bool wide_ok = !(getenv("GSR_DENSE_WIDE") && getenv("GSR_DENSE_WIDE")[0] == '0');
+    if (wide_ok && vec_out && N % DENSE8_BN == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE8_LDS_BYTES));
+            attr_set = true;
+        }
+        const int bt8 = forced_bt >= 2 && forced_bt <= DENSE_MAX_BT ? forced_bt : dense8_row_tiles(M, N / DENSE8_BN);
+        const dim3 grid8((unsigned)((M + 16 * bt8 - 1) / (16 * bt8)), (unsigned)(N / DENSE8_BN));
+        hipLaunchKernelGGL(dense_fwd8_kernel, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, N, K, X, ldx, gate, ldgate,
+                           reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, bt8, mask, ldmask, partial);
+        if (colsum_out) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, (int)grid8.x, N, (const float*)partial, colsum_out);
+        GSR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const int bt = forced_bt >= 2 && forced_bt <= DENSE_MAX_BT ? forced_bt : dense_row_tiles(M, Npad / DENSE_BN);
+    const dim3 grid((unsigned)((M + 16 * bt - 1) / (16 * bt)), (unsigned)(Npad / DENSE_BN));
+    hipLaunchKernelGGL(dense_fwd_kernel, grid, dim3(DENSE_THREADS), 0, stream, M, N, K, X, ldx, gate, ldgate,
+                       reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, vec_out ? 1 : 0, bt, mask, ldmask, partial);
+    if (colsum_out) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, (int)grid.x, N, (const float*)partial, colsum_out);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int gsr_dense_forward(int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias, int relu,
+                      float* Y, int ldy, void* stream_)
+{
+    return dense_forward_launch("gsr_dense_forward", M, N, K, X, ldx, gate, ldgate, planes, bias, relu, Y, ldy, nullptr, 0, nullptr, nullptr, stream_);
+}
+
+size_t gsr_dense_backward_input_workspace_size(int M, int N)
+{
+    if (M < 1 || N < 1) return 256;
+    return (size_t)((M + 31) / 32) * (size_t)N * sizeof(float) + 256;        // (at least two row tiles of 16 per block)
+}
+
+int gsr_dense_backward_input(int M, int N, int K, const float* G, int ldg, const void* planes_t, const float* mask, int ldmask, float* dX, int lddx,
+                             float* dbias, char* workspace, void* stream_)
+{
+    return dense_forward_launch("gsr_dense_backward_input", M, N, K, G, ldg, nullptr, 0, planes_t, nullptr, 0, dX, lddx, mask, ldmask, dbias, workspace, stream_);
+}
+
+int gsr_dense_split_many(int count, const gsr_dense_split_item* items, void* stream_)
+{
+    if (count < 0 || count > DENSE_SPLIT_MAX || (count > 0 && !items)) { g_last_error = "gsr_dense_split_many: 0 <= count <= 24 items"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (count == 0) return 0;
+    DenseSplitItems a;
+    int64_t largest = 0;
+    for (int i = 0; i < count; i++) {
+        const gsr_dense_split_item& q = items[i];
+        if (q.N < 1 || q.K < 1 || !q.W || !q.planes || q.k0 < 0 || q.ldw < q.k0 + q.K) { g_last_error = "gsr_dense_split_many: invalid item"; return GSR_ERR_INVALID_ARGUMENT; }
+        const int rows = q.transposed ? q.K : q.N, cols = q.transposed ? q.N : q.K;
+        DenseSplitItem& d = a.item[i];
+        d.W = q.W; d.planes = reinterpret_cast<unsigned short*>(q.planes); d.N = q.N; d.K = q.K; d.ldw = q.ldw; d.k0 = q.k0; d.transposed = q.transposed ? 1 : 0;
+        d.rows_pad = round_up_int(rows, DENSE_BN); d.cols_pad = round_up_int(cols, DENSE_BK);
+        largest = std::max(largest, (int64_t)d.rows_pad * d.cols_pad);
+    }
+    const unsigned bx = (unsigned)std::min<int64_t>((largest + 255) / 256, 128);
+    hipLaunchKernelGGL(dense_split_many_kernel, dim3(bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream_, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

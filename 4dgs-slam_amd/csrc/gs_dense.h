@@ -105,36 +105,71 @@ dense_split_kernel(const int N, const int K, const float* __restrict__ W, const 
     planes[2 * plane + e] = (unsigned short)(lo >> 16);
 }
 
+// several weights in one launch (the network's layers, both orientations, once per optimizer step): blockIdx.y = item
+constexpr int DENSE_SPLIT_MAX = 24;
+struct DenseSplitItem { const float* W; unsigned short* planes; int N, K, ldw, k0, transposed, rows_pad, cols_pad; };
+struct DenseSplitItems { DenseSplitItem item[DENSE_SPLIT_MAX]; };
+__global__ void __launch_bounds__(256)
+dense_split_many_kernel(const DenseSplitItems items)
+{
+    const DenseSplitItem& it = items.item[blockIdx.y];
+    const size_t plane = (size_t)it.rows_pad * it.cols_pad;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)plane; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / it.cols_pad), c = (int)(e % it.cols_pad);
+        const int n = it.transposed ? c : r, k = it.transposed ? r : c;
+        const float x = (n < it.N && k < it.K) ? it.W[(size_t)n * it.ldw + it.k0 + k] : 0.f;
+        uint32_t hi, mid, lo;
+        dense_split(x, hi, mid, lo);
+        it.planes[e] = (unsigned short)(hi >> 16);
+        it.planes[plane + e] = (unsigned short)(mid >> 16);
+        it.planes[2 * plane + e] = (unsigned short)(lo >> 16);
+    }
+}
+
 // ---- Y [M, N] = act(X [M, K] W^T + bias), W given as planes [3][Npad][Kpad] -----------------------------------------------------------------
 // X: row stride ldx floats, optional gate: X is read as x * (gate > 0) (the ReLU mask of the layer that produced the cotangent, so that the
 // input-gradient product consumes dY and the layer's output directly). relu: max(., 0) on the way out.
+constexpr int DENSE_MAX_BT = 10;           // row tiles of 16 per block: 2 .. 10 (the two wave rows take ceil / floor of them, at most five each)
 __global__ void __launch_bounds__(DENSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))      // two blocks per CU: 256 registers per lane, no spills
 dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict__ X, const int ldx, const float* __restrict__ gate, const int ldgate,
                  const unsigned short* __restrict__ planes, const int Npad, const int Kpad, const float* __restrict__ bias, const int relu,
-                 float* __restrict__ Y, const int ldy, const int vec, const int vec_out)
+                 float* __restrict__ Y, const int ldy, const int vec, const int vec_out, const int bt,
+                 const float* __restrict__ mask, const int ldmask, float* __restrict__ colsum)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_a[3][DENSE_BM * DENSE_ROW_B];
+    // mask [M, N] (optional): the result is written as y * (mask > 0) -- the input-gradient product hands its result straight to the ReLU of
+    // the layer below (G_{l-1} = (G_l W_l) [y_{l-1} > 0]); colsum [row blocks][N] (optional, 16-byte output path only): the column sums of
+    // what this block wrote, added in a fixed order (that layer's bias gradient after dense_colsum's pass over the row blocks).
+    // The block tile is 16 bt rows x 128 columns with bt chosen per launch (dense_row_tiles): with a fixed 128-row tile the node network's
+    // batch of 33 280 rows is 520 blocks for the 512 block slots of the chip -- eight blocks run a second round alone and the launch takes
+    // two block lifetimes (measured: 41 us; 32 768 rows, exactly 512 blocks: see tools/dev_dense.py). Nine row tiles per block are 464
+    // blocks, one round.
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[3][16 * DENSE_MAX_BT * DENSE_ROW_B];
     __shared__ __attribute__((aligned(16))) unsigned char s_b[3][DENSE_BN * DENSE_ROW_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * DENSE_BM, n0 = blockIdx.y * DENSE_BN;
-    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;        // this wave's 64 x 64 corner of the block tile
+    const int rows_a = 16 * bt;
+    const int m0 = blockIdx.x * rows_a, n0 = blockIdx.y * DENSE_BN;
+    const int na = (bt + 1) >> 1;                                   // row tiles of the first wave row; the second takes the rest
+    const int nt = (wave & 1) ? bt - na : na;                       // this wave's row tiles (wave-uniform) ...
+    const int wm = (wave & 1) ? 16 * na : 0, wn = (wave >> 1) * 64; // ... starting at row wm of the block tile; its 64 columns
     const int fi = lane & 15, fq = lane >> 4;                      // fragment row / column and its group of eight k
-    dense_acc acc[4][4];
+    dense_acc acc[5][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
 
-    // staging assignment: item = (row, group of eight k); 128 rows x 4 groups = 512 items, two per thread. The next step's operands are
-    // requested before this step's products are issued. (Requesting X two steps ahead -- a second set of staging registers, the loop unrolled
-    // by two -- was built and measured: 256 registers, spills, 41 -> 54 us at 33k rows.)
+    // staging assignment: item = (row, group of eight k); 16 bt rows x 4 groups of X (up to three per thread), 128 x 4 of the weight (two per
+    // thread). The next step's operands are requested before this step's products are issued. (Requesting X two steps ahead -- a second set of
+    // staging registers, the loop unrolled by two -- was built and measured: 256 registers, spills, 41 -> 54 us at 33k rows.)
     const int steps = Kpad / DENSE_BK;
-    float xa[2][8];
+    const int items_a = rows_a * 4;
+    float xa[3][8];
     dense_u4 wb[2][3];
     auto fetch = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < 3; it++) {
             const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            if (item >= items_a) continue;
             const int m = m0 + row, k = s * DENSE_BK + 8 * g;
             const float* src = X + (size_t)m * ldx + k;
             const float* gsrc = gate ? gate + (size_t)m * ldgate + k : nullptr;
@@ -158,7 +193,11 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
                     xa[it][e] = v;
                 }
             }
-            const size_t off = (size_t)(n0 + row) * Kpad + k;        // planes are padded: always in range
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            const size_t off = (size_t)(n0 + row) * Kpad + s * DENSE_BK + 8 * g;        // planes are padded: always in range
             const size_t plane = (size_t)Npad * Kpad;
 #pragma unroll
             for (int p = 0; p < 3; p++) wb[it][p] = *reinterpret_cast<const dense_u4*>(planes + p * plane + off);
@@ -166,14 +205,20 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
     };
     auto stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < 3; it++) {
             const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            if (item >= items_a) continue;
             dense_u4 h, m_, l;
             dense_split8(xa[it], h, m_, l);
             const int o = dense_off(row, g);
             *reinterpret_cast<dense_u4*>(&s_a[0][o]) = h;
             *reinterpret_cast<dense_u4*>(&s_a[1][o]) = m_;
             *reinterpret_cast<dense_u4*>(&s_a[2][o]) = l;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE_THREADS, row = item >> 2, g = item & 3;
+            const int o = dense_off(row, g);
 #pragma unroll
             for (int p = 0; p < 3; p++) *reinterpret_cast<dense_u4*>(&s_b[p][o]) = wb[it][p];
         }
@@ -190,37 +235,64 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
 #pragma unroll
             for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(&s_b[p][dense_off(wn + 16 * j + fi, fq)]);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            dense_frag a[3];
+        for (int i = 0; i < 5; i++) {
+            if (i < nt) {
+                dense_frag a[3];
 #pragma unroll
-            for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(&s_a[p][dense_off(wm + 16 * i + fi, fq)]);
-            dense_mfma6x4(a, b, acc[i]);
+                for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(&s_a[p][dense_off(wm + 16 * i + fi, fq)]);
+                dense_mfma6x4(a, b, acc[i]);
+            }
         }
     }
     // C layout: column = lane & 15, rows 4 (lane >> 4) + r. A wave's 16 x 64 slab goes through a wave-private LDS tile so that the stores are
     // 16 bytes per lane and 256 contiguous bytes per row (straight from the accumulators a store instruction wrote four 64-byte pieces)
     if (vec_out) {
         __syncthreads();                                          // the last step's fragments have been read: the staging arrays are free
-        float* slab = reinterpret_cast<float*>(&s_a[0][0]) + wave * (16 * 68);          // 4 x 4.25 KB inside s_a (30 KB)
+        float* slab = reinterpret_cast<float*>(&s_a[0][0]) + wave * (16 * 68);          // 4 x 4.25 KB inside s_a
         const int col4 = 4 * (lane & 15), nn = n0 + wn + col4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias && nn + 3 < N) bv = *reinterpret_cast<const float4*>(bias + nn);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 5; i++) {
+            if (i < nt) {                                         // (the slab is the wave's own: no block barrier between its store and its reads)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+                for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
-            __syncthreads();
+                    for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's LDS stores have landed
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int row = 4 * t + (lane >> 4), m = m0 + wm + 16 * i + row;
-                float4 v = *reinterpret_cast<const float4*>(&slab[row * 68 + col4]);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (m < M && nn + 3 < N) *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
+                for (int t = 0; t < 4; t++) {
+                    const int row = 4 * t + (lane >> 4), m = m0 + wm + 16 * i + row;
+                    float4 v = *reinterpret_cast<const float4*>(&slab[row * 68 + col4]);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (m < M && nn + 3 < N) {
+                        if (mask) {
+                            const float4 mv = *reinterpret_cast<const float4*>(mask + (size_t)m * ldmask + nn);
+                            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f; v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                        }
+                        *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;          // rows in increasing order within the lane
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
+        }
+        if (colsum) {
+            // lanes l, l + 16, l + 32, l + 48 hold rows 4 t + {0, 1, 2, 3} of the same four columns: (0 + 1) + (2 + 3), then the two wave rows
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                cs.x += __shfl_xor(cs.x, off, 64); cs.y += __shfl_xor(cs.y, off, 64); cs.z += __shfl_xor(cs.z, off, 64); cs.w += __shfl_xor(cs.w, off, 64);
+            }
+            __syncthreads();                                      // every wave is done with its slab
+            float4* s_cs = reinterpret_cast<float4*>(&s_b[0][0]);   // [4 waves][16 lanes]
+            if (lane < 16) s_cs[wave * 16 + lane] = cs;
             __syncthreads();
+            if ((wave & 1) == 0 && lane < 16 && nn + 3 < N) {
+                const float4 o = s_cs[(wave + 1) * 16 + lane];
+                *reinterpret_cast<float4*>(colsum + (size_t)blockIdx.x * N + nn) = make_float4(cs.x + o.x, cs.y + o.y, cs.z + o.z, cs.w + o.w);
+            }
         }
         return;
     }
@@ -230,18 +302,222 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
         if (n >= N) continue;
         const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 5; i++) {
+            if (i >= nt) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int m = m0 + wm + 16 * i + 4 * fq + r;
                 if (m < M) {
                     float v = acc[i][j][r] + bv;
                     if (relu) v = fmaxf(v, 0.f);
+                    if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;
                     Y[(size_t)m * ldy + n] = v;
                 }
             }
         }
     }
+}
+
+// ---- the same product, one block per CU (round 5, second form) --------------------------------------------------------------------------------
+// Ablations of dense_fwd_kernel at 32 768 rows x 256 x 256 (tools/dev_dense.py history): 10 us of launch + first fetch + epilogue, +5 us staging
+// (split + LDS stores), +5 us global fetches, +4 us fragment reads, +8 us MFMA = 32 us -- the phases ADD UP: two blocks per CU that start
+// together run in lock step (both stage, both multiply), a barrier on either side of every phase. dense_fwd8_kernel removes the lock step:
+//   * ONE block of eight waves per CU and a 16 bt x 256 tile (the whole width of the network: X is read once, not once per column tile);
+//   * the LDS holds TWO stages (2 x (30 + 48) KB): step s + 1 is staged while step s is multiplied, one barrier per step;
+//   * the two waves of a SIMD (w and w + 4) take the phases in OPPOSITE order -- one multiplies while the other splits and stores -- so the
+//     matrix pipe and the vector / LDS pipes of a SIMD are busy at the same time.
+constexpr int DENSE8_THREADS = 512, DENSE8_BN = 256;
+constexpr int DENSE8_STAGE_A = 3 * 16 * DENSE_MAX_BT * DENSE_ROW_B, DENSE8_STAGE_B = 3 * DENSE8_BN * DENSE_ROW_B;       // 30 720 + 49 152 bytes
+constexpr int DENSE8_LDS_BYTES = 2 * (DENSE8_STAGE_A + DENSE8_STAGE_B);                                                // 159 744 of 163 840
+__global__ void __launch_bounds__(DENSE8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict__ X, const int ldx, const float* __restrict__ gate, const int ldgate,
+                  const unsigned short* __restrict__ planes, const int Npad, const int Kpad, const float* __restrict__ bias, const int relu,
+                  float* __restrict__ Y, const int ldy, const int vec, const int bt,
+                  const float* __restrict__ mask, const int ldmask, float* __restrict__ colsum)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dense8[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows_a = 16 * bt;
+    const int m0 = blockIdx.x * rows_a, n0 = blockIdx.y * DENSE8_BN;
+    const int na = (bt + 1) >> 1;
+    const int nt = (wave & 1) ? bt - na : na;
+    const int wm = (wave & 1) ? 16 * na : 0, wn = ((wave >> 1) & 3) * 64;
+    const int stage_first = wave >> 2;                              // waves w and w + 4 share a SIMD: opposite phase order
+    const int fi = lane & 15, fq = lane >> 4;
+    dense_acc acc[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+    auto sa = [&](int buf, int p) __attribute__((always_inline)) { return s_dense8 + buf * (DENSE8_STAGE_A + DENSE8_STAGE_B) + p * (16 * DENSE_MAX_BT * DENSE_ROW_B); };
+    auto sb = [&](int buf, int p) __attribute__((always_inline)) { return s_dense8 + buf * (DENSE8_STAGE_A + DENSE8_STAGE_B) + DENSE8_STAGE_A + p * (DENSE8_BN * DENSE_ROW_B); };
+
+    const int steps = Kpad / DENSE_BK;
+    const int items_a = rows_a * 4;                                 // (row, group of eight k): up to 640, two per thread; the weight: 1024, two per thread
+    float xa[2][8];
+    dense_u4 wb[2][3];
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
+            if (item >= items_a) continue;
+            const int m = m0 + row, k = s * DENSE_BK + 8 * g;
+            const float* src = X + (size_t)m * ldx + k;
+            const float* gsrc = gate ? gate + (size_t)m * ldgate + k : nullptr;
+            if (vec && m < M && k + 8 <= K) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                xa[it][0] = v0.x; xa[it][1] = v0.y; xa[it][2] = v0.z; xa[it][3] = v0.w;
+                xa[it][4] = v1.x; xa[it][5] = v1.y; xa[it][6] = v1.z; xa[it][7] = v1.w;
+                if (gate) {
+                    const float4 g0 = *reinterpret_cast<const float4*>(gsrc), g1 = *reinterpret_cast<const float4*>(gsrc + 4);
+                    xa[it][0] = g0.x > 0.f ? xa[it][0] : 0.f; xa[it][1] = g0.y > 0.f ? xa[it][1] : 0.f;
+                    xa[it][2] = g0.z > 0.f ? xa[it][2] : 0.f; xa[it][3] = g0.w > 0.f ? xa[it][3] : 0.f;
+                    xa[it][4] = g1.x > 0.f ? xa[it][4] : 0.f; xa[it][5] = g1.y > 0.f ? xa[it][5] : 0.f;
+                    xa[it][6] = g1.z > 0.f ? xa[it][6] : 0.f; xa[it][7] = g1.w > 0.f ? xa[it][7] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const bool ok = m < M && k + e < K;
+                    float v = ok ? src[e] : 0.f;
+                    if (gate) v = (ok && gsrc[e] > 0.f) ? v : 0.f;
+                    xa[it][e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
+            const size_t off = (size_t)(n0 + row) * Kpad + s * DENSE_BK + 8 * g;        // planes are padded to 256 rows here: always in range
+            const size_t plane = (size_t)Npad * Kpad;
+#pragma unroll
+            for (int p = 0; p < 3; p++) wb[it][p] = *reinterpret_cast<const dense_u4*>(planes + p * plane + off);
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
+            if (item >= items_a) continue;
+            dense_u4 h, m_, l;
+            dense_split8(xa[it], h, m_, l);
+            const int o = dense_off(row, g);
+            *reinterpret_cast<dense_u4*>(sa(buf, 0) + o) = h;
+            *reinterpret_cast<dense_u4*>(sa(buf, 1) + o) = m_;
+            *reinterpret_cast<dense_u4*>(sa(buf, 2) + o) = l;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
+            const int o = dense_off(row, g);
+#pragma unroll
+            for (int p = 0; p < 3; p++) *reinterpret_cast<dense_u4*>(sb(buf, p) + o) = wb[it][p];
+        }
+    };
+    auto multiply = [&](int buf) __attribute__((always_inline)) {
+        dense_frag b[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(sb(buf, p) + dense_off(wn + 16 * j + fi, fq));
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (i < nt) {
+                dense_frag a[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(sa(buf, p) + dense_off(wm + 16 * i + fi, fq));
+                dense_mfma6x4(a, b, acc[i]);
+            }
+        }
+    };
+    fetch(0);
+    stage(0);
+    if (steps > 1) fetch(1);
+    __syncthreads();
+    for (int s = 0; s < steps; s++) {
+        const int cur = s & 1;
+        if (stage_first) {
+            if (s + 1 < steps) { stage(cur ^ 1); if (s + 2 < steps) fetch(s + 2); }
+            multiply(cur);
+        } else {
+            multiply(cur);
+            if (s + 1 < steps) { stage(cur ^ 1); if (s + 2 < steps) fetch(s + 2); }
+        }
+        __syncthreads();                       // stage cur ^ 1 is complete, stage cur has been read
+    }
+    // epilogue as in dense_fwd_kernel: a wave's 16 x 64 slab through a wave-private LDS tile (8 x 4.25 KB in the first stage), 16-byte stores
+    float* slab = reinterpret_cast<float*>(s_dense8) + wave * (16 * 68);
+    const int col4 = 4 * (lane & 15), nn = n0 + wn + col4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && nn + 3 < N) bv = *reinterpret_cast<const float4*>(bias + nn);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (i < nt) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int row = 4 * t + (lane >> 4), m = m0 + wm + 16 * i + row;
+                float4 v = *reinterpret_cast<const float4*>(&slab[row * 68 + col4]);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (m < M && nn + 3 < N) {
+                    if (mask) {
+                        const float4 mv = *reinterpret_cast<const float4*>(mask + (size_t)m * ldmask + nn);
+                        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f; v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
+                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (colsum) {
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            cs.x += __shfl_xor(cs.x, off, 64); cs.y += __shfl_xor(cs.y, off, 64); cs.z += __shfl_xor(cs.z, off, 64); cs.w += __shfl_xor(cs.w, off, 64);
+        }
+        __syncthreads();
+        float4* s_cs = reinterpret_cast<float4*>(s_dense8 + DENSE8_STAGE_A + DENSE8_STAGE_B);      // [8 waves][16 lanes] in the second stage
+        if (lane < 16) s_cs[wave * 16 + lane] = cs;
+        __syncthreads();
+        if ((wave & 1) == 0 && lane < 16 && nn + 3 < N) {
+            const float4 o = s_cs[(wave + 1) * 16 + lane];
+            *reinterpret_cast<float4*>(colsum + (size_t)blockIdx.x * N + nn) = make_float4(cs.x + o.x, cs.y + o.y, cs.z + o.z, cs.w + o.w);
+        }
+    }
+}
+
+// row tiles of 16 per block for dense_fwd8_kernel: one block per CU, 256 slots per round
+inline int dense8_row_tiles(int M, int col_tiles)
+{
+    const long units = ((long)M + 15) / 16;
+    int best = 8; long best_cost = -1;
+    for (int bt = 2; bt <= DENSE_MAX_BT; bt++) {
+        const long blocks = ((units + bt - 1) / bt) * col_tiles, rounds = (blocks + 255) / 256;
+        const long cost = rounds * (bt + 3);
+        if (best_cost < 0 || cost < best_cost) { best = bt; best_cost = cost; }
+    }
+    return best;
+}
+
+// row tiles of 16 per block for a forward launch: the count that needs the fewest rounds of the chip's 512 block slots (two blocks per CU),
+// each round weighed by the tile's rows plus a fixed share (weight staging, barriers, the epilogue)
+inline int dense_row_tiles(int M, int col_tiles)
+{
+    const long units = ((long)M + 15) / 16;
+    int best = 8; long best_cost = -1;
+    for (int bt = 2; bt <= DENSE_MAX_BT; bt++) {
+        const long blocks = ((units + bt - 1) / bt) * col_tiles, rounds = (blocks + 511) / 512;
+        const long cost = rounds * (bt + 3);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && bt == 8)) { best = bt; best_cost = cost; }
+    }
+    return best;
 }
 
 // ---- dW [N, K] = G^T X over the rows [r0, r1) of this block's slice ---------------------------------------------------------------------------

@@ -25,6 +25,10 @@ class _Trunk(C.Structure):          # gsr_trunk
     _fields_ = [("E", C.c_int32), ("n_head_outputs", C.c_int32), ("planes", C.c_void_p * 10), ("bias", C.c_void_p * 9)]
 
 
+class _SplitItem(C.Structure):      # gsr_dense_split_item
+    _fields_ = [("W", C.c_void_p), ("planes", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32), ("k0", C.c_int32), ("transposed", C.c_int32)]
+
+
 def _lib():
     global _declared
     lib = _C.load_library()
@@ -40,6 +44,12 @@ def _lib():
         lib.gsr_dense_wgrad_workspace_size.argtypes = [i, i, i]
         lib.gsr_dense_wgrad.restype = i
         lib.gsr_dense_wgrad.argtypes = [i, i, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
+        lib.gsr_dense_backward_input_workspace_size.restype = C.c_size_t
+        lib.gsr_dense_backward_input_workspace_size.argtypes = [i, i]
+        lib.gsr_dense_backward_input.restype = i
+        lib.gsr_dense_backward_input.argtypes = [i, i, i, vp, i, vp, vp, i, vp, i, vp, vp, vp]
+        lib.gsr_dense_split_many.restype = i
+        lib.gsr_dense_split_many.argtypes = [i, C.POINTER(_SplitItem), vp]
         lib.gsr_trunk_forward.restype = i
         lib.gsr_trunk_forward.argtypes = [C.POINTER(_Trunk), i, vp, C.POINTER(C.c_void_p), C.POINTER(i), vp, vp]
         _declared = True
@@ -91,6 +101,61 @@ def dense_forward(X, planes, N, K, bias=None, relu=False, gate=None, out=None):
     if rc < 0:
         _C._err(lib, rc, "gsr_dense_forward")
     return out
+
+
+def planes_size(W, k0=0, K=None, transposed=False):
+    N = int(W.shape[0])
+    K = int(W.shape[1]) - k0 if K is None else int(K)
+    return int(_lib().gsr_dense_planes_size(*((K, N) if transposed else (N, K))))
+
+
+def split_weights(requests, out=None):
+    """Several split_weight calls as ONE launch (gsr_dense_split_many): requests = [(W, k0, K or None, transposed)], at most 24. Returns the
+    planes of each request (views of one uint8 buffer, 256-byte aligned; `out`: a buffer of a previous call with the same requests, reused)."""
+    sizes = [(planes_size(W, k0, K, tr) + 255) // 256 * 256 for (W, k0, K, tr) in requests]
+    dev = requests[0][0].device
+    if out is None or out.numel() != sum(sizes):
+        out = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+    items = (_SplitItem * len(requests))()
+    views, off = [], 0
+    for j, ((W, k0, K, tr), size) in enumerate(zip(requests, sizes)):
+        W = _rows(W, "weight")
+        views.append(out[off:off + size])
+        it = items[j]
+        it.W, it.planes, it.N = W.data_ptr(), views[-1].data_ptr(), int(W.shape[0])
+        it.K, it.ldw, it.k0, it.transposed = (int(W.shape[1]) - k0 if K is None else int(K)), int(W.stride(0)), int(k0), 1 if tr else 0
+        off += size
+    lib = _lib()
+    with torch.cuda.device(dev):
+        rc = lib.gsr_dense_split_many(len(requests), items, _C._stream(dev))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_split_many")
+    return views, out
+
+
+def dense_backward_input(G, planes_t, N, K, mask=None, want_bias=True, out=None):
+    """(dX, dbias) with dX [M, N] = (G [M, K] W) * (mask > 0) and dbias [N] its column sums (None without want_bias) -- the input gradient of a
+    layer whose weight W is [K, N] (planes_t = its transposed planes), masked by the OUTPUT `mask` of the layer below and summed into that
+    layer's bias gradient, in one pass (gsr_dense_backward_input; deterministic)."""
+    G = _rows(G, "G")
+    M = int(G.shape[0])
+    if mask is not None:
+        mask = _rows(mask, "mask")
+        if int(mask.shape[0]) != M or int(mask.shape[1]) < N:
+            raise ValueError("mask must cover dX")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=G.device)
+    lib = _lib()
+    dbias = torch.empty((N,), dtype=torch.float32, device=G.device) if want_bias else None
+    ws = torch.empty((int(lib.gsr_dense_backward_input_workspace_size(M, N)),), dtype=torch.uint8, device=G.device) if want_bias else None
+    ld = lambda t, cols: int(t.stride(0)) if M > 1 else int(cols)
+    with torch.cuda.device(G.device):
+        rc = lib.gsr_dense_backward_input(M, int(N), int(K), G.data_ptr(), ld(G, G.shape[1]), planes_t.data_ptr(), None if mask is None else mask.data_ptr(),
+                                          0 if mask is None else ld(mask, mask.shape[1]), out.data_ptr(), ld(out, out.shape[1]),
+                                          None if dbias is None else dbias.data_ptr(), None if ws is None else ws.data_ptr(), _C._stream(G.device))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_backward_input")
+    return out, dbias
 
 
 def dense_wgrad(G, X, gate=None, out=None):

@@ -254,6 +254,18 @@ def _grad_weight(G, X):
 
 
 LAYER_FUSED_TRUNK = os.environ.get("GSR_LAYER_FUSED_TRUNK", "0") == "1"
+# The trunk's forward and input-gradient products on the bf16 matrix cores with fp32-accurate three-term operands (include/dense_layers.h,
+# dense_layers.py) instead of the library's fp32 GEMMs: fp32-GEMM accuracy, ~20 % less time per product at the SLAM runs' ~33 k rows, and the
+# backward's ReLU mask + bias gradient ride in the input-gradient product's epilogue (no separate pass over the rows). GSR_DENSE_TRUNK=0: the
+# library path.
+DENSE_TRUNK = os.environ.get("GSR_DENSE_TRUNK", "1") == "1"
+
+
+def _dense_trunk_ok(emb, Ws, W_heads, skip):
+    Wd, E = int(Ws[0].shape[0]), int(emb.shape[1])
+    return (DENSE_TRUNK and Wd % 128 == 0 and E % 4 == 0 and emb.is_contiguous() and len(Ws) <= 12
+            and all(int(w.shape[0]) == Wd and w.is_contiguous() for w in Ws)
+            and all(int(Ws[i].shape[1]) == (Wd + E if i == skip + 1 else Wd) for i in range(1, len(Ws))) and int(Ws[0].shape[1]) == E)
 
 
 class _FusedTrunk(torch.autograd.Function):
@@ -272,6 +284,7 @@ class _FusedTrunk(torch.autograd.Function):
     def forward(ctx, emb, skip, W_heads, b_heads, *params):
         D = len(params) // 2
         E = emb.shape[1]
+        ctx.planes_t = None
         if LAYER_FUSED_TRUNK:
             # opt-in (GSR_LAYER_FUSED_TRUNK=1): the eight layers + heads as ONE launch on the bf16 matrix cores with fp32-accurate three-term
             # operands (include/dense_layers.h gsr_trunk_forward). Same values to fp32-GEMM accuracy; faster than the library from ~50 k rows
@@ -283,6 +296,26 @@ class _FusedTrunk(torch.autograd.Function):
                 ctx.skip, ctx.D, ctx.E = skip, D, E
                 ctx.save_for_backward(W_heads, *params[0::2], *inputs, *outs)
                 return out
+        Ws = list(params[0::2])
+        if _dense_trunk_ok(emb, Ws, W_heads, skip):
+            import dense_layers
+            Wd, R = int(Ws[0].shape[0]), int(emb.shape[0])
+            # every layer's weight as bf16 planes, and the transposed planes of its hidden columns for the way back: one launch
+            requests = [(w.detach(), 0, None, False) for w in Ws] + [(Ws[i].detach(), E if i == skip + 1 else 0, Wd, True) for i in range(1, D)]
+            views, ctx.planes_buffer = dense_layers.split_weights(requests)
+            cat = emb.new_empty((R, E + Wd))                 # (:447-448: [emb | h], the input of layer skip + 1; layer skip writes its half)
+            cat[:, :E] = emb
+            inputs, outs, h = [], [], emb
+            for i in range(D):
+                inputs.append(h)
+                y = dense_layers.dense_forward(h, views[i], Wd, int(Ws[i].shape[1]), params[2 * i + 1].detach(), relu=True, out=cat[:, E:] if i == skip else None)
+                outs.append(y)
+                h = cat if i == skip else y
+            out = torch.addmm(b_heads, h, W_heads.t())
+            ctx.planes_t = views[D:]
+            ctx.skip, ctx.D, ctx.E = skip, D, E
+            ctx.save_for_backward(W_heads, *params[0::2], *inputs, *outs)
+            return out
         inputs, outs, h = [], [], emb
         for i in range(D):
             W, b = params[2 * i], params[2 * i + 1]
@@ -312,14 +345,22 @@ class _FusedTrunk(torch.autograd.Function):
         groups = _row_groups(R)
         same = [i for i in range(D) if tuple(Ws[i].shape) == tuple(Ws[D - 1].shape) and inputs[i].is_contiguous()] if groups > 1 else []
         buf = g_out.new_empty((len(same), groups) + tuple(Ws[D - 1].shape)) if len(same) > 1 else None
+        planes_t = ctx.planes_t
+        G = db = None
         for i in reversed(range(D)):
-            G, db = control_nodes.relu_backward_bias(g, outs[i])
+            if planes_t is None or i == D - 1:
+                G, db = control_nodes.relu_backward_bias(g, outs[i])
             if buf is not None and i in same:
                 torch.bmm(G.view(groups, R // groups, -1).transpose(1, 2), inputs[i].view(groups, R // groups, -1), out=buf[same.index(i)])
             else:
                 grads[2 * i] = _grad_weight(G, inputs[i])
             grads[2 * i + 1] = db
-            if i > 0:
+            if i > 0 and planes_t is not None:
+                # the layer below's G and bias gradient straight from this layer's input-gradient product (mask and column sums in its epilogue)
+                import dense_layers
+                Wd = int(Ws[i].shape[0])
+                G, db = dense_layers.dense_backward_input(G, planes_t[i - 1], Wd, Wd, mask=outs[i - 1])
+            elif i > 0:
                 g = G.mm(Ws[i][:, E:] if i == skip + 1 else Ws[i])      # (the embedding half of the skip input needs no gradient)
         if buf is not None:
             for j, dW in enumerate(buf.sum(1).unbind(0)):

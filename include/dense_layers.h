@@ -33,6 +33,25 @@ int gsr_dense_split(int N, int K, const float* W, int ldw, int k0, int transpose
 int gsr_dense_forward(int M, int N, int K, const float* X, int ldx, const float* gate, int ldgate, const void* planes, const float* bias, int relu,
                       float* Y, int ldy, void* stream);
 
+/* The input gradient of one layer handed straight to the ReLU of the layer below, with that layer's bias gradient:
+ *   dX [M, N] = (G [M, K] W) * (mask > 0),   dbias [N] = column sums of dX
+ * for W^T's planes (gsr_dense_split(..., transposed = 1) of the [K, N] weight), mask [M, N] = the OUTPUT of the layer below (post-ReLU; NULL: no
+ * mask), dbias NULL: no column sums. Replaces utils/time_utils.py:428-452's autograd chain  mm -> threshold_backward -> sum(0)  per layer: one
+ * pass over the rows instead of three. The column sums are added in a fixed order (per lane, per wave, per block, then over the row blocks):
+ * deterministic. They need N % 4 == 0 and 16-byte aligned rows of dX / mask. workspace: gsr_dense_backward_input_workspace_size(M, N) bytes. */
+size_t gsr_dense_backward_input_workspace_size(int M, int N);
+int gsr_dense_backward_input(int M, int N, int K, const float* G, int ldg, const void* planes_t, const float* mask, int ldmask, float* dX, int lddx,
+                             float* dbias, char* workspace, void* stream);
+
+/* Several weights split in ONE launch (a network's layers in both orientations, once per optimizer step): at most 24 items, each with the
+ * arguments of gsr_dense_split. */
+typedef struct gsr_dense_split_item {
+    const float* W;
+    void* planes;
+    int32_t N, K, ldw, k0, transposed;
+} gsr_dense_split_item;
+int gsr_dense_split_many(int count, const gsr_dense_split_item* items, void* stream);
+
 /* dW [N, K] = G^T X  for G [M, N] (optionally gated like X above: gate [M, N]) and X [M, K]; the rows are cut into slices whose partial products
  * are added in a fixed order (deterministic). workspace: gsr_dense_wgrad_workspace_size(M, N, K) bytes. */
 size_t gsr_dense_wgrad_workspace_size(int M, int N, int K);

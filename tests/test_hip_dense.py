@@ -124,6 +124,7 @@ def test_node_network_with_the_layer_fused_forward_matches_the_library_path(monk
     emb = torch.cat([dm._embed(x, net.multires), dm._embed(t, net.t_multires)], -1)
     cot = torch.randn((3000, 14), device=DEV)
     res = {}
+    monkeypatch.setattr(dm, "DENSE_TRUNK", False)
     for fused in (False, True):
         monkeypatch.setattr(dm, "LAYER_FUSED_TRUNK", fused)
         for p in net.parameters():
@@ -137,3 +138,92 @@ def test_node_network_with_the_layer_fused_forward_matches_the_library_path(monk
     for k in res[False][1]:
         assert rel(res[True][1][k], res[False][1][k]) < 1e-2, (k, rel(res[True][1][k], res[False][1][k]))
     assert rel(res[True][1]["gaussian_warp.weight"], res[False][1]["gaussian_warp.weight"]) < 1e-5
+
+
+@pytest.mark.parametrize("M", [1, 50, 777, 4176, 20000, 33280])
+@pytest.mark.parametrize("masked", [True, False])
+def test_dense_backward_input_mask_and_bias_gradient(M, masked):
+    """gsr_dense_backward_input: dX = (G W) [mask > 0] and its column sums in one pass, at row counts that take different row tiles per block
+    (dense_row_tiles: 2 .. 10), with the mask a column range of a wider matrix (the skip layer's output inside [emb | h])."""
+    g = torch.Generator(device="cpu").manual_seed(M)
+    N = K = 256
+    G = torch.randn((M, K), generator=g).to(DEV)
+    W = (torch.randn((K, N + 84), generator=g) / 16).to(DEV)                  # [out = K, in = 84 + N]: the skip layer's weight
+    wide = torch.randn((M, N + 84), generator=g).to(DEV)
+    mask = wide[:, 84:] if masked else None
+    planes_t = dl.split_weight(W, k0=84, K=N, transposed=True)
+    dX, db = dl.dense_backward_input(G, planes_t, N, K, mask=mask)
+    ref = G.double() @ W.double()[:, 84:]
+    if masked:
+        ref = ref * (mask > 0)
+    assert dX.shape == (M, N) and db.shape == (N,)
+    assert rel(dX, ref) < 1e-6
+    if masked:
+        assert torch.equal(dX == 0, ~(mask > 0) | (dX == 0)) and bool((dX[~(mask > 0)] == 0).all())
+    assert rel(db, ref.sum(0)) < 1e-5 and float((db.double() - dX.double().sum(0)).abs().max()) <= 1e-5 * float(dX.abs().sum(0).max()) + 1e-30
+    dX2, db2 = dl.dense_backward_input(G, planes_t, N, K, mask=mask)
+    assert torch.equal(dX, dX2) and torch.equal(db, db2)                         # fixed summation order
+    dX3, none = dl.dense_backward_input(G, planes_t, N, K, mask=mask, want_bias=False)
+    assert none is None and torch.equal(dX3, dX)
+
+
+def test_split_weights_in_one_launch_equal_the_single_splits():
+    g = torch.Generator(device="cpu").manual_seed(11)
+    Ws = [torch.randn((256, k), generator=g).to(DEV) for k in (84, 256, 340, 256)] + [torch.randn((14, 256), generator=g).to(DEV)]
+    requests = [(w, 0, None, False) for w in Ws] + [(Ws[2], 84, 256, True), (Ws[1], 0, 256, True), (Ws[4], 0, None, True)]
+    views, buf = dl.split_weights(requests)
+    for (w, k0, K, tr), v in zip(requests, views):
+        single = dl.split_weight(w, k0=k0, K=K, transposed=tr)
+        assert torch.equal(v[:single.numel()], single)
+    views2, buf2 = dl.split_weights(requests, out=buf)
+    assert buf2.data_ptr() == buf.data_ptr()
+    with pytest.raises(RuntimeError):
+        dl.split_weights([(Ws[0], 0, None, False)] * 25)
+
+
+def test_node_network_on_the_dense_layers_matches_the_library_path(monkeypatch):
+    """The default trunk (slam.deform_model.DENSE_TRUNK: per-layer products on the bf16 matrix cores, mask + bias gradient in the
+    input-gradient product's epilogue) against the library path (GSR_DENSE_TRUNK=0): heads to fp32-GEMM accuracy, parameter gradients up to the
+    ReLU-mask flips of pre-activations within rounding of zero; and bit-reproducible from call to call."""
+    from slam import deform_model as dm
+    torch.manual_seed(5)
+    net = dm.NodeNetwork().to(DEV)
+    with torch.no_grad():
+        for _, m in net.heads():
+            m.weight.normal_(0, 0.05)
+            m.bias.normal_(0, 0.1)
+    R = 4176
+    x, t = torch.rand((R, 3), device=DEV) - 0.5, torch.rand((R, 1), device=DEV)
+    emb = torch.cat([dm._embed(x, net.multires), dm._embed(t, net.t_multires)], -1)
+    cot = torch.randn((R, 14), device=DEV)
+    monkeypatch.setattr(dm, "LAYER_FUSED_TRUNK", False)
+
+    def run(dense):
+        monkeypatch.setattr(dm, "DENSE_TRUNK", dense)
+        for p in net.parameters():
+            p.grad = None
+        out = net.heads_from_embedding(emb)
+        (out * cot).sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    lib, dense, again = run(False), run(True), run(True)
+    assert rel(dense[0], lib[0]) < 2e-6
+    for k in lib[1]:
+        assert rel(dense[1][k], lib[1][k]) < 1e-2, (k, rel(dense[1][k], lib[1][k]))
+        assert torch.equal(dense[1][k], again[1][k]), k
+    assert rel(dense[1]["gaussian_warp.weight"], lib[1]["gaussian_warp.weight"]) < 1e-5
+    assert torch.equal(dense[0], again[0])
+    # against fp64 autograd of the same network: the dense path is no farther from it than the library path (both see the same few mask flips)
+    net64 = dm.NodeNetwork().to(DEV).double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    h = emb.double()
+    for i, layer in enumerate(net64.linear):
+        h = torch.relu(layer(h))
+        if i in net64.skips:
+            h = torch.cat([emb.double(), h], -1)
+    out64 = torch.cat([m(h) for _, m in net64.heads()], -1)
+    (out64 * cot.double()).sum().backward()
+    g64 = {k: p.grad for k, p in net64.named_parameters()}
+    assert rel(dense[0], out64) < 2e-6
+    for k in lib[1]:
+        assert rel(dense[1][k], g64[k]) < max(4 * rel(lib[1][k], g64[k]), 1e-5), (k, rel(dense[1][k], g64[k]), rel(lib[1][k], g64[k]))
