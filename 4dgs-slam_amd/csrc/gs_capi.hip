@@ -1790,15 +1790,25 @@ static int dense_forward_launch(const char* who, int M, int N, int K, const floa
     // 128-column kernel
     static const bool wide_ok = !(getenv("GSR_DENSE_WIDE") && getenv("GSR_DENSE_WIDE")[0] == '0');
     if (wide_ok && vec_out && N % DENSE8_BN == 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DENSE8_LDS_BYTES));
-            attr_set = true;
-        }
         const int bt8 = forced_bt >= 2 && forced_bt <= DENSE_MAX_BT ? forced_bt : dense8_row_tiles(M, N / DENSE8_BN);
         const dim3 grid8((unsigned)((M + 16 * bt8 - 1) / (16 * bt8)), (unsigned)(N / DENSE8_BN));
-        hipLaunchKernelGGL(dense_fwd8_kernel, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, N, K, X, ldx, gate, ldgate,
-                           reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, bt8, mask, ldmask, partial);
+        static bool attr_set[DENSE_MAX_BT + 1] = {};
+#define GSR_DENSE8_LAUNCH(BT)                                                                                                                          \
+        case BT:                                                                                                                                       \
+            if (!attr_set[BT]) {                                                                                                                       \
+                GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd8_kernel<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                                  DENSE8_LDS_BYTES));                                                                                  \
+                attr_set[BT] = true;                                                                                                                   \
+            }                                                                                                                                          \
+            hipLaunchKernelGGL(dense_fwd8_kernel<BT>, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, N, K, X, ldx, gate, ldgate,            \
+                               reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, mask, ldmask,      \
+                               partial);                                                                                                               \
+            break;
+        switch (bt8) {
+            GSR_DENSE8_LAUNCH(2) GSR_DENSE8_LAUNCH(3) GSR_DENSE8_LAUNCH(4) GSR_DENSE8_LAUNCH(5) GSR_DENSE8_LAUNCH(6) GSR_DENSE8_LAUNCH(7)
+            GSR_DENSE8_LAUNCH(8) GSR_DENSE8_LAUNCH(9) GSR_DENSE8_LAUNCH(10)
+        }
+#undef GSR_DENSE8_LAUNCH
         if (colsum_out) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, (int)grid8.x, N, (const float*)partial, colsum_out);
         GSR_HIP_CHECK(hipGetLastError());
         return 0;

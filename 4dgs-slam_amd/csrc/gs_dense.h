@@ -319,46 +319,49 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
 }
 
 // ---- the same product, one block per CU (round 5, second form) --------------------------------------------------------------------------------
-// Ablations of dense_fwd_kernel at 32 768 rows x 256 x 256 (tools/dev_dense.py history): 10 us of launch + first fetch + epilogue, +5 us staging
-// (split + LDS stores), +5 us global fetches, +4 us fragment reads, +8 us MFMA = 32 us -- the phases ADD UP: two blocks per CU that start
-// together run in lock step (both stage, both multiply), a barrier on either side of every phase. dense_fwd8_kernel removes the lock step:
-//   * ONE block of eight waves per CU and a 16 bt x 256 tile (the whole width of the network: X is read once, not once per column tile);
+// Ablations of dense_fwd_kernel at 32 768 rows x 256 x 256: 10 us of launch + first fetch + epilogue, +5 us staging (split + LDS stores), +5 us
+// global fetches, +4 us fragment reads, +8 us MFMA = 32 us -- the phases ADD UP: two blocks per CU that start together run in lock step (both
+// stage, both multiply), a barrier on either side of every phase. dense_fwd8_kernel removes the lock step:
+//   * ONE block of eight waves per CU and a 16 BT x 256 tile (the whole width of the network: X is read once, not once per column tile);
+//     every wave owns ALL rows of the tile and 32 columns: equal work for every wave at every BT (2 .. 10, a template parameter: the
+//     multiply phase is straight-line code whose fragment reads run one row tile ahead of its products);
 //   * the LDS holds TWO stages (2 x (30 + 48) KB): step s + 1 is staged while step s is multiplied, one barrier per step;
-//   * the two waves of a SIMD (w and w + 4) take the phases in OPPOSITE order -- one multiplies while the other splits and stores -- so the
-//     matrix pipe and the vector / LDS pipes of a SIMD are busy at the same time.
+//   * the two waves of a SIMD (w and w + 4) take the phases in OPPOSITE order -- one multiplies while the other splits and stores;
+//   * the products are formed TRANSPOSED (weight fragment as the first MFMA operand): a lane ends up with four consecutive columns of one
+//     row -- 16-byte stores straight from the accumulators, no transposition through LDS.
 constexpr int DENSE8_THREADS = 512, DENSE8_BN = 256;
 constexpr int DENSE8_STAGE_A = 3 * 16 * DENSE_MAX_BT * DENSE_ROW_B, DENSE8_STAGE_B = 3 * DENSE8_BN * DENSE_ROW_B;       // 30 720 + 49 152 bytes
 constexpr int DENSE8_LDS_BYTES = 2 * (DENSE8_STAGE_A + DENSE8_STAGE_B);                                                // 159 744 of 163 840
+template <int BT>
 __global__ void __launch_bounds__(DENSE8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict__ X, const int ldx, const float* __restrict__ gate, const int ldgate,
                   const unsigned short* __restrict__ planes, const int Npad, const int Kpad, const float* __restrict__ bias, const int relu,
-                  float* __restrict__ Y, const int ldy, const int vec, const int bt,
+                  float* __restrict__ Y, const int ldy, const int vec,
                   const float* __restrict__ mask, const int ldmask, float* __restrict__ colsum)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dense8[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows_a = 16 * bt;
+    constexpr int rows_a = 16 * BT;
     const int m0 = blockIdx.x * rows_a, n0 = blockIdx.y * DENSE8_BN;
-    const int na = (bt + 1) >> 1;
-    const int nt = (wave & 1) ? bt - na : na;
-    const int wm = (wave & 1) ? 16 * na : 0, wn = ((wave >> 1) & 3) * 64;
+    const int wn = wave * 32;                                       // this wave's 32 columns (two column tiles), all BT row tiles
     const int stage_first = wave >> 2;                              // waves w and w + 4 share a SIMD: opposite phase order
     const int fi = lane & 15, fq = lane >> 4;
-    dense_acc acc[5][4];
+    dense_acc acc[BT][2];
 #pragma unroll
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < BT; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
     auto sa = [&](int buf, int p) __attribute__((always_inline)) { return s_dense8 + buf * (DENSE8_STAGE_A + DENSE8_STAGE_B) + p * (16 * DENSE_MAX_BT * DENSE_ROW_B); };
     auto sb = [&](int buf, int p) __attribute__((always_inline)) { return s_dense8 + buf * (DENSE8_STAGE_A + DENSE8_STAGE_B) + DENSE8_STAGE_A + p * (DENSE8_BN * DENSE_ROW_B); };
 
     const int steps = Kpad / DENSE_BK;
-    const int items_a = rows_a * 4;                                 // (row, group of eight k): up to 640, two per thread; the weight: 1024, two per thread
-    float xa[2][8];
+    constexpr int items_a = rows_a * 4;                             // (row, group of eight k): up to 640, two per thread; the weight: 1024, two per thread
+    constexpr int A_ITERS = (items_a + DENSE8_THREADS - 1) / DENSE8_THREADS;
+    float xa[A_ITERS][8];
     dense_u4 wb[2][3];
     auto fetch = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < A_ITERS; it++) {
             const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
             if (item >= items_a) continue;
             const int m = m0 + row, k = s * DENSE_BK + 8 * g;
@@ -388,7 +391,7 @@ dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
-            const size_t off = (size_t)(n0 + row) * Kpad + s * DENSE_BK + 8 * g;        // planes are padded to 256 rows here: always in range
+            const size_t off = (size_t)(n0 + row) * Kpad + s * DENSE_BK + 8 * g;        // N % 256 == 0 here: always in range
             const size_t plane = (size_t)Npad * Kpad;
 #pragma unroll
             for (int p = 0; p < 3; p++) wb[it][p] = *reinterpret_cast<const dense_u4*>(planes + p * plane + off);
@@ -396,7 +399,7 @@ dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 2; it++) {
+        for (int it = 0; it < A_ITERS; it++) {
             const int item = tid + it * DENSE8_THREADS, row = item >> 2, g = item & 3;
             if (item >= items_a) continue;
             dense_u4 h, m_, l;
@@ -414,20 +417,38 @@ dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict
             for (int p = 0; p < 3; p++) *reinterpret_cast<dense_u4*>(sb(buf, p) + o) = wb[it][p];
         }
     };
+    // the six products of TWO row tiles with the wave's two column tiles, the weight fragment FIRST (the accumulator is the transposed tile:
+    // lane (fi, fq) holds columns 4 fq .. 4 fq + 3 of row fi). Four independent accumulators per term (consecutive MFMAs never share one);
+    // the next pair's fragments are read while this pair's products run
     auto multiply = [&](int buf) __attribute__((always_inline)) {
-        dense_frag b[4][3];
+        dense_frag b[2][3], a[2][2][3];                         // a[parity of the pair][tile within the pair][plane]
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(sb(buf, p) + dense_off(wn + 16 * j + fi, fq));
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            if (i < nt) {
-                dense_frag a[3];
+        for (int t = 0; t < 2; t++)
+            if (t < BT) {
 #pragma unroll
-                for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(sa(buf, p) + dense_off(wm + 16 * i + fi, fq));
-                dense_mfma6x4(a, b, acc[i]);
+                for (int p = 0; p < 3; p++) a[0][t][p] = dense_ld_frag(sa(buf, p) + dense_off(16 * t + fi, fq));
             }
+#pragma unroll
+        for (int i = 0; i < BT; i += 2) {
+            const int par = (i >> 1) & 1;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                if (i + 2 + t < BT) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) a[par ^ 1][t][p] = dense_ld_frag(sa(buf, p) + dense_off(16 * (i + 2 + t) + fi, fq));
+                }
+#define GSR_DENSE8_TERM(PA, PB)                                                                                                            \
+            _Pragma("unroll") for (int t = 0; t < 2; t++)                                                                                  \
+                if (i + t < BT) {                                                                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 2; j++)                                                                          \
+                        acc[i + t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][PB], a[par][t][PA], acc[i + t][j], 0, 0, 0);           \
+                }
+            GSR_DENSE8_TERM(2, 0) GSR_DENSE8_TERM(0, 2) GSR_DENSE8_TERM(1, 1) GSR_DENSE8_TERM(1, 0) GSR_DENSE8_TERM(0, 1) GSR_DENSE8_TERM(0, 0)
+#undef GSR_DENSE8_TERM
         }
     };
     fetch(0);
@@ -445,50 +466,39 @@ dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict
         }
         __syncthreads();                       // stage cur ^ 1 is complete, stage cur has been read
     }
-    // epilogue as in dense_fwd_kernel: a wave's 16 x 64 slab through a wave-private LDS tile (8 x 4.25 KB in the first stage), 16-byte stores
-    float* slab = reinterpret_cast<float*>(s_dense8) + wave * (16 * 68);
-    const int col4 = 4 * (lane & 15), nn = n0 + wn + col4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && nn + 3 < N) bv = *reinterpret_cast<const float4*>(bias + nn);
+    // epilogue: bias, ReLU, mask; 16-byte stores from the accumulators; the column sums of what was written (rows in increasing order per
+    // lane, then over the 16 lanes of a column group by xor shuffles: a fixed order)
+    float4 cs[2];
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        if (i < nt) {
+    for (int j = 0; j < 2; j++) {
+        const int nn = n0 + wn + 16 * j + 4 * fq;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + nn);
+        cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) slab[(4 * fq + r) * 68 + 16 * j + fi] = acc[i][j][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int row = 4 * t + (lane >> 4), m = m0 + wm + 16 * i + row;
-                float4 v = *reinterpret_cast<const float4*>(&slab[row * 68 + col4]);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (m < M && nn + 3 < N) {
-                    if (mask) {
-                        const float4 mv = *reinterpret_cast<const float4*>(mask + (size_t)m * ldmask + nn);
-                        v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f; v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
-                    }
-                    *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
-                    cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        for (int i = 0; i < BT; i++) {
+            const int m = m0 + 16 * i + fi;
+            float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (m < M) {
+                if (mask) {
+                    const float4 mv = *reinterpret_cast<const float4*>(mask + (size_t)m * ldmask + nn);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f; v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
                 }
+                *reinterpret_cast<float4*>(Y + (size_t)m * ldy + nn) = v;
+                cs[j].x += v.x; cs[j].y += v.y; cs[j].z += v.z; cs[j].w += v.w;
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     if (colsum) {
 #pragma unroll
-        for (int off = 16; off < 64; off <<= 1) {
-            cs.x += __shfl_xor(cs.x, off, 64); cs.y += __shfl_xor(cs.y, off, 64); cs.z += __shfl_xor(cs.z, off, 64); cs.w += __shfl_xor(cs.w, off, 64);
-        }
-        __syncthreads();
-        float4* s_cs = reinterpret_cast<float4*>(s_dense8 + DENSE8_STAGE_A + DENSE8_STAGE_B);      // [8 waves][16 lanes] in the second stage
-        if (lane < 16) s_cs[wave * 16 + lane] = cs;
-        __syncthreads();
-        if ((wave & 1) == 0 && lane < 16 && nn + 3 < N) {
-            const float4 o = s_cs[(wave + 1) * 16 + lane];
-            *reinterpret_cast<float4*>(colsum + (size_t)blockIdx.x * N + nn) = make_float4(cs.x + o.x, cs.y + o.y, cs.z + o.z, cs.w + o.w);
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                cs[j].x += __shfl_xor(cs[j].x, off, 64); cs[j].y += __shfl_xor(cs[j].y, off, 64);
+                cs[j].z += __shfl_xor(cs[j].z, off, 64); cs[j].w += __shfl_xor(cs[j].w, off, 64);
+            }
+            if (fi == 0) *reinterpret_cast<float4*>(colsum + (size_t)blockIdx.x * N + n0 + wn + 16 * j + 4 * fq) = cs[j];
         }
     }
 }
