@@ -57,11 +57,18 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_fwd_kernel(LossArgs a, f
 // out[k] = sum over blocks of partials[b * stride + k], k < stride, fixed order
 __global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restrict__ partials, int stride, float* __restrict__ out)
 {
-    const int k = threadIdx.x;
-    if (k >= stride) return;
-    float t = 0.f;
-    for (int b = 0; b < LOSS_BLOCKS; b++) t += partials[b * stride + k];
-    out[k] = t;
+    // one wave: lane l adds the partials of blocks l, l + 64, l + 128, l + 192 (independent loads), the lanes are added by xor shuffles -- a fixed
+    // order. (One thread per k walking all 256 partials was a chain of load latencies: 6.5 us per launch, nine launches per dynamic iteration.)
+    static_assert(LOSS_BLOCKS == 256, "loss_finalize_kernel adds four partials per lane");
+    const int lane = threadIdx.x;
+    for (int k = 0; k < stride; k++) {
+        const float v0 = partials[lane * stride + k], v1 = partials[(lane + 64) * stride + k];
+        const float v2 = partials[(lane + 128) * stride + k], v3 = partials[(lane + 192) * stride + k];
+        float t = (v0 + v1) + (v2 + v3);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if (lane == 0) out[k] = t;
+    }
 }
 
 __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, const float* __restrict__ upstream, float* __restrict__ dL_dimage,

@@ -230,9 +230,13 @@ def test_relu_backward_bias_matches_torch_and_is_reproducible(rows, cols):
 
 
 def test_fused_network_equals_the_op_by_op_network():
-    """NodeNetwork.heads_from_embedding on the device (_FusedTrunk: ReLU in the GEMM epilogue, one-pass ReLU-backward + bias gradient, weight
-    gradients batched over row groups, all heads as one layer) against the same network evaluated op by op (what runs on CPU tensors):
-    values equal to GEMM rounding, every gradient to 1e-3 of its norm."""
+    """NodeNetwork.heads_from_embedding on the device (_FusedTrunk: the layers on the bf16 matrix cores with three-term operands, ReLU mask +
+    bias gradient in the input-gradient product's epilogue, weight gradients batched over row groups, all heads as one layer) against the same
+    network evaluated op by op (what runs on CPU tensors): values equal to GEMM rounding. Gradients: a pre-activation within rounding of zero
+    may land on the other side of the ReLU in two evaluations -- a few dozen of the 68 M do, and each moves a gradient tensor by up to 1e-3 of
+    its norm (the op-by-op fp32 network is that far from fp64 autograd itself). So the gradients are compared with fp64 autograd of the network
+    evaluated WITH THE FUSED FORWARD'S OWN ReLU MASKS (its saved layer outputs): every gradient to 2e-5 of its norm; and with the op-by-op
+    network as a whole to 5e-3."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "4dgs-slam_amd"))
     from slam.deform_model import NodeNetwork
@@ -240,24 +244,38 @@ def test_fused_network_equals_the_op_by_op_network():
     net = NodeNetwork().to(DEV)
     for _, head in net.heads():                                  # (the shipped initialisation makes the heads ~0: give them something to propagate)
         torch.nn.init.normal_(head.weight, std=0.05)
-    params = [p for layer in list(net.linear) + [m for _, m in net.heads()] for p in (layer.weight, layer.bias)]
+    layers = list(net.linear) + [m for _, m in net.heads()]
+    params = [p for layer in layers for p in (layer.weight, layer.bias)]
+    D = len(net.linear)
     for rows in (6000, 33280, 6007):                             # (6007 is prime: the weight gradients fall back to single GEMMs)
         emb, cot = torch.randn(rows, net.input_ch, device=DEV), torch.randn(rows, 14, device=DEV)
         net.zero_grad(set_to_none=True)
         out = net.heads_from_embedding(emb)
         assert type(out.grad_fn).__name__.startswith("_FusedTrunk") and out.shape == (rows, 14)
+        saved = out.grad_fn.saved_tensors                       # (W_heads, D weights, D layer inputs, D layer outputs)
+        masks = [(t > 0).double() for t in saved[1 + 2 * D:1 + 3 * D]]
         out.backward(cot)
         got = [p.grad.clone() for p in params]
+        # fp64 autograd of the same network with those masks
+        p64 = [p.detach().double().requires_grad_(True) for p in params]
+        h = emb.double()
+        for i in range(D):
+            h = (h @ p64[2 * i].t() + p64[2 * i + 1]) * masks[i]
+            if i in net.skips:
+                h = torch.cat([emb.double(), h], -1)
+        out64 = torch.cat([h @ p64[2 * (D + k)].t() + p64[2 * (D + k) + 1] for k in range(len(net.heads()))], -1)
+        assert float((out.double() - out64).norm()) <= 2e-6 * float(out64.norm())
+        g64 = torch.autograd.grad(out64, p64, cot.double())
+        for a, b in zip(got, g64):
+            assert a.shape == b.shape and float((a.double() - b).norm()) <= 2e-5 * float(b.norm()), (rows, tuple(a.shape), float((a.double() - b).norm() / b.norm()))
         net.zero_grad(set_to_none=True)
-        h = net.trunk(emb)
-        want_out = torch.cat([m(h) for _, m in net.heads()], -1)
+        hh = net.trunk(emb)
+        want_out = torch.cat([m(hh) for _, m in net.heads()], -1)
         assert torch.allclose(out, want_out, rtol=1e-4, atol=1e-4)
         want_out.backward(cot)
-        # (a pre-activation within rounding of zero may land on the other side of the ReLU in the two evaluations -- a handful of the 1.5 M do,
-        # and each moves single gradient entries by a visible amount: the comparison is of the tensors as wholes)
         for a, p in zip(got, params):
             b = p.grad
-            assert a.shape == b.shape and float((a - b).norm()) <= 1e-3 * float(b.norm()), (rows, tuple(a.shape), float((a - b).norm() / b.norm()))
+            assert float((a - b).norm()) <= 5e-3 * float(b.norm()), (rows, tuple(a.shape), float((a - b).norm() / b.norm()))
 
 
 def test_node_embedding_equals_the_tensor_program():
@@ -275,3 +293,30 @@ def test_node_embedding_equals_the_tensor_program():
     assert torch.equal(got[:, :3], want[:, :3]) and torch.equal(got[:, 63], want[:, 63])
     assert float((got - want).abs().max()) <= 2e-6          # |sin|, |cos| <= 1: an ulp or two of the library functions at arguments up to 512 x
     assert cn.node_embedding(nodes, tt[:0], 10, 10).shape == (0, 84)
+
+
+@pytest.mark.parametrize("S,E,Nv,C,B", [(1, 5120, 512, 6, 4), (3, 5120, 512, 3, 12), (7, 640, 64, 3, 7), (1, 30000, 512, 21, 2), (2, 16384, 1024, 3, 2),
+                                        (1, 100, 1500, 3, 1), (1, 1, 1, 1, 1)])
+def test_gather_rows_backward_is_an_ordered_scatter_add(S, E, Nv, C, B):
+    """control_nodes.gather_rows: torch.gather's values and a backward pass that adds a target's incoming rows in a fixed order (gsr_index_csr:
+    one block per set for small sets -- a stable counting sort --, one wave per target for large ones; gsr_segment_sum). Against an fp64
+    index_add, bit-identical from call to call, targets that nobody points at included (Nv > distinct indices)."""
+    import control_nodes as cn
+    g = torch.Generator(device="cpu").manual_seed(S * 1000 + E)
+    idx = torch.randint(0, max(1, Nv - 3), (S, E), generator=g).to(DEV)          # (the last targets receive nothing)
+    table = torch.randn((B, Nv, C), generator=g).to(DEV).requires_grad_(True)
+    set_of_b = None
+    if S > 1 and S != B:
+        set_of_b = torch.arange(S, device=DEV, dtype=torch.int32).repeat_interleave(B // S)
+    sets = cn.IndexSets(idx, Nv)
+    out = cn.gather_rows(table, sets, set_of_b)
+    sel = idx if S == B else (idx.index_select(0, set_of_b.long()) if set_of_b is not None else idx.expand(B, -1))
+    assert torch.equal(out, torch.gather(table.detach(), 1, sel[:, :, None].expand(-1, -1, C)))
+    cot = torch.randn(out.shape, generator=g).to(DEV)
+    (grad,) = torch.autograd.grad(out, table, cot)
+    ref = torch.zeros((B, Nv, C), dtype=torch.float64, device=DEV)
+    ref.scatter_add_(1, sel[:, :, None].expand(-1, -1, C), cot.double())
+    assert float((grad.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    sets2 = cn.IndexSets(idx.clone(), Nv)
+    (grad2,) = torch.autograd.grad(cn.gather_rows(table, sets2, set_of_b), table, cot)
+    assert torch.equal(grad, grad2)
