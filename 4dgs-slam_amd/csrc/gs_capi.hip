@@ -1253,7 +1253,7 @@ void gsr_adam_coefficients(double lr, double beta1, double beta2, int step, floa
 static int adam_step_impl(int nseg, const gsr_adam_segment* segs, const float* coefficients, bool scheduled, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (nseg < 0 || nseg > ADAM_MAX_SEGMENTS || (nseg > 0 && !segs)) { g_last_error = "gsr_adam_step: 0..8 segments"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (nseg < 0 || nseg > ADAM_MAX_SEGMENTS || (nseg > 0 && !segs)) { g_last_error = "gsr_adam_step: 0..32 segments"; return GSR_ERR_INVALID_ARGUMENT; }
     if (scheduled && nseg > 0 && !coefficients) { g_last_error = "gsr_adam_step_scheduled: null coefficients"; return GSR_ERR_INVALID_ARGUMENT; }
     AdamArgs a;
     a.nseg = nseg; a.total = 0; a.coef = scheduled ? coefficients : nullptr;
@@ -1278,6 +1278,22 @@ static int adam_step_impl(int nseg, const gsr_adam_segment* segs, const float* c
     return 0;
 }
 int gsr_adam_step(int nseg, const gsr_adam_segment* segs, void* stream) { return adam_step_impl(nseg, segs, nullptr, false, stream); }
+int gsr_adam_step_device_count(int nseg, const gsr_adam_segment* segs, float* const* step_counts, float* coefficients, void* stream_)
+{
+    if (nseg < 0 || nseg > ADAM_MAX_SEGMENTS || (nseg > 0 && (!segs || !step_counts || !coefficients))) {
+        g_last_error = "gsr_adam_step_device_count: 0..32 segments, no null arguments"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (nseg == 0) return 0;
+    AdamDeviceSteps d;
+    d.nseg = nseg;
+    for (int k = 0; k < nseg; k++) {
+        if (!step_counts[k]) { g_last_error = "gsr_adam_step_device_count: null step count"; return GSR_ERR_INVALID_ARGUMENT; }
+        d.step[k] = step_counts[k]; d.lr[k] = segs[k].lr; d.beta1[k] = segs[k].beta1_d; d.beta2[k] = segs[k].beta2_d;
+    }
+    hipLaunchKernelGGL(adam_device_coefficients_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, d, coefficients);
+    GSR_HIP_CHECK(hipGetLastError());
+    return adam_step_impl(nseg, segs, coefficients, true, stream_);
+}
 int gsr_adam_step_scheduled(int nseg, const gsr_adam_segment* segs, const float* coefficients, void* stream)
 {
     return adam_step_impl(nseg, segs, coefficients, true, stream);

@@ -144,10 +144,28 @@ __global__ void __launch_bounds__(LOSS_THREADS) masked_l1_bwd_kernel(MaskedL1Arg
 // torch.optim.Adam's single-tensor path (no amsgrad, no weight decay):
 //   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g^2;  p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int ADAM_MAX_SEGMENTS = 8;
+constexpr int ADAM_MAX_SEGMENTS = 32;          // (the node network: 25 tensors; the Gaussian model: 6)
 struct AdamSegment { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; unsigned long long n; float step_size, inv_bc2_sqrt, eps, beta2, one_minus_beta1, one_minus_beta2; };   // 1 - beta evaluated in double on the host, as torch does
 struct AdamArgs { int nseg; unsigned long long total; unsigned long long start[ADAM_MAX_SEGMENTS + 1]; AdamSegment seg[ADAM_MAX_SEGMENTS];
                   const float* coef; };   // coef != nullptr (gsr_adam_step_scheduled): step_size / inv_bc2_sqrt of segment k are coef[2k], coef[2k+1] in DEVICE memory
+
+// The coefficients of a step whose COUNT lives on the device (a torch.optim.Adam(capturable=True) state: one float32 scalar per parameter):
+// thread k advances step[k] and writes lr / (1 - b1^t), 1 / sqrt(1 - b2^t) -- double arithmetic, as gsr_adam_coefficients -- for
+// gsr_adam_step_scheduled. One tiny launch; with it the step is two launches inside a hipGraph that replays correctly (the count is read at
+// replay time).
+struct AdamDeviceSteps { int nseg; float* step[ADAM_MAX_SEGMENTS]; float lr[ADAM_MAX_SEGMENTS]; double beta1[ADAM_MAX_SEGMENTS], beta2[ADAM_MAX_SEGMENTS]; };
+__global__ void __launch_bounds__(64) adam_device_coefficients_kernel(AdamDeviceSteps a, float* __restrict__ coef)
+{
+    const int k = threadIdx.x;
+    if (k >= a.nseg) return;
+    bool first = true;                                         // (several parameters may share one counter: advance it once)
+    for (int j = 0; j < k; j++) first = first && a.step[j] != a.step[k];
+    const float t = a.step[k][0] + 1.f;
+    const double bc1 = 1.0 - pow(a.beta1[k], (double)t), bc2 = 1.0 - pow(a.beta2[k], (double)t);
+    coef[2 * k] = (float)((double)a.lr[k] / bc1); coef[2 * k + 1] = (float)(1.0 / sqrt(bc2));
+    __syncthreads();                                           // every thread has read its counter
+    if (first) a.step[k][0] = t;
+}
 
 __global__ void __launch_bounds__(256) adam_step_kernel(AdamArgs a)
 {

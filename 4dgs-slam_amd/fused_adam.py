@@ -7,7 +7,7 @@ densification code -- ``replace_tensor_to_optimizer``, ``cat_tensors_to_optimize
 
     self.optimizer = FusedAdam(l, lr=0.0, eps=1e-15)        # instead of torch.optim.Adam(l, lr=0.0, eps=1e-15), :447
 
-Only what the reference uses is fused (no amsgrad, weight decay, maximize, capturable); anything else, more than 8 tensors with
+Only what the reference uses is fused (no amsgrad, weight decay, maximize, capturable); anything else, more than 32 tensors with
 gradients, or non-float32 / non-contiguous tensors goes through torch.optim.Adam's own step()."""
 import ctypes as C
 
@@ -15,7 +15,7 @@ import torch
 
 from diff_gaussian_rasterization import _C
 
-_MAX_SEGMENTS = 8
+_MAX_SEGMENTS = 32
 
 
 class _Segment(C.Structure):        # gsr_adam_segment
@@ -35,6 +35,8 @@ def _lib():
         lib.gsr_adam_step.argtypes = [C.c_int, C.POINTER(_Segment), C.c_void_p]
         lib.gsr_adam_step_scheduled.restype = C.c_int
         lib.gsr_adam_step_scheduled.argtypes = [C.c_int, C.POINTER(_Segment), C.c_void_p, C.c_void_p]
+        lib.gsr_adam_step_device_count.restype = C.c_int
+        lib.gsr_adam_step_device_count.argtypes = [C.c_int, C.POINTER(_Segment), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
         lib.gsr_adam_coefficients.restype = None
         lib.gsr_adam_coefficients.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_float)]
         _declared = True
@@ -207,3 +209,69 @@ class FusedAdam(torch.optim.Adam):
     def advance_steps(self, todo, n):
         for _, p in todo:
             self.state[p]["step"] += n
+
+
+class DeviceCountAdam(torch.optim.Adam):
+    """``torch.optim.Adam(..., fused=True, capturable=True)`` -- the step counts are float32 scalars ON THE DEVICE, so a step recorded in a
+    hipGraph replays correctly -- whose ``step()`` is two launches of this library (gsr_adam_step_device_count: the counts advanced and the bias
+    corrections evaluated by one tiny kernel, then every parameter tensor in one launch) instead of torch's multi-tensor kernels, which give the
+    node network's ~25 tensors 25 workgroups (2 x 24 us per step; here ~8). Same state layout as torch's (``state[p] = {"step", "exp_avg",
+    "exp_avg_sq"}``): state surgery, ``state_dict`` and the first step (which creates the state) are torch's own. The arithmetic is
+    gsr_adam_step's (= torch's single-tensor Adam). Anything it does not cover -- amsgrad, weight decay, maximize, more than 32 tensors, tensors
+    that are not contiguous float32 on one device -- goes through torch's step()."""
+
+    def __init__(self, params, **kw):
+        kw.setdefault("fused", True)
+        kw.setdefault("capturable", True)
+        super().__init__(params, **kw)
+        self._coefficients = None
+
+    def _plan(self):
+        todo = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if not todo or len(todo) > _MAX_SEGMENTS:
+            return None
+        dev = todo[0][1].device
+        for group, p in todo:
+            if group["amsgrad"] or group["weight_decay"] != 0 or group["maximize"] or group.get("differentiable"):
+                return None
+            st = self.state.get(p)
+            if not st:
+                return None                                 # the first step creates the state: torch's
+            tensors = (p, p.grad, st.get("exp_avg"), st.get("exp_avg_sq"))
+            if any(t is None or not t.is_cuda or t.device != dev or t.dtype != torch.float32 or t.is_sparse or not t.is_contiguous() or t.numel() != p.numel()
+                   for t in tensors):
+                return None
+            step = st.get("step")
+            if not torch.is_tensor(step) or not step.is_cuda or step.device != dev or step.dtype != torch.float32 or step.numel() != 1:
+                return None
+        return todo
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        todo = self._plan()
+        if todo is None:
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        n = len(todo)
+        dev = todo[0][1].device
+        if self._coefficients is None or self._coefficients.device != dev:
+            self._coefficients = torch.zeros((2 * _MAX_SEGMENTS,), dtype=torch.float32, device=dev)
+        segs = (_Segment * n)()
+        counts = (C.c_void_p * n)()
+        for k, (group, p) in enumerate(todo):
+            st = self.state[p]
+            b1, b2 = group["betas"]
+            s = segs[k]
+            s.param, s.grad, s.exp_avg, s.exp_avg_sq = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            s.n, s.lr, s.beta2, s.eps, s.step = p.numel(), float(group["lr"]), float(b2), float(group["eps"]), 1
+            s.beta1_d, s.beta2_d = float(b1), float(b2)
+            counts[k] = st["step"].data_ptr()
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_adam_step_device_count(n, segs, counts, self._coefficients.data_ptr(), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_adam_step_device_count")
+        return loss

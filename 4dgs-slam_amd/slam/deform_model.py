@@ -733,7 +733,12 @@ class DeformModel:
         # 0.14 ms of device time per mapping iteration); the same Adam arithmetic
         on_device = all(p.is_cuda for g in groups for p in g["params"])
         # capturable: the step counters live on the device and the step can be recorded in a hipGraph (slam/dynamic_graph.py); same arithmetic
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True, "capturable": True} if on_device else {}))
+        if on_device and os.environ.get("GSR_NETWORK_ADAM", "1") != "0":
+            # ... and its step as two launches of this library (fused_adam.DeviceCountAdam) instead of torch's two multi-tensor launches of 24 us
+            from fused_adam import DeviceCountAdam
+            self.optimizer = DeviceCountAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **({"fused": True, "capturable": True} if on_device else {}))
 
     def step(self, x, time_input, iteration=0, feature=None, motion_mask=None, camera_center=None, time_interval=None, **kw):
         """deform_model.py:32-33."""

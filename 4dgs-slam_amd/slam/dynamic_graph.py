@@ -56,6 +56,9 @@ FLOW_TARGET_CACHE_MAX = 512       # keyframe pairs whose flow targets are kept (
 WINDOW_SAMPLES, EXTRA_SAMPLES = (4, 8), (2, 8)        # (ARAP, elastic) time samples per window view / per random keyframe (:517-519,:646-648)
 
 
+_region = torch.autograd.profiler.record_function          # names a part of the iteration for the profiler (tools/mapping_iteration_launches.py)
+
+
 def eligible(be, views, candidates):
     """Can this map() call run in the fixed layout? (Else BackEnd.map's eager body takes it: sharded runs, test doubles, monocular input,
     fewer than three nodes, keyframes without a motion mask.)"""
@@ -298,13 +301,16 @@ class DynamicMapping:
                     _lib.check(L.gsr_slot_gather(self.n_slots, tab["partner"].data_ptr(), r.current.data_ptr(), self.partner_dst, self.pixels,
                                                  _lib.stream(dev)), "gsr_slot_gather")
         # ---- the iteration's time samples, in the fixed layout ------------------------------------------------------------------------------
-        parts = [lay["wtimes"]]
-        if self.n_slots:
-            parts.append(tab["times"].index_select(0, r.current[:self.n_slots].long()).reshape(-1))
-        parts.append(r.current.view(torch.float32)[r.samples_lo:r.samples_lo + r.n_rest])
-        it = nodes.begin_iteration_indexed(torch.cat(parts), lay["n_full"], blend=(g.get_dygs_xyz.detach(), g.motion_mask))
+        # (the _region ranges only name the iteration's parts for tools/mapping_iteration_launches.py; no effect on the work)
+        with _region("gsr.network"):
+            parts = [lay["wtimes"]]
+            if self.n_slots:
+                parts.append(tab["times"].index_select(0, r.current[:self.n_slots].long()).reshape(-1))
+            parts.append(r.current.view(torch.float32)[r.samples_lo:r.samples_lo + r.n_rest])
+            it = nodes.begin_iteration_indexed(torch.cat(parts), lay["n_full"], blend=(g.get_dygs_xyz.detach(), g.motion_mask))
         nv, ne = len(self.views), self.n_slots
-        loss_network = nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
+        with _region("gsr.regularisers"):
+            loss_network = nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
         rows = it["blended"]
         deltas_at = lambda i: (rows[0][i], rows[2][i], rows[1][i])                    # (d_xyz, d_scaling, d_rotation) of full sample i
         views = self.views + self.slots
@@ -314,13 +320,15 @@ class DynamicMapping:
         if ops is None:
             ops = self._window_ops[r.dyn] = [be.keyframe_operands.get(cfg, v, dev, rm_dynamic=False, dynamic=r.dyn) for v in self.views]
         ops = ops + [o + (ops[0][4],) for o in self.slot_ops]
-        rendered = be._render_many(views, deltas)
+        with _region("gsr.render"):
+            rendered = be._render_many(views, deltas)
         # The iteration's loss is a sum of terms whose VALUE nobody reads (the fused losses leave it uninitialised): instead of adding them up --
         # a launch per term -- every term is a root of ONE backward pass with the gradient 1 (be.unit_gradient): the same gradients, exactly
         terms = [loss_network]
-        for v, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):
-            terms.append(slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, v.exposure_a,
-                                                      v.exposure_b, alpha, compute_value=False))
+        with _region("gsr.losses"):
+            for v, pkg, (gt_image, gt_depth, w_rgb, w_dep, alpha) in zip(views, rendered, ops):
+                terms.append(slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, v.exposure_a,
+                                                          v.exposure_b, alpha, compute_value=False))
         if r.with_flow:
             from gaussian_renderer import render_flow_views
             requests, pairs, clips = [], [], []
@@ -341,17 +349,21 @@ class DynamicMapping:
                 requests += [(v, other, dx1, dx2, dr1, ds1), (other, v, dx2, dx1, dr2, ds2)]      # this keyframe -> the earlier one, and back
                 pairs.append((f6[0:2], f6[2:3], f6[4:6], f6[3:4]))
             if requests:
-                flows = render_flow_views(g, requests, clips=clips if FLOW_CLIPS else None)
+                with _region("gsr.flow_render"):
+                    flows = render_flow_views(g, requests, clips=clips if FLOW_CLIPS else None)
                 if FLOW_CLIPS and be.config["Training"].get("flow_clip_check") and not torch.cuda.is_current_stream_capturing():
                     self._check_flow_clips(requests, pairs, clips, flows)          # TEST facility: the same terms without the clips
-                for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
-                    terms.append(slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
-                                                       channels=2))
-        terms.append(be._isotropic_loss())
+                with _region("gsr.flow_losses"):
+                    for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
+                        terms.append(slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
+                                                           channels=2))
+        with _region("gsr.isotropic"):
+            terms.append(be._isotropic_loss())
         torch.autograd.backward(terms, [be.unit_gradient(dev)] * len(terms))
-        nodes.end_iteration()
+        with _region("gsr.end_iteration"):
+            nodes.end_iteration()
         split = False
-        with torch.no_grad():
+        with torch.no_grad(), _region("gsr.updates"):
             if special is not None and special.get("last"):           # (before a densification changes the row count, like the eager loop)
                 be._publish_visibility(self.current_window, {k: rendered[k]["n_touched"] for k in range(nv)}, n_views=nv)
             for pkg in rendered:

@@ -62,7 +62,7 @@ int gsr_ssim_backward(int width, int height, int channels, const float* img1, co
 
 /* ---- fused Adam step: all parameter tensors of the Gaussian model in one launch -----------------
  * Replaces optimizer.step() of scene/gaussian_model.py:447 (torch.optim.Adam(lr=0.0, eps=1e-15) over the six groups of :404-434)
- * with the arithmetic of torch.optim.Adam's single-tensor path (no amsgrad, no weight decay, no maximize). At most 8 segments. */
+ * with the arithmetic of torch.optim.Adam's single-tensor path (no amsgrad, no weight decay, no maximize). At most 32 segments. */
 typedef struct gsr_adam_segment {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;   /* device, n floats each */
     unsigned long long n;
@@ -79,6 +79,11 @@ void gsr_adam_coefficients(double lr, double beta1, double beta2, int step, floa
  * runs; segs[k].lr / .step are ignored. Lets a hipGraph that contains the optimizer step be replayed for many iterations: the host (or
  * gsr_schedule_advance, slam_map.h) rewrites 2 * nseg floats per iteration instead of re-capturing. Same arithmetic, bit for bit. */
 int gsr_adam_step_scheduled(int nseg, const gsr_adam_segment* segs, const float* coefficients, void* stream);
+/* gsr_adam_step for an optimizer whose step COUNTS live on the device (torch.optim.Adam(capturable=True): one float32 scalar per parameter,
+ * step_counts[k] for segment k; segments may share one): a first tiny launch advances the counts and evaluates the two coefficients of every
+ * segment into `coefficients` (device, 2 * nseg floats), then gsr_adam_step_scheduled. Recorded in a hipGraph the step stays correct on
+ * replay. The `step` field of the segments is ignored. */
+int gsr_adam_step_device_count(int nseg, const gsr_adam_segment* segs, float* const* step_counts, float* coefficients, void* stream);
 
 /* ---- densification statistics of one rendered view in one launch ----------------------------------------------------------
  * utils/slam_backend.py:712-720 + scene/gaussian_model.py:973-977 (add_densification_stats): for every Gaussian with radii > 0

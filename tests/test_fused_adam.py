@@ -63,3 +63,82 @@ def test_fused_adam_uses_torch_for_what_it_does_not_fuse():
     p.grad = torch.ones(4)
     opt.step()
     assert torch.allclose(p.detach(), torch.full((4,), 0.9))
+
+
+@pytest.mark.gpu
+def test_device_count_adam_tracks_torch_adam_and_replays_in_a_graph():
+    """fused_adam.DeviceCountAdam (the node network's optimizer: step counts on the device, two launches per step) against torch.optim.Adam on
+    27 tensors in two groups: step for step, through a tensor without gradient, state surgery in torch's layout, and as a captured graph whose
+    replays advance the counts (the bias corrections of step t, not of the captured step)."""
+    from fused_adam import DeviceCountAdam
+
+    def groups(dev):
+        g = torch.Generator().manual_seed(9)
+        mk = lambda *shape: torch.nn.Parameter(torch.randn(*shape, generator=g).to(dev))
+        mlp = [mk(256, 84), mk(256)] + [t for _ in range(7) for t in (mk(256, 256), mk(256))] + [t for c in (3, 3, 4, 4) for t in (mk(c, 256), mk(c))]
+        return [{"params": mlp, "lr": 8e-4, "name": "mlp"}, {"params": [mk(512, 3), mk(512), mk(512)], "lr": 8e-4, "name": "nodes"}]
+
+    ref = torch.optim.Adam(groups("cpu"), lr=0.0, eps=1e-15)
+    opt = DeviceCountAdam(groups("cuda"), lr=0.0, eps=1e-15)
+    pairs = [(pr, pf) for gr, gf in zip(ref.param_groups, opt.param_groups) for pr, pf in zip(gr["params"], gf["params"])]
+    assert len(pairs) == 27
+    gen = torch.Generator().manual_seed(10)
+
+    def grads(it, skip=None):
+        for k, (pr, pf) in enumerate(pairs):
+            if k == skip:
+                pr.grad = pf.grad = None
+                continue
+            g = torch.randn(pr.shape, generator=gen) * (10.0 ** (-(it % 4)))
+            pr.grad = g.clone()
+            if pf.grad is None:
+                pf.grad = g.to("cuda")
+            else:
+                pf.grad.copy_(g)                     # (in place: a captured step reads these addresses)
+
+    def check(it):
+        for k, (pr, pf) in enumerate(pairs):
+            assert torch.allclose(pf.detach().cpu(), pr.detach(), rtol=3e-6, atol=1e-7), (it, k)
+            if pr in ref.state:
+                assert torch.allclose(opt.state[pf]["exp_avg_sq"].cpu(), ref.state[pr]["exp_avg_sq"], rtol=3e-6, atol=1e-30)
+                assert int(opt.state[pf]["step"].item()) == int(ref.state[pr]["step"].item())
+
+    for it in range(5):                              # step 0 creates the state (torch's own step), the others are this library's launches
+        grads(it, skip=3 if it == 2 else None)
+        ref.step()
+        opt.step()
+        check(it)
+    assert opt._coefficients is not None             # (the fused path ran)
+    # state surgery as extend_node_from_point does it: a parameter replaced by a longer one, moments extended with zeros, the count kept
+    gr, gf = ref.param_groups[1], opt.param_groups[1]
+    for o, grp, dev in ((ref, gr, "cpu"), (opt, gf, "cuda")):
+        old = grp["params"][0]
+        st = o.state.pop(old)
+        p = torch.nn.Parameter(torch.cat((old.detach(), torch.ones((4, 3), device=dev)), 0))
+        st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros((4, 3), device=dev)), 0)
+        st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros((4, 3), device=dev)), 0)
+        o.state[p] = st
+        grp["params"][0] = p
+    pairs[24] = (gr["params"][0], gf["params"][0])
+    grads(5)
+    ref.step()
+    opt.step()
+    check(5)
+    # captured once, replayed three times with new gradients
+    grads(6)
+    ref.step()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        graph.capture_begin()
+        opt.step()
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    graph.replay()
+    check(6)
+    for it in (7, 8):
+        grads(it)
+        ref.step()
+        graph.replay()
+        check(it)

@@ -85,6 +85,7 @@ if "--ops" in sys.argv:              # which ops (with their input shapes) own t
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=45, max_name_column_width=60, max_shapes_column_width=90),
           file=sys.stderr)
 by_line, by_op, ktime = collections.Counter(), collections.Counter(), collections.Counter()
+by_region_n, by_region_us = collections.Counter(), collections.Counter()          # "gsr.<region>" ranges of slam/dynamic_graph.py; backward nodes by name
 LAUNCH = ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync", "hipGraphLaunch", "hipModuleLaunchKernel", "hipExtLaunchKernel")
 for e in prof.events():
     if e.device_type.name != "CPU":
@@ -94,7 +95,10 @@ for e in prof.events():
         continue
     p, op, where = e.cpu_parent, None, None          # walk up to the aten op / python frame that caused this launch
     top = e
+    region = None
     while p is not None:
+        if region is None and (p.name.startswith("gsr.") or "evaluate_function" in p.name):
+            region = p.name.split("evaluate_function: ")[-1]
         if op is None and (p.name.startswith("aten::") or "Backward" in p.name):
             op = p.name
         if where is None:
@@ -107,11 +111,15 @@ for e in prof.events():
         where = "(no python frame) " + top.name[:60]
     by_line[where] += 1
     by_op[(op or top.name)[:60]] += 1
+    region = (region or "(outside) " + top.name)[:70]
+    by_region_n[region] += 1
+    by_region_us[region] += sum(getattr(k, "duration", 0) for k in (getattr(e, "kernels", None) or ()))
 n_launch = sum(by_line.values())
 out = {"graph": graph_wall, "dynamic": dyn, "resolution": wh, "gaussians": int(be.gaussians.get_xyz.shape[0]), "window": len(window), "ms_per_iteration": wall * 1e3,
        "launches_per_iteration": n_launch / iters,
        "by_source_line_per_iteration": {k: round(v / iters, 1) for k, v in by_line.most_common(50)},
        "by_op_per_iteration": {k: round(v / iters, 1) for k, v in by_op.most_common(40)},
+       "by_region_per_iteration": {k: {"launches": round(by_region_n[k] / iters, 1), "device_us": round(v / iters, 1)} for k, v in by_region_us.most_common(60)},
        "device_us_per_iteration_by_kernel": {k: round(v / iters, 1) for k, v in ktime.most_common(30)},
        "device_us_per_iteration": round(sum(ktime.values()) / iters, 1)}
 print(json.dumps(out, indent=1))
