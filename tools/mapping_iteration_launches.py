@@ -89,7 +89,9 @@ by_region_n, by_region_us = collections.Counter(), collections.Counter()        
 LAUNCH = ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync", "hipGraphLaunch", "hipModuleLaunchKernel", "hipExtLaunchKernel")
 for e in prof.events():
     if e.device_type.name != "CPU":
-        ktime[e.name[:70]] += getattr(e, "device_time", 0) or getattr(e, "cuda_time", 0)
+        if not e.name.startswith(("gsr.", "Optimizer.step", "Memcpy", "Memset")) or e.name.startswith(("Memcpy", "Memset")):
+            # (named ranges -- slam/dynamic_graph.py's regions, the optimizer's step -- show up on the device timeline too: they are not kernels)
+            ktime[e.name[:70]] += getattr(e, "device_time", 0) or getattr(e, "cuda_time", 0)
         continue
     if not e.name.startswith(LAUNCH):
         continue
