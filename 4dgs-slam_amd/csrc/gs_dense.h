@@ -11,25 +11,24 @@
 // GEMM's own rounding). Six MFMA products at 16x the fp32 rate: 2.7x the fp32 matrix peak at equal utilisation, and the result is an fp32 GEMM
 // for every purpose of the parity tests (values 1e-6, the golden node losses unchanged at their tolerances).
 //
-// Kernels:  dense_split_kernel     W [N, K] fp32 -> bf16 planes [3][Npad][Kpad] (and / or of W^T), zero padded, once per optimizer step;
-//           dense_fwd_kernel       Y = act(X W^T + b) with W pre-split: 128 x 128 tile per block, X split while it is staged;
-//                                  also the input gradient dX = G W (W^T's planes as the weight);
+// Kernels:  dense_split_kernel / dense_split_many_kernel   W [N, K] fp32 -> bf16 planes [3][Npad][Kpad] (and / or of W^T), zero padded, once per
+//                                  optimizer step (all of a network's weights in one launch);
+//           dense_fwd8_kernel<BT>  Y = act(X W^T + b) [x (mask > 0), + column sums] for full-width outputs (N % 256 == 0): ONE block of eight
+//                                  waves per CU, 16 BT x 256 tile, two LDS stages -- the node network's forward and input gradient;
+//           dense_fwd_kernel       the same product on 128-column tiles, two blocks per CU (other widths; the first form);
 //           dense_wgrad_kernel     dW = G^T X over a slice of the rows (both operands split while staged, transposed through LDS);
-//           dense_wgrad_sum_kernel the slices' partial results added in a fixed order.
+//           dense_wgrad_sum_kernel the slices' partial results added in a fixed order;
+//           trunk_fwd_kernel       the eight layers + heads in one launch (opt-in).
 //
-// STATUS (round 5, tools/dev_dense.py on an MI355X; library = hipBLASLt fp32 through torch): correct to fp32-GEMM accuracy everywhere
-// (tests/test_hip_dense.py), faster than the library only on long batches --
-//     rows      forward 256x256      input gradient      weight gradient (library: one GEMM / row groups of ~2000)
-//     33 280    41.5 vs 46.1 us      52.6 vs 45.4 us     82.8 vs 113.6 / 44.6 us
-//     66 560    65.1 vs 111.3        82.2 vs 90.0        142 vs 214 / ~90
-//     133 120   113 vs 163 (154 TFLOP/s fp32-equivalent = 0.37 of the bf16 matrix peak after the six-fold expansion)
-// At the node network's batch of the SLAM runs (~33k rows: 260 row tiles for 256 CUs, eight K steps per block) a block lives ~40 us for ~5 us
-// of matrix work: the one-step prefetch does not cover an HBM miss, and a two-step prefetch (second register set) spilled and was slower.
-// The trunk therefore still runs on the library (slam/deform_model._FusedTrunk). The layer-fused form -- trunk_fwd_kernel at the end of this
-// file: a 64-row tile's activations resident in LDS across the eight layers, no operand from HBM inside a K loop -- was built as well:
-// correct (tests), 420 vs 389 us (library) at 33 k rows, 696 vs 875 at 66 k. It is bound by its weight stream: three bf16 planes of a
-// 64 x 256 tile fill the LDS, so every 64 rows re-read the whole network's planes from L2 (48 KB per block and K step, 1.5 GB per forward at
-// 33 k rows). Opt-in (GSR_LAYER_FUSED_TRUNK=1).
+// STATUS (round 5, tools/dev_dense.py / dev_dense_chain.py on an MI355X, profiles/r05_dense_layers.jsonl; library = hipBLASLt fp32 through torch):
+// correct to fp32-GEMM accuracy everywhere (tests/test_hip_dense.py), and with dense_fwd8_kernel faster than the library at the node network's
+// batch --
+//     rows      forward 256x256     input gradient (masked, + bias sums)          weight gradient (library: row groups of ~2000)
+//     33 280    32.4 vs 46.1 us     35.0 vs 46.4 (+ 21 for the library's pass)    83.6 vs 43.7
+//     66 560    60.4 vs 113.8       68.0 vs 94.3 (+ 34)                           144 vs 77
+// slam/deform_model._FusedTrunk uses the forward / input-gradient kernels by default and keeps the library for the weight gradients. The
+// layer-fused trunk_fwd_kernel (a 64-row tile's activations resident in LDS across the eight layers) is slower than eight chained
+// dense_fwd8 launches (420 vs 277 us at 33 k rows): bound by re-reading the network's planes from L2 per 64 rows at one wave per SIMD.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -3,12 +3,14 @@
 The node network's trunk (utils/time_utils.py:327-476: eight layers of width 256 over every (node, time sample) row of a mapping iteration) is
 GEMM-shaped work that the fp32 matrix instructions run at the fp32 VECTOR rate. Here an fp32 operand travels as three bf16 terms (24 bits of
 significand, split by truncation) and a product as its six largest cross terms on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the results
-are fp32 GEMM results (what is dropped is below 2e-7 of |x w| per product), at up to 2.7x the fp32 matrix rate.
+are fp32 GEMM results (what is dropped is below 2e-7 of |x w| per product), at 1.4x (33 k rows) to 1.9x (66 k) the library's fp32 GEMM rate.
+slam/deform_model._FusedTrunk runs the trunk's forward and input-gradient products through this module.
 
     planes = split_weight(W)                          # once per optimizer step: bf16 planes of W [N, K] ...
     planes_t = split_weight(W, transposed=True)       # ... and of its transpose (for the input gradient)
     Y = dense_forward(X, planes, N, K, bias, relu=True)
     dX = dense_forward(G, planes_t, K, N)             # G W
+    dX, db = dense_backward_input(G, planes_t, K, N, mask=Y_below)   # (G W) [Y_below > 0] and its column sums: the layer below's G and bias gradient
     dW = dense_wgrad(G, X)                            # G^T X, deterministic
 
 There is no CPU path: tensors must be fp32 on a HIP device."""
