@@ -2131,7 +2131,7 @@ int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const ch
     if (B == 0) return 0;
     int *order, *seg, *cursor;
     index_csr_carve(const_cast<char*>(csr_workspace), S, E, Nv, order, seg, cursor);
-    const size_t total = (size_t)B * Nv * C;
+    const size_t total = (size_t)B * Nv * C * SEG_LANES;
     hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, B, E, C, Nv, g, (size_t)E * C, (const int*)order, (const int*)seg,
                        set_of_b, out, (size_t)Nv * C);
     GSR_HIP_CHECK(hipGetLastError());
@@ -2177,7 +2177,7 @@ int gsr_node_blend_backward_batch(const gsr_node_blend* a, int B, const float* n
         if (int rc = gsr_index_csr(1, E, a->m, nn_idx, shared, stream_)) return rc;
         int *order, *seg, *cursor;
         index_csr_carve(shared, 1, E, a->m, order, seg, cursor);
-        const size_t nthreads = (size_t)B * a->m * NODE_GRAD;
+        const size_t nthreads = (size_t)B * a->m * NODE_GRAD * SEG_LANES;
         hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, B, E, NODE_GRAD, a->m, (const float*)contrib, stride,
                            (const int*)order, (const int*)seg, (const int*)nullptr, summed, stride);
     } else {

@@ -437,21 +437,32 @@ index_csr_kernel(const int E, const int Nv, const int64_t* __restrict__ idx, int
     if (lane == 0) { seg[2 * ((size_t)s * Nv + v)] = base; seg[2 * ((size_t)s * Nv + v) + 1] = count; }
 }
 
+// SEG_LANES adjacent lanes share one (batch, target, channel): lane j adds the entries j, j + SEG_LANES, ... of the segment in that order, the
+// lanes' sums are added pairwise ((0 + 1) + (2 + 3)) + ... by xor shuffles -- a fixed order. (One thread per output walked the whole segment:
+// the busiest control node has hundreds of Gaussians, and every step of the walk is an index load followed by a dependent gradient load.)
+constexpr int SEG_LANES = 8;
 __global__ void __launch_bounds__(256)
 segment_sum_kernel(const int B, const int E, const int C, const int Nv, const float* __restrict__ g, const size_t g_batch_stride,
                    const int* __restrict__ order, const int* __restrict__ seg, const int* __restrict__ set_of_b, float* __restrict__ out,
                    const size_t out_batch_stride)
 {
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (size_t)B * Nv * C) return;
-    const int c = (int)(t % C), v = (int)((t / C) % Nv), b = (int)(t / ((size_t)C * Nv));
-    const int s = set_of_b ? set_of_b[b] : 0;
-    const int begin = seg[2 * ((size_t)s * Nv + v)], count = seg[2 * ((size_t)s * Nv + v) + 1];
-    const int* o = order + (size_t)s * E + begin;
-    const float* gb = g + (size_t)b * g_batch_stride;
+    const size_t tt = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t t = tt / SEG_LANES;
+    const int j = (int)(tt % SEG_LANES);
+    const bool live = t < (size_t)B * Nv * C;
     float acc = 0.f;
-    for (int k = 0; k < count; k++) acc += gb[(size_t)o[k] * C + c];
-    out[(size_t)b * out_batch_stride + (size_t)v * C + c] = acc;
+    int c = 0, v = 0, b = 0;
+    if (live) {
+        c = (int)(t % C); v = (int)((t / C) % Nv); b = (int)(t / ((size_t)C * Nv));
+        const int s = set_of_b ? set_of_b[b] : 0;
+        const int begin = seg[2 * ((size_t)s * Nv + v)], count = seg[2 * ((size_t)s * Nv + v) + 1];
+        const int* o = order + (size_t)s * E + begin;
+        const float* gb = g + (size_t)b * g_batch_stride;
+        for (int k = j; k < count; k += SEG_LANES) acc += gb[(size_t)o[k] * C + c];
+    }
+#pragma unroll
+    for (int off = 1; off < SEG_LANES; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    if (live && j == 0) out[(size_t)b * out_batch_stride + (size_t)v * C + c] = acc;
 }
 
 // ---- the node network's input (DeformNetwork's embedders, utils/time_utils.py:208-273: include_input, log-spaced sin / cos) for n time

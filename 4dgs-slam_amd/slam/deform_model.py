@@ -554,8 +554,8 @@ class ControlNodes(nn.Module):
         `n_full` need every head (and, with `blend` = (x, motion_mask), the Gaussians' deltas), the others only the node positions. The
         layout is the caller's and fixed -- no sorting, no merging of equal values -- which is what lets the times come from device
         memory the host never reads (slam/dynamic_graph.py: the random keyframes' times, the regularisers' random samples of a captured
-        iteration). Returns {"d_xyz_all" [n, M, 3], "n_full", "heads" {name: [n_full, M, .]}, "blended" (rows of d_xyz, d_rotation,
-        d_scaling per full sample) or None}."""
+        iteration). Returns {"d_xyz_full" [n_full, M, 3], "d_xyz_rest" [n - n_full, M, 3] (None when empty), "n_full", "n", "heads" {name:
+        [n_full, M, .]}, "blended" (rows of d_xyz, d_rotation, d_scaling per full sample) or None}."""
         M, net = self.node_num, self.network
         n = int(tt.shape[0])
         if self.nodes.is_cuda and self.nodes.dtype == torch.float32 and os.environ.get("GSR_FUSED_EMBEDDING", "1") != "0":
@@ -567,14 +567,21 @@ class ControlNodes(nn.Module):
         # (the heads as ONE linear layer on all rows: the rotation / scaling / local-frame columns of the position-only rows are computed and
         # never read -- 11 of 14 columns of a [rows, 256] x [256, 14] product)
         heads = net.heads()
-        cols = net.heads_from_embedding(emb.reshape(n * M, -1)).reshape(n, M, -1).split([m.weight.shape[0] for _, m in heads], -1)
-        d_xyz_all = cols[0]
-        it = {"d_xyz_all": d_xyz_all, "n_full": int(n_full), "heads": {}, "blended": None}
+        n_full = int(n_full)
+        out = net.heads_from_embedding(emb.reshape(n * M, -1)).reshape(n, M, -1)
+        # rows first (full samples | position-only samples), then the full samples' columns: the backward pass is two concatenations and ONE
+        # zero-filled buffer (the position-only rows' unused columns) -- slicing every head out of the whole matrix cost a zero-fill and a copy
+        # per head plus the additions of the pieces
+        full, rest = out.split([n_full, n - n_full], 0) if 0 < n_full < n else ((out, None) if n_full else (None, out))
+        widths = [m.weight.shape[0] for _, m in heads]
+        cols = full.split(widths, -1) if full is not None else None
+        it = {"d_xyz_full": cols[0] if cols is not None else None, "d_xyz_rest": rest[..., :widths[0]] if rest is not None else None,
+              "n_full": n_full, "n": n, "heads": {}, "blended": None}
         if n_full:
-            stacked = it["heads"] = {name: c[:n_full] for (name, _), c in list(zip(heads, cols))[1:]}
+            stacked = it["heads"] = {name: c for (name, _), c in list(zip(heads, cols))[1:]}
             if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
                 x, motion_mask = blend
-                out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, d_xyz_all[:n_full],
+                out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, cols[0],
                                                      stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
                                                      K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
                 it["blended"] = [t.unbind(0) for t in out]
@@ -592,15 +599,15 @@ class ControlNodes(nn.Module):
         ea, ee = extra_samples
         nw, nx = n_window * (wa + we), n_extra * (ea + ee)
         # (split, not slices: one backward node that concatenates the pieces' gradients instead of a zero-fill + copy per slice)
-        n_all = int(it["d_xyz_all"].shape[0])
-        pieces = it["d_xyz_all"].split([it["n_full"], nw, nx] + ([n_all - it["n_full"] - nw - nx] if n_all > it["n_full"] + nw + nx else []), 0)
+        n_rest = it["n"] - it["n_full"]
+        pieces = it["d_xyz_rest"].split([nw, nx] + ([n_rest - nw - nx] if n_rest > nw + nx else []), 0)
         parts_e, reg = [], 0
         w_a = w_e = e_a = e_e = None
         if n_window:
-            w_a, w_e = (base + pieces[1].reshape(n_window, wa + we, M, 3)).split([wa, we], 1)
+            w_a, w_e = (base + pieces[0].reshape(n_window, wa + we, M, 3)).split([wa, we], 1)
             parts_e.append(w_e)
         if n_extra:
-            e_a, e_e = (base + pieces[2].reshape(n_extra, ea + ee, M, 3)).split([ea, ee], 1)
+            e_a, e_e = (base + pieces[1].reshape(n_extra, ea + ee, M, 3)).split([ea, ee], 1)
             parts_e.append(e_e)
         nodes_t = (parts_e[0] if len(parts_e) == 1 else torch.cat(parts_e, 0)).permute(0, 2, 1, 3)             # [V, M, T, 3]
         nn_weight, nn_idx = self._elastic_neighbours()

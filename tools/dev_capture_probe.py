@@ -15,13 +15,18 @@ x = torch.rand(5000, 3, device=dev)
 tt = torch.linspace(0, 1, 30, device=dev)
 w = torch.full((3,), 1e-3, device=dev)
 
+def d_xyz_all(it):
+    parts = [t for t in (it["d_xyz_full"], it["d_xyz_rest"]) if t is not None]
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+
+
 def body():
     if piece == "trunk":
         it = nodes.begin_iteration_indexed(tt, 0)
-        it["d_xyz_all"].sum().backward()
+        d_xyz_all(it).sum().backward()
     elif piece == "heads":
         it = nodes.begin_iteration_indexed(tt, 6)
-        (it["d_xyz_all"].sum() + sum(v.sum() for v in it["heads"].values())).backward()
+        (d_xyz_all(it).sum() + sum(v.sum() for v in it["heads"].values())).backward()
     elif piece == "blend":
         it = nodes.begin_iteration_indexed(tt, 6, blend=(x, None))
         sum(r.sum() for rows in it["blended"] for r in rows).backward()
@@ -29,14 +34,14 @@ def body():
         it = nodes.begin_iteration_indexed(tt, 6)
         from slam.deform_model import elastic_error
         base = nodes.nodes.detach()
-        e = base + it["d_xyz_all"][6:].reshape(2, 12, -1, 3)
+        e = base + it["d_xyz_rest"].reshape(2, 12, -1, 3)
         nn_weight, nn_idx = nodes._elastic_neighbours()
         elastic_error(e[:, 4:].permute(0, 2, 1, 3), nn_weight, nn_idx).sum().backward()
     elif piece == "arap":
         it = nodes.begin_iteration_indexed(tt, 6)
         from slam.deform_model import arap_error, connectivity_from_points
         base = nodes.nodes.detach()
-        e = base + it["d_xyz_all"][6:].reshape(2, 12, -1, 3)
+        e = base + it["d_xyz_rest"].reshape(2, 12, -1, 3)
         seq = e[:, :4]
         nn_i, keep = connectivity_from_points(seq[:, 0], K=10)
         arap_error(seq, nn_i, keep).sum().backward()
@@ -45,7 +50,7 @@ def body():
         nodes.regularisers_indexed(it, 2, 0, w[:2]).backward()
     elif piece == "adam":
         it = nodes.begin_iteration_indexed(tt, 6)
-        (it["d_xyz_all"].sum() + sum(v.sum() for v in it["heads"].values())).backward()
+        (d_xyz_all(it).sum() + sum(v.sum() for v in it["heads"].values())).backward()
         dm.optimizer.step()
         dm.optimizer.zero_grad(set_to_none=True)
     nodes.end_iteration()
