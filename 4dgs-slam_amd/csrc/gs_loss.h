@@ -11,7 +11,8 @@
 
 namespace gsr {
 
-constexpr int LOSS_BLOCKS = 256, LOSS_THREADS = 256;
+constexpr int LOSS_BLOCKS = 1024, LOSS_THREADS = 256;          // (1.2 pixels per thread at 640 x 480: with 256 blocks a thread walked five pixels,
+                                                               // each a round of dependent loads: 9.6 us for 12 MB)
 
 struct LossArgs {
     int N;                                   // pixels
@@ -57,14 +58,17 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_fwd_kernel(LossArgs a, f
 // out[k] = sum over blocks of partials[b * stride + k], k < stride, fixed order
 __global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restrict__ partials, int stride, float* __restrict__ out)
 {
-    // one wave: lane l adds the partials of blocks l, l + 64, l + 128, l + 192 (independent loads), the lanes are added by xor shuffles -- a fixed
-    // order. (One thread per k walking all 256 partials was a chain of load latencies: 6.5 us per launch, nine launches per dynamic iteration.)
-    static_assert(LOSS_BLOCKS == 256, "loss_finalize_kernel adds four partials per lane");
+    // one wave: lane l adds the partials of blocks l, l + 64, l + 128, ... (independent loads), the lanes are added by xor shuffles -- a fixed
+    // order. (One thread per k walking all partials was a chain of load latencies: 6.5 us per launch, nine launches per dynamic iteration.)
+    static_assert(LOSS_BLOCKS % 64 == 0, "loss_finalize_kernel adds LOSS_BLOCKS / 64 partials per lane");
     const int lane = threadIdx.x;
     for (int k = 0; k < stride; k++) {
-        const float v0 = partials[lane * stride + k], v1 = partials[(lane + 64) * stride + k];
-        const float v2 = partials[(lane + 128) * stride + k], v3 = partials[(lane + 192) * stride + k];
-        float t = (v0 + v1) + (v2 + v3);
+        float v[LOSS_BLOCKS / 64];
+#pragma unroll
+        for (int u = 0; u < LOSS_BLOCKS / 64; u++) v[u] = partials[(lane + 64 * u) * stride + k];
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < LOSS_BLOCKS / 64; u++) t += v[u];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
         if (lane == 0) out[k] = t;

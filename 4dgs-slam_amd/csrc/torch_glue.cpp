@@ -9,6 +9,8 @@
 //
 // Pure C++ (no device code, no HIP headers): the stream is passed in as an integer by the Python caller.
 #include <torch/extension.h>
+#include <map>
+#include <mutex>
 
 #include <cstring>
 #include <string>
@@ -639,6 +641,19 @@ using OptTensor = c10::optional<torch::Tensor>;
 OptTensor opt_of(const torch::Tensor& t) { return t.defined() ? OptTensor(t) : c10::nullopt; }
 torch::Tensor detached(const OptTensor& t) { return (t.has_value() && t->defined()) ? t->detach() : torch::Tensor(); }
 
+// The value of a loss evaluated with compute_value = false: a zero scalar without a launch -- a fresh alias of ONE zero per device (a defined
+// placeholder, NOT the loss; nobody may write into it).
+static torch::Tensor loss_placeholder(const torch::Tensor& like)
+{
+    static std::mutex mu;
+    static std::map<int, torch::Tensor> zeros;
+    std::lock_guard<std::mutex> lock(mu);
+    const int dev = like.get_device();
+    auto it = zeros.find(dev);
+    if (it == zeros.end()) it = zeros.emplace(dev, torch::zeros({}, like.options().dtype(torch::kFloat32))).first;
+    return it->second.detach();
+}
+
 struct WeightedL1Node : public torch::autograd::Function<WeightedL1Node> {
     // (optional inputs travel as c10::optional: the autograd machinery records layout / device of every Tensor argument, an undefined one has neither)
     static torch::Tensor forward(torch::autograd::AutogradContext* ctx, const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& gt_image,
@@ -653,7 +668,7 @@ struct WeightedL1Node : public torch::autograd::Function<WeightedL1Node> {
         } else {        // the caller only back-propagates: a defined placeholder (NOT the loss), the backward kernels need nothing from the forward pass
             TORCH_CHECK(image.is_cuda(), "image is on '", image.device().str(),
                         "': the MI355X rasterizer needs tensors on a HIP device (device='cuda'); there is no CPU fallback in the product path.");
-            loss = torch::zeros({}, image.options().dtype(torch::kFloat32));
+            loss = loss_placeholder(image);
             ws = torch::empty({(int64_t)gsr_l1_loss_workspace_size()}, image.options().dtype(torch::kUInt8));
         }
         ctx->saved_data["alpha"] = alpha;

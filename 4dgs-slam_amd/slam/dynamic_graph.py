@@ -356,7 +356,7 @@ class DynamicMapping:
                 with _region("gsr.flow_losses"):
                     for k, (t_back, m1, t_fwd, m2) in enumerate(pairs):
                         terms.append(slam_losses.masked_l1(r.flow_weight, [(flows[2 * k]["render"], t_back, m1), (flows[2 * k + 1]["render"], t_fwd, m2)],
-                                                           channels=2))
+                                                           channels=2, compute_value=False))          # (nobody reads the value: eligible() excludes loss_values)
         with _region("gsr.isotropic"):
             terms.append(be._isotropic_loss())
         torch.autograd.backward(terms, [be.unit_gradient(dev)] * len(terms))

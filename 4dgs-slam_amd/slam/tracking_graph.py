@@ -38,6 +38,7 @@ class TrackingGraph:
         self.alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.95
         lr = config["Training"]["lr"]
         self.lrs = (lr["cam_rot_delta"], lr["cam_trans_delta"], 0.01)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         self.static = None
         if bool(gaussians.dygs.any()):
             self.static = gaussians.dygs == False  # noqa: E712
@@ -99,7 +100,7 @@ class TrackingGraph:
         # the loss VALUE is never read in this loop: only its gradient is taken
         loss = slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], self.gt_image, self.gt_depth, self.w_rgb, self.w_dep, c.exposure_a,
                                             c.exposure_b, self.alpha, opacity=pkg["opacity"], opacity_depth_threshold=0.95, compute_value=False)
-        loss.backward()
+        loss.backward(self._one)                  # (an explicit unit gradient: backward() alone fills a ones_like per call)
         c.pose_step(*self.lrs, latch=True)
         if not self.direct and self.gaussians.optimizer is not None:
             self.gaussians.optimizer.zero_grad(set_to_none=True)

@@ -57,6 +57,19 @@ def _p(t, keep):
     return tc.data_ptr()
 
 
+_PLACEHOLDERS = {}
+
+
+def _placeholder(device):
+    """The value of a loss evaluated with compute_value=False: a zero scalar that costs no launch -- every call returns a fresh alias of ONE
+    zero per device (a defined placeholder, NOT the loss: sums and logs stay finite; nobody may write into it)."""
+    key = str(device)
+    z = _PLACEHOLDERS.get(key)
+    if z is None:
+        z = _PLACEHOLDERS[key] = torch.zeros((), dtype=torch.float32, device=device)
+    return z.detach()
+
+
 class _WeightedL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, alpha, opacity=None, opacity_thr=0.95,
@@ -67,7 +80,7 @@ class _WeightedL1(torch.autograd.Function):
         if not compute_value:
             # the caller only back-propagates (a tracking iteration inside a hipGraph): the value's two launches are skipped; the backward
             # kernels need nothing from them (the workspace is their scratch)
-            loss = torch.zeros((), dtype=torch.float32, device=image.device)     # a defined placeholder (NOT the loss): sums and logs stay finite
+            loss = _placeholder(image.device)
             ws = torch.empty((int(_lib().gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=image.device)
             ctx.save_for_backward(image, depth, gt_image, gt_depth, w_rgb, w_depth, exposure_a, exposure_b, ws, opacity)
             return loss
@@ -147,7 +160,7 @@ class _MaskedL1(torch.autograd.Function):
     """scale * sum_terms mean(|target - image[:C] * mask|) over up to four (image, target, mask) terms: two launches forward, one back."""
 
     @staticmethod
-    def forward(ctx, scale, channels, *ops):
+    def forward(ctx, scale, channels, compute_value, *ops):
         images, targets, masks = ops[0::3], ops[1::3], ops[2::3]
         lib = _lib()
         dev = images[0].device
@@ -158,12 +171,15 @@ class _MaskedL1(torch.autograd.Function):
             if tuple(im.shape) != (Cimg, H, W) or tg.numel() != channels * H * W or mk.numel() != H * W:
                 raise RuntimeError(f"masked_l1: term {t}: image {tuple(im.shape)}, target {tuple(tg.shape)}, mask {tuple(mk.shape)}")
             terms[t].image, terms[t].target, terms[t].mask = _p(im, keep), _p(tg, keep), _p(mk, keep)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        ws = torch.empty((int(lib.gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.gsr_masked_l1_forward(len(images), terms, W, H, int(channels), Cimg, float(scale), loss.data_ptr(), ws.data_ptr(), _C._stream(dev))
-        if rc < 0:
-            _C._err(lib, rc, "gsr_masked_l1_forward")
+        if compute_value:
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            ws = torch.empty((int(lib.gsr_l1_loss_workspace_size()),), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.gsr_masked_l1_forward(len(images), terms, W, H, int(channels), Cimg, float(scale), loss.data_ptr(), ws.data_ptr(), _C._stream(dev))
+            if rc < 0:
+                _C._err(lib, rc, "gsr_masked_l1_forward")
+        else:               # the caller only back-propagates (a captured mapping iteration): the backward kernel needs nothing from the forward pass
+            loss = _placeholder(dev)
         ctx.scale, ctx.channels = float(scale), int(channels)
         ctx.save_for_backward(*keep)
         return loss
@@ -185,18 +201,18 @@ class _MaskedL1(torch.autograd.Function):
             rc = lib.gsr_masked_l1_backward(n, terms, W, H, ctx.channels, Cimg, ctx.scale, _p(g, keep), _C._stream(dev))
         if rc < 0:
             _C._err(lib, rc, "gsr_masked_l1_backward")
-        out = [None, None]
+        out = [None, None, None]
         for t in range(n):
             out += [grads[t], None, None]
         return tuple(out)
 
 
-def masked_l1(scale, terms, channels):
+def masked_l1(scale, terms, channels, compute_value=True):
     """scale * sum over `terms` = [(image [Cimg,H,W], target [channels,H,W], mask [H,W] or [1,H,W]), ...] (at most four) of
     mean(|target - image[:channels] * mask|): the optical-flow terms of the dynamic mapping loop (utils/slam_backend.py:479-509) in one
     forward and one backward call. Differentiable in the images only; targets and masks are constants (fp32, the target already masked)."""
     flat = [t for term in terms for t in term]
-    return _MaskedL1.apply(float(scale), int(channels), *flat)
+    return _MaskedL1.apply(float(scale), int(channels), bool(compute_value), *flat)
 
 
 # Ground-truth-only constants of a frame (device copy of the depth map + four masks, ~10 MB at 640x480). They live in a BOUNDED cache

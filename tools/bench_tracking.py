@@ -28,7 +28,8 @@ def main():
     cfg = default_config()
     rng = np.random.default_rng(0)
     rows = []
-    for P in (10_000, 50_000, 200_000):
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [10_000, 50_000, 200_000]      # (a single size: for `rocprofv3 --stats` of that map)
+    for P in sizes:
         g = make_gaussians(P, make_camera(W, H), seed=0, sh_degree=0)
         pc = GaussianModelStub(g, isotropic=False, dyn_frac=0.0, seed=0)
         # the map's optimizer as the SLAM loop has it: FusedAdam with fused gradient accumulation (the tracking iteration zeroes its buffer)
