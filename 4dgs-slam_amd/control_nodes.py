@@ -48,6 +48,8 @@ def _lib():
         lib.gsr_node_blend_workspace_size_batch.argtypes = [i64, ctypes.c_int32, i]
         lib.gsr_node_blend_backward_batch.restype = i
         lib.gsr_node_blend_backward_batch.argtypes = [ctypes.POINTER(_Blend), i] + [vp] * 15
+        lib.gsr_multi_add.restype = i
+        lib.gsr_multi_add.argtypes = [i, ctypes.POINTER(_MultiAddItem), vp]
         lib.gsr_index_csr_workspace_size.restype = ctypes.c_size_t
         lib.gsr_index_csr_workspace_size.argtypes = [i, i, i]
         lib.gsr_index_csr.restype = i
@@ -95,6 +97,68 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, K: int = 1, version: int = 
     if return_nn:
         knn = torch.gather(p2[:, None].expand(-1, N, -1, -1), 2, idx[..., None].expand(-1, -1, -1, D))
     return _KNN(dists, idx, knn)
+
+
+class _MultiAddItem(ctypes.Structure):      # gsr_multi_add_item
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p * 4), ("count", ctypes.c_int32)]
+
+
+class _FanOut(torch.autograd.Function):
+    """outputs[k] = stacked[plan[k][0]][plan[k][1]] (aliases: no copy); backward: every row of every stacked tensor's gradient = the sum of the
+    gradients of its readers, all rows in ONE launch (gsr_multi_add)."""
+
+    @staticmethod
+    def forward(ctx, plan, *stacked):
+        ctx.plan, ctx.shapes = plan, [tuple(t.shape) for t in stacked]
+        ctx.set_materialize_grads(False)
+        return tuple(stacked[a].detach()[i] for a, i in plan)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan, shapes = ctx.plan, ctx.shapes
+        dev = next(g for g in grads if g is not None).device if any(g is not None for g in grads) else None
+        if dev is None:
+            return (None,) + (None,) * len(shapes)
+        outs = [torch.empty(shape, dtype=torch.float32, device=dev) for shape in shapes]
+        readers, keep = {}, []
+        for (a, i), g in zip(plan, grads):
+            if g is None:
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.to(torch.float32).contiguous()
+            keep.append(g)
+            readers.setdefault((a, i), []).append(g)
+        rows = [(a, i) for a, shape in enumerate(shapes) for i in range(shape[0])]
+        lib = _lib()
+        with torch.cuda.device(dev):
+            for lo in range(0, len(rows), 64):
+                part = rows[lo:lo + 64]
+                items = (_MultiAddItem * len(part))()
+                for it, (a, i) in zip(items, part):
+                    srcs = readers.get((a, i), [])
+                    if len(srcs) > 4:                     # (more readers than a launch item carries: fold the rest first)
+                        extra = srcs[3]
+                        for g in srcs[4:]:
+                            extra = extra + g
+                        keep.append(extra)
+                        srcs = srcs[:3] + [extra]
+                    it.dst, it.count = outs[a][i].data_ptr(), int(outs[a][i].numel())
+                    for k in range(4):
+                        it.src[k] = srcs[k].data_ptr() if k < len(srcs) else None
+                rc = lib.gsr_multi_add(len(part), items, _C._stream(dev))
+                if rc < 0:
+                    _C._err(lib, rc, "gsr_multi_add")
+        return (None,) + tuple(outs)
+
+
+def fan_out(stacked, plan):
+    """Rows of stacked tensors for SEVERAL readers each: returns [stacked[a][i] for (a, i) in plan] (the same row may appear many times) as one
+    autograd node whose backward pass adds the readers' gradients of all rows in one launch and hands back whole stacked gradients -- instead
+    of an unbind per tensor, a pairwise addition per extra reader and a re-stacking (32 + 3 launches of tiny kernels per dynamic mapping
+    iteration, slam/dynamic_graph.py). stacked: fp32 device tensors [S, ...]; rows nobody reads get zero gradients."""
+    for t in stacked:
+        _C._require_device(t, "stacked")
+    return list(_FanOut.apply(tuple((int(a), int(i)) for a, i in plan), *[t.contiguous() for t in stacked]))
 
 
 class IndexSets:

@@ -2124,6 +2124,25 @@ int gsr_relu_backward_bias(int rows, int cols, const float* dY, const float* Y, 
     return 0;
 }
 
+int gsr_multi_add(int count, const gsr_multi_add_item* items, void* stream_)
+{
+    if (count < 0 || count > MULTI_ADD_MAX || (count > 0 && !items)) { g_last_error = "gsr_multi_add: 0 <= count <= 64 items"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (count == 0) return 0;
+    MultiAddItems a;
+    int largest = 0;
+    for (int i = 0; i < count; i++) {
+        const gsr_multi_add_item& q = items[i];
+        if (q.count < 0 || (q.count > 0 && !q.dst)) { g_last_error = "gsr_multi_add: invalid item"; return GSR_ERR_INVALID_ARGUMENT; }
+        a.item[i].dst = q.dst; a.item[i].count = q.count;
+        for (int s = 0; s < MULTI_ADD_SOURCES; s++) a.item[i].src[s] = q.src[s];
+        largest = std::max(largest, q.count);
+    }
+    if (largest == 0) return 0;
+    hipLaunchKernelGGL(multi_add_kernel, dim3((unsigned)std::min((largest + 255) / 256, 64), (unsigned)count), dim3(256), 0, (hipStream_t)stream_, a);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

@@ -465,6 +465,25 @@ segment_sum_kernel(const int B, const int E, const int C, const int Nv, const fl
     if (live && j == 0) out[(size_t)b * out_batch_stride + (size_t)v * C + c] = acc;
 }
 
+// ---- several small sums in one launch (round 5) -------------------------------------------------------------------------------------------
+// A row of the control-node warp's output (d_xyz / d_rotation / d_scaling of one time sample) is read by up to three rasterizer calls of a
+// dynamic mapping iteration (the keyframe's render, its flow render, the partner's flow render); autograd adds the calls' gradients of that
+// row pairwise -- 32 launches of 5 000-element kernels per iteration plus the re-stacking of the rows. multi_add_kernel forms every row of
+// the stacked gradient in one launch: dst[j] = src0[j] + src1[j] + src2[j] + src3[j] (null sources skipped, that order), zero without sources.
+constexpr int MULTI_ADD_MAX = 64, MULTI_ADD_SOURCES = 4;
+struct MultiAddItem { float* dst; const float* src[MULTI_ADD_SOURCES]; int count; };
+struct MultiAddItems { MultiAddItem item[MULTI_ADD_MAX]; };
+__global__ void __launch_bounds__(256) multi_add_kernel(const MultiAddItems items)
+{
+    const MultiAddItem& it = items.item[blockIdx.y];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < it.count; j += gridDim.x * 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < MULTI_ADD_SOURCES; s++) if (it.src[s]) t += it.src[s][j];
+        it.dst[j] = t;
+    }
+}
+
 // ---- the node network's input (DeformNetwork's embedders, utils/time_utils.py:208-273: include_input, log-spaced sin / cos) for n time
 // samples x M nodes in one launch: row (i, m) = [x_m, sin(2^0 x_m), cos(2^0 x_m), ..., | t_i, sin(2^0 t_i), cos(2^0 t_i), ...]. As tensor
 // ops that is two embeddings of four launches each, two expands and a concatenation on the way to the same [n M, 3 (1 + 2 Fx) + 1 + 2 Ft]

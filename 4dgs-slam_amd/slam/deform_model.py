@@ -576,7 +576,7 @@ class ControlNodes(nn.Module):
         widths = [m.weight.shape[0] for _, m in heads]
         cols = full.split(widths, -1) if full is not None else None
         it = {"d_xyz_full": cols[0] if cols is not None else None, "d_xyz_rest": rest[..., :widths[0]] if rest is not None else None,
-              "n_full": n_full, "n": n, "heads": {}, "blended": None}
+              "n_full": n_full, "n": n, "heads": {}, "blended": None, "blended_stacked": None}
         if n_full:
             stacked = it["heads"] = {name: c for (name, _), c in list(zip(heads, cols))[1:]}
             if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
@@ -585,6 +585,7 @@ class ControlNodes(nn.Module):
                                                      stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
                                                      K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
                 it["blended"] = [t.unbind(0) for t in out]
+                it["blended_stacked"] = out                    # (d_xyz, d_rotation, d_scaling), each [n_full, n, .]: control_nodes.fan_out's input
         self._batch, self._blended, self._graph = {}, None, None       # ("inside an iteration": _elastic_neighbours keeps its graph until end_iteration)
         return it
 

@@ -35,6 +35,7 @@ import numpy as np
 import torch
 
 from diff_gaussian_rasterization import _C
+import control_nodes
 import slam_losses
 
 from . import _lib
@@ -311,10 +312,31 @@ class DynamicMapping:
         nv, ne = len(self.views), self.n_slots
         with _region("gsr.regularisers"):
             loss_network = nodes.regularisers_indexed(it, nv, ne, be._regulariser_weights(nv, ne), WINDOW_SAMPLES, EXTRA_SAMPLES)
-        rows = it["blended"]
-        deltas_at = lambda i: (rows[0][i], rows[2][i], rows[1][i])                    # (d_xyz, d_scaling, d_rotation) of full sample i
         views = self.views + self.slots
-        deltas = [deltas_at(i) for i in lay["view_idx"]]
+        # Who reads which row of the warp's output: every view's render its own sample (d_xyz, d_scaling, d_rotation); a flow pair (view sample
+        # i, partner sample j) reads i whole + j's d_xyz for "this keyframe -> the earlier one", and j whole + i's d_xyz for the way back. All
+        # readers are outputs of ONE node (control_nodes.fan_out) whose backward adds a row's gradients in one launch for all rows.
+        plan = []
+
+        def reader(i, whole):
+            pos = {"x": len(plan)}
+            plan.append((0, i))
+            if whole:
+                pos["s"], pos["r"] = len(plan), len(plan) + 1
+                plan.extend([(2, i), (1, i)])
+            return pos
+
+        render_readers = [reader(i, True) for i in lay["view_idx"]]
+        flow_readers = {}
+        if r.with_flow:
+            for k in range(len(views)):
+                if k < nv and lay["partners"][k] is None:
+                    continue
+                i = lay["view_idx"][k]
+                j = lay["partner_idx"][k] if k < nv else i + 1
+                flow_readers[k] = (reader(i, True), reader(j, False), reader(j, True), reader(i, False))
+        fan = control_nodes.fan_out(it["blended_stacked"], plan)
+        deltas = [(fan[p["x"]], fan[p["s"]], fan[p["r"]]) for p in render_readers]
         cfg = be.config
         ops = self._window_ops.get(r.dyn)          # (held by the call: a captured iteration points at these buffers)
         if ops is None:
@@ -339,14 +361,13 @@ class DynamicMapping:
                     other, f6 = lay["partners"][k], lay["flow6"][k]
                     if other is None:
                         continue
-                    d2 = deltas_at(lay["partner_idx"][k])
                     clips += list(lay["clips"][k])
                 else:
                     other, f6 = self.partner_slots[k - nv], self.partner_flow[k - nv]
-                    d2 = deltas_at(lay["view_idx"][k] + 1)
                     clips += [self.slot_clips[k - nv, 0:4], self.slot_clips[k - nv, 4:8]]
-                (dx1, ds1, dr1), (dx2, ds2, dr2) = deltas[k], d2
-                requests += [(v, other, dx1, dx2, dr1, ds1), (other, v, dx2, dx1, dr2, ds2)]      # this keyframe -> the earlier one, and back
+                a1, b1, a2, b2 = flow_readers[k]
+                requests += [(v, other, fan[a1["x"]], fan[b1["x"]], fan[a1["r"]], fan[a1["s"]]),      # this keyframe -> the earlier one,
+                             (other, v, fan[a2["x"]], fan[b2["x"]], fan[a2["r"]], fan[a2["s"]])]      # and back
                 pairs.append((f6[0:2], f6[2:3], f6[4:6], f6[3:4]))
             if requests:
                 with _region("gsr.flow_render"):

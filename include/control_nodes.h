@@ -115,6 +115,17 @@ size_t gsr_index_csr_workspace_size(int S, int E, int Nv);
 int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, void* stream);
 int gsr_segment_sum(int B, int S, int E, int C, int Nv, const float* g, const char* csr_workspace, const int* set_of_b, float* out, void* stream);
 
+/* Several small sums in ONE launch: dst[j] = src[0][j] + src[1][j] + src[2][j] + src[3][j] for j < count, per item (NULL sources are skipped;
+ * no source: zeros), at most 64 items. The rows of the control-node warp's output (utils/time_utils.py:1192-1258, one per time sample) feed up to
+ * three rasterizer calls of a dynamic mapping iteration (utils/slam_backend.py:357-509: the keyframe's render and the two flow renders); this
+ * forms every row of the stacked gradient at once where autograd adds the calls' gradients pairwise (control_nodes.fan_out). Fixed order. */
+typedef struct gsr_multi_add_item {
+    float* dst;
+    const float* src[4];
+    int32_t count;
+} gsr_multi_add_item;
+int gsr_multi_add(int count, const gsr_multi_add_item* items, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

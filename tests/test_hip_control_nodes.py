@@ -320,3 +320,27 @@ def test_gather_rows_backward_is_an_ordered_scatter_add(S, E, Nv, C, B):
     sets2 = cn.IndexSets(idx.clone(), Nv)
     (grad2,) = torch.autograd.grad(cn.gather_rows(table, sets2, set_of_b), table, cot)
     assert torch.equal(grad, grad2)
+
+
+def test_fan_out_rows_for_several_readers():
+    """control_nodes.fan_out: rows of stacked tensors handed to several readers each; the backward pass adds the readers' gradients of every row
+    in one launch (gsr_multi_add) -- equal to autograd's own accumulation through plain indexing, zeros for rows nobody reads, five readers of
+    one row (more than a launch item carries), a reader whose gradient is None."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    stacked = [torch.randn(shape, generator=g).to(DEV).requires_grad_(True) for shape in ((6, 300, 3), (6, 300, 4), (6, 300, 3))]
+    plan = [(0, 0), (2, 0), (1, 0), (0, 0), (0, 1), (0, 0), (1, 3), (2, 5), (0, 0), (0, 0), (0, 0), (1, 3)]
+    coef = [torch.randn((), generator=g).item() for _ in plan]
+    unused = 4                                                    # (this reader contributes nothing to the loss)
+
+    def loss_of(rows):
+        return sum(c * (r * r).sum() for k, (c, r) in enumerate(zip(coef, rows)) if k != unused)
+
+    rows = cn.fan_out(stacked, plan)
+    assert all(torch.equal(r, stacked[a][i]) for r, (a, i) in zip(rows, plan))
+    got = torch.autograd.grad(loss_of(rows), stacked)
+    want = torch.autograd.grad(loss_of([stacked[a][i] for a, i in plan]), stacked)
+    for a, (x, y) in enumerate(zip(got, want)):
+        assert x.shape == y.shape and torch.allclose(x, y, rtol=1e-6, atol=1e-6), a
+    assert float(got[0][2].abs().max()) == 0 and float(got[2][1].abs().max()) == 0        # rows without readers
+    again = torch.autograd.grad(loss_of(cn.fan_out(stacked, plan)), stacked)
+    assert all(torch.equal(x, y) for x, y in zip(got, again))

@@ -77,10 +77,15 @@ if "--cprofile" in sys.argv:          # host side only: where does the Python ti
     st.sort_stats("cumulative").print_stats(45)
     raise SystemExit(0)
 from torch.profiler import profile, ProfilerActivity  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes="--ops" in sys.argv,
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes="--ops" in sys.argv or "--aten" in sys.argv,
              experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     run(iters)
     torch.cuda.synchronize()
+if "--aten" in sys.argv:             # every aten op with its input shapes: calls per iteration and device time (the small tensor-op kernels)
+    rows = [(a.self_device_time_total / iters, a.count / iters, a.key, str(a.input_shapes)[:150]) for a in prof.key_averages(group_by_input_shape=True)
+            if a.key.startswith("aten::") and a.self_device_time_total > 0]
+    for us, cnt, key, shapes in sorted(rows, reverse=True)[:90]:
+        print("%8.1f us %5.1f calls  %-28s %s" % (us, cnt, key, shapes), file=sys.stderr)
 if "--ops" in sys.argv:              # which ops (with their input shapes) own the device time
     print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=45, max_name_column_width=60, max_shapes_column_width=90),
           file=sys.stderr)
