@@ -184,7 +184,7 @@ class _GatherRows(torch.autograd.Function):
     def forward(ctx, table, sets, set_of_b):
         # table [B, Nv, C]; out[b, e, :] = table[b, idx[set_of_b[b], e], :]
         B, Nv, Cn = table.shape
-        idx = sets.idx if set_of_b is None else sets.idx.index_select(0, set_of_b.long())
+        idx = sets.idx if set_of_b is None else sets.idx.index_select(0, getattr(set_of_b, "_gsr_long", None) if hasattr(set_of_b, "_gsr_long") else set_of_b.long())
         idx = idx if idx.shape[0] == B else idx.expand(B, -1)
         ctx.sets, ctx.set_of_b, ctx.shape = sets, set_of_b, (B, Nv, Cn)
         return torch.gather(table, 1, idx[:, :, None].expand(-1, -1, Cn))

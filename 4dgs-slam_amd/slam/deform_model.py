@@ -170,7 +170,21 @@ def estimate_rotation(E0, Et, weight, rotations=kabsch_rotations):
     return rotations(S)
 
 
-def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
+_SET_OF_B = {}
+
+
+def _set_of_b(V, T, offset, device):
+    """[offset, ..., offset + V - 1] each repeated T times (int32, on the device): a constant of the layout, built once (arange +
+    repeat_interleave were three launches per call)."""
+    key = (V, T, offset, str(device))
+    t = _SET_OF_B.get(key)
+    if t is None:
+        t = _SET_OF_B[key] = (torch.arange(V, dtype=torch.int32) + offset).repeat_interleave(T).to(device)
+        t._gsr_long = t.long()                   # (what gather_rows' index_select wants: no conversion launch per call)
+    return t
+
+
+def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations, sets=None, set_offset=0):
     """cal_arap_error (deform_utils.py:177-205) without edge weights (every kept edge weighs 1) and without its random vertex subsample,
     which only starts above 512 vertices (the node budget). nodes_seq [..., T, Nv, 3]; nn_idx / keep [..., Nv, K] from
     connectivity_from_points(nodes_seq[..., 0, :, :]). Returns the error per leading index. The reference loops over the samples
@@ -183,8 +197,9 @@ def arap_error(nodes_seq, nn_idx, keep, rotations=kabsch_rotations):
         # everything per (view, sample, node) -- edges, cross-covariance, Kabsch, the error and all of its backward -- in one launch each way
         V, T, M, _ = nodes_seq.shape
         K = nn_idx.shape[-1]
-        sets = control_nodes.IndexSets(nn_idx.reshape(V, M * K), M)
-        set_of_b = torch.arange(V, device=nodes_seq.device, dtype=torch.int32).repeat_interleave(T) if V > 1 else None
+        if sets is None:              # (`sets`: the reverse lists of a larger family of neighbour sets, of which nn_idx is the rows from set_offset)
+            sets, set_offset = control_nodes.IndexSets(nn_idx.reshape(V, M * K), M), 0
+        set_of_b = _set_of_b(V, T, set_offset, nodes_seq.device) if sets.S > 1 else None
         nb = control_nodes.gather_rows(nodes_seq.reshape(V * T, M, 3), sets, set_of_b).reshape(V, T, M, K, 3)
         return _ArapTerm.apply(nodes_seq, nb, keep.to(torch.float32)).sum(dim=(1, 2))
     w = keep.to(nodes_seq.dtype)
@@ -613,6 +628,14 @@ class ControlNodes(nn.Module):
         nodes_t = (parts_e[0] if len(parts_e) == 1 else torch.cat(parts_e, 0)).permute(0, 2, 1, 3)             # [V, M, T, 3]
         nn_weight, nn_idx = self._elastic_neighbours()
         reg = (elastic_error(nodes_t, nn_weight, nn_idx) * weights).sum()
+        if n_window and n_extra and w_a.is_cuda:
+            # the neighbour sets of both groups of views in one k-NN call and ONE set of reverse lists (the two groups differ in their number
+            # of samples, not in how a view's neighbours are found: deform_utils.py:58-110 on each view's first sample)
+            nn_i, keep = connectivity_from_points(torch.cat([w_a[:, 0].detach(), e_a[:, 0].detach()], 0), K=10)
+            sets = control_nodes.IndexSets(nn_i.reshape(n_window + n_extra, -1), M)
+            reg = reg + (weights[:n_window] * arap_error(w_a, nn_i[:n_window], keep[:n_window], sets=sets, set_offset=0)).sum()
+            reg = reg + (weights[n_window:] * arap_error(e_a, nn_i[n_window:], keep[n_window:], sets=sets, set_offset=n_window)).sum()
+            return reg
         if n_window:
             nn_i, keep = connectivity_from_points(w_a[:, 0], K=10)
             reg = reg + (weights[:n_window] * arap_error(w_a, nn_i, keep)).sum()
