@@ -2044,9 +2044,12 @@ static size_t node_ws_floats(int64_t n, int32_t m)      // per batch element: bl
     const size_t ordered_route = ((size_t)n * NODE_DET_MAX_K + (size_t)m) * NODE_GRAD;        // per-(Gaussian, k) contributions + the summed row
     return (std::max(atomics_route, ordered_route) + 63) & ~size_t(63);
 }
-static size_t node_ws_shared_bytes(int64_t n, int32_t m)  // once per call (any batch size): order[n K], seg[m][2], cursor -- the reverse lists of nn_idx
+static size_t index_csr_ints(int S, int E, int Nv) { return (((size_t)S * ((size_t)E + 2 * (size_t)Nv + 1) + 64) * sizeof(int) + 255) & ~size_t(255); }
+static int index_csr_epad(int E) { return round_up_int(E, CSR_REG_TRIP); }
+static size_t node_ws_shared_bytes(int64_t n, int32_t m)  // once per call (any batch size): the reverse lists of nn_idx (gsr_index_csr's workspace for one set)
 {
-    return (((size_t)n * NODE_DET_MAX_K + 2 * (size_t)m + 64) * sizeof(int) + 255) & ~size_t(255);
+    const int E = (int)std::min<int64_t>(n * NODE_DET_MAX_K, INT32_MAX / 2);
+    return index_csr_ints(1, E, m) + (size_t)index_csr_epad(E > 0 ? E : 1) * sizeof(unsigned short) + 512;
 }
 
 size_t gsr_node_blend_workspace_size(int64_t n, int32_t m)
@@ -2062,7 +2065,10 @@ size_t gsr_node_blend_workspace_size_batch(int64_t n, int32_t m, int B)
 }
 
 /* ---- deterministic scatter-add through an index array (include/control_nodes.h) ------------------------------------------------------ */
-size_t gsr_index_csr_workspace_size(int S, int E, int Nv) { return ((size_t)S * ((size_t)E + 2 * (size_t)Nv + 1) * sizeof(int)) + 512; }
+size_t gsr_index_csr_workspace_size(int S, int E, int Nv)
+{
+    return index_csr_ints(S, E, Nv) + (size_t)S * index_csr_epad(E > 0 ? E : 1) * sizeof(unsigned short) + 512;      // the lists + the set packed to 16 bits
+}
 
 static void index_csr_carve(char* workspace, int S, int E, int Nv, int*& order, int*& seg, int*& cursor)
 {
@@ -2077,6 +2083,17 @@ int gsr_index_csr(int S, int E, int Nv, const int64_t* idx, char* workspace, voi
     int *order, *seg, *cursor;
     index_csr_carve(workspace, S, E, Nv, order, seg, cursor);
     GSR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)S * sizeof(int), stream));
+    static const bool reg_ok = !(getenv("GSR_CSR_REGISTERS") && getenv("GSR_CSR_REGISTERS")[0] == '0');
+    if (reg_ok && E >= 1 && E <= 20 * CSR_REG_TRIP && Nv < 65535) {          // small sets: packed to 16 bits, a wave holds the whole set in registers
+        const int Epad = index_csr_epad(E);
+        unsigned short* packed = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(cursor) + index_csr_ints(S, E, Nv));
+        hipLaunchKernelGGL(index_csr_pack_kernel, dim3((unsigned)((Epad + 255) / 256), (unsigned)S), dim3(256), 0, stream, E, Epad, idx, packed);
+        const dim3 grid((unsigned)((Nv + 3) / 4), (unsigned)S);
+        if (Epad <= 10 * CSR_REG_TRIP) hipLaunchKernelGGL(index_csr_reg_kernel<10>, grid, dim3(256), 0, stream, E, Epad, Nv, (const unsigned short*)packed, order, seg, cursor);
+        else hipLaunchKernelGGL(index_csr_reg_kernel<20>, grid, dim3(256), 0, stream, E, Epad, Nv, (const unsigned short*)packed, order, seg, cursor);
+        GSR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(index_csr_kernel, dim3((unsigned)((Nv + 3) / 4), (unsigned)S), dim3(256), 0, stream, E, Nv, idx, order, seg, cursor);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;

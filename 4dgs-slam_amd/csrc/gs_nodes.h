@@ -437,6 +437,67 @@ index_csr_kernel(const int E, const int Nv, const int64_t* __restrict__ idx, int
     if (lane == 0) { seg[2 * ((size_t)s * Nv + v)] = base; seg[2 * ((size_t)s * Nv + v) + 1] = count; }
 }
 
+// The same lists for SMALL index sets (E <= 10 240 entries, fewer than 65 535 targets: the regularisers' neighbour sets -- 512 nodes x 10
+// neighbours --, the warp's Gaussian -> node lists of a few thousand dynamic Gaussians). The wave-per-target kernel above is a chain of
+// memory latencies: ten trips per pass, two passes, 3.5 waves per SIMD -- 20-35 us per call. Here the set is first packed to 16-bit indices
+// (index_csr_pack_kernel), then a wave fetches the WHOLE set with one 16-byte load per lane and 512 entries (all loads in flight at once) and
+// counts, reserves and places from registers: one memory latency per wave.
+constexpr int CSR_REG_TRIP = 512;                        // entries per wave-wide 16-byte load: lane l holds entries 8 l .. 8 l + 7 of the trip
+__global__ void __launch_bounds__(256)
+index_csr_pack_kernel(const int E, const int Epad, const int64_t* __restrict__ idx, unsigned short* __restrict__ packed)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (e < Epad) packed[(size_t)s * Epad + e] = e < E ? (unsigned short)idx[(size_t)s * E + e] : (unsigned short)0xFFFF;
+}
+
+template <int TRIPS>
+__global__ void __launch_bounds__(256)
+index_csr_reg_kernel(const int E, const int Epad, const int Nv, const unsigned short* __restrict__ packed, int* __restrict__ order, int* __restrict__ seg,
+                     int* __restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63, v = blockIdx.x * 4 + (threadIdx.x >> 6), s = blockIdx.y;
+    if (v >= Nv) return;
+    packed += (size_t)s * Epad; order += (size_t)s * E;
+    uint4 w[TRIPS];
+#pragma unroll
+    for (int r = 0; r < TRIPS; r++)
+        w[r] = r * CSR_REG_TRIP < Epad ? *reinterpret_cast<const uint4*>(packed + r * CSR_REG_TRIP + 8 * lane) : make_uint4(~0u, ~0u, ~0u, ~0u);
+    const unsigned int vv = (unsigned int)v;
+    auto hits = [&](const uint4& q) __attribute__((always_inline)) {      // bit j: entry 8 lane + j of the trip points at v
+        return (unsigned int)((q.x & 0xFFFFu) == vv) | ((unsigned int)((q.x >> 16) == vv) << 1) | ((unsigned int)((q.y & 0xFFFFu) == vv) << 2) |
+               ((unsigned int)((q.y >> 16) == vv) << 3) | ((unsigned int)((q.z & 0xFFFFu) == vv) << 4) | ((unsigned int)((q.z >> 16) == vv) << 5) |
+               ((unsigned int)((q.w & 0xFFFFu) == vv) << 6) | ((unsigned int)((q.w >> 16) == vv) << 7);
+    };
+    int count = 0;
+#pragma unroll
+    for (int r = 0; r < TRIPS; r++) {
+        const unsigned int h = hits(w[r]);
+        int c = __popc(h);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        count += c;
+    }
+    int base = 0;
+    if (lane == 0) base = count ? atomicAdd(&cursor[s], count) : 0;
+    base = __shfl(base, 0, 64);
+    int running = 0;
+#pragma unroll
+    for (int r = 0; r < TRIPS; r++) {
+        const unsigned int h = hits(w[r]);
+        if (!__ballot(h != 0)) continue;
+        const int mine = __popc(h);
+        int incl = mine;                                  // inclusive prefix over the lanes: the hits of lower lanes come first (positions 8 l + j)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        int pos = base + running + incl - mine;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (h & (1u << j)) order[pos++] = r * CSR_REG_TRIP + 8 * lane + j;
+        running += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) { seg[2 * ((size_t)s * Nv + v)] = base; seg[2 * ((size_t)s * Nv + v) + 1] = count; }
+}
+
 // SEG_LANES adjacent lanes share one (batch, target, channel): lane j adds the entries j, j + SEG_LANES, ... of the segment in that order, the
 // lanes' sums are added pairwise ((0 + 1) + (2 + 3)) + ... by xor shuffles -- a fixed order. (One thread per output walked the whole segment:
 // the busiest control node has hundreds of Gaussians, and every step of the walk is an index load followed by a dependent gradient load.)
