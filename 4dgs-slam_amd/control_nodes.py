@@ -21,7 +21,8 @@ class _Blend(ctypes.Structure):
                 ("rot_as_residual", ctypes.c_int32), ("node_stride", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("x", ctypes.c_void_p), ("motion_mask", ctypes.c_void_p), ("nodes", ctypes.c_void_p), ("node_radius", ctypes.c_void_p),
                 ("node_weight", ctypes.c_void_p), ("node_trans", ctypes.c_void_p), ("node_rot", ctypes.c_void_p),
-                ("node_scale", ctypes.c_void_p), ("node_frame", ctypes.c_void_p), ("node_local_rotation", ctypes.c_void_p)]
+                ("node_scale", ctypes.c_void_p), ("node_frame", ctypes.c_void_p), ("node_local_rotation", ctypes.c_void_p),
+                ("attr_stride", ctypes.c_int32), ("grad_stride", ctypes.c_int32)]
 
 
 _lib_cache = None
@@ -454,6 +455,90 @@ def node_blend_batch(x, motion_mask, nodes, node_radius, node_weight, node_trans
     (the radius / weight gradients are their sum)."""
     return _NodeBlendBatch.apply(x, motion_mask, nodes, node_radius.reshape(-1), _flat(node_weight), node_trans, node_rot, node_scale, local_rotation,
                                  K, d_rot_as_res, raw)
+
+
+class _NodeBlendBatchPacked(torch.autograd.Function):
+    """_NodeBlendBatch with the four node attributes as ONE matrix attrs [B, m, 14] = [d_xyz | d_rotation | d_scaling | local_rotation] -- the
+    node network's heads as its single head layer produces them (gsr_node_blend.attr_stride / grad_stride): no per-attribute copies on the way
+    in, one [B, m, 14] gradient on the way out (instead of four tensors that autograd concatenates)."""
+
+    COLS = (0, 3, 7, 10, 14)              # column ranges of d_xyz, d_rotation, d_scaling, local_rotation
+
+    @staticmethod
+    def forward(ctx, x, motion_mask, nodes, node_radius, node_weight, attrs, K, rot_as_residual, raw):
+        if not 1 <= K <= BLEND_MAX_K:
+            raise ValueError(f"node blend: K = {K} outside 1..{BLEND_MAX_K}")
+        x, nodes, node_radius = _f32(x, "x"), _f32(nodes, "nodes"), _f32(node_radius, "node_radius").reshape(-1)
+        attrs = _f32(attrs, "attrs")
+        n, m = x.shape[0], nodes.shape[0]
+        if x.dim() != 2 or x.shape[1] != 3 or nodes.dim() != 2 or nodes.shape[1] < 3 or attrs.dim() != 3 or tuple(attrs.shape[1:]) != (m, 14):
+            raise ValueError(f"node blend (packed) expects x [N, 3], nodes [M, >=3], attrs [B, M, 14]; got {tuple(x.shape)}, {tuple(nodes.shape)}, {tuple(attrs.shape)}")
+        B = attrs.shape[0]
+        motion_mask = None if motion_mask is None else _f32(motion_mask, "motion_mask")
+        if motion_mask is not None and motion_mask.numel() != n:
+            raise ValueError(f"motion_mask must have one value per Gaussian ({n}), got {tuple(motion_mask.shape)}")
+        node_weight = None if node_weight is None else _f32(node_weight, "node_weight").reshape(-1)
+        if node_radius.numel() != m or (node_weight is not None and node_weight.numel() != m):
+            raise ValueError("node_radius / node_weight must have one value per node")
+        keep = dict(x=x, motion_mask=motion_mask, nodes=nodes, node_radius=node_radius, node_weight=node_weight, attrs=attrs)
+        scalars = dict(n=n, m=m, K=K, local_frame=1, rot_as_residual=int(bool(rot_as_residual)), node_stride=nodes.shape[1],
+                       flags=(RADIUS_IS_LOG | WEIGHT_IS_LOGIT) if raw else 0, attr_stride=14, grad_stride=14)
+        a = _NodeBlendBatchPacked._descriptor(scalars, keep)
+        dev = x.device
+        w = torch.empty((n, K), dtype=torch.float32, device=dev)
+        dist = torch.empty((n, K), dtype=torch.float32, device=dev)
+        idx = torch.empty((n, K), dtype=torch.int64, device=dev)
+        outs = [torch.empty((B, n, c), dtype=torch.float32, device=dev) for c in (3, 4, 3)]
+        lib = _lib()
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_forward_batch(ctypes.byref(a), B, w.data_ptr(), dist.data_ptr(), idx.data_ptr(), *(o.data_ptr() for o in outs), _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_forward_batch")
+        ctx.keep, ctx.scalars, ctx.saved, ctx.B = keep, scalars, (w, dist, idx), B
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def _descriptor(scalars, keep):
+        a = _Blend(**scalars)
+        for k in ("x", "motion_mask", "nodes", "node_radius", "node_weight"):
+            setattr(a, k, keep[k].data_ptr() if keep[k] is not None else None)
+        base, c = keep["attrs"].data_ptr(), _NodeBlendBatchPacked.COLS
+        a.node_trans, a.node_rot, a.node_scale, a.node_local_rotation = base + 4 * c[0], base + 4 * c[1], base + 4 * c[2], base + 4 * c[3]
+        return a
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot, g_scale):
+        keep, sc, B = ctx.keep, ctx.scalars, ctx.B
+        n, m = sc["n"], sc["m"]
+        w, dist, idx = ctx.saved
+        dev = w.device
+        a = _NodeBlendBatchPacked._descriptor(sc, keep)
+        cot = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_xyz, g_rot, g_scale = cot(g_xyz), cot(g_rot), cot(g_scale)
+        g_radius = torch.empty((B, m), dtype=torch.float32, device=dev)
+        g_weight = torch.empty((B, m), dtype=torch.float32, device=dev) if keep["node_weight"] is not None else None
+        g_attrs = torch.empty((B, m, 14), dtype=torch.float32, device=dev)
+        lib = _lib()
+        ws = torch.empty((lib.gsr_node_blend_workspace_size_batch(n, m, B),), dtype=torch.uint8, device=dev)
+        p = lambda t: t.data_ptr() if t is not None else None
+        base, c = g_attrs.data_ptr(), _NodeBlendBatchPacked.COLS
+        with torch.cuda.device(dev):
+            rc = lib.gsr_node_blend_backward_batch(ctypes.byref(a), B, w.data_ptr(), dist.data_ptr(), idx.data_ptr(), p(g_xyz), p(g_rot), p(g_scale), None,
+                                                   base + 4 * c[0], base + 4 * c[1], base + 4 * c[2], base + 4 * c[3], p(g_radius), p(g_weight), ws.data_ptr(),
+                                                   _C._stream(dev))
+        if rc < 0:
+            _C._err(lib, rc, "gsr_node_blend_backward_batch")
+        g_radius = g_radius.sum(0).view(keep["node_radius"].shape)
+        g_weight = None if g_weight is None else g_weight.sum(0)
+        # inputs: x, motion_mask, nodes, node_radius, node_weight, attrs, K, residual, raw
+        return None, None, None, g_radius, g_weight, g_attrs, None, None, None
+
+
+def node_blend_batch_packed(x, motion_mask, nodes, node_radius, node_weight, attrs, K: int = 3, d_rot_as_res: bool = True, raw: bool = True):
+    """node_blend_batch (local frame) with the node attributes as one matrix attrs [B, M, 14] = [d_xyz | d_rotation | d_scaling |
+    local_rotation]: same values and gradients, no copies of the four column ranges and one gradient matrix."""
+    return _NodeBlendBatchPacked.apply(x, motion_mask, nodes, node_radius.reshape(-1), _flat(node_weight), attrs, K, d_rot_as_res, raw)
 
 
 def _checked(t, name, shape):

@@ -2003,6 +2003,8 @@ static int node_blend_check(const gsr_node_blend* a, const char* who)
     if (!a->nodes || !a->node_radius) return fail("null nodes / node_radius");
     if (a->node_trans && (!a->node_rot || !a->node_scale)) return fail("node_trans without node_rot / node_scale");
     if (a->node_trans && a->local_frame && !a->node_frame && !a->node_local_rotation) return fail("local_frame without node_frame / node_local_rotation");
+    if (a->attr_stride < 0 || a->grad_stride < 0 || (a->attr_stride > 0 && (a->attr_stride < 4 || a->node_frame)) || (a->grad_stride > 0 && a->grad_stride < 4))
+        return fail("attr_stride / grad_stride: 0 (packed) or >= 4 floats per node, and no node_frame with strided attributes");
     return 0;
 }
 

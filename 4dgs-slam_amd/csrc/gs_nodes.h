@@ -254,6 +254,11 @@ knn_points_kernel(const int64_t n, const int64_t m, const int D, const int K, co
 
 struct NodeFrame { float R[9]; };
 
+// floats between two nodes' rows of node_trans / node_scale (3 packed) and node_rot / node_local_rotation (4 packed): attr_stride != 0 when the
+// four are column ranges of one [., m, attr_stride] matrix (the node network's heads as it produces them)
+__device__ __forceinline__ size_t node_s3(const gsr_node_blend& a) { return a.attr_stride ? (size_t)a.attr_stride : 3; }
+__device__ __forceinline__ size_t node_s4(const gsr_node_blend& a) { return a.attr_stride ? (size_t)a.attr_stride : 4; }
+
 // quaternion_to_matrix(local_rotation + (1,0,0,0)), utils/time_utils.py:115-133,1207-1208
 __device__ __forceinline__ NodeFrame node_frame_of(const gsr_node_blend& a, int j)
 {
@@ -263,7 +268,7 @@ __device__ __forceinline__ NodeFrame node_frame_of(const gsr_node_blend& a, int 
         for (int c = 0; c < 9; c++) f.R[c] = a.node_frame[9 * (size_t)j + c];
         return f;
     }
-    const float* q = a.node_local_rotation + 4 * (size_t)j;
+    const float* q = a.node_local_rotation + node_s4(a) * (size_t)j;
     const float r = q[0] + 1.f, x = q[1], y = q[2], z = q[3];
     const float s = 2.0f / (r * r + x * x + y * y + z * z);
     f.R[0] = 1.f - s * (y * y + z * z); f.R[1] = s * (x * y - z * r); f.R[2] = s * (x * z + y * r);
@@ -290,11 +295,11 @@ __device__ __forceinline__ float node_weight_of(const gsr_node_blend& a, int j)
 __device__ __forceinline__ gsr_node_blend batch_element(gsr_node_blend a, int b)
 {
     const size_t m = (size_t)a.m;
-    if (a.node_trans) a.node_trans += (size_t)b * m * 3;
-    if (a.node_rot) a.node_rot += (size_t)b * m * 4;
-    if (a.node_scale) a.node_scale += (size_t)b * m * 3;
+    if (a.node_trans) a.node_trans += (size_t)b * m * node_s3(a);
+    if (a.node_rot) a.node_rot += (size_t)b * m * node_s4(a);
+    if (a.node_scale) a.node_scale += (size_t)b * m * node_s3(a);
     if (a.node_frame) a.node_frame += (size_t)b * m * 9;
-    if (a.node_local_rotation) a.node_local_rotation += (size_t)b * m * 4;
+    if (a.node_local_rotation) a.node_local_rotation += (size_t)b * m * node_s4(a);
     return a;
 }
 
@@ -359,7 +364,7 @@ node_blend_fwd_kernel(const gsr_node_blend a_, float* __restrict__ nn_weight, fl
     for (int k = 0; k < KMAX; k++) {
         if (k < K) {
             const int j = bi[k];
-            const float* tr = a.node_trans + 3 * (size_t)j;
+            const float* tr = a.node_trans + node_s3(a) * (size_t)j;
             if (a.local_frame) {                                  // R (x - node) + node + trans (:1209)
                 const NodeFrame F = node_frame_of(a, j);
                 const float* R = F.R;
@@ -371,10 +376,10 @@ node_blend_fwd_kernel(const gsr_node_blend a_, float* __restrict__ nn_weight, fl
 #pragma unroll
                 for (int c = 0; c < 3; c++) t[c] += w[k] * tr[c];  // :1213
             }
-            const float* qr = a.node_rot + 4 * (size_t)j;
+            const float* qr = a.node_rot + node_s4(a) * (size_t)j;
 #pragma unroll
             for (int c = 0; c < 4; c++) q[c] += w[k] * (qr[c] + ((!a.rot_as_residual && c == 0) ? 1.f : 0.f));
-            const float* sc = a.node_scale + 3 * (size_t)j;
+            const float* sc = a.node_scale + node_s3(a) * (size_t)j;
 #pragma unroll
             for (int c = 0; c < 3; c++) s[c] += w[k] * sc[c];
         }
@@ -700,9 +705,9 @@ node_blend_bwd_kernel(const gsr_node_blend a_, const float* __restrict__ nn_weig
                     for (int c = 0; c < NODE_GRAD; c++) crow[c] = 0.f;
                 }
                 if (blend) {
-                    const float* tr = a.node_trans + 3 * (size_t)j;
-                    const float* qr = a.node_rot + 4 * (size_t)j;
-                    const float* sc = a.node_scale + 3 * (size_t)j;
+                    const float* tr = a.node_trans + node_s3(a) * (size_t)j;
+                    const float* qr = a.node_rot + node_s4(a) * (size_t)j;
+                    const float* sc = a.node_scale + node_s3(a) * (size_t)j;
                     if (a.local_frame) {
                         const NodeFrame F = node_frame_of(a, j);
                         const float* R = F.R;
@@ -790,20 +795,22 @@ node_grad_finalize_kernel(const gsr_node_blend a_, const float* __restrict__ sum
     const int j = blockIdx.x * 256 + threadIdx.x;
     const gsr_node_blend a = batch_element(a_, (int)blockIdx.y);
     if (j >= a.m) return;
+    // (grad_stride != 0: the four attribute gradients are column ranges of one [B, m, grad_stride] matrix, like the attributes with attr_stride)
+    const size_t g3 = a.grad_stride ? (size_t)a.grad_stride : 3, g4 = a.grad_stride ? (size_t)a.grad_stride : 4;
     {   // every output is [B, m, .]: radius / weight gradients per batch element too (the caller sums them over B)
         const size_t b = blockIdx.y, m = (size_t)a.m;
         summed += b * batch_stride;
-        if (g_trans) g_trans += b * m * 3;
-        if (g_rot) g_rot += b * m * 4;
-        if (g_scale) g_scale += b * m * 3;
-        if (g_frame) g_frame += b * m * (a.node_local_rotation ? 4 : 9);
+        if (g_trans) g_trans += b * m * g3;
+        if (g_rot) g_rot += b * m * g4;
+        if (g_scale) g_scale += b * m * g3;
+        if (g_frame) g_frame += b * m * (a.node_local_rotation ? g4 : 9);
         if (g_radius) g_radius += b * m;
         if (g_weight) g_weight += b * m;
     }
     const float* s = summed + (size_t)j * NODE_GRAD;
-    if (g_trans) { g_trans[3 * j] = s[0]; g_trans[3 * j + 1] = s[1]; g_trans[3 * j + 2] = s[2]; }
-    if (g_rot) { g_rot[4 * j] = s[3]; g_rot[4 * j + 1] = s[4]; g_rot[4 * j + 2] = s[5]; g_rot[4 * j + 3] = s[6]; }
-    if (g_scale) { g_scale[3 * j] = s[7]; g_scale[3 * j + 1] = s[8]; g_scale[3 * j + 2] = s[9]; }
+    if (g_trans) { g_trans[g3 * j] = s[0]; g_trans[g3 * j + 1] = s[1]; g_trans[g3 * j + 2] = s[2]; }
+    if (g_rot) { g_rot[g4 * j] = s[3]; g_rot[g4 * j + 1] = s[4]; g_rot[g4 * j + 2] = s[5]; g_rot[g4 * j + 3] = s[6]; }
+    if (g_scale) { g_scale[g3 * j] = s[7]; g_scale[g3 * j + 1] = s[8]; g_scale[g3 * j + 2] = s[9]; }
     if (g_radius) g_radius[j] = (a.flags & GSR_NODE_RADIUS_IS_LOG) ? s[19] * expf(a.node_radius[j]) : s[19];       // d exp(v) = exp(v) dv
     if (g_weight && a.node_weight) {
         float g = s[20];
@@ -818,7 +825,7 @@ node_grad_finalize_kernel(const gsr_node_blend a_, const float* __restrict__ sum
         return;
     }
     // R = I + s A(q), s = 2 / |q|^2, A homogeneous quadratic (time_utils.py:115-133); q = local_rotation + (1,0,0,0)
-    const float* q = a.node_local_rotation + 4 * (size_t)j;
+    const float* q = a.node_local_rotation + node_s4(a) * (size_t)j;
     const float r = q[0] + 1.f, x = q[1], y = q[2], z = q[3];
     const float n2 = r * r + x * x + y * y + z * z, sc = 2.0f / n2;
     const float A[9] = {-(y * y + z * z), x * y - z * r, x * z + y * r, x * y + z * r, -(x * x + z * z), y * z - x * r,
@@ -831,10 +838,10 @@ node_grad_finalize_kernel(const gsr_node_blend a_, const float* __restrict__ sum
     const float dy = -2.f * y * Gm[0] + x * Gm[1] + r * Gm[2] + x * Gm[3] + z * Gm[5] - r * Gm[6] + z * Gm[7] - 2.f * y * Gm[8];
     const float dz = -2.f * z * Gm[0] - r * Gm[1] + x * Gm[2] + r * Gm[3] - 2.f * z * Gm[4] + y * Gm[5] + x * Gm[6] + y * Gm[7];
     const float k = -sc * sc * GA;                                    // d s / d q = -s^2 q
-    g_frame[4 * j] = sc * dr + k * r;
-    g_frame[4 * j + 1] = sc * dx + k * x;
-    g_frame[4 * j + 2] = sc * dy + k * y;
-    g_frame[4 * j + 3] = sc * dz + k * z;
+    g_frame[g4 * j] = sc * dr + k * r;
+    g_frame[g4 * j + 1] = sc * dx + k * x;
+    g_frame[g4 * j + 2] = sc * dy + k * y;
+    g_frame[g4 * j + 3] = sc * dz + k * z;
 }
 
 }  // namespace gsr

@@ -831,7 +831,7 @@ std::vector<torch::Tensor> node_blend_forward(const torch::Tensor& x, const c10:
                                               const c10::optional<torch::Tensor>& scale, const c10::optional<torch::Tensor>& local_rot, int64_t K,
                                               bool rot_as_residual, int64_t flags, int64_t stream)
 {
-    gsr_node_blend a;
+    gsr_node_blend a{};
     std::vector<torch::Tensor> keep;
     fill_blend(a, keep, x, mask, nodes, radius, weight, trans, rot, scale, local_rot, K, rot_as_residual, flags);
     auto fopt = x.options().dtype(torch::kFloat32);
@@ -853,7 +853,7 @@ std::vector<torch::Tensor> node_blend_backward(const torch::Tensor& x, const c10
                                                const torch::Tensor& idx, const c10::optional<torch::Tensor>& g_w, const c10::optional<torch::Tensor>& g_xyz,
                                                const c10::optional<torch::Tensor>& g_rot, const c10::optional<torch::Tensor>& g_scale, int64_t stream)
 {
-    gsr_node_blend a;
+    gsr_node_blend a{};
     std::vector<torch::Tensor> keep;
     fill_blend(a, keep, x, mask, nodes, radius, weight, trans, rot, scale, local_rot, K, rot_as_residual, flags);
     auto fopt = x.options().dtype(torch::kFloat32);

@@ -596,9 +596,14 @@ class ControlNodes(nn.Module):
             stacked = it["heads"] = {name: c for (name, _), c in list(zip(heads, cols))[1:]}
             if blend is not None and blend[0] is not None and blend[0].shape[0] > 0:
                 x, motion_mask = blend
-                out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, cols[0],
-                                                     stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
-                                                     K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
+                if self.local_frame and sum(widths) == 14 and os.environ.get("GSR_PACKED_BLEND", "1") != "0":
+                    # the heads' [n_full, M, 14] matrix as it is (gsr_node_blend.attr_stride): no copy per head, one gradient matrix back
+                    out = control_nodes.node_blend_batch_packed(x, motion_mask, self.nodes, self._node_radius, self._node_weight, full,
+                                                                K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
+                else:
+                    out = control_nodes.node_blend_batch(x, motion_mask, self.nodes, self._node_radius, self._node_weight, cols[0],
+                                                         stacked["d_rotation"], stacked["d_scaling"], stacked.get("local_rotation") if self.local_frame else None,
+                                                         K=min(self.K, self.node_num), d_rot_as_res=self.d_rot_as_res, raw=True)
                 it["blended"] = [t.unbind(0) for t in out]
                 it["blended_stacked"] = out                    # (d_xyz, d_rotation, d_scaling), each [n_full, n, .]: control_nodes.fan_out's input
         self._batch, self._blended, self._graph = {}, None, None       # ("inside an iteration": _elastic_neighbours keeps its graph until end_iteration)

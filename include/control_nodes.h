@@ -55,6 +55,11 @@ typedef struct gsr_node_blend {
     const float* node_frame;      /* [m, 9]   quaternion_to_matrix(node_attrs['local_rotation'] + (1,0,0,0)), row-major; local_frame only */
     const float* node_local_rotation; /* [m, 4] node_attrs['local_rotation'] itself (:1207): when not NULL it replaces node_frame -- the bias and
                                      quaternion_to_matrix (:115-133) are applied in the kernels, and backward returns the quaternion's gradient */
+    int32_t attr_stride;          /* 0: node_trans / node_rot / node_scale / node_local_rotation are packed [m, 3 | 4] arrays. Otherwise the floats between
+                                     two nodes' rows of ALL four: they are column ranges of one [m, attr_stride] matrix -- the node network's heads
+                                     as one linear layer produces them, [d_xyz | d_rotation | d_scaling | local_rotation] (no copies); batches
+                                     are [B, m, attr_stride]. node_frame must be NULL then. */
+    int32_t grad_stride;          /* the same for the four attribute gradients of the backward calls (0: packed) */
 } gsr_node_blend;
 
 /* Forward.  nn_weight / nn_dist [n, K] fp32 and nn_idx [n, K] int64 are the three results of cal_nn_weight (:981-1011) and are

@@ -344,3 +344,31 @@ def test_fan_out_rows_for_several_readers():
     assert float(got[0][2].abs().max()) == 0 and float(got[2][1].abs().max()) == 0        # rows without readers
     again = torch.autograd.grad(loss_of(cn.fan_out(stacked, plan)), stacked)
     assert all(torch.equal(x, y) for x, y in zip(got, again))
+
+
+def test_node_blend_batch_packed_equals_the_per_attribute_call():
+    """control_nodes.node_blend_batch_packed: the four node attributes as column ranges of one [B, M, 14] matrix (gsr_node_blend.attr_stride /
+    grad_stride) -- bit-identical values and gradients to node_blend_batch on the four copies."""
+    g = torch.Generator(device="cpu").manual_seed(8)
+    n, m, B = 3000, 300, 5
+    x = (torch.rand((n, 3), generator=g) - 0.5).to(DEV)
+    mask = (torch.rand((n,), generator=g) > 0.2).float().to(DEV)
+    nodes = (torch.rand((m, 3), generator=g) - 0.5).to(DEV)
+    radius = (torch.randn((m,), generator=g) * 0.1 - 2.0).to(DEV).requires_grad_(True)
+    weight = torch.randn((m, 1), generator=g).to(DEV).requires_grad_(True)
+    attrs = (torch.randn((B, m, 14), generator=g) * 0.05).to(DEV).requires_grad_(True)
+    cots = [torch.randn((B, n, c), generator=g).to(DEV) for c in (3, 4, 3)]
+
+    def run(packed):
+        if packed:
+            out = cn.node_blend_batch_packed(x, mask, nodes, radius, weight, attrs, K=3)
+        else:
+            t, r, s, l = attrs.split([3, 4, 3, 4], -1)
+            out = cn.node_blend_batch(x, mask, nodes, radius, weight, t, r, s, l, K=3)
+        grads = torch.autograd.grad(out, (attrs, radius, weight), cots)
+        return [o.detach() for o in out], grads
+
+    (o1, g1), (o2, g2) = run(True), run(False)
+    assert all(torch.equal(a, b) for a, b in zip(o1, o2))
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert float(g1[0].abs().sum()) > 0
