@@ -133,6 +133,25 @@ def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     cl.gsr_adam_coefficients(0.01, 0.9, 0.999, 3, out2)
     assert abs(out2[0] - 0.01 / (1 - 0.9 ** 3)) < 1e-8 and abs(out2[1] - (1 - 0.999 ** 3) ** -0.5) < 1e-4
     assert cl.gsr_forward_status_views(None) == 0
+    # round 5: strided node attributes, several small sums in one launch, the dense layers' masked input gradient / batched split, Adam with
+    # device-side step counts
+    blend = control_nodes._Blend(n=4, m=8, K=3, node_stride=3, x=4096, nodes=4096, node_radius=4096, attr_stride=2)
+    assert cl.gsr_node_blend_forward(ctypes.byref(blend), None, None, None, None, None, None, None) == -1 and b"attr_stride" in lib.gsr_last_error()
+    assert cl.gsr_multi_add(65, None, None) == -1 and b"gsr_multi_add" in lib.gsr_last_error()
+    assert cl.gsr_multi_add(0, None, None) == 0
+    assert cl.gsr_multi_add(2, None, None) == -1
+    import dense_layers
+    dn = dense_layers._lib()
+    assert dn.gsr_dense_split_many(25, None, None) == -1 and b"gsr_dense_split_many" in lib.gsr_last_error()
+    assert dn.gsr_dense_split_many(0, None, None) == 0
+    assert dn.gsr_dense_backward_input(10, 256, 256, None, 256, None, None, 0, None, 256, None, None, None) == -1 and b"gsr_dense_backward_input" in lib.gsr_last_error()
+    assert dn.gsr_dense_backward_input_workspace_size(33280, 256) >= (33280 // 32) * 256 * 4
+    assert dn.gsr_dense_forward(10, 256, 256, None, 256, None, 0, None, None, 0, None, 256, None) == -1
+    import fused_adam
+    fa = fused_adam._lib()
+    assert fa.gsr_adam_step_device_count(33, None, None, None, None) == -1 and b"gsr_adam_step_device_count" in lib.gsr_last_error()
+    assert fa.gsr_adam_step_device_count(1, None, None, None, None) == -1
+    assert fa.gsr_adam_step_device_count(0, None, None, None, None) == 0
 
 
 def test_public_names_and_settings_fields_match_reference():
