@@ -1808,6 +1808,9 @@ static int dense_forward_launch(const char* who, int M, int N, int K, const floa
     if (wide_ok && vec_out && N % DENSE8_BN == 0) {
         const int bt8 = forced_bt >= 2 && forced_bt <= DENSE_MAX_BT ? forced_bt : dense8_row_tiles(M, N / DENSE8_BN);
         const dim3 grid8((unsigned)((M + 16 * bt8 - 1) / (16 * bt8)), (unsigned)(N / DENSE8_BN));
+        Dense8Layer L;
+        L.X = X; L.gate = gate; L.planes = reinterpret_cast<const unsigned short*>(planes); L.bias = bias; L.Y = Y; L.mask = mask; L.colsum = partial;
+        L.N = N; L.K = K; L.ldx = ldx; L.ldgate = ldgate; L.Npad = Npad; L.Kpad = Kpad; L.relu = relu ? 1 : 0; L.ldy = ldy; L.vec = vec ? 1 : 0; L.ldmask = ldmask;
         static bool attr_set[DENSE_MAX_BT + 1] = {};
 #define GSR_DENSE8_LAUNCH(BT)                                                                                                                          \
         case BT:                                                                                                                                       \
@@ -1816,9 +1819,7 @@ static int dense_forward_launch(const char* who, int M, int N, int K, const floa
                                                   DENSE8_LDS_BYTES));                                                                                  \
                 attr_set[BT] = true;                                                                                                                   \
             }                                                                                                                                          \
-            hipLaunchKernelGGL(dense_fwd8_kernel<BT>, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, N, K, X, ldx, gate, ldgate,            \
-                               reinterpret_cast<const unsigned short*>(planes), Npad, Kpad, bias, relu ? 1 : 0, Y, ldy, vec ? 1 : 0, mask, ldmask,      \
-                               partial);                                                                                                               \
+            hipLaunchKernelGGL(dense_fwd8_kernel<BT>, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, L);                                    \
             break;
         switch (bt8) {
             GSR_DENSE8_LAUNCH(2) GSR_DENSE8_LAUNCH(3) GSR_DENSE8_LAUNCH(4) GSR_DENSE8_LAUNCH(5) GSR_DENSE8_LAUNCH(6) GSR_DENSE8_LAUNCH(7)
@@ -1854,6 +1855,69 @@ int gsr_dense_backward_input(int M, int N, int K, const float* G, int ldg, const
                              float* dbias, char* workspace, void* stream_)
 {
     return dense_forward_launch("gsr_dense_backward_input", M, N, K, G, ldg, nullptr, 0, planes_t, nullptr, 0, dX, lddx, mask, ldmask, dbias, workspace, stream_);
+}
+
+size_t gsr_dense_chain_workspace_size(int M, int N, int count)
+{
+    if (M < 1 || N < 1 || count < 1) return 256;
+    return (size_t)count * ((size_t)((M + 31) / 32) * (size_t)N * sizeof(float) + 256) + 256;
+}
+
+int gsr_dense_chain(int M, int N, int count, const gsr_dense_chain_op* ops, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M < 0 || N < 1 || N != DENSE8_BN || count < 1 || count > DENSE8_CHAIN_MAX || !ops) {
+        g_last_error = "gsr_dense_chain: 1..8 products of 256 output columns each"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    bool sums = false;
+    for (int l = 0; l < count; l++) {
+        const gsr_dense_chain_op& q = ops[l];
+        const bool aligned = (q.ldx % 4 == 0) && (q.ldy % 4 == 0) && !(reinterpret_cast<uintptr_t>(q.X) % 16) && !(reinterpret_cast<uintptr_t>(q.Y) % 16) &&
+                             (!q.bias || !(reinterpret_cast<uintptr_t>(q.bias) % 16)) && (!q.mask || ((q.ldmask % 4 == 0) && !(reinterpret_cast<uintptr_t>(q.mask) % 16)));
+        if (q.K < 1 || !q.planes || (M > 0 && (!q.X || !q.Y)) || q.ldx < q.K || q.ldy < N || (q.mask && q.ldmask < N) || !aligned) {
+            g_last_error = "gsr_dense_chain: invalid product (16-byte aligned rows of X / Y / mask, ldx >= K, ldy >= 256)"; return GSR_ERR_INVALID_ARGUMENT;
+        }
+        sums = sums || q.dbias;
+    }
+    if (sums && (!workspace || (reinterpret_cast<uintptr_t>(workspace) % 16))) { g_last_error = "gsr_dense_chain: the bias gradients need a 16-byte aligned workspace"; return GSR_ERR_INVALID_ARGUMENT; }
+    if (M == 0) {
+        for (int l = 0; l < count; l++) if (ops[l].dbias) GSR_HIP_CHECK(hipMemsetAsync(ops[l].dbias, 0, (size_t)N * sizeof(float), stream));
+        return 0;
+    }
+    static const int forced_bt = getenv("GSR_DENSE_ROW_TILES") ? atoi(getenv("GSR_DENSE_ROW_TILES")) : 0;
+    const int bt = forced_bt >= 2 && forced_bt <= DENSE_MAX_BT ? forced_bt : dense8_row_tiles(M, 1);
+    const unsigned blocks = (unsigned)((M + 16 * bt - 1) / (16 * bt));
+    const size_t per_op = ((size_t)((M + 31) / 32) * (size_t)N * sizeof(float) + 255) & ~size_t(255);
+    Dense8Chain c;
+    c.M = M; c.count = count;
+    float* partial[DENSE8_CHAIN_MAX];
+    for (int l = 0; l < count; l++) {
+        const gsr_dense_chain_op& q = ops[l];
+        Dense8Layer& L = c.layer[l];
+        partial[l] = q.dbias ? reinterpret_cast<float*>(workspace + (size_t)l * per_op) : nullptr;
+        L.X = q.X; L.gate = nullptr; L.planes = reinterpret_cast<const unsigned short*>(q.planes); L.bias = q.bias; L.Y = q.Y; L.mask = q.mask; L.colsum = partial[l];
+        L.N = N; L.K = q.K; L.ldx = q.ldx; L.ldgate = 0; L.Npad = round_up_int(N, DENSE_BN); L.Kpad = round_up_int(q.K, DENSE_BK); L.relu = q.relu ? 1 : 0;
+        L.ldy = q.ldy; L.vec = 1; L.ldmask = q.ldmask;
+    }
+    static bool attr_set[DENSE_MAX_BT + 1] = {};
+#define GSR_CHAIN8_LAUNCH(BT)                                                                                                                          \
+    case BT:                                                                                                                                           \
+        if (!attr_set[BT]) {                                                                                                                           \
+            GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain8_kernel<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                              DENSE8_LDS_BYTES));                                                                                      \
+            attr_set[BT] = true;                                                                                                                       \
+        }                                                                                                                                              \
+        hipLaunchKernelGGL(dense_chain8_kernel<BT>, dim3(blocks), dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, c);                                  \
+        break;
+    switch (bt) {
+        GSR_CHAIN8_LAUNCH(2) GSR_CHAIN8_LAUNCH(3) GSR_CHAIN8_LAUNCH(4) GSR_CHAIN8_LAUNCH(5) GSR_CHAIN8_LAUNCH(6) GSR_CHAIN8_LAUNCH(7)
+        GSR_CHAIN8_LAUNCH(8) GSR_CHAIN8_LAUNCH(9) GSR_CHAIN8_LAUNCH(10)
+    }
+#undef GSR_CHAIN8_LAUNCH
+    for (int l = 0; l < count; l++)
+        if (ops[l].dbias) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, stream, (int)blocks, N, (const float*)partial[l], ops[l].dbias);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int gsr_dense_split_many(int count, const gsr_dense_split_item* items, void* stream_)

@@ -331,14 +331,18 @@ dense_fwd_kernel(const int M, const int N, const int K, const float* __restrict_
 constexpr int DENSE8_THREADS = 512, DENSE8_BN = 256;
 constexpr int DENSE8_STAGE_A = 3 * 16 * DENSE_MAX_BT * DENSE_ROW_B, DENSE8_STAGE_B = 3 * DENSE8_BN * DENSE_ROW_B;       // 30 720 + 49 152 bytes
 constexpr int DENSE8_LDS_BYTES = 2 * (DENSE8_STAGE_A + DENSE8_STAGE_B);                                                // 159 744 of 163 840
+// one product of the kernel below (and of dense_chain8_kernel: several in a row on the same rows)
+struct Dense8Layer {
+    const float* X; const float* gate; const unsigned short* planes; const float* bias; float* Y; const float* mask; float* colsum;
+    int N, K, ldx, ldgate, Npad, Kpad, relu, ldy, vec, ldmask;
+};
+
 template <int BT>
-__global__ void __launch_bounds__(DENSE8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict__ X, const int ldx, const float* __restrict__ gate, const int ldgate,
-                  const unsigned short* __restrict__ planes, const int Npad, const int Kpad, const float* __restrict__ bias, const int relu,
-                  float* __restrict__ Y, const int ldy, const int vec,
-                  const float* __restrict__ mask, const int ldmask, float* __restrict__ colsum)
+__device__ __forceinline__ void dense8_layer(const int M, const Dense8Layer& L, unsigned char* s_dense8)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dense8[];
+    const int N = L.N, K = L.K, ldx = L.ldx, ldgate = L.ldgate, Npad = L.Npad, Kpad = L.Kpad, relu = L.relu, ldy = L.ldy, vec = L.vec, ldmask = L.ldmask;
+    const float* __restrict__ X = L.X; const float* __restrict__ gate = L.gate; const unsigned short* __restrict__ planes = L.planes;
+    const float* __restrict__ bias = L.bias; float* __restrict__ Y = L.Y; const float* __restrict__ mask = L.mask; float* __restrict__ colsum = L.colsum;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int rows_a = 16 * BT;
     const int m0 = blockIdx.x * rows_a, n0 = blockIdx.y * DENSE8_BN;
@@ -499,6 +503,36 @@ dense_fwd8_kernel(const int M, const int N, const int K, const float* __restrict
             }
             if (fi == 0) *reinterpret_cast<float4*>(colsum + (size_t)blockIdx.x * N + n0 + wn + 16 * j + 4 * fq) = cs[j];
         }
+    }
+}
+
+template <int BT>
+__global__ void __launch_bounds__(DENSE8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dense_fwd8_kernel(const int M, const Dense8Layer L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dense8_single[];
+    dense8_layer<BT>(M, L, s_dense8_single);
+}
+
+// Several products in a row on the SAME rows in one launch: product l + 1 reads what product l wrote (a layer's output is the next layer's
+// input; an input gradient is the next input-gradient product's cotangent). A block owns its 16 BT rows through all of them -- rows are
+// independent, so nothing is exchanged between blocks; its own stores become visible to its own loads through the block barrier between two
+// products (the addresses were never read before in this launch: no stale line in the CU's cache). Against one launch per product this
+// saves, per boundary, the launch gap, the wait for EVERY block's output stores before any block may start, and most of the first fetch:
+// the node network's forward is seven boundaries, its input-gradient chain six.
+constexpr int DENSE8_CHAIN_MAX = 8;
+struct Dense8Chain { int M, count; Dense8Layer layer[DENSE8_CHAIN_MAX]; };
+template <int BT>
+__global__ void __launch_bounds__(DENSE8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dense_chain8_kernel(const Dense8Chain c)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dense8_chain[];
+    for (int l = 0; l < c.count; l++) {
+        dense8_layer<BT>(c.M, c.layer[l], s_dense8_chain);
+        // this block's stores of product l are visible to ITS OWN waves after the block barrier (the programming model's guarantee; the CU's
+        // cache is write-through) before any of them fetches them as product l + 1's operand -- and the LDS stages are free. (A device-scope
+        // fence here is an L2 write-back per block and boundary on this multi-XCD part: measured 86 us per product instead of 36.)
+        if (l + 1 < c.count) __syncthreads();
     }
 }
 

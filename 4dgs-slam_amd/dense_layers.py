@@ -27,6 +27,11 @@ class _Trunk(C.Structure):          # gsr_trunk
     _fields_ = [("E", C.c_int32), ("n_head_outputs", C.c_int32), ("planes", C.c_void_p * 10), ("bias", C.c_void_p * 9)]
 
 
+class _ChainOp(C.Structure):         # gsr_dense_chain_op
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int32), ("K", C.c_int32), ("planes", C.c_void_p), ("bias", C.c_void_p), ("relu", C.c_int32),
+                ("Y", C.c_void_p), ("ldy", C.c_int32), ("mask", C.c_void_p), ("ldmask", C.c_int32), ("dbias", C.c_void_p)]
+
+
 class _SplitItem(C.Structure):      # gsr_dense_split_item
     _fields_ = [("W", C.c_void_p), ("planes", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32), ("k0", C.c_int32), ("transposed", C.c_int32)]
 
@@ -50,6 +55,10 @@ def _lib():
         lib.gsr_dense_backward_input_workspace_size.argtypes = [i, i]
         lib.gsr_dense_backward_input.restype = i
         lib.gsr_dense_backward_input.argtypes = [i, i, i, vp, i, vp, vp, i, vp, i, vp, vp, vp]
+        lib.gsr_dense_chain_workspace_size.restype = C.c_size_t
+        lib.gsr_dense_chain_workspace_size.argtypes = [i, i, i]
+        lib.gsr_dense_chain.restype = i
+        lib.gsr_dense_chain.argtypes = [i, i, i, C.POINTER(_ChainOp), vp, vp]
         lib.gsr_dense_split_many.restype = i
         lib.gsr_dense_split_many.argtypes = [i, C.POINTER(_SplitItem), vp]
         lib.gsr_trunk_forward.restype = i
@@ -158,6 +167,42 @@ def dense_backward_input(G, planes_t, N, K, mask=None, want_bias=True, out=None)
     if rc < 0:
         _C._err(lib, rc, "gsr_dense_backward_input")
     return out, dbias
+
+
+CHAIN_MAX, CHAIN_WIDTH = 8, 256
+
+
+def dense_chain(ops):
+    """Up to eight products of 256 output columns in a row on the same rows, in ONE launch (gsr_dense_chain): ops = [dict(X=, planes=, K=,
+    bias=None, relu=False, Y=, mask=None, dbias=None)], op l + 1 usually reading op l's Y. X / Y / mask: fp32 [M, .] device tensors (column
+    ranges of wider matrices allowed), dbias: fp32 [256] tensors that receive the column sums of Y. Returns nothing (the ops' Y / dbias are
+    written)."""
+    if not 1 <= len(ops) <= CHAIN_MAX:
+        raise ValueError(f"dense_chain: 1..{CHAIN_MAX} products")
+    M = int(ops[0]["X"].shape[0])
+    dev = ops[0]["X"].device
+    arr = (_ChainOp * len(ops))()
+    ld = lambda t: int(t.stride(0)) if M > 1 else int(t.shape[1])
+    want_ws = False
+    for o, q in zip(arr, ops):
+        X, Y = _rows(q["X"], "X"), _rows(q["Y"], "Y")
+        if int(X.shape[0]) != M or int(Y.shape[0]) != M or int(Y.shape[1]) != CHAIN_WIDTH or int(X.shape[1]) < int(q["K"]):
+            raise ValueError("dense_chain: every product maps [M, >= K] to [M, 256]")
+        o.X, o.ldx, o.K, o.planes = X.data_ptr(), ld(X), int(q["K"]), q["planes"].data_ptr()
+        bias, mask, dbias = q.get("bias"), q.get("mask"), q.get("dbias")
+        o.bias, o.relu = (None if bias is None else bias.data_ptr()), (1 if q.get("relu") else 0)
+        o.Y, o.ldy = Y.data_ptr(), ld(Y)
+        if mask is not None:
+            mask = _rows(mask, "mask")
+        o.mask, o.ldmask = (None if mask is None else mask.data_ptr()), (0 if mask is None else ld(mask))
+        o.dbias = None if dbias is None else dbias.data_ptr()
+        want_ws = want_ws or dbias is not None
+    lib = _lib()
+    ws = torch.empty((int(lib.gsr_dense_chain_workspace_size(M, CHAIN_WIDTH, len(ops))),), dtype=torch.uint8, device=dev) if want_ws else None
+    with torch.cuda.device(dev):
+        rc = lib.gsr_dense_chain(M, CHAIN_WIDTH, len(ops), arr, None if ws is None else ws.data_ptr(), _C._stream(dev))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_chain")
 
 
 def dense_wgrad(G, X, gate=None, out=None):

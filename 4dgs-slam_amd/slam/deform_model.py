@@ -274,6 +274,9 @@ LAYER_FUSED_TRUNK = os.environ.get("GSR_LAYER_FUSED_TRUNK", "0") == "1"
 # backward's ReLU mask + bias gradient ride in the input-gradient product's epilogue (no separate pass over the rows). GSR_DENSE_TRUNK=0: the
 # library path.
 DENSE_TRUNK = os.environ.get("GSR_DENSE_TRUNK", "1") == "1"
+# ... and the eight layers (and the seven input-gradient products on the way back) as ONE launch each (gsr_dense_chain: a block carries its rows
+# through all layers). GSR_DENSE_CHAIN=0: one launch per product.
+DENSE_CHAIN = os.environ.get("GSR_DENSE_CHAIN", "1") == "1"
 
 
 def _dense_trunk_ok(emb, Ws, W_heads, skip):
@@ -321,11 +324,19 @@ class _FusedTrunk(torch.autograd.Function):
             cat = emb.new_empty((R, E + Wd))                 # (:447-448: [emb | h], the input of layer skip + 1; layer skip writes its half)
             cat[:, :E] = emb
             inputs, outs, h = [], [], emb
+            chained = DENSE_CHAIN and Wd == dense_layers.CHAIN_WIDTH and D <= dense_layers.CHAIN_MAX
+            ops = []
             for i in range(D):
                 inputs.append(h)
-                y = dense_layers.dense_forward(h, views[i], Wd, int(Ws[i].shape[1]), params[2 * i + 1].detach(), relu=True, out=cat[:, E:] if i == skip else None)
+                y = cat[:, E:] if i == skip else emb.new_empty((R, Wd))
+                if chained:
+                    ops.append(dict(X=h, planes=views[i], K=int(Ws[i].shape[1]), bias=params[2 * i + 1].detach(), relu=True, Y=y))
+                else:
+                    dense_layers.dense_forward(h, views[i], Wd, int(Ws[i].shape[1]), params[2 * i + 1].detach(), relu=True, out=y)
                 outs.append(y)
                 h = cat if i == skip else y
+            if chained:
+                dense_layers.dense_chain(ops)
             out = torch.addmm(b_heads, h, W_heads.t())
             ctx.planes_t = views[D:]
             ctx.skip, ctx.D, ctx.E = skip, D, E
@@ -362,14 +373,32 @@ class _FusedTrunk(torch.autograd.Function):
         buf = g_out.new_empty((len(same), groups) + tuple(Ws[D - 1].shape)) if len(same) > 1 else None
         planes_t = ctx.planes_t
         G = db = None
+        chain_G = None
+        if planes_t is not None and DENSE_CHAIN and D - 1 <= 8 and int(Ws[0].shape[0]) == 256:
+            # all input-gradient products first, as ONE launch (each hands its result to the ReLU of the layer below and sums that layer's bias
+            # gradient), then the weight gradients from the G's they left
+            import dense_layers
+            Wd = int(Ws[0].shape[0])
+            G, db = control_nodes.relu_backward_bias(g, outs[D - 1])
+            chain_G, chain_db = [None] * D, [None] * D
+            chain_G[D - 1], chain_db[D - 1] = G, db
+            ops = []
+            for i in range(D - 1, 0, -1):
+                chain_G[i - 1], chain_db[i - 1] = G.new_empty((R, Wd)), G.new_empty((Wd,))
+                ops.append(dict(X=chain_G[i], planes=planes_t[i - 1], K=Wd, Y=chain_G[i - 1], mask=outs[i - 1], dbias=chain_db[i - 1]))
+            dense_layers.dense_chain(ops)
         for i in reversed(range(D)):
-            if planes_t is None or i == D - 1:
+            if chain_G is not None:
+                G, db = chain_G[i], chain_db[i]
+            elif planes_t is None or i == D - 1:
                 G, db = control_nodes.relu_backward_bias(g, outs[i])
             if buf is not None and i in same:
                 torch.bmm(G.view(groups, R // groups, -1).transpose(1, 2), inputs[i].view(groups, R // groups, -1), out=buf[same.index(i)])
             else:
                 grads[2 * i] = _grad_weight(G, inputs[i])
             grads[2 * i + 1] = db
+            if chain_G is not None:
+                continue
             if i > 0 and planes_t is not None:
                 # the layer below's G and bias gradient straight from this layer's input-gradient product (mask and column sums in its epilogue)
                 import dense_layers

@@ -43,6 +43,23 @@ size_t gsr_dense_backward_input_workspace_size(int M, int N);
 int gsr_dense_backward_input(int M, int N, int K, const float* G, int ldg, const void* planes_t, const float* mask, int ldmask, float* dX, int lddx,
                              float* dbias, char* workspace, void* stream);
 
+/* Several products of 256 output columns in a row on the SAME rows, in ONE launch: op l + 1 reads what op l wrote -- the node network's forward
+ * (X = the previous layer's output, relu, bias) or its input-gradient chain (X = the previous op's dX, planes = the layer's transposed planes,
+ * mask = the layer below's output, dbias = that layer's bias gradient). Each op is  Y [M, 256] = act(X [M, K] Wt + bias) * (mask > 0)  with
+ * dbias [256] = column sums of Y when not NULL. A block of the launch owns its rows through all ops (rows are independent); no operand may be
+ * written by a LATER op of the same call. All row pointers 16-byte aligned, ld* % 4 == 0. At most 8 ops. Against one launch per product this
+ * saves the launch gap, the wait for every block's output stores, and most of the first operand fetch per boundary.
+ * workspace: gsr_dense_chain_workspace_size(M, 256, count) bytes (only read when some op has dbias). */
+typedef struct gsr_dense_chain_op {
+    const float* X; int32_t ldx; int32_t K;
+    const void* planes; const float* bias; int32_t relu;
+    float* Y; int32_t ldy;
+    const float* mask; int32_t ldmask;
+    float* dbias;
+} gsr_dense_chain_op;
+size_t gsr_dense_chain_workspace_size(int M, int N, int count);
+int gsr_dense_chain(int M, int N, int count, const gsr_dense_chain_op* ops, char* workspace, void* stream);
+
 /* Several weights split in ONE launch (a network's layers in both orientations, once per optimizer step): at most 24 items, each with the
  * arguments of gsr_dense_split. */
 typedef struct gsr_dense_split_item {

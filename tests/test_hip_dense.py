@@ -181,7 +181,42 @@ def test_split_weights_in_one_launch_equal_the_single_splits():
         dl.split_weights([(Ws[0], 0, None, False)] * 25)
 
 
-def test_node_network_on_the_dense_layers_matches_the_library_path(monkeypatch):
+def test_dense_chain_equals_the_separate_launches():
+    """gsr_dense_chain: eight products in one launch, each reading its predecessor's output (with bias + ReLU: the network's forward; with a
+    mask and column sums: its input-gradient chain) -- bit-identical to one launch per product, at row counts with a ragged last block."""
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for M in (1, 700, 33280):
+        X0 = torch.randn((M, 84), generator=g).to(DEV)
+        Ws = [(torch.randn((256, 84 if i == 0 else 256), generator=g) / 12).to(DEV) for i in range(8)]
+        bs = [torch.randn((256,), generator=g).to(DEV) for _ in range(8)]
+        planes = [dl.split_weight(w) for w in Ws]
+        planes_t = [dl.split_weight(w, transposed=True) for w in Ws[1:]]
+        ys = [torch.empty((M, 256), device=DEV) for _ in range(8)]
+        dl.dense_chain([dict(X=X0 if i == 0 else ys[i - 1], planes=planes[i], K=int(Ws[i].shape[1]), bias=bs[i], relu=True, Y=ys[i]) for i in range(8)])
+        h = X0
+        for i in range(8):
+            h = dl.dense_forward(h, planes[i], 256, int(Ws[i].shape[1]), bs[i], relu=True)
+            assert torch.equal(ys[i], h), (M, i)
+        # the way back: G_{i-1} = (G_i W_i) [y_{i-1} > 0], db_{i-1} = column sums
+        G7 = torch.randn((M, 256), generator=g).to(DEV)
+        Gs = [torch.empty((M, 256), device=DEV) for _ in range(7)]
+        dbs = [torch.empty((256,), device=DEV) for _ in range(7)]
+        ops, src = [], G7
+        for i in range(7, 0, -1):
+            ops.append(dict(X=src, planes=planes_t[i - 1], K=256, Y=Gs[i - 1], mask=ys[i - 1], dbias=dbs[i - 1]))
+            src = Gs[i - 1]
+        dl.dense_chain(ops)
+        src = G7
+        for i in range(7, 0, -1):
+            want, wdb = dl.dense_backward_input(src, planes_t[i - 1], 256, 256, mask=ys[i - 1])
+            assert torch.equal(Gs[i - 1], want) and torch.equal(dbs[i - 1], wdb), (M, i)
+            src = want
+    with pytest.raises(ValueError):
+        dl.dense_chain([])
+
+
+@pytest.mark.parametrize("chain", [True, False])
+def test_node_network_on_the_dense_layers_matches_the_library_path(monkeypatch, chain):
     """The default trunk (slam.deform_model.DENSE_TRUNK: per-layer products on the bf16 matrix cores, mask + bias gradient in the
     input-gradient product's epilogue) against the library path (GSR_DENSE_TRUNK=0): heads to fp32-GEMM accuracy, parameter gradients up to the
     ReLU-mask flips of pre-activations within rounding of zero; and bit-reproducible from call to call."""
@@ -197,6 +232,8 @@ def test_node_network_on_the_dense_layers_matches_the_library_path(monkeypatch):
     emb = torch.cat([dm._embed(x, net.multires), dm._embed(t, net.t_multires)], -1)
     cot = torch.randn((R, 14), device=DEV)
     monkeypatch.setattr(dm, "LAYER_FUSED_TRUNK", False)
+
+    monkeypatch.setattr(dm, "DENSE_CHAIN", chain)
 
     def run(dense):
         monkeypatch.setattr(dm, "DENSE_TRUNK", dense)
