@@ -20,6 +20,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/gs_rasterizer.h"
 #include "../../include/simple_knn.h"
@@ -50,6 +51,21 @@ static thread_local std::string g_last_error;
             return GSR_ERR_HIP;                                                                          \
         }                                                                                                \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: `done` holds one bit per device ordinal, so a process
+// that drives several GPUs sets it on each of them (a process-wide flag left the second device at the 64 KB default and the 156 KB launch
+// failed there); atomic: the entry points may be called from several host threads.
+static int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done)
+{
+    int dev = 0;
+    GSR_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        GSR_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return 0;
+}
 
 static size_t binning_bytes(size_t carve_R, size_t cap_sorted, size_t ntiles)
 {
@@ -163,6 +179,10 @@ static inline size_t spec_capacity(size_t last)
 static thread_local bool t_options_read = false;
 static thread_local unsigned t_views_batched = 0;
 static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] != '0' : true;   // sort short tile lists inside render_fwd
+// render_bwd's work items: full pieces in tile order, then the partial pieces longest first at the end of every XCD's sequence (gs_device.h:
+// item_block_*; one extra block of the scatter launch ranks them). GSR_ORDER_ITEMS=0: tile order, as rounds 2-5 (A/B runs; the results are
+// bit-identical either way)
+static bool t_order_items = getenv("GSR_ORDER_ITEMS") ? getenv("GSR_ORDER_ITEMS")[0] != '0' : true;
 static void read_option_env()
 {
     if (t_options_read) return;
@@ -259,8 +279,8 @@ int gsr_set_option(const char* name, int value)
         if (value >= 0) t_cap_test_shrink_permille = value > 1000 ? 1000 : value;
         return old_shrink;
     }
-    bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : nullptr;
-    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, cap_margin_permille, cap_tile_margin_permille, cap_floor, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
+    bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : n == "order_items" ? &t_order_items : nullptr;
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, order_items, cap_margin_permille, cap_tile_margin_permille, cap_floor, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;
@@ -492,10 +512,11 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
-            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks + (t_order_items ? 1 : 0)), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
-                               (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr);
+                               (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr,
+                               t_order_items ? img.tile_count : (uint32_t*)nullptr);
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here
@@ -535,7 +556,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.rec,
                                background, img.final_T, img.n_contrib, out_color, out_depth,
                                out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
-                               (const uint32_t*)bin.inst_gauss, bin.sorted, (const uint32_t*)img.chunk_base, bin.chunk_info);
+                               (const uint32_t*)bin.inst_gauss, bin.sorted, (const uint32_t*)img.chunk_base, bin.chunk_info,
+                               t_order_items ? (const uint32_t*)img.tile_count : (const uint32_t*)nullptr);
         }
         GSR_STAGE("render_fwd");
         return 0;
@@ -573,7 +595,8 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
                            geom.rec, background, img.final_T, img.n_contrib, out_color,
                            out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
-                           (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr);
+                           (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr,
+                           (const uint32_t*)nullptr);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -738,7 +761,8 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     }
     {
         ScopedKernelTimer tm(K_SCATTER, stream);
-        hipLaunchKernelGGL(scatter_views_kernel, gv, dim3(GB), hist_lds_bytes, stream, t, d, a.eager);
+        hipLaunchKernelGGL(scatter_views_kernel, dim3((unsigned)d.nblocks + (t_order_items ? 1u : 0u), (unsigned)V), dim3(GB), hist_lds_bytes, stream, t, d, a.eager,
+                           t_order_items ? 1 : 0);
     }
     if (!t_fuse_sort || cap_tile > (uint32_t)SORT_SMALL_CAP) {
         ScopedKernelTimer tm(K_SORT, stream);
@@ -755,7 +779,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     }
     {
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
-        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0);
+        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0, t_order_items ? 1 : 0);
     }
     GSR_HIP_CHECK(hipGetLastError());
     // one wait per view (they are all long done by the time the host has enqueued the tile kernels); a view that outgrew its capacity is
@@ -825,8 +849,9 @@ extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, c
     }
     {
         ScopedKernelTimer tm(K_RENDER_BWD, stream);
-        if (max_R > 0)
+        if (max_R > 0) {
             hipLaunchKernelGGL(render_bwd_views_kernel, dim3((unsigned)(max_R / CHUNK + d.T), (unsigned)V), dim3(RB), 0, stream, t, d, background);
+        }
     }
     GeomBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -1005,6 +1030,16 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                               dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dtau, nullptr, debug, stream);
 }
 
+#if GSR_TIMELINE
+// dev builds only (-DGSR_TIMELINE=1): {start, end (100 MHz ticks), HW_ID, XCC_ID} of every block of the last render_fwd (which = 0, by tile) /
+// render_bwd (which = 1, by block) launch
+int gsr_debug_spans(unsigned int* out, int nwords, int which)
+{
+    GSR_HIP_CHECK(hipDeviceSynchronize());
+    GSR_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spans), (size_t)nwords * sizeof(uint32_t), (size_t)which * 8192 * 4 * sizeof(uint32_t)));
+    return 0;
+}
+#endif
 #if GSR_FWD_TIMING
 // dev builds only (-DGSR_FWD_TIMING=1): per-wave cycle accounting of the last render_fwd launch, 8 words per (tile, quadrant wave)
 int gsr_debug_fwd_timing(unsigned int* out, int nwords)
@@ -1143,6 +1178,13 @@ __global__ void debug_reduce10_kernel(const float* in, float* out)
     const float* v = in + l * 10;
     unsigned long long proc = 0; uint32_t addr;
     out[l] = wave_sum10_transposed(wave_select_masks(), v[0], f2v{v[1], v[2]}, f2v{v[3], v[4]}, v[5], f2v{v[6], v[7]}, f2v{v[8], v[9]}, proc, 0, 0u, 0, addr);
+}
+// the work-item map of gs_device.h on the host (no device needed): block index of the full piece of rank `rank` (partial = 0) or of the
+// partial piece of rank `rank` (partial = 1) in a frame of n_items pieces, n_partial of them partial
+int gsr_debug_item_block(unsigned int n_items, unsigned int n_partial, unsigned int rank, int partial)
+{
+    if (n_partial > n_items || rank >= (partial ? n_partial : n_items - n_partial)) return GSR_ERR_INVALID_ARGUMENT;
+    return (int)(partial ? item_block_partial(n_items, n_partial, rank) : item_block_full(n_items, n_partial, rank));
 }
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream_)
 {
@@ -1811,14 +1853,10 @@ static int dense_forward_launch(const char* who, int M, int N, int K, const floa
         Dense8Layer L;
         L.X = X; L.gate = gate; L.planes = reinterpret_cast<const unsigned short*>(planes); L.bias = bias; L.Y = Y; L.mask = mask; L.colsum = partial;
         L.N = N; L.K = K; L.ldx = ldx; L.ldgate = ldgate; L.Npad = Npad; L.Kpad = Kpad; L.relu = relu ? 1 : 0; L.ldy = ldy; L.vec = vec ? 1 : 0; L.ldmask = ldmask;
-        static bool attr_set[DENSE_MAX_BT + 1] = {};
+        static std::atomic<unsigned long long> attr_set[DENSE_MAX_BT + 1];
 #define GSR_DENSE8_LAUNCH(BT)                                                                                                                          \
         case BT:                                                                                                                                       \
-            if (!attr_set[BT]) {                                                                                                                       \
-                GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_fwd8_kernel<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                                  DENSE8_LDS_BYTES));                                                                                  \
-                attr_set[BT] = true;                                                                                                                   \
-            }                                                                                                                                          \
+            { const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(dense_fwd8_kernel<BT>), DENSE8_LDS_BYTES, attr_set[BT]); if (rc) return rc; } \
             hipLaunchKernelGGL(dense_fwd8_kernel<BT>, grid8, dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, M, L);                                    \
             break;
         switch (bt8) {
@@ -1899,14 +1937,10 @@ int gsr_dense_chain(int M, int N, int count, const gsr_dense_chain_op* ops, char
         L.N = N; L.K = q.K; L.ldx = q.ldx; L.ldgate = 0; L.Npad = round_up_int(N, DENSE_BN); L.Kpad = round_up_int(q.K, DENSE_BK); L.relu = q.relu ? 1 : 0;
         L.ldy = q.ldy; L.vec = 1; L.ldmask = q.ldmask;
     }
-    static bool attr_set[DENSE_MAX_BT + 1] = {};
+    static std::atomic<unsigned long long> attr_set[DENSE_MAX_BT + 1];
 #define GSR_CHAIN8_LAUNCH(BT)                                                                                                                          \
     case BT:                                                                                                                                           \
-        if (!attr_set[BT]) {                                                                                                                           \
-            GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_chain8_kernel<BT>), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                              DENSE8_LDS_BYTES));                                                                                      \
-            attr_set[BT] = true;                                                                                                                       \
-        }                                                                                                                                              \
+        { const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(dense_chain8_kernel<BT>), DENSE8_LDS_BYTES, attr_set[BT]); if (rc) return rc; } \
         hipLaunchKernelGGL(dense_chain8_kernel<BT>, dim3(blocks), dim3(DENSE8_THREADS), DENSE8_LDS_BYTES, stream, c);                                  \
         break;
     switch (bt) {
@@ -1992,11 +2026,8 @@ int gsr_trunk_forward(const gsr_trunk* t, int R, const float* emb, float* const*
         a.outs[l] = outs[l]; a.ldo[l] = ldo[l];
     }
     if (R == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GSR_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set;
+    { const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(trunk_fwd_kernel), TR_LDS_BYTES, attr_set); if (rc) return rc; }
     hipLaunchKernelGGL(trunk_fwd_kernel, dim3((unsigned)((R + TR_BM - 1) / TR_BM)), dim3(256), TR_LDS_BYTES, stream, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;

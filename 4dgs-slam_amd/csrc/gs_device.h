@@ -239,6 +239,30 @@ constexpr int CKPT_FLOATS = 5 * TILE_X * TILE_Y;   // one checkpoint: 5 planes o
 // entries in it | bit 16 = more entries follow in the list, list position of its first entry}, written by the forward tile kernel at
 // the index of the backward BLOCK that will take the piece (the XCD banding is applied by the writer). A frame has at most
 // R / CHUNK + tiles pieces.
+// Which block takes which piece (round 6): render_bwd runs ~4.3 generations of blocks per CU slot; with the pieces in tile order it ended in a
+// ~20 us tail in which the CUs ran dry one by one behind whichever pieces happened to start last (tools/tile_timeline.py,
+// profiles/r06_tile_timeline.json: mean residency 3.9 of 5 blocks per CU, the last block started at 76 of 96 us). Now every XCD's sequence
+// (block b runs on XCD b % 8, in the order of b / 8) is: first the FULL pieces (CHUNK entries) of a contiguous range of tiles, in tile order
+// -- neighbouring tiles share Gaussians and one tile's pieces share its pixel state: same L2 --, then its share of the PARTIAL last pieces
+// of all lists, dealt round robin over the XCDs in descending length, so that the launch ends on short blocks everywhere at once (96 -> 87 us
+// first block to last, residency 4.4). item_block() is that map; its inputs (per tile: full pieces in front of it, rank of its partial
+// piece; the frame's number of full pieces) come from order_tiles_body, one extra block of the scatter launch.
+__host__ __device__ inline uint32_t items_below(uint32_t M, uint32_t x) { return x * (M >> 3) + (x < (M & 7u) ? x : (M & 7u)); }   // #{b < M : b % 8 < x}
+// first full-piece rank of XCD x when the frame has N pieces, Pn of them partial: XCD x runs #{b < N : b % 8 == x} blocks, #{r < Pn : r % 8 == x} of them partial
+__host__ __device__ inline uint32_t full_start(uint32_t N, uint32_t Pn, uint32_t x) { return items_below(N, x) - items_below(Pn, x); }
+__host__ __device__ inline uint32_t item_block_full(uint32_t N, uint32_t Pn, uint32_t f /* rank among the full pieces, tile order */)
+{
+    uint32_t x = 0;
+    while (x < 7u && full_start(N, Pn, x + 1u) <= f) x++;
+    return 8u * (f - full_start(N, Pn, x)) + x;
+}
+__host__ __device__ inline uint32_t item_block_partial(uint32_t N, uint32_t Pn, uint32_t r /* rank among the partial pieces, longest first */)
+{
+    const uint32_t x = r & 7u;
+    return 8u * ((full_start(N, Pn, x + 1u) - full_start(N, Pn, x)) + (r >> 3)) + x;
+}
+// where order_tiles_body leaves its results: the padding words of the per-tile counters (CTR_STRIDE words per tile, word 0 in use)
+constexpr int POS_FULL_BASE = 1, POS_PART_RANK = 2, POS_TOTAL_FULL = 1;   // tile_count[t * CTR_STRIDE + 1 / + 2]; tile_count[T * CTR_STRIDE + 1]
 struct BinningPtrs { uint4* chunk_info; uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
 __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted, size_t ntiles)
 {

@@ -612,6 +612,43 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// F3b: where render_bwd's work items go (gs_device.h: item_block_*). ONE extra block of the scatter launch (it only needs the tile ranges,
+// which the scan wrote; it runs beside the scatter blocks and is done long before them: no launch of its own, nothing on the critical path).
+// Per tile: the number of FULL pieces (CHUNK entries) of the tiles in front of it, and the rank of its PARTIAL last piece among all partial
+// pieces of the frame, longest first (counting sort on the length 1 .. CHUNK - 1; inside a length the order comes from an LDS atomic and is
+// not fixed -- it only decides which block takes which piece: every piece writes its own instances' slots, the results do not depend on it).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_pos)
+{
+    static_assert(CHUNK == 128 && GB == 1024, "128 lengths, 1024 threads");
+    __shared__ uint32_t s_len[CHUNK], s_tmp[17];
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)CHUNK) s_len[t] = 0;
+    __syncthreads();
+    for (int i = (int)t; i < T; i += GB) {
+        const uint2 r = ranges[i];
+        const uint32_t m = (r.y - r.x) & (uint32_t)(CHUNK - 1);
+        if (m) atomicAdd(&s_len[m], 1u);
+    }
+    __syncthreads();
+    // thread k < 128 holds length 127 - k: exclusive scan in DESCENDING length -> first rank of every length
+    uint32_t v = 0, incl = 0;
+    if (t < (uint32_t)CHUNK) { v = s_len[CHUNK - 1 - t]; incl = wave_inclusive_scan(v); if (t == 63) s_tmp[0] = incl; }
+    __syncthreads();
+    if (t < (uint32_t)CHUNK) s_len[CHUNK - 1 - t] = incl - v + (t >= 64 ? s_tmp[0] : 0u);
+    __syncthreads();
+    for (int i = (int)t; i < T; i += GB) {
+        const uint2 r = ranges[i];
+        const uint32_t m = (r.y - r.x) & (uint32_t)(CHUNK - 1);
+        if (m) tile_pos[(size_t)i * CTR_STRIDE + POS_PART_RANK] = atomicAdd(&s_len[m], 1u);
+    }
+    __syncthreads();
+    const uint32_t total_full = block_exclusive_scan_1024(T, [&](int i) { const uint2 r = ranges[i]; return (r.y - r.x) / (uint32_t)CHUNK; },
+                                                          [&](int i, uint32_t excl, uint32_t) { tile_pos[(size_t)i * CTR_STRIDE + POS_FULL_BASE] = excl; }, s_tmp);
+    if (t == 0) tile_pos[(size_t)T * CTR_STRIDE + POS_TOTAL_FULL] = total_full;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // F4: per-tile depth sort. One 256-thread block per tile; bitonic network on 64-bit keys (depth bits << 32 | u), in
 // LDS when the (power-of-two padded) list fits SORT_LDS_CAP keys, otherwise in place in global memory on the tile's
 // power-of-two sized segment. Emits the sorted (gaussian id, instance id) pairs the render kernels walk.
@@ -1123,8 +1160,12 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip, uint32_t* tile_pos)
 {
+    if (tile_pos != nullptr && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F3b)
+        if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) order_tiles_body(gx * gy, ranges, tile_pos);
+        return;
+    }
     scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager, clip);
 }
 

@@ -160,13 +160,17 @@ struct AdamArgs { int nseg; unsigned long long total; unsigned long long start[A
 struct AdamDeviceSteps { int nseg; float* step[ADAM_MAX_SEGMENTS]; float lr[ADAM_MAX_SEGMENTS]; double beta1[ADAM_MAX_SEGMENTS], beta2[ADAM_MAX_SEGMENTS]; };
 __global__ void __launch_bounds__(64) adam_device_coefficients_kernel(AdamDeviceSteps a, float* __restrict__ coef)
 {
+    static_assert(ADAM_MAX_SEGMENTS <= 64, "one thread per segment, one wave");
     const int k = threadIdx.x;
-    if (k >= a.nseg) return;
-    bool first = true;                                         // (several parameters may share one counter: advance it once)
-    for (int j = 0; j < k; j++) first = first && a.step[j] != a.step[k];
-    const float t = a.step[k][0] + 1.f;
-    const double bc1 = 1.0 - pow(a.beta1[k], (double)t), bc2 = 1.0 - pow(a.beta2[k], (double)t);
-    coef[2 * k] = (float)((double)a.lr[k] / bc1); coef[2 * k + 1] = (float)(1.0 / sqrt(bc2));
+    const bool live = k < a.nseg;                              // (no early return: every thread reaches the barrier)
+    bool first = live;                                         // (several parameters may share one counter: advance it once)
+    float t = 0.f;
+    if (live) {
+        for (int j = 0; j < k; j++) first = first && a.step[j] != a.step[k];
+        t = a.step[k][0] + 1.f;
+        const double bc1 = 1.0 - pow(a.beta1[k], (double)t), bc2 = 1.0 - pow(a.beta2[k], (double)t);
+        coef[2 * k] = (float)((double)a.lr[k] / bc1); coef[2 * k + 1] = (float)(1.0 / sqrt(bc2));
+    }
     __syncthreads();                                           // every thread has read its counter
     if (first) a.step[k][0] = t;
 }

@@ -117,6 +117,69 @@ __device__ uint32_t g_bwd_timing[8 * 4 * 8192];
 #else
 #define FWD_T(...)
 #endif
+// GSR_FWD_TIMING == 2: render_fwd's batch loop in finer pieces instead of the sort's sub-phases (report slots 2, 3, 6, 7: staging, the two
+// block barriers, index lists, epilogue)
+#if GSR_FWD_TIMING == 2
+#define FWD_T2(...) __VA_ARGS__
+#else
+#define FWD_T2(...)
+#endif
+// GSR_TIMELINE (dev builds only): per-block start / end on the chip-wide 100 MHz clock (s_memrealtime) and the block's HW_ID / XCC_ID, for
+// both tile kernels -> tools/tile_timeline.py reconstructs residency over time, dispatch gaps and the tail (gsr_debug_spans()).
+#ifndef GSR_TIMELINE
+#define GSR_TIMELINE 0
+#endif
+// dev A/B knobs (tools/dev_ab.sh): wave priority by list length in render_fwd; cache policy of the large streaming stores
+#ifndef GSR_FWD_PRIO
+#define GSR_FWD_PRIO 0
+#endif
+#ifndef GSR_FWD_PRIO_T1
+#define GSR_FWD_PRIO_T1 8
+#define GSR_FWD_PRIO_T2 9
+#define GSR_FWD_PRIO_T3 10
+#endif
+#ifndef GSR_FWD_PREFETCH
+#define GSR_FWD_PREFETCH 0
+#endif
+#ifndef GSR_SLOT_STORE
+#define GSR_SLOT_STORE 0      // render_bwd's instance slots: 0 plain, 1 nontemporal, 2 write-through (sc1)
+#endif
+#ifndef GSR_CKPT_STORE
+#define GSR_CKPT_STORE 0      // render_fwd's checkpoints: 0 plain, 1 nontemporal
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store16(float4* p, float4 v)
+{
+#if GSR_SLOT_STORE == 1
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+#elif GSR_SLOT_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void ckpt_store(float* p, float v)
+{
+#if GSR_CKPT_STORE == 1
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+#if GSR_TIMELINE
+__device__ uint32_t g_spans[2][8192][4];
+#define TL_BEGIN() const uint32_t tl_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime()
+#define TL_END(which, id)                                                                                                             \
+    do {                                                                                                                              \
+        if (threadIdx.x == 0 && (id) < 8192) {                                                                                        \
+            g_spans[which][id][0] = tl_t0; g_spans[which][id][1] = (uint32_t)__builtin_amdgcn_s_memrealtime();                        \
+            g_spans[which][id][2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_spans[which][id][3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   \
+        }                                                                                                                             \
+    } while (0)
+#else
+#define TL_BEGIN()
+#define TL_END(which, id)
+#endif
 // ------------------------------------------------------------------------------------------------------------------
 // F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
 // ------------------------------------------------------------------------------------------------------------------
@@ -129,9 +192,11 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
                                                         int* __restrict__ n_touched, float4* __restrict__ final_C,
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
-                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info)
+                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
+                                                        const uint32_t* __restrict__ tile_pos)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
+    TL_BEGIN();
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[3 * RB * sizeof(float4)];
     float4* const s_a = reinterpret_cast<float4*>(s_raw);   // {mean.x, mean.y, A, B}   power*log2e = dx*(A*dx + B*dy) + C*dy*dy
     float4* const s_b = s_a + RB;                            // {C, log2 opacity, -, gaussian id bits}
@@ -159,6 +224,18 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     uint32_t last = 0;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    // (read here, with the range, for the epilogue's work-item table: at the end they would be one more memory round trip of the last block)
+    uint32_t nfull = 0, fbase = 0, prank = 0;
+    if (tile_pos != nullptr) { nfull = tile_pos[(size_t)ntiles * CTR_STRIDE + POS_TOTAL_FULL]; fbase = tile_pos[(size_t)tile * CTR_STRIDE + POS_FULL_BASE]; prank = tile_pos[(size_t)tile * CTR_STRIDE + POS_PART_RANK]; }
+#if GSR_FWD_PRIO
+    {   // The launch lasts as long as its longest tile's dependent chain (every tile of the frame is resident at once, 4.7 waves per SIMD share the
+        // issue slots): the waves of the long lists take the arbitration (s_setprio), the short ones -- which finish early anyway -- the rest.
+        const int mean = (int)(ranges[ntiles - 1].y / (uint32_t)ntiles);            // segments are exact: the last range ends at R
+        if (n * 8 > mean * GSR_FWD_PRIO_T3) __builtin_amdgcn_s_setprio(3);
+        else if (n * 8 > mean * GSR_FWD_PRIO_T2) __builtin_amdgcn_s_setprio(2);
+        else if (n * 8 > mean * GSR_FWD_PRIO_T1) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     FWD_T(uint32_t tk0 = FWD_TICK(); uint32_t tk_sort = 0, tk_stage = 0, tk_list = 0, tk_pair = 0, tk_wait = 0, n_pairs = 0, n_batches = 0; uint32_t tk_mark = tk0;)
     // keys != nullptr: this block first sorts its own tile list (the staging arrays double as the key buffer) -- one kernel and
     // one GPU drain/fill less per frame than a separate sort launch; lists beyond the LDS capacity were sorted by
@@ -183,12 +260,28 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     // pass uses the final values for a pixel that blended nothing behind the boundary.
     auto write_checkpoint = [&](int boundary) {
         float* c = ckpt + (size_t)((range.x >> 7) + (uint32_t)(boundary >> 7)) * CKPT_FLOATS + t;
-        c[0] = T; c[256] = acc_rg.x; c[512] = acc_rg.y; c[768] = acc_bd.x; c[1024] = acc_bd.y;
+        ckpt_store(c, T); ckpt_store(c + 256, acc_rg.x); ckpt_store(c + 512, acc_rg.y); ckpt_store(c + 768, acc_bd.x); ckpt_store(c + 1024, acc_bd.y);
     };
     static_assert(CHUNK == 128 && RB == 2 * CHUNK, "checkpoint cadence: one at the top of a batch, one in its middle");
 
+#if GSR_FWD_PREFETCH
+    // Round 6: the NEXT batch's list entries and records are requested while the current batch is composited. The launch is as long as its
+    // longest tile's dependent chain (tools/tile_timeline.py: every block starts within 0.5 us, the longest lasts the whole launch, nothing
+    // queues behind it), and that chain paid two dependent global latencies (entry -> record) in front of every 256-entry batch with the
+    // block's four waves parked on them. pf_gid2: Gaussian id of this thread's entry of the batch AFTER the next one (requested a whole pair
+    // phase before its record load needs it), pf_q*: this thread's record of the batch about to be staged. 13 more registers (88 -> 5 waves
+    // per SIMD allowed; a 640x480 frame is 4.7).
+    uint32_t pf_gid = 0, pf_gid2 = 0;
+    float4 pf_q0 = make_float4(0.f, 0.f, 0.f, 0.f), pf_q1 = pf_q0, pf_q2 = pf_q0;
+    if (t < n) pf_gid = sorted[range.x + t].x;
+    if (RB + t < n) pf_gid2 = sorted[range.x + RB + t].x;
+    if (t < n) { const TileRec* const g = rec + pf_gid; pf_q0 = g->q0; pf_q1 = g->q1; pf_q2 = g->q2; }
+#endif
+    FWD_T2(uint32_t t2_stage = 0, t2_bar = 0, t2_list = 0, t2_epi = 0;)
     for (int base = 0; base < n; base += RB) {
+        FWD_T2(tk_mark = FWD_TICK();)
         const int all_done = __syncthreads_and(thr > 1.0f);       // forward.cu:318-320 (also orders the LDS reuse below)
+        FWD_T2(t2_bar += FWD_TICK() - tk_mark;)
         FWD_T(tk_mark = FWD_TICK();)
         {   // flush the previous batch's n_touched increments: one global atomic per (tile, Gaussian), off the hot loop
             const int c = s_nt[t];
@@ -198,9 +291,14 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         if (base > 0) write_checkpoint(base);
         uint32_t qm = 0;
         if (base + t < n) {
+#if GSR_FWD_PREFETCH
+            const uint2 e = make_uint2(pf_gid, 0u);
+            const float4 q0 = pf_q0, q1 = pf_q1, q2 = pf_q2;
+#else
             const uint2 e = sorted[range.x + base + t];
             const TileRec* const g = rec + e.x;
             const float4 q0 = g->q0, q1 = g->q1, q2 = g->q2;
+#endif
             const float2 xy = make_float2(q0.x, q0.y);
             const float4 co = make_float4(q1.x, q1.y, q1.z, q0.w);
             qm = quadrant_mask(xy.x, xy.y, co.x, co.y, co.z, co.w, tx, ty);
@@ -218,7 +316,14 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
             const unsigned long long m = __ballot((qm >> q) & 1u);
             if (lane == 0) s_mask[q][wave] = m;
         }
+        FWD_T2(t2_stage += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
         __syncthreads();
+        FWD_T2(t2_bar += FWD_TICK() - tk_mark; tk_mark = FWD_TICK();)
+#if GSR_FWD_PREFETCH
+        pf_gid = pf_gid2;
+        if (base + RB + t < n) { const TileRec* const g = rec + pf_gid; pf_q0 = g->q0; pf_q1 = g->q1; pf_q2 = g->q2; }
+        if (base + 2 * RB + t < n) pf_gid2 = sorted[range.x + base + 2 * RB + t].x;
+#endif
         // The saturation test is per 64-entry group, not per entry: a per-entry wave vote + branch serialises the loop on the
         // VALU->SALU round trip (measured: 111 -> 86 us), and pixels that are done blend nothing anyway.
         // Per 64-entry group the wave re-votes two things: whether any of its pixels is still unsaturated (else it skips the
@@ -315,6 +420,7 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
                 if (counts) __hip_atomic_fetch_add(&s_nt[sw * 64 + lane], counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
+        FWD_T2(t2_list += FWD_TICK() - tk_mark;)
         FWD_T(tk_mark = FWD_TICK();)
         for (int sw = 0; sw < 4; sw++) {
             if (__all(thr > 1.0f)) break;
@@ -331,8 +437,10 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     if (lane == 0 && tile < 8192) {
         uint32_t* o = g_fwd_timing + (size_t)(tile * 4 + wave) * 8;
         o[0] = FWD_TICK() - tk0; o[1] = tk_sort; o[2] = tk_stage; o[3] = tk_list; o[4] = tk_pair; o[5] = n_pairs; o[6] = n_batches; o[7] = tk_wait;
+        FWD_T2(o[2] = t2_stage; o[3] = t2_bar; o[6] = t2_list; o[7] = 0;)
     }
 #endif
+    FWD_T2(tk_mark = FWD_TICK();)
     __syncthreads();
     {
         const int c = s_nt[t];
@@ -352,11 +460,14 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         __syncthreads();
         const int deepest = max(max(s_deepest[0], s_deepest[1]), max(s_deepest[2], s_deepest[3]));
         const uint32_t cb = chunk_base[tile], nchunks = chunk_base[ntiles];
+        // where the pieces go: tile order inside XCD bands (tile_pos == nullptr, rounds 2-5), or full pieces in tile order + partial pieces
+        // longest first at the end of every XCD's sequence (gs_device.h: item_block_*)
         for (int c = t; c * CHUNK < n; c += RB) {
             const int cstart = c * CHUNK, m = min(CHUNK, n - cstart);
-            chunk_info[xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)] =
-                make_uint4((uint32_t)tile, range.x + (uint32_t)cstart,
-                           (uint32_t)m | (cstart + m < n ? 0x10000u : 0u) | (deepest <= cstart ? 0x20000u : 0u), (uint32_t)cstart);
+            const uint32_t block = tile_pos == nullptr ? (uint32_t)xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)
+                                 : m == CHUNK ? item_block_full(nchunks, nchunks - nfull, fbase + (uint32_t)c) : item_block_partial(nchunks, nchunks - nfull, prank);
+            chunk_info[block] = make_uint4((uint32_t)tile, range.x + (uint32_t)cstart,
+                                           (uint32_t)m | (cstart + m < n ? 0x10000u : 0u) | (deepest <= cstart ? 0x20000u : 0u), (uint32_t)cstart);
         }
     }
     if (inside) {
@@ -370,6 +481,8 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         out_depth[pix] = acc_bd.y;
         out_opacity[pix] = 1.0f - T;
     }
+    FWD_T2(if (lane == 0 && tile < 8192) { uint32_t* o = g_fwd_timing + (size_t)(tile * 4 + wave) * 8; o[7] = FWD_TICK() - tk_mark; o[0] = FWD_TICK() - tk0; })
+    TL_END(0, tile);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -410,6 +523,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     // The XCD banding is computed over the REAL number of chunks: banding over the grid (an upper bound) put every surplus id
     // into the last XCD's band, which then ran out of work while the other seven still had a quarter of theirs.
     FWD_T(const uint32_t tk0 = FWD_TICK(); uint32_t tk_search = 0, tk_state = 0, tk_stage = 0, tk_pair = 0, tk_epi = 0, n_pairs = 0; uint32_t tk_mark = tk0;)
+    TL_BEGIN();
     // The block's work item and the header are two INDEPENDENT loads (the item table sits at offset 0 of the binning buffer and is indexed by
     // the block id: the forward pass applied the XCD banding when it wrote it). Round 2 searched chunk_base for the tile -- eleven dependent
     // scalar loads -- and then read ranges / chunk_base: seven global latencies before the first list entry could be requested, now two.
@@ -458,6 +572,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
             float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e0.y * 3;
             slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        TL_END(1, blockIdx.x);
         return;
     }
     const bool inside = px < W && py < H;
@@ -496,6 +611,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
             float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e.y * 3;
             slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        TL_END(1, blockIdx.x);
         return;
     }
 
@@ -695,10 +811,10 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
 #endif
                 float4* const slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(st_b.z) * 3;
                 // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
-                slot[0] = make_float4(-(K4.x * sum[0] + K4.y * sum[1]) * (0.5f * W), -(K4.z * sum[1] + K4.y * sum[0]) * (0.5f * H), -0.5f * sum[2], -0.5f * sum[3]);
+                stream_store16(slot, make_float4(-(K4.x * sum[0] + K4.y * sum[1]) * (0.5f * W), -(K4.z * sum[1] + K4.y * sum[0]) * (0.5f * H), -0.5f * sum[2], -0.5f * sum[3]));
                 // {M2yy, sum q, r, g} -> dL_dconic.w (:756), dL_dopacity = sum q / o = sum G dL_dalpha (:757; o = 0 blends nowhere), colour r, g (:719)
-                slot[1] = make_float4(-0.5f * sum[4], K4.w > 0.f ? sum[5] / K4.w : 0.f, sum[6], sum[7]);
-                slot[2] = make_float4(sum[8], sum[9], 0.f, 0.f);                                                  // {b, depth} (:719,:729)
+                stream_store16(slot + 1, make_float4(-0.5f * sum[4], K4.w > 0.f ? sum[5] / K4.w : 0.f, sum[6], sum[7]));
+                stream_store16(slot + 2, make_float4(sum[8], sum[9], 0.f, 0.f));                                  // {b, depth} (:719,:729)
             }
         } else if (sw == 0 && wave == 1 && t < m) {
             s_a[lane] = st_a; s_b[lane] = st_b; s_c[lane] = st_c;
@@ -713,6 +829,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
         o[0] = FWD_TICK() - tk0; o[1] = tk_search; o[2] = tk_state; o[3] = tk_stage; o[4] = tk_pair; o[5] = n_pairs; o[6] = tk_epi; o[7] = tk0;
     }
 #endif
+    TL_END(1, blockIdx.x);
 }
 
 // ---- the single-view kernels: the bodies above with their arguments passed by value (gs_views.h launches the same bodies once for
@@ -726,9 +843,10 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         int* __restrict__ n_touched, float4* __restrict__ final_C,
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
-                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info)
+                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
+                                                        const uint32_t* __restrict__ tile_pos)
 {
-    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info);
+    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos);
 }
 
 #ifndef GSR_BWD_WAVES
@@ -743,5 +861,6 @@ __global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD
 {
     render_bwd_body(ntiles, gx, bin_base, header, W, H, bg, rec, final_T, final_C, n_contrib, dL_dpix, dL_dpix_depth);
 }
+
 
 }  // namespace gsr

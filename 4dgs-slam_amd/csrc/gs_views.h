@@ -76,12 +76,16 @@ __global__ void __launch_bounds__(1024) scan_views_kernel(ViewTable t, ViewDims 
               geom.header, s.mailbox, s.seq);
 }
 
-__global__ void __launch_bounds__(GB) scatter_views_kernel(ViewTable t, ViewDims d, int eager)
+__global__ void __launch_bounds__(GB) scatter_views_kernel(ViewTable t, ViewDims d, int eager, int order_tiles)
 {
     const ViewSlot& s = t.v[blockIdx.y];
     const GeomState geom = view_geom(s, d.P);
     const ImageState img = view_image(s, d);
     const BinningPtrs bin = view_binning(s, d);
+    if (order_tiles && blockIdx.x == gridDim.x - 1) {                // the launch's extra block per view (gs_forward.h F3b)
+        if (!(geom.header[HDR_FLAGS] & FLAG_OVERFLOW)) order_tiles_body(d.T, img.ranges, img.tile_count);
+        return;
+    }
     scatter_instances_body(d.P, d.gx, d.gy, s.radii, geom.rec, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                            img.block_tile_base, bin.keys, bin.inst_gauss, geom.header, 1, s.cap, s.cap, eager, s.flow_clip);
 }
@@ -115,7 +119,7 @@ __global__ void __launch_bounds__(256) rank_long_chunks_views_kernel(ViewTable t
     rank_long_chunks_body<CHUNKK>(img.ranges, bin.keys, bin.inst_gauss, bin.sorted, geom.header, lower);
 }
 
-__global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg, int fuse_sort)
+__global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg, int fuse_sort, int order_tiles)
 {
     const ViewSlot& s = t.v[blockIdx.y];
     const GeomState geom = view_geom(s, d.P);
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewD
     const BinningPtrs bin = view_binning(s, d);
     render_fwd_body(d.T, d.gx, img.ranges, bin.sorted, d.W, d.H, geom.rec, bg, img.final_T, img.n_contrib, s.out_color, s.out_depth, s.out_opacity, s.n_touched,
                     img.final_C, bin.ckpt, geom.header, fuse_sort ? (const uint64_t*)bin.keys : nullptr, (const uint32_t*)bin.inst_gauss, bin.sorted,
-                    (const uint32_t*)img.chunk_base, bin.chunk_info);
+                    (const uint32_t*)img.chunk_base, bin.chunk_info, order_tiles ? (const uint32_t*)img.tile_count : nullptr);
 }
 
 __global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg)

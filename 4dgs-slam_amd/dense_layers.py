@@ -247,9 +247,17 @@ def trunk_forward(emb, weights, biases, W_heads, b_heads):
     R, E = int(emb.shape[0]), int(emb.shape[1])
     dev = emb.device
     skip = TRUNK_SKIP
-    planes = [split_weight(weights[0])]
+    # the kernel reads the two embedding products (layer 0, layer 5's first E columns) with a fixed K of TRUNK_MAX_EMBEDDING = 96 (three
+    # 32-column steps, plane rows 96 apart); split_weight pads K to the next multiple of 32 only, so a narrower embedding (E <= 64) gets its
+    # weight columns zero-padded to 96 here -- the kernel zero-fills the embedding's own columns [E, 96)
+    def emb_planes(Wm):
+        Wm = Wm[:, :E]
+        if (E + 31) // 32 * 32 != TRUNK_MAX_EMBEDDING:
+            Wm = torch.nn.functional.pad(Wm, (0, TRUNK_MAX_EMBEDDING - E))
+        return split_weight(Wm, k0=0, K=int(Wm.shape[1]))
+    planes = [emb_planes(weights[0])]
     planes += [split_weight(weights[k]) for k in range(1, skip + 1)]
-    planes += [split_weight(weights[skip + 1], k0=0, K=E), split_weight(weights[skip + 1], k0=E, K=TRUNK_WIDTH)]
+    planes += [emb_planes(weights[skip + 1]), split_weight(weights[skip + 1], k0=E, K=TRUNK_WIDTH)]
     planes += [split_weight(weights[k]) for k in range(skip + 2, TRUNK_LAYERS)]
     planes.append(split_weight(W_heads))
     cat = torch.empty((R, E + TRUNK_WIDTH), dtype=torch.float32, device=dev)

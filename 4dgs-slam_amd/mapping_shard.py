@@ -256,42 +256,23 @@ class ViewShard:
         net = [p for p in network_params if p.requires_grad]
         if net:
             hit = self._net_bucket
+            key = tuple(id(p) for p in net)
             dead = self.__dict__.setdefault("_net_no_grad", set())
-            if hit is not None and hit[0] == tuple(id(p) for p in net) and getattr(hit[1], "attached", False) \
+            if hit is not None and hit[0] == key and getattr(hit[1], "attached", False) \
                     and all(p.grad is v for p, v in zip(hit[1].params, hit[1].views)) and all(p.grad is None for p in net if id(p) in dead):
                 self._sum(hit[1].flat)
-                if not getattr(hit[1], "_liveness_checked", False):
-                    self._drop_untouched(net, hit[1])
             else:
-                dead.difference_update(id(p) for p in net if p.grad is not None)      # a parameter that was left out has a gradient after all
+                # Packed iteration: also the PROBE that decides which parameters the attached bucket will hold. A parameter whose .grad is
+                # None on every rank (it stays None through _packed_sum) takes no part in the loss -- the detached `nodes` group, heads the
+                # configuration switches off; Adam skips it in a single process and must here, so it stays out of the bucket (an attached
+                # view is zero rather than None). Liveness comes from None-ness alone: a parameter that is in the graph with an all-zero
+                # gradient holds a zero tensor, is stepped by a single process, and is attached here (value == 0 was the old test).
                 self._packed_sum("_net_pack", net)
-
-    def _drop_untouched(self, net, bucket):
-        """Once per attached network bucket, after its first reduction: a parameter whose gradient is exactly zero on EVERY rank did not take
-        part in the loss (the detached `nodes` group, heads the configuration switches off). An attached view is zero rather than None, so
-        Adam would step such a parameter with g = 0 and create state for it, which a single process (grad None: skipped) does not -- the
-        parameter leaves the bucket and its .grad becomes None again. One host read per bucket lifetime. Should it receive a gradient later
-        (a head that only a later phase uses), reduce_gradients notices, takes the packed path for that iteration and the next
-        attach_network() includes it again."""
-        bucket._liveness_checked = True
-        if not bucket.params:
-            return
-        peak = torch.stack([v.abs().amax() if v.numel() else v.new_zeros(()) for v in bucket.views]).tolist()
-        gone = [p for p, z in zip(bucket.params, peak) if z == 0.0]
-        if not gone:
-            return
-        kept = {id(p): v.clone() for p, v in zip(bucket.params, bucket.views)}
-        self._net_no_grad.update(id(p) for p in gone)
-        for p in gone:
-            p.grad = None
-            if hasattr(p, "_gsr_accumulate_grad"):
-                delattr(p, "_gsr_accumulate_grad")
-        self._net_bucket = None
-        nb = self.attach_network(net)
-        if nb is not None:
-            nb._liveness_checked = True
-            for p, v in zip(nb.params, nb.views):
-                v.copy_(kept[id(p)])
+                dead.clear()
+                dead.update(id(p) for p in net if p.grad is None)
+                self._net_probed = key
+                if hit is not None and getattr(hit[1], "attached", False) and [id(p) for p in hit[1].params] != [id(p) for p in net if id(p) not in dead]:
+                    hit[1].attached = False              # its parameter list is out of date: zero_network_grads() rebuilds and re-attaches
 
     def _packed_sum(self, slot, params):
         """pack -> ONE all-reduce -> unpack through a bucket cached per parameter list; gradients that are None on every rank stay None.
@@ -328,15 +309,29 @@ class ViewShard:
     def attach_network(self, params):
         """Make the network parameters' .grad views of one persistent flat bucket (GradBucket.attach without the rasterizer's fused
         accumulation): autograd accumulates into them in place and reduce_gradients all-reduces the bucket as it stands -- no pack / unpack
-        of ~20 tensors per iteration. Use zero_network_grads() in place of optimizer.zero_grad(set_to_none=True). No-op with one rank."""
-        # only parameters that RECEIVE gradients: an attached view is zero rather than None, and Adam would step a parameter the loss never
-        # reaches with g = 0 and create state for it; which ones those are is found after the first reduction (_drop_untouched)
+        of ~20 tensors per iteration. Use zero_network_grads() in place of optimizer.zero_grad(set_to_none=True). No-op with one rank.
+        Only parameters that RECEIVE gradients are attached: an attached view is zero rather than None, and Adam would step a parameter the
+        loss never reaches with g = 0 and create state for it. Which ones those are is read off ``p.grad is None`` after one PACKED
+        iteration: the first iteration of a parameter list this shard has not seen runs unattached (returns None), reduce_gradients probes,
+        and the first zero_network_grads() behind it attaches the live parameters -- same optimizer state as a single process."""
         every = [p for p in params if p.requires_grad]
-        dead = self.__dict__.setdefault("_net_no_grad", set())
-        net = [p for p in every if id(p) not in dead]
-        if not self.active or not net:
+        if not self.active or not every:
             return None
         key = tuple(id(p) for p in every)
+        self._net_want = (key, every)
+        if self.__dict__.get("_net_probed") != key:
+            return None
+        return self._attach_live()
+
+    def _attach_live(self):
+        key, every = self._net_want
+        dead = self.__dict__.setdefault("_net_no_grad", set())
+        net = [p for p in every if id(p) not in dead]
+        for p in every:
+            if id(p) in dead:
+                p.grad = None
+        if not net:
+            return None
         if self._net_bucket is None or self._net_bucket[0] != key or [id(p) for p in self._net_bucket[1].params] != [id(p) for p in net]:
             self._net_bucket = (key, GradBucket(net))
         b = self._net_bucket[1]
@@ -345,8 +340,19 @@ class ViewShard:
         return b
 
     def zero_network_grads(self, optimizer):
-        hit = self._net_bucket
-        if self.active and hit is not None and getattr(hit[1], "attached", False):
+        hit, want = self._net_bucket, self.__dict__.get("_net_want")
+        if self.active and want is not None and self.__dict__.get("_net_probed") == want[0]:
+            dead = self.__dict__.setdefault("_net_no_grad", set())
+            live = [id(p) for p in want[1] if id(p) not in dead]
+            if hit is not None and hit[0] == want[0] and getattr(hit[1], "attached", False) and [id(p) for p in hit[1].params] == live:
+                hit[1].zero_grads()
+            else:                                        # behind the probing iteration, or a parameter joined / left: (re)build and attach
+                for p in want[1]:
+                    p.grad = None
+                    if hasattr(p, "_gsr_accumulate_grad"):
+                        delattr(p, "_gsr_accumulate_grad")
+                self._attach_live()
+        elif self.active and hit is not None and getattr(hit[1], "attached", False):
             hit[1].zero_grads()
         else:
             optimizer.zero_grad(set_to_none=True)

@@ -179,7 +179,10 @@ def _set_of_b(V, T, offset, device):
     key = (V, T, offset, str(device))
     t = _SET_OF_B.get(key)
     if t is None:
-        t = _SET_OF_B[key] = (torch.arange(V, dtype=torch.int32) + offset).repeat_interleave(T).to(device)
+        if len(_SET_OF_B) >= 64:                 # (a handful of layouts per run; bounded all the same)
+            _SET_OF_B.pop(next(iter(_SET_OF_B)))
+        # built ON the device: a host-to-device copy would break a stream capture that hits a new layout first
+        t = _SET_OF_B[key] = (torch.arange(V, dtype=torch.int32, device=device) + offset).repeat_interleave(T)
         t._gsr_long = t.long()                   # (what gather_rows' index_select wants: no conversion launch per call)
     return t
 

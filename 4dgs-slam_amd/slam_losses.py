@@ -61,8 +61,13 @@ _PLACEHOLDERS = {}
 
 
 def _placeholder(device):
-    """The value of a loss evaluated with compute_value=False: a zero scalar that costs no launch -- every call returns a fresh alias of ONE
-    zero per device (a defined placeholder, NOT the loss: sums and logs stay finite; nobody may write into it)."""
+    """The value of a loss evaluated with compute_value=False: a zero scalar (a defined placeholder, NOT the loss: sums and logs stay finite).
+    Outside a stream capture it is a fresh tensor, so a caller's in-place arithmetic (`loss += x`) touches nobody else's value.
+    During a capture -- where a fill launch per loss term is what the flag exists to avoid, and the only callers are this repo's graph
+    builders (slam/tracking_graph.py, mapping_graph.py, dynamic_graph.py), which never write into a loss value -- it is an alias of ONE
+    zero per device: read-only by contract."""
+    if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return torch.zeros((), dtype=torch.float32, device=device)
     key = str(device)
     z = _PLACEHOLDERS.get(key)
     if z is None:

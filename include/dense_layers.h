@@ -83,6 +83,8 @@ int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* g
  *   planes[0]      layer 0's weight [256, E]                      planes[1..4]  layers 1..4 [256, 256]
  *   planes[5], [6] layer 5's weight, columns [0, E) and [E, E + 256)            planes[7], [8]  layers 6, 7
  *   planes[9]      the heads' weight [n_head_outputs, 256]
+ * planes[0] and planes[5] are read with a FIXED K of 96 (three 32-column steps, plane rows 96 apart): gsr_dense_split pads K to the next
+ * multiple of 32 only, so for E <= 64 split a copy of the weight whose columns [E, 96) are zero (K = 96).
  * bias[0..7] the layers' (256 floats, 16-byte aligned), bias[8] the heads'. outs[l] receives layer l's output (post-ReLU, fp32, row stride
  * ldo[l] floats, 16-byte aligned rows: the backward pass reads them; outs[4] may point INTO a [R, E + 256] buffer at column E so that layer
  * 5's input exists as one matrix), heads [R, n_head_outputs]. */

@@ -255,6 +255,10 @@ int gsr_debug_read_state(int P, int R, int width, int height,
  * out = device float[64]; lane l receives the 64-lane total of value k(l): bit 1 of l set -> (bit 5 ? 5 : 0), else
  * (bit 4 ? 6 : 1) + bit 0 + 2 * bit 5. */
 int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
+/* Test hook, host only: which render_bwd block takes a work item -- the full piece of rank `rank` in tile order (partial = 0) or the partial
+ * piece of rank `rank` in descending length (partial = 1) -- in a frame of n_items pieces, n_partial of them partial. The map is a bijection
+ * onto [0, n_items); block b runs on XCD b % 8 in the order of b / 8 (csrc/gs_device.h: item_block_*). Negative: argument out of range. */
+int gsr_debug_item_block(unsigned int n_items, unsigned int n_partial, unsigned int rank, int partial);
 
 /* Per-host-thread options of the forward pass; returns the previous value (value < 0: query only) or a negative error code.
  *   "speculate" (default 1): scatter / sort / render are enqueued on a binning buffer sized from the previous frame before the host
@@ -280,9 +284,14 @@ int gsr_debug_wave_reduce10(const float* in, float* out, void* stream);
  *                the mailbox of a view are kept per (group, flow / plain, position in the call): a caller that needs several calls per
  *                iteration (more than GSR_MAX_VIEWS flow renders) numbers them, or the v-th view of two calls would share -- and spoil -- one
  *                estimate.
+ *   "order_items" (default 1): render_bwd's work items (128-entry pieces of the tile lists) are laid out so that every XCD runs the full
+ *                pieces first, in tile order, and ends on the partial last pieces of the lists, longest first -- the launch then ends on
+ *                short blocks everywhere at once instead of a ~20 us tail. One extra block of the scatter launch ranks the pieces. The
+ *                results are bit-identical either way (every piece writes its own instances' slots); 0 = tile order. Read by the FORWARD
+ *                pass (which writes the work-item table).
  *   "cap_test_shrink_permille" (default 0 = off): TEST facility -- lay speculative buffers out for this fraction of the previous
  *                frame's count, so that overflows (and the callers' recovery paths) can be provoked deliberately.
- * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX set the initial values. */
+ * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX, GSR_ORDER_ITEMS set the initial values. */
 int gsr_set_option(const char* name, int value);
 /* overflow_count: number of forward passes of this thread whose speculative capacity was too small (sticky);
  * last_num_rendered: num_rendered of the most recent forward pass the GPU has finished binning. Never blocks. */

@@ -37,6 +37,29 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 48 + 8)
 
 
+def test_work_item_map_is_a_bijection_with_full_pieces_first_and_short_pieces_last():
+    """render_bwd's block b takes work item b; the forward pass places a frame's pieces (csrc/gs_device.h item_block_*, a host + device
+    function exposed through gsr_debug_item_block): onto [0, n_items) exactly; XCD b % 8 runs its blocks in the order of b / 8 -- first full
+    pieces with consecutive ranks (tile order: locality), then partial pieces in ascending rank (= descending length), dealt round robin."""
+    lib = _C.load_library()
+    lib.gsr_debug_item_block.restype = ctypes.c_int
+    lib.gsr_debug_item_block.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]
+    for n_items, n_partial in [(1, 0), (1, 1), (7, 3), (8, 8), (9, 1), (10, 1), (16, 5), (17, 0), (23, 23), (100, 37), (5548, 1193), (4999, 1200), (64, 1)]:
+        n_full = n_items - n_partial
+        blocks = [lib.gsr_debug_item_block(n_items, n_partial, f, 0) for f in range(n_full)] + \
+                 [lib.gsr_debug_item_block(n_items, n_partial, r, 1) for r in range(n_partial)]
+        assert sorted(blocks) == list(range(n_items)), (n_items, n_partial)
+        for x in range(8):
+            seq = sorted((b // 8, kind, rank) for kind, ranks in ((0, range(n_full)), (1, range(n_partial)))
+                         for rank in ranks for b in [blocks[rank + kind * n_full]] if b % 8 == x)
+            kinds = [k for _, k, _ in seq]
+            assert kinds == sorted(kinds), "an XCD runs its full pieces before its partial ones"
+            fulls, parts = [r for _, k, r in seq if k == 0], [r for _, k, r in seq if k == 1]
+            assert fulls == list(range(fulls[0], fulls[0] + len(fulls))) if fulls else True
+            assert parts == [x + 8 * j for j in range(len(parts))]
+    assert lib.gsr_debug_item_block(10, 11, 0, 0) < 0 and lib.gsr_debug_item_block(10, 3, 7, 0) < 0 and lib.gsr_debug_item_block(10, 3, 3, 1) < 0
+
+
 def test_c_entry_points_reject_bad_arguments_before_touching_the_gpu():
     """Argument validation is host code: negative GSR_ERR_INVALID_ARGUMENT (-1) and a message, no device needed."""
     lib = _C.load_library()

@@ -81,12 +81,13 @@ def test_dense_bad_arguments_raise():
         dl.dense_wgrad(torch.randn((9, 4), device=DEV), X)
 
 
-@pytest.mark.parametrize("R", [1, 64, 1000, 33280])
-def test_layer_fused_trunk_forward_against_fp64(R):
+@pytest.mark.parametrize("R,E", [(1, 84), (64, 84), (1000, 84), (33280, 84), (1000, 64), (333, 32), (1000, 96), (257, 4)])
+def test_layer_fused_trunk_forward_against_fp64(R, E):
     """gsr_trunk_forward (the node network's eight layers + heads in one launch, a 64-row tile's activations resident in LDS) against the
-    same network in fp64: every layer's output and the heads; the library's fp32 layer-by-layer result is measured beside it."""
+    same network in fp64: every layer's output and the heads; the library's fp32 layer-by-layer result is measured beside it. Embedding
+    widths below 65 (multires = 8, t_multires = 6 gives 64) exercise the zero-padded embedding planes."""
     g = torch.Generator(device="cpu").manual_seed(R)
-    E, W, D, skip = 84, 256, 8, 4
+    W, D, skip = 256, 8, 4
     emb = torch.randn((R, E), generator=g).to(DEV)
     Ws, bs = [], []
     for k in range(D):

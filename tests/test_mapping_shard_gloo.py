@@ -394,32 +394,45 @@ def _viewshard_worker(rank, world, port, ret):
     same_bucket = shard.__dict__["_gauss_pack"][1] is bucket_1                      # cached, not rebuilt per iteration
     # attached network bucket: gradients accumulate in place, reduced without packing
     # (the third parameter never receives a gradient -- the detached `nodes` group of the deform model: it must end with grad None and no
-    # optimizer state, as in a single process, and leave the bucket after the first reduction)
-    net = [torch.nn.Parameter(torch.ones(3, 2)), torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(5))]
-    nb = shard.attach_network(net)
-    views = [p.grad for p in net]
-    ((net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum()).backward()
-    still_views = all(p.grad is v for p, v in zip(net, views))
+    # optimizer state, as in a single process. Liveness is read off `grad is None` on a first PACKED iteration, never off
+    # values: the fourth parameter is in the graph with an all-zero gradient -- a single process steps it, so it must be attached)
+    net = [torch.nn.Parameter(torch.ones(3, 2)), torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(2))]
+    loss = lambda: (net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum() + (net[3] * 0.0).sum()
+    probe = shard.attach_network(net) is None and all(p.grad is None for p in net)      # unseen parameter list: the first iteration is the probe
+    loss().backward()
     before = shard.collectives
     shard.reduce_gradients(None, net)
-    nb = shard._net_bucket[1]
     net_opt = torch.optim.Adam(net, lr=0.1)
     net_opt.step()
-    untouched_ok = net[2].grad is None and len(nb.params) == 2 and len(net_opt.state.get(net[2], {})) == 0 and float(net[2].detach().sum()) == 5.0
+    probe = probe and shard.collectives - before == 1 and net[2].grad is None and float(net[0].grad.sum()) == 18.0 and float(net[3].grad.abs().sum()) == 0.0
+    shard.zero_network_grads(net_opt)                                                  # ... and attaches the live parameters
+    nb = shard._net_bucket[1]
+    views = [p.grad for p in net]
+    loss().backward()
+    still_views = all(p.grad is v for p, v in zip(net, views)) and views[2] is None and views[3] is not None
+    before = shard.collectives
+    shard.reduce_gradients(None, net)
+    net_opt.step()
+    untouched_ok = (probe and net[2].grad is None and [id(p) for p in nb.params] == [id(net[0]), id(net[1]), id(net[3])] and len(net_opt.state.get(net[2], {})) == 0
+                    and float(net[2].detach().sum()) == 5.0 and int(net_opt.state[net[3]]["step"]) == 2)
     attached = (net[0].grad.clone(), net[1].grad.clone(), shard.collectives - before, still_views and untouched_ok)
-    views = [p.grad for p in net[:2]]
+    views = [p.grad for p in (net[0], net[1], net[3])]
     shard.zero_network_grads(net_opt)
-    zeroed = float(nb.flat.abs().sum()) == 0.0 and all(p.grad is v for p, v in zip(net[:2], views)) and net[2].grad is None
-    # second iteration: still the attached path (one collective), the left-out parameter still None
-    ((net[0] * (rank + 1)).sum() + (net[1] * 10.0 * (rank + 1)).sum()).backward()
+    zeroed = float(nb.flat.abs().sum()) == 0.0 and all(p.grad is v for p, v in zip((net[0], net[1], net[3]), views)) and net[2].grad is None
+    # next iteration: still the attached path (one collective), the left-out parameter still None
+    loss().backward()
     before = shard.collectives
     shard.reduce_gradients(None, net)
     zeroed = zeroed and shard.collectives - before == 1 and net[2].grad is None and float(net[0].grad.sum()) == 18.0
-    # ... and if it does receive a gradient later, that iteration goes through the packed path and nothing is lost
+    # ... and if it does receive a gradient later, that iteration goes through the packed path, nothing is lost, and the next
+    # zero_network_grads() rebuilds the bucket WITH it (no stale gradient survives into the iteration after)
     shard.zero_network_grads(net_opt)
     (net[2] * (rank + 1)).sum().backward()
     shard.reduce_gradients(None, net)
     zeroed = zeroed and net[2].grad is not None and float(net[2].grad.sum()) == 15.0 and id(net[2]) not in shard._net_no_grad
+    shard.zero_network_grads(net_opt)
+    nb2 = shard._net_bucket[1]
+    zeroed = zeroed and id(net[2]) in [id(p) for p in nb2.params] and all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in (net[2], net[3]))
     # bit-packed 0 / 1 rows: 3 rows of 21 flags, owner = index % world
     rows_all = [(torch.arange(21) % (k + 2) == 0).long() for k in range(3)]
     got = shard.gather_mask_rows({k: rows_all[k] for k in range(3) if shard.owns(k)}, 3, 21, torch.device("cpu"))

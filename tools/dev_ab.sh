@@ -1,12 +1,15 @@
 #!/bin/bash
 # A/B kernel timing on ONE box: runs the bench's per-kernel timing for each variant library under 4dgs-slam_amd/_variants/*.so
-# (built locally with: cd 4dgs-slam_amd/csrc && ./build.sh -DGSR_VARIANT_X=1 -o ../_variants/x.so), twice, interleaved.
+# (built locally with tools/dev_build_variants.sh name:"-DGSR_VARIANT_X=1" ...), REPS times (default 2), interleaved.
+# A variant may come with environment settings: <name>.env beside <name>.so (one line, VAR=value ...).
+# The timeline build (timeline.so) is skipped: it is read by tools/tile_timeline.py.
 cd /root/repo
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for lib in 4dgs-slam_amd/_variants/*.so; do
-    GSR_GLUE=ctypes GSR_LIB=$PWD/$lib python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+    case $lib in *timeline*|*timing*) continue;; esac
+    env $( [ -f ${lib%.so}.env ] && cat ${lib%.so}.env ) GSR_GLUE=ctypes GSR_LIB=$PWD/$lib python bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); k = d['kernel_us']; print('%-28s' % '$lib'.split('/')[-1], ' '.join('%s %.1f' % (n[:8], v) for n, v in k.items()), 'sum %.1f' % sum(k.values()), 'step %.1f us' % (d['ms_per_step'] * 1e3))
+d = json.loads(sys.stdin.read()); k = d['kernel_us']; print('%-28s' % '$lib'.split('/')[-1], ' '.join('%s %.1f' % (n[:8], v) for n, v in k.items()), 'sum %.1f' % sum(k.values()), 'step %.1f us' % (d['ms_per_step'] * 1e3), 'graph %.1f' % ((d.get('graph_replay') or {}).get('ms_per_step', 0) * 1e3))
 "
   done
 done
