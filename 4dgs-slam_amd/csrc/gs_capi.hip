@@ -183,6 +183,9 @@ static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] !
 // item_block_*; one extra block of the scatter launch ranks them). GSR_ORDER_ITEMS=0: tile order, as rounds 2-5 (A/B runs; the results are
 // bit-identical either way)
 static bool t_order_items = getenv("GSR_ORDER_ITEMS") ? getenv("GSR_ORDER_ITEMS")[0] != '0' : true;
+// render_fwd's blocks take the tiles of their XCD band by list length, dealt over the band's CUs (gs_forward.h F3c). GSR_ORDER_TILES=0: band order
+static bool t_order_tiles = getenv("GSR_ORDER_TILES") ? getenv("GSR_ORDER_TILES")[0] != '0' : true;
+static bool order_fwd_tiles(int T, bool lds_hist) { return t_order_items && t_order_tiles && lds_hist && T / 8 >= ORDER_FWD_MIN_BAND; }
 static void read_option_env()
 {
     if (t_options_read) return;
@@ -414,6 +417,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     ImageState img = ImageState::from(ichunk, N, (size_t)T, (size_t)P);
     const bool lds_hist = use_lds_hist((size_t)T);
     const size_t hist_lds_bytes = lds_hist ? (size_t)T * sizeof(uint32_t) : 0;
+    const bool order_items = t_order_items && lds_hist;        // (the ordering block keeps the tiles' list lengths in the same dynamic LDS)
     if (!radii) radii = geom.internal_radii;   // rasterizer_impl.cu:232-235
 
     // Zero-filled scratch: the flag word only when someone can raise it (prefiltered; the reference's callers never set it), the
@@ -512,11 +516,11 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
-            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks + (t_order_items ? 1 : 0)), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks + (order_items ? 1 : 0)), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
                                (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr,
-                               t_order_items ? img.tile_count : (uint32_t*)nullptr);
+                               order_items ? img.tile_count : (uint32_t*)nullptr, order_fwd_tiles(T, lds_hist) ? 1 : 0);
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here
@@ -557,7 +561,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                                background, img.final_T, img.n_contrib, out_color, out_depth,
                                out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
                                (const uint32_t*)bin.inst_gauss, bin.sorted, (const uint32_t*)img.chunk_base, bin.chunk_info,
-                               t_order_items ? (const uint32_t*)img.tile_count : (const uint32_t*)nullptr);
+                               order_items ? (const uint32_t*)img.tile_count : (const uint32_t*)nullptr, order_fwd_tiles(T, lds_hist) ? 1 : 0);
         }
         GSR_STAGE("render_fwd");
         return 0;
@@ -596,7 +600,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                            geom.rec, background, img.final_T, img.n_contrib, out_color,
                            out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
                            (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr,
-                           (const uint32_t*)nullptr);
+                           (const uint32_t*)nullptr, 0);
     }
     GSR_STAGE("render_fwd");
     return (int)R;
@@ -762,7 +766,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     {
         ScopedKernelTimer tm(K_SCATTER, stream);
         hipLaunchKernelGGL(scatter_views_kernel, dim3((unsigned)d.nblocks + (t_order_items ? 1u : 0u), (unsigned)V), dim3(GB), hist_lds_bytes, stream, t, d, a.eager,
-                           t_order_items ? 1 : 0);
+                           t_order_items ? (order_fwd_tiles(d.T, true) ? 3 : 1) : 0);
     }
     if (!t_fuse_sort || cap_tile > (uint32_t)SORT_SMALL_CAP) {
         ScopedKernelTimer tm(K_SORT, stream);
@@ -779,7 +783,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     }
     {
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
-        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0, t_order_items ? 1 : 0);
+        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0, t_order_items ? (order_fwd_tiles(d.T, true) ? 3 : 1) : 0);
     }
     GSR_HIP_CHECK(hipGetLastError());
     // one wait per view (they are all long done by the time the host has enqueued the tile kernels); a view that outgrew its capacity is

@@ -263,6 +263,7 @@ __host__ __device__ inline uint32_t item_block_partial(uint32_t N, uint32_t Pn, 
 }
 // where order_tiles_body leaves its results: the padding words of the per-tile counters (CTR_STRIDE words per tile, word 0 in use)
 constexpr int POS_FULL_BASE = 1, POS_PART_RANK = 2, POS_TOTAL_FULL = 1;   // tile_count[t * CTR_STRIDE + 1 / + 2]; tile_count[T * CTR_STRIDE + 1]
+constexpr int POS_FWD_TILE = 3;     // tile_count[i * CTR_STRIDE + 3]: the tile that render_fwd's block takes in place of tile i (order_fwd_tiles_body)
 struct BinningPtrs { uint4* chunk_info; uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
 __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted, size_t ntiles)
 {

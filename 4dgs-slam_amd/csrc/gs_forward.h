@@ -612,38 +612,68 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// F3b: where render_bwd's work items go (gs_device.h: item_block_*). ONE extra block of the scatter launch (it only needs the tile ranges,
-// which the scan wrote; it runs beside the scatter blocks and is done long before them: no launch of its own, nothing on the critical path).
-// Per tile: the number of FULL pieces (CHUNK entries) of the tiles in front of it, and the rank of its PARTIAL last piece among all partial
-// pieces of the frame, longest first (counting sort on the length 1 .. CHUNK - 1; inside a length the order comes from an LDS atomic and is
-// not fixed -- it only decides which block takes which piece: every piece writes its own instances' slots, the results do not depend on it).
+// F3b + F3c: ONE extra block of the scatter launch (it only needs the tiles' list lengths, which the scan wrote; it runs beside the scatter
+// blocks and is done before them: no launch of its own, nothing on the critical path) decides
+//  (b) where render_bwd's work items go (gs_device.h: item_block_*) -- per tile: the number of FULL pieces (CHUNK entries) of the tiles in
+//      front of it, and the rank of its PARTIAL last piece among all partial pieces of the frame, longest first;
+//  (c) which tile a render_fwd block takes. Every tile of a 640x480 frame is resident at once (1200 blocks, 4.7 per CU) and the launch lasts
+//      as long as its slowest block; a block is slow when its CU is crowded -- measured (tools/tile_timeline.py --raw): the dispatcher deals
+//      block b of XCD b % 8 to that XCD's CU (b / 8) % 32, so the first T / 8 - 128 CUs of an XCD host five blocks and the rest four; blocks
+//      last 48.7 us on average on the former, 45.4 on the latter, and the longest block of the launch always sat on a five-block CU. The tiles
+//      of an XCD's band (the band itself stays: neighbouring tiles share Gaussians, same L2) are dealt to the CUs by list length: longest
+//      first, in a serpentine over the 32 CUs whose first pass runs from the LAST CU down (the longest lists land on the CUs that get one
+//      block less) and whose last, partial pass hands the shortest lists to the CUs that get one more.
+// Both are counting sorts in LDS (lengths 1 .. CHUNK - 1; list length >> shift in 256 buckets per band); inside a bucket the order comes from an
+// LDS atomic and is not fixed -- it only decides which block takes which piece / tile, observed placement is used for speed only, and every
+// piece / tile writes its own outputs: the results do not depend on it.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_pos)
+constexpr int XCD_CUS = 32, ORDER_BUCKETS = 256;
+constexpr int ORDER_FWD_MIN_BAND = 2 * XCD_CUS;      // below: at most two blocks per CU, nothing to balance
+__device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict__ ranges, uint32_t* s_n /* [T], LDS */, uint32_t* __restrict__ tile_pos,
+                                                 const bool order_fwd, const uint32_t longest_list)
 {
     static_assert(CHUNK == 128 && GB == 1024, "128 lengths, 1024 threads");
-    __shared__ uint32_t s_len[CHUNK], s_tmp[17];
-    const uint32_t t = threadIdx.x;
+    __shared__ uint32_t s_len[CHUNK], s_tmp[17], s_band[8][ORDER_BUCKETS];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const int q = T >> 3, r = T & 7, head = r * (q + 1);
+    auto band_of = [&](int i) { return i < head ? i / (q + 1) : r + (i - head) / q; };
+    const int shift = max(0, 32 - __clz((int)max(longest_list, 1u)) - 8);                  // longest list >> shift < 256
     if (t < (uint32_t)CHUNK) s_len[t] = 0;
+    for (uint32_t k = t; k < 8u * ORDER_BUCKETS; k += GB) (&s_band[0][0])[k] = 0;
+    for (int i = (int)t; i < T; i += GB) { const uint2 g = ranges[i]; s_n[i] = g.y - g.x; }
     __syncthreads();
     for (int i = (int)t; i < T; i += GB) {
-        const uint2 r = ranges[i];
-        const uint32_t m = (r.y - r.x) & (uint32_t)(CHUNK - 1);
+        const uint32_t n = s_n[i], m = n & (uint32_t)(CHUNK - 1);
         if (m) atomicAdd(&s_len[m], 1u);
+        if (order_fwd) atomicAdd(&s_band[band_of(i)][ORDER_BUCKETS - 1 - min((uint32_t)ORDER_BUCKETS - 1u, n >> shift)], 1u);
     }
     __syncthreads();
-    // thread k < 128 holds length 127 - k: exclusive scan in DESCENDING length -> first rank of every length
+    // exclusive scans, descending: waves 0-1 over the 127 partial lengths (thread k holds length 127 - k), waves 2-9 over one band's buckets each
+    // (bucket index = 255 - key: ascending index is descending length; four consecutive buckets per lane)
     uint32_t v = 0, incl = 0;
-    if (t < (uint32_t)CHUNK) { v = s_len[CHUNK - 1 - t]; incl = wave_inclusive_scan(v); if (t == 63) s_tmp[0] = incl; }
+    if (wave < 2) { v = s_len[CHUNK - 1 - t]; incl = wave_inclusive_scan(v); if (t == 63) s_tmp[0] = incl; }
+    else if (wave < 10 && order_fwd) {
+        uint32_t* const b = &s_band[wave - 2][4 * lane];
+        const uint32_t c0 = b[0], c1 = b[1], c2 = b[2], c3 = b[3];
+        const uint32_t base = wave_inclusive_scan(c0 + c1 + c2 + c3) - (c0 + c1 + c2 + c3);
+        b[0] = base; b[1] = base + c0; b[2] = base + c0 + c1; b[3] = base + c0 + c1 + c2;
+    }
     __syncthreads();
-    if (t < (uint32_t)CHUNK) s_len[CHUNK - 1 - t] = incl - v + (t >= 64 ? s_tmp[0] : 0u);
+    if (wave < 2) s_len[CHUNK - 1 - t] = incl - v + (t >= 64 ? s_tmp[0] : 0u);
     __syncthreads();
     for (int i = (int)t; i < T; i += GB) {
-        const uint2 r = ranges[i];
-        const uint32_t m = (r.y - r.x) & (uint32_t)(CHUNK - 1);
+        const uint32_t n = s_n[i], m = n & (uint32_t)(CHUNK - 1);
         if (m) tile_pos[(size_t)i * CTR_STRIDE + POS_PART_RANK] = atomicAdd(&s_len[m], 1u);
+        if (order_fwd) {
+            const int x = band_of(i), start = x < r ? x * (q + 1) : head + (x - r) * q, size = x < r ? q + 1 : q;
+            const uint32_t rank = atomicAdd(&s_band[x][ORDER_BUCKETS - 1 - min((uint32_t)ORDER_BUCKETS - 1u, n >> shift)], 1u);
+            const uint32_t pass = rank / XCD_CUS, p = rank % XCD_CUS, passes = (uint32_t)(size + XCD_CUS - 1) / XCD_CUS;
+            const uint32_t cu = (pass + 1 == passes || (pass & 1u)) ? p : (uint32_t)XCD_CUS - 1u - p;
+            tile_pos[(size_t)(start + (int)(pass * XCD_CUS + cu)) * CTR_STRIDE + POS_FWD_TILE] = (uint32_t)i;
+        }
     }
     __syncthreads();
-    const uint32_t total_full = block_exclusive_scan_1024(T, [&](int i) { const uint2 r = ranges[i]; return (r.y - r.x) / (uint32_t)CHUNK; },
+    const uint32_t total_full = block_exclusive_scan_1024(T, [&](int i) { return s_n[i] / (uint32_t)CHUNK; },
                                                           [&](int i, uint32_t excl, uint32_t) { tile_pos[(size_t)i * CTR_STRIDE + POS_FULL_BASE] = excl; }, s_tmp);
     if (t == 0) tile_pos[(size_t)T * CTR_STRIDE + POS_TOTAL_FULL] = total_full;
 }
@@ -1160,10 +1190,13 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip, uint32_t* tile_pos)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip, uint32_t* tile_pos, int order_fwd)
 {
-    if (tile_pos != nullptr && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F3b)
-        if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) order_tiles_body(gx * gy, ranges, tile_pos);
+    if (tile_pos != nullptr && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F3b, F3c)
+        extern __shared__ uint32_t s_dyn[];
+        if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) {
+            order_tiles_body(gx * gy, ranges, s_dyn, tile_pos, order_fwd != 0, header[HDR_MAX_TILE]);
+        }
         return;
     }
     scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager, clip);

@@ -193,7 +193,7 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
                                                         uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
-                                                        const uint32_t* __restrict__ tile_pos)
+                                                        const uint32_t* __restrict__ tile_pos, int fwd_order)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     TL_BEGIN();
@@ -205,7 +205,8 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     __shared__ int s_nt[RB];                      // per-entry n_touched increments of this tile, flushed once per batch
     __shared__ __attribute__((aligned(8))) uint32_t s_idx[4][4][IDX_STRIDE];   // [quadrant wave][64-entry group]: LDS row offsets of the entries its mask keeps
 
-    const int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    int tile = xcd_tile_of_block(blockIdx.x, ntiles);
+    if (fwd_order) tile = (int)__builtin_amdgcn_readfirstlane((int)tile_pos[(size_t)tile * CTR_STRIDE + POS_FWD_TILE]);   // gs_forward.h F3c: same band, dealt by length
     const int tx = tile % gx, ty = tile / gx;
     const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
     const int px = tx * TILE_X + (wave & 1) * 8 + (lane & 7);
@@ -844,9 +845,9 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
                                                         uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
-                                                        const uint32_t* __restrict__ tile_pos)
+                                                        const uint32_t* __restrict__ tile_pos, int fwd_order)
 {
-    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos);
+    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos, fwd_order);
 }
 
 #ifndef GSR_BWD_WAVES

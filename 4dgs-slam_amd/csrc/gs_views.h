@@ -83,7 +83,10 @@ __global__ void __launch_bounds__(GB) scatter_views_kernel(ViewTable t, ViewDims
     const ImageState img = view_image(s, d);
     const BinningPtrs bin = view_binning(s, d);
     if (order_tiles && blockIdx.x == gridDim.x - 1) {                // the launch's extra block per view (gs_forward.h F3b)
-        if (!(geom.header[HDR_FLAGS] & FLAG_OVERFLOW)) order_tiles_body(d.T, img.ranges, img.tile_count);
+        extern __shared__ uint32_t s_dyn[];
+        if (!(geom.header[HDR_FLAGS] & FLAG_OVERFLOW)) {
+            order_tiles_body(d.T, img.ranges, s_dyn, img.tile_count, (order_tiles & 2) != 0, geom.header[HDR_MAX_TILE]);
+        }
         return;
     }
     scatter_instances_body(d.P, d.gx, d.gy, s.radii, geom.rec, geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewD
     const BinningPtrs bin = view_binning(s, d);
     render_fwd_body(d.T, d.gx, img.ranges, bin.sorted, d.W, d.H, geom.rec, bg, img.final_T, img.n_contrib, s.out_color, s.out_depth, s.out_opacity, s.n_touched,
                     img.final_C, bin.ckpt, geom.header, fuse_sort ? (const uint64_t*)bin.keys : nullptr, (const uint32_t*)bin.inst_gauss, bin.sorted,
-                    (const uint32_t*)img.chunk_base, bin.chunk_info, order_tiles ? (const uint32_t*)img.tile_count : nullptr);
+                    (const uint32_t*)img.chunk_base, bin.chunk_info, order_tiles ? (const uint32_t*)img.tile_count : nullptr, (order_tiles & 2) ? 1 : 0);
 }
 
 __global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg)

@@ -14,10 +14,11 @@ Workloads (``--workload auto``: cfg2 at N = 1, cfg5 at N > 1):
         value = P * 64 * K / time (Gaussian-views per second, whole job); strong scaling (the 64 views are fixed).
   long  a SLAM-shaped variant of cfg2 (scale_mean 0.03 -> tile lists of several thousand entries, SH degree 3): profiles/ only.
 
-One JSON line on rank 0 with `roofline` (dominant kernel = render_bwd, HIP events on its launch stream inside the timed region) and
-`cpu_baseline` (BASELINE.md's baseline A: the tile-binned pure-PyTorch CPU rasterizer oracle/torch_raster.py on all host cores; the
-single-core figure, and the C port single-threaded and under OpenMP, ride along). The oracle package is imported ONLY for that leg,
-outside the timed region. At N = 1 the line also carries a short cfg5 measurement (`config5`), at N > 1 a short weak-scaling
+One JSON line on rank 0 with `roofline` (dominant kernel = render_bwd, HIP events on its launch stream inside the timed region; `issue`
+carries the binding roof: VALU issue slots used at the part's 2-cycle rate, and occupancy against what registers / LDS allow) and
+`cpu_baseline` (the FASTEST CPU path on the box: the C restatement oracle/gs_oracle.c under OpenMP on all usable cores; the single-threaded
+C port and BASELINE.md's baseline A -- the tile-binned pure-PyTorch CPU rasterizer oracle/torch_raster.py -- ride along inside it). The oracle
+package is imported ONLY for that leg, outside the timed region. `m16`: the same workload at SH degree 3 (SURVEY.md 8d's second variant). At N = 1 the line also carries a short cfg5 measurement (`config5`), at N > 1 a short weak-scaling
 cfg2 measurement (`weak_200k`), rank 0's single-GPU time for the same cfg5 iteration (`n1_reference`) with `speedup_vs_n1` / `efficiency`
 derived from it, the ranks that took part (`ranks_seen`), the all-reduce alone (`allreduce_ms`) and the step with the exchange in two
 overlapped pieces (`two_piece_exchange_ms_per_step`). The N > 1 lines name their metric "Gaussian-views/s": a different workload and
@@ -192,7 +193,8 @@ def committed_traffic(kernel="render_bwd"):
 def committed_issue():
     """What actually bounds the two tile kernels -- instruction issue, not HBM -- from the newest committed counter collection
     (profiles/r*_tile_kernel_counters.json: SQ passes + rocprofv3's derived metrics of this same workload), quoted under the same digest rule
-    as the traffic figure: VALUBusy, mean resident waves per SIMD, wave-instructions per (quadrant, Gaussian) pair."""
+    as the traffic figure. Headline pair per kernel: `valu_frac` -- VALU wave-instructions x 2 cycles against the kernel's
+    cycles, i.e. priced at the part's rate -- and `occupancy_frac` -- mean resident waves per SIMD over what registers / LDS allow."""
     import glob
     digest = csrc_digest()
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_tile_kernel_counters.json")), reverse=True):
@@ -204,19 +206,36 @@ def committed_issue():
         if d.get("csrc_sha256") != digest:
             src["refused"] = "collected on different kernel sources: not quoted"
             return {"source": src}
-        out = {"source": src, "bound": "SIMD instruction issue (a wave64 VALU instruction occupies its SIMD for >= 2 cycles; a single wave issues one "
-                                       "instruction per ~9 cycles)"}
+        out = {"source": src, "bound": "SIMD instruction issue: a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md), so the roof is "
+                                       "kernel_cycles / 2 VALU wave-instructions per SIMD -- reached only with >= 4 ready waves per SIMD, because a single wave "
+                                       "issues one instruction per ~8 cycles (profiles/r02_ubench_issue.json)",
+               "how_to_read": "valu_frac = 2 cycles x SQ_INSTS_VALU / 1024 SIMDs / kernel cycles: the share of the VALU pipe's issue slots the launch uses, priced at "
+                              "the PART's rate whatever the occupancy was (SALU and LDS instructions issue on their own ports and are listed, not added). "
+                              "occupancy_frac = mean resident waves per SIMD / the waves the kernel's registers and LDS allow: what tails, prologues and "
+                              "uneven tiles leave unused. issue_frac_at_occupancy (rounds 4-5's `issue_frac`) prices an instruction at the cycles a SIMD needs "
+                              "at the launch's OWN mean occupancy: low occupancy lowers that roof instead of the fraction, so it is not an independent roof"}
+        LDS_PER_CU, REGS_PER_LANE = 160 * 1024, 512
         for k in ("render_fwd", "render_bwd"):
             e = d["kernels"].get(k, {})
             der = e.get("derived", {})
             ipw = der.get("instr_per_wave", {})
-            out[k] = {"VALUBusy_percent": e.get("VALUBusy"), "OccupancyPercent": e.get("OccupancyPercent"),
-                      "mean_waves_per_simd": der.get("mean_waves_per_simd"), "valu_busy_2cycle_view": der.get("valu_busy_2cycle_view"),
+            vg, lds, wg = e.get("_VGPR_Count"), e.get("_LDS_Block_Size"), e.get("_Workgroup_Size") or 256
+            allowed = None
+            if vg:
+                # (rocprofv3's kernel trace reports HALF the per-lane register count on gfx950: 40 / 44 for the 80 / 88 registers that
+                # hipcc -Rpass-analysis=kernel-resource-usage prints for these two kernels)
+                by_regs = min(8, REGS_PER_LANE // (-(-2 * int(vg) // 8) * 8))
+                by_lds = (LDS_PER_CU // int(lds)) * (int(wg) // 64) // 4 if lds else 8
+                allowed = max(1, min(by_regs, by_lds, 8))
+            occ = der.get("mean_waves_per_simd")
+            out[k] = {"valu_frac": der.get("valu_busy_2cycle_view"), "mean_waves_per_simd": occ, "waves_per_simd_allowed": allowed,
+                      "occupancy_frac": (occ / allowed) if occ and allowed else None,
+                      "VALUBusy_percent_gfx94x_formula": e.get("VALUBusy"), "OccupancyPercent": e.get("OccupancyPercent"),
                       "wave_instructions_per_wave": {n: ipw.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")},
                       "waves": e.get("SQ_WAVES")}
-        # the fraction of the ISSUE roof the kernel runs at: wave-instructions per SIMD x the cycles one of them costs a SIMD at the measured
-        # occupancy (profiles/r02_ubench_issue.json, independent v_fma_f32: 8.5 / 4.25 / 3.0 / 2.42 cycles at 1 / 2 / 3 / 4 waves per SIMD,
-        # interpolated) / the kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs) -- the binding roof of the tile kernels, next to the HBM `frac`
+        # rounds 4-5's figure, kept under its honest name: wave-instructions per SIMD x the cycles one of them costs a SIMD at the MEASURED occupancy
+        # (profiles/r02_ubench_issue.json, independent v_fma_f32: 8.5 / 4.25 / 3.0 / 2.42 cycles at 1 / 2 / 3 / 4 waves per SIMD, interpolated) / the
+        # kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs)
         try:
             ub = json.load(open(os.path.join(REPO, "profiles", "r02_ubench_issue.json")))
             cpi = next(r for r in ub["results"] if r["op"].startswith("v_fma_f32 independent"))["cycles_per_wave_instruction_per_simd"]
@@ -234,12 +253,13 @@ def committed_issue():
                 occ = out[k].get("mean_waves_per_simd")
                 if n_instr and cycles and occ:
                     c = cycles_per_instruction(float(occ))
-                    out[k]["issue_frac"] = n_instr / 1024.0 * c / cycles
-                    out[k]["issue_frac_inputs"] = {"wave_instructions_per_simd": n_instr / 1024.0, "cycles_per_wave_instruction_at_occupancy": c, "kernel_cycles": cycles}
-            if "issue_frac" in out.get("render_bwd", {}):
-                out["frac"] = out["render_bwd"]["issue_frac"]          # roofline.issue.frac: the dominant kernel's
+                    out[k]["issue_frac_at_occupancy"] = n_instr / 1024.0 * c / cycles
+                    out[k]["issue_frac_at_occupancy_inputs"] = {"wave_instructions_per_simd": n_instr / 1024.0, "cycles_per_wave_instruction_at_occupancy": c, "kernel_cycles": cycles}
         except Exception:
             pass
+        if out.get("render_bwd", {}).get("valu_frac") is not None:
+            out["frac"] = out["render_bwd"]["valu_frac"]            # roofline.issue.frac: the dominant kernel's share of the VALU issue roof
+            out["occupancy_frac"] = out["render_bwd"]["occupancy_frac"]
         # (quadrant, Gaussian) pairs per wave from the cycle-accounting build of the same sources, when it was collected with them
         pc = f.replace("_tile_kernel_counters.json", "_phase_cycles.json")
         try:
@@ -453,9 +473,18 @@ def cpu_baselines(scene_g, cam, gc, gd, P, sh_degree, budget_s):
         what += (f"per-Gaussian stage over all P, then a centred window of {n_win} of {gx * gy} tiles composited and back-propagated, median of 3, "
                  f"EXTRAPOLATED linearly in the tile count ({allc['seconds_window']:.2f} s per sample -> {allc['seconds_full_extrapolated']:.1f} s for "
                  f"the frame: the full frame did not fit the time budget on this host)")
-    base = {"value": value, "unit": "Gaussians/s", "cores": cores, "kind": "port", "sample": what,
-            "seconds_full_frame_measured": full_measured, "seconds_full_frame_window_estimate": allc["seconds_full_extrapolated"],
-            "torch_one_core": None if one is None else {"value": one["value"], "cores": 1, "seconds_full_extrapolated": one["seconds_full_extrapolated"]}}
+    torch_line = {"value": value, "unit": "Gaussians/s", "cores": cores, "kind": "port", "sample": what,
+                  "seconds_full_frame_measured": full_measured, "seconds_full_frame_window_estimate": allc["seconds_full_extrapolated"],
+                  "torch_one_core": None if one is None else {"value": one["value"], "cores": 1, "seconds_full_extrapolated": one["seconds_full_extrapolated"]}}
+    # `cpu_baseline` is the FASTEST CPU path on this box: the C restatement under OpenMP on all usable cores; the PyTorch tile-binned
+    # rasterizer (BASELINE.md's baseline A, what north_star's ">= 5x the host-CPU PyTorch fallback" refers to) and the single-threaded C port ride along
+    base = {"value": P / t_omp, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/gs_oracle.c built with OpenMP (libgs_oracle_omp.so: tile and per-Gaussian loops parallel; binning, key sort and preprocess "
+                      f"serial), ONE full fwd+bwd of the same workload ({P} Gaussians @{WIDTH}x{HEIGHT}), best of 2: {t_omp:.3f} s on {cores} threads -- the fastest "
+                      f"of the three CPU paths measured here",
+            "seconds": t_omp,
+            "c_port_one_thread": {"value": P / t_port1, "cores": 1, "seconds": t_port1, "sample": "oracle/gs_oracle.c, single-threaded, one full fwd+bwd"},
+            "torch_fallback": torch_line}
     port_line = {"value": P / t_port1, "unit": "Gaussians/s", "cores": 1, "kind": "port",
                  "sample": f"oracle/gs_oracle.c, one full fwd+bwd of the same workload ({t_port1:.2f} s), single-threaded",
                  "openmp_all_cores": {"value": P / t_omp, "cores": cores, "seconds": t_omp,
@@ -608,6 +637,26 @@ def main():
                 replayed = graph_replayed_step(scene, rank, max(args.steps, 20))
                 if replayed is not None:
                     out["graph_replay"] = replayed
+        # ---- secondary: SURVEY.md 8(d)'s M = 16 variant of the headline (SH degree 3): the one place where kernels of the step are bandwidth-bound ----
+        if world == 1 and workload == "cfg2" and P == CFG2_P and sh_degree == 0 and not args.no_secondary and rank == 0:
+            note("secondary: the headline workload at SH degree 3 (M = 16)")
+            s16 = Scene(P, dev, 3, scale_mean, keyframes=(rank,), cot_seed=1 + rank)
+            _, _, step16 = run_cfg2(s16, 1, 0, 0, 10, barrier, rank)
+            n16 = max(args.steps // 4, 20)
+            t16 = timed(step16, n16, 0, barrier) / n16
+            k16 = kernel_breakdown(step16)
+            V16, nr16 = s16.view_facts(rank)
+            b16, _ = algorithmic_bytes(P, V16, nr16, N, 16)
+            # what the SH coefficients add: 48 floats read by preprocess_fwd (visible Gaussians), 48 read + 48 written by geometry_bwd
+            sh_bytes = (48 * 4) * V16, (48 * 4) * (V16 + P)
+            out["m16"] = {"workload": f"configs[1] with SH degree 3 (M = 16): {P} Gaussians, 1 cam @{WIDTH}x{HEIGHT}, fwd+bwd", "ms_per_step": t16 * 1e3,
+                          "value": P / t16, "unit": "Gaussians/s", "steps": n16, "kernel_us": k16, "whole_step_algorithmic_bytes": b16,
+                          "coefficient_bytes": {"preprocess_fwd": sh_bytes[0], "geometry_bwd": sh_bytes[1]},
+                          "coefficient_GBps": {"preprocess_fwd": sh_bytes[0] / (k16.get("preprocess_fwd", 0) * 1e-6) / 1e9 if k16.get("preprocess_fwd") else None,
+                                               "geometry_bwd": sh_bytes[1] / (k16.get("geometry_bwd", 0) * 1e-6) / 1e9 if k16.get("geometry_bwd") else None},
+                          "note": "coefficient_GBps divides the SH coefficients' bytes alone by the whole kernel's time: a lower bound of what the kernel moves"}
+            del s16
+            torch.cuda.empty_cache()
         # ---- secondary: a short config #5 iteration on this one GPU (so that the N > 1 lines have a same-workload N = 1 point) ----
         if world == 1 and workload == "cfg2" and not args.no_secondary:
             note("secondary: config #5 iteration on one GPU")

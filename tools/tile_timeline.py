@@ -76,5 +76,13 @@ def analyse(a, name):
     return out
 
 
+if "--raw" in sys.argv:      # the raw records, for offline analysis (which CU took which block, in what order): index, start, end, HW_ID, XCC_ID
+    dst = sys.argv[sys.argv.index("--raw") + 1]
+    buf = (ctypes.c_uint32 * (8192 * 4))()
+    raw = {}
+    for which, name in ((0, "fwd"), (1, "bwd")):
+        assert lib.gsr_debug_spans(buf, 8192 * 4, which) == 0
+        raw[name] = np.frombuffer(buf, np.uint32).reshape(8192, 4).copy()
+    np.savez_compressed(dst, **raw)
 res = [analyse(spans(0), "render_fwd"), analyse(spans(1), "render_bwd")]
 print(json.dumps(res, indent=1) if "--json" in sys.argv else "\n".join(str(r) for r in res))
