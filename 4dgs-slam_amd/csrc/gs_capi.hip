@@ -185,7 +185,9 @@ static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] !
 static bool t_order_items = getenv("GSR_ORDER_ITEMS") ? getenv("GSR_ORDER_ITEMS")[0] != '0' : true;
 // render_fwd's blocks take the tiles of their XCD band by list length, dealt over the band's CUs (gs_forward.h F3c). GSR_ORDER_TILES=0: band order
 static bool t_order_tiles = getenv("GSR_ORDER_TILES") ? getenv("GSR_ORDER_TILES")[0] != '0' : true;
-static bool order_fwd_tiles(int T, bool lds_hist) { return t_order_items && t_order_tiles && lds_hist && T / 8 >= ORDER_FWD_MIN_BAND; }
+static const int t_deal_heavy = getenv("GSR_DEAL_HEAVY") ? atoi(getenv("GSR_DEAL_HEAVY")) : 1;      // lists per CU held back for the CUs with one block less (gs_forward.h)
+// 0: band order; 1 + heavy otherwise (the scatter launch's argument)
+static int order_fwd_tiles(int T, bool lds_hist) { return t_order_items && t_order_tiles && lds_hist && T / 8 >= ORDER_FWD_MIN_BAND ? 1 + std::max(0, std::min(7, t_deal_heavy)) : 0; }
 static void read_option_env()
 {
     if (t_options_read) return;
@@ -520,7 +522,7 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
                                (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr,
-                               order_items ? img.tile_count : (uint32_t*)nullptr, order_fwd_tiles(T, lds_hist) ? 1 : 0);
+                               order_items ? img.tile_count : (uint32_t*)nullptr, order_fwd_tiles(T, lds_hist));
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here
@@ -766,7 +768,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     {
         ScopedKernelTimer tm(K_SCATTER, stream);
         hipLaunchKernelGGL(scatter_views_kernel, dim3((unsigned)d.nblocks + (t_order_items ? 1u : 0u), (unsigned)V), dim3(GB), hist_lds_bytes, stream, t, d, a.eager,
-                           t_order_items ? (order_fwd_tiles(d.T, true) ? 3 : 1) : 0);
+                           t_order_items ? (order_fwd_tiles(d.T, true) ? 3 + 4 * (order_fwd_tiles(d.T, true) - 1) : 1) : 0);
     }
     if (!t_fuse_sort || cap_tile > (uint32_t)SORT_SMALL_CAP) {
         ScopedKernelTimer tm(K_SORT, stream);
@@ -783,7 +785,7 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     }
     {
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
-        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0, t_order_items ? (order_fwd_tiles(d.T, true) ? 3 : 1) : 0);
+        hipLaunchKernelGGL(render_fwd_views_kernel, tv, dim3(RB), 0, stream, t, d, background, t_fuse_sort ? 1 : 0, t_order_items ? (order_fwd_tiles(d.T, true) ? 3 + 4 * (order_fwd_tiles(d.T, true) - 1) : 1) : 0);
     }
     GSR_HIP_CHECK(hipGetLastError());
     // one wait per view (they are all long done by the time the host has enqueued the tile kernels); a view that outgrew its capacity is

@@ -630,7 +630,7 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
 constexpr int XCD_CUS = 32, ORDER_BUCKETS = 256;
 constexpr int ORDER_FWD_MIN_BAND = 2 * XCD_CUS;      // below: at most two blocks per CU, nothing to balance
 __device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict__ ranges, uint32_t* s_n /* [T], LDS */, uint32_t* __restrict__ tile_pos,
-                                                 const bool order_fwd, const uint32_t longest_list)
+                                                 const bool order_fwd, const uint32_t longest_list, const uint32_t heavy)
 {
     static_assert(CHUNK == 128 && GB == 1024, "128 lengths, 1024 threads");
     __shared__ uint32_t s_len[CHUNK], s_tmp[17], s_band[8][ORDER_BUCKETS];
@@ -667,9 +667,21 @@ __device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict_
         if (order_fwd) {
             const int x = band_of(i), start = x < r ? x * (q + 1) : head + (x - r) * q, size = x < r ? q + 1 : q;
             const uint32_t rank = atomicAdd(&s_band[x][ORDER_BUCKETS - 1 - min((uint32_t)ORDER_BUCKETS - 1u, n >> shift)], 1u);
-            const uint32_t pass = rank / XCD_CUS, p = rank % XCD_CUS, passes = (uint32_t)(size + XCD_CUS - 1) / XCD_CUS;
-            const uint32_t cu = (pass + 1 == passes || (pass & 1u)) ? p : (uint32_t)XCD_CUS - 1u - p;
-            tile_pos[(size_t)(start + (int)(pass * XCD_CUS + cu)) * CTR_STRIDE + POS_FWD_TILE] = (uint32_t)i;
+            // deal: the band's CUs get `base` blocks each, the first `more` of them one more (dispatch order, observed). The `heavy` longest
+            // lists per CU go to the CUs WITHOUT the extra block first, then whole passes over all CUs, and the shortest lists -- one pass more
+            // than was held back -- to the CUs with the extra block; every pass a serpentine (odd passes run backwards)
+            const uint32_t base = (uint32_t)size / XCD_CUS, more = (uint32_t)size % XCD_CUS, lean = (uint32_t)XCD_CUS - more, H = min(heavy, base);
+            auto snake = [](uint32_t pass, uint32_t p, uint32_t n) { return (pass & 1u) ? n - 1u - p : p; };
+            uint32_t c, j;
+            if (rank < lean * H) { j = rank / lean; c = more + snake(j, rank % lean, lean); }
+            else if (rank - lean * H < (uint32_t)XCD_CUS * (base - H)) {
+                const uint32_t r2 = rank - lean * H, pass = r2 / XCD_CUS;
+                c = snake(pass + H, r2 % XCD_CUS, XCD_CUS); j = c >= more ? H + pass : pass;
+            } else {
+                const uint32_t r3 = rank - lean * H - (uint32_t)XCD_CUS * (base - H), pass = r3 / more;
+                c = snake(pass + base, r3 % more, more); j = base - H + pass;
+            }
+            tile_pos[(size_t)(start + (int)(j * XCD_CUS + c)) * CTR_STRIDE + POS_FWD_TILE] = (uint32_t)i;
         }
     }
     __syncthreads();
@@ -1195,7 +1207,7 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
     if (tile_pos != nullptr && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F3b, F3c)
         extern __shared__ uint32_t s_dyn[];
         if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) {
-            order_tiles_body(gx * gy, ranges, s_dyn, tile_pos, order_fwd != 0, header[HDR_MAX_TILE]);
+            order_tiles_body(gx * gy, ranges, s_dyn, tile_pos, order_fwd != 0, header[HDR_MAX_TILE], (uint32_t)max(0, order_fwd - 1));
         }
         return;
     }

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(GB) scatter_views_kernel(ViewTable t, ViewDims
     if (order_tiles && blockIdx.x == gridDim.x - 1) {                // the launch's extra block per view (gs_forward.h F3b)
         extern __shared__ uint32_t s_dyn[];
         if (!(geom.header[HDR_FLAGS] & FLAG_OVERFLOW)) {
-            order_tiles_body(d.T, img.ranges, s_dyn, img.tile_count, (order_tiles & 2) != 0, geom.header[HDR_MAX_TILE]);
+            order_tiles_body(d.T, img.ranges, s_dyn, img.tile_count, (order_tiles & 2) != 0, geom.header[HDR_MAX_TILE], (uint32_t)(order_tiles >> 2));
         }
         return;
     }

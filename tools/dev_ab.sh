@@ -4,6 +4,8 @@
 # A variant may come with environment settings: <name>.env beside <name>.so (one line, VAR=value ...).
 # The timeline build (timeline.so) is skipped: it is read by tools/tile_timeline.py.
 cd /root/repo
+# which dispatch pattern this box has (the forward pass's tile dealing assumes round robin over 32 CUs per XCD): one line, when the timeline build is there
+[ -f 4dgs-slam_amd/_variants/timeline.so ] && GSR_GLUE=ctypes GSR_LIB=$PWD/4dgs-slam_amd/_variants/timeline.so python tools/dev_dispatch_census.py 2>/dev/null | tail -1
 for rep in $(seq 1 ${REPS:-2}); do
   for lib in 4dgs-slam_amd/_variants/*.so; do
     case $lib in *timeline*|*timing*) continue;; esac
