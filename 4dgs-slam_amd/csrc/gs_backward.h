@@ -31,6 +31,7 @@ struct GeomBwdArgs {
     // gradients are read). Their stores, the covariance -> scale / rotation chain and the SH coefficient gradients are skipped; the
     // output pointers may be NULL.
     int pose_only;
+    int sh_rows;   // SH coefficient rows through LDS (below); 0: per lane, as rounds 1-5
     // Raw mode (raw.xyz != nullptr, see gs_device.h): the inputs are the model's raw parameters and the outputs their gradients:
     // dL_dmean3D -> d/d_xyz, dL_dscale -> d/d_scaling [P,scale_dim], dL_drot -> d/d_rotation, dL_dopacity -> d/d_opacity (logit),
     // rawg.f_dc / f_rest -> d/d_features_*, rawg.ddx / dds / ddr [K,*] -> gradients of the control-node deltas.
@@ -77,7 +78,8 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     // loads in flight while the lanes sum the current one) -- no block barrier anywhere in the kernel.
     constexpr uint32_t COOP = 16;                        // Gaussians with more instances are summed by the whole wave (below)
     constexpr uint32_t WCH = 128;                        // slots per step of a wave's window
-    __shared__ float4 s_slot[4][WCH * 3];
+    static_assert(WCH * 3 * 4 <= SH_WIN_FLOATS, "the SH row window reuses the slot window");
+    __shared__ float4 s_slot[4][SH_WIN_FLOATS / 4];   // per wave: 128 instance slots (WCH * 3 float4), later the SH row window (64 x 25 floats)
     const bool coop = cnt > COOP;
     const uint32_t ser = coop ? 0u : cnt;
     const int wv = threadIdx.x >> 6;
@@ -231,10 +233,12 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     const bool has_sh = flow ? false : (RAW ? (RG.f_dc != nullptr || a.pose_only != 0) : (a.shs != nullptr && (a.dL_dsh != nullptr || a.pose_only != 0)));   // pose-only: the view-direction term of dL_dtau still needs the SH pass
     const ShOut dsh = RAW ? ShOut{RG.f_dc + 3 * o, RG.f_rest ? RG.f_rest + o * (size_t)(a.M - 1) * 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0}
                                 : ShOut{a.dL_dsh ? a.dL_dsh + i * a.M * 3 : nullptr, a.dL_dsh ? a.dL_dsh + i * a.M * 3 + 3 : nullptr, a.accumulate != 0, {old_c[0], old_c[1], old_c[2]}, a.pose_only != 0};
+    // SH rows through LDS (top of the file) for the coefficient counts the models use; a.sh_rows = 0 (gsr_set_option "sh_rows") keeps the per-lane path
+    const bool sh_staged = a.sh_rows && has_sh && (a.M == 9 || a.M == 16);
     if (!visible) {
         // (plain stores, not dsh[k] with a run-time k: that indexed dsh.old_dc dynamically and sent the whole struct to scratch memory -- the
         // 48 bytes per lane this kernel carried for three rounds)
-        if (has_sh && in_range && !a.accumulate && !a.pose_only) {
+        if (has_sh && !sh_staged && in_range && !a.accumulate && !a.pose_only) {
             dsh.dc[0] = 0.f; dsh.dc[1] = 0.f; dsh.dc[2] = 0.f;
             for (int k = 3; k < a.M * 3; k++) dsh.rest[k - 3] = 0.f;
         }
@@ -340,7 +344,7 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         }
 
         // ---- backward.cu:21-145: colour -> SH coefficients and (through the view direction) the mean ----
-        if (has_sh) {
+        if (has_sh && !sh_staged) {
             const ShView sh = sh_view(a.shs, R, i, a.M);
             const uint32_t cb = clamp_bits;
             const float dRGB[3] = {(cb & 1u) ? 0.f : g_r, (cb & 2u) ? 0.f : g_g, (cb & 4u) ? 0.f : g_b};   // :32-35
@@ -419,6 +423,112 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
             drot[1] = 2 * y * (Dm[1][0] + Dm[0][1]) + 2 * z * (Dm[2][0] + Dm[0][2]) + 2 * r * (Dm[1][2] - Dm[2][1]) - 4 * x * (Dm[2][2] + Dm[1][1]);
             drot[2] = 2 * x * (Dm[1][0] + Dm[0][1]) + 2 * r * (Dm[2][0] - Dm[0][2]) + 2 * z * (Dm[1][2] + Dm[2][1]) - 4 * y * (Dm[2][2] + Dm[0][0]);
             drot[3] = 2 * r * (Dm[0][1] - Dm[1][0]) + 2 * x * (Dm[2][0] + Dm[0][2]) + 2 * y * (Dm[1][2] + Dm[2][1]) - 4 * z * (Dm[1][1] + Dm[0][0]);
+        }
+    }
+    if (sh_staged) {
+        // ---- backward.cu:21-145 with the coefficient rows moved by the wave (helpers at the top of the file). Control flow is wave-uniform;
+        // `visible` lanes evaluate, the row copies cover the lanes their masks name. Order of the floating-point operations: as in the
+        // per-lane path above (per channel: degree 1, 2, 3 terms of dRGB/ddir in that order; the channels' contributions added in channel order).
+        float* const win = reinterpret_cast<float*>(s_slot[wv]);
+        const int deg = a.D, ncoef = a.M * 3;
+        const ShView sh = sh_view(a.shs, R, i, a.M);
+        const uint32_t cb = clamp_bits;
+        const float dRGB[3] = {(cb & 1u) || !visible ? 0.f : g_r, (cb & 2u) || !visible ? 0.f : g_g, (cb & 4u) || !visible ? 0.f : g_b};   // :32-35
+        const f3 dir_orig = mk3(mean.x - a.campos[0], mean.y - a.campos[1], mean.z - a.campos[2]);
+        const float inv = 1.0f / sqrtf(dot3(dir_orig, dir_orig));
+        const float x = dir_orig.x * inv, y = dir_orig.y * inv, z = dir_orig.z * inv;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float rx[3] = {0.f, 0.f, 0.f}, ry[3] = {0.f, 0.f, 0.f}, rz[3] = {0.f, 0.f, 0.f};      // dRGB/d{x,y,z} per channel
+        const unsigned long long rows_rd = __ballot(visible);
+        if (deg > 0 && rows_rd) {
+            stage_rows(win, rows_rd, sh.rest, 0, deg == 1 ? 9 : 24);                          // coefficients 3 .. 11 (degree 1) or 3 .. 26 (degrees 1 + 2)
+            if (visible) {
+                const float* c = win + lane * SH_WIN_STRIDE - 3;                                // c[k] = coefficient k of this Gaussian
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    rx[k] = -SH_C1 * c[9 + k]; ry[k] = -SH_C1 * c[3 + k]; rz[k] = SH_C1 * c[6 + k];
+                    if (deg > 1) {
+                        rx[k] += SH_C2[0] * y * c[12 + k] + SH_C2[2] * 2.f * -x * c[18 + k] + SH_C2[3] * z * c[21 + k] + SH_C2[4] * 2.f * x * c[24 + k];
+                        ry[k] += SH_C2[0] * x * c[12 + k] + SH_C2[1] * z * c[15 + k] + SH_C2[2] * 2.f * -y * c[18 + k] + SH_C2[4] * 2.f * -y * c[24 + k];
+                        rz[k] += SH_C2[1] * y * c[15 + k] + SH_C2[2] * 2.f * 2.f * z * c[18 + k] + SH_C2[3] * x * c[21 + k];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (deg > 2) {
+                stage_rows(win, rows_rd, sh.rest, 24, 21);                                      // coefficients 27 .. 47
+                if (visible) {
+                    const float* c = win + lane * SH_WIN_STRIDE - 27;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        rx[k] += SH_C3[0] * c[27 + k] * 3.f * 2.f * xy + SH_C3[1] * c[30 + k] * yz + SH_C3[2] * c[33 + k] * -2.f * xy +
+                                 SH_C3[3] * c[36 + k] * -3.f * 2.f * xz + SH_C3[4] * c[39 + k] * (-3.f * xx + 4.f * zz - yy) +
+                                 SH_C3[5] * c[42 + k] * 2.f * xz + SH_C3[6] * c[45 + k] * 3.f * (xx - yy);
+                        ry[k] += SH_C3[0] * c[27 + k] * 3.f * (xx - yy) + SH_C3[1] * c[30 + k] * xz + SH_C3[2] * c[33 + k] * (-3.f * yy + 4.f * zz - xx) +
+                                 SH_C3[3] * c[36 + k] * -3.f * 2.f * yz + SH_C3[4] * c[39 + k] * -2.f * xy + SH_C3[5] * c[42 + k] * -2.f * yz +
+                                 SH_C3[6] * c[45 + k] * -3.f * 2.f * xy;
+                        rz[k] += SH_C3[1] * c[30 + k] * xy + SH_C3[2] * c[33 + k] * 4.f * 2.f * yz + SH_C3[3] * c[36 + k] * 3.f * (2.f * zz - xx - yy) +
+                                 SH_C3[4] * c[39 + k] * 4.f * 2.f * xz + SH_C3[5] * c[42 + k] * (xx - yy);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (visible) {
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;   // dL/ddir
+#pragma unroll
+            for (int k = 0; k < 3; k++) { ddx += rx[k] * dRGB[k]; ddy += ry[k] * dRGB[k]; ddz += rz[k] * dRGB[k]; }   // :131
+            // dnormvdv, auxiliary.h:107-117
+            const f3 v = dir_orig;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            const float mx = ((+sum2 - v.x * v.x) * ddx - v.y * v.x * ddy - v.z * v.x * ddz) * invsum32;
+            const float my = (-v.x * v.y * ddx + (sum2 - v.y * v.y) * ddy - v.z * v.y * ddz) * invsum32;
+            const float mz = (-v.x * v.z * ddx - v.y * v.z * ddy + (sum2 - v.z * v.z) * ddz) * invsum32;
+            dmean[0] += mx; dmean[1] += my; dmean[2] += mz;       // :139
+            dtau[0] -= mx; dtau[1] -= my; dtau[2] -= mz;          // :141-143 (Q17 ii)
+        }
+        // ---- the coefficient gradients: DC per lane (three floats), the other bands as rows; rows of invisible Gaussians are zero (left alone in
+        // accumulate mode), coefficients above the active degree are zero
+        if (!a.pose_only) {
+            const bool wr = in_range && (visible || !a.accumulate);
+            if (wr) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) dsh[k] = SH_C0 * dRGB[k];                         // (an invisible Gaussian's dRGB is zero)
+            }
+            const bool have_rest = RAW ? RG.f_rest != nullptr : a.dL_dsh != nullptr;         // (uniform: the row masks live in scalar registers)
+            const unsigned long long rows_wr = have_rest ? __ballot(wr) : 0ull;
+            // (accumulate mode adds nothing above the active degree, as the per-lane path: the rows end at the degree's last coefficient)
+            const int ncols = a.accumulate ? (deg + 1) * (deg + 1) * 3 : ncoef;
+            if (rows_wr && ncols > 3) {
+                float* const w = win + lane * SH_WIN_STRIDE;
+                // (an invisible Gaussian's row is zero by SELECTION, not by multiplication: its direction is not a number when the camera sits at the origin)
+                const bool d1 = visible && deg > 0, d2 = visible && deg > 1, d3 = visible && deg > 2;
+                const int w1 = min(24, ncols - 3);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float g = dRGB[k];
+                    w[0 + k] = d1 ? -SH_C1 * y * g : 0.f; w[3 + k] = d1 ? SH_C1 * z * g : 0.f; w[6 + k] = d1 ? -SH_C1 * x * g : 0.f;
+                    if (w1 > 9) {
+                        w[9 + k] = d2 ? SH_C2[0] * xy * g : 0.f; w[12 + k] = d2 ? SH_C2[1] * yz * g : 0.f; w[15 + k] = d2 ? SH_C2[2] * (2.f * zz - xx - yy) * g : 0.f;
+                        w[18 + k] = d2 ? SH_C2[3] * xz * g : 0.f; w[21 + k] = d2 ? SH_C2[4] * (xx - yy) * g : 0.f;
+                    }
+                }
+                flush_rows(win, rows_wr, dsh.rest, 0, w1, a.accumulate != 0);
+                if (ncols > 27) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float g = dRGB[k];
+                        w[0 + k] = d3 ? SH_C3[0] * y * (3.f * xx - yy) * g : 0.f; w[3 + k] = d3 ? SH_C3[1] * xy * z * g : 0.f;
+                        w[6 + k] = d3 ? SH_C3[2] * y * (4.f * zz - xx - yy) * g : 0.f; w[9 + k] = d3 ? SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g : 0.f;
+                        w[12 + k] = d3 ? SH_C3[4] * x * (4.f * zz - xx - yy) * g : 0.f; w[15 + k] = d3 ? SH_C3[5] * z * (xx - yy) * g : 0.f;
+                        w[18 + k] = d3 ? SH_C3[6] * x * (xx - 3.f * yy) * g : 0.f;
+                    }
+                    flush_rows(win, rows_wr, dsh.rest, 24, 21, a.accumulate != 0);
+                }
+            }
         }
     }
     GEO_TICK(4);

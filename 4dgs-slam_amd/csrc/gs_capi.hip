@@ -183,6 +183,8 @@ static bool t_fuse_sort = getenv("GSR_FUSE_SORT") ? getenv("GSR_FUSE_SORT")[0] !
 // item_block_*; one extra block of the scatter launch ranks them). GSR_ORDER_ITEMS=0: tile order, as rounds 2-5 (A/B runs; the results are
 // bit-identical either way)
 static bool t_order_items = getenv("GSR_ORDER_ITEMS") ? getenv("GSR_ORDER_ITEMS")[0] != '0' : true;
+// SH coefficient rows move through LDS in preprocess_fwd / geometry_bwd (gs_backward.h); GSR_SH_ROWS=0: per lane (bit-identical results)
+static bool t_sh_rows = getenv("GSR_SH_ROWS") ? getenv("GSR_SH_ROWS")[0] != '0' : true;
 // render_fwd's blocks take the tiles of their XCD band by list length, dealt over the band's CUs (gs_forward.h F3c). GSR_ORDER_TILES=0: band order
 static bool t_order_tiles = getenv("GSR_ORDER_TILES") ? getenv("GSR_ORDER_TILES")[0] != '0' : true;
 static const int t_deal_heavy = getenv("GSR_DEAL_HEAVY") ? atoi(getenv("GSR_DEAL_HEAVY")) : 1;      // lists per CU held back for the CUs with one block less (gs_forward.h)
@@ -284,8 +286,8 @@ int gsr_set_option(const char* name, int value)
         if (value >= 0) t_cap_test_shrink_permille = value > 1000 ? 1000 : value;
         return old_shrink;
     }
-    bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : n == "order_items" ? &t_order_items : nullptr;
-    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, order_items, cap_margin_permille, cap_tile_margin_permille, cap_floor, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
+    bool* opt = n == "speculate" ? &t_speculate : n == "lazy" ? &t_lazy : n == "mailbox" ? &t_use_mailbox : n == "order_items" ? &t_order_items : n == "sh_rows" ? &t_sh_rows : nullptr;
+    if (!opt) { g_last_error = "gsr_set_option: unknown option '" + n + "' (speculate, lazy, mailbox, order_items, sh_rows, cap_margin_permille, cap_tile_margin_permille, cap_floor, view_slot_group)"; return GSR_ERR_INVALID_ARGUMENT; }
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;
@@ -451,9 +453,21 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         {
             ScopedKernelTimer tm(K_PREPROCESS, stream);
             a.eager = eager;
-            if (raw && raw->delta_mode) hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
-            else if (raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
-            else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nblocks), dim3(GB), hist_lds_bytes, stream, a);
+            // SH rows through LDS (gs_device.h: stage_rows): one 6.25 KB window per wave behind the tile histogram, reserved only when coefficients
+            // above the DC band are read (the LDS histogram path: the windows sit in the same dynamic allocation)
+            const bool sh_win = t_sh_rows && lds_hist && D > 0 && !colors_precomp && (M == 9 || M == 16) && !(raw && raw->flow_proj1);
+            a.sh_win_offset = sh_win ? (int)((hist_lds_bytes + 15) & ~size_t(15)) : 0;
+            const size_t pre_lds = sh_win ? (size_t)a.sh_win_offset + (size_t)(GB / 64) * SH_WIN_FLOATS * sizeof(float) : hist_lds_bytes;
+            if (sh_win) {
+                static std::atomic<unsigned long long> attr_set[3];
+                const void* fn = raw && raw->delta_mode ? reinterpret_cast<const void*>(preprocess_fwd_kernel<true, true>)
+                               : raw ? reinterpret_cast<const void*>(preprocess_fwd_kernel<true>) : reinterpret_cast<const void*>(preprocess_fwd_kernel<false>);
+                const int rc = ensure_dynamic_lds(fn, (int)pre_lds, attr_set[raw && raw->delta_mode ? 2 : raw ? 1 : 0]);
+                if (rc) return rc;
+            }
+            if (raw && raw->delta_mode) hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(nblocks), dim3(GB), pre_lds, stream, a);
+            else if (raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(nblocks), dim3(GB), pre_lds, stream, a);
+            else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(nblocks), dim3(GB), pre_lds, stream, a);
         }
         GSR_STAGE("preprocess_fwd");
         if (lds_hist) {
@@ -864,6 +878,7 @@ extern "C" int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, c
     a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.scale_modifier = scale_modifier;
     a.focal_y = height / (2.0f * tan_fovy); a.focal_x = width / (2.0f * tan_fovx); a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
     a.pose_only = pose_only ? 1 : 0;
+    a.sh_rows = t_sh_rows ? 1 : 0;
     a.raw = to_device_view(in);
     a.rawg = RawGrads{};
     a.rawg.scale_dim = in->scale_dim;
@@ -929,6 +944,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     a.dL_dmean3D = dL_dmean3D; a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.dL_dtau = dL_dtau;
     a.accumulate = accumulate ? 1 : 0;
     a.pose_only = pose_only ? 1 : 0;
+    a.sh_rows = t_sh_rows ? 1 : 0;
     a.tau_partials = dL_dtau_sum ? geom.tau_partials : nullptr;
     a.raw = to_device_view(raw);
     a.rawg = RawGrads{};

@@ -446,6 +446,78 @@ __device__ __forceinline__ f3 xform_point_4x3(f3 p, const float* __restrict__ m)
                m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
 }
 
+// j = index of the lowest set bit of m; clears it.  Two SALU instructions (the C idiom m &= m - 1 costs three plus the ff1).
+__device__ __forceinline__ int pop_lowest_bit(unsigned long long& m)
+{
+    int j;
+    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
+    return j;
+}
+
+// ---- SH coefficient rows through LDS (round 6) -----------------------------------------------------------------------------------------
+// A Gaussian's coefficients are one contiguous row ([M, 3] floats); read or written per lane -- lane = Gaussian, one coefficient per
+// instruction -- every load / store touches 64 different rows: 48 + 48 instructions of 64 memory transactions each at SH degree 3, which
+// made geometry_bwd the one bandwidth-bound kernel of the step and ran it at ~1 TB/s (96 us against 24 at M = 1, profiles/r05_long_lists.json;
+// preprocess_fwd: 35 against 15).
+// Here the wave moves ROWS: stage_rows() copies a column range of the rows of the lanes in `rows` into a wave-private LDS window, one
+// LDS-DMA instruction per row (global_load_lds: lane c fetches column c, the row lands contiguously, nothing passes through registers and
+// all rows are in flight at once); flush_rows() writes a window back, a row per store instruction. The window's row stride is odd, so lane =
+// row accesses are bank-conflict free. Same values, same arithmetic as the per-lane path -- only the data movement differs.
+constexpr int SH_WIN_STRIDE = 25;                 // floats per window row: up to 24 coefficients of a Gaussian (degrees 1 + 2, or degree 3's 21)
+constexpr int SH_WIN_FLOATS = 64 * SH_WIN_STRIDE;
+__device__ __forceinline__ const float* lane_pointer(const float* p, int src)      // lane src's pointer, wave-uniform
+{
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void stage_rows(float* win, unsigned long long rows, const float* row_ptr, int col0, int width)
+{
+    const int lane = lane_id();
+    typedef __attribute__((address_space(3))) float lds_float;
+    // the DMA's LDS address travels in M0: a scalar. The window pointer is wave-uniform but derived from the thread index, so it is made
+    // provably uniform here (readfirstlane of its 32-bit LDS offset)
+    const uint32_t win_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_float*)win);
+    if (lane < width) {                            // (the lane mask is set once around the loop: inside it, it cost the loop five more instructions per row)
+        while (rows) {
+            const int g = pop_lowest_bit(rows);
+            const float* src = lane_pointer(row_ptr, g) + col0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane),
+                                             (__attribute__((address_space(3))) void*)(lds_float*)(uintptr_t)(win_off + (uint32_t)(g * SH_WIN_STRIDE * 4)), 4, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);                 // the DMA writes are ordered by vmcnt only
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// acc: the stores ADD to what the destination holds (GSR_BACKWARD_ACCUMULATE); four rows per trip, so that their LDS reads (and old values)
+// are in flight together
+__device__ __forceinline__ void flush_rows(const float* win, unsigned long long rows, float* row_ptr, int col0, int width, bool acc)
+{
+    const int lane = lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the lanes' own row writes (the window is wave-private: DS operations of one wave execute in order)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < width) {
+        while (rows) {
+            float* dst[4]; float v[4], old[4]; bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                on[u] = rows != 0ull;
+                const int g = on[u] ? pop_lowest_bit(rows) : 0;
+                dst[u] = const_cast<float*>(lane_pointer(row_ptr, g)) + col0;
+                v[u] = win[g * SH_WIN_STRIDE + lane];
+                old[u] = (acc && on[u]) ? dst[u][lane] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (on[u]) dst[u][lane] = acc ? add_separately(old[u], v[u]) : v[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // XCD-aware tile order: block b runs on XCD b % 8 (observed, speed only); give each XCD a contiguous band of tiles
 // so neighbouring tiles (which share Gaussians) hit the same L2. Bijective for any tile count.
 __device__ __forceinline__ int xcd_tile_of_block(int b, int ntiles)

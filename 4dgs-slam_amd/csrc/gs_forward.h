@@ -85,6 +85,7 @@ struct PreprocessArgs {
     TileRec* rec; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; uint32_t* block_sums; uint32_t* tile_count; uint32_t* flags;   // flags: zero-filled together with tile_count
     uint32_t* block_tile_base;   // [nblocks][T] when the LDS histogram path is taken, else nullptr
+    int sh_win_offset;           // > 0: byte offset, in the dynamic LDS, of GB / 64 SH row windows (gs_device.h: stage_rows) -- the launch reserved them
     RawInputs raw;               // raw.xyz != nullptr: read the model's raw parameters instead (fused prologue, gs_device.h)
 };
 
@@ -218,6 +219,13 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
 
     uint32_t touched = 0;
     int rx0 = 0, ry0 = 0, rw = 0;
+    // SH rows through LDS (gs_device.h: stage_rows): when the launch reserved the windows and the colours come from SH coefficients above the DC
+    // band, a lane only NOTES that it needs a colour; the wave evaluates them together behind the per-Gaussian part (same arithmetic)
+    const bool sh_rows = a.sh_win_offset > 0 && a.D > 0 && a.colors_precomp == nullptr && !(RAW && R.flow_proj1 != nullptr) && (a.M == 9 || a.M == 16);
+    bool need_sh = false;
+    f3 sh_pos = mk3(0.f, 0.f, 0.f);
+    float sh_dc[3] = {0.f, 0.f, 0.f};
+    const float* sh_rest = nullptr;
     if (idx < a.P) {
         int my_radius = 0;
         if (a.n_touched) a.n_touched[idx] = 0;
@@ -304,6 +312,9 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
                         flow_ndc(R.flow_proj2, t2, u2, v2);
                         col = mk3(u2 - u1, v2 - v1, sl >= 0 ? 1.0f : 0.0f);
                         a.clamped[idx] = 0;
+                    } else if (a.colors_precomp == nullptr && sh_rows) {
+                        need_sh = true; sh_pos = p; sh_dc[0] = dc[0]; sh_dc[1] = dc[1]; sh_dc[2] = dc[2]; sh_rest = shv.rest;
+                        col = mk3(0.f, 0.f, 0.f);                    // (q2 is written by the wave-cooperative part below)
                     } else if (a.colors_precomp == nullptr) {
                         uint32_t cb;
                         col = sh_to_rgb(a.D, ShRegs{dc[0], dc[1], dc[2], shv.rest}, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), cb);
@@ -314,7 +325,7 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
                     TileRec* const rec = a.rec + idx;
                     rec->q0 = make_float4(px, py, p_view.z, opac);
                     rec->q1 = make_float4(cv.c * det_inv, -cv.b * det_inv, cv.a * det_inv, 0.f);
-                    rec->q2 = make_float4(col.x, col.y, col.z, 0.f);
+                    if (!need_sh) rec->q2 = make_float4(col.x, col.y, col.z, 0.f);
                     my_radius = (int)rad_f;
                     touched = (uint32_t)area;
                     rx0 = x0; ry0 = y0; rw = x1 - x0;
@@ -323,6 +334,58 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
         }
         a.radii[idx] = my_radius;
         a.tiles_touched[idx] = touched;
+    }
+    if (sh_rows) {
+        // forward.cu:22-73 with the coefficient rows moved by the wave: columns 3 .. 26 (degrees 1, 2), then 27 .. 47 (degree 3); per channel the
+        // same chain of operations as sh_to_rgb
+        const unsigned long long rows = __ballot(need_sh);
+        if (rows) {
+            float* const win = reinterpret_cast<float*>(reinterpret_cast<char*>(s_hist) + a.sh_win_offset) + (size_t)wave * SH_WIN_FLOATS;
+            const int deg = a.D;
+            const f3 dir = mk3(sh_pos.x - a.cam_pos[0], sh_pos.y - a.cam_pos[1], sh_pos.z - a.cam_pos[2]);
+            const float inv = 1.0f / sqrtf(dot3(dir, dir));
+            const float x = dir.x * inv, y = dir.y * inv, z = dir.z * inv;
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            float res[3] = {0.f, 0.f, 0.f};
+            stage_rows(win, rows, sh_rest, 0, deg == 1 ? 9 : 24);
+            if (need_sh) {
+                const float* sh = win + lane * SH_WIN_STRIDE - 3;          // sh[k] = coefficient k of this Gaussian, k >= 3
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float v = SH_C0 * sh_dc[k];
+                    v = v - SH_C1 * y * sh[3 + k] + SH_C1 * z * sh[6 + k] - SH_C1 * x * sh[9 + k];
+                    if (deg > 1)
+                        v = v + SH_C2[0] * xy * sh[12 + k] + SH_C2[1] * yz * sh[15 + k] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + k] +
+                            SH_C2[3] * xz * sh[21 + k] + SH_C2[4] * (xx - yy) * sh[24 + k];
+                    res[k] = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (deg > 2) {
+                stage_rows(win, rows, sh_rest, 24, 21);
+                if (need_sh) {
+                    const float* sh = win + lane * SH_WIN_STRIDE - 27;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        float v = res[k];
+                        v = v + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + k] + SH_C3[1] * xy * z * sh[30 + k] +
+                            SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + k] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + k] +
+                            SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + k] + SH_C3[5] * z * (xx - yy) * sh[42 + k] +
+                            SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + k];
+                        res[k] = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (need_sh) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) res[k] = res[k] + 0.5f;
+                a.clamped[idx] = (uint8_t)((res[0] < 0 ? 1u : 0u) | (res[1] < 0 ? 2u : 0u) | (res[2] < 0 ? 4u : 0u));  // forward.cu:69-71
+                a.rec[idx].q2 = make_float4(fmaxf(res[0], 0.f), fmaxf(res[1], 0.f), fmaxf(res[2], 0.f), 0.f);
+            }
+        }
     }
     PRE_TICK(g_pre_timing, 2);
     // (a) per-tile histogram: every (Gaussian, tile) instance adds one to its tile's counter.

@@ -66,13 +66,6 @@ __device__ __forceinline__ uint32_t quadrant_mask(float gx, float gy, float a, f
 __device__ __forceinline__ float exact_power(float dx, float dy, float a, float b, float c) { return -0.5f * (a * dx * dx + c * dy * dy) - b * dx * dy; }
 __device__ __forceinline__ float exact_exp(float x) { return (float)exp((double)x); }
 
-// j = index of the lowest set bit of m; clears it.  Two SALU instructions (the C idiom m &= m - 1 costs three plus the ff1).
-__device__ __forceinline__ int pop_lowest_bit(unsigned long long& m)
-{
-    int j;
-    asm("s_ff1_i32_b64 %0, %1\n\ts_bitset0_b64 %1, %0" : "=&s"(j), "+s"(m));
-    return j;
-}
 
 // pop_lowest_bit + row = j * 16 in a VGPR: the byte offset of staged entry j inside every 16-byte-per-entry LDS array. One VALU
 // instruction (the compiler's s_lshl + v_mov pair costs an SALU slot more) and, being volatile, it is neither recomputed nor

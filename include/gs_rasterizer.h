@@ -289,9 +289,11 @@ int gsr_debug_item_block(unsigned int n_items, unsigned int n_partial, unsigned 
  *                short blocks everywhere at once instead of a ~20 us tail. One extra block of the scatter launch ranks the pieces. The
  *                results are bit-identical either way (every piece writes its own instances' slots); 0 = tile order. Read by the FORWARD
  *                pass (which writes the work-item table).
+ *   "sh_rows" (default 1): the SH coefficients of a wave's 64 Gaussians move as whole rows through LDS (one DMA instruction / one store per
+ *                row) instead of one strided access per coefficient and lane; same arithmetic, bit-identical results. 0 = per lane.
  *   "cap_test_shrink_permille" (default 0 = off): TEST facility -- lay speculative buffers out for this fraction of the previous
  *                frame's count, so that overflows (and the callers' recovery paths) can be provoked deliberately.
- * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX, GSR_ORDER_ITEMS set the initial values. */
+ * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX, GSR_ORDER_ITEMS, GSR_SH_ROWS set the initial values. */
 int gsr_set_option(const char* name, int value);
 /* overflow_count: number of forward passes of this thread whose speculative capacity was too small (sticky);
  * last_num_rendered: num_rendered of the most recent forward pass the GPU has finished binning. Never blocks. */
