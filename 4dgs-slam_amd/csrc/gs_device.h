@@ -471,7 +471,8 @@ __device__ __forceinline__ const float* lane_pointer(const float* p, int src)   
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
 }
-__device__ __forceinline__ void stage_rows(float* win, unsigned long long rows, const float* row_ptr, int col0, int width)
+// stage_rows = stage_rows_issue (the DMA instructions; returns at once) + stage_rows_wait (everything landed, visible to the wave)
+__device__ __forceinline__ void stage_rows_issue(float* win, unsigned long long rows, const float* row_ptr, int col0, int width)
 {
     const int lane = lane_id();
     typedef __attribute__((address_space(3))) float lds_float;
@@ -486,10 +487,18 @@ __device__ __forceinline__ void stage_rows(float* win, unsigned long long rows, 
                                              (__attribute__((address_space(3))) void*)(lds_float*)(uintptr_t)(win_off + (uint32_t)(g * SH_WIN_STRIDE * 4)), 4, 0, 0);
         }
     }
+}
+__device__ __forceinline__ void stage_rows_wait()
+{
     __builtin_amdgcn_s_waitcnt(0);                 // the DMA writes are ordered by vmcnt only
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void stage_rows(float* win, unsigned long long rows, const float* row_ptr, int col0, int width)
+{
+    stage_rows_issue(win, rows, row_ptr, col0, width);
+    stage_rows_wait();
 }
 // acc: the stores ADD to what the destination holds (GSR_BACKWARD_ACCUMULATE); four rows per trip, so that their LDS reads (and old values)
 // are in flight together

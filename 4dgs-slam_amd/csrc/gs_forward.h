@@ -226,6 +226,14 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
     f3 sh_pos = mk3(0.f, 0.f, 0.f);
     float sh_dc[3] = {0.f, 0.f, 0.f};
     const float* sh_rest = nullptr;
+    // eager launches (small P: latency-bound, every row is requested up front anyway): the first band's rows of ALL the wave's Gaussians are
+    // requested here, before anything is known about their visibility, and land while the geometry below is computed
+    const bool sh_early = sh_rows && a.eager != 0;
+    float* const sh_win = sh_rows ? reinterpret_cast<float*>(reinterpret_cast<char*>(s_hist) + a.sh_win_offset) + (size_t)wave * SH_WIN_FLOATS : nullptr;
+    if (sh_early) {
+        const float* my_rest = idx < a.P ? sh_view(a.shs, R, (size_t)idx, a.M).rest : nullptr;
+        stage_rows_issue(sh_win, __ballot(idx < a.P), my_rest, 0, a.D == 1 ? 9 : 24);
+    }
     if (idx < a.P) {
         int my_radius = 0;
         if (a.n_touched) a.n_touched[idx] = 0;
@@ -339,15 +347,16 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
         // forward.cu:22-73 with the coefficient rows moved by the wave: columns 3 .. 26 (degrees 1, 2), then 27 .. 47 (degree 3); per channel the
         // same chain of operations as sh_to_rgb
         const unsigned long long rows = __ballot(need_sh);
+        if (sh_early && !rows) stage_rows_wait();          // (nothing visible in this wave: the early rows must still have landed before the window is reused)
         if (rows) {
-            float* const win = reinterpret_cast<float*>(reinterpret_cast<char*>(s_hist) + a.sh_win_offset) + (size_t)wave * SH_WIN_FLOATS;
+            float* const win = sh_win;
             const int deg = a.D;
             const f3 dir = mk3(sh_pos.x - a.cam_pos[0], sh_pos.y - a.cam_pos[1], sh_pos.z - a.cam_pos[2]);
             const float inv = 1.0f / sqrtf(dot3(dir, dir));
             const float x = dir.x * inv, y = dir.y * inv, z = dir.z * inv;
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             float res[3] = {0.f, 0.f, 0.f};
-            stage_rows(win, rows, sh_rest, 0, deg == 1 ? 9 : 24);
+            if (sh_early) stage_rows_wait(); else stage_rows(win, rows, sh_rest, 0, deg == 1 ? 9 : 24);
             if (need_sh) {
                 const float* sh = win + lane * SH_WIN_STRIDE - 3;          // sh[k] = coefficient k of this Gaussian, k >= 3
 #pragma unroll
