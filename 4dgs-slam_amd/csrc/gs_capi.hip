@@ -474,10 +474,10 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
             ScopedKernelTimer tm(K_SCAN, stream);
             if (nblocks <= TO_SEGS * 16)
                 hipLaunchKernelGGL((tile_offsets_kernel<TO_SEGS, 16>), dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS), 0, stream, nblocks, T,
-                               img.block_tile_base, img.tile_count);
+                               img.block_tile_base, img.tile_count, img.tile_cursor);      // (tile_cursor: free on this path; holds the dense list lengths)
             else
                 hipLaunchKernelGGL((tile_offsets_kernel<TO_SEGS_BIG, 32>), dim3((T + TO_COLS - 1) / TO_COLS), dim3(TO_COLS * TO_SEGS_BIG), 0, stream, nblocks, T,
-                               img.block_tile_base, img.tile_count);
+                               img.block_tile_base, img.tile_count, img.tile_cursor);
         }
         GSR_STAGE("tile_offsets");
     } else if (lds_hist) {
@@ -512,14 +512,19 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
                             : want_tile <= (uint32_t)SORT_MID_CAP ? (uint32_t)SORT_MID_CAP
                             : want_tile <= (uint32_t)SORT_LDS_CAP ? (uint32_t)SORT_LDS_CAP
                             : (want_tile + (uint32_t)SORT_LDS_CAP - 1) / (uint32_t)SORT_LDS_CAP * (uint32_t)SORT_LDS_CAP;
+    // F2b (gs_forward.h): on a speculative frame of the LDS-histogram path the scatter launch does the scan's work itself -- one launch less
+    // (GSR_SCAN_IN_SCATTER=0: the scan as its own launch, as rounds 1-5)
+    static const bool scan_in_scatter_ok = !(getenv("GSR_SCAN_IN_SCATTER") && getenv("GSR_SCAN_IN_SCATTER")[0] == '0');
+    const bool scan_in_scatter = scan_in_scatter_ok && speculate && lds_hist && nblocks <= GB;
     {
         ScopedKernelTimer tm(K_SCAN, stream);
         { const int rc = ensure_mailbox(); if (rc) return rc; }
         if (++t_seq == 0) t_seq = 1;
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
-                           img.ranges, img.tile_cursor, prefiltered ? flags : (const uint32_t*)nullptr, (uint32_t)cap, cap_tile, img.chunk_base,
-                           geom.header,
-                           t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
+        if (!scan_in_scatter)
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, geom.block_sums, geom.block_base, T, img.tile_count,
+                               img.ranges, img.tile_cursor, prefiltered ? flags : (const uint32_t*)nullptr, (uint32_t)cap, cap_tile, img.chunk_base,
+                               geom.header,
+                               t_use_mailbox ? t_mailbox_dev : nullptr, t_seq);
     }
     GSR_STAGE("scan");
 
@@ -532,11 +537,17 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         if (any_padding) GSR_HIP_CHECK(hipMemsetAsync(bin.keys, 0xFF, cap_sorted * sizeof(uint64_t), stream));   // sort padding
         {
             ScopedKernelTimer tm(K_SCATTER, stream);
-            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks + (order_items ? 1 : 0)), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
+            ScanInScatter sis{};
+            if (spec && scan_in_scatter) {
+                sis.dense_total = img.tile_cursor; sis.block_sums = geom.block_sums; sis.nblocks = nblocks; sis.ranges = img.ranges; sis.block_base = geom.block_base;
+                sis.chunk_base = img.chunk_base; sis.flags = prefiltered ? flags : (const uint32_t*)nullptr; sis.cap_R = (uint32_t)cap; sis.cap_tile_list = cap_tile;
+                sis.host_mailbox = t_use_mailbox ? t_mailbox_dev : nullptr; sis.seq = t_seq;
+            }
+            hipLaunchKernelGGL(scatter_instances_kernel, dim3(nblocks + (order_items || sis.dense_total ? 1 : 0)), dim3(GB), hist_lds_bytes, stream, P, gx, gy, radii, geom.rec,
                                geom.tiles_touched, geom.block_base, geom.point_offsets, img.tile_cursor, img.ranges,
                                lds_hist ? img.block_tile_base : nullptr, bin.keys, bin.inst_gauss, geom.header, spec ? 1 : 0,
                                (uint32_t)carve_R, (uint32_t)cap_sorted, eager, (raw && raw->flow_proj1) ? t_clip_single : (const int*)nullptr,
-                               order_items ? img.tile_count : (uint32_t*)nullptr, order_fwd_tiles(T, lds_hist));
+                               order_items ? img.tile_count : (uint32_t*)nullptr, order_fwd_tiles(T, lds_hist), sis);
         }
         GSR_STAGE("scatter_instances");
         if (!t_fuse_sort || long_lists) {   // lists of up to SORT_SMALL_CAP entries are sorted inside render_fwd (fused); longer ones here

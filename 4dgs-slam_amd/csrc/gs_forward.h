@@ -435,7 +435,7 @@ __device__ __forceinline__ void preprocess_fwd_body(PreprocessArgs a)
 constexpr int TO_COLS = 16, TO_SEGS = 16, TO_SEGS_BIG = 64;
 template <int SEGS, int RMAX>
 __device__ __forceinline__ void tile_offsets_body(int nblocks, int T, uint32_t* __restrict__ hist,
-                                                                      uint32_t* __restrict__ tile_count)
+                                                                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ dense_total = nullptr)
 {
     __shared__ uint32_t s_seg[SEGS][TO_COLS];
     const int c = threadIdx.x & (TO_COLS - 1), seg = threadIdx.x / TO_COLS;
@@ -474,7 +474,10 @@ __device__ __forceinline__ void tile_offsets_body(int nblocks, int T, uint32_t* 
                 run += x;
             }
         }
-        if (seg == 0) tile_count[(size_t)col * CTR_STRIDE] = total;
+        if (seg == 0) {
+            tile_count[(size_t)col * CTR_STRIDE] = total;
+            if (dense_total != nullptr) dense_total[col] = total;      // (contiguous copy for the scatter launch's own scan: ScanInScatter)
+        }
     }
 }
 
@@ -513,6 +516,27 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(int n, LOAD load, 
         __syncthreads();
     }
     return carry;
+}
+
+// n <= 2048, 1024 threads, ONE block barrier: thread t takes elements 2t and 2t + 1; the sixteen wave totals go through LDS and every thread adds up
+// the ones in front of its wave itself (sixteen broadcast reads) instead of waiting for a serial pass of thread 0 behind a second barrier.
+// extra[0 .. 15], extra2[0 .. 15] (optional, LDS): per-wave values the caller wants every thread to see behind the same barrier. Returns the total.
+template <typename LOAD, typename STORE>
+__device__ __forceinline__ uint32_t block_exclusive_scan_2048_once(int n, LOAD load, STORE store, uint32_t* s_tot /*[16]*/)
+{
+    const int t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+    const int i0 = 2 * t, i1 = i0 + 1;
+    const uint32_t v0 = i0 < n ? load(i0) : 0u, v1 = i1 < n ? load(i1) : 0u;
+    const uint32_t incl = wave_inclusive_scan(v0 + v1);
+    if (lane == 63) s_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const uint32_t x = s_tot[w]; base += w < wave ? x : 0u; total += x; }
+    const uint32_t e0 = base + incl - (v0 + v1);
+    if (i0 < n) store(i0, e0, v0);
+    if (i1 < n) store(i1, e0 + v0, v1);
+    return total;
 }
 
 __device__ __forceinline__ unsigned long long wave_inclusive_scan64(unsigned long long v)
@@ -605,6 +629,72 @@ __device__ __forceinline__ void scan_body(int nblocks, const uint32_t* block_sum
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// F2b (round 6): the scan INSIDE the scatter launch. On a speculative frame (the steady state: the binning buffer was laid out from the
+// previous frame, nobody waits for the instance count before the binning is enqueued) the one-block scan_kernel above was a launch of its
+// own between tile_offsets and scatter: 7.7 us of a 210 us step for a 1200-element prefix sum, plus a kernel boundary. Every scatter block
+// needs the tiles' first positions and the instances in front of its Gaussians; both are prefix sums of data that tile_offsets and
+// preprocess_fwd have already written, so every scatter block now forms them ITSELF (a 1200-element block scan in LDS and a 196-element
+// masked sum: ~1.5 us, in parallel on all blocks, no communication between blocks), and the launch's extra block -- the one that ranks
+// pieces and tiles (F3b, F3c) -- writes what the rest of the frame reads from memory: ranges, chunk_base, block_base, the header and the
+// host mailbox, exactly as scan_body does. The non-speculative path (first frame, or the redo of a frame that outgrew its buffer), where the
+// host needs the instance count BEFORE it can lay the buffer out, keeps scan_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+struct ScanInScatter {
+    const uint32_t* dense_total;     // [T] tile list lengths, contiguous (tile_offsets_body); nullptr: the scan ran as its own launch
+    const uint32_t* block_sums; int nblocks;
+    uint2* ranges; uint32_t* block_base; uint32_t* chunk_base;
+    const uint32_t* flags; uint32_t cap_R, cap_tile_list; uint32_t* host_mailbox; uint32_t seq;
+};
+// the extra block: everything scan_body writes, from the dense totals. s_n [T] (LDS) is left holding the list lengths; returns the longest
+// list in `longest` and whether the frame fits its speculative buffer.
+__device__ __forceinline__ bool scan_in_scatter_bookkeeping(int T, const ScanInScatter& m, uint32_t* s_n, uint32_t* __restrict__ header, uint32_t& longest)
+{
+    __shared__ uint32_t s_tmp[17], s_mx, s_t1[16], s_t2[16], s_t3[16];
+    if (threadIdx.x == 0) s_mx = 0;
+    uint32_t mx = 0, R, nchunks;
+    auto load_n = [&](int i) { const uint32_t v = m.dense_total[i]; s_n[i] = v; mx = max(mx, v); return v; };
+    auto store_range = [&](int i, uint32_t excl, uint32_t v) { m.ranges[i] = make_uint2(excl, excl + v); };
+    auto store_chunks = [&](int i, uint32_t excl, uint32_t) { m.chunk_base[i] = excl; };
+    auto load_bs = [&](int i) { return m.block_sums[i]; };
+    auto store_bb = [&](int i, uint32_t excl, uint32_t) { m.block_base[i] = excl; };
+    if (T <= 2048 && m.nblocks <= 2048) {            // three one-barrier scans (their wave totals in three arrays: no barrier between them either)
+        const int i0 = 2 * (int)threadIdx.x;
+        const uint32_t v0 = i0 < T ? load_n(i0) : 0u, v1 = i0 + 1 < T ? load_n(i0 + 1) : 0u;
+        auto pick = [&](int i) { return (i & 1) ? v1 : v0; };
+        R = block_exclusive_scan_2048_once(T, pick, store_range, s_t1);
+        nchunks = block_exclusive_scan_2048_once(T, [&](int i) { return (pick(i) + (uint32_t)CHUNK - 1) / (uint32_t)CHUNK; }, store_chunks, s_t2);
+        block_exclusive_scan_2048_once(m.nblocks, load_bs, store_bb, s_t3);
+    } else {
+        R = block_exclusive_scan_1024(T, load_n, store_range, s_tmp);
+        nchunks = block_exclusive_scan_1024(T, [&](int i) { return (s_n[i] + (uint32_t)CHUNK - 1) / (uint32_t)CHUNK; }, store_chunks, s_tmp);
+        block_exclusive_scan_1024(m.nblocks, load_bs, store_bb, s_tmp);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane_id() == 0) atomicMax(&s_mx, mx);
+    __syncthreads();
+    mx = s_mx;
+    longest = mx;
+    uint32_t err = m.flags ? __hip_atomic_load(m.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (m.cap_R && (R > m.cap_R || mx > m.cap_tile_list)) err |= (uint32_t)FLAG_OVERFLOW;
+    if (threadIdx.x == 0) {
+        m.chunk_base[T] = nchunks;
+        header[HDR_R] = R; header[HDR_FLAGS] = err; header[HDR_R_ALLOC] = R; header[HDR_MAX_TILE] = mx; header[HDR_CARVE_R] = m.cap_R;
+        header[HDR_CAP_SORTED] = m.cap_R; header[HDR_CHUNKS] = nchunks;
+        if (m.host_mailbox) {        // (as scan_body: pinned, host-coherent)
+            __hip_atomic_store(&m.host_mailbox[0], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&m.host_mailbox[1], err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&m.host_mailbox[2], R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&m.host_mailbox[3], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (err & (uint32_t)FLAG_OVERFLOW) __hip_atomic_fetch_add(&m.host_mailbox[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(&m.host_mailbox[4], m.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    return !(err & (uint32_t)FLAG_OVERFLOW);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // F3: scatter every (Gaussian, tile) instance into its tile's segment (replaces duplicateWithKeys,
 // rasterizer_impl.cu:70-111). Instance id u = point_offsets_exclusive[g] + k is the reference's position in the
 // unsorted duplicate list; since u grows with g, sorting by (depth bits, u) reproduces the reference's stable
@@ -616,9 +706,13 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip = nullptr)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip = nullptr,
+                                                               const ScanInScatter* scan = nullptr)
 {
-    if (speculative) {
+    const bool merged = scan != nullptr && scan->dense_total != nullptr;     // F2b: this launch does the scan's work (always a speculative frame)
+    if (merged) {
+        // (the header of this frame is being written by the launch's extra block: the overflow test is made from the block's own sums below)
+    } else if (speculative) {
         if (header[HDR_FLAGS] & FLAG_OVERFLOW) return;          // uniform: the buffer behind keys/inst_gauss is too small for this frame
     } else if (blockIdx.x == 0 && threadIdx.x == 0) {
         header[HDR_CARVE_R] = carve_R;                          // the host waited for R and laid the buffer out for exactly R
@@ -641,13 +735,49 @@ __device__ __forceinline__ void scatter_instances_body(int P, int gx, int gy, co
     if (eager && idx < P) { q0 = rec[idx].q0; my_radius = radii[idx]; }
     const uint32_t incl = wave_inclusive_scan(cnt);
     if (lane == 63) s_wave_sum[wave] = incl;
-    if (lds_path) {
+    __shared__ uint32_t s_red[2], s_scan_tmp[17], s_wmx[16], s_wbefore[16];
+    uint32_t merged_before = 0;          // F2b: instances of the Gaussian blocks in front of this one
+    if (merged) {
+        // F2b: first position of every tile = exclusive scan of the list lengths (every block forms it for itself), + this block's offset inside the
+        // tile's segment; the instances in front of this block's Gaussians = the sum of the earlier blocks' counts; the overflow test from the
+        // same sums the extra block writes into the header. Up to 2048 tiles all of it sits behind ONE block barrier (the one this kernel had).
         const uint32_t* row = block_tile_base + (size_t)blockIdx.x * T;
-        for (int t = threadIdx.x; t < T; t += GB) s_pos[t] = ranges[t].x + row[t];
+        uint32_t mx = 0, before = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += GB) before += scan->block_sums[b];
+        auto load_total = [&](int i) { const uint32_t v = scan->dense_total[i]; mx = max(mx, v); return v; };
+        auto store_pos = [&](int i, uint32_t excl, uint32_t) { s_pos[i] = excl + row[i]; };
+        uint32_t R;
+        if (T <= 2048) {
+            // (the per-wave maxima and sums ride behind the scan's barrier: the loads above are issued first, their values reduced here)
+            const uint32_t v0 = 2 * (int)threadIdx.x < T ? load_total(2 * (int)threadIdx.x) : 0u, v1 = 2 * (int)threadIdx.x + 1 < T ? load_total(2 * (int)threadIdx.x + 1) : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); before += __shfl_xor(before, d, 64); }
+            if (lane == 0) { s_wmx[wave] = mx; s_wbefore[wave] = before; }
+            R = block_exclusive_scan_2048_once(T, [&](int i) { return (i & 1) ? v1 : v0; }, store_pos, s_scan_tmp);
+            mx = 0; before = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) { mx = max(mx, s_wmx[w]); before += s_wbefore[w]; }
+        } else {
+            if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
+            R = block_exclusive_scan_1024(T, load_total, store_pos, s_scan_tmp);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); before += __shfl_xor(before, d, 64); }
+            if (lane == 0) { atomicMax(&s_red[0], mx); if (before) atomicAdd(&s_red[1], before); }
+            __syncthreads();
+            mx = s_red[0]; before = s_red[1];
+        }
+        merged_before = before;
+        if (scan->cap_R && (R > scan->cap_R || mx > scan->cap_tile_list)) return;      // uniform: the frame does not fit its speculative buffer
+        __syncthreads();                                                                // s_pos and s_wave_sum are complete
+    } else {
+        if (lds_path) {
+            const uint32_t* row = block_tile_base + (size_t)blockIdx.x * T;
+            for (int t = threadIdx.x; t < T; t += GB) s_pos[t] = ranges[t].x + row[t];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     PRE_TICK(g_sca_timing, 1);
-    uint32_t wbase = block_base[blockIdx.x];
+    uint32_t wbase = merged ? merged_before : block_base[blockIdx.x];
     for (int w = 0; w < wave; w++) wbase += s_wave_sum[w];
     const uint32_t off_incl = wbase + incl;
     if (idx < P) point_offsets[idx] = off_incl;
@@ -712,7 +842,7 @@ __device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict_
     const int shift = max(0, 32 - __clz((int)max(longest_list, 1u)) - 8);                  // longest list >> shift < 256
     if (t < (uint32_t)CHUNK) s_len[t] = 0;
     for (uint32_t k = t; k < 8u * ORDER_BUCKETS; k += GB) (&s_band[0][0])[k] = 0;
-    for (int i = (int)t; i < T; i += GB) { const uint2 g = ranges[i]; s_n[i] = g.y - g.x; }
+    if (ranges != nullptr) for (int i = (int)t; i < T; i += GB) { const uint2 g = ranges[i]; s_n[i] = g.y - g.x; }      // (nullptr: s_n holds the lengths already)
     __syncthreads();
     for (int i = (int)t; i < T; i += GB) {
         const uint32_t n = s_n[i], m = n & (uint32_t)(CHUNK - 1);
@@ -1256,9 +1386,9 @@ __global__ void __launch_bounds__(GB) preprocess_fwd_kernel(PreprocessArgs a)
 
 template <int SEGS, int RMAX>
 __global__ void __launch_bounds__(TO_COLS * SEGS) tile_offsets_kernel(int nblocks, int T, uint32_t* __restrict__ hist,
-                                                                      uint32_t* __restrict__ tile_count)
+                                                                      uint32_t* __restrict__ tile_count, uint32_t* __restrict__ dense_total)
 {
-    tile_offsets_body<SEGS, RMAX>(nblocks, T, hist, tile_count);
+    tile_offsets_body<SEGS, RMAX>(nblocks, T, hist, tile_count, dense_total);
 }
 
 __global__ void __launch_bounds__(1024) scan_kernel(int nblocks, const uint32_t* block_sums, uint32_t* block_base,
@@ -1274,16 +1404,22 @@ __global__ void __launch_bounds__(GB) scatter_instances_kernel(int P, int gx, in
                                                                const uint32_t* block_base, uint32_t* point_offsets,
                                                                uint32_t* tile_cursor, const uint2* ranges, const uint32_t* block_tile_base,
                                                                uint64_t* keys, uint32_t* inst_gauss, uint32_t* header, int speculative,
-                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip, uint32_t* tile_pos, int order_fwd)
+                                                               uint32_t carve_R, uint32_t cap_sorted, int eager, const int* clip, uint32_t* tile_pos, int order_fwd,
+                                                               ScanInScatter scan)
 {
-    if (tile_pos != nullptr && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F3b, F3c)
+    const bool merged = scan.dense_total != nullptr;
+    if ((tile_pos != nullptr || merged) && blockIdx.x == gridDim.x - 1) {        // the launch's extra block (F2b, F3b, F3c)
         extern __shared__ uint32_t s_dyn[];
-        if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) {
+        if (merged) {
+            uint32_t longest = 0;
+            const bool fits = scan_in_scatter_bookkeeping(gx * gy, scan, s_dyn, header, longest);
+            if (fits && tile_pos != nullptr) { __syncthreads(); order_tiles_body(gx * gy, nullptr, s_dyn, tile_pos, order_fwd != 0, longest, (uint32_t)max(0, order_fwd - 1)); }
+        } else if (!(speculative && (header[HDR_FLAGS] & FLAG_OVERFLOW))) {
             order_tiles_body(gx * gy, ranges, s_dyn, tile_pos, order_fwd != 0, header[HDR_MAX_TILE], (uint32_t)max(0, order_fwd - 1));
         }
         return;
     }
-    scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager, clip);
+    scatter_instances_body(P, gx, gy, radii, rec, tiles_touched, block_base, point_offsets, tile_cursor, ranges, block_tile_base, keys, inst_gauss, header, speculative, carve_R, cap_sorted, eager, clip, &scan);
 }
 
 template <int CAP, int LOWER>

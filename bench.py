@@ -507,6 +507,7 @@ def main():
     ap.add_argument("--view-by-view", action="store_true", help="cfg5: one rasterizer call per keyframe (round 3's step) instead of the multi-view entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the embedded secondary measurements (config5 / weak_200k / n1_reference)")
+    ap.add_argument("--graph-replay", action="store_true", help="with --no-secondary: still measure the step captured as one hipGraph (tools/dev_ab.sh)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-timeout", type=float, default=150.0)
     args = ap.parse_args()
@@ -633,7 +634,7 @@ def main():
                 out["roofline"]["evaluated_pair_evals_per_s_bwd"] = rb["pairs_per_wave"] * rb["waves"] * 64 / dom_s
             if nospec is not None:
                 out["ms_per_step_nonspeculative"] = nospec * 1e3
-            if world == 1 and not args.no_secondary:
+            if world == 1 and (not args.no_secondary or args.graph_replay):
                 replayed = graph_replayed_step(scene, rank, max(args.steps, 20))
                 if replayed is not None:
                     out["graph_replay"] = replayed

@@ -9,7 +9,7 @@ cd /root/repo
 for rep in $(seq 1 ${REPS:-2}); do
   for lib in 4dgs-slam_amd/_variants/*.so; do
     case $lib in *timeline*|*timing*) continue;; esac
-    env $( [ -f ${lib%.so}.env ] && cat ${lib%.so}.env ) GSR_GLUE=ctypes GSR_LIB=$PWD/$lib python bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+    env $( [ -f ${lib%.so}.env ] && cat ${lib%.so}.env ) GSR_GLUE=ctypes GSR_LIB=$PWD/$lib python bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-secondary --graph-replay 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); k = d['kernel_us']; print('%-28s' % '$lib'.split('/')[-1], ' '.join('%s %.1f' % (n[:8], v) for n, v in k.items()), 'sum %.1f' % sum(k.values()), 'step %.1f us' % (d['ms_per_step'] * 1e3), 'graph %.1f' % ((d.get('graph_replay') or {}).get('ms_per_step', 0) * 1e3))
 "
