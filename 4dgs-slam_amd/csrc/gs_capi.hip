@@ -141,9 +141,8 @@ constexpr int VIEW_SLOT_GROUPS = 4;                             // gsr_set_optio
 constexpr int SPEC_SLOTS = 1 + 2 * MAX_VIEWS * VIEW_SLOT_GROUPS;
 static thread_local SpecState t_spec[16][SPEC_SLOTS];   // [device][0 = single-view calls | per group: 1..V views of a batch | MAX_VIEWS+1.. views of a flow batch]
 static thread_local int t_view_slot_group = 0;
-// gsr_set_flow_clips: per view of the NEXT flow gsr_forward_views call of this thread, a device pointer to its tile rectangle (or null)
-static thread_local const int* t_view_clips[MAX_VIEWS] = {};
-static thread_local const int* t_clip_single = nullptr;     // the same for a view that goes through the single-view path inside that call
+// a flow view's tile rectangle (gsr_view.flow_clip) for a view that goes through the single-view path inside a gsr_forward_views call
+static thread_local const int* t_clip_single = nullptr;
 static thread_local SpecState* t_cur = &t_spec[0][0];
 static int select_device_state(int slot = 0)
 {
@@ -291,13 +290,6 @@ int gsr_set_option(const char* name, int value)
     const int old = *opt ? 1 : 0;
     if (value >= 0) *opt = value != 0;
     return old;
-}
-
-int gsr_set_flow_clips(int V, const int* const* clips)
-{
-    if (V < 0 || V > MAX_VIEWS) { g_last_error = "gsr_set_flow_clips: 0 <= V <= GSR_MAX_VIEWS"; return GSR_ERR_INVALID_ARGUMENT; }
-    for (int v = 0; v < MAX_VIEWS; v++) t_view_clips[v] = (clips && v < V) ? clips[v] : nullptr;
-    return 0;
 }
 
 int gsr_forward_status(unsigned int* overflow_count, unsigned int* last_num_rendered)
@@ -700,10 +692,6 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
                                  float tan_fovy, int debug, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    // gsr_set_flow_clips (deprecated): whatever is pending is taken and cleared HERE, before anything can return -- a call that fails its
-    // checks, or a non-flow call, must not leave rectangles (possibly dangling device pointers) for a later, unrelated flow batch
-    const int* pending_clips[MAX_VIEWS];
-    for (int v = 0; v < MAX_VIEWS; v++) { pending_clips[v] = t_view_clips[v]; t_view_clips[v] = nullptr; }
     if (V < 1 || V > MAX_VIEWS || !views || !in || P <= 0 || width <= 0 || height <= 0 || !geometry_alloc || !binning_alloc || !image_alloc || !background ||
         M <= 0 || D < 0 || D > 3 || (D + 1) * (D + 1) > M || in->gather || in->flow_proj1) {
         g_last_error = "gsr_forward_views: invalid argument (1 <= V <= GSR_MAX_VIEWS, P > 0, raw inputs without gather; flow mode is per view)"; return GSR_ERR_INVALID_ARGUMENT;
@@ -722,8 +710,8 @@ extern "C" int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_a
     // several (view_slot_group): a slot shared by two calls per iteration sees its estimate flip between two cameras -- eager calls then redo
     // the view through the single-view path every time, captured ones overflow at every replay
     const int slot0 = 1 + t_view_slot_group * 2 * MAX_VIEWS + (flow ? MAX_VIEWS : 0);
-    const int* clips[MAX_VIEWS];                             // a flow view's tile rectangle: gsr_view.flow_clip, else what gsr_set_flow_clips left
-    for (int v = 0; v < MAX_VIEWS; v++) clips[v] = (flow && v < V) ? (views[v].flow_clip ? views[v].flow_clip : pending_clips[v]) : nullptr;
+    const int* clips[MAX_VIEWS];                             // a flow view's tile rectangle: gsr_view.flow_clip
+    for (int v = 0; v < MAX_VIEWS; v++) clips[v] = (flow && v < V) ? views[v].flow_clip : nullptr;
     const ViewDims d = view_dims(P, width, height);
     read_option_env();
     // the batched path needs a capacity estimate for every slot (the first iteration of a window goes view by view and leaves one)

@@ -308,7 +308,7 @@ struct RawInputs {
     const float* f_dc; const float* f_rest; const int* dyn_slot; const float* dx; const float* ds; const float* dr;
     const int* gather;   // optional: rasterized Gaussian i reads row gather[i] of the raw tensors (render()'s boolean mask, :179-191)
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2;   // flow mode (render_flow, :229-361): see include/gs_rasterizer.h
-    const int* flow_clip;        // flow mode, optional: tile rectangle [x0, y0, x1, y1) outside of which nothing is needed (gsr_set_flow_clips)
+    const int* flow_clip;        // flow mode, optional: tile rectangle [x0, y0, x1, y1) outside of which nothing is needed (gsr_view.flow_clip)
     // delta_mode 1 (kernels instantiated with PRE = true): dx / ds / dr are the outputs of the 4DGaussians deformation network
     // (gaussian_renderer/__init__.py:149-157, utils/deformation.py:113-149), added to the RAW parameters IN FRONT of the activations:
     // scales = exp(_scaling + ds), rotations = normalize(_rotation + dr) -- not the control-node deltas of :159-174, which are added behind

@@ -29,7 +29,7 @@ struct ViewSlot {
     uint32_t* mailbox; uint32_t cap; uint32_t cap_tile; uint32_t seq;
     // flow mode (render_flow, gs_rasterizer.h gsr_raw_inputs.flow_*): this view's second displacement and the two projections; ddx2 its gradient
     const float* flow_dx2; const float* flow_proj1; const float* flow_proj2; float* ddx2;
-    const int* flow_clip;                                                   // optional tile rectangle of a flow view (gsr_set_flow_clips)
+    const int* flow_clip;                                                   // optional tile rectangle of a flow view (gsr_view.flow_clip)
 };
 struct ViewTable { ViewSlot v[MAX_VIEWS]; };
 static_assert(sizeof(ViewTable) + sizeof(PreprocessArgs) + 64 <= 4096 && sizeof(ViewTable) + sizeof(GeomBwdArgs) + 64 <= 4096,

@@ -115,26 +115,6 @@ def set_option(name: str, value: int = -1) -> int:
     return rc
 
 
-def set_flow_clips(clips):
-    """gsr_set_flow_clips (include/gs_rasterizer.h): per view of the NEXT flow call of rasterize_flow_views_raw on this thread, an int32 [4]
-    device tensor (tile rectangle [x0, y0, x1, y1) the caller reads) or None. The caller keeps the tensors alive until the call has run
-    (a captured call: as long as the graph is replayed)."""
-    import ctypes as C
-    lib = load_library()
-    n = len(clips) if clips else 0
-    arr = (C.c_void_p * max(1, n))()
-    for v in range(n):
-        t = clips[v]
-        if t is not None:
-            if t.dtype != torch.int32 or t.numel() != 4 or not t.is_cuda or not t.is_contiguous():
-                raise ValueError("set_flow_clips: int32 [4] contiguous device tensors (or None)")
-            arr[v] = t.data_ptr()
-    lib.gsr_set_flow_clips.argtypes = [C.c_int, C.c_void_p]
-    rc = lib.gsr_set_flow_clips(n, arr if n else None)
-    if rc < 0:
-        _err(lib, rc, "gsr_set_flow_clips")
-
-
 def debug_view_slots(max_slots: int = 8):
     """Per capacity slot of this thread (0 = single-view calls, then the view slots of the multi-view entry point): what the GPU last
     reported -- num_rendered, flags, R_alloc, longest tile list, sequence number, sticky overflow count -- and the estimates the next

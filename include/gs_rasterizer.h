@@ -220,11 +220,6 @@ typedef struct gsr_view {
 int gsr_forward_views(int V, gsr_view* views, gsr_alloc_fn geometry_alloc, gsr_alloc_fn binning_alloc, gsr_alloc_fn image_alloc,
                       int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in, float scale_modifier,
                       float tan_fovx, float tan_fovy, int debug, void* stream);
-/* DEPRECATED in favour of gsr_view.flow_clip (round 4's interface, kept for callers that fill gsr_view without that field): clips[v] for the NEXT
- * gsr_forward_views call of this thread, used for a view whose own flow_clip is NULL. The pending clips are taken and cleared at the very top of
- * EVERY gsr_forward_views call -- flow or not, valid arguments or not -- so that a call that fails, or a caller that raises between the two
- * calls, cannot leave rectangles behind for an unrelated later batch. */
-int gsr_set_flow_clips(int V, const int* const* clips);
 /* scratch: device memory of gsr_views_scratch_size() bytes (one row of parameter gradients per view); not needed with GSR_BACKWARD_POSE_ONLY */
 size_t gsr_views_scratch_size(int V, int P, int M, int scale_dim);
 int gsr_backward_views(int V, gsr_view* views, int P, int D, int M, const float* background, int width, int height,

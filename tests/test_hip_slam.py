@@ -703,7 +703,7 @@ def _directly_executed_dynamic_run():
 
 
 def test_flow_images_are_rendered_only_where_the_loss_reads_them():
-    """gsr_set_flow_clips: the dynamic mapping call renders every flow image with the Gaussians' tile rectangles clipped to the rectangle of
+    """gsr_view.flow_clip: the dynamic mapping call renders every flow image with the Gaussians' tile rectangles clipped to the rectangle of
     its loss mask (the keyframe's moving pixels). Checked inside a real run (Training.flow_clip_check renders every direct iteration's flow
     images again without the clips): the masked images are EQUAL, the gradients of the flow loss agree to rounding (the per-Gaussian sums
     of instance slots lose exact zeros, which regroups a tree sum), and the clips really remove work."""
