@@ -49,9 +49,11 @@ __device__ __forceinline__ void topk_insert(float (&bd)[KMAX], int (&bi)[KMAX], 
 template <int KMAX>
 __device__ __forceinline__ float topk_worst(const float (&bd)[KMAX], const int K)
 {
+    // the list is ascending (unfilled places hold +inf), so its K-th entry is the maximum of the first K; written as a maximum because the
+    // select chain `k < K ? bd[k] : w` is recognised as bd[K - 1] -- a run-time index that sent the whole list to scratch memory (32-144 B per lane)
     float w = bd[0];
 #pragma unroll
-    for (int k = 1; k < KMAX; k++) w = k < K ? bd[k] : w;
+    for (int k = 1; k < KMAX; k++) w = fmaxf(w, k < K ? bd[k] : w);
     return w;
 }
 
