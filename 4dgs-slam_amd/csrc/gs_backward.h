@@ -60,8 +60,8 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     const int radius = in_range ? a.radii[idx] : 0;
     const uint32_t touched = in_range ? a.tiles_touched[idx] : 0u;
     const uint32_t incl = in_range ? a.point_offsets[idx] : 0u;
-    const float4* __restrict__ partials = carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], a.header[HDR_CAP_SORTED],
-                                                        (size_t)(((a.W + TILE_X - 1) / TILE_X) * ((a.H + TILE_Y - 1) / TILE_Y))).partials;
+    const float* __restrict__ partials = reinterpret_cast<const float*>(carve_binning(const_cast<char*>(a.bin_base), a.header[HDR_CARVE_R], a.header[HDR_CAP_SORTED],
+                                                        (size_t)(((a.W + TILE_X - 1) / TILE_X) * ((a.H + TILE_Y - 1) / TILE_Y))).partials);
     if (a.header[HDR_FLAGS] & FLAG_OVERFLOW) return;     // lazy forward pass that outgrew its buffer: there are no instance slots to sum (tested
                                                          // HERE, behind the level-1 loads: in front of them it was a global latency of its own)
     const bool visible = radius > 0;                     // backward.cu:163,443
@@ -78,8 +78,9 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     // loads in flight while the lanes sum the current one) -- no block barrier anywhere in the kernel.
     constexpr uint32_t COOP = 16;                        // Gaussians with more instances are summed by the whole wave (below)
     constexpr uint32_t WCH = 128;                        // slots per step of a wave's window
-    static_assert(WCH * 3 * 4 <= SH_WIN_FLOATS, "the SH row window reuses the slot window");
-    __shared__ float4 s_slot[4][SH_WIN_FLOATS / 4];   // per wave: 128 instance slots (WCH * 3 float4), later the SH row window (64 x 25 floats)
+    static_assert(WCH * SLOT_FLOATS <= SH_WIN_FLOATS && (WCH * SLOT_FLOATS) % 4 == 0, "the SH row window reuses the slot window");
+    constexpr int WIN4 = WCH * SLOT_FLOATS / 4;       // float4 per full window (320: five per lane)
+    __shared__ float4 s_slot[4][SH_WIN_FLOATS / 4];   // per wave: 128 instance slots (1280 floats), later the SH row window (64 x 25 floats)
     const bool coop = cnt > COOP;
     const uint32_t ser = coop ? 0u : cnt;
     const int wv = threadIdx.x >> 6;
@@ -87,12 +88,12 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
     const uint32_t W1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, min(63, a.P - 1 - (blockIdx.x * 256 + wv * 64)));
     const bool any_ser = __any(ser > 0);
     float g_m2x = 0.f, g_m2y = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-    float4 nx[6];
-    auto fetch_window = [&](uint32_t c0) {      // this lane's six float4 of the window that starts at slot c0
-        const uint32_t n3 = min(WCH, W1 - c0) * 3u;
-        const float4* src = partials + (size_t)c0 * 3;
+    float4 nx[WIN4 / 64];
+    auto fetch_window = [&](uint32_t c0) {      // this lane's five float4 of the window that starts at slot c0 (8-byte aligned: 40-byte slots)
+        const uint32_t n4 = (min(WCH, W1 - c0) * (uint32_t)SLOT_FLOATS + 3u) / 4u;      // (an odd slot count ends in half a float4: its other half is the next slot's, or padding)
+        const float4_a8* src = reinterpret_cast<const float4_a8*>(partials + (size_t)c0 * SLOT_FLOATS);
 #pragma unroll
-        for (int j = 0; j < 6; j++) nx[j] = (uint32_t)lane + 64u * j < n3 ? src[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < WIN4 / 64; j++) nx[j] = (uint32_t)lane + 64u * j < n4 ? (float4)src[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     const bool wave_has_slots = any_ser && W0 < W1;                 // uniform per wave (lanes beyond P take part in the window copy)
     // Only windows that hold a slot of a serially summed Gaussian are copied: on a SLAM-sized map most of a wave's range belongs to
@@ -145,18 +146,18 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
         float4* const win = s_slot[wv];
         for (uint32_t c0 = first_window, cn; c0 < W1; c0 = cn) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) win[lane + 64 * j] = nx[j];
+            for (int j = 0; j < WIN4 / 64; j++) win[lane + 64 * j] = nx[j];
             cn = next_needed_window(c0 + WCH);
             if (cn < W1) fetch_window(cn);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the window is wave-private: DS operations of one wave execute in order
             __builtin_amdgcn_wave_barrier();
             const uint32_t lo = max(u0, c0), hi = min(u0 + ser, min(c0 + WCH, W1));
             for (uint32_t u = lo; u < hi; u++) {                       // ascending instance order: the order every earlier revision summed in
-                const float4* sl = win + (u - c0) * 3;
-                const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
-                g_m2x += v0.x; g_m2y += v0.y; g_cx += v0.z; g_cy += v0.w;
-                g_cw += v1.x; g_op += v1.y; g_r += v1.z; g_g += v1.w;
-                g_b += v2.x; g_d += v2.y;
+                const float2* sl = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(win) + (u - c0) * SLOT_FLOATS);   // ten floats, 8-byte aligned
+                const float2 v0 = sl[0], v1 = sl[1], v2 = sl[2], v3 = sl[3], v4 = sl[4];
+                g_m2x += v0.x; g_m2y += v0.y; g_cx += v1.x; g_cy += v1.y;
+                g_cw += v2.x; g_op += v2.y; g_r += v3.x; g_g += v3.y;
+                g_b += v4.x; g_d += v4.y;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -175,30 +176,30 @@ __device__ __forceinline__ void geometry_bwd_body(GeomBwdArgs a)
             int h = pop_lowest_bit(cm);
             uint32_t hc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h), hu = (uint32_t)__builtin_amdgcn_readlane((int)u0, h);
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 p0 = zero4, p1 = zero4, p2 = zero4;
+            const float2 zero2 = make_float2(0.f, 0.f);
+            float4 p0 = zero4, p1 = zero4; float2 p2 = zero2;
             bool pv = (uint32_t)lane < hc;
-            if (pv) { const float4* sl = partials + (size_t)(hu + (uint32_t)lane) * 3; p0 = sl[0]; p1 = sl[1]; p2 = sl[2]; }
+            if (pv) slot_load(partials, (size_t)(hu + (uint32_t)lane), p0, p1, p2);
             for (;;) {
                 const bool more = cm != 0ull;
                 int h2 = 0;
                 uint32_t hc2 = 0, hu2 = 0;
-                float4 q0 = zero4, q1 = zero4, q2 = zero4;
+                float4 q0 = zero4, q1 = zero4; float2 q2 = zero2;
                 bool qv = false;
                 if (more) {
                     h2 = pop_lowest_bit(cm);
                     hc2 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, h2); hu2 = (uint32_t)__builtin_amdgcn_readlane((int)u0, h2);
                     qv = (uint32_t)lane < hc2;
-                    if (qv) { const float4* sl = partials + (size_t)(hu2 + (uint32_t)lane) * 3; q0 = sl[0]; q1 = sl[1]; q2 = sl[2]; }
+                    if (qv) slot_load(partials, (size_t)(hu2 + (uint32_t)lane), q0, q1, q2);
                 }
                 float s0 = 0.f, s5 = 0.f;
                 f2v a12 = {0.f, 0.f}, a34 = {0.f, 0.f}, a67 = {0.f, 0.f}, a89 = {0.f, 0.f};
                 if (pv) { s0 += p0.x; a12 += f2v{p0.y, p0.z}; a34 += f2v{p0.w, p1.x}; s5 += p1.y; a67 += f2v{p1.z, p1.w}; a89 += f2v{p2.x, p2.y}; }
                 for (uint32_t k = (uint32_t)lane + 64u; k < hc; k += 128) {       // two trips' loads in flight (same summation order)
                     const bool two = k + 64u < hc;
-                    const float4* sl = partials + (size_t)(hu + k) * 3;
-                    const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
-                    float4 w0 = zero4, w1 = zero4, w2 = zero4;
-                    if (two) { w0 = sl[192]; w1 = sl[193]; w2 = sl[194]; }
+                    float4 v0, v1, w0 = zero4, w1 = zero4; float2 v2, w2 = zero2;
+                    slot_load(partials, (size_t)(hu + k), v0, v1, v2);
+                    if (two) slot_load(partials, (size_t)(hu + k + 64u), w0, w1, w2);
                     s0 += v0.x; a12 += f2v{v0.y, v0.z}; a34 += f2v{v0.w, v1.x}; s5 += v1.y; a67 += f2v{v1.z, v1.w}; a89 += f2v{v2.x, v2.y};
                     if (two) { s0 += w0.x; a12 += f2v{w0.y, w0.z}; a34 += f2v{w0.w, w1.x}; s5 += w1.y; a67 += f2v{w1.z, w1.w}; a89 += f2v{w2.x, w2.y}; }
                 }

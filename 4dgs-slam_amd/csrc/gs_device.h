@@ -227,13 +227,28 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
 }
 
 // ---- the binning scratch buffer (the reference's BinningState, rasterizer_impl.h:55-66) --------------------------------
-// chunk_info | inst_gauss[carve_R] | partials[carve_R] x 48 B (forward: aliased by the sort keys) | sorted[cap] | ckpt, each 256-byte
+// chunk_info | inst_gauss[carve_R] | partials[carve_R] x 40 B (forward: aliased by the sort keys) | sorted[cap] | ckpt, each 256-byte
 // aligned. ckpt = per-pixel compositing state (T, r, g, b, depth) at every CHUNK-th entry of every tile list, written by the
 // forward tile kernel: with it the backward pass can start anywhere in a list (see render_bwd_kernel).
 // carve_R is the instance count the buffer was LAID OUT for: the exact R when the host waited for it before allocating, or
 // the speculative capacity when the forward pass was enqueued without waiting. It lives in the geometry header (word 4),
 // so the backward kernels derive their pointers on the device and the host never has to know which of the two it was.
 constexpr int CHUNK = 128;              // entries of a tile list per backward work item
+// One gradient slot per (tile, Gaussian) instance, written by render_bwd and summed per Gaussian by geometry_bwd: ten floats, 40 bytes (round 6;
+// 48 with two dead floats before: 10 MB less to write and read again per frame at config #2)
+//   {dmean2D.x, dmean2D.y, dconic.x, dconic.y | dconic.w, dopacity, r, g | b, depth}
+constexpr int SLOT_FLOATS = 10;
+typedef float4 __attribute__((aligned(8))) float4_a8;       // a slot's 16-byte pieces sit at 8-byte aligned addresses (global memory: any dword alignment is legal)
+__device__ __forceinline__ void slot_store(float* partials, size_t instance, float4 a, float4 b, float2 c)
+{
+    float* const s = partials + instance * SLOT_FLOATS;
+    *reinterpret_cast<float4_a8*>(s) = a; *reinterpret_cast<float4_a8*>(s + 4) = b; *reinterpret_cast<float2*>(s + 8) = c;
+}
+__device__ __forceinline__ void slot_load(const float* partials, size_t instance, float4& a, float4& b, float2& c)
+{
+    const float* const s = partials + instance * SLOT_FLOATS;
+    a = *reinterpret_cast<const float4_a8*>(s); b = *reinterpret_cast<const float4_a8*>(s + 4); c = *reinterpret_cast<const float2*>(s + 8);
+}
 constexpr int CKPT_FLOATS = 5 * TILE_X * TILE_Y;   // one checkpoint: 5 planes of 256 pixels
 // Work items of render_bwd_kernel: one 16-byte record per CHUNK-entry piece of a tile list, {tile, position of the piece in sorted[],
 // entries in it | bit 16 = more entries follow in the list, list position of its first entry}, written by the forward tile kernel at
@@ -243,9 +258,11 @@ constexpr int CKPT_FLOATS = 5 * TILE_X * TILE_Y;   // one checkpoint: 5 planes o
 // ~20 us tail in which the CUs ran dry one by one behind whichever pieces happened to start last (tools/tile_timeline.py,
 // profiles/r06_tile_timeline.json: mean residency 3.9 of 5 blocks per CU, the last block started at 76 of 96 us). Now every XCD's sequence
 // (block b runs on XCD b % 8, in the order of b / 8) is: first the FULL pieces (CHUNK entries) of a contiguous range of tiles, in tile order
-// -- neighbouring tiles share Gaussians and one tile's pieces share its pixel state: same L2 --, then its share of the PARTIAL last pieces
-// of all lists, dealt round robin over the XCDs in descending length, so that the launch ends on short blocks everywhere at once (96 -> 87 us
-// first block to last, residency 4.4). item_block() is that map; its inputs (per tile: full pieces in front of it, rank of its partial
+// -- neighbouring tiles share Gaussians and one tile's pieces share its pixel state: same L2 --, then the PARTIAL last pieces of the lists of
+// ITS band of tiles, in descending length, so that the launch ends on short blocks everywhere at once (96 -> 87 us first block to last,
+// residency 4.4) and a tile's partial piece runs where the tile's pixel state already is (dealt round robin over all XCDs instead -- the map
+// below, kept as the fallback for frames in which a band holds more partial pieces than its XCD runs blocks -- they cost 15 MB of fabric
+// traffic per frame). item_block() is that map; its inputs (per tile: full pieces in front of it, rank of its partial
 // piece; the frame's number of full pieces) come from order_tiles_body, one extra block of the scatter launch.
 __host__ __device__ inline uint32_t items_below(uint32_t M, uint32_t x) { return x * (M >> 3) + (x < (M & 7u) ? x : (M & 7u)); }   // #{b < M : b % 8 < x}
 // first full-piece rank of XCD x when the frame has N pieces, Pn of them partial: XCD x runs #{b < N : b % 8 == x} blocks, #{r < Pn : r % 8 == x} of them partial
@@ -263,6 +280,9 @@ __host__ __device__ inline uint32_t item_block_partial(uint32_t N, uint32_t Pn, 
 }
 // where order_tiles_body leaves its results: the padding words of the per-tile counters (CTR_STRIDE words per tile, word 0 in use)
 constexpr int POS_FULL_BASE = 1, POS_PART_RANK = 2, POS_TOTAL_FULL = 1;   // tile_count[t * CTR_STRIDE + 1 / + 2]; tile_count[T * CTR_STRIDE + 1]
+// tile_count[T * CTR_STRIDE + 2]: 1 = a tile's partial piece runs on the XCD of the tile's band (POS_PART_RANK is its rank inside that band,
+// tile_count[T * CTR_STRIDE + 32 + x], x = 0 .. 8: first full-piece rank of XCD x), 0 = the round-robin map of item_block_*
+constexpr int POS_PART_HOME = 2, POS_FULL_START = 32;
 constexpr int POS_FWD_TILE = 3;     // tile_count[i * CTR_STRIDE + 3]: the tile that render_fwd's block takes in place of tile i (order_fwd_tiles_body)
 struct BinningPtrs { uint4* chunk_info; uint32_t* inst_gauss; float4* partials; uint64_t* keys; uint2* sorted; float* ckpt; char* end; };
 __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R, size_t cap_sorted, size_t ntiles)
@@ -275,7 +295,7 @@ __host__ __device__ inline BinningPtrs carve_binning(char* base, size_t carve_R,
     p = (p + carve_R * sizeof(uint32_t) + 255) & ~uintptr_t(255);
     b.partials = reinterpret_cast<float4*>(p);
     b.keys = reinterpret_cast<uint64_t*>(p);
-    p = (p + carve_R * 3 * sizeof(float4) + 255) & ~uintptr_t(255);
+    p = (p + carve_R * SLOT_FLOATS * sizeof(float) + 255) & ~uintptr_t(255);
     b.sorted = reinterpret_cast<uint2*>(p);
     p = (p + cap_sorted * sizeof(uint2) + 255) & ~uintptr_t(255);
     b.ckpt = reinterpret_cast<float*>(p);            // checkpoint id = sorted position / CHUNK, ids 1 .. cap/CHUNK + 1

@@ -835,37 +835,63 @@ __device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict_
                                                  const bool order_fwd, const uint32_t longest_list, const uint32_t heavy)
 {
     static_assert(CHUNK == 128 && GB == 1024, "128 lengths, 1024 threads");
-    __shared__ uint32_t s_len[CHUNK], s_tmp[17], s_band[8][ORDER_BUCKETS];
+    // s_len[x][m]: partial pieces of length m whose tile lies in XCD band x -- a tile's partial piece runs on the XCD of its band of tiles (where
+    // most of the tile's full pieces ran: dealt round robin over all XCDs, the partial pieces cost render_bwd 7 MB more fabric traffic per frame;
+    // placing them by the XCD of the tile's own full pieces instead of by its band was measured too: the same traffic, and the extra table
+    // reads made this block the last one of the scatter launch). Row 8: all bands together, for the round-robin fallback.
+    __shared__ uint32_t s_len[9][CHUNK], s_tmp[17], s_band[8][ORDER_BUCKETS], s_fs[10];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const int q = T >> 3, r = T & 7, head = r * (q + 1);
     auto band_of = [&](int i) { return i < head ? i / (q + 1) : r + (i - head) / q; };
     const int shift = max(0, 32 - __clz((int)max(longest_list, 1u)) - 8);                  // longest list >> shift < 256
-    if (t < (uint32_t)CHUNK) s_len[t] = 0;
+    for (uint32_t k = t; k < 9u * CHUNK; k += GB) (&s_len[0][0])[k] = 0;
     for (uint32_t k = t; k < 8u * ORDER_BUCKETS; k += GB) (&s_band[0][0])[k] = 0;
     if (ranges != nullptr) for (int i = (int)t; i < T; i += GB) { const uint2 g = ranges[i]; s_n[i] = g.y - g.x; }      // (nullptr: s_n holds the lengths already)
     __syncthreads();
+    // the number of FULL pieces (CHUNK entries) in front of every tile, and their total
+    const uint32_t total_full = block_exclusive_scan_1024(T, [&](int i) { return s_n[i] / (uint32_t)CHUNK; },
+                                                          [&](int i, uint32_t excl, uint32_t) { tile_pos[(size_t)i * CTR_STRIDE + POS_FULL_BASE] = excl; }, s_tmp);
     for (int i = (int)t; i < T; i += GB) {
         const uint32_t n = s_n[i], m = n & (uint32_t)(CHUNK - 1);
-        if (m) atomicAdd(&s_len[m], 1u);
+        if (m) { atomicAdd(&s_len[band_of(i)][m], 1u); atomicAdd(&s_len[8][m], 1u); }
         if (order_fwd) atomicAdd(&s_band[band_of(i)][ORDER_BUCKETS - 1 - min((uint32_t)ORDER_BUCKETS - 1u, n >> shift)], 1u);
     }
     __syncthreads();
-    // exclusive scans, descending: waves 0-1 over the 127 partial lengths (thread k holds length 127 - k), waves 2-9 over one band's buckets each
-    // (bucket index = 255 - key: ascending index is descending length; four consecutive buckets per lane)
-    uint32_t v = 0, incl = 0;
-    if (wave < 2) { v = s_len[CHUNK - 1 - t]; incl = wave_inclusive_scan(v); if (t == 63) s_tmp[0] = incl; }
-    else if (wave < 10 && order_fwd) {
+    // exclusive scans, descending length. Waves 0-8: one row of s_len each (lane l holds lengths 127 - 2 l and 126 - 2 l); waves 2-9 ALSO one
+    // band's list-length buckets each (bucket index = 255 - key: ascending index is descending length; four consecutive buckets per lane)
+    if (wave < 9) {
+        uint32_t* const row = s_len[wave];
+        const uint32_t c0 = row[CHUNK - 1 - 2 * lane], c1 = row[CHUNK - 2 - 2 * lane];
+        const uint32_t incl = wave_inclusive_scan(c0 + c1);
+        row[CHUNK - 1 - 2 * lane] = incl - c0 - c1; row[CHUNK - 2 - 2 * lane] = incl - c1;          // first rank of every length inside the band
+        if (lane == 63) s_tmp[wave] = incl;                                                         // partial pieces of the band (row 8: of the frame)
+    }
+    if (wave >= 2 && wave < 10 && order_fwd) {
         uint32_t* const b = &s_band[wave - 2][4 * lane];
         const uint32_t c0 = b[0], c1 = b[1], c2 = b[2], c3 = b[3];
         const uint32_t base = wave_inclusive_scan(c0 + c1 + c2 + c3) - (c0 + c1 + c2 + c3);
         b[0] = base; b[1] = base + c0; b[2] = base + c0 + c1; b[3] = base + c0 + c1 + c2;
     }
     __syncthreads();
-    if (wave < 2) s_len[CHUNK - 1 - t] = incl - v + (t >= 64 ? s_tmp[0] : 0u);
+    // full-piece ranges of the XCDs: XCD x runs #{b < N : b % 8 == x} blocks, its band's partial pieces among them, full pieces for the rest
+    if (t == 0) {
+        const uint32_t N = total_full + s_tmp[8];
+        uint32_t fs = 0; bool home = true;
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t cnt = items_below(N, x + 1) - items_below(N, x);
+            s_fs[x] = fs;
+            if (s_tmp[x] > cnt) home = false; else fs += cnt - s_tmp[x];
+        }
+        s_fs[8] = fs; s_fs[9] = home ? 1u : 0u;                // (a band with more partial pieces than its XCD runs blocks: round robin over all XCDs)
+        for (int x = 0; x < 9; x++) tile_pos[(size_t)T * CTR_STRIDE + POS_FULL_START + x] = s_fs[x];
+        tile_pos[(size_t)T * CTR_STRIDE + POS_TOTAL_FULL] = total_full;
+        tile_pos[(size_t)T * CTR_STRIDE + POS_PART_HOME] = s_fs[9];
+    }
     __syncthreads();
+    const bool home = s_fs[9] != 0;
     for (int i = (int)t; i < T; i += GB) {
         const uint32_t n = s_n[i], m = n & (uint32_t)(CHUNK - 1);
-        if (m) tile_pos[(size_t)i * CTR_STRIDE + POS_PART_RANK] = atomicAdd(&s_len[m], 1u);
+        if (m) tile_pos[(size_t)i * CTR_STRIDE + POS_PART_RANK] = atomicAdd(&s_len[home ? band_of(i) : 8][m], 1u);
         if (order_fwd) {
             const int x = band_of(i), start = x < r ? x * (q + 1) : head + (x - r) * q, size = x < r ? q + 1 : q;
             const uint32_t rank = atomicAdd(&s_band[x][ORDER_BUCKETS - 1 - min((uint32_t)ORDER_BUCKETS - 1u, n >> shift)], 1u);
@@ -886,10 +912,6 @@ __device__ __forceinline__ void order_tiles_body(int T, const uint2* __restrict_
             tile_pos[(size_t)(start + (int)(j * XCD_CUS + c)) * CTR_STRIDE + POS_FWD_TILE] = (uint32_t)i;
         }
     }
-    __syncthreads();
-    const uint32_t total_full = block_exclusive_scan_1024(T, [&](int i) { return s_n[i] / (uint32_t)CHUNK; },
-                                                          [&](int i, uint32_t excl, uint32_t) { tile_pos[(size_t)i * CTR_STRIDE + POS_FULL_BASE] = excl; }, s_tmp);
-    if (t == 0) tile_pos[(size_t)T * CTR_STRIDE + POS_TOTAL_FULL] = total_full;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

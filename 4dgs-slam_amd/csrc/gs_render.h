@@ -134,23 +134,9 @@ __device__ uint32_t g_bwd_timing[8 * 4 * 8192];
 #ifndef GSR_FWD_PREFETCH
 #define GSR_FWD_PREFETCH 0
 #endif
-#ifndef GSR_SLOT_STORE
-#define GSR_SLOT_STORE 0      // render_bwd's instance slots: 0 plain, 1 nontemporal, 2 write-through (sc1)
-#endif
 #ifndef GSR_CKPT_STORE
-#define GSR_CKPT_STORE 0      // render_fwd's checkpoints: 0 plain, 1 nontemporal
+#define GSR_CKPT_STORE 0      // render_fwd's checkpoints: 0 plain, 1 nontemporal (dev A/B: no difference measured)
 #endif
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_store16(float4* p, float4 v)
-{
-#if GSR_SLOT_STORE == 1
-    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
-#elif GSR_SLOT_STORE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v4f{v.x, v.y, v.z, v.w}) : "memory");
-#else
-    *p = v;
-#endif
-}
 __device__ __forceinline__ void ckpt_store(float* p, float v)
 {
 #if GSR_CKPT_STORE == 1
@@ -219,8 +205,14 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     // (read here, with the range, for the epilogue's work-item table: at the end they would be one more memory round trip of the last block)
-    uint32_t nfull = 0, fbase = 0, prank = 0;
-    if (tile_pos != nullptr) { nfull = tile_pos[(size_t)ntiles * CTR_STRIDE + POS_TOTAL_FULL]; fbase = tile_pos[(size_t)tile * CTR_STRIDE + POS_FULL_BASE]; prank = tile_pos[(size_t)tile * CTR_STRIDE + POS_PART_RANK]; }
+    uint32_t nfull = 0, fbase = 0, prank = 0, part_home = 0, fs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tile_pos != nullptr) {
+        const uint32_t* const frame = tile_pos + (size_t)ntiles * CTR_STRIDE;
+        nfull = frame[POS_TOTAL_FULL]; part_home = frame[POS_PART_HOME];
+#pragma unroll
+        for (int x = 0; x < 9; x++) fs[x] = frame[POS_FULL_START + x];
+        fbase = tile_pos[(size_t)tile * CTR_STRIDE + POS_FULL_BASE]; prank = tile_pos[(size_t)tile * CTR_STRIDE + POS_PART_RANK];
+    }
 #if GSR_FWD_PRIO
     {   // The launch lasts as long as its longest tile's dependent chain (every tile of the frame is resident at once, 4.7 waves per SIMD share the
         // issue slots): the waves of the long lists take the arbitration (s_setprio), the short ones -- which finish early anyway -- the rest.
@@ -458,8 +450,23 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
         // longest first at the end of every XCD's sequence (gs_device.h: item_block_*)
         for (int c = t; c * CHUNK < n; c += RB) {
             const int cstart = c * CHUNK, m = min(CHUNK, n - cstart);
-            const uint32_t block = tile_pos == nullptr ? (uint32_t)xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks)
-                                 : m == CHUNK ? item_block_full(nchunks, nchunks - nfull, fbase + (uint32_t)c) : item_block_partial(nchunks, nchunks - nfull, prank);
+            uint32_t block;
+            if (tile_pos == nullptr) block = (uint32_t)xcd_block_of_tile((int)(cb + (uint32_t)c), (int)nchunks);
+            else if (!part_home) block = m == CHUNK ? item_block_full(nchunks, nchunks - nfull, fbase + (uint32_t)c) : item_block_partial(nchunks, nchunks - nfull, prank);
+            else if (m == CHUNK) {                      // full piece of rank f: the XCD whose range holds f
+                const uint32_t f = fbase + (uint32_t)c;
+                uint32_t x = 0, start = fs[0];          // (selects, not fs[x]: a run-time index would send the table to scratch memory)
+#pragma unroll
+                for (int k = 1; k < 8; k++) if (fs[k] <= f) { x = (uint32_t)k; start = fs[k]; }
+                block = 8u * (f - start) + x;
+            } else {                                    // partial piece: behind the full pieces of the XCD of this tile's band
+                const int q8 = ntiles >> 3, r8 = ntiles & 7, head8 = r8 * (q8 + 1);
+                const uint32_t x = (uint32_t)(tile < head8 ? tile / (q8 + 1) : r8 + (tile - head8) / q8);
+                uint32_t lo = fs[0], hi = fs[1];
+#pragma unroll
+                for (int k = 1; k < 8; k++) if (x >= (uint32_t)k) { lo = fs[k]; hi = fs[k + 1]; }
+                block = 8u * ((hi - lo) + prank) + x;
+            }
             chunk_info[block] = make_uint4((uint32_t)tile, range.x + (uint32_t)cstart,
                                            (uint32_t)m | (cstart + m < n ? 0x10000u : 0u) | (deepest <= cstart ? 0x20000u : 0u), (uint32_t)cstart);
         }
@@ -485,14 +492,14 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
 //    instructions for all ten values); the reference runs a 256-thread shared-memory tree with 8 block barriers x 5
 //    arrays for every listed Gaussian (backward.cu:541-559,759-765);
 //  * the four quadrant waves drop their totals into LDS (ten lanes, one ds_write each); after the batch the block adds
-//    the quadrants in a fixed order and writes one 48-byte slot per (tile, Gaussian) instance, coalesced. The reference
+//    the quadrants in a fixed order and writes one 40-byte slot per (tile, Gaussian) instance, coalesced. The reference
 //    issues 10 float atomics per instance instead (backward.cu:774-783). B2 then sums a Gaussian's consecutive
 //    instance slots in a fixed order: bit-reproducible gradients, nothing to zero-fill, no atomics;
 //  * besides the quadrant cull, entries behind the deepest contributor of the quadrant (max n_contrib) are dropped
 //    at staging time, so saturated regions skip their occluded tail entirely;
 //  * one block per CHUNK entries of a tile list, not per tile: the forward pass checkpoints the per-pixel compositing state
 //    every CHUNK entries, so every chunk can be differentiated on its own (details at the state set-up below).
-// Slot (12 floats): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth, -, -
+// Slot (SLOT_FLOATS = 10): dmean2D.x, dmean2D.y, dconic.x, dconic.y, dconic.w, dopacity, dcolor.r, dcolor.g, dcolor.b, ddepth
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TB = 8;       // entries per batch of the LDS-transposed reduction
 // value of lane (lane & ~7) + I: the I-th lane of this lane's group of eight (ds_swizzle in bit-mask mode: and_mask 0x18, or_mask I inside
@@ -563,8 +570,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     if (__builtin_amdgcn_readfirstlane(item.z) & 0x20000u) {                 // nothing of this chunk was blended by any pixel of the tile: its
         if (t < m) {                                                         // instances' slots must still be written (zero), nothing else is read
             const uint2 e0 = sorted[first + (uint32_t)(m - 1 - t)];
-            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e0.y * 3;
-            slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            slot_store(partials, e0.y, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float2(0.f, 0.f));
         }
         TL_END(1, blockIdx.x);
         return;
@@ -602,8 +608,7 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
     __syncthreads();
     if (max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) <= cstart) {
         if (t < m) {
-            float4* slot = reinterpret_cast<float4*>(partials) + (size_t)e.y * 3;
-            slot[0] = slot[1] = slot[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            slot_store(partials, e.y, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float2(0.f, 0.f));
         }
         TL_END(1, blockIdx.x);
         return;
@@ -803,12 +808,12 @@ __device__ __forceinline__ void render_bwd_body(int ntiles, int gx, const char* 
                 // the unscaled conic: undoes the scaling of A, B, C (one rounding, <= 1.5 ulp on the factor of dL_dmean2D)
                 const float4 K4 = make_float4(st_a.z * (-2.0f / LOG2E), st_a.w * (-1.0f / LOG2E), st_b.x * (-2.0f / LOG2E), st_b.w);
 #endif
-                float4* const slot = reinterpret_cast<float4*>(partials) + (size_t)__float_as_uint(st_b.z) * 3;
                 // {M1x, M1y, M2xx, M2xy} -> dL_dmean2D (:749-753 with ddelx_dx, :643), dL_dconic.x, .y (:754-755)
-                stream_store16(slot, make_float4(-(K4.x * sum[0] + K4.y * sum[1]) * (0.5f * W), -(K4.z * sum[1] + K4.y * sum[0]) * (0.5f * H), -0.5f * sum[2], -0.5f * sum[3]));
                 // {M2yy, sum q, r, g} -> dL_dconic.w (:756), dL_dopacity = sum q / o = sum G dL_dalpha (:757; o = 0 blends nowhere), colour r, g (:719)
-                stream_store16(slot + 1, make_float4(-0.5f * sum[4], K4.w > 0.f ? sum[5] / K4.w : 0.f, sum[6], sum[7]));
-                stream_store16(slot + 2, make_float4(sum[8], sum[9], 0.f, 0.f));                                  // {b, depth} (:719,:729)
+                // {b, depth} (:719,:729)
+                slot_store(partials, __float_as_uint(st_b.z),
+                           make_float4(-(K4.x * sum[0] + K4.y * sum[1]) * (0.5f * W), -(K4.z * sum[1] + K4.y * sum[0]) * (0.5f * H), -0.5f * sum[2], -0.5f * sum[3]),
+                           make_float4(-0.5f * sum[4], K4.w > 0.f ? sum[5] / K4.w : 0.f, sum[6], sum[7]), make_float2(sum[8], sum[9]));
             }
         } else if (sw == 0 && wave == 1 && t < m) {
             s_a[lane] = st_a; s_b[lane] = st_b; s_c[lane] = st_c;

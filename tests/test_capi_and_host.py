@@ -34,7 +34,7 @@ def test_library_loads_and_exports_all_declared_symbols():
     # sizes are pure host functions
     assert lib.gsr_geometry_buffer_size(1000) > 1000 * 70
     assert lib.gsr_image_buffer_size(640, 480, 200000) >= 640 * 480 * 8
-    assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 48 + 8)
+    assert lib.gsr_binning_buffer_size(1000) >= 1000 * (4 + 40 + 8)
 
 
 def test_work_item_map_is_a_bijection_with_full_pieces_first_and_short_pieces_last():

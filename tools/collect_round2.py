@@ -57,7 +57,8 @@ for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "track
              "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json",
              "phase_cycles.json", "phase_cycles_slam_scale.json", "views.json", "views_deltas.json", "views_100k.json", "backend_map.jsonl",
              "mapping_iteration_launches_dynamic.json", "mapping_iteration_launches_static.json", "dynamic_reproducibility.txt",
-             "bench_two_ranks_one_gpu_gloo.json", "config4_stand_in.json", "mapping_iteration_launches_dynamic_library_trunk.json", "dense_layers.jsonl"):
+             "bench_two_ranks_one_gpu_gloo.json", "config4_stand_in.json", "mapping_iteration_launches_dynamic_library_trunk.json", "dense_layers.jsonl", "tile_timeline.json", "tile_timeline_tile_order.json",
+             "dispatch_census.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name.replace('iterationflow', 'iteration_flow').replace('iterationnodesflow', 'iteration_nodes_flow').replace('iterationnodes', 'iteration_nodes')}"))
