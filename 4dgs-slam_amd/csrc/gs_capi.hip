@@ -143,6 +143,10 @@ static thread_local SpecState t_spec[16][SPEC_SLOTS];   // [device][0 = single-v
 static thread_local int t_view_slot_group = 0;
 // a flow view's tile rectangle (gsr_view.flow_clip) for a view that goes through the single-view path inside a gsr_forward_views call
 static thread_local const int* t_clip_single = nullptr;
+// gsr_track_step (include/slam_map.h): the loss epilogue of the forward pass's render_fwd launches, and the launch that replaces tau_sum_kernel
+static thread_local const TrackLossArgs* t_track_loss = nullptr;
+struct TrackTail { const float* exposure_partials; float* dL_dexposure; CameraStepArgs step; };
+static thread_local const TrackTail* t_track_tail = nullptr;
 static thread_local SpecState* t_cur = &t_spec[0][0];
 static int select_device_state(int slot = 0)
 {
@@ -475,7 +479,6 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
     } else if (lds_hist) {
         GSR_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * CTR_STRIDE * sizeof(uint32_t), stream));   // no Gaussians: no columns to scan
     }
-
     // Speculation: a SLAM loop renders nearly the same scene again and again, so the binning buffer is allocated for what
     // sufficed last time plus slack and scatter / sort / render are enqueued right behind the scan, WITHOUT waiting for R;
     // the host reads R from the mailbox afterwards, while the GPU is already busy with them. The scan kernel compares the
@@ -576,6 +579,13 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         GSR_STAGE("sort_tiles");
         {   // Tiles with an empty range still run and write the background (forward.cu:297-299,382-391; Q21).
             ScopedKernelTimer tm(K_RENDER_FWD, stream);
+            if (t_track_loss)
+                hipLaunchKernelGGL(render_fwd_track_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.rec,
+                                   background, img.final_T, img.n_contrib, out_color, out_depth,
+                                   out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
+                                   (const uint32_t*)bin.inst_gauss, bin.sorted, (const uint32_t*)img.chunk_base, bin.chunk_info,
+                                   order_items ? (const uint32_t*)img.tile_count : (const uint32_t*)nullptr, order_fwd_tiles(T, lds_hist) ? 1 : 0, *t_track_loss);
+            else
             hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, bin.sorted, width, height, geom.rec,
                                background, img.final_T, img.n_contrib, out_color, out_depth,
                                out_opacity, n_touched, img.final_C, bin.ckpt, chk, t_fuse_sort ? (const uint64_t*)bin.keys : nullptr,
@@ -615,6 +625,13 @@ static int forward_impl(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_al
         // keep point_offsets defined for debug readers / backward even when nothing is visible
         if (P > 0) GSR_HIP_CHECK(hipMemsetAsync(geom.point_offsets, 0, (size_t)P * sizeof(uint32_t), stream));
         ScopedKernelTimer tm(K_RENDER_FWD, stream);
+        if (t_track_loss)
+            hipLaunchKernelGGL(render_fwd_track_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
+                               geom.rec, background, img.final_T, img.n_contrib, out_color,
+                               out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
+                               (const uint64_t*)nullptr, (const uint32_t*)nullptr, (uint2*)nullptr, (const uint32_t*)nullptr, (uint4*)nullptr,
+                               (const uint32_t*)nullptr, 0, *t_track_loss);
+        else
         hipLaunchKernelGGL(render_fwd_kernel, dim3(T), dim3(RB), 0, stream, T, gx, img.ranges, (const uint2*)nullptr, width, height,
                            geom.rec, background, img.final_T, img.n_contrib, out_color,
                            out_depth, out_opacity, n_touched, img.final_C, (float*)nullptr, (const uint32_t*)nullptr,
@@ -953,7 +970,10 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
         if (raw && raw->delta_mode) hipLaunchKernelGGL((geometry_bwd_kernel<true, true>), dim3((P + 255) / 256), dim3(256), 0, stream, a);
         else if (raw) hipLaunchKernelGGL(geometry_bwd_kernel<true>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(geometry_bwd_kernel<false>, dim3((P + 255) / 256), dim3(256), 0, stream, a);
-        if (dL_dtau_sum)
+        if (dL_dtau_sum && t_track_tail)     // gsr_track_step: pose-gradient sum + exposure-gradient sum + camera step in one launch
+            hipLaunchKernelGGL(track_tail_kernel, dim3(1), dim3(384), 0, stream, (P + 255) / 256, (const float*)geom.tau_partials, dL_dtau_sum, T,
+                               t_track_tail->exposure_partials, t_track_tail->dL_dexposure, t_track_tail->step);
+        else if (dL_dtau_sum)
             hipLaunchKernelGGL(tau_sum_kernel, dim3(1), dim3(384), 0, stream, (P + 255) / 256, geom.tau_partials, dL_dtau_sum);
     }
     GSR_STAGE("geometry_bwd");
@@ -1751,6 +1771,27 @@ int gsr_deform_mlp_forward(const gsr_deform_mlp* mlp, int64_t n, const float* fe
     if (int rc = mlp_fill(mlp, &w, "gsr_deform_mlp_forward")) return rc;
     if (n < 0 || (n > 0 && (!features || !out))) { g_last_error = "gsr_deform_mlp_forward: null / invalid argument"; return GSR_ERR_INVALID_ARGUMENT; }
     if (n == 0) return 0;
+    // round 6: the bf16-split kernel (gs_mlp.h: three terms per operand, six products, weights stationary in registers) for the widths the
+    // shipped networks use; GSR_MLP_FP32=1: the fp32-MFMA kernel of rounds 1-5 (also every other width)
+    static const bool fp32_only = getenv("GSR_MLP_FP32") && getenv("GSR_MLP_FP32")[0] == '1';
+    static const int rt = getenv("GSR_MLP_RT") ? atoi(getenv("GSR_MLP_RT")) : 2;      // row tiles per block: 2 (two blocks per CU: 1.37 ms at 4 M rows) or 4 (one: 1.65)
+    const int nt = w.in_dim / 16;
+    if (!fp32_only && (nt == 2 || nt == 4 || nt == 8)) {
+        static std::atomic<unsigned long long> attr_set[6];
+#define GSR_MLP3_LAUNCH(NT, RT, SLOT)                                                                                                             \
+        do {                                                                                                                                      \
+            using L = Mlp3Layout<NT, RT>;                                                                                                         \
+            { const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(deform_mlp_fwd3_kernel<NT, RT>), L::BYTES, attr_set[SLOT]); if (rc) return rc; } \
+            const int64_t tiles = (n + L::R - 1) / L::R;                                                                                          \
+            hipLaunchKernelGGL((deform_mlp_fwd3_kernel<NT, RT>), dim3((unsigned)std::min<int64_t>(tiles, 256 * (RT >= 4 ? 1 : 2))), dim3(MLP3_THREADS), L::BYTES, \
+                               (hipStream_t)stream_, n, features, w, out);                                                                        \
+        } while (0)
+        if (rt == 2) { if (nt == 2) GSR_MLP3_LAUNCH(2, 2, 0); else if (nt == 4) GSR_MLP3_LAUNCH(4, 2, 1); else GSR_MLP3_LAUNCH(8, 2, 2); }
+        else { if (nt == 2) GSR_MLP3_LAUNCH(2, 4, 3); else if (nt == 4) GSR_MLP3_LAUNCH(4, 4, 4); else GSR_MLP3_LAUNCH(8, 4, 5); }
+#undef GSR_MLP3_LAUNCH
+        GSR_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     switch (w.in_dim / 16) {
 #define GSR_MLPF_CASE(NT) case NT: hipLaunchKernelGGL((deform_mlp_fwd_kernel<NT>), mlp_grid(n), dim3(MLP_BLOCK), 0, (hipStream_t)stream_, n, features, w, out); break;
         GSR_MLPF_CASE(1) GSR_MLPF_CASE(2) GSR_MLPF_CASE(3) GSR_MLPF_CASE(4) GSR_MLPF_CASE(5) GSR_MLPF_CASE(6) GSR_MLPF_CASE(7) GSR_MLPF_CASE(8)
@@ -2456,6 +2497,60 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream_)
     hipLaunchKernelGGL(camera_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, a);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+size_t gsr_track_workspace_size(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    const size_t N = (size_t)width * height, T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
+    return (4 * N + 2 * T + 8) * sizeof(float);
+}
+
+int gsr_track_step(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user, gsr_alloc_fn image_alloc,
+                   void* image_user, int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in,
+                   float scale_modifier, const float* projmatrix_raw, float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                   float* out_opacity, int* radii, int* n_touched, const gsr_track_loss* loss, const gsr_camera_step* step, float* dL_dmean2D,
+                   char* workspace, void* stream)
+{
+    if (!in || !loss || !step || !workspace || !dL_dmean2D || !projmatrix_raw || P <= 0 || width <= 0 || height <= 0 || !loss->gt_image || !loss->gt_depth ||
+        !step->full_proj || !step->campos || !step->rot_delta || !step->trans_delta || (step->exposure_a == nullptr) != (step->exposure_b == nullptr) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        g_last_error = "gsr_track_step: null / invalid argument (P > 0; loss targets, pose deltas, full_proj, campos, a 16-byte aligned workspace of gsr_track_workspace_size bytes)";
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const size_t N = (size_t)width * height, T = (size_t)((width + TILE_X - 1) / TILE_X) * ((height + TILE_Y - 1) / TILE_Y);
+    float* const ws = reinterpret_cast<float*>(workspace);
+    float* const g_image = ws, * const g_depth = ws + 3 * N, * const partials = ws + 4 * N, * const tau6 = partials + 2 * T, * const g_exp = tau6 + 6;
+    gsr_camera_step st = *step;                   // which tensors are stepped: the pose always, the exposure pair when it is given
+    st.g_rot_delta = tau6 + 3; st.g_trans_delta = tau6;
+    st.g_exposure_a = st.exposure_a ? g_exp : nullptr; st.g_exposure_b = st.exposure_b ? g_exp + 1 : nullptr;
+    TrackTail tail;
+    { const int rc = camera_step_args(&st, tail.step); if (rc) return rc; }
+    tail.exposure_partials = partials; tail.dL_dexposure = g_exp;
+    TrackLossArgs tl;
+    tl.gt_image = loss->gt_image; tl.gt_depth = loss->gt_depth; tl.w_rgb = loss->w_rgb; tl.w_depth = loss->w_depth;
+    tl.exposure_a = step->exposure_a; tl.exposure_b = step->exposure_b;
+    tl.opacity_thr = loss->opacity_depth_threshold; tl.use_opacity = loss->opacity_weights ? 1 : 0;
+    tl.c_rgb = loss->alpha / (3.0f * (float)N); tl.c_depth = (1.0f - loss->alpha) / (float)N;          // (make_loss_args)
+    tl.dL_dimage = g_image; tl.dL_ddepth = g_depth; tl.partials = partials;
+    CapturedAlloc g{geometry_alloc, geometry_user, nullptr}, b{binning_alloc, binning_user, nullptr}, i{image_alloc, image_user, nullptr};
+    t_track_loss = &tl;
+    const int R = forward_impl(captured_alloc, &g, captured_alloc, &b, captured_alloc, &i, P, D, M, background, width, height, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, scale_modifier, nullptr, nullptr, step->viewmatrix, step->full_proj, step->campos, tan_fovx, tan_fovy, 0,
+                               out_color, out_depth, out_opacity, radii, n_touched, 0, stream, in);
+    t_track_loss = nullptr;
+    if (R < 0) return R;
+    gsr_raw_grads none;
+    memset(&none, 0, sizeof(none));
+    t_track_tail = &tail;
+    const int rc = backward_impl(P, D, M, R, background, width, height, nullptr, nullptr, nullptr, nullptr, scale_modifier, nullptr, nullptr, step->viewmatrix,
+                                 step->full_proj, projmatrix_raw, step->campos, tan_fovx, tan_fovy, radii, g.got, b.got, i.got, g_image, g_depth, dL_dmean2D,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tau6, GSR_BACKWARD_POSE_ONLY, stream,
+                                 in, &none);
+    t_track_tail = nullptr;
+    if (rc < 0) return rc;
+    GSR_HIP_CHECK(hipGetLastError());
+    return R;
 }
 
 int gsr_camera_steps_launch(int n, const gsr_camera_step* steps, void* stream_)

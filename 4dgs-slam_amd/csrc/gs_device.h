@@ -567,4 +567,36 @@ __device__ __forceinline__ int xcd_block_of_tile(int id, int ntiles)
     return (rest % q) * 8 + r + rest / q;
 }
 
+// ---- the weighted L1 loss's cotangents of ONE pixel (gs_loss.h: l1_loss_bwd_kernel; gs_render.h: the tracking epilogue of render_fwd) ----
+// wr, wd: the pixel's weights with the loss coefficients and the upstream gradient already multiplied in (and, for the tracking loss,
+// the rendered opacity / the opacity test: utils/slam_utils.py:118-135). One function for both callers, so that a pixel's cotangents are the
+// same bits whichever kernel forms them.
+__device__ __forceinline__ float l1_sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // d|v|/dv as torch defines it
+struct L1PixelGrad { float gi[3]; float gd; };
+__device__ __forceinline__ L1PixelGrad l1_bwd_pixel(float wr, float wd, float ea, float eb, const float (&I)[3], const float (&gt)[3], float depth, float gt_depth,
+                                                    float& da, float& db /* running exposure-gradient sums of the calling thread */)
+{
+    L1PixelGrad o;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float s = wr * l1_sgn(ea * I[c] + eb - gt[c]);     // dL / d(exp(a) I + b)
+        o.gi[c] = s * ea;
+        da += s * ea * I[c];
+        db += s;
+    }
+    o.gd = wd * l1_sgn(depth - gt_depth);
+    return o;
+}
+
+// The tracking loss fused into render_fwd's epilogue (include/slam_map.h: gsr_track_step): gt_image == nullptr switches it off.
+struct TrackLossArgs {
+    const float* gt_image; const float* gt_depth;      // [3, N], [N]
+    const float* w_rgb; const float* w_depth;          // [N] each or nullptr (= 1)
+    const float* exposure_a; const float* exposure_b;  // device scalars or nullptr
+    float opacity_thr; int use_opacity;                // tracking: w_rgb *= rendered opacity, w_depth *= (opacity > thr)
+    float c_rgb, c_depth;                              // alpha / (3 N), (1 - alpha) / N
+    float* dL_dimage; float* dL_ddepth;                // out: [3, N], [N]
+    float* partials;                                   // out: [tiles][2] exposure-gradient partial sums (d/da, d/db)
+};
+
 }  // namespace gsr

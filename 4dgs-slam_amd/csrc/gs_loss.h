@@ -36,7 +36,7 @@ __device__ __forceinline__ float block_sum_fixed(float v, float* s_tmp /*[LOSS_T
     return t;
 }
 
-__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // d|v|/dv as torch defines it
+__device__ __forceinline__ float sgn(float v) { return l1_sgn(v); }   // d|v|/dv as torch defines it (gs_device.h)
 
 __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_fwd_kernel(LossArgs a, float* __restrict__ partials)
 {
@@ -86,15 +86,12 @@ __global__ void __launch_bounds__(LOSS_THREADS) l1_loss_bwd_kernel(LossArgs a, c
         float wr = (a.w_rgb ? a.w_rgb[p] : 1.f) * a.c_rgb * g, wd = (a.w_depth ? a.w_depth[p] : 1.f) * a.c_depth * g;
         if (a.opacity) { const float op = a.opacity[p]; wr *= op; wd = op > a.opacity_thr ? wd : 0.f; }   // opacity is a weight: the rasterizer
                                                                                                     // drops its cotangent anyway
+        const float I[3] = {a.image[p], a.image[(size_t)a.N + p], a.image[2 * (size_t)a.N + p]};
+        const float gt[3] = {a.gt_image[p], a.gt_image[(size_t)a.N + p], a.gt_image[2 * (size_t)a.N + p]};
+        const L1PixelGrad o = l1_bwd_pixel(wr, wd, ea, eb, I, gt, a.depth[p], a.gt_depth[p], da, db);   // gs_device.h: shared with render_fwd's tracking epilogue
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float I = a.image[(size_t)c * a.N + p];
-            const float s = wr * sgn(ea * I + eb - a.gt_image[(size_t)c * a.N + p]);   // dL / d(exp(a) I + b)
-            dL_dimage[(size_t)c * a.N + p] = s * ea;
-            da += s * ea * I;
-            db += s;
-        }
-        dL_ddepth[p] = wd * sgn(a.depth[p] - a.gt_depth[p]);
+        for (int c = 0; c < 3; c++) dL_dimage[(size_t)c * a.N + p] = o.gi[c];
+        dL_ddepth[p] = o.gd;
     }
     const float ta = block_sum_fixed(da, s_tmp), tb = block_sum_fixed(db, s_tmp);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ta; partials[2 * blockIdx.x + 1] = tb; }

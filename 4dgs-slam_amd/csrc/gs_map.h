@@ -153,42 +153,69 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
-__device__ __forceinline__ void camera_step_body(const CameraStepArgs& a)
+// Everything the step reads, requested in one go (round 6): the step count, the eight Adam elements (lane k < 8 owns flat element k of the state:
+// rot 3, trans 3, a, b -- the n[] of camera_step_args), the pose. Taken where they are used -- four tensors one after the other, each behind the
+// previous one's stores, then the pose behind a block barrier, then the stepped deltas back from memory -- they were seven dependent memory
+// round trips in a one-block kernel that runs once per tracking iteration. track_tail_kernel issues them before its gradient sums.
+struct CameraStepLoads { bool skip, any_grad, mine; int e; float* ps; float lrs, step0, gr, m, v, pv; float Rm[9], Tv[3]; };
+__device__ __forceinline__ CameraStepLoads camera_step_loads(const CameraStepArgs& a, bool grads_come_later)
 {
-    if (a.latch && a.converged && a.converged[0]) return;      // converged earlier in this frame's loop: the reference has left the loop by now
-
+    CameraStepLoads L;
+    L.skip = a.latch && a.converged && a.converged[0];       // converged earlier in this frame's loop: the reference has left the loop by now
     const int lane = threadIdx.x;
+    L.any_grad = false;
+    for (int s = 0; s < 4; s++) L.any_grad |= a.g[s] != nullptr;
+    const int s = lane < 3 ? 0 : lane < 6 ? 1 : lane == 6 ? 2 : 3;
+    L.e = lane - (s == 0 ? 0 : s == 1 ? 3 : s == 2 ? 6 : 7);
+    const float* const gs = s == 0 ? a.g[0] : s == 1 ? a.g[1] : s == 2 ? a.g[2] : a.g[3];          // (selects: a run-time index would go through scratch memory)
+    L.ps = s == 0 ? a.p[0] : s == 1 ? a.p[1] : s == 2 ? a.p[2] : a.p[3];
+    L.lrs = s == 0 ? a.lr[0] : s == 1 ? a.lr[1] : s == 2 ? a.lr[2] : a.lr[3];
+    L.mine = lane < 8 && gs != nullptr;
+    L.step0 = L.any_grad ? a.step[0] : 0.f;
+    L.gr = 0.f; L.m = 0.f; L.v = 0.f; L.pv = 0.f;
+    if (L.mine) { if (!grads_come_later) L.gr = gs[L.e]; L.m = a.exp_avg[lane]; L.v = a.exp_avg_sq[lane]; }
+    if (lane < 8 && L.ps != nullptr) L.pv = L.ps[L.e];
+    for (int k = 0; k < 9; k++) L.Rm[k] = a.R[k];
+    for (int k = 0; k < 3; k++) L.Tv[k] = a.T[k];
+    return L;
+}
+
+// lg (optional, LDS): the eight gradients in the Adam state's order (rot 3, trans 3, a, b) -- track_tail_kernel formed them a moment ago in this
+// very block; a.g[s] then only says WHICH tensors are stepped.
+__device__ __forceinline__ void camera_step_apply(const CameraStepArgs& a, const CameraStepLoads& L, const float* lg = nullptr)
+{
+    if (L.skip) return;
+    const int lane = threadIdx.x;
+    const bool any_grad = L.any_grad, mine = L.mine;
+    const int e = L.e;
+    float* const ps = L.ps;
+    const float lrs = L.lrs, step0 = L.step0;
+    float gr = lg && mine ? lg[lane] : L.gr, m = L.m, v = L.v, pv = L.pv;
+    float Rm[9], Tv[3];
+    for (int k = 0; k < 9; k++) Rm[k] = L.Rm[k];
+    for (int k = 0; k < 3; k++) Tv[k] = L.Tv[k];
     // (1) Adam, torch.optim.Adam single-tensor arithmetic (bias corrections in double like torch's _single_tensor_adam)
-    bool any_grad = false;
-    for (int s = 0; s < 4; s++) any_grad |= a.g[s] != nullptr;
     if (any_grad) {
-        const float stepf = a.step[0] + 1.0f;
+        const float stepf = step0 + 1.0f;
         const double bc1 = 1.0 - pow((double)a.beta1, (double)stepf), bc2 = 1.0 - pow((double)a.beta2, (double)stepf);
-        int base = 0;
-        for (int s = 0; s < 4; s++) {
-            if (a.g[s] && lane < a.n[s]) {
-                const float gr = a.g[s][lane];
-                float m = a.exp_avg[base + lane], v = a.exp_avg_sq[base + lane];
-                m = m + (gr - m) * (float)(1.0 - (double)a.beta1);
-                v = v * a.beta2 + (float)(1.0 - (double)a.beta2) * gr * gr;
-                a.exp_avg[base + lane] = m; a.exp_avg_sq[base + lane] = v;
-                const float step_size = (float)((double)a.lr[s] / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-                a.p[s][lane] = a.p[s][lane] - step_size * (m / (sqrtf(v) * inv_bc2_sqrt + a.eps));
-            }
-            base += a.n[s];
+        if (mine) {
+            m = m + (gr - m) * (float)(1.0 - (double)a.beta1);
+            v = v * a.beta2 + (float)(1.0 - (double)a.beta2) * gr * gr;
+            a.exp_avg[lane] = m; a.exp_avg_sq[lane] = v;
+            const float step_size = (float)((double)lrs / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+            pv = pv - step_size * (m / (sqrtf(v) * inv_bc2_sqrt + a.eps));
+            ps[e] = pv;
         }
-        __syncthreads();
         if (lane == 0) a.step[0] = stepf;
     }
-    __threadfence_block();
-    __syncthreads();
+    if (threadIdx.x >= 64) return;                             // (track_tail_kernel: the other waves are done)
+    // the stepped pose deltas, from the lanes that hold them (the whole first wave takes part in the shuffles)
+    const float th0 = __shfl(pv, 0, 64), th1 = __shfl(pv, 1, 64), th2 = __shfl(pv, 2, 64);
+    const float rh0 = __shfl(pv, 3, 64), rh1 = __shfl(pv, 4, 64), rh2 = __shfl(pv, 5, 64);
     if (lane != 0) return;
-    float Rm[9], Tv[3];
-    for (int k = 0; k < 9; k++) Rm[k] = a.R[k];
-    for (int k = 0; k < 3; k++) Tv[k] = a.T[k];
     if (a.do_pose) {
         // (2) SE3_exp(tau) @ [R | T], pose_utils.py:27-97
-        const float rho[3] = {a.p[1][0], a.p[1][1], a.p[1][2]}, th[3] = {a.p[0][0], a.p[0][1], a.p[0][2]};
+        const float rho[3] = {rh0, rh1, rh2}, th[3] = {th0, th1, th2};
         const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};          // skew_sym_mat
         float W2[9];
         mat3_mul(Wm, Wm, W2);
@@ -237,7 +264,34 @@ __device__ __forceinline__ void camera_step_body(const CameraStepArgs& a)
     }
 }
 
+__device__ __forceinline__ void camera_step_body(const CameraStepArgs& a) { camera_step_apply(a, camera_step_loads(a, false)); }
+
 __global__ void __launch_bounds__(64) camera_step_kernel(CameraStepArgs a) { camera_step_body(a); }
+
+// ---- the tail of a tracking iteration in ONE launch (include/slam_map.h: gsr_track_step) ---------------------------------------------
+// What tau_sum_kernel, loss_finalize_kernel and camera_step_kernel did as three dependent launches of one block each (4.3 + 4.3 + 5.7 us of a
+// ~80 us iteration at SLAM sizes, every one of them a kernel boundary plus two dependent memory round trips): the last level of the pose-gradient
+// sum (six waves, one per component, fixed order: tau_sum_body), the last level of the two exposure-gradient sums (the tiles' partial sums that
+// render_fwd's tracking epilogue left, waves 0 and 1, fixed order), then the camera step with the gradients handed over through LDS.
+__global__ void __launch_bounds__(384) track_tail_kernel(int nblocks, const float* __restrict__ tau_partials, float* __restrict__ tau6, int ntiles,
+                                                         const float* __restrict__ exposure_partials, float* __restrict__ dL_dexposure, CameraStepArgs a)
+{
+    __shared__ float s_g[8];
+    const CameraStepLoads pre = camera_step_loads(a, true);        // in flight while the sums are formed
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float v = 0.f, e = 0.f;
+    for (int b = lane; b < nblocks; b += 64) v += tau_partials[(size_t)b * 6 + k];          // (tau_sum_body's order)
+    if (k < 2) for (int b = lane; b < ntiles; b += 64) e += exposure_partials[2 * (size_t)b + k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d, 64); e += __shfl_xor(e, d, 64); }
+    if (lane == 0) {
+        tau6[k] = v;                              // tau = [rho | theta] (DGR/diff_gaussian_rasterization/__init__.py:152-154)
+        s_g[k < 3 ? 3 + k : k - 3] = v;           // Adam state order: rot (theta) first, then trans (rho)
+        if (k < 2) { dL_dexposure[k] = e; s_g[6 + k] = e; }
+    }
+    __syncthreads();
+    camera_step_apply(a, pre, s_g);
+}
 
 // the window keyframes of a mapping iteration in one launch: block k steps camera k
 constexpr int CAMERA_STEPS_MAX = 12;

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "gs_linear.h"
+#include "gs_dense.h"
 
 namespace gsr {
 
@@ -176,6 +177,214 @@ deform_mlp_fwd_kernel(const int64_t n, const float* __restrict__ feat, const Mlp
         __syncthreads();                                          // the tiles are rewritten by the next iteration
 #pragma unroll
         for (int S = 0; S < NT_IN; S++) cur[S] = nxt[S];
+    }
+}
+
+// ---- round 6: the same network on the bf16 matrix cores (three-term split, six products: gs_dense.h) -------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 matrix rate; with every fp32 operand split into three bf16 terms and the six cross terms
+// of weight >= 2^-16 kept (gs_dense.h: fp32-GEMM accuracy, 1.8e-7 relative) a product costs 6/16 of its fp32 time. What bounds such a kernel is
+// no longer the matrix pipe but its operands: a 16-byte fragment per lane and MFMA is 64 B / cycle / SIMD, twice what the LDS delivers to a CU.
+// So the WEIGHTS ARE STATIONARY IN REGISTERS: wave w of the block's four holds the fragments of output features 16 w .. 16 w + 15 of W0 and
+// of every W1j (120 registers, split once per kernel from the fp32 weights: no workspace, no extra launch), and all R = 16 RT rows of the
+// block's tile stream through every wave; only the activations -- the second MFMA operand -- come from LDS, as bf16 planes [plane][row][k]
+// written once by the layer that produced them. Products are formed TRANSPOSED (weight fragment first): a lane ends with FOUR CONSECUTIVE
+// output features of one row -- one 8-byte LDS store per plane, already in the next layer's operand layout. The heads run one after the other
+// through two v buffers (one barrier per head); W2j (3-4 rows) comes from a 4.6 KB LDS copy. Five block barriers per 16 RT rows.
+constexpr int MLP3_THREADS = 256;
+template <int NT_IN, int RT>
+struct Mlp3Layout {
+    static constexpr int IN = 16 * NT_IN, KS0 = (IN + 31) / 32, KP0 = 32 * KS0, R = 16 * RT;
+    // bytes per row of a plane; the 16-byte chunks of a row are permuted (mlp3_off) so that the fragment reads are bank-conflict free
+    static constexpr int LDF = 2 * KP0, LDA = 2 * MLP_W;
+    static constexpr int OFF_F = 0, OFF_A = OFF_F + 3 * R * LDF, OFF_V = OFF_A + 3 * R * LDA, OFF_W2 = OFF_V + 2 * 3 * R * LDA;
+    static constexpr int BYTES = OFF_W2 + MLP_HEADS * 3 * 4 * (2 * MLP_W);
+    static constexpr int U = R * (KP0 / 4) / MLP3_THREADS;      // float4 of features per thread and tile
+};
+
+// Byte offset of the 16-byte chunk `c` (eight k) of row `row` in a plane whose rows hold CH chunks (4, 8 or 16: 32, 64 or 128 k). ds_read_b128
+// serves a wave in four groups of sixteen lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same in the upper half (MI355X_MICROARCH.md,
+// LDS) -- i.e. with lane = (row fi, chunk fq) the rows {0-3, 12-15} of one chunk together with the rows 4-11 of its neighbour: the XOR below
+// sends those sixteen accesses to the sixteen 16-byte slots of a 256-byte bank row (enumerated for the three widths). Padding the rows by 16
+// bytes -- the first layout -- left every group with 2-way conflicts.
+template <int CH>
+__device__ __forceinline__ int mlp3_off(int row, int c)
+{
+    const int r = row & 15;
+    const int swz = CH == 16 ? r : CH == 8 ? (r >> 1) & 7 : ((0x1230 >> (4 * ((r >> 2) & 3))) & 3);      // CH == 4: rows 0-3 -> 0, 4-7 -> 3, 8-11 -> 2, 12-15 -> 1
+    return row * (16 * CH) + 16 * (c ^ swz);
+}
+
+__device__ __forceinline__ void mlp3_split4(const float (&x)[4], uint2& h, uint2& m, uint2& l)
+{
+    uint32_t a[4], b[4], c[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) dense_split(x[e], a[e], b[e], c[e]);
+    h = make_uint2(dense_pack(a[0], a[1]), dense_pack(a[2], a[3]));
+    m = make_uint2(dense_pack(b[0], b[1]), dense_pack(b[2], b[3]));
+    l = make_uint2(dense_pack(c[0], c[1]), dense_pack(c[2], c[3]));
+}
+
+// eight consecutive weights W[row][k0 .. k0 + 7] (zero beyond K) -> this lane's fragment of each plane
+__device__ __forceinline__ void mlp3_weight_frag(const float* __restrict__ W, int ld, int K, int row, int k0, dense_frag (&dst)[3])
+{
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) x[e] = k0 + e < K ? W[(size_t)row * ld + k0 + e] : 0.f;
+    dense_u4 h, m, l;
+    dense_split8(x, h, m, l);
+    dst[0] = __builtin_bit_cast(dense_frag, h); dst[1] = __builtin_bit_cast(dense_frag, m); dst[2] = __builtin_bit_cast(dense_frag, l);
+}
+
+// the six products of ONE weight fragment set with RT activation fragment sets, smallest terms first. Every accumulator is kept as TWO partial
+// sums (c0: lo hi + mid mid + hi mid; c1: hi lo + mid hi + hi hi), added by the caller at the end: 2 RT independent chains, so that a dependent
+// v_mfma_f32_16x16x32_bf16 is at least 2 RT - 1 issues behind its predecessor (back to back it waits for the predecessor's passes: with two
+// row tiles and one chain each the matrix phases ran at half rate).
+template <int RT>
+__device__ __forceinline__ void mlp3_mfma6(const dense_frag (&a)[3], const dense_frag (&b)[RT][3], dense_acc (&c0)[RT], dense_acc (&c1)[RT])
+{
+#define GSR_MLP3_TERM(C, PA, PB)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < RT; t++) C[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA], b[t][PB], C[t], 0, 0, 0);
+    GSR_MLP3_TERM(c0, 2, 0) GSR_MLP3_TERM(c1, 0, 2) GSR_MLP3_TERM(c0, 1, 1) GSR_MLP3_TERM(c1, 1, 0) GSR_MLP3_TERM(c0, 0, 1) GSR_MLP3_TERM(c1, 0, 0)
+#undef GSR_MLP3_TERM
+}
+
+template <int NT_IN, int RT>
+__global__ void __launch_bounds__(MLP3_THREADS) __attribute__((amdgpu_waves_per_eu(RT >= 4 ? 1 : 2, RT >= 4 ? 1 : 2)))
+deform_mlp_fwd3_kernel(const int64_t n, const float* __restrict__ feat, const MlpWeights w, float* __restrict__ out)
+{
+    using L = Mlp3Layout<NT_IN, RT>;
+    constexpr int IN = L::IN, KS0 = L::KS0, KP0 = L::KP0, R = L::R, LDF = L::LDF, LDA = L::LDA, U = L::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    unsigned char* const s_f = s_mem + L::OFF_F;          // [3][R][LDF]   the tile's features
+    unsigned char* const s_a = s_mem + L::OFF_A;          // [3][R][LDA]   a = relu(h0)
+    unsigned char* const s_v = s_mem + L::OFF_V;          // [2][3][R][LDA] v_j = relu(u_j), heads alternate
+    unsigned char* const s_w2 = s_mem + L::OFF_W2;        // [head][plane][4 rows][64] W2j (rows >= o_j zero)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fq = lane >> 4;
+
+    // ---- this wave's share of the network, once per kernel: fragments (output feature 16 wave + fi, k = 32 s + 8 fq ..) of W0 and the W1j ----
+    dense_frag w0[KS0][3], w1[MLP_HEADS][2][3];
+#pragma unroll
+    for (int s = 0; s < KS0; s++) mlp3_weight_frag(w.W0, IN, IN, 16 * wave + fi, 32 * s + 8 * fq, w0[s]);
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) mlp3_weight_frag(w.W1[j], MLP_W, MLP_W, 16 * wave + fi, 32 * s + 8 * fq, w1[j][s]);
+    for (int e = tid; e < MLP_HEADS * 4 * MLP_W; e += MLP3_THREADS) {
+        const int j = e / (4 * MLP_W), row = (e / MLP_W) & 3, k = e & (MLP_W - 1);
+        uint32_t hi, mid, lo;
+        dense_split(row < w.out_dim[j] ? w.W2[j][(size_t)row * MLP_W + k] : 0.f, hi, mid, lo);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(s_w2 + ((j * 3) * 4 + row) * (2 * MLP_W)) + k;
+        dst[0] = (unsigned short)(hi >> 16); dst[4 * MLP_W] = (unsigned short)(mid >> 16); dst[8 * MLP_W] = (unsigned short)(lo >> 16);
+    }
+    float b0v[4], b1v[MLP_HEADS][4], b2v[MLP_HEADS][4];     // biases of this lane's four output features (transposed result: features 4 fq + r)
+#pragma unroll
+    for (int r = 0; r < 4; r++) b0v[r] = w.b0[16 * wave + 4 * fq + r];
+#pragma unroll
+    for (int j = 0; j < MLP_HEADS; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            b1v[j][r] = w.b1[j][16 * wave + 4 * fq + r];
+            b2v[j][r] = (fq == 0 && r < w.out_dim[j]) ? w.b2[j][r] : 0.f;
+        }
+
+    const int64_t tiles = (n + R - 1) / R;
+    auto load_tile = [&](int64_t tile, float4 (&dst)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + MLP3_THREADS * u, row = e / (KP0 / 4), k = 4 * (e % (KP0 / 4));
+            const int64_t p = tile * R + row;
+            dst[u] = (tile < tiles && p < n && k < IN) ? *reinterpret_cast<const float4*>(feat + p * IN + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto relu_split_store = [&](const dense_acc& acc, unsigned char* base, int row) {     // four features 16 wave + 4 fq .. of row `row` -> three planes
+        const float x[4] = {fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f)};
+        uint2 h, m, l;
+        mlp3_split4(x, h, m, l);
+        unsigned char* d = base + mlp3_off<MLP_W / 8>(row, 2 * wave + (fq >> 1)) + 8 * (fq & 1);
+        *reinterpret_cast<uint2*>(d) = h; *reinterpret_cast<uint2*>(d + R * LDA) = m; *reinterpret_cast<uint2*>(d + 2 * R * LDA) = l;
+    };
+    float4 cur[U], nxt[U];
+    load_tile(blockIdx.x, cur);
+    __syncthreads();                                              // s_w2 is complete
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        // ---- stage the tile's features as planes; request the next tile's ----
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + MLP3_THREADS * u, row = e / (KP0 / 4), k = 4 * (e % (KP0 / 4));
+            const float x[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+            uint2 h, m, l;
+            mlp3_split4(x, h, m, l);
+            unsigned char* d = s_f + mlp3_off<KP0 / 8>(row, k >> 3) + 2 * (k & 7);
+            *reinterpret_cast<uint2*>(d) = h; *reinterpret_cast<uint2*>(d + R * LDF) = m; *reinterpret_cast<uint2*>(d + 2 * R * LDF) = l;
+        }
+        load_tile(tile + gridDim.x, nxt);
+        __syncthreads();
+        // ---- h0 = F W0^T + b0 -> a = relu(h0): this wave's 16 features, all rows ----
+        {
+            dense_acc acc[RT], acc1[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++) { acc[t] = dense_acc{0.f, 0.f, 0.f, 0.f}; acc1[t] = dense_acc{b0v[0], b0v[1], b0v[2], b0v[3]}; }
+#pragma unroll
+            for (int s = 0; s < KS0; s++) {
+                dense_frag b[RT][3];
+#pragma unroll
+                for (int t = 0; t < RT; t++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) b[t][p] = dense_ld_frag(s_f + p * (R * LDF) + mlp3_off<KP0 / 8>(16 * t + fi, 4 * s + fq));
+                mlp3_mfma6<RT>(w0[s], b, acc, acc1);
+            }
+#pragma unroll
+            for (int t = 0; t < RT; t++) relu_split_store(acc[t] + acc1[t], s_a, 16 * t + fi);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MLP_HEADS; j++) {
+            unsigned char* const sv = s_v + (j & 1) * (3 * R * LDA);
+            // ---- u_j = a W1j^T + b1j -> v_j = relu(u_j) ----
+            {
+                dense_acc acc[RT], acc1[RT];
+#pragma unroll
+                for (int t = 0; t < RT; t++) { acc[t] = dense_acc{0.f, 0.f, 0.f, 0.f}; acc1[t] = dense_acc{b1v[j][0], b1v[j][1], b1v[j][2], b1v[j][3]}; }
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    dense_frag b[RT][3];
+#pragma unroll
+                    for (int t = 0; t < RT; t++)
+#pragma unroll
+                        for (int p = 0; p < 3; p++) b[t][p] = dense_ld_frag(s_a + p * (R * LDA) + mlp3_off<MLP_W / 8>(16 * t + fi, 4 * s + fq));
+                    mlp3_mfma6<RT>(w1[j][s], b, acc, acc1);
+                }
+#pragma unroll
+                for (int t = 0; t < RT; t++) relu_split_store(acc[t] + acc1[t], sv, 16 * t + fi);
+            }
+            __syncthreads();
+            // ---- o_j = v_j W2j^T + b2j: one 16-feature tile (o_j valid), the row tiles dealt to the waves ----
+            for (int t = wave; t < RT; t += MLP3_THREADS / 64) {
+                // (the two k steps as the "row tiles" of mlp3_mfma6: four independent chains of three products)
+                dense_frag a[2][3], b[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) {
+                        a[s][p] = fi < 4 ? dense_ld_frag(s_w2 + ((j * 3 + p) * 4 + fi) * (2 * MLP_W) + 2 * (32 * s + 8 * fq)) : dense_frag{0, 0, 0, 0, 0, 0, 0, 0};
+                        b[s][p] = dense_ld_frag(sv + p * (R * LDA) + mlp3_off<MLP_W / 8>(16 * t + fi, 4 * s + fq));
+                    }
+                dense_acc c0[2] = {dense_acc{0.f, 0.f, 0.f, 0.f}, dense_acc{0.f, 0.f, 0.f, 0.f}};
+                dense_acc c1[2] = {dense_acc{b2v[j][0], b2v[j][1], b2v[j][2], b2v[j][3]}, dense_acc{0.f, 0.f, 0.f, 0.f}};
+#define GSR_MLP3_TERM2(C, PA, PB)                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 2; s++) C[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][PA], b[s][PB], C[s], 0, 0, 0);
+                GSR_MLP3_TERM2(c0, 2, 0) GSR_MLP3_TERM2(c1, 0, 2) GSR_MLP3_TERM2(c0, 1, 1) GSR_MLP3_TERM2(c1, 1, 0) GSR_MLP3_TERM2(c0, 0, 1) GSR_MLP3_TERM2(c1, 0, 0)
+#undef GSR_MLP3_TERM2
+                const dense_acc acc = (c0[0] + c1[0]) + (c0[1] + c1[1]);
+                const int64_t p = tile * R + 16 * t + fi;
+                if (fq == 0 && p < n) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (r < w.out_dim[j]) out[p * MLP_OUT + w.out_off[j] + r] = acc[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
 }
 

@@ -162,6 +162,7 @@ __device__ uint32_t g_spans[2][8192][4];
 // ------------------------------------------------------------------------------------------------------------------
 // F5: tile compositing, DGR/cuda_rasterizer/forward.cu:263-392.
 // ------------------------------------------------------------------------------------------------------------------
+template <bool TRACK = false>     // TRACK: the tracking loss's cotangents in the epilogue (gsr_track_step); a kernel of its own, so the plain one keeps its registers
 __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2* __restrict__ ranges,
                                                         const uint2* sorted /* may alias sorted_out */, int W, int H,
                                                         const TileRec* __restrict__ rec,
@@ -172,7 +173,7 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
                                                         float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
                                                         const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
                                                         uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
-                                                        const uint32_t* __restrict__ tile_pos, int fwd_order)
+                                                        const uint32_t* __restrict__ tile_pos, int fwd_order, const TrackLossArgs& tl)
 {
     if (spec_header && (spec_header[HDR_FLAGS] & FLAG_OVERFLOW)) return;   // speculative launch on a buffer that turned out too small
     TL_BEGIN();
@@ -197,6 +198,18 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
     // costs in the loop (six SALU instructions per pair).
     const float INF = __builtin_inff();
     float thr = inside ? 1.0f / 255.0f : INF;
+    // TRACK: the loss's operands of this pixel are requested now and consumed in the epilogue (there they would be a memory round trip at the
+    // end of every block of a launch that lasts 15 us at tracking sizes)
+    float tl_gt[3] = {0.f, 0.f, 0.f}, tl_gtd = 0.f, tl_wr = 1.f, tl_wd = 1.f, tl_a = 0.f, tl_b = 0.f;
+    if (TRACK && tl.gt_image != nullptr && inside) {
+        const size_t N = (size_t)H * W, pix = (size_t)py * W + px;
+        tl_gt[0] = tl.gt_image[pix]; tl_gt[1] = tl.gt_image[N + pix]; tl_gt[2] = tl.gt_image[2 * N + pix];
+        tl_gtd = tl.gt_depth[pix];
+        if (tl.w_rgb) tl_wr = tl.w_rgb[pix];
+        if (tl.w_depth) tl_wd = tl.w_depth[pix];
+        if (tl.exposure_a) tl_a = tl.exposure_a[0];
+        if (tl.exposure_b) tl_b = tl.exposure_b[0];
+    }
     s_nt[t] = 0;
     float T = 1.0f;
     f2 acc_rg = {0.f, 0.f}, acc_bd = {0.f, 0.f};   // (C.r, C.g) and (C.b, D): accumulated with v_pk_fma_f32
@@ -471,16 +484,39 @@ __device__ __forceinline__ void render_fwd_body(int ntiles, int gx, const uint2*
                                            (uint32_t)m | (cstart + m < n ? 0x10000u : 0u) | (deepest <= cstart ? 0x20000u : 0u), (uint32_t)cstart);
         }
     }
+    const float out_rgb[3] = {acc_rg.x + T * bg[0], acc_rg.y + T * bg[1], acc_bd.x + T * bg[2]};    // forward.cu:384-390
+    const float out_op = 1.0f - T;
     if (inside) {
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = T;
         n_contrib[pix] = last;
         final_C[pix] = make_float4(acc_rg.x, acc_rg.y, acc_bd.x, acc_bd.y);   // colour / depth without the background term
-        out_color[pix] = acc_rg.x + T * bg[0];                                                      // forward.cu:384-390
-        out_color[(size_t)H * W + pix] = acc_rg.y + T * bg[1];
-        out_color[2 * (size_t)H * W + pix] = acc_bd.x + T * bg[2];
+        out_color[pix] = out_rgb[0];
+        out_color[(size_t)H * W + pix] = out_rgb[1];
+        out_color[2 * (size_t)H * W + pix] = out_rgb[2];
         out_depth[pix] = acc_bd.y;
-        out_opacity[pix] = 1.0f - T;
+        out_opacity[pix] = out_op;
+    }
+    if (TRACK && tl.gt_image != nullptr) {
+        // Tracking (gsr_track_step): the weighted L1 loss's cotangents of this pixel, formed from the values still in registers -- what
+        // l1_loss_bwd_kernel computes from the stored image one launch later (same function, same bits) -- and the tile's share of the two
+        // exposure gradients (256 pixels in a fixed order; the tail kernel adds the tiles).
+        const size_t N = (size_t)H * W, pix = (size_t)py * W + px;
+        float da = 0.f, db = 0.f;
+        if (inside) {
+            const float ea = tl.exposure_a ? expf(tl_a) : 1.f, eb = tl_b;
+            float wr = tl_wr * tl.c_rgb, wd = tl_wd * tl.c_depth;
+            if (tl.use_opacity) { wr *= out_op; wd = out_op > tl.opacity_thr ? wd : 0.f; }
+            const L1PixelGrad o = l1_bwd_pixel(wr, wd, ea, eb, out_rgb, tl_gt, acc_bd.y, tl_gtd, da, db);
+            tl.dL_dimage[pix] = o.gi[0]; tl.dL_dimage[N + pix] = o.gi[1]; tl.dL_dimage[2 * N + pix] = o.gi[2];
+            tl.dL_ddepth[pix] = o.gd;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { da += __shfl_xor(da, d, 64); db += __shfl_xor(db, d, 64); }
+        __shared__ float s_exp[4][2];
+        if (lane == 0) { s_exp[wave][0] = da; s_exp[wave][1] = db; }
+        __syncthreads();
+        if (t < 2) tl.partials[2 * (size_t)tile + t] = (s_exp[0][t] + s_exp[1][t]) + (s_exp[2][t] + s_exp[3][t]);
     }
     FWD_T2(if (lane == 0 && tile < 8192) { uint32_t* o = g_fwd_timing + (size_t)(tile * 4 + wave) * 8; o[7] = FWD_TICK() - tk_mark; o[0] = FWD_TICK() - tk0; })
     TL_END(0, tile);
@@ -845,7 +881,23 @@ __global__ void __launch_bounds__(RB) render_fwd_kernel(int ntiles, int gx, cons
                                                         uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
                                                         const uint32_t* __restrict__ tile_pos, int fwd_order)
 {
-    render_fwd_body(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos, fwd_order);
+    render_fwd_body<false>(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos, fwd_order, TrackLossArgs{});
+}
+
+// the same tile kernel with the tracking loss's cotangents formed in its epilogue (gsr_track_step)
+__global__ void __launch_bounds__(RB) render_fwd_track_kernel(int ntiles, int gx, const uint2* __restrict__ ranges,
+                                                        const uint2* sorted /* may alias sorted_out */, int W, int H,
+                                                        const TileRec* __restrict__ rec,
+                                                        const float* __restrict__ bg, float* __restrict__ final_T,
+                                                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                                                        float* __restrict__ out_depth, float* __restrict__ out_opacity,
+                                                        int* __restrict__ n_touched, float4* __restrict__ final_C,
+                                                        float* __restrict__ ckpt, const uint32_t* __restrict__ spec_header,
+                                                        const uint64_t* __restrict__ keys, const uint32_t* __restrict__ inst_gauss,
+                                                        uint2* sorted_out, const uint32_t* __restrict__ chunk_base, uint4* __restrict__ chunk_info,
+                                                        const uint32_t* __restrict__ tile_pos, int fwd_order, TrackLossArgs tl)
+{
+    render_fwd_body<true>(ntiles, gx, ranges, sorted, W, H, rec, bg, final_T, n_contrib, out_color, out_depth, out_opacity, n_touched, final_C, ckpt, spec_header, keys, inst_gauss, sorted_out, chunk_base, chunk_info, tile_pos, fwd_order, tl);
 }
 
 #ifndef GSR_BWD_WAVES

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(RB) render_fwd_views_kernel(ViewTable t, ViewD
     const BinningPtrs bin = view_binning(s, d);
     render_fwd_body(d.T, d.gx, img.ranges, bin.sorted, d.W, d.H, geom.rec, bg, img.final_T, img.n_contrib, s.out_color, s.out_depth, s.out_opacity, s.n_touched,
                     img.final_C, bin.ckpt, geom.header, fuse_sort ? (const uint64_t*)bin.keys : nullptr, (const uint32_t*)bin.inst_gauss, bin.sorted,
-                    (const uint32_t*)img.chunk_base, bin.chunk_info, order_tiles ? (const uint32_t*)img.tile_count : nullptr, (order_tiles & 2) ? 1 : 0);
+                    (const uint32_t*)img.chunk_base, bin.chunk_info, order_tiles ? (const uint32_t*)img.tile_count : nullptr, (order_tiles & 2) ? 1 : 0, TrackLossArgs{});
 }
 
 __global__ void __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, 8))) render_bwd_views_kernel(ViewTable t, ViewDims d, const float* __restrict__ bg)

@@ -21,6 +21,11 @@ class CameraStep(C.Structure):          # gsr_camera_step
                 ("converged", _vp), ("converged_threshold", _f), ("do_pose", _i), ("latch", _i)]
 
 
+class TrackLoss(C.Structure):           # gsr_track_loss
+    _fields_ = [("gt_image", _vp), ("gt_depth", _vp), ("w_rgb", _vp), ("w_depth", _vp), ("alpha", _f), ("opacity_depth_threshold", _f),
+                ("opacity_weights", _i)]
+
+
 class KeyframeEntry(C.Structure):       # gsr_keyframe_entry
     _fields_ = [(n, _vp) for n in ("viewmatrix", "full_proj", "campos", "exposure_a", "exposure_b", "gt_image", "gt_depth", "w_rgb", "w_depth")]
 
@@ -46,6 +51,12 @@ def lib():
         L.gsr_camera_step_launch.argtypes = [C.POINTER(CameraStep), _vp]
         L.gsr_camera_steps_launch.restype = _i
         L.gsr_camera_steps_launch.argtypes = [_i, C.POINTER(CameraStep), _vp]
+        from diff_gaussian_rasterization.raw import _RawInputs
+        L.gsr_track_workspace_size.restype = C.c_size_t
+        L.gsr_track_workspace_size.argtypes = [_i, _i]
+        L.gsr_track_step.restype = _i
+        L.gsr_track_step.argtypes = [_C._ALLOC_FN, _vp, _C._ALLOC_FN, _vp, _C._ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, C.POINTER(_RawInputs), _f, _vp,
+                                     _f, _f, _vp, _vp, _vp, _vp, _vp, C.POINTER(TrackLoss), C.POINTER(CameraStep), _vp, _vp, _vp]
         L.gsr_schedule_advance.restype = _i
         L.gsr_schedule_advance.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
         L.gsr_slot_gather.restype = _i

@@ -11,6 +11,9 @@ flag every few iterations. Three things make the iteration capturable:
   * the frame's data (image, depth, loss weights, pose) is COPIED into a static slot per frame, so one captured graph serves every
     frame tracked against the same map; it is re-captured when the map's tensors change (after every keyframe).
 If a frame outgrows the speculative binning capacity during replay (gsr_forward_status), the caller repeats the frame eagerly."""
+import ctypes as C
+import math
+import os
 import types
 
 import torch
@@ -21,7 +24,11 @@ import gaussian_renderer
 from gaussian_renderer import render
 import slam_losses
 
+from . import _lib
 from .camera import Camera
+
+# GSR_TRACK_STEP=0: the iteration through autograd (render -> weighted_l1_loss -> backward -> pose_step: ten launches), as rounds 2-5 ran it
+FUSED_STEP = os.environ.get("GSR_TRACK_STEP", "1") not in ("", "0")
 
 
 class TrackingGraph:
@@ -49,6 +56,8 @@ class TrackingGraph:
         # screen-space gradients, the visibility mask) are two launches per iteration that tracking never looks at
         self.direct = gaussian_renderer._fused_prologue_ok(gaussians, pipeline_params, self.static, False) and gaussians.get_xyz.shape[0] > 0
         self.means2D = torch.zeros_like(gaussians.get_xyz)
+        bg_ok = isinstance(background, torch.Tensor) and background.is_cuda and background.dtype == torch.float32 and background.is_contiguous()
+        self.fused = FUSED_STEP and self.direct and bg_ok
         # ... and with DETACHED parameters: tracking reads the pose gradient only, so the backward pass runs in its pose-only mode
         # (GSR_BACKWARD_POSE_ONLY: no parameter-gradient stores, no covariance -> scale / rotation chain, nothing to zero per iteration)
         g = gaussians
@@ -89,8 +98,43 @@ class TrackingGraph:
         viewpoint.exposure_b.copy_(self.cam.exposure_b)
 
     # ---- the iteration ---------------------------------------------------------------------------------------------------
+    def _fused_iteration(self):
+        """The whole iteration as ONE C call, five launches (include/slam_map.h: gsr_track_step): the loss's cotangents in the tile kernel's
+        epilogue, pose-only backward, and one tail launch for the gradient sums + the camera step. Pixel cotangents and the pose gradient are
+        the bits of the autograd route; the two exposure gradients are summed per tile instead of per 256 strided pixels (equal to rounding)."""
+        c, g = self.cam, self.frozen
+        dev = c.device
+        H, W = int(c.image_height), int(c.image_width)
+        P = int(g._xyz.shape[0] if self.static is None else self.static._gsr_gather.shape[0])
+        M = 1 + (int(g._features_rest.shape[1]) if g._features_rest.numel() else 0)
+        img = torch.empty((_C.NUM_CHANNELS + 2, H, W), dtype=torch.float32, device=dev)
+        color, depth, opacity = img[:_C.NUM_CHANNELS], img[_C.NUM_CHANNELS:_C.NUM_CHANNELS + 1], img[_C.NUM_CHANNELS + 1:]
+        ints = torch.empty((2, P), dtype=torch.int32, device=dev)
+        lib = _lib.lib()
+        ws = torch.empty((int(lib.gsr_track_workspace_size(W, H)),), dtype=torch.uint8, device=dev)
+        geom, binning, imgbuf = _C._Arena(dev), _C._Arena(dev), _C._Arena(dev)
+        keep = []
+        f_rest = g._features_rest if g._features_rest.numel() else None
+        desc = _raw._describe(g._xyz, g._scaling, g._rotation, g._opacity, g._features_dc, f_rest, None, None, None, None, keep,
+                              None if self.static is None else self.static._gsr_gather)
+        loss = _lib.TrackLoss()
+        loss.gt_image, loss.gt_depth = self.gt_image.data_ptr(), self.gt_depth.data_ptr()
+        loss.w_rgb, loss.w_depth = self.w_rgb.data_ptr(), self.w_dep.data_ptr()
+        loss.alpha, loss.opacity_depth_threshold, loss.opacity_weights = float(self.alpha), 0.95, 1
+        step = c._step_desc(None, tuple(float(x) for x in self.lrs), True, 1e-4, True)
+        with torch.cuda.device(dev):
+            rc = lib.gsr_track_step(geom.cb, None, binning.cb, None, imgbuf.cb, None, P, int(g.active_sh_degree), M, self.background.data_ptr(), W, H,
+                                    C.byref(desc), 1.0, c.projection_matrix.data_ptr(), math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5),
+                                    color.data_ptr(), depth.data_ptr(), opacity.data_ptr(), ints[0].data_ptr(), ints[1].data_ptr(),
+                                    C.byref(loss), C.byref(step), self.means2D.data_ptr(), ws.data_ptr(), _lib.stream(dev))
+        _lib.check(rc, "gsr_track_step")
+        self.workspace = ws         # (tests read the cotangents and the gradient sums from it)
+        return {"render": color, "radii": ints[0], "depth": depth, "opacity": opacity, "n_touched": ints[1]}
+
     def iteration(self):
         c = self.cam
+        if self.fused:
+            return self._fused_iteration()
         if self.direct:
             image, radii, depth, opacity, n_touched = gaussian_renderer._render_fused(c, self.frozen, self.background, 1.0, self.means2D, None, None,
                                                                                       None, self.static, False)

@@ -9,6 +9,7 @@
 #define SLAM_MAP_H_INCLUDED
 
 #include <stddef.h>
+#include "gs_rasterizer.h"   /* gsr_alloc_fn, gsr_raw_inputs (gsr_track_step) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -98,6 +99,33 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
  * (utils/slam_backend.py:748-755, :1213-1222) are stepped together. Same arithmetic per camera as gsr_camera_step_launch. */
 #define GSR_CAMERA_STEPS_MAX 12
 int gsr_camera_steps_launch(int n, const gsr_camera_step* steps /* host array */, void* stream);
+
+/* ---- a tracking iteration in one call: utils/slam_frontend.py:405-448 (render -> get_loss_tracking -> loss.backward() -> pose_optimizer.step()
+ * -> update_pose), five launches at SLAM sizes (round 6; ten before) ---------------------------------------------------------------
+ * gsr_forward_raw's pipeline with the weighted L1 tracking loss's cotangents (utils/slam_utils.py:57-173, include/slam_losses.h:
+ * gsr_l1_loss_backward's arithmetic, pixel for pixel the same bits) formed in the epilogue of the tile kernel from the pixel still in
+ * registers; the backward pass in its pose-only mode (GSR_BACKWARD_POSE_ONLY); and ONE tail launch that finishes the pose-gradient sum
+ * dL/dtau [rho | theta] and the two exposure-gradient sums in a fixed order and performs gsr_camera_step_launch's step with them (handed over
+ * in LDS). Nothing passes through autograd or the host; capturable in a hipGraph (lazy mode, like gsr_forward_raw).
+ *   camera: `step` -- its viewmatrix / full_proj / campos are the matrices the pass renders with (and the step refreshes), rot_delta /
+ *     trans_delta are stepped always, exposure_a / exposure_b when given (both or neither; they also enter the loss as exp(a) I + b). The
+ *     g_* fields are ignored. projmatrix_raw: the projection without the view (P^T), as gsr_backward_raw takes it.
+ *   loss: alpha * mean_{3,H,W}(w_rgb |exp(a) I + b - gt_image|) + (1 - alpha) * mean_{H,W}(w_depth |D - gt_depth|); opacity_weights = 1
+ *     (tracking): w_rgb *= rendered opacity, w_depth *= (opacity > opacity_depth_threshold). Weights may be NULL (= 1).
+ *   workspace (gsr_track_workspace_size bytes, 16-byte aligned), as floats: dL_dimage [3 N] | dL_ddepth [N] | exposure partial sums [2 T] |
+ *     dL_dtau [6] | dL_dexposure [2]  (N = width * height, T = 16 x 16 tiles) -- readable after the call (tests compare them with the
+ *     autograd route: images and dL_dtau bit-identical, the exposure sums equal to rounding: per tile here, per 256 strided pixels there).
+ * Returns what gsr_forward_raw returns (instances, or the speculative capacity in lazy mode); < 0: error. Outputs as gsr_forward_raw. */
+typedef struct gsr_track_loss {
+    const float* gt_image; const float* gt_depth; const float* w_rgb; const float* w_depth;
+    float alpha; float opacity_depth_threshold; int opacity_weights;
+} gsr_track_loss;
+size_t gsr_track_workspace_size(int width, int height);
+int gsr_track_step(gsr_alloc_fn geometry_alloc, void* geometry_user, gsr_alloc_fn binning_alloc, void* binning_user, gsr_alloc_fn image_alloc,
+                   void* image_user, int P, int D, int M, const float* background, int width, int height, const gsr_raw_inputs* in,
+                   float scale_modifier, const float* projmatrix_raw, float tan_fovx, float tan_fovy, float* out_color, float* out_depth,
+                   float* out_opacity, int* radii, int* n_touched, const gsr_track_loss* loss, const gsr_camera_step* step, float* dL_dmean2D,
+                   char* workspace, void* stream);
 
 /* ---- a mapping iteration as ONE hipGraph (utils/slam_backend.py:1013-1224; slam/mapping_graph.py) ----------------------------------
  * A captured graph cannot take new host values per replay. What changes from one mapping iteration to the next -- WHICH two random

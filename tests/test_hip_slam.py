@@ -396,6 +396,65 @@ def test_tracking_iteration_as_hip_graph_is_bit_identical_to_eager():
     assert torch.equal(tg2.cam.R, tg.cam.R) and torch.equal(tg2.cam.T, tg.cam.T)
 
 
+def test_fused_tracking_step_equals_the_autograd_iteration():
+    """gsr_track_step (loss cotangents in render_fwd's epilogue, pose-only backward, one tail launch for the gradient sums and the camera
+    step) against the same iteration through autograd (render -> weighted_l1_loss -> backward -> pose_step): the image, the loss's pixel
+    cotangents and the pose gradient are the SAME BITS; the two exposure gradients are sums in another order (per tile / per 256 strided
+    pixels) and agree to rounding; after ten iterations the poses agree to 1e-6."""
+    import slam.tracking_graph as tgm
+    from diff_gaussian_rasterization import raw as _raw
+    import slam_losses
+    slam, cam = _tracking_fixture()
+    fe = slam.frontend
+    fused = tgm.TrackingGraph(fe.gaussians, fe.pipeline_params, fe.background, fe.config, cam)
+    assert fused.fused                                            # the route the front-end takes
+    old = tgm.FUSED_STEP
+    tgm.FUSED_STEP = False
+    try:
+        auto = tgm.TrackingGraph(fe.gaussians, fe.pipeline_params, fe.background, fe.config, cam)
+    finally:
+        tgm.FUSED_STEP = old
+    assert not auto.fused
+    fused.load(cam); auto.load(cam)
+    with torch.no_grad():                                         # a non-trivial exposure, so that exp(a) and b matter
+        for t in (fused, auto):
+            t.cam.exposure_a.fill_(0.03); t.cam.exposure_b.fill_(-0.01)
+    # (1) one iteration from the same state, gradients captured on the autograd side
+    c = auto.cam
+    image, radii, depth, opacity, n_touched = __import__("gaussian_renderer")._render_fused(c, auto.frozen, auto.background, 1.0, auto.means2D, None, None,
+                                                                                             None, auto.static, False)
+    image.retain_grad(); depth.retain_grad()
+    loss = slam_losses.weighted_l1_loss(image, depth, auto.gt_image, auto.gt_depth, auto.w_rgb, auto.w_dep, c.exposure_a, c.exposure_b, auto.alpha,
+                                        opacity=opacity, opacity_depth_threshold=0.95, compute_value=False)
+    loss.backward(auto._one)
+    g_img, g_dep = image.grad.clone(), depth.grad.clone()
+    g_rot, g_trans = c.cam_rot_delta.grad.clone(), c.cam_trans_delta.grad.clone()
+    g_a, g_b = c.exposure_a.grad.clone(), c.exposure_b.grad.clone()
+    c.pose_step(*auto.lrs, latch=True)
+    pkg = fused.iteration()
+    H, W = int(c.image_height), int(c.image_width)
+    N, T = H * W, ((W + 15) // 16) * ((H + 15) // 16)
+    ws = fused.workspace.view(torch.float32)
+    assert torch.equal(pkg["render"], image.detach()) and torch.equal(pkg["depth"], depth.detach()) and torch.equal(pkg["opacity"], opacity.detach())
+    assert torch.equal(ws[:3 * N].view(3, H, W), g_img) and torch.equal(ws[3 * N:4 * N].view(1, H, W), g_dep)
+    tau = ws[4 * N + 2 * T:4 * N + 2 * T + 6]
+    assert float(g_rot.abs().max()) > 0 and float(g_trans.abs().max()) > 0
+    assert torch.equal(tau[3:], g_rot.view(-1)) and torch.equal(tau[:3], g_trans.view(-1))
+    g_exp = ws[4 * N + 2 * T + 6:4 * N + 2 * T + 8]
+    torch.testing.assert_close(g_exp[0:1], g_a.view(-1), rtol=2e-5, atol=1e-8)
+    torch.testing.assert_close(g_exp[1:2], g_b.view(-1), rtol=2e-5, atol=1e-8)
+    assert torch.equal(fused.cam.R, auto.cam.R) and torch.equal(fused.cam.T, auto.cam.T)        # the pose step saw the same pose gradient
+    torch.testing.assert_close(fused.cam.exposure_a.detach(), auto.cam.exposure_a.detach(), rtol=1e-5, atol=1e-8)
+    # (2) nine more: the exposures differ by rounding from here on, the poses follow each other
+    for _ in range(9):
+        fused.iteration(); auto.iteration()
+    torch.testing.assert_close(fused.cam.R, auto.cam.R, rtol=0, atol=2e-6)
+    torch.testing.assert_close(fused.cam.T, auto.cam.T, rtol=0, atol=2e-6)
+    torch.testing.assert_close(fused.cam.exposure_a.detach(), auto.cam.exposure_a.detach(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(fused.cam.exposure_b.detach(), auto.cam.exposure_b.detach(), rtol=1e-4, atol=1e-7)
+    assert float(fused.cam._adam[16]) == 10.0 == float(auto.cam._adam[16])                  # ten Adam steps on both sides
+
+
 def test_slam_with_tracking_graph_matches_eager_quality():
     from slam.dataset import SyntheticRGBDDataset
     from slam.system import SLAM
