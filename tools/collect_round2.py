@@ -55,7 +55,7 @@ out["whole_step_traffic_over_algorithmic"] = out["whole_step_traffic_bytes"] / b
 json.dump(out, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_rocprof.json", "long_lists.json", "tracking_graph.json", "config3.json", "render_wrapper.json", "slam_demo.json",
              "mapping_iteration.json", "mapping_iterationflow.json", "mapping_iterationnodes.json", "mapping_iterationnodesflow.json",
-             "phase_cycles.json", "phase_cycles_slam_scale.json", "views.json", "views_deltas.json", "views_100k.json", "backend_map.jsonl",
+             "phase_cycles.json", "phase_cycles_slam_scale.json", "tracking_probe.json", "tracking_probe_autograd_route.json", "deform_mlp.jsonl", "views.json", "views_deltas.json", "views_100k.json", "backend_map.jsonl",
              "mapping_iteration_launches_dynamic.json", "mapping_iteration_launches_static.json", "dynamic_reproducibility.txt",
              "bench_two_ranks_one_gpu_gloo.json", "config4_stand_in.json", "mapping_iteration_launches_dynamic_library_trunk.json", "dense_layers.jsonl", "tile_timeline.json", "tile_timeline_tile_order.json",
              "dispatch_census.json"):

@@ -32,6 +32,9 @@ GSR_BENCH_DEVICE=0 GSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --
 if [ -z "$CORE" ]; then
 python tools/bench_views.py 2> /dev/null | tail -1 > $O/views.json
 python tools/bench_tracking.py 2> /dev/null | tail -1 > $O/tracking_graph.json
+python tools/dev_track_probe.py 2> /dev/null | tail -1 > $O/tracking_probe.json
+GSR_TRACK_STEP=0 python tools/dev_track_probe.py 2> /dev/null | tail -1 > $O/tracking_probe_autograd_route.json
+( for e in "GSR_MLP_FP32=1" "GSR_MLP_RT=2" "GSR_MLP_RT=4"; do env $e python tools/dev_mlp_bench.py 2> /dev/null | tail -1; done ) > $O/deform_mlp.jsonl
 python tools/bench_config3.py 2> /dev/null | tail -1 > $O/config3.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/config3_stats -o r06 -- python $R/tools/bench_config3.py --modes batched --iters 3 > /dev/null 2> $O/config3_stats.err )
 cp $(find $O/config3_stats -name '*kernel_stats.csv' | head -1) $O/config3_kernel_stats.csv 2> /dev/null; rm -rf $O/config3_stats
