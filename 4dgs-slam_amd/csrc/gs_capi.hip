@@ -2073,6 +2073,65 @@ int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* g
     return 0;
 }
 
+// several weight gradients over the same rows in one launch (gs_dense.h, round 6)
+static int dense_wgrad_many_plan(int M, int count, const gsr_dense_wgrad_item* items, DenseWgradItems* out, int* slices, int* rows_per_slice)
+{
+    if (count < 1 || count > DENSE_WGM_MAX || !items) return -1;
+    int tiles = 0;
+    for (int i = 0; i < count; i++) {
+        const gsr_dense_wgrad_item& q = items[i];
+        if (q.N < 1 || q.K < 1 || q.ldg < q.N || q.ldx < q.K || q.lddw < q.K) return -1;
+        if (out) {
+            DenseWgradItem& d = out->item[i];
+            d.G = q.G; d.X = q.X; d.dW = q.dW; d.ldg = q.ldg; d.ldx = q.ldx; d.lddw = q.lddw; d.N = q.N; d.K = q.K;
+            d.tiles_k = (q.K + DENSE_BN - 1) / DENSE_BN; d.tile0 = tiles;
+            d.vec = (q.N % 4 == 0 && q.K % 4 == 0 && q.ldg % 4 == 0 && q.ldx % 4 == 0 && reinterpret_cast<uintptr_t>(q.G) % 16 == 0 && reinterpret_cast<uintptr_t>(q.X) % 16 == 0) ? 1 : 0;
+        }
+        tiles += ((q.N + DENSE_BM - 1) / DENSE_BM) * ((q.K + DENSE_BN - 1) / DENSE_BN);
+    }
+    if (out) { out->count = count; out->total_tiles = tiles; }
+    // every block resident at once (two per CU), at least four 32-row steps per slice; GSR_WGM_BLOCKS: dev knob
+    static const int blocks = getenv("GSR_WGM_BLOCKS") ? std::max(1, atoi(getenv("GSR_WGM_BLOCKS"))) : 512;
+    int s = std::max(1, blocks / std::max(1, tiles));
+    s = std::min(s, std::max(1, (M + 4 * DENSE_WG_ROWS - 1) / (4 * DENSE_WG_ROWS)));
+    const int rps = std::max(DENSE_WG_ROWS, round_up_int((std::max(M, 1) + s - 1) / s, DENSE_WG_ROWS));
+    *rows_per_slice = rps;
+    *slices = std::max(1, (M + rps - 1) / rps);
+    return tiles;
+}
+
+size_t gsr_dense_wgrad_many_workspace_size(int M, int count, const gsr_dense_wgrad_item* items)
+{
+    int slices, rps;
+    const int tiles = dense_wgrad_many_plan(M, count, items, nullptr, &slices, &rps);
+    if (tiles < 0 || M < 1) return 256;
+    return (size_t)slices * tiles * (DENSE_BM * DENSE_BN) * sizeof(float) + 256;
+}
+
+int gsr_dense_wgrad_many(int M, int count, const gsr_dense_wgrad_item* items, char* workspace, void* stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DenseWgradItems t;
+    memset(&t, 0, sizeof(t));
+    int slices, rps;
+    const int tiles = M < 0 ? -1 : dense_wgrad_many_plan(M, count, items, &t, &slices, &rps);
+    bool ok = tiles > 0;
+    for (int i = 0; ok && i < count; i++) ok = items[i].dW && (M == 0 || (items[i].G && items[i].X));
+    if (!ok || (M > 0 && !workspace)) {
+        g_last_error = "gsr_dense_wgrad_many: invalid argument (1..12 items, ldg >= N, ldx >= K, lddw >= K, non-null operands and workspace)"; return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (M == 0) {
+        for (int i = 0; i < count; i++)
+            GSR_HIP_CHECK(hipMemset2DAsync(items[i].dW, (size_t)items[i].lddw * sizeof(float), 0, (size_t)items[i].K * sizeof(float), (size_t)items[i].N, stream));
+        return 0;
+    }
+    float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+    hipLaunchKernelGGL(dense_wgrad_many_kernel, dim3((unsigned)tiles, (unsigned)slices), dim3(DENSE_THREADS), 0, stream, M, t, rps, partial);
+    hipLaunchKernelGGL(dense_wgrad_many_sum_kernel, dim3((unsigned)tiles, 16), dim3(256), 0, stream, t, slices, (const float*)partial);
+    GSR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int gsr_trunk_forward(const gsr_trunk* t, int R, const float* emb, float* const* outs, const int* ldo, float* heads, void* stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;

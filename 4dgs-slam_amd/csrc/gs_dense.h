@@ -666,6 +666,162 @@ dense_wgrad_sum_kernel(const int slices, const int count, const float* __restric
     dW[(size_t)(e / K) * lddw + e % K] = (s0 + s1) + (s2 + s3);
 }
 
+// ---- round 6: SEVERAL weight gradients in one launch (gsr_dense_wgrad_many) ----------------------------------------------------------------------
+// The node network's backward leaves every layer's G and input in memory (the chained input-gradient launch), so the D + 1 products
+// dW_i = G_i^T X_i over the same M rows are independent: ONE launch of (all 128 x 128 result tiles) x (row slices), sized so that the chip holds
+// every block at once (two per CU), instead of one launch per layer whose 256 x 256 result gives the chip four tiles to spread over 256 CUs.
+// What the single-product kernel above spent besides its matrix instructions is cut here:
+//  * operands come in as float4 (a thread: four rows x four consecutive columns of G and of X per 32-row step -- 8 loads of 16 bytes instead of
+//    32 of 4), are split once per block and step, and go to LDS TRANSPOSED as 8-byte pieces (four k of one column, one ds_write_b64 per plane).
+//    Thread <-> (rows, columns) and the order in which a thread writes its four columns are chosen so that the sixteen lanes the LDS serves
+//    together always write sixteen different 8-byte slots of a 128-byte bank row: lane bits {0} = row group, {1} = column order flipped (column
+//    parity), {2, 3} = column group mod 4 (which selects the chunk swizzle g below) -- conflict-free stores AND conflict-free ds_read_b128
+//    fragment reads (the read pattern is mlp3_off<4>'s: g = 0, 3, 2, 1 for columns 0-3, 4-7, 8-11, 12-15 of a 16-column tile);
+//  * the slices' partial tiles are stored tile-local ([slice][tile][128][128]) and summed by float4 in a fixed order.
+// Items whose rows are not 16-byte aligned (the heads' [M, 14] cotangent) take scalar loads.
+constexpr int DENSE_WGM_MAX = 12;
+struct DenseWgradItem { const float* G; const float* X; float* dW; int ldg, ldx, lddw, N, K, tiles_k, tile0, vec; };   // tile0: first tile of the item; vec: float4 loads allowed
+struct DenseWgradItems { DenseWgradItem item[DENSE_WGM_MAX]; int count, total_tiles; };
+
+// byte offset of the 8-byte piece s (k = 4 s .. 4 s + 3) of column c in a [128][32 k] bf16 plane
+__device__ __forceinline__ int dense_wgm_off(int c, int s) { return c * DENSE_ROW_B + 16 * ((s >> 1) ^ ((0 - (c >> 2)) & 3)) + 8 * (s & 1); }
+
+template <bool VEC>
+__device__ __forceinline__ void dense_wgrad_many_body(const int M, const DenseWgradItems& items, const int it, const int rows_per_slice, float* __restrict__ partial,
+                                                      unsigned char (&s_g)[3][DENSE_BM * DENSE_ROW_B], unsigned char (&s_x)[3][DENSE_BN * DENSE_ROW_B])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DenseWgradItem& q = items.item[it];
+    const int tl = (int)blockIdx.x - q.tile0, n0 = (tl / q.tiles_k) * DENSE_BM, k0 = (tl % q.tiles_k) * DENSE_BN;
+    const int N = q.N, K = q.K, ldg = q.ldg, ldx = q.ldx;
+    const float* __restrict__ G = q.G;
+    const float* __restrict__ X = q.X;
+    const int r_begin = blockIdx.y * rows_per_slice, r_end = min(M, r_begin + rows_per_slice);
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    const int fi = lane & 15, fq = lane >> 4;
+    dense_acc acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = dense_acc{0.f, 0.f, 0.f, 0.f};
+    // staging: thread = (row group rg: rows 4 rg .. 4 rg + 3 of the step, column group cg: columns 4 cg .. 4 cg + 3 of the tile)
+    const int rg = (lane & 1) | (wave << 1);
+    const int cg = ((lane >> 2) & 3) | (((lane >> 1) & 1) << 2) | ((lane >> 4) << 3);
+    const bool flip = ((lane >> 1) & 1) != 0;
+    const int st_base = dense_wgm_off(4 * cg, rg);                 // + 64 per column (the swizzle depends on cg only)
+    float4 gv[4], xv[4];
+    auto load4 = [&](const float* __restrict__ P, int ld, int r, int c, int C) -> float4 {
+        if (r >= r_end || c >= C) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* p = P + (size_t)r * ld + c;
+        if (VEC) return *reinterpret_cast<const float4*>(p);      // (C % 4 == 0, 16-byte aligned rows)
+        return make_float4(p[0], c + 1 < C ? p[1] : 0.f, c + 2 < C ? p[2] : 0.f, c + 3 < C ? p[3] : 0.f);
+    };
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            gv[i] = load4(G, ldg, r0 + 4 * rg + i, n0 + 4 * cg, N);
+            xv[i] = load4(X, ldx, r0 + 4 * rg + i, k0 + 4 * cg, K);
+        }
+    };
+    auto stage_one = [&](const float4 (&v)[4], unsigned char (&dst)[3][DENSE_BM * DENSE_ROW_B]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // column 4 cg + (j ^ flip): the four rows of that column
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float a = j == 0 ? v[i].x : j == 1 ? v[i].y : j == 2 ? v[i].z : v[i].w;
+                const float b = j == 0 ? v[i].y : j == 1 ? v[i].x : j == 2 ? v[i].w : v[i].z;
+                x[i] = flip ? b : a;
+            }
+            uint2 h, m, l;
+            {
+                uint32_t a[4], b[4], c[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) dense_split(x[e], a[e], b[e], c[e]);
+                h = make_uint2(dense_pack(a[0], a[1]), dense_pack(a[2], a[3]));
+                m = make_uint2(dense_pack(b[0], b[1]), dense_pack(b[2], b[3]));
+                l = make_uint2(dense_pack(c[0], c[1]), dense_pack(c[2], c[3]));
+            }
+            const int o = st_base + DENSE_ROW_B * (flip ? (j ^ 1) : j);
+            *reinterpret_cast<uint2*>(&dst[0][o]) = h; *reinterpret_cast<uint2*>(&dst[1][o]) = m; *reinterpret_cast<uint2*>(&dst[2][o]) = l;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += DENSE_WG_ROWS) {
+        __syncthreads();
+        stage_one(gv, s_g);
+        stage_one(xv, s_x);
+        __syncthreads();
+        if (r0 + DENSE_WG_ROWS < r_end) fetch(r0 + DENSE_WG_ROWS);
+        const int rsw = 16 * (fq ^ ((0 - (fi >> 2)) & 3));        // = dense_wgm_off(16 t + fi, 2 fq) - (16 t + fi) * 64
+        dense_frag b[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) b[j][p] = dense_ld_frag(&s_x[p][(wn + 16 * j + fi) * DENSE_ROW_B + rsw]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            dense_frag a[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) a[p] = dense_ld_frag(&s_g[p][(wm + 16 * i + fi) * DENSE_ROW_B + rsw]);
+            dense_mfma6x4(a, b, acc[i]);
+        }
+    }
+    // the block's partial tile, tile-local [128 n][128 k]
+    float* out = partial + ((size_t)blockIdx.y * items.total_tiles + blockIdx.x) * (DENSE_BM * DENSE_BN);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(wm + 16 * i + 4 * fq + r) * DENSE_BN + wn + 16 * j + fi] = acc[i][j][r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(DENSE_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+dense_wgrad_many_kernel(const int M, const DenseWgradItems items, const int rows_per_slice, float* __restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_g[3][DENSE_BM * DENSE_ROW_B];   // [plane][n][32 rows]
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[3][DENSE_BN * DENSE_ROW_B];   // [plane][k][32 rows]
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < items.count; i++) if ((int)blockIdx.x >= items.item[i].tile0) it = i;
+    // two copies of the body: with the flag tested per load the compiler merged both forms into a dword + dwordx3 pair
+    if (items.item[it].vec) dense_wgrad_many_body<true>(M, items, it, rows_per_slice, partial, s_g, s_x);
+    else dense_wgrad_many_body<false>(M, items, it, rows_per_slice, partial, s_g, s_x);
+}
+
+// dW tiles = the slices' partial tiles added in slice order; grid = (tiles, 16): a block sums 8 rows of 128 of a tile per round, float4 per thread
+__global__ void __launch_bounds__(256)
+dense_wgrad_many_sum_kernel(const DenseWgradItems items, const int slices, const float* __restrict__ partial)
+{
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < items.count; i++) if ((int)blockIdx.x >= items.item[i].tile0) it = i;
+    const DenseWgradItem& q = items.item[it];
+    const int tl = (int)blockIdx.x - q.tile0, n0 = (tl / q.tiles_k) * DENSE_BM, k0 = (tl % q.tiles_k) * DENSE_BN;
+    const size_t tile_stride = (size_t)items.total_tiles * (DENSE_BM * DENSE_BN);
+    const float* src = partial + (size_t)blockIdx.x * (DENSE_BM * DENSE_BN);
+    const int e4 = blockIdx.y * 256 + threadIdx.x;                // float4 index inside the tile: 4096 per tile, 16 blocks of 256
+    const int row = e4 >> 5, col = (e4 & 31) * 4;
+    const float4* p = reinterpret_cast<const float4*>(src) + e4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int b = 0;
+    for (; b + 3 < slices; b += 4) {
+        const float4 v0 = p[(size_t)b * (tile_stride / 4)], v1 = p[(size_t)(b + 1) * (tile_stride / 4)];
+        const float4 v2 = p[(size_t)(b + 2) * (tile_stride / 4)], v3 = p[(size_t)(b + 3) * (tile_stride / 4)];
+        add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
+    }
+    for (; b < slices; b++) add(s0, p[(size_t)b * (tile_stride / 4)]);
+    const float o[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+    const int n = n0 + row;
+    if (n >= q.N) return;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (k0 + col + e < q.K) q.dW[(size_t)n * q.lddw + k0 + col + e] = o[e];
+}
 
 // ---- the node network's trunk, forward, layer-fused -------------------------------------------------------------------------------------------
 // utils/time_utils.py:428-452 with the shipped structure: eight layers y = relu(x W^T + b) of width 256, the embedding (width E <= 96)

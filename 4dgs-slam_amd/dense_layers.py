@@ -32,6 +32,11 @@ class _ChainOp(C.Structure):         # gsr_dense_chain_op
                 ("Y", C.c_void_p), ("ldy", C.c_int32), ("mask", C.c_void_p), ("ldmask", C.c_int32), ("dbias", C.c_void_p)]
 
 
+class _WgradItem(C.Structure):      # gsr_dense_wgrad_item
+    _fields_ = [("G", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("ldg", C.c_int32), ("ldx", C.c_int32), ("lddw", C.c_int32),
+                ("N", C.c_int32), ("K", C.c_int32)]
+
+
 class _SplitItem(C.Structure):      # gsr_dense_split_item
     _fields_ = [("W", C.c_void_p), ("planes", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("ldw", C.c_int32), ("k0", C.c_int32), ("transposed", C.c_int32)]
 
@@ -51,6 +56,10 @@ def _lib():
         lib.gsr_dense_wgrad_workspace_size.argtypes = [i, i, i]
         lib.gsr_dense_wgrad.restype = i
         lib.gsr_dense_wgrad.argtypes = [i, i, i, vp, i, vp, i, vp, i, vp, i, vp, vp]
+        lib.gsr_dense_wgrad_many_workspace_size.restype = C.c_size_t
+        lib.gsr_dense_wgrad_many_workspace_size.argtypes = [i, i, C.POINTER(_WgradItem)]
+        lib.gsr_dense_wgrad_many.restype = i
+        lib.gsr_dense_wgrad_many.argtypes = [i, i, C.POINTER(_WgradItem), vp, vp]
         lib.gsr_dense_backward_input_workspace_size.restype = C.c_size_t
         lib.gsr_dense_backward_input_workspace_size.argtypes = [i, i]
         lib.gsr_dense_backward_input.restype = i
@@ -224,6 +233,35 @@ def dense_wgrad(G, X, gate=None, out=None):
     if rc < 0:
         _C._err(lib, rc, "gsr_dense_wgrad")
     return out
+
+
+WGRAD_MANY_MAX = 12
+
+
+def dense_wgrad_many(pairs, outs=None):
+    """dW_i = G_i^T X_i for up to 12 (G_i [M, N_i], X_i [M, K_i]) pairs over the SAME M rows in ONE launch (gsr_dense_wgrad_many: every 128 x 128
+    result tile x row slice resident at once, slices added in a fixed order). Returns the list of dW_i [N_i, K_i]."""
+    if not 1 <= len(pairs) <= WGRAD_MANY_MAX:
+        raise ValueError("dense_wgrad_many: 1..12 products")
+    pairs = [(_rows(G, "G"), _rows(X, "X")) for G, X in pairs]
+    M = int(pairs[0][0].shape[0])
+    dev = pairs[0][0].device
+    if any(int(G.shape[0]) != M or int(X.shape[0]) != M for G, X in pairs):
+        raise ValueError("dense_wgrad_many: every G and X must have the same number of rows")
+    if outs is None:
+        outs = [torch.empty((int(G.shape[1]), int(X.shape[1])), dtype=torch.float32, device=dev) for G, X in pairs]
+    ld = lambda t: int(t.stride(0)) if M > 1 else int(t.shape[1])
+    arr = (_WgradItem * len(pairs))()
+    for it, (G, X), o in zip(arr, pairs, outs):
+        it.G, it.X, it.dW = G.data_ptr(), X.data_ptr(), o.data_ptr()
+        it.ldg, it.ldx, it.lddw, it.N, it.K = ld(G), ld(X), int(o.stride(0)), int(G.shape[1]), int(X.shape[1])
+    lib = _lib()
+    ws = torch.empty((int(lib.gsr_dense_wgrad_many_workspace_size(M, len(pairs), arr)),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gsr_dense_wgrad_many(M, len(pairs), arr, ws.data_ptr(), _C._stream(dev))
+    if rc < 0:
+        _C._err(lib, rc, "gsr_dense_wgrad_many")
+    return outs
 
 
 TRUNK_LAYERS, TRUNK_WIDTH, TRUNK_SKIP, TRUNK_MAX_EMBEDDING, TRUNK_MAX_HEAD_OUTPUTS = 8, 256, 4, 96, 16

@@ -280,6 +280,9 @@ DENSE_TRUNK = os.environ.get("GSR_DENSE_TRUNK", "1") == "1"
 # ... and the eight layers (and the seven input-gradient products on the way back) as ONE launch each (gsr_dense_chain: a block carries its rows
 # through all layers). GSR_DENSE_CHAIN=0: one launch per product.
 DENSE_CHAIN = os.environ.get("GSR_DENSE_CHAIN", "1") == "1"
+# ... and the weight gradients of all layers + heads, which the chained backward leaves as independent products over the same rows, as ONE launch
+# on the same three-term operands (gsr_dense_wgrad_many). GSR_DENSE_WGRAD_MANY=0: the library's batched fp32 GEMMs (rounds 4-5).
+DENSE_WGRAD_MANY = os.environ.get("GSR_DENSE_WGRAD_MANY", "1") == "1"
 
 
 def _dense_trunk_ok(emb, Ws, W_heads, skip):
@@ -366,7 +369,9 @@ class _FusedTrunk(torch.autograd.Function):
         grads = [None] * (2 * D)
         g_out = g_out.contiguous()
         h_last = outs[D - 1]
-        gW_heads, gb_heads = _grad_weight(g_out, h_last), g_out.sum(0)
+        wgrad_many = (DENSE_WGRAD_MANY and ctx.planes_t is not None and DENSE_CHAIN and D - 1 <= 8 and int(Ws[0].shape[0]) == 256
+                      and D + 1 <= 12 and h_last.is_contiguous())
+        gW_heads, gb_heads = (None if wgrad_many else _grad_weight(g_out, h_last)), g_out.sum(0)
         g = g_out.mm(W_heads)
         # the weight gradients of the layers of one shape (six of the eight are [W, W]) are batched products into ONE buffer, summed over their
         # row groups by one launch at the end instead of one per layer (they feed nothing on the way back)
@@ -390,6 +395,12 @@ class _FusedTrunk(torch.autograd.Function):
                 chain_G[i - 1], chain_db[i - 1] = G.new_empty((R, Wd)), G.new_empty((Wd,))
                 ops.append(dict(X=chain_G[i], planes=planes_t[i - 1], K=Wd, Y=chain_G[i - 1], mask=outs[i - 1], dbias=chain_db[i - 1]))
             dense_layers.dense_chain(ops)
+            if wgrad_many:
+                # every layer's G and input now exist: the D + 1 weight gradients as ONE launch (gsr_dense_wgrad_many), no library GEMM
+                dWs = dense_layers.dense_wgrad_many([(chain_G[i], inputs[i]) for i in range(D)] + [(g_out, h_last)])
+                for i in range(D):
+                    grads[2 * i], grads[2 * i + 1] = dWs[i], chain_db[i]
+                return (None, None, dWs[D], gb_heads, *grads)
         for i in reversed(range(D)):
             if chain_G is not None:
                 G, db = chain_G[i], chain_db[i]

@@ -75,6 +75,19 @@ size_t gsr_dense_wgrad_workspace_size(int M, int N, int K);
 int gsr_dense_wgrad(int M, int N, int K, const float* G, int ldg, const float* gate, int ldgate, const float* X, int ldx, float* dW, int lddw,
                     char* workspace, void* stream);
 
+/* Several weight gradients over the SAME M rows in one launch (the backward pass of utils/time_utils.py:428-452's eight layers + heads leaves
+ * every layer's G and input in memory): dW_i [N_i, K_i] = G_i^T X_i, at most 12 items. All 128 x 128 result tiles x row slices are resident at
+ * once; the slices' partial tiles are added in a fixed order (deterministic). Rows of G / X that are 16-byte aligned with N, K, ldg, ldx % 4 == 0
+ * are read as float4, others (the heads' [M, 14] cotangent) element-wise. workspace: gsr_dense_wgrad_many_workspace_size(M, count, items) bytes. */
+typedef struct gsr_dense_wgrad_item {
+    const float* G;
+    const float* X;
+    float* dW;
+    int32_t ldg, ldx, lddw, N, K;
+} gsr_dense_wgrad_item;
+size_t gsr_dense_wgrad_many_workspace_size(int M, int count, const gsr_dense_wgrad_item* items);
+int gsr_dense_wgrad_many(int M, int count, const gsr_dense_wgrad_item* items, char* workspace, void* stream);
+
 /* ---- the node network's trunk, forward, as ONE launch ------------------------------------------------------------------------------------
  * utils/time_utils.py:428-452 with the shipped structure: eight layers y = relu(x W^T + b) of width 256 on the embedding emb [R, E] (E <= 96),
  * the embedding re-injected behind layer 4 (layer 5's weight is [256, E + 256] and reads [emb | h]), then all heads as one linear layer of

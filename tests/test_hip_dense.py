@@ -70,6 +70,39 @@ def test_dense_wgrad_against_fp64_and_reproducible(M, N, K, gated):
     assert torch.equal(dW, dl.dense_wgrad(G, X, gate=gate))                        # fixed summation order
 
 
+@pytest.mark.parametrize("M", [1, 37, 2080, 33280, 100003])
+def test_dense_wgrad_many_against_fp64_reproducible_and_transpose_detecting(M):
+    """The node network's shapes in ONE launch (gsr_dense_wgrad_many): layer 0 [256, 84], a [256, 256] layer with strided operands (the skip
+    buffer's column window), the skip layer [256, 340], the heads [14, 256] (rows not 16-byte aligned: element-wise loads) and an odd shape."""
+    g = torch.Generator(device="cpu").manual_seed(M)
+    shapes = [(256, 84), (256, 256), (256, 340), (14, 256), (129, 33)]
+    pairs = []
+    for n, k in shapes:
+        G, X = torch.randn((M, n), generator=g).to(DEV), torch.randn((M, k), generator=g).to(DEV)
+        pairs.append((G, X))
+    wide = torch.randn((M, 340), generator=g).to(DEV)
+    pairs[1] = (pairs[1][0], wide[:, 84:])                                        # row stride 340, first column 84: 16-byte aligned rows
+    outs = dl.dense_wgrad_many(pairs)
+    for (G, X), dW in zip(pairs, outs):
+        ref = G.double().t() @ X.double()
+        err, err32 = rel(dW, ref), rel(G.t() @ X, ref)
+        assert dW.shape == ref.shape and err < 2e-6 and err < 4 * err32 + 2e-7, (tuple(dW.shape), err, err32)
+    again = dl.dense_wgrad_many(pairs)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))                      # fixed summation order
+    single = dl.dense_wgrad_many(pairs[2:3])[0]                                     # another slicing of the rows: same product to rounding
+    assert rel(single, outs[2]) < 4e-6
+
+
+def test_dense_wgrad_many_bad_arguments_raise():
+    G, X = torch.randn((9, 4), device=DEV), torch.randn((10, 8), device=DEV)
+    with pytest.raises(ValueError):
+        dl.dense_wgrad_many([(G, X)])
+    with pytest.raises(ValueError):
+        dl.dense_wgrad_many([])
+    with pytest.raises(ValueError):
+        dl.dense_wgrad_many([(X, X)] * 13)
+
+
 def test_dense_bad_arguments_raise():
     X = torch.randn((10, 8), device=DEV)
     W = torch.randn((4, 8), device=DEV)
