@@ -308,7 +308,7 @@ class _FusedTrunk(torch.autograd.Function):
     def forward(ctx, emb, skip, W_heads, b_heads, *params):
         D = len(params) // 2
         E = emb.shape[1]
-        ctx.planes_t = None
+        ctx.planes_t = ctx.heads_planes_t = None
         if LAYER_FUSED_TRUNK:
             # opt-in (GSR_LAYER_FUSED_TRUNK=1): the eight layers + heads as ONE launch on the bf16 matrix cores with fp32-accurate three-term
             # operands (include/dense_layers.h gsr_trunk_forward). Same values to fp32-GEMM accuracy; faster than the library from ~50 k rows
@@ -326,6 +326,9 @@ class _FusedTrunk(torch.autograd.Function):
             Wd, R = int(Ws[0].shape[0]), int(emb.shape[0])
             # every layer's weight as bf16 planes, and the transposed planes of its hidden columns for the way back: one launch
             requests = [(w.detach(), 0, None, False) for w in Ws] + [(Ws[i].detach(), E if i == skip + 1 else 0, Wd, True) for i in range(1, D)]
+            heads_dense = DENSE_WGRAD_MANY and int(W_heads.shape[1]) == Wd and W_heads.is_contiguous() and len(requests) + 2 <= 24
+            if heads_dense:                                  # the heads' weight too, both orientations (no library GEMM left in the network)
+                requests += [(W_heads.detach(), 0, None, False), (W_heads.detach(), 0, Wd, True)]
             views, ctx.planes_buffer = dense_layers.split_weights(requests)
             cat = emb.new_empty((R, E + Wd))                 # (:447-448: [emb | h], the input of layer skip + 1; layer skip writes its half)
             cat[:, :E] = emb
@@ -343,8 +346,12 @@ class _FusedTrunk(torch.autograd.Function):
                 h = cat if i == skip else y
             if chained:
                 dense_layers.dense_chain(ops)
-            out = torch.addmm(b_heads, h, W_heads.t())
-            ctx.planes_t = views[D:]
+            if heads_dense and h.is_contiguous():
+                out = dense_layers.dense_forward(h, views[2 * D - 1], int(W_heads.shape[0]), Wd, b_heads.detach())
+            else:
+                out = torch.addmm(b_heads, h, W_heads.t())
+            ctx.planes_t = views[D:2 * D - 1]
+            ctx.heads_planes_t = views[2 * D] if heads_dense else None
             ctx.skip, ctx.D, ctx.E = skip, D, E
             ctx.save_for_backward(W_heads, *params[0::2], *inputs, *outs)
             return out
@@ -372,7 +379,8 @@ class _FusedTrunk(torch.autograd.Function):
         wgrad_many = (DENSE_WGRAD_MANY and ctx.planes_t is not None and DENSE_CHAIN and D - 1 <= 8 and int(Ws[0].shape[0]) == 256
                       and D + 1 <= 12 and h_last.is_contiguous())
         gW_heads, gb_heads = (None if wgrad_many else _grad_weight(g_out, h_last)), g_out.sum(0)
-        g = g_out.mm(W_heads)
+        heads_t = getattr(ctx, "heads_planes_t", None) if wgrad_many else None
+        g = None if heads_t is not None else g_out.mm(W_heads)
         # the weight gradients of the layers of one shape (six of the eight are [W, W]) are batched products into ONE buffer, summed over their
         # row groups by one launch at the end instead of one per layer (they feed nothing on the way back)
         R = int(g_out.shape[0])
@@ -387,7 +395,10 @@ class _FusedTrunk(torch.autograd.Function):
             # gradient), then the weight gradients from the G's they left
             import dense_layers
             Wd = int(Ws[0].shape[0])
-            G, db = control_nodes.relu_backward_bias(g, outs[D - 1])
+            if heads_t is not None:      # (g_out W_heads) [y > 0] and its column sums in one pass: the last layer's G and bias gradient
+                G, db = dense_layers.dense_backward_input(g_out, heads_t, Wd, int(W_heads.shape[0]), mask=outs[D - 1])
+            else:
+                G, db = control_nodes.relu_backward_bias(g, outs[D - 1])
             chain_G, chain_db = [None] * D, [None] * D
             chain_G[D - 1], chain_db[D - 1] = G, db
             ops = []
