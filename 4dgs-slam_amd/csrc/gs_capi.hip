@@ -193,6 +193,8 @@ static bool t_order_tiles = getenv("GSR_ORDER_TILES") ? getenv("GSR_ORDER_TILES"
 static const int t_deal_heavy = getenv("GSR_DEAL_HEAVY") ? atoi(getenv("GSR_DEAL_HEAVY")) : 1;      // lists per CU held back for the CUs with one block less (gs_forward.h)
 // 0: band order; 1 + heavy otherwise (the scatter launch's argument)
 static int order_fwd_tiles(int T, bool lds_hist) { return t_order_items && t_order_tiles && lds_hist && T / 8 >= ORDER_FWD_MIN_BAND ? 1 + std::max(0, std::min(7, t_deal_heavy)) : 0; }
+// HexPlane plane gradients as fixed-point integer sums (gs_hexplane_binned.h: HexOrd): bitwise the same run to run. 0: float atomics (rounds 1-5)
+static std::atomic<int> g_hex_ordered{getenv("GSR_HEX_ORDERED") ? (getenv("GSR_HEX_ORDERED")[0] != '0' ? 1 : 0) : 1};
 static void read_option_env()
 {
     if (t_options_read) return;
@@ -263,6 +265,11 @@ int gsr_set_option(const char* name, int value)
     if (!name) { g_last_error = "gsr_set_option: null name"; return GSR_ERR_INVALID_ARGUMENT; }
     const std::string n(name);
     if (n == "views_batched") return (int)t_views_batched;     // read-only: multi-view calls of this thread that took the one-launch-per-stage path
+    if (n == "hex_ordered") {                                  // process-wide (the workspace sizes depend on it); value < 0 only reads
+        const int old_ordered = g_hex_ordered.load();
+        if (value >= 0) g_hex_ordered.store(value ? 1 : 0);
+        return old_ordered;
+    }
     if (n == "cap_margin_permille") {
         const int old_margin = t_cap_margin_permille;
         if (value >= 0) t_cap_margin_permille = value > 4000 ? 4000 : value;
@@ -1486,7 +1493,40 @@ static void hexsort_plan(const gsr_hexplane_field& f, HexSortPlan* P)
     P->key_off[6] = off;
 }
 
-static size_t hexsort_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, char* base, HexSortWs* ws)
+// Ordered mode (HexOrd): where the planes' fixed-point sums live. `plane_mask`: the planes the generic walk scatters into (all six, or the three
+// spatial ones of the batched-views path, whose time families keep column sums per view instead: V > 0). Returns the elements of acc / acc_t.
+static void hexord_plan(const gsr_hexplane_field& f, int64_t n, int V, int plane_mask, HexOrd* o, size_t* acc_elems, size_t* acct_elems)
+{
+    static const int C0[6] = {0, 0, 0, 1, 1, 2}, C1[6] = {1, 2, 3, 2, 3, 3};
+    HexOrd h{};
+    size_t off = 0;
+    for (int l = 0; l < f.num_levels; l++)
+        for (int pl = 0; pl < 6; pl++) {
+            h.off[l][pl] = off;
+            if ((plane_mask >> pl) & 1) off +=          // (whether or not the plane's gradient is asked for: the size must not depend on it)
+                (size_t)f.levels[l].res[C0[pl]] * f.levels[l].res[C1[pl]] * f.feat_dim;
+        }
+    size_t rows = 0;
+    if (V > 0)
+        for (int j = 0; j < 3; j++) {
+            uint32_t cols = 0;
+            for (int l = 0; l < f.num_levels; l++) { h.tcol[j][l] = cols; cols += (uint32_t)f.levels[l].res[j]; }
+            h.tcols[j] = cols;
+            h.tbase[j] = (uint32_t)rows;
+            rows += (size_t)V * cols;
+        }
+    // a texel receives at most 4 n contributions (four cells, every point once: the views are summed before): the largest one is scaled to just
+    // below 2^budget, the sum stays below 2^62; 40 bits at most, so that HEXSORT_CHUNK of them stay exact in a double
+    int lg = 0;
+    while (((int64_t)1 << lg) < 4 * std::max<int64_t>(n, 1)) lg++;
+    h.budget = std::min(40, 62 - lg);
+    if (o) *o = h;
+    if (acc_elems) *acc_elems = off;
+    if (acct_elems) *acct_elems = rows * f.feat_dim;
+}
+
+static size_t hexsort_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, char* base, HexSortWs* ws, HexOrd* ord = nullptr,
+                            size_t* ord_bytes = nullptr)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
@@ -1500,8 +1540,28 @@ static size_t hexsort_carve(const gsr_hexplane_field& f, const HexSortPlan& P, i
     w.rank = reinterpret_cast<int*>(take((size_t)6 * n * sizeof(int)));
     w.scoords = reinterpret_cast<float4*>(take((size_t)6 * n * sizeof(float4)));
     w.gs = reinterpret_cast<float*>(take((size_t)6 * n * f.num_levels * f.feat_dim * sizeof(float)));
+    if (g_hex_ordered.load()) {
+        HexOrd h;
+        size_t elems;
+        hexord_plan(f, n, 0, 63, &h, &elems, nullptr);
+        h.acc = reinterpret_cast<unsigned long long*>(take(elems * sizeof(unsigned long long)));
+        if (ord) *ord = h;
+        if (ord_bytes) *ord_bytes = elems * sizeof(unsigned long long);
+    } else if (ord) {
+        *ord = HexOrd{};
+    }
     if (ws) *ws = w;
     return off + 256;
+}
+
+static void hexord_convert(const gsr_hexplane_field& f, const HexOrd& ord, const uint32_t* header, int plane_mask, hipStream_t stream)
+{
+    size_t largest = 0;
+    for (int l = 0; l < f.num_levels; l++)
+        for (int a = 0; a < 4; a++)
+            for (int b = a + 1; b < 4; b++) largest = std::max(largest, (size_t)f.levels[l].res[a] * f.levels[l].res[b] * f.feat_dim);
+    hipLaunchKernelGGL(hexord_convert_kernel, dim3((unsigned)((largest + 511) / 512), (unsigned)(6 * f.num_levels)), dim3(256), 0, stream, f, ord, header,
+                       plane_mask);
 }
 
 static bool hexsort_supported(const gsr_hexplane_field& f, int64_t n)
@@ -1536,9 +1596,16 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
     HexSortPlan P;
     hexsort_plan(f, &P);
     HexSortWs ws;
-    hexsort_carve(f, P, n, workspace, &ws);
+    HexOrd ord;
+    size_t ord_bytes = 0;
+    hexsort_carve(f, P, n, workspace, &ws, &ord, &ord_bytes);
+    const int ordered = ord.acc != nullptr;
     const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
     GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
+    if (ordered) {
+        GSR_HIP_CHECK(hipMemsetAsync(ws.header, 0, 256, stream));
+        GSR_HIP_CHECK(hipMemsetAsync(ord.acc, 0, ord_bytes, stream));
+    }
     const dim3 per_point((unsigned)((n + 255) / 256));
     hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, time, time_stride,
                        dL_dfeatures, (const uint32_t*)nullptr);
@@ -1553,12 +1620,18 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
 #define GSR_HEXSORT_CASE(CC)                                                                                                              \
     case CC:                                                                                                                               \
         hipLaunchKernelGGL((hexsort_phase1_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, n, xyz, xyz_stride, time, time_stride,       \
-                           dL_dfeatures, dL_dxyz);                                                                                          \
-        if (f.num_levels <= 4) hipLaunchKernelGGL((hexsort_phase2_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, n);                     \
-        else hipLaunchKernelGGL((hexsort_phase2_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, n);                 \
+                           dL_dfeatures, dL_dxyz, ordered);                                                                                 \
+        if (f.num_levels <= 4) {                                                                                                           \
+            if (ordered) hipLaunchKernelGGL((hexsort_phase2_kernel<CC, 4, true>), g2, dim3(256), 0, stream, f, ws, n, ord);                 \
+            else hipLaunchKernelGGL((hexsort_phase2_kernel<CC, 4, false>), g2, dim3(256), 0, stream, f, ws, n, ord);                        \
+        } else {                                                                                                                           \
+            if (ordered) hipLaunchKernelGGL((hexsort_phase2_kernel<CC, GSR_HEXPLANE_MAX_LEVELS, true>), g2, dim3(256), 0, stream, f, ws, n, ord);   \
+            else hipLaunchKernelGGL((hexsort_phase2_kernel<CC, GSR_HEXPLANE_MAX_LEVELS, false>), g2, dim3(256), 0, stream, f, ws, n, ord);          \
+        }                                                                                                                                  \
         break;
     switch (C) { GSR_HEXSORT_CASE(8) GSR_HEXSORT_CASE(16) GSR_HEXSORT_CASE(32) GSR_HEXSORT_CASE(64) }
 #undef GSR_HEXSORT_CASE
+    if (ordered) hexord_convert(f, ord, ws.header, 63, stream);
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1605,7 +1678,8 @@ int gsr_hexplane_forward_views(const gsr_hexplane_field* field, int64_t n, const
     return 0;
 }
 
-static size_t hexviews_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, int V, char* base, HexSortWs* ws, HexViewsWs* vw)
+static size_t hexviews_carve(const gsr_hexplane_field& f, const HexSortPlan& P, int64_t n, int V, char* base, HexSortWs* ws, HexViewsWs* vw,
+                             HexOrd* ord = nullptr, size_t* ord_bytes = nullptr)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
@@ -1621,6 +1695,17 @@ static size_t hexviews_carve(const gsr_hexplane_field& f, const HexSortPlan& P, 
     w.scoords = reinterpret_cast<float4*>(take((size_t)6 * n * sizeof(float4)));
     v.gs_sp = reinterpret_cast<float*>(take((size_t)3 * n * row * sizeof(float)));
     v.gs_t = reinterpret_cast<float*>(take((size_t)3 * V * n * row * sizeof(float)));
+    if (g_hex_ordered.load()) {                                     // one region (one memset): the spatial planes' sums, then the time families' column sums
+        HexOrd h;
+        size_t elems, telems;
+        hexord_plan(f, n, V, (1 << 0) | (1 << 1) | (1 << 3), &h, &elems, &telems);
+        h.acc = reinterpret_cast<unsigned long long*>(take((elems + telems) * sizeof(unsigned long long)));
+        h.acc_t = h.acc ? h.acc + elems : nullptr;
+        if (ord) *ord = h;
+        if (ord_bytes) *ord_bytes = (elems + telems) * sizeof(unsigned long long);
+    } else if (ord) {
+        *ord = HexOrd{};
+    }
     if (ws) *ws = w;
     if (vw) *vw = v;
     return off + 256;
@@ -1657,9 +1742,16 @@ int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, cons
     hexsort_plan(f, &P);
     HexSortWs ws;
     HexViewsWs vw;
-    hexviews_carve(f, P, n, V, workspace, &ws, &vw);
+    HexOrd ord;
+    size_t ord_bytes = 0;
+    hexviews_carve(f, P, n, V, workspace, &ws, &vw, &ord, &ord_bytes);
+    const int ordered = ord.acc != nullptr;
     const int nb = P.key_off[6], scan_blocks = (nb + 1024 * HEXSORT_SCAN_ITEMS - 1) / (1024 * HEXSORT_SCAN_ITEMS);
     GSR_HIP_CHECK(hipMemsetAsync(ws.count, 0, (size_t)nb * sizeof(uint32_t), stream));
+    if (ordered) {
+        GSR_HIP_CHECK(hipMemsetAsync(ws.header, 0, 256, stream));
+        GSR_HIP_CHECK(hipMemsetAsync(ord.acc, 0, ord_bytes, stream));
+    }
     hipLaunchKernelGGL(hexsort_count_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, f, P, ws, n, xyz, xyz_stride, (const float*)nullptr, (int64_t)0,
                        (const float*)nullptr, view_mask);
     hipLaunchKernelGGL(hexsort_scan_sums_kernel, dim3(scan_blocks), dim3(1024), 0, stream, (const uint32_t*)ws.count, nb, ws.block_sums);
@@ -1677,17 +1769,31 @@ int gsr_hexplane_backward_views(const gsr_hexplane_field* field, int64_t n, cons
     const dim3 g3((unsigned)((chunks2 + per_block - 1) / per_block), (unsigned)(3 * ((V + HEXT_VB - 1) / HEXT_VB)));
 #define GSR_HEXVB_CASE(CC)                                                                                                              \
     case CC:                                                                                                                             \
-        hipLaunchKernelGGL((hexsort_phase1_views_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz);   \
-        if (f.num_levels <= 4) {                                                                                                        \
-            if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, 4>), g2, dim3(256), 0, stream, f, ws, vw, n);            \
-            if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, 4>), g3, dim3(256), 0, stream, f, ws, vw, tv, n);         \
-        } else {                                                                                                                        \
-            if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g2, dim3(256), 0, stream, f, ws, vw, n);       \
-            if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, GSR_HEXPLANE_MAX_LEVELS>), g3, dim3(256), 0, stream, f, ws, vw, tv, n);    \
-        }                                                                                                                               \
+        hipLaunchKernelGGL((hexsort_phase1_views_kernel<CC>), g1, dim3(HEX_BLOCK), 0, stream, f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz, ordered);   \
+        GSR_HEXVB_PHASE2(CC, 4, f.num_levels <= 4)                                                                                       \
+        GSR_HEXVB_PHASE2(CC, GSR_HEXPLANE_MAX_LEVELS, f.num_levels > 4)                                                                  \
         break;
+#define GSR_HEXVB_PHASE2(CC, LM, when)                                                                                                  \
+        if (when) {                                                                                                                     \
+            if (ordered) {                                                                                                              \
+                if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, LM, true>), g2, dim3(256), 0, stream, f, ws, vw, n, ord);        \
+                if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, LM, true>), g3, dim3(256), 0, stream, f, ws, vw, tv, n, ord);     \
+            } else {                                                                                                                    \
+                if (!(dbg & 1)) hipLaunchKernelGGL((hexsort_phase2_views_kernel<CC, LM, false>), g2, dim3(256), 0, stream, f, ws, vw, n, ord);       \
+                if (!(dbg & 2)) hipLaunchKernelGGL((hexsort_phase2_time_kernel<CC, LM, false>), g3, dim3(256), 0, stream, f, ws, vw, tv, n, ord);    \
+            }                                                                                                                           \
+        }
     switch (C) { GSR_HEXVB_CASE(8) GSR_HEXVB_CASE(16) GSR_HEXVB_CASE(32) GSR_HEXVB_CASE(64) }
+#undef GSR_HEXVB_PHASE2
 #undef GSR_HEXVB_CASE
+    if (ordered) {
+        hexord_convert(f, ord, ws.header, (1 << 0) | (1 << 1) | (1 << 3), stream);
+        int wmax = 1;
+        for (int l = 0; l < f.num_levels; l++)
+            for (int k = 0; k < 3; k++) wmax = std::max(wmax, (int)f.levels[l].res[k]);
+        hipLaunchKernelGGL(hexord_time_convert_kernel, dim3((unsigned)(((size_t)wmax * C + 255) / 256), (unsigned)(3 * f.num_levels)), dim3(256), 0, stream, f, tv,
+                           ord, (const uint32_t*)ws.header);
+    }
     GSR_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gs_hexplane.h"
 
 namespace gsr {
@@ -38,11 +40,59 @@ struct HexSortWs {                              // device pointers carved from t
     uint32_t* key;                              // [6][n]    counter index of the point in each family
     uint32_t* count;                            // [NB]      histogram, then (after the scan) the running cursor
     uint32_t* block_sums;                       // [ceil(NB / 8192)]
-    uint32_t* header;                           // [0] = 6 x (number of points with a non-zero cotangent row)
+    uint32_t* header;                           // [0] = 6 x (number of points with a non-zero cotangent row); [1] = bits of the largest |dL/dsample| (ordered mode)
     int* rank;                                  // [6][n]    sorted slot of the point in each family (0 .. 6n)
     float4* scoords;                            // [6n]      coordinates in sorted order
     float* gs;                                  // [6n][L][C]  dL/dsample in sorted order
 };
+
+// ---- ordered accumulation (gsr_set_option("hex_ordered", 1), the default): plane gradients that are bitwise the same run to run ------------
+// Float atomics add in whatever order the waves arrive, and the counting sort's cursors hand out the slots of a cell in arrival order too, so
+// the float sums of rounds 1-5 were reproducible to rounding only. Here every contribution  dL/dsample x corner weight  is rounded ONCE to a
+// multiple of a power-of-two quantum (2^-40 of the largest |dL/dsample| of the call, found by phase 1) and from there on only integers are
+// added -- in registers as integer-valued doubles (exact below 2^53: a walk adds at most HEXSORT_CHUNK values below 2^40), in LDS and in
+// memory as 64-bit integer atomics. Integer addition is associative: neither the order inside a cell, nor where the chunks split, nor
+// the order of the atomics can change a bit of the result. One pass at the end converts the sums and adds them to the float planes. The time
+// families of the batched-views path keep their sums per (view, column) and that pass applies the two time-row weights, views in
+// their order.
+struct HexOrd {
+    unsigned long long* acc;                        // fixed-point sums of the planes the walks scatter into (null: float atomics, rounds 1-5)
+    unsigned long long* acc_t;                      // batched views: the time families' column sums [family][view][column of every level][C]
+    uint64_t off[GSR_HEXPLANE_MAX_LEVELS][6];       // first element of plane (level, pl) in acc
+    uint32_t tcol[3][GSR_HEXPLANE_MAX_LEVELS];      // first column of a level inside one view's row of family j
+    uint32_t tcols[3];                              // columns of one view of family j (all levels)
+    uint32_t tbase[3];                              // first column row of family j: V x the earlier families' tcols
+    int budget;                                     // the largest |dL/dsample| is scaled to just below 2^budget
+};
+
+// S = the largest power of two with  max x S < 2^budget  (max given by its bit pattern; 0 when nothing was written), and its inverse
+__device__ __forceinline__ int hexord_shift(uint32_t maxbits, int budget)
+{
+    const int e = (int)(maxbits >> 23) - 127;       // max in [2^e, 2^(e + 1))
+    return min(127, max(-126, budget - 1 - e));
+}
+__device__ __forceinline__ float hexord_scale(uint32_t maxbits, int budget)
+{
+    return maxbits == 0u ? 0.f : __uint_as_float((uint32_t)(hexord_shift(maxbits, budget) + 127) << 23);
+}
+__device__ __forceinline__ double hexord_inverse(uint32_t maxbits, int budget)
+{
+    return maxbits == 0u ? 0.0 : __longlong_as_double((long long)(1023 - hexord_shift(maxbits, budget)) << 52);
+}
+__device__ __forceinline__ void hexord_add(unsigned long long* p, double v)
+{
+    if (v != 0.0) atomicAdd(p, (unsigned long long)(long long)v);
+}
+// the wave's largest |dL/dsample| -> header[1] (a maximum is order-free); once the word has grown, almost no wave still has to write
+__device__ __forceinline__ void hexord_publish_max(float mx, uint32_t* maxp)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t b = __float_as_uint(mx);
+        if (b > __hip_atomic_load(maxp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxp, b);
+    }
+}
 
 __device__ __forceinline__ uint32_t morton_spread(uint32_t v)   // 0000 abcd -> 0a0b 0c0d (up to 16 bits)
 {
@@ -183,19 +233,20 @@ hexsort_scatter_kernel(const HexSortWs ws, const int64_t n)
 }
 
 // ---- phase 1: dL/dsample of all 24 planes (written to the sorted slots) and dL/dxyz ------------------------------------------------
+// (returns the largest |dL/dsample| this lane wrote: the ordered mode's scale, hexord_publish_max)
 template <int C>
-__global__ void __launch_bounds__(HEX_BLOCK)
-hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n, const float* __restrict__ xyz, const int64_t xyz_stride,
-                      const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures,
-                      float* __restrict__ dL_dxyz)
+__device__ __forceinline__ float hexsort_phase1_body(const gsr_hexplane_field& f, const HexSortWs& ws, const int64_t n, const float* __restrict__ xyz,
+                                                     const int64_t xyz_stride, const float* __restrict__ time, const int64_t time_stride,
+                                                     const float* __restrict__ dL_dfeatures, float* __restrict__ dL_dxyz)
 {
     const int ch = threadIdx.x % C;
     const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / C) + threadIdx.x / C;
-    if (i >= n) return;
+    if (i >= n) return 0.f;
     if (ws.rank[i] < 0) {                                         // zero cotangent: nothing to gather, nothing to hand over
         if (dL_dxyz && ch < 3) dL_dxyz[3 * i + ch] = 0.f;
-        return;
+        return 0.f;
     }
+    float mx = 0.f;
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, time + i * time_stride);
     const float (&c)[4] = p.c;
     const int L = f.num_levels;
@@ -246,6 +297,7 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
             const float gs = prefix * suffix[pl];
             prefix *= s[pl];
             __builtin_nontemporal_store(gs, &ws.gs[slot[pl] + (size_t)l * C]);   // streamed once: keep the planes in L2 (331 -> 299 us)
+            mx = fmaxf(mx, fabsf(gs));
             if (dL_dxyz) {
                 const float nw = corner[pl][0] * gs, ne = X.has1 ? corner[pl][1] * gs : 0.f, sw = Y.has1 ? corner[pl][2] * gs : 0.f;
                 const float se = X.has1 && Y.has1 ? corner[pl][3] * gs : 0.f;
@@ -265,36 +317,58 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
             for (int k = 0; k < 3; k++) dL_dxyz[3 * i + k] = gc[k] * p.dscale[k];
         }
     }
+    return mx;
+}
+
+template <int C>
+__global__ void __launch_bounds__(HEX_BLOCK)
+hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n, const float* __restrict__ xyz, const int64_t xyz_stride,
+                      const float* __restrict__ time, const int64_t time_stride, const float* __restrict__ dL_dfeatures,
+                      float* __restrict__ dL_dxyz, const int ordered)
+{
+    const float mx = hexsort_phase1_body<C>(f, ws, n, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
+    if (ordered) hexord_publish_max(mx, ws.header + 1);
 }
 
 // ---- phase 2: run-length accumulation along the sorted order --------------------------------------------------------------------------
 // One group of C lanes (one channel each) walks `cnt` consecutive sorted points of plane family `pl`: coordinates `sc[k]` (with the time
 // replaced by `t_fixed` when `fix_t`: the batched-views caller sorts once for all views), dL/dsample rows `gsrow[k * L * C + l * C]`.
-template <int C, int LMAX>
+template <int C, int LMAX, bool ORD>
 __device__ __forceinline__ void hexsort_phase2_walk(const gsr_hexplane_field& f, const int pl, const float4* __restrict__ sc,
-                                                    const float* __restrict__ gsrow, const int cnt, const bool fix_t, const float t_fixed)
+                                                    const float* __restrict__ gsrow, const int cnt, const bool fix_t, const float t_fixed,
+                                                    const HexOrd& o, const float S)
 {
+    using Acc = std::conditional_t<ORD, double, float>;           // ORD: integer-valued doubles (see HexOrd)
     const int ch = threadIdx.x % C;
     const int c0 = hex_c0(pl), c1 = hex_c1(pl);
     const int L = f.num_levels;
-    float acc[LMAX][4];
+    Acc acc[LMAX][4];
     int cx[LMAX], cy[LMAX];
 #pragma unroll
-    for (int l = 0; l < LMAX; l++) { cx[l] = cy[l] = -1; acc[l][0] = acc[l][1] = acc[l][2] = acc[l][3] = 0.f; }
+    for (int l = 0; l < LMAX; l++) { cx[l] = cy[l] = -1; acc[l][0] = acc[l][1] = acc[l][2] = acc[l][3] = 0; }
 
     auto flush = [&](int l) {                                     // four texel-wide atomics for the cell (cx, cy) of level l
         const gsr_hexplane_level& Lv = f.levels[l];
         float* gp = Lv.grad_planes[pl];
         const int W = Lv.res[c0], H = Lv.res[c1];
         if (gp && cx[l] >= 0) {
-            float* t = gp + ((size_t)cy[l] * W + cx[l]) * C + ch;
+            const size_t at = ((size_t)cy[l] * W + cx[l]) * C + ch;
             const bool x1 = cx[l] + 1 < W, y1 = cy[l] + 1 < H;     // safe_add_2d: corners outside the plane receive nothing
-            if (acc[l][0] != 0.f) unsafeAtomicAdd(t, acc[l][0]);
-            if (x1 && acc[l][1] != 0.f) unsafeAtomicAdd(t + C, acc[l][1]);
-            if (y1 && acc[l][2] != 0.f) unsafeAtomicAdd(t + (size_t)W * C, acc[l][2]);
-            if (x1 && y1 && acc[l][3] != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, acc[l][3]);
+            if constexpr (ORD) {
+                unsigned long long* t = o.acc + o.off[l][pl] + at;
+                hexord_add(t, acc[l][0]);
+                if (x1) hexord_add(t + C, acc[l][1]);
+                if (y1) hexord_add(t + (size_t)W * C, acc[l][2]);
+                if (x1 && y1) hexord_add(t + (size_t)(W + 1) * C, acc[l][3]);
+            } else {
+                float* t = gp + at;
+                if (acc[l][0] != 0.f) unsafeAtomicAdd(t, acc[l][0]);
+                if (x1 && acc[l][1] != 0.f) unsafeAtomicAdd(t + C, acc[l][1]);
+                if (y1 && acc[l][2] != 0.f) unsafeAtomicAdd(t + (size_t)W * C, acc[l][2]);
+                if (x1 && y1 && acc[l][3] != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, acc[l][3]);
+            }
         }
-        acc[l][0] = acc[l][1] = acc[l][2] = acc[l][3] = 0.f;
+        acc[l][0] = acc[l][1] = acc[l][2] = acc[l][3] = 0;
     };
 
     // the loads of point k + 1 (coordinates, dL/dsample of every level) are issued before point k is processed: the walk is
@@ -318,16 +392,24 @@ __device__ __forceinline__ void hexsort_phase2_walk(const gsr_hexplane_field& f,
             if (l < L) {
                 const gsr_hexplane_level& Lv = f.levels[l];
                 const HexAxis X = hex_axis(c[c0], Lv.res[c0]), Y = hex_axis(c[c1], Lv.res[c1]);
-                const float gs = g_cur[l];
                 if (X.i0 != cx[l] || Y.i0 != cy[l]) {
                     flush(l);
                     cx[l] = X.i0;
                     cy[l] = Y.i0;
                 }
-                acc[l][0] = fmaf(gs, X.w0 * Y.w0, acc[l][0]);
-                acc[l][1] = fmaf(gs, X.w1 * Y.w0, acc[l][1]);
-                acc[l][2] = fmaf(gs, X.w0 * Y.w1, acc[l][2]);
-                acc[l][3] = fmaf(gs, X.w1 * Y.w1, acc[l][3]);
+                if constexpr (ORD) {                              // every product rounded once to the call's quantum, then integers only
+                    const float gs = g_cur[l] * S;
+                    acc[l][0] += (double)rintf(gs * (X.w0 * Y.w0));
+                    acc[l][1] += (double)rintf(gs * (X.w1 * Y.w0));
+                    acc[l][2] += (double)rintf(gs * (X.w0 * Y.w1));
+                    acc[l][3] += (double)rintf(gs * (X.w1 * Y.w1));
+                } else {
+                    const float gs = g_cur[l];
+                    acc[l][0] = fmaf(gs, X.w0 * Y.w0, acc[l][0]);
+                    acc[l][1] = fmaf(gs, X.w1 * Y.w0, acc[l][1]);
+                    acc[l][2] = fmaf(gs, X.w0 * Y.w1, acc[l][2]);
+                    acc[l][3] = fmaf(gs, X.w1 * Y.w1, acc[l][3]);
+                }
             }
         }
     }
@@ -337,9 +419,9 @@ __device__ __forceinline__ void hexsort_phase2_walk(const gsr_hexplane_field& f,
     }
 }
 
-template <int C, int LMAX>
+template <int C, int LMAX, bool ORD>
 __global__ void __launch_bounds__(256)
-hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n)
+hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int64_t n, const HexOrd o)
 {
     constexpr int GROUPS = 256 / C;
     const int ch = threadIdx.x % C;
@@ -350,7 +432,28 @@ hexsort_phase2_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
     const int pl = (int)(gid / chunks_per_family);
     const int64_t first = (gid - pl * chunks_per_family) * HEXSORT_CHUNK;
     const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
-    hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * na + first, ws.gs + ((size_t)pl * na + first) * f.num_levels * C + ch, cnt, false, 0.f);
+    const float S = ORD ? hexord_scale(ws.header[1], o.budget) : 0.f;
+    hexsort_phase2_walk<C, LMAX, ORD>(f, pl, ws.scoords + (size_t)pl * na + first, ws.gs + ((size_t)pl * na + first) * f.num_levels * C + ch, cnt, false, 0.f,
+                                      o, S);
+}
+
+// ---- ordered mode, last pass: the fixed-point sums -> the float gradient planes (ACCUMULATED into, like the atomics they replace) -----------
+// grid (elements / 512, level x 6 + plane); a thread converts two neighbouring elements. Every element has one owner: no atomics.
+__global__ void __launch_bounds__(256)
+hexord_convert_kernel(const gsr_hexplane_field f, const HexOrd o, const uint32_t* __restrict__ header, const int plane_mask)
+{
+    const int l = blockIdx.y / 6, pl = blockIdx.y % 6;
+    if (!((plane_mask >> pl) & 1)) return;
+    const gsr_hexplane_level& Lv = f.levels[l];
+    float* gp = Lv.grad_planes[pl];
+    const size_t count = (size_t)Lv.res[hex_c0(pl)] * Lv.res[hex_c1(pl)] * f.feat_dim;      // even: the channel counts are multiples of 8
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (!gp || e >= count) return;
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(o.acc + o.off[l][pl] + e);
+    if ((v.x | v.y) == 0ull) return;
+    const double inv = hexord_inverse(header[1], o.budget);
+    if (v.x) gp[e] += (float)((double)(long long)v.x * inv);
+    if (v.y) gp[e + 1] += (float)((double)(long long)v.y * inv);
 }
 
 // ---- which rows of a batch's cotangent are not zero (gsr_row_mask) ---------------------------------------------------------------------
@@ -424,18 +527,18 @@ struct HexViewsWs {
 };
 
 template <int C>
-__global__ void __launch_bounds__(HEX_BLOCK)
-hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n,
-                            const float* __restrict__ xyz, const int64_t xyz_stride, const float* __restrict__ dL_dfeatures,
-                            float* __restrict__ dL_dxyz)
+__device__ __forceinline__ float hexsort_phase1_views_body(const gsr_hexplane_field& f, const HexSortWs& ws, const HexViewsWs& vw, const HexTimes& tv,
+                                                           const int64_t n, const float* __restrict__ xyz, const int64_t xyz_stride,
+                                                           const float* __restrict__ dL_dfeatures, float* __restrict__ dL_dxyz)
 {
     const int ch = threadIdx.x % C;
     const int64_t i = (int64_t)blockIdx.x * (HEX_BLOCK / C) + threadIdx.x / C;
-    if (i >= n) return;
+    if (i >= n) return 0.f;
     if (ws.rank[i] < 0) {                                         // no view's cotangent reaches this point: nothing to gather, nothing to hand over
         if (dL_dxyz && ch < 3) dL_dxyz[3 * i + ch] = 0.f;
-        return;
+        return 0.f;
     }
+    float mx = 0.f;
     const uint32_t vbits = __float_as_uint(ws.coords[i].w);       // views whose cotangent row of this point is not zero
     const float zero_time = 0.f;
     const HexPoint p = hex_point(f.aabb, xyz + i * xyz_stride, &zero_time);
@@ -523,6 +626,7 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
             for (int j = 0; j < 3; j++) {
                 const float gt = gs[TP[j]];
                 __builtin_nontemporal_store(gt, &vw.gs_t[t_slot[j] + (size_t)v * n * row + (size_t)l * C]);
+                mx = fmaxf(mx, fabsf(gt));
                 if (dL_dxyz) {                                    // the time itself receives no gradient
                     const HexAxis& X = ax[j];
                     const float nw = ct[j][0] * gt, ne = X.has1 ? ct[j][1] * gt : 0.f, sw = T.has1 ? ct[j][2] * gt : 0.f;
@@ -538,6 +642,7 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
             const HexAxis& Y = ax[c1];
             const float gsp = Gs[j];
             __builtin_nontemporal_store(gsp, &vw.gs_sp[sp_slot[j] + (size_t)l * C]);
+            mx = fmaxf(mx, fabsf(gsp));
             if (dL_dxyz) {
                 const float nw = cs[j][0] * gsp, ne = X.has1 ? cs[j][1] * gsp : 0.f, sw = Y.has1 ? cs[j][2] * gsp : 0.f;
                 const float se = X.has1 && Y.has1 ? cs[j][3] * gsp : 0.f;
@@ -557,6 +662,17 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
             for (int k = 0; k < 3; k++) dL_dxyz[3 * i + k] = gc[k] * p.dscale[k];
         }
     }
+    return mx;
+}
+
+template <int C>
+__global__ void __launch_bounds__(HEX_BLOCK)
+hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n,
+                            const float* __restrict__ xyz, const int64_t xyz_stride, const float* __restrict__ dL_dfeatures,
+                            float* __restrict__ dL_dxyz, const int ordered)
+{
+    const float mx = hexsort_phase1_views_body<C>(f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz);
+    if (ordered) hexord_publish_max(mx, ws.header + 1);
 }
 
 // ---- phase 2 of the TIME families, all views ----------------------------------------------------------------------------------------
@@ -571,13 +687,16 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
 constexpr int HEXT_VB = 4;        // views per block
 constexpr int HEXT_ROUNDS = 4;    // chunks per group
 constexpr int HEXT_WIN = 16;      // columns of the LDS window per level (runs outside it go to global memory directly)
+constexpr int HEXT_WIN_ORD = 8;   // ... of the ordered mode's 64-bit window (the same LDS footprint; a block's 2 048 sorted points span 3-4 columns of the finest level at config #3)
 
-template <int C, int LMAX>
+template <int C, int LMAX, bool ORD>
 __global__ void __launch_bounds__(256)
-hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n)
+hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const HexTimes tv, const int64_t n, const HexOrd o)
 {
-    constexpr int GROUPS = 256 / C, VB = HEXT_VB;
-    __shared__ float s_acc[VB][LMAX][HEXT_WIN][C];
+    constexpr int GROUPS = 256 / C, VB = HEXT_VB, WIN = ORD ? HEXT_WIN_ORD : HEXT_WIN;
+    using Win = std::conditional_t<ORD, unsigned long long, float>;
+    using Acc = std::conditional_t<ORD, double, float>;
+    __shared__ Win s_acc[VB][LMAX][WIN][C];
     const int ch = threadIdx.x % C, grp = threadIdx.x / C;
     const int j = blockIdx.y % 3, v0 = (blockIdx.y / 3) * VB;     // family (x, y, z) and first view of this block
     const int nv = min(VB, tv.V - v0);
@@ -588,10 +707,13 @@ hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const
     const int64_t chunks = (na + HEXSORT_CHUNK - 1) / HEXSORT_CHUNK;
     const int64_t chunk0 = (int64_t)blockIdx.x * (GROUPS * HEXT_ROUNDS);
     if (chunk0 >= chunks) return;
+    const float S = ORD ? hexord_scale(ws.header[1], o.budget) : 0.f;
     const float4* __restrict__ sc = ws.scoords + (size_t)pl * na;
     const float* __restrict__ gs = vw.gs_t + ((size_t)j * tv.V + v0) * view_stride + ch;
     auto coord = [&](const float4& c) { return j == 0 ? c.x : (j == 1 ? c.y : c.z); };
-    for (int e = threadIdx.x; e < VB * LMAX * HEXT_WIN * C; e += 256) (&s_acc[0][0][0][0])[e] = 0.f;
+    for (int e = threadIdx.x; e < VB * LMAX * WIN * C; e += 256) (&s_acc[0][0][0][0])[e] = 0;
+    // ordered mode: element of (view v0 + v, level l, column col) in the family's column sums
+    auto ord_at = [&](int v, int l, int col) { return o.acc_t + ((size_t)o.tbase[j] + (size_t)(v0 + v) * o.tcols[j] + o.tcol[j][l] + col) * C + ch; };
     int col0[LMAX];                                               // first column of the window: the cell of the block's first point
     {
         const float c_first = coord(sc[chunk0 * HEXSORT_CHUNK]);
@@ -599,43 +721,53 @@ hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const
         for (int l = 0; l < LMAX; l++) col0[l] = l < L ? hex_axis(c_first, f.levels[l].res[j]).i0 : 0;
     }
     __syncthreads();
-    float acc[VB][LMAX][2];
+    Acc acc[VB][LMAX][2];
     int cx[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; l++) {
         cx[l] = -1;
 #pragma unroll
-        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
+        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0;
     }
     auto flush = [&](int l) {                                     // the run of level l ends: its sums go to the window (or, outside it, to memory)
         if (cx[l] >= 0) {
             const gsr_hexplane_level& Lv = f.levels[l];
             const int W = Lv.res[j], rel = cx[l] - col0[l];
             const bool x1 = cx[l] + 1 < W;                          // safe_add_2d: a column outside the plane receives nothing
-            if (rel >= 0 && rel + 1 < HEXT_WIN) {
+            if (rel >= 0 && rel + 1 < WIN) {
 #pragma unroll
                 for (int v = 0; v < VB; v++) {
-                    if (acc[v][l][0] != 0.f) atomicAdd(&s_acc[v][l][rel][ch], acc[v][l][0]);
-                    if (x1 && acc[v][l][1] != 0.f) atomicAdd(&s_acc[v][l][rel + 1][ch], acc[v][l][1]);
+                    if constexpr (ORD) {
+                        hexord_add(&s_acc[v][l][rel][ch], acc[v][l][0]);
+                        if (x1) hexord_add(&s_acc[v][l][rel + 1][ch], acc[v][l][1]);
+                    } else {
+                        if (acc[v][l][0] != 0.f) atomicAdd(&s_acc[v][l][rel][ch], acc[v][l][0]);
+                        if (x1 && acc[v][l][1] != 0.f) atomicAdd(&s_acc[v][l][rel + 1][ch], acc[v][l][1]);
+                    }
                 }
             } else {
                 float* gp = Lv.grad_planes[pl];
 #pragma unroll
                 for (int v = 0; v < VB; v++) {
                     if (gp && v < nv) {
-                        const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
-                        float* t = gp + ((size_t)T.i0 * W + cx[l]) * C + ch;
-                        const float a0 = acc[v][l][0], a1 = acc[v][l][1];
-                        if (a0 != 0.f) unsafeAtomicAdd(t, a0 * T.w0);
-                        if (x1 && a1 != 0.f) unsafeAtomicAdd(t + C, a1 * T.w0);
-                        if (T.has1 && a0 != 0.f) unsafeAtomicAdd(t + (size_t)W * C, a0 * T.w1);
-                        if (T.has1 && x1 && a1 != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, a1 * T.w1);
+                        if constexpr (ORD) {
+                            hexord_add(ord_at(v, l, cx[l]), acc[v][l][0]);
+                            if (x1) hexord_add(ord_at(v, l, cx[l] + 1), acc[v][l][1]);
+                        } else {
+                            const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
+                            float* t = gp + ((size_t)T.i0 * W + cx[l]) * C + ch;
+                            const float a0 = acc[v][l][0], a1 = acc[v][l][1];
+                            if (a0 != 0.f) unsafeAtomicAdd(t, a0 * T.w0);
+                            if (x1 && a1 != 0.f) unsafeAtomicAdd(t + C, a1 * T.w0);
+                            if (T.has1 && a0 != 0.f) unsafeAtomicAdd(t + (size_t)W * C, a0 * T.w1);
+                            if (T.has1 && x1 && a1 != 0.f) unsafeAtomicAdd(t + (size_t)(W + 1) * C, a1 * T.w1);
+                        }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0.f;
+        for (int v = 0; v < VB; v++) acc[v][l][0] = acc[v][l][1] = 0;
     };
     for (int r = 0; r < HEXT_ROUNDS; r++) {
         const int64_t chunk = chunk0 + (int64_t)r * GROUPS + grp;  // the groups of a block walk neighbouring chunks at the same time
@@ -683,8 +815,14 @@ hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const
                     }
 #pragma unroll
                     for (int v = 0; v < VB; v++) {
-                        acc[v][l][0] = fmaf(g_cur[v][l], X.w0, acc[v][l][0]);
-                        acc[v][l][1] = fmaf(g_cur[v][l], X.w1, acc[v][l][1]);
+                        if constexpr (ORD) {
+                            const float g = g_cur[v][l] * S;
+                            acc[v][l][0] += (double)rintf(g * X.w0);
+                            acc[v][l][1] += (double)rintf(g * X.w1);
+                        } else {
+                            acc[v][l][0] = fmaf(g_cur[v][l], X.w0, acc[v][l][0]);
+                            acc[v][l][1] = fmaf(g_cur[v][l], X.w1, acc[v][l][1]);
+                        }
                     }
                 }
             }
@@ -695,26 +833,56 @@ hexsort_phase2_time_kernel(const gsr_hexplane_field f, const HexSortWs ws, const
         }
     }
     __syncthreads();
-    // the window -> the two time rows of every view: one pair of atomics per (view, level, column) the block touched
-    for (int e = grp; e < VB * LMAX * HEXT_WIN; e += GROUPS) {
-        const int v = e / (LMAX * HEXT_WIN), l = (e / HEXT_WIN) % LMAX, rel = e % HEXT_WIN;
+    // the window -> (ordered) the family's column sums / (float) the two time rows of every view: once per (view, level, column) the block touched
+    for (int e = grp; e < VB * LMAX * WIN; e += GROUPS) {
+        const int v = e / (LMAX * WIN), l = (e / WIN) % LMAX, rel = e % WIN;
         if (v >= nv || l >= L) continue;
-        const float a = s_acc[v][l][rel][ch];
+        const Win a = s_acc[v][l][rel][ch];
         const gsr_hexplane_level& Lv = f.levels[l];
         float* gp = Lv.grad_planes[pl];
         const int W = Lv.res[j], col = col0[l] + rel;
-        if (a == 0.f || !gp || col >= W) continue;
-        const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
+        if (a == 0 || !gp || col >= W) continue;
+        if constexpr (ORD) {
+            atomicAdd(ord_at(v, l, col), a);
+        } else {
+            const HexAxis T = hex_axis(tv.t[v0 + v], Lv.res[3]);
+            float* t = gp + ((size_t)T.i0 * W + col) * C + ch;
+            unsafeAtomicAdd(t, a * T.w0);
+            if (T.has1) unsafeAtomicAdd(t + (size_t)W * C, a * T.w1);
+        }
+    }
+}
+
+// ordered mode: the time families' column sums -> the planes. grid (columns x C / 256, family x levels + level); a thread owns one (column,
+// channel) of one level of one family and adds the views in their order, each to the view's two time rows with its weights.
+__global__ void __launch_bounds__(256)
+hexord_time_convert_kernel(const gsr_hexplane_field f, const HexTimes tv, const HexOrd o, const uint32_t* __restrict__ header)
+{
+    const int L = f.num_levels, C = f.feat_dim;
+    const int j = blockIdx.y / L, l = blockIdx.y % L;
+    const int pl = j == 0 ? 2 : 3 + j;
+    const gsr_hexplane_level& Lv = f.levels[l];
+    float* gp = Lv.grad_planes[pl];
+    const int W = Lv.res[j];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (!gp || e >= W * C) return;
+    const int col = e / C, ch = e % C;
+    const double inv = hexord_inverse(header[1], o.budget);
+    for (int v = 0; v < tv.V; v++) {
+        const unsigned long long a = o.acc_t[((size_t)o.tbase[j] + (size_t)v * o.tcols[j] + o.tcol[j][l] + col) * C + ch];
+        if (a == 0ull) continue;
+        const float val = (float)((double)(long long)a * inv);
+        const HexAxis T = hex_axis(tv.t[v], Lv.res[3]);
         float* t = gp + ((size_t)T.i0 * W + col) * C + ch;
-        unsafeAtomicAdd(t, a * T.w0);
-        if (T.has1) unsafeAtomicAdd(t + (size_t)W * C, a * T.w1);
+        *t += val * T.w0;
+        if (T.has1) t[(size_t)W * C] += val * T.w1;
     }
 }
 
 // the spatial families (planes 0, 1, 3), whose dL/dsample phase 1 summed over the views: the generic walk, one stream per family
-template <int C, int LMAX>
+template <int C, int LMAX, bool ORD>
 __global__ void __launch_bounds__(256)
-hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const int64_t n)
+hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, const HexViewsWs vw, const int64_t n, const HexOrd o)
 {
     constexpr int GROUPS = 256 / C;
     constexpr int GPW = C >= 64 ? 1 : 64 / C;                     // groups per wave: they take the same stream (one code path per wave) ...
@@ -733,7 +901,8 @@ hexsort_phase2_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
     const int cnt = (int)min((int64_t)HEXSORT_CHUNK, na - first);
     const size_t row = (size_t)f.num_levels * C;
     const int pl = st == 2 ? 3 : st;
-    hexsort_phase2_walk<C, LMAX>(f, pl, ws.scoords + (size_t)pl * na + first, vw.gs_sp + ((size_t)st * n + first) * row + ch, cnt, false, 0.f);
+    const float S = ORD ? hexord_scale(ws.header[1], o.budget) : 0.f;
+    hexsort_phase2_walk<C, LMAX, ORD>(f, pl, ws.scoords + (size_t)pl * na + first, vw.gs_sp + ((size_t)st * n + first) * row + ch, cnt, false, 0.f, o, S);
 }
 
 }  // namespace gsr

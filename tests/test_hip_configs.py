@@ -157,6 +157,44 @@ def test_config3_batched_keyframes_equal_the_per_view_iteration():
     assert ms < 45.0, ms
 
 
+def test_config3_is_bit_reproducible():
+    """configs[2], batched keyframes, twice from the same state: EVERY gradient -- Gaussians, camera poses, the deformation MLP and the 24
+    HexPlane planes -- is bitwise the same. The rasterizer has been atomic-free since round 2; the plane gradients are fixed-point integer
+    sums since round 6 (gs_hexplane_binned.h HexOrd: the counting sort's cursor order and the order of the atomics cannot change a bit)."""
+    import gaussian_renderer as gr
+    from diff_gaussian_rasterization import _C
+    from slam_losses import get_loss_mapping
+    assert _C.set_option("hex_ordered") == 1
+    S = _config3_scene()
+    m, views, leaves, config, pipe, bg = S["m"], S["views"], S["leaves"], S["config"], S["pipe"], S["bg"]
+
+    def iteration():
+        S["opt"].zero_grad(set_to_none=True)
+        S["net_opt"].zero_grad(set_to_none=True)
+        for v in views:
+            for p_ in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b):
+                p_.grad = None
+        outs = gr.render_views(views, m, pipe, bg, dynamic=True)
+        assert isinstance(outs[0], gr._RenderPackage)
+        loss = sum(get_loss_mapping(config, o["render"], o["depth"], v, o["opacity"]) for v, o in zip(views, outs))
+        loss.backward()
+        grads = {f"leaf{k}": p_.grad.clone() for k, p_ in enumerate(leaves)}
+        grads.update({f"net{k}": p_.grad.clone() for k, p_ in enumerate(S["net_params"]) if p_.grad is not None})
+        for k, v in enumerate(views):
+            grads[f"theta{k}"], grads[f"rho{k}"] = v.cam_rot_delta.grad.clone(), v.cam_trans_delta.grad.clone()
+        return loss.detach().clone(), grads
+
+    iteration()                                                                    # (first call: single-view kernels inside gsr_forward_views)
+    loss0, ref = iteration()
+    planes = [k for k in ref if ref[k].dim() == 4]
+    assert len(planes) == 24 and all(float(ref[k].abs().sum()) > 0 for k in planes)
+    for _ in range(2):
+        loss1, got = iteration()
+        assert torch.equal(loss0, loss1) and set(got) == set(ref)
+        different = [k for k in ref if not torch.equal(got[k], ref[k])]
+        assert not different, different
+
+
 def test_config3_real_network_500k_gaussians_8_keyframes():
     """configs[2] as BASELINE.json states it: 500k Gaussians, every one moved by the default HexPlane deformation network
     (deformation.deform_network) through render(dynamic=True), 8 keyframes, pose-grad on, fused mapping loss, one backward, FusedAdam on

@@ -632,3 +632,75 @@ def test_render_views_dynamic_equals_per_camera_render_dynamic(iso, row_mask, mo
                 assert float(got[k].abs().max()) < 1e-9, k
             else:
                 assert rel(got[k], ref[k]) < (1e-4 if k.startswith("net.") else 2e-5), (attempt, k, rel(got[k], ref[k]))
+
+
+def _plane_grads(field):
+    return [p.grad.clone() for lv in field.grids for p in lv]
+
+
+@pytest.mark.parametrize("route", ["views", "single"])
+def test_plane_gradients_are_bitwise_reproducible_and_do_not_depend_on_the_point_order(route, monkeypatch):
+    """Ordered mode (gsr_set_option "hex_ordered", the default; gs_hexplane_binned.h HexOrd): every dL/dsample x corner-weight product is rounded
+    once to a power-of-two quantum and summed as integers, so the plane gradients are the same BITS (a) run to run and (b) for any
+    permutation of the points -- the order the counting sort's cursors or the atomics happen to take cannot matter. The float-atomic mode
+    of rounds 1-5 agrees to rounding."""
+    from diff_gaussian_rasterization import _C
+    assert _C.set_option("hex_ordered") == 1
+    monkeypatch.setenv("GSR_HEX_BINNED", "1")
+    field = _shipped_field(seed=5)
+    n, V = 40000, 5
+    g = torch.Generator(device="cpu").manual_seed(11)
+    pts = ((torch.rand((n, 3), generator=g) * 3.6 - 1.8) * torch.tensor([1.0, 0.3, 0.05])).to(DEV)       # crowded along y and z: long runs, busy cells
+    times = [float(t) for t in np.linspace(-0.9, 1.1, V)]
+    cot = torch.randn((V, n, field.feat_dim), generator=g).to(DEV) * torch.logspace(-6, 2, n).to(DEV)[None, :, None]
+    cot[:, torch.rand(n, generator=g).to(DEV) < 0.3] = 0.0
+    cot[2, torch.rand(n, generator=g).to(DEV) < 0.5] = 0.0
+
+    def run(perm=None):
+        for p in field.parameters():
+            p.grad = None
+        x, c = (pts, cot) if perm is None else (pts[perm], cot[:, perm])
+        x = x.clone().requires_grad_(True)
+        if route == "views":
+            (field.forward_views(x, times) * c).sum().backward()
+        else:
+            (field(x, torch.full((n, 1), times[1], device=DEV)) * c[1]).sum().backward()
+        return _plane_grads(field), x.grad
+
+    base, gx = run()
+    assert all(torch.isfinite(b).all() for b in base) and sum(float(b.abs().sum()) for b in base) > 0
+    for _ in range(3):
+        again, gx2 = run()
+        assert all(torch.equal(a, b) for a, b in zip(again, base)) and torch.equal(gx, gx2)
+    perm = torch.randperm(n, generator=g).to(DEV)
+    shuffled, gxp = run(perm)
+    assert all(torch.equal(a, b) for a, b in zip(shuffled, base))
+    assert torch.equal(gxp, gx[perm])
+    # the float-atomic mode: the same sums to rounding
+    old = _C.set_option("hex_ordered", 0)
+    try:
+        loose, _ = run()
+    finally:
+        _C.set_option("hex_ordered", old)
+    for a, b in zip(loose, base):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-30
+        assert rel(a, b) < 1e-5
+
+
+def test_ordered_plane_gradients_scale_with_the_cotangent():
+    """The fixed-point quantum follows the call's largest |dL/dsample|: cotangents scaled by 2^-60 or 2^+40 give gradients scaled by exactly
+    that power of two (no overflow, no flush to zero)."""
+    field = _shipped_field(seed=6)
+    n, V = 20000, 3
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pts = (torch.rand((n, 3), generator=g) * 3.0 - 1.5).to(DEV)
+    cot = torch.randn((V, n, field.feat_dim), generator=g).to(DEV)
+    out = {}
+    for k in (0, -60, 40):
+        for p in field.parameters():
+            p.grad = None
+        (field.forward_views(pts, [-0.5, 0.0, 0.8]) * (cot * 2.0 ** k)).sum().backward()
+        out[k] = _plane_grads(field)
+    for k in (-60, 40):
+        for a, b in zip(out[k], out[0]):
+            assert torch.equal(a, b * 2.0 ** k)
