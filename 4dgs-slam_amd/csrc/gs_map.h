@@ -157,7 +157,7 @@ __device__ __forceinline__ void mat3_mul(const float* A, const float* B, float* 
 // rot 3, trans 3, a, b -- the n[] of camera_step_args), the pose. Taken where they are used -- four tensors one after the other, each behind the
 // previous one's stores, then the pose behind a block barrier, then the stepped deltas back from memory -- they were seven dependent memory
 // round trips in a one-block kernel that runs once per tracking iteration. track_tail_kernel issues them before its gradient sums.
-struct CameraStepLoads { bool skip, any_grad, mine; int e; float* ps; float lrs, step0, gr, m, v, pv; float Rm[9], Tv[3]; };
+struct CameraStepLoads { bool skip, any_grad, mine; int e; float* ps; float lrs, step0, gr, m, v, pv; float Rm[9], Tv[3], proj[16]; };
 __device__ __forceinline__ CameraStepLoads camera_step_loads(const CameraStepArgs& a, bool grads_come_later)
 {
     CameraStepLoads L;
@@ -167,9 +167,18 @@ __device__ __forceinline__ CameraStepLoads camera_step_loads(const CameraStepArg
     for (int s = 0; s < 4; s++) L.any_grad |= a.g[s] != nullptr;
     const int s = lane < 3 ? 0 : lane < 6 ? 1 : lane == 6 ? 2 : 3;
     L.e = lane - (s == 0 ? 0 : s == 1 ? 3 : s == 2 ? 6 : 7);
-    const float* const gs = s == 0 ? a.g[0] : s == 1 ? a.g[1] : s == 2 ? a.g[2] : a.g[3];          // (selects: a run-time index would go through scratch memory)
-    L.ps = s == 0 ? a.p[0] : s == 1 ? a.p[1] : s == 2 ? a.p[2] : a.p[3];
-    L.lrs = s == 0 ? a.lr[0] : s == 1 ? a.lr[1] : s == 2 ? a.lr[2] : a.lr[3];
+    // (selects between values pinned in scalar registers: left to itself the compiler turns the selects back into ONE load with a run-time index,
+    // and for that it copies the whole argument block to scratch memory -- 216 bytes per lane written and read back at the head of a kernel
+    // whose whole point is latency)
+    const float* g4[4]; float* p4[4]; float lr4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        g4[k] = a.g[k]; p4[k] = a.p[k]; lr4[k] = a.lr[k];
+        asm volatile("" : "+s"(g4[k]), "+s"(p4[k]), "+s"(lr4[k]));
+    }
+    const float* const gs = s == 0 ? g4[0] : s == 1 ? g4[1] : s == 2 ? g4[2] : g4[3];
+    L.ps = s == 0 ? p4[0] : s == 1 ? p4[1] : s == 2 ? p4[2] : p4[3];
+    L.lrs = s == 0 ? lr4[0] : s == 1 ? lr4[1] : s == 2 ? lr4[2] : lr4[3];
     L.mine = lane < 8 && gs != nullptr;
     L.step0 = L.any_grad ? a.step[0] : 0.f;
     L.gr = 0.f; L.m = 0.f; L.v = 0.f; L.pv = 0.f;
@@ -177,6 +186,9 @@ __device__ __forceinline__ CameraStepLoads camera_step_loads(const CameraStepArg
     if (lane < 8 && L.ps != nullptr) L.pv = L.ps[L.e];
     for (int k = 0; k < 9; k++) L.Rm[k] = a.R[k];
     for (int k = 0; k < 3; k++) L.Tv[k] = a.T[k];
+    // (the projection too: read where it is used -- between the stores of view[] and full[], which it may alias for all the compiler knows --
+    // every row of the product waited for its own four loads behind the previous row's store: sixteen dependent round trips in lane 0)
+    for (int k = 0; k < 16; k++) L.proj[k] = a.full ? a.proj[k] : 0.f;
     return L;
 }
 
@@ -250,18 +262,18 @@ __device__ __forceinline__ void camera_step_apply(const CameraStepArgs& a, const
         view[4 * r + 3] = 0.f;
     }
     view[15] = 1.f;
+    float full[16], campos[3];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s = 0.f;
+            for (int k = 0; k < 4; k++) s += view[4 * i + k] * L.proj[4 * k + j];
+            full[4 * i + j] = s;
+        }
+    for (int c = 0; c < 3; c++) campos[c] = -(Rm[c] * Tv[0] + Rm[3 + c] * Tv[1] + Rm[6 + c] * Tv[2]);   // camera centre = -R^T T  (= inverse(view)[3, :3])
+    // all stores at the end, nothing read in between
     for (int k = 0; k < 16; k++) a.view[k] = view[k];
-    if (a.full) {
-        for (int i = 0; i < 4; i++)
-            for (int j = 0; j < 4; j++) {
-                float s = 0.f;
-                for (int k = 0; k < 4; k++) s += view[4 * i + k] * a.proj[4 * k + j];
-                a.full[4 * i + j] = s;
-            }
-    }
-    if (a.campos) {   // camera centre = -R^T T  (= inverse(view)[3, :3])
-        for (int c = 0; c < 3; c++) a.campos[c] = -(Rm[c] * Tv[0] + Rm[3 + c] * Tv[1] + Rm[6 + c] * Tv[2]);
-    }
+    if (a.full) for (int k = 0; k < 16; k++) a.full[k] = full[k];
+    if (a.campos) for (int c = 0; c < 3; c++) a.campos[c] = campos[c];
 }
 
 __device__ __forceinline__ void camera_step_body(const CameraStepArgs& a) { camera_step_apply(a, camera_step_loads(a, false)); }
@@ -279,9 +291,24 @@ __global__ void __launch_bounds__(384) track_tail_kernel(int nblocks, const floa
     __shared__ float s_g[8];
     const CameraStepLoads pre = camera_step_loads(a, true);        // in flight while the sums are formed
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (tau_sum_body's order, a lane's terms fetched eight at a time: one load per trip of a loop of unknown length waits for each of them in turn --
+    // 19 dependent round trips for the 1 200 tiles of a 640 x 480 frame, 10 of this kernel's 14.5 us)
     float v = 0.f, e = 0.f;
-    for (int b = lane; b < nblocks; b += 64) v += tau_partials[(size_t)b * 6 + k];          // (tau_sum_body's order)
-    if (k < 2) for (int b = lane; b < ntiles; b += 64) e += exposure_partials[2 * (size_t)b + k];
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = b0 + 64 * j < nblocks ? tau_partials[(size_t)(b0 + 64 * j) * 6 + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (b0 + 64 * j < nblocks) v += t[j];
+    }
+    if (k < 2)
+        for (int b0 = lane; b0 < ntiles; b0 += 64 * 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = b0 + 64 * j < ntiles ? exposure_partials[2 * (size_t)(b0 + 64 * j) + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (b0 + 64 * j < ntiles) e += t[j];
+        }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { v += __shfl_xor(v, d, 64); e += __shfl_xor(e, d, 64); }
     if (lane == 0) {
