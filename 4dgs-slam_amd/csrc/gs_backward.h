@@ -661,7 +661,13 @@ __device__ __forceinline__ void tau_sum_body(int nblocks, const float* __restric
 {
     const int k = threadIdx.x >> 6, lane = lane_id();
     float v = 0.f;
-    for (int b = lane; b < nblocks; b += 64) v += partials[(size_t)b * 6 + k];
+    for (int b0 = lane; b0 < nblocks; b0 += 64 * 8) {          // eight of a lane's terms in flight per trip; added in the order of b (782 blocks at config #2:
+        float t[8];                                             // thirteen dependent round trips otherwise)
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = b0 + 64 * j < nblocks ? partials[(size_t)(b0 + 64 * j) * 6 + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (b0 + 64 * j < nblocks) v += t[j];
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     if (lane == 0) out6[k] = v;

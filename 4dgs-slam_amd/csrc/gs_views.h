@@ -194,20 +194,37 @@ __global__ void __launch_bounds__(256) views_reduce_kernel(int V, ViewTable t, i
     if (i >= P) return;
     const PartLayout L = part_layout((size_t)P, M, S);
     uint32_t seen = 0;
-    for (int v = 0; v < V; v++) seen |= (t.v[v].radii[i] > 0 ? 1u : 0u) << v;
+#pragma unroll
+    for (int v = 0; v < MAX_VIEWS; v++) seen |= (v < V && t.v[v].radii[i] > 0 ? 1u : 0u) << v;
     if (!seen && accumulate) return;                     // accumulate mode leaves the rows of Gaussians no view saw alone
+    // Four elements of the row at a time: the views' values are all requested first (and the old value, in accumulate mode), then added in
+    // view order. (Element by element, view by view, every term waited for its own load: V x 14 dependent round trips per thread in a kernel
+    // of 76 blocks at SLAM sizes.)
     auto fold = [&](float* dst, size_t base, int width) {
         if (!dst) return;                                 // a gradient the caller did not ask for (flow mode: everything but the positions)
-        for (int k = 0; k < width; k++) {
-            float acc = accumulate ? dst[(size_t)i * width + k] : 0.f;
+        for (int k0 = 0; k0 < width; k0 += 4) {
+            const int w = min(4, width - k0);
+            const size_t at = (size_t)i * width + k0;
+            float g[MAX_VIEWS][4], acc[4];
+#pragma unroll
+            for (int v = 0; v < MAX_VIEWS; v++) {
+                const bool on = v < V && ((seen >> v) & 1u);
+                const float* row = t.v[v].part + base + at;
+#pragma unroll
+                for (int k = 0; k < 4; k++) g[v][k] = on && k < w ? row[k] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = accumulate && k < w ? dst[at + k] : 0.f;
             bool first = !accumulate;
-            for (int v = 0; v < V; v++) {
-                if (!((seen >> v) & 1u)) continue;
-                const float g = t.v[v].part[base + (size_t)i * width + k];
-                acc = first ? g : add_separately(acc, g);
+#pragma unroll
+            for (int v = 0; v < MAX_VIEWS; v++) {
+                if (!(v < V && ((seen >> v) & 1u))) continue;
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] = first ? g[v][k] : add_separately(acc[k], g[v][k]);
                 first = false;
             }
-            dst[(size_t)i * width + k] = acc;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k < w) dst[at + k] = acc[k];
         }
     };
     fold(out.xyz, L.xyz, 3);
