@@ -66,7 +66,15 @@ int gsr_hexplane_backward(const gsr_hexplane_field* field, int64_t n, const floa
  * are counting-sorted per plane family by the Morton code of their finest-level cell, dL/dsample is staged in the workspace in
  * sorted order, and runs of points that share a cell are summed in registers before ONE set of four atomics per run
  * (channels-last planes, resolutions <= 1024) -- the fast path for large n, and the one whose cost falls rather than rises when
- * many points share texels.  workspace NULL = one float atomic per (point, corner), no extra memory. */
+ * many points share texels.  workspace NULL = one float atomic per (point, corner), no extra memory.
+ *
+ * Ordered mode (gsr_set_option("hex_ordered", 1), the default; both sorted entry points): the plane gradients are BITWISE reproducible -- run
+ * to run and under any permutation of the points. Every product dL/dsample x corner weight is rounded once to a power-of-two quantum
+ * (2^-40 of the call's largest |dL/dsample|; 2^-(62 - ceil(log2(4 n))) beyond 1 M points) and from there on only integers are added
+ * (registers, LDS and 64-bit integer atomics in the workspace); a last pass converts the sums and ADDS them to grad_planes, one owner per
+ * texel. Against the float-atomic mode (0: rounds 1-5) the sums differ by rounding only. The workspace grows by 8 bytes per texel of the
+ * planes: read the size AFTER setting the option and do not change the option between the size query and the call. The unsorted
+ * path (workspace NULL) keeps its float atomics. */
 size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int64_t n);
 
 /* ---- the views of one mapping iteration at once ---------------------------------------------------------------------------------
@@ -79,7 +87,9 @@ size_t gsr_hexplane_backward_workspace_size(const gsr_hexplane_field* field, int
  *   backward: dL_dfeatures [V][n][L*C]; ONE counting sort of the points for all views, dL/dsample of the spatial planes summed over the
  *             views in registers before the (single) spatial scatter, the time planes' per view; accumulates into grad_planes like V
  *             gsr_hexplane_backward calls, WRITES dL_dxyz [n,3] = the sum over the views. Needs channels-last planes, resolutions
- *             <= 1024 and a workspace of gsr_hexplane_backward_views_workspace_size() bytes (0 = unsupported geometry: call view by view). */
+ *             <= 1024 and a workspace of gsr_hexplane_backward_views_workspace_size() bytes (0 = unsupported geometry: call view by view).
+ *             Ordered mode (above): the spatial planes as there; the time families keep integer column sums per view and the last pass
+ *             applies each view's two time-row weights, views in their order. */
 #define GSR_HEXPLANE_MAX_VIEWS 12
 int gsr_hexplane_forward_views(const gsr_hexplane_field* field, int64_t n, const float* xyz, int64_t xyz_stride, int V, const float* times,
                                float* features, void* stream);

@@ -286,6 +286,8 @@ int gsr_debug_item_block(unsigned int n_items, unsigned int n_partial, unsigned 
  *                pass (which writes the work-item table).
  *   "sh_rows" (default 1): the SH coefficients of a wave's 64 Gaussians move as whole rows through LDS (one DMA instruction / one store per
  *                row) instead of one strided access per coefficient and lane; same arithmetic, bit-identical results. 0 = per lane.
+ *   "hex_ordered" (default 1; PROCESS-wide, value < 0 only reads): the HexPlane field's sorted backward passes (deformation_field.h) sum the plane
+ *                gradients as fixed-point integers -- bitwise reproducible; 0 = float atomics. Environment: GSR_HEX_ORDERED.
  *   "cap_test_shrink_permille" (default 0 = off): TEST facility -- lay speculative buffers out for this fraction of the previous
  *                frame's count, so that overflows (and the callers' recovery paths) can be provoked deliberately.
  * Environment: GSR_SPECULATE, GSR_LAZY, GSR_MAILBOX, GSR_ORDER_ITEMS, GSR_SH_ROWS set the initial values. */
