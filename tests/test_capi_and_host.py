@@ -247,3 +247,35 @@ def test_render_package_forms_the_visibility_filter_when_it_is_read():
     assert pkg["visibility_filter"].tolist() == [False, True, False, True] and "visibility_filter" in pkg
     with pytest.raises(KeyError):
         pkg["depth"]
+
+
+def test_hexplane_workspace_follows_the_ordered_option():
+    """gsr_set_option("hex_ordered") (include/gs_rasterizer.h, include/deformation_field.h): process-wide, default 1, value < 0 only reads; the
+    sorted backward's workspace carries 8 bytes per plane texel more in ordered mode (host-side arithmetic only: no GPU needed)."""
+    import hexplane
+    lib = _C.load_library()
+    hl = hexplane._lib()
+    assert _C.set_option("hex_ordered") == 1 and _C.set_option("hex_ordered", -1) == 1
+    C, n, V = 32, 100_000, 8
+    res = [[64 * m, 64 * m, 64 * m, 25] for m in (1, 2, 4, 8)]
+    field = hexplane._Field()
+    field.num_levels, field.feat_dim, field.channels_last = 4, C, 1
+    for l, r in enumerate(res):
+        for k in range(4):
+            field.levels[l].res[k] = r[k]
+    combos = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    texels_all = sum(r[a] * r[b] * C for r in res for a, b in combos)
+    texels_spatial = sum(r[a] * r[b] * C for r in res for a, b in combos if b != 3)
+    columns = sum(r[k] for r in res for k in range(3)) * V * C
+    try:
+        sizes = {}
+        for mode in (0, 1):
+            _C.set_option("hex_ordered", mode)
+            sizes[mode] = (hl.gsr_hexplane_backward_workspace_size(ctypes.byref(field), n),
+                           hl.gsr_hexplane_backward_views_workspace_size(ctypes.byref(field), n, V))
+    finally:
+        _C.set_option("hex_ordered", 1)
+    pad = 512                                                        # the carve rounds every region up to 256 bytes
+    assert 0 <= sizes[1][0] - sizes[0][0] - 8 * texels_all <= pad
+    assert 0 <= sizes[1][1] - sizes[0][1] - 8 * (texels_spatial + columns) <= pad
+    assert lib is not None

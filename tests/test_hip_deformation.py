@@ -704,3 +704,33 @@ def test_ordered_plane_gradients_scale_with_the_cotangent():
     for k in (-60, 40):
         for a, b in zip(out[k], out[0]):
             assert torch.equal(a, b * 2.0 ** k)
+
+
+def test_ordered_plane_gradients_beyond_a_million_points():
+    """n > 2^20: the fixed-point budget shrinks below 40 bits (62 - ceil(log2 4n), gs_capi.hip hexord_plan) so that 4 n contributions of the
+    largest magnitude cannot overflow 63 bits. Every point in ONE texel with the same sign -- the worst case for the sum --: finite,
+    reproducible, and equal to the float-atomic mode's sums to its own rounding noise."""
+    from diff_gaussian_rasterization import _C
+    field = _shipped_field(seed=7)
+    n = 1_300_000
+    g = torch.Generator(device="cpu").manual_seed(2)
+    pts = (torch.tensor([[0.123, 0.456, -0.789]]) + (torch.rand((n, 3), generator=g) - 0.5) * 1e-4).to(DEV)
+    cot = (torch.rand((1, n, field.feat_dim), generator=g) + 0.5).to(DEV)             # all positive: nothing cancels
+
+    def run():
+        for p in field.parameters():
+            p.grad = None
+        (field.forward_views(pts, [0.25]) * cot).sum().backward()
+        return _plane_grads(field)
+
+    a = run()
+    b = run()
+    assert all(torch.isfinite(x).all() for x in a) and all(torch.equal(x, y) for x, y in zip(a, b))
+    old = _C.set_option("hex_ordered", 0)
+    try:
+        loose = run()
+    finally:
+        _C.set_option("hex_ordered", old)
+    for x, y in zip(a, loose):
+        assert float(x.abs().max()) > 0
+        assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max())           # (650 k float additions into one texel: the atomic mode's own drift)
