@@ -83,14 +83,25 @@ __device__ __forceinline__ void hexord_add(unsigned long long* p, double v)
 {
     if (v != 0.0) atomicAdd(p, (unsigned long long)(long long)v);
 }
-// the wave's largest |dL/dsample| -> header[1] (a maximum is order-free); once the word has grown, almost no wave still has to write
-__device__ __forceinline__ void hexord_publish_max(float mx, uint32_t* maxp)
+// the wave's largest finite |dL/dsample| -> header[1] (a maximum is order-free); once the word has grown, almost no wave still has to write.
+// A NaN or an infinity among the values (fmaxf drops a NaN, and neither survives the conversion to an integer) raises header[2] instead: the
+// last pass then makes every gradient of the call NaN -- as loud as the float path, where the value itself would have reached its texels.
+__device__ __forceinline__ float hexord_track(float mx, float v)
 {
+    const float a = fabsf(v);
+    return a <= 3.4028234664e38f ? fmaxf(mx, a) : __uint_as_float(0x7f800000u);          // +inf marks "something was not finite"
+}
+__device__ __forceinline__ void hexord_publish_max(float mx, uint32_t* header)
+{
+    const bool bad = !(mx <= 3.4028234664e38f);
+    if (bad) mx = 0.f;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    const bool any_bad = __any(bad);
     if ((threadIdx.x & 63) == 0) {
         const uint32_t b = __float_as_uint(mx);
-        if (b > __hip_atomic_load(maxp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxp, b);
+        if (b > __hip_atomic_load(header + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(header + 1, b);
+        if (any_bad) atomicOr(header + 2, 1u);
     }
 }
 
@@ -297,7 +308,7 @@ __device__ __forceinline__ float hexsort_phase1_body(const gsr_hexplane_field& f
             const float gs = prefix * suffix[pl];
             prefix *= s[pl];
             __builtin_nontemporal_store(gs, &ws.gs[slot[pl] + (size_t)l * C]);   // streamed once: keep the planes in L2 (331 -> 299 us)
-            mx = fmaxf(mx, fabsf(gs));
+            mx = hexord_track(mx, gs);
             if (dL_dxyz) {
                 const float nw = corner[pl][0] * gs, ne = X.has1 ? corner[pl][1] * gs : 0.f, sw = Y.has1 ? corner[pl][2] * gs : 0.f;
                 const float se = X.has1 && Y.has1 ? corner[pl][3] * gs : 0.f;
@@ -327,7 +338,7 @@ hexsort_phase1_kernel(const gsr_hexplane_field f, const HexSortWs ws, const int6
                       float* __restrict__ dL_dxyz, const int ordered)
 {
     const float mx = hexsort_phase1_body<C>(f, ws, n, xyz, xyz_stride, time, time_stride, dL_dfeatures, dL_dxyz);
-    if (ordered) hexord_publish_max(mx, ws.header + 1);
+    if (ordered) hexord_publish_max(mx, ws.header);
 }
 
 // ---- phase 2: run-length accumulation along the sorted order --------------------------------------------------------------------------
@@ -449,6 +460,7 @@ hexord_convert_kernel(const gsr_hexplane_field f, const HexOrd o, const uint32_t
     const size_t count = (size_t)Lv.res[hex_c0(pl)] * Lv.res[hex_c1(pl)] * f.feat_dim;      // even: the channel counts are multiples of 8
     const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
     if (!gp || e >= count) return;
+    if (header[2]) { gp[e] = gp[e + 1] = __uint_as_float(0x7fc00000u); return; }      // a non-finite dL/dsample somewhere in the call (hexord_publish_max)
     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(o.acc + o.off[l][pl] + e);
     if ((v.x | v.y) == 0ull) return;
     const double inv = hexord_inverse(header[1], o.budget);
@@ -626,7 +638,7 @@ __device__ __forceinline__ float hexsort_phase1_views_body(const gsr_hexplane_fi
             for (int j = 0; j < 3; j++) {
                 const float gt = gs[TP[j]];
                 __builtin_nontemporal_store(gt, &vw.gs_t[t_slot[j] + (size_t)v * n * row + (size_t)l * C]);
-                mx = fmaxf(mx, fabsf(gt));
+                mx = hexord_track(mx, gt);
                 if (dL_dxyz) {                                    // the time itself receives no gradient
                     const HexAxis& X = ax[j];
                     const float nw = ct[j][0] * gt, ne = X.has1 ? ct[j][1] * gt : 0.f, sw = T.has1 ? ct[j][2] * gt : 0.f;
@@ -642,7 +654,7 @@ __device__ __forceinline__ float hexsort_phase1_views_body(const gsr_hexplane_fi
             const HexAxis& Y = ax[c1];
             const float gsp = Gs[j];
             __builtin_nontemporal_store(gsp, &vw.gs_sp[sp_slot[j] + (size_t)l * C]);
-            mx = fmaxf(mx, fabsf(gsp));
+            mx = hexord_track(mx, gsp);
             if (dL_dxyz) {
                 const float nw = cs[j][0] * gsp, ne = X.has1 ? cs[j][1] * gsp : 0.f, sw = Y.has1 ? cs[j][2] * gsp : 0.f;
                 const float se = X.has1 && Y.has1 ? cs[j][3] * gsp : 0.f;
@@ -672,7 +684,7 @@ hexsort_phase1_views_kernel(const gsr_hexplane_field f, const HexSortWs ws, cons
                             float* __restrict__ dL_dxyz, const int ordered)
 {
     const float mx = hexsort_phase1_views_body<C>(f, ws, vw, tv, n, xyz, xyz_stride, dL_dfeatures, dL_dxyz);
-    if (ordered) hexord_publish_max(mx, ws.header + 1);
+    if (ordered) hexord_publish_max(mx, ws.header);
 }
 
 // ---- phase 2 of the TIME families, all views ----------------------------------------------------------------------------------------
@@ -867,6 +879,10 @@ hexord_time_convert_kernel(const gsr_hexplane_field f, const HexTimes tv, const 
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (!gp || e >= W * C) return;
     const int col = e / C, ch = e % C;
+    if (header[2]) {                                              // a non-finite dL/dsample somewhere in the call: every row of the plane
+        for (int r = 0; r < Lv.res[3]; r++) gp[((size_t)r * W + col) * C + ch] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     const double inv = hexord_inverse(header[1], o.budget);
     for (int v = 0; v < tv.V; v++) {
         const unsigned long long a = o.acc_t[((size_t)o.tbase[j] + (size_t)v * o.tcols[j] + o.tcol[j][l] + col) * C + ch];

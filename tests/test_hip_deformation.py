@@ -734,3 +734,25 @@ def test_ordered_plane_gradients_beyond_a_million_points():
     for x, y in zip(a, loose):
         assert float(x.abs().max()) > 0
         assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max())           # (650 k float additions into one texel: the atomic mode's own drift)
+
+
+@pytest.mark.parametrize("poison", [float("nan"), float("inf")])
+def test_ordered_plane_gradients_stay_loud_about_non_finite_cotangents(poison, monkeypatch):
+    """A NaN / infinite cotangent cannot be represented in the fixed-point sums; instead of dropping it the ordered mode makes EVERY plane
+    gradient of the call NaN (the float path would have delivered the value to the texels it touches)."""
+    monkeypatch.setenv("GSR_HEX_BINNED", "1")
+    field = _shipped_field(seed=8)
+    n = 5000
+    g = torch.Generator(device="cpu").manual_seed(4)
+    pts = (torch.rand((n, 3), generator=g) * 3.0 - 1.5).to(DEV)
+    for route in ("views", "single"):
+        cot = torch.randn((2, n, field.feat_dim), generator=g).to(DEV)
+        cot[1, 1234, 17] = poison
+        for p in field.parameters():
+            p.grad = None
+        if route == "views":
+            (field.forward_views(pts, [-0.5, 0.4]) * cot).sum().backward()
+        else:
+            (field(pts, torch.full((n, 1), 0.4, device=DEV)) * cot[1]).sum().backward()
+        grads = _plane_grads(field)
+        assert len(grads) == 24 and all(torch.isnan(x).all() for x in grads), route
