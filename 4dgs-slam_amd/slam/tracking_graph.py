@@ -99,7 +99,7 @@ class TrackingGraph:
 
     # ---- the iteration ---------------------------------------------------------------------------------------------------
     def _fused_iteration(self):
-        """The whole iteration as ONE C call, five launches (include/slam_map.h: gsr_track_step): the loss's cotangents in the tile kernel's
+        """The whole iteration as ONE C call, seven launches (include/slam_map.h: gsr_track_step): the loss's cotangents in the tile kernel's
         epilogue, pose-only backward, and one tail launch for the gradient sums + the camera step. Pixel cotangents and the pose gradient are
         the bits of the autograd route; the two exposure gradients are summed per tile instead of per 256 strided pixels (equal to rounding)."""
         c, g = self.cam, self.frozen

@@ -101,7 +101,7 @@ int gsr_camera_step_launch(const gsr_camera_step* s, void* stream);
 int gsr_camera_steps_launch(int n, const gsr_camera_step* steps /* host array */, void* stream);
 
 /* ---- a tracking iteration in one call: utils/slam_frontend.py:405-448 (render -> get_loss_tracking -> loss.backward() -> pose_optimizer.step()
- * -> update_pose), five launches at SLAM sizes (round 6; ten before) ---------------------------------------------------------------
+ * -> update_pose), seven launches (round 6; eleven before) ---------------------------------------------------------------
  * gsr_forward_raw's pipeline with the weighted L1 tracking loss's cotangents (utils/slam_utils.py:57-173, include/slam_losses.h:
  * gsr_l1_loss_backward's arithmetic, pixel for pixel the same bits) formed in the epilogue of the tile kernel from the pixel still in
  * registers; the backward pass in its pose-only mode (GSR_BACKWARD_POSE_ONLY); and ONE tail launch that finishes the pose-gradient sum
