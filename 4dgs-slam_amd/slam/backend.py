@@ -804,21 +804,47 @@ class BackEnd:
             loss = loss + slam_losses.masked_l1(flow_weight, [(rendered[2 * k]["render"], t_back, m1), (rendered[2 * k + 1]["render"], t_fwd, m2)], channels=2)
         return loss
 
-    def color_refinement(self, iteration_total=1500, views_per_iter=10):
-        """:777-862 (static form): L1 + D-SSIM on random keyframes, Gaussians only."""
+    def color_refinement(self, iteration_total=1500, views_per_iter=10, dynamic_network=None):
+        """:777-858: L1 + D-SSIM (+ 0.1 depth L1, + the isotropic term) on ten random keyframes per iteration. `dynamic_network` defaults to
+        the model's flag, as the reference's caller passes it (:899-900). Static form (:828-833): the moving pixels are masked out, only the
+        Gaussians step. Dynamic form, once the node network is initialised (:791-802,:822-827,:855-857): every view is rendered through the
+        warp WITH its graph, the loss is unmasked, each view adds 1e-4 x arap_loss(t = its time, delta_t = 5 intervals, 8 samples), and the
+        network's optimizer steps beside the Gaussians'. The iteration's views and ARAP samples go through the node network as ONE batch
+        (deform_model.begin_iteration: the fused trunk) -- view by view, op by op, the 512-row network cost ten forward and ten backward
+        passes of library GEMMs per iteration, each weight gradient a single 256 x 256 macro tile on one CU (119 us: 1.3 s of the
+        reference-schedule stand-in's 200 iterations)."""
+        from .deform_model import draw_arap_times
         lam = self.opt_params.lambda_dssim
+        g = self.gaussians
+        if dynamic_network is None:
+            dynamic_network = self.dynamic_model
+        unmasked = bool(dynamic_network and self.dynamic_model and g.deform_init)
+        use_net = bool(unmasked and g.dyn_rows().shape[0] > 0)
         ids = list(self.viewpoints.keys())
         shard = self.shard
+        net_params = [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else []
+        if use_net:
+            shard.attach_network(net_params)           # (sharded runs: the network's gradients live in one flat bucket, reduced in place)
         for iteration in range(1, iteration_total + 1):
             loss = 0
-            for k, idx in enumerate(random.sample(ids, min(views_per_iter, len(ids)))):      # the same draw on every rank
+            cams = [self.viewpoints[idx] for idx in random.sample(ids, min(views_per_iter, len(ids)))]      # the same draw on every rank
+            if use_net:
+                nodes = g.deform.deform
+                plans = [draw_arap_times(cam.time, 5 * g.time_interval, 8) for cam in cams]            # drawn on every rank (streams in step)
+                regularise = shard.rank == 0 and nodes.node_num >= 3                                    # (the regularisers are rank 0's, as in map())
+                nodes.begin_iteration([cam.time for k, cam in enumerate(cams) if shard.owns(k)],
+                                      positions_only=[t for plan in plans for t in plan] if regularise else [],
+                                      blend=(g.get_dygs_xyz.detach(), g.motion_mask))
+                self._delta_cache = {}
+                if regularise:
+                    loss = loss + 1e-4 * nodes.arap_loss_batch(plans).sum()                            # :827, one term per view
+            for k, cam in enumerate(cams):
                 if not shard.owns(k):
                     continue
-                cam = self.viewpoints[idx]
                 pkg = self._render(cam, self._deltas(cam))
                 image = torch.exp(cam.exposure_a) * pkg["render"] + cam.exposure_b
                 gt_image = cam.original_image.to(image.device)
-                mm = cam.motion_mask if not (self.dynamic_model and self.gaussians.deform_init) else None
+                mm = None if unmasked else cam.motion_mask
                 Ll1 = torch.abs(image - gt_image).mean() if mm is None else torch.abs(image * mm - gt_image * mm).mean()
                 loss = loss + (1.0 - lam) * Ll1 + lam * (1.0 - slam_losses.ssim(image, gt_image, mask=mm))
                 gt_depth = cam.depth_device()[None]
@@ -828,11 +854,17 @@ class BackEnd:
                 loss = loss + self._isotropic_loss()
             if torch.is_tensor(loss) and loss.requires_grad:
                 loss.backward()
-            shard.reduce_gradients(self.gaussians.optimizer)
+            if use_net:
+                g.deform.deform.end_iteration()
+                self._delta_cache = None
+            shard.reduce_gradients(g.optimizer, net_params)
             with torch.no_grad():
-                self.gaussians.optimizer.step()
-                self.gaussians.optimizer.zero_grad(set_to_none=True)
-                self.gaussians.update_learning_rate(iteration)
+                g.optimizer.step()
+                g.optimizer.zero_grad(set_to_none=True)
+                g.update_learning_rate(iteration)
+                if use_net:                                                   # :855-857
+                    g.deform.optimizer.step()
+                    shard.zero_network_grads(g.deform.optimizer)
                 self._clear_camera_grads(self.viewpoints.values())
 
     # ---- messages of run() (:879-1010) as calls ----------------------------------------------------------------------------

@@ -245,6 +245,12 @@ def draw_loss_times(t, arap_delta, arap_samples, elastic_delta, elastic_samples=
     return {"arap": arap, "elastic": elastic}
 
 
+def draw_arap_times(t, delta, samples):
+    """The time samples ONE ControlNodeWarp.arap_loss(t, delta_t, t_samp_num) call draws (:1129-1132), as host floats (CPU generator)."""
+    ta = t + delta * (float(torch.rand(())) - 0.5)
+    return (torch.rand(samples) * delta + ta - 0.5 * delta).tolist()
+
+
 @functools.lru_cache(maxsize=256)
 def _row_groups(R, target=2048):
     """Into how many equal parts to split R rows so that a part has about `target` rows: the divisor g of R with R / g closest to the target

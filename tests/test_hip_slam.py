@@ -898,6 +898,53 @@ def test_color_refinement_improves_the_map_and_runs_sharded_code_path():
     assert torch.isfinite(be.gaussians._xyz).all()
 
 
+def test_color_refinement_dynamic_form_trains_the_node_network_too():
+    """utils/slam_backend.py:791-802,:822-827,:855-857 (color_refinement(dynamic_network=self.dynamic_model), :899-900): with an initialised
+    node network every view is rendered through the warp with its graph, the loss is unmasked, each view adds 1e-4 x arap_loss, and the
+    network's optimizer steps beside the Gaussians'. The iteration's views and ARAP samples go through the network as one batch
+    (begin_iteration): no library GEMM per view. Two runs from the same seeds: bit-identical Gaussians and network."""
+    import random
+
+    def run():
+        res, _, net_before, slam = _short_dynamic_run()
+        be, g = slam.backend, slam.gaussians
+        assert g.deform_init and int(g.dygs.sum()) > 0
+        net = [p for grp in g.deform.optimizer.param_groups for p in grp["params"]]
+
+        def mean_psnr():
+            out = []
+            with torch.no_grad():
+                for cam in be.viewpoints.values():
+                    img = torch.clamp(be._render(cam, be._deltas(cam, train=False))["render"], 0.0, 1.0)
+                    gt = cam.original_image.to(img.device)
+                    out.append(float(-10.0 * torch.log10(((img - gt) ** 2).mean())))
+            return sum(out) / len(out)
+
+        before = mean_psnr()
+        torch.manual_seed(3)
+        random.seed(3)
+        be.color_refinement(iteration_total=25, views_per_iter=4)
+        after = mean_psnr()
+        gauss = [p.detach().clone() for p in (g._xyz, g._features_dc, g._opacity, g._scaling, g._rotation)]
+        return before, after, gauss, [p.detach().clone() for p in net], net_before, slam
+
+    b0, a0, g0, n0, start, slam = run()
+    print("dynamic refinement, PSNR over the keyframes: %.2f -> %.2f dB" % (b0, a0))
+    assert a0 >= b0 - 0.05 and all(torch.isfinite(p).all() for p in g0 + n0)
+    moved = [float((p - q).abs().max()) for p, q in zip(n0, start)]
+    assert max(moved) > 0 and sum(m > 0 for m in moved) >= len(moved) // 2, moved          # the network's optimizer stepped (:855-857)
+    b1, a1, g1, n1, _, _ = run()
+    assert (b0, a0) == (b1, a1)
+    for xs, ys in ((g0, g1), (n0, n1)):
+        assert all(torch.equal(x, y) for x, y in zip(xs, ys))
+    # the static form leaves the network alone
+    be = slam.backend
+    net = [p for grp in slam.gaussians.deform.optimizer.param_groups for p in grp["params"]]
+    frozen = [p.detach().clone() for p in net]
+    be.color_refinement(iteration_total=3, views_per_iter=4, dynamic_network=False)
+    assert all(torch.equal(p, q) for p, q in zip(net, frozen))
+
+
 def test_slam_loop_through_the_ctypes_binding():
     """The SLAM loop with GSR_GLUE=ctypes (the binding a non-PyTorch-extension integration would use): a child process, 10 frames."""
     import subprocess
