@@ -592,6 +592,29 @@ class ControlNodes(nn.Module):
             self._batch = None
             return
         M, net = self.node_num, self.network
+        if self.nodes.is_cuda and self.nodes.dtype == torch.float32 and os.environ.get("GSR_BATCH_TRUNK", "1") != "0":
+            # On the device the batch goes through begin_iteration_indexed: the whole network as ONE autograd node on the dense kernels
+            # (_FusedTrunk: embedding in one launch, the layers as one chain, the nine weight gradients as one launch), the heads as one
+            # matrix, the blend packed -- the path the captured iterations take; only the bookkeeping by host time is this function's.
+            # (The layer-by-layer form below ran the eager map() iterations and colour refinement on the library's GEMMs: 81 samples x 512
+            # nodes per refinement iteration, a weight gradient of [256, 41 472] x [41 472, 84] at 146 us on a 32 x 64 macro tile.)
+            it = self.begin_iteration_indexed(self._upload(keys), len(full), blend=blend)
+            batch = {key: {} for key in keys}
+            for group, rows in ((full, it["d_xyz_full"]), (rest, it["d_xyz_rest"])):
+                if rows is not None:
+                    for i, row in enumerate(rows.unbind(0)):
+                        batch[group[i]]["d_xyz"] = row
+            for name, t in it["heads"].items():
+                for i, row in enumerate(t.unbind(0)):
+                    batch[full[i]][name] = row
+            self._batch = batch
+            if it["blended"] is not None:
+                rows = it["blended"]
+                self._blended = {"n": int(blend[0].shape[0]), "masked": blend[1] is not None,
+                                 "rows": {key: {"d_xyz": rows[0][i], "d_rotation": rows[1][i], "d_scaling": rows[2][i], "d_opacity": None, "d_color": None}
+                                          for i, key in enumerate(full)}}
+            self._graph = None
+            return
         tt = self._upload(keys)[:, None]
         xe = _embed(self.nodes.detach(), net.multires)
         te = _embed(tt, net.t_multires)
