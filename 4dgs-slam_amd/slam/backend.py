@@ -825,6 +825,10 @@ class BackEnd:
         net_params = [p for grp in g.deform.optimizer.param_groups for p in grp["params"]] if use_net else []
         if use_net:
             shard.attach_network(net_params)           # (sharded runs: the network's gradients live in one flat bucket, reduced in place)
+        constants = {}
+        l1_scale = (1.0 - lam) + 0.1
+        l1_alpha = (1.0 - lam) / l1_scale
+        fused_l1 = os.environ.get("GSR_REFINE_FUSED_L1", "1") != "0" and g.get_xyz.is_cuda
         for iteration in range(1, iteration_total + 1):
             loss = 0
             cams = [self.viewpoints[idx] for idx in random.sample(ids, min(views_per_iter, len(ids)))]      # the same draw on every rank
@@ -843,13 +847,26 @@ class BackEnd:
                     continue
                 pkg = self._render(cam, self._deltas(cam))
                 image = torch.exp(cam.exposure_a) * pkg["render"] + cam.exposure_b
-                gt_image = cam.original_image.to(image.device)
-                mm = None if unmasked else cam.motion_mask
-                Ll1 = torch.abs(image - gt_image).mean() if mm is None else torch.abs(image * mm - gt_image * mm).mean()
-                loss = loss + (1.0 - lam) * Ll1 + lam * (1.0 - slam_losses.ssim(image, gt_image, mask=mm))
-                gt_depth = cam.depth_device()[None]
-                dm = (gt_depth > 0.01) if mm is None else (gt_depth > 0.01) & mm[None]
-                loss = loss + 0.1 * torch.abs(pkg["depth"] * dm - gt_depth * dm).mean()
+                # the view's constants (ground truth on the device, the depth mask and -- static form -- the motion mask as float weights): once per
+                # call of this function, not per iteration
+                hit = constants.get(cam.uid)
+                if hit is None:
+                    gt_image = cam.original_image.to(image.device)
+                    gt_depth = cam.depth_device()[None]
+                    mm = None if unmasked else cam.motion_mask
+                    dm = (gt_depth > 0.01) if mm is None else (gt_depth > 0.01) & mm[None]
+                    hit = constants[cam.uid] = (gt_image, gt_depth, mm, None if mm is None else mm.to(torch.float32).reshape(1, *gt_depth.shape[-2:]),
+                                                dm.to(torch.float32))
+                gt_image, gt_depth, mm, w_rgb, w_dep = hit
+                if fused_l1:
+                    # (1 - lam) mean|exp(a) I + b - gt| (masked: x mm) + 0.1 mean(dm |D - gt_D|) as ONE fused weighted-L1 node (slam_losses:
+                    # s (a X + (1 - a) Y) with s = (1 - lam) + 0.1, a = (1 - lam) / s), instead of ~25 element-wise launches each way per view
+                    loss = loss + l1_scale * slam_losses.weighted_l1_loss(pkg["render"], pkg["depth"], gt_image, gt_depth, w_rgb, w_dep, cam.exposure_a,
+                                                                         cam.exposure_b, l1_alpha)
+                else:
+                    Ll1 = torch.abs(image - gt_image).mean() if mm is None else torch.abs(image * mm - gt_image * mm).mean()
+                    loss = loss + (1.0 - lam) * Ll1 + 0.1 * torch.abs(pkg["depth"] * w_dep - gt_depth * w_dep).mean()
+                loss = loss + lam * (1.0 - slam_losses.ssim(image, gt_image, mask=mm))
             if shard.rank == 0:
                 loss = loss + self._isotropic_loss()
             if torch.is_tensor(loss) and loss.requires_grad:
