@@ -70,10 +70,27 @@ def connectivity_from_points(points, radius=0.1, K=10, least_edge_num=3):
     K = min(K, pts.shape[1] - 1)
     knn = control_nodes.knn_points(pts, pts, K=K + 1)
     nn_dist, nn_idx = knn.dists[:, :, 1:], knn.idx[:, :, 1:]
-    keep = torch.ones_like(nn_idx, dtype=torch.bool)
-    keep[:, :, least_edge_num:] = nn_dist[:, :, least_edge_num:] < radius ** 2
+    # keep[..., :least_edge_num] = True, beyond that dist < radius^2: ONE comparison against a per-column bound (inf for the first columns; the
+    # fill + compare + slice copy of the literal form were three launches per call)
+    keep = nn_dist < _edge_bounds(K, least_edge_num, radius, nn_dist.device)
     shape = points.shape[:-1] + (K,)
     return nn_idx.reshape(shape), keep.reshape(shape)
+
+
+_EDGE_BOUNDS = {}
+
+
+def _edge_bounds(K, least_edge_num, radius, device):
+    key = (K, least_edge_num, float(radius), str(device))
+    t = _EDGE_BOUNDS.get(key)
+    if t is None:
+        if len(_EDGE_BOUNDS) >= 16:
+            _EDGE_BOUNDS.pop(next(iter(_EDGE_BOUNDS)))
+        # built ON the device (a host-to-device copy would break a stream capture that meets a new layout first)
+        t = torch.full((K,), float(radius) ** 2, dtype=torch.float32, device=device)
+        t[:least_edge_num] = float("inf")
+        _EDGE_BOUNDS[key] = t
+    return t
 
 
 def edge_matrix(verts, nn_idx, keep):
@@ -715,14 +732,15 @@ class ControlNodes(nn.Module):
             parts_e.append(e_e)
         nodes_t = (parts_e[0] if len(parts_e) == 1 else torch.cat(parts_e, 0)).permute(0, 2, 1, 3)             # [V, M, T, 3]
         nn_weight, nn_idx = self._elastic_neighbours()
-        reg = (elastic_error(nodes_t, nn_weight, nn_idx) * weights).sum()
+        # (weighted sums as dot products: one launch each way instead of a product and a reduction; nobody reads the value's last bit)
+        reg = torch.dot(elastic_error(nodes_t, nn_weight, nn_idx), weights)
         if n_window and n_extra and w_a.is_cuda:
             # the neighbour sets of both groups of views in one k-NN call and ONE set of reverse lists (the two groups differ in their number
             # of samples, not in how a view's neighbours are found: deform_utils.py:58-110 on each view's first sample)
             nn_i, keep = connectivity_from_points(torch.cat([w_a[:, 0].detach(), e_a[:, 0].detach()], 0), K=10)
             sets = control_nodes.IndexSets(nn_i.reshape(n_window + n_extra, -1), M)
-            reg = reg + (weights[:n_window] * arap_error(w_a, nn_i[:n_window], keep[:n_window], sets=sets, set_offset=0)).sum()
-            reg = reg + (weights[n_window:] * arap_error(e_a, nn_i[n_window:], keep[n_window:], sets=sets, set_offset=n_window)).sum()
+            reg = reg + torch.dot(weights[:n_window], arap_error(w_a, nn_i[:n_window], keep[:n_window], sets=sets, set_offset=0))
+            reg = reg + torch.dot(weights[n_window:], arap_error(e_a, nn_i[n_window:], keep[n_window:], sets=sets, set_offset=n_window))
             return reg
         if n_window:
             nn_i, keep = connectivity_from_points(w_a[:, 0], K=10)
