@@ -855,6 +855,8 @@ class BackEnd:
                     gt_depth = cam.depth_device()[None]
                     mm = None if unmasked else cam.motion_mask
                     dm = (gt_depth > 0.01) if mm is None else (gt_depth > 0.01) & mm[None]
+                    if len(constants) >= 512:                      # (~2.5 MB of derived weights per keyframe at 640 x 480: bounded all the same)
+                        constants.pop(next(iter(constants)))
                     hit = constants[cam.uid] = (gt_image, gt_depth, mm, None if mm is None else mm.to(torch.float32).reshape(1, *gt_depth.shape[-2:]),
                                                 dm.to(torch.float32))
                 gt_image, gt_depth, mm, w_rgb, w_dep = hit
