@@ -225,6 +225,45 @@ def test_batched_node_network_evaluation_equals_the_direct_one():
 
 
 @pytest.mark.gpu
+def test_batched_node_network_on_the_device_goes_through_the_fused_trunk_and_equals_the_layerwise_route(monkeypatch):
+    """ControlNodes.begin_iteration on the device = begin_iteration_indexed (the whole network as ONE autograd node on the dense kernels, round 6)
+    with the bookkeeping by host time on top; GSR_BATCH_TRUNK=0 keeps the layer-by-layer library route. Same lookups (full samples, position-only
+    samples, the blended rows of the Gaussians), same values and gradients to fp32-GEMM accuracy."""
+    from slam.deform_model import ControlNodes
+    results = {}
+    for route in ("1", "0"):
+        monkeypatch.setenv("GSR_BATCH_TRUNK", route)
+        torch.manual_seed(0)
+        cn = ControlNodes(node_num=256, device="cuda")
+        cn.init((torch.randn(200, 3) * 0.3).cuda())
+        with torch.no_grad():
+            for head in (cn.network.gaussian_warp, cn.network.gaussian_rotation, cn.network.gaussian_scaling, cn.network.local_rotation):
+                head.weight.normal_(std=0.3)
+        x = (torch.randn(3000, 3, generator=torch.Generator().manual_seed(1)) * 0.3).cuda()
+        times, extra = [0.1, 0.25, 0.9], [0.4, 0.55, 0.1]
+        cn.begin_iteration(times, positions_only=extra, blend=(x, None))
+        assert set(cn._batch) == {0.1, 0.25, 0.9, 0.4, 0.55} and set(cn._batch[0.4]) == {"d_xyz"} and "d_rotation" in cn._batch[0.1]
+        pos = cn.node_positions(extra)
+        warped = [cn.forward(x, torch.full((x.shape[0], 1), tv, device="cuda"), t_key=tv) for tv in times]
+        loss = pos.square().sum() + sum((w["d_xyz"].square().sum() + w["d_rotation"].sum() + w["d_scaling"].square().sum()) for w in warped)
+        loss.backward()
+        results[route] = (pos.detach().clone(), [w["d_xyz"].detach().clone() for w in warped],
+                          [None if p.grad is None else p.grad.clone() for p in cn.network.parameters()])
+        cn.end_iteration()
+        assert cn._batch is None
+    (pa, wa, ga), (pb, wb, gb) = results["1"], results["0"]
+    # (eight 256-wide layers in fp32 on two GEMM implementations: differences of a few 1e-6 of the largest entry)
+    assert torch.allclose(pa, pb, rtol=1e-5, atol=4e-6 * float(pb.abs().max()))
+    for a, b in zip(wa, wb):
+        assert torch.allclose(a, b, rtol=1e-5, atol=4e-6 * float(b.abs().max()))
+    assert sum(g is not None for g in ga) >= 18
+    for a, b in zip(ga, gb):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 + 2e-5 * float(b.abs().max()))
+
+
+@pytest.mark.gpu
 def test_fused_regularisers_equal_the_op_by_op_ones():
     """arap_error / elastic_error on the device through the one-launch kernels (gsr_arap_forward / _backward, gsr_elastic_forward / _backward)
     against the tensor programs they replace (the ones the CPU tests compare with the reference): several views, values and gradients."""
